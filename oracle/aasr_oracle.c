@@ -1,0 +1,704 @@
+/*
+ * aasr_oracle.c -- CPU restatement of AaltoASR's acoustic-likelihood hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (aaltoasr_amd/) may
+ * include, link or call this file.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg use it, and there only as the checker.
+ *
+ * Every function restates one reference function (cited file:line, relative
+ * to /root/reference) with the same arithmetic types per stage: the reference
+ * mixes float32 "islands" (pre-emphasis, Hamming, KissFFT, mel accumulators,
+ * power sum, cosf tables, module parameters) into a double pipeline, and the
+ * restatement keeps every one of them.  Compile with -ffp-contract=off so no
+ * a*b+c is fused (the reference build is plain x86-64 -O2, no FMA).
+ *
+ * PINNING STATUS
+ *  - feature chain: pinned against the reference's own golden files
+ *    aku/tests/{mfcc_p_dd,mfcc_cms_norm}.ref (2-decimal prints, +-0.005) and
+ *    the FFT bit-for-bit against the reference's vendored KissFFT compiled in
+ *    place (oracle/_ref/libkissfft_ref.so).
+ *  - GMM scoring / LNA: PARITY UNPINNED.  The reference holds no golden
+ *    vectors for scoring and aku/Distributions.cc cannot be built here
+ *    (needs the un-vendored LapackPP 2.5.4 library).  The restatement follows
+ *    the cited lines; util::safe_log is pinned against the real util.hh via
+ *    oracle/_ref/libaku_ref.so.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_TINY_FOR_LOG 1e-50 /* aku/util.hh:131 */
+
+/* ------------------------------------------------------------------ */
+/* util::safe_log  (aku/util.hh:132-139)                               */
+/* ------------------------------------------------------------------ */
+double orc_safe_log(double x)
+{
+    if (x < ORC_TINY_FOR_LOG)
+        return log(ORC_TINY_FOR_LOG);
+    return log(x);
+}
+
+/* ================================================================== */
+/*  G1  DiagonalGaussian                                               */
+/* ================================================================== */
+
+/* DiagonalGaussian::read + set_constant
+ * (aku/Distributions.cc:1131-1150, 1273-1288).
+ * prec = var>0 ? 1/var : 0; constant = log(sqrt(prod prec)) when the product
+ * is > 0, else the constant is left holding the raw product (the reference's
+ * "invalid Gaussian" state: it is still scored, with that value).  No 2*pi. */
+void orc_diag_setup(int dim, int64_t G, const double *var, double *prec,
+                    double *cst)
+{
+    for (int64_t g = 0; g < G; g++) {
+        double c = 1;
+        for (int i = 0; i < dim; i++) {
+            double v = var[g * dim + i];
+            double p = (v > 0) ? 1 / v : 0;
+            prec[g * dim + i] = p;
+        }
+        for (int i = 0; i < dim; i++)
+            c *= prec[g * dim + i];
+        if (c > 0)
+            c = log(sqrt(c));
+        cst[g] = c;
+    }
+}
+
+/* DiagonalGaussian::compute_log_likelihood (aku/Distributions.cc:1040-1062) */
+double orc_diag_loglik(int dim, const double *f, const double *mean,
+                       const double *prec, double cst)
+{
+    double ll = 0;
+    for (int i = 0; i < dim; i++) {
+        double d = f[i] - mean[i];
+        ll += d * d * prec[i];
+    }
+    ll *= -0.5;
+    ll += cst;
+    return ll;
+}
+
+/* PDFPool::precompute_likelihoods, no-clustering branch
+ * (aku/Distributions.cc:2663-2682): likelihood of every pool Gaussian for one
+ * frame, in linear domain = exp(log-likelihood) (:1033-1037).
+ * gauss_ll (optional) receives the log-likelihoods. */
+void orc_pool_likelihoods(int dim, int64_t G, const double *mean,
+                          const double *prec, const double *cst,
+                          const double *frame, double *gauss_lik,
+                          double *gauss_ll)
+{
+    for (int64_t g = 0; g < G; g++) {
+        double ll = orc_diag_loglik(dim, frame, mean + g * dim, prec + g * dim,
+                                    cst[g]);
+        if (gauss_ll)
+            gauss_ll[g] = ll;
+        gauss_lik[g] = exp(ll);
+    }
+}
+
+/* Mixture::normalize_weights (aku/Distributions.cc:2067-2075), applied by
+ * Mixture::read (:2418-2434) to every mixture. */
+void orc_mixture_normalize(int64_t S, const int32_t *mix_off, double *mix_w)
+{
+    for (int64_t s = 0; s < S; s++) {
+        double sum = 0;
+        for (int32_t k = mix_off[s]; k < mix_off[s + 1]; k++)
+            sum += mix_w[k];
+        for (int32_t k = mix_off[s]; k < mix_off[s + 1]; k++)
+            mix_w[k] /= sum;
+    }
+}
+
+/* Mixture::compute_likelihood (aku/Distributions.cc:2078-2086) followed by
+ * the 1e-50 clamp of HmmSet::precompute_likelihoods (aku/HmmSet.cc:495-500).
+ * Linear-domain weighted sum in component order; arbitrary (tied) indices. */
+void orc_state_likelihoods(int64_t S, const int32_t *mix_off,
+                           const int32_t *mix_idx, const double *mix_w,
+                           const double *gauss_lik, double *state_lik)
+{
+    for (int64_t s = 0; s < S; s++) {
+        double l = 0;
+        for (int32_t k = mix_off[s]; k < mix_off[s + 1]; k++)
+            l += mix_w[k] * gauss_lik[mix_idx[k]];
+        if (l < ORC_TINY_FOR_LOG)
+            l = ORC_TINY_FOR_LOG;
+        state_lik[s] = l;
+    }
+}
+
+/* Batched form of HmmSet::precompute_likelihoods (aku/HmmSet.cc:484-501):
+ * frames [F x dim] double; out_loglik[F x S] = log(state likelihood) (the
+ * clamp makes every value >= log(1e-50)).  scratch must hold G doubles.
+ * out_lik (optional) receives the linear state likelihoods. */
+void orc_score_frames(int dim, int64_t G, const double *mean,
+                      const double *prec, const double *cst, int64_t S,
+                      const int32_t *mix_off, const int32_t *mix_idx,
+                      const double *mix_w, int64_t F, const double *frames,
+                      double *scratch, double *out_loglik, double *out_lik)
+{
+    double *slik = (double *)malloc(sizeof(double) * (size_t)S);
+    for (int64_t f = 0; f < F; f++) {
+        orc_pool_likelihoods(dim, G, mean, prec, cst, frames + f * dim,
+                             scratch, NULL);
+        orc_state_likelihoods(S, mix_off, mix_idx, mix_w, scratch, slik);
+        for (int64_t s = 0; s < S; s++) {
+            if (out_loglik)
+                out_loglik[f * S + s] = log(slik[s]);
+            if (out_lik)
+                out_lik[f * S + s] = slik[s];
+        }
+    }
+    free(slik);
+}
+
+/* ================================================================== */
+/*  P1  phone_probs frame normalisation + LNA encoding                 */
+/* ================================================================== */
+
+/* aku/phone_probs.cc:224-262 (PPToolbox: aku/PhoneProbsToolbox.cc:84-131 is
+ * the same with lnabytes fixed to 2 and normalisation always on).
+ *   obs[i]  = (float) state_likelihood(i)           -- float storage!
+ *   Z       = sum_i (double) obs[i];  if (!normalize || Z == 0) Z = 1
+ *   obs[i]  = (float) safe_log(obs[i] / Z)
+ *   2-byte: obs < -36.008 -> FF FF else big-endian (int)(-1820*obs + .5)
+ *   4-byte: raw little-endian float
+ * lp_out[S] receives the float log-probs; bytes_out[S*lnabytes] the bytes. */
+void orc_lna_frame(const double *state_lik, int64_t S, int normalize,
+                   int lnabytes, float *lp_out, uint8_t *bytes_out)
+{
+    double z = 0;
+    for (int64_t i = 0; i < S; i++) {
+        lp_out[i] = (float)state_lik[i];
+        z += lp_out[i];
+    }
+    if (!normalize || z == 0)
+        z = 1;
+    for (int64_t i = 0; i < S; i++)
+        lp_out[i] = (float)orc_safe_log(lp_out[i] / z);
+    if (!bytes_out)
+        return;
+    for (int64_t i = 0; i < S; i++) {
+        if (lnabytes == 4) {
+            uint32_t u;
+            memcpy(&u, &lp_out[i], 4);
+            bytes_out[4 * i + 0] = (uint8_t)(u & 255);
+            bytes_out[4 * i + 1] = (uint8_t)((u >> 8) & 255);
+            bytes_out[4 * i + 2] = (uint8_t)((u >> 16) & 255);
+            bytes_out[4 * i + 3] = (uint8_t)((u >> 24) & 255);
+        } else {
+            if (lp_out[i] < -36.008) {
+                bytes_out[2 * i] = 255;
+                bytes_out[2 * i + 1] = 255;
+            } else {
+                int temp = (int)(-1820.0 * lp_out[i] + .5);
+                bytes_out[2 * i] = (uint8_t)((temp >> 8) & 255);
+                bytes_out[2 * i + 1] = (uint8_t)(temp & 255);
+            }
+        }
+    }
+}
+
+/* ================================================================== */
+/*  F1  AudioFileModule                                                */
+/* ================================================================== */
+
+/* AudioFileModule::set_module_config (aku/FeatureModules.cc:336-342):
+ * window_advance = (float)(sample_rate / frame_rate)  [int / float]
+ * window_width   = (int)(2 * sample_rate / frame_rate) unless configured. */
+float orc_window_advance(int sample_rate, float frame_rate)
+{
+    return sample_rate / frame_rate;
+}
+int orc_default_window_width(int sample_rate, float frame_rate)
+{
+    return (int)(2 * sample_rate / frame_rate);
+}
+
+/* AudioFileModule::last_frame (aku/FeatureModules.cc:305-308):
+ * int / float division, truncated. */
+int orc_last_frame(int64_t n_samples, int window_width, float window_advance)
+{
+    return (int)(((int)n_samples - window_width - 1) / window_advance);
+}
+
+static inline int16_t orc_sample(const int16_t *pcm, int64_t n, int64_t i)
+{
+    /* AudioReader::read_from_file zero-fills outside the file
+     * (aku/AudioReader.cc:183-189, 209-212) */
+    return (i < 0 || i >= n) ? 0 : pcm[i];
+}
+
+/* AudioFileModule::generate (aku/FeatureModules.cc:370-440) for frames
+ * first_frame .. first_frame+n_frames-1.  out is [n_frames x window_width].
+ *  - window_start = (int)(frame * window_advance)   (float product)
+ *  - copy_borders: frames < 0 return frame 0's vector; frames >= eof_frame
+ *    (= last_frame()+1, :417) return the last whole frame's vector.
+ *  - y[t] = x[ws+t+1] - emph * x[ws+t] evaluated in FLOAT (short - float*short)
+ * Returns 0, or -1 for "audio shorter than frame" (:408-409). */
+int orc_audio_frames(const int16_t *pcm, int64_t n_samples, float window_advance,
+                     int window_width, float emph, int copy_borders,
+                     int first_frame, int n_frames, double *out)
+{
+    int eof_frame = orc_last_frame(n_samples, window_width, window_advance) + 1;
+    if (n_samples < window_width + 1)
+        return -1;
+    for (int j = 0; j < n_frames; j++) {
+        int frame = first_frame + j;
+        int src = frame;
+        if (copy_borders) {
+            if (src < 0)
+                src = 0;
+            if (src >= eof_frame)
+                src = eof_frame - 1;
+        }
+        int ws = (int)(src * window_advance);
+        double *y = out + (size_t)j * window_width;
+        for (int t = 0; t < window_width; t++) {
+            float a = orc_sample(pcm, n_samples, (int64_t)ws + t + 1);
+            float b = orc_sample(pcm, n_samples, (int64_t)ws + t);
+            float prod = emph * b;
+            y[t] = a - prod;
+        }
+    }
+    return 0;
+}
+
+/* ================================================================== */
+/*  F2  FFTModule + KissFFT (float32) restated                          */
+/* ================================================================== */
+
+typedef struct { float r, i; } orc_cpx;
+
+/* complex product with the rounding sequence of KissFFT's float C_MUL
+ * (vendor/kiss_fft/_kiss_fft_guts.h:95-97): four products, one sub, one add */
+static inline orc_cpx orc_cmul(orc_cpx a, orc_cpx b)
+{
+    orc_cpx m;
+    m.r = a.r * b.r - a.i * b.i;
+    m.i = a.r * b.i + a.i * b.r;
+    return m;
+}
+
+/* radix schedule of kf_factor (vendor/kiss_fft/kiss_fft.c:309-331): powers of
+ * 4, then 2, then odd primes.  Only radices 2 and 4 are restated; returns the
+ * number of stages or -1 if another radix would be needed. */
+static int orc_fft_plan(int n, int *radix, int *sublen)
+{
+    int ns = 0, p = 4;
+    double root = floor(sqrt((double)n));
+    do {
+        while (n % p) {
+            if (p == 4) p = 2;
+            else if (p == 2) p = 3;
+            else p += 2;
+            if (p > root) p = n;
+        }
+        n /= p;
+        if (p != 2 && p != 4) return -1;
+        radix[ns] = p;
+        sublen[ns] = n;
+        ns++;
+    } while (n > 1);
+    return ns;
+}
+
+/* Complex FFT of length n with KissFFT's decimation-in-time structure
+ * (kf_work, vendor/kiss_fft/kiss_fft.c:240-302) unrolled into: mixed-radix
+ * digit-reversed load, then butterfly passes from the innermost stage out.
+ * Butterfly arithmetic follows kf_bfly2 / kf_bfly4 (:21-90) operation by
+ * operation so the float32 result is bit-identical.  tw = n twiddles
+ * (float)cos / (float)sin of -2*pi*k/n computed in double (:355-363). */
+static void orc_cfft(int n, const orc_cpx *in, orc_cpx *out, const orc_cpx *tw,
+                     int ns, const int *radix, const int *sublen)
+{
+    /* digit-reversed load: out[sum k_s*sublen_s] = in[sum k_s*stride_s] */
+    for (int o = 0; o < n; o++) {
+        int rem = o, src = 0, stride = 1;
+        for (int s = 0; s < ns; s++) {
+            int k = rem / sublen[s];
+            rem -= k * sublen[s];
+            src += k * stride;
+            stride *= radix[s];
+        }
+        out[o] = in[src];
+    }
+    for (int s = ns - 1; s >= 0; s--) {
+        int p = radix[s], m = sublen[s];
+        int fstride = n / (p * m);
+        for (int base = 0; base < n; base += p * m) {
+            orc_cpx *F = out + base;
+            if (p == 2) {
+                for (int j = 0; j < m; j++) {
+                    orc_cpx t = orc_cmul(F[m + j], tw[j * fstride]);
+                    F[m + j].r = F[j].r - t.r;
+                    F[m + j].i = F[j].i - t.i;
+                    F[j].r += t.r;
+                    F[j].i += t.i;
+                }
+            } else {
+                for (int j = 0; j < m; j++) {
+                    orc_cpx s0 = orc_cmul(F[m + j], tw[j * fstride]);
+                    orc_cpx s1 = orc_cmul(F[2 * m + j], tw[2 * j * fstride]);
+                    orc_cpx s2 = orc_cmul(F[3 * m + j], tw[3 * j * fstride]);
+                    orc_cpx s3, s4, s5;
+                    s5.r = F[j].r - s1.r;  s5.i = F[j].i - s1.i;
+                    F[j].r += s1.r;        F[j].i += s1.i;
+                    s3.r = s0.r + s2.r;    s3.i = s0.i + s2.i;
+                    s4.r = s0.r - s2.r;    s4.i = s0.i - s2.i;
+                    F[2 * m + j].r = F[j].r - s3.r;
+                    F[2 * m + j].i = F[j].i - s3.i;
+                    F[j].r += s3.r;        F[j].i += s3.i;
+                    F[m + j].r = s5.r + s4.i;
+                    F[m + j].i = s5.i - s4.r;
+                    F[3 * m + j].r = s5.r - s4.i;
+                    F[3 * m + j].i = s5.i + s4.r;
+                }
+            }
+        }
+    }
+}
+
+/* Real FFT of nfft (even) float samples -> nfft/2+1 complex bins, following
+ * kiss_fftr (vendor/kiss_fft/kiss_fftr.c:67-121): half-length complex FFT of
+ * the even/odd packed signal, then the split step with "super twiddles"
+ * exp(-i*pi*((k+1)/ncfft + 1/2)) (:57-63).  Returns 0 or -1 (unsupported n). */
+int orc_rfft(int nfft, const float *timedata, float *freq_re, float *freq_im)
+{
+    if (nfft & 1) return -1;
+    int nc = nfft / 2;
+    int radix[32], sublen[32];
+    int ns = orc_fft_plan(nc, radix, sublen);
+    if (ns < 0) return -1;
+    orc_cpx *tw = (orc_cpx *)malloc(sizeof(orc_cpx) * (size_t)nc);
+    orc_cpx *stw = (orc_cpx *)malloc(sizeof(orc_cpx) * (size_t)(nc / 2 + 1));
+    orc_cpx *in = (orc_cpx *)malloc(sizeof(orc_cpx) * (size_t)nc);
+    orc_cpx *tmp = (orc_cpx *)malloc(sizeof(orc_cpx) * (size_t)nc);
+    const double pi = 3.141592653589793238462643383279502884197169399375105820974944;
+    for (int i = 0; i < nc; i++) {
+        double phase = -2 * pi * i / nc;
+        tw[i].r = (float)cos(phase);
+        tw[i].i = (float)sin(phase);
+    }
+    for (int i = 0; i < nc / 2; i++) {
+        double phase = -3.14159265358979323846264338327 * ((double)(i + 1) / nc + .5);
+        stw[i].r = (float)cos(phase);
+        stw[i].i = (float)sin(phase);
+    }
+    for (int i = 0; i < nc; i++) {
+        in[i].r = timedata[2 * i];
+        in[i].i = timedata[2 * i + 1];
+    }
+    orc_cfft(nc, in, tmp, tw, ns, radix, sublen);
+
+    freq_re[0] = tmp[0].r + tmp[0].i;
+    freq_re[nc] = tmp[0].r - tmp[0].i;
+    freq_im[0] = 0;
+    freq_im[nc] = 0;
+    for (int k = 1; k <= nc / 2; k++) {
+        orc_cpx fpk = tmp[k], fpnk, f1k, f2k, t;
+        fpnk.r = tmp[nc - k].r;
+        fpnk.i = -tmp[nc - k].i;
+        f1k.r = fpk.r + fpnk.r;  f1k.i = fpk.i + fpnk.i;
+        f2k.r = fpk.r - fpnk.r;  f2k.i = fpk.i - fpnk.i;
+        t = orc_cmul(f2k, stw[k - 1]);
+        /* HALF_OF(x) = x*.5 evaluated in double, stored to float */
+        freq_re[k] = (float)((f1k.r + t.r) * .5);
+        freq_im[k] = (float)((f1k.i + t.i) * .5);
+        freq_re[nc - k] = (float)((f1k.r - t.r) * .5);
+        freq_im[nc - k] = (float)((t.i - f1k.i) * .5);
+    }
+    free(tw); free(stw); free(in); free(tmp);
+    return 0;
+}
+
+/* FFTModule::set_module_config Hamming window (aku/FeatureModules.cc:488-490):
+ * stored as float: (float)(.54 - .46*cosf(2*pi*i/(W-1.0))) */
+void orc_hamming(int width, float *w)
+{
+    for (int i = 0; i < width; i++)
+        w[i] = .54 - .46 * cosf(2 * M_PI * i / (width - 1.0));
+}
+
+/* FFTModule::generate, KISS_FFT branch (aku/FeatureModules.cc:520-566).
+ * in [n x width] double -> out [n x (width/2+1)] double.
+ * datain = (float)(hamming * x); power = r*r + i*i in float; then optional
+ * sqrtf (magnitude, default 1) and logf. */
+int orc_fft_module(const double *in, int n, int width, int magnitude,
+                   int take_log, double *out)
+{
+    int dim = width / 2 + 1;
+    float *ham = (float *)malloc(sizeof(float) * (size_t)width);
+    float *td = (float *)malloc(sizeof(float) * (size_t)width);
+    float *re = (float *)malloc(sizeof(float) * (size_t)dim);
+    float *im = (float *)malloc(sizeof(float) * (size_t)dim);
+    int rc = 0;
+    orc_hamming(width, ham);
+    for (int f = 0; f < n && rc == 0; f++) {
+        const double *x = in + (size_t)f * width;
+        double *y = out + (size_t)f * dim;
+        for (int t = 0; t < width; t++)
+            td[t] = ham[t] * x[t];
+        rc = orc_rfft(width, td, re, im);
+        if (rc) break;
+        for (int t = 0; t < dim; t++) {
+            float pr = re[t] * re[t];
+            float pi_ = im[t] * im[t];
+            y[t] = pr + pi_;
+        }
+        for (int t = 0; t < dim; t++) {
+            if (magnitude)
+                y[t] = sqrtf(y[t]);
+            if (take_log)
+                y[t] = logf(y[t]);
+        }
+    }
+    free(ham); free(td); free(re); free(im);
+    return rc;
+}
+
+/* ================================================================== */
+/*  F3  MelModule                                                      */
+/* ================================================================== */
+
+/* MelModule::set_module_config (aku/FeatureModules.cc:784-785) */
+int orc_mel_dim(int sample_rate)
+{
+    return (int)((21 + 2) * log10f(1 + sample_rate / 1400.0) /
+                 log10f(1 + 16000 / 1400.0) - 2);
+}
+
+/* MelModule::create_mel_bins (aku/FeatureModules.cc:790-803):
+ * edges[dim+2] as float. */
+void orc_mel_edges(int sample_rate, int mel_dim, int src_dim, float *edges_out)
+{
+    int edges = mel_dim + 2;
+    float rate = sample_rate;
+    float mel_step = 2595 * log10f(1.0 + rate / 1400.0) / edges;
+    for (int i = 0; i < edges; i++)
+        edges_out[i] = 1400.0 * (pow(10, (i + 1) * mel_step / 2595) - 1) *
+                       (src_dim - 1) / rate;
+}
+
+/* MelModule::generate (aku/FeatureModules.cc:805-849).  float beg/end/val/
+ * scale/sum; the product scale*data[t] and the accumulation happen in double
+ * and are rounded back to float at each step.  in [n x src_dim], out
+ * [n x mel_dim]. */
+void orc_mel_module(const double *in, int n, int src_dim, int sample_rate,
+                    int root, double *out)
+{
+    int dim = orc_mel_dim(sample_rate);
+    float *edge = (float *)malloc(sizeof(float) * (size_t)(dim + 2));
+    orc_mel_edges(sample_rate, dim, src_dim, edge);
+    for (int f = 0; f < n; f++) {
+        const double *data = in + (size_t)f * src_dim;
+        for (int b = 0; b < dim; b++) {
+            float val = 0, sum = 0, scale;
+            float beg = edge[b] - 1;
+            float end = edge[b + 1];
+            int t = (int)fmaxf(ceilf(beg), 0.0f);
+            while (t < end) {
+                scale = (t - beg) / (end - beg);
+                val += scale * data[t];
+                sum += scale;
+                t++;
+            }
+            beg = end;
+            end = edge[b + 2];
+            while (t < end) {
+                scale = (end - t) / (end - beg);
+                val += scale * data[t];
+                sum += scale;
+                t++;
+            }
+            if (root)
+                out[(size_t)f * dim + b] = pow((double)(val / sum), 0.1);
+            else
+                out[(size_t)f * dim + b] = logf(val / sum + 1);
+        }
+    }
+    free(edge);
+}
+
+/* ================================================================== */
+/*  F4  PowerModule   (aku/FeatureModules.cc:874-885)                   */
+/* ================================================================== */
+void orc_power_module(const double *in, int n, int src_dim, double *out)
+{
+    for (int f = 0; f < n; f++) {
+        float power = 0;
+        for (int i = 0; i < src_dim; i++)
+            power += in[(size_t)f * src_dim + i];
+        out[f] = log(power + 1e-10);
+    }
+}
+
+/* ================================================================== */
+/*  F5  DCTModule     (aku/FeatureModules.cc:955-979)                   */
+/* ================================================================== */
+void orc_dct_module(const double *in, int n, int src_dim, int dim, int zeroth,
+                    double *out)
+{
+    for (int f = 0; f < n; f++) {
+        const double *src = in + (size_t)f * src_dim;
+        double *tgt = out + (size_t)f * dim;
+        int i = 0, bias = 0;
+        if (zeroth) {
+            tgt[0] = 0.0;
+            for (int b = 0; b < src_dim; b++)
+                tgt[0] += src[b];
+            bias = 1;
+        }
+        for (; i < dim - bias; i++) {
+            tgt[i + bias] = 0.0;
+            for (int b = 0; b < src_dim; b++)
+                tgt[i + bias] += src[b] * cosf((i + 1) * (b + 0.5) * M_PI / src_dim);
+        }
+    }
+}
+
+/* ================================================================== */
+/*  F7  DeltaModule   (aku/FeatureModules.cc:998-1037)                  */
+/* ================================================================== */
+
+/* default normalisation: integer arithmetic, then float (:1008) */
+float orc_delta_default_norm(int width)
+{
+    return 2 * width * (width + 1) * (2 * width + 1) / 6;
+}
+
+/* in holds frames (first-width) .. (first+n-1+width): [(n+2*width) x dim];
+ * out [n x dim]. */
+void orc_delta_module(const double *in, int n, int dim, int width, float norm,
+                      double *out)
+{
+    for (int f = 0; f < n; f++) {
+        double *tgt = out + (size_t)f * dim;
+        const double *centre = in + (size_t)(f + width) * dim;
+        for (int i = 0; i < dim; i++)
+            tgt[i] = 0;
+        for (int k = 1; k <= width; k++) {
+            const double *left = centre - (size_t)k * dim;
+            const double *right = centre + (size_t)k * dim;
+            for (int i = 0; i < dim; i++)
+                tgt[i] += k * (right[i] - left[i]);
+        }
+        for (int i = 0; i < dim; i++)
+            tgt[i] /= norm;
+    }
+}
+
+/* ================================================================== */
+/*  F8  NormalizationModule (aku/FeatureModules.cc:1135-1142)           */
+/*      "var" config: scale = 1/sqrtf(var) in float (:1075-1076)        */
+/* ================================================================== */
+void orc_var_to_scale(int dim, float *scale)
+{
+    for (int i = 0; i < dim; i++)
+        scale[i] = 1 / sqrtf(scale[i]);
+}
+
+void orc_normalization_module(const double *in, int n, int dim,
+                              const float *mean, const float *scale,
+                              double *out)
+{
+    for (size_t f = 0; f < (size_t)n; f++)
+        for (int i = 0; i < dim; i++)
+            out[f * dim + i] = (in[f * dim + i] - mean[i]) * scale[i];
+}
+
+/* ================================================================== */
+/*  F9  LinTransformModule (aku/FeatureModules.cc:1243-1269)            */
+/*      matrix row-major [dim x src_dim] float; NULL = identity copy;    */
+/*      bias NULL = none.                                                */
+/* ================================================================== */
+void orc_lin_transform_module(const double *in, int n, int src_dim, int dim,
+                              const float *matrix, const float *bias,
+                              double *out)
+{
+    for (size_t f = 0; f < (size_t)n; f++) {
+        const double *src = in + f * src_dim;
+        double *tgt = out + f * dim;
+        if (matrix) {
+            int index = 0;
+            for (int i = 0; i < dim; i++) {
+                tgt[i] = 0;
+                for (int j = 0; j < src_dim; j++, index++)
+                    tgt[i] += matrix[index] * src[j];
+            }
+        } else {
+            for (int i = 0; i < dim; i++)
+                tgt[i] = src[i];
+        }
+        if (bias)
+            for (int i = 0; i < dim; i++)
+                tgt[i] += bias[i];
+    }
+}
+
+/* ================================================================== */
+/*  F10 MeanSubtractorModule (aku/FeatureModules.cc:1384-1454)          */
+/* ================================================================== */
+
+/* left/right are the CONFIG values (the module stores left+1/right+1,
+ * :1396-1400).  width = left+right+1.  in holds frames (first-left-1) ..
+ * (first+n-1+right): [(n+left+1+right) x dim] -- one extra frame on the left
+ * because the incremental update subtracts frame-own_left = frame-left-1.
+ * Mirrors sequential access starting at `first`: full window sum for the
+ * first frame (:1440-1450), then cur_mean += (a - r)/width (:1420-1426). */
+void orc_mean_subtract_module(const double *in, int n, int dim, int left,
+                              int right, double *out)
+{
+    int width = left + right + 1;
+    double *mean = (double *)malloc(sizeof(double) * (size_t)dim);
+    for (int f = 0; f < n; f++) {
+        const double *centre = in + (size_t)(f + left + 1) * dim;
+        if (f == 0) {
+            for (int d = 0; d < dim; d++)
+                mean[d] = 0;
+            for (int i = -left; i <= right; i++)
+                for (int d = 0; d < dim; d++)
+                    mean[d] += centre[(ptrdiff_t)i * dim + d];
+            for (int d = 0; d < dim; d++)
+                mean[d] /= width;
+        } else {
+            const double *r = centre - (size_t)(left + 1) * dim;
+            const double *a = centre + (size_t)right * dim;
+            for (int d = 0; d < dim; d++)
+                mean[d] += (a[d] - r[d]) / width;
+        }
+        for (int d = 0; d < dim; d++)
+            out[(size_t)f * dim + d] = centre[d] - mean[d];
+    }
+    free(mean);
+}
+
+/* ================================================================== */
+/*  CPU baseline helper: reference-shaped scoring loop, timed by        */
+/*  bench.py.  Same per-frame / per-Gaussian scalar structure as        */
+/*  phone_probs.cc:217-234 -> HmmSet.cc:484-501 -> Distributions.cc     */
+/*  :2674-2681, 1040-1062, 2078-2086 (double, exp per Gaussian, linear   */
+/*  mixture sum).  Returns a checksum so the work cannot be elided.      */
+/* ================================================================== */
+double orc_cpu_baseline_score(int dim, int64_t G, const double *mean,
+                              const double *prec, const double *cst, int64_t S,
+                              const int32_t *mix_off, const int32_t *mix_idx,
+                              const double *mix_w, int64_t F,
+                              const double *frames)
+{
+    double *glik = (double *)malloc(sizeof(double) * (size_t)G);
+    double *slik = (double *)malloc(sizeof(double) * (size_t)S);
+    float *lp = (float *)malloc(sizeof(float) * (size_t)S);
+    double check = 0;
+    for (int64_t f = 0; f < F; f++) {
+        orc_pool_likelihoods(dim, G, mean, prec, cst, frames + f * dim, glik, NULL);
+        orc_state_likelihoods(S, mix_off, mix_idx, mix_w, glik, slik);
+        orc_lna_frame(slik, S, 1, 2, lp, NULL);
+        check += lp[f % S];
+    }
+    free(glik); free(slik); free(lp);
+    return check;
+}

@@ -1,0 +1,765 @@
+"""oracle.py -- Python face of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module, and only as the checker.  The product path
+(aaltoasr_amd/) never imports it.
+
+The numeric kernels live in oracle/aasr_oracle.c (each function cites the
+reference lines it restates); this file holds the text-format restatements
+(.cfg feature graphs, .gk/.mc/.ph model files, recipes, LNA files) and the
+graph walk that strings the per-module C functions together.
+
+Reference citations are relative to /root/reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import struct
+import subprocess
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+TINY_FOR_LOG = 1e-50  # aku/util.hh:131
+
+
+def build(force: bool = False) -> None:
+    """Compile liboracle.so (and oracle/_ref when /root/reference exists)."""
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "aasr_oracle.c"))
+    ):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _p(a: np.ndarray, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _declare(L: C.CDLL) -> None:
+    d, f, i32, i64 = C.c_double, C.c_float, C.c_int, C.c_int64
+    pd, pf = C.POINTER(d), C.POINTER(f)
+    pi32, pi16, pu8 = C.POINTER(C.c_int32), C.POINTER(C.c_int16), C.POINTER(C.c_uint8)
+    L.orc_safe_log.restype = d
+    L.orc_safe_log.argtypes = [d]
+    L.orc_diag_setup.argtypes = [i32, i64, pd, pd, pd]
+    L.orc_diag_loglik.restype = d
+    L.orc_diag_loglik.argtypes = [i32, pd, pd, pd, d]
+    L.orc_pool_likelihoods.argtypes = [i32, i64, pd, pd, pd, pd, pd, pd]
+    L.orc_mixture_normalize.argtypes = [i64, pi32, pd]
+    L.orc_state_likelihoods.argtypes = [i64, pi32, pi32, pd, pd, pd]
+    L.orc_score_frames.argtypes = [i32, i64, pd, pd, pd, i64, pi32, pi32, pd, i64, pd, pd, pd, pd]
+    L.orc_lna_frame.argtypes = [pd, i64, i32, i32, pf, pu8]
+    L.orc_window_advance.restype = f
+    L.orc_window_advance.argtypes = [i32, f]
+    L.orc_default_window_width.restype = i32
+    L.orc_default_window_width.argtypes = [i32, f]
+    L.orc_last_frame.restype = i32
+    L.orc_last_frame.argtypes = [i64, i32, f]
+    L.orc_audio_frames.restype = i32
+    L.orc_audio_frames.argtypes = [pi16, i64, f, i32, f, i32, i32, i32, pd]
+    L.orc_rfft.restype = i32
+    L.orc_rfft.argtypes = [i32, pf, pf, pf]
+    L.orc_hamming.argtypes = [i32, pf]
+    L.orc_fft_module.restype = i32
+    L.orc_fft_module.argtypes = [pd, i32, i32, i32, i32, pd]
+    L.orc_mel_dim.restype = i32
+    L.orc_mel_dim.argtypes = [i32]
+    L.orc_mel_edges.argtypes = [i32, i32, i32, pf]
+    L.orc_mel_module.argtypes = [pd, i32, i32, i32, i32, pd]
+    L.orc_power_module.argtypes = [pd, i32, i32, pd]
+    L.orc_dct_module.argtypes = [pd, i32, i32, i32, i32, pd]
+    L.orc_delta_default_norm.restype = f
+    L.orc_delta_default_norm.argtypes = [i32]
+    L.orc_delta_module.argtypes = [pd, i32, i32, i32, f, pd]
+    L.orc_var_to_scale.argtypes = [i32, pf]
+    L.orc_normalization_module.argtypes = [pd, i32, i32, pf, pf, pd]
+    L.orc_lin_transform_module.argtypes = [pd, i32, i32, i32, pf, pf, pd]
+    L.orc_mean_subtract_module.argtypes = [pd, i32, i32, i32, i32, pd]
+    L.orc_cpu_baseline_score.restype = d
+    L.orc_cpu_baseline_score.argtypes = [i32, i64, pd, pd, pd, i64, pi32, pi32, pd, i64, pd]
+
+
+# ---------------------------------------------------------------------------
+# text helpers
+# ---------------------------------------------------------------------------
+
+def str2float(s: str) -> np.float32:
+    """str::str2float (aku/str.cc:260-282): strtod, then narrowed to float."""
+    return np.float32(float(s))
+
+
+def _floats(s: str) -> np.ndarray:
+    return np.array([str2float(x) for x in s.split()], dtype=np.float32)
+
+
+# ---------------------------------------------------------------------------
+# .cfg feature graph  (ModuleConfig::read aku/ModuleConfig.cc:166-202,
+# FeatureGenerator::load_configuration aku/FeatureGenerator.cc:96-219)
+# ---------------------------------------------------------------------------
+
+def parse_feature_config(text: str) -> List[Dict[str, str]]:
+    """Returns the list of module option dicts in file order."""
+    lines = text.split("\n")
+    mods: List[Dict[str, str]] = []
+    i = 0
+    while i < len(lines):
+        line = lines[i].strip(" \t\r")
+        i += 1
+        if not line:
+            continue
+        if line != "module":
+            raise ValueError("expected keyword 'module' on line %d: %s" % (i, line))
+        opts: Dict[str, str] = {}
+        first = True
+        while True:
+            if i >= len(lines):
+                raise ValueError("unexpected end of module config file")
+            l2 = lines[i].strip(" \t\r")
+            i += 1
+            if not l2:
+                continue
+            if first:
+                if l2 != "{":
+                    raise ValueError("'{' expected in module config file: " + l2)
+                first = False
+                continue
+            if l2 == "}":
+                break
+            parts = l2.split(None, 1)
+            if len(parts) == 1:
+                raise ValueError("value missing for option: " + l2)
+            if parts[0] in opts:
+                raise ValueError("value redefined: " + l2)
+            opts[parts[0]] = parts[1].strip(" \t")
+        if "type" not in opts:
+            raise ValueError("type not defined for module")
+        if "name" not in opts:
+            raise ValueError("name not defined for module")
+        mods.append(opts)
+    if not mods:
+        raise ValueError("no feature modules defined")
+    return mods
+
+
+@dataclass
+class _Mod:
+    name: str
+    type: str
+    opts: Dict[str, str]
+    sources: List["_Mod"] = field(default_factory=list)
+    dim: int = 0
+    prm: dict = field(default_factory=dict)
+
+
+class FeatureChain:
+    """Restatement of aku::FeatureGenerator for the MFCC-chain module types.
+
+    Module semantics: aku/FeatureModules.cc (audiofile :327-440, fft :475-566,
+    mel :775-849, power :874-885, dct :937-979, delta :998-1037, normalization
+    :1056-1142, lin_transform :1167-1269, merge :1335-1364, mean_subtractor
+    :1384-1454).  Output of a module at frame t is a pure function of t, so
+    the ring buffers of FeatureModule::at (:102-158) are replaced by range
+    evaluation with halos.
+    """
+
+    SUPPORTED = ("audiofile", "fft", "mel", "power", "dct", "delta",
+                 "normalization", "lin_transform", "merge", "mean_subtractor")
+
+    def __init__(self, cfg_text: str):
+        L = lib()
+        self.mods: List[_Mod] = []
+        self.by_name: Dict[str, _Mod] = {}
+        for opts in parse_feature_config(cfg_text):
+            m = _Mod(opts["name"], opts["type"], opts)
+            if m.type not in self.SUPPORTED:
+                raise ValueError("Unknown module type '%s'" % m.type)
+            if not self.mods:
+                if m.type != "audiofile":
+                    raise ValueError("first module should be a base module")
+                if "sources" in opts:
+                    raise ValueError("can not define sources for the first module")
+            else:
+                if "sources" not in opts:
+                    raise ValueError("sources not defined for module: " + m.name)
+                for s in opts["sources"].split():
+                    if s not in self.by_name:
+                        raise ValueError("unknown source module: " + s)
+                    if m.sources and m.type != "merge":
+                        raise ValueError("Multiple sources are not allowed for module " + m.type)
+                    m.sources.append(self.by_name[s])
+            if m.name in self.by_name:
+                raise ValueError("multiple definitions of module name: " + m.name)
+            self._configure(m, L)
+            self.mods.append(m)
+            self.by_name[m.name] = m
+        self.base = self.mods[0]
+        self.last = self.mods[-1]
+
+    # -- per-module set_module_config ---------------------------------------
+    def _configure(self, m: _Mod, L) -> None:
+        o = m.opts
+        t = m.type
+        if t == "audiofile":
+            if "sample_rate" not in o:
+                raise ValueError("AudioFileModule: Must set sample rate")
+            sr = int(o["sample_rate"])
+            emph = str2float(o["pre_emph_coef"]) if "pre_emph_coef" in o else np.float32(0.97)
+            fr = str2float(o["frame_rate"]) if "frame_rate" in o else np.float32(125)
+            adv = np.float32(L.orc_window_advance(sr, float(fr)))
+            ww = L.orc_default_window_width(sr, float(fr))
+            if "window_width" in o:
+                ww = int(o["window_width"])
+            cb = int(o["copy_borders"]) if "copy_borders" in o else 1
+            m.dim = ww
+            m.prm = dict(sample_rate=sr, emph=emph, frame_rate=fr, advance=adv,
+                         width=ww, copy_borders=cb)
+            self.sample_rate = sr
+        elif t == "fft":
+            m.prm = dict(magnitude=int(o.get("magnitude", 1)), log=int(o.get("log", 0)))
+            m.dim = m.sources[-1].dim // 2 + 1
+        elif t == "mel":
+            m.prm = dict(root=int(o.get("root", 0)))
+            m.dim = L.orc_mel_dim(self.sample_rate)
+        elif t == "power":
+            m.dim = 1
+        elif t == "dct":
+            m.dim = int(o.get("dim", 12))
+            if m.dim < 1:
+                raise ValueError("DCTModule: Dimension must be > 0")
+            m.prm = dict(zeroth=int(o.get("zeroth", 0)))
+        elif t == "delta":
+            m.dim = m.sources[-1].dim
+            w = int(o.get("width", 2))
+            norm = np.float32(L.orc_delta_default_norm(w))
+            if "normalization" in o:
+                norm = str2float(o["normalization"])
+            if w < 1:
+                raise ValueError("DeltaModule: Delta width must be > 0")
+            m.prm = dict(width=w, norm=norm)
+        elif t == "normalization":
+            m.dim = m.sources[-1].dim
+            mean = np.zeros(m.dim, np.float32)
+            scale = np.ones(m.dim, np.float32)
+            if "mean" in o:
+                mean = _floats(o["mean"])
+            if len(mean) != m.dim:
+                raise ValueError("NormalizationModule: Invalid mean dimension")
+            if "var" in o and "scale" in o:
+                raise ValueError("NormalizationModule: Both scale and var can not be defined simultaneously")
+            if "var" in o:
+                scale = _floats(o["var"])
+                if len(scale) != m.dim:
+                    raise ValueError("Normalization module: Invalid variance dimension")
+                L.orc_var_to_scale(m.dim, _p(scale, C.c_float))
+            elif "scale" in o:
+                scale = _floats(o["scale"])
+            m.prm = dict(mean=mean, scale=scale)
+        elif t == "lin_transform":
+            src_dim = m.sources[-1].dim
+            m.dim = int(o["dim"]) if "dim" in o else src_dim
+            if m.dim < 1:
+                raise ValueError("LinTransformModule: Dimension must be > 0")
+            mat = _floats(o["matrix"]) if "matrix" in o else None
+            bias = _floats(o["bias"]) if "bias" in o else None
+            if mat is not None and len(mat) == 0:
+                mat = None
+            if bias is not None and len(bias) == 0:
+                bias = None
+            if mat is not None and len(mat) != m.dim * src_dim:
+                raise ValueError("LinTransformModule: Invalid matrix dimension")
+            if mat is None and m.dim != src_dim:
+                # identity fallback copies dim values (reference would read
+                # past the source for dim > src_dim); keep it strict here
+                raise ValueError("LinTransformModule: identity needs dim == src_dim")
+            if bias is not None and len(bias) != m.dim:
+                raise ValueError("LinTransformModule: Invalid bias dimension")
+            m.prm = dict(matrix=mat, bias=bias, src_dim=src_dim)
+        elif t == "merge":
+            m.dim = sum(s.dim for s in m.sources)
+        elif t == "mean_subtractor":
+            m.dim = m.sources[-1].dim
+            left = int(o.get("left", 75))
+            right = int(o.get("right", 75))
+            if left + 1 < 1 or right + 1 < 1:
+                raise ValueError("MeanSubtractorModule: context widths must be >= 0")
+            m.prm = dict(left=left, right=right)
+
+    # -- FeatureGenerator surface ---------------------------------------------
+    @property
+    def dim(self) -> int:
+        return self.last.dim
+
+    @property
+    def frame_rate(self) -> float:
+        return float(self.base.prm["frame_rate"])
+
+    def last_frame(self, n_samples: int) -> int:
+        p = self.base.prm
+        return lib().orc_last_frame(int(n_samples), p["width"], float(p["advance"]))
+
+    def num_frames(self, n_samples: int) -> int:
+        """frames phone_probs emits for a whole file: 0..last_frame
+        (aku/phone_probs.cc:217-221 with AudioFileModule::eof)."""
+        return self.last_frame(n_samples) + 1
+
+    def halo(self) -> Tuple[int, int]:
+        """(left, right) base-module frames needed around one output frame."""
+        def rec(m: _Mod) -> Tuple[int, int]:
+            l = r = 0
+            if m.type == "delta":
+                l = r = m.prm["width"]
+            elif m.type == "mean_subtractor":
+                l, r = m.prm["left"], m.prm["right"]
+            bl = br = 0
+            for s in m.sources:
+                sl, sr = rec(s)
+                bl, br = max(bl, sl), max(br, sr)
+            return l + bl, r + br
+        return rec(self.last)
+
+    def generate(self, pcm: np.ndarray, first_frame: int, n_frames: int,
+                 module: Optional[str] = None) -> np.ndarray:
+        """Frames first_frame .. first_frame+n_frames-1 of `module` (default:
+        the last module) as float64 [n_frames x dim]."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        target = self.by_name[module] if module else self.last
+        memo: Dict[Tuple[str, int, int], np.ndarray] = {}
+        return self._eval(target, first_frame, first_frame + n_frames - 1, pcm, memo)
+
+    def _eval(self, m: _Mod, lo: int, hi: int, pcm: np.ndarray, memo) -> np.ndarray:
+        key = (m.name, lo, hi)
+        if key in memo:
+            return memo[key]
+        L = lib()
+        n = hi - lo + 1
+        out = np.empty((n, m.dim), dtype=np.float64)
+        pd = C.c_double
+        t = m.type
+        if t == "audiofile":
+            p = m.prm
+            rc = L.orc_audio_frames(_p(pcm, C.c_int16), len(pcm), float(p["advance"]),
+                                    p["width"], float(p["emph"]), p["copy_borders"],
+                                    lo, n, _p(out, pd))
+            if rc != 0:
+                raise ValueError("audio shorter than frame")
+        elif t == "merge":
+            out = np.ascontiguousarray(
+                np.hstack([self._eval(s, lo, hi, pcm, memo) for s in m.sources]))
+        elif t == "delta":
+            w = m.prm["width"]
+            src = self._eval(m.sources[-1], lo - w, hi + w, pcm, memo)
+            L.orc_delta_module(_p(src, pd), n, m.dim, w, float(m.prm["norm"]), _p(out, pd))
+        elif t == "mean_subtractor":
+            l, r = m.prm["left"], m.prm["right"]
+            src = self._eval(m.sources[-1], lo - l - 1, hi + r, pcm, memo)
+            L.orc_mean_subtract_module(_p(src, pd), n, m.dim, l, r, _p(out, pd))
+        else:
+            src = self._eval(m.sources[-1], lo, hi, pcm, memo)
+            sd = m.sources[-1].dim
+            if t == "fft":
+                rc = L.orc_fft_module(_p(src, pd), n, sd, m.prm["magnitude"], m.prm["log"], _p(out, pd))
+                if rc != 0:
+                    raise ValueError("FFT window width %d needs a radix the oracle does not restate" % sd)
+            elif t == "mel":
+                L.orc_mel_module(_p(src, pd), n, sd, self.sample_rate, m.prm["root"], _p(out, pd))
+            elif t == "power":
+                L.orc_power_module(_p(src, pd), n, sd, _p(out, pd))
+            elif t == "dct":
+                L.orc_dct_module(_p(src, pd), n, sd, m.dim, m.prm["zeroth"], _p(out, pd))
+            elif t == "normalization":
+                L.orc_normalization_module(_p(src, pd), n, m.dim, _p(m.prm["mean"], C.c_float),
+                                           _p(m.prm["scale"], C.c_float), _p(out, pd))
+            elif t == "lin_transform":
+                mat, bias = m.prm["matrix"], m.prm["bias"]
+                L.orc_lin_transform_module(
+                    _p(src, pd), n, sd, m.dim,
+                    _p(mat, C.c_float) if mat is not None else None,
+                    _p(bias, C.c_float) if bias is not None else None, _p(out, pd))
+            else:
+                raise AssertionError(t)
+        memo[key] = out
+        return out
+
+
+# ---------------------------------------------------------------------------
+# acoustic model  (HmmSet / PDFPool / Mixture)
+# ---------------------------------------------------------------------------
+
+@dataclass
+class DiagModel:
+    """Diagonal-Gaussian HmmSet: pool means/variances + per-state mixtures.
+
+    mix_off[S+1], mix_idx, mix_w form the CSR of Mixture pointers/weights
+    (aku/Distributions.hh Mixture::m_pointers/m_weights); legacy .ph models map
+    state i to emission pdf i (aku/HmmSet.cc:245,319-322).
+    """
+    mean: np.ndarray      # [G, D] float64
+    var: np.ndarray       # [G, D] float64
+    mix_off: np.ndarray   # [S+1] int32
+    mix_idx: np.ndarray   # [K] int32
+    mix_w: np.ndarray     # [K] float64 (normalised like Mixture::read)
+    prec: np.ndarray = None
+    cst: np.ndarray = None
+
+    def __post_init__(self):
+        self.mean = np.ascontiguousarray(self.mean, np.float64)
+        self.var = np.ascontiguousarray(self.var, np.float64)
+        self.mix_off = np.ascontiguousarray(self.mix_off, np.int32)
+        self.mix_idx = np.ascontiguousarray(self.mix_idx, np.int32)
+        self.mix_w = np.ascontiguousarray(self.mix_w, np.float64).copy()
+        L = lib()
+        L.orc_mixture_normalize(self.S, _p(self.mix_off, C.c_int32), _p(self.mix_w, C.c_double))
+        self.prec = np.empty_like(self.mean)
+        self.cst = np.empty(self.G, np.float64)
+        L.orc_diag_setup(self.D, self.G, _p(self.var, C.c_double), _p(self.prec, C.c_double),
+                         _p(self.cst, C.c_double))
+
+    @property
+    def G(self) -> int:
+        return self.mean.shape[0]
+
+    @property
+    def D(self) -> int:
+        return self.mean.shape[1]
+
+    @property
+    def S(self) -> int:
+        return len(self.mix_off) - 1
+
+    def gauss_loglik(self, frames: np.ndarray) -> np.ndarray:
+        """[F x G] log-likelihood of every pool Gaussian."""
+        frames = np.ascontiguousarray(frames, np.float64)
+        L = lib()
+        F = frames.shape[0]
+        out = np.empty((F, self.G))
+        lik = np.empty(self.G)
+        pd = C.c_double
+        for f in range(F):
+            L.orc_pool_likelihoods(self.D, self.G, _p(self.mean, pd), _p(self.prec, pd),
+                                   _p(self.cst, pd), _p(frames[f], pd), _p(lik, pd), _p(out[f], pd))
+        return out
+
+    def score(self, frames: np.ndarray, want_lik: bool = False):
+        """[F x S] log state likelihood, log(max(sum_k w_k exp(ll_k), 1e-50))."""
+        frames = np.ascontiguousarray(frames, np.float64)
+        L = lib()
+        F = frames.shape[0]
+        out = np.empty((F, self.S))
+        lik = np.empty((F, self.S)) if want_lik else None
+        scratch = np.empty(self.G)
+        pd = C.c_double
+        L.orc_score_frames(self.D, self.G, _p(self.mean, pd), _p(self.prec, pd), _p(self.cst, pd),
+                           self.S, _p(self.mix_off, C.c_int32), _p(self.mix_idx, C.c_int32),
+                           _p(self.mix_w, pd), F, _p(frames, pd), _p(scratch, pd), _p(out, pd),
+                           _p(lik, pd) if want_lik else None)
+        return (out, lik) if want_lik else out
+
+    def cpu_baseline(self, frames: np.ndarray) -> float:
+        frames = np.ascontiguousarray(frames, np.float64)
+        pd = C.c_double
+        return lib().orc_cpu_baseline_score(
+            self.D, self.G, _p(self.mean, pd), _p(self.prec, pd), _p(self.cst, pd), self.S,
+            _p(self.mix_off, C.c_int32), _p(self.mix_idx, C.c_int32), _p(self.mix_w, pd),
+            frames.shape[0], _p(frames, pd))
+
+
+def lna_encode(state_lik: np.ndarray, normalize: bool = True, lnabytes: int = 2):
+    """phone_probs frame loop tail (aku/phone_probs.cc:224-262) on linear state
+    likelihoods [F x S] (float64).  Returns (float32 log-probs, uint8 bytes)."""
+    state_lik = np.ascontiguousarray(state_lik, np.float64)
+    F, S = state_lik.shape
+    lp = np.empty((F, S), np.float32)
+    by = np.empty((F, S * lnabytes), np.uint8)
+    L = lib()
+    for f in range(F):
+        L.orc_lna_frame(_p(state_lik[f], C.c_double), S, int(normalize), lnabytes,
+                        _p(lp[f], C.c_float), _p(by[f], C.c_uint8))
+    return lp, by
+
+
+def lna_header(num_states: int, lnabytes: int) -> bytes:
+    """write_int + fputc (aku/phone_probs.cc:32-43, 213-214)."""
+    return struct.pack(">I", num_states) + bytes([lnabytes])
+
+
+def lna_decode(data: bytes) -> np.ndarray:
+    """LnaReaderCircular::go_to conventions (decoder/src/LnaReaderCircular.cc
+    :129-209): 2-byte -> -(hi*256+lo)/1820, 4-byte -> LE float."""
+    S, B = struct.unpack(">IB", data[:5])
+    body = np.frombuffer(data[5:], np.uint8)
+    if B == 2:
+        v = body.reshape(-1, S, 2).astype(np.float64)
+        return -(v[..., 0] * 256 + v[..., 1]) / 1820.0
+    if B == 4:
+        return body.view("<f4").reshape(-1, S).astype(np.float64)
+    raise ValueError("bytes per value %d" % B)
+
+
+# ---------------------------------------------------------------------------
+# model files
+# ---------------------------------------------------------------------------
+
+def write_gk(path: str, mean: np.ndarray, var: np.ndarray, legacy: bool = False) -> None:
+    """PDFPool::write_gk format (read side: aku/Distributions.cc:2811-2910):
+    header 'G dim variable' then per Gaussian 'diag mean.. var..'; legacy
+    header 'G dim diagonal_cov' has no per-line tag."""
+    G, D = mean.shape
+    with open(path, "w") as f:
+        f.write("%d %d %s\n" % (G, D, "diagonal_cov" if legacy else "variable"))
+        for g in range(G):
+            vals = " ".join(repr(float(x)) for x in mean[g]) + " " + \
+                   " ".join(repr(float(x)) for x in var[g])
+            f.write(vals + "\n" if legacy else "diag " + vals + "\n")
+
+
+def read_gk(path: str) -> Tuple[np.ndarray, np.ndarray]:
+    """PDFPool::read_gk (aku/Distributions.cc:2811-2910), diagonal types only.
+    Token-based like the reference's istream >>."""
+    toks = open(path).read().split()
+    G, D, kind = int(toks[0]), int(toks[1]), toks[2]
+    pos = 3
+    mean = np.empty((G, D))
+    var = np.empty((G, D))
+    for g in range(G):
+        if kind == "variable":
+            tag = toks[pos]
+            pos += 1
+            if tag != "diag":
+                raise ValueError("oracle reads diagonal Gaussians only, got " + tag)
+        elif kind != "diagonal_cov":
+            raise ValueError("oracle reads diagonal Gaussians only, got " + kind)
+        mean[g] = [float(x) for x in toks[pos:pos + D]]
+        pos += D
+        var[g] = [float(x) for x in toks[pos:pos + D]]
+        pos += D
+    return mean, var
+
+
+def write_mc(path: str, mix_off, mix_idx, mix_w) -> None:
+    """HmmSet::write_mc / Mixture::write (read side aku/HmmSet.cc:156-180,
+    aku/Distributions.cc:2418-2434): 'S' then per mixture 'n idx w idx w ...'."""
+    S = len(mix_off) - 1
+    with open(path, "w") as f:
+        f.write("%d\n" % S)
+        for s in range(S):
+            a, b = mix_off[s], mix_off[s + 1]
+            f.write("%d" % (b - a))
+            for k in range(a, b):
+                f.write(" %d %s" % (mix_idx[k], repr(float(mix_w[k]))))
+            f.write("\n")
+
+
+def read_mc(path: str):
+    toks = open(path).read().split()
+    S = int(toks[0])
+    pos = 1
+    off = [0]
+    idx: List[int] = []
+    w: List[float] = []
+    for _ in range(S):
+        n = int(toks[pos])
+        pos += 1
+        for _k in range(n):
+            idx.append(int(toks[pos]))
+            w.append(float(toks[pos + 1]))
+            pos += 2
+        off.append(len(idx))
+    return np.array(off, np.int32), np.array(idx, np.int32), np.array(w, np.float64)
+
+
+def write_ph(path: str, num_states: int, states_per_hmm: int = 1) -> None:
+    """Legacy Noway PHONE file (read side HmmSet::read_legacy_ph,
+    aku/HmmSet.cc:194-329): header 'PHONE', hmm count, then per hmm
+    'index nstates+2 label', state line ('-1 -2 s0 s1..': dummy initial and
+    final state ids are negative), and one transition line per state
+    'from ntrans target prob ...'.  State i's emission pdf is i."""
+    assert num_states % states_per_hmm == 0
+    nh = num_states // states_per_hmm
+    with open(path, "w") as f:
+        f.write("PHONE\n%d\n" % nh)
+        for h in range(nh):
+            ns = states_per_hmm
+            f.write("%d %d h%d\n" % (h + 1, ns + 2, h))
+            ids = [-1, -2] + [h * ns + j for j in range(ns)]
+            f.write(" ".join(str(x) for x in ids) + "\n")
+            # source dummy state: one transition to the first real state
+            f.write("0 1 2 1.0\n")
+            f.write("1 0\n")
+            for j in range(ns):
+                nxt = 2 + j + 1 if j + 1 < ns else 1
+                f.write("%d 2 %d 0.5 %d 0.5\n" % (2 + j, 2 + j, nxt))
+
+
+def read_model(base: str) -> DiagModel:
+    mean, var = read_gk(base + ".gk")
+    off, idx, w = read_mc(base + ".mc")
+    return DiagModel(mean, var, off, idx, w)
+
+
+# ---------------------------------------------------------------------------
+# recipes  (Recipe::read, aku/Recipe.cc:23-149)
+# ---------------------------------------------------------------------------
+
+@dataclass
+class RecipeInfo:
+    audio_path: str = ""
+    alt_audio_path: str = ""
+    transcript_path: str = ""
+    alignment_path: str = ""
+    hmmnet_path: str = ""
+    den_hmmnet_path: str = ""
+    lna_path: str = ""
+    start_time: float = 0.0
+    end_time: float = 0.0
+    start_line: int = 0
+    end_line: int = 0
+    speaker_id: str = ""
+    utterance_id: str = ""
+
+
+_RECIPE_KEYS = {
+    "audio": "audio_path", "alt-audio": "alt_audio_path", "transcript": "transcript_path",
+    "alignment": "alignment_path", "hmmnet": "hmmnet_path", "den-hmmnet": "den_hmmnet_path",
+    "lna": "lna_path", "speaker": "speaker_id", "utterance": "utterance_id",
+}
+
+
+def recipe_read(text: str, num_batches: int = 0, batch_index: int = 0,
+                cluster_speakers: bool = False) -> List[RecipeInfo]:
+    """Restates Recipe::read including its quirks: the key=value map is NOT
+    cleared between lines (keys persist, aku/Recipe.cc:31,82-90), batches are
+    contiguous with the first (L mod n) batches one line longer (:63-112)."""
+    if num_batches > 1 and (batch_index < 1 or batch_index > num_batches):
+        raise ValueError("Invalid batch index")
+    line_buffer = []
+    for raw in text.split("\n"):
+        line = raw.strip("\n\t \r")
+        if not line or line[0] == "#":
+            continue
+        line_buffer.append(line)
+    batch_remainder = 0
+    if num_batches <= 1:
+        target_lines = len(line_buffer)
+    else:
+        target_lines = len(line_buffer) // num_batches
+        batch_remainder = len(line_buffer) % num_batches
+    extra_line = 1
+    if target_lines < 1:
+        target_lines = 1
+        extra_line = 0
+    if batch_remainder == 0:
+        extra_line = 0
+    infos: List[RecipeInfo] = []
+    kv: Dict[str, str] = {}
+    cur_index = 1
+    cur_line = 0
+    cur_speaker = ""
+    for line in line_buffer:
+        for fld in line.split():
+            parts = fld.split("=")
+            if len(parts) != 2:
+                raise ValueError("Invalid recipe line: " + line)
+            kv[parts[0]] = parts[1]
+        if num_batches > 1 and cur_index < num_batches:
+            new_speaker = kv.get("speaker", "")
+            if cur_line >= target_lines + extra_line and (
+                    not cluster_speakers or len(cur_speaker) == 0 or cur_speaker != new_speaker):
+                cur_index += 1
+                if cur_index > batch_index:
+                    break
+                cur_line -= target_lines + extra_line
+                if cur_index > batch_remainder:
+                    extra_line = 0
+            cur_speaker = new_speaker
+        if num_batches <= 1 or cur_index == batch_index:
+            info = RecipeInfo()
+            for k, attr in _RECIPE_KEYS.items():
+                if k in kv:
+                    setattr(info, attr, kv[k])
+            if "start-time" in kv:
+                info.start_time = _atof(kv["start-time"])
+            if "end-time" in kv:
+                info.end_time = _atof(kv["end-time"])
+            if "start-line" in kv:
+                info.start_line = _atoi(kv["start-line"])
+            if "end-line" in kv:
+                info.end_line = _atoi(kv["end-line"])
+            infos.append(info)
+        cur_line += 1
+    return infos
+
+
+def _atof(s: str) -> float:
+    import re
+    m = re.match(r"\s*[-+]?(\d+\.?\d*([eE][-+]?\d+)?|\.\d+([eE][-+]?\d+)?)", s)
+    return float(m.group(0)) if m else 0.0
+
+
+def _atoi(s: str) -> int:
+    import re
+    m = re.match(r"\s*[-+]?\d+", s)
+    return int(m.group(0)) if m else 0
+
+
+# ---------------------------------------------------------------------------
+# WAV helper (PCM16 mono) -- stands in for libsndfile's sf_read_short on the
+# files the tests use (aku/AudioReader.cc:92-110,196-197)
+# ---------------------------------------------------------------------------
+
+def read_wav_pcm16(path: str) -> Tuple[np.ndarray, int]:
+    import wave
+    with wave.open(path, "rb") as w:
+        if w.getnchannels() != 1:
+            raise ValueError("AudioReader: sorry, audio files with multiple channels not supported")
+        if w.getsampwidth() != 2:
+            raise ValueError("oracle WAV reader handles PCM16 only")
+        data = w.readframes(w.getnframes())
+        return np.frombuffer(data, "<i2").copy(), w.getframerate()
+
+
+# ---------------------------------------------------------------------------
+# real-reference hooks (oracle/_ref, present only where it was built)
+# ---------------------------------------------------------------------------
+
+def ref_kissfft():
+    p = os.path.join(_HERE, "_ref", "libkissfft_ref.so")
+    if not os.path.exists(p):
+        return None
+    K = C.CDLL(p)
+    K.kiss_fftr_alloc.restype = C.c_void_p
+    K.kiss_fftr_alloc.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    K.kiss_fftr.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    return K
+
+
+def ref_aku():
+    p = os.path.join(_HERE, "_ref", "libaku_ref.so")
+    if not os.path.exists(p):
+        return None
+    A = C.CDLL(p)
+    A.ref_safe_log.restype = C.c_double
+    A.ref_safe_log.argtypes = [C.c_double]
+    A.ref_str2float.restype = C.c_double
+    A.ref_str2float.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+    A.ref_module_config_read.restype = C.c_int
+    A.ref_module_config_read.argtypes = [C.c_char_p, C.c_long, C.c_char_p, C.c_int, C.POINTER(C.c_long)]
+    A.ref_module_config_get_floats.restype = C.c_int
+    A.ref_module_config_get_floats.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_float), C.c_int]
+    return A
