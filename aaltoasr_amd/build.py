@@ -1,0 +1,88 @@
+"""build.py -- compiles libaasr.so (HIP kernels + C ABI) in-tree for gfx950.
+
+    python -m aaltoasr_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The shared library lands in
+aaltoasr_amd/lib/ (git-ignored, travels to the GPU box with the snapshot).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+LIB = os.path.join(LIBDIR, "libaasr.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+# -ffp-contract=off: the feature kernels restate float32/float64 arithmetic of
+# the reference operation by operation; fused multiply-adds would change bits.
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
+          "-Wno-unused-function", f"--offload-arch={ARCH}", "-I", os.path.join(HERE, "..", "include")]
+
+
+def _sources():
+    out = []
+    for root, _dirs, files in os.walk(CSRC):
+        for f in sorted(files):
+            if f.endswith((".hip", ".cc")) and not f.startswith("main_"):
+                out.append(os.path.join(root, f))
+    return sorted(out)
+
+
+def _headers_digest() -> str:
+    h = hashlib.sha1()
+    paths = [os.path.join(HERE, "..", "include", "aasr.h")]
+    for root, _dirs, files in os.walk(CSRC):
+        for f in sorted(files):
+            if f.endswith(".h") or f.endswith(".hh"):
+                paths.append(os.path.join(root, f))
+    for p in sorted(paths):
+        h.update(open(p, "rb").read())
+    h.update(" ".join(COMMON).encode())
+    return h.hexdigest()
+
+
+def _compile(src: str, digest: str, force: bool) -> str:
+    rel = os.path.relpath(src, CSRC).replace(os.sep, "_")
+    obj = os.path.join(OBJDIR, rel + ".o")
+    stamp = obj + ".stamp"
+    key = digest + hashlib.sha1(open(src, "rb").read()).hexdigest()
+    if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == key:
+        return obj
+    cmd = [HIPCC] + COMMON + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    open(stamp, "w").write(key)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJDIR, exist_ok=True)
+    srcs = _sources()
+    digest = _headers_digest()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, digest, force), srcs))
+    newest = max(os.path.getmtime(o) for o in objs)
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + \
+              ["-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,242 @@
+"""capi.py -- ctypes binding of libaasr.so (the C ABI in include/aasr.h).
+
+This is plumbing for tests, bench.py and the Python mirror of the aku classes.
+It never falls back to a CPU path: if the shared library is missing it raises,
+and compute calls without a HIP device return AASR_ERR_NO_DEVICE.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from typing import Optional
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libaasr.so")
+HEADER_PATH = os.path.join(HERE, "..", "include", "aasr.h")
+
+AASR_OK = 0
+AASR_ERR_INVALID = -1
+AASR_ERR_UNSUPPORTED = -2
+AASR_ERR_NO_DEVICE = -3
+AASR_ERR_IO = -4
+AASR_ERR_SHORT_AUDIO = -5
+
+
+class AasrError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("aasr status %d: %s" % (code, msg))
+        self.code = code
+        self.msg = msg
+
+
+class RunOptions(C.Structure):
+    _fields_ = [("lnabytes", C.c_int32), ("normalize", C.c_int32), ("num_batches", C.c_int32),
+                ("batch_index", C.c_int32), ("no_overwrite", C.c_int32), ("raw_audio", C.c_int32),
+                ("info", C.c_int32), ("out_dir", C.c_char_p), ("lna_suffix", C.c_char_p)]
+
+
+class RunStats(C.Structure):
+    _fields_ = [("utterances", C.c_int64), ("frames", C.c_int64),
+                ("seconds_total", C.c_double), ("seconds_device", C.c_double)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def declared_symbols() -> list:
+    """Function names declared in include/aasr.h."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(aasr_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib() -> C.CDLL:
+    """Loads libaasr.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libaasr.so is missing (%s): build it with `python -m aaltoasr_amd.build`; "
+            "this engine has no CPU fallback" % LIB_PATH)
+    # torch bundles its own libamdhip64.so.7; importing it first makes both
+    # share one HIP runtime so torch device pointers are valid in libaasr.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH)
+    _declare(L)
+    _lib = L
+    return L
+
+
+def _declare(L: C.CDLL) -> None:
+    i32, i64, f, d, vp, cp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p, C.c_char_p
+    pvp = C.POINTER(vp)
+    L.aasr_last_error.restype = cp
+    L.aasr_version.restype = cp
+    L.aasr_device_count.restype = C.c_int
+    L.aasr_set_device.argtypes = [C.c_int]
+    L.aasr_feat_create.argtypes = [cp, pvp]
+    L.aasr_feat_destroy.argtypes = [vp]
+    L.aasr_feat_destroy.restype = None
+    L.aasr_feat_dim.argtypes = [vp]
+    L.aasr_feat_frame_rate.argtypes = [vp]
+    L.aasr_feat_frame_rate.restype = f
+    L.aasr_feat_sample_rate.argtypes = [vp]
+    L.aasr_feat_module_dim.argtypes = [vp, cp]
+    L.aasr_feat_halo.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.aasr_feat_halo.restype = None
+    L.aasr_feat_last_frame.argtypes = [vp, i64]
+    L.aasr_feat_run.argtypes = [vp, vp, i64, i32, i32, cp, vp]
+    L.aasr_feat_run_dev.argtypes = [vp, vp, i64, i32, i32, vp, vp]
+    L.aasr_feat_run_f64.argtypes = [vp, vp, i64, i32, i32, cp, vp]
+    L.aasr_feat_run_batch_dev.argtypes = [vp, vp, vp, vp, i32, vp, vp]
+    L.aasr_feat_set_parameters.argtypes = [vp, cp, cp]
+    L.aasr_gmm_create_diag.argtypes = [i32, i32, vp, vp, i32, vp, vp, vp, pvp]
+    L.aasr_gmm_create_from_files.argtypes = [cp, cp, cp, pvp]
+    L.aasr_gmm_destroy.argtypes = [vp]
+    L.aasr_gmm_destroy.restype = None
+    L.aasr_gmm_dim.argtypes = [vp]
+    L.aasr_gmm_num_states.argtypes = [vp]
+    L.aasr_gmm_num_gaussians.argtypes = [vp]
+    L.aasr_gmm_expanded_rows.argtypes = [vp]
+    L.aasr_gmm_expanded_rows.restype = i64
+    L.aasr_gmm_set_precision.argtypes = [vp, C.c_int]
+    L.aasr_gmm_score.argtypes = [vp, vp, i64, vp]
+    L.aasr_gmm_score_dev.argtypes = [vp, vp, i64, vp, vp]
+    L.aasr_gmm_gauss_loglik.argtypes = [vp, vp, i64, vp]
+    L.aasr_gmm_gauss_loglik_dev.argtypes = [vp, vp, i64, vp, vp]
+    L.aasr_lna_encode.argtypes = [vp, i64, i32, C.c_int, C.c_int, vp, vp]
+    L.aasr_lna_encode_dev.argtypes = [vp, i64, i32, C.c_int, C.c_int, vp, vp, vp]
+    L.aasr_lna_header.argtypes = [i32, C.c_int, vp]
+    L.aasr_lna_header.restype = None
+    L.aasr_recipe_batch_range.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.aasr_run_recipe.argtypes = [vp, vp, cp, C.POINTER(RunOptions), C.POINTER(RunStats)]
+    L.aasr_run_utterance.argtypes = [vp, vp, vp, i64, i32, i32, C.c_int, C.c_int,
+                                     C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(i64), C.POINTER(i64)]
+    L.aasr_free.argtypes = [vp]
+    L.aasr_free.restype = None
+
+
+def check(status: int) -> None:
+    if status != AASR_OK:
+        raise AasrError(status, lib().aasr_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a) -> int:
+    """Address of a numpy array or torch tensor (host or device)."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a.data_ptr()
+
+
+def _stream_handle(stream) -> Optional[int]:
+    if stream is None:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                return torch.cuda.current_stream().cuda_stream
+        except Exception:
+            pass
+        return None
+    if isinstance(stream, int):
+        return stream
+    return stream.cuda_stream
+
+
+class Gmm:
+    """Owner of an aasr_gmm handle (HmmSet scoring surface)."""
+
+    def __init__(self, handle: int):
+        self._h = handle
+
+    @classmethod
+    def from_arrays(cls, mean, var, mix_off, mix_idx, mix_w) -> "Gmm":
+        mean = np.ascontiguousarray(mean, np.float64)
+        var = np.ascontiguousarray(var, np.float64)
+        mix_off = np.ascontiguousarray(mix_off, np.int32)
+        mix_idx = np.ascontiguousarray(mix_idx, np.int32)
+        mix_w = np.ascontiguousarray(mix_w, np.float64)
+        h = C.c_void_p()
+        check(lib().aasr_gmm_create_diag(mean.shape[1], mean.shape[0], _ptr(mean), _ptr(var),
+                                         len(mix_off) - 1, _ptr(mix_off), _ptr(mix_idx),
+                                         _ptr(mix_w), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_files(cls, gk: str, mc: str, ph: Optional[str] = None) -> "Gmm":
+        h = C.c_void_p()
+        check(lib().aasr_gmm_create_from_files(gk.encode(), mc.encode(),
+                                               ph.encode() if ph else None, C.byref(h)))
+        return cls(h.value)
+
+    def close(self) -> None:
+        if self._h:
+            lib().aasr_gmm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def dim(self) -> int:
+        return lib().aasr_gmm_dim(self._h)
+
+    @property
+    def num_states(self) -> int:
+        return lib().aasr_gmm_num_states(self._h)
+
+    @property
+    def num_gaussians(self) -> int:
+        return lib().aasr_gmm_num_gaussians(self._h)
+
+    @property
+    def expanded_rows(self) -> int:
+        return lib().aasr_gmm_expanded_rows(self._h)
+
+    def score(self, frames: np.ndarray) -> np.ndarray:
+        frames = np.ascontiguousarray(frames, np.float32)
+        out = np.empty((frames.shape[0], self.num_states), np.float32)
+        check(lib().aasr_gmm_score(self._h, _ptr(frames), frames.shape[0], _ptr(out)))
+        return out
+
+    def score_dev(self, d_frames, d_out, stream=None) -> None:
+        check(lib().aasr_gmm_score_dev(self._h, _ptr(d_frames), d_frames.shape[0], _ptr(d_out),
+                                       _stream_handle(stream)))
+
+    def gauss_loglik(self, frames: np.ndarray) -> np.ndarray:
+        frames = np.ascontiguousarray(frames, np.float32)
+        out = np.empty((frames.shape[0], self.num_gaussians), np.float32)
+        check(lib().aasr_gmm_gauss_loglik(self._h, _ptr(frames), frames.shape[0], _ptr(out)))
+        return out
+
+
+def lna_encode(state_loglik: np.ndarray, normalize: bool = True, lnabytes: int = 2):
+    x = np.ascontiguousarray(state_loglik, np.float32)
+    F, S = x.shape
+    lp = np.empty((F, S), np.float32)
+    by = np.empty((F, S * lnabytes), np.uint8)
+    check(lib().aasr_lna_encode(_ptr(x), F, S, int(normalize), lnabytes, _ptr(lp), _ptr(by)))
+    return lp, by
+
+
+def lna_encode_dev(d_loglik, normalize: bool, lnabytes: int, d_lp=None, d_bytes=None, stream=None):
+    F, S = d_loglik.shape
+    check(lib().aasr_lna_encode_dev(_ptr(d_loglik), F, S, int(normalize), lnabytes, _ptr(d_lp),
+                                    _ptr(d_bytes), _stream_handle(stream)))
+
+
+def lna_header(num_states: int, lnabytes: int) -> bytes:
+    buf = (C.c_uint8 * 5)()
+    lib().aasr_lna_header(num_states, lnabytes, buf)
+    return bytes(buf)

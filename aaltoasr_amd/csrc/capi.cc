@@ -1,0 +1,238 @@
+// capi.cc -- extern "C" boundary of libaasr (declared in include/aasr.h).
+// Nothing throws across this file; every entry point is wrapped in guarded().
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+#include "feat.h"
+#include "gmm.h"
+
+namespace aasr {
+
+std::string &last_error() {
+  static thread_local std::string msg;
+  return msg;
+}
+
+aasr_status fail(aasr_status code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  last_error() = buf;
+  return code;
+}
+
+void raise(aasr_status code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  throw Error{code, buf};
+}
+
+void require_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    raise(AASR_ERR_NO_DEVICE,
+          "no HIP device available (%s): this engine has no CPU fallback",
+          e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+}
+
+void lna_encode_launch(const float *d_loglik, int64_t F, int S, int normalize,
+                       int lnabytes, float *d_lp, uint8_t *d_bytes, hipStream_t stream);
+
+}  // namespace aasr
+
+using namespace aasr;
+
+extern "C" {
+
+const char *aasr_last_error(void) { return last_error().c_str(); }
+const char *aasr_version(void) { return "aaltoasr_amd 0.1 (gfx950)"; }
+
+int aasr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+aasr_status aasr_set_device(int ordinal) {
+  return guarded([&] { AASR_HIP(hipSetDevice(ordinal)); });
+}
+
+// ---------------------------------------------------------------- GMM -----
+
+aasr_status aasr_gmm_create_diag(int32_t dim, int32_t num_gaussians, const double *mean,
+                                 const double *var, int32_t num_states,
+                                 const int32_t *mix_off, const int32_t *mix_idx,
+                                 const double *mix_w, aasr_gmm **out) {
+  return guarded([&] {
+    if (!out || !mean || !var || !mix_off || !mix_idx || !mix_w)
+      raise(AASR_ERR_INVALID, "aasr_gmm_create_diag: null argument");
+    if (dim <= 0 || num_gaussians <= 0 || num_states <= 0)
+      raise(AASR_ERR_INVALID, "aasr_gmm_create_diag: non-positive size");
+    *out = nullptr;
+    HostModel m;
+    m.dim = dim;
+    m.G = num_gaussians;
+    m.S = num_states;
+    m.mean.assign(mean, mean + (size_t)num_gaussians * dim);
+    m.var.assign(var, var + (size_t)num_gaussians * dim);
+    m.mix_off.assign(mix_off, mix_off + num_states + 1);
+    if (m.mix_off[0] != 0) raise(AASR_ERR_INVALID, "mix_off[0] must be 0");
+    for (int s = 0; s < num_states; s++)
+      if (m.mix_off[s + 1] < m.mix_off[s]) raise(AASR_ERR_INVALID, "mix_off must be non-decreasing");
+    size_t K = (size_t)m.mix_off[num_states];
+    m.mix_idx.assign(mix_idx, mix_idx + K);
+    m.mix_w.assign(mix_w, mix_w + K);
+    aasr_gmm *g = new aasr_gmm();
+    try {
+      AASR_HIP(hipGetDevice(&g->device));
+      gmm_build(g, m);
+    } catch (...) {
+      delete g;
+      throw;
+    }
+    *out = g;
+  });
+}
+
+aasr_status aasr_gmm_create_from_files(const char *gk_path, const char *mc_path,
+                                       const char *ph_path, aasr_gmm **out) {
+  return guarded([&] {
+    if (!out || !gk_path || !mc_path)
+      raise(AASR_ERR_INVALID, "aasr_gmm_create_from_files: null argument");
+    *out = nullptr;
+    HostModel m = read_model_files(gk_path, mc_path, ph_path);
+    aasr_gmm *g = new aasr_gmm();
+    try {
+      AASR_HIP(hipGetDevice(&g->device));
+      gmm_build(g, m);
+    } catch (...) {
+      delete g;
+      throw;
+    }
+    *out = g;
+  });
+}
+
+void aasr_gmm_destroy(aasr_gmm *h) { delete h; }
+int aasr_gmm_dim(const aasr_gmm *h) { return h ? h->dim : -1; }
+int aasr_gmm_num_states(const aasr_gmm *h) { return h ? (int)h->S : -1; }
+int aasr_gmm_num_gaussians(const aasr_gmm *h) { return h ? (int)h->G : -1; }
+int64_t aasr_gmm_expanded_rows(const aasr_gmm *h) { return h ? h->mix.rows : -1; }
+
+aasr_status aasr_gmm_set_precision(aasr_gmm *h, int prec) {
+  return guarded([&] {
+    if (!h) raise(AASR_ERR_INVALID, "null handle");
+    if (prec == AASR_PREC_F32) {
+      h->precision = prec;
+      return;
+    }
+    if (prec == AASR_PREC_F64)
+      raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 contraction is not built yet");
+    raise(AASR_ERR_INVALID, "unknown precision %d", prec);
+  });
+}
+
+aasr_status aasr_gmm_score_dev(aasr_gmm *h, const float *d_frames, int64_t F,
+                               float *d_state_loglik, void *stream) {
+  return guarded([&] {
+    if (!h || (F > 0 && (!d_frames || !d_state_loglik)))
+      raise(AASR_ERR_INVALID, "aasr_gmm_score_dev: null argument");
+    gmm_score_launch(h, d_frames, F, d_state_loglik, (hipStream_t)stream);
+  });
+}
+
+aasr_status aasr_gmm_score(aasr_gmm *h, const float *frames, int64_t F, float *state_loglik) {
+  return guarded([&] {
+    if (!h || (F > 0 && (!frames || !state_loglik)))
+      raise(AASR_ERR_INVALID, "aasr_gmm_score: null argument");
+    if (F <= 0) return;
+    h->d_frames.ensure((size_t)F * h->dim);
+    h->d_out.ensure((size_t)F * h->S);
+    AASR_HIP(hipMemcpy(h->d_frames.p, frames, (size_t)F * h->dim * sizeof(float), hipMemcpyHostToDevice));
+    gmm_score_launch(h, h->d_frames.p, F, h->d_out.p, nullptr);
+    AASR_HIP(hipMemcpy(state_loglik, h->d_out.p, (size_t)F * h->S * sizeof(float), hipMemcpyDeviceToHost));
+  });
+}
+
+aasr_status aasr_gmm_gauss_loglik_dev(aasr_gmm *h, const float *d_frames, int64_t F,
+                                      float *d_gauss_loglik, void *stream) {
+  return guarded([&] {
+    if (!h || (F > 0 && (!d_frames || !d_gauss_loglik)))
+      raise(AASR_ERR_INVALID, "aasr_gmm_gauss_loglik_dev: null argument");
+    gmm_gauss_launch(h, d_frames, F, d_gauss_loglik, (hipStream_t)stream);
+  });
+}
+
+aasr_status aasr_gmm_gauss_loglik(aasr_gmm *h, const float *frames, int64_t F,
+                                  float *gauss_loglik) {
+  return guarded([&] {
+    if (!h || (F > 0 && (!frames || !gauss_loglik)))
+      raise(AASR_ERR_INVALID, "aasr_gmm_gauss_loglik: null argument");
+    if (F <= 0) return;
+    h->d_frames.ensure((size_t)F * h->dim);
+    h->d_out.ensure((size_t)F * h->G);
+    AASR_HIP(hipMemcpy(h->d_frames.p, frames, (size_t)F * h->dim * sizeof(float), hipMemcpyHostToDevice));
+    gmm_gauss_launch(h, h->d_frames.p, F, h->d_out.p, nullptr);
+    AASR_HIP(hipMemcpy(gauss_loglik, h->d_out.p, (size_t)F * h->G * sizeof(float), hipMemcpyDeviceToHost));
+  });
+}
+
+// ---------------------------------------------------------------- LNA -----
+
+aasr_status aasr_lna_encode_dev(const float *d_state_loglik, int64_t F, int32_t S,
+                                int normalize, int lnabytes, float *d_lp_out,
+                                uint8_t *d_bytes_out, void *stream) {
+  return guarded([&] {
+    if (lnabytes != 2 && lnabytes != 4)
+      raise(AASR_ERR_INVALID, "lnabytes must be 2 or 4, got %d", lnabytes);
+    if (F > 0 && !d_state_loglik) raise(AASR_ERR_INVALID, "aasr_lna_encode_dev: null input");
+    if (S <= 0) raise(AASR_ERR_INVALID, "aasr_lna_encode_dev: S must be positive");
+    require_device();
+    lna_encode_launch(d_state_loglik, F, S, normalize, lnabytes, d_lp_out, d_bytes_out,
+                      (hipStream_t)stream);
+  });
+}
+
+aasr_status aasr_lna_encode(const float *state_loglik, int64_t F, int32_t S, int normalize,
+                            int lnabytes, float *lp_out, uint8_t *bytes_out) {
+  return guarded([&] {
+    if (lnabytes != 2 && lnabytes != 4)
+      raise(AASR_ERR_INVALID, "lnabytes must be 2 or 4, got %d", lnabytes);
+    if (S <= 0) raise(AASR_ERR_INVALID, "aasr_lna_encode: S must be positive");
+    if (F <= 0) return;
+    if (!state_loglik) raise(AASR_ERR_INVALID, "aasr_lna_encode: null input");
+    require_device();
+    size_t n = (size_t)F * S;
+    DevBuf<float> d_in, d_lp;
+    DevBuf<uint8_t> d_by;
+    d_in.upload(state_loglik, n);
+    if (lp_out) d_lp.alloc(n);
+    if (bytes_out) d_by.alloc(n * lnabytes);
+    lna_encode_launch(d_in.p, F, S, normalize, lnabytes, d_lp.p, d_by.p, nullptr);
+    if (lp_out) AASR_HIP(hipMemcpy(lp_out, d_lp.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (bytes_out) AASR_HIP(hipMemcpy(bytes_out, d_by.p, n * lnabytes, hipMemcpyDeviceToHost));
+    AASR_HIP(hipDeviceSynchronize());
+  });
+}
+
+void aasr_lna_header(int32_t num_states, int lnabytes, uint8_t out[5]) {
+  uint32_t i = (uint32_t)num_states;
+  out[0] = (i >> 24) & 0xff;
+  out[1] = (i >> 16) & 0xff;
+  out[2] = (i >> 8) & 0xff;
+  out[3] = i & 0xff;
+  out[4] = (uint8_t)lnabytes;
+}
+
+void aasr_free(void *p) { free(p); }
+
+}  // extern "C"

@@ -1,0 +1,273 @@
+// gmm_score.hip -- frame x Gaussian scoring kernels for gfx950 (MI355X).
+//
+// Replaces the per-frame loop
+//   HmmSet::precompute_likelihoods        aku/HmmSet.cc:484-501
+//     PDFPool::precompute_likelihoods     aku/Distributions.cc:2663-2682
+//       DiagonalGaussian::compute_log_likelihood   :1040-1062  (+ exp :1033)
+//     Mixture::compute_likelihood         aku/Distributions.cc:2078-2086
+// with one launch over a block of frames.
+//
+// Formulation.  ll_g(x) = c_g - 1/2 sum_d p_gd (x_d - mu_gd)^2 is expanded
+// around a per-dimension pivot v (x' = x - v, mu' = mu - v) into a dense
+// contraction over K = 2*dim + 1:
+//     log2e * ll = sum_d [p mu' log2e] x'_d + [-p/2 log2e] x'_d^2 + C_g * 1
+// so the frame x Gaussian quadratic forms are an exact-f32 GEMM that runs on
+// the matrix cores (v_mfma_f32_32x32x2_f32: one instruction = one dimension's
+// (x', x'^2) pair), with the mixture log-sum-exp fused behind it.  log(w) of
+// the mixture weight is folded into C_g, the result is in log2 units so the
+// epilogue is max -> v_exp_f32(x - max) -> add -> v_log_f32.
+//
+// Work decomposition (frame-stationary).  A workgroup of 4 waves owns 256
+// frames; each wave keeps its 64 frames' K x 64 operand in VGPRs for the whole
+// kernel (nkk x 2 registers) and the Gaussian rows stream past in tiles of 64
+// rows: HBM/L2 -> LDS by global_load_lds (double buffered, one barrier per
+// tile), LDS -> A fragments by ds_read_b128.  Each wave computes a 64-row x
+// 64-frame tile as 2x2 MFMA blocks.  The epilogue dumps one 32-row block pair
+// at a time to a wave-private LDS staging area laid out [row][frame], then
+// every lane owns one frame and reduces the rows of each mixture segment
+// (16 rows at a time in registers, merged online) -- no cross-lane traffic,
+// arbitrary components per state, segments may span chunks and tiles.
+//
+// Roofline: FP32 matrix rate, 2*K flop per frame x row pair; see DESIGN.md.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "gmm.h"
+
+namespace aasr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LN2_F 0.69314718055994530942f
+// log(1e-50): HmmSet clamps state likelihoods at util::tiny_for_log
+// (aku/HmmSet.cc:497-498, aku/util.hh:131)
+#define LOG_TINY_F (-115.12925464970228f)
+#define NEG_BIG_F (-3.0e38f)
+
+template <int NKK>
+struct ScoreSmem {
+  // [2 buffers][NKK/2][64 lanes][4] floats
+  static constexpr int kTileFloats = (NKK / 2) * 64 * 4;
+  static constexpr int kStageFloatsPerWave = CHUNK_ROWS * FRAMES_PER_WAVE;
+  static constexpr int kBytes =
+      (2 * kTileFloats + WAVES_PER_BLOCK * kStageFloatsPerWave) * 4;
+};
+
+__device__ __forceinline__ void issue_tile_copy(const float *__restrict__ gtile,
+                                                float *lds_buf, int tile_floats,
+                                                int wave, int lane) {
+  // 16 bytes per lane per issue; the LDS destination of a global_load_lds is
+  // wave-uniform base + lane*16, i.e. lane-linear -- exactly the packed layout.
+  const int chunks = tile_floats / 4;  // 16-byte pieces
+  for (int c0 = wave * 64; c0 < chunks; c0 += WAVES_PER_BLOCK * 64) {
+    const float *src = gtile + (size_t)(c0 + lane) * 4;
+    float *dst = lds_buf + (size_t)c0 * 4;
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)src,
+        (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+  }
+}
+
+// Reduce rows [a, b) of the staged chunk for this lane's frame, 16 rows at a
+// time, merging into the running (m, s) pair:  sum_r 2^v_r = s * 2^m.
+__device__ __forceinline__ void reduce_rows(const float *stage_col, int a, int b,
+                                            float &m, float &s) {
+  for (int r0 = a; r0 < b; r0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      int r = r0 + i;
+      int rc = r < b ? r : b - 1;
+      float x = stage_col[rc * FRAMES_PER_WAVE];
+      v[i] = r < b ? x : NEG_BIG_F;
+    }
+    float gm = v[0];
+#pragma unroll
+    for (int i = 1; i < 16; i++) gm = fmaxf(gm, v[i]);
+    float mn = fmaxf(m, gm);
+    float acc = s * __builtin_amdgcn_exp2f(m - mn);
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc += __builtin_amdgcn_exp2f(v[i] - mn);
+    m = mn;
+    s = acc;
+  }
+}
+
+// MODE 0: per-state mixture log-likelihoods (segmented log-sum-exp)
+// MODE 1: raw per-row log-likelihoods (pool view), out[f][row]
+template <int NKK, int MODE>
+__global__ __launch_bounds__(256, 2) void k_gmm_diag_score(
+    const float *__restrict__ frames, int64_t F, int dim,
+    const float *__restrict__ pivot, const float *__restrict__ apack,
+    int64_t tiles, const int32_t *__restrict__ chunk_seg_begin,
+    const uint32_t *__restrict__ seg_desc, const int32_t *__restrict__ seg_out,
+    float *__restrict__ out, int64_t out_cols, int64_t rows) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *smem = (float *)smem_raw;
+  constexpr int kTileFloats = ScoreSmem<NKK>::kTileFloats;
+  float *abuf0 = smem;
+  float *abuf1 = smem + kTileFloats;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  float *stage = smem + 2 * kTileFloats + wave * ScoreSmem<NKK>::kStageFloatsPerWave;
+
+  const int n = lane & 31;   // MFMA column (frame within a 32-block)
+  const int h = lane >> 5;   // K parity held by this lane
+  const int64_t f0 = (int64_t)blockIdx.x * FRAMES_PER_BLOCK + wave * FRAMES_PER_WAVE;
+
+  // ---- frame operand: B[kk][nb] = h ? x'^2 : x'  (kk<dim), 1 at kk==dim/h==0
+  float bf[NKK][2];
+#pragma unroll
+  for (int nb = 0; nb < 2; nb++) {
+    int64_t f = f0 + nb * 32 + n;
+    if (f > F - 1) f = F - 1;
+    const float *xr = frames + f * dim;
+#pragma unroll
+    for (int kk = 0; kk < NKK; kk++) {
+      float v = 0.0f;
+      if (kk < dim) {
+        float xc = xr[kk] - pivot[kk];
+        v = h ? xc * xc : xc;
+      } else if (kk == dim) {
+        v = h ? 0.0f : 1.0f;
+      }
+      bf[kk][nb] = v;
+    }
+  }
+
+  float carry_m = NEG_BIG_F, carry_s = 0.0f;
+
+  // prologue: tile 0 -> buffer 0
+  if (tiles > 0) issue_tile_copy(apack, abuf0, kTileFloats, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int64_t my_frame = f0 + lane;  // epilogue: lane <-> frame
+  const bool frame_ok = my_frame < F;
+
+  for (int64_t t = 0; t < tiles; t++) {
+    float *acur = (t & 1) ? abuf1 : abuf0;
+    float *anext = (t & 1) ? abuf0 : abuf1;
+    if (t + 1 < tiles)
+      issue_tile_copy(apack + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
+
+    f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
+    const f32x4 *afrag = (const f32x4 *)acur;
+#pragma unroll
+    for (int q = 0; q < NKK / 2; q++) {
+      f32x4 av = afrag[q * 64 + lane];  // {mb0 kk0, mb0 kk1, mb1 kk0, mb1 kk1}
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf[2 * q][0], c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf[2 * q][1], c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf[2 * q][0], c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf[2 * q][1], c11, 0, 0, 0);
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf[2 * q + 1][0], c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf[2 * q + 1][1], c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf[2 * q + 1][0], c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf[2 * q + 1][1], c11, 0, 0, 0);
+    }
+
+    // ---- epilogue, one 32-row chunk at a time
+#pragma unroll
+    for (int mb = 0; mb < 2; mb++) {
+      const f32x16 &ca = mb ? c10 : c00;
+      const f32x16 &cb = mb ? c11 : c01;
+      // C layout: lane (n,h), reg i -> row 8*(i/4) + 4*h + (i%4), col n
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        int row = 8 * (i >> 2) + 4 * h + (i & 3);
+        stage[row * FRAMES_PER_WAVE + n] = ca[i];
+        stage[row * FRAMES_PER_WAVE + 32 + n] = cb[i];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      const float *col = stage + lane;
+      const int64_t chunk = t * 2 + mb;
+      if (MODE == 0) {
+        const int sb = chunk_seg_begin[chunk];
+        const int se = chunk_seg_begin[chunk + 1];
+        for (int si = sb; si < se; si++) {
+          const uint32_t d = seg_desc[si];
+          const int a = d & 0xff, b = (d >> 8) & 0xff;
+          const bool cont = (d >> 16) & 1, open = (d >> 17) & 1;
+          float m = cont ? carry_m : NEG_BIG_F;
+          float s = cont ? carry_s : 0.0f;
+          reduce_rows(col, a, b, m, s);
+          if (open) {
+            carry_m = m;
+            carry_s = s;
+          } else if (frame_ok) {
+            float lg = __builtin_amdgcn_logf(s);  // log2
+            float ll = fmaf(m, LN2_F, lg * LN2_F);
+            ll = fmaxf(ll, LOG_TINY_F);
+            out[my_frame * out_cols + seg_out[si]] = ll;
+          }
+        }
+      } else {
+        const int64_t rbase = chunk * CHUNK_ROWS;
+        if (frame_ok) {
+          for (int r = 0; r < CHUNK_ROWS; r++) {
+            if (rbase + r < rows)
+              out[my_frame * out_cols + rbase + r] = col[r * FRAMES_PER_WAVE] * LN2_F;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
+template <int NKK, int MODE>
+static void launch_t(const aasr_gmm *g, const PackedRows &pr, const float *d_frames,
+                     int64_t F, float *d_out, int64_t out_cols, hipStream_t stream) {
+  if (F <= 0) return;
+  const int64_t blocks = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
+  constexpr int smem = ScoreSmem<NKK>::kBytes;
+  static bool attr_set[64] = {false};
+  auto kern = k_gmm_diag_score<NKK, MODE>;
+  if (!attr_set[g->device & 63]) {
+    AASR_HIP(hipFuncSetAttribute((const void *)kern,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set[g->device & 63] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, stream, d_frames, F,
+                     g->dim, g->d_pivot.p, pr.a.p, pr.tiles, pr.chunk_seg_begin.p,
+                     pr.seg_desc.p, pr.seg_out.p, d_out, out_cols, pr.rows);
+  AASR_HIP(hipGetLastError());
+}
+
+template <int MODE>
+static void launch(const aasr_gmm *g, const PackedRows &pr, const float *d_frames,
+                   int64_t F, float *d_out, int64_t out_cols, hipStream_t stream) {
+  switch (pr.nkk) {
+#define AASR_CASE(N)                                                    \
+  case N:                                                               \
+    launch_t<N, MODE>(g, pr, d_frames, F, d_out, out_cols, stream);     \
+    return;
+    AASR_CASE(8) AASR_CASE(14) AASR_CASE(20) AASR_CASE(26) AASR_CASE(32) AASR_CASE(40)
+    AASR_CASE(48) AASR_CASE(64)
+#undef AASR_CASE
+    default:
+      break;
+  }
+  raise(AASR_ERR_UNSUPPORTED, "no kernel instance for K/2 = %d", pr.nkk);
+}
+
+void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
+                      hipStream_t stream) {
+  launch<0>(g, g->mix, d_frames, F, d_out, g->S, stream);
+}
+
+void gmm_gauss_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
+                      hipStream_t stream) {
+  gmm_build_pool(g);
+  launch<1>(g, g->pool, d_frames, F, d_out, g->G, stream);
+}
+
+}  // namespace aasr

@@ -1,0 +1,121 @@
+// lna_encode.hip -- per-frame state normalisation + LNA packing on device.
+//
+// Replaces the tail of the phone_probs frame loop (aku/phone_probs.cc:224-262;
+// PPToolbox: aku/PhoneProbsToolbox.cc:84-131):
+//   obs[i] = (float) state_likelihood(i);  Z = sum_i (double) obs[i]
+//   if (no-normalization || Z == 0) Z = 1
+//   obs[i] = (float) safe_log(obs[i] / Z)            (floor log(1e-50))
+//   2-byte: obs < -36.008 -> FF FF, else big-endian (int)(-1820*obs + .5)
+//   4-byte: little-endian float
+// The input here is the LOG state likelihood (float32, >= log(1e-50)), so the
+// reference's float storage of the LINEAR likelihood is emulated:
+//   ll <  ln(2^-150)            -> (float)lik == 0  -> output log(1e-50)
+//   ln(2^-150) <= ll < ln(2^-126) -> denormal: q = rint(lik * 2^149) quanta
+//   otherwise                   -> normal float, relative rounding 6e-8 (kept)
+//
+// One workgroup per frame; HBM-bound: S*(4 in + lnabytes out) bytes per frame.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "common.h"
+
+namespace aasr {
+
+#define LN2_D 0.69314718055994530942
+#define LOG_TINY_D (-115.12925464970228420090)  // log(1e-50)
+#define LN_FLT_MIN_F (-87.33654475f)             // ln(2^-126)
+
+__device__ __forceinline__ double float_cast_loglik(float ll) {
+  // log of (float)exp(ll) as the reference stores it; -inf when it flushes to 0
+  if (ll >= LN_FLT_MIN_F) return (double)ll;
+  double q = rint(exp((double)ll + 149.0 * LN2_D));
+  if (q <= 0.0) return -INFINITY;
+  return log(q) - 149.0 * LN2_D;
+}
+
+template <class T>
+__device__ __forceinline__ T wave_reduce_max(T v) {
+  for (int o = 32; o > 0; o >>= 1) {
+    T u = __shfl_xor(v, o, 64);
+    v = u > v ? u : v;
+  }
+  return v;
+}
+__device__ __forceinline__ double wave_reduce_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_state_norm_lna(
+    const float *__restrict__ loglik, int64_t F, int S, int normalize,
+    int lnabytes, float *__restrict__ lp_out, uint8_t *__restrict__ bytes_out) {
+  __shared__ double red[8];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int64_t f = blockIdx.x; f < F; f += gridDim.x) {
+    const float *row = loglik + f * (int64_t)S;
+    double logz = 0.0;
+    if (normalize) {
+      // pass 1: max of the float-cast log-likelihoods
+      double m = -INFINITY;
+      for (int i = tid; i < S; i += 256) {
+        double v = float_cast_loglik(row[i]);
+        m = v > m ? v : m;
+      }
+      m = wave_reduce_max(m);
+      if (lane == 0) red[wave] = m;
+      __syncthreads();
+      m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+      __syncthreads();
+      if (m > -INFINITY) {
+        // pass 2: Z / exp(m) accumulated in double
+        double z = 0.0;
+        for (int i = tid; i < S; i += 256) {
+          double v = float_cast_loglik(row[i]);
+          z += (double)expf((float)(v - m));
+        }
+        z = wave_reduce_sum(z);
+        if (lane == 0) red[4 + wave] = z;
+        __syncthreads();
+        z = (red[4] + red[5]) + (red[6] + red[7]);
+        __syncthreads();
+        logz = m + log(z);
+      }  // all zero -> Z = 1 (phone_probs.cc:231-232)
+    }
+    // pass 3: normalise, cast, pack
+    for (int i = tid; i < S; i += 256) {
+      double v = float_cast_loglik(row[i]);
+      double lpd = v - logz;
+      if (!(lpd >= LOG_TINY_D)) lpd = LOG_TINY_D;  // safe_log floor (also -inf)
+      float lp = (float)lpd;
+      int64_t o = f * (int64_t)S + i;
+      if (lp_out) lp_out[o] = lp;
+      if (bytes_out) {
+        if (lnabytes == 4) {
+          ((float *)bytes_out)[o] = lp;
+        } else {
+          unsigned short code;
+          if ((double)lp < -36.008) {
+            code = 0xffff;
+          } else {
+            int temp = (int)(-1820.0 * (double)lp + .5);
+            unsigned b0 = (temp >> 8) & 255, b1 = temp & 255;
+            code = (unsigned short)(b0 | (b1 << 8));  // big-endian on disk
+          }
+          ((unsigned short *)bytes_out)[o] = code;
+        }
+      }
+    }
+  }
+}
+
+void lna_encode_launch(const float *d_loglik, int64_t F, int S, int normalize,
+                       int lnabytes, float *d_lp, uint8_t *d_bytes, hipStream_t stream) {
+  if (F <= 0 || S <= 0) return;
+  int64_t blocks = F < (1 << 20) ? F : (1 << 20);
+  hipLaunchKernelGGL(k_state_norm_lna, dim3((unsigned)blocks), dim3(256), 0, stream, d_loglik,
+                     F, S, normalize, lnabytes, d_lp, d_bytes);
+  AASR_HIP(hipGetLastError());
+}
+
+}  // namespace aasr

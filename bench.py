@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py -- frames/sec of the acoustic-likelihood hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gmm|full]
+
+A "step" is one pass of the hot path over one batch of synthetic input that is
+already resident in HBM:
+  gmm  (BASELINE configs[1]): 1 000 000 x 39 float32 frames against a
+        50 000-Gaussian / 3 125-state x 16 diagonal HmmSet -> [F x S] state
+        log-likelihoods (k_gmm_diag_score).
+  full (BASELINE configs[2]): 1 h of 16 kHz int16 audio as 360 x 10 s
+        utterances -> MFCC chain -> same scoring -> 2-byte LNA codes.
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): every rank
+scores its own shard of frames/utterances, no collective on the scoring path;
+value = total frames / max-over-ranks time ("weak" scaling).
+
+Prints ONE JSON line on rank 0.  The roofline block prices the dominant
+kernel (k_gmm_diag_score) in ALGORITHMIC flops: 4*dim = 156 flop per
+frame x Gaussian pair against the dense FP32 matrix
+peak of 157.3 TFLOP/s (MI355X_MICROARCH.md).  The cpu_baseline block times
+the oracle's reference-shaped scalar double loop on this host.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3
+DIM = 39
+G = 50000
+S = 3125
+COMPS = 16
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["gmm", "full"], default=os.environ.get("AASR_BENCH_WORKLOAD", "gmm"))
+    ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step (gmm workload)")
+    ap.add_argument("--utts", type=int, default=360, help="10-s utterances per GPU per step (full workload)")
+    ap.add_argument("--cpu-frames", type=int, default=4000, help="frames timed on the CPU baseline (0 = skip)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from aaltoasr_amd import build, capi, synth
+    if rank == 0:
+        build.build()
+    if world > 1:
+        dist.barrier()
+    capi.check(capi.lib().aasr_set_device(local_rank))
+
+    # ---- model: identical on every rank (seeded), like every aku process
+    # reading the same .gk/.mc files (phone_probs.cc:96-110)
+    mean, var, off, idx, w = synth.make_model(D=DIM, G=G, S=S, comps=COMPS)
+    gmm = capi.Gmm.from_arrays(mean, var, off, idx, w)
+    rows = gmm.expanded_rows
+
+    stream = torch.cuda.current_stream()
+    feat = None
+    if args.workload == "gmm":
+        F = args.frames
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(synth.SEED + 17 * rank)
+        d_frames = torch.randn((F, DIM), generator=gen, device=dev, dtype=torch.float32)
+        d_out = torch.empty((F, S), device=dev, dtype=torch.float32)
+        workload = "configs[1]: batched diag-GMM log-likelihood, %d x %d-d frames x %d Gaussians (%d states x %d)" % (
+            F, DIM, G, S, COMPS)
+
+        def step():
+            gmm.score_dev(d_frames, d_out, stream)
+
+        def score_only():
+            gmm.score_dev(d_frames, d_out, stream)
+    else:
+        from aaltoasr_amd import pipeline
+        runner = pipeline.FullChainBench(gmm, n_utts=args.utts, seconds=10.0, rank=rank, device=dev)
+        F = runner.total_frames
+        workload = "configs[2]: MFCC chain + %d-Gaussian scoring + 2-byte LNA, %d x 10 s synthetic 16 kHz utterances (%d frames)" % (
+            G, args.utts, F)
+        step = runner.step
+        score_only = runner.score_only
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * F * args.steps / elapsed
+
+    # ---- dominant-kernel time: HIP events on the launch stream, scoring only
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    kreps = max(1, args.steps)
+    torch.cuda.synchronize()
+    ev0.record(stream)
+    for _ in range(kreps):
+        score_only()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    k_ms = ev0.elapsed_time(ev1) / kreps
+    algo_flop = 4.0 * DIM * float(F) * float(rows)
+    achieved = algo_flop / (k_ms * 1e-3) / 1e12
+    roofline = {
+        "bound": "mfma", "kernel": "k_gmm_diag_score", "achieved": round(achieved, 3),
+        "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+        "kernel_ms": round(k_ms, 4), "algorithmic_flop_per_launch": algo_flop,
+    }
+
+    # ---- CPU baseline (rank 0, N=1 only): oracle's reference-shaped loop
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
+        from oracle import oracle as O
+        O.build()
+        om = O.DiagModel(mean, var, off, idx, w)
+        cf = synth.make_frames(args.cpu_frames, DIM, seed=synth.SEED + 99).astype(np.float64)
+        om.cpu_baseline(cf[:50])
+        c0 = time.perf_counter()
+        om.cpu_baseline(cf)
+        cdt = time.perf_counter() - c0
+        cpu = {
+            "value": round(args.cpu_frames / cdt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d of the step's frames, same 50k-Gaussian model, oracle/aasr_oracle.c "
+                      "orc_cpu_baseline_score (double, per-frame per-Gaussian exp, linear mixture sum, "
+                      "float-cast normalisation) single thread, %.1f s" % (args.cpu_frames, cdt),
+            "host": _cpu_model(), "host_cores": os.cpu_count(),
+        }
+
+    if rank == 0:
+        line = {
+            "metric": "frames/sec GMM log-lik (39-d, 50k Gauss) + MFCC",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "frames_per_gpu_per_step": F, "dim": DIM, "gaussians": G,
+                       "states": S, "components_per_state": COMPS, "sharding": "frames/utterances per rank, no collective"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,238 @@
+/*
+ * aasr.h -- C ABI of the MI355X-native acoustic-likelihood engine.
+ *
+ * Drop-in boundary for AaltoASR's frame-parallel hot path
+ *     16 kHz PCM -> MFCC chain -> diagonal-GMM state likelihoods -> LNA
+ * i.e. what aku/phone_probs.cc and aku/PhoneProbsToolbox.cc drive through
+ * aku::FeatureGenerator and aku::HmmSet.  Plain pointers and sizes only; no
+ * C++/torch types.  Each entry point cites the reference interface it
+ * replaces (paths relative to the AaltoASR tree).
+ *
+ * Conventions
+ *  - Every function returns AASR_OK (0) or a negative aasr_status; the message
+ *    is available from aasr_last_error() (thread-local).  Nothing throws
+ *    across this boundary.  The C++ adapters in aaltoasr_amd/csrc/aku/ rethrow
+ *    as std::string / HmmSet::*Error exactly where the reference throws.
+ *  - Handles own their device memory.  Caller owns every host buffer.
+ *  - "_dev" variants take device pointers (hipMalloc'ed / torch tensors) and a
+ *    hipStream_t passed as void*; they enqueue work and do not synchronise.
+ *    Host variants copy in, run, copy out, and synchronise.
+ *  - A handle is bound to the HIP device current at creation; handles are not
+ *    thread-safe, distinct handles are independent.
+ *  - There is NO CPU fallback: without a usable HIP device the compute entry
+ *    points return AASR_ERR_NO_DEVICE.
+ */
+#ifndef AASR_H
+#define AASR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int aasr_status;
+enum {
+  AASR_OK = 0,
+  AASR_ERR_INVALID = -1,     /* bad argument / malformed config or model      */
+  AASR_ERR_UNSUPPORTED = -2, /* valid for the reference, not built here (loud) */
+  AASR_ERR_NO_DEVICE = -3,   /* no HIP device / HIP runtime error              */
+  AASR_ERR_IO = -4,          /* file open/read/write failure                   */
+  AASR_ERR_SHORT_AUDIO = -5  /* "audio shorter than frame" FeatureModules.cc:409 */
+};
+
+typedef struct aasr_feat aasr_feat;   /* compiled feature graph (.cfg)  */
+typedef struct aasr_gmm aasr_gmm;     /* acoustic model resident in HBM */
+
+const char *aasr_last_error(void);
+const char *aasr_version(void);
+/* number of visible HIP devices (0 when none / no driver) */
+int aasr_device_count(void);
+aasr_status aasr_set_device(int ordinal);
+
+/* ------------------------------------------------------------------------ */
+/* Feature chain: replaces aku::FeatureGenerator + FeatureModule::generate  */
+/* ------------------------------------------------------------------------ */
+
+/* FeatureGenerator::load_configuration (aku/FeatureGenerator.cc:96-219):
+ * cfg_text is the text of a feature configuration file ("module { ... }"
+ * blocks, aku/ModuleConfig.cc:166-202).  Supported module types: audiofile,
+ * fft, mel, power, dct, delta, normalization, lin_transform, merge,
+ * mean_subtractor; any other reference type -> AASR_ERR_UNSUPPORTED, unknown
+ * type -> AASR_ERR_INVALID ("Unknown module type"). */
+aasr_status aasr_feat_create(const char *cfg_text, aasr_feat **out);
+void aasr_feat_destroy(aasr_feat *h);
+
+/* FeatureGenerator::dim / frame_rate / sample_rate
+ * (aku/FeatureGenerator.cc:281-300) */
+int aasr_feat_dim(const aasr_feat *h);
+float aasr_feat_frame_rate(const aasr_feat *h);
+int aasr_feat_sample_rate(const aasr_feat *h);
+/* dim of a named module (FeatureGenerator::module(name)->dim()), -1 unknown */
+int aasr_feat_module_dim(const aasr_feat *h, const char *module_name);
+/* base-module frames of look-around one output frame needs (left, right):
+ * the sum of DeltaModule / MeanSubtractorModule offsets along the graph
+ * (aku/FeatureModules.cc:1014-1015, 1390-1400) */
+void aasr_feat_halo(const aasr_feat *h, int *left, int *right);
+
+/* AudioFileModule::last_frame (aku/FeatureModules.cc:305-308) for a file of
+ * n_samples; the whole-file frame count phone_probs emits is last_frame+1
+ * (aku/phone_probs.cc:217-221). */
+int aasr_feat_last_frame(const aasr_feat *h, int64_t n_samples);
+
+/* FeatureGenerator::generate(frame) for frames first_frame ..
+ * first_frame+n_frames-1 of one utterance whose complete PCM (mono int16,
+ * what AudioReader::fetch delivers, aku/AudioReader.cc:219-230) is pcm[0..
+ * n_samples).  Negative frames and frames past EOF follow copy_borders
+ * (aku/FeatureModules.cc:381-397).  out is float32 [n_frames x dim].
+ * module_name NULL = last module (the generator's output). */
+aasr_status aasr_feat_run(aasr_feat *h, const int16_t *pcm, int64_t n_samples,
+                          int32_t first_frame, int32_t n_frames,
+                          const char *module_name, float *out);
+aasr_status aasr_feat_run_dev(aasr_feat *h, const int16_t *d_pcm,
+                              int64_t n_samples, int32_t first_frame,
+                              int32_t n_frames, float *d_out, void *stream);
+/* double-precision output of the same frames (the reference's FeatureVec is
+ * double, aku/FeatureBuffer.hh:15-89); used by the adapters and parity tests */
+aasr_status aasr_feat_run_f64(aasr_feat *h, const int16_t *pcm,
+                              int64_t n_samples, int32_t first_frame,
+                              int32_t n_frames, const char *module_name,
+                              double *out);
+
+/* Batched form for a recipe slice: n_utts utterances concatenated in d_pcm;
+ * utterance u occupies samples [pcm_off[u], pcm_off[u+1]) and emits frames
+ * 0 .. last_frame(u) into d_out rows [frame_off[u], frame_off[u+1]).
+ * pcm_off/frame_off are HOST arrays of n_utts+1 entries. */
+aasr_status aasr_feat_run_batch_dev(aasr_feat *h, const int16_t *d_pcm,
+                                    const int64_t *pcm_off,
+                                    const int64_t *frame_off, int32_t n_utts,
+                                    float *d_out, void *stream);
+
+/* FeatureModule::set_parameters for "normalization" / "lin_transform"
+ * (aku/FeatureModules.cc:1094-1117, 1188-1196): params_text is a
+ * "{ key value ... }" block as in .spkc files. */
+aasr_status aasr_feat_set_parameters(aasr_feat *h, const char *module_name,
+                                     const char *params_text);
+
+/* ------------------------------------------------------------------------ */
+/* Acoustic model: replaces aku::HmmSet / PDFPool / Mixture scoring          */
+/* ------------------------------------------------------------------------ */
+
+/* In-memory construction.  mean/var are [G x dim] row-major doubles as
+ * DiagonalGaussian::read stores them (aku/Distributions.cc:1131-1150;
+ * var<=0 -> precision 0); mixtures in CSR form: state s owns components
+ * mix_off[s] .. mix_off[s+1]-1 with pool indices mix_idx[] (arbitrary, tied
+ * pools allowed) and weights mix_w[] (renormalised to sum 1 like
+ * Mixture::read, aku/Distributions.cc:2418-2434). */
+aasr_status aasr_gmm_create_diag(int32_t dim, int32_t num_gaussians,
+                                 const double *mean, const double *var,
+                                 int32_t num_states, const int32_t *mix_off,
+                                 const int32_t *mix_idx, const double *mix_w,
+                                 aasr_gmm **out);
+/* HmmSet::read_all(base) = read_mc + read_ph + read_gk
+ * (aku/HmmSet.cc:351-357); individual paths like phone_probs -g -m -p.
+ * ph_path may be NULL (state count = mixture count). */
+aasr_status aasr_gmm_create_from_files(const char *gk_path, const char *mc_path,
+                                       const char *ph_path, aasr_gmm **out);
+void aasr_gmm_destroy(aasr_gmm *h);
+
+int aasr_gmm_dim(const aasr_gmm *h);            /* HmmSet::dim()        */
+int aasr_gmm_num_states(const aasr_gmm *h);     /* HmmSet::num_states() */
+int aasr_gmm_num_gaussians(const aasr_gmm *h);  /* PDFPool::size()      */
+/* rows of the component-expanded layout the kernel streams (>= sum n_s) */
+int64_t aasr_gmm_expanded_rows(const aasr_gmm *h);
+
+/* Arithmetic used for the frame x Gaussian contraction. */
+enum { AASR_PREC_F32 = 0, AASR_PREC_F64 = 1 };
+aasr_status aasr_gmm_set_precision(aasr_gmm *h, int prec);
+
+/* HmmSet::precompute_likelihoods + state_likelihood for a block of frames
+ * (aku/HmmSet.cc:484-501, aku/HmmSet.hh:309): frames float32 [F x dim];
+ * state_loglik float32 [F x S] = log(max(sum_k w_k exp(ll_k), 1e-50)). */
+aasr_status aasr_gmm_score(aasr_gmm *h, const float *frames, int64_t F,
+                           float *state_loglik);
+aasr_status aasr_gmm_score_dev(aasr_gmm *h, const float *d_frames, int64_t F,
+                               float *d_state_loglik, void *stream);
+
+/* PDFPool::precompute_likelihoods (aku/Distributions.cc:2647-2682): the
+ * log-likelihood of every pool Gaussian, float32 [F x G]. */
+aasr_status aasr_gmm_gauss_loglik(aasr_gmm *h, const float *frames, int64_t F,
+                                  float *gauss_loglik);
+aasr_status aasr_gmm_gauss_loglik_dev(aasr_gmm *h, const float *d_frames,
+                                      int64_t F, float *d_gauss_loglik,
+                                      void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* LNA: replaces the frame loop tail of aku/phone_probs.cc:224-262           */
+/* ------------------------------------------------------------------------ */
+
+/* state_loglik float32 [F x S] (output of aasr_gmm_score) -> normalised
+ * float log-probabilities and LNA bytes.  Emulates the reference's float
+ * storage of linear likelihoods (values below FLT_TRUE_MIN flush to 0 ->
+ * log(1e-50); denormal quantisation), Z = sum over states (Z==0 or
+ * !normalize -> 1), safe_log, then 2-byte big-endian (int)(-1820*lp+.5)
+ * (0xFFFF below -36.008) or 4-byte little-endian float.
+ * bytes_out: [F x S x lnabytes] (may be NULL); lp_out: [F x S] (may be NULL) */
+aasr_status aasr_lna_encode(const float *state_loglik, int64_t F, int32_t S,
+                            int normalize, int lnabytes, float *lp_out,
+                            uint8_t *bytes_out);
+aasr_status aasr_lna_encode_dev(const float *d_state_loglik, int64_t F,
+                                int32_t S, int normalize, int lnabytes,
+                                float *d_lp_out, uint8_t *d_bytes_out,
+                                void *stream);
+/* 5-byte file header: big-endian uint32 S + 1 byte lnabytes
+ * (aku/phone_probs.cc:32-43, 213-214) */
+void aasr_lna_header(int32_t num_states, int lnabytes, uint8_t out[5]);
+
+/* ------------------------------------------------------------------------ */
+/* Recipe + whole-path driver: replaces the body of phone_probs main()       */
+/* ------------------------------------------------------------------------ */
+
+/* Recipe::read batch selection (aku/Recipe.cc:23-149): returns in
+ * first_line/num_lines the contiguous slice of the L non-empty,
+ * non-comment recipe lines that batch batch_index (1-based) of num_batches
+ * receives (cluster_speakers=false form). */
+aasr_status aasr_recipe_batch_range(int32_t num_lines_total, int32_t num_batches,
+                                    int32_t batch_index, int32_t *first_line,
+                                    int32_t *num_lines);
+
+typedef struct aasr_run_options {
+  int32_t lnabytes;        /* 2 or 4          (--lnabytes)          */
+  int32_t normalize;       /* 0 = -N / --no-normalization           */
+  int32_t num_batches;     /* -B (0/1 = no batching)                */
+  int32_t batch_index;     /* -I, 1-based                           */
+  int32_t no_overwrite;    /* -n: skip utterances whose LNA exists  */
+  int32_t raw_audio;       /* treat inputs as headerless PCM16      */
+  int32_t info;            /* -i verbosity                          */
+  const char *out_dir;     /* -o: directory for LNA files or NULL   */
+  const char *lna_suffix;  /* default ".lna" when recipe has no lna= */
+} aasr_run_options;
+
+typedef struct aasr_run_stats {
+  int64_t utterances;
+  int64_t frames;
+  double seconds_total;
+  double seconds_device;   /* feature + scoring + LNA kernels */
+} aasr_run_stats;
+
+/* phone_probs main loop (aku/phone_probs.cc:145-267) for one recipe slice on
+ * the current device: read audio, features, scoring, LNA files. */
+aasr_status aasr_run_recipe(aasr_feat *feat, aasr_gmm *gmm,
+                            const char *recipe_path,
+                            const aasr_run_options *opt, aasr_run_stats *stats);
+
+/* PPToolbox::generate_from_file_to_fd equivalent for one utterance
+ * (aku/PhoneProbsToolbox.cc:135-208: lnabytes 2, normalised): returns a
+ * malloc'ed LNA image (header + frames) the caller frees with aasr_free. */
+aasr_status aasr_run_utterance(aasr_feat *feat, aasr_gmm *gmm,
+                               const int16_t *pcm, int64_t n_samples,
+                               int32_t start_frame, int32_t end_frame,
+                               int normalize, int lnabytes, uint8_t **lna_out,
+                               int64_t *lna_len, int64_t *frames_out);
+void aasr_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AASR_H */

@@ -1,0 +1,138 @@
+"""GPU parity: aasr_gmm_score / aasr_gmm_gauss_loglik (HIP, through the C ABI)
+against the CPU oracle (oracle/aasr_oracle.c restating HmmSet.cc:484-501,
+Distributions.cc:1040-1062, 2078-2086).  Tolerance 1e-4 absolute on natural
+log-likelihoods (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from aaltoasr_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _check(capi, oracle, model, frames, tol=TOL):
+    mean, var, off, idx, w = model
+    ref = oracle.DiagModel(mean, var, off, idx, w).score(frames.astype(np.float64))
+    g = capi.Gmm.from_arrays(mean, var, off, idx, w)
+    got = g.score(frames)
+    assert got.shape == ref.shape
+    assert np.isfinite(got).all()
+    err = np.abs(got.astype(np.float64) - ref)
+    assert err.max() <= tol, "max |dll| %.3g at %s" % (err.max(), np.unravel_index(err.argmax(), err.shape))
+    g.close()
+    return err.max()
+
+
+@pytest.mark.parametrize("F", [1, 63, 64, 65, 255, 256, 257, 1000])
+def test_config1_shape_ragged_frames(capi, oracle, F):
+    """BASELINE config 1 model: D=39, G=256, S=32x8; ragged frame counts."""
+    model = synth.make_model(D=39, G=256, S=32, comps=8)
+    _check(capi, oracle, model, synth.make_frames(F))
+
+
+def test_sixteen_components_disjoint(capi, oracle):
+    """cfg-2 layout in miniature: 16 comps/state, continuous-density pool."""
+    model = synth.make_model(D=39, G=2048, S=128, comps=16)
+    _check(capi, oracle, model, synth.make_frames(300))
+
+
+def test_tied_pool(capi, oracle):
+    """Mixtures point at arbitrary (shared) pool Gaussians."""
+    model = synth.make_model(D=39, G=512, S=96, comps=16, tied=True)
+    _check(capi, oracle, model, synth.make_frames(200))
+
+
+def test_variable_components_and_long_states(capi, oracle):
+    """n_s from 1 to 150: segments span 32-row chunks and 64-row tiles."""
+    model = synth.make_model(D=39, G=8192, S=64, comps_range=(1, 150), seed=5, tied=True)
+    _check(capi, oracle, model, synth.make_frames(130))
+
+
+@pytest.mark.parametrize("D", [1, 7, 8, 13, 25, 26, 39, 40, 47, 63])
+def test_dimensions(capi, oracle, D):
+    model = synth.make_model(D=D, G=96, S=12, comps=8, seed=D)
+    _check(capi, oracle, model, synth.make_frames(70, D=D, seed=100 + D))
+
+
+def test_empty_state_and_zero_weight(capi, oracle):
+    mean, var, off, idx, w = synth.make_model(D=13, G=64, S=8, comps=8, seed=3)
+    # state 2 loses all components; one component of state 5 gets weight 0
+    n = np.diff(off)
+    n[2] = 0
+    keep = np.ones(len(idx), bool)
+    keep[off[2]:off[3]] = False
+    idx, w = idx[keep], w[keep]
+    off = np.concatenate([[0], np.cumsum(n)]).astype(np.int32)
+    w[off[5]] = 0.0
+    model = (mean, var, off, idx, w)
+    frames = synth.make_frames(40, D=13)
+    _check(capi, oracle, model, frames)
+    g = capi.Gmm.from_arrays(*model)
+    got = g.score(frames)
+    assert np.allclose(got[:, 2], np.log(1e-50), atol=1e-5)
+
+
+def test_floor_and_far_frames(capi, oracle):
+    """Frames far from every Gaussian: state likelihood < 1e-50 clamps to
+    log(1e-50) (HmmSet.cc:497-498); mid-range values stay within tolerance."""
+    model = synth.make_model(D=39, G=256, S=32, comps=8)
+    fr = synth.make_frames(64)
+    fr[:16] *= 3.0
+    fr[16:32] *= 6.0
+    fr[32:48] += 4.0
+    _check(capi, oracle, model, fr, tol=2e-4)
+
+
+def test_zero_variance_dimension(capi, oracle):
+    """var <= 0 -> precision 0 -> 'invalid' Gaussian with constant 0
+    (Distributions.cc:1144-1147, 1276-1287)."""
+    mean, var, off, idx, w = synth.make_model(D=8, G=32, S=4, comps=8, seed=9)
+    var[3, 2] = 0.0
+    var[7, :] = -1.0
+    _check(capi, oracle, (mean, var, off, idx, w), synth.make_frames(50, D=8))
+
+
+def test_gauss_loglik_pool_view(capi, oracle):
+    mean, var, off, idx, w = synth.make_model(D=39, G=200, S=25, comps=8)
+    frames = synth.make_frames(90)
+    ref = oracle.DiagModel(mean, var, off, idx, w).gauss_loglik(frames.astype(np.float64))
+    g = capi.Gmm.from_arrays(mean, var, off, idx, w)
+    got = g.gauss_loglik(frames)
+    assert np.abs(got - ref).max() <= TOL
+
+
+def test_model_files_roundtrip(capi, oracle, tmp_path):
+    mean, var, off, idx, w = synth.make_model(D=13, G=64, S=8, comps=8, seed=11)
+    base = str(tmp_path / "m")
+    oracle.write_gk(base + ".gk", mean, var)
+    oracle.write_mc(base + ".mc", off, idx, w)
+    oracle.write_ph(base + ".ph", 8)
+    g = capi.Gmm.from_files(base + ".gk", base + ".mc", base + ".ph")
+    assert (g.dim, g.num_states, g.num_gaussians) == (13, 8, 64)
+    frames = synth.make_frames(33, D=13)
+    ref = oracle.read_model(base).score(frames.astype(np.float64))
+    assert np.abs(g.score(frames) - ref).max() <= TOL
+
+
+def test_block_partition_invariance(capi):
+    """Scoring is per-frame: any split of the frame block gives identical bits."""
+    model = synth.make_model(D=39, G=256, S=32, comps=8)
+    g = capi.Gmm.from_arrays(*model)
+    fr = synth.make_frames(700)
+    whole = g.score(fr)
+    parts = np.vstack([g.score(fr[:1]), g.score(fr[1:300]), g.score(fr[300:])])
+    assert np.array_equal(whole.view(np.uint32), parts.view(np.uint32))
+
+
+def test_device_pointer_entry(capi, oracle):
+    import torch
+    model = synth.make_model(D=39, G=256, S=32, comps=8)
+    g = capi.Gmm.from_arrays(*model)
+    fr = synth.make_frames(513)
+    d_fr = torch.from_numpy(fr).cuda()
+    d_out = torch.empty((513, 32), dtype=torch.float32, device="cuda")
+    g.score_dev(d_fr, d_out)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint32), g.score(fr).view(np.uint32))

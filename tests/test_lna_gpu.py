@@ -1,0 +1,69 @@
+"""GPU parity of aasr_lna_encode against the oracle's restatement of
+phone_probs.cc:224-262 (float storage, normalisation, 2/4-byte packing)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LOG_TINY = np.log(1e-50)
+
+
+def _ref(oracle, ll64, normalize, nbytes):
+    lik = np.maximum(np.exp(ll64), 1e-50)
+    return oracle.lna_encode(lik, normalize, nbytes)
+
+
+def _band_ok(ll):
+    # outside the float-denormal band the float cast of exp(ll) is smooth
+    return (ll > -87.0) | (ll < -104.5)
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+@pytest.mark.parametrize("nbytes", [2, 4])
+def test_lna_matches_oracle(capi, oracle, normalize, nbytes):
+    rng = np.random.default_rng(7)
+    F, S = 64, 257
+    ll = rng.uniform(-80.0, -20.0, (F, S))
+    ll[5] = rng.uniform(-115.0, -85.0, S)       # denormal band / flush to zero
+    ll[6] = LOG_TINY                              # every state at the floor -> Z == 0
+    ll[7, :] = -30.0
+    ll[8] = rng.uniform(-10.0, 5.0, S)           # likelihoods > 1
+    ll = np.maximum(ll, LOG_TINY).astype(np.float32)
+    lp_ref, by_ref = _ref(oracle, ll.astype(np.float64), normalize, nbytes)
+    lp, by = capi.lna_encode(ll, normalize, nbytes)
+    ok = _band_ok(ll)
+    assert np.abs(lp - lp_ref)[ok].max() <= 1e-5
+    # inside the band the quantum index may differ by one step at a rounding tie
+    q = np.abs(lp - lp_ref)[~ok]
+    assert (q <= 1e-5).mean() > 0.95
+    if nbytes == 4:
+        assert np.array_equal(by.view(np.float32), lp)
+    else:
+        code = by.reshape(F, S, 2).astype(np.int32)
+        code = code[..., 0] * 256 + code[..., 1]
+        cref = by_ref.reshape(F, S, 2).astype(np.int32)
+        cref = cref[..., 0] * 256 + cref[..., 1]
+        d = np.abs(code - cref)[ok]
+        assert d.max() <= 1                      # |dlp| 1e-5 * 1820 << 1 code
+        assert (d == 0).mean() > 0.97
+    assert np.allclose(lp[6], LOG_TINY, atol=1e-5)
+
+
+def test_lna_bytes_follow_own_lp(capi):
+    """Given the float lp the engine emits, the 2-byte code must be exactly
+    (int)(-1820*lp+.5) big-endian, 0xFFFF below -36.008."""
+    rng = np.random.default_rng(8)
+    ll = rng.uniform(-60.0, -20.0, (32, 100)).astype(np.float32)
+    lp, by = capi.lna_encode(ll, True, 2)
+    code = by.reshape(32, 100, 2).astype(np.int64)
+    code = code[..., 0] * 256 + code[..., 1]
+    exp = np.where(lp.astype(np.float64) < -36.008, 0xFFFF,
+                   (-1820.0 * lp.astype(np.float64) + .5).astype(np.int64) & 0xFFFF)
+    assert np.array_equal(code, exp)
+
+
+def test_lna_normalised_rows_sum_to_one(capi):
+    rng = np.random.default_rng(9)
+    ll = rng.uniform(-70.0, -30.0, (16, 3125)).astype(np.float32)
+    lp, _ = capi.lna_encode(ll, True, 4)
+    assert np.allclose(np.exp(lp.astype(np.float64)).sum(1), 1.0, atol=1e-5)
