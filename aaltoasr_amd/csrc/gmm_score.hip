@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 
 #include "gmm.h"
 
@@ -45,14 +46,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // (aku/HmmSet.cc:497-498, aku/util.hh:131)
 #define LOG_TINY_F (-115.12925464970228f)
 #define NEG_BIG_F (-3.0e38f)
+// finished state log-likelihoods are buffered per wave and written OUT_GROUP
+// consecutive states at a time: 32 contiguous bytes per frame row
+constexpr int OUT_GROUP = 8;
 
 template <int NKK>
 struct ScoreSmem {
   // [2 buffers][NKK/2][64 lanes][4] floats
   static constexpr int kTileFloats = (NKK / 2) * 64 * 4;
   static constexpr int kStageFloatsPerWave = CHUNK_ROWS * FRAMES_PER_WAVE;
+  // per-wave output transposition buffer: OUT_GROUP finished states x 64 frames
+  static constexpr int kOutFloatsPerWave = OUT_GROUP * FRAMES_PER_WAVE;
   static constexpr int kBytes =
-      (2 * kTileFloats + WAVES_PER_BLOCK * kStageFloatsPerWave) * 4;
+      (2 * kTileFloats + WAVES_PER_BLOCK * (kStageFloatsPerWave + kOutFloatsPerWave)) * 4;
 };
 
 __device__ __forceinline__ void issue_tile_copy(const float *__restrict__ gtile,
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score(
     const float *__restrict__ pivot, const float *__restrict__ apack,
     int64_t tiles, const int32_t *__restrict__ chunk_seg_begin,
     const uint32_t *__restrict__ seg_desc, const int32_t *__restrict__ seg_out,
-    float *__restrict__ out, int64_t out_cols, int64_t rows) {
+    float *__restrict__ out, int64_t out_cols, int64_t rows, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float *smem = (float *)smem_raw;
   constexpr int kTileFloats = ScoreSmem<NKK>::kTileFloats;
@@ -127,21 +133,22 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score(
     const float *xr = frames + f * dim;
 #pragma unroll
     for (int kk = 0; kk < NKK; kk++) {
-      float v = 0.0f;
-      if (kk < dim) {
-        float xc = xr[kk] - pivot[kk];
-        v = h ? xc * xc : xc;
-      } else if (kk == dim) {
-        v = h ? 0.0f : 1.0f;
-      }
+      const int kc = kk < dim ? kk : 0;
+      const float xc = xr[kc] - pivot[kc];
+      float v = h ? xc * xc : xc;
+      if (kk == dim) v = h ? 0.0f : 1.0f;
+      if (kk > dim) v = 0.0f;
       bf[kk][nb] = v;
     }
   }
 
   float carry_m = NEG_BIG_F, carry_s = 0.0f;
+  float *ost = smem + 2 * kTileFloats + WAVES_PER_BLOCK * ScoreSmem<NKK>::kStageFloatsPerWave +
+               wave * ScoreSmem<NKK>::kOutFloatsPerWave;
+  int n_closed = 0;  // states finished so far == index of the next state (MODE 0)
 
   // prologue: tile 0 -> buffer 0
-  if (tiles > 0) issue_tile_copy(apack, abuf0, kTileFloats, wave, lane);
+  issue_tile_copy(apack, abuf0, kTileFloats, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -151,14 +158,21 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score(
   for (int64_t t = 0; t < tiles; t++) {
     float *acur = (t & 1) ? abuf1 : abuf0;
     float *anext = (t & 1) ? abuf0 : abuf1;
+    // Buffer `anext` was last read by the MFMA loop of tile t-1; every wave is
+    // past the barrier that followed that loop, so it can be refilled now.
     if (t + 1 < tiles)
       issue_tile_copy(apack + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
 
     f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
-    const f32x4 *afrag = (const f32x4 *)acur;
+    const f32x4 *afrag = (const f32x4 *)acur + lane;
+    // A fragments are fetched two kk-pairs ahead of their MFMAs
+    f32x4 a0 = afrag[0];
+    f32x4 a1 = afrag[(NKK / 2 > 1 ? 1 : 0) * 64];
 #pragma unroll
     for (int q = 0; q < NKK / 2; q++) {
-      f32x4 av = afrag[q * 64 + lane];  // {mb0 kk0, mb0 kk1, mb1 kk0, mb1 kk1}
+      const int qn = (q + 2 < NKK / 2) ? q + 2 : NKK / 2 - 1;
+      f32x4 a2 = afrag[qn * 64];
+      const f32x4 av = a0;  // {mb0 kk0, mb0 kk1, mb1 kk0, mb1 kk1}
       c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf[2 * q][0], c00, 0, 0, 0);
       c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf[2 * q][1], c01, 0, 0, 0);
       c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf[2 * q][0], c10, 0, 0, 0);
@@ -167,8 +181,23 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score(
       c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf[2 * q + 1][1], c01, 0, 0, 0);
       c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf[2 * q + 1][0], c10, 0, 0, 0);
       c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf[2 * q + 1][1], c11, 0, 0, 0);
+      a0 = a1;
+      a1 = a2;
     }
 
+    // One barrier per tile, here: (a) every wave has finished reading `acur`,
+    // (b) every wave's share of tile t+1 has landed (the global_load_lds were
+    // issued before this tile's MFMAs; the only other outstanding vector-memory
+    // ops are the previous tile's output stores, long retired).  The epilogue
+    // below then runs without any inter-wave synchronisation and its stores
+    // stay in flight across the next MFMA phase.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    if (dbg & 1) {  // ablation: MFMA only (keep the accumulators live)
+      asm volatile("" ::"v"(c00), "v"(c01), "v"(c10), "v"(c11));
+      continue;
+    }
     // ---- epilogue, one 32-row chunk at a time
 #pragma unroll
     for (int mb = 0; mb < 2; mb++) {
@@ -181,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score(
         stage[row * FRAMES_PER_WAVE + n] = ca[i];
         stage[row * FRAMES_PER_WAVE + 32 + n] = cb[i];
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       const float *col = stage + lane;
       const int64_t chunk = t * 2 + mb;
@@ -198,11 +227,29 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score(
           if (open) {
             carry_m = m;
             carry_s = s;
-          } else if (frame_ok) {
+          } else {
             float lg = __builtin_amdgcn_logf(s);  // log2
             float ll = fmaf(m, LN2_F, lg * LN2_F);
             ll = fmaxf(ll, LOG_TINY_F);
-            out[my_frame * out_cols + seg_out[si]] = ll;
+            // states close in index order: buffer [frame][k], k = n_closed % 8
+            const int k = n_closed & (OUT_GROUP - 1);
+            ost[lane * OUT_GROUP + k] = ll;
+            n_closed++;
+            if ((n_closed & (OUT_GROUP - 1)) == 0 || n_closed == (int)out_cols) {
+              const int cnt = ((n_closed - 1) & (OUT_GROUP - 1)) + 1;
+              const int s_base = n_closed - cnt;
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              const int kk2 = lane & (OUT_GROUP - 1);
+#pragma unroll
+              for (int i = 0; i < FRAMES_PER_WAVE / (64 / OUT_GROUP); i++) {
+                const int j = i * (64 / OUT_GROUP) + (lane / OUT_GROUP);
+                const float v = ost[j * OUT_GROUP + kk2];
+                if (kk2 < cnt && f0 + j < F) out[(f0 + j) * out_cols + s_base + kk2] = v;
+              }
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+            }
           }
         }
       } else {
@@ -214,12 +261,9 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score(
           }
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
   }
 }
 
@@ -228,7 +272,9 @@ static void launch_t(const aasr_gmm *g, const PackedRows &pr, const float *d_fra
                      int64_t F, float *d_out, int64_t out_cols, hipStream_t stream) {
   if (F <= 0) return;
   const int64_t blocks = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
-  constexpr int smem = ScoreSmem<NKK>::kBytes;
+  int smem = ScoreSmem<NKK>::kBytes;
+  static const int dbg = getenv("AASR_DBG") ? atoi(getenv("AASR_DBG")) : 0;
+  if (dbg & 2) smem = 100 * 1024;  // ablation: one workgroup per CU
   static bool attr_set[64] = {false};
   auto kern = k_gmm_diag_score<NKK, MODE>;
   if (!attr_set[g->device & 63]) {
@@ -238,7 +284,7 @@ static void launch_t(const aasr_gmm *g, const PackedRows &pr, const float *d_fra
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, pr.a.p, pr.tiles, pr.chunk_seg_begin.p,
-                     pr.seg_desc.p, pr.seg_out.p, d_out, out_cols, pr.rows);
+                     pr.seg_desc.p, pr.seg_out.p, d_out, out_cols, pr.rows, dbg);
   AASR_HIP(hipGetLastError());
 }
 
@@ -257,6 +303,19 @@ static void launch(const aasr_gmm *g, const PackedRows &pr, const float *d_frame
       break;
   }
   raise(AASR_ERR_UNSUPPORTED, "no kernel instance for K/2 = %d", pr.nkk);
+}
+
+// Diagnostic (not part of the public ABI): resident workgroups per CU the
+// runtime predicts for the NKK=40 scoring kernel.
+extern "C" int aasr_debug_score_occupancy(void) {
+  int nb = -1;
+  auto kern = k_gmm_diag_score<40, 0>;
+  (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            ScoreSmem<40>::kBytes);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, 256,
+                                                   ScoreSmem<40>::kBytes) != hipSuccess)
+    return -1;
+  return nb;
 }
 
 void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
