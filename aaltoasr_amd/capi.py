@@ -35,7 +35,7 @@ class AasrError(RuntimeError):
 class RunOptions(C.Structure):
     _fields_ = [("lnabytes", C.c_int32), ("normalize", C.c_int32), ("num_batches", C.c_int32),
                 ("batch_index", C.c_int32), ("no_overwrite", C.c_int32), ("raw_audio", C.c_int32),
-                ("info", C.c_int32), ("out_dir", C.c_char_p), ("lna_suffix", C.c_char_p)]
+                ("info", C.c_int32), ("afname", C.c_int32), ("out_dir", C.c_char_p)]
 
 
 class RunStats(C.Structure):
@@ -240,3 +240,104 @@ def lna_header(num_states: int, lnabytes: int) -> bytes:
     buf = (C.c_uint8 * 5)()
     lib().aasr_lna_header(num_states, lnabytes, buf)
     return bytes(buf)
+
+
+class Feat:
+    """Owner of an aasr_feat handle (FeatureGenerator surface)."""
+
+    def __init__(self, cfg_text: str):
+        h = C.c_void_p()
+        check(lib().aasr_feat_create(cfg_text.encode(), C.byref(h)))
+        self._h = h.value
+
+    @classmethod
+    def from_file(cls, path: str) -> "Feat":
+        return cls(open(path).read())
+
+    def close(self) -> None:
+        if self._h:
+            lib().aasr_feat_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def dim(self) -> int:
+        return lib().aasr_feat_dim(self._h)
+
+    @property
+    def frame_rate(self) -> float:
+        return lib().aasr_feat_frame_rate(self._h)
+
+    @property
+    def sample_rate(self) -> int:
+        return lib().aasr_feat_sample_rate(self._h)
+
+    def module_dim(self, name: str) -> int:
+        return lib().aasr_feat_module_dim(self._h, name.encode())
+
+    def halo(self):
+        l, r = C.c_int(), C.c_int()
+        lib().aasr_feat_halo(self._h, C.byref(l), C.byref(r))
+        return l.value, r.value
+
+    def last_frame(self, n_samples: int) -> int:
+        return lib().aasr_feat_last_frame(self._h, n_samples)
+
+    def run(self, pcm: np.ndarray, first_frame: int, n_frames: int, module: Optional[str] = None,
+            dtype=np.float32) -> np.ndarray:
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        dim = self.module_dim(module) if module else self.dim
+        if dim < 0:
+            raise AasrError(AASR_ERR_INVALID, "unknown module requested: %s" % module)
+        out = np.empty((n_frames, dim), dtype)
+        fn = lib().aasr_feat_run if dtype == np.float32 else lib().aasr_feat_run_f64
+        check(fn(self._h, _ptr(pcm), len(pcm), first_frame, n_frames,
+                 module.encode() if module else None, _ptr(out)))
+        return out
+
+    def run_batch_dev(self, d_pcm, pcm_off: np.ndarray, frame_off: np.ndarray, d_out, stream=None):
+        pcm_off = np.ascontiguousarray(pcm_off, np.int64)
+        frame_off = np.ascontiguousarray(frame_off, np.int64)
+        check(lib().aasr_feat_run_batch_dev(self._h, _ptr(d_pcm), _ptr(pcm_off), _ptr(frame_off),
+                                            len(pcm_off) - 1, _ptr(d_out), _stream_handle(stream)))
+
+    def set_parameters(self, module: str, block_text: str) -> None:
+        check(lib().aasr_feat_set_parameters(self._h, module.encode(), block_text.encode()))
+
+
+def recipe_batch_range(total: int, num_batches: int, batch_index: int):
+    f, n = C.c_int32(), C.c_int32()
+    check(lib().aasr_recipe_batch_range(total, num_batches, batch_index, C.byref(f), C.byref(n)))
+    return f.value, n.value
+
+
+def run_utterance(feat: Feat, gmm: Gmm, pcm: np.ndarray, start_frame: int = 0, end_frame: int = 0,
+                  normalize: bool = True, lnabytes: int = 2):
+    """Returns (lna file image as bytes, number of frames)."""
+    pcm = np.ascontiguousarray(pcm, np.int16)
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_int64()
+    frames = C.c_int64()
+    check(lib().aasr_run_utterance(feat._h, gmm._h, _ptr(pcm), len(pcm), start_frame, end_frame,
+                                   int(normalize), lnabytes, C.byref(out), C.byref(n), C.byref(frames)))
+    try:
+        data = C.string_at(out, n.value)
+    finally:
+        lib().aasr_free(out)
+    return data, frames.value
+
+
+def run_recipe(feat: Feat, gmm: Gmm, recipe_path: str, lnabytes: int = 2, normalize: bool = True,
+               num_batches: int = 0, batch_index: int = 0, no_overwrite: bool = False,
+               raw_audio: bool = False, info: int = 0, afname: bool = False,
+               out_dir: Optional[str] = None) -> RunStats:
+    opt = RunOptions(lnabytes, int(normalize), num_batches, batch_index, int(no_overwrite),
+                     int(raw_audio), info, int(afname), out_dir.encode() if out_dir else None)
+    st = RunStats()
+    check(lib().aasr_run_recipe(feat._h, gmm._h, recipe_path.encode(), C.byref(opt), C.byref(st)))
+    return st

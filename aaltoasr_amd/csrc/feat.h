@@ -1,3 +1,127 @@
-// feat.h -- compiled feature graph (aasr_feat); see feat_graph.cc.
+// feat.h -- compiled feature graph (aasr_feat): host-side mirror of
+// aku::FeatureGenerator's module DAG plus the device plan that evaluates it.
+//
+// The reference evaluates the graph one frame at a time through per-module
+// ring buffers (FeatureModule::at, aku/FeatureModules.cc:102-158).  Every
+// module's output at frame t is a pure function of t, so here each module is
+// evaluated ONCE over the frame range its consumers need (output frames plus
+// the accumulated Delta / MeanSubtractor look-around, "halo"), for a whole
+// batch of utterances per launch.
 #pragma once
+#include <map>
+#include <string>
+#include <vector>
+
 #include "common.h"
+
+namespace aasr {
+
+enum ModType {
+  MOD_AUDIOFILE, MOD_FFT, MOD_MEL, MOD_POWER, MOD_DCT, MOD_DELTA,
+  MOD_NORMALIZATION, MOD_LIN_TRANSFORM, MOD_MERGE, MOD_MEAN_SUBTRACTOR
+};
+
+// One "{ key value ... }" block (aku::ModuleConfig, aku/ModuleConfig.cc).
+struct ModuleConfig {
+  std::vector<std::string> names, values;
+  std::map<std::string, int> index;
+  bool exists(const std::string &k) const { return index.count(k) != 0; }
+  bool get(const std::string &k, std::string &v) const;
+  bool get(const std::string &k, int &v) const;
+  bool get(const std::string &k, float &v) const;
+  bool get(const std::string &k, std::vector<float> &v) const;
+  bool get(const std::string &k, std::vector<std::string> &v) const;
+  // parses one block from `text` starting at *pos (just after the "module"
+  // line); advances *pos past the closing brace
+  void read(const std::string &text, size_t *pos);
+};
+
+struct FftPlan {
+  int nc = 0;  // complex length = window/2
+  int ns = 0;
+  int radix[16], sublen[16];
+  DevBuf<float> hamming;   // [window]
+  DevBuf<float> twiddle;   // [nc][2]
+  DevBuf<float> stwiddle;  // [nc/2][2]
+  DevBuf<int32_t> perm;    // [nc] digit-reversed source index
+};
+
+struct FeatModule {
+  std::string name, type_str;
+  ModType type;
+  std::vector<int> sources;
+  int dim = 0;
+  // audiofile
+  int sample_rate = 0, width = 0, copy_borders = 1;
+  float emph = 0.97f, frame_rate = 125.0f, advance = 0.0f;
+  // fft
+  int magnitude = 1, take_log = 0;
+  FftPlan fft;
+  // mel
+  int root = 0;
+  DevBuf<int32_t> mel_off, mel_t;   // CSR over bins: source index t per term
+  DevBuf<float> mel_scale, mel_sum;  // per term scale, per bin float sum
+  // dct
+  int zeroth = 0;
+  DevBuf<float> dct_cos;  // [dim-bias][src_dim]
+  // delta
+  int delta_width = 2;
+  float delta_norm = 10.0f;
+  // normalization
+  std::vector<float> mean, scale;
+  DevBuf<float> d_mean, d_scale;
+  // lin_transform
+  int src_dim = 0;
+  std::vector<float> matrix, bias;
+  bool matrix_defined = false, bias_defined = false;
+  DevBuf<float> d_matrix, d_bias;
+  // merge
+  DevBuf<int32_t> merge_src_col;  // per output column: source slot, column
+  // mean_subtractor (config values; the reference stores left+1 / right+1)
+  int cms_left = 75, cms_right = 75;
+  // look-around this module itself adds around its sources
+  int own_left = 0, own_right = 0;
+};
+
+}  // namespace aasr
+
+struct aasr_feat {
+  int device = 0;
+  std::vector<aasr::FeatModule> mods;
+  std::map<std::string, int> by_name;
+  // scratch, grown on demand
+  std::vector<aasr::DevBuf<double>> bufs;  // one per module
+  aasr::DevBuf<int64_t> d_frame_off, d_pcm_off, d_nsamp;
+  aasr::DevBuf<int32_t> d_first, d_eof;
+  aasr::DevBuf<int16_t> d_pcm;
+  aasr::DevBuf<float> d_out_f32;
+  aasr::DevBuf<double> d_out_f64;
+  void *stage_host = nullptr;   // pinned descriptor staging
+  size_t stage_cap = 0;
+  hipEvent_t stage_event = nullptr;
+  bool stage_busy = false;
+  ~aasr_feat() {
+    if (stage_host) (void)hipHostFree(stage_host);
+    if (stage_event) (void)hipEventDestroy(stage_event);
+  }
+};
+
+namespace aasr {
+
+struct UttBatch {
+  int32_t n_utts = 0;
+  std::vector<int64_t> frame_off;  // [n+1] prefix of frames emitted
+  std::vector<int64_t> pcm_off;    // [n+1] sample offsets in d_pcm
+  std::vector<int32_t> first;      // [n] first emitted frame
+};
+
+aasr_feat *feat_create(const std::string &cfg_text);
+int feat_last_frame(const aasr_feat *h, int64_t n_samples);
+void feat_halo(const aasr_feat *h, int target, int *left, int *right);
+// Evaluates module `target` for the batch; exactly one of out_f32 / out_f64
+// (device pointers, [total_frames x dim]) is written.
+void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &b, int target,
+                    float *out_f32, double *out_f64, hipStream_t stream);
+void feat_set_parameters(aasr_feat *h, const std::string &module, const std::string &block);
+
+}  // namespace aasr

@@ -1,0 +1,140 @@
+// feat_capi.cc -- extern "C" entry points of the feature chain (include/aasr.h).
+#include <cstring>
+
+#include "feat.h"
+
+using namespace aasr;
+
+namespace {
+
+int resolve_target(const aasr_feat *h, const char *module_name) {
+  if (!module_name || !*module_name) return (int)h->mods.size() - 1;
+  auto it = h->by_name.find(module_name);
+  if (it == h->by_name.end())
+    raise(AASR_ERR_INVALID, "unknown module requested: %s", module_name);
+  return it->second;
+}
+
+UttBatch single(int64_t n_samples, int32_t first_frame, int32_t n_frames) {
+  UttBatch b;
+  b.n_utts = 1;
+  b.frame_off = {0, n_frames};
+  b.pcm_off = {0, n_samples};
+  b.first = {first_frame};
+  return b;
+}
+
+template <class T>
+void run_host(aasr_feat *h, const int16_t *pcm, int64_t n_samples, int32_t first_frame,
+              int32_t n_frames, const char *module_name, T *out) {
+  if (!h || !pcm || (n_frames > 0 && !out)) raise(AASR_ERR_INVALID, "aasr_feat_run: null argument");
+  if (n_frames < 0 || n_samples < 0) raise(AASR_ERR_INVALID, "aasr_feat_run: negative size");
+  if (n_frames == 0) return;
+  const int target = resolve_target(h, module_name);
+  const int dim = h->mods[target].dim;
+  h->d_pcm.ensure((size_t)n_samples);
+  AASR_HIP(hipMemcpy(h->d_pcm.p, pcm, (size_t)n_samples * sizeof(int16_t), hipMemcpyHostToDevice));
+  UttBatch b = single(n_samples, first_frame, n_frames);
+  const size_t n = (size_t)n_frames * dim;
+  if (sizeof(T) == 4) {
+    h->d_out_f32.ensure(n);
+    feat_run_batch(h, h->d_pcm.p, b, target, h->d_out_f32.p, nullptr, nullptr);
+    AASR_HIP(hipMemcpy(out, h->d_out_f32.p, n * 4, hipMemcpyDeviceToHost));
+  } else {
+    h->d_out_f64.ensure(n);
+    feat_run_batch(h, h->d_pcm.p, b, target, nullptr, h->d_out_f64.p, nullptr);
+    AASR_HIP(hipMemcpy(out, h->d_out_f64.p, n * 8, hipMemcpyDeviceToHost));
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+aasr_status aasr_feat_create(const char *cfg_text, aasr_feat **out) {
+  return guarded([&] {
+    if (!cfg_text || !out) raise(AASR_ERR_INVALID, "aasr_feat_create: null argument");
+    *out = nullptr;
+    *out = feat_create(cfg_text);
+  });
+}
+
+void aasr_feat_destroy(aasr_feat *h) { delete h; }
+int aasr_feat_dim(const aasr_feat *h) { return h ? h->mods.back().dim : -1; }
+float aasr_feat_frame_rate(const aasr_feat *h) { return h ? h->mods[0].frame_rate : 0.0f; }
+int aasr_feat_sample_rate(const aasr_feat *h) { return h ? h->mods[0].sample_rate : -1; }
+
+int aasr_feat_module_dim(const aasr_feat *h, const char *module_name) {
+  if (!h || !module_name) return -1;
+  auto it = h->by_name.find(module_name);
+  return it == h->by_name.end() ? -1 : h->mods[it->second].dim;
+}
+
+void aasr_feat_halo(const aasr_feat *h, int *left, int *right) {
+  int l = 0, r = 0;
+  if (h) feat_halo(h, (int)h->mods.size() - 1, &l, &r);
+  if (left) *left = l;
+  if (right) *right = r;
+}
+
+int aasr_feat_last_frame(const aasr_feat *h, int64_t n_samples) {
+  return h ? feat_last_frame(h, n_samples) : -1;
+}
+
+aasr_status aasr_feat_run(aasr_feat *h, const int16_t *pcm, int64_t n_samples,
+                          int32_t first_frame, int32_t n_frames, const char *module_name,
+                          float *out) {
+  return guarded([&] { run_host<float>(h, pcm, n_samples, first_frame, n_frames, module_name, out); });
+}
+
+aasr_status aasr_feat_run_f64(aasr_feat *h, const int16_t *pcm, int64_t n_samples,
+                              int32_t first_frame, int32_t n_frames, const char *module_name,
+                              double *out) {
+  return guarded([&] { run_host<double>(h, pcm, n_samples, first_frame, n_frames, module_name, out); });
+}
+
+aasr_status aasr_feat_run_dev(aasr_feat *h, const int16_t *d_pcm, int64_t n_samples,
+                              int32_t first_frame, int32_t n_frames, float *d_out, void *stream) {
+  return guarded([&] {
+    if (!h || !d_pcm || (n_frames > 0 && !d_out))
+      raise(AASR_ERR_INVALID, "aasr_feat_run_dev: null argument");
+    if (n_frames <= 0) return;
+    UttBatch b = single(n_samples, first_frame, n_frames);
+    feat_run_batch(h, d_pcm, b, (int)h->mods.size() - 1, d_out, nullptr, (hipStream_t)stream);
+  });
+}
+
+aasr_status aasr_feat_run_batch_dev(aasr_feat *h, const int16_t *d_pcm, const int64_t *pcm_off,
+                                    const int64_t *frame_off, int32_t n_utts, float *d_out,
+                                    void *stream) {
+  return guarded([&] {
+    if (!h || !d_pcm || !pcm_off || !frame_off || !d_out)
+      raise(AASR_ERR_INVALID, "aasr_feat_run_batch_dev: null argument");
+    if (n_utts <= 0) return;
+    UttBatch b;
+    b.n_utts = n_utts;
+    b.frame_off.assign(frame_off, frame_off + n_utts + 1);
+    b.pcm_off.assign(pcm_off, pcm_off + n_utts + 1);
+    b.first.assign((size_t)n_utts, 0);
+    for (int u = 0; u < n_utts; u++) {
+      int64_t ns = pcm_off[u + 1] - pcm_off[u];
+      int64_t nf = frame_off[u + 1] - frame_off[u];
+      if (nf != (int64_t)feat_last_frame(h, ns) + 1)
+        raise(AASR_ERR_INVALID,
+              "utterance %d: frame_off says %ld frames but %ld samples give last_frame()+1 = %d",
+              u, (long)nf, (long)ns, feat_last_frame(h, ns) + 1);
+    }
+    feat_run_batch(h, d_pcm, b, (int)h->mods.size() - 1, d_out, nullptr, (hipStream_t)stream);
+  });
+}
+
+aasr_status aasr_feat_set_parameters(aasr_feat *h, const char *module_name,
+                                     const char *params_text) {
+  return guarded([&] {
+    if (!h || !module_name || !params_text)
+      raise(AASR_ERR_INVALID, "aasr_feat_set_parameters: null argument");
+    feat_set_parameters(h, module_name, params_text);
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,550 @@
+// feat_graph.cc -- parses an aku feature configuration and builds the device
+// tables of each module.
+//
+// Reference behaviour restated here (paths relative to the AaltoASR tree):
+//   ModuleConfig::read / get           aku/ModuleConfig.cc:15-202
+//   FeatureGenerator::load_configuration  aku/FeatureGenerator.cc:96-219
+//   *Module::set_module_config         aku/FeatureModules.cc (cited per module)
+// Tables that the reference derives with libm float functions (Hamming window,
+// mel edges, DCT cosines, KissFFT twiddles) are computed HERE on the host with
+// the same expressions, so the device never evaluates cosf/log10f/pow itself.
+#include <climits>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "feat.h"
+
+namespace aasr {
+
+// ------------------------------------------------------------ ModuleConfig --
+
+static std::string clean(const std::string &s, const char *chars) {
+  size_t a = s.find_first_not_of(chars);
+  if (a == std::string::npos) return "";
+  size_t b = s.find_last_not_of(chars);
+  return s.substr(a, b - a + 1);
+}
+
+static std::vector<std::string> split_ws(const std::string &s) {
+  std::vector<std::string> out;
+  size_t i = 0;
+  while (i < s.size()) {
+    while (i < s.size() && (s[i] == ' ' || s[i] == '\t')) i++;
+    size_t j = i;
+    while (j < s.size() && s[j] != ' ' && s[j] != '\t') j++;
+    if (j > i) out.push_back(s.substr(i, j - i));
+    i = j;
+  }
+  return out;
+}
+
+static bool next_line(const std::string &text, size_t *pos, std::string *line) {
+  if (*pos >= text.size()) return false;
+  size_t e = text.find('\n', *pos);
+  if (e == std::string::npos) e = text.size();
+  *line = text.substr(*pos, e - *pos);
+  if (!line->empty() && line->back() == '\r') line->pop_back();
+  *pos = e + 1;
+  return true;
+}
+
+// str::str2float (aku/str.cc:260-282): strtod narrowed to float
+static float str2float(const std::string &s, bool *ok) {
+  char *end;
+  float v = (float)strtod(s.c_str(), &end);
+  if (s.empty() || *end != '\0') *ok = false;
+  return v;
+}
+static long str2long(const std::string &s, bool *ok) {
+  char *end;
+  long v = strtol(s.c_str(), &end, 10);
+  if (s.empty() || *end != '\0') *ok = false;
+  return v;
+}
+
+void ModuleConfig::read(const std::string &text, size_t *pos) {
+  bool first_line = true;
+  std::string line;
+  while (true) {
+    if (!next_line(text, pos, &line))
+      raise(AASR_ERR_INVALID, "unexpected end of module config file");
+    line = clean(line, " \t");
+    if (line.empty()) continue;
+    if (first_line) {
+      if (line != "{")
+        raise(AASR_ERR_INVALID, "'{' expected in module config file: %s", line.c_str());
+      first_line = false;
+      continue;
+    }
+    if (line == "}") break;
+    size_t sp = line.find_first_of(" \t");
+    if (sp == std::string::npos)
+      raise(AASR_ERR_INVALID, "value missing for option: %s", line.c_str());
+    std::string key = line.substr(0, sp);
+    std::string val = clean(line.substr(sp), " \t");
+    if (val.empty()) raise(AASR_ERR_INVALID, "value missing for option: %s", line.c_str());
+    if (index.count(key)) raise(AASR_ERR_INVALID, "value redefined: %s", line.c_str());
+    index[key] = (int)values.size();
+    names.push_back(key);
+    values.push_back(val);
+  }
+}
+
+bool ModuleConfig::get(const std::string &k, std::string &v) const {
+  auto it = index.find(k);
+  if (it == index.end()) return false;
+  v = values[it->second];
+  return true;
+}
+bool ModuleConfig::get(const std::string &k, int &v) const {
+  auto it = index.find(k);
+  if (it == index.end()) return false;
+  bool ok = true;
+  v = (int)str2long(values[it->second], &ok);
+  if (!ok) raise(AASR_ERR_INVALID, "invalid integer value: %s", values[it->second].c_str());
+  return true;
+}
+bool ModuleConfig::get(const std::string &k, float &v) const {
+  auto it = index.find(k);
+  if (it == index.end()) return false;
+  bool ok = true;
+  v = str2float(values[it->second], &ok);
+  if (!ok) raise(AASR_ERR_INVALID, "invalid float value: %s", values[it->second].c_str());
+  return true;
+}
+bool ModuleConfig::get(const std::string &k, std::vector<float> &v) const {
+  auto it = index.find(k);
+  if (it == index.end()) return false;
+  std::vector<std::string> f = split_ws(values[it->second]);
+  v.resize(f.size());
+  bool ok = true;
+  for (size_t i = 0; i < f.size(); i++) {
+    v[i] = str2float(f[i], &ok);
+    if (!ok)
+      raise(AASR_ERR_INVALID, "invalid value '%s' in float vector: %s", f[i].c_str(),
+            values[it->second].substr(0, 200).c_str());
+  }
+  return true;
+}
+bool ModuleConfig::get(const std::string &k, std::vector<std::string> &v) const {
+  auto it = index.find(k);
+  if (it == index.end()) return false;
+  v = split_ws(values[it->second]);
+  return true;
+}
+
+// ------------------------------------------------------------- FFT tables --
+
+// Radix schedule of KissFFT's kf_factor (vendor/kiss_fft/kiss_fft.c:309-331):
+// 4s first, then 2s, then odd primes.  Only radices 2 and 4 have kernels.
+static void build_fft_plan(FftPlan &p, int window) {
+  if (window & 1) raise(AASR_ERR_INVALID, "Real FFT optimization must be even.");
+  int nc = window / 2;
+  if (nc < 2) raise(AASR_ERR_UNSUPPORTED, "FFT window %d too short", window);
+  p.nc = nc;
+  int n = nc, r = 4, ns = 0;
+  double root = floor(sqrt((double)n));
+  do {
+    while (n % r) {
+      if (r == 4) r = 2;
+      else if (r == 2) r = 3;
+      else r += 2;
+      if (r > root) r = n;
+    }
+    n /= r;
+    if (r != 2 && r != 4)
+      raise(AASR_ERR_UNSUPPORTED,
+            "FFT window %d needs a radix-%d butterfly; only power-of-two windows are built", window, r);
+    if (ns >= 16) raise(AASR_ERR_UNSUPPORTED, "FFT window %d too long", window);
+    p.radix[ns] = r;
+    p.sublen[ns] = n;
+    ns++;
+  } while (n > 1);
+  p.ns = ns;
+  if (nc > 2048) raise(AASR_ERR_UNSUPPORTED, "FFT window %d > 4096 samples is not built", window);
+
+  // FFTModule::set_module_config (aku/FeatureModules.cc:488-490)
+  std::vector<float> ham((size_t)window);
+  for (int i = 0; i < window; i++)
+    ham[i] = .54 - .46 * cosf(2 * M_PI * i / (window - 1.0));
+  p.hamming.upload(ham.data(), ham.size());
+  // kiss_fft_alloc twiddles (vendor/kiss_fft/kiss_fft.c:355-363)
+  std::vector<float> tw((size_t)nc * 2);
+  const double pi = 3.141592653589793238462643383279502884197169399375105820974944;
+  for (int i = 0; i < nc; i++) {
+    double phase = -2 * pi * i / nc;
+    tw[2 * i] = (float)cos(phase);
+    tw[2 * i + 1] = (float)sin(phase);
+  }
+  p.twiddle.upload(tw.data(), tw.size());
+  // kiss_fftr_alloc super twiddles (vendor/kiss_fft/kiss_fftr.c:57-63)
+  std::vector<float> st((size_t)(nc / 2 + 1) * 2, 0.0f);
+  for (int i = 0; i < nc / 2; i++) {
+    double phase = -3.14159265358979323846264338327 * ((double)(i + 1) / nc + .5);
+    st[2 * i] = (float)cos(phase);
+    st[2 * i + 1] = (float)sin(phase);
+  }
+  p.stwiddle.upload(st.data(), st.size());
+  // mixed-radix digit reversal implied by kf_work's recursion (:240-302)
+  std::vector<int32_t> perm((size_t)nc);
+  for (int o = 0; o < nc; o++) {
+    int rem = o, src = 0, stride = 1;
+    for (int s = 0; s < ns; s++) {
+      int k = rem / p.sublen[s];
+      rem -= k * p.sublen[s];
+      src += k * stride;
+      stride *= p.radix[s];
+    }
+    perm[o] = src;
+  }
+  p.perm.upload(perm.data(), perm.size());
+}
+
+// ------------------------------------------------------- module configure --
+
+static void configure(aasr_feat *h, FeatModule &m, const ModuleConfig &c) {
+  auto src = [&](int i) -> const FeatModule & { return h->mods[m.sources[i]]; };
+  switch (m.type) {
+    case MOD_AUDIOFILE: {
+      // AudioFileModule::set_module_config (aku/FeatureModules.cc:327-360)
+      if (!c.get("sample_rate", m.sample_rate))
+        raise(AASR_ERR_INVALID, "AudioFileModule: Must set sample rate");
+      m.emph = 0.97;
+      c.get("pre_emph_coef", m.emph);
+      m.frame_rate = 125;
+      c.get("frame_rate", m.frame_rate);
+      m.advance = m.sample_rate / m.frame_rate;
+      m.width = (int)(2 * m.sample_rate / m.frame_rate);
+      c.get("window_width", m.width);
+      m.dim = m.width;
+      m.copy_borders = 1;
+      c.get("copy_borders", m.copy_borders);
+      if (m.width <= 0 || !(m.advance > 0))
+        raise(AASR_ERR_INVALID, "AudioFileModule: invalid window (%d samples, advance %g)", m.width, m.advance);
+      break;
+    }
+    case MOD_FFT: {
+      // FFTModule::set_module_config (aku/FeatureModules.cc:475-518)
+      m.magnitude = 1;
+      c.get("magnitude", m.magnitude);
+      m.take_log = 0;
+      c.get("log", m.take_log);
+      int source_dim = src(0).dim;
+      m.dim = source_dim / 2 + 1;
+      build_fft_plan(m.fft, source_dim);
+      break;
+    }
+    case MOD_MEL: {
+      // MelModule::set_module_config / create_mel_bins (aku/FeatureModules.cc:775-803)
+      m.root = 0;
+      c.get("root", m.root);
+      int sr = h->mods[0].sample_rate;
+      m.dim = (int)((21 + 2) * log10f(1 + sr / 1400.0) / log10f(1 + 16000 / 1400.0) - 2);
+      if (m.dim < 1) raise(AASR_ERR_INVALID, "MelModule: sample rate %d gives no mel bins", sr);
+      int edges = m.dim + 2;
+      float rate = sr;
+      float mel_step = 2595 * log10f(1.0 + rate / 1400.0) / edges;
+      std::vector<float> edge((size_t)edges);
+      int sdim = src(0).dim;
+      for (int i = 0; i < edges; i++)
+        edge[i] = 1400.0 * (pow(10, (i + 1) * mel_step / 2595) - 1) * (sdim - 1) / rate;
+      // MelModule::generate's triangular ramps (:805-835), evaluated once: the
+      // float scale of every (bin, t) term in accumulation order and the float
+      // running sum per bin.
+      std::vector<int32_t> off(1, 0), tt;
+      std::vector<float> sc, sums;
+      for (int b = 0; b < m.dim; b++) {
+        float sum = 0, scale;
+        float beg = edge[b] - 1;
+        float end = edge[b + 1];
+        int t = (int)std::max(ceilf(beg), 0.0f);
+        while (t < end) {
+          scale = (t - beg) / (end - beg);
+          if (t >= sdim) raise(AASR_ERR_INVALID, "MelModule: bin edge beyond the spectrum");
+          tt.push_back(t);
+          sc.push_back(scale);
+          sum += scale;
+          t++;
+        }
+        beg = end;
+        end = edge[b + 2];
+        while (t < end) {
+          scale = (end - t) / (end - beg);
+          if (t >= sdim) raise(AASR_ERR_INVALID, "MelModule: bin edge beyond the spectrum");
+          tt.push_back(t);
+          sc.push_back(scale);
+          sum += scale;
+          t++;
+        }
+        sums.push_back(sum);
+        off.push_back((int32_t)tt.size());
+      }
+      m.mel_off.upload(off.data(), off.size());
+      m.mel_t.upload(tt.data(), tt.size());
+      m.mel_scale.upload(sc.data(), sc.size());
+      m.mel_sum.upload(sums.data(), sums.size());
+      break;
+    }
+    case MOD_POWER:
+      m.dim = 1;  // PowerModule::set_module_config (aku/FeatureModules.cc:866-872)
+      break;
+    case MOD_DCT: {
+      // DCTModule::set_module_config / generate (aku/FeatureModules.cc:937-979)
+      m.dim = 12;
+      m.zeroth = 0;
+      c.get("dim", m.dim);
+      if (m.dim < 1) raise(AASR_ERR_INVALID, "DCTModule: Dimension must be > 0");
+      c.get("zeroth", m.zeroth);
+      int sdim = src(0).dim;
+      int bias = m.zeroth ? 1 : 0;
+      std::vector<float> cs((size_t)std::max(1, m.dim - bias) * sdim);
+      for (int i = 0; i < m.dim - bias; i++)
+        for (int b = 0; b < sdim; b++)
+          cs[(size_t)i * sdim + b] = cosf((i + 1) * (b + 0.5) * M_PI / sdim);
+      m.dct_cos.upload(cs.data(), cs.size());
+      break;
+    }
+    case MOD_DELTA: {
+      // DeltaModule::set_module_config (aku/FeatureModules.cc:998-1016)
+      m.dim = src(0).dim;
+      m.delta_width = 2;
+      c.get("width", m.delta_width);
+      m.delta_norm = 2 * m.delta_width * (m.delta_width + 1) * (2 * m.delta_width + 1) / 6;
+      c.get("normalization", m.delta_norm);
+      if (m.delta_width < 1) raise(AASR_ERR_INVALID, "DeltaModule: Delta width must be > 0");
+      m.own_left = m.own_right = m.delta_width;
+      break;
+    }
+    case MOD_NORMALIZATION: {
+      // NormalizationModule::set_module_config (aku/FeatureModules.cc:1056-1086)
+      m.dim = src(0).dim;
+      m.mean.assign(m.dim, 0.0f);
+      m.scale.assign(m.dim, 1.0f);
+      c.get("mean", m.mean);
+      if ((int)m.mean.size() != m.dim)
+        raise(AASR_ERR_INVALID, "NormalizationModule: Invalid mean dimension");
+      if (c.exists("var") && c.exists("scale"))
+        raise(AASR_ERR_INVALID, "NormalizationModule: Both scale and var can not be defined simultaneously");
+      if (c.get("var", m.scale)) {
+        if ((int)m.scale.size() != m.dim)
+          raise(AASR_ERR_INVALID, "Normalization module: Invalid variance dimension");
+        for (int i = 0; i < m.dim; i++) m.scale[i] = 1 / sqrtf(m.scale[i]);
+      } else if (c.get("scale", m.scale)) {
+        if ((int)m.scale.size() != m.dim)
+          raise(AASR_ERR_INVALID, "NormalizationModule: Invalid scale dimension");
+      }
+      m.d_mean.upload(m.mean.data(), m.mean.size());
+      m.d_scale.upload(m.scale.data(), m.scale.size());
+      break;
+    }
+    case MOD_LIN_TRANSFORM: {
+      // LinTransformModule::set_module_config / check_transform_parameters
+      // (aku/FeatureModules.cc:1167-1241)
+      m.src_dim = src(0).dim;
+      m.dim = m.src_dim;
+      m.matrix.clear();
+      m.bias.clear();
+      c.get("matrix", m.matrix);
+      c.get("bias", m.bias);
+      c.get("dim", m.dim);
+      if (m.dim < 1) raise(AASR_ERR_INVALID, "LinTransformModule: Dimension must be > 0");
+      m.matrix_defined = !m.matrix.empty();
+      m.bias_defined = !m.bias.empty();
+      if (m.matrix_defined && (int)m.matrix.size() != m.dim * m.src_dim)
+        raise(AASR_ERR_INVALID, "LinTransformModule: Invalid matrix dimension");
+      if (m.bias_defined && (int)m.bias.size() != m.dim)
+        raise(AASR_ERR_INVALID, "LinTransformModule: Invalid bias dimension");
+      if (!m.matrix_defined && m.dim > m.src_dim)
+        raise(AASR_ERR_INVALID, "LinTransformModule: identity transform needs dim <= source dim");
+      m.d_matrix.upload(m.matrix.data(), m.matrix.size());
+      m.d_bias.upload(m.bias.data(), m.bias.size());
+      break;
+    }
+    case MOD_MERGE: {
+      // MergerModule::set_module_config (aku/FeatureModules.cc:1341-1349)
+      m.dim = 0;
+      std::vector<int32_t> sc;
+      for (size_t i = 0; i < m.sources.size(); i++) {
+        for (int j = 0; j < src((int)i).dim; j++) {
+          sc.push_back((int32_t)i);
+          sc.push_back(j);
+        }
+        m.dim += src((int)i).dim;
+      }
+      m.merge_src_col.upload(sc.data(), sc.size());
+      break;
+    }
+    case MOD_MEAN_SUBTRACTOR: {
+      // MeanSubtractorModule::set_module_config (aku/FeatureModules.cc:1384-1404)
+      m.dim = src(0).dim;
+      m.cms_left = 75;
+      c.get("left", m.cms_left);
+      m.cms_right = 75;
+      c.get("right", m.cms_right);
+      if (m.cms_left + 1 < 1 || m.cms_right + 1 < 1)
+        raise(AASR_ERR_INVALID, "MeanSubtractorModule: context widths must be >= 0");
+      m.own_left = m.cms_left;
+      m.own_right = m.cms_right;
+      break;
+    }
+  }
+  if (m.dim <= 0) raise(AASR_ERR_INVALID, "module %s has no output dimension", m.name.c_str());
+}
+
+aasr_feat *feat_create(const std::string &text) {
+  require_device();
+  aasr_feat *h = new aasr_feat();
+  try {
+    AASR_HIP(hipGetDevice(&h->device));
+    size_t pos = 0;
+    std::string line;
+    int lineno = 0;
+    while (next_line(text, &pos, &line)) {
+      lineno++;
+      line = clean(line, " \t");
+      if (line.empty()) continue;
+      if (line != "module")
+        raise(AASR_ERR_INVALID, "expected keyword 'module' on line %d: %s", lineno, line.c_str());
+      ModuleConfig cfg;
+      size_t before = pos;
+      try {
+        cfg.read(text, &pos);
+      } catch (Error &e) {
+        raise(e.code, "failed reading feature module around line %d: %s", lineno, e.msg.c_str());
+      }
+      for (size_t i = before; i < pos && i < text.size(); i++)
+        if (text[i] == '\n') lineno++;
+      std::string type, name;
+      if (!cfg.get("type", type))
+        raise(AASR_ERR_INVALID, "type not defined for module ending on line %d", lineno);
+      if (!cfg.get("name", name))
+        raise(AASR_ERR_INVALID, "name not defined for module ending on line %d", lineno);
+      if (name.find_first_of(" \t\n") != std::string::npos)
+        raise(AASR_ERR_INVALID, "module name may not contain whitespaces");
+      h->mods.emplace_back();  // DevBuf members are non-copyable: build in place
+      FeatModule &m = h->mods.back();
+      m.name = name;
+      m.type_str = type;
+      static const struct { const char *s; ModType t; } kinds[] = {
+          {"audiofile", MOD_AUDIOFILE}, {"fft", MOD_FFT}, {"mel", MOD_MEL},
+          {"power", MOD_POWER}, {"dct", MOD_DCT}, {"delta", MOD_DELTA},
+          {"normalization", MOD_NORMALIZATION}, {"lin_transform", MOD_LIN_TRANSFORM},
+          {"merge", MOD_MERGE}, {"mean_subtractor", MOD_MEAN_SUBTRACTOR}};
+      bool found = false;
+      for (auto &k : kinds)
+        if (type == k.s) {
+          m.type = k.t;
+          found = true;
+        }
+      if (!found) {
+        static const char *later[] = {"pre", "mel_power", "concat", "vtln", "sr_norm", "quanteq"};
+        for (auto *l : later)
+          if (type == l)
+            raise(AASR_ERR_UNSUPPORTED,
+                  "module type '%s' exists in aku but is not built in this engine yet", l);
+        raise(AASR_ERR_INVALID, "Unknown module type '%s'", type.c_str());
+      }
+      const bool is_first = h->mods.size() == 1;
+      if (is_first && m.type != MOD_AUDIOFILE)
+        raise(AASR_ERR_INVALID, "first module should be a base module");
+      if (h->by_name.count(name))
+        raise(AASR_ERR_INVALID, "multiple definitions of module name: %s", name.c_str());
+      bool has_sources = cfg.exists("sources");
+      if (is_first && has_sources)
+        raise(AASR_ERR_INVALID, "can not define sources for the first module");
+      if (!is_first && !has_sources)
+        raise(AASR_ERR_INVALID, "sources not defined for module: %s", name.c_str());
+      if (!is_first && m.type == MOD_AUDIOFILE)
+        raise(AASR_ERR_INVALID, "base module FFT can not have sources");
+      if (has_sources) {
+        std::vector<std::string> srcs;
+        cfg.get("sources", srcs);
+        for (auto &s : srcs) {
+          auto it = h->by_name.find(s);
+          if (it == h->by_name.end())
+            raise(AASR_ERR_INVALID, "unknown source module: %s", s.c_str());
+          if (!m.sources.empty() && m.type != MOD_MERGE)
+            raise(AASR_ERR_INVALID, "Multiple sources are not allowed for module %s", type.c_str());
+          m.sources.push_back(it->second);
+        }
+      }
+      h->by_name[name] = (int)h->mods.size() - 1;
+      configure(h, m, cfg);
+    }
+    if (h->mods.empty()) raise(AASR_ERR_INVALID, "no feature modules defined");
+    h->bufs.resize(h->mods.size());
+  } catch (...) {
+    delete h;
+    throw;
+  }
+  return h;
+}
+
+// AudioFileModule::last_frame (aku/FeatureModules.cc:305-308): int/float, truncated
+int feat_last_frame(const aasr_feat *h, int64_t n_samples) {
+  const FeatModule &a = h->mods[0];
+  return (int)(((int)n_samples - a.width - 1) / a.advance);
+}
+
+void feat_halo(const aasr_feat *h, int target, int *left, int *right) {
+  // longest accumulated look-around from `target` down to the base module
+  std::vector<int> L(h->mods.size(), -1), R(h->mods.size(), -1);
+  L[target] = R[target] = 0;
+  for (int i = target; i >= 0; i--) {
+    if (L[i] < 0) continue;
+    const FeatModule &m = h->mods[i];
+    for (int s : m.sources) {
+      L[s] = std::max(L[s], L[i] + m.own_left);
+      R[s] = std::max(R[s], R[i] + m.own_right);
+    }
+  }
+  *left = std::max(0, L[0]);
+  *right = std::max(0, R[0]);
+}
+
+void feat_set_parameters(aasr_feat *h, const std::string &module, const std::string &block) {
+  auto it = h->by_name.find(module);
+  if (it == h->by_name.end())
+    raise(AASR_ERR_INVALID, "unknown module requested: %s", module.c_str());
+  FeatModule &m = h->mods[it->second];
+  ModuleConfig c;
+  size_t pos = 0;
+  c.read(block, &pos);
+  if (m.type == MOD_NORMALIZATION) {
+    // NormalizationModule::set_parameters (aku/FeatureModules.cc:1089-1112)
+    c.get("mean", m.mean);
+    if ((int)m.mean.size() != m.dim)
+      raise(AASR_ERR_INVALID, "NormalizationModule: Invalid mean dimension");
+    if (c.exists("var") && c.exists("scale"))
+      raise(AASR_ERR_INVALID, "NormalizationModule: Both scale and var can not be defined simultaneously");
+    if (c.get("var", m.scale)) {
+      if ((int)m.scale.size() != m.dim)
+        raise(AASR_ERR_INVALID, "Normalization module: Invalid variance dimension");
+      for (int i = 0; i < m.dim; i++) m.scale[i] = 1 / sqrtf(m.scale[i]);
+    } else if (c.get("scale", m.scale)) {
+      if ((int)m.scale.size() != m.dim)
+        raise(AASR_ERR_INVALID, "NormalizationModule: Invalid scale dimension");
+    }
+    m.d_mean.upload(m.mean.data(), m.mean.size());
+    m.d_scale.upload(m.scale.data(), m.scale.size());
+  } else if (m.type == MOD_LIN_TRANSFORM) {
+    // LinTransformModule::set_parameters (aku/FeatureModules.cc:1188-1196)
+    m.matrix.clear();
+    m.bias.clear();
+    c.get("matrix", m.matrix);
+    c.get("bias", m.bias);
+    m.matrix_defined = !m.matrix.empty();
+    m.bias_defined = !m.bias.empty();
+    if (m.matrix_defined && (int)m.matrix.size() != m.dim * m.src_dim)
+      raise(AASR_ERR_INVALID, "LinTransformModule: Invalid matrix dimension");
+    if (m.bias_defined && (int)m.bias.size() != m.dim)
+      raise(AASR_ERR_INVALID, "LinTransformModule: Invalid bias dimension");
+    m.d_matrix.upload(m.matrix.data(), m.matrix.size());
+    m.d_bias.upload(m.bias.data(), m.bias.size());
+  } else {
+    // FeatureModule::set_parameters default is a no-op (aku/FeatureModule.hh:107)
+  }
+}
+
+}  // namespace aasr

@@ -1,0 +1,419 @@
+// pipeline.cc -- recipe handling and the whole-path driver
+// (audio -> features -> state likelihoods -> LNA files) behind
+// aasr_run_recipe / aasr_run_utterance.
+//
+// Replaces the body of phone_probs' main loop (aku/phone_probs.cc:145-267) and
+// PPToolbox::generate_from_file_to_fd (aku/PhoneProbsToolbox.cc:135-208).  The
+// reference walks one frame at a time; here the utterances of a recipe slice
+// are packed into blocks of frames, each block runs the feature graph, the
+// scoring kernel and the LNA packer back to back on the device, and the packed
+// bytes come back in one copy per block.
+#include <sys/stat.h>
+
+#include <chrono>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+
+#include "feat.h"
+#include "gmm.h"
+#include "pipeline.h"
+
+namespace aasr {
+
+void lna_encode_launch(const float *d_loglik, int64_t F, int S, int normalize, int lnabytes,
+                       float *d_lp, uint8_t *d_bytes, hipStream_t stream);
+
+// ------------------------------------------------------------------ recipe --
+
+// Recipe::read's batch arithmetic (aku/Recipe.cc:63-112) for
+// cluster_speakers=false: walks the lines exactly like the reference loop and
+// reports which lines land in batch_index.
+void recipe_batch_range(int total, int num_batches, int batch_index, int *first, int *count) {
+  if (num_batches > 1 && (batch_index < 1 || batch_index > num_batches))
+    raise(AASR_ERR_INVALID, "Invalid batch index");
+  int target_lines, batch_remainder = 0;
+  if (num_batches <= 1) {
+    target_lines = total;
+  } else {
+    target_lines = total / num_batches;
+    batch_remainder = total % num_batches;
+  }
+  int extra_line = 1;
+  if (target_lines < 1) {
+    target_lines = 1;
+    extra_line = 0;
+  }
+  if (batch_remainder == 0) extra_line = 0;
+  int cur_index = 1, cur_line = 0;
+  *first = -1;
+  *count = 0;
+  for (int i = 0; i < total; i++) {
+    if (num_batches > 1 && cur_index < num_batches) {
+      if (cur_line >= target_lines + extra_line) {
+        cur_index++;
+        if (cur_index > batch_index) break;
+        cur_line -= target_lines + extra_line;
+        if (cur_index > batch_remainder) extra_line = 0;
+      }
+    }
+    if (num_batches <= 1 || cur_index == batch_index) {
+      if (*first < 0) *first = i;
+      (*count)++;
+    }
+    cur_line++;
+  }
+  if (*first < 0) *first = total;
+}
+
+static std::string strip(const std::string &s, const char *chars) {
+  size_t a = s.find_first_not_of(chars);
+  if (a == std::string::npos) return "";
+  size_t b = s.find_last_not_of(chars);
+  return s.substr(a, b - a + 1);
+}
+
+// Recipe::read (aku/Recipe.cc:23-149).  Quirk kept: the key=value map is not
+// cleared between lines, so a key missing on a line inherits the value of the
+// previous line that set it -- including lines that belong to other batches.
+std::vector<RecipeInfo> recipe_read(const std::string &text, int num_batches, int batch_index) {
+  std::vector<std::string> lines;
+  {
+    std::istringstream in(text);
+    std::string line;
+    while (std::getline(in, line)) {
+      line = strip(line, "\n\t \r");
+      if (line.empty() || line[0] == '#') continue;
+      lines.push_back(line);
+    }
+  }
+  int first = 0, count = 0;
+  recipe_batch_range((int)lines.size(), num_batches, batch_index, &first, &count);
+  std::vector<RecipeInfo> infos;
+  std::map<std::string, std::string> kv;
+  for (int i = 0; i < (int)lines.size() && i < first + count; i++) {
+    std::istringstream fs(lines[i]);
+    std::string field;
+    while (fs >> field) {
+      size_t eq = field.find('=');
+      // str::split(&field, "=", false): exactly two parts required
+      if (eq == std::string::npos || field.find('=', eq + 1) != std::string::npos)
+        raise(AASR_ERR_INVALID, "Invalid recipe line: %s", lines[i].c_str());
+      kv[field.substr(0, eq)] = field.substr(eq + 1);
+    }
+    if (i < first) continue;
+    RecipeInfo info;
+    auto get = [&](const char *k, std::string &dst) {
+      auto it = kv.find(k);
+      if (it != kv.end()) dst = it->second;
+    };
+    get("audio", info.audio_path);
+    get("lna", info.lna_path);
+    get("speaker", info.speaker_id);
+    get("utterance", info.utterance_id);
+    auto it = kv.find("start-time");
+    if (it != kv.end()) info.start_time = atof(it->second.c_str());
+    it = kv.find("end-time");
+    if (it != kv.end()) info.end_time = atof(it->second.c_str());
+    infos.push_back(info);
+  }
+  return infos;
+}
+
+// ------------------------------------------------------------------- audio --
+
+// Stand-in for the libsndfile calls of AudioReader::open/read_from_file
+// (aku/AudioReader.cc:86-110,170-213): RIFF/WAVE PCM16 mono, else -- as the
+// reference's fallback does -- headerless 16-bit PCM (little endian).
+std::vector<int16_t> read_audio_file(const std::string &path, bool force_raw, int expect_rate) {
+  std::ifstream in(path, std::ios::binary);
+  if (!in) raise(AASR_ERR_IO, "AudioReader::open(): could not open file:%s", path.c_str());
+  std::vector<char> data((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+  auto u32 = [&](size_t o) {
+    return (uint32_t)(uint8_t)data[o] | ((uint32_t)(uint8_t)data[o + 1] << 8) |
+           ((uint32_t)(uint8_t)data[o + 2] << 16) | ((uint32_t)(uint8_t)data[o + 3] << 24);
+  };
+  auto u16 = [&](size_t o) { return (uint16_t)((uint8_t)data[o] | ((uint8_t)data[o + 1] << 8)); };
+  size_t body = 0, nbytes = data.size();
+  if (!force_raw && data.size() >= 12 && !memcmp(data.data(), "RIFF", 4) &&
+      !memcmp(data.data() + 8, "WAVE", 4)) {
+    size_t pos = 12;
+    bool have_fmt = false, have_data = false;
+    int channels = 0, bits = 0, fmt = 0, rate = 0;
+    while (pos + 8 <= data.size()) {
+      uint32_t len = u32(pos + 4);
+      if (!memcmp(data.data() + pos, "fmt ", 4) && pos + 8 + 16 <= data.size()) {
+        fmt = u16(pos + 8);
+        channels = u16(pos + 10);
+        rate = (int)u32(pos + 12);
+        bits = u16(pos + 22);
+        have_fmt = true;
+      } else if (!memcmp(data.data() + pos, "data", 4)) {
+        body = pos + 8;
+        nbytes = std::min<size_t>(len, data.size() - body);
+        have_data = true;
+        break;
+      }
+      pos += 8 + (size_t)len + (len & 1);
+    }
+    if (!have_fmt || !have_data) raise(AASR_ERR_IO, "malformed WAV file: %s", path.c_str());
+    if (channels != 1)
+      raise(AASR_ERR_INVALID, "AudioReader: sorry, audio files with multiple channels not supported");
+    if (fmt != 1 || bits != 16)
+      raise(AASR_ERR_UNSUPPORTED, "audio sample format is not PCM16 (format %d, %d bits): %s", fmt,
+            bits, path.c_str());
+    if (expect_rate > 0 && rate != expect_rate)
+      raise(AASR_ERR_INVALID,
+            "Audio file sample rate (%d Hz) and model configuration (%d Hz) don't agree.", rate,
+            expect_rate);
+  }
+  std::vector<int16_t> pcm(nbytes / 2);
+  for (size_t i = 0; i < pcm.size(); i++) pcm[i] = (int16_t)u16(body + 2 * i);
+  return pcm;
+}
+
+// ------------------------------------------------------------------ driver --
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct Job {
+  size_t info_index;
+  std::vector<int16_t> pcm;
+  int32_t start, count;  // frames start .. start+count-1
+  std::string out_file;
+};
+
+struct BlockRunner {
+  aasr_feat *feat;
+  aasr_gmm *gmm;
+  int lnabytes, normalize;
+  DevBuf<int16_t> d_pcm;
+  DevBuf<float> d_fea, d_ll;
+  DevBuf<uint8_t> d_bytes;
+  std::vector<uint8_t> h_bytes;
+  double device_seconds = 0;
+
+  // features + scoring + LNA for a block of jobs; h_bytes = [sum count][S*lnabytes]
+  void run(const std::vector<Job *> &jobs) {
+    UttBatch ub;
+    ub.n_utts = (int32_t)jobs.size();
+    ub.frame_off.assign(1, 0);
+    ub.pcm_off.assign(1, 0);
+    for (Job *j : jobs) {
+      ub.first.push_back(j->start);
+      ub.frame_off.push_back(ub.frame_off.back() + j->count);
+      ub.pcm_off.push_back(ub.pcm_off.back() + (int64_t)j->pcm.size());
+    }
+    const int64_t F = ub.frame_off.back();
+    const int dim = feat->mods.back().dim;
+    const int64_t S = gmm->S;
+    if (F <= 0) {
+      h_bytes.clear();
+      return;
+    }
+    double t0 = now_s();
+    d_pcm.ensure((size_t)ub.pcm_off.back());
+    for (size_t k = 0; k < jobs.size(); k++)
+      AASR_HIP(hipMemcpyAsync(d_pcm.p + ub.pcm_off[k], jobs[k]->pcm.data(),
+                              jobs[k]->pcm.size() * sizeof(int16_t), hipMemcpyHostToDevice, nullptr));
+    d_fea.ensure((size_t)F * dim);
+    d_ll.ensure((size_t)F * S);
+    d_bytes.ensure((size_t)F * S * lnabytes);
+    feat_run_batch(feat, d_pcm.p, ub, (int)feat->mods.size() - 1, d_fea.p, nullptr, nullptr);
+    gmm_score_launch(gmm, d_fea.p, F, d_ll.p, nullptr);
+    lna_encode_launch(d_ll.p, F, (int)S, normalize, lnabytes, nullptr, d_bytes.p, nullptr);
+    h_bytes.resize((size_t)F * S * lnabytes);
+    AASR_HIP(hipMemcpy(h_bytes.data(), d_bytes.p, h_bytes.size(), hipMemcpyDeviceToHost));
+    device_seconds += now_s() - t0;
+  }
+};
+
+static void frame_range(aasr_feat *feat, int64_t n_samples, double start_time, double end_time,
+                        int32_t *start, int32_t *count) {
+  // start/end frame = (int)(time * frame_rate) (aku/phone_probs.cc:199-206); the
+  // loop stops at the first frame for which AudioFileModule::eof() holds
+  float fr = feat->mods[0].frame_rate;
+  int start_frame = (int)(start_time * fr);
+  int end_frame = (int)(end_time * fr);
+  if (end_frame == 0) end_frame = INT_MAX;
+  if (n_samples < feat->mods[0].width + 1) raise(AASR_ERR_SHORT_AUDIO, "audio shorter than frame");
+  int eof_frame = feat_last_frame(feat, n_samples) + 1;
+  int stop = std::min(end_frame, eof_frame);
+  *start = start_frame;
+  *count = stop > start_frame ? stop - start_frame : 0;
+}
+
+static void write_lna_file(const std::string &path, int32_t S, int lnabytes, const uint8_t *body,
+                           size_t nbytes) {
+  // write to a temporary name and rename: a killed run never leaves a
+  // truncated .lna that --no-overwrite would later trust
+  std::string tmp = path + ".tmp";
+  FILE *fp = fopen(tmp.c_str(), "wb");
+  if (!fp) raise(AASR_ERR_IO, "could not open %s for writing", tmp.c_str());
+  uint8_t hdr[5];
+  aasr_lna_header(S, lnabytes, hdr);
+  bool ok = fwrite(hdr, 1, 5, fp) == 5 && (nbytes == 0 || fwrite(body, 1, nbytes, fp) == nbytes);
+  ok = (fclose(fp) == 0) && ok;
+  if (!ok || rename(tmp.c_str(), path.c_str()) != 0) {
+    remove(tmp.c_str());
+    raise(AASR_ERR_IO, "Write error");
+  }
+}
+
+void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
+                const aasr_run_options &opt, aasr_run_stats *stats) {
+  if (opt.lnabytes != 2 && opt.lnabytes != 4) raise(AASR_ERR_INVALID, "Invalid number of LNA bytes");
+  if (gmm->dim != feat->mods.back().dim)
+    raise(AASR_ERR_INVALID, "Gaussian dimension is %d but feature dimension is %d.", gmm->dim,
+          feat->mods.back().dim);
+  std::ifstream rin(recipe_path);
+  if (!rin) raise(AASR_ERR_IO, "could not open recipe %s", recipe_path.c_str());
+  std::stringstream ss;
+  ss << rin.rdbuf();
+  std::vector<RecipeInfo> infos = recipe_read(ss.str(), opt.num_batches, opt.batch_index);
+  std::string out_dir = opt.out_dir ? opt.out_dir : "";
+  if (!out_dir.empty() && out_dir.back() != '/') out_dir += "/";
+
+  double t_start = now_s();
+  BlockRunner br{feat, gmm, opt.lnabytes, opt.normalize};
+  const int64_t S = gmm->S;
+  // frames per device block: bounded by the [F x S] float + byte buffers (~2 GiB)
+  const int64_t block_frames = std::max<int64_t>(4096, (int64_t)(2.0e9 / (double)(S * (4 + opt.lnabytes))));
+  std::vector<Job> pending;
+  int64_t pending_frames = 0, total_frames = 0, total_utts = 0;
+
+  auto flush = [&]() {
+    if (pending.empty()) return;
+    std::vector<Job *> jobs;
+    for (Job &j : pending) jobs.push_back(&j);
+    br.run(jobs);
+    size_t off = 0;
+    for (Job &j : pending) {
+      size_t nb = (size_t)j.count * S * opt.lnabytes;
+      write_lna_file(j.out_file, (int32_t)S, opt.lnabytes, br.h_bytes.data() + off, nb);
+      off += nb;
+    }
+    pending.clear();
+    pending_frames = 0;
+  };
+
+  for (size_t ri = 0; ri < infos.size(); ri++) {
+    const RecipeInfo &info = infos[ri];
+    if (opt.info > 0) {
+      printf("Processing file %d/%d\n", (int)ri + 1, (int)infos.size());
+      printf("Input: %s\n", info.audio_path.c_str());
+    }
+    std::string out_file = out_dir + info.lna_path;
+    if (opt.afname) {
+      std::string file = info.audio_path;
+      size_t pos = file.rfind('/');
+      if (pos != std::string::npos && pos + 1 < file.size()) file = file.substr(pos + 1);
+      pos = file.rfind('.');
+      if (pos != std::string::npos && pos > 0) file.erase(pos);
+      out_file = out_dir + file + ".lna";
+    }
+    if (opt.info > 0) printf("Output: %s\n", out_file.c_str());
+    if (opt.no_overwrite) {
+      struct stat sb;
+      if (stat(out_file.c_str(), &sb) == 0) {
+        fprintf(stderr, "WARNING: skipping existing lna file %s\n", out_file.c_str());
+        continue;
+      }
+    }
+    Job j;
+    j.info_index = ri;
+    j.out_file = out_file;
+    j.pcm = read_audio_file(info.audio_path, opt.raw_audio != 0, feat->mods[0].sample_rate);
+    frame_range(feat, (int64_t)j.pcm.size(), info.start_time, info.end_time, &j.start, &j.count);
+    if (opt.info > 0 && (j.start != 0 || info.end_time != 0))
+      printf("Generating frames %d - %d\n", j.start, j.start + j.count);
+    if (pending_frames + j.count > block_frames) flush();
+    pending_frames += j.count;
+    total_frames += j.count;
+    total_utts++;
+    pending.push_back(std::move(j));
+  }
+  flush();
+  if (stats) {
+    stats->utterances = total_utts;
+    stats->frames = total_frames;
+    stats->seconds_total = now_s() - t_start;
+    stats->seconds_device = br.device_seconds;
+  }
+}
+
+void run_utterance(aasr_feat *feat, aasr_gmm *gmm, const int16_t *pcm, int64_t n_samples,
+                   int32_t start_frame, int32_t end_frame, int normalize, int lnabytes,
+                   std::vector<uint8_t> *lna, int64_t *frames_out) {
+  if (lnabytes != 2 && lnabytes != 4) raise(AASR_ERR_INVALID, "Invalid number of LNA bytes");
+  if (gmm->dim != feat->mods.back().dim)
+    raise(AASR_ERR_INVALID, "Gaussian dimension is %d but feature dimension is %d.", gmm->dim,
+          feat->mods.back().dim);
+  if (n_samples < feat->mods[0].width + 1) raise(AASR_ERR_SHORT_AUDIO, "audio shorter than frame");
+  Job j;
+  j.pcm.assign(pcm, pcm + n_samples);
+  int eof_frame = feat_last_frame(feat, n_samples) + 1;
+  if (end_frame <= 0) end_frame = INT_MAX;
+  int stop = std::min(end_frame, eof_frame);
+  j.start = start_frame;
+  j.count = stop > start_frame ? stop - start_frame : 0;
+  BlockRunner br{feat, gmm, lnabytes, normalize};
+  std::vector<Job *> jobs{&j};
+  br.run(jobs);
+  lna->resize(5 + br.h_bytes.size());
+  aasr_lna_header((int32_t)gmm->S, lnabytes, lna->data());
+  if (!br.h_bytes.empty()) memcpy(lna->data() + 5, br.h_bytes.data(), br.h_bytes.size());
+  *frames_out = j.count;
+}
+
+}  // namespace aasr
+
+using namespace aasr;
+
+extern "C" {
+
+aasr_status aasr_recipe_batch_range(int32_t num_lines_total, int32_t num_batches,
+                                    int32_t batch_index, int32_t *first_line, int32_t *num_lines) {
+  return guarded([&] {
+    if (!first_line || !num_lines || num_lines_total < 0)
+      raise(AASR_ERR_INVALID, "aasr_recipe_batch_range: bad argument");
+    int f = 0, c = 0;
+    recipe_batch_range(num_lines_total, num_batches, batch_index, &f, &c);
+    *first_line = f;
+    *num_lines = c;
+  });
+}
+
+aasr_status aasr_run_recipe(aasr_feat *feat, aasr_gmm *gmm, const char *recipe_path,
+                            const aasr_run_options *opt, aasr_run_stats *stats) {
+  return guarded([&] {
+    if (!feat || !gmm || !recipe_path || !opt) raise(AASR_ERR_INVALID, "aasr_run_recipe: null argument");
+    run_recipe(feat, gmm, recipe_path, *opt, stats);
+  });
+}
+
+aasr_status aasr_run_utterance(aasr_feat *feat, aasr_gmm *gmm, const int16_t *pcm,
+                               int64_t n_samples, int32_t start_frame, int32_t end_frame,
+                               int normalize, int lnabytes, uint8_t **lna_out, int64_t *lna_len,
+                               int64_t *frames_out) {
+  return guarded([&] {
+    if (!feat || !gmm || !pcm || !lna_out || !lna_len)
+      raise(AASR_ERR_INVALID, "aasr_run_utterance: null argument");
+    std::vector<uint8_t> lna;
+    int64_t frames = 0;
+    run_utterance(feat, gmm, pcm, n_samples, start_frame, end_frame, normalize, lnabytes, &lna, &frames);
+    *lna_out = (uint8_t *)malloc(lna.size());
+    if (!*lna_out) raise(AASR_ERR_INVALID, "out of memory");
+    memcpy(*lna_out, lna.data(), lna.size());
+    *lna_len = (int64_t)lna.size();
+    if (frames_out) *frames_out = frames;
+  });
+}
+
+}  // extern "C"

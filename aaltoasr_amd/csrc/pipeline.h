@@ -1,0 +1,20 @@
+// pipeline.h -- recipe structures shared by pipeline.cc and the aku adapters.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace aasr {
+
+// the fields of aku::Recipe::Info the hot path consumes (aku/Recipe.hh)
+struct RecipeInfo {
+  std::string audio_path, lna_path, speaker_id, utterance_id;
+  double start_time = 0, end_time = 0;
+};
+
+void recipe_batch_range(int total, int num_batches, int batch_index, int *first, int *count);
+std::vector<RecipeInfo> recipe_read(const std::string &text, int num_batches, int batch_index);
+std::vector<int16_t> read_audio_file(const std::string &path, bool force_raw, int expect_rate);
+
+}  // namespace aasr

@@ -205,8 +205,8 @@ typedef struct aasr_run_options {
   int32_t no_overwrite;    /* -n: skip utterances whose LNA exists  */
   int32_t raw_audio;       /* treat inputs as headerless PCM16      */
   int32_t info;            /* -i verbosity                          */
-  const char *out_dir;     /* -o: directory for LNA files or NULL   */
-  const char *lna_suffix;  /* default ".lna" when recipe has no lna= */
+  int32_t afname;          /* -a: name outputs after the audio file */
+  const char *out_dir;     /* -o: prefix for LNA paths or NULL      */
 } aasr_run_options;
 
 typedef struct aasr_run_stats {

@@ -1,0 +1,119 @@
+"""End-to-end GPU parity of the whole path (BASELINE config 1): one 5-s 16 kHz
+WAV -> MFCC chain -> 256-Gaussian diagonal HmmSet -> LNA, against the oracle's
+restatement of phone_probs (aku/phone_probs.cc:145-267)."""
+import os
+import struct
+import wave
+
+import numpy as np
+import pytest
+
+from aaltoasr_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_wav(path, pcm, rate=16000):
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(rate)
+        w.writeframes(pcm.astype("<i2").tobytes())
+
+
+def _oracle_lna(oracle, ch, om, pcm, nbytes, normalize=True, start=0, end=None):
+    n = ch.num_frames(len(pcm))
+    stop = n if end is None else min(end, n)
+    fea = ch.generate(pcm, start, stop - start)
+    _, lik = om.score(fea, want_lik=True)
+    lp, by = oracle.lna_encode(lik, normalize, nbytes)
+    return lp, by
+
+
+@pytest.fixture(scope="module")
+def setup(capi, oracle, golden_dir):
+    cfg = open(os.path.join(golden_dir, "mfcc_cms_norm.feaconf")).read()
+    model = synth.make_model(D=39, G=256, S=32, comps=8)
+    # move the Gaussians into the region real features occupy so that the
+    # posteriors are not all at the floor
+    return dict(cfg=cfg, model=model, ch=oracle.FeatureChain(cfg), om=oracle.DiagModel(*model),
+                ft=capi.Feat(cfg), gm=capi.Gmm.from_arrays(*model))
+
+
+@pytest.mark.parametrize("nbytes", [2, 4])
+def test_config1_utterance_lna(capi, oracle, setup, nbytes):
+    pcm = synth.make_audio(80000)
+    data, frames = capi.run_utterance(setup["ft"], setup["gm"], pcm, lnabytes=nbytes)
+    assert frames == 623
+    assert data[:5] == oracle.lna_header(32, nbytes)
+    lp_ref, by_ref = _oracle_lna(oracle, setup["ch"], setup["om"], pcm, nbytes)
+    body = np.frombuffer(data[5:], np.uint8).reshape(623, -1)
+    if nbytes == 4:
+        lp = body.view("<f4")
+        # log-likelihoods within 1e-4 of the reference path (north_star); states
+        # in the float-denormal band of the reference's float storage are exempt
+        ll_ref = setup["om"].score(setup["ch"].generate(pcm, 0, 623))
+        smooth = (ll_ref > -87.0) | (ll_ref < -104.5)
+        assert np.abs(lp - lp_ref)[smooth].max() <= 1e-4
+    else:
+        code = body.reshape(623, 32, 2).astype(int)
+        code = code[..., 0] * 256 + code[..., 1]
+        cref = by_ref.reshape(623, 32, 2).astype(int)
+        cref = cref[..., 0] * 256 + cref[..., 1]
+        assert np.abs(code - cref).max() <= 1
+        assert (code == cref).mean() > 0.97
+    dec = oracle.lna_decode(data)
+    assert dec.shape == (623, 32)
+
+
+def test_frame_window_and_no_normalization(capi, oracle, setup):
+    pcm = synth.make_audio(32000, seed=11)
+    data, frames = capi.run_utterance(setup["ft"], setup["gm"], pcm, start_frame=10, end_frame=60,
+                                      normalize=False, lnabytes=4)
+    assert frames == 50
+    lp = np.frombuffer(data[5:], "<f4").reshape(50, 32)
+    lp_ref, _ = _oracle_lna(oracle, setup["ch"], setup["om"], pcm, 4, normalize=False, start=10, end=60)
+    ll_ref = setup["om"].score(setup["ch"].generate(pcm, 10, 50))
+    smooth = (ll_ref > -87.0) | (ll_ref < -104.5)
+    assert np.abs(lp - lp_ref)[smooth].max() <= 1e-4
+
+
+def test_recipe_run_and_batches(capi, oracle, setup, tmp_path):
+    lens = [16000, 24000, 9506, 40000, 12345]
+    lines = []
+    pcms = []
+    for i, n in enumerate(lens):
+        pcm = synth.make_audio(n, seed=20 + i)
+        pcms.append(pcm)
+        _write_wav(str(tmp_path / ("u%d.wav" % i)), pcm)
+        lines.append("audio=%s lna=%s" % (tmp_path / ("u%d.wav" % i), "u%d.lna" % i))
+    recipe = str(tmp_path / "r.recipe")
+    open(recipe, "w").write("# synthetic recipe\n" + "\n".join(lines) + "\n")
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    st = capi.run_recipe(setup["ft"], setup["gm"], recipe, lnabytes=2, out_dir=out)
+    assert st.utterances == 5
+    assert st.frames == sum(setup["ch"].num_frames(n) for n in lens)
+    whole = {}
+    for i, pcm in enumerate(pcms):
+        data = open(os.path.join(out, "u%d.lna" % i), "rb").read()
+        single, _ = capi.run_utterance(setup["ft"], setup["gm"], pcm, lnabytes=2)
+        assert data == single           # blocked run == per-utterance run, byte for byte
+        whole[i] = data
+    # two "ranks" with the reference's -B 2 -I k slicing reproduce the same files
+    out2 = str(tmp_path / "out2")
+    os.makedirs(out2)
+    s1 = capi.run_recipe(setup["ft"], setup["gm"], recipe, num_batches=2, batch_index=1, out_dir=out2)
+    s2 = capi.run_recipe(setup["ft"], setup["gm"], recipe, num_batches=2, batch_index=2, out_dir=out2)
+    assert (s1.utterances, s2.utterances) == (3, 2)
+    for i in range(5):
+        assert open(os.path.join(out2, "u%d.lna" % i), "rb").read() == whole[i]
+    # --no-overwrite skips existing outputs
+    s3 = capi.run_recipe(setup["ft"], setup["gm"], recipe, no_overwrite=True, out_dir=out)
+    assert s3.utterances == 0
+
+
+def test_dimension_mismatch_is_reported(capi, setup):
+    g13 = capi.Gmm.from_arrays(*synth.make_model(D=13, G=16, S=2, comps=8))
+    with pytest.raises(capi.AasrError, match="Gaussian dimension is 13 but feature dimension is 39"):
+        capi.run_utterance(setup["ft"], g13, synth.make_audio(8000))
