@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_fft(DevBatch b, const int16_t *__restri
     float a = re * re;
     float c = im * im;
     float v = a + c;
-    if (fp.magnitude) v = __fsqrt_rn(v);
+    if (fp.magnitude) v = (float)sqrt((double)v);  // == correctly rounded sqrtf
     if (fp.take_log) v = (float)log((double)v);
     out[k] = (double)v;
   };
@@ -245,7 +245,8 @@ __global__ void k_mel(DevBatch b, const double *__restrict__ src, SrcMap sm, int
   float val = 0;
   for (int e = off[bin]; e < off[bin + 1]; e++)
     val = (float)((double)val + (double)sc[e] * data[tt[e]]);
-  float q = val / sums[bin];
+  // float division, evaluated in double and rounded once (identical result)
+  float q = (float)((double)val / (double)sums[bin]);
   double o;
   if (root) {
     o = pow((double)q, 0.1);

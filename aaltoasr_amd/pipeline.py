@@ -1,0 +1,52 @@
+"""pipeline.py -- device-resident whole-path runner used by bench.py
+(BASELINE configs[2]/[3]): synthetic 16 kHz utterances -> MFCC chain ->
+state log-likelihoods -> 2-byte LNA codes, everything resident in HBM.
+
+Plumbing only: every stage is a call through the C ABI (capi.Feat / capi.Gmm /
+capi.lna_encode_dev); torch supplies device memory and the stream.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import capi, synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_CFG = os.path.join(HERE, "..", "tests", "golden", "mfcc_cms_norm.feaconf")
+
+
+class FullChainBench:
+    def __init__(self, gmm: capi.Gmm, n_utts: int, seconds: float, rank: int, device,
+                 cfg_path: str = DEFAULT_CFG, lnabytes: int = 2):
+        import torch
+        self.torch = torch
+        self.gmm = gmm
+        self.feat = capi.Feat.from_file(cfg_path)
+        self.lnabytes = lnabytes
+        sr = self.feat.sample_rate
+        n = int(round(seconds * sr))
+        # a handful of distinct seeded utterances, tiled: the audio content does
+        # not change the work, generating 1 h of noise on the host would only
+        # slow the bench start-up
+        base = [synth.make_audio(n, seed=synth.SEED + 1000 * rank + i, sample_rate=sr) for i in range(8)]
+        utts = [base[i % len(base)] for i in range(n_utts)]
+        frames = [self.feat.last_frame(len(u)) + 1 for u in utts]
+        self.pcm_off = np.concatenate([[0], np.cumsum([len(u) for u in utts])]).astype(np.int64)
+        self.frame_off = np.concatenate([[0], np.cumsum(frames)]).astype(np.int64)
+        self.total_frames = int(self.frame_off[-1])
+        self.d_pcm = torch.from_numpy(np.concatenate(utts)).to(device)
+        S = gmm.num_states
+        self.d_fea = torch.empty((self.total_frames, self.feat.dim), dtype=torch.float32, device=device)
+        self.d_ll = torch.empty((self.total_frames, S), dtype=torch.float32, device=device)
+        self.d_bytes = torch.empty((self.total_frames, S * lnabytes), dtype=torch.uint8, device=device)
+        self.stream = torch.cuda.current_stream()
+
+    def step(self) -> None:
+        self.feat.run_batch_dev(self.d_pcm, self.pcm_off, self.frame_off, self.d_fea, self.stream)
+        self.gmm.score_dev(self.d_fea, self.d_ll, self.stream)
+        capi.lna_encode_dev(self.d_ll, True, self.lnabytes, None, self.d_bytes, self.stream)
+
+    def score_only(self) -> None:
+        self.gmm.score_dev(self.d_fea, self.d_ll, self.stream)
