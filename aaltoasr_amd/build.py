@@ -79,6 +79,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    # command-line tools on top of the library
+    bindir = os.path.join(LIBDIR, "bin")
+    os.makedirs(bindir, exist_ok=True)
+    for name, src in (("phone_probs", "aku/main_phone_probs.cc"),
+                      ("aku_adapter_check", "aku/main_adapter_check.cc")):
+        srcp = os.path.join(CSRC, src)
+        exe = os.path.join(bindir, name)
+        if force or not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(srcp), os.path.getmtime(LIB)):
+            cmd = [HIPCC, "-O2", "-std=c++17", srcp, "-o", exe, "-L", LIBDIR, "-laasr",
+                   "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("building %s failed:\n%s\n%s" % (name, r.stdout, r.stderr))
     if verbose:
         print("built", LIB)
     return LIB

@@ -1,0 +1,132 @@
+// HmmSet.cc -- see HmmSet.hh.
+#include "HmmSet.hh"
+
+#include <cmath>
+#include <cstdio>
+
+namespace aku {
+
+HmmSet::HmmSet()
+    : m_gmm(nullptr), m_owner(nullptr), m_serial(0), m_first(0), m_count(0), m_row(nullptr) {}
+
+HmmSet::~HmmSet() { drop_model(); }
+
+void HmmSet::drop_model() {
+  if (m_gmm) aasr_gmm_destroy(m_gmm);
+  m_gmm = nullptr;
+  m_owner = nullptr;
+  m_count = 0;
+  m_row = nullptr;
+}
+
+static bool readable(const std::string &p) {
+  FILE *f = fopen(p.c_str(), "r");
+  if (!f) return false;
+  fclose(f);
+  return true;
+}
+
+void HmmSet::read_gk(const std::string &filename) {
+  if (!readable(filename))
+    throw std::string("PDFPool::read_gk(): could not open ") + filename + "\n";
+  m_gk = filename;
+  drop_model();
+}
+
+void HmmSet::read_mc(const std::string &filename) {
+  if (!readable(filename)) {
+    fprintf(stderr, "HmmSet::read_mc(): could not open %s\n", filename.c_str());
+    throw OpenError();
+  }
+  m_mc = filename;
+  drop_model();
+}
+
+bool HmmSet::read_ph(const std::string &filename) {
+  if (!readable(filename)) {
+    fprintf(stderr, "HmmSet::read_ph(): could not open %s\n", filename.c_str());
+    throw OpenError();
+  }
+  m_ph = filename;
+  drop_model();
+  return true;  // legacy PHONE format is the only one the reference reads too
+}
+
+void HmmSet::read_all(const std::string &base) {
+  // same order as aku/HmmSet.cc:351-357
+  read_mc(base + ".mc");
+  read_ph(base + ".ph");
+  read_gk(base + ".gk");
+  ensure_model();
+}
+
+void HmmSet::ensure_model() {
+  if (m_gmm) return;
+  if (m_gk.empty() || m_mc.empty())
+    throw std::string("HmmSet: model files have not been read");
+  aasr_status st = aasr_gmm_create_from_files(m_gk.c_str(), m_mc.c_str(),
+                                              m_ph.empty() ? nullptr : m_ph.c_str(), &m_gmm);
+  if (st == AASR_ERR_IO) throw OpenError();
+  if (st != AASR_OK) {
+    std::string msg = aasr_last_error();
+    if (msg.find("read_ph") != std::string::npos) throw ReadError();
+    throw msg;
+  }
+}
+
+int HmmSet::dim() {
+  ensure_model();
+  return aasr_gmm_dim(m_gmm);
+}
+
+int HmmSet::num_states() {
+  ensure_model();
+  return aasr_gmm_num_states(m_gmm);
+}
+
+void HmmSet::reset_cache() { m_row = nullptr; }
+
+const float *HmmSet::state_loglik_row(const FeatureVec &f) {
+  ensure_model();
+  const int S = aasr_gmm_num_states(m_gmm);
+  const FeatureGenerator *own = f.owner();
+  if (own) {
+    int first = 0, count = 0;
+    const float *blk = own->block_f32(f.frame(), &first, &count);
+    if (blk) {
+      if (m_owner != own || m_serial != own->block_serial() || m_count == 0) {
+        m_block_ll.resize((size_t)count * S);
+        if (aasr_gmm_score(m_gmm, blk, count, m_block_ll.data()) != AASR_OK)
+          throw std::string(aasr_last_error());
+        m_owner = own;
+        m_serial = own->block_serial();
+        m_first = first;
+        m_count = count;
+      }
+      return &m_block_ll[(size_t)(f.frame() - m_first) * S];
+    }
+  }
+  // a vector that does not come from a cached block: score it alone
+  if (f.dim() != aasr_gmm_dim(m_gmm))
+    throw std::string("HmmSet: feature dimension does not match the model");
+  std::vector<float> x;
+  f.get(x);
+  m_single_ll.resize(S);
+  if (aasr_gmm_score(m_gmm, x.data(), 1, m_single_ll.data()) != AASR_OK)
+    throw std::string(aasr_last_error());
+  return m_single_ll.data();
+}
+
+void HmmSet::precompute_likelihoods(const FeatureVec &f) {
+  reset_cache();
+  m_row = state_loglik_row(f);
+}
+
+double HmmSet::state_likelihood(const int s, const FeatureVec &f) {
+  if (!m_row) m_row = state_loglik_row(f);  // lazy style: reset_cache() then single states
+  if (s < 0 || s >= aasr_gmm_num_states(m_gmm)) throw std::string("HmmSet: state index out of range");
+  // the row holds log(max(lik, 1e-50)) (aku/HmmSet.cc:497-498)
+  return std::exp((double)m_row[s]);
+}
+
+}  // namespace aku

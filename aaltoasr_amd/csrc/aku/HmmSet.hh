@@ -1,0 +1,72 @@
+// HmmSet.hh -- aku::HmmSet scoring surface on top of the C ABI.
+//
+// Mirrors the subset of aku/HmmSet.hh callers on the scoring path use
+// (:120,163,246-271,299-321,474-493,511-534): read_all / read_gk / read_mc /
+// read_ph, dim, num_states, reset_cache, precompute_likelihoods,
+// state_likelihood, pdf_likelihood, and the OpenError / ReadError exceptions.
+// Likelihood caches in the reference are caller-managed per frame
+// (reset_cache() whenever the frame changes, HmmSet.cc:444-457); here a frame
+// that came from a FeatureGenerator block is scored together with its whole
+// block on the device the first time any of its frames is asked for, and
+// reset_cache() only drops the current-frame view.
+#ifndef AKU_AMD_HMMSET_HH
+#define AKU_AMD_HMMSET_HH
+
+#include <exception>
+#include <string>
+#include <vector>
+
+#include "FeatureGenerator.hh"
+
+namespace aku {
+
+class HmmSet {
+public:
+  struct OpenError : public std::exception {
+    virtual const char *what() const throw() { return "HmmSet: open error"; }
+  };
+  struct ReadError : public std::exception {
+    virtual const char *what() const throw() { return "HmmSet: read error"; }
+  };
+
+  HmmSet();
+  ~HmmSet();
+
+  void read_all(const std::string &base);
+  void read_gk(const std::string &filename);
+  void read_mc(const std::string &filename);
+  bool read_ph(const std::string &filename);
+
+  int dim();
+  int num_states();
+  int num_emission_pdfs() { return num_states(); }
+
+  void reset_cache();
+  void precompute_likelihoods(const FeatureVec &f);
+  double state_likelihood(const int s, const FeatureVec &f);
+  double pdf_likelihood(const int p, const FeatureVec &f) { return state_likelihood(p, f); }
+
+  aasr_gmm *handle() {
+    ensure_model();
+    return m_gmm;
+  }
+  /** log state likelihoods of the cached block row for f (S floats) */
+  const float *state_loglik_row(const FeatureVec &f);
+
+private:
+  void ensure_model();
+  void drop_model();
+  std::string m_gk, m_mc, m_ph;
+  aasr_gmm *m_gmm;
+  // block cache
+  const FeatureGenerator *m_owner;
+  uint64_t m_serial;
+  int m_first, m_count;
+  std::vector<float> m_block_ll;  // [count x S]
+  std::vector<float> m_single_ll;  // one frame, for vectors without a block
+  const float *m_row;
+};
+
+}  // namespace aku
+
+#endif

@@ -1,0 +1,88 @@
+// PhoneProbsToolbox.cc -- see PhoneProbsToolbox.hh.
+#include "PhoneProbsToolbox.hh"
+
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace aasr {
+std::vector<int16_t> read_audio_file(const std::string &path, bool force_raw, int expect_rate);
+}
+
+namespace aku {
+
+void PPToolbox::read_configuration(const std::string &cfgname) {
+  FILE *fp = fopen(cfgname.c_str(), "r");
+  if (!fp) throw std::string("could not open ") + cfgname;
+  try {
+    m_gen.load_configuration(fp);
+  } catch (...) {
+    fclose(fp);
+    throw;
+  }
+  fclose(fp);
+}
+
+void PPToolbox::read_models(const std::string &base) { m_model.read_all(base); }
+
+static void write_all(int fd, const uint8_t *p, size_t n) {
+  while (n > 0) {
+    ssize_t w = write(fd, p, n);
+    if (w <= 0) throw std::string("Write error");
+    p += w;
+    n -= (size_t)w;
+  }
+}
+
+static void run(FeatureGenerator &gen, HmmSet &model, const std::vector<int16_t> &pcm, int out_fd) {
+  if (model.dim() != gen.dim()) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "Gaussian dimension is %d but feature dimension is %d.", model.dim(),
+             gen.dim());
+    throw std::string(buf);
+  }
+  uint8_t *lna = nullptr;
+  int64_t len = 0, frames = 0;
+  if (aasr_run_utterance(gen.handle(), model.handle(), pcm.data(), (int64_t)pcm.size(), 0, 0, 1, 2,
+                         &lna, &len, &frames) != AASR_OK)
+    throw std::string(aasr_last_error());
+  try {
+    write_all(out_fd, lna, (size_t)len);
+  } catch (...) {
+    aasr_free(lna);
+    throw;
+  }
+  aasr_free(lna);
+}
+
+void PPToolbox::generate_from_file_to_fd(const std::string &input, int out_fd, bool raw) {
+  std::vector<int16_t> pcm = aasr::read_audio_file(input, raw, raw ? 0 : m_gen.sample_rate());
+  run(m_gen, m_model, pcm, out_fd);
+}
+
+void PPToolbox::generate_to_fd(int in_fd, int out_fd, bool) {
+  std::vector<uint8_t> data;
+  uint8_t buf[65536];
+  ssize_t n;
+  while ((n = read(in_fd, buf, sizeof buf)) > 0) data.insert(data.end(), buf, buf + n);
+  std::vector<int16_t> pcm(data.size() / 2);
+  for (size_t i = 0; i < pcm.size(); i++) pcm[i] = (int16_t)(data[2 * i] | (data[2 * i + 1] << 8));
+  run(m_gen, m_model, pcm, out_fd);
+}
+
+void PPToolbox::generate(const std::string &input, const std::string &output, bool raw) {
+  FILE *fp = fopen(output.c_str(), "wb");
+  if (!fp) throw std::string("could not open ") + output;
+  try {
+    fflush(fp);
+    generate_from_file_to_fd(input, fileno(fp), raw);
+  } catch (...) {
+    fclose(fp);
+    throw;
+  }
+  fclose(fp);
+}
+
+}  // namespace aku

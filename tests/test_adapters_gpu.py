@@ -1,0 +1,97 @@
+"""The aku-shaped C++ surface on the GPU: the reference tool's command line
+(phone_probs) and the reference's own per-frame calling sequence written
+against aku::FeatureGenerator / aku::HmmSet adapters."""
+import os
+import subprocess
+import wave
+
+import numpy as np
+import pytest
+
+from aaltoasr_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+BIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aaltoasr_amd", "lib", "bin")
+
+
+def _write_wav(path, pcm, rate=16000):
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(rate)
+        w.writeframes(pcm.astype("<i2").tobytes())
+
+
+@pytest.fixture(scope="module")
+def world(capi, oracle, golden_dir, tmp_path_factory):
+    d = tmp_path_factory.mktemp("aku")
+    cfg_path = os.path.join(golden_dir, "mfcc_cms_norm.feaconf")
+    model = synth.make_model(D=39, G=256, S=32, comps=8)
+    base = str(d / "model")
+    oracle.write_gk(base + ".gk", model[0], model[1])
+    oracle.write_mc(base + ".mc", model[2], model[3], model[4])
+    oracle.write_ph(base + ".ph", 32)
+    pcms = [synth.make_audio(n, seed=40 + i) for i, n in enumerate([80000, 16000, 30000])]
+    lines = []
+    for i, p in enumerate(pcms):
+        _write_wav(str(d / ("a%d.wav" % i)), p)
+        lines.append("audio=%s lna=%s" % (d / ("a%d.wav" % i), d / ("a%d.lna" % i)))
+    recipe = str(d / "test.recipe")
+    open(recipe, "w").write("\n".join(lines) + "\n")
+    return dict(dir=d, cfg=cfg_path, base=base, pcms=pcms, recipe=recipe, model=model,
+                ft=capi.Feat.from_file(cfg_path), gm=capi.Gmm.from_files(base + ".gk", base + ".mc", base + ".ph"))
+
+
+@pytest.mark.parametrize("nbytes", [2, 4])
+def test_phone_probs_cli(capi, world, nbytes):
+    out = world["dir"] / ("cli%d" % nbytes)
+    os.makedirs(out)
+    r = subprocess.run([os.path.join(BIN, "phone_probs"), "-b", world["base"], "-c", world["cfg"],
+                        "-r", world["recipe"], "-a", "-o", str(out), "--lnabytes=%d" % nbytes, "-i", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Processing file 1/3" in r.stdout
+    for i, pcm in enumerate(world["pcms"]):
+        want, _ = capi.run_utterance(world["ft"], world["gm"], pcm, lnabytes=nbytes)
+        assert open(out / ("a%d.lna" % i), "rb").read() == want
+
+
+def test_phone_probs_cli_batches_and_errors(world):
+    exe = os.path.join(BIN, "phone_probs")
+    out = world["dir"] / "clib"
+    os.makedirs(out)
+    for k in (1, 2):
+        r = subprocess.run([exe, "-b", world["base"], "-c", world["cfg"], "-r", world["recipe"], "-a",
+                            "-o", str(out), "-B", "2", "-I", str(k)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+    assert sorted(os.listdir(out)) == ["a0.lna", "a1.lna", "a2.lna"]
+    r = subprocess.run([exe, "-b", world["base"], "-c", world["cfg"], "-r", world["recipe"], "-B", "2"],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "Must give both --batch and --bindex" in r.stderr
+    r = subprocess.run([exe, "-b", world["base"], "-c", world["cfg"], "-r", world["recipe"], "-C", "x.gcl"],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "not built" in r.stderr
+    r = subprocess.run([exe, "-c", world["cfg"], "-r", world["recipe"]], capture_output=True, text=True)
+    assert r.returncode != 0 and "Must give either --base" in r.stderr
+
+
+@pytest.mark.parametrize("nbytes", [2, 4])
+def test_reference_style_frame_loop_on_adapters(capi, oracle, world, nbytes):
+    """aku_adapter_check is phone_probs.cc's frame loop verbatim on the adapter
+    classes: generate(f) / eof() / reset_cache / precompute_likelihoods /
+    state_likelihood, float normalisation on the host."""
+    out = str(world["dir"] / ("loop%d.lna" % nbytes))
+    r = subprocess.run([os.path.join(BIN, "aku_adapter_check"), world["cfg"], world["base"],
+                        str(world["dir"] / "a0.wav"), out, str(nbytes)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = open(out, "rb").read()
+    eng, frames = capi.run_utterance(world["ft"], world["gm"], world["pcms"][0], lnabytes=nbytes)
+    assert frames == 623 and len(got) == len(eng) and got[:5] == eng[:5]
+    a = oracle.lna_decode(got)
+    b = oracle.lna_decode(eng)
+    ch = oracle.FeatureChain(open(world["cfg"]).read())
+    ll_ref = oracle.DiagModel(*world["model"]).score(ch.generate(world["pcms"][0], 0, 623))
+    smooth = (ll_ref > -87.0) | (ll_ref < -104.5)
+    tol = 1.0 / 1820 + 1e-6 if nbytes == 2 else 2e-5
+    assert np.abs(a - b)[smooth].max() <= tol
