@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument("--workload", choices=["gmm", "full"], default=os.environ.get("AASR_BENCH_WORKLOAD", "gmm"))
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step (gmm workload)")
     ap.add_argument("--utts", type=int, default=360, help="10-s utterances per GPU per step (full workload)")
-    ap.add_argument("--cpu-frames", type=int, default=4000, help="frames timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=20000, help="frames timed on the CPU baseline (0 = skip)")
     return ap.parse_args()
 
 
@@ -77,9 +77,18 @@ def main():
         dist.barrier()
     capi.check(capi.lib().aasr_set_device(local_rank))
 
-    # ---- model: identical on every rank (seeded), like every aku process
-    # reading the same .gk/.mc files (phone_probs.cc:96-110)
-    mean, var, off, idx, w = synth.make_model(D=DIM, G=G, S=S, comps=COMPS)
+    # ---- model: built on rank 0 and broadcast once (RCCL over xGMI) -- the only
+    # collective of the job; the reference has every process re-read the
+    # .gk/.mc files instead (phone_probs.cc:96-110)
+    names = ["mean", "var", "mix_off", "mix_idx", "mix_w"]
+    if rank == 0:
+        model = dict(zip(names, synth.make_model(D=DIM, G=G, S=S, comps=COMPS)))
+    else:
+        model = dict.fromkeys(names)
+    if world > 1:
+        from aaltoasr_amd import shard
+        model = shard.broadcast_model(model, src=0, device=dev)
+    mean, var, off, idx, w = (model[k] for k in names)
     gmm = capi.Gmm.from_arrays(mean, var, off, idx, w)
     rows = gmm.expanded_rows
 
@@ -148,6 +157,10 @@ def main():
         "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
         "kernel_ms": round(k_ms, 4), "algorithmic_flop_per_launch": algo_flop,
     }
+    td = _pmc_traffic(F)
+    if td:
+        roofline["traffic"] = td["bytes"]
+        roofline["traffic_detail"] = td
 
     # ---- CPU baseline (rank 0, N=1 only): oracle's reference-shaped loop
     cpu = None
@@ -182,6 +195,28 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _pmc_traffic(frames):
+    """HBM bytes per launch of k_gmm_diag_score from the committed rocprofv3 PMC
+    passes (profiles/*_pmc*.json: FETCH_SIZE and WRITE_SIZE in KiB, collected in
+    separate passes at 1 000 000 frames/launch; FETCH_SIZE doubled per
+    MI355X_MICROARCH.md's gfx950 note), scaled to this launch's frame count.
+    None when no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*gmm_pmc*.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        fetch = d["FETCH_SIZE"]["mean_per_launch"] * 1024.0 * 2.0
+        write = d["WRITE_SIZE"]["mean_per_launch"] * 1024.0
+        base = float(d.get("frames_per_launch", 1_000_000))
+        return {"bytes": round((fetch + write) * frames / base), "fetch_bytes": round(fetch * frames / base),
+                "write_bytes": round(write * frames / base), "source": os.path.basename(files[-1]),
+                "algorithmic_bytes": int(frames * (DIM * 4 + S * 4) + G * (2 * DIM + 1) * 4)}
+    except Exception:
+        return None
 
 
 def _cpu_model():
