@@ -32,6 +32,8 @@ constexpr int CHUNK_ROWS = 32;
 constexpr int FRAMES_PER_WAVE = 64;
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int FRAMES_PER_BLOCK = FRAMES_PER_WAVE * WAVES_PER_BLOCK;
+constexpr int PAIRED_OUT_GROUP = 32;   // states written per frame row at a time
+constexpr int PAIRED_MAX_SPLITS = 16;  // row-range cuts available to the launcher
 
 // Kernel instances exist for these K/2 values; a model uses the smallest one
 // that holds dim+1 (zero-padded beyond).
@@ -70,6 +72,15 @@ struct aasr_gmm {
   aasr::PackedRows mix;             // component-expanded, per-state reduce
   aasr::PackedRows pool;            // pool Gaussians, raw log-likelihoods
   bool pool_built = false;
+  // paired-track layout for the in-register epilogue (built when eligible)
+  aasr::PackedRows paired;
+  aasr::DevBuf<uint8_t> paired_close;  // per tile: bit p = a state pair closes after quad p
+  int64_t paired_rows_padded = 0;
+  float paired_ref_ln = 0.0f;          // reference exponent * ln 2
+  aasr::DevBuf<int32_t> paired_splits; // [MAX_SPLITS][MAX_SPLITS+1][2]: tile, pairs closed
+  int paired_max_splits = 1;
+  int num_cus = 0;
+  bool paired_ok = false;
   // staging for the host-buffer entry points
   aasr::DevBuf<float> d_frames, d_out;
 };

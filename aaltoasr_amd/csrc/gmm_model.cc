@@ -137,8 +137,9 @@ HostModel read_model_files(const char *gk, const char *mc, const char *ph) {
 // ---------------------------------------------------------------------------
 
 struct RowSpec {
-  int64_t g;        // pool Gaussian
+  int64_t g;        // pool Gaussian, < 0 for a null (padding) row
   double logw;      // log mixture weight (natural), -inf for zero weight
+  double bias = 0;  // added to the constant in log2 units (paired layout reference)
 };
 
 // Write rows into the [tiles][nkk/2][64][4] layout the kernel streams:
@@ -162,7 +163,7 @@ static void pack_rows(const aasr_gmm *g, const std::vector<RowSpec> &rows,
   std::vector<double> coef(2 * (size_t)nkk);
   for (int64_t r = 0; r < out.tiles * TILE_ROWS; r++) {
     std::fill(coef.begin(), coef.end(), 0.0);
-    if (r < out.rows) {
+    if (r < out.rows && rows[(size_t)r].g >= 0) {
       const RowSpec &rs = rows[(size_t)r];
       const double *mu = &m.mean[(size_t)rs.g * D];
       const double *var = &m.var[(size_t)rs.g * D];
@@ -187,7 +188,7 @@ static void pack_rows(const aasr_gmm *g, const std::vector<RowSpec> &rows,
                 "Gaussian %ld has a non-finite constant (precision product overflow)", (long)rs.g);
         coef[2 * D] = kNullConst;
       } else {
-        coef[2 * D] = c * kLog2e;
+        coef[2 * D] = c * kLog2e + rs.bias;
       }
     } else {
       coef[2 * D] = kNullConst;  // padding row: contributes exp2(-1e30 - max) = 0
@@ -209,8 +210,16 @@ static void pack_rows(const aasr_gmm *g, const std::vector<RowSpec> &rows,
   out.a.upload(a.data(), a.size());
 }
 
+void gmm_build_paired(aasr_gmm *g);
+
 void gmm_build(aasr_gmm *g, const HostModel &model) {
   require_device();
+  {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+      g->num_cus = cus;
+  }
   g->host = model;
   HostModel &m = g->host;
   g->dim = m.dim;
@@ -289,6 +298,139 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
   g->mix.chunk_seg_begin.upload(chunk_seg_begin.data(), chunk_seg_begin.size());
   g->mix.seg_desc.upload(seg_desc.data(), seg_desc.size());
   g->mix.seg_out.upload(seg_out.data(), seg_out.size());
+  gmm_build_paired(g);
+}
+
+// Paired-track layout for the in-register epilogue (k_gmm_diag_score_paired).
+//
+// In a 32x32 MFMA accumulator block lane (n, h) holds, for frame column n, the
+// 16 rows {8q + 4h + e : q < 4, e < 4}.  Rows are therefore laid out as two
+// "tracks" h = 0/1 of 4-row quads; states 2j and 2j+1 sit side by side on tracks
+// 0 and 1 over the same quads (the shorter one padded with null rows), so each
+// lane sums its own state's components straight out of its accumulator
+// registers.  No running maximum is needed: a fixed reference 2^kPairedRef is
+// folded into the constants, valid as long as every component's peak value
+// (c_g + log w) leaves headroom in the f32 exponent -- checked here.
+// The reference exponent is chosen per model: as large as the peaks allow (cap
+// 72), and at least 56 so that components 2^16 below the 1e-50 state floor
+// (2^-166) still land in the normal f32 range (v_exp_f32 flushes denormals).
+static const double kPairedRefMin = 56.0, kPairedRefMax = 72.0;
+static const double kPairedPeakMax = 120.0;   // max (peak*log2e + ref) accepted
+
+void gmm_build_paired(aasr_gmm *g) {
+  const HostModel &m = g->host;
+  g->paired_ok = false;
+  const int D = m.dim;
+  // eligibility 1: exponent headroom
+  double max_peak_log2 = -INFINITY;
+  for (size_t k = 0; k < m.mix_idx.size(); k++) {
+    const double *var = &m.var[(size_t)m.mix_idx[k] * D];
+    double prod = 1;
+    for (int d = 0; d < D; d++) prod *= (var[d] > 0) ? 1 / var[d] : 0;
+    double cst = (prod > 0) ? std::log(std::sqrt(prod)) : prod;
+    double w = m.mix_w[k];
+    double peak = cst + (w > 0 ? std::log(w) : -INFINITY);
+    if (std::isnan(peak) || peak == INFINITY) return;
+    max_peak_log2 = std::max(max_peak_log2, peak * kLog2e);
+  }
+  double ref = std::floor(std::min(kPairedRefMax, kPairedPeakMax - max_peak_log2));
+  if (!(ref >= kPairedRefMin)) return;
+  const double kPairedRef = ref;
+  g->paired_ref_ln = (float)(ref * 0.69314718055994530942);
+  // eligibility 2: padding overhead (pairs padded to a common number of quads)
+  const int64_t pairs = (m.S + 1) / 2;
+  int64_t quads = 0;
+  std::vector<int32_t> pair_quads((size_t)pairs);
+  for (int64_t j = 0; j < pairs; j++) {
+    int64_t n0 = m.mix_off[2 * j + 1] - m.mix_off[2 * j];
+    int64_t n1 = (2 * j + 1 < m.S) ? m.mix_off[2 * j + 2] - m.mix_off[2 * j + 1] : 0;
+    int64_t q = std::max<int64_t>(1, (std::max(n0, n1) + 3) / 4);
+    pair_quads[(size_t)j] = (int32_t)q;
+    quads += q;
+  }
+  const int64_t rows_padded = quads * 8;
+  const int64_t rows_real = std::max<int64_t>(1, (int64_t)m.mix_idx.size());
+  if ((double)rows_padded > 1.25 * (double)rows_real + 64) return;
+
+  const int64_t tiles = (quads + 7) / 8;  // 8 quad positions per 64-row tile
+  std::vector<RowSpec> rows((size_t)tiles * TILE_ROWS, RowSpec{-1, 0.0, 0.0});
+  std::vector<uint8_t> close_mask((size_t)tiles, 0);
+  int64_t p = 0;  // quad position along the tracks
+  for (int64_t j = 0; j < pairs; j++) {
+    for (int h = 0; h < 2; h++) {
+      int64_t s = 2 * j + h;
+      if (s >= m.S) continue;
+      int32_t a = m.mix_off[s], b = m.mix_off[s + 1];
+      for (int32_t k = a; k < b; k++) {
+        int64_t pos = p + (k - a) / 4;
+        int e = (k - a) % 4;
+        int64_t t = pos / 8;
+        int mb = (int)((pos / 4) % 2), q = (int)(pos % 4);
+        int64_t row = t * TILE_ROWS + mb * 32 + 8 * q + 4 * h + e;
+        double w = m.mix_w[k];
+        rows[(size_t)row] = RowSpec{m.mix_idx[k], (w > 0) ? std::log(w) : -INFINITY, kPairedRef};
+      }
+    }
+    p += pair_quads[(size_t)j];
+    int64_t last = p - 1;
+    close_mask[(size_t)(last / 8)] |= (uint8_t)(1u << (last % 8));
+  }
+  // Row-split table: the tile range can be cut into R contiguous chunks that
+  // different workgroups score for the same frames (finer work quanta -> no
+  // tail round on the 256 CUs).  A cut is legal where no state pair is open
+  // and the number of finished states is a multiple of the 32-state output
+  // group.  Row R-1 of the table holds R+1 tile boundaries and the number of
+  // pairs closed before each.
+  {
+    std::vector<int64_t> cand_tile{0}, cand_pairs{0};
+    int64_t closed = 0;
+    for (int64_t t = 0; t < tiles; t++) {
+      closed += __builtin_popcount(close_mask[(size_t)t]);
+      bool ends_closed = (close_mask[(size_t)t] >> 7) & 1;
+      if (t + 1 < tiles && ends_closed && closed % (PAIRED_OUT_GROUP / 2) == 0) {
+        cand_tile.push_back(t + 1);
+        cand_pairs.push_back(closed);
+      }
+    }
+    cand_tile.push_back(tiles);
+    cand_pairs.push_back(closed);
+    std::vector<int32_t> table((size_t)PAIRED_MAX_SPLITS * (PAIRED_MAX_SPLITS + 1) * 2, 0);
+    g->paired_max_splits = 1;
+    for (int R = 1; R <= PAIRED_MAX_SPLITS; R++) {
+      std::vector<size_t> pick{0};
+      bool ok = true;
+      for (int i = 1; i < R && ok; i++) {
+        double want = (double)tiles * i / R;
+        size_t best = pick.back();
+        double bd = 1e300;
+        for (size_t c = pick.back() + 1; c + 1 < cand_tile.size(); c++) {
+          double d = std::fabs((double)cand_tile[c] - want);
+          if (d < bd) { bd = d; best = c; }
+        }
+        if (best == pick.back()) ok = false;
+        pick.push_back(best);
+      }
+      if (!ok) break;
+      pick.push_back(cand_tile.size() - 1);
+      // reject very uneven cuts (chunk more than 25 % above the mean)
+      int64_t worst = 0;
+      for (int i = 0; i < R; i++)
+        worst = std::max(worst, cand_tile[pick[i + 1]] - cand_tile[pick[i]]);
+      if ((double)worst > 1.25 * (double)tiles / R + 1) break;
+      int32_t *row = &table[(size_t)(R - 1) * (PAIRED_MAX_SPLITS + 1) * 2];
+      for (int i = 0; i <= R; i++) {
+        row[2 * i] = (int32_t)cand_tile[pick[i]];
+        row[2 * i + 1] = (int32_t)cand_pairs[pick[i]];
+      }
+      g->paired_max_splits = R;
+    }
+    g->paired_splits.upload(table.data(), table.size());
+  }
+  pack_rows(g, rows, g->paired, nullptr);
+  g->paired.rows = (int64_t)m.mix_idx.size();  // real rows (algorithmic work)
+  g->paired_close.upload(close_mask.data(), close_mask.size());
+  g->paired_rows_padded = rows_padded;
+  g->paired_ok = true;
 }
 
 void gmm_build_pool(aasr_gmm *g) {

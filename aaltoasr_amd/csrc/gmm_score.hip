@@ -267,6 +267,206 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score(
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Paired-track variant: in-register epilogue (see gmm_build_paired()).
+//
+// The host lays states 2j / 2j+1 on the two row tracks that lane halves h = 0 /
+// 1 hold in their accumulator registers, and folds a fixed reference 2^ref into
+// the constants, so the epilogue is 16 v_exp_f32 + 16 adds per accumulator
+// block with no LDS round trip, no running maximum and no descriptor loads
+// beyond one byte per tile.  Finished states are transposed through a
+// wave-private LDS buffer and written OG consecutive states per frame row.
+// ---------------------------------------------------------------------------
+
+template <int NKK, int OG>
+struct PairedSmem {
+  static constexpr int kTileFloats = (NKK / 2) * 64 * 4;
+  static constexpr int kOutStride = OG + 1;  // +1: conflict-free column writes
+  static constexpr int kOutFloatsPerWave = FRAMES_PER_WAVE * kOutStride;
+  static constexpr int kBytes = (2 * kTileFloats + WAVES_PER_BLOCK * kOutFloatsPerWave) * 4;
+};
+
+template <int NKK, int OG>
+__global__ __launch_bounds__(256, 2) void k_gmm_diag_score_paired(
+    const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
+    const float *__restrict__ apack, const int32_t *__restrict__ split_row,
+    const uint8_t *__restrict__ close_mask, float *__restrict__ out, int64_t S, float ref_ln,
+    int dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *smem = (float *)smem_raw;
+  constexpr int kTileFloats = PairedSmem<NKK, OG>::kTileFloats;
+  constexpr int kOS = PairedSmem<NKK, OG>::kOutStride;
+  float *abuf0 = smem;
+  float *abuf1 = smem + kTileFloats;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  float *ost = smem + 2 * kTileFloats + wave * PairedSmem<NKK, OG>::kOutFloatsPerWave;
+  const int n = lane & 31;
+  const int h = lane >> 5;
+  const int64_t f0 = (int64_t)blockIdx.x * FRAMES_PER_BLOCK + wave * FRAMES_PER_WAVE;
+
+  float bf[NKK][2];
+#pragma unroll
+  for (int nb = 0; nb < 2; nb++) {
+    int64_t f = f0 + nb * 32 + n;
+    if (f > F - 1) f = F - 1;
+    const float *xr = frames + f * dim;
+#pragma unroll
+    for (int kk = 0; kk < NKK; kk++) {
+      const int kc = kk < dim ? kk : 0;
+      const float xc = xr[kc] - pivot[kc];
+      float v = h ? xc * xc : xc;
+      if (kk == dim) v = h ? 0.0f : 1.0f;
+      if (kk > dim) v = 0.0f;
+      bf[kk][nb] = v;
+    }
+  }
+
+  // this workgroup's share of the rows: tiles [t_begin, t_end)
+  const int64_t t_begin = split_row[2 * blockIdx.y];
+  const int64_t t_end = split_row[2 * blockIdx.y + 2];
+  issue_tile_copy(apack + (size_t)t_begin * kTileFloats, abuf0, kTileFloats, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  float s0 = 0.0f, s1 = 0.0f;  // running sum_k 2^(v_k) of this lane's open state, frames n / 32+n
+  int pairs_closed = split_row[2 * blockIdx.y + 1];
+
+  for (int64_t t = t_begin; t < t_end; t++) {
+    const int par = (int)((t - t_begin) & 1);
+    float *acur = par ? abuf1 : abuf0;
+    float *anext = par ? abuf0 : abuf1;
+    if (t + 1 < t_end)
+      issue_tile_copy(apack + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
+    const unsigned mask = close_mask[t];
+
+    f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
+    const f32x4 *afrag = (const f32x4 *)acur + lane;
+    f32x4 a0 = afrag[0];
+    f32x4 a1 = afrag[(NKK / 2 > 1 ? 1 : 0) * 64];
+#pragma unroll
+    for (int q = 0; q < NKK / 2; q++) {
+      const int qn = (q + 2 < NKK / 2) ? q + 2 : NKK / 2 - 1;
+      f32x4 a2 = afrag[qn * 64];
+      const f32x4 av = a0;
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf[2 * q][0], c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf[2 * q][1], c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf[2 * q][0], c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf[2 * q][1], c11, 0, 0, 0);
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf[2 * q + 1][0], c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf[2 * q + 1][1], c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf[2 * q + 1][0], c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf[2 * q + 1][1], c11, 0, 0, 0);
+      a0 = a1;
+      a1 = a2;
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    if (dbg & 1) {
+      asm volatile("" ::"v"(c00), "v"(c01), "v"(c10), "v"(c11));
+      continue;
+    }
+
+#pragma unroll
+    for (int mb = 0; mb < 2; mb++) {
+      const f32x16 &ca = mb ? c10 : c00;
+      const f32x16 &cb = mb ? c11 : c01;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        // this lane's quad q of the block: accumulator registers 4q .. 4q+3
+        float e0 = __builtin_amdgcn_exp2f(ca[4 * q]) + __builtin_amdgcn_exp2f(ca[4 * q + 1]);
+        float e1 = __builtin_amdgcn_exp2f(ca[4 * q + 2]) + __builtin_amdgcn_exp2f(ca[4 * q + 3]);
+        float g0 = __builtin_amdgcn_exp2f(cb[4 * q]) + __builtin_amdgcn_exp2f(cb[4 * q + 1]);
+        float g1 = __builtin_amdgcn_exp2f(cb[4 * q + 2]) + __builtin_amdgcn_exp2f(cb[4 * q + 3]);
+        s0 += e0 + e1;
+        s1 += g0 + g1;
+        if ((mask >> (mb * 4 + q)) & 1) {
+          float l0 = fmaf(__builtin_amdgcn_logf(s0), LN2_F, -ref_ln);
+          float l1 = fmaf(__builtin_amdgcn_logf(s1), LN2_F, -ref_ln);
+          l0 = fmaxf(l0, LOG_TINY_F);
+          l1 = fmaxf(l1, LOG_TINY_F);
+          const int slot = ((2 * pairs_closed) & (OG - 1)) + h;
+          ost[n * kOS + slot] = l0;
+          ost[(32 + n) * kOS + slot] = l1;
+          s0 = 0.0f;
+          s1 = 0.0f;
+          pairs_closed++;
+          const int64_t closed = 2 * (int64_t)pairs_closed < S ? 2 * (int64_t)pairs_closed : S;
+          if ((((2 * pairs_closed) & (OG - 1)) == 0 || 2 * (int64_t)pairs_closed >= S) && !(dbg & 16)) {
+            const int64_t s_base = ((closed - 1) / OG) * OG;
+            const int cnt = (int)(closed - s_base);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            constexpr int RPI = 64 / OG;  // frame rows per store instruction
+            const int k = lane & (OG - 1);
+#pragma unroll 4
+            for (int i = 0; i < FRAMES_PER_WAVE / RPI; i++) {
+              const int row = i * RPI + lane / OG;
+              const float v = ost[row * kOS + k];
+              if (k < cnt && f0 + row < F) out[(f0 + row) * S + s_base + k] = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int NKK, int OG>
+static void launch_paired_t(const aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
+                            hipStream_t stream) {
+  const int64_t blocks = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
+  const int smem = PairedSmem<NKK, OG>::kBytes;
+  static const int dbg = getenv("AASR_DBG") ? atoi(getenv("AASR_DBG")) : 0;
+  static bool attr_set[64] = {false};
+  auto kern = k_gmm_diag_score_paired<NKK, OG>;
+  if (!attr_set[g->device & 63]) {
+    AASR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set[g->device & 63] = true;
+  }
+  // Row-range cuts: pick the number of cuts R that leaves the smallest tail
+  // round on the chip (2 workgroups per CU resident), preferring fewer cuts.
+  static const int force_r = getenv("AASR_SPLITS") ? atoi(getenv("AASR_SPLITS")) : 0;
+  const double slots = 2.0 * (g->num_cus > 0 ? g->num_cus : 256);
+  int R = 1;
+  double best_eff = 0;
+  for (int r = 1; r <= g->paired_max_splits; r++) {
+    double x = (double)blocks * r / slots;
+    double eff = x / std::ceil(x);
+    if (eff > best_eff + 0.005) {
+      best_eff = eff;
+      R = r;
+    }
+  }
+  if (force_r >= 1 && force_r <= g->paired_max_splits) R = force_r;
+  const int32_t *split_row = g->paired_splits.p + (size_t)(R - 1) * (PAIRED_MAX_SPLITS + 1) * 2;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(256), smem, stream, d_frames, F,
+                     g->dim, g->d_pivot.p, g->paired.a.p, split_row, g->paired_close.p, d_out, g->S,
+                     g->paired_ref_ln, dbg);
+  AASR_HIP(hipGetLastError());
+}
+
+static bool launch_paired(const aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
+                          hipStream_t stream) {
+  switch (g->paired.nkk) {
+#define AASR_CASE(N)                                                              \
+  case N:                                                                         \
+    launch_paired_t<N, PAIRED_OUT_GROUP>(g, d_frames, F, d_out, stream);          \
+    return true;
+    AASR_CASE(8) AASR_CASE(14) AASR_CASE(20) AASR_CASE(26) AASR_CASE(32) AASR_CASE(40)
+    AASR_CASE(48) AASR_CASE(64)
+#undef AASR_CASE
+    default:
+      return false;
+  }
+}
+
 template <int NKK, int MODE>
 static void launch_t(const aasr_gmm *g, const PackedRows &pr, const float *d_frames,
                      int64_t F, float *d_out, int64_t out_cols, hipStream_t stream) {
@@ -320,6 +520,9 @@ extern "C" int aasr_debug_score_occupancy(void) {
 
 void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                       hipStream_t stream) {
+  if (F <= 0) return;
+  static const bool no_paired = getenv("AASR_NO_PAIRED") != nullptr;
+  if (g->paired_ok && !no_paired && launch_paired(g, d_frames, F, d_out, stream)) return;
   launch<0>(g, g->mix, d_frames, F, d_out, g->S, stream);
 }
 
