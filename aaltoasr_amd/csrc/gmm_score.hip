@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score(
 template <int NKK, int OG>
 struct PairedSmem {
   static constexpr int kTileFloats = (NKK / 2) * 64 * 4;
-  static constexpr int kOutStride = OG + 1;  // +1: conflict-free column writes
+  static constexpr int kOutStride = OG + 4;  // 16-byte aligned rows for ds_read_b128
   static constexpr int kOutFloatsPerWave = FRAMES_PER_WAVE * kOutStride;
   static constexpr int kBytes = (2 * kTileFloats + WAVES_PER_BLOCK * kOutFloatsPerWave) * 4;
 };
@@ -401,13 +401,28 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_paired(
             const int cnt = (int)(closed - s_base);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            constexpr int RPI = 64 / OG;  // frame rows per store instruction
-            const int k = lane & (OG - 1);
+            if (cnt == OG && f0 + FRAMES_PER_WAVE <= F) {
+              // full group: each lane moves 4 consecutive states (16 B) of one
+              // frame row; 8 lanes cover the 32-state group, 8 rows per instruction
+              const int k4 = lane & 7, r8 = lane >> 3;
+              float *op = out + (f0 + r8) * S + s_base + 4 * k4;
+              const float *ip = ost + r8 * kOS + 4 * k4;
+#pragma unroll
+              for (int i = 0; i < FRAMES_PER_WAVE / 8; i++) {
+                const f32x4 v = *(const f32x4 *)(ip + i * 8 * kOS);
+                // rows of the [F x S] output are only 4-byte aligned
+                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                *(f32x4u *)(op + (int64_t)i * 8 * S) = v;
+              }
+            } else {
+              constexpr int RPI = 64 / OG;  // frame rows per store instruction
+              const int k = lane & (OG - 1);
 #pragma unroll 4
-            for (int i = 0; i < FRAMES_PER_WAVE / RPI; i++) {
-              const int row = i * RPI + lane / OG;
-              const float v = ost[row * kOS + k];
-              if (k < cnt && f0 + row < F) out[(f0 + row) * S + s_base + k] = v;
+              for (int i = 0; i < FRAMES_PER_WAVE / RPI; i++) {
+                const int row = i * RPI + lane / OG;
+                const float v = ost[row * kOS + k];
+                if (k < cnt && f0 + row < F) out[(f0 + row) * S + s_base + k] = v;
+              }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
