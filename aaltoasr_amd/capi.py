@@ -204,6 +204,19 @@ class Gmm:
     def expanded_rows(self) -> int:
         return lib().aasr_gmm_expanded_rows(self._h)
 
+    def set_layouts(self, mask: int) -> None:
+        """Diagnostic: restrict the scoring kernels the launcher may pick (bit 0
+        grouped tracks, bit 1 independent tracks, 0 = general LDS-staged)."""
+        L = lib()
+        L.aasr_debug_set_layouts.argtypes = [C.c_void_p, C.c_int]
+        L.aasr_debug_set_layouts.restype = None
+        L.aasr_debug_set_layouts(self._h, mask)
+
+    def active_layout(self) -> int:
+        L = lib()
+        L.aasr_debug_active_layout.argtypes = [C.c_void_p]
+        return L.aasr_debug_active_layout(self._h)
+
     def score(self, frames: np.ndarray) -> np.ndarray:
         frames = np.ascontiguousarray(frames, np.float32)
         out = np.empty((frames.shape[0], self.num_states), np.float32)

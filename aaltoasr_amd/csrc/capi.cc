@@ -131,7 +131,9 @@ int64_t aasr_gmm_expanded_rows(const aasr_gmm *h) { return h ? h->mix.rows : -1;
 aasr_status aasr_gmm_set_precision(aasr_gmm *h, int prec) {
   return guarded([&] {
     if (!h) raise(AASR_ERR_INVALID, "null handle");
-    if (prec == AASR_PREC_F32) {
+    if (prec == AASR_PREC_F32 || prec == AASR_PREC_F32_CENTRED) {
+      if (prec == AASR_PREC_F32_CENTRED && !h->centred_ok)
+        raise(AASR_ERR_UNSUPPORTED, "the centred kernel is not available for dimension %d", h->dim);
       h->precision = prec;
       return;
     }

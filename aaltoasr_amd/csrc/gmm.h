@@ -32,8 +32,11 @@ constexpr int CHUNK_ROWS = 32;
 constexpr int FRAMES_PER_WAVE = 64;
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int FRAMES_PER_BLOCK = FRAMES_PER_WAVE * WAVES_PER_BLOCK;
-constexpr int PAIRED_OUT_GROUP = 32;   // states written per frame row at a time
-constexpr int PAIRED_MAX_SPLITS = 16;  // row-range cuts available to the launcher
+constexpr int TRACK_OUT_GROUP = 32;   // states written per frame row at a time (grouped)
+constexpr int TRACK_MAX_SPLITS = 16;  // row-range cuts available to the launcher
+constexpr int CENTRED_MAX_SPLITS = 32;
+// expanded-form error estimate eps * kappa beyond which the centred kernel is used
+constexpr double KAPPA_LIMIT = 600.0;
 
 // Kernel instances exist for these K/2 values; a model uses the smallest one
 // that holds dim+1 (zero-padded beyond).
@@ -59,6 +62,20 @@ struct PackedRows {
   DevBuf<double> a64;
 };
 
+// Two-track row layout for the in-register epilogue (see gmm_build_tracks()).
+struct TrackLayout {
+  bool ok = false;
+  bool grouped = false;
+  PackedRows rows;
+  DevBuf<uint16_t> close;    // per tile: bit p (+8 for track 1) = a state closes after quad p
+  DevBuf<int32_t> sid;       // [2][sid_stride] state index of the k-th close on each track
+  int32_t sid_stride = 0;
+  DevBuf<int32_t> splits;    // [MAX_SPLITS][MAX_SPLITS+1][4]: tile, closes track 0, closes track 1
+  int max_splits = 1;
+  int64_t rows_padded = 0;
+  float ref_ln = 0.0f;       // reference exponent * ln 2
+};
+
 }  // namespace aasr
 
 struct aasr_gmm {
@@ -72,15 +89,19 @@ struct aasr_gmm {
   aasr::PackedRows mix;             // component-expanded, per-state reduce
   aasr::PackedRows pool;            // pool Gaussians, raw log-likelihoods
   bool pool_built = false;
-  // paired-track layout for the in-register epilogue (built when eligible)
-  aasr::PackedRows paired;
-  aasr::DevBuf<uint8_t> paired_close;  // per tile: bit p = a state pair closes after quad p
-  int64_t paired_rows_padded = 0;
-  float paired_ref_ln = 0.0f;          // reference exponent * ln 2
-  aasr::DevBuf<int32_t> paired_splits; // [MAX_SPLITS][MAX_SPLITS+1][2]: tile, pairs closed
-  int paired_max_splits = 1;
+  // track layouts for the in-register epilogue (built when eligible)
+  aasr::TrackLayout paired;   // grouped: states 2j/2j+1 side by side
+  aasr::TrackLayout tracks;   // independent tracks (built when `paired` is not)
   int num_cus = 0;
-  bool paired_ok = false;
+  int layout_mask = 7;        // see aasr_debug_set_layouts()
+  // centred-form (numerically safe) kernel operands
+  bool centred_ok = false, ill_conditioned = false;
+  double kappa = 0;           // conditioning estimate of the expanded form
+  int centred_dimp = 0;
+  aasr::DevBuf<float> centred_recs;        // [rows][2*dimp+4]
+  aasr::DevBuf<int32_t> centred_state_off; // [S+1]
+  aasr::DevBuf<int32_t> centred_splits;    // [MAX][MAX+1] state boundaries
+  int centred_max_splits = 1;
   // staging for the host-buffer entry points
   aasr::DevBuf<float> d_frames, d_out;
 };
@@ -88,6 +109,8 @@ struct aasr_gmm {
 namespace aasr {
 void gmm_build(aasr_gmm *g, const HostModel &m);
 void gmm_build_pool(aasr_gmm *g);
+void gmm_build_tracks(aasr_gmm *g, bool grouped);
+void gmm_build_centred(aasr_gmm *g);
 void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F,
                       float *d_out, hipStream_t stream);
 void gmm_gauss_launch(aasr_gmm *g, const float *d_frames, int64_t F,

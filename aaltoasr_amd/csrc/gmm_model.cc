@@ -8,6 +8,7 @@
 // (aku/Distributions.cc:1273-1288) -- no (2*pi)^(-d/2) term.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -210,7 +211,7 @@ static void pack_rows(const aasr_gmm *g, const std::vector<RowSpec> &rows,
   out.a.upload(a.data(), a.size());
 }
 
-void gmm_build_paired(aasr_gmm *g);
+void gmm_build_tracks(aasr_gmm *g, bool grouped);
 
 void gmm_build(aasr_gmm *g, const HostModel &model) {
   require_device();
@@ -298,30 +299,44 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
   g->mix.chunk_seg_begin.upload(chunk_seg_begin.data(), chunk_seg_begin.size());
   g->mix.seg_desc.upload(seg_desc.data(), seg_desc.size());
   g->mix.seg_out.upload(seg_out.data(), seg_out.size());
-  gmm_build_paired(g);
+  gmm_build_tracks(g, true);
+  if (!g->paired.ok) gmm_build_tracks(g, false);
+  gmm_build_centred(g);
+  // profiling hook: AASR_LAYOUTS=<mask> restricts the kernels like
+  // aasr_debug_set_layouts (1 grouped, 2 independent tracks, 4 centred, 0 general)
+  if (const char *e = getenv("AASR_LAYOUTS")) {
+    g->layout_mask = atoi(e);
+    if ((g->layout_mask & 2) && !g->tracks.ok) gmm_build_tracks(g, false);
+  }
 }
 
-// Paired-track layout for the in-register epilogue (k_gmm_diag_score_paired).
+// Track layouts for the in-register epilogue (k_gmm_diag_score_tracks).
 //
 // In a 32x32 MFMA accumulator block lane (n, h) holds, for frame column n, the
 // 16 rows {8q + 4h + e : q < 4, e < 4}.  Rows are therefore laid out as two
-// "tracks" h = 0/1 of 4-row quads; states 2j and 2j+1 sit side by side on tracks
-// 0 and 1 over the same quads (the shorter one padded with null rows), so each
-// lane sums its own state's components straight out of its accumulator
-// registers.  No running maximum is needed: a fixed reference 2^kPairedRef is
-// folded into the constants, valid as long as every component's peak value
-// (c_g + log w) leaves headroom in the f32 exponent -- checked here.
+// "tracks" h = 0/1 of 4-row quads (8 quad positions per track per 64-row
+// tile), every state lives on ONE track over consecutive quads (padded to a
+// quad with null rows), and each lane sums its own state's components straight
+// out of its accumulator registers.  No running maximum is needed: a fixed
+// reference 2^ref is folded into the constants, valid as long as every
+// component's peak value (c_g + log w) leaves headroom in the f32 exponent.
+//
+//  grouped  (paired): states 2j / 2j+1 side by side on tracks 0 / 1 over the
+//            same quads, so they finish together and results can be written 32
+//            consecutive states per frame row.  Used when padding the shorter
+//            partner costs <= 25 % extra rows (uniform models: nothing).
+//  independent: each state goes to the currently shorter track; the tracks close
+//            states independently and results are written per state.  Padding
+//            is only the quad round-up.
+//
 // The reference exponent is chosen per model: as large as the peaks allow (cap
-// 72), and at least 56 so that components 2^16 below the 1e-50 state floor
-// (2^-166) still land in the normal f32 range (v_exp_f32 flushes denormals).
-static const double kPairedRefMin = 56.0, kPairedRefMax = 72.0;
-static const double kPairedPeakMax = 120.0;   // max (peak*log2e + ref) accepted
+// 72), at least 56 so that components 2^16 below the 1e-50 state floor (2^-166)
+// still land in the normal f32 range (v_exp_f32 flushes denormals).
+static const double kRefMin = 56.0, kRefMax = 72.0;
+static const double kPeakMax = 120.0;  // max (peak*log2e + ref) accepted
 
-void gmm_build_paired(aasr_gmm *g) {
-  const HostModel &m = g->host;
-  g->paired_ok = false;
+static bool choose_reference(const HostModel &m, double *ref_out) {
   const int D = m.dim;
-  // eligibility 1: exponent headroom
   double max_peak_log2 = -INFINITY;
   for (size_t k = 0; k < m.mix_idx.size(); k++) {
     const double *var = &m.var[(size_t)m.mix_idx[k] * D];
@@ -330,107 +345,241 @@ void gmm_build_paired(aasr_gmm *g) {
     double cst = (prod > 0) ? std::log(std::sqrt(prod)) : prod;
     double w = m.mix_w[k];
     double peak = cst + (w > 0 ? std::log(w) : -INFINITY);
-    if (std::isnan(peak) || peak == INFINITY) return;
+    if (std::isnan(peak) || peak == INFINITY) return false;
     max_peak_log2 = std::max(max_peak_log2, peak * kLog2e);
   }
-  double ref = std::floor(std::min(kPairedRefMax, kPairedPeakMax - max_peak_log2));
-  if (!(ref >= kPairedRefMin)) return;
-  const double kPairedRef = ref;
-  g->paired_ref_ln = (float)(ref * 0.69314718055994530942);
-  // eligibility 2: padding overhead (pairs padded to a common number of quads)
-  const int64_t pairs = (m.S + 1) / 2;
-  int64_t quads = 0;
-  std::vector<int32_t> pair_quads((size_t)pairs);
-  for (int64_t j = 0; j < pairs; j++) {
-    int64_t n0 = m.mix_off[2 * j + 1] - m.mix_off[2 * j];
-    int64_t n1 = (2 * j + 1 < m.S) ? m.mix_off[2 * j + 2] - m.mix_off[2 * j + 1] : 0;
-    int64_t q = std::max<int64_t>(1, (std::max(n0, n1) + 3) / 4);
-    pair_quads[(size_t)j] = (int32_t)q;
-    quads += q;
-  }
-  const int64_t rows_padded = quads * 8;
-  const int64_t rows_real = std::max<int64_t>(1, (int64_t)m.mix_idx.size());
-  if ((double)rows_padded > 1.25 * (double)rows_real + 64) return;
+  double ref = std::floor(std::min(kRefMax, kPeakMax - max_peak_log2));
+  if (!(ref >= kRefMin)) return false;
+  *ref_out = ref;
+  return true;
+}
 
-  const int64_t tiles = (quads + 7) / 8;  // 8 quad positions per 64-row tile
+// Row-split table: the tile range can be cut into R contiguous chunks that
+// different workgroups score for the same frames (finer work quanta -> no tail
+// round on the 256 CUs).  cand_* list the legal cut points (tile index and the
+// number of states each track has closed before it); row R-1 of the table holds
+// R+1 entries {tile, closes track 0, closes track 1, 0}.
+static void build_split_table(TrackLayout &L, int64_t tiles, const std::vector<int64_t> &cand_tile,
+                              const std::vector<int64_t> &cand_k0,
+                              const std::vector<int64_t> &cand_k1) {
+  std::vector<int32_t> table((size_t)TRACK_MAX_SPLITS * (TRACK_MAX_SPLITS + 1) * 4, 0);
+  L.max_splits = 1;
+  for (int R = 1; R <= TRACK_MAX_SPLITS; R++) {
+    std::vector<size_t> pick{0};
+    bool ok = true;
+    for (int i = 1; i < R && ok; i++) {
+      double want = (double)tiles * i / R;
+      size_t best = pick.back();
+      double bd = 1e300;
+      for (size_t c = pick.back() + 1; c + 1 < cand_tile.size(); c++) {
+        double d = std::fabs((double)cand_tile[c] - want);
+        if (d < bd) { bd = d; best = c; }
+      }
+      if (best == pick.back()) ok = false;
+      pick.push_back(best);
+    }
+    if (!ok) break;
+    pick.push_back(cand_tile.size() - 1);
+    int64_t worst = 0;
+    for (int i = 0; i < R; i++) worst = std::max(worst, cand_tile[pick[i + 1]] - cand_tile[pick[i]]);
+    if ((double)worst > 1.25 * (double)tiles / R + 1) break;  // too uneven
+    int32_t *row = &table[(size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4];
+    for (int i = 0; i <= R; i++) {
+      row[4 * i] = (int32_t)cand_tile[pick[i]];
+      row[4 * i + 1] = (int32_t)cand_k0[pick[i]];
+      row[4 * i + 2] = (int32_t)cand_k1[pick[i]];
+    }
+    L.max_splits = R;
+  }
+  L.splits.upload(table.data(), table.size());
+}
+
+static inline int64_t track_row(int64_t pos, int h, int e) {
+  // quad position `pos` of track h, element e -> row in the tile-major layout
+  int64_t t = pos / 8;
+  int mb = (int)((pos / 4) % 2), q = (int)(pos % 4);
+  return t * TILE_ROWS + mb * 32 + 8 * q + 4 * h + e;
+}
+
+void gmm_build_tracks(aasr_gmm *g, bool grouped) {
+  const HostModel &m = g->host;
+  TrackLayout &L = grouped ? g->paired : g->tracks;
+  L.ok = false;
+  L.grouped = grouped;
+  double ref = 0;
+  if (!choose_reference(m, &ref)) return;
+  L.ref_ln = (float)(ref * 0.69314718055994530942);
+  const int64_t rows_real = std::max<int64_t>(1, (int64_t)m.mix_idx.size());
+
+  // ---- placement: (track, first quad, quads) per state
+  std::vector<int8_t> st_track((size_t)m.S);
+  std::vector<int64_t> st_pos((size_t)m.S);
+  int64_t len[2] = {0, 0};
+  std::vector<int64_t> cand_tile{0}, cand_k0{0}, cand_k1{0};
+  int64_t closed[2] = {0, 0};
+  auto quads_of = [&](int64_t s) {
+    return std::max<int64_t>(1, ((int64_t)(m.mix_off[s + 1] - m.mix_off[s]) + 3) / 4);
+  };
+  if (grouped) {
+    for (int64_t j = 0; 2 * j < m.S; j++) {
+      int64_t q = quads_of(2 * j);
+      if (2 * j + 1 < m.S) q = std::max(q, quads_of(2 * j + 1));
+      for (int h = 0; h < 2 && 2 * j + h < m.S; h++) {
+        st_track[(size_t)(2 * j + h)] = (int8_t)h;
+        st_pos[(size_t)(2 * j + h)] = len[0];
+      }
+      len[0] += q;
+      len[1] = len[0];
+      closed[0]++;
+      closed[1]++;
+      if (len[0] % 8 == 0 && (2 * closed[0]) % TRACK_OUT_GROUP == 0) {
+        cand_tile.push_back(len[0] / 8);
+        cand_k0.push_back(closed[0]);
+        cand_k1.push_back(closed[1]);
+      }
+    }
+    if ((double)(len[0] * 8) > 1.25 * (double)rows_real + 64) return;  // too much padding
+  } else {
+    // cut candidates are created by padding both tracks to a tile boundary
+    // roughly every 1/32 of the expected length
+    int64_t total_quads = 0;
+    for (int64_t s = 0; s < m.S; s++) total_quads += quads_of(s);
+    const int64_t sync_every = std::max<int64_t>(64, total_quads / 2 / 32);
+    int64_t next_sync = sync_every;
+    for (int64_t s = 0; s < m.S; s++) {
+      int h = len[1] < len[0] ? 1 : 0;
+      st_track[(size_t)s] = (int8_t)h;
+      st_pos[(size_t)s] = len[h];
+      len[h] += quads_of(s);
+      closed[h]++;
+      if (std::min(len[0], len[1]) >= next_sync && s + 1 < m.S) {
+        int64_t top = (std::max(len[0], len[1]) + 7) / 8 * 8;
+        len[0] = len[1] = top;
+        cand_tile.push_back(top / 8);
+        cand_k0.push_back(closed[0]);
+        cand_k1.push_back(closed[1]);
+        next_sync = top + sync_every;
+      }
+    }
+  }
+  const int64_t quads = std::max(len[0], len[1]);
+  const int64_t tiles = std::max<int64_t>(1, (quads + 7) / 8);
+  if (cand_tile.back() == tiles) {  // the end is always the last boundary
+    cand_tile.pop_back();
+    cand_k0.pop_back();
+    cand_k1.pop_back();
+  }
+  cand_tile.push_back(tiles);
+  cand_k0.push_back(closed[0]);
+  cand_k1.push_back(closed[1]);
+
+  // ---- rows, close bits, per-track state lists
   std::vector<RowSpec> rows((size_t)tiles * TILE_ROWS, RowSpec{-1, 0.0, 0.0});
-  std::vector<uint8_t> close_mask((size_t)tiles, 0);
-  int64_t p = 0;  // quad position along the tracks
-  for (int64_t j = 0; j < pairs; j++) {
-    for (int h = 0; h < 2; h++) {
-      int64_t s = 2 * j + h;
-      if (s >= m.S) continue;
-      int32_t a = m.mix_off[s], b = m.mix_off[s + 1];
-      for (int32_t k = a; k < b; k++) {
-        int64_t pos = p + (k - a) / 4;
-        int e = (k - a) % 4;
-        int64_t t = pos / 8;
-        int mb = (int)((pos / 4) % 2), q = (int)(pos % 4);
-        int64_t row = t * TILE_ROWS + mb * 32 + 8 * q + 4 * h + e;
-        double w = m.mix_w[k];
-        rows[(size_t)row] = RowSpec{m.mix_idx[k], (w > 0) ? std::log(w) : -INFINITY, kPairedRef};
-      }
+  std::vector<uint16_t> close_mask((size_t)tiles, 0);
+  std::vector<int32_t> sid[2];
+  for (int64_t s = 0; s < m.S; s++) {
+    const int h = st_track[(size_t)s];
+    const int64_t p0 = st_pos[(size_t)s];
+    const int32_t a = m.mix_off[s], b = m.mix_off[s + 1];
+    for (int32_t k = a; k < b; k++) {
+      double w = m.mix_w[k];
+      rows[(size_t)track_row(p0 + (k - a) / 4, h, (k - a) % 4)] =
+          RowSpec{m.mix_idx[k], (w > 0) ? std::log(w) : -INFINITY, ref};
     }
-    p += pair_quads[(size_t)j];
-    int64_t last = p - 1;
-    close_mask[(size_t)(last / 8)] |= (uint8_t)(1u << (last % 8));
+    int64_t q = quads_of(s);
+    if (grouped) {
+      // the pair closes where its longer member ends
+      int64_t partner = s ^ 1;
+      if (partner < m.S) q = std::max(q, quads_of(partner));
+    }
+    const int64_t last = p0 + q - 1;
+    close_mask[(size_t)(last / 8)] |= (uint16_t)(1u << (last % 8 + 8 * h));
+    sid[h].push_back((int32_t)s);
   }
-  // Row-split table: the tile range can be cut into R contiguous chunks that
-  // different workgroups score for the same frames (finer work quanta -> no
-  // tail round on the 256 CUs).  A cut is legal where no state pair is open
-  // and the number of finished states is a multiple of the 32-state output
-  // group.  Row R-1 of the table holds R+1 tile boundaries and the number of
-  // pairs closed before each.
-  {
-    std::vector<int64_t> cand_tile{0}, cand_pairs{0};
-    int64_t closed = 0;
-    for (int64_t t = 0; t < tiles; t++) {
-      closed += __builtin_popcount(close_mask[(size_t)t]);
-      bool ends_closed = (close_mask[(size_t)t] >> 7) & 1;
-      if (t + 1 < tiles && ends_closed && closed % (PAIRED_OUT_GROUP / 2) == 0) {
-        cand_tile.push_back(t + 1);
-        cand_pairs.push_back(closed);
-      }
-    }
-    cand_tile.push_back(tiles);
-    cand_pairs.push_back(closed);
-    std::vector<int32_t> table((size_t)PAIRED_MAX_SPLITS * (PAIRED_MAX_SPLITS + 1) * 2, 0);
-    g->paired_max_splits = 1;
-    for (int R = 1; R <= PAIRED_MAX_SPLITS; R++) {
-      std::vector<size_t> pick{0};
-      bool ok = true;
-      for (int i = 1; i < R && ok; i++) {
-        double want = (double)tiles * i / R;
-        size_t best = pick.back();
-        double bd = 1e300;
-        for (size_t c = pick.back() + 1; c + 1 < cand_tile.size(); c++) {
-          double d = std::fabs((double)cand_tile[c] - want);
-          if (d < bd) { bd = d; best = c; }
-        }
-        if (best == pick.back()) ok = false;
-        pick.push_back(best);
-      }
-      if (!ok) break;
-      pick.push_back(cand_tile.size() - 1);
-      // reject very uneven cuts (chunk more than 25 % above the mean)
-      int64_t worst = 0;
-      for (int i = 0; i < R; i++)
-        worst = std::max(worst, cand_tile[pick[i + 1]] - cand_tile[pick[i]]);
-      if ((double)worst > 1.25 * (double)tiles / R + 1) break;
-      int32_t *row = &table[(size_t)(R - 1) * (PAIRED_MAX_SPLITS + 1) * 2];
-      for (int i = 0; i <= R; i++) {
-        row[2 * i] = (int32_t)cand_tile[pick[i]];
-        row[2 * i + 1] = (int32_t)cand_pairs[pick[i]];
-      }
-      g->paired_max_splits = R;
-    }
-    g->paired_splits.upload(table.data(), table.size());
+  if (grouped && (m.S & 1)) {
+    // odd state count: track 1 of the last pair is all padding but must close too
+    int64_t last = st_pos[(size_t)(m.S - 1)] + quads_of(m.S - 1) - 1;
+    close_mask[(size_t)(last / 8)] |= (uint16_t)(1u << (last % 8 + 8));
   }
-  pack_rows(g, rows, g->paired, nullptr);
-  g->paired.rows = (int64_t)m.mix_idx.size();  // real rows (algorithmic work)
-  g->paired_close.upload(close_mask.data(), close_mask.size());
-  g->paired_rows_padded = rows_padded;
-  g->paired_ok = true;
+  const size_t ns = std::max(sid[0].size(), sid[1].size()) + 1;
+  std::vector<int32_t> sid_flat(2 * ns, 0);
+  for (int h = 0; h < 2; h++)
+    for (size_t k = 0; k < sid[h].size(); k++) sid_flat[h * ns + k] = sid[h][k];
+  L.sid_stride = (int32_t)ns;
+  L.sid.upload(sid_flat.data(), sid_flat.size());
+  build_split_table(L, tiles, cand_tile, cand_k0, cand_k1);
+  pack_rows(g, rows, L.rows, nullptr);
+  L.rows.rows = (int64_t)m.mix_idx.size();  // real rows (algorithmic work)
+  L.close.upload(close_mask.data(), close_mask.size());
+  L.rows_padded = tiles * TILE_ROWS;
+  L.ok = true;
+}
+
+// Operands of the centred-form kernel + the conditioning estimate that decides
+// whether the matrix-core (expanded form) kernels may be used.
+void gmm_build_centred(aasr_gmm *g) {
+  const HostModel &m = g->host;
+  const int D = m.dim;
+  g->centred_ok = false;
+  int dimp = 0;
+  for (int c : {8, 16, 24, 32, 40, 48, 64})
+    if (D <= c) { dimp = c; break; }
+  // conditioning of the expanded form: kappa = max_g sum_d p (mu - pivot)^2
+  double kappa = 0;
+  for (int64_t i = 0; i < m.G; i++) {
+    double k = 0;
+    for (int d = 0; d < D; d++) {
+      double v = m.var[(size_t)i * D + d];
+      double p = v > 0 ? 1 / v : 0;
+      double mc = m.mean[(size_t)i * D + d] - (double)g->pivot[d];
+      k += p * mc * mc;
+    }
+    kappa = std::max(kappa, k);
+  }
+  g->kappa = kappa;
+  g->ill_conditioned = kappa > KAPPA_LIMIT;
+  if (!dimp) return;
+  g->centred_dimp = dimp;
+  const int rec = 2 * dimp + 4;
+  const size_t rows = m.mix_idx.size();
+  std::vector<float> recs(std::max<size_t>(1, rows) * rec, 0.0f);
+  for (size_t k = 0; k < rows; k++) {
+    const int64_t gi = m.mix_idx[k];
+    double prod = 1;
+    for (int d = 0; d < D; d++) {
+      double v = m.var[(size_t)gi * D + d];
+      double p = v > 0 ? 1 / v : 0;
+      prod *= p;
+      recs[k * rec + d] = (float)m.mean[(size_t)gi * D + d];
+      recs[k * rec + dimp + d] = (float)(-0.5 * p * kLog2e);
+    }
+    double cst = (prod > 0) ? std::log(std::sqrt(prod)) : prod;
+    double w = m.mix_w[k];
+    double c = cst + (w > 0 ? std::log(w) : -INFINITY);
+    if (std::isnan(c) || c == INFINITY)
+      raise(AASR_ERR_INVALID, "Gaussian %ld has a non-finite constant (precision product overflow)", (long)gi);
+    recs[k * rec + 2 * dimp] = std::isfinite(c) ? (float)(c * kLog2e) : kNullConst;
+  }
+  g->centred_recs.upload(recs.data(), recs.size());
+  g->centred_state_off.upload(m.mix_off.data(), m.mix_off.size());
+  // state-range cut table: row R-1 = R+1 boundaries with near-equal row counts
+  std::vector<int32_t> table((size_t)CENTRED_MAX_SPLITS * (CENTRED_MAX_SPLITS + 1), 0);
+  g->centred_max_splits = (int)std::min<int64_t>(CENTRED_MAX_SPLITS, m.S);
+  for (int R = 1; R <= g->centred_max_splits; R++) {
+    int32_t *row = &table[(size_t)(R - 1) * (CENTRED_MAX_SPLITS + 1)];
+    int64_t s = 0;
+    row[0] = 0;
+    for (int i = 1; i < R; i++) {
+      int64_t want = (int64_t)((double)rows * i / R);
+      while (s < m.S && m.mix_off[s] < want) s++;
+      if (s <= row[i - 1]) s = row[i - 1] + 1;
+      if (s > m.S) s = m.S;
+      row[i] = (int32_t)s;
+    }
+    row[R] = (int32_t)m.S;
+  }
+  g->centred_splits.upload(table.data(), table.size());
+  g->centred_ok = true;
 }
 
 void gmm_build_pool(aasr_gmm *g) {

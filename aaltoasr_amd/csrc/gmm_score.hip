@@ -269,40 +269,48 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score(
 
 
 // ---------------------------------------------------------------------------
-// Paired-track variant: in-register epilogue (see gmm_build_paired()).
+// Track layouts: in-register epilogue (see gmm_build_tracks()).
 //
-// The host lays states 2j / 2j+1 on the two row tracks that lane halves h = 0 /
-// 1 hold in their accumulator registers, and folds a fixed reference 2^ref into
-// the constants, so the epilogue is 16 v_exp_f32 + 16 adds per accumulator
-// block with no LDS round trip, no running maximum and no descriptor loads
-// beyond one byte per tile.  Finished states are transposed through a
-// wave-private LDS buffer and written OG consecutive states per frame row.
+// The host lays every state on one of the two row tracks that lane halves
+// h = 0 / 1 hold in their accumulator registers and folds a fixed reference
+// 2^ref into the constants, so the epilogue is 16 v_exp_f32 + 16 adds per
+// accumulator block with no LDS round trip, no running maximum and one 16-bit
+// close mask per tile.  On gfx950 the f32 MFMA executes on the same lanes as
+// the VALU (SQ_VALU_MFMA_COEXEC_CYCLES = 0), so every VALU instruction removed
+// from the epilogue is matrix time won back.
+//   GROUPED: states 2j/2j+1 finish together; results are transposed through a
+//            wave-private LDS buffer and written 32 consecutive states (128 B)
+//            per frame row with 16-byte stores.
+//   !GROUPED: the tracks close states independently; results are stored per
+//            state (4-byte scatter, one store instruction per 32 frames).
+// The row range can be cut (blockIdx.y) so that the grid has no tail round.
 // ---------------------------------------------------------------------------
-
-template <int NKK, int OG>
-struct PairedSmem {
+template <int NKK, bool GROUPED>
+struct TrackSmem {
+  static constexpr int OG = TRACK_OUT_GROUP;
   static constexpr int kTileFloats = (NKK / 2) * 64 * 4;
   static constexpr int kOutStride = OG + 4;  // 16-byte aligned rows for ds_read_b128
-  static constexpr int kOutFloatsPerWave = FRAMES_PER_WAVE * kOutStride;
+  static constexpr int kOutFloatsPerWave = GROUPED ? FRAMES_PER_WAVE * kOutStride : 0;
   static constexpr int kBytes = (2 * kTileFloats + WAVES_PER_BLOCK * kOutFloatsPerWave) * 4;
 };
 
-template <int NKK, int OG>
-__global__ __launch_bounds__(256, 2) void k_gmm_diag_score_paired(
+template <int NKK, bool GROUPED>
+__global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
     const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
     const float *__restrict__ apack, const int32_t *__restrict__ split_row,
-    const uint8_t *__restrict__ close_mask, float *__restrict__ out, int64_t S, float ref_ln,
-    int dbg) {
+    const uint16_t *__restrict__ close_mask, const int32_t *__restrict__ sid, int sid_stride,
+    float *__restrict__ out, int64_t S, float ref_ln, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float *smem = (float *)smem_raw;
-  constexpr int kTileFloats = PairedSmem<NKK, OG>::kTileFloats;
-  constexpr int kOS = PairedSmem<NKK, OG>::kOutStride;
+  constexpr int OG = TRACK_OUT_GROUP;
+  constexpr int kTileFloats = TrackSmem<NKK, GROUPED>::kTileFloats;
+  constexpr int kOS = TrackSmem<NKK, GROUPED>::kOutStride;
   float *abuf0 = smem;
   float *abuf1 = smem + kTileFloats;
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const int lane = tid & 63;
-  float *ost = smem + 2 * kTileFloats + wave * PairedSmem<NKK, OG>::kOutFloatsPerWave;
+  float *ost = smem + 2 * kTileFloats + wave * TrackSmem<NKK, GROUPED>::kOutFloatsPerWave;
   const int n = lane & 31;
   const int h = lane >> 5;
   const int64_t f0 = (int64_t)blockIdx.x * FRAMES_PER_BLOCK + wave * FRAMES_PER_WAVE;
@@ -325,14 +333,20 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_paired(
   }
 
   // this workgroup's share of the rows: tiles [t_begin, t_end)
-  const int64_t t_begin = split_row[2 * blockIdx.y];
-  const int64_t t_end = split_row[2 * blockIdx.y + 2];
+  const int64_t t_begin = split_row[4 * blockIdx.y];
+  const int64_t t_end = split_row[4 * blockIdx.y + 4];
   issue_tile_copy(apack + (size_t)t_begin * kTileFloats, abuf0, kTileFloats, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   float s0 = 0.0f, s1 = 0.0f;  // running sum_k 2^(v_k) of this lane's open state, frames n / 32+n
-  int pairs_closed = split_row[2 * blockIdx.y + 1];
+  // closes so far on this lane's track (GROUPED: pairs closed, same on both tracks)
+  int closes = split_row[4 * blockIdx.y + 1 + (GROUPED ? 0 : h)];
+  const int32_t *my_sid = sid + h * sid_stride;
+  int next_sid = GROUPED ? 0 : my_sid[closes];
+  float *orow0 = out + (f0 + n) * S;       // !GROUPED: this lane's two output rows
+  float *orow1 = out + (f0 + 32 + n) * S;
+  const bool ok0 = f0 + n < F, ok1 = f0 + 32 + n < F;
 
   for (int64_t t = t_begin; t < t_end; t++) {
     const int par = (int)((t - t_begin) & 1);
@@ -340,7 +354,9 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_paired(
     float *anext = par ? abuf0 : abuf1;
     if (t + 1 < t_end)
       issue_tile_copy(apack + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
-    const unsigned mask = close_mask[t];
+    const unsigned mask16 = close_mask[t];
+    // GROUPED: both tracks carry the same bits -> wave-uniform branch
+    const unsigned mask = GROUPED ? (mask16 & 0xffu) : (h ? (mask16 >> 8) : (mask16 & 0xffu));
 
     f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
     const f32x4 *afrag = (const f32x4 *)acur + lane;
@@ -363,10 +379,12 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_paired(
       a1 = a2;
     }
 
+    // One barrier per tile: every wave is done reading `acur` and every wave's
+    // share of tile t+1 has landed; the epilogue then needs no inter-wave sync.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    if (dbg & 1) {
+    if (dbg & 1) {  // ablation: MFMA only
       asm volatile("" ::"v"(c00), "v"(c01), "v"(c10), "v"(c11));
       continue;
     }
@@ -389,43 +407,51 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_paired(
           float l1 = fmaf(__builtin_amdgcn_logf(s1), LN2_F, -ref_ln);
           l0 = fmaxf(l0, LOG_TINY_F);
           l1 = fmaxf(l1, LOG_TINY_F);
-          const int slot = ((2 * pairs_closed) & (OG - 1)) + h;
-          ost[n * kOS + slot] = l0;
-          ost[(32 + n) * kOS + slot] = l1;
           s0 = 0.0f;
           s1 = 0.0f;
-          pairs_closed++;
-          const int64_t closed = 2 * (int64_t)pairs_closed < S ? 2 * (int64_t)pairs_closed : S;
-          if ((((2 * pairs_closed) & (OG - 1)) == 0 || 2 * (int64_t)pairs_closed >= S) && !(dbg & 16)) {
-            const int64_t s_base = ((closed - 1) / OG) * OG;
-            const int cnt = (int)(closed - s_base);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (cnt == OG && f0 + FRAMES_PER_WAVE <= F) {
-              // full group: each lane moves 4 consecutive states (16 B) of one
-              // frame row; 8 lanes cover the 32-state group, 8 rows per instruction
-              const int k4 = lane & 7, r8 = lane >> 3;
-              float *op = out + (f0 + r8) * S + s_base + 4 * k4;
-              const float *ip = ost + r8 * kOS + 4 * k4;
+          closes++;
+          if (!GROUPED) {
+            if (ok0) orow0[next_sid] = l0;
+            if (ok1) orow1[next_sid] = l1;
+            next_sid = my_sid[closes];  // list is padded by one entry
+          } else {
+            const int pairs_closed = closes;
+            const int slot = ((2 * (pairs_closed - 1)) & (OG - 1)) + h;
+            ost[n * kOS + slot] = l0;
+            ost[(32 + n) * kOS + slot] = l1;
+            const int64_t closed = 2 * (int64_t)pairs_closed < S ? 2 * (int64_t)pairs_closed : S;
+            if ((((2 * pairs_closed) & (OG - 1)) == 0 || 2 * (int64_t)pairs_closed >= S) &&
+                !(dbg & 16)) {
+              const int64_t s_base = ((closed - 1) / OG) * OG;
+              const int cnt = (int)(closed - s_base);
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              if (cnt == OG && f0 + FRAMES_PER_WAVE <= F) {
+                // full group: each lane moves 4 consecutive states (16 B) of one
+                // frame row; 8 lanes cover the 32-state group, 8 rows per instruction
+                const int k4 = lane & 7, r8 = lane >> 3;
+                float *op = out + (f0 + r8) * S + s_base + 4 * k4;
+                const float *ip = ost + r8 * kOS + 4 * k4;
 #pragma unroll
-              for (int i = 0; i < FRAMES_PER_WAVE / 8; i++) {
-                const f32x4 v = *(const f32x4 *)(ip + i * 8 * kOS);
-                // rows of the [F x S] output are only 4-byte aligned
-                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-                *(f32x4u *)(op + (int64_t)i * 8 * S) = v;
-              }
-            } else {
-              constexpr int RPI = 64 / OG;  // frame rows per store instruction
-              const int k = lane & (OG - 1);
+                for (int i = 0; i < FRAMES_PER_WAVE / 8; i++) {
+                  const f32x4 v = *(const f32x4 *)(ip + i * 8 * kOS);
+                  // rows of the [F x S] output are only 4-byte aligned
+                  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                  *(f32x4u *)(op + (int64_t)i * 8 * S) = v;
+                }
+              } else {
+                constexpr int RPI = 64 / OG;  // frame rows per store instruction
+                const int k = lane & (OG - 1);
 #pragma unroll 4
-              for (int i = 0; i < FRAMES_PER_WAVE / RPI; i++) {
-                const int row = i * RPI + lane / OG;
-                const float v = ost[row * kOS + k];
-                if (k < cnt && f0 + row < F) out[(f0 + row) * S + s_base + k] = v;
+                for (int i = 0; i < FRAMES_PER_WAVE / RPI; i++) {
+                  const int row = i * RPI + lane / OG;
+                  const float v = ost[row * kOS + k];
+                  if (k < cnt && f0 + row < F) out[(f0 + row) * S + s_base + k] = v;
+                }
               }
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
           }
         }
       }
@@ -433,14 +459,14 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_paired(
   }
 }
 
-template <int NKK, int OG>
-static void launch_paired_t(const aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
-                            hipStream_t stream) {
+template <int NKK, bool GROUPED>
+static void launch_tracks_t(const aasr_gmm *g, const TrackLayout &L, const float *d_frames,
+                            int64_t F, float *d_out, hipStream_t stream) {
   const int64_t blocks = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
-  const int smem = PairedSmem<NKK, OG>::kBytes;
+  const int smem = TrackSmem<NKK, GROUPED>::kBytes;
   static const int dbg = getenv("AASR_DBG") ? atoi(getenv("AASR_DBG")) : 0;
   static bool attr_set[64] = {false};
-  auto kern = k_gmm_diag_score_paired<NKK, OG>;
+  auto kern = k_gmm_diag_score_tracks<NKK, GROUPED>;
   if (!attr_set[g->device & 63]) {
     AASR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set[g->device & 63] = true;
@@ -451,7 +477,7 @@ static void launch_paired_t(const aasr_gmm *g, const float *d_frames, int64_t F,
   const double slots = 2.0 * (g->num_cus > 0 ? g->num_cus : 256);
   int R = 1;
   double best_eff = 0;
-  for (int r = 1; r <= g->paired_max_splits; r++) {
+  for (int r = 1; r <= L.max_splits; r++) {
     double x = (double)blocks * r / slots;
     double eff = x / std::ceil(x);
     if (eff > best_eff + 0.005) {
@@ -459,23 +485,113 @@ static void launch_paired_t(const aasr_gmm *g, const float *d_frames, int64_t F,
       R = r;
     }
   }
-  if (force_r >= 1 && force_r <= g->paired_max_splits) R = force_r;
-  const int32_t *split_row = g->paired_splits.p + (size_t)(R - 1) * (PAIRED_MAX_SPLITS + 1) * 2;
+  if (force_r >= 1 && force_r <= L.max_splits) R = force_r;
+  const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(256), smem, stream, d_frames, F,
-                     g->dim, g->d_pivot.p, g->paired.a.p, split_row, g->paired_close.p, d_out, g->S,
-                     g->paired_ref_ln, dbg);
+                     g->dim, g->d_pivot.p, L.rows.a.p, split_row, L.close.p, L.sid.p, L.sid_stride,
+                     d_out, g->S, L.ref_ln, dbg);
   AASR_HIP(hipGetLastError());
 }
 
-static bool launch_paired(const aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
-                          hipStream_t stream) {
-  switch (g->paired.nkk) {
-#define AASR_CASE(N)                                                              \
-  case N:                                                                         \
-    launch_paired_t<N, PAIRED_OUT_GROUP>(g, d_frames, F, d_out, stream);          \
+static bool launch_tracks(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
+                          float *d_out, hipStream_t stream) {
+  switch (L.rows.nkk) {
+#define AASR_CASE(N)                                                                  \
+  case N:                                                                             \
+    if (L.grouped) launch_tracks_t<N, true>(g, L, d_frames, F, d_out, stream);        \
+    else launch_tracks_t<N, false>(g, L, d_frames, F, d_out, stream);                 \
     return true;
     AASR_CASE(8) AASR_CASE(14) AASR_CASE(20) AASR_CASE(26) AASR_CASE(32) AASR_CASE(40)
     AASR_CASE(48) AASR_CASE(64)
+#undef AASR_CASE
+    default:
+      return false;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Centred-form kernel: the numerically safe path.
+//
+// The expanded (GEMM) form cancels when |mu - pivot| / sigma is large; models
+// whose conditioning estimate kappa = max_g sum_d p_gd (mu_gd - v_d)^2 would push
+// the f32 error past the 1e-4 budget are scored with the reference's own
+// arithmetic shape instead: t = x - mu, acc += (p') t^2 per dimension (all terms
+// of one sign, no cancellation), online (max, sum) over a state's components.
+// One lane owns one frame (its x vector lives in VGPRs), the Gaussian
+// parameters are wave-uniform and arrive through the scalar cache (s_load), so
+// the inner loop is 3 VALU instructions per dimension.  The f32 MFMA runs on
+// the same lanes as the VALU anyway, so this costs ~1.5x the matrix path, not
+// 16x.  Also the fallback for any model the track layouts cannot hold.
+// ---------------------------------------------------------------------------
+template <int DIMP>
+__global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
+    const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ recs,
+    const int32_t *__restrict__ state_off, const int32_t *__restrict__ split_state,
+    float *__restrict__ out, int64_t S) {
+  constexpr int REC = 2 * DIMP + 4;  // [mu x DIMP][p' x DIMP][C, pad, pad, pad]
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t fc = f < F ? f : F - 1;
+  float x[DIMP];
+#pragma unroll
+  for (int d = 0; d < DIMP; d++) x[d] = d < dim ? frames[fc * dim + d] : 0.0f;
+  const int s_begin = split_state[blockIdx.y], s_end = split_state[blockIdx.y + 1];
+  for (int s = s_begin; s < s_end; s++) {
+    const int r0 = state_off[s], r1 = state_off[s + 1];
+    float m = NEG_BIG_F, acc_s = 0.0f;
+    for (int r = r0; r < r1; r++) {
+      const float *rec = recs + (size_t)r * REC;
+      float a0 = 0.0f, a1 = 0.0f;  // two chains: halves the dependent-add latency
+#pragma unroll
+      for (int d = 0; d < DIMP; d += 2) {
+        const float t0 = x[d] - rec[d];
+        const float t1 = x[d + 1] - rec[d + 1];
+        a0 = fmaf(t0 * t0, rec[DIMP + d], a0);
+        a1 = fmaf(t1 * t1, rec[DIMP + d + 1], a1);
+      }
+      const float ll2 = rec[2 * DIMP] + (a0 + a1);  // log2 units
+      const float mn = fmaxf(m, ll2);
+      acc_s = acc_s * __builtin_amdgcn_exp2f(m - mn) + __builtin_amdgcn_exp2f(ll2 - mn);
+      m = mn;
+    }
+    float ll = fmaf(m, LN2_F, __builtin_amdgcn_logf(acc_s) * LN2_F);
+    ll = fmaxf(ll, LOG_TINY_F);
+    if (r1 <= r0) ll = LOG_TINY_F;
+    if (f < F) out[f * S + s] = ll;
+  }
+}
+
+template <int DIMP>
+static void launch_centred_t(const aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
+                             hipStream_t stream) {
+  const int64_t blocks = (F + 255) / 256;
+  // state-range cuts so that the grid fills the chip evenly (8 workgroups per CU)
+  const double slots = 8.0 * (g->num_cus > 0 ? g->num_cus : 256);
+  int R = 1;
+  double best = 0;
+  for (int r = 1; r <= g->centred_max_splits; r++) {
+    double xw = (double)blocks * r / slots;
+    double eff = xw / std::ceil(xw);
+    if (xw < 1.0) eff = xw;  // under-filled chip: more cuts = more parallelism
+    if (eff > best + 0.005) {
+      best = eff;
+      R = r;
+    }
+  }
+  const int32_t *split = g->centred_splits.p + (size_t)(R - 1) * (CENTRED_MAX_SPLITS + 1);
+  hipLaunchKernelGGL(k_gmm_diag_score_centred<DIMP>, dim3((unsigned)blocks, (unsigned)R), dim3(256), 0,
+                     stream, d_frames, F, g->dim, g->centred_recs.p, g->centred_state_off.p, split,
+                     d_out, g->S);
+  AASR_HIP(hipGetLastError());
+}
+
+static bool launch_centred(const aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
+                           hipStream_t stream) {
+  switch (g->centred_dimp) {
+#define AASR_CASE(N)                                          \
+  case N:                                                     \
+    launch_centred_t<N>(g, d_frames, F, d_out, stream);       \
+    return true;
+    AASR_CASE(8) AASR_CASE(16) AASR_CASE(24) AASR_CASE(32) AASR_CASE(40) AASR_CASE(48) AASR_CASE(64)
 #undef AASR_CASE
     default:
       return false;
@@ -520,6 +636,29 @@ static void launch(const aasr_gmm *g, const PackedRows &pr, const float *d_frame
   raise(AASR_ERR_UNSUPPORTED, "no kernel instance for K/2 = %d", pr.nkk);
 }
 
+// Diagnostic (not part of the public ABI): restrict the kernels the scoring
+// launcher may use (bit 0 grouped tracks, bit 1 independent tracks, bit 2 the
+// centred-form kernel; with bits 0-1 clear and bit 2 set the centred kernel is
+// forced, with all clear the general LDS-staged MFMA kernel).  Lets the tests
+// cover every kernel.
+extern "C" void aasr_debug_set_layouts(aasr_gmm *g, int mask) {
+  if (!g) return;
+  g->layout_mask = mask;
+  if ((mask & 2) && !g->tracks.ok) gmm_build_tracks(g, false);
+}
+// which kernel a launch would use now: 4 centred, 1 grouped tracks,
+// 2 independent tracks, 0 general LDS-staged MFMA kernel
+extern "C" int aasr_debug_active_layout(const aasr_gmm *g) {
+  if (!g) return -1;
+  if ((g->layout_mask & 4) && (g->ill_conditioned || g->precision == AASR_PREC_F32_CENTRED ||
+                               !(g->layout_mask & 3)) && g->centred_ok)
+    return 4;
+  if ((g->layout_mask & 1) && g->paired.ok) return 1;
+  if ((g->layout_mask & 2) && g->tracks.ok) return 2;
+  return 0;
+}
+extern "C" double aasr_debug_kappa(const aasr_gmm *g) { return g ? g->kappa : -1.0; }
+
 // Diagnostic (not part of the public ABI): resident workgroups per CU the
 // runtime predicts for the NKK=40 scoring kernel.
 extern "C" int aasr_debug_score_occupancy(void) {
@@ -536,8 +675,15 @@ extern "C" int aasr_debug_score_occupancy(void) {
 void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                       hipStream_t stream) {
   if (F <= 0) return;
-  static const bool no_paired = getenv("AASR_NO_PAIRED") != nullptr;
-  if (g->paired_ok && !no_paired && launch_paired(g, d_frames, F, d_out, stream)) return;
+  // numerically safe path first when the model needs it (or it is forced)
+  if ((g->layout_mask & 4) && (g->ill_conditioned || g->precision == AASR_PREC_F32_CENTRED ||
+                               !(g->layout_mask & 3) ) && g->centred_ok)
+    if (launch_centred(g, d_frames, F, d_out, stream)) return;
+  // layout choice: grouped tracks > independent tracks > general (LDS-staged)
+  if (g->layout_mask & 1)
+    if (g->paired.ok && launch_tracks(g, g->paired, d_frames, F, d_out, stream)) return;
+  if (g->layout_mask & 2)
+    if (g->tracks.ok && launch_tracks(g, g->tracks, d_frames, F, d_out, stream)) return;
   launch<0>(g, g->mix, d_frames, F, d_out, g->S, stream);
 }
 

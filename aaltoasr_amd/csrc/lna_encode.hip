@@ -109,12 +109,94 @@ __global__ __launch_bounds__(256) void k_state_norm_lna(
   }
 }
 
+
+// Register-resident variant for S <= 256*VPT: one global read of the row, the
+// three passes (max, sum, pack) run on registers.
+__device__ __forceinline__ void lna_store(float lp, int lnabytes, int64_t o,
+                                          float *__restrict__ lp_out,
+                                          uint8_t *__restrict__ bytes_out) {
+  if (lp_out) lp_out[o] = lp;
+  if (bytes_out) {
+    if (lnabytes == 4) {
+      ((float *)bytes_out)[o] = lp;
+    } else {
+      unsigned short code;
+      if ((double)lp < -36.008) {
+        code = 0xffff;
+      } else {
+        int temp = (int)(-1820.0 * (double)lp + .5);
+        unsigned b0 = (temp >> 8) & 255, b1 = temp & 255;
+        code = (unsigned short)(b0 | (b1 << 8));  // big-endian on disk
+      }
+      ((unsigned short *)bytes_out)[o] = code;
+    }
+  }
+}
+
+template <int VPT>
+__global__ __launch_bounds__(256) void k_state_norm_lna_reg(
+    const float *__restrict__ loglik, int64_t F, int S, int normalize, int lnabytes,
+    float *__restrict__ lp_out, uint8_t *__restrict__ bytes_out) {
+  __shared__ double red[8];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int64_t f = blockIdx.x; f < F; f += gridDim.x) {
+    const float *row = loglik + f * (int64_t)S;
+    double v[VPT];
+#pragma unroll
+    for (int j = 0; j < VPT; j++) {
+      const int i = tid + 256 * j;
+      v[j] = i < S ? float_cast_loglik(row[i]) : -INFINITY;
+    }
+    double logz = 0.0;
+    if (normalize) {
+      double m = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < VPT; j++) m = v[j] > m ? v[j] : m;
+      m = wave_reduce_max(m);
+      if (lane == 0) red[wave] = m;
+      __syncthreads();
+      m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+      __syncthreads();
+      if (m > -INFINITY) {
+        double z = 0.0;
+#pragma unroll
+        for (int j = 0; j < VPT; j++) z += (double)expf((float)(v[j] - m));
+        z = wave_reduce_sum(z);
+        if (lane == 0) red[4 + wave] = z;
+        __syncthreads();
+        z = (red[4] + red[5]) + (red[6] + red[7]);
+        __syncthreads();
+        logz = m + log(z);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VPT; j++) {
+      const int i = tid + 256 * j;
+      if (i < S) {
+        double lpd = v[j] - logz;
+        if (!(lpd >= LOG_TINY_D)) lpd = LOG_TINY_D;
+        lna_store((float)lpd, lnabytes, f * (int64_t)S + i, lp_out, bytes_out);
+      }
+    }
+  }
+}
+
 void lna_encode_launch(const float *d_loglik, int64_t F, int S, int normalize,
                        int lnabytes, float *d_lp, uint8_t *d_bytes, hipStream_t stream) {
   if (F <= 0 || S <= 0) return;
   int64_t blocks = F < (1 << 20) ? F : (1 << 20);
-  hipLaunchKernelGGL(k_state_norm_lna, dim3((unsigned)blocks), dim3(256), 0, stream, d_loglik,
-                     F, S, normalize, lnabytes, d_lp, d_bytes);
+  if (S <= 256 * 4)
+    hipLaunchKernelGGL(k_state_norm_lna_reg<4>, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       d_loglik, F, S, normalize, lnabytes, d_lp, d_bytes);
+  else if (S <= 256 * 8)
+    hipLaunchKernelGGL(k_state_norm_lna_reg<8>, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       d_loglik, F, S, normalize, lnabytes, d_lp, d_bytes);
+  else if (S <= 256 * 16)
+    hipLaunchKernelGGL(k_state_norm_lna_reg<16>, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       d_loglik, F, S, normalize, lnabytes, d_lp, d_bytes);
+  else
+    hipLaunchKernelGGL(k_state_norm_lna, dim3((unsigned)blocks), dim3(256), 0, stream, d_loglik,
+                       F, S, normalize, lnabytes, d_lp, d_bytes);
   AASR_HIP(hipGetLastError());
 }
 

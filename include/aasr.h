@@ -143,8 +143,14 @@ int aasr_gmm_num_gaussians(const aasr_gmm *h);  /* PDFPool::size()      */
 /* rows of the component-expanded layout the kernel streams (>= sum n_s) */
 int64_t aasr_gmm_expanded_rows(const aasr_gmm *h);
 
-/* Arithmetic used for the frame x Gaussian contraction. */
-enum { AASR_PREC_F32 = 0, AASR_PREC_F64 = 1 };
+/* Arithmetic used for the frame x Gaussian quadratic forms.
+ *  AASR_PREC_F32          default: f32 matrix-core contraction of the expanded
+ *                         form; models whose conditioning would break the 1e-4
+ *                         budget are switched to the centred form automatically
+ *  AASR_PREC_F32_CENTRED  always the centred form (x-mu)^2*p on the vector ALU,
+ *                         the reference's own arithmetic shape in f32
+ *  AASR_PREC_F64          reserved (f64 matrix cores), not built */
+enum { AASR_PREC_F32 = 0, AASR_PREC_F64 = 1, AASR_PREC_F32_CENTRED = 2 };
 aasr_status aasr_gmm_set_precision(aasr_gmm *h, int prec);
 
 /* HmmSet::precompute_likelihoods + state_likelihood for a block of frames

@@ -12,17 +12,30 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def _check(capi, oracle, model, frames, tol=TOL):
+# every scoring kernel is exercised: the launcher's own choice (7), the
+# independent-track layout (2), the general LDS-staged MFMA kernel (0) and the
+# centred-form vector kernel (4)
+LAYOUTS = [7, 2, 0, 4]
+
+
+def _check(capi, oracle, model, frames, tol=TOL, layouts=LAYOUTS):
     mean, var, off, idx, w = model
     ref = oracle.DiagModel(mean, var, off, idx, w).score(frames.astype(np.float64))
     g = capi.Gmm.from_arrays(mean, var, off, idx, w)
-    got = g.score(frames)
-    assert got.shape == ref.shape
-    assert np.isfinite(got).all()
-    err = np.abs(got.astype(np.float64) - ref)
-    assert err.max() <= tol, "max |dll| %.3g at %s" % (err.max(), np.unravel_index(err.argmax(), err.shape))
+    worst = 0.0
+    used = set()
+    for mask in layouts:
+        g.set_layouts(mask)
+        used.add(g.active_layout())
+        got = g.score(frames)
+        assert got.shape == ref.shape
+        assert np.isfinite(got).all()
+        err = np.abs(got.astype(np.float64) - ref)
+        assert err.max() <= tol, "layout %d (kernel %d): max |dll| %.3g at %s" % (
+            mask, g.active_layout(), err.max(), np.unravel_index(err.argmax(), err.shape))
+        worst = max(worst, err.max())
     g.close()
-    return err.max()
+    return worst, used
 
 
 @pytest.mark.parametrize("F", [1, 63, 64, 65, 255, 256, 257, 1000])
@@ -114,6 +127,29 @@ def test_model_files_roundtrip(capi, oracle, tmp_path):
     frames = synth.make_frames(33, D=13)
     ref = oracle.read_model(base).score(frames.astype(np.float64))
     assert np.abs(g.score(frames) - ref).max() <= TOL
+
+
+def test_layout_selection(capi):
+    """Uniform models take the grouped-track kernel, ragged ones the independent
+    tracks, models whose peak likelihood leaves no exponent headroom the general
+    kernel."""
+    g = capi.Gmm.from_arrays(*synth.make_model(D=39, G=2048, S=128, comps=16))
+    assert g.active_layout() == 1
+    g = capi.Gmm.from_arrays(*synth.make_model(D=39, G=8192, S=64, comps_range=(1, 150), seed=5, tied=True))
+    assert g.active_layout() == 2
+    mean, var, off, idx, w = synth.make_model(D=39, G=64, S=8, comps=8)
+    g = capi.Gmm.from_arrays(mean, var * 1e-4, off, idx, w)   # sigma ~ 0.01: ill-conditioned
+    assert g.active_layout() == 4
+
+
+def test_ill_conditioned_model_takes_the_centred_kernel(capi, oracle):
+    """sigma ~ 0.03 with means ~ N(0,1): the expanded (GEMM) form would lose
+    ~1e-2 to cancellation; the launcher must pick the centred form by itself."""
+    mean, var, off, idx, w = synth.make_model(D=39, G=64, S=8, comps=8, seed=21)
+    var = var * 1e-3
+    frames = (mean[np.arange(40) % 64] + 0.03 * synth.make_frames(40, seed=5)).astype(np.float32)
+    worst, used = _check(capi, oracle, (mean, var, off, idx, w), frames, tol=2e-4, layouts=[7, 4])
+    assert used == {4}
 
 
 def test_block_partition_invariance(capi):
