@@ -529,43 +529,59 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
     const int32_t *__restrict__ state_off, const int32_t *__restrict__ split_state,
     float *__restrict__ out, int64_t S) {
   constexpr int REC = 2 * DIMP + 4;  // [mu x DIMP][p' x DIMP][C, pad, pad, pad]
-  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t fc = f < F ? f : F - 1;
-  float x[DIMP];
+  // each lane owns TWO frames (f, f + 256): one scalar fetch of a Gaussian's
+  // parameters feeds 128 frame x Gaussian pairs per wave
+  const int64_t fa = (int64_t)blockIdx.x * 512 + threadIdx.x;
+  const int64_t fb = fa + 256;
+  const int64_t fac = fa < F ? fa : F - 1, fbc = fb < F ? fb : F - 1;
+  float xa[DIMP], xb[DIMP];
 #pragma unroll
-  for (int d = 0; d < DIMP; d++) x[d] = d < dim ? frames[fc * dim + d] : 0.0f;
+  for (int d = 0; d < DIMP; d++) {
+    xa[d] = d < dim ? frames[fac * dim + d] : 0.0f;
+    xb[d] = d < dim ? frames[fbc * dim + d] : 0.0f;
+  }
   const int s_begin = split_state[blockIdx.y], s_end = split_state[blockIdx.y + 1];
   for (int s = s_begin; s < s_end; s++) {
     const int r0 = state_off[s], r1 = state_off[s + 1];
-    float m = NEG_BIG_F, acc_s = 0.0f;
+    float ma = NEG_BIG_F, sa = 0.0f, mb = NEG_BIG_F, sb = 0.0f;
     for (int r = r0; r < r1; r++) {
       const float *rec = recs + (size_t)r * REC;
-      float a0 = 0.0f, a1 = 0.0f;  // two chains: halves the dependent-add latency
+      float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;  // two chains per frame
 #pragma unroll
       for (int d = 0; d < DIMP; d += 2) {
-        const float t0 = x[d] - rec[d];
-        const float t1 = x[d + 1] - rec[d + 1];
-        a0 = fmaf(t0 * t0, rec[DIMP + d], a0);
-        a1 = fmaf(t1 * t1, rec[DIMP + d + 1], a1);
+        const float mu0 = rec[d], mu1 = rec[d + 1];
+        const float p0 = rec[DIMP + d], p1 = rec[DIMP + d + 1];
+        const float ta0 = xa[d] - mu0, ta1 = xa[d + 1] - mu1;
+        const float tb0 = xb[d] - mu0, tb1 = xb[d + 1] - mu1;
+        a0 = fmaf(ta0 * ta0, p0, a0);
+        a1 = fmaf(ta1 * ta1, p1, a1);
+        b0 = fmaf(tb0 * tb0, p0, b0);
+        b1 = fmaf(tb1 * tb1, p1, b1);
       }
-      const float ll2 = rec[2 * DIMP] + (a0 + a1);  // log2 units
-      const float mn = fmaxf(m, ll2);
-      acc_s = acc_s * __builtin_amdgcn_exp2f(m - mn) + __builtin_amdgcn_exp2f(ll2 - mn);
-      m = mn;
+      const float c = rec[2 * DIMP];
+      const float la = c + (a0 + a1), lb = c + (b0 + b1);  // log2 units
+      const float na = fmaxf(ma, la), nb = fmaxf(mb, lb);
+      sa = sa * __builtin_amdgcn_exp2f(ma - na) + __builtin_amdgcn_exp2f(la - na);
+      sb = sb * __builtin_amdgcn_exp2f(mb - nb) + __builtin_amdgcn_exp2f(lb - nb);
+      ma = na;
+      mb = nb;
     }
-    float ll = fmaf(m, LN2_F, __builtin_amdgcn_logf(acc_s) * LN2_F);
-    ll = fmaxf(ll, LOG_TINY_F);
-    if (r1 <= r0) ll = LOG_TINY_F;
-    if (f < F) out[f * S + s] = ll;
+    float lla = fmaf(ma, LN2_F, __builtin_amdgcn_logf(sa) * LN2_F);
+    float llb = fmaf(mb, LN2_F, __builtin_amdgcn_logf(sb) * LN2_F);
+    lla = fmaxf(lla, LOG_TINY_F);
+    llb = fmaxf(llb, LOG_TINY_F);
+    if (r1 <= r0) lla = llb = LOG_TINY_F;
+    if (fa < F) out[fa * S + s] = lla;
+    if (fb < F) out[fb * S + s] = llb;
   }
 }
 
 template <int DIMP>
 static void launch_centred_t(const aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                              hipStream_t stream) {
-  const int64_t blocks = (F + 255) / 256;
-  // state-range cuts so that the grid fills the chip evenly (8 workgroups per CU)
-  const double slots = 8.0 * (g->num_cus > 0 ? g->num_cus : 256);
+  const int64_t blocks = (F + 511) / 512;
+  // state-range cuts so that the grid fills the chip evenly (4 workgroups per CU)
+  const double slots = 4.0 * (g->num_cus > 0 ? g->num_cus : 256);
   int R = 1;
   double best = 0;
   for (int r = 1; r <= g->centred_max_splits; r++) {
