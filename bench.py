@@ -152,7 +152,7 @@ def main():
     algo_flop = 4.0 * DIM * float(F) * float(rows)
     achieved = algo_flop / (k_ms * 1e-3) / 1e12
     roofline = {
-        "bound": "mfma", "kernel": "k_gmm_diag_score", "achieved": round(achieved, 3),
+        "bound": "mfma", "kernel": "k_gmm_diag_score_tracks<40,true>", "achieved": round(achieved, 3),
         "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
         "kernel_ms": round(k_ms, 4), "algorithmic_flop_per_launch": algo_flop,
