@@ -267,6 +267,33 @@ __global__ void k_power(DevBatch b, const double *__restrict__ src, SrcMap sm, i
   dst[r] = log((double)power + 1e-10);
 }
 
+// PowerModule when the source is an FFT module: every input is a float stored in
+// a double (FFTModule keeps float results), so (float)((double)power + x) is the
+// plain float sum power + (float)x.  One wave per frame: coalesced row load, then
+// the reference's left-to-right float accumulation with lane broadcasts.
+__global__ __launch_bounds__(256) void k_power_f32src(DevBatch b, const double *__restrict__ src,
+                                                      SrcMap sm, int span, int64_t rows,
+                                                      int src_dim, double *__restrict__ dst) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  if (r >= rows) return;
+  const double *data = src + src_row(b, r, span, sm) * src_dim;
+  float power = 0;
+  for (int base = 0; base < src_dim; base += 64) {
+    const float v = (base + lane < src_dim) ? (float)data[base + lane] : 0.0f;
+    const int cnt = src_dim - base < 64 ? src_dim - base : 64;
+    if (cnt == 64) {
+#pragma unroll
+      for (int i = 0; i < 64; i++)
+        power = power + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i));
+    } else {
+      for (int i = 0; i < cnt; i++)
+        power = power + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i));
+    }
+  }
+  if (lane == 0) dst[r] = log((double)power + 1e-10);
+}
+
 __global__ void k_dct(DevBatch b, const double *__restrict__ src, SrcMap sm, int span, int64_t rows,
                       int src_dim, int dim, int zeroth, const float *__restrict__ cs,
                       double *__restrict__ dst) {
@@ -331,6 +358,76 @@ __global__ void k_lin_transform(DevBatch b, const double *__restrict__ src, SrcM
   }
   if (bias) acc += (double)bias[i];
   dst[idx] = acc;
+}
+
+// LinTransformModule, tiled: a block stages ROWS source rows and the matrix in
+// LDS; thread (row, i) accumulates sum_j matrix[i][j]*src[j] in j order (same
+// order and types as the reference loop).
+template <int ROWS>
+__global__ __launch_bounds__(256) void k_lin_transform_tiled(
+    DevBatch b, const double *__restrict__ src, SrcMap sm, int span, int64_t rows, int src_dim,
+    int dim, const float *__restrict__ matrix, const float *__restrict__ bias,
+    double *__restrict__ dst) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double *xs = (double *)smem_raw;                  // [ROWS][src_dim]
+  float *ms = (float *)(xs + (size_t)ROWS * src_dim);  // [dim][src_dim + 1]
+  const int64_t r0 = (int64_t)blockIdx.x * ROWS;
+  const int mstride = src_dim + 1;
+  for (int e = threadIdx.x; e < dim * src_dim; e += 256)
+    ms[(e / src_dim) * mstride + (e % src_dim)] = matrix[e];
+  for (int e = threadIdx.x; e < ROWS * src_dim; e += 256) {
+    int64_t r = r0 + e / src_dim;
+    xs[e] = r < rows ? src[src_row(b, r, span, sm) * src_dim + (e % src_dim)] : 0.0;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < ROWS * dim; e += 256) {
+    const int lr = e / dim, i = e - lr * dim;
+    const int64_t r = r0 + lr;
+    if (r >= rows) continue;
+    const double *x = xs + (size_t)lr * src_dim;
+    const float *mr = ms + (size_t)i * mstride;
+    double acc = 0;
+    for (int j = 0; j < src_dim; j++) acc += (double)mr[j] * x[j];
+    if (bias) acc += (double)bias[i];
+    dst[r * dim + i] = acc;
+  }
+}
+
+// MeanSubtractorModule, tiled: the block's rows plus the window look-around are
+// staged in LDS once; each thread sums its window in frame order.
+template <int ROWS>
+__global__ __launch_bounds__(256) void k_mean_subtract_tiled(
+    DevBatch b, const double *__restrict__ src, SrcMap sm, int span, int64_t rows, int dim,
+    int left, int right, double *__restrict__ dst) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double *xs = (double *)smem_raw;  // [ROWS + left + right][dim]
+  const int64_t tile0 = (int64_t)blockIdx.x * ROWS;
+  const int64_t tile1 = tile0 + ROWS < rows ? tile0 + ROWS : rows;
+  // A tile may straddle utterances: source rows of consecutive module rows are
+  // consecutive only inside one utterance, so the tile is walked one utterance
+  // segment at a time (rows of utterance u: key(u) .. key(u+1)-1 with
+  // key(u) = frame_off[u] + u*span).
+  int64_t r0 = tile0;
+  while (r0 < tile1) {
+    const int u = find_utt(b, r0, span);
+    const int64_t u_end = b.frame_off[u + 1] + (int64_t)(u + 1) * span;
+    const int64_t r_end = u_end < tile1 ? u_end : tile1;
+    const int64_t s0 = r0 + (int64_t)u * sm.span_diff + sm.shift;  // source row of r0
+    const int n_seg = (int)(r_end - r0);
+    const int n_src = n_seg + left + right;
+    for (int e = threadIdx.x; e < n_src * dim; e += 256) xs[e] = src[(s0 - left) * dim + e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_seg * dim; e += 256) {
+      const int lr = e / dim, d = e - lr * dim;
+      const double *c = xs + (size_t)(lr + left) * dim + d;
+      double mean = 0;
+      for (int i = -left; i <= right; i++) mean += c[(ptrdiff_t)i * dim];
+      mean /= (left + right + 1);
+      dst[(r0 + lr) * dim + d] = c[0] - mean;
+    }
+    __syncthreads();
+    r0 = r_end;
+  }
 }
 
 struct MergeSrc {
@@ -503,8 +600,12 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
                            m.mel_sum.p, m.root, dst);
         break;
       case MOD_POWER:
-        hipLaunchKernelGGL(k_power, dim3(grid_for(rows)), dim3(256), 0, stream, db, src, sm, span,
-                           rows, h->mods[s0].dim, dst);
+        if (h->mods[s0].type == MOD_FFT)
+          hipLaunchKernelGGL(k_power_f32src, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream,
+                             db, src, sm, span, rows, h->mods[s0].dim, dst);
+        else
+          hipLaunchKernelGGL(k_power, dim3(grid_for(rows)), dim3(256), 0, stream, db, src, sm, span,
+                             rows, h->mods[s0].dim, dst);
         break;
       case MOD_DCT:
         hipLaunchKernelGGL(k_dct, dim3(grid_for(nelem)), dim3(256), 0, stream, db, src, sm, span,
@@ -518,12 +619,20 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
         hipLaunchKernelGGL(k_normalization, dim3(grid_for(nelem)), dim3(256), 0, stream, db, src,
                            sm, span, rows, m.dim, m.d_mean.p, m.d_scale.p, dst);
         break;
-      case MOD_LIN_TRANSFORM:
-        hipLaunchKernelGGL(k_lin_transform, dim3(grid_for(nelem)), dim3(256), 0, stream, db, src,
-                           sm, span, rows, m.src_dim, m.dim,
-                           m.matrix_defined ? m.d_matrix.p : (const float *)nullptr,
-                           m.bias_defined ? m.d_bias.p : (const float *)nullptr, dst);
+      case MOD_LIN_TRANSFORM: {
+        constexpr int LT_ROWS = 64;
+        const size_t lt_smem = (size_t)LT_ROWS * m.src_dim * 8 + (size_t)m.dim * (m.src_dim + 1) * 4;
+        if (m.matrix_defined && lt_smem <= 60 * 1024)
+          hipLaunchKernelGGL(k_lin_transform_tiled<LT_ROWS>, dim3((unsigned)((rows + LT_ROWS - 1) / LT_ROWS)),
+                             dim3(256), lt_smem, stream, db, src, sm, span, rows, m.src_dim, m.dim,
+                             m.d_matrix.p, m.bias_defined ? m.d_bias.p : (const float *)nullptr, dst);
+        else
+          hipLaunchKernelGGL(k_lin_transform, dim3(grid_for(nelem)), dim3(256), 0, stream, db, src,
+                             sm, span, rows, m.src_dim, m.dim,
+                             m.matrix_defined ? m.d_matrix.p : (const float *)nullptr,
+                             m.bias_defined ? m.d_bias.p : (const float *)nullptr, dst);
         break;
+      }
       case MOD_MERGE: {
         if (m.sources.size() > 8)
           raise(AASR_ERR_UNSUPPORTED, "merge module with more than 8 sources");
@@ -542,10 +651,18 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
                            m.dim, m.merge_src_col.p, dst);
         break;
       }
-      case MOD_MEAN_SUBTRACTOR:
-        hipLaunchKernelGGL(k_mean_subtract, dim3(grid_for(nelem)), dim3(256), 0, stream, db, src,
-                           sm, span, rows, m.dim, m.cms_left, m.cms_right, dst);
+      case MOD_MEAN_SUBTRACTOR: {
+        constexpr int MS_ROWS = 64;
+        const size_t ms_smem = (size_t)(MS_ROWS + m.cms_left + m.cms_right) * m.dim * 8;
+        if (ms_smem <= 60 * 1024)
+          hipLaunchKernelGGL(k_mean_subtract_tiled<MS_ROWS>, dim3((unsigned)((rows + MS_ROWS - 1) / MS_ROWS)),
+                             dim3(256), ms_smem, stream, db, src, sm, span, rows, m.dim, m.cms_left,
+                             m.cms_right, dst);
+        else
+          hipLaunchKernelGGL(k_mean_subtract, dim3(grid_for(nelem)), dim3(256), 0, stream, db, src,
+                             sm, span, rows, m.dim, m.cms_left, m.cms_right, dst);
         break;
+      }
     }
     AASR_HIP(hipGetLastError());
   }

@@ -121,7 +121,9 @@ __device__ __forceinline__ void lna_store(float lp, int lnabytes, int64_t o,
       ((float *)bytes_out)[o] = lp;
     } else {
       unsigned short code;
-      if ((double)lp < -36.008) {
+      // (double)lp < -36.008  <=>  lp < (float)-36.008: the float nearest to
+      // -36.008 lies on its zero side, so no float falls between the two
+      if (lp < -36.008f) {
         code = 0xffff;
       } else {
         int temp = (int)(-1820.0 * (double)lp + .5);
@@ -133,6 +135,12 @@ __device__ __forceinline__ void lna_store(float lp, int lnabytes, int64_t o,
   }
 }
 
+// Values stay float in registers; only elements inside the reference's float
+// denormal band (rare) take the double-precision quantisation detour.
+__device__ __forceinline__ float cast_f(float ll) {
+  return ll >= LN_FLT_MIN_F ? ll : (float)float_cast_loglik(ll);
+}
+
 template <int VPT>
 __global__ __launch_bounds__(256) void k_state_norm_lna_reg(
     const float *__restrict__ loglik, int64_t F, int S, int normalize, int lnabytes,
@@ -141,39 +149,41 @@ __global__ __launch_bounds__(256) void k_state_norm_lna_reg(
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int64_t f = blockIdx.x; f < F; f += gridDim.x) {
     const float *row = loglik + f * (int64_t)S;
-    double v[VPT];
+    float v[VPT];
 #pragma unroll
     for (int j = 0; j < VPT; j++) {
       const int i = tid + 256 * j;
-      v[j] = i < S ? float_cast_loglik(row[i]) : -INFINITY;
+      v[j] = i < S ? row[i] : -INFINITY;
     }
     double logz = 0.0;
     if (normalize) {
-      double m = -INFINITY;
+      float m = -INFINITY;
 #pragma unroll
-      for (int j = 0; j < VPT; j++) m = v[j] > m ? v[j] : m;
+      for (int j = 0; j < VPT; j++) m = fmaxf(m, cast_f(v[j]));
       m = wave_reduce_max(m);
-      if (lane == 0) red[wave] = m;
+      if (lane == 0) red[wave] = (double)m;
       __syncthreads();
-      m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+      m = (float)fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
       __syncthreads();
       if (m > -INFINITY) {
         double z = 0.0;
 #pragma unroll
-        for (int j = 0; j < VPT; j++) z += (double)expf((float)(v[j] - m));
+        for (int j = 0; j < VPT; j++)
+          z += (double)__builtin_amdgcn_exp2f((cast_f(v[j]) - m) * 1.44269504088896340736f);
         z = wave_reduce_sum(z);
         if (lane == 0) red[4 + wave] = z;
         __syncthreads();
         z = (red[4] + red[5]) + (red[6] + red[7]);
         __syncthreads();
-        logz = m + log(z);
+        logz = (double)m + log(z);
       }
     }
 #pragma unroll
     for (int j = 0; j < VPT; j++) {
       const int i = tid + 256 * j;
       if (i < S) {
-        double lpd = v[j] - logz;
+        const double vd = v[j] >= LN_FLT_MIN_F ? (double)v[j] : float_cast_loglik(v[j]);
+        double lpd = vd - logz;
         if (!(lpd >= LOG_TINY_D)) lpd = LOG_TINY_D;
         lna_store((float)lpd, lnabytes, f * (int64_t)S + i, lp_out, bytes_out);
       }
