@@ -98,6 +98,7 @@ def _declare(L: C.CDLL) -> None:
     L.aasr_feat_run_batch_dev.argtypes = [vp, vp, vp, vp, i32, vp, vp]
     L.aasr_feat_set_parameters.argtypes = [vp, cp, cp]
     L.aasr_gmm_create_diag.argtypes = [i32, i32, vp, vp, i32, vp, vp, vp, pvp]
+    L.aasr_gmm_create_full.argtypes = [i32, i32, vp, vp, i32, vp, vp, vp, pvp]
     L.aasr_gmm_create_from_files.argtypes = [cp, cp, cp, pvp]
     L.aasr_gmm_destroy.argtypes = [vp]
     L.aasr_gmm_destroy.restype = None
@@ -166,6 +167,20 @@ class Gmm:
         mix_w = np.ascontiguousarray(mix_w, np.float64)
         h = C.c_void_p()
         check(lib().aasr_gmm_create_diag(mean.shape[1], mean.shape[0], _ptr(mean), _ptr(var),
+                                         len(mix_off) - 1, _ptr(mix_off), _ptr(mix_idx),
+                                         _ptr(mix_w), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_full(cls, mean, cov, mix_off, mix_idx, mix_w) -> "Gmm":
+        """Full-covariance pool: cov [G, D, D]."""
+        mean = np.ascontiguousarray(mean, np.float64)
+        cov = np.ascontiguousarray(cov, np.float64)
+        mix_off = np.ascontiguousarray(mix_off, np.int32)
+        mix_idx = np.ascontiguousarray(mix_idx, np.int32)
+        mix_w = np.ascontiguousarray(mix_w, np.float64)
+        h = C.c_void_p()
+        check(lib().aasr_gmm_create_full(mean.shape[1], mean.shape[0], _ptr(mean), _ptr(cov),
                                          len(mix_off) - 1, _ptr(mix_off), _ptr(mix_idx),
                                          _ptr(mix_w), C.byref(h)))
         return cls(h.value)

@@ -103,6 +103,45 @@ aasr_status aasr_gmm_create_diag(int32_t dim, int32_t num_gaussians, const doubl
   });
 }
 
+aasr_status aasr_gmm_create_full(int32_t dim, int32_t num_gaussians, const double *mean,
+                                 const double *cov, int32_t num_states, const int32_t *mix_off,
+                                 const int32_t *mix_idx, const double *mix_w, aasr_gmm **out) {
+  return guarded([&] {
+    if (!out || !mean || !cov || !mix_off || !mix_idx || !mix_w)
+      raise(AASR_ERR_INVALID, "aasr_gmm_create_full: null argument");
+    if (dim <= 0 || num_gaussians <= 0 || num_states <= 0)
+      raise(AASR_ERR_INVALID, "aasr_gmm_create_full: non-positive size");
+    *out = nullptr;
+    HostModel m;
+    m.dim = dim;
+    m.G = num_gaussians;
+    m.S = num_states;
+    const size_t D = (size_t)dim;
+    m.mean.assign(mean, mean + (size_t)num_gaussians * D);
+    m.cov.assign(cov, cov + (size_t)num_gaussians * D * D);
+    m.is_full.assign((size_t)num_gaussians, 1);
+    m.var.resize((size_t)num_gaussians * D);
+    for (size_t g = 0; g < (size_t)num_gaussians; g++)
+      for (size_t i = 0; i < D; i++) m.var[g * D + i] = cov[g * D * D + i * D + i];
+    m.mix_off.assign(mix_off, mix_off + num_states + 1);
+    if (m.mix_off[0] != 0) raise(AASR_ERR_INVALID, "mix_off[0] must be 0");
+    for (int s = 0; s < num_states; s++)
+      if (m.mix_off[s + 1] < m.mix_off[s]) raise(AASR_ERR_INVALID, "mix_off must be non-decreasing");
+    size_t K = (size_t)m.mix_off[num_states];
+    m.mix_idx.assign(mix_idx, mix_idx + K);
+    m.mix_w.assign(mix_w, mix_w + K);
+    aasr_gmm *g = new aasr_gmm();
+    try {
+      AASR_HIP(hipGetDevice(&g->device));
+      gmm_build(g, m);
+    } catch (...) {
+      delete g;
+      throw;
+    }
+    *out = g;
+  });
+}
+
 aasr_status aasr_gmm_create_from_files(const char *gk_path, const char *mc_path,
                                        const char *ph_path, aasr_gmm **out) {
   return guarded([&] {

@@ -17,6 +17,12 @@ struct HostModel {
   int dim = 0;
   int64_t G = 0;
   std::vector<double> mean, var;        // [G x dim]
+  // full-covariance Gaussians (FullCovarianceGaussian, aku/Distributions.cc
+  // :1466-1488): cov is [G x dim x dim] row-major, is_full[g] marks which
+  // entries use it; both empty for purely diagonal pools
+  std::vector<double> cov;
+  std::vector<uint8_t> is_full;
+  bool any_full() const { return !is_full.empty(); }
   int64_t S = 0;
   std::vector<int32_t> mix_off;         // [S+1]
   std::vector<int32_t> mix_idx;         // [K]
@@ -76,6 +82,23 @@ struct TrackLayout {
   float ref_ln = 0.0f;       // reference exponent * ln 2
 };
 
+// Row layout of the full-covariance kernel: every mixture component occupies
+// ceil(dim/4) consecutive quads of one track with the rows of
+// sqrt(log2e/2) * R^-1 (Sigma = R R^T), so that the accumulator holds
+// y = R^-1 (x - mu) and the quadratic form is a sum of squares.
+struct FullLayout {
+  bool ok = false;
+  PackedRows rows;
+  DevBuf<uint32_t> close;   // per tile: bits 0-7/8-15 Gaussian closes (track 0/1),
+                            //           bits 16-23/24-31 state closes
+  DevBuf<float> gconst;     // [2][g_stride] (c_g + log w)*log2e + ref per Gaussian close
+  DevBuf<int32_t> sid;      // [2][s_stride] state index per state close
+  int32_t g_stride = 0, s_stride = 0;
+  DevBuf<int32_t> splits;   // [MAX_SPLITS][MAX_SPLITS+1][8]: tile, ks0, ks1, kg0, kg1
+  int max_splits = 1;
+  float ref_ln = 0.0f;
+};
+
 }  // namespace aasr
 
 struct aasr_gmm {
@@ -92,6 +115,9 @@ struct aasr_gmm {
   // track layouts for the in-register epilogue (built when eligible)
   aasr::TrackLayout paired;   // grouped: states 2j/2j+1 side by side
   aasr::TrackLayout tracks;   // independent tracks (built when `paired` is not)
+  // full-covariance path (k_gmm_full_score): rows are the rows of R^-1 of
+  // every component, see gmm_build_fullcov()
+  aasr::FullLayout full;
   int num_cus = 0;
   int layout_mask = 7;        // see aasr_debug_set_layouts()
   // centred-form (numerically safe) kernel operands
@@ -111,6 +137,9 @@ void gmm_build(aasr_gmm *g, const HostModel &m);
 void gmm_build_pool(aasr_gmm *g);
 void gmm_build_tracks(aasr_gmm *g, bool grouped);
 void gmm_build_centred(aasr_gmm *g);
+void gmm_build_fullcov(aasr_gmm *g);
+void gmm_full_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
+                     hipStream_t stream);
 void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F,
                       float *d_out, hipStream_t stream);
 void gmm_gauss_launch(aasr_gmm *g, const float *d_frames, int64_t F,

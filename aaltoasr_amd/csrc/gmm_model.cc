@@ -34,28 +34,44 @@ HostModel read_model_files(const char *gk, const char *mc, const char *ph) {
     if (!in || pdfs < 0 || m.dim <= 0)
       raise(AASR_ERR_INVALID, "PDFPool::read_gk(): error reading file: %s", gk);
     bool variable = (type == "variable");
-    if (!variable && type != "diagonal_cov") {
-      if (type == "full_cov" || type == "pcgmm" || type == "scgmm")
+    bool all_full = (type == "full_cov");
+    if (!variable && !all_full && type != "diagonal_cov") {
+      if (type == "pcgmm" || type == "scgmm")
         raise(AASR_ERR_UNSUPPORTED,
-              "gk type '%s' (non-diagonal Gaussians) is not built in this engine yet", type.c_str());
+              "gk type '%s' (subspace Gaussians) is not built in this engine yet", type.c_str());
       raise(AASR_ERR_INVALID, "Unknown model type");
     }
     m.G = pdfs;
-    m.mean.resize((size_t)pdfs * m.dim);
-    m.var.resize((size_t)pdfs * m.dim);
+    const size_t D = (size_t)m.dim;
+    m.mean.resize((size_t)pdfs * D);
+    m.var.assign((size_t)pdfs * D, 0.0);
     for (long g = 0; g < pdfs; g++) {
+      bool full = all_full;
       if (variable) {
         in >> type;
-        if (type != "diag") {
-          if (type == "full" || type == "pcgmm" || type == "scgmm" ||
-              type == "precision_subspace" || type == "exponential_subspace")
+        if (type == "full") {
+          full = true;
+        } else if (type != "diag") {
+          if (type == "pcgmm" || type == "scgmm" || type == "precision_subspace" ||
+              type == "exponential_subspace")
             raise(AASR_ERR_UNSUPPORTED,
                   "Gaussian type '%s' is not built in this engine yet", type.c_str());
           raise(AASR_ERR_INVALID, "Unknown model type\n%s", type.c_str());
         }
       }
-      for (int i = 0; i < m.dim; i++) in >> m.mean[(size_t)g * m.dim + i];
-      for (int i = 0; i < m.dim; i++) in >> m.var[(size_t)g * m.dim + i];
+      for (size_t i = 0; i < D; i++) in >> m.mean[(size_t)g * D + i];
+      if (full) {
+        if (m.is_full.empty()) {
+          m.is_full.assign((size_t)pdfs, 0);
+          m.cov.assign((size_t)pdfs * D * D, 0.0);
+        }
+        m.is_full[(size_t)g] = 1;
+        // FullCovarianceGaussian::read (aku/Distributions.cc:1466-1488): row-major d x d
+        for (size_t i = 0; i < D * D; i++) in >> m.cov[(size_t)g * D * D + i];
+        for (size_t i = 0; i < D; i++) m.var[(size_t)g * D + i] = m.cov[(size_t)g * D * D + i * D + i];
+      } else {
+        for (size_t i = 0; i < D; i++) in >> m.var[(size_t)g * D + i];
+      }
       if (in.fail())
         raise(AASR_ERR_INVALID, "Error in reading Gaussian specifications");
     }
@@ -136,6 +152,31 @@ HostModel read_model_files(const char *gk, const char *mc, const char *ph) {
 // ---------------------------------------------------------------------------
 // packing
 // ---------------------------------------------------------------------------
+
+// Writes explicit coefficient rows (coef[r][k], k = 2*kk + h) into the tile
+// layout; rows beyond n_rows are zero.
+static void pack_coef_rows(int nkk, const std::vector<double> &coef, int64_t n_rows,
+                           PackedRows &out) {
+  out.nkk = nkk;
+  out.rows = n_rows;
+  out.tiles = std::max<int64_t>(1, (n_rows + TILE_ROWS - 1) / TILE_ROWS);
+  const size_t tile_floats = (size_t)(nkk / 2) * 64 * 4;
+  const size_t K = 2 * (size_t)nkk;
+  std::vector<float> a((size_t)out.tiles * tile_floats, 0.0f);
+  for (int64_t r = 0; r < n_rows; r++) {
+    int64_t t = r / TILE_ROWS;
+    int j = (int)(r % TILE_ROWS);
+    int mb = j / 32, r32 = j % 32;
+    for (int kk = 0; kk < nkk; kk++) {
+      int q = kk / 2, e = kk % 2;
+      for (int h = 0; h < 2; h++) {
+        size_t idx = (size_t)t * tile_floats + ((size_t)q * 64 + (size_t)(h * 32 + r32)) * 4 + (size_t)(mb * 2 + e);
+        a[idx] = (float)coef[(size_t)r * K + 2 * kk + h];
+      }
+    }
+  }
+  out.a.upload(a.data(), a.size());
+}
 
 struct RowSpec {
   int64_t g;        // pool Gaussian, < 0 for a null (padding) row
@@ -251,6 +292,14 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
     g->pivot[d] = (float)(acc / (double)m.G);
   }
   g->d_pivot.upload(g->pivot.data(), g->pivot.size());
+  if (m.any_full()) {
+    // pools with full-covariance Gaussians are scored by k_gmm_full_score only
+    if ((int64_t)m.cov.size() != m.G * m.dim * m.dim || (int64_t)m.is_full.size() != m.G)
+      raise(AASR_ERR_INVALID, "covariance array does not match the pool size");
+    g->mix.rows = (int64_t)m.mix_idx.size();
+    gmm_build_fullcov(g);
+    return;
+  }
 
   // component-expanded rows in state order + segment metadata
   std::vector<RowSpec> rows;
@@ -580,6 +629,221 @@ void gmm_build_centred(aasr_gmm *g) {
   }
   g->centred_splits.upload(table.data(), table.size());
   g->centred_ok = true;
+}
+
+// ---------------------------------------------------------------------------
+// Full-covariance Gaussians (G2; FullCovarianceGaussian, Distributions.cc
+// :1412-1446, 1466-1488, 1559-1586).  The reference inverts Sigma (LU), takes
+// log sqrt det P by its own Cholesky and scores with the 819-term exponential
+// form theta.phi(f).  Here Sigma = R R^T (Cholesky, double, host) and
+//     -1/2 (x-mu)^T P (x-mu) = -1/2 || R^-1 (x-mu) ||^2
+// so each component contributes the dim rows of sqrt(log2e/2)*R^-1 (and the
+// bias -R^-1 mu' in the constant column) to the streamed operand: the MFMA
+// accumulators hold y directly, the epilogue squares and sums -- no
+// cancellation, K = dim+1 instead of dim(dim+3)/2.  A diagonal Gaussian in a
+// mixed pool is the special case R = diag(sigma).  Non-SPD covariance: the
+// reference zeroes the precision and the constant (an "invalid" Gaussian with
+// log-likelihood 0); mirrored.
+// ---------------------------------------------------------------------------
+static bool cholesky_lower(int d, const double *a, std::vector<double> &r) {
+  r.assign((size_t)d * d, 0.0);
+  for (int j = 0; j < d; j++) {
+    double s = a[(size_t)j * d + j];
+    for (int k = 0; k < j; k++) s -= r[(size_t)j * d + k] * r[(size_t)j * d + k];
+    if (!(s > 0)) return false;
+    double rjj = std::sqrt(s);
+    r[(size_t)j * d + j] = rjj;
+    for (int i = j + 1; i < d; i++) {
+      double t = 0.5 * (a[(size_t)i * d + j] + a[(size_t)j * d + i]);
+      for (int k = 0; k < j; k++) t -= r[(size_t)i * d + k] * r[(size_t)j * d + k];
+      r[(size_t)i * d + j] = t / rjj;
+    }
+  }
+  return true;
+}
+
+static void invert_lower(int d, const std::vector<double> &r, std::vector<double> &w) {
+  w.assign((size_t)d * d, 0.0);
+  for (int c = 0; c < d; c++) {
+    w[(size_t)c * d + c] = 1.0 / r[(size_t)c * d + c];
+    for (int i = c + 1; i < d; i++) {
+      double s = 0;
+      for (int k = c; k < i; k++) s += r[(size_t)i * d + k] * w[(size_t)k * d + c];
+      w[(size_t)i * d + c] = -s / r[(size_t)i * d + i];
+    }
+  }
+}
+
+void gmm_build_fullcov(aasr_gmm *g) {
+  const HostModel &m = g->host;
+  FullLayout &L = g->full;
+  L.ok = false;
+  const int D = m.dim;
+  // K = D + 1 coefficient slots (k = 0..D) -> K/2 = D/2 + 1 MFMA steps;
+  // pick_nkk(x) returns the smallest kernel instance >= x + 1
+  const int nkk = pick_nkk(D / 2);
+  if (nkk < 0) raise(AASR_ERR_UNSUPPORTED, "feature dimension %d is not built for full covariances", D);
+  const int K2 = 2 * nkk;
+  if (D + 1 > K2) raise(AASR_ERR_UNSUPPORTED, "feature dimension %d is not built for full covariances", D);
+  const int gq = (D + 3) / 4;  // quads per component
+  const double sc = std::sqrt(0.5 * kLog2e);
+
+  // per-Gaussian factor rows, constants
+  std::vector<double> Wall((size_t)m.G * D * D, 0.0), cst((size_t)m.G, 0.0);
+  std::vector<double> r, w, a((size_t)D * D);
+  double max_c = -INFINITY;
+  for (int64_t gi = 0; gi < m.G; gi++) {
+    if (m.any_full() && m.is_full[(size_t)gi]) {
+      for (int i = 0; i < D * D; i++) a[(size_t)i] = m.cov[(size_t)gi * D * D + i];
+    } else {
+      std::fill(a.begin(), a.end(), 0.0);
+      for (int i = 0; i < D; i++) a[(size_t)i * D + i] = m.var[(size_t)gi * D + i];
+    }
+    if (cholesky_lower(D, a.data(), r)) {
+      invert_lower(D, r, w);
+      double ld = 0;
+      for (int i = 0; i < D; i++) ld += std::log(r[(size_t)i * D + i]);
+      cst[(size_t)gi] = -ld;  // log sqrt det P
+      for (int i = 0; i < D * D; i++) Wall[(size_t)gi * D * D + i] = w[(size_t)i];
+    } else {
+      cst[(size_t)gi] = 0.0;  // invalid: precision 0, constant 0
+    }
+    max_c = std::max(max_c, cst[(size_t)gi]);
+  }
+  double ref = std::floor(std::min(kRefMax, kPeakMax - max_c * kLog2e));
+  if (!(ref >= kRefMin))
+    raise(AASR_ERR_UNSUPPORTED,
+          "full-covariance model leaves no f32 exponent headroom (peak log-likelihood %.1f)", max_c);
+  L.ref_ln = (float)(ref * 0.69314718055994530942);
+
+  // placement: states on the shorter track, components back to back
+  std::vector<int8_t> st_track((size_t)m.S);
+  std::vector<int64_t> st_pos((size_t)m.S);
+  int64_t len[2] = {0, 0};
+  int64_t ks[2] = {0, 0}, kg[2] = {0, 0};
+  std::vector<int64_t> cand[5];
+  for (auto &c : cand) c.push_back(0);
+  auto quads_of = [&](int64_t s) {
+    return std::max<int64_t>(1, (int64_t)(m.mix_off[s + 1] - m.mix_off[s]) * gq);
+  };
+  int64_t total_quads = 0;
+  for (int64_t s = 0; s < m.S; s++) total_quads += quads_of(s);
+  const int64_t sync_every = std::max<int64_t>(64, total_quads / 2 / 32);
+  int64_t next_sync = sync_every;
+  for (int64_t s = 0; s < m.S; s++) {
+    int h = len[1] < len[0] ? 1 : 0;
+    st_track[(size_t)s] = (int8_t)h;
+    st_pos[(size_t)s] = len[h];
+    len[h] += quads_of(s);
+    ks[h]++;
+    kg[h] += std::max<int64_t>(1, m.mix_off[s + 1] - m.mix_off[s]);
+    if (std::min(len[0], len[1]) >= next_sync && s + 1 < m.S) {
+      int64_t top = (std::max(len[0], len[1]) + 7) / 8 * 8;
+      len[0] = len[1] = top;
+      cand[0].push_back(top / 8);
+      cand[1].push_back(ks[0]);
+      cand[2].push_back(ks[1]);
+      cand[3].push_back(kg[0]);
+      cand[4].push_back(kg[1]);
+      next_sync = top + sync_every;
+    }
+  }
+  const int64_t tiles = std::max<int64_t>(1, (std::max(len[0], len[1]) + 7) / 8);
+  if (cand[0].back() == tiles)
+    for (auto &c : cand) c.pop_back();
+  cand[0].push_back(tiles);
+  cand[1].push_back(ks[0]);
+  cand[2].push_back(ks[1]);
+  cand[3].push_back(kg[0]);
+  cand[4].push_back(kg[1]);
+
+  std::vector<double> coef((size_t)tiles * TILE_ROWS * K2, 0.0);
+  std::vector<uint32_t> close((size_t)tiles, 0);
+  std::vector<float> gc[2];
+  std::vector<int32_t> sid[2];
+  for (int64_t s = 0; s < m.S; s++) {
+    const int h = st_track[(size_t)s];
+    int64_t p = st_pos[(size_t)s];
+    const int32_t a0 = m.mix_off[s], b0 = m.mix_off[s + 1];
+    if (b0 <= a0) {
+      // empty state: one null component whose constant underflows to nothing
+      gc[h].push_back(kNullConst);
+      close[(size_t)(p / 8)] |= 1u << (p % 8 + 8 * h);
+      close[(size_t)(p / 8)] |= 1u << (16 + p % 8 + 8 * h);
+      sid[h].push_back((int32_t)s);
+      continue;
+    }
+    for (int32_t k = a0; k < b0; k++) {
+      const int64_t gi = m.mix_idx[k];
+      const double *W = &Wall[(size_t)gi * D * D];
+      for (int i = 0; i < D; i++) {
+        const int64_t row = track_row(p + i / 4, h, i % 4);
+        double *cr = &coef[(size_t)row * K2];
+        double bias = 0;
+        for (int d = 0; d < D; d++) {
+          cr[d] = sc * W[(size_t)i * D + d];
+          bias += W[(size_t)i * D + d] * (m.mean[(size_t)gi * D + d] - (double)g->pivot[d]);
+        }
+        cr[D] = -sc * bias;
+      }
+      const double wgt = m.mix_w[k];
+      const double c = cst[(size_t)gi] + (wgt > 0 ? std::log(wgt) : -INFINITY);
+      gc[h].push_back(std::isfinite(c) ? (float)(c * kLog2e + ref) : kNullConst);
+      const int64_t last = p + gq - 1;
+      close[(size_t)(last / 8)] |= 1u << (last % 8 + 8 * h);
+      if (k + 1 == b0) {
+        close[(size_t)(last / 8)] |= 1u << (16 + last % 8 + 8 * h);
+        sid[h].push_back((int32_t)s);
+      }
+      p += gq;
+    }
+  }
+  const size_t gs = std::max(gc[0].size(), gc[1].size()) + 1;
+  const size_t ss = std::max(sid[0].size(), sid[1].size()) + 1;
+  std::vector<float> gflat(2 * gs, kNullConst);
+  std::vector<int32_t> sflat(2 * ss, 0);
+  for (int h = 0; h < 2; h++) {
+    for (size_t k = 0; k < gc[h].size(); k++) gflat[h * gs + k] = gc[h][k];
+    for (size_t k = 0; k < sid[h].size(); k++) sflat[h * ss + k] = sid[h][k];
+  }
+  L.g_stride = (int32_t)gs;
+  L.s_stride = (int32_t)ss;
+  L.gconst.upload(gflat.data(), gflat.size());
+  L.sid.upload(sflat.data(), sflat.size());
+  L.close.upload(close.data(), close.size());
+  // split table, entries of 8 ints
+  {
+    std::vector<int32_t> table((size_t)TRACK_MAX_SPLITS * (TRACK_MAX_SPLITS + 1) * 8, 0);
+    L.max_splits = 1;
+    const size_t nc = cand[0].size();
+    for (int R = 1; R <= TRACK_MAX_SPLITS; R++) {
+      std::vector<size_t> pick{0};
+      bool ok = true;
+      for (int i = 1; i < R && ok; i++) {
+        double want = (double)tiles * i / R;
+        size_t best = pick.back();
+        double bd = 1e300;
+        for (size_t c = pick.back() + 1; c + 1 < nc; c++) {
+          double dd = std::fabs((double)cand[0][c] - want);
+          if (dd < bd) { bd = dd; best = c; }
+        }
+        if (best == pick.back()) ok = false;
+        pick.push_back(best);
+      }
+      if (!ok) break;
+      pick.push_back(nc - 1);
+      int64_t worst = 0;
+      for (int i = 0; i < R; i++) worst = std::max(worst, cand[0][pick[i + 1]] - cand[0][pick[i]]);
+      if ((double)worst > 1.25 * (double)tiles / R + 1) break;
+      int32_t *row = &table[(size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 8];
+      for (int i = 0; i <= R; i++)
+        for (int c = 0; c < 5; c++) row[8 * i + c] = (int32_t)cand[c][pick[i]];
+      L.max_splits = R;
+    }
+    L.splits.upload(table.data(), table.size());
+  }
+  pack_coef_rows(nkk, coef, tiles * TILE_ROWS, L.rows);
+  L.ok = true;
 }
 
 void gmm_build_pool(aasr_gmm *g) {

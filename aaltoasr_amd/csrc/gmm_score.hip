@@ -510,6 +510,179 @@ static bool launch_tracks(const aasr_gmm *g, const TrackLayout &L, const float *
 }
 
 // ---------------------------------------------------------------------------
+// Full-covariance kernel (see gmm_build_fullcov()).
+//
+// Same frame-stationary skeleton; the streamed rows are the rows of
+// sqrt(log2e/2) * R^-1 of every mixture component (Sigma = R R^T), K = dim + 1.
+// The accumulators hold y = R^-1 (x - mu); the epilogue squares and sums them
+// per component (one FMA per value), turns each finished component into
+// 2^(C_g - |y|^2 + ref) and adds it to its state's running sum.  Two
+// independent row tracks, results stored per state.
+// ---------------------------------------------------------------------------
+template <int NKK>
+__global__ __launch_bounds__(256, 2) void k_gmm_full_score(
+    const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
+    const float *__restrict__ apack, const int32_t *__restrict__ split_row,
+    const uint32_t *__restrict__ close_mask, const float *__restrict__ gconst, int g_stride,
+    const int32_t *__restrict__ sid, int s_stride, float *__restrict__ out, int64_t S, float ref_ln) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *smem = (float *)smem_raw;
+  constexpr int kTileFloats = (NKK / 2) * 64 * 4;
+  float *abuf0 = smem;
+  float *abuf1 = smem + kTileFloats;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int n = lane & 31;
+  const int h = lane >> 5;
+  const int64_t f0 = (int64_t)blockIdx.x * FRAMES_PER_BLOCK + wave * FRAMES_PER_WAVE;
+
+  // B[kk][nb]: K index k = 2*kk + h -> x'_k (k < dim), 1 (k == dim), 0 beyond
+  float bf[NKK][2];
+#pragma unroll
+  for (int nb = 0; nb < 2; nb++) {
+    int64_t f = f0 + nb * 32 + n;
+    if (f > F - 1) f = F - 1;
+    const float *xr = frames + f * dim;
+#pragma unroll
+    for (int kk = 0; kk < NKK; kk++) {
+      const int k = 2 * kk + h;
+      const int kc = k < dim ? k : 0;
+      float v = xr[kc] - pivot[kc];
+      if (k == dim) v = 1.0f;
+      if (k > dim) v = 0.0f;
+      bf[kk][nb] = v;
+    }
+  }
+
+  const int64_t t_begin = split_row[8 * blockIdx.y];
+  const int64_t t_end = split_row[8 * blockIdx.y + 8];
+  issue_tile_copy(apack + (size_t)t_begin * kTileFloats, abuf0, kTileFloats, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  float q0 = 0.0f, q1 = 0.0f;  // |y|^2 of the open component, frames n / 32+n
+  float s0 = 0.0f, s1 = 0.0f;  // sum over finished components of the open state
+  int ks = split_row[8 * blockIdx.y + 1 + h];
+  int kg = split_row[8 * blockIdx.y + 3 + h];
+  const int32_t *my_sid = sid + h * s_stride;
+  const float *my_gc = gconst + h * g_stride;
+  int next_sid = my_sid[ks];
+  float next_gc = my_gc[kg];
+  float *orow0 = out + (f0 + n) * S;
+  float *orow1 = out + (f0 + 32 + n) * S;
+  const bool ok0 = f0 + n < F, ok1 = f0 + 32 + n < F;
+
+  for (int64_t t = t_begin; t < t_end; t++) {
+    const int par = (int)((t - t_begin) & 1);
+    float *acur = par ? abuf1 : abuf0;
+    float *anext = par ? abuf0 : abuf1;
+    if (t + 1 < t_end)
+      issue_tile_copy(apack + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
+    const unsigned m32 = close_mask[t];
+    const unsigned gmask = h ? ((m32 >> 8) & 0xffu) : (m32 & 0xffu);
+    const unsigned smask = h ? ((m32 >> 24) & 0xffu) : ((m32 >> 16) & 0xffu);
+
+    f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
+    const f32x4 *afrag = (const f32x4 *)acur + lane;
+    f32x4 a0 = afrag[0];
+    f32x4 a1 = afrag[(NKK / 2 > 1 ? 1 : 0) * 64];
+#pragma unroll
+    for (int q = 0; q < NKK / 2; q++) {
+      const int qn = (q + 2 < NKK / 2) ? q + 2 : NKK / 2 - 1;
+      f32x4 a2 = afrag[qn * 64];
+      const f32x4 av = a0;
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf[2 * q][0], c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf[2 * q][1], c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf[2 * q][0], c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf[2 * q][1], c11, 0, 0, 0);
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf[2 * q + 1][0], c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf[2 * q + 1][1], c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf[2 * q + 1][0], c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf[2 * q + 1][1], c11, 0, 0, 0);
+      a0 = a1;
+      a1 = a2;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+#pragma unroll
+    for (int mb = 0; mb < 2; mb++) {
+      const f32x16 &ca = mb ? c10 : c00;
+      const f32x16 &cb = mb ? c11 : c01;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          q0 = fmaf(ca[4 * q + e], ca[4 * q + e], q0);
+          q1 = fmaf(cb[4 * q + e], cb[4 * q + e], q1);
+        }
+        if ((gmask >> (mb * 4 + q)) & 1) {
+          s0 += __builtin_amdgcn_exp2f(next_gc - q0);
+          s1 += __builtin_amdgcn_exp2f(next_gc - q1);
+          q0 = 0.0f;
+          q1 = 0.0f;
+          kg++;
+          next_gc = my_gc[kg];
+          if ((smask >> (mb * 4 + q)) & 1) {
+            float l0 = fmaf(__builtin_amdgcn_logf(s0), LN2_F, -ref_ln);
+            float l1 = fmaf(__builtin_amdgcn_logf(s1), LN2_F, -ref_ln);
+            l0 = fmaxf(l0, LOG_TINY_F);
+            l1 = fmaxf(l1, LOG_TINY_F);
+            if (ok0) orow0[next_sid] = l0;
+            if (ok1) orow1[next_sid] = l1;
+            s0 = 0.0f;
+            s1 = 0.0f;
+            ks++;
+            next_sid = my_sid[ks];
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int NKK>
+static void launch_full_t(const aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
+                          hipStream_t stream) {
+  const FullLayout &L = g->full;
+  const int64_t blocks = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
+  const int smem = 2 * (NKK / 2) * 64 * 4 * 4;
+  const double slots = 2.0 * (g->num_cus > 0 ? g->num_cus : 256);
+  int R = 1;
+  double best_eff = 0;
+  for (int r = 1; r <= L.max_splits; r++) {
+    double x = (double)blocks * r / slots;
+    double eff = x / std::ceil(x);
+    if (x < 1.0) eff = x;
+    if (eff > best_eff + 0.005) {
+      best_eff = eff;
+      R = r;
+    }
+  }
+  const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 8;
+  hipLaunchKernelGGL(k_gmm_full_score<NKK>, dim3((unsigned)blocks, (unsigned)R), dim3(256), smem, stream,
+                     d_frames, F, g->dim, g->d_pivot.p, L.rows.a.p, split_row, L.close.p, L.gconst.p,
+                     L.g_stride, L.sid.p, L.s_stride, d_out, g->S, L.ref_ln);
+  AASR_HIP(hipGetLastError());
+}
+
+void gmm_full_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
+                     hipStream_t stream) {
+  if (!g->full.ok) raise(AASR_ERR_UNSUPPORTED, "full-covariance layout was not built for this model");
+  switch (g->full.rows.nkk) {
+#define AASR_CASE(N)                                   \
+  case N:                                              \
+    launch_full_t<N>(g, d_frames, F, d_out, stream);   \
+    return;
+    AASR_CASE(8) AASR_CASE(14) AASR_CASE(20) AASR_CASE(26) AASR_CASE(32)
+#undef AASR_CASE
+    default:
+      raise(AASR_ERR_UNSUPPORTED, "no full-covariance kernel instance for K/2 = %d", g->full.rows.nkk);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Centred-form kernel: the numerically safe path.
 //
 // The expanded (GEMM) form cancels when |mu - pivot| / sigma is large; models
@@ -691,6 +864,10 @@ extern "C" int aasr_debug_score_occupancy(void) {
 void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                       hipStream_t stream) {
   if (F <= 0) return;
+  if (g->host.any_full()) {
+    gmm_full_launch(g, d_frames, F, d_out, stream);
+    return;
+  }
   // numerically safe path first when the model needs it (or it is forced)
   if ((g->layout_mask & 4) && (g->ill_conditioned || g->precision == AASR_PREC_F32_CENTRED ||
                                !(g->layout_mask & 3) ) && g->centred_ok)
@@ -705,6 +882,8 @@ void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
 
 void gmm_gauss_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                       hipStream_t stream) {
+  if (g->host.any_full())
+    raise(AASR_ERR_UNSUPPORTED, "per-Gaussian log-likelihoods are not built for full-covariance pools");
   gmm_build_pool(g);
   launch<1>(g, g->pool, d_frames, F, d_out, g->G, stream);
 }

@@ -130,6 +130,16 @@ aasr_status aasr_gmm_create_diag(int32_t dim, int32_t num_gaussians,
                                  int32_t num_states, const int32_t *mix_off,
                                  const int32_t *mix_idx, const double *mix_w,
                                  aasr_gmm **out);
+/* Full-covariance pool (FullCovarianceGaussian::read / set_covariance,
+ * aku/Distributions.cc:1466-1488, 1559-1586): cov is [G x dim x dim] row-major.
+ * Non-SPD covariances become the reference's "invalid" Gaussian (precision and
+ * constant 0).  Scored like PDFPool::precompute_likelihoods' exponential-form
+ * branch (:2664-2680) but through the Cholesky factor, see DESIGN.md. */
+aasr_status aasr_gmm_create_full(int32_t dim, int32_t num_gaussians,
+                                 const double *mean, const double *cov,
+                                 int32_t num_states, const int32_t *mix_off,
+                                 const int32_t *mix_idx, const double *mix_w,
+                                 aasr_gmm **out);
 /* HmmSet::read_all(base) = read_mc + read_ph + read_gk
  * (aku/HmmSet.cc:351-357); individual paths like phone_probs -g -m -p.
  * ph_path may be NULL (state count = mixture count). */

@@ -763,3 +763,94 @@ def ref_aku():
     A.ref_module_config_get_floats.restype = C.c_int
     A.ref_module_config_get_floats.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_float), C.c_int]
     return A
+
+
+# ---------------------------------------------------------------------------
+# full-covariance Gaussians (G2)
+# ---------------------------------------------------------------------------
+
+def map_m2v(mat: np.ndarray) -> np.ndarray:
+    """LinearAlgebra::map_m2v (aku/LinearAlgebra.cc:219-240): lower triangle in
+    row order, off-diagonal elements times sqrt(2)."""
+    d = mat.shape[0]
+    out = []
+    for i in range(d):
+        for j in range(i + 1):
+            out.append(mat[i, j] if i == j else np.sqrt(2.0) * mat[i, j])
+    return np.array(out)
+
+
+class FullModel:
+    """FullCovarianceGaussian pool + mixtures, scored the way
+    PDFPool::precompute_likelihoods does without clustering
+    (aku/Distributions.cc:2664-2680): exponential feature phi(f) = [f ;
+    map_m2v(f f^T)], ll = theta . phi + normalizer + constant with
+    theta = [P mu ; -1/2 map_m2v(P)], normalizer = -1/2 mu^T P mu
+    (recompute_exponential_parameters, :1529-1547), constant = log sqrt det P
+    (set_covariance, :1559-1586).  A covariance that is not SPD (is_spd: all
+    eigenvalues > 0, aku/LinearAlgebra.cc:420-434) leaves precision and
+    constant at 0: an 'invalid' Gaussian with log-likelihood 0.
+
+    PARITY UNPINNED: no reference goldens; LapackPP (LU inverse, dsyev) is
+    replaced by numpy.linalg here."""
+
+    def __init__(self, mean, cov, mix_off, mix_idx, mix_w):
+        self.mean = np.ascontiguousarray(mean, np.float64)
+        self.cov = np.ascontiguousarray(cov, np.float64)
+        self.mix_off = np.ascontiguousarray(mix_off, np.int32)
+        self.mix_idx = np.ascontiguousarray(mix_idx, np.int32)
+        self.mix_w = np.ascontiguousarray(mix_w, np.float64).copy()
+        lib().orc_mixture_normalize(len(self.mix_off) - 1, _p(self.mix_off, C.c_int32),
+                                    _p(self.mix_w, C.c_double))
+        G, D = self.mean.shape
+        self.G, self.D, self.S = G, D, len(self.mix_off) - 1
+        self.theta = np.zeros((G, D * (D + 3) // 2))
+        self.norm = np.zeros(G)
+        self.cst = np.zeros(G)
+        self.valid = np.zeros(G, bool)
+        for g in range(G):
+            c = self.cov[g]
+            if np.all(np.linalg.eigvalsh(0.5 * (c + c.T)) > 0):
+                P = np.linalg.inv(c)
+                self.cst[g] = np.log(np.sqrt(np.linalg.det(P)))
+                tm = P @ self.mean[g]
+                self.norm[g] = -0.5 * tm @ self.mean[g]
+                self.theta[g, :D] = tm
+                self.theta[g, D:] = -0.5 * map_m2v(P)
+                self.valid[g] = True
+
+    def gauss_loglik(self, frames):
+        frames = np.asarray(frames, np.float64)
+        out = np.empty((frames.shape[0], self.G))
+        for f, x in enumerate(frames):
+            phi = np.concatenate([x, map_m2v(np.outer(x, x))])
+            out[f] = self.theta @ phi + self.norm + self.cst
+        return out
+
+    def score(self, frames):
+        ll = self.gauss_loglik(frames)
+        lik = np.exp(ll)
+        out = np.empty((ll.shape[0], self.S))
+        for s in range(self.S):
+            a, b = self.mix_off[s], self.mix_off[s + 1]
+            l = lik[:, self.mix_idx[a:b]] @ self.mix_w[a:b] if b > a else np.zeros(ll.shape[0])
+            out[:, s] = np.log(np.maximum(l, TINY_FOR_LOG))
+        return out
+
+
+def write_gk_full(path: str, mean: np.ndarray, cov: np.ndarray, is_full=None, var=None,
+                  legacy: bool = False) -> None:
+    """'variable' .gk with 'full' (mean + d*d covariance) and 'diag' entries, or
+    the legacy 'full_cov' header (aku/Distributions.cc:2823-2906)."""
+    G, D = mean.shape
+    with open(path, "w") as f:
+        f.write("%d %d %s\n" % (G, D, "full_cov" if legacy else "variable"))
+        for g in range(G):
+            full = True if is_full is None else bool(is_full[g])
+            vals = " ".join(repr(float(x)) for x in mean[g]) + " "
+            if full:
+                vals += " ".join(repr(float(x)) for x in cov[g].ravel())
+                f.write(vals + "\n" if legacy else "full " + vals + "\n")
+            else:
+                vals += " ".join(repr(float(x)) for x in var[g])
+                f.write("diag " + vals + "\n")

@@ -1,0 +1,80 @@
+"""GPU parity of the full-covariance path (BASELINE config 5
+in miniature): aasr_gmm_create_full / 'full' .gk files -> k_gmm_full_score
+against the oracle's exponential-form restatement
+(aku/Distributions.cc:1412-1446, 1529-1586, 2664-2680)."""
+import numpy as np
+import pytest
+
+from aaltoasr_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _full_model(D, G, S, comps, seed, tied=False):
+    rng = np.random.default_rng(seed)
+    mean = rng.standard_normal((G, D))
+    cov = np.empty((G, D, D))
+    for g in range(G):
+        a = rng.standard_normal((D, D)) * 0.35
+        cov[g] = a @ a.T + 0.1 * np.eye(D) + np.diag(rng.uniform(0.2, 1.0, D))
+    _, _, off, idx, w = synth.make_model(D=D, G=G, S=S, comps=comps, seed=seed, tied=tied)
+    return mean, cov, off, idx, w
+
+
+@pytest.mark.parametrize("D,G,S,comps,F", [(8, 64, 8, 8, 70), (13, 48, 12, 4, 130),
+                                            (39, 64, 16, 4, 100), (39, 60, 6, 10, 257)])
+def test_full_covariance_scoring(capi, oracle, D, G, S, comps, F):
+    mean, cov, off, idx, w = _full_model(D, G, S, comps, seed=D + G)
+    frames = synth.make_frames(F, D=D, seed=5)
+    ref = oracle.FullModel(mean, cov, off, idx, w).score(frames.astype(np.float64))
+    g = capi.Gmm.from_full(mean, cov, off, idx, w)
+    got = g.score(frames)
+    err = np.abs(got - ref)
+    assert err.max() <= 1e-4, "max |dll| %.3g" % err.max()
+
+
+def test_tied_and_ragged_states(capi, oracle):
+    rng = np.random.default_rng(3)
+    mean, cov, _, _, _ = _full_model(13, 40, 4, 4, seed=9)
+    n = np.array([1, 7, 0, 3, 12, 2])
+    off = np.concatenate([[0], np.cumsum(n)]).astype(np.int32)
+    idx = rng.integers(0, 40, off[-1]).astype(np.int32)
+    w = rng.uniform(0.1, 1.0, off[-1])
+    w[3] = 0.0
+    frames = synth.make_frames(90, D=13, seed=6)
+    ref = oracle.FullModel(mean, cov, off, idx, w).score(frames.astype(np.float64))
+    got = capi.Gmm.from_full(mean, cov, off, idx, w).score(frames)
+    assert np.abs(got - ref).max() <= 1e-4
+    assert np.allclose(got[:, 2], np.log(1e-50), atol=1e-5)
+
+
+def test_non_spd_covariance_is_the_reference_invalid_gaussian(capi, oracle):
+    mean, cov, off, idx, w = _full_model(8, 16, 2, 8, seed=4)
+    cov[5] = -np.eye(8)                      # not SPD -> precision 0, constant 0 -> ll == 0
+    frames = synth.make_frames(40, D=8, seed=7) * 2
+    ref = oracle.FullModel(mean, cov, off, idx, w).score(frames.astype(np.float64))
+    got = capi.Gmm.from_full(mean, cov, off, idx, w).score(frames)
+    assert np.abs(got - ref).max() <= 1e-4
+
+
+def test_full_gk_files_and_mixed_pool(capi, oracle, tmp_path):
+    mean, cov, off, idx, w = _full_model(8, 24, 3, 8, seed=12)
+    rng = np.random.default_rng(1)
+    is_full = rng.integers(0, 2, 24).astype(bool)
+    var = np.exp(rng.uniform(-1, 1, (24, 8)))
+    cov_eff = cov.copy()
+    for g in range(24):
+        if not is_full[g]:
+            cov_eff[g] = np.diag(var[g])
+    base = str(tmp_path / "mixed")
+    oracle.write_gk_full(base + ".gk", mean, cov, is_full=is_full, var=var)
+    oracle.write_mc(base + ".mc", off, idx, w)
+    oracle.write_ph(base + ".ph", 3)
+    frames = synth.make_frames(64, D=8, seed=2)
+    ref = oracle.FullModel(mean, cov_eff, off, idx, w).score(frames.astype(np.float64))
+    g = capi.Gmm.from_files(base + ".gk", base + ".mc", base + ".ph")
+    assert np.abs(g.score(frames) - ref).max() <= 1e-4
+    oracle.write_gk_full(base + "_legacy.gk", mean, cov, legacy=True)
+    ref2 = oracle.FullModel(mean, cov, off, idx, w).score(frames.astype(np.float64))
+    g2 = capi.Gmm.from_files(base + "_legacy.gk", base + ".mc", None)
+    assert np.abs(g2.score(frames) - ref2).max() <= 1e-4
