@@ -108,6 +108,7 @@ def _declare(L: C.CDLL) -> None:
     L.aasr_gmm_expanded_rows.argtypes = [vp]
     L.aasr_gmm_expanded_rows.restype = i64
     L.aasr_gmm_set_precision.argtypes = [vp, C.c_int]
+    L.aasr_gmm_set_cmllr.argtypes = [vp, i32, vp, vp]
     L.aasr_gmm_score.argtypes = [vp, vp, i64, vp]
     L.aasr_gmm_score_dev.argtypes = [vp, vp, i64, vp, vp]
     L.aasr_gmm_gauss_loglik.argtypes = [vp, vp, i64, vp]
@@ -218,6 +219,16 @@ class Gmm:
     @property
     def expanded_rows(self) -> int:
         return lib().aasr_gmm_expanded_rows(self._h)
+
+    def set_cmllr(self, gauss_to_transform=None, W=None) -> None:
+        """W [n, D, D+1] with column 0 = bias; gauss_to_transform [G] (-1 = none).
+        Call without arguments to remove the adaptation."""
+        if W is None:
+            check(lib().aasr_gmm_set_cmllr(self._h, 0, None, None))
+            return
+        W = np.ascontiguousarray(W, np.float64)
+        g2t = np.ascontiguousarray(gauss_to_transform, np.int32)
+        check(lib().aasr_gmm_set_cmllr(self._h, W.shape[0], _ptr(g2t), _ptr(W)))
 
     def set_layouts(self, mask: int) -> None:
         """Diagnostic: restrict the scoring kernels the launcher may pick (bit 0

@@ -182,6 +182,25 @@ aasr_status aasr_gmm_set_precision(aasr_gmm *h, int prec) {
   });
 }
 
+aasr_status aasr_gmm_set_cmllr(aasr_gmm *h, int32_t n_transforms,
+                               const int32_t *gauss_to_transform, const double *W) {
+  return guarded([&] {
+    if (!h) raise(AASR_ERR_INVALID, "null handle");
+    if (n_transforms < 0 || (n_transforms > 0 && (!gauss_to_transform || !W)))
+      raise(AASR_ERR_INVALID, "aasr_gmm_set_cmllr: bad argument");
+    HostModel m = h->host;
+    m.n_transforms = n_transforms;
+    m.g2t.clear();
+    m.xform.clear();
+    if (n_transforms > 0) {
+      m.g2t.assign(gauss_to_transform, gauss_to_transform + m.G);
+      m.xform.assign(W, W + (size_t)n_transforms * m.dim * (m.dim + 1));
+    }
+    h->pool_built = false;
+    gmm_build(h, m);
+  });
+}
+
 aasr_status aasr_gmm_score_dev(aasr_gmm *h, const float *d_frames, int64_t F,
                                float *d_state_loglik, void *stream) {
   return guarded([&] {

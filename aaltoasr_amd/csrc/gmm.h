@@ -4,6 +4,7 @@
 // DiagonalGaussian (aku/HmmSet.cc:484-501, aku/Distributions.cc:1040-1062,
 // 2078-2086, 2647-2682).  See DESIGN.md "GMM scoring kernel" for the layout.
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -23,6 +24,25 @@ struct HostModel {
   std::vector<double> cov;
   std::vector<uint8_t> is_full;
   bool any_full() const { return !is_full.empty(); }
+  // model-side constrained MLLR (ConstrainedMllr / AdaptedGaussian,
+  // aku/ModelModules.hh:128-212): Gaussian g scores A_t f + b_t instead of f and
+  // its likelihood is multiplied by |prod diag A_t| (the reference's
+  // full_matrix_determinant, aku/LinearAlgebra.cc:73-86).  xform is
+  // [n][dim][dim+1] with column 0 = b (the reference's W layout).
+  int n_transforms = 0;
+  std::vector<int32_t> g2t;   // [G] transform index or -1
+  std::vector<double> xform;
+  double logw_bias = 0;       // log|det| of a global transform, folded into every weight
+  double logw(size_t k) const {
+    return mix_w[k] > 0 ? std::log(mix_w[k]) + logw_bias : -INFINITY;
+  }
+  bool global_xform() const {
+    if (n_transforms != 1) return false;
+    for (int32_t t : g2t)
+      if (t != 0) return false;
+    return true;
+  }
+  bool factor_path() const { return any_full() || (n_transforms > 0 && !global_xform()); }
   int64_t S = 0;
   std::vector<int32_t> mix_off;         // [S+1]
   std::vector<int32_t> mix_idx;         // [K]
@@ -128,6 +148,9 @@ struct aasr_gmm {
   aasr::DevBuf<int32_t> centred_state_off; // [S+1]
   aasr::DevBuf<int32_t> centred_splits;    // [MAX][MAX+1] state boundaries
   int centred_max_splits = 1;
+  // global CMLLR transform applied to the frames before scoring
+  aasr::DevBuf<double> xf_a, xf_b;
+  aasr::DevBuf<float> d_xframes;
   // staging for the host-buffer entry points
   aasr::DevBuf<float> d_frames, d_out;
 };

@@ -292,13 +292,41 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
     g->pivot[d] = (float)(acc / (double)m.G);
   }
   g->d_pivot.upload(g->pivot.data(), g->pivot.size());
-  if (m.any_full()) {
-    // pools with full-covariance Gaussians are scored by k_gmm_full_score only
-    if ((int64_t)m.cov.size() != m.G * m.dim * m.dim || (int64_t)m.is_full.size() != m.G)
-      raise(AASR_ERR_INVALID, "covariance array does not match the pool size");
+  if (m.any_full() &&
+      ((int64_t)m.cov.size() != m.G * m.dim * m.dim || (int64_t)m.is_full.size() != m.G))
+    raise(AASR_ERR_INVALID, "covariance array does not match the pool size");
+  if (m.n_transforms > 0) {
+    if ((int64_t)m.g2t.size() != m.G ||
+        (int64_t)m.xform.size() != (int64_t)m.n_transforms * m.dim * (m.dim + 1))
+      raise(AASR_ERR_INVALID, "transform arrays do not match the model");
+    for (int32_t t : m.g2t)
+      if (t < -1 || t >= m.n_transforms) raise(AASR_ERR_INVALID, "transform index %d out of range", t);
+  }
+  m.logw_bias = 0;
+  g->xf_a.release();
+  g->xf_b.release();
+  if (m.factor_path()) {
+    // full-covariance Gaussians and per-class CMLLR are scored through factor
+    // rows by k_gmm_full_score only
     g->mix.rows = (int64_t)m.mix_idx.size();
+    g->paired.ok = g->tracks.ok = g->centred_ok = false;
     gmm_build_fullcov(g);
     return;
+  }
+  g->full.ok = false;
+  if (m.global_xform()) {
+    // one transform for every Gaussian == transform the frames once, add log|det|
+    const int D = m.dim;
+    std::vector<double> A((size_t)D * D), b((size_t)D);
+    double det = 1;
+    for (int i = 0; i < D; i++) {
+      b[(size_t)i] = m.xform[(size_t)i * (D + 1)];
+      for (int j = 0; j < D; j++) A[(size_t)i * D + j] = m.xform[(size_t)i * (D + 1) + 1 + j];
+      det *= A[(size_t)i * D + i];
+    }
+    m.logw_bias = std::log(std::fabs(det));
+    g->xf_a.upload(A.data(), A.size());
+    g->xf_b.upload(b.data(), b.size());
   }
 
   // component-expanded rows in state order + segment metadata
@@ -322,10 +350,7 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
       per_chunk[(size_t)c].push_back({rb | (rb << 8), (int32_t)s});
       continue;
     }
-    for (int32_t k = a; k < b; k++) {
-      double w = m.mix_w[k];
-      rows.push_back({m.mix_idx[k], (w > 0) ? std::log(w) : -INFINITY});
-    }
+    for (int32_t k = a; k < b; k++) rows.push_back({m.mix_idx[k], m.logw((size_t)k)});
     int64_t r0 = row, r1 = row + (b - a);
     for (int64_t c = r0 / CHUNK_ROWS; c * CHUNK_ROWS < r1; c++) {
       int64_t lo = std::max(r0, c * CHUNK_ROWS), hi = std::min(r1, (c + 1) * CHUNK_ROWS);
@@ -392,8 +417,7 @@ static bool choose_reference(const HostModel &m, double *ref_out) {
     double prod = 1;
     for (int d = 0; d < D; d++) prod *= (var[d] > 0) ? 1 / var[d] : 0;
     double cst = (prod > 0) ? std::log(std::sqrt(prod)) : prod;
-    double w = m.mix_w[k];
-    double peak = cst + (w > 0 ? std::log(w) : -INFINITY);
+    double peak = cst + m.logw(k);
     if (std::isnan(peak) || peak == INFINITY) return false;
     max_peak_log2 = std::max(max_peak_log2, peak * kLog2e);
   }
@@ -531,9 +555,8 @@ void gmm_build_tracks(aasr_gmm *g, bool grouped) {
     const int64_t p0 = st_pos[(size_t)s];
     const int32_t a = m.mix_off[s], b = m.mix_off[s + 1];
     for (int32_t k = a; k < b; k++) {
-      double w = m.mix_w[k];
       rows[(size_t)track_row(p0 + (k - a) / 4, h, (k - a) % 4)] =
-          RowSpec{m.mix_idx[k], (w > 0) ? std::log(w) : -INFINITY, ref};
+          RowSpec{m.mix_idx[k], m.logw((size_t)k), ref};
     }
     int64_t q = quads_of(s);
     if (grouped) {
@@ -603,8 +626,7 @@ void gmm_build_centred(aasr_gmm *g) {
       recs[k * rec + dimp + d] = (float)(-0.5 * p * kLog2e);
     }
     double cst = (prod > 0) ? std::log(std::sqrt(prod)) : prod;
-    double w = m.mix_w[k];
-    double c = cst + (w > 0 ? std::log(w) : -INFINITY);
+    double c = cst + m.logw(k);
     if (std::isnan(c) || c == INFINITY)
       raise(AASR_ERR_INVALID, "Gaussian %ld has a non-finite constant (precision product overflow)", (long)gi);
     recs[k * rec + 2 * dimp] = std::isfinite(c) ? (float)(c * kLog2e) : kNullConst;
@@ -689,8 +711,9 @@ void gmm_build_fullcov(aasr_gmm *g) {
   const double sc = std::sqrt(0.5 * kLog2e);
 
   // per-Gaussian factor rows, constants
-  std::vector<double> Wall((size_t)m.G * D * D, 0.0), cst((size_t)m.G, 0.0);
-  std::vector<double> r, w, a((size_t)D * D);
+  // y = W x + beta per Gaussian (original feature space)
+  std::vector<double> Wall((size_t)m.G * D * D, 0.0), Beta((size_t)m.G * D, 0.0), cst((size_t)m.G, 0.0);
+  std::vector<double> r, w, a((size_t)D * D), wt((size_t)D * D), bt((size_t)D);
   double max_c = -INFINITY;
   for (int64_t gi = 0; gi < m.G; gi++) {
     if (m.any_full() && m.is_full[(size_t)gi]) {
@@ -704,11 +727,40 @@ void gmm_build_fullcov(aasr_gmm *g) {
       double ld = 0;
       for (int i = 0; i < D; i++) ld += std::log(r[(size_t)i * D + i]);
       cst[(size_t)gi] = -ld;  // log sqrt det P
-      for (int i = 0; i < D * D; i++) Wall[(size_t)gi * D * D + i] = w[(size_t)i];
+      for (int i = 0; i < D; i++) {
+        double bi = 0;
+        for (int d = 0; d < D; d++) {
+          Wall[(size_t)gi * D * D + (size_t)i * D + d] = w[(size_t)i * D + d];
+          bi -= w[(size_t)i * D + d] * m.mean[(size_t)gi * D + d];
+        }
+        Beta[(size_t)gi * D + i] = bi;
+      }
     } else {
       cst[(size_t)gi] = 0.0;  // invalid: precision 0, constant 0
     }
-    max_c = std::max(max_c, cst[(size_t)gi]);
+    // model-side CMLLR: the Gaussian sees A f + b  ->  W' = W A, beta' = W b + beta,
+    // likelihood times |prod diag A|
+    if (m.n_transforms > 0 && m.g2t[(size_t)gi] >= 0) {
+      const double *X = &m.xform[(size_t)m.g2t[(size_t)gi] * D * (D + 1)];
+      double *Wg = &Wall[(size_t)gi * D * D];
+      double *Bg = &Beta[(size_t)gi * D];
+      double det = 1;
+      for (int i = 0; i < D; i++) det *= X[(size_t)i * (D + 1) + 1 + i];
+      for (int i = 0; i < D; i++) {
+        double bi = Bg[i];
+        for (int j = 0; j < D; j++) {
+          double acc = 0;
+          for (int d = 0; d < D; d++) acc += Wg[(size_t)i * D + d] * X[(size_t)d * (D + 1) + 1 + j];
+          wt[(size_t)i * D + j] = acc;
+          bi += Wg[(size_t)i * D + j] * X[(size_t)j * (D + 1)];
+        }
+        bt[(size_t)i] = bi;
+      }
+      for (int i = 0; i < D * D; i++) Wg[i] = wt[(size_t)i];
+      for (int i = 0; i < D; i++) Bg[i] = bt[(size_t)i];
+      cst[(size_t)gi] += std::log(std::fabs(det));  // -inf when a diagonal entry is 0
+    }
+    if (std::isfinite(cst[(size_t)gi])) max_c = std::max(max_c, cst[(size_t)gi]);
   }
   double ref = std::floor(std::min(kRefMax, kPeakMax - max_c * kLog2e));
   if (!(ref >= kRefMin))
@@ -779,12 +831,12 @@ void gmm_build_fullcov(aasr_gmm *g) {
       for (int i = 0; i < D; i++) {
         const int64_t row = track_row(p + i / 4, h, i % 4);
         double *cr = &coef[(size_t)row * K2];
-        double bias = 0;
+        double bias = Beta[(size_t)gi * D + i];  // + W v: frames arrive pivot-centred
         for (int d = 0; d < D; d++) {
           cr[d] = sc * W[(size_t)i * D + d];
-          bias += W[(size_t)i * D + d] * (m.mean[(size_t)gi * D + d] - (double)g->pivot[d]);
+          bias += W[(size_t)i * D + d] * (double)g->pivot[d];
         }
-        cr[D] = -sc * bias;
+        cr[D] = sc * bias;
       }
       const double wgt = m.mix_w[k];
       const double c = cst[(size_t)gi] + (wgt > 0 ? std::log(wgt) : -INFINITY);

@@ -825,6 +825,18 @@ static void launch(const aasr_gmm *g, const PackedRows &pr, const float *d_frame
   raise(AASR_ERR_UNSUPPORTED, "no kernel instance for K/2 = %d", pr.nkk);
 }
 
+__global__ void k_affine_frames(const float *__restrict__ x, int64_t F, int dim,
+                                const double *__restrict__ A, const double *__restrict__ b,
+                                float *__restrict__ y) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= F * dim) return;
+  int64_t f = idx / dim;
+  int i = (int)(idx - f * dim);
+  double acc = b[i];
+  for (int j = 0; j < dim; j++) acc += A[(size_t)i * dim + j] * (double)x[f * dim + j];
+  y[idx] = (float)acc;
+}
+
 // Diagnostic (not part of the public ABI): restrict the kernels the scoring
 // launcher may use (bit 0 grouped tracks, bit 1 independent tracks, bit 2 the
 // centred-form kernel; with bits 0-1 clear and bit 2 set the centred kernel is
@@ -864,9 +876,19 @@ extern "C" int aasr_debug_score_occupancy(void) {
 void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                       hipStream_t stream) {
   if (F <= 0) return;
-  if (g->host.any_full()) {
+  if (g->host.factor_path()) {
     gmm_full_launch(g, d_frames, F, d_out, stream);
     return;
+  }
+  if (g->xf_a.p) {
+    // global constrained-MLLR transform: f' = A f + b once per frame
+    // (AdaptedFeatureVector::calculate_new_ada_vector, aku/ModelModules.hh:208-212)
+    g->d_xframes.ensure((size_t)F * g->dim);
+    const int64_t n = F * g->dim;
+    hipLaunchKernelGGL(k_affine_frames, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       d_frames, F, g->dim, g->xf_a.p, g->xf_b.p, g->d_xframes.p);
+    AASR_HIP(hipGetLastError());
+    d_frames = g->d_xframes.p;
   }
   // numerically safe path first when the model needs it (or it is forced)
   if ((g->layout_mask & 4) && (g->ill_conditioned || g->precision == AASR_PREC_F32_CENTRED ||
@@ -882,8 +904,9 @@ void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
 
 void gmm_gauss_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                       hipStream_t stream) {
-  if (g->host.any_full())
-    raise(AASR_ERR_UNSUPPORTED, "per-Gaussian log-likelihoods are not built for full-covariance pools");
+  if (g->host.factor_path() || g->xf_a.p)
+    raise(AASR_ERR_UNSUPPORTED,
+          "per-Gaussian log-likelihoods are not built for full-covariance or adapted pools");
   gmm_build_pool(g);
   launch<1>(g, g->pool, d_frames, F, d_out, g->G, stream);
 }

@@ -153,6 +153,21 @@ int aasr_gmm_num_gaussians(const aasr_gmm *h);  /* PDFPool::size()      */
 /* rows of the component-expanded layout the kernel streams (>= sum n_s) */
 int64_t aasr_gmm_expanded_rows(const aasr_gmm *h);
 
+/* Model-side constrained MLLR (ConstrainedMllr::load_transform /
+ * AdaptedGaussian, aku/ModelModules.cc:164-232, aku/ModelModules.hh:128-212):
+ * pool Gaussian g scores A_t f + b_t instead of f, t = gauss_to_transform[g]
+ * (-1 = unadapted), and its likelihood is multiplied by |prod diag A_t| -- the
+ * reference's full_matrix_determinant (aku/LinearAlgebra.cc:73-86) returns the
+ * product of A's diagonal, kept for parity.  W is [n][dim][dim+1] row-major with
+ * column 0 = b_t and columns 1..dim = A_t, the layout of the reference's W
+ * matrices.  One transform shared by every Gaussian is applied to the frames
+ * (cost of a dim x dim product per frame, like the reference); per-class
+ * transforms are folded into per-Gaussian factor rows and scored by the
+ * full-covariance kernel.  n_transforms = 0 removes the adaptation
+ * (ConstrainedMllr::reset_transform). */
+aasr_status aasr_gmm_set_cmllr(aasr_gmm *h, int32_t n_transforms,
+                               const int32_t *gauss_to_transform, const double *W);
+
 /* Arithmetic used for the frame x Gaussian quadratic forms.
  *  AASR_PREC_F32          default: f32 matrix-core contraction of the expanded
  *                         form; models whose conditioning would break the 1e-4

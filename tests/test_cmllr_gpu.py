@@ -1,0 +1,101 @@
+"""GPU parity of model-side constrained MLLR:
+aasr_gmm_set_cmllr against a numpy restatement of AdaptedGaussian
+(aku/ModelModules.hh:172-173, 208-212): likelihood = g(A f + b) * |prod diag A|
+(the reference's full_matrix_determinant returns the product of A's diagonal,
+aku/LinearAlgebra.cc:73-86)."""
+import numpy as np
+import pytest
+
+from aaltoasr_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_adapted(oracle, model, frames, g2t, W):
+    """Per-Gaussian adapted log-likelihoods -> mixtures, in double."""
+    mean, var, off, idx, w = model
+    om = oracle.DiagModel(mean, var, off, idx, w)
+    G = mean.shape[0]
+    x = frames.astype(np.float64)
+    ll = np.empty((x.shape[0], G))
+    base = om.gauss_loglik(x)
+    per_t = {}
+    for t in range(W.shape[0]):
+        A, b = W[t][:, 1:], W[t][:, 0]
+        det = abs(np.prod(np.diag(A)))
+        with np.errstate(divide="ignore"):
+            per_t[t] = om.gauss_loglik(x @ A.T + b) + np.log(det)
+    for g in range(G):
+        ll[:, g] = base[:, g] if g2t[g] < 0 else per_t[int(g2t[g])][:, g]
+    lik = np.exp(ll)
+    out = np.empty((x.shape[0], om.S))
+    for s in range(om.S):
+        a, b_ = om.mix_off[s], om.mix_off[s + 1]
+        out[:, s] = np.log(np.maximum(lik[:, om.mix_idx[a:b_]] @ om.mix_w[a:b_], 1e-50))
+    return out
+
+
+def _transforms(n, D, seed):
+    rng = np.random.default_rng(seed)
+    W = np.empty((n, D, D + 1))
+    for t in range(n):
+        W[t][:, 1:] = np.eye(D) * rng.uniform(0.8, 1.2, D) + 0.05 * rng.standard_normal((D, D))
+        W[t][:, 0] = 0.2 * rng.standard_normal(D)
+    return W
+
+
+@pytest.mark.parametrize("D,G,S,comps", [(13, 64, 8, 8), (39, 128, 16, 8)])
+def test_global_transform(capi, oracle, D, G, S, comps):
+    model = synth.make_model(D=D, G=G, S=S, comps=comps, seed=D)
+    frames = synth.make_frames(150, D=D, seed=3)
+    W = _transforms(1, D, seed=1)
+    g2t = np.zeros(G, np.int32)
+    ref = _oracle_adapted(oracle, model, frames, g2t, W)
+    g = capi.Gmm.from_arrays(*model)
+    plain = g.score(frames)
+    g.set_cmllr(g2t, W)
+    got = g.score(frames)
+    assert np.abs(got - ref).max() <= 1e-4
+    assert np.abs(got - plain).max() > 1e-2       # the transform does something
+    g.set_cmllr()                                   # reset_transform
+    assert np.array_equal(g.score(frames), plain)
+
+
+@pytest.mark.parametrize("D,G,S,comps", [(13, 64, 8, 8), (39, 96, 12, 8)])
+def test_regression_classes_and_unadapted_gaussians(capi, oracle, D, G, S, comps):
+    """Three regression classes assigned per Gaussian (UNIT_GAUSSIAN style), some
+    Gaussians left unadapted: components of one mixture use different transforms."""
+    model = synth.make_model(D=D, G=G, S=S, comps=comps, seed=7)
+    frames = synth.make_frames(130, D=D, seed=4)
+    W = _transforms(3, D, seed=2)
+    rng = np.random.default_rng(5)
+    g2t = rng.integers(-1, 3, G).astype(np.int32)
+    ref = _oracle_adapted(oracle, model, frames, g2t, W)
+    g = capi.Gmm.from_arrays(*model)
+    g.set_cmllr(g2t, W)
+    got = g.score(frames)
+    assert np.abs(got - ref).max() <= 1e-4
+
+
+def test_zero_diagonal_kills_the_adapted_gaussians(capi, oracle):
+    """prod diag A == 0 -> likelihood 0 for the adapted Gaussians."""
+    D, G = 8, 16
+    model = synth.make_model(D=D, G=G, S=2, comps=8, seed=9)
+    frames = synth.make_frames(40, D=D, seed=8)
+    W = _transforms(2, D, seed=3)
+    W[1][2, 3] = 0.0
+    W[1][2, 1 + 2] = 0.0
+    g2t = np.array([0] * 8 + [1] * 8, np.int32)
+    ref = _oracle_adapted(oracle, model, frames, g2t, W)
+    g = capi.Gmm.from_arrays(*model)
+    g.set_cmllr(g2t, W)
+    got = g.score(frames)
+    assert np.abs(got - ref).max() <= 1e-4
+    assert np.allclose(got[:, 1], np.log(1e-50), atol=1e-5)
+
+
+def test_argument_validation(capi):
+    model = synth.make_model(D=8, G=16, S=2, comps=8)
+    g = capi.Gmm.from_arrays(*model)
+    with pytest.raises(capi.AasrError, match="out of range"):
+        g.set_cmllr(np.full(16, 4, np.int32), _transforms(2, 8, 0))
