@@ -230,6 +230,10 @@ class Gmm:
         g2t = np.ascontiguousarray(gauss_to_transform, np.int32)
         check(lib().aasr_gmm_set_cmllr(self._h, W.shape[0], _ptr(g2t), _ptr(W)))
 
+    def set_precision(self, prec: int) -> None:
+        """0 = f32 (default), 2 = f32 centred form, 3 = bf16x3 split."""
+        check(lib().aasr_gmm_set_precision(self._h, prec))
+
     def set_layouts(self, mask: int) -> None:
         """Diagnostic: restrict the scoring kernels the launcher may pick (bit 0
         grouped tracks, bit 1 independent tracks, 0 = general LDS-staged)."""

@@ -93,6 +93,10 @@ struct TrackLayout {
   bool ok = false;
   bool grouped = false;
   PackedRows rows;
+  // the same rows split into three bf16 terms for k_gmm_diag_score_bf16x3:
+  // [tile][K/16 slabs][3 splits][2 row blocks][64 lanes][8 bf16]
+  DevBuf<uint16_t> a16;
+  int nk16 = 0;              // K/16 (K = 2*KH, KH = 8*nk16 >= dim+1)
   DevBuf<uint16_t> close;    // per tile: bit p (+8 for track 1) = a state closes after quad p
   DevBuf<int32_t> sid;       // [2][sid_stride] state index of the k-th close on each track
   int32_t sid_stride = 0;
@@ -140,6 +144,7 @@ struct aasr_gmm {
   aasr::FullLayout full;
   int num_cus = 0;
   int layout_mask = 7;        // see aasr_debug_set_layouts()
+  bool use_bf16x3 = false;    // score with the 3-way bf16 split kernel (AASR_PREC_BF16X3)
   // centred-form (numerically safe) kernel operands
   bool centred_ok = false, ill_conditioned = false;
   double kappa = 0;           // conditioning estimate of the expanded form

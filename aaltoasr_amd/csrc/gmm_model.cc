@@ -378,6 +378,10 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
   gmm_build_centred(g);
   // profiling hook: AASR_LAYOUTS=<mask> restricts the kernels like
   // aasr_debug_set_layouts (1 grouped, 2 independent tracks, 4 centred, 0 general)
+  if (const char *e = getenv("AASR_PREC")) {
+    g->use_bf16x3 = atoi(e) == AASR_PREC_BF16X3;
+    if (g->use_bf16x3) g->precision = AASR_PREC_BF16X3;
+  }
   if (const char *e = getenv("AASR_LAYOUTS")) {
     g->layout_mask = atoi(e);
     if ((g->layout_mask & 2) && !g->tracks.ok) gmm_build_tracks(g, false);
@@ -465,6 +469,63 @@ static void build_split_table(TrackLayout &L, int64_t tiles, const std::vector<i
     L.max_splits = R;
   }
   L.splits.upload(table.data(), table.size());
+}
+
+// Three-term bf16 split of the coefficient rows for the bf16x3 kernel.  coef64
+// is [rows][2*D+1] in the f32 kernel's K order (k = 2d linear, 2d+1 quadratic,
+// 2D constant); the bf16 kernel uses K = 2*KH with k < KH: linear d = k, constant
+// at k = D; k >= KH: quadratic d = k - KH.
+static inline uint16_t bf16_rne(float x, float *back) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  uint32_t r = u + 0x7fffu + ((u >> 16) & 1u);
+  uint16_t h = (uint16_t)(r >> 16);
+  uint32_t b = (uint32_t)h << 16;
+  memcpy(back, &b, 4);
+  return h;
+}
+
+static void pack_bf16x3(int D, const std::vector<double> &coef64, int64_t tiles, TrackLayout &L) {
+  int nk16 = (2 * (D + 1) + 15) / 16;  // KH = 8*nk16 >= D+1
+  while (8 * nk16 < D + 1) nk16++;
+  static const int inst[] = {1, 2, 3, 4, 5, 6, 8};
+  int pick = -1;
+  for (int c : inst)
+    if (c >= nk16) { pick = c; break; }
+  if (pick < 0) return;  // no instance: layout stays f32-only
+  nk16 = pick;
+  const int KH = 8 * nk16;
+  const size_t tile_elems = (size_t)nk16 * 3 * 2 * 64 * 8;
+  std::vector<uint16_t> a((size_t)tiles * tile_elems, 0);
+  const size_t stride = 2 * (size_t)D + 1;
+  for (int64_t r = 0; r < tiles * TILE_ROWS; r++) {
+    const double *c = &coef64[(size_t)r * stride];
+    const int64_t t = r / TILE_ROWS;
+    const int jrow = (int)(r % TILE_ROWS);
+    const int mb = jrow / 32, m32 = jrow % 32;
+    for (int k = 0; k < 2 * KH; k++) {
+      double v = 0;
+      if (k < KH) {
+        if (k < D) v = c[2 * k];
+        else if (k == D) v = c[2 * D];
+      } else if (k - KH < D) {
+        v = c[2 * (k - KH) + 1];
+      }
+      float x = (float)v, b1, b2, b3;
+      uint16_t h1 = bf16_rne(x, &b1);
+      uint16_t h2 = bf16_rne(x - b1, &b2);
+      uint16_t h3 = bf16_rne((x - b1) - b2, &b3);
+      const uint16_t hs[3] = {h1, h2, h3};
+      const int slab = k / 16, hk = (k % 16) / 8, i = k % 8;
+      const int lane = hk * 32 + m32;
+      for (int sp = 0; sp < 3; sp++) {
+        size_t idx = (size_t)t * tile_elems + ((((size_t)slab * 3 + sp) * 2 + mb) * 64 + lane) * 8 + i;
+        a[idx] = hs[sp];
+      }
+    }
+  }
+  L.a16.upload(a.data(), a.size());
+  L.nk16 = nk16;
 }
 
 static inline int64_t track_row(int64_t pos, int h, int e) {
@@ -580,7 +641,9 @@ void gmm_build_tracks(aasr_gmm *g, bool grouped) {
   L.sid_stride = (int32_t)ns;
   L.sid.upload(sid_flat.data(), sid_flat.size());
   build_split_table(L, tiles, cand_tile, cand_k0, cand_k1);
-  pack_rows(g, rows, L.rows, nullptr);
+  std::vector<double> coef64;
+  pack_rows(g, rows, L.rows, &coef64);
+  pack_bf16x3(m.dim, coef64, tiles, L);
   L.rows.rows = (int64_t)m.mix_idx.size();  // real rows (algorithmic work)
   L.close.upload(close_mask.data(), close_mask.size());
   L.rows_padded = tiles * TILE_ROWS;

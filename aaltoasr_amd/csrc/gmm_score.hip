@@ -510,6 +510,283 @@ static bool launch_tracks(const aasr_gmm *g, const TrackLayout &L, const float *
 }
 
 // ---------------------------------------------------------------------------
+// bf16x3 variant of the track kernel (AASR_PREC_BF16X3).
+//
+// The f32 MFMA shares its lanes with the VALU and runs at 1/16 of the bf16
+// matrix rate.  Here both operands are split into three bf16 terms
+// (x = x1 + x2 + x3, 8 significant bits each, so the split is exact to 2^-24) and
+// the six products of order <= 2^-16 are accumulated in f32 by
+// v_mfma_f32_32x32x16_bf16:  a1b3 + a2b2 + a3b1 + a1b2 + a2b1 + a1b1, i.e. six
+// K = 16 MFMAs per 16 values of K -- 0.375x the matrix cycles of the f32 form,
+// f32-class accuracy (dropped terms are 2^-24 relative; every MFMA rounds once
+// per 16 products instead of once per product), and the bf16 pipe co-executes
+// with the VALU epilogue of the other wave on the SIMD.
+// K order: k < KH: linear term of dimension k (k == dim: the constant, B = 1);
+// k >= KH: quadratic term of dimension k - KH; KH = 8*NK16.
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned bf16_bits_rne(float x) {
+  unsigned u = __float_as_uint(x);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// three-term split of two floats, packed pairwise (lo = first value)
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &p1, unsigned &p2,
+                                            unsigned &p3) {
+  unsigned a1 = bf16_bits_rne(x0), b1 = bf16_bits_rne(x1);
+  float r0 = x0 - __uint_as_float(a1 << 16), r1 = x1 - __uint_as_float(b1 << 16);
+  unsigned a2 = bf16_bits_rne(r0), b2 = bf16_bits_rne(r1);
+  r0 -= __uint_as_float(a2 << 16);
+  r1 -= __uint_as_float(b2 << 16);
+  unsigned a3 = bf16_bits_rne(r0), b3 = bf16_bits_rne(r1);
+  p1 = a1 | (b1 << 16);
+  p2 = a2 | (b2 << 16);
+  p3 = a3 | (b3 << 16);
+}
+
+template <int NK16, bool GROUPED>
+struct Bf16Smem {
+  static constexpr int OG = 16;  // states per output group (LDS budget: 2 workgroups per CU)
+  static constexpr int kTileBytes = NK16 * 3 * 2 * 64 * 16;
+  static constexpr int kOutStride = OG + 4;
+  static constexpr int kOutFloatsPerWave = GROUPED ? FRAMES_PER_WAVE * kOutStride : 0;
+  static constexpr int kBytes = 2 * kTileBytes + WAVES_PER_BLOCK * kOutFloatsPerWave * 4;
+};
+
+template <int NK16, bool GROUPED>
+__global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
+    const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
+    const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
+    const uint16_t *__restrict__ close_mask, const int32_t *__restrict__ sid, int sid_stride,
+    float *__restrict__ out, int64_t S, float ref_ln, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int OG = Bf16Smem<NK16, GROUPED>::OG;
+  constexpr int kTileBytes = Bf16Smem<NK16, GROUPED>::kTileBytes;
+  constexpr int kTileFloats = kTileBytes / 4;
+  constexpr int kOS = Bf16Smem<NK16, GROUPED>::kOutStride;
+  constexpr int KH = 8 * NK16;
+  float *abuf0 = (float *)smem_raw;
+  float *abuf1 = abuf0 + kTileFloats;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  float *ost = abuf0 + 2 * kTileFloats + wave * Bf16Smem<NK16, GROUPED>::kOutFloatsPerWave;
+  const int n = lane & 31;
+  const int h = lane >> 5;  // K half of a slab held by this lane AND its row track
+  const int64_t f0 = (int64_t)blockIdx.x * FRAMES_PER_BLOCK + wave * FRAMES_PER_WAVE;
+
+  // ---- frame operand: lane (n, h) holds k = 16*j + 8*h + i, i < 8, of slab j
+  u32x4 bq[NK16][3][2];
+#pragma unroll
+  for (int nb = 0; nb < 2; nb++) {
+    int64_t f = f0 + nb * 32 + n;
+    if (f > F - 1) f = F - 1;
+    const float *xr = frames + f * dim;
+#pragma unroll
+    for (int j = 0; j < NK16; j++) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int k = 16 * j + 8 * h + i;
+        const int d = k < KH ? k : k - KH;
+        const int dc = d < dim ? d : 0;
+        const float xc = xr[dc] - pivot[dc];
+        float val = k < KH ? xc : xc * xc;
+        if (d >= dim) val = (k == dim) ? 1.0f : 0.0f;
+        v[i] = val;
+      }
+      unsigned w1[4], w2[4], w3[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) split3_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i], w3[i]);
+      bq[j][0][nb] = u32x4{w1[0], w1[1], w1[2], w1[3]};
+      bq[j][1][nb] = u32x4{w2[0], w2[1], w2[2], w2[3]};
+      bq[j][2][nb] = u32x4{w3[0], w3[1], w3[2], w3[3]};
+    }
+  }
+
+  const int64_t t_begin = split_row[4 * blockIdx.y];
+  const int64_t t_end = split_row[4 * blockIdx.y + 4];
+  const float *apf = (const float *)apack;
+  issue_tile_copy(apf + (size_t)t_begin * kTileFloats, abuf0, kTileFloats, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  float s0 = 0.0f, s1 = 0.0f;
+  int closes = split_row[4 * blockIdx.y + 1 + (GROUPED ? 0 : h)];
+  const int32_t *my_sid = sid + h * sid_stride;
+  int next_sid = GROUPED ? 0 : my_sid[closes];
+  float *orow0 = out + (f0 + n) * S;
+  float *orow1 = out + (f0 + 32 + n) * S;
+  const bool ok0 = f0 + n < F, ok1 = f0 + 32 + n < F;
+
+  if (dbg & 4) {  // experiment: de-phase co-resident workgroups
+    unsigned hsh = ((unsigned)blockIdx.x + 977u * blockIdx.y) * 2654435761u;
+    int bucket = (hsh >> 28) & 15;
+    for (int i = 0; i < bucket; i++) __builtin_amdgcn_s_sleep(8);
+  }
+  if (dbg & 8) {  // experiment: raise priority of every second workgroup
+    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(2);
+  }
+  for (int64_t t = t_begin; t < t_end; t++) {
+    const int par = (int)((t - t_begin) & 1);
+    float *acur = par ? abuf1 : abuf0;
+    float *anext = par ? abuf0 : abuf1;
+    if (t + 1 < t_end)
+      issue_tile_copy(apf + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
+    const unsigned mask16 = close_mask[t];
+    const unsigned mask = GROUPED ? (mask16 & 0xffu) : (h ? (mask16 >> 8) : (mask16 & 0xffu));
+
+    f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
+    const u32x4 *afrag = (const u32x4 *)acur + lane;  // [slab][split][mb][64 lanes]
+#pragma unroll
+    for (int j = 0; j < NK16; j++) {
+      u32x4 a[3][2];
+#pragma unroll
+      for (int sp = 0; sp < 3; sp++) {
+        a[sp][0] = afrag[((j * 3 + sp) * 2 + 0) * 64];
+        a[sp][1] = afrag[((j * 3 + sp) * 2 + 1) * 64];
+      }
+      // smallest products first: (a1,b3) (a2,b2) (a3,b1) (a1,b2) (a2,b1) (a1,b1)
+      constexpr int SA[6] = {0, 1, 2, 0, 1, 0};
+      constexpr int SB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        const bf16x8 a_m0 = __builtin_bit_cast(bf16x8, a[SA[c]][0]);
+        const bf16x8 a_m1 = __builtin_bit_cast(bf16x8, a[SA[c]][1]);
+        const bf16x8 b_n0 = __builtin_bit_cast(bf16x8, bq[j][SB[c]][0]);
+        const bf16x8 b_n1 = __builtin_bit_cast(bf16x8, bq[j][SB[c]][1]);
+        c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m0, b_n0, c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m0, b_n1, c01, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m1, b_n0, c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m1, b_n1, c11, 0, 0, 0);
+      }
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    if (dbg & 1) {
+      asm volatile("" ::"v"(c00), "v"(c01), "v"(c10), "v"(c11));
+      continue;
+    }
+
+#pragma unroll
+    for (int mb = 0; mb < 2; mb++) {
+      const f32x16 &ca = mb ? c10 : c00;
+      const f32x16 &cb = mb ? c11 : c01;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        float e0 = __builtin_amdgcn_exp2f(ca[4 * q]) + __builtin_amdgcn_exp2f(ca[4 * q + 1]);
+        float e1 = __builtin_amdgcn_exp2f(ca[4 * q + 2]) + __builtin_amdgcn_exp2f(ca[4 * q + 3]);
+        float g0 = __builtin_amdgcn_exp2f(cb[4 * q]) + __builtin_amdgcn_exp2f(cb[4 * q + 1]);
+        float g1 = __builtin_amdgcn_exp2f(cb[4 * q + 2]) + __builtin_amdgcn_exp2f(cb[4 * q + 3]);
+        s0 += e0 + e1;
+        s1 += g0 + g1;
+        if ((mask >> (mb * 4 + q)) & 1) {
+          float l0 = fmaf(__builtin_amdgcn_logf(s0), LN2_F, -ref_ln);
+          float l1 = fmaf(__builtin_amdgcn_logf(s1), LN2_F, -ref_ln);
+          l0 = fmaxf(l0, LOG_TINY_F);
+          l1 = fmaxf(l1, LOG_TINY_F);
+          s0 = 0.0f;
+          s1 = 0.0f;
+          closes++;
+          if (!GROUPED) {
+            if (ok0) orow0[next_sid] = l0;
+            if (ok1) orow1[next_sid] = l1;
+            next_sid = my_sid[closes];
+          } else {
+            const int pairs_closed = closes;
+            const int slot = ((2 * (pairs_closed - 1)) & (OG - 1)) + h;
+            ost[n * kOS + slot] = l0;
+            ost[(32 + n) * kOS + slot] = l1;
+            const int64_t closed = 2 * (int64_t)pairs_closed < S ? 2 * (int64_t)pairs_closed : S;
+            if (((2 * pairs_closed) & (OG - 1)) == 0 || 2 * (int64_t)pairs_closed >= S) {
+              const int64_t s_base = ((closed - 1) / OG) * OG;
+              const int cnt = (int)(closed - s_base);
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              if (cnt == OG && f0 + FRAMES_PER_WAVE <= F) {
+                // 4 lanes x 16 B cover the 16-state group; 16 frame rows per instruction
+                const int k4 = lane & 3, r16 = lane >> 2;
+                float *op = out + (f0 + r16) * S + s_base + 4 * k4;
+                const float *ip = ost + r16 * kOS + 4 * k4;
+#pragma unroll
+                for (int i = 0; i < FRAMES_PER_WAVE / 16; i++) {
+                  const f32x4 v = *(const f32x4 *)(ip + i * 16 * kOS);
+                  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                  *(f32x4u *)(op + (int64_t)i * 16 * S) = v;
+                }
+              } else {
+                constexpr int RPI = 64 / OG;
+                const int k = lane & (OG - 1);
+#pragma unroll 4
+                for (int i = 0; i < FRAMES_PER_WAVE / RPI; i++) {
+                  const int row = i * RPI + lane / OG;
+                  const float v = ost[row * kOS + k];
+                  if (k < cnt && f0 + row < F) out[(f0 + row) * S + s_base + k] = v;
+                }
+              }
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int NK16, bool GROUPED>
+static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
+                          float *d_out, hipStream_t stream) {
+  const int64_t blocks = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
+  const int smem = Bf16Smem<NK16, GROUPED>::kBytes;
+  static const int dbg = getenv("AASR_DBG") ? atoi(getenv("AASR_DBG")) : 0;
+  static bool attr_set[64] = {false};
+  auto kern = k_gmm_diag_score_bf16x3<NK16, GROUPED>;
+  if (!attr_set[g->device & 63]) {
+    AASR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set[g->device & 63] = true;
+  }
+  static const int force_r = getenv("AASR_SPLITS") ? atoi(getenv("AASR_SPLITS")) : 0;
+  const double slots = 2.0 * (g->num_cus > 0 ? g->num_cus : 256);
+  int R = 1;
+  double best_eff = 0;
+  for (int r = 1; r <= L.max_splits; r++) {
+    double x = (double)blocks * r / slots;
+    double eff = x / std::ceil(x);
+    if (eff > best_eff + 0.005) {
+      best_eff = eff;
+      R = r;
+    }
+  }
+  if (force_r >= 1 && force_r <= L.max_splits) R = force_r;
+  const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(256), smem, stream, d_frames, F,
+                     g->dim, g->d_pivot.p, L.a16.p, split_row, L.close.p, L.sid.p, L.sid_stride,
+                     d_out, g->S, L.ref_ln, dbg);
+  AASR_HIP(hipGetLastError());
+}
+
+static bool launch_bf16(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
+                        float *d_out, hipStream_t stream) {
+  if (!L.a16.p) return false;
+  switch (L.nk16) {
+#define AASR_CASE(N)                                                                \
+  case N:                                                                           \
+    if (L.grouped) launch_bf16_t<N, true>(g, L, d_frames, F, d_out, stream);        \
+    else launch_bf16_t<N, false>(g, L, d_frames, F, d_out, stream);                 \
+    return true;
+    AASR_CASE(1) AASR_CASE(2) AASR_CASE(3) AASR_CASE(4) AASR_CASE(5) AASR_CASE(6) AASR_CASE(8)
+#undef AASR_CASE
+    default:
+      return false;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Full-covariance kernel (see gmm_build_fullcov()).
 //
 // Same frame-stationary skeleton; the streamed rows are the rows of
@@ -896,9 +1173,15 @@ void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
     if (launch_centred(g, d_frames, F, d_out, stream)) return;
   // layout choice: grouped tracks > independent tracks > general (LDS-staged)
   if (g->layout_mask & 1)
-    if (g->paired.ok && launch_tracks(g, g->paired, d_frames, F, d_out, stream)) return;
+    if (g->paired.ok) {
+      if (g->use_bf16x3 && launch_bf16(g, g->paired, d_frames, F, d_out, stream)) return;
+      if (launch_tracks(g, g->paired, d_frames, F, d_out, stream)) return;
+    }
   if (g->layout_mask & 2)
-    if (g->tracks.ok && launch_tracks(g, g->tracks, d_frames, F, d_out, stream)) return;
+    if (g->tracks.ok) {
+      if (g->use_bf16x3 && launch_bf16(g, g->tracks, d_frames, F, d_out, stream)) return;
+      if (launch_tracks(g, g->tracks, d_frames, F, d_out, stream)) return;
+    }
   launch<0>(g, g->mix, d_frames, F, d_out, g->S, stream);
 }
 

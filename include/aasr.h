@@ -174,8 +174,12 @@ aasr_status aasr_gmm_set_cmllr(aasr_gmm *h, int32_t n_transforms,
  *                         budget are switched to the centred form automatically
  *  AASR_PREC_F32_CENTRED  always the centred form (x-mu)^2*p on the vector ALU,
  *                         the reference's own arithmetic shape in f32
+ *  AASR_PREC_BF16X3       both operands split into three bf16 terms, six bf16
+ *                         matrix-core products per f32 product accumulated in
+ *                         f32: f32-class accuracy at ~2.7x the matrix rate
+ *                         (ill-conditioned models still take the centred form)
  *  AASR_PREC_F64          reserved (f64 matrix cores), not built */
-enum { AASR_PREC_F32 = 0, AASR_PREC_F64 = 1, AASR_PREC_F32_CENTRED = 2 };
+enum { AASR_PREC_F32 = 0, AASR_PREC_F64 = 1, AASR_PREC_F32_CENTRED = 2, AASR_PREC_BF16X3 = 3 };
 aasr_status aasr_gmm_set_precision(aasr_gmm *h, int prec);
 
 /* HmmSet::precompute_likelihoods + state_likelihood for a block of frames

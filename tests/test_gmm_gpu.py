@@ -34,6 +34,17 @@ def _check(capi, oracle, model, frames, tol=TOL, layouts=LAYOUTS):
         assert err.max() <= tol, "layout %d (kernel %d): max |dll| %.3g at %s" % (
             mask, g.active_layout(), err.max(), np.unravel_index(err.argmax(), err.shape))
         worst = max(worst, err.max())
+    # the bf16x3 split kernel on whichever track layout the model has
+    g.set_layouts(7)
+    if g.active_layout() in (1, 2):
+        g.set_precision(3)
+        got = g.score(frames)
+        err = np.abs(got.astype(np.float64) - ref)
+        assert np.isfinite(got).all()
+        assert err.max() <= tol, "bf16x3 on layout %d: max |dll| %.3g at %s" % (
+            g.active_layout(), err.max(), np.unravel_index(err.argmax(), err.shape))
+        worst = max(worst, err.max())
+        g.set_precision(0)
     g.close()
     return worst, used
 
