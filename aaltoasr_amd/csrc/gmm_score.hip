@@ -738,6 +738,258 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Software-pipelined bf16x3 kernel.  Cross-wave overlap of the VALU epilogue with
+// matrix work turned out to be poor in practice (SQ_VALU_MFMA_COEXEC_CYCLES only
+// 4 % of the MFMA cycles with two waves per SIMD), but VALU instructions placed
+// BETWEEN a wave's own MFMAs do hide.  So each wave keeps two accumulator sets:
+// while the MFMAs of tile t run into one, the 32 v_exp_f32 + adds of tile t-1
+// are issued from the other (branch-free: per-quad sums), and only the cheap
+// close/flush logic runs after the barrier.  To make room for the second
+// accumulator set a wave owns 32 frames (one 32-column block, both 32-row
+// blocks of the tile); a workgroup is 8 waves = 256 frames.
+// ---------------------------------------------------------------------------
+template <int NK16, bool GROUPED>
+struct Bf16PSmem {
+  static constexpr int OG = 16;
+  static constexpr int WAVES = 8;
+  static constexpr int kTileBytes = NK16 * 3 * 2 * 64 * 16;
+  static constexpr int kOutStride = OG + 4;
+  static constexpr int kOutFloatsPerWave = GROUPED ? 32 * kOutStride : 0;
+  static constexpr int kBytes = 2 * kTileBytes + WAVES * kOutFloatsPerWave * 4;
+};
+
+__device__ __forceinline__ void issue_tile_copy8(const float *__restrict__ gtile, float *lds_buf,
+                                                 int tile_floats, int wave, int lane) {
+  const int chunks = tile_floats / 4;
+  for (int c0 = wave * 64; c0 < chunks; c0 += 8 * 64) {
+    const float *src = gtile + (size_t)(c0 + lane) * 4;
+    float *dst = lds_buf + (size_t)c0 * 4;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+  }
+}
+
+template <int NK16, bool GROUPED>
+__global__ __launch_bounds__(512, 2) void k_gmm_diag_score_bf16x3p(
+    const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
+    const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
+    const uint16_t *__restrict__ close_mask, const int32_t *__restrict__ sid, int sid_stride,
+    float *__restrict__ out, int64_t S, float ref_ln, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int OG = Bf16PSmem<NK16, GROUPED>::OG;
+  constexpr int kTileFloats = Bf16PSmem<NK16, GROUPED>::kTileBytes / 4;
+  constexpr int kOS = Bf16PSmem<NK16, GROUPED>::kOutStride;
+  constexpr int KH = 8 * NK16;
+  float *abuf0 = (float *)smem_raw;
+  float *abuf1 = abuf0 + kTileFloats;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  float *ost = abuf0 + 2 * kTileFloats + wave * Bf16PSmem<NK16, GROUPED>::kOutFloatsPerWave;
+  const int n = lane & 31;
+  const int h = lane >> 5;
+  const int64_t f0 = (int64_t)blockIdx.x * 256 + wave * 32;
+
+  u32x4 bq[NK16][3];
+  {
+    int64_t f = f0 + n;
+    if (f > F - 1) f = F - 1;
+    const float *xr = frames + f * dim;
+#pragma unroll
+    for (int j = 0; j < NK16; j++) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int k = 16 * j + 8 * h + i;
+        const int d = k < KH ? k : k - KH;
+        const int dc = d < dim ? d : 0;
+        const float xc = xr[dc] - pivot[dc];
+        float val = k < KH ? xc : xc * xc;
+        if (d >= dim) val = (k == dim) ? 1.0f : 0.0f;
+        v[i] = val;
+      }
+      unsigned w1[4], w2[4], w3[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) split3_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i], w3[i]);
+      bq[j][0] = u32x4{w1[0], w1[1], w1[2], w1[3]};
+      bq[j][1] = u32x4{w2[0], w2[1], w2[2], w2[3]};
+      bq[j][2] = u32x4{w3[0], w3[1], w3[2], w3[3]};
+    }
+  }
+
+  const int64_t t_begin = split_row[4 * blockIdx.y];
+  const int64_t t_end = split_row[4 * blockIdx.y + 4];
+  const float *apf = (const float *)apack;
+  issue_tile_copy8(apf + (size_t)t_begin * kTileFloats, abuf0, kTileFloats, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  float ssum = 0.0f;  // running sum of the open state on this lane's track
+  int closes = split_row[4 * blockIdx.y + 1 + (GROUPED ? 0 : h)];
+  const int32_t *my_sid = sid + h * sid_stride;
+  int next_sid = GROUPED ? 0 : my_sid[closes];
+  float *orow = out + (f0 + n) * S;
+  const bool okf = f0 + n < F;
+
+  // close / flush logic of one tile given its eight per-quad sums
+  auto finish_tile = [&](const float (&qs)[8], unsigned mask16) {
+    const unsigned mask = GROUPED ? (mask16 & 0xffu) : (h ? (mask16 >> 8) : (mask16 & 0xffu));
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+      ssum += qs[p];
+      if ((mask >> p) & 1) {
+        float l0 = fmaf(__builtin_amdgcn_logf(ssum), LN2_F, -ref_ln);
+        l0 = fmaxf(l0, LOG_TINY_F);
+        ssum = 0.0f;
+        closes++;
+        if (!GROUPED) {
+          if (okf) orow[next_sid] = l0;
+          next_sid = my_sid[closes];
+        } else {
+          const int pairs_closed = closes;
+          const int slot = ((2 * (pairs_closed - 1)) & (OG - 1)) + h;
+          ost[n * kOS + slot] = l0;
+          const int64_t closed = 2 * (int64_t)pairs_closed < S ? 2 * (int64_t)pairs_closed : S;
+          if (((2 * pairs_closed) & (OG - 1)) == 0 || 2 * (int64_t)pairs_closed >= S) {
+            const int64_t s_base = ((closed - 1) / OG) * OG;
+            const int cnt = (int)(closed - s_base);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (cnt == OG && f0 + 32 <= F) {
+              const int k4 = lane & 3, r16 = lane >> 2;
+              float *op = out + (f0 + r16) * S + s_base + 4 * k4;
+              const float *ip = ost + r16 * kOS + 4 * k4;
+#pragma unroll
+              for (int i = 0; i < 2; i++) {
+                const f32x4 v = *(const f32x4 *)(ip + i * 16 * kOS);
+                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                *(f32x4u *)(op + (int64_t)i * 16 * S) = v;
+              }
+            } else {
+              const int k = lane & (OG - 1);
+#pragma unroll 4
+              for (int i = 0; i < 32 / (64 / OG); i++) {
+                const int row = i * (64 / OG) + lane / OG;
+                const float v = ost[row * kOS + k];
+                if (k < cnt && f0 + row < F) out[(f0 + row) * S + s_base + k] = v;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+      }
+    }
+  };
+
+  f32x16 p0 = {0}, p1 = {0};  // accumulators of the previous tile (rows 0-31 / 32-63)
+  unsigned mask_prev = 0;
+  bool have_prev = false;
+
+  for (int64_t t = t_begin; t < t_end; t++) {
+    const int par = (int)((t - t_begin) & 1);
+    float *acur = par ? abuf1 : abuf0;
+    float *anext = par ? abuf0 : abuf1;
+    if (t + 1 < t_end)
+      issue_tile_copy8(apf + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
+    const unsigned mask16 = close_mask[t];
+
+    f32x16 c0 = {0}, c1 = {0};
+    float qs[8];
+    float ev[32];  // 2^v of the previous tile's 32 accumulator values of this lane
+    const u32x4 *afrag = (const u32x4 *)acur + lane;
+#pragma unroll
+    for (int j = 0; j < NK16; j++) {
+      u32x4 a[3][2];
+#pragma unroll
+      for (int sp = 0; sp < 3; sp++) {
+        a[sp][0] = afrag[((j * 3 + sp) * 2 + 0) * 64];
+        a[sp][1] = afrag[((j * 3 + sp) * 2 + 1) * 64];
+      }
+      constexpr int SA[6] = {0, 1, 2, 0, 1, 0};
+      constexpr int SB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        const bf16x8 bv = __builtin_bit_cast(bf16x8, bq[j][SB[c]]);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[SA[c]][0]), bv, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[SA[c]][1]), bv, c1, 0, 0, 0);
+        // one transcendental of the PREVIOUS tile rides behind each MFMA pair
+        constexpr int SLOTS = NK16 * 6;
+        const int slot = j * 6 + c;
+#pragma unroll
+        for (int e = 0; e < 32; e++)
+          if (e * SLOTS / 32 == slot || (SLOTS < 32 && slot == SLOTS - 1 && e * SLOTS / 32 >= SLOTS)) {
+            // volatile asm: keeps the transcendental at this point of the stream
+            // (a pure builtin would be sunk to its first use after the MFMAs);
+            // its consumers are a whole MFMA phase away, no wait states needed
+            const float xv = e < 16 ? p0[e] : p1[e - 16];
+            asm volatile("v_exp_f32_e32 %0, %1" : "=v"(ev[e]) : "v"(xv));
+          }
+        // MFMA / VALU order is pinned; LDS, VMEM and scalar work may still move
+        __builtin_amdgcn_sched_barrier(0x0094);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      qs[q] = (ev[4 * q] + ev[4 * q + 1]) + (ev[4 * q + 2] + ev[4 * q + 3]);
+      qs[4 + q] = (ev[16 + 4 * q] + ev[16 + 4 * q + 1]) + (ev[16 + 4 * q + 2] + ev[16 + 4 * q + 3]);
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    if (have_prev && !(dbg & 1)) finish_tile(qs, mask_prev);
+    p0 = c0;
+    p1 = c1;
+    mask_prev = mask16;
+    have_prev = true;
+  }
+  if (have_prev && !(dbg & 1)) {
+    float qs[8];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      qs[q] = (__builtin_amdgcn_exp2f(p0[4 * q]) + __builtin_amdgcn_exp2f(p0[4 * q + 1])) +
+              (__builtin_amdgcn_exp2f(p0[4 * q + 2]) + __builtin_amdgcn_exp2f(p0[4 * q + 3]));
+      qs[4 + q] = (__builtin_amdgcn_exp2f(p1[4 * q]) + __builtin_amdgcn_exp2f(p1[4 * q + 1])) +
+                  (__builtin_amdgcn_exp2f(p1[4 * q + 2]) + __builtin_amdgcn_exp2f(p1[4 * q + 3]));
+    }
+    finish_tile(qs, mask_prev);
+  }
+}
+
+template <int NK16, bool GROUPED>
+static void launch_bf16p_t(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
+                           float *d_out, hipStream_t stream) {
+  const int64_t blocks = (F + 255) / 256;
+  const int smem = Bf16PSmem<NK16, GROUPED>::kBytes;
+  static const int dbg = getenv("AASR_DBG") ? atoi(getenv("AASR_DBG")) : 0;
+  static bool attr_set[64] = {false};
+  auto kern = k_gmm_diag_score_bf16x3p<NK16, GROUPED>;
+  if (!attr_set[g->device & 63]) {
+    AASR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set[g->device & 63] = true;
+  }
+  static const int force_r = getenv("AASR_SPLITS") ? atoi(getenv("AASR_SPLITS")) : 0;
+  const double slots = 1.0 * (g->num_cus > 0 ? g->num_cus : 256);  // one 8-wave workgroup per CU
+  int R = 1;
+  double best_eff = 0;
+  for (int r = 1; r <= L.max_splits; r++) {
+    double x = (double)blocks * r / slots;
+    double eff = x / std::ceil(x);
+    if (eff > best_eff + 0.005) {
+      best_eff = eff;
+      R = r;
+    }
+  }
+  if (force_r >= 1 && force_r <= L.max_splits) R = force_r;
+  const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(512), smem, stream, d_frames, F,
+                     g->dim, g->d_pivot.p, L.a16.p, split_row, L.close.p, L.sid.p, L.sid_stride,
+                     d_out, g->S, L.ref_ln, dbg);
+  AASR_HIP(hipGetLastError());
+}
+
 template <int NK16, bool GROUPED>
 static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
                           float *d_out, hipStream_t stream) {
@@ -773,6 +1025,12 @@ static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *
 static bool launch_bf16(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
                         float *d_out, hipStream_t stream) {
   if (!L.a16.p) return false;
+  static const bool pipelined = getenv("AASR_BF16_PIPE") ? atoi(getenv("AASR_BF16_PIPE")) != 0 : false;
+  if (pipelined && L.nk16 == 5) {
+    if (L.grouped) launch_bf16p_t<5, true>(g, L, d_frames, F, d_out, stream);
+    else launch_bf16p_t<5, false>(g, L, d_frames, F, d_out, stream);
+    return true;
+  }
   switch (L.nk16) {
 #define AASR_CASE(N)                                                                \
   case N:                                                                           \
