@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3
+BF16_MATRIX_PEAK_TFLOPS = 2500.0
 DIM = 39
 G = 50000
 S = 3125
@@ -49,6 +50,8 @@ def parse_args():
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step (gmm workload)")
     ap.add_argument("--utts", type=int, default=360, help="10-s utterances per GPU per step (full workload)")
     ap.add_argument("--cpu-frames", type=int, default=20000, help="frames timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--precision", choices=["bf16x3", "f32"], default=os.environ.get("AASR_BENCH_PRECISION", "bf16x3"),
+                    help="contraction arithmetic of the scoring kernel (both meet the 1e-4 parity bar)")
     return ap.parse_args()
 
 
@@ -90,6 +93,8 @@ def main():
         model = shard.broadcast_model(model, src=0, device=dev)
     mean, var, off, idx, w = (model[k] for k in names)
     gmm = capi.Gmm.from_arrays(mean, var, off, idx, w)
+    if args.precision == "bf16x3":
+        gmm.set_precision(3)   # AASR_PREC_BF16X3
     rows = gmm.expanded_rows
 
     stream = torch.cuda.current_stream()
@@ -151,13 +156,24 @@ def main():
     k_ms = ev0.elapsed_time(ev1) / kreps
     algo_flop = 4.0 * DIM * float(F) * float(rows)
     achieved = algo_flop / (k_ms * 1e-3) / 1e12
+    if args.precision == "f32":
+        kernel, peak, dtype = "k_gmm_diag_score_tracks<40,true>", FP32_MATRIX_PEAK_TFLOPS, "f32"
+        peak_note = "dense FP32 matrix peak (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md"
+    else:
+        # every f32-accurate product is six bf16 matrix products (3-term split of
+        # both operands, terms below 2^-16 dropped), so the ceiling for ALGORITHMIC
+        # flops on the bf16 pipe is the dense bf16 peak / 6
+        kernel, peak, dtype = "k_gmm_diag_score_bf16x3<5,true>", BF16_MATRIX_PEAK_TFLOPS / 6.0, "bf16x3"
+        peak_note = ("dense BF16 matrix peak 2500 TFLOP/s / 6 bf16 products per f32-accurate product; "
+                     "executed matrix flops = 6 * 160/156 * achieved")
     roofline = {
-        "bound": "mfma", "kernel": "k_gmm_diag_score_tracks<40,true>", "achieved": round(achieved, 3),
-        "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
-        "kernel_ms": round(k_ms, 4), "algorithmic_flop_per_launch": algo_flop,
+        "bound": "mfma", "kernel": kernel, "achieved": round(achieved, 3),
+        "peak": round(peak, 2), "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4), "traffic": None,
+        "kernel_ms": round(k_ms, 4), "algorithmic_flop_per_launch": algo_flop, "peak_note": peak_note,
+        "frac_of_fp32_matrix_peak": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
     }
-    td = _pmc_traffic(F)
+    td = _pmc_traffic(F, args.precision)
     if td:
         roofline["traffic"] = td["bytes"]
         roofline["traffic_detail"] = td
@@ -186,7 +202,7 @@ def main():
             "metric": "frames/sec GMM log-lik (39-d, 50k Gauss) + MFCC",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": workload, "frames_per_gpu_per_step": F, "dim": DIM, "gaussians": G,
                        "states": S, "components_per_state": COMPS, "sharding": "frames/utterances per rank, no collective"},
             "roofline": roofline, "cpu_baseline": cpu,
@@ -197,14 +213,16 @@ def main():
         dist.destroy_process_group()
 
 
-def _pmc_traffic(frames):
+def _pmc_traffic(frames, precision="f32"):
     """HBM bytes per launch of k_gmm_diag_score from the committed rocprofv3 PMC
     passes (profiles/*_pmc*.json: FETCH_SIZE and WRITE_SIZE in KiB, collected in
     separate passes at 1 000 000 frames/launch; FETCH_SIZE doubled per
     MI355X_MICROARCH.md's gfx950 note), scaled to this launch's frame count.
     None when no profile is committed."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*gmm_pmc*.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*gmm_%s_pmc*.json" % precision)))
+    if not files and precision == "f32":
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*gmm_pmc*.json")))
     if not files:
         return None
     try:
