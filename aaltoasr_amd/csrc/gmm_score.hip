@@ -770,6 +770,52 @@ __device__ __forceinline__ void issue_tile_copy8(const float *__restrict__ gtile
   }
 }
 
+// MFMAs of one tile into (c0, c1) with the 32 transcendentals of the previous
+// tile's accumulators (p0, p1) riding behind the MFMA pairs; A fragments of the
+// next K slab are requested before the current slab's MFMAs.
+template <int NK16>
+__device__ __forceinline__ void bf16p_tile(const u32x4 *afrag, const u32x4 (&bq)[NK16][3],
+                                           f32x16 &c0, f32x16 &c1, const f32x16 &p0,
+                                           const f32x16 &p1, float (&ev)[32]) {
+  u32x4 a[2][3][2];
+#pragma unroll
+  for (int sp = 0; sp < 3; sp++) {
+    a[0][sp][0] = afrag[((0 * 3 + sp) * 2 + 0) * 64];
+    a[0][sp][1] = afrag[((0 * 3 + sp) * 2 + 1) * 64];
+  }
+#pragma unroll
+  for (int j = 0; j < NK16; j++) {
+    if (j + 1 < NK16) {
+#pragma unroll
+      for (int sp = 0; sp < 3; sp++) {
+        a[(j + 1) & 1][sp][0] = afrag[(((j + 1) * 3 + sp) * 2 + 0) * 64];
+        a[(j + 1) & 1][sp][1] = afrag[(((j + 1) * 3 + sp) * 2 + 1) * 64];
+      }
+    }
+    constexpr int SA[6] = {0, 1, 2, 0, 1, 0};
+    constexpr int SB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      const bf16x8 bv = __builtin_bit_cast(bf16x8, bq[j][SB[c]]);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j & 1][SA[c]][0]), bv, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j & 1][SA[c]][1]), bv, c1, 0, 0, 0);
+      constexpr int SLOTS = NK16 * 6;
+      const int slot = j * 6 + c;
+#pragma unroll
+      for (int e = 0; e < 32; e++)
+        if (e * SLOTS / 32 == slot || (SLOTS < 32 && slot == SLOTS - 1 && e * SLOTS / 32 >= SLOTS)) {
+          // volatile asm keeps the transcendental at this point of the stream (a
+          // pure builtin would be sunk to its first use after the MFMAs); its
+          // consumers are a whole MFMA phase away, no wait states needed
+          const float xv = e < 16 ? p0[e] : p1[e - 16];
+          asm volatile("v_exp_f32_e32 %0, %1" : "=v"(ev[e]) : "v"(xv));
+        }
+      // MFMA / VALU order is pinned; LDS, VMEM and scalar work may still move
+      __builtin_amdgcn_sched_barrier(0x0094);
+    }
+  }
+}
+
 template <int NK16, bool GROUPED>
 __global__ __launch_bounds__(512, 2) void k_gmm_diag_score_bf16x3p(
     const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
@@ -832,21 +878,34 @@ __global__ __launch_bounds__(512, 2) void k_gmm_diag_score_bf16x3p(
   float *orow = out + (f0 + n) * S;
   const bool okf = f0 + n < F;
 
-  // close / flush logic of one tile given its eight per-quad sums
-  auto finish_tile = [&](const float (&qs)[8], unsigned mask16) {
+  // close / flush logic of one finished tile given its 32 exponentials
+  auto finish_tile = [&](const float (&ev)[32], unsigned mask16) {
     const unsigned mask = GROUPED ? (mask16 & 0xffu) : (h ? (mask16 >> 8) : (mask16 & 0xffu));
+    const unsigned any = GROUPED ? (mask16 & 0xffu) : ((mask16 | (mask16 >> 8)) & 0xffu);
+    // branch-free running sums: r[p] = sum of the open state up to quad p
+    float r[8];
+    float run = ssum;
 #pragma unroll
     for (int p = 0; p < 8; p++) {
-      ssum += qs[p];
-      if ((mask >> p) & 1) {
-        float l0 = fmaf(__builtin_amdgcn_logf(ssum), LN2_F, -ref_ln);
+      run += (ev[4 * p] + ev[4 * p + 1]) + (ev[4 * p + 2] + ev[4 * p + 3]);
+      r[p] = run;
+      run = ((mask >> p) & 1) ? 0.0f : run;
+    }
+    ssum = run;
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+      if ((any >> p) & 1) {  // wave-uniform: some track closes a state after quad p
+        const bool mine = (mask >> p) & 1;
+        float l0 = fmaf(__builtin_amdgcn_logf(r[p]), LN2_F, -ref_ln);
         l0 = fmaxf(l0, LOG_TINY_F);
-        ssum = 0.0f;
-        closes++;
         if (!GROUPED) {
-          if (okf) orow[next_sid] = l0;
-          next_sid = my_sid[closes];
+          if (mine) {
+            closes++;
+            if (okf) orow[next_sid] = l0;
+            next_sid = my_sid[closes];
+          }
         } else {
+          closes++;
           const int pairs_closed = closes;
           const int slot = ((2 * (pairs_closed - 1)) & (OG - 1)) + h;
           ost[n * kOS + slot] = l0;
@@ -883,78 +942,58 @@ __global__ __launch_bounds__(512, 2) void k_gmm_diag_score_bf16x3p(
     }
   };
 
-  f32x16 p0 = {0}, p1 = {0};  // accumulators of the previous tile (rows 0-31 / 32-63)
-  unsigned mask_prev = 0;
-  bool have_prev = false;
+  // two accumulator sets; the loop is unrolled by two so that no set is copied
+  f32x16 a0 = {0}, a1 = {0}, b0 = {0}, b1 = {0};
+  float ev[32];
+  unsigned mask_a = 0, mask_b = 0;
+  bool have_b = false;  // set B holds a finished, not yet reduced tile
 
-  for (int64_t t = t_begin; t < t_end; t++) {
-    const int par = (int)((t - t_begin) & 1);
-    float *acur = par ? abuf1 : abuf0;
-    float *anext = par ? abuf0 : abuf1;
-    if (t + 1 < t_end)
-      issue_tile_copy8(apf + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
-    const unsigned mask16 = close_mask[t];
-
-    f32x16 c0 = {0}, c1 = {0};
-    float qs[8];
-    float ev[32];  // 2^v of the previous tile's 32 accumulator values of this lane
-    const u32x4 *afrag = (const u32x4 *)acur + lane;
+  int64_t t = t_begin;
+  while (t < t_end) {
+    {  // tile t -> set A, exps of set B
+      const int par = (int)((t - t_begin) & 1);
+      float *acur = par ? abuf1 : abuf0;
+      float *anext = par ? abuf0 : abuf1;
+      if (t + 1 < t_end)
+        issue_tile_copy8(apf + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
+      mask_a = close_mask[t];
 #pragma unroll
-    for (int j = 0; j < NK16; j++) {
-      u32x4 a[3][2];
-#pragma unroll
-      for (int sp = 0; sp < 3; sp++) {
-        a[sp][0] = afrag[((j * 3 + sp) * 2 + 0) * 64];
-        a[sp][1] = afrag[((j * 3 + sp) * 2 + 1) * 64];
-      }
-      constexpr int SA[6] = {0, 1, 2, 0, 1, 0};
-      constexpr int SB[6] = {2, 1, 0, 1, 0, 0};
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        const bf16x8 bv = __builtin_bit_cast(bf16x8, bq[j][SB[c]]);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[SA[c]][0]), bv, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[SA[c]][1]), bv, c1, 0, 0, 0);
-        // one transcendental of the PREVIOUS tile rides behind each MFMA pair
-        constexpr int SLOTS = NK16 * 6;
-        const int slot = j * 6 + c;
-#pragma unroll
-        for (int e = 0; e < 32; e++)
-          if (e * SLOTS / 32 == slot || (SLOTS < 32 && slot == SLOTS - 1 && e * SLOTS / 32 >= SLOTS)) {
-            // volatile asm: keeps the transcendental at this point of the stream
-            // (a pure builtin would be sunk to its first use after the MFMAs);
-            // its consumers are a whole MFMA phase away, no wait states needed
-            const float xv = e < 16 ? p0[e] : p1[e - 16];
-            asm volatile("v_exp_f32_e32 %0, %1" : "=v"(ev[e]) : "v"(xv));
-          }
-        // MFMA / VALU order is pinned; LDS, VMEM and scalar work may still move
-        __builtin_amdgcn_sched_barrier(0x0094);
-      }
+      for (int i = 0; i < 16; i++) { a0[i] = 0.0f; a1[i] = 0.0f; }
+      bf16p_tile<NK16>((const u32x4 *)acur + lane, bq, a0, a1, b0, b1, ev);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (have_b && !(dbg & 1)) finish_tile(ev, mask_b);
+      t++;
     }
+    if (t >= t_end) {
+      // odd tile count: set A is the last one
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      qs[q] = (ev[4 * q] + ev[4 * q + 1]) + (ev[4 * q + 2] + ev[4 * q + 3]);
-      qs[4 + q] = (ev[16 + 4 * q] + ev[16 + 4 * q + 1]) + (ev[16 + 4 * q + 2] + ev[16 + 4 * q + 3]);
+      for (int e = 0; e < 32; e++) ev[e] = __builtin_amdgcn_exp2f(e < 16 ? a0[e] : a1[e - 16]);
+      if (!(dbg & 1)) finish_tile(ev, mask_a);
+      have_b = false;
+      break;
     }
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    if (have_prev && !(dbg & 1)) finish_tile(qs, mask_prev);
-    p0 = c0;
-    p1 = c1;
-    mask_prev = mask16;
-    have_prev = true;
+    {  // tile t -> set B, exps of set A
+      const int par = (int)((t - t_begin) & 1);
+      float *acur = par ? abuf1 : abuf0;
+      float *anext = par ? abuf0 : abuf1;
+      if (t + 1 < t_end)
+        issue_tile_copy8(apf + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
+      mask_b = close_mask[t];
+#pragma unroll
+      for (int i = 0; i < 16; i++) { b0[i] = 0.0f; b1[i] = 0.0f; }
+      bf16p_tile<NK16>((const u32x4 *)acur + lane, bq, b0, b1, a0, a1, ev);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (!(dbg & 1)) finish_tile(ev, mask_a);
+      have_b = true;
+      t++;
+    }
   }
-  if (have_prev && !(dbg & 1)) {
-    float qs[8];
+  if (have_b) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      qs[q] = (__builtin_amdgcn_exp2f(p0[4 * q]) + __builtin_amdgcn_exp2f(p0[4 * q + 1])) +
-              (__builtin_amdgcn_exp2f(p0[4 * q + 2]) + __builtin_amdgcn_exp2f(p0[4 * q + 3]));
-      qs[4 + q] = (__builtin_amdgcn_exp2f(p1[4 * q]) + __builtin_amdgcn_exp2f(p1[4 * q + 1])) +
-                  (__builtin_amdgcn_exp2f(p1[4 * q + 2]) + __builtin_amdgcn_exp2f(p1[4 * q + 3]));
-    }
-    finish_tile(qs, mask_prev);
+    for (int e = 0; e < 32; e++) ev[e] = __builtin_amdgcn_exp2f(e < 16 ? b0[e] : b1[e - 16]);
+    if (!(dbg & 1)) finish_tile(ev, mask_b);
   }
 }
 
