@@ -137,7 +137,7 @@ bool ModuleConfig::get(const std::string &k, std::vector<std::string> &v) const 
 // ------------------------------------------------------------- FFT tables --
 
 // Radix schedule of KissFFT's kf_factor (vendor/kiss_fft/kiss_fft.c:309-331):
-// 4s first, then 2s, then odd primes.  Only radices 2 and 4 have kernels.
+// 4s first, then 2s, then odd primes.  Radices 2, 3, 4 and 5 have kernels.
 static void build_fft_plan(FftPlan &p, int window) {
   if (window & 1) raise(AASR_ERR_INVALID, "Real FFT optimization must be even.");
   int nc = window / 2;
@@ -153,9 +153,10 @@ static void build_fft_plan(FftPlan &p, int window) {
       if (r > root) r = n;
     }
     n /= r;
-    if (r != 2 && r != 4)
+    if (r != 2 && r != 3 && r != 4 && r != 5)
       raise(AASR_ERR_UNSUPPORTED,
-            "FFT window %d needs a radix-%d butterfly; only power-of-two windows are built", window, r);
+            "FFT window %d needs KissFFT's generic radix-%d butterfly, which is not built "
+            "(radices 2, 3, 4, 5 are)", window, r);
     if (ns >= 16) raise(AASR_ERR_UNSUPPORTED, "FFT window %d too long", window);
     p.radix[ns] = r;
     p.sublen[ns] = n;

@@ -179,6 +179,59 @@ __global__ __launch_bounds__(256) void k_fft(DevBatch b, const int16_t *__restri
         f0.i += t.i;
         F[m + j] = o1;
         F[j] = f0;
+      } else if (pr == 3) {
+        // kf_bfly3 (vendor/kiss_fft/kiss_fft.c:92-135); HALF_OF(x) = x*.5 in double
+        const cpx epi3 = tw[fstride * m];
+        cpx s1 = cmul(F[m + j], tw[j * fstride]);
+        cpx s2 = cmul(F[2 * m + j], tw[2 * j * fstride]);
+        cpx f0 = F[j], s3, s0, o1, o2;
+        s3.r = s1.r + s2.r;  s3.i = s1.i + s2.i;
+        s0.r = s1.r - s2.r;  s0.i = s1.i - s2.i;
+        o1.r = (float)((double)f0.r - (double)s3.r * .5);
+        o1.i = (float)((double)f0.i - (double)s3.i * .5);
+        s0.r *= epi3.i;
+        s0.i *= epi3.i;
+        f0.r += s3.r;
+        f0.i += s3.i;
+        o2.r = o1.r + s0.i;
+        o2.i = o1.i - s0.r;
+        o1.r -= s0.i;
+        o1.i += s0.r;
+        F[j] = f0;
+        F[m + j] = o1;
+        F[2 * m + j] = o2;
+      } else if (pr == 5) {
+        // kf_bfly5 (vendor/kiss_fft/kiss_fft.c:137-198)
+        const cpx ya = tw[fstride * m], yb = tw[fstride * 2 * m];
+        cpx s0 = F[j];
+        cpx s1 = cmul(F[m + j], tw[j * fstride]);
+        cpx s2 = cmul(F[2 * m + j], tw[2 * j * fstride]);
+        cpx s3 = cmul(F[3 * m + j], tw[3 * j * fstride]);
+        cpx s4 = cmul(F[4 * m + j], tw[4 * j * fstride]);
+        cpx s5, s6, s7, s8, s9, s10, s11, s12, f0 = s0, o1, o2, o3, o4;
+        s7.r = s1.r + s4.r;   s7.i = s1.i + s4.i;
+        s10.r = s1.r - s4.r;  s10.i = s1.i - s4.i;
+        s8.r = s2.r + s3.r;   s8.i = s2.i + s3.i;
+        s9.r = s2.r - s3.r;   s9.i = s2.i - s3.i;
+        f0.r += s7.r + s8.r;
+        f0.i += s7.i + s8.i;
+        s5.r = s0.r + s7.r * ya.r + s8.r * yb.r;
+        s5.i = s0.i + s7.i * ya.r + s8.i * yb.r;
+        s6.r = s10.i * ya.i + s9.i * yb.i;
+        s6.i = -(s10.r * ya.i) - s9.r * yb.i;
+        o1.r = s5.r - s6.r;  o1.i = s5.i - s6.i;
+        o4.r = s5.r + s6.r;  o4.i = s5.i + s6.i;
+        s11.r = s0.r + s7.r * yb.r + s8.r * ya.r;
+        s11.i = s0.i + s7.i * yb.r + s8.i * ya.r;
+        s12.r = -(s10.i * yb.i) + s9.i * ya.i;
+        s12.i = s10.r * yb.i - s9.r * ya.i;
+        o2.r = s11.r + s12.r;  o2.i = s11.i + s12.i;
+        o3.r = s11.r - s12.r;  o3.i = s11.i - s12.i;
+        F[j] = f0;
+        F[m + j] = o1;
+        F[2 * m + j] = o2;
+        F[3 * m + j] = o3;
+        F[4 * m + j] = o4;
       } else {
         cpx s0 = cmul(F[m + j], tw[j * fstride]);
         cpx s1 = cmul(F[2 * m + j], tw[2 * j * fstride]);

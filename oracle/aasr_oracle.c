@@ -284,8 +284,8 @@ static inline orc_cpx orc_cmul(orc_cpx a, orc_cpx b)
 }
 
 /* radix schedule of kf_factor (vendor/kiss_fft/kiss_fft.c:309-331): powers of
- * 4, then 2, then odd primes.  Only radices 2 and 4 are restated; returns the
- * number of stages or -1 if another radix would be needed. */
+ * 4, then 2, then odd primes.  Radices 2, 3, 4 and 5 are restated (the generic
+ * butterfly for larger primes is not); returns the number of stages or -1. */
 static int orc_fft_plan(int n, int *radix, int *sublen)
 {
     int ns = 0, p = 4;
@@ -298,7 +298,7 @@ static int orc_fft_plan(int n, int *radix, int *sublen)
             if (p > root) p = n;
         }
         n /= p;
-        if (p != 2 && p != 4) return -1;
+        if (p != 2 && p != 3 && p != 4 && p != 5) return -1;
         radix[ns] = p;
         sublen[ns] = n;
         ns++;
@@ -338,6 +338,57 @@ static void orc_cfft(int n, const orc_cpx *in, orc_cpx *out, const orc_cpx *tw,
                     F[m + j].i = F[j].i - t.i;
                     F[j].r += t.r;
                     F[j].i += t.i;
+                }
+            } else if (p == 3) {
+                /* kf_bfly3 (vendor/kiss_fft/kiss_fft.c:92-135); HALF_OF(x) = x*.5
+                 * is evaluated in double, so "a - HALF_OF(b)" is a double
+                 * subtraction rounded to float */
+                const orc_cpx epi3 = tw[fstride * m];
+                for (int j = 0; j < m; j++) {
+                    orc_cpx s1 = orc_cmul(F[m + j], tw[j * fstride]);
+                    orc_cpx s2 = orc_cmul(F[2 * m + j], tw[2 * j * fstride]);
+                    orc_cpx s3, s0;
+                    s3.r = s1.r + s2.r;  s3.i = s1.i + s2.i;
+                    s0.r = s1.r - s2.r;  s0.i = s1.i - s2.i;
+                    F[m + j].r = F[j].r - s3.r * .5;
+                    F[m + j].i = F[j].i - s3.i * .5;
+                    s0.r *= epi3.i;
+                    s0.i *= epi3.i;
+                    F[j].r += s3.r;
+                    F[j].i += s3.i;
+                    F[2 * m + j].r = F[m + j].r + s0.i;
+                    F[2 * m + j].i = F[m + j].i - s0.r;
+                    F[m + j].r -= s0.i;
+                    F[m + j].i += s0.r;
+                }
+            } else if (p == 5) {
+                /* kf_bfly5 (vendor/kiss_fft/kiss_fft.c:137-198) */
+                const orc_cpx ya = tw[fstride * m], yb = tw[fstride * 2 * m];
+                for (int j = 0; j < m; j++) {
+                    orc_cpx s0 = F[j];
+                    orc_cpx s1 = orc_cmul(F[m + j], tw[j * fstride]);
+                    orc_cpx s2 = orc_cmul(F[2 * m + j], tw[2 * j * fstride]);
+                    orc_cpx s3 = orc_cmul(F[3 * m + j], tw[3 * j * fstride]);
+                    orc_cpx s4 = orc_cmul(F[4 * m + j], tw[4 * j * fstride]);
+                    orc_cpx s5, s6, s7, s8, s9, s10, s11, s12;
+                    s7.r = s1.r + s4.r;   s7.i = s1.i + s4.i;
+                    s10.r = s1.r - s4.r;  s10.i = s1.i - s4.i;
+                    s8.r = s2.r + s3.r;   s8.i = s2.i + s3.i;
+                    s9.r = s2.r - s3.r;   s9.i = s2.i - s3.i;
+                    F[j].r += s7.r + s8.r;
+                    F[j].i += s7.i + s8.i;
+                    s5.r = s0.r + s7.r * ya.r + s8.r * yb.r;
+                    s5.i = s0.i + s7.i * ya.r + s8.i * yb.r;
+                    s6.r = s10.i * ya.i + s9.i * yb.i;
+                    s6.i = -(s10.r * ya.i) - s9.r * yb.i;
+                    F[m + j].r = s5.r - s6.r;      F[m + j].i = s5.i - s6.i;
+                    F[4 * m + j].r = s5.r + s6.r;  F[4 * m + j].i = s5.i + s6.i;
+                    s11.r = s0.r + s7.r * yb.r + s8.r * ya.r;
+                    s11.i = s0.i + s7.i * yb.r + s8.i * ya.r;
+                    s12.r = -(s10.i * yb.i) + s9.i * ya.i;
+                    s12.i = s10.r * yb.i - s9.r * ya.i;
+                    F[2 * m + j].r = s11.r + s12.r;  F[2 * m + j].i = s11.i + s12.i;
+                    F[3 * m + j].r = s11.r - s12.r;  F[3 * m + j].i = s11.i - s12.i;
                 }
             } else {
                 for (int j = 0; j < m; j++) {

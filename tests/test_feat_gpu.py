@@ -173,6 +173,27 @@ module
         assert np.abs(got - want)[both].max() <= 1e-5 * scale, name
 
 
+@pytest.mark.parametrize("rate,frame_rate,width", [(16000, 100, 0), (16000, 100, 400), (8000, 100, 200),
+                                                   (16000, 125, 240), (44100, 100, 1000)])
+def test_non_power_of_two_windows(capi, oracle, rate, frame_rate, width):
+    """25-ms style windows need KissFFT's radix-3/5 butterflies (kf_bfly3 / kf_bfly5)."""
+    cfg = "module\n{\n name a\n type audiofile\n sample_rate %d\n frame_rate %d\n%s}\n" % (
+        rate, frame_rate, (" window_width %d\n" % width) if width else "")
+    cfg += "module\n{\n name f\n type fft\n magnitude 0\n sources a\n}\n"
+    cfg += "module\n{\n name m\n type mel\n sources f\n}\n"
+    pcm = synth.make_audio(rate, seed=9, sample_rate=rate)
+    ch = oracle.FeatureChain(cfg)
+    ft = capi.Feat(cfg)
+    n = min(60, ft.last_frame(len(pcm)) + 1)
+    for mod in ("f", "m"):
+        want = ch.generate(pcm, -2, n, module=mod)
+        got = ft.run(pcm, -2, n, module=mod, dtype=np.float64)
+        if mod == "f":
+            assert np.array_equal(got, want)          # spectrum bit-identical
+        else:
+            assert np.abs(got - want).max() <= FEAT_TOL
+
+
 def test_set_parameters(capi, oracle, golden_dir, short_wav):
     cfg = _cfg(golden_dir, "mfcc_cms_norm")
     ft = capi.Feat(cfg)
