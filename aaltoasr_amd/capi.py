@@ -109,6 +109,11 @@ def _declare(L: C.CDLL) -> None:
     L.aasr_gmm_expanded_rows.restype = i64
     L.aasr_gmm_set_precision.argtypes = [vp, C.c_int]
     L.aasr_gmm_set_cmllr.argtypes = [vp, i32, vp, vp]
+    L.aasr_gmm_read_clustering.argtypes = [vp, cp]
+    L.aasr_gmm_set_clustering.argtypes = [vp, i32, i64, vp, vp]
+    L.aasr_gmm_set_clustering_min_evals.argtypes = [vp, C.c_double, C.c_double]
+    L.aasr_gmm_num_clusters.argtypes = [vp]
+    L.aasr_gmm_num_clusters.restype = i32
     L.aasr_gmm_score.argtypes = [vp, vp, i64, vp]
     L.aasr_gmm_score_dev.argtypes = [vp, vp, i64, vp, vp]
     L.aasr_gmm_gauss_loglik.argtypes = [vp, vp, i64, vp]
@@ -229,6 +234,35 @@ class Gmm:
         W = np.ascontiguousarray(W, np.float64)
         g2t = np.ascontiguousarray(gauss_to_transform, np.int32)
         check(lib().aasr_gmm_set_cmllr(self._h, W.shape[0], _ptr(g2t), _ptr(W)))
+
+    def read_clustering(self, path: str) -> None:
+        """HmmSet::read_clustering (.gcl file)."""
+        check(lib().aasr_gmm_read_clustering(self._h, path.encode()))
+
+    def set_clustering(self, n_clusters: int, pairs=()) -> None:
+        """In-memory clustering: pairs = [(gauss_index, cluster_index), ...] taken
+        literally; n_clusters = 0 removes it."""
+        gi = np.ascontiguousarray([p[0] for p in pairs], np.int32)
+        ci = np.ascontiguousarray([p[1] for p in pairs], np.int32)
+        check(lib().aasr_gmm_set_clustering(self._h, n_clusters, len(gi), _ptr(gi), _ptr(ci)))
+
+    def set_clustering_min_evals(self, min_clusters: float = 1.0, min_gaussians: float = 1.0) -> None:
+        """HmmSet::set_clustering_min_evals: ratios of clusters / pool Gaussians."""
+        check(lib().aasr_gmm_set_clustering_min_evals(self._h, min_clusters, min_gaussians))
+
+    @property
+    def num_clusters(self) -> int:
+        return lib().aasr_gmm_num_clusters(self._h)
+
+    def cluster_exact_counts(self, n: int) -> np.ndarray:
+        """Diagnostic: clusters evaluated exactly for the first n frames of the last
+        clustered scoring pass."""
+        L = lib()
+        L.aasr_debug_cluster_exact_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        out = np.zeros(n, np.int32)
+        if L.aasr_debug_cluster_exact_counts(self._h, _ptr(out), n) != 0:
+            raise RuntimeError("no clustered scoring pass to report")
+        return out
 
     def set_precision(self, prec: int) -> None:
         """0 = f32 (default), 2 = f32 centred form, 3 = bf16x3 split."""

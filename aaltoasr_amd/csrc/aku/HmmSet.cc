@@ -74,6 +74,23 @@ void HmmSet::ensure_model() {
   }
 }
 
+void HmmSet::read_clustering(const std::string &filename) {
+  ensure_model();
+  // PDFPool::read_clustering throws std::string (aku/Distributions.cc:3118-3140)
+  if (aasr_gmm_read_clustering(m_gmm, filename.c_str()) != AASR_OK)
+    throw std::string(aasr_last_error());
+  m_count = 0;  // cached block rows were scored without the clustering
+  m_row = nullptr;
+}
+
+void HmmSet::set_clustering_min_evals(double min_clusters, double min_gaussians) {
+  ensure_model();
+  if (aasr_gmm_set_clustering_min_evals(m_gmm, min_clusters, min_gaussians) != AASR_OK)
+    throw std::string(aasr_last_error());
+  m_count = 0;
+  m_row = nullptr;
+}
+
 int HmmSet::dim() {
   ensure_model();
   return aasr_gmm_dim(m_gmm);

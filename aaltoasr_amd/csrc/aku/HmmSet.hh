@@ -41,6 +41,10 @@ public:
   int num_states();
   int num_emission_pdfs() { return num_states(); }
 
+  /** aku/HmmSet.hh:477,492 -- Gaussian clustering for the likelihood precomputation */
+  void read_clustering(const std::string &filename);
+  void set_clustering_min_evals(double min_clusters = 1.0, double min_gaussians = 1.0);
+
   void reset_cache();
   void precompute_likelihoods(const FeatureVec &f);
   double state_likelihood(const int s, const FeatureVec &f);

@@ -27,6 +27,12 @@ void PPToolbox::read_configuration(const std::string &cfgname) {
 
 void PPToolbox::read_models(const std::string &base) { m_model.read_all(base); }
 
+// aku/PhoneProbsToolbox.cc:50-53
+void PPToolbox::set_clustering(const std::string &clfile_name, double eval_minc, double eval_ming) {
+  m_model.read_clustering(clfile_name);
+  m_model.set_clustering_min_evals(eval_minc, eval_ming);
+}
+
 static void write_all(int fd, const uint8_t *p, size_t n) {
   while (n > 0) {
     ssize_t w = write(fd, p, n);

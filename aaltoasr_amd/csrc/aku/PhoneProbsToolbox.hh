@@ -16,6 +16,8 @@ class PPToolbox {
 public:
   void read_configuration(const std::string &cfgname);
   void read_models(const std::string &base);
+  /** aku/PhoneProbsToolbox.hh:18 */
+  void set_clustering(const std::string &clfile_name, double eval_minc, double eval_ming);
   /** audio file (or raw PCM16 when raw is set) -> LNA file */
   void generate(const std::string &input, const std::string &output, bool raw = false);
   void generate_from_file_to_fd(const std::string &input, int out_fd, bool raw = false);

@@ -22,8 +22,8 @@ static double safe_log(double x) {  // aku/util.hh:132-139
 }
 
 int main(int argc, char **argv) {
-  if (argc != 6) {
-    fprintf(stderr, "usage: aku_adapter_check CFG MODEL_BASE AUDIO OUT.lna LNABYTES\n");
+  if (argc != 6 && argc != 9) {
+    fprintf(stderr, "usage: aku_adapter_check CFG MODEL_BASE AUDIO OUT.lna LNABYTES [GCL MINC MING]\n");
     return 2;
   }
   try {
@@ -34,6 +34,10 @@ int main(int argc, char **argv) {
     gen.load_configuration(cf);
     fclose(cf);
     model.read_all(argv[2]);
+    if (argc == 9) {  // aku/phone_probs.cc:112-117
+      model.read_clustering(argv[6]);
+      model.set_clustering_min_evals(atof(argv[7]), atof(argv[8]));
+    }
     const int lnabytes = atoi(argv[5]);
     if (model.dim() != gen.dim()) throw std::string("dimension mismatch");
     gen.open(argv[3]);

@@ -3,9 +3,9 @@
 //
 //   phone_probs (-b BASE | -g GK -m MC -p PH) -c CFG -r RECIPE [-o DIR]
 //               [--lnabytes 2|4] [-a] [-n] [-N] [-B n -I k] [-i level]
+//               [-C GCL --eval-minc R --eval-ming R]
 //
-// Not built (fail loudly): -S speakers, -C clusters / --eval-minc /
-// --eval-ming, --sort-recipe.  One process drives one GPU (--device N or
+// Not built (fail loudly): -S speakers, --sort-recipe.  One process drives one GPU (--device N or
 // HIP_VISIBLE_DEVICES); run N processes with -B N -I k for N GPUs, exactly as
 // the reference scales over CPU cores.
 #include <getopt.h>
@@ -26,6 +26,8 @@ static void die(const std::string &msg) {
 
 int main(int argc, char *argv[]) {
   std::string base, gk, mc, ph, cfg, recipe, out_dir;
+  std::string clusters;
+  double eval_minc = 0.0, eval_ming = 0.1;  // defaults of aku/phone_probs.cc:74-75
   int lnabytes = 2, info = 0, batch = 0, bindex = 0, device = -1;
   bool afname = false, no_overwrite = false, no_norm = false, batch_set = false, bindex_set = false;
   static struct option opts[] = {
@@ -48,7 +50,9 @@ int main(int argc, char *argv[]) {
                "  -b BASE | -g GK -m MC -p PH   model files\n  -c CFG   feature configuration\n"
                "  -r RECIPE  recipe file\n  -o DIR   output directory\n  --lnabytes=2|4\n"
                "  -a  use audio file name\n  -n  no overwrite\n  -N  no normalization\n"
-               "  -B n -I k  batch k of n\n  -i level  info\n  --device=N  GPU ordinal\n");
+               "  -B n -I k  batch k of n\n  -i level  info\n  --device=N  GPU ordinal\n"
+               "  -C GCL  Gaussian clustering file\n  --eval-minc=R  minimum ratio of top clusters\n"
+               "  --eval-ming=R  minimum ratio of Gaussians to evaluate\n");
         return 0;
       case 'b': base = optarg; break;
       case 'g': gk = optarg; break;
@@ -66,7 +70,9 @@ int main(int argc, char *argv[]) {
       case 'i': info = atoi(optarg); break;
       case 5: device = atoi(optarg); break;
       case 'S': die("--speakers (speaker adaptation) is not built in this engine yet");
-      case 'C': case 2: case 3: die("Gaussian clustering (--clusters/--eval-*) is not built in this engine yet");
+      case 'C': clusters = optarg; break;
+      case 2: eval_minc = atof(optarg); break;
+      case 3: eval_ming = atof(optarg); break;
       case 4: die("--sort-recipe is not built in this engine yet");
       default: return 2;
     }
@@ -92,6 +98,12 @@ int main(int argc, char *argv[]) {
   if (aasr_feat_create(ss.str().c_str(), &feat) != AASR_OK) die(aasr_last_error());
   if (aasr_gmm_create_from_files(gk.c_str(), mc.c_str(), ph.c_str(), &gmm) != AASR_OK)
     die(aasr_last_error());
+  if (!clusters.empty()) {
+    // aku/phone_probs.cc:112-117
+    if (aasr_gmm_read_clustering(gmm, clusters.c_str()) != AASR_OK) die(aasr_last_error());
+    if (aasr_gmm_set_clustering_min_evals(gmm, eval_minc, eval_ming) != AASR_OK)
+      die(aasr_last_error());
+  }
   aasr_run_options opt;
   memset(&opt, 0, sizeof opt);
   opt.lnabytes = lnabytes;

@@ -191,6 +191,8 @@ aasr_status aasr_gmm_set_cmllr(aasr_gmm *h, int32_t n_transforms,
     if (!h) raise(AASR_ERR_INVALID, "null handle");
     if (n_transforms < 0 || (n_transforms > 0 && (!gauss_to_transform || !W)))
       raise(AASR_ERR_INVALID, "aasr_gmm_set_cmllr: bad argument");
+    if (n_transforms > 0 && h->cl.loaded)
+      raise(AASR_ERR_UNSUPPORTED, "model-side CMLLR together with Gaussian clustering is not built");
     HostModel m = h->host;
     m.n_transforms = n_transforms;
     m.g2t.clear();
@@ -203,6 +205,31 @@ aasr_status aasr_gmm_set_cmllr(aasr_gmm *h, int32_t n_transforms,
     gmm_build(h, m);
   });
 }
+
+aasr_status aasr_gmm_read_clustering(aasr_gmm *h, const char *gcl_path) {
+  return guarded([&] {
+    if (!h || !gcl_path) raise(AASR_ERR_INVALID, "aasr_gmm_read_clustering: null argument");
+    gmm_read_clustering(h, gcl_path);
+  });
+}
+
+aasr_status aasr_gmm_set_clustering(aasr_gmm *h, int32_t n_clusters, int64_t n_pairs,
+                                    const int32_t *gauss_index, const int32_t *cluster_index) {
+  return guarded([&] {
+    if (!h) raise(AASR_ERR_INVALID, "null handle");
+    gmm_set_clustering(h, n_clusters, n_pairs, gauss_index, cluster_index);
+  });
+}
+
+aasr_status aasr_gmm_set_clustering_min_evals(aasr_gmm *h, double min_clusters,
+                                              double min_gaussians) {
+  return guarded([&] {
+    if (!h) raise(AASR_ERR_INVALID, "null handle");
+    gmm_set_clustering_min_evals(h, min_clusters, min_gaussians);
+  });
+}
+
+int32_t aasr_gmm_num_clusters(const aasr_gmm *h) { return h && h->cl.loaded ? h->cl.C : 0; }
 
 aasr_status aasr_gmm_score_dev(aasr_gmm *h, const float *d_frames, int64_t F,
                                float *d_state_loglik, void *stream) {

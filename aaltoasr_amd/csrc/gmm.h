@@ -104,6 +104,8 @@ struct TrackLayout {
   int max_splits = 1;
   int64_t rows_padded = 0;
   float ref_ln = 0.0f;       // reference exponent * ln 2
+  double ref_log2 = 0;       // the reference exponent itself
+  std::vector<int32_t> row_gauss;   // host: pool Gaussian of every packed row, -1 = null row
 };
 
 // Row layout of the full-covariance kernel: every mixture component occupies
@@ -121,6 +123,37 @@ struct FullLayout {
   DevBuf<int32_t> splits;   // [MAX_SPLITS][MAX_SPLITS+1][8]: tile, ks0, ks1, kg0, kg1
   int max_splits = 1;
   float ref_ln = 0.0f;
+};
+
+// Gaussian clustering (PDFPool::read_clustering + the cluster branch of
+// PDFPool::precompute_likelihoods, aku/Distributions.cc:3114-3170, 2684-2722).
+struct ClusterState {
+  bool loaded = false;   // a clustering has been read
+  bool enabled = false;  // set_clustering_min_evals() switches it on (HmmSet.cc:1359-1366)
+  int32_t C = 0, Cs = 0;           // clusters, padded to a multiple of 8
+  int min_clusters = 0, min_gaussians = 0;
+  std::vector<int32_t> g2c;        // [G] cluster of each Gaussian, -1 = none
+  std::vector<int32_t> csize_h;    // [C] members, duplicates counted as the reference does
+  std::vector<double> c_mean, c_prec, c_cst;   // centres (host copy for the adapters/tests)
+  int dimp = 0;                    // dimension padded to a multiple of 8
+  DevBuf<double> rec;              // [Cs/8][dimp][8][2] (mean, precision) of the centres
+  DevBuf<double> cconst;           // [Cs] constants
+  DevBuf<int32_t> csize;           // [Cs] members per cluster (0 beyond C)
+  DevBuf<int32_t> crow[2];         // cluster of each packed row of the grouped / independent
+                                   // track layout (C = no cluster or null row)
+  // per-state centre weights W[s][c] = sum of the weights of s's components in
+  // cluster c, ELL layout [nnz][S]
+  int nnz = 0;
+  DevBuf<int32_t> w_cluster;
+  DevBuf<float> w_weight;
+  double ref_log2 = 0;             // reference exponent shared with the track kernels
+  // per-call scratch, sized for Fc frames
+  int64_t Fc = 0;
+  DevBuf<double> ll64;             // [Fc][Cs] centre log-likelihoods
+  DevBuf<unsigned long long> maskw;  // [Fc/64][C+1] bit f = frame f takes the exact values
+  DevBuf<unsigned long long> maskrow;  // [Fc/64][rows_padded] the same per packed row
+  DevBuf<float> cval;              // [Fc][C] 2^(log2e*ll_c + ref) of the centres that stand in
+  DevBuf<int32_t> n_exact;         // [Fc] clusters evaluated exactly (diagnostic)
 };
 
 }  // namespace aasr
@@ -156,6 +189,7 @@ struct aasr_gmm {
   // global CMLLR transform applied to the frames before scoring
   aasr::DevBuf<double> xf_a, xf_b;
   aasr::DevBuf<float> d_xframes;
+  aasr::ClusterState cl;
   // staging for the host-buffer entry points
   aasr::DevBuf<float> d_frames, d_out;
 };
@@ -172,4 +206,14 @@ void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F,
                       float *d_out, hipStream_t stream);
 void gmm_gauss_launch(aasr_gmm *g, const float *d_frames, int64_t F,
                       float *d_out, hipStream_t stream);
+// gmm_cluster.hip
+void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
+                        const int32_t *gauss_index, const int32_t *cluster_index);
+void gmm_read_clustering(aasr_gmm *g, const char *path);
+void gmm_set_clustering_min_evals(aasr_gmm *g, double min_clusters, double min_gaussians);
+void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
+                              hipStream_t stream);
+void gmm_tracks_masked_launch(aasr_gmm *g, int which, const float *d_frames, int64_t F,
+                              float *d_out, const unsigned long long *maskrow,
+                              hipStream_t stream);
 }  // namespace aasr

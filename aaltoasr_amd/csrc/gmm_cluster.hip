@@ -1,0 +1,665 @@
+// gmm_cluster.hip -- Gaussian clustering for the scoring path.
+//
+// Replaces, for a block of frames,
+//   PDFPool::read_clustering              aku/Distributions.cc:3114-3170
+//     Gaussian::merge (unit weights)      aku/Distributions.cc:853-898
+//   HmmSet::set_clustering_min_evals      aku/HmmSet.cc:1359-1366
+//   PDFPool::precompute_likelihoods, cluster branch   aku/Distributions.cc:2684-2722
+//   PDFPool::compute_likelihood (cache rule)           aku/Distributions.cc:2636-2644
+//
+// What the reference does per frame: evaluate every cluster centre, pop the
+// centres best first and evaluate their member Gaussians exactly until both
+// `min_clusters` clusters and `min_gaussians` Gaussians are done; every other
+// Gaussian gets its centre's likelihood.  A cached value <= 0 is not trusted by
+// PDFPool::compute_likelihood, so a Gaussian whose centre underflowed to 0 (or
+// that is in no cluster) is still evaluated exactly when a mixture reads it.
+//
+// The mixture sum is linear, so a state's likelihood splits into
+//     sum over components whose exact value is used            (matrix kernel)
+//   + sum over clusters c of W[s][c] * centre likelihood(c)    (sparse, per state)
+// with W[s][c] the total weight of the state's components in cluster c.  Per
+// block of frames that is five launches:
+//   k_cluster_centres  f64 centre log-likelihoods, same operation order as
+//                      DiagonalGaussian::compute_log_likelihood (:1040-1062), so
+//                      the ranking of the centres is the reference's ranking;
+//   k_cluster_select   one wave per 64 frames: per frame the threshold T with
+//                      "centre >= T  <=>  popped by the reference's first loop",
+//                      found by a multi-level 64-bucket histogram selection
+//                      (exact: buckets are a monotone function of the value);
+//                      writes one bit per (cluster, frame) -- 1 = exact -- and
+//                      the linear centre values 2^(log2e*ll + ref) of the rest;
+//   k_cluster_expand   the bits per packed row of the track layout in use;
+//   track kernel <CL>  the regular scoring kernel (f32 or bf16x3) with the bits
+//                      applied to its accumulators (one v_cndmask per register,
+//                      masks fetched with 64-byte scalar loads), no floor;
+//   k_cluster_merge    out = log(max(exact part + sum_c W[s][c] centre_c, 1e-50)).
+// The matrix work is not reduced (on this machine evaluating every Gaussian is
+// cheaper than gathering per-frame cluster subsets); the point of this path is
+// output parity with recognisers configured with -C/--eval-ming.
+// Ties: equal centre values are all treated alike (the reference pops them in
+// heap order); equal doubles only occur for underflowed zeros, which are
+// evaluated exactly either way.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <fstream>
+#include <map>
+#include <sstream>
+
+#include "gmm.h"
+
+namespace aasr {
+
+static const double kLog2eD = 1.4426950408889634074;
+// exp(x) rounds to 0.0 in double below ln(2^-1075)
+#define AASR_EXP_UNDERFLOW_LL (-745.13321910194122)
+#define AASR_LOG_TINY_F (-115.12925464970228f)
+
+// ---------------------------------------------------------------- centres --
+// thread = frame (float values parked in LDS, [dimension][thread]); the records
+// of 8 clusters at a time are staged in LDS (double buffered) and read back as
+// 16-byte broadcasts, so every thread runs 8 independent accumulation chains.
+// The dimension loop is a real loop: fully unrolled, the compiler hoists every
+// operand load of a group and spills.
+constexpr int kCentreThreads = 256;
+
+__global__ __launch_bounds__(kCentreThreads) void k_cluster_centres(
+    const float *__restrict__ frames, int64_t F, int dim, int dimp,
+    const double *__restrict__ rec, const double *__restrict__ cconst, int groups,
+    int groups_per_y, double *__restrict__ ll64, int64_t Cs) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  double *pbuf = (double *)smem_c;                              // [2][dimp][8][2]
+  float *xs = (float *)(smem_c + (size_t)2 * dimp * 16 * 8);    // [dimp][kCentreThreads]
+  const int tid = threadIdx.x;
+  const int64_t f = (int64_t)blockIdx.x * kCentreThreads + tid;
+  const int64_t fc = f < F ? f : F - 1;
+  for (int d = 0; d < dimp; d++) xs[d * kCentreThreads + tid] = d < dim ? frames[fc * dim + d] : 0.0f;
+  const int g_begin = blockIdx.y * groups_per_y;
+  const int g_end = min(groups, g_begin + groups_per_y);
+  const int rec_doubles = dimp * 16;
+  for (int i = tid; i < rec_doubles; i += kCentreThreads)
+    pbuf[i] = rec[(size_t)g_begin * rec_doubles + i];
+  __syncthreads();
+  for (int cg = g_begin; cg < g_end; cg++) {
+    const double *cur = pbuf + ((cg - g_begin) & 1) * rec_doubles;
+    double *nxt = pbuf + ((cg - g_begin + 1) & 1) * rec_doubles;
+    if (cg + 1 < g_end)
+      for (int i = tid; i < rec_doubles; i += kCentreThreads)
+        nxt[i] = rec[(size_t)(cg + 1) * rec_doubles + i];
+    double acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0.0;
+#pragma unroll 2
+    for (int d = 0; d < dimp; d++) {
+      const double x = (double)xs[d * kCentreThreads + tid];
+      const f64x2 *r = (const f64x2 *)(cur + d * 16);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const f64x2 mp = r[j];  // (mean, precision): one broadcast read
+        const double dd = x - mp.x;
+        acc[j] += dd * dd * mp.y;  // (d*d)*prec, then the sum: reference order
+      }
+    }
+    if (f < F) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        double ll = acc[j] * -0.5;
+        ll += cconst[cg * 8 + j];
+        ll64[f * Cs + (int64_t)cg * 8 + j] = ll;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ----------------------------------------------------------------- select --
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+
+// One wave per 64 consecutive frames (= one word of the selection masks);
+// lane l holds clusters l, 64 + l, ...  (KPL per lane).
+template <int KPL>
+__global__ __launch_bounds__(64) void k_cluster_select(
+    const double *__restrict__ ll64, int64_t F, int C, int64_t Cs,
+    const int32_t *__restrict__ csize, int min_clusters, int min_gaussians, double ref,
+    unsigned long long *__restrict__ maskw, float *__restrict__ cval,
+    int32_t *__restrict__ n_exact) {
+  __shared__ unsigned long long hist[64];
+  __shared__ unsigned long long bits[64][KPL];  // [frame in word][cluster slot] ballots
+  const int lane = threadIdx.x;
+  int sz[KPL];
+#pragma unroll
+  for (int j = 0; j < KPL; j++) {
+    const int c = j * 64 + lane;
+    sz[j] = c < C ? csize[c] : 0;
+  }
+  const int64_t word = blockIdx.x;
+  for (int fi = 0; fi < 64; fi++) {
+    const int64_t f = word * 64 + fi;
+    if (f >= F) {  // wave-uniform
+#pragma unroll
+      for (int j = 0; j < KPL; j++)
+        if (lane == 0) bits[fi][j] = 0ull;
+      continue;
+    }
+    const double *row = ll64 + f * Cs;
+    double v[KPL];
+    unsigned long long cand = 0;
+#pragma unroll
+    for (int j = 0; j < KPL; j++) {
+      const int c = j * 64 + lane;
+      const double x = c < C ? row[c] : 0.0;
+      v[j] = x;
+      if (c < C && x == x) cand |= 1ull << j;
+    }
+    int need_c = min_clusters, need_g = min_gaussians;
+    double T = INFINITY;  // centre >= T  <=>  members evaluated exactly
+    if (need_c > 0 || need_g > 0) {
+      for (int level = 0; level < 64; level++) {
+        double lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < KPL; j++)
+          if ((cand >> j) & 1) {
+            lo = fmin(lo, v[j]);
+            hi = fmax(hi, v[j]);
+          }
+        lo = wave_min_f64(lo);
+        hi = wave_max_f64(hi);
+        if (!(hi >= lo)) {  // no candidate left: the request exceeds what is there
+          T = -INFINITY;
+          break;
+        }
+        const double scale = 64.0 / (hi - lo);
+        if (!(hi > lo) || !(scale < 1.0e300)) {  // one value left (single centre or ties)
+          T = lo;
+          break;
+        }
+        hist[lane] = 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < KPL; j++)
+          if ((cand >> j) & 1) {
+            int b = (int)((hi - v[j]) * scale);
+            b = b > 63 ? 63 : b;
+            atomicAdd(&hist[b], (1ull << 32) | (unsigned long long)(unsigned)sz[j]);
+          }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long h = hist[lane];
+        unsigned long long cum = h;  // inclusive prefix over buckets 0..lane
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned long long t = __shfl_up(cum, o);
+          if (lane >= o) cum += t;
+        }
+        const long long cumc = (long long)(cum >> 32), cumg = (long long)(cum & 0xffffffffull);
+        const bool sat = (need_c - cumc <= 0) && (need_g - cumg <= 0);
+        const unsigned long long ballot = __ballot(sat);
+        if (ballot == 0ull) {
+          T = -INFINITY;
+          break;
+        }
+        const int B = __ffsll((long long)ballot) - 1;
+        const unsigned long long excl = __shfl(cum - h, B);
+        need_c -= (int)(excl >> 32);
+        need_g -= (int)(excl & 0xffffffffull);
+        // the boundary lies in bucket B: better buckets are taken, worse ones are not
+#pragma unroll
+        for (int j = 0; j < KPL; j++)
+          if ((cand >> j) & 1) {
+            int b = (int)((hi - v[j]) * scale);
+            b = b > 63 ? 63 : b;
+            if (b != B) cand &= ~(1ull << j);
+          }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    int exact = 0;
+#pragma unroll
+    for (int j = 0; j < KPL; j++) {
+      const int c = j * 64 + lane;
+      const bool valid = c < C;
+      const bool sel = valid && v[j] >= T;
+      exact += sel ? 1 : 0;
+      // a centre whose likelihood is 0.0 in double is not trusted by
+      // PDFPool::compute_likelihood: its members are evaluated exactly
+      const bool use_exact = sel || !(v[j] >= AASR_EXP_UNDERFLOW_LL);
+      const unsigned long long bal = __ballot(valid && use_exact);
+      if (lane == 0) bits[fi][j] = bal;
+      if (valid) cval[f * C + c] = use_exact ? 0.0f : exp2f((float)(v[j] * kLog2eD + ref));
+    }
+    if (n_exact) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) exact += __shfl_xor(exact, o);
+      if (lane == 0) n_exact[f] = exact;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // transpose 64x64 bit blocks: lane l assembles the word of cluster 64 j + l
+#pragma unroll
+  for (int j = 0; j < KPL; j++) {
+    const int c = j * 64 + lane;
+    unsigned long long w = 0;
+    for (int fi = 0; fi < 64; fi++) w |= ((bits[fi][j] >> lane) & 1ull) << fi;
+    if (c < C) maskw[word * (C + 1) + c] = w;
+  }
+  if (lane == 0) maskw[word * (C + 1) + C] = ~0ull;  // rows in no cluster: always exact
+}
+
+// ----------------------------------------------------------------- expand --
+// Lane masks for the track kernels (see ClusterArgs in gmm_score.hip): for the
+// register pair e of quad q of block mb of a tile, rows r0 = 8q+e (track 0) and
+// r1 = 8q+4+e (track 1) of the block;
+//   left  = frames  0-31 of r0 in lanes 0-31, of r1 in lanes 32-63
+//   right = frames 32-63 of r0 in lanes 0-31, of r1 in lanes 32-63.
+__global__ __launch_bounds__(256) void k_cluster_expand(
+    const unsigned long long *__restrict__ maskw, int mask_stride,
+    const int32_t *__restrict__ crow, int64_t rows_padded,
+    unsigned long long *__restrict__ maskrow) {
+  const int64_t pair = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (tile, mb, q, e)
+  if (pair >= rows_padded / 2) return;
+  const int64_t word = blockIdx.y;
+  const int e = (int)(pair & 3);
+  const int64_t quad = pair >> 2;  // tile*8 + mb*4 + q
+  const int64_t r0 = quad * 8 + e;
+  const unsigned long long m0 = maskw[word * mask_stride + crow[r0]];
+  const unsigned long long m1 = maskw[word * mask_stride + crow[r0 + 4]];
+  unsigned long long *o = maskrow + word * rows_padded + quad * 8 + 2 * e;
+  o[0] = (m0 & 0xffffffffull) | (m1 << 32);
+  o[1] = (m0 >> 32) | (m1 & 0xffffffff00000000ull);
+}
+
+// ------------------------------------------------------------------ merge --
+// out[f][s] = log(max(exact part + sum_c W[s][c] * centre value(f, c), 1e-50)).
+// A workgroup of 1024 threads owns kMergeFrames frames x 2048 states per step:
+// the frames' centre values are staged in LDS transposed to [cluster][frame], so
+// one 16-byte LDS read serves four frames of a (state, cluster) pair; every
+// thread keeps the centre weights of its two states in registers.
+constexpr int kMergeFrames = 8;
+constexpr int kMergeThreads = 1024;
+constexpr int kMergeSPT = 2;  // states per thread
+
+template <int NNZ>
+__global__ __launch_bounds__(kMergeThreads) void k_cluster_merge(
+    float *__restrict__ out, int64_t F, int64_t S, const float *__restrict__ cval, int C,
+    const int32_t *__restrict__ w_cluster, const float *__restrict__ w_weight, int nnz,
+    float ref, int frames_per_block, int cstride) {
+  // [C][cstride]: cstride = 12 floats spreads the 16-byte reads of different
+  // clusters over all banks (8 would put every read on 4 bank groups)
+  extern __shared__ __attribute__((aligned(16))) float cv[];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x;
+  int64_t st[kMergeSPT];
+  bool live[kMergeSPT];
+  int wc[kMergeSPT][NNZ];
+  float ww[kMergeSPT][NNZ];
+#pragma unroll
+  for (int u = 0; u < kMergeSPT; u++) {
+    st[u] = ((int64_t)blockIdx.x * kMergeSPT + u) * kMergeThreads + tid;
+    live[u] = st[u] < S;
+    const int64_t sc = live[u] ? st[u] : S - 1;
+#pragma unroll
+    for (int j = 0; j < NNZ; j++) {
+      wc[u][j] = j < nnz ? w_cluster[(int64_t)j * S + sc] : 0;
+      ww[u][j] = j < nnz ? w_weight[(int64_t)j * S + sc] : 0.0f;
+    }
+  }
+  const int64_t f_begin = (int64_t)blockIdx.y * frames_per_block;
+  const int64_t f_end = min(F, f_begin + frames_per_block);
+  const float ref_ln = ref * 0.69314718055994530942f;
+  for (int64_t fg = f_begin; fg < f_end; fg += kMergeFrames) {
+    const int nf = (int)min((int64_t)kMergeFrames, f_end - fg);
+    __syncthreads();
+    for (int i = tid; i < kMergeFrames * C; i += kMergeThreads) {
+      const int k = i / C, c = i - k * C;
+      cv[c * cstride + k] = k < nf ? cval[(fg + k) * C + c] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kMergeSPT; u++) {
+      if (!live[u]) continue;
+      float lin[kMergeFrames];
+#pragma unroll
+      for (int k = 0; k < kMergeFrames; k++)
+        lin[k] = k < nf ? exp2f(fmaf(out[(fg + k) * S + st[u]], 1.4426950408889634f, ref)) : 0.0f;
+#pragma unroll
+      for (int j = 0; j < NNZ; j++) {
+        const f32x4 *p = (const f32x4 *)(cv + wc[u][j] * cstride);
+        const f32x4 a = p[0], b = p[1];
+        const float w = ww[u][j];
+        lin[0] = fmaf(w, a.x, lin[0]);
+        lin[1] = fmaf(w, a.y, lin[1]);
+        lin[2] = fmaf(w, a.z, lin[2]);
+        lin[3] = fmaf(w, a.w, lin[3]);
+        lin[4] = fmaf(w, b.x, lin[4]);
+        lin[5] = fmaf(w, b.y, lin[5]);
+        lin[6] = fmaf(w, b.z, lin[6]);
+        lin[7] = fmaf(w, b.w, lin[7]);
+      }
+      for (int j = NNZ; j < nnz; j++) {
+        const float w = w_weight[(int64_t)j * S + st[u]];
+        const float *p = cv + w_cluster[(int64_t)j * S + st[u]] * cstride;
+#pragma unroll
+        for (int k = 0; k < kMergeFrames; k++) lin[k] = fmaf(w, p[k], lin[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < kMergeFrames; k++)
+        if (k < nf) {
+          const float l = fmaf(__log2f(lin[k]), 0.69314718055994530942f, -ref_ln);
+          out[(fg + k) * S + st[u]] = fmaxf(l, AASR_LOG_TINY_F);
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------- host --
+
+// Centre of one cluster: Gaussian::merge with unit weights into a
+// DiagonalGaussian (aku/Distributions.cc:853-898, 1208-1228, 1273-1288).
+static void merge_centre(const HostModel &m, const std::vector<int32_t> &members, double *mean,
+                         double *prec, double *cst) {
+  const int D = m.dim;
+  double weight_sum = 0;
+  for (size_t i = 0; i < members.size(); i++) weight_sum += 1.0;
+  if (weight_sum < 1e-15) weight_sum = 1;
+  const double scale = 1.0 / weight_sum;
+  double c = 1;
+  for (int d = 0; d < D; d++) {
+    double nm = 0, nc = 0;
+    for (int32_t g : members) {
+      const double mu = m.mean[(size_t)g * D + d];
+      const double var = m.var[(size_t)g * D + d];
+      nc += 1.0 * (var + mu * mu);
+      nm += 1.0 * mu;
+    }
+    nm *= scale;
+    nc *= scale;
+    nc += -1.0 * nm * nm;
+    mean[d] = nm;
+    prec[d] = nc > 0 ? 1 / nc : 0;
+  }
+  for (int d = 0; d < D; d++) c *= prec[d];
+  if (c > 0) c = std::log(std::sqrt(c));
+  *cst = c;
+}
+
+// cluster of every packed row of a track layout
+static void build_crow(const aasr_gmm *g, const TrackLayout &L, const ClusterState &cl,
+                       DevBuf<int32_t> &out) {
+  std::vector<int32_t> crow(L.row_gauss.size(), cl.C);
+  for (size_t r = 0; r < crow.size(); r++) {
+    const int32_t gi = L.row_gauss[r];
+    if (gi >= 0 && cl.g2c[(size_t)gi] >= 0) crow[r] = cl.g2c[(size_t)gi];
+  }
+  out.upload(crow.data(), crow.size());
+}
+
+void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
+                        const int32_t *gauss_index, const int32_t *cluster_index) {
+  ClusterState &cl = g->cl;
+  if (n_clusters <= 0) {
+    cl = ClusterState();
+    return;
+  }
+  const HostModel &m = g->host;
+  if (m.factor_path() || m.n_transforms > 0)
+    raise(AASR_ERR_UNSUPPORTED,
+          "Gaussian clustering is built for diagonal, unadapted pools only");
+  if (n_clusters > 0.3 * (double)m.G)
+    raise(AASR_ERR_INVALID,
+          "PDFPool::read_clustering(): Number of clusters (%d) seems insensible compared to the "
+          "number of Gaussians (%ld).", n_clusters, (long)m.G);
+  if (n_clusters > 64 * 64)
+    raise(AASR_ERR_UNSUPPORTED, "more than 4096 clusters are not built (%d asked)", n_clusters);
+  if (n_pairs > 0 && (!gauss_index || !cluster_index))
+    raise(AASR_ERR_INVALID, "aasr_gmm_set_clustering: null argument");
+  if (!g->paired.ok && !g->tracks.ok)
+    raise(AASR_ERR_UNSUPPORTED,
+          "Gaussian clustering needs the fixed-reference track kernels, which this model's "
+          "constants rule out");
+  std::vector<std::vector<int32_t>> members((size_t)n_clusters);
+  std::vector<int32_t> g2c((size_t)m.G, -1);
+  for (int64_t i = 0; i < n_pairs; i++) {
+    const int32_t gi = gauss_index[i], ci = cluster_index[i];
+    if (gi < 0 || gi >= m.G)
+      raise(AASR_ERR_INVALID, "PDFPool::read_clustering(): Gauss index out of bounds");
+    if (ci < 0 || ci >= n_clusters)
+      raise(AASR_ERR_INVALID, "PDFPool::read_clustering(): Cluster index out of bounds");
+    if (g2c[(size_t)gi] >= 0 && g2c[(size_t)gi] != ci)
+      raise(AASR_ERR_INVALID, "Gaussian %d is listed in clusters %d and %d", gi, g2c[(size_t)gi], ci);
+    g2c[(size_t)gi] = ci;
+    members[(size_t)ci].push_back(gi);
+  }
+  ClusterState n;
+  n.C = n_clusters;
+  n.Cs = (n_clusters + 7) / 8 * 8;
+  n.g2c = g2c;
+  n.dimp = (m.dim + 7) / 8 * 8;
+  n.ref_log2 = g->paired.ok ? g->paired.ref_log2 : g->tracks.ref_log2;
+  n.csize_h.resize((size_t)n.Cs, 0);
+  n.c_mean.assign((size_t)n.C * m.dim, 0.0);
+  n.c_prec.assign((size_t)n.C * m.dim, 0.0);
+  n.c_cst.assign((size_t)n.Cs, 0.0);
+  std::vector<double> rec((size_t)n.Cs / 8 * n.dimp * 16, 0.0);
+  for (int c = 0; c < n.C; c++) {
+    n.csize_h[(size_t)c] = (int32_t)members[(size_t)c].size();
+    merge_centre(m, members[(size_t)c], &n.c_mean[(size_t)c * m.dim], &n.c_prec[(size_t)c * m.dim],
+                 &n.c_cst[(size_t)c]);
+    // the linear centre values share the track kernels' reference exponent
+    if (!(n.c_cst[(size_t)c] * kLog2eD + n.ref_log2 <= 126.0))
+      raise(AASR_ERR_UNSUPPORTED, "cluster %d: centre constant %.1f leaves no f32 headroom", c,
+            n.c_cst[(size_t)c]);
+    for (int d = 0; d < m.dim; d++) {
+      const size_t at = ((size_t)(c / 8) * n.dimp + d) * 16 + 2 * (size_t)(c % 8);
+      rec[at] = n.c_mean[(size_t)c * m.dim + d];
+      rec[at + 1] = n.c_prec[(size_t)c * m.dim + d];
+    }
+  }
+  n.rec.upload(rec.data(), rec.size());
+  n.cconst.upload(n.c_cst.data(), n.c_cst.size());
+  n.csize.upload(n.csize_h.data(), n.csize_h.size());
+  // W[s][c]: weight of state s carried by cluster c (components outside every cluster are
+  // always exact and carry none)
+  std::vector<std::map<int32_t, double>> W((size_t)m.S);
+  int nnz = 1;
+  for (int64_t s = 0; s < m.S; s++) {
+    for (int32_t k = m.mix_off[s]; k < m.mix_off[s + 1]; k++) {
+      const int32_t c = g2c[(size_t)m.mix_idx[k]];
+      if (c >= 0) W[(size_t)s][c] += m.mix_w[(size_t)k];
+    }
+    nnz = std::max(nnz, (int)W[(size_t)s].size());
+  }
+  std::vector<int32_t> wc((size_t)nnz * m.S, 0);
+  std::vector<float> ww((size_t)nnz * m.S, 0.0f);
+  for (int64_t s = 0; s < m.S; s++) {
+    int j = 0;
+    for (auto &kv : W[(size_t)s]) {
+      wc[(size_t)j * m.S + s] = kv.first;
+      ww[(size_t)j * m.S + s] = (float)kv.second;
+      j++;
+    }
+  }
+  n.nnz = nnz;
+  n.w_cluster.upload(wc.data(), wc.size());
+  n.w_weight.upload(ww.data(), ww.size());
+  if (g->paired.ok) build_crow(g, g->paired, n, n.crow[0]);
+  if (g->tracks.ok) build_crow(g, g->tracks, n, n.crow[1]);
+  n.loaded = true;
+  // thresholds and the on/off state survive a re-read like the reference's members do
+  n.enabled = cl.enabled;
+  n.min_clusters = cl.min_clusters;
+  n.min_gaussians = cl.min_gaussians;
+  cl = std::move(n);
+}
+
+// PDFPool::read_clustering's reader (aku/Distributions.cc:3121-3148):
+//   in >> nclusters;  while (in) { int g, c; in >> g >> c; checks; push; }
+// The iteration that runs into end-of-file still executes its body with the
+// operands of the previous iteration (the extraction leaves them untouched when
+// the stream sentry fails), so the last pair of a file is pushed twice: that
+// Gaussian is merged into its centre with weight 2 and counted twice by the
+// min-Gaussians test.  Kept.
+void gmm_read_clustering(aasr_gmm *g, const char *path) {
+  std::ifstream in(path);
+  if (!in)
+    raise(AASR_ERR_IO, "PDFPool::read_clustering(): could not open %s", path);
+  long n = 0;
+  if (!(in >> n) || n <= 0) raise(AASR_ERR_INVALID, "%s: cluster count missing", path);
+  std::vector<int32_t> gi, ci;
+  long a, b;
+  while (in >> a) {
+    if (!(in >> b)) raise(AASR_ERR_INVALID, "%s: Gaussian index %ld without a cluster index", path, a);
+    if (a < 0 || b < 0) raise(AASR_ERR_INVALID, "%s: negative index", path);
+    gi.push_back((int32_t)a);
+    ci.push_back((int32_t)b);
+  }
+  if (!in.eof()) raise(AASR_ERR_INVALID, "%s: unexpected text after %zu pairs", path, gi.size());
+  if (gi.empty()) raise(AASR_ERR_INVALID, "%s: no Gaussian-cluster pairs", path);
+  gi.push_back(gi.back());
+  ci.push_back(ci.back());
+  gmm_set_clustering(g, (int32_t)n, (int64_t)gi.size(), gi.data(), ci.data());
+}
+
+void gmm_set_clustering_min_evals(aasr_gmm *g, double min_clusters, double min_gaussians) {
+  ClusterState &cl = g->cl;
+  if (!cl.loaded)
+    raise(AASR_ERR_INVALID, "set_clustering_min_evals(): no clustering has been read");
+  // HmmSet::set_clustering_min_evals (aku/HmmSet.cc:1359-1366)
+  cl.min_clusters = (int)(min_clusters * cl.C);
+  cl.min_gaussians = (int)(min_gaussians * (double)g->G);
+  cl.enabled = true;
+}
+
+static void launch_centres(aasr_gmm *g, const float *d_frames, int64_t F, hipStream_t stream) {
+  ClusterState &cl = g->cl;
+  const int groups = cl.Cs / 8;
+  const int64_t bx = (F + kCentreThreads - 1) / kCentreThreads;
+  int ny = (int)std::min<int64_t>(groups, std::max<int64_t>(1, 1536 / bx));
+  const int gpy = (groups + ny - 1) / ny;
+  ny = (groups + gpy - 1) / gpy;
+  const int smem = 2 * cl.dimp * 16 * 8 + cl.dimp * kCentreThreads * (int)sizeof(float);
+  static bool attr_set[64] = {false};
+  if (!attr_set[g->device & 63]) {
+    AASR_HIP(hipFuncSetAttribute((const void *)k_cluster_centres,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 2 * 64 * 16 * 8 + 64 * kCentreThreads * 4));
+    attr_set[g->device & 63] = true;
+  }
+  hipLaunchKernelGGL(k_cluster_centres, dim3((unsigned)bx, (unsigned)ny), dim3(kCentreThreads), smem,
+                     stream, d_frames, F, g->dim, cl.dimp, cl.rec.p, cl.cconst.p, groups, gpy,
+                     cl.ll64.p, (int64_t)cl.Cs);
+  AASR_HIP(hipGetLastError());
+}
+
+template <int KPL>
+static void launch_select_t(aasr_gmm *g, int64_t F, hipStream_t stream) {
+  ClusterState &cl = g->cl;
+  const int64_t words = (F + 63) / 64;
+  hipLaunchKernelGGL(k_cluster_select<KPL>, dim3((unsigned)words), dim3(64), 0, stream, cl.ll64.p, F,
+                     cl.C, (int64_t)cl.Cs, cl.csize.p, cl.min_clusters, cl.min_gaussians, cl.ref_log2,
+                     cl.maskw.p, cl.cval.p, cl.n_exact.p);
+  AASR_HIP(hipGetLastError());
+}
+
+template <int NNZ>
+static void launch_merge_t(aasr_gmm *g, float *d_out, int64_t F, hipStream_t stream) {
+  ClusterState &cl = g->cl;
+  const int64_t bx = (g->S + kMergeThreads * kMergeSPT - 1) / (kMergeThreads * kMergeSPT);
+  // enough workgroups to fill the chip, each walking a contiguous run of frames
+  int64_t by = std::max<int64_t>(1, std::min<int64_t>((F + kMergeFrames - 1) / kMergeFrames, 1024 / bx));
+  int fpb = (int)((F + by - 1) / by);
+  fpb = (fpb + kMergeFrames - 1) / kMergeFrames * kMergeFrames;
+  by = (F + fpb - 1) / fpb;
+  const int cstride = cl.C * 12 * 4 <= 144 * 1024 ? 12 : kMergeFrames;
+  const int smem = cstride * cl.C * (int)sizeof(float);
+  static bool attr_set[64] = {false};
+  if (!attr_set[g->device & 63]) {
+    AASR_HIP(hipFuncSetAttribute((const void *)k_cluster_merge<NNZ>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    attr_set[g->device & 63] = true;
+  }
+  hipLaunchKernelGGL(k_cluster_merge<NNZ>, dim3((unsigned)bx, (unsigned)by), dim3(kMergeThreads), smem,
+                     stream, d_out, F, g->S, cl.cval.p, cl.C, cl.w_cluster.p, cl.w_weight.p, cl.nnz,
+                     (float)cl.ref_log2, fpb, cstride);
+  AASR_HIP(hipGetLastError());
+}
+
+void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
+                              hipStream_t stream) {
+  ClusterState &cl = g->cl;
+  if (g->host.factor_path() || g->xf_a.p)
+    raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering is built for diagonal, unadapted pools only");
+  if (g->ill_conditioned)
+    raise(AASR_ERR_UNSUPPORTED,
+          "Gaussian clustering is not built for models that need the centred kernel (kappa %.0f)",
+          g->kappa);
+  // the layout the exact part runs on: grouped unless it is missing or masked out
+  const int which = (g->paired.ok && ((g->layout_mask & 1) || !g->tracks.ok)) ? 0 : 1;
+  const TrackLayout &L = which == 0 ? g->paired : g->tracks;
+  if (!L.ok) raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering needs a track layout for this model");
+  if (cl.crow[which].n != L.row_gauss.size()) build_crow(g, L, cl, cl.crow[which]);
+  // Frames per pass.  A pass is whole rounds of the track kernel (2 workgroups of 256
+  // frames per CU), so passes are sized in rounds: as many as ~6 GB of scratch allow
+  // (12 B per frame x cluster for the centre values, 1 bit per frame x packed row).
+  const double per_frame = 12.0 * (double)(cl.Cs + 1) + (double)L.rows_padded / 8.0;
+  const int64_t round_frames = 2 * (int64_t)(g->num_cus > 0 ? g->num_cus : 256) * FRAMES_PER_BLOCK;
+  int64_t fc = (int64_t)(6.0e9 / per_frame);
+  if (fc >= round_frames) fc = std::min<int64_t>(fc / round_frames, 4) * round_frames;
+  else fc = std::max<int64_t>(FRAMES_PER_BLOCK, fc / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK);
+  fc = std::min<int64_t>(fc, (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK);
+  const size_t need_rows = (size_t)(fc / 64) * (size_t)L.rows_padded;
+  if (fc > cl.Fc || need_rows > cl.maskrow.n) {
+    fc = std::max(fc, cl.Fc);
+    cl.ll64.alloc((size_t)fc * cl.Cs);
+    cl.cval.alloc((size_t)fc * cl.C);
+    cl.maskw.alloc((size_t)(fc / 64) * (cl.C + 1));
+    cl.maskrow.alloc((size_t)(fc / 64) * (size_t)L.rows_padded);
+    cl.n_exact.alloc((size_t)fc);
+    cl.Fc = fc;
+  }
+  for (int64_t f0 = 0; f0 < F; f0 += cl.Fc) {
+    const int64_t n = std::min<int64_t>(cl.Fc, F - f0);
+    const float *fr = d_frames + f0 * g->dim;
+    float *out = d_out + f0 * g->S;
+    launch_centres(g, fr, n, stream);
+    const int kpl = (cl.C + 63) / 64;
+    if (kpl <= 4) launch_select_t<4>(g, n, stream);
+    else if (kpl <= 16) launch_select_t<16>(g, n, stream);
+    else if (kpl <= 32) launch_select_t<32>(g, n, stream);
+    else launch_select_t<64>(g, n, stream);
+    const int64_t words = (n + 63) / 64;
+    hipLaunchKernelGGL(k_cluster_expand, dim3((unsigned)((L.rows_padded / 2 + 255) / 256), (unsigned)words),
+                       dim3(256), 0, stream, cl.maskw.p, cl.C + 1, cl.crow[which].p, L.rows_padded,
+                       cl.maskrow.p);
+    AASR_HIP(hipGetLastError());
+    gmm_tracks_masked_launch(g, which, fr, n, out, cl.maskrow.p, stream);
+    if (cl.nnz <= 8) launch_merge_t<8>(g, out, n, stream);
+    else launch_merge_t<16>(g, out, n, stream);   // weights beyond 16 per state come from L2
+  }
+}
+
+}  // namespace aasr
+
+// Diagnostic (not part of the public ABI): clusters evaluated exactly for each of
+// the first n frames of the most recent clustered scoring pass.
+extern "C" int aasr_debug_cluster_exact_counts(aasr_gmm *g, int32_t *out, int64_t n) {
+  if (!g || !g->cl.n_exact.p || n > g->cl.Fc) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return hipMemcpy(out, g->cl.n_exact.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost) ==
+                 hipSuccess
+             ? 0
+             : -1;
+}

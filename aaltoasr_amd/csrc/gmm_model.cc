@@ -647,6 +647,9 @@ void gmm_build_tracks(aasr_gmm *g, bool grouped) {
   L.rows.rows = (int64_t)m.mix_idx.size();  // real rows (algorithmic work)
   L.close.upload(close_mask.data(), close_mask.size());
   L.rows_padded = tiles * TILE_ROWS;
+  L.ref_log2 = ref;
+  L.row_gauss.resize(rows.size());
+  for (size_t r = 0; r < rows.size(); r++) L.row_gauss[r] = (int32_t)rows[r].g;
   L.ok = true;
 }
 

@@ -285,6 +285,35 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score(
 //            state (4-byte scatter, one store instruction per 32 frames).
 // The row range can be cut (blockIdx.y) so that the grid has no tail round.
 // ---------------------------------------------------------------------------
+// Gaussian-clustering hook of the track kernels (CL = true; see gmm_cluster.hip).
+// One bit per (packed row, frame): 1 = use the Gaussian's exact value, 0 = the row
+// contributes nothing here (its cluster centre is added by k_cluster_merge).
+// k_cluster_expand stores the bits as ready-made lane masks: a wave's 64 frames
+// are one 64-bit word, and accumulator register 4q+e of a block holds rows 8q+e
+// (lanes 0-31) and 8q+4+e (lanes 32-63) for frames n (left block) / 32+n (right
+// block), so maskrow[word][tile][mb][q] is one 64-byte vector {left_e, right_e :
+// e < 4}.  It is a wave-uniform scalar load, prefetched one quad ahead, and each
+// mask is applied with one v_cndmask -- no mask arithmetic in this kernel.
+struct ClusterArgs {
+  const unsigned long long *maskrow = nullptr;
+  int64_t rows_padded = 0;
+  float floor_val = LOG_TINY_F;
+};
+
+// The table is read-only for the whole launch: addressing it through the
+// constant address space lets the compiler use scalar loads (plain global loads
+// are not scalarised in a kernel that also stores).
+typedef unsigned long long u64x8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(4))) u64x8 *cl_mask8_ptr;
+
+__device__ __forceinline__ float mask_select(float x, unsigned long long lane_mask) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(NEG_BIG_F), "v"(x), "s"(lane_mask));
+  return r;
+}
+
+#define AASR_CL_MASKS(mv, e) const unsigned long long ma_ = (mv)[2 * (e)], mb_ = (mv)[2 * (e) + 1];
+
 template <int NKK, bool GROUPED>
 struct TrackSmem {
   static constexpr int OG = TRACK_OUT_GROUP;
@@ -294,12 +323,12 @@ struct TrackSmem {
   static constexpr int kBytes = (2 * kTileFloats + WAVES_PER_BLOCK * kOutFloatsPerWave) * 4;
 };
 
-template <int NKK, bool GROUPED>
+template <int NKK, bool GROUPED, bool CL>
 __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
     const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
     const float *__restrict__ apack, const int32_t *__restrict__ split_row,
     const uint16_t *__restrict__ close_mask, const int32_t *__restrict__ sid, int sid_stride,
-    float *__restrict__ out, int64_t S, float ref_ln, int dbg) {
+    float *__restrict__ out, int64_t S, float ref_ln, int dbg, ClusterArgs cl) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float *smem = (float *)smem_raw;
   constexpr int OG = TRACK_OUT_GROUP;
@@ -347,6 +376,10 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
   float *orow0 = out + (f0 + n) * S;       // !GROUPED: this lane's two output rows
   float *orow1 = out + (f0 + 32 + n) * S;
   const bool ok0 = f0 + n < F, ok1 = f0 + 32 + n < F;
+  const float floor_val = CL ? cl.floor_val : LOG_TINY_F;
+  // this wave's 64 frames are one word of the selection masks
+  const cl_mask8_ptr mrow = (cl_mask8_ptr)(
+      CL ? cl.maskrow + (size_t)__builtin_amdgcn_readfirstlane((int)(f0 >> 6)) * cl.rows_padded : nullptr);
 
   for (int64_t t = t_begin; t < t_end; t++) {
     const int par = (int)((t - t_begin) & 1);
@@ -357,6 +390,11 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
     const unsigned mask16 = close_mask[t];
     // GROUPED: both tracks carry the same bits -> wave-uniform branch
     const unsigned mask = GROUPED ? (mask16 & 0xffu) : (h ? (mask16 >> 8) : (mask16 & 0xffu));
+    // 8 mask vectors per tile, [mb][q]; the first is fetched before the matrix loop
+    const cl_mask8_ptr mt =
+        CL ? mrow + (size_t)__builtin_amdgcn_readfirstlane((int)t) * (TILE_ROWS / 8) : nullptr;
+    u64x8 mnext;
+    if (CL) mnext = mt[0];
 
     f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
     const f32x4 *afrag = (const f32x4 *)acur + lane;
@@ -396,17 +434,38 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         // this lane's quad q of the block: accumulator registers 4q .. 4q+3
-        float e0 = __builtin_amdgcn_exp2f(ca[4 * q]) + __builtin_amdgcn_exp2f(ca[4 * q + 1]);
-        float e1 = __builtin_amdgcn_exp2f(ca[4 * q + 2]) + __builtin_amdgcn_exp2f(ca[4 * q + 3]);
-        float g0 = __builtin_amdgcn_exp2f(cb[4 * q]) + __builtin_amdgcn_exp2f(cb[4 * q + 1]);
-        float g1 = __builtin_amdgcn_exp2f(cb[4 * q + 2]) + __builtin_amdgcn_exp2f(cb[4 * q + 3]);
+        float va[4], vb[4];
+        u64x8 mv;
+        if (CL) {
+          // Scalar loads return out of order, so the only wait is lgkmcnt(0): take
+          // this quad's masks first, THEN put the next quad's load in flight (the
+          // asm ties the next index to the wait so the load cannot be hoisted).
+          int nxt = mb * 4 + q + 1;
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(nxt) : : "memory");
+          mv = mnext;
+          if (mb * 4 + q + 1 < 8) mnext = mt[nxt];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          va[e] = ca[4 * q + e];
+          vb[e] = cb[4 * q + e];
+          if (CL) {
+            AASR_CL_MASKS(mv, e)
+            va[e] = mask_select(va[e], ma_);
+            vb[e] = mask_select(vb[e], mb_);
+          }
+        }
+        float e0 = __builtin_amdgcn_exp2f(va[0]) + __builtin_amdgcn_exp2f(va[1]);
+        float e1 = __builtin_amdgcn_exp2f(va[2]) + __builtin_amdgcn_exp2f(va[3]);
+        float g0 = __builtin_amdgcn_exp2f(vb[0]) + __builtin_amdgcn_exp2f(vb[1]);
+        float g1 = __builtin_amdgcn_exp2f(vb[2]) + __builtin_amdgcn_exp2f(vb[3]);
         s0 += e0 + e1;
         s1 += g0 + g1;
         if ((mask >> (mb * 4 + q)) & 1) {
           float l0 = fmaf(__builtin_amdgcn_logf(s0), LN2_F, -ref_ln);
           float l1 = fmaf(__builtin_amdgcn_logf(s1), LN2_F, -ref_ln);
-          l0 = fmaxf(l0, LOG_TINY_F);
-          l1 = fmaxf(l1, LOG_TINY_F);
+          l0 = fmaxf(l0, floor_val);
+          l1 = fmaxf(l1, floor_val);
           s0 = 0.0f;
           s1 = 0.0f;
           closes++;
@@ -459,14 +518,14 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
   }
 }
 
-template <int NKK, bool GROUPED>
+template <int NKK, bool GROUPED, bool CL>
 static void launch_tracks_t(const aasr_gmm *g, const TrackLayout &L, const float *d_frames,
-                            int64_t F, float *d_out, hipStream_t stream) {
+                            int64_t F, float *d_out, hipStream_t stream, const ClusterArgs &cl) {
   const int64_t blocks = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
   const int smem = TrackSmem<NKK, GROUPED>::kBytes;
   static const int dbg = getenv("AASR_DBG") ? atoi(getenv("AASR_DBG")) : 0;
   static bool attr_set[64] = {false};
-  auto kern = k_gmm_diag_score_tracks<NKK, GROUPED>;
+  auto kern = k_gmm_diag_score_tracks<NKK, GROUPED, CL>;
   if (!attr_set[g->device & 63]) {
     AASR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set[g->device & 63] = true;
@@ -489,17 +548,23 @@ static void launch_tracks_t(const aasr_gmm *g, const TrackLayout &L, const float
   const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(256), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, L.rows.a.p, split_row, L.close.p, L.sid.p, L.sid_stride,
-                     d_out, g->S, L.ref_ln, dbg);
+                     d_out, g->S, L.ref_ln, dbg, cl);
   AASR_HIP(hipGetLastError());
 }
 
 static bool launch_tracks(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
-                          float *d_out, hipStream_t stream) {
+                          float *d_out, hipStream_t stream, const ClusterArgs *cl = nullptr) {
+  const ClusterArgs none;
   switch (L.rows.nkk) {
-#define AASR_CASE(N)                                                                  \
-  case N:                                                                             \
-    if (L.grouped) launch_tracks_t<N, true>(g, L, d_frames, F, d_out, stream);        \
-    else launch_tracks_t<N, false>(g, L, d_frames, F, d_out, stream);                 \
+#define AASR_CASE(N)                                                                        \
+  case N:                                                                                   \
+    if (cl) {                                                                               \
+      if (L.grouped) launch_tracks_t<N, true, true>(g, L, d_frames, F, d_out, stream, *cl); \
+      else launch_tracks_t<N, false, true>(g, L, d_frames, F, d_out, stream, *cl);          \
+    } else {                                                                                \
+      if (L.grouped) launch_tracks_t<N, true, false>(g, L, d_frames, F, d_out, stream, none); \
+      else launch_tracks_t<N, false, false>(g, L, d_frames, F, d_out, stream, none);        \
+    }                                                                                       \
     return true;
     AASR_CASE(8) AASR_CASE(14) AASR_CASE(20) AASR_CASE(26) AASR_CASE(32) AASR_CASE(40)
     AASR_CASE(48) AASR_CASE(64)
@@ -555,12 +620,12 @@ struct Bf16Smem {
   static constexpr int kBytes = 2 * kTileBytes + WAVES_PER_BLOCK * kOutFloatsPerWave * 4;
 };
 
-template <int NK16, bool GROUPED>
+template <int NK16, bool GROUPED, bool CL>
 __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
     const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
     const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
     const uint16_t *__restrict__ close_mask, const int32_t *__restrict__ sid, int sid_stride,
-    float *__restrict__ out, int64_t S, float ref_ln, int dbg) {
+    float *__restrict__ out, int64_t S, float ref_ln, int dbg, ClusterArgs cl) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int OG = Bf16Smem<NK16, GROUPED>::OG;
   constexpr int kTileBytes = Bf16Smem<NK16, GROUPED>::kTileBytes;
@@ -620,6 +685,10 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
   float *orow0 = out + (f0 + n) * S;
   float *orow1 = out + (f0 + 32 + n) * S;
   const bool ok0 = f0 + n < F, ok1 = f0 + 32 + n < F;
+  const float floor_val = CL ? cl.floor_val : LOG_TINY_F;
+  // this wave's 64 frames are one word of the selection masks
+  const cl_mask8_ptr mrow = (cl_mask8_ptr)(
+      CL ? cl.maskrow + (size_t)__builtin_amdgcn_readfirstlane((int)(f0 >> 6)) * cl.rows_padded : nullptr);
 
   if (dbg & 4) {  // experiment: de-phase co-resident workgroups
     unsigned hsh = ((unsigned)blockIdx.x + 977u * blockIdx.y) * 2654435761u;
@@ -637,6 +706,11 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
       issue_tile_copy(apf + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
     const unsigned mask16 = close_mask[t];
     const unsigned mask = GROUPED ? (mask16 & 0xffu) : (h ? (mask16 >> 8) : (mask16 & 0xffu));
+    // 8 mask vectors per tile, [mb][q]; the first is fetched before the matrix loop
+    const cl_mask8_ptr mt =
+        CL ? mrow + (size_t)__builtin_amdgcn_readfirstlane((int)t) * (TILE_ROWS / 8) : nullptr;
+    u64x8 mnext;
+    if (CL) mnext = mt[0];
 
     f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
     const u32x4 *afrag = (const u32x4 *)acur + lane;  // [slab][split][mb][64 lanes]
@@ -678,17 +752,38 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
       const f32x16 &cb = mb ? c11 : c01;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        float e0 = __builtin_amdgcn_exp2f(ca[4 * q]) + __builtin_amdgcn_exp2f(ca[4 * q + 1]);
-        float e1 = __builtin_amdgcn_exp2f(ca[4 * q + 2]) + __builtin_amdgcn_exp2f(ca[4 * q + 3]);
-        float g0 = __builtin_amdgcn_exp2f(cb[4 * q]) + __builtin_amdgcn_exp2f(cb[4 * q + 1]);
-        float g1 = __builtin_amdgcn_exp2f(cb[4 * q + 2]) + __builtin_amdgcn_exp2f(cb[4 * q + 3]);
+        float va[4], vb[4];
+        u64x8 mv;
+        if (CL) {
+          // Scalar loads return out of order, so the only wait is lgkmcnt(0): take
+          // this quad's masks first, THEN put the next quad's load in flight (the
+          // asm ties the next index to the wait so the load cannot be hoisted).
+          int nxt = mb * 4 + q + 1;
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(nxt) : : "memory");
+          mv = mnext;
+          if (mb * 4 + q + 1 < 8) mnext = mt[nxt];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          va[e] = ca[4 * q + e];
+          vb[e] = cb[4 * q + e];
+          if (CL) {
+            AASR_CL_MASKS(mv, e)
+            va[e] = mask_select(va[e], ma_);
+            vb[e] = mask_select(vb[e], mb_);
+          }
+        }
+        float e0 = __builtin_amdgcn_exp2f(va[0]) + __builtin_amdgcn_exp2f(va[1]);
+        float e1 = __builtin_amdgcn_exp2f(va[2]) + __builtin_amdgcn_exp2f(va[3]);
+        float g0 = __builtin_amdgcn_exp2f(vb[0]) + __builtin_amdgcn_exp2f(vb[1]);
+        float g1 = __builtin_amdgcn_exp2f(vb[2]) + __builtin_amdgcn_exp2f(vb[3]);
         s0 += e0 + e1;
         s1 += g0 + g1;
         if ((mask >> (mb * 4 + q)) & 1) {
           float l0 = fmaf(__builtin_amdgcn_logf(s0), LN2_F, -ref_ln);
           float l1 = fmaf(__builtin_amdgcn_logf(s1), LN2_F, -ref_ln);
-          l0 = fmaxf(l0, LOG_TINY_F);
-          l1 = fmaxf(l1, LOG_TINY_F);
+          l0 = fmaxf(l0, floor_val);
+          l1 = fmaxf(l1, floor_val);
           s0 = 0.0f;
           s1 = 0.0f;
           closes++;
@@ -1029,14 +1124,14 @@ static void launch_bf16p_t(const aasr_gmm *g, const TrackLayout &L, const float 
   AASR_HIP(hipGetLastError());
 }
 
-template <int NK16, bool GROUPED>
+template <int NK16, bool GROUPED, bool CL>
 static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
-                          float *d_out, hipStream_t stream) {
+                          float *d_out, hipStream_t stream, const ClusterArgs &cl) {
   const int64_t blocks = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
   const int smem = Bf16Smem<NK16, GROUPED>::kBytes;
   static const int dbg = getenv("AASR_DBG") ? atoi(getenv("AASR_DBG")) : 0;
   static bool attr_set[64] = {false};
-  auto kern = k_gmm_diag_score_bf16x3<NK16, GROUPED>;
+  auto kern = k_gmm_diag_score_bf16x3<NK16, GROUPED, CL>;
   if (!attr_set[g->device & 63]) {
     AASR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set[g->device & 63] = true;
@@ -1057,24 +1152,30 @@ static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *
   const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(256), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, L.a16.p, split_row, L.close.p, L.sid.p, L.sid_stride,
-                     d_out, g->S, L.ref_ln, dbg);
+                     d_out, g->S, L.ref_ln, dbg, cl);
   AASR_HIP(hipGetLastError());
 }
 
 static bool launch_bf16(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
-                        float *d_out, hipStream_t stream) {
+                        float *d_out, hipStream_t stream, const ClusterArgs *cl = nullptr) {
   if (!L.a16.p) return false;
+  const ClusterArgs none;
   static const bool pipelined = getenv("AASR_BF16_PIPE") ? atoi(getenv("AASR_BF16_PIPE")) != 0 : false;
-  if (pipelined && L.nk16 == 5) {
+  if (pipelined && L.nk16 == 5 && !cl) {
     if (L.grouped) launch_bf16p_t<5, true>(g, L, d_frames, F, d_out, stream);
     else launch_bf16p_t<5, false>(g, L, d_frames, F, d_out, stream);
     return true;
   }
   switch (L.nk16) {
-#define AASR_CASE(N)                                                                \
-  case N:                                                                           \
-    if (L.grouped) launch_bf16_t<N, true>(g, L, d_frames, F, d_out, stream);        \
-    else launch_bf16_t<N, false>(g, L, d_frames, F, d_out, stream);                 \
+#define AASR_CASE(N)                                                                      \
+  case N:                                                                                 \
+    if (cl) {                                                                             \
+      if (L.grouped) launch_bf16_t<N, true, true>(g, L, d_frames, F, d_out, stream, *cl); \
+      else launch_bf16_t<N, false, true>(g, L, d_frames, F, d_out, stream, *cl);          \
+    } else {                                                                              \
+      if (L.grouped) launch_bf16_t<N, true, false>(g, L, d_frames, F, d_out, stream, none); \
+      else launch_bf16_t<N, false, false>(g, L, d_frames, F, d_out, stream, none);        \
+    }                                                                                     \
     return true;
     AASR_CASE(1) AASR_CASE(2) AASR_CASE(3) AASR_CASE(4) AASR_CASE(5) AASR_CASE(6) AASR_CASE(8)
 #undef AASR_CASE
@@ -1447,9 +1548,31 @@ extern "C" int aasr_debug_score_occupancy(void) {
   return nb;
 }
 
+// The exact part of a clustered scoring pass: a track layout with the selection
+// masks applied and no 1e-50 floor (k_cluster_merge adds the centre terms and
+// floors).
+// which == 0: grouped layout, 1: independent tracks (gmm_cluster_layout()).
+void gmm_tracks_masked_launch(aasr_gmm *g, int which, const float *d_frames, int64_t F,
+                              float *d_out, const unsigned long long *maskrow,
+                              hipStream_t stream) {
+  const TrackLayout &L = which == 0 ? g->paired : g->tracks;
+  if (!L.ok) raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering needs a track layout for this model");
+  ClusterArgs cl;
+  cl.maskrow = maskrow;
+  cl.rows_padded = L.rows_padded;
+  cl.floor_val = NEG_BIG_F;
+  if (g->use_bf16x3 && launch_bf16(g, L, d_frames, F, d_out, stream, &cl)) return;
+  if (!launch_tracks(g, L, d_frames, F, d_out, stream, &cl))
+    raise(AASR_ERR_UNSUPPORTED, "no track kernel instance for this model");
+}
+
 void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                       hipStream_t stream) {
   if (F <= 0) return;
+  if (g->cl.enabled) {
+    gmm_cluster_score_launch(g, d_frames, F, d_out, stream);
+    return;
+  }
   if (g->host.factor_path()) {
     gmm_full_launch(g, d_frames, F, d_out, stream);
     return;

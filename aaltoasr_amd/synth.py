@@ -42,6 +42,28 @@ def make_model(D=39, G=256, S=32, comps=8, seed=SEED, tied=False, var_lo=0.25, v
     return mean, var, off, idx, w
 
 
+def make_clustering(mean, n_clusters, seed=SEED + 3, iters=4):
+    """Deterministic k-means on the Gaussian means (what aku's gcluster produces in
+    spirit): returns gauss_to_cluster [G] int32 with every cluster non-empty."""
+    rng = np.random.default_rng(seed)
+    mean = np.asarray(mean, np.float64)
+    G = mean.shape[0]
+    cent = mean[rng.choice(G, n_clusters, replace=False)].copy()
+    assign = np.zeros(G, np.int64)
+    for _ in range(iters):
+        d2 = (mean * mean).sum(1)[:, None] - 2.0 * mean @ cent.T + (cent * cent).sum(1)[None, :]
+        assign = d2.argmin(1)
+        for c in range(n_clusters):
+            m = assign == c
+            if m.any():
+                cent[c] = mean[m].mean(0)
+    for c in range(n_clusters):          # no empty cluster: steal a Gaussian
+        if not (assign == c).any():
+            donor = np.bincount(assign, minlength=n_clusters).argmax()
+            assign[np.flatnonzero(assign == donor)[0]] = c
+    return assign.astype(np.int32)
+
+
 def make_frames(F, D=39, seed=SEED + 1, scale=1.0):
     rng = np.random.default_rng(seed)
     return (rng.standard_normal((F, D)) * scale).astype(np.float32)

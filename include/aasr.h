@@ -168,6 +168,36 @@ int64_t aasr_gmm_expanded_rows(const aasr_gmm *h);
 aasr_status aasr_gmm_set_cmllr(aasr_gmm *h, int32_t n_transforms,
                                const int32_t *gauss_to_transform, const double *W);
 
+/* Gaussian clustering: HmmSet::read_clustering / PDFPool::read_clustering
+ * (aku/HmmSet.cc:1353-1357, aku/Distributions.cc:3114-3170) and
+ * HmmSet::set_clustering_min_evals (aku/HmmSet.cc:1359-1366) -- what
+ * phone_probs -C FILE --eval-minc R --eval-ming R sets up
+ * (aku/phone_probs.cc:112-117) and PPToolbox::set_clustering
+ * (aku/PhoneProbsToolbox.cc:50-53).
+ * Once enabled, scoring follows the cluster branch of
+ * PDFPool::precompute_likelihoods (aku/Distributions.cc:2684-2722): per frame the
+ * cluster centres (unit-weight merges of their members, diagonal) are ranked;
+ * members of the best clusters are evaluated exactly until int(min_clusters *
+ * clusters) clusters and int(min_gaussians * pool size) Gaussians are done;
+ * every other Gaussian takes its centre's likelihood, except where that is 0 in
+ * double precision or the Gaussian is in no cluster (PDFPool::compute_likelihood
+ * re-evaluates cached values <= 0, aku/Distributions.cc:2636-2644).
+ *
+ * aasr_gmm_read_clustering reads a .gcl file ("clusters" then "gaussian
+ * cluster" pairs).  Like the reference's reader it counts the LAST pair of the
+ * file twice (its while(in) loop runs once more on stale operands), which
+ * weights that Gaussian double in its centre and in the Gaussian count.
+ * aasr_gmm_set_clustering takes the pairs literally (n_clusters = 0 removes the
+ * clustering).  Built for diagonal, unadapted pools with at most 4096 clusters;
+ * more than 0.3 * pool size clusters is rejected like the reference does. */
+aasr_status aasr_gmm_read_clustering(aasr_gmm *h, const char *gcl_path);
+aasr_status aasr_gmm_set_clustering(aasr_gmm *h, int32_t n_clusters, int64_t n_pairs,
+                                    const int32_t *gauss_index, const int32_t *cluster_index);
+aasr_status aasr_gmm_set_clustering_min_evals(aasr_gmm *h, double min_clusters,
+                                              double min_gaussians);
+/* PDFPool::number_of_clusters(); 0 without a clustering */
+int32_t aasr_gmm_num_clusters(const aasr_gmm *h);
+
 /* Arithmetic used for the frame x Gaussian quadratic forms.
  *  AASR_PREC_F32          default: f32 matrix-core contraction of the expanded
  *                         form; models whose conditioning would break the 1e-4

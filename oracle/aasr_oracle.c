@@ -156,6 +156,183 @@ void orc_score_frames(int dim, int64_t G, const double *mean,
 }
 
 /* ================================================================== */
+/*  G3b  Gaussian clustering (PDFPool, cluster branch)                  */
+/* ================================================================== */
+
+/* Cluster centres of PDFPool::read_clustering (aku/Distributions.cc:3151-3169):
+ * Gaussian::merge with unit weights (:853-898) into a DiagonalGaussian, which
+ * keeps the diagonal of the merged covariance (:1208-1228) and gets the usual
+ * constant (:1273-1288).  covdiag is the diagonal of every pool Gaussian's
+ * covariance (the variances of a diagonal Gaussian).  members may list a
+ * Gaussian more than once (see orc_read_gcl_pairs in oracle.py).  An empty
+ * cluster ends with zero precision and the "invalid" constant 0, i.e. a centre
+ * likelihood of exp(0) = 1 -- kept. */
+void orc_cluster_centres(int dim, int C, const int32_t *cl_off,
+                         const int32_t *cl_members, const double *mean,
+                         const double *covdiag, double *c_mean, double *c_prec,
+                         double *c_cst)
+{
+    for (int c = 0; c < C; c++) {
+        int n = cl_off[c + 1] - cl_off[c];
+        double weight_sum = 0;
+        for (int i = 0; i < n; i++)
+            weight_sum += 1.0;
+        if (weight_sum < 1e-15)
+            weight_sum = 1;
+        double *m = c_mean + (size_t)c * dim, *p = c_prec + (size_t)c * dim;
+        double scale = 1.0 / weight_sum; /* Blas_Scale(1.0/weight_sum, .) */
+        double cst = 1;
+        for (int d = 0; d < dim; d++) {
+            double nm = 0, nc = 0;
+            for (int i = 0; i < n; i++) {
+                int64_t g = cl_members[cl_off[c] + i];
+                double mu = mean[g * dim + d];
+                double cur = covdiag[g * dim + d] + mu * mu; /* R1 update  */
+                nc += 1.0 * cur;                              /* weight 1.0 */
+                nm += 1.0 * mu;
+            }
+            nm *= scale;
+            nc *= scale;
+            nc += -1.0 * nm * nm; /* Blas_R1_Update(cov, mean, mean, -1.0) */
+            m[d] = nm;
+            p[d] = (nc > 0) ? 1 / nc : 0;
+        }
+        for (int d = 0; d < dim; d++)
+            cst *= p[d];
+        if (cst > 0)
+            cst = log(sqrt(cst));
+        c_cst[c] = cst;
+    }
+}
+
+/* std::priority_queue<pair<int,double>, vector, cl_compare> as libstdc++
+ * implements it (push_heap / pop_heap of bits/stl_heap.h), so that equal
+ * likelihoods pop in the order the reference build pops them.
+ * cl_compare: a.second < b.second (aku/Distributions.hh:291-299). */
+typedef struct { int idx; double lik; } orc_clpair;
+
+static void orc_heap_push(orc_clpair *h, int hole, int top, orc_clpair v)
+{
+    int parent = (hole - 1) / 2;
+    while (hole > top && h[parent].lik < v.lik) {
+        h[hole] = h[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    h[hole] = v;
+}
+
+static void orc_heap_pop(orc_clpair *h, int n) /* n = size before the pop */
+{
+    if (n <= 1)
+        return;
+    int len = n - 1;
+    orc_clpair v = h[len];
+    h[len] = h[0];
+    int hole = 0, child = 0;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (h[child].lik < h[child - 1].lik)
+            child--;
+        h[hole] = h[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        h[hole] = h[child - 1];
+        hole = child - 1;
+    }
+    orc_heap_push(h, hole, 0, v);
+}
+
+/* PDFPool::precompute_likelihoods, clustering branch
+ * (aku/Distributions.cc:2684-2722) followed by the access rule of
+ * PDFPool::compute_likelihood (:2636-2644): a cached value is only used when
+ * it is > 0, so Gaussians outside every cluster (cache -1) and Gaussians whose
+ * value is 0 (an underflowed centre) are evaluated exactly when a mixture
+ * asks for them.
+ * Clusters are popped best centre first; their members are evaluated exactly
+ * until BOTH min_clusters clusters and min_gaussians Gaussians (cluster sizes,
+ * duplicates included) have been done; members of the rest get the centre's
+ * likelihood.  n_exact (optional) returns how many clusters were evaluated. */
+void orc_pool_likelihoods_clustered(int dim, int64_t G, const double *mean,
+                                    const double *prec, const double *cst,
+                                    int C, const int32_t *cl_off,
+                                    const int32_t *cl_members,
+                                    const double *c_mean, const double *c_prec,
+                                    const double *c_cst, int min_clusters,
+                                    int min_gaussians, const double *frame,
+                                    double *gauss_lik, int32_t *n_exact)
+{
+    orc_clpair *heap = (orc_clpair *)malloc(sizeof(orc_clpair) * (size_t)(C > 0 ? C : 1));
+    int n = 0;
+    for (int64_t g = 0; g < G; g++)
+        gauss_lik[g] = -1.0; /* PDFPool::reset_cache (:2617-2622) */
+    for (int c = 0; c < C; c++) {
+        orc_clpair v;
+        v.idx = c;
+        v.lik = exp(orc_diag_loglik(dim, frame, c_mean + (size_t)c * dim,
+                                    c_prec + (size_t)c * dim, c_cst[c]));
+        heap[n] = v;
+        orc_heap_push(heap, n, 0, v);
+        n++;
+    }
+    int clusters_done = 0, gauss_done = 0;
+    while ((clusters_done < min_clusters || gauss_done < min_gaussians) && n > 0) {
+        int c = heap[0].idx;
+        for (int32_t j = cl_off[c]; j < cl_off[c + 1]; j++) {
+            int64_t g = cl_members[j];
+            gauss_lik[g] = exp(orc_diag_loglik(dim, frame, mean + g * dim,
+                                               prec + g * dim, cst[g]));
+        }
+        clusters_done++;
+        gauss_done += cl_off[c + 1] - cl_off[c];
+        orc_heap_pop(heap, n);
+        n--;
+    }
+    if (n_exact)
+        *n_exact = clusters_done;
+    while (n > 0) {
+        int c = heap[0].idx;
+        for (int32_t j = cl_off[c]; j < cl_off[c + 1]; j++)
+            gauss_lik[cl_members[j]] = heap[0].lik;
+        orc_heap_pop(heap, n);
+        n--;
+    }
+    free(heap);
+    for (int64_t g = 0; g < G; g++)
+        if (!(gauss_lik[g] > 0))
+            gauss_lik[g] = exp(orc_diag_loglik(dim, frame, mean + g * dim,
+                                               prec + g * dim, cst[g]));
+}
+
+/* orc_score_frames with the clustered pool evaluation. */
+void orc_score_frames_clustered(int dim, int64_t G, const double *mean,
+                                const double *prec, const double *cst,
+                                int64_t S, const int32_t *mix_off,
+                                const int32_t *mix_idx, const double *mix_w,
+                                int C, const int32_t *cl_off,
+                                const int32_t *cl_members, const double *c_mean,
+                                const double *c_prec, const double *c_cst,
+                                int min_clusters, int min_gaussians, int64_t F,
+                                const double *frames, double *scratch,
+                                double *out_loglik, int32_t *n_exact)
+{
+    double *slik = (double *)malloc(sizeof(double) * (size_t)S);
+    for (int64_t f = 0; f < F; f++) {
+        orc_pool_likelihoods_clustered(dim, G, mean, prec, cst, C, cl_off,
+                                       cl_members, c_mean, c_prec, c_cst,
+                                       min_clusters, min_gaussians,
+                                       frames + f * dim, scratch,
+                                       n_exact ? n_exact + f : NULL);
+        orc_state_likelihoods(S, mix_off, mix_idx, mix_w, scratch, slik);
+        for (int64_t s = 0; s < S; s++)
+            out_loglik[f * S + s] = log(slik[s]);
+    }
+    free(slik);
+}
+
+/* ================================================================== */
 /*  P1  phone_probs frame normalisation + LNA encoding                 */
 /* ================================================================== */
 

@@ -66,6 +66,9 @@ def _declare(L: C.CDLL) -> None:
     L.orc_state_likelihoods.argtypes = [i64, pi32, pi32, pd, pd, pd]
     L.orc_score_frames.argtypes = [i32, i64, pd, pd, pd, i64, pi32, pi32, pd, i64, pd, pd, pd, pd]
     L.orc_lna_frame.argtypes = [pd, i64, i32, i32, pf, pu8]
+    L.orc_cluster_centres.argtypes = [i32, i32, pi32, pi32, pd, pd, pd, pd, pd]
+    L.orc_score_frames_clustered.argtypes = [i32, i64, pd, pd, pd, i64, pi32, pi32, pd, i32, pi32, pi32,
+                                             pd, pd, pd, i32, i32, i64, pd, pd, pd, pi32]
     L.orc_window_advance.restype = f
     L.orc_window_advance.argtypes = [i32, f]
     L.orc_default_window_width.restype = i32
@@ -471,6 +474,47 @@ class DiagModel:
                            _p(lik, pd) if want_lik else None)
         return (out, lik) if want_lik else out
 
+    # -- Gaussian clustering (PDFPool::read_clustering / HmmSet::set_clustering_min_evals)
+    def set_clustering(self, n_clusters: int, pairs, eval_minc: float = 0.0, eval_ming: float = 0.1):
+        """pairs = [(gauss_index, cluster_index), ...] exactly as
+        PDFPool::read_clustering pushes them (aku/Distributions.cc:3136-3148), i.e.
+        read_gcl()'s output with the final pair repeated.  Thresholds follow
+        HmmSet::set_clustering_min_evals (aku/HmmSet.cc:1359-1366):
+        int(ratio * clusters), int(ratio * pool size)."""
+        members = [[] for _ in range(n_clusters)]
+        for g, c in pairs:
+            members[c].append(g)
+        self.cl_off = np.zeros(n_clusters + 1, np.int32)
+        self.cl_off[1:] = np.cumsum([len(m) for m in members])
+        self.cl_members = np.array([g for m in members for g in m], np.int32)
+        self.n_clusters = n_clusters
+        self.c_mean = np.zeros((n_clusters, self.D))
+        self.c_prec = np.zeros((n_clusters, self.D))
+        self.c_cst = np.zeros(n_clusters)
+        pd = C.c_double
+        lib().orc_cluster_centres(self.D, n_clusters, _p(self.cl_off, C.c_int32),
+                                  _p(self.cl_members, C.c_int32), _p(self.mean, pd), _p(self.var, pd),
+                                  _p(self.c_mean, pd), _p(self.c_prec, pd), _p(self.c_cst, pd))
+        self.min_clusters = int(eval_minc * n_clusters)
+        self.min_gaussians = int(eval_ming * self.G)
+
+    def score_clustered(self, frames: np.ndarray, want_counts: bool = False):
+        """[F x S] log state likelihood with the clustered pool evaluation of
+        PDFPool::precompute_likelihoods (aku/Distributions.cc:2684-2722)."""
+        frames = np.ascontiguousarray(frames, np.float64)
+        F = frames.shape[0]
+        out = np.empty((F, self.S))
+        scratch = np.empty(self.G)
+        counts = np.zeros(F, np.int32)
+        pd, pi = C.c_double, C.c_int32
+        lib().orc_score_frames_clustered(
+            self.D, self.G, _p(self.mean, pd), _p(self.prec, pd), _p(self.cst, pd), self.S,
+            _p(self.mix_off, pi), _p(self.mix_idx, pi), _p(self.mix_w, pd), self.n_clusters,
+            _p(self.cl_off, pi), _p(self.cl_members, pi), _p(self.c_mean, pd), _p(self.c_prec, pd),
+            _p(self.c_cst, pd), self.min_clusters, self.min_gaussians, F, _p(frames, pd),
+            _p(scratch, pd), _p(out, pd), _p(counts, pi))
+        return (out, counts) if want_counts else out
+
     def cpu_baseline(self, frames: np.ndarray) -> float:
         frames = np.ascontiguousarray(frames, np.float64)
         pd = C.c_double
@@ -605,6 +649,50 @@ def write_ph(path: str, num_states: int, states_per_hmm: int = 1) -> None:
             for j in range(ns):
                 nxt = 2 + j + 1 if j + 1 < ns else 1
                 f.write("%d 2 %d 0.5 %d 0.5\n" % (2 + j, 2 + j, nxt))
+
+
+def write_gcl(path: str, n_clusters: int, gauss_to_cluster) -> None:
+    """.gcl as gcluster writes it: cluster count, then 'gauss cluster' pairs
+    (aku/Distributions.cc:3121-3147)."""
+    with open(path, "w") as f:
+        f.write("%d\n" % n_clusters)
+        for g, c in enumerate(gauss_to_cluster):
+            if c >= 0:
+                f.write("%d %d\n" % (g, c))
+
+
+def read_gcl(path: str, pool_size: int):
+    """PDFPool::read_clustering's reader (aku/Distributions.cc:3121-3148).
+    Returns (n_clusters, pairs).  The reference loop is
+        while (in) { int g, c; in >> g >> c; ...checks...; push }
+    so the iteration that hits end-of-file still runs its body with the values
+    left from the previous pair (libstdc++ leaves the operands untouched when
+    the stream sentry fails): the LAST pair of every file is pushed twice.
+    That changes the centre of its cluster (the Gaussian is merged with weight
+    2) and the member count used by the min-Gaussians test; kept."""
+    toks = open(path).read().split()
+    if not toks:
+        raise ValueError("empty clustering file")
+    n = int(toks[0])
+    if n > 0.3 * pool_size:
+        raise ValueError("PDFPool::read_clustering(): Number of clusters (%d) seems insensible "
+                         "compared to the number of Gaussians (%d)." % (n, pool_size))
+    pairs = []
+    i = 1
+    while i + 1 < len(toks):
+        try:
+            g, c = int(toks[i]), int(toks[i + 1])
+        except ValueError:
+            break
+        if g >= pool_size:
+            raise ValueError("PDFPool::read_clustering(): Gauss index out of bounds")
+        if c >= n:
+            raise ValueError("PDFPool::read_clustering(): Cluster index out of bounds")
+        pairs.append((g, c))
+        i += 2
+    if pairs:
+        pairs.append(pairs[-1])
+    return n, pairs
 
 
 def read_model(base: str) -> DiagModel:

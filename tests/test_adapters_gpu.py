@@ -71,6 +71,9 @@ def test_phone_probs_cli_batches_and_errors(world):
     assert r.returncode != 0 and "Must give both --batch and --bindex" in r.stderr
     r = subprocess.run([exe, "-b", world["base"], "-c", world["cfg"], "-r", world["recipe"], "-C", "x.gcl"],
                        capture_output=True, text=True)
+    assert r.returncode != 0 and "could not open x.gcl" in r.stderr
+    r = subprocess.run([exe, "-b", world["base"], "-c", world["cfg"], "-r", world["recipe"], "-S", "x.spkc"],
+                       capture_output=True, text=True)
     assert r.returncode != 0 and "not built" in r.stderr
     r = subprocess.run([exe, "-c", world["cfg"], "-r", world["recipe"]], capture_output=True, text=True)
     assert r.returncode != 0 and "Must give either --base" in r.stderr
@@ -95,3 +98,31 @@ def test_reference_style_frame_loop_on_adapters(capi, oracle, world, nbytes):
     smooth = (ll_ref > -87.0) | (ll_ref < -104.5)
     tol = 1.0 / 1820 + 1e-6 if nbytes == 2 else 2e-5
     assert np.abs(a - b)[smooth].max() <= tol
+
+
+def test_clustering_through_cli_and_adapters(capi, oracle, world):
+    """phone_probs -C GCL --eval-ming R (aku/phone_probs.cc:112-117) and the same
+    two HmmSet calls on the adapter class give the engine's clustered scores."""
+    gcl = str(world["dir"] / "model.gcl")
+    oracle.write_gcl(gcl, 16, synth.make_clustering(world["model"][0], 16))
+    gm = capi.Gmm.from_files(world["base"] + ".gk", world["base"] + ".mc", world["base"] + ".ph")
+    gm.read_clustering(gcl)
+    gm.set_clustering_min_evals(0.0, 0.25)
+    want, frames = capi.run_utterance(world["ft"], gm, world["pcms"][0], lnabytes=4)
+    plain, _ = capi.run_utterance(world["ft"], world["gm"], world["pcms"][0], lnabytes=4)
+    assert want != plain                      # the approximation is visible
+    out = world["dir"] / "clicl"
+    os.makedirs(out)
+    r = subprocess.run([os.path.join(BIN, "phone_probs"), "-b", world["base"], "-c", world["cfg"],
+                        "-r", world["recipe"], "-a", "-o", str(out), "--lnabytes=4", "-C", gcl,
+                        "--eval-ming", "0.25"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert open(out / "a0.lna", "rb").read() == want
+    loop = str(world["dir"] / "loopcl.lna")
+    r = subprocess.run([os.path.join(BIN, "aku_adapter_check"), world["cfg"], world["base"],
+                        str(world["dir"] / "a0.wav"), loop, "4", gcl, "0", "0.25"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    a, b = oracle.lna_decode(open(loop, "rb").read()), oracle.lna_decode(want)
+    smooth = (b > -80.0)
+    assert a.shape == b.shape and np.abs(a - b)[smooth].max() <= 2e-5

@@ -1,0 +1,142 @@
+"""Gaussian clustering: the product's clustered scoring vs
+the oracle's restatement of PDFPool::precompute_likelihoods' cluster branch
+(aku/Distributions.cc:2684-2722) on the same frames.  Tolerance 1e-4 on the
+state log-likelihoods (BASELINE north_star); the per-frame number of clusters
+evaluated exactly is an integer and must match."""
+import os
+
+import numpy as np
+import pytest
+
+from aaltoasr_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _pairs(g2c):
+    return [(int(g), int(c)) for g, c in enumerate(g2c) if c >= 0]
+
+
+def _check(capi, oracle, model, g2c, C, minc, ming, frames, pairs=None, tol=TOL, counts=True):
+    mean, var, off, idx, w = model
+    pairs = _pairs(g2c) if pairs is None else pairs
+    om = oracle.DiagModel(mean, var, off, idx, w)
+    om.set_clustering(C, pairs, minc, ming)
+    want, want_n = om.score_clustered(frames.astype(np.float64), want_counts=True)
+    gm = capi.Gmm.from_arrays(mean, var, off, idx, w)
+    gm.set_clustering(C, pairs)
+    gm.set_clustering_min_evals(minc, ming)
+    # every kernel that carries the selection masks: grouped / independent track
+    # layouts, f32 and bf16x3 contraction
+    for layouts in (7, 2):
+        gm.set_layouts(layouts)
+        for prec in (0, 3):
+            gm.set_precision(prec)
+            got = gm.score(frames)
+            got_n = gm.cluster_exact_counts(len(frames))
+            if counts:
+                assert np.array_equal(got_n, want_n), (got_n[:10], want_n[:10])
+            err = np.abs(got - want).max()
+            assert err <= tol, (layouts, prec, err)
+    gm.set_layouts(7)
+    gm.set_precision(0)
+    got = gm.score(frames)
+    return gm, om, got, want
+
+
+@pytest.mark.parametrize("minc,ming", [(0.0, 0.1), (0.0, 0.25), (0.3, 0.0), (0.2, 0.5), (0.0, 0.0),
+                                       (1.0, 1.0)])
+def test_clustered_scores_match_oracle(capi, oracle, minc, ming):
+    model = synth.make_model(D=39, G=2048, S=128, comps=16)
+    g2c = synth.make_clustering(model[0], 64)
+    frames = synth.make_frames(500)
+    gm, om, got, want = _check(capi, oracle, model, g2c, 64, minc, ming, frames)
+    if minc == 1.0:
+        # every cluster evaluated exactly == no clustering at all
+        assert np.abs(got - om.score(frames.astype(np.float64))).max() <= TOL
+    if minc == 0.0 and ming == 0.0:
+        # nothing exact: the approximation must actually differ from exact scoring
+        assert np.abs(want - om.score(frames.astype(np.float64))).max() > 0.1
+
+
+def test_tied_pool_ragged_states_unclustered_gaussians(capi, oracle):
+    model = synth.make_model(D=24, G=700, S=90, tied=True, comps_range=(1, 23))
+    g2c = synth.make_clustering(model[0], 40)
+    g2c[::17] = -1                      # Gaussians in no cluster: always exact
+    _check(capi, oracle, model, g2c, 40, 0.1, 0.2, synth.make_frames(300, D=24))
+
+
+def test_far_frames_underflowed_centres_fall_back_to_exact(capi, oracle):
+    """Centre likelihood 0.0 in double -> PDFPool::compute_likelihood re-evaluates
+    (aku/Distributions.cc:2636-2644)."""
+    model = synth.make_model(D=39, G=1024, S=64, comps=16)
+    g2c = synth.make_clustering(model[0], 32)
+    frames = synth.make_frames(256)
+    frames[::3] *= 9.0                  # centre ll below -745 for most clusters
+    frames[1::3] *= 4.0
+    # Underflowed centres tie at likelihood 0.0; the reference pops ties in heap
+    # order, this engine by log-likelihood, so the NUMBER of clusters popped can
+    # differ -- the scores cannot, because a zero centre is re-evaluated exactly.
+    gm, om, got, want = _check(capi, oracle, model, g2c, 32, 0.0, 0.1, frames, counts=False)
+    zero_centres = np.exp(-0.5 * ((frames[:, None, :].astype(np.float64) - om.c_mean[None]) ** 2
+                                  * om.c_prec[None]).sum(-1) + om.c_cst[None]) == 0.0
+    assert zero_centres[::3].mean() > 0.5 and not zero_centres[2::3].any()
+    near = np.flatnonzero(~zero_centres.any(1))
+    assert np.array_equal(gm.cluster_exact_counts(len(frames))[near],
+                          om.score_clustered(frames.astype(np.float64), True)[1][near])
+
+
+def test_gcl_file_counts_last_pair_twice(capi, oracle, tmp_path):
+    model = synth.make_model(D=20, G=600, S=60, comps=10)
+    mean, var, off, idx, w = model
+    g2c = synth.make_clustering(mean, 30)
+    path = str(tmp_path / "m.gcl")
+    oracle.write_gcl(path, 30, g2c)
+    n, pairs = oracle.read_gcl(path, 600)
+    assert n == 30 and len(pairs) == 601 and pairs[-1] == pairs[-2]
+    frames = synth.make_frames(200, D=20)
+    om = oracle.DiagModel(mean, var, off, idx, w)
+    om.set_clustering(n, pairs, 0.0, 0.15)
+    want, want_n = om.score_clustered(frames.astype(np.float64), want_counts=True)
+    gm = capi.Gmm.from_arrays(mean, var, off, idx, w)
+    gm.read_clustering(path)
+    assert gm.num_clusters == 30
+    gm.set_clustering_min_evals(0.0, 0.15)
+    got = gm.score(frames)
+    assert np.array_equal(gm.cluster_exact_counts(200), want_n)
+    assert np.abs(got - want).max() <= TOL
+    # without the repeated pair exactly one centre (the last Gaussian's) is different
+    dup = om.c_mean.copy()
+    om.set_clustering(n, pairs[:-1], 0.0, 0.15)
+    changed = np.flatnonzero((dup != om.c_mean).any(1))
+    assert list(changed) == [pairs[-1][1]]
+
+
+def test_many_clusters_multi_pass(capi, oracle):
+    """> 1024 clusters (32 keys per lane in k_cluster_select)."""
+    model = synth.make_model(D=13, G=6000, S=300, comps=20)
+    g2c = synth.make_clustering(model[0], 1500, iters=2)
+    _check(capi, oracle, model, g2c, 1500, 0.05, 0.2, synth.make_frames(130, D=13))
+
+
+def test_clustering_errors(capi, tmp_path):
+    mean, var, off, idx, w = synth.make_model(D=8, G=100, S=10, comps=10)
+    gm = capi.Gmm.from_arrays(mean, var, off, idx, w)
+    with pytest.raises(capi.AasrError, match="insensible"):
+        gm.set_clustering(31, [(0, 0)])
+    with pytest.raises(capi.AasrError, match="Gauss index out of bounds"):
+        gm.set_clustering(10, [(100, 0)])
+    with pytest.raises(capi.AasrError, match="Cluster index out of bounds"):
+        gm.set_clustering(10, [(1, 10)])
+    with pytest.raises(capi.AasrError, match="no clustering"):
+        gm.set_clustering_min_evals(0.0, 0.1)
+    with pytest.raises(capi.AasrError, match="could not open"):
+        gm.read_clustering(str(tmp_path / "missing.gcl"))
+    gm.set_clustering(10, [(g, g % 10) for g in range(100)])
+    gm.set_clustering_min_evals(0.0, 0.1)
+    assert gm.num_clusters == 10
+    gm.set_clustering(0)
+    assert gm.num_clusters == 0
+    frames = synth.make_frames(10, D=8)
+    assert np.isfinite(gm.score(frames)).all()

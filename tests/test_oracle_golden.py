@@ -229,3 +229,47 @@ def test_config_errors(oracle):
     ch = oracle.FeatureChain("module\n{\n name a\n type audiofile\n sample_rate 16000\n}\n")
     with pytest.raises(ValueError, match="audio shorter than frame"):
         ch.generate(np.zeros(100, np.int16), 0, 1)
+
+
+def test_clustering_oracle_properties(oracle, tmp_path):
+    """The restatement of PDFPool's cluster branch (no reference goldens exist for
+    it): evaluating every cluster == plain scoring; evaluating none == every
+    Gaussian replaced by its centre; the .gcl reader repeats the last pair; the
+    heap pops best-first."""
+    from aaltoasr_amd import synth
+    mean, var, off, idx, w = synth.make_model(D=12, G=300, S=30, comps=10)
+    g2c = synth.make_clustering(mean, 20)
+    om = oracle.DiagModel(mean, var, off, idx, w)
+    frames = synth.make_frames(40, D=12).astype(np.float64)
+    exact = om.score(frames)
+    pairs = [(g, int(c)) for g, c in enumerate(g2c)]
+    om.set_clustering(20, pairs, 1.0, 1.0)
+    assert om.min_clusters == 20 and om.min_gaussians == 300
+    s_all, n_all = om.score_clustered(frames, want_counts=True)
+    assert np.array_equal(s_all, exact) and (n_all == 20).all()
+    om.set_clustering(20, pairs, 0.0, 0.0)
+    s_none, n_none = om.score_clustered(frames, want_counts=True)
+    assert (n_none == 0).all()
+    # every Gaussian stands for its centre: rebuild that model by hand
+    c_var = np.where(om.c_prec > 0, 1.0 / np.where(om.c_prec > 0, om.c_prec, 1.0), 0.0)
+    sub = oracle.DiagModel(om.c_mean[g2c], c_var[g2c], off, idx, w)
+    assert np.abs(sub.score(frames) - s_none).max() < 1e-9
+    # monotone in the thresholds: more exact clusters never fewer
+    om.set_clustering(20, pairs, 0.0, 0.2)
+    n20 = om.score_clustered(frames, want_counts=True)[1]
+    om.set_clustering(20, pairs, 0.0, 0.5)
+    n50 = om.score_clustered(frames, want_counts=True)[1]
+    assert (n50 >= n20).all() and (n20 >= 1).all()
+    # centre = unit-weight moment match of its members
+    c = 3
+    mem = np.flatnonzero(g2c == c)
+    assert np.allclose(om.c_mean[c], mean[mem].mean(0), rtol=1e-13)
+    want_var = (var[mem] + mean[mem] ** 2).mean(0) - mean[mem].mean(0) ** 2
+    assert np.allclose(1.0 / om.c_prec[c], want_var, rtol=1e-11)
+    # reader: last pair twice, "insensible" cluster counts refused like the reference
+    path = str(tmp_path / "x.gcl")
+    oracle.write_gcl(path, 20, g2c)
+    n, rp = oracle.read_gcl(path, 300)
+    assert n == 20 and rp[:-1] == pairs and rp[-1] == pairs[-1]
+    with pytest.raises(ValueError, match="insensible"):
+        oracle.read_gcl(path, 60)
