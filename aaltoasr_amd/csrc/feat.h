@@ -18,7 +18,8 @@ namespace aasr {
 
 enum ModType {
   MOD_AUDIOFILE, MOD_FFT, MOD_MEL, MOD_POWER, MOD_DCT, MOD_DELTA,
-  MOD_NORMALIZATION, MOD_LIN_TRANSFORM, MOD_MERGE, MOD_MEAN_SUBTRACTOR
+  MOD_NORMALIZATION, MOD_LIN_TRANSFORM, MOD_MERGE, MOD_MEAN_SUBTRACTOR,
+  MOD_CONCAT, MOD_VTLN, MOD_SR_NORM, MOD_MEL_POWER, MOD_QUANTEQ
 };
 
 // One "{ key value ... }" block (aku::ModuleConfig, aku/ModuleConfig.cc).
@@ -79,6 +80,23 @@ struct FeatModule {
   DevBuf<int32_t> merge_src_col;  // per output column: source slot, column
   // mean_subtractor (config values; the reference stores left+1 / right+1)
   int cms_left = 75, cms_right = 75;
+  // vtln (VtlnModule, aku/FeatureModules.cc:1529-1937)
+  int use_pwlin = 0, use_slapt = 0, sinc_rad = 8, all_pass = 0;
+  bool lanczos = true;
+  float pwlin_turn = 0.8f, warp_factor = 1.0f;
+  std::vector<float> slapt_params, vtln_bins;
+  DevBuf<float> d_vtln_bins;
+  // sr_norm (SRNormModule, :1953-2058)
+  int in_frames = 0, out_frames = 0, lanczos_order = 4, frame_dim = 1;
+  float speech_rate = 1.0f;
+  // windowed interpolation shared by vtln and sr_norm: output group i reads
+  // sp_len[i] source groups from sp_start[i] with weights sp_coef[i][.]
+  DevBuf<int32_t> sp_start, sp_len;
+  DevBuf<float> sp_coef;
+  int sp_stride = 0;
+  // quanteq (QuantEqModule, :2078-2141)
+  std::vector<float> q_alpha, q_gamma, q_max;
+  DevBuf<float> d_q_alpha, d_q_gamma, d_q_max;
   // look-around this module itself adds around its sources
   int own_left = 0, own_right = 0;
 };

@@ -202,6 +202,161 @@ static void build_fft_plan(FftPlan &p, int window) {
   p.perm.upload(perm.data(), perm.size());
 }
 
+// ---------------------------------------------------- vtln / sr_norm tables --
+
+// util::sinc (aku/util.hh:151-159): float argument, double sine, float result
+static float aku_sinc(float x) {
+  const double PI = 3.14159265358979323846;
+  if (fabs(x) < 1e-8) return 1;
+  double y = PI * x;
+  return sin(y) / y;
+}
+
+// VtlnModule::set_warp_factor / set_slapt_warp (aku/FeatureModules.cc:1600-1623):
+// warped bin positions, then the interpolation weights of every output bin.
+static void build_vtln_tables(FeatModule &m) {
+  const int dim = m.dim;
+  std::vector<float> &bins = m.vtln_bins;
+  bins.assign((size_t)dim, 0.0f);
+  int t;
+  if (m.use_slapt) {
+    // create_slapt_bins (:1669-1686)
+    for (t = 0; t < dim - 1; t++) {
+      double nf = M_PI * (double)t / (dim - 1);
+      bins[t] = t;
+      for (int i = 0; i < (int)m.slapt_params.size(); i++)
+        bins[t] += m.slapt_params[i] * sin((i + 1) * nf) * (dim - 1);
+    }
+    bins[t] = dim - 1;
+  } else if (m.use_pwlin) {
+    // create_pwlin_bins (:1625-1651), float arithmetic throughout
+    float border, slope = 0, point = 0;
+    bool limit = false;
+    border = m.pwlin_turn * (float)(dim - 1);
+    for (t = 0; t < dim - 1; t++) {
+      if (!limit) bins[t] = m.warp_factor * (float)t;
+      else bins[t] = slope * (float)t + point;
+      if (!limit && (t >= border || bins[t] >= border)) {
+        slope = ((float)dim - 1 - bins[t]) / ((float)dim - 1 - t);
+        point = (1 - slope) * (float)(dim - 1);
+        limit = true;
+      }
+    }
+    bins[t] = (float)(dim - 1);
+  } else {
+    // create_blin_bins (:1653-1667)
+    for (t = 0; t < dim - 1; t++) {
+      double nf = M_PI * (double)t / (dim - 1);
+      bins[t] = t + 2 * atan2((m.warp_factor - 1) * sin(nf), 1 + (1 - m.warp_factor) * cos(nf)) / M_PI * (dim - 1);
+    }
+    bins[t] = dim - 1;
+  }
+  m.d_vtln_bins.upload(bins.data(), bins.size());
+  std::vector<int32_t> start((size_t)dim, 0), len((size_t)dim, 0);
+  std::vector<float> coef;
+  if (m.all_pass) {
+    if (m.use_slapt)
+      raise(AASR_ERR_UNSUPPORTED, "VtlnModule: all-pass with slapt is not built in this engine yet");
+    // create_all_pass_blin_transform + set_all_pass_transform (:1716-1756, 1870-1905):
+    // final = IDCT * (bilinear series * DCT); the reference multiplies with BLAS dgemm
+    // (summation order unpinned), plain k-ascending loops here.
+    const size_t n = (size_t)dim;
+    std::vector<double> q1(n, 0.0), q(n, 0.0), qn(n, 0.0), tr(n * n, 0.0), dct(n * n), tmp(n * n);
+    double alpha = m.warp_factor - 1;
+    double temp;
+    q1[0] = -alpha;
+    temp = 1 - alpha * alpha;
+    for (int i = 1; i < dim; i++) {
+      q1[i] = temp;
+      temp *= alpha;
+    }
+    q[0] = 1;
+    tr[0] = 1;
+    for (int i = 1; i < dim; i++) {
+      for (int j = 0; j < dim; j++) {
+        temp = 0;
+        for (int k = 0; k <= j; k++) temp += q[k] * q1[j - k];
+        qn[j] = temp;
+      }
+      q = qn;
+      tr[i] = 2 * q[0];
+      for (int j = 1; j < dim; j++) tr[j * n + i] = q[j];
+    }
+    for (int i = 0; i < dim; i++)
+      for (int j = 0; j < dim; j++) dct[i * n + j] = cos(i * (j + 0.5) * M_PI / dim);
+    for (int i = 0; i < dim; i++)
+      for (int j = 0; j < dim; j++) {
+        double a = 0;
+        for (int k = 0; k < dim; k++) a += tr[i * n + k] * dct[k * n + j];
+        tmp[i * n + j] = a;
+      }
+    for (int i = 0; i < dim; i++) {
+      dct[i * n] = 1.0 / dim;
+      for (int j = 1; j < dim; j++) dct[i * n + j] = cos((i + 0.5) * j * M_PI / dim) * 2 / dim;
+    }
+    coef.assign(n * n, 0.0f);
+    for (int i = 0; i < dim; i++)
+      for (int j = 0; j < dim; j++) {
+        double a = 0;
+        for (int k = 0; k < dim; k++) a += dct[i * n + k] * tmp[k * n + j];
+        coef[i * n + j] = a;
+      }
+    std::fill(len.begin(), len.end(), dim);
+    m.sp_stride = dim;
+  } else if (m.sinc_rad > 0) {
+    // create_sinc_coef_table (:1688-1714)
+    const int rad = m.sinc_rad;
+    m.sp_stride = 2 * rad + 1;
+    coef.assign((size_t)dim * m.sp_stride, 0.0f);
+    for (int b = 0; b < dim; b++) {
+      int cent = (int)(bins[b] + 0.5);
+      int min_i = std::max(cent - rad, 0);
+      int max_i = std::min(cent + rad + 1, dim);
+      start[b] = min_i;
+      len[b] = std::max(0, max_i - min_i);
+      for (int i = min_i; i < max_i; i++) {
+        float w = aku_sinc(i - bins[b]);
+        if (m.lanczos) {
+          if (fabs(i - bins[b]) < rad) w *= aku_sinc((i - bins[b]) / (float)rad);
+          else w = 0;
+        }
+        coef[(size_t)b * m.sp_stride + (i - min_i)] = w;
+      }
+    }
+  } else {
+    m.sp_stride = 0;  // linear interpolation on the bins themselves
+  }
+  m.sp_start.upload(start.data(), start.size());
+  m.sp_len.upload(len.data(), len.size());
+  m.sp_coef.upload(coef.data(), coef.size());
+}
+
+// SRNormModule::set_speech_rate (aku/FeatureModules.cc:2003-2034)
+static void build_srnorm_table(FeatModule &m) {
+  float in_cent = (float)(m.in_frames - 1) / 2;
+  float out_cent = (float)(m.out_frames - 1) / 2;
+  m.sp_stride = 2 * m.lanczos_order + 1;
+  std::vector<int32_t> start((size_t)m.out_frames, 0), len((size_t)m.out_frames, 0);
+  std::vector<float> coef((size_t)m.out_frames * m.sp_stride, 0.0f);
+  for (int i = 0; i < m.out_frames; i++) {
+    float target_pos = (i - out_cent) / m.speech_rate + in_cent;
+    int cent = (int)roundf(target_pos);
+    int a = std::max(cent - m.lanczos_order, 0);
+    int b = std::min(cent + m.lanczos_order + 1, m.in_frames);
+    start[i] = a;
+    len[i] = std::max(0, b - a);
+    for (int j = a; j < b; j++) {
+      float w = aku_sinc(j - target_pos);
+      if (fabs(j - target_pos) < m.lanczos_order) w *= aku_sinc((j - target_pos) / (float)m.lanczos_order);
+      else w = 0;
+      coef[(size_t)i * m.sp_stride + (j - a)] = w;
+    }
+  }
+  m.sp_start.upload(start.data(), start.size());
+  m.sp_len.upload(len.data(), len.size());
+  m.sp_coef.upload(coef.data(), coef.size());
+}
+
 // ------------------------------------------------------- module configure --
 
 static void configure(aasr_feat *h, FeatModule &m, const ModuleConfig &c) {
@@ -389,6 +544,73 @@ static void configure(aasr_feat *h, FeatModule &m, const ModuleConfig &c) {
       m.own_right = m.cms_right;
       break;
     }
+    case MOD_CONCAT: {
+      // ConcatModule::set_module_config (aku/FeatureModules.cc:1472-1486)
+      m.own_left = m.own_right = 0;
+      c.get("left", m.own_left);
+      c.get("right", m.own_right);
+      if (m.own_left < 0 || m.own_right < 0)
+        raise(AASR_ERR_INVALID, "ConcatModule: context spans must be >= 0");
+      m.src_dim = src(0).dim;
+      m.dim = m.src_dim * (1 + m.own_left + m.own_right);
+      break;
+    }
+    case MOD_MEL_POWER:
+      m.dim = 1;  // MelPowerModule::set_module_config (aku/FeatureModules.cc:904-910)
+      break;
+    case MOD_VTLN: {
+      // VtlnModule::set_module_config (aku/FeatureModules.cc:1529-1573)
+      m.dim = src(0).dim;
+      m.use_pwlin = 0;
+      m.pwlin_turn = 0.8;
+      c.get("pwlin_vtln", m.use_pwlin);
+      c.get("pwlin_turnpoint", m.pwlin_turn);
+      m.use_slapt = 0;
+      c.get("slapt", m.use_slapt);
+      if (m.use_pwlin && m.use_slapt)
+        raise(AASR_ERR_INVALID, "VtlnModule: Can not use both pwlin_vtln and slapt!");
+      m.sinc_rad = 8;
+      c.get("sinc_interpolation_rad", m.sinc_rad);
+      m.all_pass = 0;
+      c.get("all-pass", m.all_pass);
+      if (m.use_pwlin && m.all_pass)
+        raise(AASR_ERR_INVALID, "VtlnModule: Can not use both pwlin_vtln and all-pass!");
+      int lanczos = m.all_pass ? 0 : 1;
+      c.get("lanczos_window", lanczos);
+      m.lanczos = lanczos > 0;
+      if (m.lanczos && m.all_pass)
+        raise(AASR_ERR_INVALID, "VtlnModule: Can not use both lanczos_window and all-pass!");
+      m.warp_factor = 1.0;
+      m.slapt_params.assign(1, 0.0f);
+      build_vtln_tables(m);
+      break;
+    }
+    case MOD_SR_NORM: {
+      // SRNormModule::set_module_config (aku/FeatureModules.cc:1953-1987)
+      m.in_frames = m.out_frames = 0;
+      c.get("in_frames", m.in_frames);
+      c.get("out_frames", m.out_frames);
+      if (m.in_frames == 0 || m.out_frames == 0)
+        raise(AASR_ERR_INVALID, "SRNormModule: Must set both in_frames and out_frames.");
+      if (m.in_frames < 0 || m.out_frames < 0)
+        raise(AASR_ERR_INVALID, "SRNormModule: frame counts must be positive");
+      m.frame_dim = src(0).dim / m.in_frames;
+      if (src(0).dim % m.in_frames != 0)
+        raise(AASR_ERR_INVALID, "SRNormModule: in_frames does not match with the input dimension");
+      m.dim = m.out_frames * m.frame_dim;
+      m.lanczos_order = 4;
+      c.get("lanczos_order", m.lanczos_order);
+      if (m.lanczos_order < 1) raise(AASR_ERR_INVALID, "SRNormModule: lanczos_order must be positive.");
+      m.speech_rate = 1.0;
+      c.get("speech_rate", m.speech_rate);
+      build_srnorm_table(m);
+      break;
+    }
+    case MOD_QUANTEQ:
+      // QuantEqModule::set_module_config (aku/FeatureModules.cc:2078-2083); the
+      // channel parameters only arrive through set_parameters
+      m.dim = src(0).dim;
+      break;
   }
   if (m.dim <= 0) raise(AASR_ERR_INVALID, "module %s has no output dimension", m.name.c_str());
 }
@@ -431,7 +653,9 @@ aasr_feat *feat_create(const std::string &text) {
           {"audiofile", MOD_AUDIOFILE}, {"fft", MOD_FFT}, {"mel", MOD_MEL},
           {"power", MOD_POWER}, {"dct", MOD_DCT}, {"delta", MOD_DELTA},
           {"normalization", MOD_NORMALIZATION}, {"lin_transform", MOD_LIN_TRANSFORM},
-          {"merge", MOD_MERGE}, {"mean_subtractor", MOD_MEAN_SUBTRACTOR}};
+          {"merge", MOD_MERGE}, {"mean_subtractor", MOD_MEAN_SUBTRACTOR},
+          {"concat", MOD_CONCAT}, {"vtln", MOD_VTLN}, {"sr_norm", MOD_SR_NORM},
+          {"mel_power", MOD_MEL_POWER}, {"quanteq", MOD_QUANTEQ}};
       bool found = false;
       for (auto &k : kinds)
         if (type == k.s) {
@@ -439,7 +663,7 @@ aasr_feat *feat_create(const std::string &text) {
           found = true;
         }
       if (!found) {
-        static const char *later[] = {"pre", "mel_power", "concat", "vtln", "sr_norm", "quanteq"};
+        static const char *later[] = {"pre"};
         for (auto *l : later)
           if (type == l)
             raise(AASR_ERR_UNSUPPORTED,
@@ -543,6 +767,32 @@ void feat_set_parameters(aasr_feat *h, const std::string &module, const std::str
       raise(AASR_ERR_INVALID, "LinTransformModule: Invalid bias dimension");
     m.d_matrix.upload(m.matrix.data(), m.matrix.size());
     m.d_bias.upload(m.bias.data(), m.bias.size());
+  } else if (m.type == MOD_VTLN) {
+    // VtlnModule::set_parameters (aku/FeatureModules.cc:1575-1592)
+    if (m.use_slapt) {
+      m.slapt_params.assign(1, 0.0f);
+      c.get("slapt_coef", m.slapt_params);
+    } else {
+      m.warp_factor = 1.0;
+      c.get("warp_factor", m.warp_factor);
+    }
+    build_vtln_tables(m);
+  } else if (m.type == MOD_SR_NORM) {
+    // SRNormModule::set_parameters (aku/FeatureModules.cc:1990-1996)
+    m.speech_rate = 1.0;
+    c.get("speech_rate", m.speech_rate);
+    build_srnorm_table(m);
+  } else if (m.type == MOD_QUANTEQ) {
+    // QuantEqModule::set_parameters (aku/FeatureModules.cc:2085-2094)
+    if (!c.get("alpha", m.q_alpha)) m.q_alpha.clear();
+    if (!c.get("gamma", m.q_gamma)) m.q_gamma.clear();
+    if (!c.get("quant_max", m.q_max)) m.q_max.clear();
+    const bool any = !m.q_alpha.empty() && !m.q_gamma.empty() && !m.q_max.empty();
+    if (any && ((int)m.q_alpha.size() < m.dim || (int)m.q_gamma.size() < m.dim || (int)m.q_max.size() < m.dim))
+      raise(AASR_ERR_INVALID, "QuantEqModule: alpha, gamma and quant_max need %d values each", m.dim);
+    m.d_q_alpha.upload(m.q_alpha.data(), m.q_alpha.size());
+    m.d_q_gamma.upload(m.q_gamma.data(), m.q_gamma.size());
+    m.d_q_max.upload(m.q_max.data(), m.q_max.size());
   } else {
     // FeatureModule::set_parameters default is a no-op (aku/FeatureModule.hh:107)
   }

@@ -513,6 +513,89 @@ __global__ void k_mean_subtract(DevBatch b, const double *__restrict__ src, SrcM
   dst[idx] = src[sr * dim + d] - mean;
 }
 
+// ConcatModule::generate (aku/FeatureModules.cc:1488-1501): frames t-left..t+right
+// of the source side by side
+__global__ void k_concat(DevBatch b, const double *__restrict__ src, SrcMap sm, int span,
+                         int64_t rows, int src_dim, int dim, int left, double *__restrict__ dst) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * dim) return;
+  int64_t r = idx / dim;
+  int i = (int)(idx - r * dim);
+  int k = i / src_dim, j = i - k * src_dim;
+  dst[idx] = src[(src_row(b, r, span, sm) + (k - left)) * src_dim + j];
+}
+
+// MelPowerModule::generate (aku/FeatureModules.cc:912-923): float running sum of
+// double exponentials, natural log
+__global__ void k_mel_power(DevBatch b, const double *__restrict__ src, SrcMap sm, int span,
+                            int64_t rows, int src_dim, double *__restrict__ dst) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const double *data = src + src_row(b, r, span, sm) * src_dim;
+  float power = 0;
+  for (int i = 0; i < src_dim; i++) power = (float)((double)power + exp(data[i]));
+  dst[r] = log((double)power + 1e-10);
+}
+
+// Windowed interpolation of VtlnModule::generate (sinc / all-pass weights,
+// aku/FeatureModules.cc:1913-1925) and SRNormModule::generate (:2045-2057):
+// output element (i, d) = max((float) sum_j w[i][j] * src[(start[i]+j)*fd + d], 0).
+__global__ void k_window_interp(DevBatch b, const double *__restrict__ src, SrcMap sm, int span,
+                                int64_t rows, int src_dim, int dim, int frame_dim,
+                                const int32_t *__restrict__ start, const int32_t *__restrict__ len,
+                                const float *__restrict__ coef, int stride,
+                                double *__restrict__ dst) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * dim) return;
+  int64_t r = idx / dim;
+  int e = (int)(idx - r * dim);
+  int i = e / frame_dim, d = e - i * frame_dim;
+  const double *data = src + src_row(b, r, span, sm) * src_dim;
+  const float *w = coef + (size_t)i * stride;
+  double t = 0;
+  for (int j = 0, fi = start[i]; j < len[i]; j++, fi++) t += data[fi * frame_dim + d] * (double)w[j];
+  const float v = (float)t;
+  dst[idx] = (v < 0.0f) ? 0.0f : v;  // std::max((float)t, 0.0f)
+}
+
+// VtlnModule::generate without sinc interpolation (:1927-1935)
+__global__ void k_vtln_linear(DevBatch b, const double *__restrict__ src, SrcMap sm, int span,
+                              int64_t rows, int dim, const float *__restrict__ bins,
+                              double *__restrict__ dst) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * dim) return;
+  int64_t r = idx / dim;
+  int bi = (int)(idx - r * dim);
+  const double *data = src + src_row(b, r, span, sm) * dim;
+  const float pos = bins[bi];
+  const float p = ceilf(pos) - pos;
+  const float q = 1 - p;
+  const double lo = (double)p * data[(int)floorf(pos)];
+  const double hi = (double)q * data[(int)ceilf(pos)];
+  dst[idx] = lo + hi;
+}
+
+// QuantEqModule::generate (aku/FeatureModules.cc:2122-2141); the exponent is
+// gamma + (1-alpha)*(x/qmax), the reference's parenthesisation
+__global__ void k_quanteq(DevBatch b, const double *__restrict__ src, SrcMap sm, int span,
+                          int64_t rows, int dim, const float *__restrict__ alpha,
+                          const float *__restrict__ gamma, const float *__restrict__ qmax,
+                          double *__restrict__ dst) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * dim) return;
+  int64_t r = idx / dim;
+  int k = (int)(idx - r * dim);
+  const double x = src[src_row(b, r, span, sm) * dim + k];
+  if (!alpha) {
+    dst[idx] = x;
+    return;
+  }
+  const double ratio = x / (double)qmax[k];
+  const float one_minus = 1 - alpha[k];
+  const double ex = (double)gamma[k] + (double)one_minus * ratio;
+  dst[idx] = (double)qmax[k] * ((double)alpha[k] * pow(ratio, ex));
+}
+
 template <class T>
 __global__ void k_emit(const double *__restrict__ src, int64_t n, T *__restrict__ dst) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -702,6 +785,35 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
         }
         hipLaunchKernelGGL(k_merge, dim3(grid_for(nelem)), dim3(256), 0, stream, db, ms, span, rows,
                            m.dim, m.merge_src_col.p, dst);
+        break;
+      }
+      case MOD_CONCAT:
+        hipLaunchKernelGGL(k_concat, dim3(grid_for(nelem)), dim3(256), 0, stream, db, src, sm, span,
+                           rows, m.src_dim, m.dim, m.own_left, dst);
+        break;
+      case MOD_MEL_POWER:
+        hipLaunchKernelGGL(k_mel_power, dim3(grid_for(rows)), dim3(256), 0, stream, db, src, sm,
+                           span, rows, h->mods[s0].dim, dst);
+        break;
+      case MOD_VTLN:
+        if (m.sp_stride > 0)
+          hipLaunchKernelGGL(k_window_interp, dim3(grid_for(nelem)), dim3(256), 0, stream, db, src,
+                             sm, span, rows, m.dim, m.dim, 1, m.sp_start.p, m.sp_len.p, m.sp_coef.p,
+                             m.sp_stride, dst);
+        else
+          hipLaunchKernelGGL(k_vtln_linear, dim3(grid_for(nelem)), dim3(256), 0, stream, db, src, sm,
+                             span, rows, m.dim, m.d_vtln_bins.p, dst);
+        break;
+      case MOD_SR_NORM:
+        hipLaunchKernelGGL(k_window_interp, dim3(grid_for(nelem)), dim3(256), 0, stream, db, src, sm,
+                           span, rows, h->mods[s0].dim, m.dim, m.frame_dim, m.sp_start.p, m.sp_len.p,
+                           m.sp_coef.p, m.sp_stride, dst);
+        break;
+      case MOD_QUANTEQ: {
+        const bool full = !m.q_alpha.empty() && !m.q_gamma.empty() && !m.q_max.empty();
+        hipLaunchKernelGGL(k_quanteq, dim3(grid_for(nelem)), dim3(256), 0, stream, db, src, sm, span,
+                           rows, m.dim, full ? m.d_q_alpha.p : (const float *)nullptr, m.d_q_gamma.p,
+                           m.d_q_max.p, dst);
         break;
       }
       case MOD_MEAN_SUBTRACTOR: {

@@ -905,6 +905,255 @@ void orc_mean_subtract_module(const double *in, int n, int dim, int left,
 }
 
 /* ================================================================== */
+/*  Speaker-adaptation side modules: vtln, sr_norm, mel_power, quanteq   */
+/* ================================================================== */
+
+/* util::sinc (aku/util.hh:151-159): float argument, double sine, float result */
+static float orc_sinc(float x)
+{
+    const double PI = 3.14159265358979323846;
+    if (fabs(x) < 1e-8)
+        return 1;
+    double y = PI * x;
+    return sin(y) / y;
+}
+
+/* VtlnModule::create_{pwlin,blin,slapt}_bins (aku/FeatureModules.cc:1625-1686):
+ * the warped position of every spectral bin, float. */
+void orc_vtln_bins(int dim, int use_pwlin, float pwlin_turn, int use_slapt,
+                   float warp, const float *slapt, int n_slapt, float *bins)
+{
+    int t;
+    if (use_slapt) {
+        for (t = 0; t < dim - 1; t++) {
+            double nf = M_PI * (double)t / (dim - 1);
+            bins[t] = t;
+            for (int i = 0; i < n_slapt; i++)
+                bins[t] += slapt[i] * sin((i + 1) * nf) * (dim - 1);
+        }
+        bins[t] = dim - 1;
+    } else if (use_pwlin) {
+        float border, slope = 0, point = 0;
+        int limit = 0;
+        border = pwlin_turn * (float)(dim - 1);
+        for (t = 0; t < dim - 1; t++) {
+            if (!limit)
+                bins[t] = warp * (float)t;
+            else
+                bins[t] = slope * (float)t + point;
+            if (!limit && (t >= border || bins[t] >= border)) {
+                slope = ((float)dim - 1 - bins[t]) / ((float)dim - 1 - t);
+                point = (1 - slope) * (float)(dim - 1);
+                limit = 1;
+            }
+        }
+        bins[t] = (float)(dim - 1);
+    } else {
+        for (t = 0; t < dim - 1; t++) {
+            double nf = M_PI * (double)t / (dim - 1);
+            bins[t] = t + 2 * atan2((warp - 1) * sin(nf), 1 + (1 - warp) * cos(nf)) / M_PI * (dim - 1);
+        }
+        bins[t] = dim - 1;
+    }
+}
+
+/* VtlnModule::create_sinc_coef_table (:1688-1714).  coef is [dim][2*rad+1]. */
+void orc_vtln_sinc_table(int dim, const float *bins, int rad, int lanczos,
+                         int32_t *start, int32_t *len, float *coef)
+{
+    for (int b = 0; b < dim; b++) {
+        int cent = (int)(bins[b] + 0.5);
+        int min_i = cent - rad > 0 ? cent - rad : 0;
+        int max_i = cent + rad + 1 < dim ? cent + rad + 1 : dim;
+        float t;
+        start[b] = min_i;
+        len[b] = max_i > min_i ? max_i - min_i : 0;
+        for (int i = min_i; i < max_i; i++) {
+            t = orc_sinc(i - bins[b]);
+            if (lanczos) {
+                if (fabs(i - bins[b]) < rad)
+                    t *= orc_sinc((i - bins[b]) / (float)rad);
+                else
+                    t = 0;
+            }
+            coef[(size_t)b * (2 * rad + 1) + (i - min_i)] = t;
+        }
+    }
+}
+
+/* VtlnModule::set_all_pass_transform (:1870-1905): final = IDCT * (trmat * DCT),
+ * rows of `final` become the per-bin interpolation weights.  The reference
+ * multiplies with BLAS dgemm (summation order unpinned); plain k-ascending
+ * loops here.  trmat and coef are [dim][dim] row-major. */
+static void orc_vtln_allpass_finish(int dim, const double *trmat, float *coef)
+{
+    size_t n = (size_t)dim;
+    double *dct = (double *)malloc(sizeof(double) * n * n);
+    double *tmp = (double *)malloc(sizeof(double) * n * n);
+    for (int i = 0; i < dim; i++)
+        for (int j = 0; j < dim; j++)
+            dct[i * n + j] = cos(i * (j + 0.5) * M_PI / dim);
+    for (int i = 0; i < dim; i++)
+        for (int j = 0; j < dim; j++) {
+            double a = 0;
+            for (int k = 0; k < dim; k++)
+                a += trmat[i * n + k] * dct[k * n + j];
+            tmp[i * n + j] = a;
+        }
+    for (int i = 0; i < dim; i++) {
+        dct[i * n] = 1.0 / dim;
+        for (int j = 1; j < dim; j++)
+            dct[i * n + j] = cos((i + 0.5) * j * M_PI / dim) * 2 / dim;
+    }
+    for (int i = 0; i < dim; i++)
+        for (int j = 0; j < dim; j++) {
+            double a = 0;
+            for (int k = 0; k < dim; k++)
+                a += dct[i * n + k] * tmp[k * n + j];
+            coef[i * n + j] = a;
+        }
+    free(dct);
+    free(tmp);
+}
+
+/* VtlnModule::create_all_pass_blin_transform (:1716-1756) */
+void orc_vtln_allpass_blin(int dim, float warp, float *coef)
+{
+    size_t n = (size_t)dim;
+    double *q1 = (double *)calloc(n, sizeof(double));
+    double *q = (double *)calloc(n, sizeof(double));
+    double *qn = (double *)calloc(n, sizeof(double));
+    double *tr = (double *)calloc(n * n, sizeof(double));
+    double alpha = warp - 1;
+    double temp;
+    q1[0] = -alpha;
+    temp = 1 - alpha * alpha;
+    for (int i = 1; i < dim; i++) {
+        q1[i] = temp;
+        temp *= alpha;
+    }
+    q[0] = 1;
+    tr[0] = 1;
+    for (int i = 1; i < dim; i++) {
+        for (int j = 0; j < dim; j++) {
+            temp = 0;
+            for (int k = 0; k <= j; k++)
+                temp += q[k] * q1[j - k];
+            qn[j] = temp;
+        }
+        memcpy(q, qn, sizeof(double) * n);
+        tr[i] = 2 * q[0];
+        for (int j = 1; j < dim; j++)
+            tr[j * n + i] = q[j];
+    }
+    orc_vtln_allpass_finish(dim, tr, coef);
+    free(q1);
+    free(q);
+    free(qn);
+    free(tr);
+}
+
+/* VtlnModule::generate (:1907-1937).  rad > 0: windowed dot product with a
+ * float clamp at 0; rad == 0: linear interpolation between neighbouring bins. */
+void orc_vtln_module(const double *in, int n, int dim, int rad,
+                     const float *bins, const int32_t *start,
+                     const int32_t *len, const float *coef, int coef_stride,
+                     double *out)
+{
+    for (int f = 0; f < n; f++) {
+        const double *data = in + (size_t)f * dim;
+        double *target = out + (size_t)f * dim;
+        if (rad > 0) {
+            for (int b = 0; b < dim; b++) {
+                double t = 0;
+                for (int i = 0, di = start[b]; i < len[b]; i++, di++)
+                    t += data[di] * coef[(size_t)b * coef_stride + i];
+                float v = (float)t; /* std::max((float)t, 0.0f) */
+                target[b] = (v < 0.0f) ? 0.0f : v;
+            }
+        } else {
+            for (int b = 0; b < dim; b++) {
+                float p = ceil(bins[b]) - bins[b];
+                target[b] = p * data[(int)floor(bins[b])] + (1 - p) * data[(int)ceil(bins[b])];
+            }
+        }
+    }
+}
+
+/* SRNormModule::set_speech_rate (aku/FeatureModules.cc:2003-2034).
+ * coef is [out_frames][2*order+1]. */
+void orc_srnorm_table(int in_frames, int out_frames, int order, float sr,
+                      int32_t *start, int32_t *len, float *coef)
+{
+    float in_cent = (float)(in_frames - 1) / 2;
+    float out_cent = (float)(out_frames - 1) / 2;
+    for (int i = 0; i < out_frames; i++) {
+        float target_pos = (i - out_cent) / sr + in_cent;
+        int cent = (int)roundf(target_pos);
+        int a = cent - order > 0 ? cent - order : 0;
+        int b = cent + order + 1 < in_frames ? cent + order + 1 : in_frames;
+        start[i] = a;
+        len[i] = b > a ? b - a : 0;
+        for (int j = a; j < b; j++) {
+            float t = orc_sinc(j - target_pos);
+            if (fabs(j - target_pos) < order)
+                t *= orc_sinc((j - target_pos) / (float)order);
+            else
+                t = 0;
+            coef[(size_t)i * (2 * order + 1) + (j - a)] = t;
+        }
+    }
+}
+
+/* SRNormModule::generate (:2037-2058) */
+void orc_srnorm_module(const double *in, int n, int in_frames, int out_frames,
+                       int frame_dim, const int32_t *start, const int32_t *len,
+                       const float *coef, int coef_stride, double *out)
+{
+    for (int f = 0; f < n; f++) {
+        const double *data = in + (size_t)f * in_frames * frame_dim;
+        double *target = out + (size_t)f * out_frames * frame_dim;
+        for (int i = 0; i < out_frames; i++)
+            for (int d = 0; d < frame_dim; d++) {
+                double t = 0;
+                for (int j = 0, fi = start[i]; j < len[i]; j++, fi++)
+                    t += coef[(size_t)i * coef_stride + j] * data[fi * frame_dim + d];
+                float v = (float)t; /* std::max((float)t, 0.0f) */
+                target[i * frame_dim + d] = (v < 0.0f) ? 0.0f : v;
+            }
+    }
+}
+
+/* MelPowerModule::generate (aku/FeatureModules.cc:912-923): float sum of
+ * exp(src), natural log */
+void orc_mel_power_module(const double *in, int n, int src_dim, double *out)
+{
+    for (int f = 0; f < n; f++) {
+        float power = 0;
+        for (int i = 0; i < src_dim; i++)
+            power += exp(in[(size_t)f * src_dim + i]);
+        out[f] = log(power + 1e-10);
+    }
+}
+
+/* QuantEqModule::generate (aku/FeatureModules.cc:2122-2141).  The exponent
+ * really is gamma + (1-alpha)*(x/qmax): the reference's parenthesisation. */
+void orc_quanteq_module(const double *in, int n, int dim, const float *alpha,
+                        const float *gamma, const float *qmax, double *out)
+{
+    for (int f = 0; f < n; f++)
+        for (int k = 0; k < dim; k++) {
+            double x = in[(size_t)f * dim + k];
+            if (alpha)
+                out[(size_t)f * dim + k] =
+                    qmax[k] * (alpha[k] * pow((double)(x / qmax[k]),
+                                              (double)(gamma[k]) + (1 - alpha[k]) * (x / qmax[k])));
+            else
+                out[(size_t)f * dim + k] = x;
+        }
+}
+
+/* ================================================================== */
 /*  CPU baseline helper: reference-shaped scoring loop, timed by        */
 /*  bench.py.  Same per-frame / per-Gaussian scalar structure as        */
 /*  phone_probs.cc:217-234 -> HmmSet.cc:484-501 -> Distributions.cc     */

@@ -95,6 +95,14 @@ def _declare(L: C.CDLL) -> None:
     L.orc_normalization_module.argtypes = [pd, i32, i32, pf, pf, pd]
     L.orc_lin_transform_module.argtypes = [pd, i32, i32, i32, pf, pf, pd]
     L.orc_mean_subtract_module.argtypes = [pd, i32, i32, i32, i32, pd]
+    L.orc_vtln_bins.argtypes = [i32, i32, f, i32, f, pf, i32, pf]
+    L.orc_vtln_sinc_table.argtypes = [i32, pf, i32, i32, pi32, pi32, pf]
+    L.orc_vtln_allpass_blin.argtypes = [i32, f, pf]
+    L.orc_vtln_module.argtypes = [pd, i32, i32, i32, pf, pi32, pi32, pf, i32, pd]
+    L.orc_srnorm_table.argtypes = [i32, i32, i32, f, pi32, pi32, pf]
+    L.orc_srnorm_module.argtypes = [pd, i32, i32, i32, i32, pi32, pi32, pf, i32, pd]
+    L.orc_mel_power_module.argtypes = [pd, i32, i32, pd]
+    L.orc_quanteq_module.argtypes = [pd, i32, i32, pf, pf, pf, pd]
     L.orc_cpu_baseline_score.restype = d
     L.orc_cpu_baseline_score.argtypes = [i32, i64, pd, pd, pd, i64, pi32, pi32, pd, i64, pd]
 
@@ -175,15 +183,19 @@ class FeatureChain:
     """Restatement of aku::FeatureGenerator for the MFCC-chain module types.
 
     Module semantics: aku/FeatureModules.cc (audiofile :327-440, fft :475-566,
-    mel :775-849, power :874-885, dct :937-979, delta :998-1037, normalization
-    :1056-1142, lin_transform :1167-1269, merge :1335-1364, mean_subtractor
-    :1384-1454).  Output of a module at frame t is a pure function of t, so
+    mel :775-849, power :874-885, mel_power :904-923, dct :937-979, delta
+    :998-1037, normalization :1056-1142, lin_transform :1167-1269, merge
+    :1335-1364, mean_subtractor :1384-1454, concat :1472-1501, vtln :1529-1937,
+    sr_norm :1953-2058, quanteq :2078-2141).  set_parameters() is the
+    per-speaker hook SpeakerConfig drives (aku/SpeakerConfig.cc:365-378).
+    Output of a module at frame t is a pure function of t, so
     the ring buffers of FeatureModule::at (:102-158) are replaced by range
     evaluation with halos.
     """
 
     SUPPORTED = ("audiofile", "fft", "mel", "power", "dct", "delta",
-                 "normalization", "lin_transform", "merge", "mean_subtractor")
+                 "normalization", "lin_transform", "merge", "mean_subtractor",
+                 "concat", "vtln", "sr_norm", "mel_power", "quanteq")
 
     def __init__(self, cfg_text: str):
         L = lib()
@@ -303,6 +315,130 @@ class FeatureChain:
             if left + 1 < 1 or right + 1 < 1:
                 raise ValueError("MeanSubtractorModule: context widths must be >= 0")
             m.prm = dict(left=left, right=right)
+        elif t == "concat":
+            left, right = int(o.get("left", 0)), int(o.get("right", 0))
+            if left < 0 or right < 0:
+                raise ValueError("ConcatModule: context spans must be >= 0")
+            m.dim = m.sources[-1].dim * (1 + left + right)
+            m.prm = dict(left=left, right=right)
+        elif t == "mel_power":
+            m.dim = 1
+        elif t == "vtln":
+            m.dim = m.sources[0].dim
+            p = dict(pwlin=int(o.get("pwlin_vtln", 0)),
+                     turn=str2float(o["pwlin_turnpoint"]) if "pwlin_turnpoint" in o else np.float32(0.8),
+                     slapt=int(o.get("slapt", 0)), rad=int(o.get("sinc_interpolation_rad", 8)),
+                     all_pass=int(o.get("all-pass", 0)))
+            if p["pwlin"] and p["slapt"]:
+                raise ValueError("VtlnModule: Can not use both pwlin_vtln and slapt!")
+            if p["pwlin"] and p["all_pass"]:
+                raise ValueError("VtlnModule: Can not use both pwlin_vtln and all-pass!")
+            p["lanczos"] = int(o.get("lanczos_window", 0 if p["all_pass"] else 1)) > 0
+            if p["lanczos"] and p["all_pass"]:
+                raise ValueError("VtlnModule: Can not use both lanczos_window and all-pass!")
+            m.prm = p
+            self._vtln_tables(m, warp=np.float32(1.0), slapt=np.zeros(1, np.float32))
+        elif t == "sr_norm":
+            p = dict(in_frames=int(o.get("in_frames", 0)), out_frames=int(o.get("out_frames", 0)),
+                     order=int(o.get("lanczos_order", 4)))
+            if p["in_frames"] == 0 or p["out_frames"] == 0:
+                raise ValueError("SRNormModule: Must set both in_frames and out_frames.")
+            if m.sources[0].dim % p["in_frames"]:
+                raise ValueError("SRNormModule: in_frames does not match with the input dimension")
+            if p["order"] < 1:
+                raise ValueError("SRNormModule: lanczos_order must be positive.")
+            p["frame_dim"] = m.sources[0].dim // p["in_frames"]
+            m.dim = p["out_frames"] * p["frame_dim"]
+            m.prm = p
+            self._srnorm_table(m, str2float(o["speech_rate"]) if "speech_rate" in o else np.float32(1.0))
+        elif t == "quanteq":
+            m.dim = m.sources[-1].dim
+            m.prm = dict(alpha=None, gamma=None, qmax=None)
+
+    def _vtln_tables(self, m: _Mod, warp, slapt) -> None:
+        L, p, dim = lib(), m.prm, m.dim
+        pf, pi = C.c_float, C.c_int32
+        slapt = np.ascontiguousarray(slapt, np.float32)
+        p["warp"], p["slapt_params"] = np.float32(warp), slapt
+        bins = np.zeros(dim, np.float32)
+        L.orc_vtln_bins(dim, p["pwlin"], float(p["turn"]), p["slapt"], float(warp), _p(slapt, pf),
+                        len(slapt), _p(bins, pf))
+        p["bins"] = bins
+        if p["all_pass"]:
+            if p["slapt"]:
+                raise ValueError("VtlnModule: all-pass with slapt is not restated")
+            coef = np.zeros((dim, dim), np.float32)
+            L.orc_vtln_allpass_blin(dim, float(warp), _p(coef, pf))
+            p["start"], p["len"], p["coef"] = np.zeros(dim, np.int32), np.full(dim, dim, np.int32), coef
+        elif p["rad"] > 0:
+            w = 2 * p["rad"] + 1
+            p["start"], p["len"] = np.zeros(dim, np.int32), np.zeros(dim, np.int32)
+            p["coef"] = np.zeros((dim, w), np.float32)
+            L.orc_vtln_sinc_table(dim, _p(bins, pf), p["rad"], int(p["lanczos"]), _p(p["start"], pi),
+                                  _p(p["len"], pi), _p(p["coef"], pf))
+        else:
+            p["start"], p["len"], p["coef"] = np.zeros(dim, np.int32), np.zeros(dim, np.int32), np.zeros((dim, 1), np.float32)
+
+    def _srnorm_table(self, m: _Mod, sr) -> None:
+        p = m.prm
+        w = 2 * p["order"] + 1
+        p["speech_rate"] = np.float32(sr)
+        p["start"], p["len"] = np.zeros(p["out_frames"], np.int32), np.zeros(p["out_frames"], np.int32)
+        p["coef"] = np.zeros((p["out_frames"], w), np.float32)
+        lib().orc_srnorm_table(p["in_frames"], p["out_frames"], p["order"], float(sr), _p(p["start"], C.c_int32),
+                               _p(p["len"], C.c_int32), _p(p["coef"], C.c_float))
+
+    def set_parameters(self, module: str, opts: Dict[str, str]) -> None:
+        """FeatureModule::set_parameters of `module` with one parsed { key value }
+        block (normalization :1089-1112, lin_transform :1187-1196, vtln :1575-1592,
+        sr_norm :1990-1996, quanteq :2085-2094; a no-op for every other type)."""
+        if module not in self.by_name:
+            raise ValueError("unknown module requested: " + module)
+        m = self.by_name[module]
+        o = opts
+        if m.type == "normalization":
+            mean = _floats(o["mean"]) if "mean" in o else m.prm["mean"]
+            if len(mean) != m.dim:
+                raise ValueError("NormalizationModule: Invalid mean dimension")
+            scale = m.prm["scale"]
+            if "var" in o and "scale" in o:
+                raise ValueError("NormalizationModule: Both scale and var can not be defined simultaneously")
+            if "var" in o:
+                scale = _floats(o["var"])
+                if len(scale) != m.dim:
+                    raise ValueError("Normalization module: Invalid variance dimension")
+                lib().orc_var_to_scale(m.dim, _p(scale, C.c_float))
+            elif "scale" in o:
+                scale = _floats(o["scale"])
+                if len(scale) != m.dim:
+                    raise ValueError("NormalizationModule: Invalid scale dimension")
+            m.prm = dict(mean=mean, scale=scale)
+        elif m.type == "lin_transform":
+            mat = _floats(o["matrix"]) if "matrix" in o else None
+            bias = _floats(o["bias"]) if "bias" in o else None
+            if mat is not None and len(mat) == 0:
+                mat = None
+            if bias is not None and len(bias) == 0:
+                bias = None
+            sd = m.prm["src_dim"]
+            if mat is not None and len(mat) != m.dim * sd:
+                raise ValueError("LinTransformModule: Invalid matrix dimension")
+            if bias is not None and len(bias) != m.dim:
+                raise ValueError("LinTransformModule: Invalid bias dimension")
+            m.prm = dict(matrix=mat, bias=bias, src_dim=sd)
+        elif m.type == "vtln":
+            if m.prm["slapt"]:
+                self._vtln_tables(m, m.prm["warp"], _floats(o["slapt_coef"]) if "slapt_coef" in o
+                                  else np.zeros(1, np.float32))
+            else:
+                self._vtln_tables(m, str2float(o["warp_factor"]) if "warp_factor" in o else np.float32(1.0),
+                                  m.prm["slapt_params"])
+        elif m.type == "sr_norm":
+            self._srnorm_table(m, str2float(o["speech_rate"]) if "speech_rate" in o else np.float32(1.0))
+        elif m.type == "quanteq":
+            m.prm = dict(alpha=_floats(o["alpha"]) if "alpha" in o else None,
+                         gamma=_floats(o["gamma"]) if "gamma" in o else None,
+                         qmax=_floats(o["quant_max"]) if "quant_max" in o else None)
 
     # -- FeatureGenerator surface ---------------------------------------------
     @property
@@ -328,7 +464,7 @@ class FeatureChain:
             l = r = 0
             if m.type == "delta":
                 l = r = m.prm["width"]
-            elif m.type == "mean_subtractor":
+            elif m.type in ("mean_subtractor", "concat"):
                 l, r = m.prm["left"], m.prm["right"]
             bl = br = 0
             for s in m.sources:
@@ -373,6 +509,11 @@ class FeatureChain:
             l, r = m.prm["left"], m.prm["right"]
             src = self._eval(m.sources[-1], lo - l - 1, hi + r, pcm, memo)
             L.orc_mean_subtract_module(_p(src, pd), n, m.dim, l, r, _p(out, pd))
+        elif t == "concat":
+            # ConcatModule::generate (aku/FeatureModules.cc:1488-1501)
+            l, r = m.prm["left"], m.prm["right"]
+            src = self._eval(m.sources[-1], lo - l, hi + r, pcm, memo)
+            out = np.ascontiguousarray(np.hstack([src[i:i + n] for i in range(l + r + 1)]))
         else:
             src = self._eval(m.sources[-1], lo, hi, pcm, memo)
             sd = m.sources[-1].dim
@@ -395,6 +536,27 @@ class FeatureChain:
                     _p(src, pd), n, sd, m.dim,
                     _p(mat, C.c_float) if mat is not None else None,
                     _p(bias, C.c_float) if bias is not None else None, _p(out, pd))
+            elif t == "mel_power":
+                L.orc_mel_power_module(_p(src, pd), n, sd, _p(out, pd))
+            elif t == "vtln":
+                p = m.prm
+                rad = m.dim if p["all_pass"] else p["rad"]   # all-pass: full-row weights
+                L.orc_vtln_module(_p(src, pd), n, m.dim, rad, _p(p["bins"], C.c_float),
+                                  _p(p["start"], C.c_int32), _p(p["len"], C.c_int32),
+                                  _p(p["coef"], C.c_float), p["coef"].shape[1], _p(out, pd))
+            elif t == "sr_norm":
+                p = m.prm
+                L.orc_srnorm_module(_p(src, pd), n, p["in_frames"], p["out_frames"], p["frame_dim"],
+                                    _p(p["start"], C.c_int32), _p(p["len"], C.c_int32),
+                                    _p(p["coef"], C.c_float), p["coef"].shape[1], _p(out, pd))
+            elif t == "quanteq":
+                p = m.prm
+                full = p["alpha"] is not None and p["gamma"] is not None and p["qmax"] is not None \
+                    and len(p["alpha"]) and len(p["gamma"]) and len(p["qmax"])
+                L.orc_quanteq_module(_p(src, pd), n, m.dim,
+                                     _p(p["alpha"], C.c_float) if full else None,
+                                     _p(p["gamma"], C.c_float) if full else None,
+                                     _p(p["qmax"], C.c_float) if full else None, _p(out, pd))
             else:
                 raise AssertionError(t)
         memo[key] = out
