@@ -35,7 +35,8 @@ class AasrError(RuntimeError):
 class RunOptions(C.Structure):
     _fields_ = [("lnabytes", C.c_int32), ("normalize", C.c_int32), ("num_batches", C.c_int32),
                 ("batch_index", C.c_int32), ("no_overwrite", C.c_int32), ("raw_audio", C.c_int32),
-                ("info", C.c_int32), ("afname", C.c_int32), ("out_dir", C.c_char_p)]
+                ("info", C.c_int32), ("afname", C.c_int32), ("out_dir", C.c_char_p),
+                ("speakers", C.c_void_p)]
 
 
 class RunStats(C.Structure):
@@ -122,6 +123,16 @@ def _declare(L: C.CDLL) -> None:
     L.aasr_lna_encode_dev.argtypes = [vp, i64, i32, C.c_int, C.c_int, vp, vp, vp]
     L.aasr_lna_header.argtypes = [i32, C.c_int, vp]
     L.aasr_lna_header.restype = None
+    L.aasr_spkc_create.argtypes = [vp, vp, C.POINTER(vp)]
+    L.aasr_spkc_destroy.argtypes = [vp]
+    L.aasr_spkc_destroy.restype = None
+    L.aasr_spkc_set_model.argtypes = [vp, vp]
+    L.aasr_spkc_read_file.argtypes = [vp, cp]
+    L.aasr_spkc_read_text.argtypes = [vp, cp]
+    L.aasr_spkc_set_speaker.argtypes = [vp, cp]
+    L.aasr_spkc_set_utterance.argtypes = [vp, cp]
+    L.aasr_spkc_num_changes.argtypes = [vp]
+    L.aasr_spkc_num_changes.restype = i64
     L.aasr_recipe_batch_range.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
     L.aasr_run_recipe.argtypes = [vp, vp, cp, C.POINTER(RunOptions), C.POINTER(RunStats)]
     L.aasr_run_utterance.argtypes = [vp, vp, vp, i64, i32, i32, C.c_int, C.c_int,
@@ -409,12 +420,47 @@ def run_utterance(feat: Feat, gmm: Gmm, pcm: np.ndarray, start_frame: int = 0, e
     return data, frames.value
 
 
+class SpeakerConfig:
+    """aku::SpeakerConfig on the engine's handles (aasr_spkc_*)."""
+
+    def __init__(self, feat: "Feat", gmm: Optional["Gmm"] = None):
+        self._h = C.c_void_p()
+        self._keep = (feat, gmm)
+        check(lib().aasr_spkc_create(feat._h, gmm._h if gmm is not None else None, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.aasr_spkc_destroy(self._h)
+            self._h = None
+
+    def set_model(self, gmm: "Gmm") -> None:
+        self._keep = (self._keep[0], gmm)
+        check(lib().aasr_spkc_set_model(self._h, gmm._h))
+
+    def read_file(self, path: str) -> None:
+        check(lib().aasr_spkc_read_file(self._h, path.encode()))
+
+    def read_text(self, text: str) -> None:
+        check(lib().aasr_spkc_read_text(self._h, text.encode()))
+
+    def set_speaker(self, speaker_id: str = "") -> None:
+        check(lib().aasr_spkc_set_speaker(self._h, speaker_id.encode()))
+
+    def set_utterance(self, utterance_id: str = "") -> None:
+        check(lib().aasr_spkc_set_utterance(self._h, utterance_id.encode()))
+
+    @property
+    def num_changes(self) -> int:
+        return lib().aasr_spkc_num_changes(self._h)
+
+
 def run_recipe(feat: Feat, gmm: Gmm, recipe_path: str, lnabytes: int = 2, normalize: bool = True,
                num_batches: int = 0, batch_index: int = 0, no_overwrite: bool = False,
                raw_audio: bool = False, info: int = 0, afname: bool = False,
-               out_dir: Optional[str] = None) -> RunStats:
+               out_dir: Optional[str] = None, speakers: Optional[SpeakerConfig] = None) -> RunStats:
     opt = RunOptions(lnabytes, int(normalize), num_batches, batch_index, int(no_overwrite),
-                     int(raw_audio), info, int(afname), out_dir.encode() if out_dir else None)
+                     int(raw_audio), info, int(afname), out_dir.encode() if out_dir else None,
+                     speakers._h if speakers is not None else None)
     st = RunStats()
     check(lib().aasr_run_recipe(feat._h, gmm._h, recipe_path.encode(), C.byref(opt), C.byref(st)))
     return st

@@ -81,6 +81,8 @@ public:
   const float *block_f32(int frame, int *first, int *count) const;
   uint64_t block_serial() const { return m_block_serial; }
   void set_block_frames(int n) { m_block_frames = n > 0 ? n : 1; }
+  /** module parameters changed (SpeakerConfig): cached frames are stale */
+  void invalidate_block() { m_block_count = 0; }
 
 private:
   void fill_block(int frame);

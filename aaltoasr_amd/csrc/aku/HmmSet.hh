@@ -54,6 +54,11 @@ public:
     ensure_model();
     return m_gmm;
   }
+  /** the model changed underneath (SpeakerConfig loaded a transform) */
+  void invalidate_block() {
+    m_count = 0;
+    m_row = nullptr;
+  }
   /** log state likelihoods of the cached block row for f (S floats) */
   const float *state_loglik_row(const FeatureVec &f);
 

@@ -5,7 +5,8 @@
 // show that code shaped like the reference's callers runs unchanged on the
 // engine and produces the same LNA as the batched entry point.
 //
-//   aku_adapter_check CFG MODEL_BASE AUDIO OUT.lna LNABYTES
+//   aku_adapter_check CFG MODEL_BASE AUDIO OUT.lna LNABYTES [GCL MINC MING]
+//                     [spkc SPKC SPEAKER UTTERANCE]
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -15,6 +16,7 @@
 
 #include "FeatureGenerator.hh"
 #include "HmmSet.hh"
+#include "SpeakerConfig.hh"
 
 static double safe_log(double x) {  // aku/util.hh:132-139
   const double tiny_for_log = 1e-50;
@@ -22,8 +24,9 @@ static double safe_log(double x) {  // aku/util.hh:132-139
 }
 
 int main(int argc, char **argv) {
-  if (argc != 6 && argc != 9) {
-    fprintf(stderr, "usage: aku_adapter_check CFG MODEL_BASE AUDIO OUT.lna LNABYTES [GCL MINC MING]\n");
+  if (argc != 6 && argc != 9 && argc != 10 && argc != 13) {
+    fprintf(stderr, "usage: aku_adapter_check CFG MODEL_BASE AUDIO OUT.lna LNABYTES [GCL MINC MING] "
+                    "[spkc SPKC SPEAKER UTTERANCE]\n");
     return 2;
   }
   try {
@@ -33,10 +36,25 @@ int main(int argc, char **argv) {
     if (!cf) throw std::string("could not open config");
     gen.load_configuration(cf);
     fclose(cf);
+    aku::SpeakerConfig speaker_conf(gen, &model);
+    int arg = 6;
+    const bool with_gcl = arg < argc && std::string(argv[arg]) != "spkc";
+    const int spk_arg = with_gcl ? arg + 3 : arg;
+    const bool with_spk = spk_arg < argc && std::string(argv[spk_arg]) == "spkc";
+    if (with_spk) {  // aku/phone_probs.cc:94-95: before the model is read
+      FILE *sf = fopen(argv[spk_arg + 1], "r");
+      if (!sf) throw std::string("could not open speaker file");
+      speaker_conf.read_speaker_file(sf);
+      fclose(sf);
+    }
     model.read_all(argv[2]);
-    if (argc == 9) {  // aku/phone_probs.cc:112-117
-      model.read_clustering(argv[6]);
-      model.set_clustering_min_evals(atof(argv[7]), atof(argv[8]));
+    if (with_gcl) {  // aku/phone_probs.cc:112-117
+      model.read_clustering(argv[arg]);
+      model.set_clustering_min_evals(atof(argv[arg + 1]), atof(argv[arg + 2]));
+    }
+    if (with_spk) {  // aku/phone_probs.cc:191-196
+      speaker_conf.set_speaker(argv[spk_arg + 2]);
+      if (argv[spk_arg + 3][0]) speaker_conf.set_utterance(argv[spk_arg + 3]);
     }
     const int lnabytes = atoi(argv[5]);
     if (model.dim() != gen.dim()) throw std::string("dimension mismatch");

@@ -3,9 +3,9 @@
 //
 //   phone_probs (-b BASE | -g GK -m MC -p PH) -c CFG -r RECIPE [-o DIR]
 //               [--lnabytes 2|4] [-a] [-n] [-N] [-B n -I k] [-i level]
-//               [-C GCL --eval-minc R --eval-ming R]
+//               [-C GCL --eval-minc R --eval-ming R] [-S SPKC]
 //
-// Not built (fail loudly): -S speakers, --sort-recipe.  One process drives one GPU (--device N or
+// Not built (fail loudly): --sort-recipe.  One process drives one GPU (--device N or
 // HIP_VISIBLE_DEVICES); run N processes with -B N -I k for N GPUs, exactly as
 // the reference scales over CPU cores.
 #include <getopt.h>
@@ -26,7 +26,7 @@ static void die(const std::string &msg) {
 
 int main(int argc, char *argv[]) {
   std::string base, gk, mc, ph, cfg, recipe, out_dir;
-  std::string clusters;
+  std::string clusters, speakers;
   double eval_minc = 0.0, eval_ming = 0.1;  // defaults of aku/phone_probs.cc:74-75
   int lnabytes = 2, info = 0, batch = 0, bindex = 0, device = -1;
   bool afname = false, no_overwrite = false, no_norm = false, batch_set = false, bindex_set = false;
@@ -51,7 +51,7 @@ int main(int argc, char *argv[]) {
                "  -r RECIPE  recipe file\n  -o DIR   output directory\n  --lnabytes=2|4\n"
                "  -a  use audio file name\n  -n  no overwrite\n  -N  no normalization\n"
                "  -B n -I k  batch k of n\n  -i level  info\n  --device=N  GPU ordinal\n"
-               "  -C GCL  Gaussian clustering file\n  --eval-minc=R  minimum ratio of top clusters\n"
+               "  -S SPKC  speaker configuration file\n  -C GCL  Gaussian clustering file\n  --eval-minc=R  minimum ratio of top clusters\n"
                "  --eval-ming=R  minimum ratio of Gaussians to evaluate\n");
         return 0;
       case 'b': base = optarg; break;
@@ -69,7 +69,7 @@ int main(int argc, char *argv[]) {
       case 'I': bindex = atoi(optarg); bindex_set = true; break;
       case 'i': info = atoi(optarg); break;
       case 5: device = atoi(optarg); break;
-      case 'S': die("--speakers (speaker adaptation) is not built in this engine yet");
+      case 'S': speakers = optarg; break;
       case 'C': clusters = optarg; break;
       case 2: eval_minc = atof(optarg); break;
       case 3: eval_ming = atof(optarg); break;
@@ -104,6 +104,11 @@ int main(int argc, char *argv[]) {
     if (aasr_gmm_set_clustering_min_evals(gmm, eval_minc, eval_ming) != AASR_OK)
       die(aasr_last_error());
   }
+  aasr_spkc *spk = nullptr;
+  if (!speakers.empty()) {
+    if (aasr_spkc_create(feat, gmm, &spk) != AASR_OK) die(aasr_last_error());
+    if (aasr_spkc_read_file(spk, speakers.c_str()) != AASR_OK) die(aasr_last_error());
+  }
   aasr_run_options opt;
   memset(&opt, 0, sizeof opt);
   opt.lnabytes = lnabytes;
@@ -114,6 +119,7 @@ int main(int argc, char *argv[]) {
   opt.info = info;
   opt.afname = afname;
   opt.out_dir = out_dir.empty() ? nullptr : out_dir.c_str();
+  opt.speakers = spk;
   aasr_run_stats st;
   memset(&st, 0, sizeof st);
   if (aasr_run_recipe(feat, gmm, recipe.c_str(), &opt, &st) != AASR_OK) die(aasr_last_error());
@@ -121,6 +127,7 @@ int main(int argc, char *argv[]) {
     fprintf(stderr, "{\"utterances\": %ld, \"frames\": %ld, \"seconds\": %.3f, \"device_seconds\": %.3f, \"frames_per_s\": %.1f}\n",
             (long)st.utterances, (long)st.frames, st.seconds_total, st.seconds_device,
             st.seconds_total > 0 ? st.frames / st.seconds_total : 0.0);
+  aasr_spkc_destroy(spk);
   aasr_gmm_destroy(gmm);
   aasr_feat_destroy(feat);
   return 0;

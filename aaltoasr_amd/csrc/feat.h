@@ -35,6 +35,11 @@ struct ModuleConfig {
   // parses one block from `text` starting at *pos (just after the "module"
   // line); advances *pos past the closing brace
   void read(const std::string &text, size_t *pos);
+  // ModuleConfig::insert (aku/ModuleConfig.cc:225-238): replaces an existing key
+  void insert(const std::string &name, const std::string &value);
+  // ModuleConfig::set for float / float-vector values: "%g" formatting (:21-26, 49-60)
+  void set(const std::string &name, float value);
+  void set(const std::string &name, const std::vector<float> &vec);
 };
 
 struct FftPlan {
@@ -141,5 +146,8 @@ void feat_halo(const aasr_feat *h, int target, int *left, int *right);
 void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &b, int target,
                     float *out_f32, double *out_f64, hipStream_t stream);
 void feat_set_parameters(aasr_feat *h, const std::string &module, const std::string &block);
+void feat_set_parameters(aasr_feat *h, const std::string &module, const ModuleConfig &c);
+// FeatureModule::get_parameters of `module` into c (existing keys are replaced)
+void feat_get_parameters(const aasr_feat *h, const std::string &module, ModuleConfig &c);
 
 }  // namespace aasr

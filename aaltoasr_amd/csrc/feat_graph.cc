@@ -91,6 +91,34 @@ void ModuleConfig::read(const std::string &text, size_t *pos) {
   }
 }
 
+void ModuleConfig::insert(const std::string &name, const std::string &value) {
+  auto it = index.find(name);
+  if (it == index.end()) {
+    index[name] = (int)values.size();
+    names.push_back(name);
+    values.push_back(value);
+  } else {
+    values[it->second] = value;
+  }
+}
+
+static std::string fmt_g(float v) {
+  char buf[64];
+  snprintf(buf, sizeof buf, "%g", v);
+  return buf;
+}
+
+void ModuleConfig::set(const std::string &name, float value) { insert(name, fmt_g(value)); }
+
+void ModuleConfig::set(const std::string &name, const std::vector<float> &vec) {
+  std::string v;
+  for (size_t i = 0; i < vec.size(); i++) {
+    if (i) v += " ";
+    v += fmt_g(vec[i]);
+  }
+  insert(name, v);
+}
+
 bool ModuleConfig::get(const std::string &k, std::string &v) const {
   auto it = index.find(k);
   if (it == index.end()) return false;
@@ -729,13 +757,55 @@ void feat_halo(const aasr_feat *h, int target, int *left, int *right) {
 }
 
 void feat_set_parameters(aasr_feat *h, const std::string &module, const std::string &block) {
+  ModuleConfig c;
+  size_t pos = 0;
+  c.read(block, &pos);
+  feat_set_parameters(h, module, c);
+}
+
+void feat_get_parameters(const aasr_feat *h, const std::string &module, ModuleConfig &c) {
+  auto it = h->by_name.find(module);
+  if (it == h->by_name.end())
+    raise(AASR_ERR_INVALID, "unknown module requested: %s", module.c_str());
+  const FeatModule &m = h->mods[it->second];
+  switch (m.type) {
+    case MOD_NORMALIZATION:  // aku/FeatureModules.cc:1114-1119
+      c.set("mean", m.mean);
+      c.set("scale", m.scale);
+      break;
+    case MOD_LIN_TRANSFORM: {  // :1197-1202; undefined parts read back as identity / zeros
+      std::vector<float> mat = m.matrix, bias = m.bias;
+      if (!m.matrix_defined) {
+        mat.assign((size_t)m.dim * m.src_dim, 0.0f);
+        for (int r = 0; r < m.dim && r < m.src_dim; r++) mat[(size_t)r * m.src_dim + r] = 1.0f;
+      }
+      if (!m.bias_defined) bias.assign((size_t)m.dim, 0.0f);
+      c.set("matrix", mat);
+      c.set("bias", bias);
+      break;
+    }
+    case MOD_VTLN:  // :1594-1600
+      if (m.use_slapt) c.set("slapt_coef", m.slapt_params);
+      else c.set("warp_factor", m.warp_factor);
+      break;
+    case MOD_SR_NORM:  // :1998-2001
+      c.set("speech_rate", m.speech_rate);
+      break;
+    case MOD_QUANTEQ:  // :2096-2102
+      c.set("alpha", m.q_alpha);
+      c.set("gamma", m.q_gamma);
+      c.set("quant_max", m.q_max);
+      break;
+    default:  // FeatureModule::get_parameters is a no-op (aku/FeatureModule.hh:108)
+      break;
+  }
+}
+
+void feat_set_parameters(aasr_feat *h, const std::string &module, const ModuleConfig &c) {
   auto it = h->by_name.find(module);
   if (it == h->by_name.end())
     raise(AASR_ERR_INVALID, "unknown module requested: %s", module.c_str());
   FeatModule &m = h->mods[it->second];
-  ModuleConfig c;
-  size_t pos = 0;
-  c.read(block, &pos);
   if (m.type == MOD_NORMALIZATION) {
     // NormalizationModule::set_parameters (aku/FeatureModules.cc:1089-1112)
     c.get("mean", m.mean);

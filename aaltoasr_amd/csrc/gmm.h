@@ -43,6 +43,10 @@ struct HostModel {
     return true;
   }
   bool factor_path() const { return any_full() || (n_transforms > 0 && !global_xform()); }
+  // HMM inventory of the .ph file (label, emission pdf of every state); only
+  // models created from files have it.  Used by UNIT_PHONE regression classes.
+  std::vector<std::string> hmm_label;
+  std::vector<std::vector<int32_t>> hmm_states;
   int64_t S = 0;
   std::vector<int32_t> mix_off;         // [S+1]
   std::vector<int32_t> mix_idx;         // [K]

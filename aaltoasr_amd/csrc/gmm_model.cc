@@ -119,10 +119,13 @@ HostModel read_model_files(const char *gk, const char *mc, const char *ph) {
       states -= 2;
       int dummy;
       in >> dummy >> dummy;
+      m.hmm_label.push_back(label);
+      m.hmm_states.emplace_back();
       for (int s = 0; s < states; s++) {
         int pdf;
         in >> pdf;
         if (pdf > max_pdf) max_pdf = pdf;
+        m.hmm_states.back().push_back(pdf);
       }
       for (int s = -2; s < states; s++) {
         int source = 0, transitions = 0;

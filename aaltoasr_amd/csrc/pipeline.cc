@@ -303,6 +303,14 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
     pending_frames = 0;
   };
 
+  // -S: parameters change between utterances; everything queued so far must be
+  // computed with the old ones
+  struct Unhook {
+    aasr_spkc *s;
+    ~Unhook() { if (s) spkc_set_before_change(s, nullptr); }
+  } unhook{opt.speakers};
+  if (opt.speakers) spkc_set_before_change(opt.speakers, flush);
+
   for (size_t ri = 0; ri < infos.size(); ri++) {
     const RecipeInfo &info = infos[ri];
     if (opt.info > 0) {
@@ -325,6 +333,10 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
         fprintf(stderr, "WARNING: skipping existing lna file %s\n", out_file.c_str());
         continue;
       }
+    }
+    if (opt.speakers) {  // aku/phone_probs.cc:191-196
+      spkc_set_speaker(opt.speakers, info.speaker_id);
+      if (!info.utterance_id.empty()) spkc_set_utterance(opt.speakers, info.utterance_id);
     }
     Job j;
     j.info_index = ri;

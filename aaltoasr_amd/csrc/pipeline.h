@@ -18,3 +18,15 @@ std::vector<RecipeInfo> recipe_read(const std::string &text, int num_batches, in
 std::vector<int16_t> read_audio_file(const std::string &path, bool force_raw, int expect_rate);
 
 }  // namespace aasr
+
+#include <functional>
+struct aasr_spkc;
+namespace aasr {
+// speaker_config.cc
+void spkc_read_text(aasr_spkc *h, const std::string &text);
+void spkc_set_speaker(aasr_spkc *h, const std::string &speaker_id);
+void spkc_set_utterance(aasr_spkc *h, const std::string &utterance_id);
+// called right before any module's device parameters change
+void spkc_set_before_change(aasr_spkc *h, std::function<void()> fn);
+
+}  // namespace aasr

@@ -262,6 +262,33 @@ aasr_status aasr_recipe_batch_range(int32_t num_lines_total, int32_t num_batches
                                     int32_t batch_index, int32_t *first_line,
                                     int32_t *num_lines);
 
+/* ---------------------------------------------------------------------------
+ * Speaker / utterance configuration: aku::SpeakerConfig
+ * (aku/SpeakerConfig.hh:15-60, aku/SpeakerConfig.cc) -- what phone_probs -S FILE
+ * drives (aku/phone_probs.cc:94-95, 191-196).  A .spkc file holds, per speaker
+ * and per utterance (and for the "default" of each), parameter blocks for named
+ * feature modules ("feature NAME" or just "NAME": normalization, lin_transform,
+ * vtln, sr_norm, quanteq take parameters) and for the model module "cmllr"
+ * (constrained MLLR matrices w1, w2, ... with unitmode UNIT_NO / UNIT_GAUSSIAN /
+ * UNIT_MIX / UNIT_PHONE; the engine maps them onto aasr_gmm_set_cmllr).
+ * set_speaker / set_utterance follow the reference step by step, including the
+ * read-back of the current speaker's parameters through "%g" before a switch;
+ * see aaltoasr_amd/csrc/speaker_config.cc for the list of kept quirks.
+ * The handle borrows feat and gmm (gmm may be NULL, or given later with
+ * aasr_spkc_set_model -- phone_probs reads the speaker file before the model). */
+typedef struct aasr_spkc aasr_spkc;
+aasr_status aasr_spkc_create(aasr_feat *feat, aasr_gmm *gmm, aasr_spkc **out);
+void aasr_spkc_destroy(aasr_spkc *h);
+aasr_status aasr_spkc_set_model(aasr_spkc *h, aasr_gmm *gmm);
+/* SpeakerConfig::read_speaker_file */
+aasr_status aasr_spkc_read_file(aasr_spkc *h, const char *path);
+aasr_status aasr_spkc_read_text(aasr_spkc *h, const char *text);
+/* SpeakerConfig::set_speaker / set_utterance; "" (or NULL) selects the default */
+aasr_status aasr_spkc_set_speaker(aasr_spkc *h, const char *speaker_id);
+aasr_status aasr_spkc_set_utterance(aasr_spkc *h, const char *utterance_id);
+/* number of times a module's device parameters were actually rewritten */
+int64_t aasr_spkc_num_changes(const aasr_spkc *h);
+
 typedef struct aasr_run_options {
   int32_t lnabytes;        /* 2 or 4          (--lnabytes)          */
   int32_t normalize;       /* 0 = -N / --no-normalization           */
@@ -272,6 +299,7 @@ typedef struct aasr_run_options {
   int32_t info;            /* -i verbosity                          */
   int32_t afname;          /* -a: name outputs after the audio file */
   const char *out_dir;     /* -o: prefix for LNA paths or NULL      */
+  struct aasr_spkc *speakers; /* -S: speaker configuration or NULL   */
 } aasr_run_options;
 
 typedef struct aasr_run_stats {

@@ -440,6 +440,29 @@ class FeatureChain:
                          gamma=_floats(o["gamma"]) if "gamma" in o else None,
                          qmax=_floats(o["quant_max"]) if "quant_max" in o else None)
 
+    def get_parameters(self, module: str, opts: Dict[str, str]) -> None:
+        """FeatureModule::get_parameters: writes the module's current parameters
+        into opts, every float printed with "%g" (ModuleConfig::set,
+        aku/ModuleConfig.cc:21-26, 49-60)."""
+        m = self.by_name[module]
+        g = lambda v: " ".join("%g" % float(x) for x in v)
+        if m.type == "normalization":
+            opts["mean"], opts["scale"] = g(m.prm["mean"]), g(m.prm["scale"])
+        elif m.type == "lin_transform":
+            mat, bias, sd = m.prm["matrix"], m.prm["bias"], m.prm["src_dim"]
+            opts["matrix"] = g(mat if mat is not None else np.eye(m.dim, sd, dtype=np.float32).ravel())
+            opts["bias"] = g(bias if bias is not None else np.zeros(m.dim, np.float32))
+        elif m.type == "vtln":
+            if m.prm["slapt"]:
+                opts["slapt_coef"] = g(m.prm["slapt_params"])
+            else:
+                opts["warp_factor"] = "%g" % float(m.prm["warp"])
+        elif m.type == "sr_norm":
+            opts["speech_rate"] = "%g" % float(m.prm["speech_rate"])
+        elif m.type == "quanteq":
+            for key, name in (("alpha", "alpha"), ("gamma", "gamma"), ("qmax", "quant_max")):
+                opts[name] = g(m.prm[key]) if m.prm[key] is not None else ""
+
     # -- FeatureGenerator surface ---------------------------------------------
     @property
     def dim(self) -> int:
@@ -861,6 +884,243 @@ def read_model(base: str) -> DiagModel:
     mean, var = read_gk(base + ".gk")
     off, idx, w = read_mc(base + ".mc")
     return DiagModel(mean, var, off, idx, w)
+
+
+# ---------------------------------------------------------------------------
+# speaker configuration  (SpeakerConfig, aku/SpeakerConfig.cc)
+# ---------------------------------------------------------------------------
+
+class SpeakerConfig:
+    """aku::SpeakerConfig driving a FeatureChain and, for "model cmllr" blocks,
+    a DiagModel: read_speaker_file (aku/SpeakerConfig.cc:20-153), set_speaker
+    (:239-286), set_utterance (:288-318), retrieve_* (:322-362), set_modules
+    (:365-378); ConstrainedMllr::set_parameters / get_parameters / load_transform
+    (aku/ModelModules.cc:62-97, 129-160, 164-232) with the Gaussian sets of
+    RegClassTree::Unit*::get_gaussians (aku/RegClassTree.cc:301-479).
+
+    After set_speaker, `g2t` / `W` describe the model transform in force:
+    g2t[g] = index into W (or -1), W[t] = [b | A] (float-rounded entries)."""
+
+    UNITS = ("UNIT_PHONE", "UNIT_MIX", "UNIT_GAUSSIAN", "UNIT_NO")
+
+    def __init__(self, chain: "FeatureChain", model: Optional[DiagModel] = None,
+                 hmms: Optional[List[Tuple[str, List[int]]]] = None):
+        self.chain, self.model, self.hmms = chain, model, hmms
+        self.speakers: Dict[str, Dict[str, Dict[str, str]]] = {}
+        self.utterances: Dict[str, Dict[str, Dict[str, str]]] = {}
+        self.default_speaker: Optional[Dict[str, Dict[str, str]]] = None
+        self.default_utterance: Optional[Dict[str, Dict[str, str]]] = None
+        self.cur_speaker = self.cur_utterance = ""
+        self.has_cmllr = False
+        self.trans_is_reset, self.cmllr_loaded = True, False
+        self.unit_mode = "UNIT_NO"
+        self.trans: Dict[Tuple[str, ...], np.ndarray] = {}
+        self.g2t = None if model is None else np.full(model.G, -1, np.int32)
+        self.W = np.zeros((0, 0, 0))
+
+    # -- reading ---------------------------------------------------------------
+    def read_text(self, text: str) -> None:
+        lines = text.split("\n")
+        i = 0
+
+        def nonempty():
+            nonlocal i
+            while i < len(lines):
+                l = lines[i].strip(" \t\r")
+                i += 1
+                if l:
+                    return l
+            return None
+        while True:
+            l = nonempty()
+            if l is None:
+                return
+            f = l.split()
+            if len(f) != 2 or f[0] not in ("speaker", "utterance"):
+                raise ValueError("SpeakerConfig: Syntax error on line %d: %s" % (i, l))
+            is_spk, is_def = f[0] == "speaker", f[1] == "default"
+            if is_def:
+                if (self.default_speaker if is_spk else self.default_utterance) is not None:
+                    raise ValueError("SpeakerConfig: Default %s configuration already defined" % f[0])
+                target: Dict[str, Dict[str, str]] = {}
+                if is_spk:
+                    self.default_speaker = target
+                else:
+                    self.default_utterance = target
+            else:
+                target = (self.speakers if is_spk else self.utterances).setdefault(f[1], {})
+            l = nonempty()
+            if l != "{":
+                raise ValueError("'{' expected in speaker config file: %s" % l)
+            while True:
+                l = nonempty()
+                if l is None or l == "}":
+                    break
+                parts = l.split(None, 1)
+                if len(parts) < 2:
+                    l = "feature " + l
+                    parts = l.split(None, 1)
+                elif parts[0] not in ("model", "feature"):
+                    raise ValueError("SpeakerConfig: Unknown module namespace at line %d" % i)
+                if parts[0] == "feature" and parts[1] not in self.chain.by_name:
+                    raise ValueError("SpeakerConfig: error on line %d: unknown module requested: %s" % (i, parts[1]))
+                if parts[0] == "model":
+                    if parts[1] != "cmllr":
+                        raise ValueError("SpeakerConfig: error on line %d: unknown model module requested: %s"
+                                         % (i, parts[1]))
+                    self.has_cmllr = True
+                # ModuleConfig::read
+                opts: Dict[str, str] = {}
+                if nonempty() != "{":
+                    raise ValueError("SpeakerConfig: Failed reading module parameters: '{' expected")
+                while True:
+                    v = nonempty()
+                    if v is None:
+                        raise ValueError("SpeakerConfig: Failed reading module parameters: unexpected end")
+                    if v == "}":
+                        break
+                    kv = v.split(None, 1)
+                    if len(kv) < 2:
+                        raise ValueError("value missing for option: " + v)
+                    if kv[0] in opts:
+                        raise ValueError("value redefined: " + v)
+                    opts[kv[0]] = kv[1].strip(" \t")
+                target.setdefault(l, opts)          # std::map::insert: first one stays
+
+    # -- ConstrainedMllr -----------------------------------------------------------
+    def _cmllr_set(self, opts: Dict[str, str]) -> None:
+        self.trans = {}
+        if opts.get("unitmode") in self.UNITS:
+            self.unit_mode = opts["unitmode"]
+        d = self.model.D
+        n = d * (d + 1)
+        k = 1
+        while ("w%d" % k) in opts:
+            parts = opts["w%d" % k].split()
+            if len(parts) < (n if self.unit_mode == "UNIT_NO" else n + 1):
+                raise ValueError("ERROR: not enough elements for matrix w%d" % k)
+            unit = tuple(parts[:len(parts) - n])
+            self.trans[unit] = np.array([str2float(x) for x in parts[len(parts) - n:]],
+                                        np.float64).reshape(d, d + 1)
+            k += 1
+        if self.unit_mode == "UNIT_NO" and len(self.trans) > 1:
+            raise ValueError("ERROR: speaker can only contain one transform when UNIT_NO (global transform) is set")
+
+    def _cmllr_get(self, opts: Dict[str, str]) -> None:
+        for k, unit in enumerate(sorted(self.trans), 1):
+            opts["w%d" % k] = " ".join(list(unit) + ["%g" % v for v in self.trans[unit].ravel()])
+        opts["unitmode"] = self.unit_mode
+
+    def _unit_gaussians(self, unit: Tuple[str, ...]) -> List[int]:
+        m = self.model
+        comps = lambda s: [int(g) for g in m.mix_idx[m.mix_off[s]:m.mix_off[s + 1]]]
+        if self.unit_mode == "UNIT_NO":
+            return list(range(m.G))
+        if self.unit_mode == "UNIT_GAUSSIAN":
+            return [int(e) for e in unit]
+        if self.unit_mode == "UNIT_MIX":
+            return [g for e in unit if e.lstrip("-").isdigit() for g in comps(int(e))]
+        out: List[int] = []
+        for label, states in self.hmms or []:
+            p1, p2 = label.rfind("-"), label.find("+")
+            if p1 >= 0 and p2 >= 0:
+                c = label[p1 + 1:p2] if p2 > p1 + 1 else ""
+            elif p1 >= 0:
+                c = label[p1 + 1:]
+            elif p2 >= 0:
+                c = label[:p2]
+            else:
+                c = label
+            if c in unit:
+                for s_ in states:
+                    out += comps(s_)
+        return out
+
+    def _load_transforms(self) -> None:
+        if self.has_cmllr and not self.cmllr_loaded:
+            self.g2t = np.full(self.model.G, -1, np.int32)
+            units = sorted(self.trans)               # std::map order over vector<string>
+            for t, unit in enumerate(units):
+                for g in self._unit_gaussians(unit):
+                    self.g2t[g] = t                  # later transforms override
+            d = self.model.D
+            self.W = np.array([self.trans[u] for u in units]).reshape(len(units), d, d + 1)
+            self.cmllr_loaded = True
+        self.trans_is_reset = False
+
+    # -- SpeakerConfig ---------------------------------------------------------------
+    def _set_modules(self, modules: Dict[str, Dict[str, str]]) -> None:
+        for key in sorted(modules):                  # std::map order over the key line
+            ns, name = key.split(None, 1)
+            if ns == "feature":
+                self.chain.set_parameters(name, modules[key])
+            else:
+                self._cmllr_set(modules[key])
+
+    def set_utterance(self, utterance_id: str = "") -> None:
+        if self.cur_utterance:
+            self._set_modules(self.utterances[self.cur_utterance])   # "retrieve" sets (reference quirk)
+        if not utterance_id:
+            if self.default_utterance is None:
+                raise ValueError("SpeakerConfig: Default utterance is required.")
+            self._set_modules(self.default_utterance)
+        else:
+            if utterance_id not in self.utterances:
+                if self.default_utterance is None:
+                    raise ValueError("SpeakerConfig: Unknown utterance %s, and default utterance settings are missing."
+                                     % utterance_id)
+                self.utterances[utterance_id] = {k: dict(v) for k, v in self.default_utterance.items()}
+            self._set_modules(self.utterances[utterance_id])
+        self.cur_utterance = utterance_id
+
+    def set_speaker(self, speaker_id: str = "") -> None:
+        if self.cur_speaker:
+            for key, opts in self.speakers[self.cur_speaker].items():
+                ns, name = key.split(None, 1)
+                if ns == "feature":
+                    self.chain.get_parameters(name, opts)
+                else:
+                    self._cmllr_get(opts)
+        if self.cur_utterance:
+            self.set_utterance("")
+        if speaker_id != self.cur_speaker and not self.trans_is_reset and self.has_cmllr:
+            self.cmllr_loaded, self.trans_is_reset = False, True
+        load_new = self.trans_is_reset
+        if not speaker_id:
+            if self.default_speaker is None:
+                raise ValueError("SpeakerConfig: No speaker defined, needs a default speaker.")
+            self._set_modules(self.default_speaker)
+        else:
+            if speaker_id not in self.speakers:
+                if self.default_speaker is None:
+                    raise ValueError("SpeakerConfig: Unknown speaker %s, and default speaker settings are missing."
+                                     % speaker_id)
+                self.speakers[speaker_id] = {k: dict(v) for k, v in self.default_speaker.items()}
+            self._set_modules(self.speakers[speaker_id])
+        self.cur_speaker = speaker_id
+        if load_new:
+            self._load_transforms()
+
+
+def score_adapted(model: DiagModel, frames: np.ndarray, g2t, W) -> np.ndarray:
+    """AdaptedGaussian scoring (aku/ModelModules.hh:172-173, 208-212): Gaussian g
+    evaluates A f + b of its transform and is scaled by |prod diag A|
+    (full_matrix_determinant, aku/LinearAlgebra.cc:73-86); then the usual mixture
+    sum and floor."""
+    x = np.asarray(frames, np.float64)
+    ll = model.gauss_loglik(x)
+    for t in range(len(W)):
+        A, b = W[t][:, 1:], W[t][:, 0]
+        with np.errstate(divide="ignore"):
+            adapted = model.gauss_loglik(x @ A.T + b) + np.log(abs(np.prod(np.diag(A))))
+        sel = np.flatnonzero(np.asarray(g2t) == t)
+        ll[:, sel] = adapted[:, sel]
+    lik = np.exp(ll)
+    out = np.empty((x.shape[0], model.S))
+    for s_ in range(model.S):
+        a, b_ = model.mix_off[s_], model.mix_off[s_ + 1]
+        out[:, s_] = np.log(np.maximum(lik[:, model.mix_idx[a:b_]] @ model.mix_w[a:b_], TINY_FOR_LOG))
+    return out
 
 
 # ---------------------------------------------------------------------------

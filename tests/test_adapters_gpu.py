@@ -74,6 +74,9 @@ def test_phone_probs_cli_batches_and_errors(world):
     assert r.returncode != 0 and "could not open x.gcl" in r.stderr
     r = subprocess.run([exe, "-b", world["base"], "-c", world["cfg"], "-r", world["recipe"], "-S", "x.spkc"],
                        capture_output=True, text=True)
+    assert r.returncode != 0 and "could not open x.spkc" in r.stderr
+    r = subprocess.run([exe, "-b", world["base"], "-c", world["cfg"], "-r", world["recipe"], "--sort-recipe"],
+                       capture_output=True, text=True)
     assert r.returncode != 0 and "not built" in r.stderr
     r = subprocess.run([exe, "-c", world["cfg"], "-r", world["recipe"]], capture_output=True, text=True)
     assert r.returncode != 0 and "Must give either --base" in r.stderr

@@ -273,3 +273,35 @@ def test_clustering_oracle_properties(oracle, tmp_path):
     assert n == 20 and rp[:-1] == pairs and rp[-1] == pairs[-1]
     with pytest.raises(ValueError, match="insensible"):
         oracle.read_gcl(path, 60)
+
+
+def test_speaker_config_oracle(oracle):
+    """The SpeakerConfig restatement on the CPU: module order, defaults for unknown
+    speakers, the "%g" read-back of a repeated speaker, stale model transforms."""
+    cfg = ("module\n{\n name a\n type audiofile\n sample_rate 16000\n}\n"
+           "module\n{\n name f\n type fft\n sources a\n}\nmodule\n{\n name v\n type vtln\n sources f\n}\n"
+           "module\n{\n name m\n type mel\n sources v\n}\nmodule\n{\n name n\n type normalization\n sources m\n}\n")
+    ch = oracle.FeatureChain(cfg)
+    from aaltoasr_amd import synth
+    om = oracle.DiagModel(*synth.make_model(D=21, G=40, S=4, comps=10))
+    w = np.hstack([np.zeros((21, 1)), np.eye(21)])
+    w[0, 0] = 0.123456789
+    text = ("speaker default\n{\n v\n {\n }\n}\n"
+            "speaker s1\n{\n feature v\n {\n  warp_factor 1.0123456\n }\n model cmllr\n {\n  unitmode UNIT_MIX\n"
+            "  w1 1 2 %s\n }\n}\n" % " ".join("%.9g" % x for x in w.ravel()))
+    sc = oracle.SpeakerConfig(ch, om)
+    sc.read_text(text)
+    sc.set_speaker("s1")
+    assert float(ch.by_name["v"].prm["warp"]) == float(np.float32(1.0123456))
+    assert set(np.flatnonzero(sc.g2t >= 0)) == set(range(10, 30))
+    assert sc.W[0][0, 0] == float(np.float32(0.123456789))       # str2float
+    sc.set_speaker("s1")                                           # read back through "%g"
+    assert float(ch.by_name["v"].prm["warp"]) == float(np.float32(1.01235))
+    assert sc.speakers["s1"]["model cmllr"]["w1"].split()[2] == "0.123457"
+    sc.set_speaker("nobody")                                       # defaults; cmllr block absent:
+    assert float(ch.by_name["v"].prm["warp"]) == 1.0               # the previous transform stays loaded
+    assert set(np.flatnonzero(sc.g2t >= 0)) == set(range(10, 30)) and "nobody" in sc.speakers
+    with pytest.raises(ValueError, match="Default utterance is required"):
+        sc.set_utterance("")
+    with pytest.raises(ValueError, match="Syntax error"):
+        oracle.SpeakerConfig(ch).read_text("spk x\n{\n}\n")

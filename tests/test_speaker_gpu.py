@@ -1,0 +1,312 @@
+"""Speaker / utterance configuration: aasr_spkc_* and
+phone_probs -S against the oracle's restatement of aku::SpeakerConfig
+(aku/SpeakerConfig.cc) driving the oracle feature chain and AdaptedGaussian
+scoring.  Same tolerances as the rest: 5e-6 on features, 1e-4 on state
+log-likelihoods."""
+import os
+import subprocess
+import wave
+
+import numpy as np
+import pytest
+
+from aaltoasr_amd import synth
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aaltoasr_amd", "lib", "bin")
+
+CFG = """module
+{
+  name audiofile
+  type audiofile
+  sample_rate 16000
+}
+module
+{
+  name fft
+  type fft
+  magnitude 0
+  sources audiofile
+}
+module
+{
+  name vtln
+  type vtln
+  sources fft
+}
+module
+{
+  name mel
+  type mel
+  sources vtln
+}
+module
+{
+  name mfcc
+  type dct
+  dim 12
+  sources mel
+}
+module
+{
+  name d1
+  type delta
+  sources mfcc
+}
+module
+{
+  name merged
+  type merge
+  sources mfcc d1
+}
+module
+{
+  name norm
+  type normalization
+  sources merged
+}
+module
+{
+  name mllr
+  type lin_transform
+  sources norm
+}
+"""
+D = 24
+
+
+def _nums(rng, n, lo, hi, digits=6):
+    return " ".join(("%%.%dg" % digits) % v for v in rng.uniform(lo, hi, n))
+
+
+def _matrix_text(rng, digits=6):
+    a = np.eye(D) * rng.uniform(0.95, 1.05, D) + 0.01 * rng.standard_normal((D, D))
+    b = 0.2 * rng.standard_normal(D)
+    w = np.hstack([b[:, None], a])
+    return " ".join(("%%.%dg" % digits) % v for v in w.ravel()), w
+
+
+def _spkc(digits=6):
+    rng = np.random.default_rng(77)
+    spk = {}
+    text = "speaker default\n{\n  vtln\n  {\n  }\n  feature norm\n  {\n  }\n  feature mllr\n  {\n  }\n}\n"
+    for name, warp in (("anna", 1.08), ("bert", 0.93)):
+        wtxt, _ = _matrix_text(rng, digits)
+        mean = _nums(rng, D, -1, 1, digits)
+        scale = _nums(rng, D, 0.9, 1.1, digits)
+        lin = " ".join(("%%.%dg" % digits) % v for v in (np.eye(D) + 0.01 * rng.standard_normal((D, D))).ravel())
+        text += ("speaker %s\n{\n  feature vtln\n  {\n    warp_factor %g\n  }\n  norm\n  {\n    mean %s\n    scale %s\n  }\n"
+                 "  feature mllr\n  {\n    matrix %s\n    bias %s\n  }\n  model cmllr\n  {\n    unitmode UNIT_NO\n    w1 %s\n  }\n}\n"
+                 % (name, warp, mean, scale, lin, _nums(rng, D, -0.1, 0.1, digits), wtxt))
+    # regression-class style speaker: two mixture groups + one phone group
+    w1, _ = _matrix_text(rng)
+    w2, _ = _matrix_text(rng)
+    text += ("speaker carl\n{\n  model cmllr\n  {\n    unitmode UNIT_MIX\n    w1 0 1 2 3 4 5 6 7 %s\n    w2 6 7 8 9 10 %s\n  }\n}\n"
+             % (w1, w2))
+    text += "utterance default\n{\n  vtln\n  {\n  }\n}\nutterance u7\n{\n  vtln\n  {\n    warp_factor 1.02\n  }\n}\n"
+    return text
+
+
+def _write_wav(path, pcm, rate=16000):
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(rate)
+        w.writeframes(pcm.astype("<i2").tobytes())
+
+
+@pytest.fixture(scope="module")
+def world(capi, oracle, tmp_path_factory):
+    d = tmp_path_factory.mktemp("spk")
+    model = list(synth.make_model(D=D, G=128, S=16, comps=8, var_lo=1.0, var_hi=6.0))
+    # put the synthetic pool where this chain's features live
+    fea = oracle.FeatureChain(CFG).generate(synth.make_audio(24000, seed=90), 0, 180)
+    mu, sd = fea.mean(0), fea.std(0) + 1e-3
+    model[0] = mu + 0.7 * sd * model[0]
+    model[1] = sd * sd * model[1]
+    base = str(d / "m")
+    oracle.write_gk(base + ".gk", model[0], model[1])
+    oracle.write_mc(base + ".mc", model[2], model[3], model[4])
+    oracle.write_ph(base + ".ph", 16)
+    mean, var = oracle.read_gk(base + ".gk")
+    cfg_path = str(d / "f.cfg")
+    open(cfg_path, "w").write(CFG)
+    spkc_path = str(d / "s.spkc")
+    open(spkc_path, "w").write(_spkc())
+    pcms = [synth.make_audio(n, seed=90 + i) for i, n in enumerate([24000, 20000, 30000, 18000, 26000])]
+    # (speaker, utterance) per recipe line: repeated and interleaved speakers, an unknown
+    # speaker (gets the defaults), an utterance entry
+    who = [("anna", ""), ("anna", ""), ("bert", "u7"), ("zoe", ""), ("anna", "")]
+    lines = []
+    for i, p in enumerate(pcms):
+        _write_wav(str(d / ("a%d.wav" % i)), p)
+        l = "audio=%s lna=%s speaker=%s" % (d / ("a%d.wav" % i), d / ("a%d.lna" % i), who[i][0])
+        if who[i][1]:
+            l += " utterance=" + who[i][1]
+        lines.append(l)
+    recipe = str(d / "r.recipe")
+    open(recipe, "w").write("\n".join(lines) + "\n")
+    return dict(dir=d, base=base, cfg=cfg_path, spkc=spkc_path, pcms=pcms, who=who, recipe=recipe,
+                model=(mean, var, model[2], model[3], model[4]))
+
+
+def _oracle_lna(oracle, world, spkc_text=None):
+    """What the reference loop produces for every recipe line (4-byte LNA values)."""
+    ch = oracle.FeatureChain(CFG)
+    om = oracle.DiagModel(*world["model"])
+    sc = oracle.SpeakerConfig(ch, om)
+    sc.read_text(spkc_text if spkc_text is not None else open(world["spkc"]).read())
+    outs = []
+    # Recipe::read keeps a key's value on later lines that do not repeat it
+    # (aku/Recipe.cc:31,82-90): the utterance=u7 of line 3 also applies to lines 4 and 5
+    infos = oracle.recipe_read(open(world["recipe"]).read())
+    assert [i.utterance_id for i in infos] == ["", "", "u7", "u7", "u7"]
+    for pcm, info in zip(world["pcms"], infos):
+        spk, utt = info.speaker_id, info.utterance_id
+        sc.set_speaker(spk)
+        if utt:
+            sc.set_utterance(utt)
+        n = ch.num_frames(len(pcm))
+        fea = ch.generate(pcm, 0, n)
+        ll = oracle.score_adapted(om, fea, sc.g2t, sc.W)
+        outs.append((fea, ll))
+    return outs
+
+
+def test_recipe_with_speakers_matches_oracle(capi, oracle, world):
+    want = _oracle_lna(oracle, world)
+    ft = capi.Feat.from_file(world["cfg"])
+    gm = capi.Gmm.from_files(world["base"] + ".gk", world["base"] + ".mc", world["base"] + ".ph")
+    sc = capi.SpeakerConfig(ft, gm)
+    sc.read_file(world["spkc"])
+    out = world["dir"] / "eng"
+    os.makedirs(out)
+    st = capi.run_recipe(ft, gm, world["recipe"], lnabytes=4, normalize=False, afname=True,
+                         out_dir=str(out), speakers=sc)
+    assert st.utterances == 5
+    for i, (fea, ll) in enumerate(want):
+        got = oracle.lna_decode(open(out / ("a%d.lna" % i), "rb").read())
+        assert got.shape == ll.shape
+        ok = ll > -85
+        assert ok.mean() > 0.2 and np.abs(got - ll)[ok].max() <= 1e-4, i
+    # lines 0 and 1 share every setting (the file is written with 6 digits, so the "%g"
+    # read-back changes nothing): they stayed in one device batch
+    assert sc.num_changes > 0
+
+
+def test_direct_calls_and_feature_parity(capi, oracle, world):
+    ch = oracle.FeatureChain(CFG)
+    om = oracle.DiagModel(*world["model"])
+    osc = oracle.SpeakerConfig(ch, om)
+    osc.read_text(open(world["spkc"]).read())
+    ft = capi.Feat.from_file(world["cfg"])
+    gm = capi.Gmm.from_files(world["base"] + ".gk", world["base"] + ".mc", world["base"] + ".ph")
+    sc = capi.SpeakerConfig(ft)          # phone_probs reads the speaker file before the model
+    sc.read_file(world["spkc"])
+    sc.set_model(gm)
+    pcm = world["pcms"][0]
+    for spk, utt in [("bert", ""), ("carl", ""), ("carl", "u7"), ("", ""), ("anna", "x-unknown")]:
+        osc.set_speaker(spk)
+        sc.set_speaker(spk)
+        if utt:
+            osc.set_utterance(utt)
+            sc.set_utterance(utt)
+        fea = ch.generate(pcm, -3, 60)
+        got = ft.run(pcm, -3, 60, dtype=np.float64)
+        assert np.abs(got - fea).max() <= 5e-6, (spk, utt)
+        ll = oracle.score_adapted(om, fea.astype(np.float32), osc.g2t, osc.W)
+        assert np.abs(gm.score(fea.astype(np.float32)) - ll).max() <= 1e-4, (spk, utt)
+    # carl: mixtures 6 and 7 are claimed by both transforms; the later key ("6 7 8 9 10")
+    # sorts after ("0 1 ... 7") and wins
+    osc.set_speaker("carl")
+    m = om
+    assert set(osc.g2t[m.mix_idx[m.mix_off[6]:m.mix_off[8]]]) == {1}
+    assert set(osc.g2t[m.mix_idx[m.mix_off[0]:m.mix_off[6]]]) == {0}
+    assert (osc.g2t[m.mix_idx[m.mix_off[11]:]] == -1).all()
+
+
+def test_percent_g_round_trip_of_a_repeated_speaker(capi, oracle, world):
+    """Parameters with more than 6 significant digits: the second set_speaker of the same
+    speaker applies the "%g" read-back (aku/SpeakerConfig.cc:242-243, 322-340)."""
+    text = _spkc(digits=9)
+    ch = oracle.FeatureChain(CFG)
+    osc = oracle.SpeakerConfig(ch, oracle.DiagModel(*world["model"]))
+    osc.read_text(text)
+    ft = capi.Feat.from_file(world["cfg"])
+    gm = capi.Gmm.from_files(world["base"] + ".gk", world["base"] + ".mc", world["base"] + ".ph")
+    sc = capi.SpeakerConfig(ft, gm)
+    sc.read_text(text)
+    pcm = world["pcms"][1]
+    feats = []
+    for k in range(3):
+        osc.set_speaker("anna")
+        sc.set_speaker("anna")
+        want = ch.generate(pcm, 0, 40)
+        got = ft.run(pcm, 0, 40, dtype=np.float64)
+        assert np.abs(got - want).max() <= 5e-6, k
+        feats.append(got)
+    assert np.abs(feats[1] - feats[0]).max() > 1e-7     # the round trip moved the parameters
+    assert np.array_equal(feats[2], feats[1])            # and is idempotent afterwards
+
+
+def test_errors_follow_the_reference(capi, world):
+    ft = capi.Feat.from_file(world["cfg"])
+    sc = capi.SpeakerConfig(ft)
+    with pytest.raises(capi.AasrError, match="Syntax error on line 1"):
+        sc.read_text("speakers anna\n{\n}\n")
+    with pytest.raises(capi.AasrError, match="unknown module requested: nosuch"):
+        sc.read_text("speaker a\n{\n  nosuch\n  {\n  }\n}\n")
+    with pytest.raises(capi.AasrError, match="Unknown module namespace"):
+        sc.read_text("speaker a\n{\n  decoder x\n  {\n  }\n}\n")
+    with pytest.raises(capi.AasrError, match="unknown model module requested"):
+        sc.read_text("speaker a\n{\n  model mllr\n  {\n  }\n}\n")
+    sc2 = capi.SpeakerConfig(ft)
+    sc2.read_text("speaker a\n{\n  norm\n  {\n    mean %s\n    var %s\n  }\n}\n"
+                  % (" ".join(["0"] * D), " ".join(["4"] * D)))
+    with pytest.raises(capi.AasrError, match="needs a default speaker"):
+        sc2.set_speaker("")
+    with pytest.raises(capi.AasrError, match="Unknown speaker b, and default speaker settings are missing"):
+        sc2.set_speaker("b")
+    sc2.set_speaker("a")
+    # the read-back added `scale` next to the file's `var`: the reference refuses the block
+    with pytest.raises(capi.AasrError, match="Both scale and var"):
+        sc2.set_speaker("a")
+    with pytest.raises(capi.AasrError, match="Default utterance is required"):
+        capi.SpeakerConfig(ft).set_utterance("")
+
+
+def test_phone_probs_cli_speakers(capi, oracle, world):
+    out = world["dir"] / "cli"
+    os.makedirs(out)
+    r = subprocess.run([os.path.join(BIN, "phone_probs"), "-b", world["base"], "-c", world["cfg"],
+                        "-r", world["recipe"], "-a", "-o", str(out), "--lnabytes=4", "-N",
+                        "-S", world["spkc"]], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    want = _oracle_lna(oracle, world)
+    for i, (fea, ll) in enumerate(want):
+        got = oracle.lna_decode(open(out / ("a%d.lna" % i), "rb").read())
+        ok = ll > -85
+        assert np.abs(got - ll)[ok].max() <= 1e-4, i
+
+
+def test_reference_style_loop_with_speaker_config(capi, oracle, world):
+    """phone_probs.cc's calling sequence (read_speaker_file before the model, set_speaker /
+    set_utterance before gen.open, then the per-frame loop) on the aku adapter classes."""
+    out = str(world["dir"] / "loop.lna")
+    r = subprocess.run([os.path.join(BIN, "aku_adapter_check"), world["cfg"], world["base"],
+                        str(world["dir"] / "a2.wav"), out, "4", "spkc", world["spkc"], "bert", "u7"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    ch = oracle.FeatureChain(CFG)
+    om = oracle.DiagModel(*world["model"])
+    sc = oracle.SpeakerConfig(ch, om)
+    sc.read_text(open(world["spkc"]).read())
+    sc.set_speaker("bert")
+    sc.set_utterance("u7")
+    pcm = world["pcms"][2]
+    fea = ch.generate(pcm, 0, ch.num_frames(len(pcm)))
+    lik = np.exp(oracle.score_adapted(om, fea, sc.g2t, sc.W))
+    want, _ = oracle.lna_encode(lik, True, 4)
+    got = oracle.lna_decode(open(out, "rb").read())
+    ok = want > -60
+    assert got.shape == want.shape and np.abs(got - want)[ok].max() <= 1e-4
