@@ -98,6 +98,11 @@ def _declare(L: C.CDLL) -> None:
     L.aasr_feat_run_f64.argtypes = [vp, vp, i64, i32, i32, cp, vp]
     L.aasr_feat_run_batch_dev.argtypes = [vp, vp, vp, vp, i32, vp, vp]
     L.aasr_feat_set_parameters.argtypes = [vp, cp, cp]
+    L.aasr_feat_run_features.argtypes = [vp, vp, i64, i32, i32, cp, vp]
+    L.aasr_feat_run_features_f64.argtypes = [vp, vp, i64, i32, i32, cp, vp]
+    L.aasr_feat_input_is_features.argtypes = [vp]
+    L.aasr_feat_pre_legacy.argtypes = [vp]
+    L.aasr_feat_input_dim.argtypes = [vp]
     L.aasr_gmm_create_diag.argtypes = [i32, i32, vp, vp, i32, vp, vp, vp, pvp]
     L.aasr_gmm_create_full.argtypes = [i32, i32, vp, vp, i32, vp, vp, vp, pvp]
     L.aasr_gmm_create_from_files.argtypes = [cp, cp, cp, pvp]
@@ -108,6 +113,8 @@ def _declare(L: C.CDLL) -> None:
     L.aasr_gmm_num_gaussians.argtypes = [vp]
     L.aasr_gmm_expanded_rows.argtypes = [vp]
     L.aasr_gmm_expanded_rows.restype = i64
+    L.aasr_gmm_write_cache.argtypes = [vp, cp]
+    L.aasr_gmm_create_from_cache.argtypes = [cp, C.POINTER(vp)]
     L.aasr_gmm_set_precision.argtypes = [vp, C.c_int]
     L.aasr_gmm_set_cmllr.argtypes = [vp, i32, vp, vp]
     L.aasr_gmm_read_clustering.argtypes = [vp, cp]
@@ -208,6 +215,15 @@ class Gmm:
         check(lib().aasr_gmm_create_from_files(gk.encode(), mc.encode(),
                                                ph.encode() if ph else None, C.byref(h)))
         return cls(h.value)
+
+    @classmethod
+    def from_cache(cls, path: str) -> "Gmm":
+        h = C.c_void_p()
+        check(lib().aasr_gmm_create_from_cache(path.encode(), C.byref(h)))
+        return cls(h.value)
+
+    def write_cache(self, path: str) -> None:
+        check(lib().aasr_gmm_write_cache(self._h, path.encode()))
 
     def close(self) -> None:
         if self._h:
@@ -385,6 +401,17 @@ class Feat:
         out = np.empty((n_frames, dim), dtype)
         fn = lib().aasr_feat_run if dtype == np.float32 else lib().aasr_feat_run_f64
         check(fn(self._h, _ptr(pcm), len(pcm), first_frame, n_frames,
+                 module.encode() if module else None, _ptr(out)))
+        return out
+
+    def run_features(self, frames: np.ndarray, first_frame: int, n_frames: int,
+                     module: Optional[str] = None, dtype=np.float32) -> np.ndarray:
+        """Graphs with a `pre` base module: float feature frames [N x dim] in."""
+        frames = np.ascontiguousarray(frames, np.float32)
+        dim = self.module_dim(module) if module else self.dim
+        out = np.empty((n_frames, dim), dtype)
+        fn = lib().aasr_feat_run_features if dtype == np.float32 else lib().aasr_feat_run_features_f64
+        check(fn(self._h, _ptr(frames), frames.size, first_frame, n_frames,
                  module.encode() if module else None, _ptr(out)))
         return out
 

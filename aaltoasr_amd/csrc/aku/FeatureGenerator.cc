@@ -4,9 +4,7 @@
 #include <climits>
 #include <cstring>
 
-namespace aasr {
-std::vector<int16_t> read_audio_file(const std::string &path, bool force_raw, int expect_rate);
-}
+#include "../pipeline.h"
 
 namespace aku {
 
@@ -44,10 +42,20 @@ void FeatureGenerator::close_configuration() {
 
 void FeatureGenerator::open(const std::string &filename) {
   if (!m_feat) throw std::string("no feature modules defined");
-  try {
-    m_pcm = aasr::read_audio_file(filename, false, aasr_feat_sample_rate(m_feat));
-  } catch (...) {
-    throw std::string("AudioReader::open(): could not open file:") + filename;
+  if (aasr_feat_input_is_features(m_feat)) {
+    // PreModule::set_fname / set_file (aku/FeatureModules.cc:588-631)
+    try {
+      m_pcm = aasr::read_feature_file(filename, aasr_feat_input_dim(m_feat),
+                                      aasr_feat_pre_legacy(m_feat) != 0);
+    } catch (aasr::Error &e) {
+      throw std::string(e.msg);
+    }
+  } else {
+    try {
+      m_pcm = aasr::read_audio_file(filename, false, aasr_feat_sample_rate(m_feat));
+    } catch (...) {
+      throw std::string("AudioReader::open(): could not open file:") + filename;
+    }
   }
   m_open = true;
   m_block_count = 0;
@@ -60,6 +68,17 @@ void FeatureGenerator::open(FILE *file, bool) {
   char buf[65536];
   size_t n;
   while ((n = fread(buf, 1, sizeof buf, file)) > 0) data.insert(data.end(), buf, buf + n);
+  if (aasr_feat_input_is_features(m_feat)) {
+    try {
+      m_pcm = aasr::parse_feature_data(data, aasr_feat_input_dim(m_feat), aasr_feat_pre_legacy(m_feat) != 0);
+    } catch (aasr::Error &e) {
+      throw std::string(e.msg);
+    }
+    m_open = true;
+    m_block_count = 0;
+    m_eof_on_last_frame = false;
+    return;
+  }
   // RIFF header handling lives in read_audio_file; streams carry raw PCM16 or WAV
   size_t body = 0;
   if (data.size() >= 44 && !memcmp(data.data(), "RIFF", 4) && !memcmp(data.data() + 8, "WAVE", 4)) {

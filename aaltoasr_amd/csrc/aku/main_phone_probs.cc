@@ -26,7 +26,7 @@ static void die(const std::string &msg) {
 
 int main(int argc, char *argv[]) {
   std::string base, gk, mc, ph, cfg, recipe, out_dir;
-  std::string clusters, speakers;
+  std::string clusters, speakers, model_cache;
   double eval_minc = 0.0, eval_ming = 0.1;  // defaults of aku/phone_probs.cc:74-75
   int lnabytes = 2, info = 0, batch = 0, bindex = 0, device = -1;
   bool afname = false, no_overwrite = false, no_norm = false, batch_set = false, bindex_set = false;
@@ -41,7 +41,8 @@ int main(int argc, char *argv[]) {
       {"eval-ming", required_argument, 0, 3}, {"sort-recipe", no_argument, 0, 4},
       {"no-normalization", no_argument, 0, 'N'}, {"batch", required_argument, 0, 'B'},
       {"bindex", required_argument, 0, 'I'},  {"info", required_argument, 0, 'i'},
-      {"device", required_argument, 0, 5},    {0, 0, 0, 0}};
+      {"device", required_argument, 0, 5},    {"model-cache", required_argument, 0, 6},
+      {0, 0, 0, 0}};
   int c;
   while ((c = getopt_long(argc, argv, "hb:g:m:p:c:r:o:anS:C:NB:I:i:", opts, nullptr)) != -1) {
     switch (c) {
@@ -51,7 +52,7 @@ int main(int argc, char *argv[]) {
                "  -r RECIPE  recipe file\n  -o DIR   output directory\n  --lnabytes=2|4\n"
                "  -a  use audio file name\n  -n  no overwrite\n  -N  no normalization\n"
                "  -B n -I k  batch k of n\n  -i level  info\n  --device=N  GPU ordinal\n"
-               "  -S SPKC  speaker configuration file\n  -C GCL  Gaussian clustering file\n  --eval-minc=R  minimum ratio of top clusters\n"
+               "  --model-cache=FILE  binary model image (written on first use)\n  -S SPKC  speaker configuration file\n  -C GCL  Gaussian clustering file\n  --eval-minc=R  minimum ratio of top clusters\n"
                "  --eval-ming=R  minimum ratio of Gaussians to evaluate\n");
         return 0;
       case 'b': base = optarg; break;
@@ -69,6 +70,7 @@ int main(int argc, char *argv[]) {
       case 'I': bindex = atoi(optarg); bindex_set = true; break;
       case 'i': info = atoi(optarg); break;
       case 5: device = atoi(optarg); break;
+      case 6: model_cache = optarg; break;
       case 'S': speakers = optarg; break;
       case 'C': clusters = optarg; break;
       case 2: eval_minc = atof(optarg); break;
@@ -96,8 +98,15 @@ int main(int argc, char *argv[]) {
   aasr_feat *feat = nullptr;
   aasr_gmm *gmm = nullptr;
   if (aasr_feat_create(ss.str().c_str(), &feat) != AASR_OK) die(aasr_last_error());
-  if (aasr_gmm_create_from_files(gk.c_str(), mc.c_str(), ph.c_str(), &gmm) != AASR_OK)
-    die(aasr_last_error());
+  // --model-cache FILE (new): binary image of the parsed model; created on the first run
+  if (!model_cache.empty() && aasr_gmm_create_from_cache(model_cache.c_str(), &gmm) == AASR_OK) {
+    if (info > 0) printf("Model read from cache %s\n", model_cache.c_str());
+  } else {
+    if (aasr_gmm_create_from_files(gk.c_str(), mc.c_str(), ph.c_str(), &gmm) != AASR_OK)
+      die(aasr_last_error());
+    if (!model_cache.empty() && aasr_gmm_write_cache(gmm, model_cache.c_str()) != AASR_OK)
+      fprintf(stderr, "WARNING: could not write model cache: %s\n", aasr_last_error());
+  }
   if (!clusters.empty()) {
     // aku/phone_probs.cc:112-117
     if (aasr_gmm_read_clustering(gmm, clusters.c_str()) != AASR_OK) die(aasr_last_error());

@@ -161,6 +161,30 @@ aasr_status aasr_gmm_create_from_files(const char *gk_path, const char *mc_path,
   });
 }
 
+aasr_status aasr_gmm_write_cache(const aasr_gmm *h, const char *cache_path) {
+  return guarded([&] {
+    if (!h || !cache_path) raise(AASR_ERR_INVALID, "aasr_gmm_write_cache: null argument");
+    write_model_cache(h->host, cache_path);
+  });
+}
+
+aasr_status aasr_gmm_create_from_cache(const char *cache_path, aasr_gmm **out) {
+  return guarded([&] {
+    if (!out || !cache_path) raise(AASR_ERR_INVALID, "aasr_gmm_create_from_cache: null argument");
+    *out = nullptr;
+    HostModel m = read_model_cache(cache_path);
+    aasr_gmm *g = new aasr_gmm();
+    try {
+      AASR_HIP(hipGetDevice(&g->device));
+      gmm_build(g, m);
+    } catch (...) {
+      delete g;
+      throw;
+    }
+    *out = g;
+  });
+}
+
 void aasr_gmm_destroy(aasr_gmm *h) { delete h; }
 int aasr_gmm_dim(const aasr_gmm *h) { return h ? h->dim : -1; }
 int aasr_gmm_num_states(const aasr_gmm *h) { return h ? (int)h->S : -1; }

@@ -19,7 +19,7 @@ namespace aasr {
 enum ModType {
   MOD_AUDIOFILE, MOD_FFT, MOD_MEL, MOD_POWER, MOD_DCT, MOD_DELTA,
   MOD_NORMALIZATION, MOD_LIN_TRANSFORM, MOD_MERGE, MOD_MEAN_SUBTRACTOR,
-  MOD_CONCAT, MOD_VTLN, MOD_SR_NORM, MOD_MEL_POWER, MOD_QUANTEQ
+  MOD_CONCAT, MOD_VTLN, MOD_SR_NORM, MOD_MEL_POWER, MOD_QUANTEQ, MOD_PRE
 };
 
 // One "{ key value ... }" block (aku::ModuleConfig, aku/ModuleConfig.cc).
@@ -60,6 +60,10 @@ struct FeatModule {
   // audiofile
   int sample_rate = 0, width = 0, copy_borders = 1;
   float emph = 0.97f, frame_rate = 125.0f, advance = 0.0f;
+  // pre (PreModule, aku/FeatureModules.cc:572-755): the base module reads float
+  // feature frames instead of audio.  Its input travels through the same int16
+  // buffers as audio, two units per float.
+  int legacy_file = 0;
   // fft
   int magnitude = 1, take_log = 0;
   FftPlan fft;

@@ -28,6 +28,8 @@ template <class T>
 void run_host(aasr_feat *h, const int16_t *pcm, int64_t n_samples, int32_t first_frame,
               int32_t n_frames, const char *module_name, T *out) {
   if (!h || !pcm || (n_frames > 0 && !out)) raise(AASR_ERR_INVALID, "aasr_feat_run: null argument");
+  if (h->mods[0].type == MOD_PRE && (n_samples & 1))
+    raise(AASR_ERR_INVALID, "aasr_feat_run: a pre module takes float input (aasr_feat_run_features)");
   if (n_frames < 0 || n_samples < 0) raise(AASR_ERR_INVALID, "aasr_feat_run: negative size");
   if (n_frames == 0) return;
   const int target = resolve_target(h, module_name);
@@ -92,6 +94,31 @@ aasr_status aasr_feat_run_f64(aasr_feat *h, const int16_t *pcm, int64_t n_sample
                               double *out) {
   return guarded([&] { run_host<double>(h, pcm, n_samples, first_frame, n_frames, module_name, out); });
 }
+
+// PreModule input: float frames [n_values / dim x dim] instead of audio
+aasr_status aasr_feat_run_features(aasr_feat *h, const float *features, int64_t n_values,
+                                   int32_t first_frame, int32_t n_frames,
+                                   const char *module_name, float *out) {
+  return guarded([&] {
+    if (h && h->mods[0].type != MOD_PRE)
+      raise(AASR_ERR_INVALID, "aasr_feat_run_features: the first module is not a pre module");
+    run_host<float>(h, (const int16_t *)features, 2 * n_values, first_frame, n_frames, module_name, out);
+  });
+}
+
+aasr_status aasr_feat_run_features_f64(aasr_feat *h, const float *features, int64_t n_values,
+                                       int32_t first_frame, int32_t n_frames,
+                                       const char *module_name, double *out) {
+  return guarded([&] {
+    if (h && h->mods[0].type != MOD_PRE)
+      raise(AASR_ERR_INVALID, "aasr_feat_run_features: the first module is not a pre module");
+    run_host<double>(h, (const int16_t *)features, 2 * n_values, first_frame, n_frames, module_name, out);
+  });
+}
+
+int aasr_feat_input_is_features(const aasr_feat *h) { return h && h->mods[0].type == MOD_PRE ? 1 : 0; }
+int aasr_feat_pre_legacy(const aasr_feat *h) { return h && h->mods[0].type == MOD_PRE ? h->mods[0].legacy_file : 0; }
+int aasr_feat_input_dim(const aasr_feat *h) { return h ? h->mods[0].dim : -1; }
 
 aasr_status aasr_feat_run_dev(aasr_feat *h, const int16_t *d_pcm, int64_t n_samples,
                               int32_t first_frame, int32_t n_frames, float *d_out, void *stream) {

@@ -408,6 +408,21 @@ static void configure(aasr_feat *h, FeatModule &m, const ModuleConfig &c) {
         raise(AASR_ERR_INVALID, "AudioFileModule: invalid window (%d samples, advance %g)", m.width, m.advance);
       break;
     }
+    case MOD_PRE: {
+      // PreModule::set_module_config (aku/FeatureModules.cc:672-690)
+      m.frame_rate = 125;
+      m.sample_rate = 16000;
+      m.legacy_file = 0;
+      c.get("sample_rate", m.sample_rate);
+      c.get("frame_rate", m.frame_rate);
+      c.get("legacy_file", m.legacy_file);
+      if (!c.get("dim", m.dim)) raise(AASR_ERR_INVALID, "PreModule: Must set dimension");
+      if (m.legacy_file && m.dim > 127)
+        raise(AASR_ERR_INVALID, "PreModule: legacy files store the dimension in one signed byte");
+      m.width = 0;
+      m.advance = m.sample_rate / m.frame_rate;
+      break;
+    }
     case MOD_FFT: {
       // FFTModule::set_module_config (aku/FeatureModules.cc:475-518)
       m.magnitude = 1;
@@ -683,23 +698,17 @@ aasr_feat *feat_create(const std::string &text) {
           {"normalization", MOD_NORMALIZATION}, {"lin_transform", MOD_LIN_TRANSFORM},
           {"merge", MOD_MERGE}, {"mean_subtractor", MOD_MEAN_SUBTRACTOR},
           {"concat", MOD_CONCAT}, {"vtln", MOD_VTLN}, {"sr_norm", MOD_SR_NORM},
-          {"mel_power", MOD_MEL_POWER}, {"quanteq", MOD_QUANTEQ}};
+          {"mel_power", MOD_MEL_POWER}, {"quanteq", MOD_QUANTEQ}, {"pre", MOD_PRE}};
       bool found = false;
       for (auto &k : kinds)
         if (type == k.s) {
           m.type = k.t;
           found = true;
         }
-      if (!found) {
-        static const char *later[] = {"pre"};
-        for (auto *l : later)
-          if (type == l)
-            raise(AASR_ERR_UNSUPPORTED,
-                  "module type '%s' exists in aku but is not built in this engine yet", l);
-        raise(AASR_ERR_INVALID, "Unknown module type '%s'", type.c_str());
-      }
+      if (!found) raise(AASR_ERR_INVALID, "Unknown module type '%s'", type.c_str());
       const bool is_first = h->mods.size() == 1;
-      if (is_first && m.type != MOD_AUDIOFILE)
+      const bool is_base = m.type == MOD_AUDIOFILE || m.type == MOD_PRE;
+      if (is_first && !is_base)
         raise(AASR_ERR_INVALID, "first module should be a base module");
       if (h->by_name.count(name))
         raise(AASR_ERR_INVALID, "multiple definitions of module name: %s", name.c_str());
@@ -708,7 +717,7 @@ aasr_feat *feat_create(const std::string &text) {
         raise(AASR_ERR_INVALID, "can not define sources for the first module");
       if (!is_first && !has_sources)
         raise(AASR_ERR_INVALID, "sources not defined for module: %s", name.c_str());
-      if (!is_first && m.type == MOD_AUDIOFILE)
+      if (!is_first && is_base)
         raise(AASR_ERR_INVALID, "base module FFT can not have sources");
       if (has_sources) {
         std::vector<std::string> srcs;
@@ -737,6 +746,9 @@ aasr_feat *feat_create(const std::string &text) {
 // AudioFileModule::last_frame (aku/FeatureModules.cc:305-308): int/float, truncated
 int feat_last_frame(const aasr_feat *h, int64_t n_samples) {
   const FeatModule &a = h->mods[0];
+  // PreModule::last_frame (aku/FeatureModules.cc:649-660): whole frames in the file - 1;
+  // n_samples counts int16 units, two per float
+  if (a.type == MOD_PRE) return (int)(n_samples / 2 / a.dim) - 1;
   return (int)(((int)n_samples - a.width - 1) / a.advance);
 }
 

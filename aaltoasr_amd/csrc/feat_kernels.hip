@@ -99,6 +99,23 @@ __global__ void k_audio_frames(DevBatch b, const int16_t *__restrict__ pcm, Audi
   dst[idx] = (double)preemph_sample(p, ns, ws + j, ap.emph);
 }
 
+// PreModule::generate (aku/FeatureModules.cc:705-755): frame t of the feature file;
+// frames before 0 repeat frame 0, frames from the end of the file on repeat the last
+// one.  `in` is the float view of the input buffer (pcm_off counts int16 units).
+__global__ void k_pre_frames(DevBatch b, const float *__restrict__ in, int dim, int L, int R,
+                             int64_t rows, double *__restrict__ dst) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * dim) return;
+  int64_t r = idx / dim;
+  int j = (int)(idx - r * dim);
+  int u = find_utt(b, r, L + R);
+  int frame = b.first[u] - L + (int)(r - (b.frame_off[u] + (int64_t)u * (L + R)));
+  const int eof = b.eof_frame[u];
+  if (frame < 0) frame = 0;
+  if (frame >= eof) frame = eof - 1;
+  dst[idx] = (double)in[b.pcm_off[u] / 2 + (int64_t)frame * dim + j];
+}
+
 struct FftPrm {
   int nc, ns;
   int radix[16], sublen[16];
@@ -632,6 +649,12 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
   std::vector<int32_t> eof(n);
   for (int u = 0; u < n; u++) {
     int64_t ns = ub.pcm_off[u + 1] - ub.pcm_off[u];
+    if (base.type == MOD_PRE) {
+      if ((ub.pcm_off[u] & 1) || ns / 2 / base.dim < 1)
+        raise(AASR_ERR_SHORT_AUDIO, "PreModule: Could not read the file");
+      eof[u] = (int32_t)(ns / 2 / base.dim);
+      continue;
+    }
     if (ns < base.width + 1)
       raise(AASR_ERR_SHORT_AUDIO, "audio shorter than frame");
     if (ns > INT32_MAX)
@@ -701,6 +724,10 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
     SrcMap sm = s0 >= 0 ? map_of(i, s0) : SrcMap{0, 0};
     const int64_t nelem = rows * m.dim;
     switch (m.type) {
+      case MOD_PRE:
+        hipLaunchKernelGGL(k_pre_frames, dim3(grid_for(nelem)), dim3(256), 0, stream, db,
+                           (const float *)d_pcm, m.dim, L[i], R[i], rows, dst);
+        break;
       case MOD_AUDIOFILE:
         hipLaunchKernelGGL(k_audio_frames, dim3(grid_for(nelem)), dim3(256), 0, stream, db, d_pcm,
                            ap, L[i], R[i], rows, dst);

@@ -50,10 +50,14 @@ struct HostModel {
   int64_t S = 0;
   std::vector<int32_t> mix_off;         // [S+1]
   std::vector<int32_t> mix_idx;         // [K]
-  std::vector<double> mix_w;            // [K] (as read; normalised in build)
+  std::vector<double> mix_w;            // [K] (as read; normalised by the first build)
+  bool weights_normalized = false;      // Mixture::normalize_weights already applied
 };
 
 HostModel read_model_files(const char *gk, const char *mc, const char *ph);
+// model_cache.cc: parsed model <-> one binary blob (magic, sizes, arrays, FNV-1a checksum)
+void write_model_cache(const HostModel &m, const char *path);
+HostModel read_model_cache(const char *path);
 
 // Rows of the streamed operand are processed in tiles of TILE_ROWS; the
 // epilogue reduces them in chunks of CHUNK_ROWS (one 32x32 MFMA block).

@@ -280,11 +280,15 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
     if (m.mix_idx[k] < 0 || m.mix_idx[k] >= m.G)
       raise(AASR_ERR_INVALID, "mixture component %zu points at Gaussian %d outside the pool of %ld",
             k, m.mix_idx[k], (long)m.G);
-  // Mixture::normalize_weights (Distributions.cc:2067-2075)
-  for (int64_t s = 0; s < m.S; s++) {
-    double sum = 0;
-    for (int32_t k = m.mix_off[s]; k < m.mix_off[s + 1]; k++) sum += m.mix_w[k];
-    for (int32_t k = m.mix_off[s]; k < m.mix_off[s + 1]; k++) m.mix_w[k] /= sum;
+  // Mixture::normalize_weights (Distributions.cc:2067-2075) -- once: a rebuild (CMLLR,
+  // model cache) must not divide by a sum that is already 1 +- 1 ulp
+  if (!m.weights_normalized) {
+    for (int64_t s = 0; s < m.S; s++) {
+      double sum = 0;
+      for (int32_t k = m.mix_off[s]; k < m.mix_off[s + 1]; k++) sum += m.mix_w[k];
+      for (int32_t k = m.mix_off[s]; k < m.mix_off[s + 1]; k++) m.mix_w[k] /= sum;
+    }
+    m.weights_normalized = true;
   }
   // centring pivot: per-dimension mean of the pool means, rounded to float so
   // the device subtracts exactly the value the constants were built with

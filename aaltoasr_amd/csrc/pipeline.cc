@@ -176,6 +176,45 @@ std::vector<int16_t> read_audio_file(const std::string &path, bool force_raw, in
   return pcm;
 }
 
+// PreModule::set_file (aku/FeatureModules.cc:603-631): a feature file is the
+// dimension (native int32, or one byte for legacy files) followed by float32
+// frames.  Returned in int16 units (two per float), the layout every feature
+// entry point shares with audio.
+std::vector<int16_t> parse_feature_data(const std::vector<char> &data, int dim, bool legacy) {
+  size_t off;
+  int file_dim;
+  if (legacy) {
+    if (data.size() < 1) raise(AASR_ERR_IO, "PreModule: Could not read the file.");
+    file_dim = (signed char)data[0];
+    off = 1;
+  } else {
+    if (data.size() < 4) raise(AASR_ERR_IO, "PreModule: Could not read the file.");
+    int32_t d;
+    memcpy(&d, data.data(), 4);
+    file_dim = d;
+    off = 4;
+  }
+  if (file_dim != dim) raise(AASR_ERR_INVALID, "PreModule: The file has invalid dimension");
+  const size_t frames = (data.size() - off) / ((size_t)dim * 4);
+  std::vector<int16_t> out(frames * dim * 2);
+  if (!out.empty()) memcpy(out.data(), data.data() + off, out.size() * 2);
+  return out;
+}
+
+std::vector<int16_t> read_feature_file(const std::string &path, int dim, bool legacy) {
+  std::ifstream in(path, std::ios::binary);
+  if (!in) raise(AASR_ERR_IO, "could not open file %s", path.c_str());
+  std::vector<char> data((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+  return parse_feature_data(data, dim, legacy);
+}
+
+// FeatureGenerator::open for whichever base module the graph has
+std::vector<int16_t> read_input_file(const aasr_feat *feat, const std::string &path, bool force_raw) {
+  const FeatModule &b = feat->mods[0];
+  if (b.type == MOD_PRE) return read_feature_file(path, b.dim, b.legacy_file != 0);
+  return read_audio_file(path, force_raw, b.sample_rate);
+}
+
 // ------------------------------------------------------------------ driver --
 
 static double now_s() {
@@ -242,7 +281,8 @@ static void frame_range(aasr_feat *feat, int64_t n_samples, double start_time, d
   int start_frame = (int)(start_time * fr);
   int end_frame = (int)(end_time * fr);
   if (end_frame == 0) end_frame = INT_MAX;
-  if (n_samples < feat->mods[0].width + 1) raise(AASR_ERR_SHORT_AUDIO, "audio shorter than frame");
+  if (feat->mods[0].type != MOD_PRE && n_samples < feat->mods[0].width + 1)
+    raise(AASR_ERR_SHORT_AUDIO, "audio shorter than frame");
   int eof_frame = feat_last_frame(feat, n_samples) + 1;
   int stop = std::min(end_frame, eof_frame);
   *start = start_frame;
@@ -341,7 +381,7 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
     Job j;
     j.info_index = ri;
     j.out_file = out_file;
-    j.pcm = read_audio_file(info.audio_path, opt.raw_audio != 0, feat->mods[0].sample_rate);
+    j.pcm = read_input_file(feat, info.audio_path, opt.raw_audio != 0);
     frame_range(feat, (int64_t)j.pcm.size(), info.start_time, info.end_time, &j.start, &j.count);
     if (opt.info > 0 && (j.start != 0 || info.end_time != 0))
       printf("Generating frames %d - %d\n", j.start, j.start + j.count);
@@ -367,7 +407,8 @@ void run_utterance(aasr_feat *feat, aasr_gmm *gmm, const int16_t *pcm, int64_t n
   if (gmm->dim != feat->mods.back().dim)
     raise(AASR_ERR_INVALID, "Gaussian dimension is %d but feature dimension is %d.", gmm->dim,
           feat->mods.back().dim);
-  if (n_samples < feat->mods[0].width + 1) raise(AASR_ERR_SHORT_AUDIO, "audio shorter than frame");
+  if (feat->mods[0].type != MOD_PRE && n_samples < feat->mods[0].width + 1)
+    raise(AASR_ERR_SHORT_AUDIO, "audio shorter than frame");
   Job j;
   j.pcm.assign(pcm, pcm + n_samples);
   int eof_frame = feat_last_frame(feat, n_samples) + 1;

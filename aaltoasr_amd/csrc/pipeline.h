@@ -16,6 +16,8 @@ struct RecipeInfo {
 void recipe_batch_range(int total, int num_batches, int batch_index, int *first, int *count);
 std::vector<RecipeInfo> recipe_read(const std::string &text, int num_batches, int batch_index);
 std::vector<int16_t> read_audio_file(const std::string &path, bool force_raw, int expect_rate);
+std::vector<int16_t> parse_feature_data(const std::vector<char> &data, int dim, bool legacy);
+std::vector<int16_t> read_feature_file(const std::string &path, int dim, bool legacy);
 
 }  // namespace aasr
 

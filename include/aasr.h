@@ -81,6 +81,23 @@ void aasr_feat_halo(const aasr_feat *h, int *left, int *right);
  * (aku/phone_probs.cc:217-221). */
 int aasr_feat_last_frame(const aasr_feat *h, int64_t n_samples);
 
+/* Graphs whose first module is a `pre` module (PreModule,
+ * aku/FeatureModules.cc:572-755) take float feature frames instead of audio:
+ * what `feacat --raw-output -H` writes (int32 dimension, then float32 frames;
+ * legacy_file 1: a one-byte dimension).  Frames before 0 repeat frame 0, frames
+ * past the end repeat the last one.  n_values = frames x input dimension.
+ * aasr_feat_last_frame and the batch entry points count such input in int16
+ * units (2 per float) so that audio and feature input share every buffer. */
+aasr_status aasr_feat_run_features(aasr_feat *h, const float *features, int64_t n_values,
+                                   int32_t first_frame, int32_t n_frames,
+                                   const char *module_name, float *out);
+aasr_status aasr_feat_run_features_f64(aasr_feat *h, const float *features, int64_t n_values,
+                                       int32_t first_frame, int32_t n_frames,
+                                       const char *module_name, double *out);
+int aasr_feat_input_is_features(const aasr_feat *h);   /* 1 when the base module is `pre` */
+int aasr_feat_pre_legacy(const aasr_feat *h);          /* its legacy_file option */
+int aasr_feat_input_dim(const aasr_feat *h);           /* dimension of the base module */
+
 /* FeatureGenerator::generate(frame) for frames first_frame ..
  * first_frame+n_frames-1 of one utterance whose complete PCM (mono int16,
  * what AudioReader::fetch delivers, aku/AudioReader.cc:219-230) is pcm[0..
@@ -145,6 +162,13 @@ aasr_status aasr_gmm_create_full(int32_t dim, int32_t num_gaussians,
  * ph_path may be NULL (state count = mixture count). */
 aasr_status aasr_gmm_create_from_files(const char *gk_path, const char *mc_path,
                                        const char *ph_path, aasr_gmm **out);
+/* Binary model cache (new): everything the text parser of
+ * aasr_gmm_create_from_files produced, in double precision, with a checksum.
+ * A model created from the cache scores bit-identically to one created from
+ * the .gk/.mc/.ph files it was written from; the text parse (seconds for a
+ * 50 000-Gaussian pool, paid by every per-GPU process of a run) is skipped. */
+aasr_status aasr_gmm_write_cache(const aasr_gmm *h, const char *cache_path);
+aasr_status aasr_gmm_create_from_cache(const char *cache_path, aasr_gmm **out);
 void aasr_gmm_destroy(aasr_gmm *h);
 
 int aasr_gmm_dim(const aasr_gmm *h);            /* HmmSet::dim()        */

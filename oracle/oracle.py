@@ -193,7 +193,7 @@ class FeatureChain:
     evaluation with halos.
     """
 
-    SUPPORTED = ("audiofile", "fft", "mel", "power", "dct", "delta",
+    SUPPORTED = ("audiofile", "pre", "fft", "mel", "power", "dct", "delta",
                  "normalization", "lin_transform", "merge", "mean_subtractor",
                  "concat", "vtln", "sr_norm", "mel_power", "quanteq")
 
@@ -206,7 +206,7 @@ class FeatureChain:
             if m.type not in self.SUPPORTED:
                 raise ValueError("Unknown module type '%s'" % m.type)
             if not self.mods:
-                if m.type != "audiofile":
+                if m.type not in ("audiofile", "pre"):
                     raise ValueError("first module should be a base module")
                 if "sources" in opts:
                     raise ValueError("can not define sources for the first module")
@@ -246,6 +246,15 @@ class FeatureChain:
             m.prm = dict(sample_rate=sr, emph=emph, frame_rate=fr, advance=adv,
                          width=ww, copy_borders=cb)
             self.sample_rate = sr
+        elif t == "pre":
+            # PreModule::set_module_config (aku/FeatureModules.cc:672-690)
+            if "dim" not in o:
+                raise ValueError("PreModule: Must set dimension")
+            m.dim = int(o["dim"])
+            m.prm = dict(sample_rate=int(o.get("sample_rate", 16000)),
+                         frame_rate=str2float(o["frame_rate"]) if "frame_rate" in o else np.float32(125),
+                         legacy=int(o.get("legacy_file", 0)))
+            self.sample_rate = m.prm["sample_rate"]
         elif t == "fft":
             m.prm = dict(magnitude=int(o.get("magnitude", 1)), log=int(o.get("log", 0)))
             m.dim = m.sources[-1].dim // 2 + 1
@@ -473,6 +482,9 @@ class FeatureChain:
         return float(self.base.prm["frame_rate"])
 
     def last_frame(self, n_samples: int) -> int:
+        if self.base.type == "pre":
+            # PreModule::last_frame (:649-660); n_samples = number of float values
+            return int(n_samples) // self.base.dim - 1
         p = self.base.prm
         return lib().orc_last_frame(int(n_samples), p["width"], float(p["advance"]))
 
@@ -500,7 +512,10 @@ class FeatureChain:
                  module: Optional[str] = None) -> np.ndarray:
         """Frames first_frame .. first_frame+n_frames-1 of `module` (default:
         the last module) as float64 [n_frames x dim]."""
-        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        if self.base.type == "pre":
+            pcm = np.ascontiguousarray(pcm, dtype=np.float32).reshape(-1, self.base.dim)
+        else:
+            pcm = np.ascontiguousarray(pcm, dtype=np.int16)
         target = self.by_name[module] if module else self.last
         memo: Dict[Tuple[str, int, int], np.ndarray] = {}
         return self._eval(target, first_frame, first_frame + n_frames - 1, pcm, memo)
@@ -514,7 +529,14 @@ class FeatureChain:
         out = np.empty((n, m.dim), dtype=np.float64)
         pd = C.c_double
         t = m.type
-        if t == "audiofile":
+        if t == "pre":
+            # PreModule::generate (aku/FeatureModules.cc:705-755): frames before 0
+            # give frame 0, frames from the end of the file on give the last frame
+            if len(pcm) < 1:
+                raise ValueError("PreModule: Could not read the file")
+            idx = np.clip(np.arange(lo, hi + 1), 0, len(pcm) - 1)
+            out = pcm[idx].astype(np.float64)
+        elif t == "audiofile":
             p = m.prm
             rc = L.orc_audio_frames(_p(pcm, C.c_int16), len(pcm), float(p["advance"]),
                                     p["width"], float(p["emph"]), p["copy_borders"],
@@ -834,6 +856,15 @@ def write_ph(path: str, num_states: int, states_per_hmm: int = 1) -> None:
             for j in range(ns):
                 nxt = 2 + j + 1 if j + 1 < ns else 1
                 f.write("%d 2 %d 0.5 %d 0.5\n" % (2 + j, 2 + j, nxt))
+
+
+def write_feature_file(path: str, frames: np.ndarray, legacy: bool = False) -> None:
+    """feacat --raw-output -H (aku/feacat.cc:19-24, 95-100): int32 dimension (one
+    byte for PreModule's legacy_file), then float32 frames."""
+    frames = np.ascontiguousarray(frames, np.float32)
+    with open(path, "wb") as f:
+        f.write(struct.pack("b", frames.shape[1]) if legacy else struct.pack("=i", frames.shape[1]))
+        f.write(frames.tobytes())
 
 
 def write_gcl(path: str, n_clusters: int, gauss_to_cluster) -> None:

@@ -183,3 +183,29 @@ def test_device_pointer_entry(capi, oracle):
     g.score_dev(d_fr, d_out)
     torch.cuda.synchronize()
     assert np.array_equal(d_out.cpu().numpy().view(np.uint32), g.score(fr).view(np.uint32))
+
+
+def test_model_cache_round_trip(capi, oracle, tmp_path):
+    """aasr_gmm_write_cache / create_from_cache: same scores bit for bit, HMM inventory
+    kept, corruption detected."""
+    mean, var, off, idx, w = synth.make_model(D=20, G=300, S=25, tied=True, comps_range=(1, 17))
+    base = str(tmp_path / "m")
+    oracle.write_gk(base + ".gk", mean, var)
+    oracle.write_mc(base + ".mc", off, idx, w)
+    oracle.write_ph(base + ".ph", 25)
+    g1 = capi.Gmm.from_files(base + ".gk", base + ".mc", base + ".ph")
+    cache = str(tmp_path / "m.aasr")
+    g1.write_cache(cache)
+    g2 = capi.Gmm.from_cache(cache)
+    frames = synth.make_frames(200, D=20)
+    assert (g2.dim, g2.num_states, g2.num_gaussians) == (20, 25, 300)
+    assert np.array_equal(g1.score(frames), g2.score(frames))
+    g2.write_cache(str(tmp_path / "again.aasr"))          # a cache of a cache is the same file
+    assert open(cache, "rb").read() == open(tmp_path / "again.aasr", "rb").read()
+    blob = bytearray(open(cache, "rb").read())
+    blob[len(blob) // 2] ^= 0x40
+    open(tmp_path / "bad.aasr", "wb").write(bytes(blob))
+    with pytest.raises(capi.AasrError, match="checksum mismatch"):
+        capi.Gmm.from_cache(str(tmp_path / "bad.aasr"))
+    with pytest.raises(capi.AasrError, match="not a model cache"):
+        capi.Gmm.from_cache(base + ".gk")

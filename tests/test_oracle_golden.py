@@ -305,3 +305,18 @@ def test_speaker_config_oracle(oracle):
         sc.set_utterance("")
     with pytest.raises(ValueError, match="Syntax error"):
         oracle.SpeakerConfig(ch).read_text("spk x\n{\n}\n")
+
+
+def test_pre_module_golden(oracle, golden_dir):
+    """aku/tests/pre_test.script on the oracle: frames 10..60 of the mfcc_p_dd chain written
+    as float32 and read back through pre.feaconf == aku/tests/pre_test.ref (two decimals)."""
+    pcm, _ = oracle.read_wav_pcm16(os.path.join(golden_dir, "short.wav"))
+    src = oracle.FeatureChain(open(os.path.join(golden_dir, "mfcc_p_dd.feaconf")).read())
+    feats = src.generate(pcm, 10, 51).astype(np.float32)
+    pre = oracle.FeatureChain(open(os.path.join(golden_dir, "pre.feaconf")).read())
+    assert pre.dim == 39 and pre.last_frame(feats.size) == 50
+    out = pre.generate(feats, 0, 51)
+    ref = np.loadtxt(os.path.join(golden_dir, "pre_test.ref"))
+    assert np.abs(out - ref).max() <= 0.005 + 1e-9
+    assert np.array_equal(pre.generate(feats, -2, 2), np.repeat(out[:1], 2, 0))
+    assert np.array_equal(pre.generate(feats, 51, 3), np.repeat(out[-1:], 3, 0))
