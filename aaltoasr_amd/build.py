@@ -84,7 +84,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(bindir, exist_ok=True)
     for name, src in (("phone_probs", "aku/main_phone_probs.cc"),
                       ("aku_adapter_check", "aku/main_adapter_check.cc"),
-                      ("feacat", "aku/main_feacat.cc")):
+                      ("feacat", "aku/main_feacat.cc"),
+                      ("acoustics_check", "decoder/main_acoustics_check.cc")):
         srcp = os.path.join(CSRC, src)
         exe = os.path.join(bindir, name)
         if force or not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(srcp), os.path.getmtime(LIB)):

@@ -129,3 +129,25 @@ def test_clustering_through_cli_and_adapters(capi, oracle, world):
     a, b = oracle.lna_decode(open(loop, "rb").read()), oracle.lna_decode(want)
     smooth = (b > -80.0)
     assert a.shape == b.shape and np.abs(a - b)[smooth].max() <= 2e-5
+
+
+@pytest.mark.parametrize("nbytes,block", [(4, 100), (2, 4096), (4, 1)])
+def test_engine_acoustics_equals_lna_reader_view(capi, oracle, world, nbytes, block):
+    """the decoder's Acoustics interface (go_to / log_prob) served from
+    the GPU returns exactly what LnaReaderCircular reads from the LNA file phone_probs writes
+    (decoder/src/LnaReaderCircular.cc:129-209)."""
+    out = str(world["dir"] / ("ac_%d_%d.f32" % (nbytes, block)))
+    r = subprocess.run([os.path.join(BIN, "acoustics_check"), world["cfg"], world["base"],
+                        str(world["dir"] / "a1.wav"), str(nbytes), str(block), out],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lna, frames = capi.run_utterance(world["ft"], world["gm"], world["pcms"][1], lnabytes=nbytes)
+    assert r.stdout.split()[0] == str(frames) and r.stdout.split()[-1] == str(frames)
+    got = np.fromfile(out, np.float32).reshape(frames, 32)
+    body = np.frombuffer(lna[5:], np.uint8)
+    if nbytes == 4:
+        want = body.view("<f4").reshape(frames, 32)
+    else:
+        b = body.reshape(-1, 2).astype(np.int64)
+        want = ((b[:, 0] * 256 + b[:, 1]) / -1820.0).astype(np.float32).reshape(frames, 32)
+    assert np.array_equal(got, want)
