@@ -834,77 +834,83 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
 }
 
 // ---------------------------------------------------------------------------
-// Software-pipelined bf16x3 kernel.  Cross-wave overlap of the VALU epilogue with
-// matrix work turned out to be poor in practice (SQ_VALU_MFMA_COEXEC_CYCLES only
-// 4 % of the MFMA cycles with two waves per SIMD), but VALU instructions placed
-// BETWEEN a wave's own MFMAs do hide.  So each wave keeps two accumulator sets:
-// while the MFMAs of tile t run into one, the 32 v_exp_f32 + adds of tile t-1
-// are issued from the other (branch-free: per-quad sums), and only the cheap
-// close/flush logic runs after the barrier.  To make room for the second
-// accumulator set a wave owns 32 frames (one 32-column block, both 32-row
-// blocks of the tile); a workgroup is 8 waves = 256 frames.
+// Half-tile pipelined bf16x3 kernel (experimental: AASR_BF16_PIPE=2).
+//
+// Measured on gfx950: VALU work co-executes with another wave's bf16 MFMAs only
+// marginally (SQ_VALU_MFMA_COEXEC_CYCLES ~4 % with two waves per SIMD) but hides
+// completely when placed between a wave's own MFMAs.  A tile's two 32-row blocks
+// do not depend on each
+// other, so the MFMA stream of block 1 carries the 32 v_exp_f32 + 24 adds of
+// block 0, and the stream of the NEXT tile's block 0 carries those of block 1:
+// same four accumulators, same 64 frames per wave and the same per-tile
+// overheads as k_gmm_diag_score_bf16x3, with the transcendentals off the
+// critical path.  What runs after a stream is only the close / flush logic on
+// the eight per-quad sums.  The order of the VALU instructions is pinned with
+// volatile asm + scheduling barriers (a pure builtin is sunk to its first use).
+// Ablations (1 M frames x 50 k Gaussians, ms): matrix stream only 30.3; with the
+// exponentials riding in it 31.6; with close logic, no output stores 32.4; full
+// 35.3 (k_gmm_diag_score_bf16x3: 35.7).  The transcendentals are hidden; what is
+// left is the 12.5 GB of output stores (3 ms, 1 ms of it from the 4-byte row
+// alignment of S = 3125), which cost the matrix pipe clock under the power cap
+// rather than issue slots -- hence only ~1 % over the plain kernel.
 // ---------------------------------------------------------------------------
-template <int NK16, bool GROUPED>
-struct Bf16PSmem {
-  static constexpr int OG = 16;
-  static constexpr int WAVES = 8;
-  static constexpr int kTileBytes = NK16 * 3 * 2 * 64 * 16;
-  static constexpr int kOutStride = OG + 4;
-  static constexpr int kOutFloatsPerWave = GROUPED ? 32 * kOutStride : 0;
-  static constexpr int kBytes = 2 * kTileBytes + WAVES * kOutFloatsPerWave * 4;
-};
-
-__device__ __forceinline__ void issue_tile_copy8(const float *__restrict__ gtile, float *lds_buf,
-                                                 int tile_floats, int wave, int lane) {
-  const int chunks = tile_floats / 4;
-  for (int c0 = wave * 64; c0 < chunks; c0 += 8 * 64) {
-    const float *src = gtile + (size_t)(c0 + lane) * 4;
-    float *dst = lds_buf + (size_t)c0 * 4;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-  }
+__device__ __forceinline__ float pinned_exp2(float x) {
+  float r;
+  asm volatile("v_exp_f32_e32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ float pinned_add(float a, float b) {
+  float r;
+  asm volatile("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 
-// MFMAs of one tile into (c0, c1) with the 32 transcendentals of the previous
-// tile's accumulators (p0, p1) riding behind the MFMA pairs; A fragments of the
-// next K slab are requested before the current slab's MFMAs.
-template <int NK16>
-__device__ __forceinline__ void bf16p_tile(const u32x4 *afrag, const u32x4 (&bq)[NK16][3],
-                                           f32x16 &c0, f32x16 &c1, const f32x16 &p0,
-                                           const f32x16 &p1, float (&ev)[32]) {
-  u32x4 a[2][3][2];
+// MFMAs of row block MB of the tile at `afrag` into (c0, c1) = frames n / 32+n.
+// With PENDING, the exponentials and per-quad sums of the finished block (p0, p1)
+// ride behind the MFMA pairs: qs[q] (frames n) and qs[4+q] (frames 32+n), q < 4.
+template <int NK16, int MB, bool PENDING>
+__device__ __forceinline__ void bf16h_phase(const u32x4 *afrag, const u32x4 (&bq)[NK16][3][2],
+                                            f32x16 &c0, f32x16 &c1, const f32x16 &p0,
+                                            const f32x16 &p1, float (&qs)[8]) {
+  u32x4 a[2][3];
 #pragma unroll
-  for (int sp = 0; sp < 3; sp++) {
-    a[0][sp][0] = afrag[((0 * 3 + sp) * 2 + 0) * 64];
-    a[0][sp][1] = afrag[((0 * 3 + sp) * 2 + 1) * 64];
-  }
+  for (int sp = 0; sp < 3; sp++) a[0][sp] = afrag[((0 * 3 + sp) * 2 + MB) * 64];
+  float e[2][4], tq[2][2];
+  constexpr int SLOTS = NK16 * 6;
+  constexpr int STEPS = 10, OPS = STEPS * 7;  // quad tau: 4 exps, then 2 + 1 adds one / two steps later
 #pragma unroll
   for (int j = 0; j < NK16; j++) {
     if (j + 1 < NK16) {
 #pragma unroll
-      for (int sp = 0; sp < 3; sp++) {
-        a[(j + 1) & 1][sp][0] = afrag[(((j + 1) * 3 + sp) * 2 + 0) * 64];
-        a[(j + 1) & 1][sp][1] = afrag[(((j + 1) * 3 + sp) * 2 + 1) * 64];
-      }
+      for (int sp = 0; sp < 3; sp++) a[(j + 1) & 1][sp] = afrag[(((j + 1) * 3 + sp) * 2 + MB) * 64];
     }
+    // smallest products first: (a1,b3) (a2,b2) (a3,b1) (a1,b2) (a2,b1) (a1,b1)
     constexpr int SA[6] = {0, 1, 2, 0, 1, 0};
     constexpr int SB[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
     for (int c = 0; c < 6; c++) {
-      const bf16x8 bv = __builtin_bit_cast(bf16x8, bq[j][SB[c]]);
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j & 1][SA[c]][0]), bv, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j & 1][SA[c]][1]), bv, c1, 0, 0, 0);
-      constexpr int SLOTS = NK16 * 6;
-      const int slot = j * 6 + c;
+      const bf16x8 av = __builtin_bit_cast(bf16x8, a[j & 1][SA[c]]);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, bq[j][SB[c]][0]), c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, bq[j][SB[c]][1]), c1, 0, 0, 0);
+      if (PENDING) {
+        const int slot = j * 6 + c;
 #pragma unroll
-      for (int e = 0; e < 32; e++)
-        if (e * SLOTS / 32 == slot || (SLOTS < 32 && slot == SLOTS - 1 && e * SLOTS / 32 >= SLOTS)) {
-          // volatile asm keeps the transcendental at this point of the stream (a
-          // pure builtin would be sunk to its first use after the MFMAs); its
-          // consumers are a whole MFMA phase away, no wait states needed
-          const float xv = e < 16 ? p0[e] : p1[e - 16];
-          asm volatile("v_exp_f32_e32 %0, %1" : "=v"(ev[e]) : "v"(xv));
+        for (int o = 0; o < OPS; o++) {
+          if (o * SLOTS / OPS != slot) continue;
+          const int tau = o / 7, k = o % 7;
+          if (k < 4) {
+            const int quad = tau;
+            if (quad < 8) e[quad & 1][k] = pinned_exp2(quad < 4 ? p0[4 * quad + k] : p1[4 * (quad - 4) + k]);
+          } else if (k < 6) {
+            const int quad = tau - 1;
+            if (quad >= 0 && quad < 8)
+              tq[quad & 1][k - 4] = pinned_add(e[quad & 1][2 * (k - 4)], e[quad & 1][2 * (k - 4) + 1]);
+          } else {
+            const int quad = tau - 2;
+            if (quad >= 0 && quad < 8) qs[quad] = pinned_add(tq[quad & 1][0], tq[quad & 1][1]);
+          }
         }
+      }
       // MFMA / VALU order is pinned; LDS, VMEM and scalar work may still move
       __builtin_amdgcn_sched_barrier(0x0094);
     }
@@ -912,29 +918,30 @@ __device__ __forceinline__ void bf16p_tile(const u32x4 *afrag, const u32x4 (&bq)
 }
 
 template <int NK16, bool GROUPED>
-__global__ __launch_bounds__(512, 2) void k_gmm_diag_score_bf16x3p(
+__global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3h(
     const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
     const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
     const uint16_t *__restrict__ close_mask, const int32_t *__restrict__ sid, int sid_stride,
     float *__restrict__ out, int64_t S, float ref_ln, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr int OG = Bf16PSmem<NK16, GROUPED>::OG;
-  constexpr int kTileFloats = Bf16PSmem<NK16, GROUPED>::kTileBytes / 4;
-  constexpr int kOS = Bf16PSmem<NK16, GROUPED>::kOutStride;
+  constexpr int OG = Bf16Smem<NK16, GROUPED>::OG;
+  constexpr int kTileFloats = Bf16Smem<NK16, GROUPED>::kTileBytes / 4;
+  constexpr int kOS = Bf16Smem<NK16, GROUPED>::kOutStride;
   constexpr int KH = 8 * NK16;
   float *abuf0 = (float *)smem_raw;
   float *abuf1 = abuf0 + kTileFloats;
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const int lane = tid & 63;
-  float *ost = abuf0 + 2 * kTileFloats + wave * Bf16PSmem<NK16, GROUPED>::kOutFloatsPerWave;
+  float *ost = abuf0 + 2 * kTileFloats + wave * Bf16Smem<NK16, GROUPED>::kOutFloatsPerWave;
   const int n = lane & 31;
   const int h = lane >> 5;
-  const int64_t f0 = (int64_t)blockIdx.x * 256 + wave * 32;
+  const int64_t f0 = (int64_t)blockIdx.x * FRAMES_PER_BLOCK + wave * FRAMES_PER_WAVE;
 
-  u32x4 bq[NK16][3];
-  {
-    int64_t f = f0 + n;
+  u32x4 bq[NK16][3][2];
+#pragma unroll
+  for (int nb = 0; nb < 2; nb++) {
+    int64_t f = f0 + nb * 32 + n;
     if (f > F - 1) f = F - 1;
     const float *xr = frames + f * dim;
 #pragma unroll
@@ -953,78 +960,83 @@ __global__ __launch_bounds__(512, 2) void k_gmm_diag_score_bf16x3p(
       unsigned w1[4], w2[4], w3[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) split3_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i], w3[i]);
-      bq[j][0] = u32x4{w1[0], w1[1], w1[2], w1[3]};
-      bq[j][1] = u32x4{w2[0], w2[1], w2[2], w2[3]};
-      bq[j][2] = u32x4{w3[0], w3[1], w3[2], w3[3]};
+      bq[j][0][nb] = u32x4{w1[0], w1[1], w1[2], w1[3]};
+      bq[j][1][nb] = u32x4{w2[0], w2[1], w2[2], w2[3]};
+      bq[j][2][nb] = u32x4{w3[0], w3[1], w3[2], w3[3]};
     }
   }
 
   const int64_t t_begin = split_row[4 * blockIdx.y];
   const int64_t t_end = split_row[4 * blockIdx.y + 4];
   const float *apf = (const float *)apack;
-  issue_tile_copy8(apf + (size_t)t_begin * kTileFloats, abuf0, kTileFloats, wave, lane);
+  issue_tile_copy(apf + (size_t)t_begin * kTileFloats, abuf0, kTileFloats, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  float ssum = 0.0f;  // running sum of the open state on this lane's track
+  float s0 = 0.0f, s1 = 0.0f;
   int closes = split_row[4 * blockIdx.y + 1 + (GROUPED ? 0 : h)];
   const int32_t *my_sid = sid + h * sid_stride;
   int next_sid = GROUPED ? 0 : my_sid[closes];
-  float *orow = out + (f0 + n) * S;
-  const bool okf = f0 + n < F;
+  float *orow0 = out + (f0 + n) * S;
+  float *orow1 = out + (f0 + 32 + n) * S;
+  const bool ok0 = f0 + n < F, ok1 = f0 + 32 + n < F;
 
-  // close / flush logic of one finished tile given its 32 exponentials
-  auto finish_tile = [&](const float (&ev)[32], unsigned mask16) {
+  // close / flush logic of one finished 32-row block given its per-quad sums
+  // (returns the number of vector stores it issued, -1 = not counted)
+  auto finish_block = [&](const float (&qs)[8], unsigned mask16, int mb) -> int {
+    int stores = 0;
     const unsigned mask = GROUPED ? (mask16 & 0xffu) : (h ? (mask16 >> 8) : (mask16 & 0xffu));
-    const unsigned any = GROUPED ? (mask16 & 0xffu) : ((mask16 | (mask16 >> 8)) & 0xffu);
-    // branch-free running sums: r[p] = sum of the open state up to quad p
-    float r[8];
-    float run = ssum;
 #pragma unroll
-    for (int p = 0; p < 8; p++) {
-      run += (ev[4 * p] + ev[4 * p + 1]) + (ev[4 * p + 2] + ev[4 * p + 3]);
-      r[p] = run;
-      run = ((mask >> p) & 1) ? 0.0f : run;
-    }
-    ssum = run;
-#pragma unroll
-    for (int p = 0; p < 8; p++) {
-      if ((any >> p) & 1) {  // wave-uniform: some track closes a state after quad p
-        const bool mine = (mask >> p) & 1;
-        float l0 = fmaf(__builtin_amdgcn_logf(r[p]), LN2_F, -ref_ln);
+    for (int q = 0; q < 4; q++) {
+      s0 += qs[q];
+      s1 += qs[4 + q];
+      if ((mask >> (mb * 4 + q)) & 1) {
+        float l0 = fmaf(__builtin_amdgcn_logf(s0), LN2_F, -ref_ln);
+        float l1 = fmaf(__builtin_amdgcn_logf(s1), LN2_F, -ref_ln);
         l0 = fmaxf(l0, LOG_TINY_F);
+        l1 = fmaxf(l1, LOG_TINY_F);
+        s0 = 0.0f;
+        s1 = 0.0f;
+        closes++;
         if (!GROUPED) {
-          if (mine) {
-            closes++;
-            if (okf) orow[next_sid] = l0;
-            next_sid = my_sid[closes];
-          }
+          if (ok0) orow0[next_sid] = l0;
+          if (ok1) orow1[next_sid] = l1;
+          next_sid = my_sid[closes];
+          stores = -1;
         } else {
-          closes++;
           const int pairs_closed = closes;
           const int slot = ((2 * (pairs_closed - 1)) & (OG - 1)) + h;
+          if (dbg & 4) {
+            asm volatile("" ::"v"(l0), "v"(l1));
+            continue;
+          }
           ost[n * kOS + slot] = l0;
+          ost[(32 + n) * kOS + slot] = l1;
           const int64_t closed = 2 * (int64_t)pairs_closed < S ? 2 * (int64_t)pairs_closed : S;
-          if (((2 * pairs_closed) & (OG - 1)) == 0 || 2 * (int64_t)pairs_closed >= S) {
+          if ((((2 * pairs_closed) & (OG - 1)) == 0 || 2 * (int64_t)pairs_closed >= S) && !(dbg & 8)) {
             const int64_t s_base = ((closed - 1) / OG) * OG;
             const int cnt = (int)(closed - s_base);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (cnt == OG && f0 + 32 <= F) {
+            if (cnt == OG && f0 + FRAMES_PER_WAVE <= F) {
               const int k4 = lane & 3, r16 = lane >> 2;
               float *op = out + (f0 + r16) * S + s_base + 4 * k4;
               const float *ip = ost + r16 * kOS + 4 * k4;
 #pragma unroll
-              for (int i = 0; i < 2; i++) {
+              for (int i = 0; i < FRAMES_PER_WAVE / 16; i++) {
                 const f32x4 v = *(const f32x4 *)(ip + i * 16 * kOS);
                 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-                *(f32x4u *)(op + (int64_t)i * 16 * S) = v;
+                if (dbg & 32) asm volatile("" ::"v"(v));  // ablation: LDS read only
+                else *(f32x4u *)(op + (int64_t)i * 16 * S) = v;
               }
+              if (stores >= 0 && !(dbg & 32)) stores += FRAMES_PER_WAVE / 16;
             } else {
+              stores = -1;
+              constexpr int RPI = 64 / OG;
               const int k = lane & (OG - 1);
 #pragma unroll 4
-              for (int i = 0; i < 32 / (64 / OG); i++) {
-                const int row = i * (64 / OG) + lane / OG;
+              for (int i = 0; i < FRAMES_PER_WAVE / RPI; i++) {
+                const int row = i * RPI + lane / OG;
                 const float v = ost[row * kOS + k];
                 if (k < cnt && f0 + row < F) out[(f0 + row) * S + s_base + k] = v;
               }
@@ -1035,77 +1047,79 @@ __global__ __launch_bounds__(512, 2) void k_gmm_diag_score_bf16x3p(
         }
       }
     }
+    return stores;
   };
 
-  // two accumulator sets; the loop is unrolled by two so that no set is copied
-  f32x16 a0 = {0}, a1 = {0}, b0 = {0}, b1 = {0};
-  float ev[32];
-  unsigned mask_a = 0, mask_b = 0;
-  bool have_b = false;  // set B holds a finished, not yet reduced tile
-
-  int64_t t = t_begin;
-  while (t < t_end) {
-    {  // tile t -> set A, exps of set B
-      const int par = (int)((t - t_begin) & 1);
-      float *acur = par ? abuf1 : abuf0;
-      float *anext = par ? abuf0 : abuf1;
-      if (t + 1 < t_end)
-        issue_tile_copy8(apf + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
-      mask_a = close_mask[t];
+  f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
+  float qs[8];
+  unsigned prev_mask = 0;
+  // Tile t+1 is requested right after the barrier of tile t-1, BEFORE the stores of
+  // that tile's close logic: vector-memory operations complete in issue order, so
+  // the wait in front of the next barrier only has to cover the tile load --
+  // s_waitcnt vmcnt(number of stores issued since) -- and never an output store.
+  if (t_begin + 1 < t_end)
+    issue_tile_copy(apf + (size_t)(t_begin + 1) * kTileFloats, abuf1, kTileFloats, wave, lane);
+  int pend = 0;  // stores issued after the outstanding tile request (-1: unknown)
+  for (int64_t t = t_begin; t < t_end; t++) {
+    const int par = (int)((t - t_begin) & 1);
+    float *acur = par ? abuf1 : abuf0;
+    const unsigned mask16 = close_mask[t];
+    const u32x4 *afrag = (const u32x4 *)acur + lane;
+    // block 0 of tile t; the stream carries block 1 of tile t-1
 #pragma unroll
-      for (int i = 0; i < 16; i++) { a0[i] = 0.0f; a1[i] = 0.0f; }
-      bf16p_tile<NK16>((const u32x4 *)acur + lane, bq, a0, a1, b0, b1, ev);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (have_b && !(dbg & 1)) finish_tile(ev, mask_b);
-      t++;
+    for (int i = 0; i < 16; i++) { c00[i] = 0.0f; c01[i] = 0.0f; }
+    if (t > t_begin && !(dbg & 2)) {
+      bf16h_phase<NK16, 0, true>(afrag, bq, c00, c01, c10, c11, qs);
+      if (!(dbg & 1)) {
+        const int st = finish_block(qs, prev_mask, 1);
+        pend = (pend < 0 || st < 0) ? -1 : pend + st;
+      }
+    } else {
+      bf16h_phase<NK16, 0, false>(afrag, bq, c00, c01, c10, c11, qs);
     }
-    if (t >= t_end) {
-      // odd tile count: set A is the last one
+    // block 1 of tile t; the stream carries block 0 of tile t
 #pragma unroll
-      for (int e = 0; e < 32; e++) ev[e] = __builtin_amdgcn_exp2f(e < 16 ? a0[e] : a1[e - 16]);
-      if (!(dbg & 1)) finish_tile(ev, mask_a);
-      have_b = false;
-      break;
-    }
-    {  // tile t -> set B, exps of set A
-      const int par = (int)((t - t_begin) & 1);
-      float *acur = par ? abuf1 : abuf0;
-      float *anext = par ? abuf0 : abuf1;
-      if (t + 1 < t_end)
-        issue_tile_copy8(apf + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
-      mask_b = close_mask[t];
-#pragma unroll
-      for (int i = 0; i < 16; i++) { b0[i] = 0.0f; b1[i] = 0.0f; }
-      bf16p_tile<NK16>((const u32x4 *)acur + lane, bq, b0, b1, a0, a1, ev);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (!(dbg & 1)) finish_tile(ev, mask_a);
-      have_b = true;
-      t++;
-    }
+    for (int i = 0; i < 16; i++) { c10[i] = 0.0f; c11[i] = 0.0f; }
+    if (dbg & 2) bf16h_phase<NK16, 1, false>(afrag, bq, c10, c11, c00, c01, qs);
+    else bf16h_phase<NK16, 1, true>(afrag, bq, c10, c11, c00, c01, qs);
+    // tile t+1 has landed (its request is older than `pend` stores) ...
+    if (pend == FRAMES_PER_WAVE / 16 && !(dbg & 16)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (pend == 2 * (FRAMES_PER_WAVE / 16) && !(dbg & 16)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ... and every wave is done reading `acur`, which can take tile t+2
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < t_end)
+      issue_tile_copy(apf + (size_t)(t + 2) * kTileFloats, acur, kTileFloats, wave, lane);
+    pend = 0;
+    if (!(dbg & 3)) pend = finish_block(qs, mask16, 0);
+    if (dbg & 2) asm volatile("" ::"v"(c00), "v"(c01), "v"(c10), "v"(c11));
+    prev_mask = mask16;
   }
-  if (have_b) {
+  // block 1 of the last tile: nothing left to hide behind
 #pragma unroll
-    for (int e = 0; e < 32; e++) ev[e] = __builtin_amdgcn_exp2f(e < 16 ? b0[e] : b1[e - 16]);
-    if (!(dbg & 1)) finish_tile(ev, mask_b);
+  for (int q = 0; q < 4; q++) {
+    qs[q] = (__builtin_amdgcn_exp2f(c10[4 * q]) + __builtin_amdgcn_exp2f(c10[4 * q + 1])) +
+            (__builtin_amdgcn_exp2f(c10[4 * q + 2]) + __builtin_amdgcn_exp2f(c10[4 * q + 3]));
+    qs[4 + q] = (__builtin_amdgcn_exp2f(c11[4 * q]) + __builtin_amdgcn_exp2f(c11[4 * q + 1])) +
+                (__builtin_amdgcn_exp2f(c11[4 * q + 2]) + __builtin_amdgcn_exp2f(c11[4 * q + 3]));
   }
+  if (t_end > t_begin) finish_block(qs, prev_mask, 1);
 }
 
 template <int NK16, bool GROUPED>
-static void launch_bf16p_t(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
+static void launch_bf16h_t(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
                            float *d_out, hipStream_t stream) {
-  const int64_t blocks = (F + 255) / 256;
-  const int smem = Bf16PSmem<NK16, GROUPED>::kBytes;
+  const int64_t blocks = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
+  const int smem = Bf16Smem<NK16, GROUPED>::kBytes;
   static const int dbg = getenv("AASR_DBG") ? atoi(getenv("AASR_DBG")) : 0;
   static bool attr_set[64] = {false};
-  auto kern = k_gmm_diag_score_bf16x3p<NK16, GROUPED>;
+  auto kern = k_gmm_diag_score_bf16x3h<NK16, GROUPED>;
   if (!attr_set[g->device & 63]) {
     AASR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set[g->device & 63] = true;
   }
   static const int force_r = getenv("AASR_SPLITS") ? atoi(getenv("AASR_SPLITS")) : 0;
-  const double slots = 1.0 * (g->num_cus > 0 ? g->num_cus : 256);  // one 8-wave workgroup per CU
+  const double slots = 2.0 * (g->num_cus > 0 ? g->num_cus : 256);
   int R = 1;
   double best_eff = 0;
   for (int r = 1; r <= L.max_splits; r++) {
@@ -1118,7 +1132,7 @@ static void launch_bf16p_t(const aasr_gmm *g, const TrackLayout &L, const float 
   }
   if (force_r >= 1 && force_r <= L.max_splits) R = force_r;
   const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(512), smem, stream, d_frames, F,
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(256), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, L.a16.p, split_row, L.close.p, L.sid.p, L.sid_stride,
                      d_out, g->S, L.ref_ln, dbg);
   AASR_HIP(hipGetLastError());
@@ -1160,11 +1174,19 @@ static bool launch_bf16(const aasr_gmm *g, const TrackLayout &L, const float *d_
                         float *d_out, hipStream_t stream, const ClusterArgs *cl = nullptr) {
   if (!L.a16.p) return false;
   const ClusterArgs none;
-  static const bool pipelined = getenv("AASR_BF16_PIPE") ? atoi(getenv("AASR_BF16_PIPE")) != 0 : false;
-  if (pipelined && L.nk16 == 5 && !cl) {
-    if (L.grouped) launch_bf16p_t<5, true>(g, L, d_frames, F, d_out, stream);
-    else launch_bf16p_t<5, false>(g, L, d_frames, F, d_out, stream);
+  static const int pipe_mode = getenv("AASR_BF16_PIPE") ? atoi(getenv("AASR_BF16_PIPE")) : 0;
+  if (pipe_mode == 2 && !cl) {
+    switch (L.nk16) {
+#define AASR_CASE(N)                                                        \
+  case N:                                                                   \
+    if (L.grouped) launch_bf16h_t<N, true>(g, L, d_frames, F, d_out, stream); \
+    else launch_bf16h_t<N, false>(g, L, d_frames, F, d_out, stream);        \
     return true;
+      AASR_CASE(1) AASR_CASE(2) AASR_CASE(3) AASR_CASE(4) AASR_CASE(5) AASR_CASE(6) AASR_CASE(8)
+#undef AASR_CASE
+      default:
+        break;
+    }
   }
   switch (L.nk16) {
 #define AASR_CASE(N)                                                                      \

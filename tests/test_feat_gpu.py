@@ -211,7 +211,9 @@ def test_config_errors(capi):
             capi.Feat(text)
         return ei.value
     assert "Unknown module type" in err("module\n{\n name a\n type nosuch\n}\n").msg
-    assert err("module\n{\n name a\n type pre\n}\n").code == capi.AASR_ERR_UNSUPPORTED
+    assert "PreModule: Must set dimension" in err("module\n{\n name a\n type pre\n}\n").msg
+    assert err("module\n{\n name a\n type audiofile\n sample_rate 16000\n}\nmodule\n{\n name f\n type fft\n sources a\n}\n"
+               "module\n{\n name v\n type vtln\n all-pass 1\n slapt 1\n lanczos_window 0\n sources f\n}\n").code == capi.AASR_ERR_UNSUPPORTED
     assert "first module should be a base module" in err("module\n{\n name a\n type fft\n}\n").msg
     assert "Must set sample rate" in err("module\n{\n name a\n type audiofile\n}\n").msg
     assert "value redefined" in err("module\n{\n name a\n name b\n type audiofile\n}\n").msg
