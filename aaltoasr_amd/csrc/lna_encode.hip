@@ -14,9 +14,13 @@
 //   otherwise                   -> normal float, relative rounding 6e-8 (kept)
 //
 // One workgroup per frame; HBM-bound: S*(4 in + lnabytes out) bytes per frame.
+// (A wave-per-frame variant without workgroup barriers was measured 2.5 ms slower
+// on 449 280 x 3125: it reads the row three times with 4-byte loads.)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -26,12 +30,26 @@ namespace aasr {
 #define LOG_TINY_D (-115.12925464970228420090)  // log(1e-50)
 #define LN_FLT_MIN_F (-87.33654475f)             // ln(2^-126)
 
+// log of (float)exp(ll) as the reference stores it; -inf when it flushes to 0.
+// Inside the denormal band the stored value is q * 2^-149 with
+// q = rint(2^149 * e^ll) in [1, 2^23].  q is computed in float: the product
+// ll * log2(e) is carried as hi + lo (error-free split), 2^(hi + 149) comes from
+// v_exp_f32 (the addition is exact) and lo is applied as a first-order factor, so
+// q is right except within ~2 float ulps of a rounding tie -- at most one quantum,
+// i.e. <= 2.4e-7 relative for q > 2^22 and exact for small q.  log(q) is taken in
+// float (error < 2e-6); the band is wave-divergent and frequent for weak states,
+// so a double exp/log pair here used to dominate the kernel.
 __device__ __forceinline__ double float_cast_loglik(float ll) {
-  // log of (float)exp(ll) as the reference stores it; -inf when it flushes to 0
   if (ll >= LN_FLT_MIN_F) return (double)ll;
-  double q = rint(exp((double)ll + 149.0 * LN2_D));
-  if (q <= 0.0) return -INFINITY;
-  return log(q) - 149.0 * LN2_D;
+  if (ll < -103.98f) return -INFINITY;  // 2^149 e^ll < 0.5: rounds to zero
+  const float L1 = 1.44269502162933349609375f;   // float(log2 e)
+  const float L2 = 1.92596303350001e-08f;        // log2 e - L1
+  const float hi = ll * L1;
+  const float lo = fmaf(ll, L1, -hi) + ll * L2;
+  const float t = __builtin_amdgcn_exp2f(hi + 149.0f) * (1.0f + lo * 0.69314718f);
+  const float q = rintf(t);
+  if (q <= 0.0f) return -INFINITY;
+  return (double)(__builtin_amdgcn_logf(q) * 0.69314718f) - 149.0 * LN2_D;
 }
 
 template <class T>
