@@ -36,7 +36,7 @@ class RunOptions(C.Structure):
     _fields_ = [("lnabytes", C.c_int32), ("normalize", C.c_int32), ("num_batches", C.c_int32),
                 ("batch_index", C.c_int32), ("no_overwrite", C.c_int32), ("raw_audio", C.c_int32),
                 ("info", C.c_int32), ("afname", C.c_int32), ("out_dir", C.c_char_p),
-                ("speakers", C.c_void_p)]
+                ("speakers", C.c_void_p), ("sort_recipe", C.c_int32)]
 
 
 class RunStats(C.Structure):
@@ -484,10 +484,11 @@ class SpeakerConfig:
 def run_recipe(feat: Feat, gmm: Gmm, recipe_path: str, lnabytes: int = 2, normalize: bool = True,
                num_batches: int = 0, batch_index: int = 0, no_overwrite: bool = False,
                raw_audio: bool = False, info: int = 0, afname: bool = False,
-               out_dir: Optional[str] = None, speakers: Optional[SpeakerConfig] = None) -> RunStats:
+               out_dir: Optional[str] = None, speakers: Optional[SpeakerConfig] = None,
+               sort_recipe: bool = False) -> RunStats:
     opt = RunOptions(lnabytes, int(normalize), num_batches, batch_index, int(no_overwrite),
                      int(raw_audio), info, int(afname), out_dir.encode() if out_dir else None,
-                     speakers._h if speakers is not None else None)
+                     speakers._h if speakers is not None else None, int(sort_recipe))
     st = RunStats()
     check(lib().aasr_run_recipe(feat._h, gmm._h, recipe_path.encode(), C.byref(opt), C.byref(st)))
     return st

@@ -4,8 +4,8 @@
 //   phone_probs (-b BASE | -g GK -m MC -p PH) -c CFG -r RECIPE [-o DIR]
 //               [--lnabytes 2|4] [-a] [-n] [-N] [-B n -I k] [-i level]
 //               [-C GCL --eval-minc R --eval-ming R] [-S SPKC]
-//
-// Not built (fail loudly): --sort-recipe.  One process drives one GPU (--device N or
+//               [--sort-recipe] [--model-cache FILE]
+// One process drives one GPU (--device N or
 // HIP_VISIBLE_DEVICES); run N processes with -B N -I k for N GPUs, exactly as
 // the reference scales over CPU cores.
 #include <getopt.h>
@@ -29,6 +29,7 @@ int main(int argc, char *argv[]) {
   std::string clusters, speakers, model_cache;
   double eval_minc = 0.0, eval_ming = 0.1;  // defaults of aku/phone_probs.cc:74-75
   int lnabytes = 2, info = 0, batch = 0, bindex = 0, device = -1;
+  bool sort_recipe = false;
   bool afname = false, no_overwrite = false, no_norm = false, batch_set = false, bindex_set = false;
   static struct option opts[] = {
       {"help", no_argument, 0, 'h'},          {"base", required_argument, 0, 'b'},
@@ -75,7 +76,7 @@ int main(int argc, char *argv[]) {
       case 'C': clusters = optarg; break;
       case 2: eval_minc = atof(optarg); break;
       case 3: eval_ming = atof(optarg); break;
-      case 4: die("--sort-recipe is not built in this engine yet");
+      case 4: sort_recipe = true; break;
       default: return 2;
     }
   }
@@ -129,6 +130,7 @@ int main(int argc, char *argv[]) {
   opt.afname = afname;
   opt.out_dir = out_dir.empty() ? nullptr : out_dir.c_str();
   opt.speakers = spk;
+  opt.sort_recipe = sort_recipe;
   aasr_run_stats st;
   memset(&st, 0, sizeof st);
   if (aasr_run_recipe(feat, gmm, recipe.c_str(), &opt, &st) != AASR_OK) die(aasr_last_error());

@@ -10,6 +10,7 @@
 // bytes come back in one copy per block.
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <chrono>
 #include <climits>
 #include <cstdio>
@@ -317,6 +318,10 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
   std::stringstream ss;
   ss << rin.rdbuf();
   std::vector<RecipeInfo> infos = recipe_read(ss.str(), opt.num_batches, opt.batch_index);
+  if (opt.sort_recipe)  // Recipe::sort_infos after the batch slice (aku/phone_probs.cc:140-141)
+    std::stable_sort(infos.begin(), infos.end(), [](const RecipeInfo &a, const RecipeInfo &b) {
+      return a.speaker_id < b.speaker_id;
+    });
   std::string out_dir = opt.out_dir ? opt.out_dir : "";
   if (!out_dir.empty() && out_dir.back() != '/') out_dir += "/";
 

@@ -324,6 +324,8 @@ typedef struct aasr_run_options {
   int32_t afname;          /* -a: name outputs after the audio file */
   const char *out_dir;     /* -o: prefix for LNA paths or NULL      */
   struct aasr_spkc *speakers; /* -S: speaker configuration or NULL   */
+  int32_t sort_recipe;     /* --sort-recipe: stable sort of the slice by speaker id
+                              (Recipe::sort_infos, aku/Recipe.hh:86-88,115-117) */
 } aasr_run_options;
 
 typedef struct aasr_run_stats {

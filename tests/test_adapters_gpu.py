@@ -75,9 +75,15 @@ def test_phone_probs_cli_batches_and_errors(world):
     r = subprocess.run([exe, "-b", world["base"], "-c", world["cfg"], "-r", world["recipe"], "-S", "x.spkc"],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "could not open x.spkc" in r.stderr
-    r = subprocess.run([exe, "-b", world["base"], "-c", world["cfg"], "-r", world["recipe"], "--sort-recipe"],
-                       capture_output=True, text=True)
-    assert r.returncode != 0 and "not built" in r.stderr
+    # --sort-recipe: stable sort by speaker id (Recipe::sort_infos); processing order changes
+    rec = str(world["dir"] / "spk.recipe")
+    lines = open(world["recipe"]).read().split("\n")[:3]
+    open(rec, "w").write("\n".join(l + " speaker=%s" % s for l, s in zip(lines, "bab")) + "\n")
+    r = subprocess.run([exe, "-b", world["base"], "-c", world["cfg"], "-r", rec, "-a", "-o", str(out),
+                        "--sort-recipe", "-i", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    order = [l.split("/")[-1] for l in r.stdout.split("\n") if l.startswith("Input:")]
+    assert order == ["a1.wav", "a0.wav", "a2.wav"]
     r = subprocess.run([exe, "-c", world["cfg"], "-r", world["recipe"]], capture_output=True, text=True)
     assert r.returncode != 0 and "Must give either --base" in r.stderr
 
