@@ -155,9 +155,9 @@ struct ClusterState {
   DevBuf<int32_t> w_cluster;
   DevBuf<float> w_weight;
   double ref_log2 = 0;             // reference exponent shared with the track kernels
-  // per-call scratch, sized for Fc frames
-  int64_t Fc = 0;
-  DevBuf<double> ll64;             // [Fc][Cs] centre log-likelihoods
+  // per-call scratch: pass-wide buffers sized for Fc frames, ll64 for a sub-pass of Fs
+  int64_t Fc = 0, Fs = 0;
+  DevBuf<double> ll64;             // [Fs][Cs] centre log-likelihoods
   DevBuf<unsigned long long> maskw;  // [Fc/64][C+1] bit f = frame f takes the exact values
   DevBuf<unsigned long long> maskrow;  // [Fc/64][rows_padded] the same per packed row
   DevBuf<float> cval;              // [Fc][C] 2^(log2e*ll_c + ref) of the centres that stand in

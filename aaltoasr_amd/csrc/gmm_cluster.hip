@@ -564,14 +564,25 @@ static void launch_centres(aasr_gmm *g, const float *d_frames, int64_t F, hipStr
   AASR_HIP(hipGetLastError());
 }
 
+// sub-pass [s0, s0 + F) of the current pass: masks, centre values and counts land at
+// their place in the pass-wide buffers (s0 is a multiple of 64)
 template <int KPL>
-static void launch_select_t(aasr_gmm *g, int64_t F, hipStream_t stream) {
+static void launch_select_t(aasr_gmm *g, int64_t s0, int64_t F, hipStream_t stream) {
   ClusterState &cl = g->cl;
   const int64_t words = (F + 63) / 64;
   hipLaunchKernelGGL(k_cluster_select<KPL>, dim3((unsigned)words), dim3(64), 0, stream, cl.ll64.p, F,
                      cl.C, (int64_t)cl.Cs, cl.csize.p, cl.min_clusters, cl.min_gaussians, cl.ref_log2,
-                     cl.maskw.p, cl.cval.p, cl.n_exact.p);
+                     cl.maskw.p + (size_t)(s0 / 64) * (cl.C + 1), cl.cval.p + (size_t)s0 * cl.C,
+                     cl.n_exact.p + s0);
   AASR_HIP(hipGetLastError());
+}
+
+static void launch_select(aasr_gmm *g, int64_t s0, int64_t F, hipStream_t stream) {
+  const int kpl = (g->cl.C + 63) / 64;
+  if (kpl <= 4) launch_select_t<4>(g, s0, F, stream);
+  else if (kpl <= 16) launch_select_t<16>(g, s0, F, stream);
+  else if (kpl <= 32) launch_select_t<32>(g, s0, F, stream);
+  else launch_select_t<64>(g, s0, F, stream);
 }
 
 template <int NNZ>
@@ -611,35 +622,40 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
   const TrackLayout &L = which == 0 ? g->paired : g->tracks;
   if (!L.ok) raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering needs a track layout for this model");
   if (cl.crow[which].n != L.row_gauss.size()) build_crow(g, L, cl, cl.crow[which]);
-  // Frames per pass.  A pass is whole rounds of the track kernel (2 workgroups of 256
-  // frames per CU), so passes are sized in rounds: as many as ~6 GB of scratch allow
-  // (12 B per frame x cluster for the centre values, 1 bit per frame x packed row).
-  const double per_frame = 12.0 * (double)(cl.Cs + 1) + (double)L.rows_padded / 8.0;
+  // Frames per pass.  The track kernel and the merge run once per pass, so a pass is
+  // as large as ~16 GB of scratch allow (1 bit per frame x packed row for the lane
+  // masks, 4 B per frame x cluster for the centre values) and a whole number of rounds
+  // of the track kernel (2 workgroups of 256 frames per CU); the f64 centre
+  // log-likelihoods (8 B per frame x cluster) only live for a sub-pass of <= 2 GB.
+  const double per_frame = (double)L.rows_padded / 8.0 + 4.125 * (double)(cl.C + 1) + 4.0;
   const int64_t round_frames = 2 * (int64_t)(g->num_cus > 0 ? g->num_cus : 256) * FRAMES_PER_BLOCK;
-  int64_t fc = (int64_t)(6.0e9 / per_frame);
-  if (fc >= round_frames) fc = std::min<int64_t>(fc / round_frames, 4) * round_frames;
-  else fc = std::max<int64_t>(FRAMES_PER_BLOCK, fc / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK);
-  fc = std::min<int64_t>(fc, (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK);
-  const size_t need_rows = (size_t)(fc / 64) * (size_t)L.rows_padded;
-  if (fc > cl.Fc || need_rows > cl.maskrow.n) {
-    fc = std::max(fc, cl.Fc);
-    cl.ll64.alloc((size_t)fc * cl.Cs);
-    cl.cval.alloc((size_t)fc * cl.C);
-    cl.maskw.alloc((size_t)(fc / 64) * (cl.C + 1));
-    cl.maskrow.alloc((size_t)(fc / 64) * (size_t)L.rows_padded);
-    cl.n_exact.alloc((size_t)fc);
-    cl.Fc = fc;
+  const int64_t f_rounded = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK;
+  int64_t fb = (int64_t)(16.0e9 / per_frame);
+  if (fb >= round_frames) fb = fb / round_frames * round_frames;
+  else fb = std::max<int64_t>(FRAMES_PER_BLOCK, fb / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK);
+  fb = std::min<int64_t>(fb, f_rounded);
+  int64_t fs = (int64_t)(2.0e9 / (8.0 * (double)cl.Cs));
+  fs = std::min<int64_t>(fb, std::max<int64_t>(FRAMES_PER_BLOCK, fs / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK));
+  const size_t need_rows = (size_t)(fb / 64) * (size_t)L.rows_padded;
+  if (fb > cl.Fc || need_rows > cl.maskrow.n || (size_t)fs * cl.Cs > cl.ll64.n) {
+    fb = std::max(fb, cl.Fc);
+    cl.ll64.alloc((size_t)fs * cl.Cs);
+    cl.cval.alloc((size_t)fb * cl.C);
+    cl.maskw.alloc((size_t)(fb / 64) * (cl.C + 1));
+    cl.maskrow.alloc((size_t)(fb / 64) * (size_t)L.rows_padded);
+    cl.n_exact.alloc((size_t)fb);
+    cl.Fc = fb;
+    cl.Fs = fs;
   }
   for (int64_t f0 = 0; f0 < F; f0 += cl.Fc) {
     const int64_t n = std::min<int64_t>(cl.Fc, F - f0);
     const float *fr = d_frames + f0 * g->dim;
     float *out = d_out + f0 * g->S;
-    launch_centres(g, fr, n, stream);
-    const int kpl = (cl.C + 63) / 64;
-    if (kpl <= 4) launch_select_t<4>(g, n, stream);
-    else if (kpl <= 16) launch_select_t<16>(g, n, stream);
-    else if (kpl <= 32) launch_select_t<32>(g, n, stream);
-    else launch_select_t<64>(g, n, stream);
+    for (int64_t s0 = 0; s0 < n; s0 += cl.Fs) {
+      const int64_t ns = std::min<int64_t>(cl.Fs, n - s0);
+      launch_centres(g, fr + s0 * g->dim, ns, stream);
+      launch_select(g, s0, ns, stream);
+    }
     const int64_t words = (n + 63) / 64;
     hipLaunchKernelGGL(k_cluster_expand, dim3((unsigned)((L.rows_padded / 2 + 255) / 256), (unsigned)words),
                        dim3(256), 0, stream, cl.maskw.p, cl.C + 1, cl.crow[which].p, L.rows_padded,
