@@ -50,13 +50,69 @@ def parse_args():
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step (gmm workload)")
     ap.add_argument("--utts", type=int, default=360, help="10-s utterances per GPU per step (full workload)")
     ap.add_argument("--cpu-frames", type=int, default=20000, help="frames timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-procs", type=int, default=-1,
+                    help="processes of the all-cores CPU baseline (-1 = one per usable core, 0 = skip)")
+    ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--precision", choices=["bf16x3", "f32"], default=os.environ.get("AASR_BENCH_PRECISION", "bf16x3"),
                     help="contraction arithmetic of the scoring kernel (both meet the 1e-4 parity bar)")
     return ap.parse_args()
 
 
+def cpu_worker(n_frames):
+    """One process of the all-cores CPU baseline: the reference scales over cores by
+    running independent phone_probs processes on recipe slices (-B n -I k,
+    aku/Recipe.cc:63-115), so N copies of the single-thread loop is its native mode."""
+    from aaltoasr_amd import synth
+    from oracle import oracle as O
+    om = O.DiagModel(*synth.make_model(D=DIM, G=G, S=S, comps=COMPS))
+    cf = synth.make_frames(n_frames, DIM, seed=synth.SEED + 99).astype(np.float64)
+    om.cpu_baseline(cf[:20])
+    c0 = time.perf_counter()
+    om.cpu_baseline(cf)
+    print("CPUWORKER %d %.6f" % (n_frames, time.perf_counter() - c0), flush=True)
+
+
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (the GPU boxes expose 256 logical CPUs but schedule only a fraction of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_all_cores(n_procs, n_frames):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(n_frames)]
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for _ in range(n_procs)]
+    rate, done = 0.0, 0
+    for p in procs:
+        out, _ = p.communicate()
+        for ln in out.splitlines():
+            if ln.startswith("CPUWORKER"):
+                _, k, dt = ln.split()
+                rate += int(k) / float(dt)
+                done += 1
+    return rate, done, time.perf_counter() - t0
+
+
 def main():
     args = parse_args()
+    if args.cpu_worker > 0:
+        cpu_worker(args.cpu_worker)
+        return
     import torch
     import torch.distributed as dist
 
@@ -194,8 +250,17 @@ def main():
             "sample": "%d of the step's frames, same 50k-Gaussian model, oracle/aasr_oracle.c "
                       "orc_cpu_baseline_score (double, per-frame per-Gaussian exp, linear mixture sum, "
                       "float-cast normalisation) single thread, %.1f s" % (args.cpu_frames, cdt),
-            "host": _cpu_model(), "host_cores": os.cpu_count(),
+            "host": _cpu_model(), "host_cores": os.cpu_count(), "usable_cores": usable_cores(),
         }
+        n_procs = usable_cores() if args.cpu_procs < 0 else args.cpu_procs
+        if n_procs and n_procs > 1:
+            per = max(200, args.cpu_frames // 10)
+            rate, done, wall = cpu_all_cores(n_procs, per)
+            if done:
+                cpu["all_cores"] = {
+                    "value": round(rate, 1), "unit": "frames/s", "cores": done,
+                    "sample": "%d independent single-thread processes (the reference's -B/-I mode), %d frames "
+                              "each, sum of the per-process rates, %.1f s wall incl. start-up" % (done, per, wall)}
 
     if rank == 0:
         line = {
