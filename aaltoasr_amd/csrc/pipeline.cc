@@ -17,8 +17,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <condition_variable>
+#include <deque>
+#include <exception>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <sstream>
+#include <thread>
 
 #include "feat.h"
 #include "gmm.h"
@@ -239,8 +245,9 @@ struct BlockRunner {
   std::vector<uint8_t> h_bytes;
   double device_seconds = 0;
 
-  // features + scoring + LNA for a block of jobs; h_bytes = [sum count][S*lnabytes]
-  void run(const std::vector<Job *> &jobs) {
+  // features + scoring + LNA for a block of jobs; the packed rows [sum count][S*lnabytes]
+  // go to `dst` (a pinned buffer of the recipe runner) or, when null, to h_bytes
+  void run(const std::vector<Job *> &jobs, uint8_t *dst = nullptr, size_t dst_cap = 0) {
     UttBatch ub;
     ub.n_utts = (int32_t)jobs.size();
     ub.frame_off.assign(1, 0);
@@ -268,8 +275,14 @@ struct BlockRunner {
     feat_run_batch(feat, d_pcm.p, ub, (int)feat->mods.size() - 1, d_fea.p, nullptr, nullptr);
     gmm_score_launch(gmm, d_fea.p, F, d_ll.p, nullptr);
     lna_encode_launch(d_ll.p, F, (int)S, normalize, lnabytes, nullptr, d_bytes.p, nullptr);
-    h_bytes.resize((size_t)F * S * lnabytes);
-    AASR_HIP(hipMemcpy(h_bytes.data(), d_bytes.p, h_bytes.size(), hipMemcpyDeviceToHost));
+    const size_t nb = (size_t)F * S * lnabytes;
+    if (dst) {
+      if (nb > dst_cap) raise(AASR_ERR_INVALID, "internal: result buffer too small");
+      AASR_HIP(hipMemcpy(dst, d_bytes.p, nb, hipMemcpyDeviceToHost));
+    } else {
+      h_bytes.resize(nb);
+      AASR_HIP(hipMemcpy(h_bytes.data(), d_bytes.p, nb, hipMemcpyDeviceToHost));
+    }
     device_seconds += now_s() - t0;
   }
 };
@@ -330,22 +343,170 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
   const int64_t S = gmm->S;
   // frames per device block: bounded by the [F x S] float + byte buffers (~2 GiB)
   const int64_t block_frames = std::max<int64_t>(4096, (int64_t)(2.0e9 / (double)(S * (4 + opt.lnabytes))));
+
+  // Three stages: a reader thread (recipe order: skip checks, audio files, frame ranges), this
+  // thread (speaker settings, device blocks) and a writer thread (LNA files), so file IO
+  // overlaps the device.  Results travel through two pinned buffers.
+  struct Item {
+    Job job;
+    std::exception_ptr error;  // reading this utterance failed: rethrown in order
+    bool end = false;
+  };
+  struct Queue {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Item> q;
+    int64_t frames = 0;
+    bool abort = false;
+  } inq;
+  struct OutBlock {
+    std::vector<Job> jobs;
+    int slot = -1;
+    bool end = false;
+  };
+  struct OutQueue {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<OutBlock> q;
+    bool slot_busy[2] = {false, false};
+    std::exception_ptr error;
+  } outq;
+  uint8_t *pinned[2] = {nullptr, nullptr};
+  size_t pinned_cap = 0;
+  struct PinnedFree {
+    uint8_t **p;
+    ~PinnedFree() {
+      for (int i = 0; i < 2; i++)
+        if (p[i]) (void)hipHostFree(p[i]);
+    }
+  } pinned_free{pinned};
+
+  std::thread reader([&] {
+    for (size_t ri = 0; ri < infos.size(); ri++) {
+      Item it;
+      try {
+        const RecipeInfo &info = infos[ri];
+        if (opt.info > 0) {
+          printf("Processing file %d/%d\n", (int)ri + 1, (int)infos.size());
+          printf("Input: %s\n", info.audio_path.c_str());
+        }
+        std::string out_file = out_dir + info.lna_path;
+        if (opt.afname) {
+          std::string file = info.audio_path;
+          size_t pos = file.rfind('/');
+          if (pos != std::string::npos && pos + 1 < file.size()) file = file.substr(pos + 1);
+          pos = file.rfind('.');
+          if (pos != std::string::npos && pos > 0) file.erase(pos);
+          out_file = out_dir + file + ".lna";
+        }
+        if (opt.info > 0) printf("Output: %s\n", out_file.c_str());
+        if (opt.no_overwrite) {
+          struct stat sb;
+          if (stat(out_file.c_str(), &sb) == 0) {
+            fprintf(stderr, "WARNING: skipping existing lna file %s\n", out_file.c_str());
+            continue;
+          }
+        }
+        it.job.info_index = ri;
+        it.job.out_file = out_file;
+        it.job.pcm = read_input_file(feat, info.audio_path, opt.raw_audio != 0);
+        frame_range(feat, (int64_t)it.job.pcm.size(), info.start_time, info.end_time, &it.job.start,
+                    &it.job.count);
+        if (opt.info > 0 && (it.job.start != 0 || info.end_time != 0))
+          printf("Generating frames %d - %d\n", it.job.start, it.job.start + it.job.count);
+      } catch (...) {
+        it.error = std::current_exception();
+      }
+      const bool failed = (bool)it.error;
+      {
+        std::unique_lock<std::mutex> lk(inq.m);
+        inq.cv.wait(lk, [&] { return inq.abort || inq.frames < 2 * block_frames; });
+        if (inq.abort) return;
+        inq.frames += it.job.count;
+        inq.q.push_back(std::move(it));
+      }
+      inq.cv.notify_all();
+      if (failed) return;  // the reference stops at the first error
+    }
+    {
+      std::lock_guard<std::mutex> lk(inq.m);
+      Item e;
+      e.end = true;
+      inq.q.push_back(std::move(e));
+    }
+    inq.cv.notify_all();
+  });
+
+  std::thread writer([&] {
+    for (;;) {
+      OutBlock b;
+      {
+        std::unique_lock<std::mutex> lk(outq.m);
+        outq.cv.wait(lk, [&] { return !outq.q.empty(); });
+        b = std::move(outq.q.front());
+        outq.q.pop_front();
+      }
+      if (b.end) return;
+      try {
+        if (!outq.error) {
+          size_t off = 0;
+          for (Job &j : b.jobs) {
+            const size_t nb = (size_t)j.count * S * opt.lnabytes;
+            write_lna_file(j.out_file, (int32_t)S, opt.lnabytes, pinned[b.slot] + off, nb);
+            off += nb;
+          }
+        }
+      } catch (...) {
+        std::lock_guard<std::mutex> lk(outq.m);
+        if (!outq.error) outq.error = std::current_exception();
+      }
+      {
+        std::lock_guard<std::mutex> lk(outq.m);
+        outq.slot_busy[b.slot] = false;
+      }
+      outq.cv.notify_all();
+    }
+  });
+
   std::vector<Job> pending;
   int64_t pending_frames = 0, total_frames = 0, total_utts = 0;
+  int next_slot = 0;
+  std::exception_ptr failure;
 
   auto flush = [&]() {
     if (pending.empty()) return;
+    const size_t need = (size_t)pending_frames * S * opt.lnabytes;
+    const int slot = next_slot;
+    next_slot ^= 1;
+    {
+      std::unique_lock<std::mutex> lk(outq.m);
+      outq.cv.wait(lk, [&] { return !outq.slot_busy[slot] && (need <= pinned_cap || !outq.slot_busy[slot ^ 1]); });
+      if (outq.error) std::rethrow_exception(outq.error);
+      outq.slot_busy[slot] = true;
+    }
+    if (need > pinned_cap) {  // both slots idle here: grow them together
+      const size_t cap = std::max(need, (size_t)block_frames * S * opt.lnabytes);
+      for (int i = 0; i < 2; i++) {
+        if (pinned[i]) (void)hipHostFree(pinned[i]);
+        pinned[i] = nullptr;
+        AASR_HIP(hipHostMalloc((void **)&pinned[i], cap, hipHostMallocDefault));
+      }
+      pinned_cap = cap;
+    }
     std::vector<Job *> jobs;
     for (Job &j : pending) jobs.push_back(&j);
-    br.run(jobs);
-    size_t off = 0;
-    for (Job &j : pending) {
-      size_t nb = (size_t)j.count * S * opt.lnabytes;
-      write_lna_file(j.out_file, (int32_t)S, opt.lnabytes, br.h_bytes.data() + off, nb);
-      off += nb;
-    }
+    br.run(jobs, pinned[slot], pinned_cap);
+    OutBlock ob;
+    ob.slot = slot;
+    ob.jobs = std::move(pending);
+    for (Job &j : ob.jobs) std::vector<int16_t>().swap(j.pcm);
     pending.clear();
     pending_frames = 0;
+    {
+      std::lock_guard<std::mutex> lk(outq.m);
+      outq.q.push_back(std::move(ob));
+    }
+    outq.cv.notify_all();
   };
 
   // -S: parameters change between utterances; everything queued so far must be
@@ -356,47 +517,50 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
   } unhook{opt.speakers};
   if (opt.speakers) spkc_set_before_change(opt.speakers, flush);
 
-  for (size_t ri = 0; ri < infos.size(); ri++) {
-    const RecipeInfo &info = infos[ri];
-    if (opt.info > 0) {
-      printf("Processing file %d/%d\n", (int)ri + 1, (int)infos.size());
-      printf("Input: %s\n", info.audio_path.c_str());
-    }
-    std::string out_file = out_dir + info.lna_path;
-    if (opt.afname) {
-      std::string file = info.audio_path;
-      size_t pos = file.rfind('/');
-      if (pos != std::string::npos && pos + 1 < file.size()) file = file.substr(pos + 1);
-      pos = file.rfind('.');
-      if (pos != std::string::npos && pos > 0) file.erase(pos);
-      out_file = out_dir + file + ".lna";
-    }
-    if (opt.info > 0) printf("Output: %s\n", out_file.c_str());
-    if (opt.no_overwrite) {
-      struct stat sb;
-      if (stat(out_file.c_str(), &sb) == 0) {
-        fprintf(stderr, "WARNING: skipping existing lna file %s\n", out_file.c_str());
-        continue;
+  try {
+    for (;;) {
+      Item it;
+      {
+        std::unique_lock<std::mutex> lk(inq.m);
+        inq.cv.wait(lk, [&] { return !inq.q.empty(); });
+        it = std::move(inq.q.front());
+        inq.q.pop_front();
+        inq.frames -= it.job.count;
       }
+      inq.cv.notify_all();
+      if (it.end) break;
+      if (it.error) std::rethrow_exception(it.error);
+      const RecipeInfo &info = infos[it.job.info_index];
+      if (opt.speakers) {  // aku/phone_probs.cc:191-196
+        spkc_set_speaker(opt.speakers, info.speaker_id);
+        if (!info.utterance_id.empty()) spkc_set_utterance(opt.speakers, info.utterance_id);
+      }
+      if (pending_frames + it.job.count > block_frames) flush();
+      pending_frames += it.job.count;
+      total_frames += it.job.count;
+      total_utts++;
+      pending.push_back(std::move(it.job));
     }
-    if (opt.speakers) {  // aku/phone_probs.cc:191-196
-      spkc_set_speaker(opt.speakers, info.speaker_id);
-      if (!info.utterance_id.empty()) spkc_set_utterance(opt.speakers, info.utterance_id);
-    }
-    Job j;
-    j.info_index = ri;
-    j.out_file = out_file;
-    j.pcm = read_input_file(feat, info.audio_path, opt.raw_audio != 0);
-    frame_range(feat, (int64_t)j.pcm.size(), info.start_time, info.end_time, &j.start, &j.count);
-    if (opt.info > 0 && (j.start != 0 || info.end_time != 0))
-      printf("Generating frames %d - %d\n", j.start, j.start + j.count);
-    if (pending_frames + j.count > block_frames) flush();
-    pending_frames += j.count;
-    total_frames += j.count;
-    total_utts++;
-    pending.push_back(std::move(j));
+    flush();
+  } catch (...) {
+    failure = std::current_exception();
   }
-  flush();
+  {  // stop the helpers (the writer first finishes what was queued)
+    std::lock_guard<std::mutex> lk(inq.m);
+    inq.abort = true;
+  }
+  inq.cv.notify_all();
+  {
+    std::lock_guard<std::mutex> lk(outq.m);
+    OutBlock e;
+    e.end = true;
+    outq.q.push_back(std::move(e));
+  }
+  outq.cv.notify_all();
+  reader.join();
+  writer.join();
+  if (failure) std::rethrow_exception(failure);
+  if (outq.error) std::rethrow_exception(outq.error);
   if (stats) {
     stats->utterances = total_utts;
     stats->frames = total_frames;
