@@ -39,6 +39,7 @@ DIM = 39
 G = 50000
 S = 3125
 COMPS = 16
+NOMINAL_SCLK_MHZ = 2400.0   # the clock the datasheet peaks are quoted at
 
 
 def parse_args():
@@ -229,6 +230,15 @@ def main():
         "kernel_ms": round(k_ms, 4), "algorithmic_flop_per_launch": algo_flop, "peak_note": peak_note,
         "frac_of_fp32_matrix_peak": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
     }
+    # clock / power while the kernel runs: the bf16 matrix pipe draws the chip into its
+    # power cap, so the nominal-clock peak above is not what the silicon offers
+    obs = _observe_clock(lambda: [score_only() for _ in range(max(8, int(1500.0 / max(k_ms, 1e-3))))],
+                         torch) if rank == 0 else None
+    if obs:
+        roofline.update(obs)
+        if obs.get("sclk_mhz"):
+            adj = peak * obs["sclk_mhz"] / NOMINAL_SCLK_MHZ
+            roofline["frac_of_clock_adjusted_peak"] = round(achieved / adj, 4)
     td = _pmc_traffic(F, args.precision)
     if td:
         roofline["traffic"] = td["bytes"]
@@ -276,6 +286,33 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _observe_clock(enqueue, torch):
+    """Queues ~1.5 s of scoring launches and reads rocm-smi once while they run."""
+    import re
+    import subprocess
+    try:
+        torch.cuda.synchronize()
+        enqueue()
+        time.sleep(0.4)
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True,
+                             timeout=20).stdout
+        torch.cuda.synchronize()
+        res = {}
+        m = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
+        if m:
+            res["sclk_mhz"] = int(m.group(1))
+        m = re.search(r"Package Power \(W\): ([0-9.]+)", out)
+        if m:
+            res["power_w"] = float(m.group(1))
+        return res or None
+    except Exception:
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
+        return None
 
 
 def _pmc_traffic(frames, precision="f32"):
