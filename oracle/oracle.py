@@ -1290,6 +1290,32 @@ def ref_kissfft():
     return K
 
 
+def ref_lna():
+    """The reference recogniser's LNA reader (decoder/src/LnaReaderCircular.cc)
+    compiled in place (oracle/Makefile) -- None when oracle/_ref is absent."""
+    p = os.path.join(_HERE, "_ref", "liblna_ref.so")
+    if not os.path.exists(p):
+        return None
+    R = C.CDLL(p)
+    R.ref_lna_read.restype = C.c_int
+    R.ref_lna_read.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int,
+                               C.POINTER(C.c_int)]
+    return R
+
+
+def ref_lna_read(path: str, max_frames: int, num_states: int, buf_size: int = 8, order: int = 0):
+    """[frames x S] float32 as LnaReaderCircular::go_to / log_prob serve them."""
+    R = ref_lna()
+    out = np.zeros((max_frames, num_states), np.float32)
+    S = C.c_int()
+    n = R.ref_lna_read(path.encode(), buf_size, order, _p(out, C.c_float), max_frames, C.byref(S))
+    if n < 0:
+        raise RuntimeError("LnaReaderCircular look-back returned different values")
+    if S.value != num_states:
+        raise ValueError("header says %d states" % S.value)
+    return out[:n]
+
+
 def ref_aku():
     p = os.path.join(_HERE, "_ref", "libaku_ref.so")
     if not os.path.exists(p):

@@ -157,3 +157,25 @@ def test_engine_acoustics_equals_lna_reader_view(capi, oracle, world, nbytes, bl
         b = body.reshape(-1, 2).astype(np.int64)
         want = ((b[:, 0] * 256 + b[:, 1]) / -1820.0).astype(np.float32).reshape(frames, 32)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("nbytes", [2, 4])
+def test_engine_lna_files_through_the_reference_decoder_reader(capi, oracle, world, nbytes):
+    """Files written by this engine's phone_probs, opened with the reference recogniser's own
+    LnaReaderCircular (compiled in place into oracle/_ref/liblna_ref.so; the prebuilt library
+    travels to the GPU box): frame count, state count and every log_prob() are what
+    EngineAcoustics serves in memory."""
+    if oracle.ref_lna() is None:
+        pytest.skip("oracle/_ref/liblna_ref.so not built")
+    lna, frames = capi.run_utterance(world["ft"], world["gm"], world["pcms"][1], lnabytes=nbytes)
+    path = str(world["dir"] / ("reader_%d.lna" % nbytes))
+    with open(path, "wb") as f:
+        f.write(lna)
+    got = oracle.ref_lna_read(path, frames + 10, 32, buf_size=16, order=1)
+    assert got.shape == (frames, 32)
+    out = str(world["dir"] / ("ac_reader_%d.f32" % nbytes))
+    r = subprocess.run([os.path.join(BIN, "acoustics_check"), world["cfg"], world["base"],
+                        str(world["dir"] / "a1.wav"), str(nbytes), "256", out],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(got, np.fromfile(out, np.float32).reshape(frames, 32))

@@ -320,3 +320,35 @@ def test_pre_module_golden(oracle, golden_dir):
     assert np.abs(out - ref).max() <= 0.005 + 1e-9
     assert np.array_equal(pre.generate(feats, -2, 2), np.repeat(out[:1], 2, 0))
     assert np.array_equal(pre.generate(feats, 51, 3), np.repeat(out[-1:], 3, 0))
+
+
+@pytest.mark.parametrize("nbytes", [2, 4])
+def test_lna_files_read_by_the_reference_decoder_reader(oracle, tmp_path, nbytes):
+    """The consumer side of the LNA format, pinned on the real reference code: a file written
+    by the oracle's phone_probs restatement (aku/phone_probs.cc:213-262) is opened with the
+    recogniser's own LnaReaderCircular (decoder/src/LnaReaderCircular.cc, compiled in place) and
+    its log_prob() view is (a) what the oracle's lna_decode says and (b) within the format's
+    resolution of the log-probabilities phone_probs computed."""
+    if oracle.ref_lna() is None:
+        pytest.skip("oracle/_ref/liblna_ref.so not built (no reference tree)")
+    rng = np.random.default_rng(11)
+    F, S = 57, 43
+    lik = np.exp(rng.uniform(-60, 3, (F, S)))
+    lik[3, :] = 0.0                       # Z == 0 row
+    lik[5, 7] = 1e-300                    # far below the 2-byte range
+    lp, by = oracle.lna_encode(lik, True, nbytes)
+    path = str(tmp_path / "x.lna")
+    with open(path, "wb") as f:
+        f.write(oracle.lna_header(S, nbytes))
+        f.write(by.tobytes())
+    for order, buf in ((0, 1), (0, 8), (1, 8), (1, 57)):
+        got = oracle.ref_lna_read(path, F + 5, S, buf_size=buf, order=order)
+        assert got.shape == (F, S)       # go_to() reports EOF exactly after the last frame
+        want = oracle.lna_decode(open(path, "rb").read())
+        assert np.array_equal(got, want.astype(np.float32))
+    if nbytes == 4:
+        assert np.array_equal(got, lp)
+    else:
+        inside = lp > -36.0
+        assert np.abs(got - lp)[inside].max() <= 0.5 / 1820 + 1e-6
+        assert np.all(got[~inside] <= -36.0)
