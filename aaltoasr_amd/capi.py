@@ -146,6 +146,8 @@ def _declare(L: C.CDLL) -> None:
                                      C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(i64), C.POINTER(i64)]
     L.aasr_free.argtypes = [vp]
     L.aasr_free.restype = None
+    L.aasr_audio_read.argtypes = [vp, cp, C.POINTER(C.POINTER(C.c_int16)), C.POINTER(i64),
+                                  C.POINTER(i32)]
 
 
 def check(status: int) -> None:
@@ -429,6 +431,20 @@ def recipe_batch_range(total: int, num_batches: int, batch_index: int):
     f, n = C.c_int32(), C.c_int32()
     check(lib().aasr_recipe_batch_range(total, num_batches, batch_index, C.byref(f), C.byref(n)))
     return f.value, n.value
+
+
+def audio_read(path: str, feat: Optional["Feat"] = None):
+    """AudioReader::open + read (host only).  Returns (int16 samples, sample rate)."""
+    out = C.POINTER(C.c_int16)()
+    n = C.c_int64()
+    rate = C.c_int32()
+    check(lib().aasr_audio_read(feat._h if feat is not None else None, path.encode(), C.byref(out),
+                                C.byref(n), C.byref(rate)))
+    try:
+        pcm = np.ctypeslib.as_array(out, shape=(max(n.value, 1),))[:n.value].copy()
+    finally:
+        lib().aasr_free(out)
+    return pcm, rate.value
 
 
 def run_utterance(feat: Feat, gmm: Gmm, pcm: np.ndarray, start_frame: int = 0, end_frame: int = 0,

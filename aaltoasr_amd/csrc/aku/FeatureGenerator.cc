@@ -42,20 +42,11 @@ void FeatureGenerator::close_configuration() {
 
 void FeatureGenerator::open(const std::string &filename) {
   if (!m_feat) throw std::string("no feature modules defined");
-  if (aasr_feat_input_is_features(m_feat)) {
-    // PreModule::set_fname / set_file (aku/FeatureModules.cc:588-631)
-    try {
-      m_pcm = aasr::read_feature_file(filename, aasr_feat_input_dim(m_feat),
-                                      aasr_feat_pre_legacy(m_feat) != 0);
-    } catch (aasr::Error &e) {
-      throw std::string(e.msg);
-    }
-  } else {
-    try {
-      m_pcm = aasr::read_audio_file(filename, false, aasr_feat_sample_rate(m_feat));
-    } catch (...) {
-      throw std::string("AudioReader::open(): could not open file:") + filename;
-    }
+  // AudioFileModule::set_fname / PreModule::set_fname (aku/FeatureModules.cc:244-262, 588-631)
+  try {
+    m_pcm = aasr::read_input_file(m_feat, filename, false);
+  } catch (aasr::Error &e) {
+    throw std::string(e.msg);
   }
   m_open = true;
   m_block_count = 0;
@@ -68,33 +59,13 @@ void FeatureGenerator::open(FILE *file, bool) {
   char buf[65536];
   size_t n;
   while ((n = fread(buf, 1, sizeof buf, file)) > 0) data.insert(data.end(), buf, buf + n);
-  if (aasr_feat_input_is_features(m_feat)) {
-    try {
-      m_pcm = aasr::parse_feature_data(data, aasr_feat_input_dim(m_feat), aasr_feat_pre_legacy(m_feat) != 0);
-    } catch (aasr::Error &e) {
-      throw std::string(e.msg);
-    }
-    m_open = true;
-    m_block_count = 0;
-    m_eof_on_last_frame = false;
-    return;
+  // sf_open_fd on the stream, headerless PCM16 when no container is recognised
+  // (aku/AudioReader.cc:112-142); feature data for `pre` graphs
+  try {
+    m_pcm = aasr::decode_input_data(m_feat, data, "(stream)");
+  } catch (aasr::Error &e) {
+    throw std::string(e.msg);
   }
-  // RIFF header handling lives in read_audio_file; streams carry raw PCM16 or WAV
-  size_t body = 0;
-  if (data.size() >= 44 && !memcmp(data.data(), "RIFF", 4) && !memcmp(data.data() + 8, "WAVE", 4)) {
-    size_t pos = 12;
-    while (pos + 8 <= data.size()) {
-      uint32_t len;
-      memcpy(&len, data.data() + pos + 4, 4);
-      if (!memcmp(data.data() + pos, "data", 4)) {
-        body = pos + 8;
-        break;
-      }
-      pos += 8 + len + (len & 1);
-    }
-  }
-  m_pcm.resize((data.size() - body) / 2);
-  if (!m_pcm.empty()) memcpy(m_pcm.data(), data.data() + body, m_pcm.size() * 2);
   m_open = true;
   m_block_count = 0;
   m_eof_on_last_frame = false;

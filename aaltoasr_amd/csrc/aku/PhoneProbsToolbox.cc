@@ -7,9 +7,7 @@
 #include <cstdlib>
 #include <vector>
 
-namespace aasr {
-std::vector<int16_t> read_audio_file(const std::string &path, bool force_raw, int expect_rate);
-}
+#include "../pipeline.h"
 
 namespace aku {
 
@@ -63,8 +61,15 @@ static void run(FeatureGenerator &gen, HmmSet &model, const std::vector<int16_t>
   aasr_free(lna);
 }
 
-void PPToolbox::generate_from_file_to_fd(const std::string &input, int out_fd, bool raw) {
-  std::vector<int16_t> pcm = aasr::read_audio_file(input, raw, raw ? 0 : m_gen.sample_rate());
+void PPToolbox::generate_from_file_to_fd(const std::string &input, int out_fd, bool) {
+  // the reference never looks at raw_flag (aku/PhoneProbsToolbox.cc:135-151 calls gen.open(name));
+  // headerless input is the audiofile module's `raw` option or the open fallback
+  std::vector<int16_t> pcm;
+  try {
+    pcm = aasr::read_input_file(m_gen.handle(), input, false);
+  } catch (aasr::Error &e) {
+    throw std::string(e.msg);
+  }
   run(m_gen, m_model, pcm, out_fd);
 }
 
@@ -73,8 +78,13 @@ void PPToolbox::generate_to_fd(int in_fd, int out_fd, bool) {
   uint8_t buf[65536];
   ssize_t n;
   while ((n = read(in_fd, buf, sizeof buf)) > 0) data.insert(data.end(), buf, buf + n);
-  std::vector<int16_t> pcm(data.size() / 2);
-  for (size_t i = 0; i < pcm.size(); i++) pcm[i] = (int16_t)(data[2 * i] | (data[2 * i + 1] << 8));
+  // FeatureGenerator::open_fd -> open(FILE*) (aku/FeatureGenerator.cc:55-66): raw_audio is ignored there too
+  std::vector<int16_t> pcm;
+  try {
+    pcm = aasr::decode_input_data(m_gen.handle(), std::vector<char>(data.begin(), data.end()), "(fd)");
+  } catch (aasr::Error &e) {
+    throw std::string(e.msg);
+  }
   run(m_gen, m_model, pcm, out_fd);
 }
 

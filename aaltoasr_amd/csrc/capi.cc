@@ -8,6 +8,7 @@
 #include "common.h"
 #include "feat.h"
 #include "gmm.h"
+#include "pipeline.h"
 
 namespace aasr {
 
@@ -348,5 +349,27 @@ void aasr_lna_header(int32_t num_states, int lnabytes, uint8_t out[5]) {
 }
 
 void aasr_free(void *p) { free(p); }
+
+aasr_status aasr_audio_read(const aasr_feat *feat, const char *path, int16_t **pcm, int64_t *n_samples,
+                            int32_t *sample_rate) {
+  return guarded([&] {
+    if (!path || !pcm || !n_samples) raise(AASR_ERR_INVALID, "aasr_audio_read: null argument");
+    int rate = 0;
+    std::vector<int16_t> v;
+    if (feat) {
+      const FeatModule &b = feat->mods[0];
+      if (b.type != MOD_AUDIOFILE) raise(AASR_ERR_INVALID, "aasr_audio_read: the graph does not start with an audiofile module");
+      v = read_audio_file(path, b.raw_audio != 0, b.sample_rate, b.endian == 2, &rate);
+    } else {
+      v = read_audio_file(path, false, 0, false, &rate);
+    }
+    int16_t *out = (int16_t *)malloc(std::max<size_t>(v.size(), 1) * sizeof(int16_t));
+    if (!out) raise(AASR_ERR_INVALID, "aasr_audio_read: out of memory");
+    if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(int16_t));
+    *pcm = out;
+    *n_samples = (int64_t)v.size();
+    if (sample_rate) *sample_rate = rate;
+  });
+}
 
 }  // extern "C"

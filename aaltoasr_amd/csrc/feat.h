@@ -64,6 +64,7 @@ struct FeatModule {
   // feature frames instead of audio.  Its input travels through the same int16
   // buffers as audio, two units per float.
   int legacy_file = 0;
+  int raw_audio = 0, endian = 0;  // audiofile: `raw 1`, `endian little|big` (1 / 2)
   // fft
   int magnitude = 1, take_log = 0;
   FftPlan fft;

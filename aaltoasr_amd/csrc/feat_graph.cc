@@ -404,6 +404,15 @@ static void configure(aasr_feat *h, FeatModule &m, const ModuleConfig &c) {
       m.dim = m.width;
       m.copy_borders = 1;
       c.get("copy_borders", m.copy_borders);
+      {
+        // :345-356 -- headerless input and its byte order
+        std::string endian;
+        c.get("endian", endian);
+        m.endian = endian == "little" ? 1 : endian == "big" ? 2 : 0;
+        int raw = 0;
+        c.get("raw", raw);
+        m.raw_audio = raw ? 1 : 0;
+      }
       if (m.width <= 0 || !(m.advance > 0))
         raise(AASR_ERR_INVALID, "AudioFileModule: invalid window (%d samples, advance %g)", m.width, m.advance);
       break;

@@ -133,55 +133,7 @@ std::vector<RecipeInfo> recipe_read(const std::string &text, int num_batches, in
 
 // ------------------------------------------------------------------- audio --
 
-// Stand-in for the libsndfile calls of AudioReader::open/read_from_file
-// (aku/AudioReader.cc:86-110,170-213): RIFF/WAVE PCM16 mono, else -- as the
-// reference's fallback does -- headerless 16-bit PCM (little endian).
-std::vector<int16_t> read_audio_file(const std::string &path, bool force_raw, int expect_rate) {
-  std::ifstream in(path, std::ios::binary);
-  if (!in) raise(AASR_ERR_IO, "AudioReader::open(): could not open file:%s", path.c_str());
-  std::vector<char> data((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
-  auto u32 = [&](size_t o) {
-    return (uint32_t)(uint8_t)data[o] | ((uint32_t)(uint8_t)data[o + 1] << 8) |
-           ((uint32_t)(uint8_t)data[o + 2] << 16) | ((uint32_t)(uint8_t)data[o + 3] << 24);
-  };
-  auto u16 = [&](size_t o) { return (uint16_t)((uint8_t)data[o] | ((uint8_t)data[o + 1] << 8)); };
-  size_t body = 0, nbytes = data.size();
-  if (!force_raw && data.size() >= 12 && !memcmp(data.data(), "RIFF", 4) &&
-      !memcmp(data.data() + 8, "WAVE", 4)) {
-    size_t pos = 12;
-    bool have_fmt = false, have_data = false;
-    int channels = 0, bits = 0, fmt = 0, rate = 0;
-    while (pos + 8 <= data.size()) {
-      uint32_t len = u32(pos + 4);
-      if (!memcmp(data.data() + pos, "fmt ", 4) && pos + 8 + 16 <= data.size()) {
-        fmt = u16(pos + 8);
-        channels = u16(pos + 10);
-        rate = (int)u32(pos + 12);
-        bits = u16(pos + 22);
-        have_fmt = true;
-      } else if (!memcmp(data.data() + pos, "data", 4)) {
-        body = pos + 8;
-        nbytes = std::min<size_t>(len, data.size() - body);
-        have_data = true;
-        break;
-      }
-      pos += 8 + (size_t)len + (len & 1);
-    }
-    if (!have_fmt || !have_data) raise(AASR_ERR_IO, "malformed WAV file: %s", path.c_str());
-    if (channels != 1)
-      raise(AASR_ERR_INVALID, "AudioReader: sorry, audio files with multiple channels not supported");
-    if (fmt != 1 || bits != 16)
-      raise(AASR_ERR_UNSUPPORTED, "audio sample format is not PCM16 (format %d, %d bits): %s", fmt,
-            bits, path.c_str());
-    if (expect_rate > 0 && rate != expect_rate)
-      raise(AASR_ERR_INVALID,
-            "Audio file sample rate (%d Hz) and model configuration (%d Hz) don't agree.", rate,
-            expect_rate);
-  }
-  std::vector<int16_t> pcm(nbytes / 2);
-  for (size_t i = 0; i < pcm.size(); i++) pcm[i] = (int16_t)u16(body + 2 * i);
-  return pcm;
-}
+// read_audio_file / decode_audio: audio_reader.cc
 
 // PreModule::set_file (aku/FeatureModules.cc:603-631): a feature file is the
 // dimension (native int32, or one byte for legacy files) followed by float32
@@ -219,7 +171,15 @@ std::vector<int16_t> read_feature_file(const std::string &path, int dim, bool le
 std::vector<int16_t> read_input_file(const aasr_feat *feat, const std::string &path, bool force_raw) {
   const FeatModule &b = feat->mods[0];
   if (b.type == MOD_PRE) return read_feature_file(path, b.dim, b.legacy_file != 0);
-  return read_audio_file(path, force_raw, b.sample_rate);
+  const bool raw = force_raw || b.raw_audio != 0;
+  return read_audio_file(path, raw, b.sample_rate, b.endian == 2);
+}
+
+std::vector<int16_t> decode_input_data(const aasr_feat *feat, const std::vector<char> &data,
+                                       const std::string &name) {
+  const FeatModule &b = feat->mods[0];
+  if (b.type == MOD_PRE) return parse_feature_data(data, b.dim, b.legacy_file != 0);
+  return decode_audio(data, name, b.raw_audio != 0, b.endian == 2, b.sample_rate);
 }
 
 // ------------------------------------------------------------------ driver --

@@ -15,9 +15,22 @@ struct RecipeInfo {
 
 void recipe_batch_range(int total, int num_batches, int batch_index, int *first, int *count);
 std::vector<RecipeInfo> recipe_read(const std::string &text, int num_batches, int batch_index);
-std::vector<int16_t> read_audio_file(const std::string &path, bool force_raw, int expect_rate);
+// audio_reader.cc
+std::vector<int16_t> read_audio_file(const std::string &path, bool force_raw, int expect_rate,
+                                     bool big_endian = false, int *rate_out = nullptr);
+std::vector<int16_t> decode_audio(const std::vector<char> &data, const std::string &name, bool force_raw,
+                                  bool big_endian, int expect_rate, int *rate_out = nullptr);
 std::vector<int16_t> parse_feature_data(const std::vector<char> &data, int dim, bool legacy);
 std::vector<int16_t> read_feature_file(const std::string &path, int dim, bool legacy);
+
+}  // namespace aasr
+struct aasr_feat;
+namespace aasr {
+// FeatureGenerator::open(filename) / open(FILE*) for whichever base module the graph has
+// (audiofile: container detection + the module's `raw` / `endian` options; pre: feature file)
+std::vector<int16_t> read_input_file(const aasr_feat *feat, const std::string &path, bool force_raw);
+std::vector<int16_t> decode_input_data(const aasr_feat *feat, const std::vector<char> &data,
+                                       const std::string &name);
 
 }  // namespace aasr
 

@@ -351,6 +351,19 @@ aasr_status aasr_run_utterance(aasr_feat *feat, aasr_gmm *gmm,
                                int64_t *lna_len, int64_t *frames_out);
 void aasr_free(void *p);
 
+/* Audio input of the audiofile module, host only (no device needed).  Replaces
+ * AudioReader::open + check_audio_parameters + read_from_file
+ * (aku/AudioReader.cc:86-110, 145-156, 170-213) and AudioFileModule::set_fname's
+ * sample-rate check (aku/FeatureModules.cc:244-262): RIFF/WAVE, AU, AIFF/AIFF-C
+ * and NIST SPHERE files holding integer PCM or G.711, converted to 16-bit the
+ * way sf_read_short() does; anything else is read as headerless PCM16 in the
+ * module's byte order -- the reference's fallback.  `feat` supplies the
+ * module's `sample_rate`, `raw` and `endian` options (NULL: no rate check,
+ * container detection on, little endian).  *pcm is malloc'ed; free it with
+ * aasr_free. */
+aasr_status aasr_audio_read(const aasr_feat *feat, const char *path, int16_t **pcm,
+                            int64_t *n_samples, int32_t *sample_rate);
+
 #ifdef __cplusplus
 }
 #endif

@@ -179,3 +179,54 @@ def test_engine_lna_files_through_the_reference_decoder_reader(capi, oracle, wor
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert np.array_equal(got, np.fromfile(out, np.float32).reshape(frames, 32))
+
+
+def test_audio_containers_and_raw_endian_options_through_phone_probs(capi, world):
+    """AudioFileModule's `raw` / `endian` options (aku/FeatureModules.cc:345-356) and the
+    containers libsndfile opens for the reference: the same samples as big-endian headerless
+    PCM (`raw 1`, `endian big`), Sun AU, AIFF and NIST SPHERE files give byte-identical LNA
+    files to the WAV input, from the CLI (recipe path) and the per-frame adapters (stream open)."""
+    import sunau
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)
+        import aifc
+    d = world["dir"]
+    pcm = world["pcms"][1]
+    want, _ = capi.run_utterance(world["ft"], world["gm"], pcm)
+    be = pcm.astype(">i2").tobytes()
+    open(str(d / "c.raw"), "wb").write(be)
+    with sunau.open(str(d / "c.au"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.setcomptype("NONE", "")
+        w.writeframes(be)
+    with aifc.open(str(d / "c.aiff"), "wb") as w:
+        w.aiff(); w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes(be)
+    head = ("NIST_1A\n   1024\nsample_count -i %d\nsample_n_bytes -i 2\nchannel_count -i 1\n"
+            "sample_byte_format -s2 10\nsample_rate -i 16000\nsample_coding -s3 pcm\nend_head\n" % len(pcm))
+    open(str(d / "c.sph"), "wb").write(head.encode().ljust(1024, b" ") + be)
+    cfg_text = open(world["cfg"]).read()
+    raw_cfg = str(d / "raw_be.feaconf")
+    assert "sample_rate 16000" in cfg_text
+    open(raw_cfg, "w").write(cfg_text.replace("sample_rate 16000", "sample_rate 16000\n  raw 1\n  endian big", 1))
+    for name, cfg in (("c.raw", raw_cfg), ("c.au", world["cfg"]), ("c.aiff", world["cfg"]), ("c.sph", world["cfg"])):
+        rec = str(d / "cont.recipe")
+        out = str(d / (name + ".lna"))
+        open(rec, "w").write("audio=%s lna=%s\n" % (d / name, out))
+        r = subprocess.run([os.path.join(BIN, "phone_probs"), "-b", world["base"], "-c", cfg, "-r", rec],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert open(out, "rb").read() == want, name
+    # a headerless little-endian file needs no option at all (AudioReader::open's fallback), and
+    # `raw 1` makes a WAV header part of the signal, as enforce_raw does
+    open(str(d / "c_le.raw"), "wb").write(pcm.astype("<i2").tobytes())
+    got, rate = capi.audio_read(str(d / "c_le.raw"), world["ft"])
+    assert rate == 16000 and np.array_equal(got, pcm)
+    ft_raw = capi.Feat(open(raw_cfg).read().replace("endian big", "endian little"))
+    got, _ = capi.audio_read(str(d / "a1.wav"), ft_raw)
+    assert len(got) == len(pcm) + 22 and np.array_equal(got[22:], pcm)
+    # sample-rate mismatch: the reference's message (aku/FeatureModules.cc:254-260)
+    _write_wav(str(d / "c8k.wav"), pcm, rate=8000)
+    with pytest.raises(capi.AasrError) as ei:
+        capi.audio_read(str(d / "c8k.wav"), world["ft"])
+    assert "Audio file sample rate (8000 Hz) and model configuration (16000 Hz) don't agree." in str(ei.value)
