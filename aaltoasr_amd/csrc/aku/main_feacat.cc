@@ -9,8 +9,6 @@
 // "%8.4f " per value (aku/feacat.cc:27-31); raw output is float32 with an
 // optional int32 dimension header (-H), the format PreModule reads back.
 // Not built: -w/--write-config, -G/--gaussian-std.
-#include <getopt.h>
-
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +16,7 @@
 #include <string>
 
 #include "FeatureGenerator.hh"
+#include "conf.hh"
 #include "SpeakerConfig.hh"
 
 static void die(const std::string &msg) {
@@ -26,40 +25,31 @@ static void die(const std::string &msg) {
 }
 
 int main(int argc, char *argv[]) {
-  std::string cfg, speakers, speaker_id, utterance_id;
-  bool raw_output = false, header = false, utt_set = false;
-  int start_frame = 0, end_frame = INT_MAX;
-  static struct option opts[] = {
-      {"help", no_argument, 0, 'h'},           {"config", required_argument, 0, 'c'},
-      {"write-config", required_argument, 0, 'w'}, {"raw-output", no_argument, 0, 1},
-      {"header", no_argument, 0, 'H'},         {"start-frame", required_argument, 0, 's'},
-      {"end-frame", required_argument, 0, 'e'}, {"speakers", required_argument, 0, 'S'},
-      {"speaker-id", required_argument, 0, 'd'}, {"utterance-id", required_argument, 0, 'u'},
-      {"gaussian-std", required_argument, 0, 'G'}, {0, 0, 0, 0}};
-  int c;
-  while ((c = getopt_long(argc, argv, "hc:w:Hs:e:S:d:u:G:", opts, nullptr)) != -1) {
-    switch (c) {
-      case 'h':
-        printf("usage: feacat [OPTION...] FILE\n  -c CFG  feature configuration\n  --raw-output  raw float output\n"
-               "  -H  write a header (feature dim, 32 bits) in raw output\n  -s INT  start frame\n"
-               "  -e INT  end frame\n  -S FILE  speaker configuration\n  -d NAME  speaker ID\n"
-               "  -u NAME  utterance ID\n");
-        return 0;
-      case 'c': cfg = optarg; break;
-      case 1: raw_output = true; break;
-      case 'H': header = true; break;
-      case 's': start_frame = atoi(optarg); break;
-      case 'e': end_frame = atoi(optarg); break;
-      case 'S': speakers = optarg; break;
-      case 'd': speaker_id = optarg; break;
-      case 'u': utterance_id = optarg; utt_set = true; break;
-      case 'w': die("--write-config is not built in this engine yet");
-      case 'G': die("--gaussian-std is not built in this engine yet");
-      default: return 2;
-    }
-  }
-  if (cfg.empty()) die("option --config is required");
-  if (argc - optind != 1) die("usage: feacat [OPTION...] FILE");
+  // option table of aku/feacat.cc:50-63, grammar of conf.hh
+  aku::conf::Config config;
+  config("usage: feacat [OPTION...] FILE\n")
+    ('h', "help", "", "", "display help")
+    ('c', "config=FILE", "arg must", "", "read feature configuration")
+    ('w', "write-config=FILE", "arg", "", "write feature configuration")
+    ('\0', "raw-output", "", "", "raw float output")
+    ('H', "header", "", "", "write a header (feature dim, 32 bits) in raw output")
+    ('s', "start-frame=INT", "arg", "", "audio start frame")
+    ('e', "end-frame=INT", "arg", "", "audio end frame")
+    ('S', "speakers=FILE", "arg", "", "speaker configuration file")
+    ('d', "speaker-id=NAME", "arg", "", "speaker ID")
+    ('u', "utterance-id=NAME", "arg", "", "utterance ID")
+    ('G', "gaussian-std=FLOAT", "arg", "", "Gaussian noise std added to features");
+  config.default_parse(argc, argv);
+  if (config.arguments.size() != 1) config.print_help(stderr, 1);
+  if (config["write-config"].specified) die("--write-config is not built in this engine yet");
+  if (config["gaussian-std"].specified) die("--gaussian-std is not built in this engine yet");
+  const bool raw_output = config["raw-output"].specified, header = config["header"].specified;
+  const std::string cfg = config["config"].get_str();
+  const std::string speakers = config["speakers"].specified ? config["speakers"].get_str() : "";
+  const std::string speaker_id = config["speaker-id"].get_str(), utterance_id = config["utterance-id"].get_str();
+  const bool utt_set = config["utterance-id"].specified;
+  const int start_frame = config["start-frame"].specified ? config["start-frame"].get_int() : 0;
+  const int end_frame = config["end-frame"].specified ? config["end-frame"].get_int() : INT_MAX;
   if (header && !raw_output) fprintf(stderr, "Warning: header is only written in raw output mode\n");
   try {
     aku::FeatureGenerator gen;
@@ -68,7 +58,7 @@ int main(int argc, char *argv[]) {
     if (!cf) throw std::string("could not open ") + cfg;
     gen.load_configuration(cf);
     fclose(cf);
-    std::string in = argv[optind];
+    const std::string in = config.arguments[0];
     if (in == "-") gen.open(stdin, true);
     else gen.open(in);
     if (!speakers.empty()) {

@@ -8,8 +8,6 @@
 // One process drives one GPU (--device N or
 // HIP_VISIBLE_DEVICES); run N processes with -B N -I k for N GPUs, exactly as
 // the reference scales over CPU cores.
-#include <getopt.h>
-
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -18,6 +16,7 @@
 #include <string>
 
 #include "../../../include/aasr.h"
+#include "conf.hh"
 
 static void die(const std::string &msg) {
   fprintf(stderr, "exception: %s\n", msg.c_str());
@@ -25,71 +24,61 @@ static void die(const std::string &msg) {
 }
 
 int main(int argc, char *argv[]) {
-  std::string base, gk, mc, ph, cfg, recipe, out_dir;
-  std::string clusters, speakers, model_cache;
-  double eval_minc = 0.0, eval_ming = 0.1;  // defaults of aku/phone_probs.cc:74-75
-  int lnabytes = 2, info = 0, batch = 0, bindex = 0, device = -1;
-  bool sort_recipe = false;
-  bool afname = false, no_overwrite = false, no_norm = false, batch_set = false, bindex_set = false;
-  static struct option opts[] = {
-      {"help", no_argument, 0, 'h'},          {"base", required_argument, 0, 'b'},
-      {"gk", required_argument, 0, 'g'},      {"mc", required_argument, 0, 'm'},
-      {"ph", required_argument, 0, 'p'},      {"config", required_argument, 0, 'c'},
-      {"recipe", required_argument, 0, 'r'},  {"output-dir", required_argument, 0, 'o'},
-      {"lnabytes", required_argument, 0, 1},  {"afname", no_argument, 0, 'a'},
-      {"no-overwrite", no_argument, 0, 'n'},  {"speakers", required_argument, 0, 'S'},
-      {"clusters", required_argument, 0, 'C'}, {"eval-minc", required_argument, 0, 2},
-      {"eval-ming", required_argument, 0, 3}, {"sort-recipe", no_argument, 0, 4},
-      {"no-normalization", no_argument, 0, 'N'}, {"batch", required_argument, 0, 'B'},
-      {"bindex", required_argument, 0, 'I'},  {"info", required_argument, 0, 'i'},
-      {"device", required_argument, 0, 5},    {"model-cache", required_argument, 0, 6},
-      {0, 0, 0, 0}};
-  int c;
-  while ((c = getopt_long(argc, argv, "hb:g:m:p:c:r:o:anS:C:NB:I:i:", opts, nullptr)) != -1) {
-    switch (c) {
-      case 'h':
-        printf("usage: phone_probs [OPTION...]\n"
-               "  -b BASE | -g GK -m MC -p PH   model files\n  -c CFG   feature configuration\n"
-               "  -r RECIPE  recipe file\n  -o DIR   output directory\n  --lnabytes=2|4\n"
-               "  -a  use audio file name\n  -n  no overwrite\n  -N  no normalization\n"
-               "  -B n -I k  batch k of n\n  -i level  info\n  --device=N  GPU ordinal\n"
-               "  --model-cache=FILE  binary model image (written on first use)\n  -S SPKC  speaker configuration file\n  -C GCL  Gaussian clustering file\n  --eval-minc=R  minimum ratio of top clusters\n"
-               "  --eval-ming=R  minimum ratio of Gaussians to evaluate\n");
-        return 0;
-      case 'b': base = optarg; break;
-      case 'g': gk = optarg; break;
-      case 'm': mc = optarg; break;
-      case 'p': ph = optarg; break;
-      case 'c': cfg = optarg; break;
-      case 'r': recipe = optarg; break;
-      case 'o': out_dir = optarg; break;
-      case 1: lnabytes = atoi(optarg); break;
-      case 'a': afname = true; break;
-      case 'n': no_overwrite = true; break;
-      case 'N': no_norm = true; break;
-      case 'B': batch = atoi(optarg); batch_set = true; break;
-      case 'I': bindex = atoi(optarg); bindex_set = true; break;
-      case 'i': info = atoi(optarg); break;
-      case 5: device = atoi(optarg); break;
-      case 6: model_cache = optarg; break;
-      case 'S': speakers = optarg; break;
-      case 'C': clusters = optarg; break;
-      case 2: eval_minc = atof(optarg); break;
-      case 3: eval_ming = atof(optarg); break;
-      case 4: sort_recipe = true; break;
-      default: return 2;
-    }
-  }
-  if (cfg.empty() || recipe.empty()) die("options --config and --recipe are required");
+  // the reference's option table (aku/phone_probs.cc:60-81) and grammar (conf.hh), plus the two
+  // options this engine adds
+  aku::conf::Config config;
+  config("usage: phone_probs [OPTION...]\n")
+    ('h', "help", "", "", "display help")
+    ('b', "base=BASENAME", "arg", "", "base filename for model files")
+    ('g', "gk=FILE", "arg", "", "Gaussian kernels")
+    ('m', "mc=FILE", "arg", "", "kernel indices for states")
+    ('p', "ph=FILE", "arg", "", "HMM definitions")
+    ('c', "config=FILE", "arg must", "", "feature configuration")
+    ('r', "recipe=FILE", "arg must", "", "recipe file")
+    ('o', "output-dir=DIR", "arg", "", "output directory (default: use filenames from recipe)")
+    ('\0', "lnabytes=INT", "arg", "2", "number of bytes for probabilities, 2 (default) or 4")
+    ('a', "afname", "", "", "use audio file name")
+    ('n', "no-overwrite", "", "", "prevent overwriting existing files")
+    ('S', "speakers=FILE", "arg", "", "speaker configuration file")
+    ('C', "clusters=FILE", "arg", "", "Gaussian clustering file")
+    ('\0', "eval-minc=FLOAT", "arg", "0", "minimum ratio of top clusters to evaluate")
+    ('\0', "eval-ming=FLOAT", "arg", "0.1", "minimum ratio of Gaussians to evaluate")
+    ('\0', "sort-recipe", "", "", "sort recipe lines, useful with adaptation")
+    ('N', "no-normalization", "", "", "do not normalize the likelihoods")
+    ('B', "batch=INT", "arg", "0", "number of batch processes with the same recipe")
+    ('I', "bindex=INT", "arg", "0", "batch process index")
+    ('i', "info=INT", "arg", "0", "info level")
+    ('\0', "device=INT", "arg", "-1", "GPU ordinal (default: the first visible device)")
+    ('\0', "model-cache=FILE", "arg", "", "binary model image, written on first use");
+  config.default_parse(argc, argv);
+
+  const int info = config["info"].get_int();
+  const std::string cfg = config["config"].get_str(), recipe = config["recipe"].get_str();
+  const int lnabytes = config["lnabytes"].get_int();
   if (lnabytes != 2 && lnabytes != 4) die("Invalid number of LNA bytes");
-  if (!base.empty()) {
+  const bool no_overwrite = config["no-overwrite"].specified, afname = config["afname"].specified;
+  const bool no_norm = config["no-normalization"].specified, sort_recipe = config["sort-recipe"].specified;
+  const std::string speakers = config["speakers"].specified ? config["speakers"].get_str() : "";
+  const std::string clusters = config["clusters"].specified ? config["clusters"].get_str() : "";
+  const std::string model_cache = config["model-cache"].get_str();
+  std::string gk, mc, ph, out_dir;
+  if (config["base"].specified) {
+    const std::string base = config["base"].get_str();
     gk = base + ".gk";
     mc = base + ".mc";
     ph = base + ".ph";
-  } else if (gk.empty() || mc.empty() || ph.empty()) {
+  } else if (config["gk"].specified && config["mc"].specified && config["ph"].specified) {
+    gk = config["gk"].get_str();
+    mc = config["mc"].get_str();
+    ph = config["ph"].get_str();
+  } else {
     die("Must give either --base or all --gk, --mc and --ph");
   }
-  if (batch_set != bindex_set) die("Must give both --batch and --bindex");
+  const double eval_minc = config["eval-minc"].get_double(), eval_ming = config["eval-ming"].get_double();
+  if (config["output-dir"].specified) out_dir = config["output-dir"].get_str();
+  if (config["batch"].specified ^ config["bindex"].specified) die("Must give both --batch and --bindex");
+  const int batch = config["batch"].get_int(), bindex = config["bindex"].get_int();
+  const int device = config["device"].get_int();
   if (device >= 0 && aasr_set_device(device) != AASR_OK) die(aasr_last_error());
 
   std::ifstream cin_(cfg);

@@ -230,3 +230,25 @@ def test_audio_containers_and_raw_endian_options_through_phone_probs(capi, world
     with pytest.raises(capi.AasrError) as ei:
         capi.audio_read(str(d / "c8k.wav"), world["ft"])
     assert "Audio file sample rate (8000 Hz) and model configuration (16000 Hz) don't agree." in str(ei.value)
+
+
+def test_phone_probs_takes_the_reference_option_grammar(world):
+    """Grouped short options with deferred arguments, --name=value, and `-i10` being three options
+    (aku/conf.hh:12-40); the grammar itself is pinned against aku/conf.cc in tests/test_conf_cli.py."""
+    d = world["dir"]
+    out = d / "grammar"
+    out.mkdir(exist_ok=True)
+    exe = os.path.join(BIN, "phone_probs")
+    r = subprocess.run([exe, "-bcr", world["base"], world["cfg"], world["recipe"], "-aN", "--lnabytes=4",
+                        "--output-dir", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    os.makedirs(str(d / "grammar2"), exist_ok=True)
+    r2 = subprocess.run([exe, "-b", world["base"], "-c", world["cfg"], "-r", world["recipe"], "-a", "-N",
+                         "--lnabytes", "4", "-o", str(d / "grammar2") + "/"], capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr
+    for i in range(3):
+        a = open(str(out / ("a%d.lna" % i)), "rb").read()
+        assert a == open(str(d / "grammar2" / ("a%d.lna" % i)), "rb").read() and a[4] == 4
+    r = subprocess.run([exe, "-b", world["base"], "-c", world["cfg"], "-r", world["recipe"], "-i10"],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and r.stderr.startswith("invalid option -1")
