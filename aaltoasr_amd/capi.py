@@ -146,6 +146,7 @@ def _declare(L: C.CDLL) -> None:
                                      C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(i64), C.POINTER(i64)]
     L.aasr_free.argtypes = [vp]
     L.aasr_free.restype = None
+    L.aasr_recipe_read.argtypes = [cp, i32, i32, C.POINTER(C.c_void_p), C.POINTER(i64)]
     L.aasr_audio_read.argtypes = [vp, cp, C.POINTER(C.POINTER(C.c_int16)), C.POINTER(i64),
                                   C.POINTER(i32)]
 
@@ -431,6 +432,23 @@ def recipe_batch_range(total: int, num_batches: int, batch_index: int):
     f, n = C.c_int32(), C.c_int32()
     check(lib().aasr_recipe_batch_range(total, num_batches, batch_index, C.byref(f), C.byref(n)))
     return f.value, n.value
+
+
+def recipe_read(text, num_batches: int = 0, batch_index: int = 0):
+    """Recipe::read on the host: list of (audio, lna, speaker, utterance, start_time, end_time)."""
+    out = C.c_void_p()
+    n = C.c_int64()
+    raw = text if isinstance(text, bytes) else text.encode()
+    check(lib().aasr_recipe_read(raw, num_batches, batch_index, C.byref(out), C.byref(n)))
+    try:
+        table = C.string_at(out, n.value)
+    finally:
+        lib().aasr_free(out)
+    rows = []
+    for line in table.split(b"\n")[:-1]:
+        f = line.split(b"\x1f")
+        rows.append(tuple(x.decode("latin-1") for x in f[:4]) + (float(f[4]), float(f[5])))
+    return rows
 
 
 def audio_read(path: str, feat: Optional["Feat"] = None):

@@ -77,11 +77,35 @@ void recipe_batch_range(int total, int num_batches, int batch_index, int *first,
   if (*first < 0) *first = total;
 }
 
-static std::string strip(const std::string &s, const char *chars) {
-  size_t a = s.find_first_not_of(chars);
+// str::clean (aku/str.cc:124-140): drop leading and trailing characters of `chars`
+std::string str_clean(const std::string &s, const char *chars) {
+  const size_t a = s.find_first_not_of(chars);
   if (a == std::string::npos) return "";
-  size_t b = s.find_last_not_of(chars);
+  const size_t b = s.find_last_not_of(chars);
   return s.substr(a, b - a + 1);
+}
+
+// str::split (aku/str.cc:142-172).  Kept as the reference has it: a field ends at the next
+// delimiter, ONE delimiter is eaten (all adjacent ones with `group`), and the loop stops when the
+// text is used up -- so a trailing delimiter does not open an empty last field ("a=" is one field,
+// "a=b=" two, "=b" two with an empty first).  With num_fields > 0 the last field takes the rest.
+std::vector<std::string> str_split(const std::string &s, const char *delims, bool group, int num_fields) {
+  std::vector<std::string> fields;
+  size_t begin = 0;
+  while (begin < s.size()) {
+    if (num_fields > 0 && (int)fields.size() == num_fields - 1) {
+      fields.push_back(s.substr(begin));
+      break;
+    }
+    size_t end = s.find_first_of(delims, begin);
+    if (end == std::string::npos) end = s.size();
+    fields.push_back(s.substr(begin, end - begin));
+    end++;
+    if (group)
+      while (end < s.size() && strchr(delims, s[end]) && s[end]) end++;
+    begin = end;
+  }
+  return fields;
 }
 
 // Recipe::read (aku/Recipe.cc:23-149).  Quirk kept: the key=value map is not
@@ -93,7 +117,7 @@ std::vector<RecipeInfo> recipe_read(const std::string &text, int num_batches, in
     std::istringstream in(text);
     std::string line;
     while (std::getline(in, line)) {
-      line = strip(line, "\n\t \r");
+      line = str_clean(line, "\n\t ");  // not '\r': the reference keeps it (aku/Recipe.cc:57)
       if (line.empty() || line[0] == '#') continue;
       lines.push_back(line);
     }
@@ -102,17 +126,16 @@ std::vector<RecipeInfo> recipe_read(const std::string &text, int num_batches, in
   recipe_batch_range((int)lines.size(), num_batches, batch_index, &first, &count);
   std::vector<RecipeInfo> infos;
   std::map<std::string, std::string> kv;
-  for (int i = 0; i < (int)lines.size() && i < first + count; i++) {
-    std::istringstream fs(lines[i]);
-    std::string field;
-    while (fs >> field) {
-      size_t eq = field.find('=');
-      // str::split(&field, "=", false): exactly two parts required
-      if (eq == std::string::npos || field.find('=', eq + 1) != std::string::npos)
-        raise(AASR_ERR_INVALID, "Invalid recipe line: %s", lines[i].c_str());
-      kv[field.substr(0, eq)] = field.substr(eq + 1);
+  // the reference parses a line before it decides that the line opens the next batch, so the
+  // line after the slice is still checked for syntax (aku/Recipe.cc:79-103)
+  for (int i = 0; i < (int)lines.size() && i <= first + count; i++) {
+    for (const std::string &field : str_split(lines[i], " \t", true)) {
+      const std::vector<std::string> key_value = str_split(field, "=", false);
+      if (key_value.size() != 2) raise(AASR_ERR_INVALID, "Invalid recipe line: %s", lines[i].c_str());
+      kv[key_value[0]] = key_value[1];
     }
     if (i < first) continue;
+    if (i >= first + count) break;
     RecipeInfo info;
     auto get = [&](const char *k, std::string &dst) {
       auto it = kv.find(k);
@@ -569,6 +592,25 @@ aasr_status aasr_recipe_batch_range(int32_t num_lines_total, int32_t num_batches
     recipe_batch_range(num_lines_total, num_batches, batch_index, &f, &c);
     *first_line = f;
     *num_lines = c;
+  });
+}
+
+aasr_status aasr_recipe_read(const char *recipe_text, int32_t num_batches, int32_t batch_index,
+                             char **table_out, int64_t *table_len) {
+  return guarded([&] {
+    if (!recipe_text || !table_out || !table_len) raise(AASR_ERR_INVALID, "aasr_recipe_read: null argument");
+    std::string t;
+    char num[64];
+    for (const RecipeInfo &i : recipe_read(recipe_text, num_batches, batch_index)) {
+      t += i.audio_path + "\x1f" + i.lna_path + "\x1f" + i.speaker_id + "\x1f" + i.utterance_id + "\x1f";
+      snprintf(num, sizeof num, "%.17g\x1f%.17g\n", i.start_time, i.end_time);
+      t += num;
+    }
+    char *out = (char *)malloc(t.size() + 1);
+    if (!out) raise(AASR_ERR_INVALID, "aasr_recipe_read: out of memory");
+    memcpy(out, t.c_str(), t.size() + 1);
+    *table_out = out;
+    *table_len = (int64_t)t.size();
   });
 }
 

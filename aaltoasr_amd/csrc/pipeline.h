@@ -13,6 +13,8 @@ struct RecipeInfo {
   double start_time = 0, end_time = 0;
 };
 
+std::string str_clean(const std::string &s, const char *chars);
+std::vector<std::string> str_split(const std::string &s, const char *delims, bool group, int num_fields = 0);
 void recipe_batch_range(int total, int num_batches, int batch_index, int *first, int *count);
 std::vector<RecipeInfo> recipe_read(const std::string &text, int num_batches, int batch_index);
 // audio_reader.cc

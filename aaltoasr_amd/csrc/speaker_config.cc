@@ -66,30 +66,11 @@ struct aasr_spkc {
 
 namespace aasr {
 
-static std::string clean_ws(const std::string &s) {
-  size_t a = s.find_first_not_of(" \t");
-  if (a == std::string::npos) return "";
-  size_t b = s.find_last_not_of(" \t");
-  return s.substr(a, b - a + 1);
-}
+static std::string clean_ws(const std::string &s) { return str_clean(s, " \t"); }
 
-// str::split with grouping and an optional field limit (aku/str.cc)
+// str::split(&line, " \t", true, &fields, limit) (aku/str.cc:142-172)
 static std::vector<std::string> split_fields(const std::string &s, int limit = 0) {
-  std::vector<std::string> out;
-  size_t i = 0;
-  while (i < s.size()) {
-    while (i < s.size() && (s[i] == ' ' || s[i] == '\t')) i++;
-    if (i >= s.size()) break;
-    if (limit > 0 && (int)out.size() == limit - 1) {
-      out.push_back(s.substr(i));
-      break;
-    }
-    size_t j = i;
-    while (j < s.size() && s[j] != ' ' && s[j] != '\t') j++;
-    out.push_back(s.substr(i, j - i));
-    i = j;
-  }
-  return out;
+  return str_split(s, " \t", true, limit);
 }
 
 static bool next_line(const std::string &text, size_t *pos, std::string *line) {
@@ -97,7 +78,6 @@ static bool next_line(const std::string &text, size_t *pos, std::string *line) {
   size_t e = text.find('\n', *pos);
   if (e == std::string::npos) e = text.size();
   *line = text.substr(*pos, e - *pos);
-  if (!line->empty() && line->back() == '\r') line->pop_back();
   *pos = e + 1;
   return true;
 }

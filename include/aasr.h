@@ -286,6 +286,15 @@ aasr_status aasr_recipe_batch_range(int32_t num_lines_total, int32_t num_batches
                                     int32_t batch_index, int32_t *first_line,
                                     int32_t *num_lines);
 
+/* Recipe::read itself (aku/Recipe.cc:23-149), host only: parses recipe text and
+ * returns the utterances of one batch as a malloc'ed text table (aasr_free), one
+ * line per utterance with the fields audio, lna, speaker, utterance, start-time,
+ * end-time separated by 0x1f (times as "%.17g").  Kept from the reference: lines
+ * are cleaned of " \t\n" only, fields split on blanks and tabs, `key=value`
+ * through str::split (a trailing '=' is dropped), keys persist across lines. */
+aasr_status aasr_recipe_read(const char *recipe_text, int32_t num_batches, int32_t batch_index,
+                             char **table_out, int64_t *table_len);
+
 /* ---------------------------------------------------------------------------
  * Speaker / utterance configuration: aku::SpeakerConfig
  * (aku/SpeakerConfig.hh:15-60, aku/SpeakerConfig.cc) -- what phone_probs -S FILE

@@ -957,7 +957,7 @@ class SpeakerConfig:
         def nonempty():
             nonlocal i
             while i < len(lines):
-                l = lines[i].strip(" \t\r")
+                l = str_clean(lines[i], " \t")
                 i += 1
                 if l:
                     return l
@@ -966,7 +966,7 @@ class SpeakerConfig:
             l = nonempty()
             if l is None:
                 return
-            f = l.split()
+            f = str_split(l, " \t", True)
             if len(f) != 2 or f[0] not in ("speaker", "utterance"):
                 raise ValueError("SpeakerConfig: Syntax error on line %d: %s" % (i, l))
             is_spk, is_def = f[0] == "speaker", f[1] == "default"
@@ -987,10 +987,10 @@ class SpeakerConfig:
                 l = nonempty()
                 if l is None or l == "}":
                     break
-                parts = l.split(None, 1)
+                parts = str_split(l, " \t", True, 2)
                 if len(parts) < 2:
                     l = "feature " + l
-                    parts = l.split(None, 1)
+                    parts = str_split(l, " \t", True, 2)
                 elif parts[0] not in ("model", "feature"):
                     raise ValueError("SpeakerConfig: Unknown module namespace at line %d" % i)
                 if parts[0] == "feature" and parts[1] not in self.chain.by_name:
@@ -1182,6 +1182,33 @@ _RECIPE_KEYS = {
 }
 
 
+def str_clean(s: str, chars: str) -> str:
+    """str::clean (aku/str.cc:124-140)."""
+    return s.strip(chars)
+
+
+def str_split(s: str, delims: str, group: bool, num_fields: int = 0) -> List[str]:
+    """str::split (aku/str.cc:142-172): one delimiter (a run of them with `group`) ends a
+    field; the loop ends with the text, so a trailing delimiter opens no empty last field."""
+    fields: List[str] = []
+    begin = 0
+    n = len(s)
+    while begin < n:
+        if num_fields > 0 and len(fields) == num_fields - 1:
+            fields.append(s[begin:])
+            break
+        end = begin
+        while end < n and s[end] not in delims:
+            end += 1
+        fields.append(s[begin:end])
+        end += 1
+        if group:
+            while end < n and s[end] in delims:
+                end += 1
+        begin = end
+    return fields
+
+
 def recipe_read(text: str, num_batches: int = 0, batch_index: int = 0,
                 cluster_speakers: bool = False) -> List[RecipeInfo]:
     """Restates Recipe::read including its quirks: the key=value map is NOT
@@ -1191,7 +1218,7 @@ def recipe_read(text: str, num_batches: int = 0, batch_index: int = 0,
         raise ValueError("Invalid batch index")
     line_buffer = []
     for raw in text.split("\n"):
-        line = raw.strip("\n\t \r")
+        line = str_clean(raw, "\n\t ")          # '\r' stays, as in the reference
         if not line or line[0] == "#":
             continue
         line_buffer.append(line)
@@ -1213,8 +1240,8 @@ def recipe_read(text: str, num_batches: int = 0, batch_index: int = 0,
     cur_line = 0
     cur_speaker = ""
     for line in line_buffer:
-        for fld in line.split():
-            parts = fld.split("=")
+        for fld in str_split(line, " \t", True):
+            parts = str_split(fld, "=", False)
             if len(parts) != 2:
                 raise ValueError("Invalid recipe line: " + line)
             kv[parts[0]] = parts[1]
@@ -1325,6 +1352,10 @@ def ref_aku():
     A.ref_safe_log.argtypes = [C.c_double]
     A.ref_str2float.restype = C.c_double
     A.ref_str2float.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+    A.ref_str_split.restype = C.c_int
+    A.ref_str_split.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
+    A.ref_str_clean.restype = C.c_int
+    A.ref_str_clean.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
     A.ref_module_config_read.restype = C.c_int
     A.ref_module_config_read.argtypes = [C.c_char_p, C.c_long, C.c_char_p, C.c_int, C.POINTER(C.c_long)]
     A.ref_module_config_get_floats.restype = C.c_int

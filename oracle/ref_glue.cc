@@ -28,6 +28,30 @@ double ref_str2float(const char *s, int *ok)
   return v;
 }
 
+// str::split / str::clean (aku/str.cc:124-172) as the recipe and speaker-configuration readers
+// call them.  Fields come back joined by 0x1f; the return value is the number of fields.
+int ref_str_split(const char *s, const char *delims, int group, int num_fields, char *buf, int buflen)
+{
+  std::string str(s);
+  std::vector<std::string> fields;
+  aku::str::split(&str, delims, group != 0, &fields, num_fields);
+  std::string out;
+  for (size_t i = 0; i < fields.size(); i++) {
+    if (i) out += "\x1f";
+    out += fields[i];
+  }
+  snprintf(buf, buflen, "%s", out.c_str());
+  return (int)fields.size();
+}
+
+int ref_str_clean(const char *s, const char *chars, char *buf, int buflen)
+{
+  std::string str(s);
+  aku::str::clean(&str, chars);
+  snprintf(buf, buflen, "%s", str.c_str());
+  return (int)str.size();
+}
+
 // Parse ONE "{ key value ... }" block from a file positioned just after the
 // "module" keyword line (ModuleConfig::read, aku/ModuleConfig.cc:166-202) and
 // return "key\x1fvalue\x1e..." in buf.  Returns number of lines consumed or

@@ -21,3 +21,72 @@ def test_recipe_batch_index_validation(capi):
         capi.recipe_batch_range(10, 4, 5)
     with pytest.raises(capi.AasrError, match="Invalid batch index"):
         capi.recipe_batch_range(10, 4, 0)
+
+
+def _random_text(rng, alphabet, n):
+    return "".join(alphabet[int(i)] for i in rng.integers(0, len(alphabet), n))
+
+
+def test_str_split_and_clean_vs_reference(oracle):
+    """The oracle's str::split / str::clean restatements against the reference's own str.cc
+    (compiled in place into oracle/_ref/libaku_ref.so) on random strings, in the three ways the
+    recipe and speaker-configuration readers call them (aku/Recipe.cc:57,79-83,
+    aku/SpeakerConfig.cc:33-38,102)."""
+    import ctypes as C
+    import numpy as np
+    A = oracle.ref_aku()
+    if A is None:
+        pytest.skip("oracle/_ref/libaku_ref.so not built (no reference tree)")
+    rng = np.random.default_rng(23)
+    buf = C.create_string_buffer(4096)
+    cases = ["", "a=", "=b", "a=b=", "a==b", "=", "==", "a", " a  b ", "\ta \t b", "a b ", "k=v=w"]
+    cases += [_random_text(rng, "ab= \t\rx", int(rng.integers(0, 12))) for _ in range(3000)]
+    for s in cases:
+        for delims, group, nf in ((" \t", 1, 0), ("=", 0, 0), (" \t", 1, 2)):
+            n = A.ref_str_split(s.encode(), delims.encode(), group, nf, buf, 4096)
+            want = buf.value.decode().split("\x1f") if n else []
+            assert oracle.str_split(s, delims, bool(group), nf) == want, (s, delims, group, nf)
+        for chars in (" \t", "\n\t "):
+            A.ref_str_clean(s.encode(), chars.encode(), buf, 4096)
+            assert oracle.str_clean(s, chars) == buf.value.decode(), (s, chars)
+
+
+def test_engine_recipe_reader_matches_oracle(capi, oracle):
+    """aasr_recipe_read (host) against the oracle's Recipe::read on recipes with the odd cases:
+    key persistence, comments, tabs, runs of blanks, CR line ends (kept), trailing '=',
+    empty keys, start/end times, every batch of several splits."""
+    import numpy as np
+    rng = np.random.default_rng(29)
+    keys = ["audio", "lna", "speaker", "utterance", "start-time", "end-time", "transcript", ""]
+    vals = ["a.wav", "x/y.lna", "spk1", "u7", "1.5", "2.25e1", "12abc", "", "v=", "=", "\r"]
+
+    def rows(infos):
+        return [(i.audio_path, i.lna_path, i.speaker_id, i.utterance_id, i.start_time, i.end_time) for i in infos]
+
+    fixed = ("# comment\n\n  audio=a.wav\tlna=a.lna speaker=s1 start-time=0.5\n"
+             "audio=b.wav   lna=b.lna=\n\t\naudio=c.wav lna=c.lna utterance=u\r end-time=3\r\n#x\nlna=d.lna")
+    texts = [fixed, "", "\n\n", "audio=a lna=b"]
+    for _ in range(300):
+        lines = []
+        for _ in range(int(rng.integers(0, 9))):
+            fields = ["%s=%s" % (keys[int(rng.integers(0, len(keys)))], vals[int(rng.integers(0, len(vals)))])
+                      for _ in range(int(rng.integers(0, 5)))]
+            sep = [" ", "\t", "  ", " \t "][int(rng.integers(0, 4))]
+            lines.append(["", " ", "#"][int(rng.integers(0, 3)) if rng.random() < 0.2 else 0] + sep.join(fields))
+        texts.append("\n".join(lines) + ("\n" if rng.random() < 0.5 else ""))
+    checked = 0
+    for text in texts:
+        for n, b in ((0, 0), (1, 1), (2, 1), (2, 2), (3, 2), (4, 4)):
+            try:
+                want = rows(oracle.recipe_read(text, n, b))
+            except ValueError as e:
+                with pytest.raises(capi.AasrError) as ei:
+                    capi.recipe_read(text, n, b)
+                assert str(e) in str(ei.value)
+                continue
+            assert capi.recipe_read(text, n, b) == want, (text, n, b)
+            checked += 1
+    assert checked > 500
+    got = capi.recipe_read(fixed)
+    assert got[1][:2] == ("b.wav", "b.lna") and got[1][2] == "s1" and got[2][4] == 0.5 and got[3][1] == "d.lna"
+    assert got[2][3] == "u\r" and got[2][5] == 3.0          # the reference does not strip CR
