@@ -698,6 +698,14 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
   if (dbg & 8) {  // experiment: raise priority of every second workgroup
     if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(2);
   }
+  u32x4 afr[3][2];  // A fragments of the current slab, [split][row block]
+  if (t_begin < t_end) {
+#pragma unroll
+    for (int sp = 2; sp >= 0; sp--) {
+      afr[sp][0] = ((const u32x4 *)abuf0 + lane)[(sp * 2 + 0) * 64];
+      afr[sp][1] = ((const u32x4 *)abuf0 + lane)[(sp * 2 + 1) * 64];
+    }
+  }
   for (int64_t t = t_begin; t < t_end; t++) {
     const int par = (int)((t - t_begin) & 1);
     float *acur = par ? abuf1 : abuf0;
@@ -714,32 +722,52 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
 
     f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
     const u32x4 *afrag = (const u32x4 *)acur + lane;  // [slab][split][mb][64 lanes]
+    // Rolling A-fragment prefetch.  The products of a slab are ordered by the A split they use,
+    // (a3,b1) | (a2,b2) (a2,b1) | (a1,b3) (a1,b2) (a1,b1), so each split's registers fall free as
+    // early as possible and are refilled for the NEXT slab right then: every ds_read has 12-20
+    // MFMAs (>= 384 cycles) to land and no extra registers are needed.  Left to itself the
+    // compiler sinks the reads to their first use (one exposed LDS round trip per slab), hence
+    // the full scheduling barriers.  The 2^-16 products still precede the 2^-8 ones of the same
+    // A split; the sum already holds earlier slabs, so the order inside a slab is immaterial.
 #pragma unroll
     for (int j = 0; j < NK16; j++) {
-      u32x4 a[3][2];
 #pragma unroll
-      for (int sp = 0; sp < 3; sp++) {
-        a[sp][0] = afrag[((j * 3 + sp) * 2 + 0) * 64];
-        a[sp][1] = afrag[((j * 3 + sp) * 2 + 1) * 64];
-      }
-      // smallest products first: (a1,b3) (a2,b2) (a3,b1) (a1,b2) (a2,b1) (a1,b1)
-      constexpr int SA[6] = {0, 1, 2, 0, 1, 0};
-      constexpr int SB[6] = {2, 1, 0, 1, 0, 0};
+      for (int grp = 0; grp < 3; grp++) {
+        const int sp = 2 - grp;        // A split used by this group: a3, a2, a1
+        const int nprod = grp + 1;     // paired with b1 | b2 b1 | b3 b2 b1
 #pragma unroll
-      for (int c = 0; c < 6; c++) {
-        const bf16x8 a_m0 = __builtin_bit_cast(bf16x8, a[SA[c]][0]);
-        const bf16x8 a_m1 = __builtin_bit_cast(bf16x8, a[SA[c]][1]);
-        const bf16x8 b_n0 = __builtin_bit_cast(bf16x8, bq[j][SB[c]][0]);
-        const bf16x8 b_n1 = __builtin_bit_cast(bf16x8, bq[j][SB[c]][1]);
-        c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m0, b_n0, c00, 0, 0, 0);
-        c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m0, b_n1, c01, 0, 0, 0);
-        c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m1, b_n0, c10, 0, 0, 0);
-        c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m1, b_n1, c11, 0, 0, 0);
+        for (int c = 0; c < nprod; c++) {
+          const int sb = nprod - 1 - c;
+          const bf16x8 a_m0 = __builtin_bit_cast(bf16x8, afr[sp][0]);
+          const bf16x8 a_m1 = __builtin_bit_cast(bf16x8, afr[sp][1]);
+          const bf16x8 b_n0 = __builtin_bit_cast(bf16x8, bq[j][sb][0]);
+          const bf16x8 b_n1 = __builtin_bit_cast(bf16x8, bq[j][sb][1]);
+          c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m0, b_n0, c00, 0, 0, 0);
+          c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m0, b_n1, c01, 0, 0, 0);
+          c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m1, b_n0, c10, 0, 0, 0);
+          c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m1, b_n1, c11, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < NK16) {
+          afr[sp][0] = afrag[(((j + 1) * 3 + sp) * 2 + 0) * 64];
+          afr[sp][1] = afrag[(((j + 1) * 3 + sp) * 2 + 1) * 64];
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (t + 1 < t_end) {
+      // slab 0 of the next tile: in flight while the epilogue runs
+      const u32x4 *nfrag = (const u32x4 *)anext + lane;
+#pragma unroll
+      for (int sp = 2; sp >= 0; sp--) {
+        afr[sp][0] = nfrag[(sp * 2 + 0) * 64];
+        afr[sp][1] = nfrag[(sp * 2 + 1) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 
     if (dbg & 1) {
       asm volatile("" ::"v"(c00), "v"(c01), "v"(c10), "v"(c11));
