@@ -652,6 +652,7 @@ void gmm_build_tracks(aasr_gmm *g, bool grouped) {
   pack_rows(g, rows, L.rows, &coef64);
   pack_bf16x3(m.dim, coef64, tiles, L);
   L.rows.rows = (int64_t)m.mix_idx.size();  // real rows (algorithmic work)
+  close_mask.push_back(0);  // the kernels read the bits as aligned 32-bit words (scalar loads)
   L.close.upload(close_mask.data(), close_mask.size());
   L.rows_padded = tiles * TILE_ROWS;
   L.ref_log2 = ref;

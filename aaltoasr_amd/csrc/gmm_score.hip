@@ -76,6 +76,43 @@ __device__ __forceinline__ void issue_tile_copy(const float *__restrict__ gtile,
   }
 }
 
+// The same copy issued through inline assembly, i.e. invisible to the compiler's wait-count
+// bookkeeping.  The builtin is modelled as a FLAT access that touches LDS and global memory at
+// once; while one is outstanding the compiler degrades EVERY s_waitcnt lgkmcnt(n) to
+// lgkmcnt(0), which serialises the A-fragment prefetch of the matrix stream against LDS latency.
+// Callers must order the copy themselves: s_waitcnt vmcnt(0) + barrier before the tile is read.
+__device__ __forceinline__ void issue_tile_copy_raw(const float *__restrict__ gtile, float *lds_buf,
+                                                    int tile_floats, int wave, int lane) {
+  const int chunks = tile_floats / 4;
+  for (int c0 = wave * 64; c0 < chunks; c0 += WAVES_PER_BLOCK * 64) {
+    const float *src = gtile + (size_t)(c0 + lane) * 4;
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(size_t)(__attribute__((address_space(3))) float *)(lds_buf + (size_t)c0 * 4));
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(dst), "v"(src) : "memory", "m0");
+  }
+}
+
+// Per-tile close bits through the scalar cache (SMEM, lgkmcnt).  A vector load here is a trap:
+// its result is needed as a scalar, the compiler waits for it with s_waitcnt vmcnt(0), and
+// vmcnt counts in issue order -- so the wave would sit until the tile copy issued just before
+// it has landed (measured: 5 ms of 30 in the bf16x3 matrix stream).  t is wave-uniform.
+typedef const __attribute__((address_space(4))) uint32_t *cmask32_ptr;
+__device__ __forceinline__ unsigned sload_close_pair(const uint16_t *close_mask, int64_t t) {
+  return ((cmask32_ptr)close_mask)[__builtin_amdgcn_readfirstlane((int)(t >> 1))];
+}
+// Bits of tile t out of a word requested earlier; the empty asm keeps the compiler from doing the
+// extraction (and therefore the lgkmcnt wait) right behind the request.
+__device__ __forceinline__ unsigned close16_of_pair(unsigned pair, int64_t t) {
+  asm volatile("" : "+s"(pair));
+  return (t & 1) ? pair >> 16 : pair & 0xffffu;
+}
+__device__ __forceinline__ unsigned sload_close16(const uint16_t *close_mask, int64_t t) {
+  return close16_of_pair(sload_close_pair(close_mask, t), t);
+}
+__device__ __forceinline__ unsigned sload_close32(const uint32_t *close_mask, int64_t t) {
+  return ((cmask32_ptr)close_mask)[__builtin_amdgcn_readfirstlane((int)t)];
+}
+
 // Reduce rows [a, b) of the staged chunk for this lane's frame, 16 rows at a
 // time, merging into the running (m, s) pair:  sum_r 2^v_r = s * 2^m.
 __device__ __forceinline__ void reduce_rows(const float *stage_col, int a, int b,
@@ -381,13 +418,15 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
   const cl_mask8_ptr mrow = (cl_mask8_ptr)(
       CL ? cl.maskrow + (size_t)__builtin_amdgcn_readfirstlane((int)(f0 >> 6)) * cl.rows_padded : nullptr);
 
+  // close bits of the next tile are requested (scalar) right after the barrier, one tile ahead
+  unsigned pair_next = t_begin < t_end ? sload_close_pair(close_mask, t_begin) : 0u;
   for (int64_t t = t_begin; t < t_end; t++) {
     const int par = (int)((t - t_begin) & 1);
     float *acur = par ? abuf1 : abuf0;
     float *anext = par ? abuf0 : abuf1;
     if (t + 1 < t_end)
       issue_tile_copy(apack + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
-    const unsigned mask16 = close_mask[t];
+    const unsigned mask16 = close16_of_pair(pair_next, t);
     // GROUPED: both tracks carry the same bits -> wave-uniform branch
     const unsigned mask = GROUPED ? (mask16 & 0xffu) : (h ? (mask16 >> 8) : (mask16 & 0xffu));
     // 8 mask vectors per tile, [mb][q]; the first is fetched before the matrix loop
@@ -421,6 +460,7 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
     // share of tile t+1 has landed; the epilogue then needs no inter-wave sync.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (t + 1 < t_end) pair_next = sload_close_pair(close_mask, t + 1);
 
     if (dbg & 1) {  // ablation: MFMA only
       asm volatile("" ::"v"(c00), "v"(c01), "v"(c10), "v"(c11));
@@ -674,7 +714,7 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
   const int64_t t_begin = split_row[4 * blockIdx.y];
   const int64_t t_end = split_row[4 * blockIdx.y + 4];
   const float *apf = (const float *)apack;
-  issue_tile_copy(apf + (size_t)t_begin * kTileFloats, abuf0, kTileFloats, wave, lane);
+  issue_tile_copy_raw(apf + (size_t)t_begin * kTileFloats, abuf0, kTileFloats, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -698,6 +738,13 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
   if (dbg & 8) {  // experiment: raise priority of every second workgroup
     if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(2);
   }
+  // Close bits of a tile: a VECTOR load issued in the middle of the previous tile's matrix stream
+  // and turned into a scalar after that tile's barrier, whose vmcnt(0) covers it.  Two traps are
+  // avoided this way: loaded at the top of a tile, the compiler waits for it with vmcnt(0) right
+  // behind the tile copy (vmcnt is in issue order; measured 5 ms of 30 in the matrix stream), and a
+  // scalar load anywhere in the loop turns every LDS wait of the stream into lgkmcnt(0).
+  unsigned mask16_next = t_begin < t_end ? (unsigned)__builtin_amdgcn_readfirstlane((int)close_mask[t_begin]) : 0u;
+  unsigned mask_v = 0;
   u32x4 afr[3][2];  // A fragments of the current slab, [split][row block]
   if (t_begin < t_end) {
 #pragma unroll
@@ -710,9 +757,9 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
     const int par = (int)((t - t_begin) & 1);
     float *acur = par ? abuf1 : abuf0;
     float *anext = par ? abuf0 : abuf1;
-    if (t + 1 < t_end)
-      issue_tile_copy(apf + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
-    const unsigned mask16 = close_mask[t];
+    if (t + 1 < t_end && !(dbg & 256) && !((dbg & 512) && (t & 1)))  // ablations: 256 no tile traffic, 512 half of it
+      issue_tile_copy_raw(apf + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
+    const unsigned mask16 = mask16_next;
     const unsigned mask = GROUPED ? (mask16 & 0xffu) : (h ? (mask16 >> 8) : (mask16 & 0xffu));
     // 8 mask vectors per tile, [mb][q]; the first is fetched before the matrix loop
     const cl_mask8_ptr mt =
@@ -748,6 +795,7 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
           c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m1, b_n1, c11, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (j == (NK16 > 1 ? 1 : 0) && grp == 0) mask_v = close_mask[t + 1];  // the array has one spare element
         if (j + 1 < NK16) {
           afr[sp][0] = afrag[(((j + 1) * 3 + sp) * 2 + 0) * 64];
           afr[sp][1] = afrag[(((j + 1) * 3 + sp) * 2 + 1) * 64];
@@ -756,8 +804,9 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
       }
     }
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(mask_v) : : "memory");
     __builtin_amdgcn_s_barrier();
+    mask16_next = (unsigned)__builtin_amdgcn_readfirstlane((int)mask_v);
     if (t + 1 < t_end) {
       // slab 0 of the next tile: in flight while the epilogue runs
       const u32x4 *nfrag = (const u32x4 *)anext + lane;
@@ -1091,7 +1140,7 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3h(
   for (int64_t t = t_begin; t < t_end; t++) {
     const int par = (int)((t - t_begin) & 1);
     float *acur = par ? abuf1 : abuf0;
-    const unsigned mask16 = close_mask[t];
+    const unsigned mask16 = sload_close16(close_mask, t);
     const u32x4 *afrag = (const u32x4 *)acur + lane;
     // block 0 of tile t; the stream carries block 1 of tile t-1
 #pragma unroll
@@ -1304,7 +1353,7 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score(
     float *anext = par ? abuf0 : abuf1;
     if (t + 1 < t_end)
       issue_tile_copy(apack + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
-    const unsigned m32 = close_mask[t];
+    const unsigned m32 = sload_close32(close_mask, t);
     const unsigned gmask = h ? ((m32 >> 8) & 0xffu) : (m32 & 0xffu);
     const unsigned smask = h ? ((m32 >> 24) & 0xffu) : ((m32 >> 16) & 0xffu);
 
