@@ -82,9 +82,10 @@ __device__ __forceinline__ void issue_tile_copy(const float *__restrict__ gtile,
 // lgkmcnt(0), which serialises the A-fragment prefetch of the matrix stream against LDS latency.
 // Callers must order the copy themselves: s_waitcnt vmcnt(0) + barrier before the tile is read.
 __device__ __forceinline__ void issue_tile_copy_raw(const float *__restrict__ gtile, float *lds_buf,
-                                                    int tile_floats, int wave, int lane) {
+                                                    int tile_floats, int wave, int lane,
+                                                    int nwaves = WAVES_PER_BLOCK) {
   const int chunks = tile_floats / 4;
-  for (int c0 = wave * 64; c0 < chunks; c0 += WAVES_PER_BLOCK * 64) {
+  for (int c0 = wave * 64; c0 < chunks; c0 += nwaves * 64) {
     const float *src = gtile + (size_t)(c0 + lane) * 4;
     const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(
         (int)(unsigned)(size_t)(__attribute__((address_space(3))) float *)(lds_buf + (size_t)c0 * 4));
@@ -660,8 +661,14 @@ struct Bf16Smem {
   static constexpr int kBytes = 2 * kTileBytes + WAVES_PER_BLOCK * kOutFloatsPerWave * 4;
 };
 
-template <int NK16, bool GROUPED, bool CL>
-__global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
+// WIDE: one workgroup of 8 waves (512 frames) per CU instead of two of 4 waves, so a tile is
+// fetched from L2 once per 512 frames -- the L2 -> LDS tile traffic is what the power-capped
+// matrix stream pays for (measured: no traffic -6.3 ms, half of it -2.1 ms of 34.9).  The two wave
+// groups run the same tile sequence half a tile apart (group 1 lags by one barrier; every wave
+// passes two barriers per tile, one in the middle of its stream), which puts one group's
+// epilogue under the other group's matrix stream; three tile buffers make the lag legal.
+template <int NK16, bool GROUPED, bool CL, bool WIDE>
+__global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_score_bf16x3(
     const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
     const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
     const uint16_t *__restrict__ close_mask, const int32_t *__restrict__ sid, int sid_stride,
@@ -672,15 +679,18 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
   constexpr int kTileFloats = kTileBytes / 4;
   constexpr int kOS = Bf16Smem<NK16, GROUPED>::kOutStride;
   constexpr int KH = 8 * NK16;
+  constexpr int NW = WIDE ? 8 : 4;    // waves per workgroup
+  constexpr int NBUF = WIDE ? 3 : 2;  // tile buffers
+  constexpr int JMID = (NK16 + 1) / 2;  // WIDE: slabs before the mid-stream barrier
   float *abuf0 = (float *)smem_raw;
-  float *abuf1 = abuf0 + kTileFloats;
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const int lane = tid & 63;
-  float *ost = abuf0 + 2 * kTileFloats + wave * Bf16Smem<NK16, GROUPED>::kOutFloatsPerWave;
+  const int group = WIDE ? __builtin_amdgcn_readfirstlane(wave >> 2) : 0;
+  float *ost = abuf0 + NBUF * kTileFloats + wave * Bf16Smem<NK16, GROUPED>::kOutFloatsPerWave;
   const int n = lane & 31;
   const int h = lane >> 5;  // K half of a slab held by this lane AND its row track
-  const int64_t f0 = (int64_t)blockIdx.x * FRAMES_PER_BLOCK + wave * FRAMES_PER_WAVE;
+  const int64_t f0 = (int64_t)blockIdx.x * (NW * FRAMES_PER_WAVE) + wave * FRAMES_PER_WAVE;
 
   // ---- frame operand: lane (n, h) holds k = 16*j + 8*h + i, i < 8, of slab j
   u32x4 bq[NK16][3][2];
@@ -714,9 +724,12 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
   const int64_t t_begin = split_row[4 * blockIdx.y];
   const int64_t t_end = split_row[4 * blockIdx.y + 4];
   const float *apf = (const float *)apack;
-  issue_tile_copy_raw(apf + (size_t)t_begin * kTileFloats, abuf0, kTileFloats, wave, lane);
+  issue_tile_copy_raw(apf + (size_t)t_begin * kTileFloats, abuf0, kTileFloats, wave, lane, NW);
+  if (WIDE && t_begin + 1 < t_end)
+    issue_tile_copy_raw(apf + (size_t)(t_begin + 1) * kTileFloats, abuf0 + kTileFloats, kTileFloats, wave, lane, NW);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (WIDE && group == 1) __builtin_amdgcn_s_barrier();  // the lagging group's "end of tile -1"
 
   float s0 = 0.0f, s1 = 0.0f;
   int closes = split_row[4 * blockIdx.y + 1 + (GROUPED ? 0 : h)];
@@ -753,12 +766,20 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
       afr[sp][1] = ((const u32x4 *)abuf0 + lane)[(sp * 2 + 1) * 64];
     }
   }
+  int bi = 0;  // buffer of the current tile
   for (int64_t t = t_begin; t < t_end; t++) {
-    const int par = (int)((t - t_begin) & 1);
-    float *acur = par ? abuf1 : abuf0;
-    float *anext = par ? abuf0 : abuf1;
-    if (t + 1 < t_end && !(dbg & 256) && !((dbg & 512) && (t & 1)))  // ablations: 256 no tile traffic, 512 half of it
-      issue_tile_copy_raw(apf + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
+    float *acur = abuf0 + bi * kTileFloats;
+    const int bn = bi + 1 < NBUF ? bi + 1 : 0;         // buffer of tile t+1
+    const int bnn = bn + 1 < NBUF ? bn + 1 : 0;        // WIDE: buffer of tile t+2 (held tile t-1)
+    float *anext = abuf0 + bn * kTileFloats;
+    if (!WIDE) {
+      if (t + 1 < t_end && !(dbg & 256) && !((dbg & 512) && (t & 1)))  // ablations: 256 no tile traffic, 512 half of it
+        issue_tile_copy_raw(apf + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane, NW);
+    } else if (group == 1 && t + 2 < t_end) {
+      // both groups are past tile t-1 once the lagging group has passed its end-of-tile barrier
+      issue_tile_copy_raw(apf + (size_t)(t + 2) * kTileFloats, abuf0 + bnn * kTileFloats, kTileFloats, wave, lane, NW);
+    }
+    bi = bn;
     const unsigned mask16 = mask16_next;
     const unsigned mask = GROUPED ? (mask16 & 0xffu) : (h ? (mask16 >> 8) : (mask16 & 0xffu));
     // 8 mask vectors per tile, [mb][q]; the first is fetched before the matrix loop
@@ -778,6 +799,13 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
     // A split; the sum already holds earlier slabs, so the order inside a slab is immaterial.
 #pragma unroll
     for (int j = 0; j < NK16; j++) {
+      if (WIDE && j == JMID) {
+        // mid-stream barrier = the other group's end-of-tile barrier
+        __builtin_amdgcn_s_barrier();
+        if (group == 0 && t + 2 < t_end)
+          issue_tile_copy_raw(apf + (size_t)(t + 2) * kTileFloats, abuf0 + bnn * kTileFloats, kTileFloats, wave, lane, NW);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int grp = 0; grp < 3; grp++) {
         const int sp = 2 - grp;        // A split used by this group: a3, a2, a1
@@ -795,7 +823,9 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
           c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m1, b_n1, c11, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (j == (NK16 > 1 ? 1 : 0) && grp == 0) mask_v = close_mask[t + 1];  // the array has one spare element
+        // the aligned word holding tile t+1's bits (the array has a spare element); a 16-bit load
+        // would need a zero-extension, which the compiler places -- with its vmcnt wait -- right here
+        if (j == (NK16 > 1 ? 1 : 0) && grp == 0) mask_v = ((const uint32_t *)close_mask)[(t + 1) >> 1];
         if (j + 1 < NK16) {
           afr[sp][0] = afrag[(((j + 1) * 3 + sp) * 2 + 0) * 64];
           afr[sp][1] = afrag[(((j + 1) * 3 + sp) * 2 + 1) * 64];
@@ -804,9 +834,15 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
       }
     }
 
+    if (WIDE && JMID >= NK16) {
+      __builtin_amdgcn_s_barrier();
+      if (group == 0 && t + 2 < t_end)
+        issue_tile_copy_raw(apf + (size_t)(t + 2) * kTileFloats, abuf0 + bnn * kTileFloats, kTileFloats, wave, lane, NW);
+    }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(mask_v) : : "memory");
     __builtin_amdgcn_s_barrier();
     mask16_next = (unsigned)__builtin_amdgcn_readfirstlane((int)mask_v);
+    mask16_next = ((t + 1) & 1) ? mask16_next >> 16 : mask16_next & 0xffffu;
     if (t + 1 < t_end) {
       // slab 0 of the next tile: in flight while the epilogue runs
       const u32x4 *nfrag = (const u32x4 *)anext + lane;
@@ -908,327 +944,25 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3(
       }
     }
   }
+  if (WIDE && group == 0) __builtin_amdgcn_s_barrier();  // pairs with the lagging group's last end-of-tile barrier
 }
 
-// ---------------------------------------------------------------------------
-// Half-tile pipelined bf16x3 kernel (experimental: AASR_BF16_PIPE=2).
-//
-// Measured on gfx950: VALU work co-executes with another wave's bf16 MFMAs only
-// marginally (SQ_VALU_MFMA_COEXEC_CYCLES ~4 % with two waves per SIMD) but hides
-// completely when placed between a wave's own MFMAs.  A tile's two 32-row blocks
-// do not depend on each
-// other, so the MFMA stream of block 1 carries the 32 v_exp_f32 + 24 adds of
-// block 0, and the stream of the NEXT tile's block 0 carries those of block 1:
-// same four accumulators, same 64 frames per wave and the same per-tile
-// overheads as k_gmm_diag_score_bf16x3, with the transcendentals off the
-// critical path.  What runs after a stream is only the close / flush logic on
-// the eight per-quad sums.  The order of the VALU instructions is pinned with
-// volatile asm + scheduling barriers (a pure builtin is sunk to its first use).
-// Ablations (1 M frames x 50 k Gaussians, ms): matrix stream only 30.3; with the
-// exponentials riding in it 31.6; with close logic, no output stores 32.4; full
-// 35.3 (k_gmm_diag_score_bf16x3: 35.7).  The transcendentals are hidden; what is
-// left is the 12.5 GB of output stores (3 ms, 1 ms of it from the 4-byte row
-// alignment of S = 3125), which cost the matrix pipe clock under the power cap
-// rather than issue slots -- hence only ~1 % over the plain kernel.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ float pinned_exp2(float x) {
-  float r;
-  asm volatile("v_exp_f32_e32 %0, %1" : "=v"(r) : "v"(x));
-  return r;
-}
-__device__ __forceinline__ float pinned_add(float a, float b) {
-  float r;
-  asm volatile("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
-// MFMAs of row block MB of the tile at `afrag` into (c0, c1) = frames n / 32+n.
-// With PENDING, the exponentials and per-quad sums of the finished block (p0, p1)
-// ride behind the MFMA pairs: qs[q] (frames n) and qs[4+q] (frames 32+n), q < 4.
-template <int NK16, int MB, bool PENDING>
-__device__ __forceinline__ void bf16h_phase(const u32x4 *afrag, const u32x4 (&bq)[NK16][3][2],
-                                            f32x16 &c0, f32x16 &c1, const f32x16 &p0,
-                                            const f32x16 &p1, float (&qs)[8]) {
-  u32x4 a[2][3];
-#pragma unroll
-  for (int sp = 0; sp < 3; sp++) a[0][sp] = afrag[((0 * 3 + sp) * 2 + MB) * 64];
-  float e[2][4], tq[2][2];
-  constexpr int SLOTS = NK16 * 6;
-  constexpr int STEPS = 10, OPS = STEPS * 7;  // quad tau: 4 exps, then 2 + 1 adds one / two steps later
-#pragma unroll
-  for (int j = 0; j < NK16; j++) {
-    if (j + 1 < NK16) {
-#pragma unroll
-      for (int sp = 0; sp < 3; sp++) a[(j + 1) & 1][sp] = afrag[(((j + 1) * 3 + sp) * 2 + MB) * 64];
-    }
-    // smallest products first: (a1,b3) (a2,b2) (a3,b1) (a1,b2) (a2,b1) (a1,b1)
-    constexpr int SA[6] = {0, 1, 2, 0, 1, 0};
-    constexpr int SB[6] = {2, 1, 0, 1, 0, 0};
-#pragma unroll
-    for (int c = 0; c < 6; c++) {
-      const bf16x8 av = __builtin_bit_cast(bf16x8, a[j & 1][SA[c]]);
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, bq[j][SB[c]][0]), c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, bq[j][SB[c]][1]), c1, 0, 0, 0);
-      if (PENDING) {
-        const int slot = j * 6 + c;
-#pragma unroll
-        for (int o = 0; o < OPS; o++) {
-          if (o * SLOTS / OPS != slot) continue;
-          const int tau = o / 7, k = o % 7;
-          if (k < 4) {
-            const int quad = tau;
-            if (quad < 8) e[quad & 1][k] = pinned_exp2(quad < 4 ? p0[4 * quad + k] : p1[4 * (quad - 4) + k]);
-          } else if (k < 6) {
-            const int quad = tau - 1;
-            if (quad >= 0 && quad < 8)
-              tq[quad & 1][k - 4] = pinned_add(e[quad & 1][2 * (k - 4)], e[quad & 1][2 * (k - 4) + 1]);
-          } else {
-            const int quad = tau - 2;
-            if (quad >= 0 && quad < 8) qs[quad] = pinned_add(tq[quad & 1][0], tq[quad & 1][1]);
-          }
-        }
-      }
-      // MFMA / VALU order is pinned; LDS, VMEM and scalar work may still move
-      __builtin_amdgcn_sched_barrier(0x0094);
-    }
-  }
-}
-
-template <int NK16, bool GROUPED>
-__global__ __launch_bounds__(256, 2) void k_gmm_diag_score_bf16x3h(
-    const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
-    const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
-    const uint16_t *__restrict__ close_mask, const int32_t *__restrict__ sid, int sid_stride,
-    float *__restrict__ out, int64_t S, float ref_ln, int dbg) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr int OG = Bf16Smem<NK16, GROUPED>::OG;
-  constexpr int kTileFloats = Bf16Smem<NK16, GROUPED>::kTileBytes / 4;
-  constexpr int kOS = Bf16Smem<NK16, GROUPED>::kOutStride;
-  constexpr int KH = 8 * NK16;
-  float *abuf0 = (float *)smem_raw;
-  float *abuf1 = abuf0 + kTileFloats;
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6;
-  const int lane = tid & 63;
-  float *ost = abuf0 + 2 * kTileFloats + wave * Bf16Smem<NK16, GROUPED>::kOutFloatsPerWave;
-  const int n = lane & 31;
-  const int h = lane >> 5;
-  const int64_t f0 = (int64_t)blockIdx.x * FRAMES_PER_BLOCK + wave * FRAMES_PER_WAVE;
-
-  u32x4 bq[NK16][3][2];
-#pragma unroll
-  for (int nb = 0; nb < 2; nb++) {
-    int64_t f = f0 + nb * 32 + n;
-    if (f > F - 1) f = F - 1;
-    const float *xr = frames + f * dim;
-#pragma unroll
-    for (int j = 0; j < NK16; j++) {
-      float v[8];
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const int k = 16 * j + 8 * h + i;
-        const int d = k < KH ? k : k - KH;
-        const int dc = d < dim ? d : 0;
-        const float xc = xr[dc] - pivot[dc];
-        float val = k < KH ? xc : xc * xc;
-        if (d >= dim) val = (k == dim) ? 1.0f : 0.0f;
-        v[i] = val;
-      }
-      unsigned w1[4], w2[4], w3[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) split3_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i], w3[i]);
-      bq[j][0][nb] = u32x4{w1[0], w1[1], w1[2], w1[3]};
-      bq[j][1][nb] = u32x4{w2[0], w2[1], w2[2], w2[3]};
-      bq[j][2][nb] = u32x4{w3[0], w3[1], w3[2], w3[3]};
-    }
-  }
-
-  const int64_t t_begin = split_row[4 * blockIdx.y];
-  const int64_t t_end = split_row[4 * blockIdx.y + 4];
-  const float *apf = (const float *)apack;
-  issue_tile_copy(apf + (size_t)t_begin * kTileFloats, abuf0, kTileFloats, wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  float s0 = 0.0f, s1 = 0.0f;
-  int closes = split_row[4 * blockIdx.y + 1 + (GROUPED ? 0 : h)];
-  const int32_t *my_sid = sid + h * sid_stride;
-  int next_sid = GROUPED ? 0 : my_sid[closes];
-  float *orow0 = out + (f0 + n) * S;
-  float *orow1 = out + (f0 + 32 + n) * S;
-  const bool ok0 = f0 + n < F, ok1 = f0 + 32 + n < F;
-
-  // close / flush logic of one finished 32-row block given its per-quad sums
-  // (returns the number of vector stores it issued, -1 = not counted)
-  auto finish_block = [&](const float (&qs)[8], unsigned mask16, int mb) -> int {
-    int stores = 0;
-    const unsigned mask = GROUPED ? (mask16 & 0xffu) : (h ? (mask16 >> 8) : (mask16 & 0xffu));
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      s0 += qs[q];
-      s1 += qs[4 + q];
-      if ((mask >> (mb * 4 + q)) & 1) {
-        float l0 = fmaf(__builtin_amdgcn_logf(s0), LN2_F, -ref_ln);
-        float l1 = fmaf(__builtin_amdgcn_logf(s1), LN2_F, -ref_ln);
-        l0 = fmaxf(l0, LOG_TINY_F);
-        l1 = fmaxf(l1, LOG_TINY_F);
-        s0 = 0.0f;
-        s1 = 0.0f;
-        closes++;
-        if (!GROUPED) {
-          if (ok0) orow0[next_sid] = l0;
-          if (ok1) orow1[next_sid] = l1;
-          next_sid = my_sid[closes];
-          stores = -1;
-        } else {
-          const int pairs_closed = closes;
-          const int slot = ((2 * (pairs_closed - 1)) & (OG - 1)) + h;
-          if (dbg & 4) {
-            asm volatile("" ::"v"(l0), "v"(l1));
-            continue;
-          }
-          ost[n * kOS + slot] = l0;
-          ost[(32 + n) * kOS + slot] = l1;
-          const int64_t closed = 2 * (int64_t)pairs_closed < S ? 2 * (int64_t)pairs_closed : S;
-          if ((((2 * pairs_closed) & (OG - 1)) == 0 || 2 * (int64_t)pairs_closed >= S) && !(dbg & 8)) {
-            const int64_t s_base = ((closed - 1) / OG) * OG;
-            const int cnt = (int)(closed - s_base);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (cnt == OG && f0 + FRAMES_PER_WAVE <= F) {
-              const int k4 = lane & 3, r16 = lane >> 2;
-              float *op = out + (f0 + r16) * S + s_base + 4 * k4;
-              const float *ip = ost + r16 * kOS + 4 * k4;
-#pragma unroll
-              for (int i = 0; i < FRAMES_PER_WAVE / 16; i++) {
-                const f32x4 v = *(const f32x4 *)(ip + i * 16 * kOS);
-                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-                if (dbg & 32) asm volatile("" ::"v"(v));  // ablation: LDS read only
-                else *(f32x4u *)(op + (int64_t)i * 16 * S) = v;
-              }
-              if (stores >= 0 && !(dbg & 32)) stores += FRAMES_PER_WAVE / 16;
-            } else {
-              stores = -1;
-              constexpr int RPI = 64 / OG;
-              const int k = lane & (OG - 1);
-#pragma unroll 4
-              for (int i = 0; i < FRAMES_PER_WAVE / RPI; i++) {
-                const int row = i * RPI + lane / OG;
-                const float v = ost[row * kOS + k];
-                if (k < cnt && f0 + row < F) out[(f0 + row) * S + s_base + k] = v;
-              }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-          }
-        }
-      }
-    }
-    return stores;
-  };
-
-  f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
-  float qs[8];
-  unsigned prev_mask = 0;
-  // Tile t+1 is requested right after the barrier of tile t-1, BEFORE the stores of
-  // that tile's close logic: vector-memory operations complete in issue order, so
-  // the wait in front of the next barrier only has to cover the tile load --
-  // s_waitcnt vmcnt(number of stores issued since) -- and never an output store.
-  if (t_begin + 1 < t_end)
-    issue_tile_copy(apf + (size_t)(t_begin + 1) * kTileFloats, abuf1, kTileFloats, wave, lane);
-  int pend = 0;  // stores issued after the outstanding tile request (-1: unknown)
-  for (int64_t t = t_begin; t < t_end; t++) {
-    const int par = (int)((t - t_begin) & 1);
-    float *acur = par ? abuf1 : abuf0;
-    const unsigned mask16 = sload_close16(close_mask, t);
-    const u32x4 *afrag = (const u32x4 *)acur + lane;
-    // block 0 of tile t; the stream carries block 1 of tile t-1
-#pragma unroll
-    for (int i = 0; i < 16; i++) { c00[i] = 0.0f; c01[i] = 0.0f; }
-    if (t > t_begin && !(dbg & 2)) {
-      bf16h_phase<NK16, 0, true>(afrag, bq, c00, c01, c10, c11, qs);
-      if (!(dbg & 1)) {
-        const int st = finish_block(qs, prev_mask, 1);
-        pend = (pend < 0 || st < 0) ? -1 : pend + st;
-      }
-    } else {
-      bf16h_phase<NK16, 0, false>(afrag, bq, c00, c01, c10, c11, qs);
-    }
-    // block 1 of tile t; the stream carries block 0 of tile t
-#pragma unroll
-    for (int i = 0; i < 16; i++) { c10[i] = 0.0f; c11[i] = 0.0f; }
-    if (dbg & 2) bf16h_phase<NK16, 1, false>(afrag, bq, c10, c11, c00, c01, qs);
-    else bf16h_phase<NK16, 1, true>(afrag, bq, c10, c11, c00, c01, qs);
-    // tile t+1 has landed (its request is older than `pend` stores) ...
-    if (pend == FRAMES_PER_WAVE / 16 && !(dbg & 16)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (pend == 2 * (FRAMES_PER_WAVE / 16) && !(dbg & 16)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // ... and every wave is done reading `acur`, which can take tile t+2
-    __builtin_amdgcn_s_barrier();
-    if (t + 2 < t_end)
-      issue_tile_copy(apf + (size_t)(t + 2) * kTileFloats, acur, kTileFloats, wave, lane);
-    pend = 0;
-    if (!(dbg & 3)) pend = finish_block(qs, mask16, 0);
-    if (dbg & 2) asm volatile("" ::"v"(c00), "v"(c01), "v"(c10), "v"(c11));
-    prev_mask = mask16;
-  }
-  // block 1 of the last tile: nothing left to hide behind
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    qs[q] = (__builtin_amdgcn_exp2f(c10[4 * q]) + __builtin_amdgcn_exp2f(c10[4 * q + 1])) +
-            (__builtin_amdgcn_exp2f(c10[4 * q + 2]) + __builtin_amdgcn_exp2f(c10[4 * q + 3]));
-    qs[4 + q] = (__builtin_amdgcn_exp2f(c11[4 * q]) + __builtin_amdgcn_exp2f(c11[4 * q + 1])) +
-                (__builtin_amdgcn_exp2f(c11[4 * q + 2]) + __builtin_amdgcn_exp2f(c11[4 * q + 3]));
-  }
-  if (t_end > t_begin) finish_block(qs, prev_mask, 1);
-}
-
-template <int NK16, bool GROUPED>
-static void launch_bf16h_t(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
-                           float *d_out, hipStream_t stream) {
-  const int64_t blocks = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
-  const int smem = Bf16Smem<NK16, GROUPED>::kBytes;
-  static const int dbg = getenv("AASR_DBG") ? atoi(getenv("AASR_DBG")) : 0;
-  static bool attr_set[64] = {false};
-  auto kern = k_gmm_diag_score_bf16x3h<NK16, GROUPED>;
-  if (!attr_set[g->device & 63]) {
-    AASR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set[g->device & 63] = true;
-  }
-  static const int force_r = getenv("AASR_SPLITS") ? atoi(getenv("AASR_SPLITS")) : 0;
-  const double slots = 2.0 * (g->num_cus > 0 ? g->num_cus : 256);
-  int R = 1;
-  double best_eff = 0;
-  for (int r = 1; r <= L.max_splits; r++) {
-    double x = (double)blocks * r / slots;
-    double eff = x / std::ceil(x);
-    if (eff > best_eff + 0.005) {
-      best_eff = eff;
-      R = r;
-    }
-  }
-  if (force_r >= 1 && force_r <= L.max_splits) R = force_r;
-  const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(256), smem, stream, d_frames, F,
-                     g->dim, g->d_pivot.p, L.a16.p, split_row, L.close.p, L.sid.p, L.sid_stride,
-                     d_out, g->S, L.ref_ln, dbg);
-  AASR_HIP(hipGetLastError());
-}
-
-template <int NK16, bool GROUPED, bool CL>
+template <int NK16, bool GROUPED, bool CL, bool WIDE>
 static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
                           float *d_out, hipStream_t stream, const ClusterArgs &cl) {
-  const int64_t blocks = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
-  const int smem = Bf16Smem<NK16, GROUPED>::kBytes;
+  constexpr int NW = WIDE ? 8 : 4;
+  const int64_t blocks = (F + NW * FRAMES_PER_WAVE - 1) / (NW * FRAMES_PER_WAVE);
+  const int smem = (WIDE ? 3 : 2) * Bf16Smem<NK16, GROUPED>::kTileBytes +
+                   NW * Bf16Smem<NK16, GROUPED>::kOutFloatsPerWave * 4;
   static const int dbg = getenv("AASR_DBG") ? atoi(getenv("AASR_DBG")) : 0;
   static bool attr_set[64] = {false};
-  auto kern = k_gmm_diag_score_bf16x3<NK16, GROUPED, CL>;
+  auto kern = k_gmm_diag_score_bf16x3<NK16, GROUPED, CL, WIDE>;
   if (!attr_set[g->device & 63]) {
     AASR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set[g->device & 63] = true;
   }
   static const int force_r = getenv("AASR_SPLITS") ? atoi(getenv("AASR_SPLITS")) : 0;
-  const double slots = 2.0 * (g->num_cus > 0 ? g->num_cus : 256);
+  const double slots = (WIDE ? 1.0 : 2.0) * (g->num_cus > 0 ? g->num_cus : 256);
   int R = 1;
   double best_eff = 0;
   for (int r = 1; r <= L.max_splits; r++) {
@@ -1241,7 +975,7 @@ static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *
   }
   if (force_r >= 1 && force_r <= L.max_splits) R = force_r;
   const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(256), smem, stream, d_frames, F,
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(NW * 64), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, L.a16.p, split_row, L.close.p, L.sid.p, L.sid_stride,
                      d_out, g->S, L.ref_ln, dbg, cl);
   AASR_HIP(hipGetLastError());
@@ -1251,30 +985,21 @@ static bool launch_bf16(const aasr_gmm *g, const TrackLayout &L, const float *d_
                         float *d_out, hipStream_t stream, const ClusterArgs *cl = nullptr) {
   if (!L.a16.p) return false;
   const ClusterArgs none;
-  static const int pipe_mode = getenv("AASR_BF16_PIPE") ? atoi(getenv("AASR_BF16_PIPE")) : 0;
-  if (pipe_mode == 2 && !cl) {
-    switch (L.nk16) {
-#define AASR_CASE(N)                                                        \
-  case N:                                                                   \
-    if (L.grouped) launch_bf16h_t<N, true>(g, L, d_frames, F, d_out, stream); \
-    else launch_bf16h_t<N, false>(g, L, d_frames, F, d_out, stream);        \
-    return true;
-      AASR_CASE(1) AASR_CASE(2) AASR_CASE(3) AASR_CASE(4) AASR_CASE(5) AASR_CASE(6) AASR_CASE(8)
-#undef AASR_CASE
-      default:
-        break;
-    }
-  }
+  // AASR_BF16_WIDE=0 selects the 4-wave workgroups (the clustered runs always use them)
+  static const int wide = getenv("AASR_BF16_WIDE") ? atoi(getenv("AASR_BF16_WIDE")) : 1;
   switch (L.nk16) {
-#define AASR_CASE(N)                                                                      \
-  case N:                                                                                 \
-    if (cl) {                                                                             \
-      if (L.grouped) launch_bf16_t<N, true, true>(g, L, d_frames, F, d_out, stream, *cl); \
-      else launch_bf16_t<N, false, true>(g, L, d_frames, F, d_out, stream, *cl);          \
-    } else {                                                                              \
-      if (L.grouped) launch_bf16_t<N, true, false>(g, L, d_frames, F, d_out, stream, none); \
-      else launch_bf16_t<N, false, false>(g, L, d_frames, F, d_out, stream, none);        \
-    }                                                                                     \
+#define AASR_CASE(N)                                                                               \
+  case N:                                                                                          \
+    if (cl) {                                                                                      \
+      if (L.grouped) launch_bf16_t<N, true, true, false>(g, L, d_frames, F, d_out, stream, *cl);   \
+      else launch_bf16_t<N, false, true, false>(g, L, d_frames, F, d_out, stream, *cl);            \
+    } else if (wide && 3 * Bf16Smem<N, true>::kTileBytes + 8 * Bf16Smem<N, true>::kOutFloatsPerWave * 4 <= 160 * 1024) { \
+      if (L.grouped) launch_bf16_t<N, true, false, true>(g, L, d_frames, F, d_out, stream, none);  \
+      else launch_bf16_t<N, false, false, true>(g, L, d_frames, F, d_out, stream, none);           \
+    } else {                                                                                       \
+      if (L.grouped) launch_bf16_t<N, true, false, false>(g, L, d_frames, F, d_out, stream, none); \
+      else launch_bf16_t<N, false, false, false>(g, L, d_frames, F, d_out, stream, none);          \
+    }                                                                                              \
     return true;
     AASR_CASE(1) AASR_CASE(2) AASR_CASE(3) AASR_CASE(4) AASR_CASE(5) AASR_CASE(6) AASR_CASE(8)
 #undef AASR_CASE
