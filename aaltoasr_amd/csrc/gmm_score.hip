@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
   // this workgroup's share of the rows: tiles [t_begin, t_end)
   const int64_t t_begin = split_row[4 * blockIdx.y];
   const int64_t t_end = split_row[4 * blockIdx.y + 4];
-  issue_tile_copy(apack + (size_t)t_begin * kTileFloats, abuf0, kTileFloats, wave, lane);
+  issue_tile_copy_raw(apack + (size_t)t_begin * kTileFloats, abuf0, kTileFloats, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
     float *acur = par ? abuf1 : abuf0;
     float *anext = par ? abuf0 : abuf1;
     if (t + 1 < t_end)
-      issue_tile_copy(apack + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
+      issue_tile_copy_raw(apack + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
     const unsigned mask16 = close16_of_pair(pair_next, t);
     // GROUPED: both tracks carry the same bits -> wave-uniform branch
     const unsigned mask = GROUPED ? (mask16 & 0xffu) : (h ? (mask16 >> 8) : (mask16 & 0xffu));
@@ -442,8 +442,12 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
     f32x4 a1 = afrag[(NKK / 2 > 1 ? 1 : 0) * 64];
 #pragma unroll
     for (int q = 0; q < NKK / 2; q++) {
+      // fetched two kk-pairs ahead; the scheduling barriers keep the compiler from sinking the
+      // read to its first use (which exposes one LDS round trip per 8 MFMAs)
       const int qn = (q + 2 < NKK / 2) ? q + 2 : NKK / 2 - 1;
+      __builtin_amdgcn_sched_barrier(0);
       f32x4 a2 = afrag[qn * 64];
+      __builtin_amdgcn_sched_barrier(0);
       const f32x4 av = a0;
       c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf[2 * q][0], c00, 0, 0, 0);
       c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf[2 * q][1], c01, 0, 0, 0);
