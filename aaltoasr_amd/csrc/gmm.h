@@ -131,6 +131,10 @@ struct FullLayout {
   DevBuf<int32_t> splits;   // [MAX_SPLITS][MAX_SPLITS+1][8]: tile, ks0, ks1, kg0, kg1
   int max_splits = 1;
   float ref_ln = 0.0f;
+  // the same rows as three bf16 terms for k_gmm_full_score_bf16x3:
+  // [tile][K/16 slabs][3 splits][2 row blocks][64 lanes][8 bf16], K index = column
+  DevBuf<uint16_t> a16;
+  int nk16 = 0;
 };
 
 // Gaussian clustering (PDFPool::read_clustering + the cluster branch of

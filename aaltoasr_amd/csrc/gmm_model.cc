@@ -936,6 +936,7 @@ void gmm_build_fullcov(aasr_gmm *g) {
   L.s_stride = (int32_t)ss;
   L.gconst.upload(gflat.data(), gflat.size());
   L.sid.upload(sflat.data(), sflat.size());
+  close.push_back(0);  // the bf16x3 kernel requests the next tile's word one tile ahead
   L.close.upload(close.data(), close.size());
   // split table, entries of 8 ints
   {
@@ -969,6 +970,32 @@ void gmm_build_fullcov(aasr_gmm *g) {
     L.splits.upload(table.data(), table.size());
   }
   pack_coef_rows(nkk, coef, tiles * TILE_ROWS, L.rows);
+  // three-term bf16 split of the same rows (AASR_PREC_BF16X3): K index = column, padded to 16
+  {
+    const int nk16 = (D + 1 + 15) / 16;
+    L.nk16 = 0;
+    L.a16 = DevBuf<uint16_t>();
+    if (nk16 <= 4) {
+      const size_t tile_elems = (size_t)nk16 * 3 * 2 * 64 * 8;
+      std::vector<uint16_t> a((size_t)tiles * tile_elems, 0);
+      for (int64_t r = 0; r < tiles * TILE_ROWS; r++) {
+        const int64_t t = r / TILE_ROWS;
+        const int jrow = (int)(r % TILE_ROWS);
+        const int mb = jrow / 32, m32 = jrow % 32;
+        for (int k = 0; k <= D; k++) {
+          const float x = (float)coef[(size_t)r * K2 + k];
+          float b1, b2, b3;
+          const uint16_t hs[3] = {bf16_rne(x, &b1), bf16_rne(x - b1, &b2), bf16_rne((x - b1) - b2, &b3)};
+          const int slab = k / 16, hk = (k % 16) / 8, i = k % 8;
+          const int lane = hk * 32 + m32;
+          for (int sp = 0; sp < 3; sp++)
+            a[(size_t)t * tile_elems + ((((size_t)slab * 3 + sp) * 2 + mb) * 64 + lane) * 8 + i] = hs[sp];
+        }
+      }
+      L.a16.upload(a.data(), a.size());
+      L.nk16 = nk16;
+    }
+  }
   L.ok = true;
 }
 

@@ -1145,6 +1145,200 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score(
   }
 }
 
+// ---------------------------------------------------------------------------
+// The same kernel on the bf16 matrix pipe (AASR_PREC_BF16X3): rows and frames as
+// three bf16 terms, six products per slab accumulated in f32 -- the scheme of
+// k_gmm_diag_score_bf16x3 (rolling A-fragment prefetch ordered by split, tile
+// copy through inline assembly, close bits requested mid-stream one tile ahead).
+// K = dim + 1 padded to a multiple of 16, K index = column of R^-1 | bias.
+// ---------------------------------------------------------------------------
+template <int NK16>
+__global__ __launch_bounds__(256, 2) void k_gmm_full_score_bf16x3(
+    const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
+    const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
+    const uint32_t *__restrict__ close_mask, const float *__restrict__ gconst, int g_stride,
+    const int32_t *__restrict__ sid, int s_stride, float *__restrict__ out, int64_t S, float ref_ln) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int kTileFloats = NK16 * 3 * 2 * 64 * 16 / 4;
+  float *abuf0 = (float *)smem_raw;
+  float *abuf1 = abuf0 + kTileFloats;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int n = lane & 31;
+  const int h = lane >> 5;
+  const int64_t f0 = (int64_t)blockIdx.x * FRAMES_PER_BLOCK + wave * FRAMES_PER_WAVE;
+
+  // frame operand: lane (n, h) holds k = 16*j + 8*h + i, i < 8: x'_k (k < dim), 1 (k == dim), 0 beyond
+  u32x4 bq[NK16][3][2];
+#pragma unroll
+  for (int nb = 0; nb < 2; nb++) {
+    int64_t f = f0 + nb * 32 + n;
+    if (f > F - 1) f = F - 1;
+    const float *xr = frames + f * dim;
+#pragma unroll
+    for (int j = 0; j < NK16; j++) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int k = 16 * j + 8 * h + i;
+        const int kc = k < dim ? k : 0;
+        float val = xr[kc] - pivot[kc];
+        if (k == dim) val = 1.0f;
+        if (k > dim) val = 0.0f;
+        v[i] = val;
+      }
+      unsigned w1[4], w2[4], w3[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) split3_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i], w3[i]);
+      bq[j][0][nb] = u32x4{w1[0], w1[1], w1[2], w1[3]};
+      bq[j][1][nb] = u32x4{w2[0], w2[1], w2[2], w2[3]};
+      bq[j][2][nb] = u32x4{w3[0], w3[1], w3[2], w3[3]};
+    }
+  }
+
+  const int64_t t_begin = split_row[8 * blockIdx.y];
+  const int64_t t_end = split_row[8 * blockIdx.y + 8];
+  const float *apf = (const float *)apack;
+  issue_tile_copy_raw(apf + (size_t)t_begin * kTileFloats, abuf0, kTileFloats, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  float q0 = 0.0f, q1 = 0.0f;  // |y|^2 of the open component, frames n / 32+n
+  float s0 = 0.0f, s1 = 0.0f;  // sum over finished components of the open state
+  int ks = split_row[8 * blockIdx.y + 1 + h];
+  int kg = split_row[8 * blockIdx.y + 3 + h];
+  const int32_t *my_sid = sid + h * s_stride;
+  const float *my_gc = gconst + h * g_stride;
+  int next_sid = my_sid[ks];
+  float next_gc = my_gc[kg];
+  float *orow0 = out + (f0 + n) * S;
+  float *orow1 = out + (f0 + 32 + n) * S;
+  const bool ok0 = f0 + n < F, ok1 = f0 + 32 + n < F;
+
+  unsigned m32_next = t_begin < t_end ? (unsigned)__builtin_amdgcn_readfirstlane((int)close_mask[t_begin]) : 0u;
+  unsigned mask_v = 0;
+  u32x4 afr[3][2];
+  if (t_begin < t_end) {
+#pragma unroll
+    for (int sp = 2; sp >= 0; sp--) {
+      afr[sp][0] = ((const u32x4 *)abuf0 + lane)[(sp * 2 + 0) * 64];
+      afr[sp][1] = ((const u32x4 *)abuf0 + lane)[(sp * 2 + 1) * 64];
+    }
+  }
+  for (int64_t t = t_begin; t < t_end; t++) {
+    const int par = (int)((t - t_begin) & 1);
+    float *acur = par ? abuf1 : abuf0;
+    float *anext = par ? abuf0 : abuf1;
+    if (t + 1 < t_end)
+      issue_tile_copy_raw(apf + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
+    const unsigned m32 = m32_next;
+    const unsigned gmask = h ? ((m32 >> 8) & 0xffu) : (m32 & 0xffu);
+    const unsigned smask = h ? ((m32 >> 24) & 0xffu) : ((m32 >> 16) & 0xffu);
+
+    f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
+    const u32x4 *afrag = (const u32x4 *)acur + lane;  // [slab][split][mb][64 lanes]
+#pragma unroll
+    for (int j = 0; j < NK16; j++) {
+#pragma unroll
+      for (int grp = 0; grp < 3; grp++) {
+        const int sp = 2 - grp;     // a3 | a2 | a1
+        const int nprod = grp + 1;  // b1 | b2 b1 | b3 b2 b1
+#pragma unroll
+        for (int c = 0; c < nprod; c++) {
+          const int sb = nprod - 1 - c;
+          const bf16x8 a_m0 = __builtin_bit_cast(bf16x8, afr[sp][0]);
+          const bf16x8 a_m1 = __builtin_bit_cast(bf16x8, afr[sp][1]);
+          const bf16x8 b_n0 = __builtin_bit_cast(bf16x8, bq[j][sb][0]);
+          const bf16x8 b_n1 = __builtin_bit_cast(bf16x8, bq[j][sb][1]);
+          c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m0, b_n0, c00, 0, 0, 0);
+          c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m0, b_n1, c01, 0, 0, 0);
+          c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m1, b_n0, c10, 0, 0, 0);
+          c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m1, b_n1, c11, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (j == 0 && grp == 0) mask_v = close_mask[t + 1];  // the array has one spare element
+        if (j + 1 < NK16) {
+          afr[sp][0] = afrag[(((j + 1) * 3 + sp) * 2 + 0) * 64];
+          afr[sp][1] = afrag[(((j + 1) * 3 + sp) * 2 + 1) * 64];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(mask_v) : : "memory");
+    __builtin_amdgcn_s_barrier();
+    m32_next = (unsigned)__builtin_amdgcn_readfirstlane((int)mask_v);
+    if (t + 1 < t_end) {
+      const u32x4 *nfrag = (const u32x4 *)anext + lane;
+#pragma unroll
+      for (int sp = 2; sp >= 0; sp--) {
+        afr[sp][0] = nfrag[(sp * 2 + 0) * 64];
+        afr[sp][1] = nfrag[(sp * 2 + 1) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+#pragma unroll
+    for (int mb = 0; mb < 2; mb++) {
+      const f32x16 &ca = mb ? c10 : c00;
+      const f32x16 &cb = mb ? c11 : c01;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          q0 = fmaf(ca[4 * q + e], ca[4 * q + e], q0);
+          q1 = fmaf(cb[4 * q + e], cb[4 * q + e], q1);
+        }
+        if ((gmask >> (mb * 4 + q)) & 1) {
+          s0 += __builtin_amdgcn_exp2f(next_gc - q0);
+          s1 += __builtin_amdgcn_exp2f(next_gc - q1);
+          q0 = 0.0f;
+          q1 = 0.0f;
+          kg++;
+          next_gc = my_gc[kg];
+          if ((smask >> (mb * 4 + q)) & 1) {
+            float l0 = fmaf(__builtin_amdgcn_logf(s0), LN2_F, -ref_ln);
+            float l1 = fmaf(__builtin_amdgcn_logf(s1), LN2_F, -ref_ln);
+            l0 = fmaxf(l0, LOG_TINY_F);
+            l1 = fmaxf(l1, LOG_TINY_F);
+            if (ok0) orow0[next_sid] = l0;
+            if (ok1) orow1[next_sid] = l1;
+            s0 = 0.0f;
+            s1 = 0.0f;
+            ks++;
+            next_sid = my_sid[ks];
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int NK16>
+static void launch_full_bf16_t(const aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
+                               hipStream_t stream) {
+  const FullLayout &L = g->full;
+  const int64_t blocks = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
+  const int smem = 2 * NK16 * 3 * 2 * 64 * 16;
+  const double slots = 2.0 * (g->num_cus > 0 ? g->num_cus : 256);
+  int R = 1;
+  double best_eff = 0;
+  for (int r = 1; r <= L.max_splits; r++) {
+    double x = (double)blocks * r / slots;
+    double eff = x / std::ceil(x);
+    if (x < 1.0) eff = x;
+    if (eff > best_eff + 0.005) {
+      best_eff = eff;
+      R = r;
+    }
+  }
+  const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 8;
+  hipLaunchKernelGGL(k_gmm_full_score_bf16x3<NK16>, dim3((unsigned)blocks, (unsigned)R), dim3(256), smem,
+                     stream, d_frames, F, g->dim, g->d_pivot.p, L.a16.p, split_row, L.close.p, L.gconst.p,
+                     L.g_stride, L.sid.p, L.s_stride, d_out, g->S, L.ref_ln);
+  AASR_HIP(hipGetLastError());
+}
+
 template <int NKK>
 static void launch_full_t(const aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                           hipStream_t stream) {
@@ -1173,6 +1367,15 @@ static void launch_full_t(const aasr_gmm *g, const float *d_frames, int64_t F, f
 void gmm_full_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                      hipStream_t stream) {
   if (!g->full.ok) raise(AASR_ERR_UNSUPPORTED, "full-covariance layout was not built for this model");
+  if (g->use_bf16x3 && g->full.a16.p) {
+    switch (g->full.nk16) {
+      case 1: launch_full_bf16_t<1>(g, d_frames, F, d_out, stream); return;
+      case 2: launch_full_bf16_t<2>(g, d_frames, F, d_out, stream); return;
+      case 3: launch_full_bf16_t<3>(g, d_frames, F, d_out, stream); return;
+      case 4: launch_full_bf16_t<4>(g, d_frames, F, d_out, stream); return;
+      default: break;
+    }
+  }
   switch (g->full.rows.nkk) {
 #define AASR_CASE(N)                                   \
   case N:                                              \

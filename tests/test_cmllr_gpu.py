@@ -75,6 +75,8 @@ def test_regression_classes_and_unadapted_gaussians(capi, oracle, D, G, S, comps
     g.set_cmllr(g2t, W)
     got = g.score(frames)
     assert np.abs(got - ref).max() <= 1e-4
+    g.set_precision(3)      # the per-class factor rows on the bf16 pipe (k_gmm_full_score_bf16x3)
+    assert np.abs(g.score(frames) - ref).max() <= 1e-4
 
 
 def test_zero_diagonal_kills_the_adapted_gaussians(capi, oracle):

@@ -21,16 +21,26 @@ def _full_model(D, G, S, comps, seed, tied=False):
     return mean, cov, off, idx, w
 
 
-@pytest.mark.parametrize("D,G,S,comps,F", [(8, 64, 8, 8, 70), (13, 48, 12, 4, 130),
-                                            (39, 64, 16, 4, 100), (39, 60, 6, 10, 257)])
+def _score_both(g, frames):
+    """f32 matrix kernel, then the same rows on the bf16 pipe (three-term split)."""
+    a = g.score(frames)
+    g.set_precision(3)
+    b = g.score(frames)
+    g.set_precision(0)
+    return a, b
+
+
+@pytest.mark.parametrize("D,G,S,comps,F", [(8, 64, 8, 8, 70), (13, 48, 12, 4, 130), (15, 40, 5, 8, 64),
+                                            (16, 40, 5, 8, 300), (39, 64, 16, 4, 100), (39, 60, 6, 10, 257),
+                                            (47, 32, 4, 8, 90), (63, 32, 4, 8, 65)])
 def test_full_covariance_scoring(capi, oracle, D, G, S, comps, F):
     mean, cov, off, idx, w = _full_model(D, G, S, comps, seed=D + G)
     frames = synth.make_frames(F, D=D, seed=5)
     ref = oracle.FullModel(mean, cov, off, idx, w).score(frames.astype(np.float64))
     g = capi.Gmm.from_full(mean, cov, off, idx, w)
-    got = g.score(frames)
-    err = np.abs(got - ref)
-    assert err.max() <= 1e-4, "max |dll| %.3g" % err.max()
+    for got in _score_both(g, frames):
+        err = np.abs(got - ref)
+        assert err.max() <= 1e-4, "max |dll| %.3g" % err.max()
 
 
 def test_tied_and_ragged_states(capi, oracle):
@@ -43,9 +53,9 @@ def test_tied_and_ragged_states(capi, oracle):
     w[3] = 0.0
     frames = synth.make_frames(90, D=13, seed=6)
     ref = oracle.FullModel(mean, cov, off, idx, w).score(frames.astype(np.float64))
-    got = capi.Gmm.from_full(mean, cov, off, idx, w).score(frames)
-    assert np.abs(got - ref).max() <= 1e-4
-    assert np.allclose(got[:, 2], np.log(1e-50), atol=1e-5)
+    for got in _score_both(capi.Gmm.from_full(mean, cov, off, idx, w), frames):
+        assert np.abs(got - ref).max() <= 1e-4
+        assert np.allclose(got[:, 2], np.log(1e-50), atol=1e-5)
 
 
 def test_non_spd_covariance_is_the_reference_invalid_gaussian(capi, oracle):
@@ -53,8 +63,8 @@ def test_non_spd_covariance_is_the_reference_invalid_gaussian(capi, oracle):
     cov[5] = -np.eye(8)                      # not SPD -> precision 0, constant 0 -> ll == 0
     frames = synth.make_frames(40, D=8, seed=7) * 2
     ref = oracle.FullModel(mean, cov, off, idx, w).score(frames.astype(np.float64))
-    got = capi.Gmm.from_full(mean, cov, off, idx, w).score(frames)
-    assert np.abs(got - ref).max() <= 1e-4
+    for got in _score_both(capi.Gmm.from_full(mean, cov, off, idx, w), frames):
+        assert np.abs(got - ref).max() <= 1e-4
 
 
 def test_full_gk_files_and_mixed_pool(capi, oracle, tmp_path):
@@ -73,7 +83,8 @@ def test_full_gk_files_and_mixed_pool(capi, oracle, tmp_path):
     frames = synth.make_frames(64, D=8, seed=2)
     ref = oracle.FullModel(mean, cov_eff, off, idx, w).score(frames.astype(np.float64))
     g = capi.Gmm.from_files(base + ".gk", base + ".mc", base + ".ph")
-    assert np.abs(g.score(frames) - ref).max() <= 1e-4
+    for got in _score_both(g, frames):
+        assert np.abs(got - ref).max() <= 1e-4
     oracle.write_gk_full(base + "_legacy.gk", mean, cov, legacy=True)
     ref2 = oracle.FullModel(mean, cov, off, idx, w).score(frames.astype(np.float64))
     g2 = capi.Gmm.from_files(base + "_legacy.gk", base + ".mc", None)
