@@ -135,6 +135,11 @@ struct FullLayout {
   // [tile][K/16 slabs][3 splits][2 row blocks][64 lanes][8 bf16], K index = column
   DevBuf<uint16_t> a16;
   int nk16 = 0;
+  // per tile and track, by quad position: constant of the component / index of the state that
+  // closes there ([tiles][2][8]) -- the bf16x3 kernel fetches them with the tile instead of
+  // chasing gconst / sid through dependent loads in its epilogue
+  DevBuf<float> gc_tile;
+  DevBuf<int32_t> sid_tile;
 };
 
 // Gaussian clustering (PDFPool::read_clustering + the cluster branch of

@@ -887,6 +887,8 @@ void gmm_build_fullcov(aasr_gmm *g) {
   std::vector<uint32_t> close((size_t)tiles, 0);
   std::vector<float> gc[2];
   std::vector<int32_t> sid[2];
+  std::vector<float> gc_tile((size_t)(tiles + 1) * 16, kNullConst);
+  std::vector<int32_t> sid_tile((size_t)(tiles + 1) * 16, 0);
   for (int64_t s = 0; s < m.S; s++) {
     const int h = st_track[(size_t)s];
     int64_t p = st_pos[(size_t)s];
@@ -897,6 +899,8 @@ void gmm_build_fullcov(aasr_gmm *g) {
       close[(size_t)(p / 8)] |= 1u << (p % 8 + 8 * h);
       close[(size_t)(p / 8)] |= 1u << (16 + p % 8 + 8 * h);
       sid[h].push_back((int32_t)s);
+      gc_tile[(size_t)(p / 8) * 16 + h * 8 + p % 8] = kNullConst;
+      sid_tile[(size_t)(p / 8) * 16 + h * 8 + p % 8] = (int32_t)s;
       continue;
     }
     for (int32_t k = a0; k < b0; k++) {
@@ -917,9 +921,11 @@ void gmm_build_fullcov(aasr_gmm *g) {
       gc[h].push_back(std::isfinite(c) ? (float)(c * kLog2e + ref) : kNullConst);
       const int64_t last = p + gq - 1;
       close[(size_t)(last / 8)] |= 1u << (last % 8 + 8 * h);
+      gc_tile[(size_t)(last / 8) * 16 + h * 8 + last % 8] = gc[h].back();
       if (k + 1 == b0) {
         close[(size_t)(last / 8)] |= 1u << (16 + last % 8 + 8 * h);
         sid[h].push_back((int32_t)s);
+        sid_tile[(size_t)(last / 8) * 16 + h * 8 + last % 8] = (int32_t)s;
       }
       p += gq;
     }
@@ -936,6 +942,8 @@ void gmm_build_fullcov(aasr_gmm *g) {
   L.s_stride = (int32_t)ss;
   L.gconst.upload(gflat.data(), gflat.size());
   L.sid.upload(sflat.data(), sflat.size());
+  L.gc_tile.upload(gc_tile.data(), gc_tile.size());
+  L.sid_tile.upload(sid_tile.data(), sid_tile.size());
   close.push_back(0);  // the bf16x3 kernel requests the next tile's word one tile ahead
   L.close.upload(close.data(), close.size());
   // split table, entries of 8 ints

@@ -1156,8 +1156,8 @@ template <int NK16>
 __global__ __launch_bounds__(256, 2) void k_gmm_full_score_bf16x3(
     const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
     const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
-    const uint32_t *__restrict__ close_mask, const float *__restrict__ gconst, int g_stride,
-    const int32_t *__restrict__ sid, int s_stride, float *__restrict__ out, int64_t S, float ref_ln) {
+    const uint32_t *__restrict__ close_mask, const float *__restrict__ gc_tile,
+    const int32_t *__restrict__ sid_tile, float *__restrict__ out, int64_t S, float ref_ln) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int kTileFloats = NK16 * 3 * 2 * 64 * 16 / 4;
   float *abuf0 = (float *)smem_raw;
@@ -1206,12 +1206,10 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score_bf16x3(
 
   float q0 = 0.0f, q1 = 0.0f;  // |y|^2 of the open component, frames n / 32+n
   float s0 = 0.0f, s1 = 0.0f;  // sum over finished components of the open state
-  int ks = split_row[8 * blockIdx.y + 1 + h];
-  int kg = split_row[8 * blockIdx.y + 3 + h];
-  const int32_t *my_sid = sid + h * s_stride;
-  const float *my_gc = gconst + h * g_stride;
-  int next_sid = my_sid[ks];
-  float next_gc = my_gc[kg];
+  // this track's closing constants / state indices of a tile, by quad position
+  const f32x4 *gct = (const f32x4 *)(gc_tile + h * 8);
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const i32x4 *sdt = (const i32x4 *)(sid_tile + h * 8);
   float *orow0 = out + (f0 + n) * S;
   float *orow1 = out + (f0 + 32 + n) * S;
   const bool ok0 = f0 + n < F, ok1 = f0 + 32 + n < F;
@@ -1232,6 +1230,11 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score_bf16x3(
     float *anext = par ? abuf0 : abuf1;
     if (t + 1 < t_end)
       issue_tile_copy_raw(apf + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
+    // fetched with the tile: they land under the matrix stream, the epilogue never waits on memory
+    const f32x4 gca = gct[4 * t], gcb = gct[4 * t + 1];
+    const i32x4 sda = sdt[4 * t], sdb = sdt[4 * t + 1];
+    const float gcv[8] = {gca.x, gca.y, gca.z, gca.w, gcb.x, gcb.y, gcb.z, gcb.w};
+    const int sdv[8] = {sda.x, sda.y, sda.z, sda.w, sdb.x, sdb.y, sdb.z, sdb.w};
     const unsigned m32 = m32_next;
     const unsigned gmask = h ? ((m32 >> 8) & 0xffu) : (m32 & 0xffu);
     const unsigned smask = h ? ((m32 >> 24) & 0xffu) : ((m32 >> 16) & 0xffu);
@@ -1290,23 +1293,19 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score_bf16x3(
           q1 = fmaf(cb[4 * q + e], cb[4 * q + e], q1);
         }
         if ((gmask >> (mb * 4 + q)) & 1) {
-          s0 += __builtin_amdgcn_exp2f(next_gc - q0);
-          s1 += __builtin_amdgcn_exp2f(next_gc - q1);
+          s0 += __builtin_amdgcn_exp2f(gcv[mb * 4 + q] - q0);
+          s1 += __builtin_amdgcn_exp2f(gcv[mb * 4 + q] - q1);
           q0 = 0.0f;
           q1 = 0.0f;
-          kg++;
-          next_gc = my_gc[kg];
           if ((smask >> (mb * 4 + q)) & 1) {
             float l0 = fmaf(__builtin_amdgcn_logf(s0), LN2_F, -ref_ln);
             float l1 = fmaf(__builtin_amdgcn_logf(s1), LN2_F, -ref_ln);
             l0 = fmaxf(l0, LOG_TINY_F);
             l1 = fmaxf(l1, LOG_TINY_F);
-            if (ok0) orow0[next_sid] = l0;
-            if (ok1) orow1[next_sid] = l1;
+            if (ok0) orow0[sdv[mb * 4 + q]] = l0;
+            if (ok1) orow1[sdv[mb * 4 + q]] = l1;
             s0 = 0.0f;
             s1 = 0.0f;
-            ks++;
-            next_sid = my_sid[ks];
           }
         }
       }
@@ -1334,8 +1333,8 @@ static void launch_full_bf16_t(const aasr_gmm *g, const float *d_frames, int64_t
   }
   const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 8;
   hipLaunchKernelGGL(k_gmm_full_score_bf16x3<NK16>, dim3((unsigned)blocks, (unsigned)R), dim3(256), smem,
-                     stream, d_frames, F, g->dim, g->d_pivot.p, L.a16.p, split_row, L.close.p, L.gconst.p,
-                     L.g_stride, L.sid.p, L.s_stride, d_out, g->S, L.ref_ln);
+                     stream, d_frames, F, g->dim, g->d_pivot.p, L.a16.p, split_row, L.close.p, L.gc_tile.p,
+                     L.sid_tile.p, d_out, g->S, L.ref_ln);
   AASR_HIP(hipGetLastError());
 }
 
