@@ -1412,11 +1412,15 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
   const int64_t fa = (int64_t)blockIdx.x * 512 + threadIdx.x;
   const int64_t fb = fa + 256;
   const int64_t fac = fa < F ? fa : F - 1, fbc = fb < F ? fb : F - 1;
-  float xa[DIMP], xb[DIMP];
+  // The two frames of a lane travel as one <2 x float>: t = x - mu, t*t, fma with p' are
+  // v_pk_add / v_pk_mul / v_pk_fma_f32 (two frames per instruction, the scalar operand
+  // broadcast) -- 1.5 VALU instructions per frame and dimension instead of 3, same roundings.
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 x2[DIMP];
 #pragma unroll
   for (int d = 0; d < DIMP; d++) {
-    xa[d] = d < dim ? frames[fac * dim + d] : 0.0f;
-    xb[d] = d < dim ? frames[fbc * dim + d] : 0.0f;
+    x2[d].x = d < dim ? frames[fac * dim + d] : 0.0f;
+    x2[d].y = d < dim ? frames[fbc * dim + d] : 0.0f;
   }
   const int s_begin = split_state[blockIdx.y], s_end = split_state[blockIdx.y + 1];
   for (int s = s_begin; s < s_end; s++) {
@@ -1424,18 +1428,16 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
     float ma = NEG_BIG_F, sa = 0.0f, mb = NEG_BIG_F, sb = 0.0f;
     for (int r = r0; r < r1; r++) {
       const float *rec = recs + (size_t)r * REC;
-      float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;  // two chains per frame
+      f32x2 acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};  // two chains per frame
 #pragma unroll
       for (int d = 0; d < DIMP; d += 2) {
         const float mu0 = rec[d], mu1 = rec[d + 1];
         const float p0 = rec[DIMP + d], p1 = rec[DIMP + d + 1];
-        const float ta0 = xa[d] - mu0, ta1 = xa[d + 1] - mu1;
-        const float tb0 = xb[d] - mu0, tb1 = xb[d + 1] - mu1;
-        a0 = fmaf(ta0 * ta0, p0, a0);
-        a1 = fmaf(ta1 * ta1, p1, a1);
-        b0 = fmaf(tb0 * tb0, p0, b0);
-        b1 = fmaf(tb1 * tb1, p1, b1);
+        const f32x2 t0 = x2[d] - (f32x2){mu0, mu0}, t1 = x2[d + 1] - (f32x2){mu1, mu1};
+        acc0 = __builtin_elementwise_fma(t0 * t0, (f32x2){p0, p0}, acc0);
+        acc1 = __builtin_elementwise_fma(t1 * t1, (f32x2){p1, p1}, acc1);
       }
+      const float a0 = acc0.x, b0 = acc0.y, a1 = acc1.x, b1 = acc1.y;
       const float c = rec[2 * DIMP];
       const float la = c + (a0 + a1), lb = c + (b0 + b1);  // log2 units
       const float na = fmaxf(ma, la), nb = fmaxf(mb, lb);
