@@ -985,19 +985,25 @@ static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *
   AASR_HIP(hipGetLastError());
 }
 
+// the 8-wave form needs three tile buffers + eight staging areas in 160 KB of LDS
+template <int N>
+static constexpr bool wide_ok() {
+  return 3 * Bf16Smem<N, true>::kTileBytes + 8 * Bf16Smem<N, true>::kOutFloatsPerWave * 4 <= 160 * 1024;
+}
+
 static bool launch_bf16(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
                         float *d_out, hipStream_t stream, const ClusterArgs *cl = nullptr) {
   if (!L.a16.p) return false;
   const ClusterArgs none;
-  // AASR_BF16_WIDE=0 selects the 4-wave workgroups (the clustered runs always use them)
+  // AASR_BF16_WIDE=0 selects the 4-wave workgroups
   static const int wide = getenv("AASR_BF16_WIDE") ? atoi(getenv("AASR_BF16_WIDE")) : 1;
   switch (L.nk16) {
 #define AASR_CASE(N)                                                                               \
   case N:                                                                                          \
-    if (cl) {                                                                                      \
+    if (cl) { /* 4-wave form: the selection masks are laid out per 256-frame workgroup */          \
       if (L.grouped) launch_bf16_t<N, true, true, false>(g, L, d_frames, F, d_out, stream, *cl);   \
       else launch_bf16_t<N, false, true, false>(g, L, d_frames, F, d_out, stream, *cl);            \
-    } else if (wide && 3 * Bf16Smem<N, true>::kTileBytes + 8 * Bf16Smem<N, true>::kOutFloatsPerWave * 4 <= 160 * 1024) { \
+    } else if (wide && wide_ok<N>()) {                                                             \
       if (L.grouped) launch_bf16_t<N, true, false, true>(g, L, d_frames, F, d_out, stream, none);  \
       else launch_bf16_t<N, false, false, true>(g, L, d_frames, F, d_out, stream, none);           \
     } else {                                                                                       \
