@@ -295,7 +295,7 @@ class Gmm:
         return out
 
     def set_precision(self, prec: int) -> None:
-        """0 = f32 (default), 2 = f32 centred form, 3 = bf16x3 split."""
+        """0 = f32, 2 = f32 centred form, 3 = bf16x3 split (default)."""
         check(lib().aasr_gmm_set_precision(self._h, prec))
 
     def set_layouts(self, mask: int) -> None:

@@ -387,7 +387,7 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
   // aasr_debug_set_layouts (1 grouped, 2 independent tracks, 4 centred, 0 general)
   if (const char *e = getenv("AASR_PREC")) {
     g->use_bf16x3 = atoi(e) == AASR_PREC_BF16X3;
-    if (g->use_bf16x3) g->precision = AASR_PREC_BF16X3;
+    g->precision = g->use_bf16x3 ? AASR_PREC_BF16X3 : AASR_PREC_F32;
   }
   if (const char *e = getenv("AASR_LAYOUTS")) {
     g->layout_mask = atoi(e);

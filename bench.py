@@ -150,8 +150,7 @@ def main():
         model = shard.broadcast_model(model, src=0, device=dev)
     mean, var, off, idx, w = (model[k] for k in names)
     gmm = capi.Gmm.from_arrays(mean, var, off, idx, w)
-    if args.precision == "bf16x3":
-        gmm.set_precision(3)   # AASR_PREC_BF16X3
+    gmm.set_precision(3 if args.precision == "bf16x3" else 0)   # AASR_PREC_BF16X3 / AASR_PREC_F32
     rows = gmm.expanded_rows
 
     stream = torch.cuda.current_stream()

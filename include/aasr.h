@@ -223,15 +223,18 @@ aasr_status aasr_gmm_set_clustering_min_evals(aasr_gmm *h, double min_clusters,
 int32_t aasr_gmm_num_clusters(const aasr_gmm *h);
 
 /* Arithmetic used for the frame x Gaussian quadratic forms.
- *  AASR_PREC_F32          default: f32 matrix-core contraction of the expanded
- *                         form; models whose conditioning would break the 1e-4
- *                         budget are switched to the centred form automatically
+ *  AASR_PREC_F32          f32 matrix-core contraction of the expanded form; models
+ *                         whose conditioning would break the 1e-4 budget are
+ *                         switched to the centred form automatically
  *  AASR_PREC_F32_CENTRED  always the centred form (x-mu)^2*p on the vector ALU,
  *                         the reference's own arithmetic shape in f32
- *  AASR_PREC_BF16X3       both operands split into three bf16 terms, six bf16
- *                         matrix-core products per f32 product accumulated in
- *                         f32: f32-class accuracy at ~2.7x the matrix rate
- *                         (ill-conditioned models still take the centred form)
+ *  AASR_PREC_BF16X3       default: both operands split into three bf16 terms, six
+ *                         bf16 matrix-core products per f32 product accumulated
+ *                         in f32: f32-class accuracy (same 1e-4 parity bar) at
+ *                         ~1.8x the speed of the f32 kernel; diagonal, full-
+ *                         covariance and per-class CMLLR models (ill-conditioned
+ *                         models still take the centred form).  The environment
+ *                         variable AASR_PREC=0 selects AASR_PREC_F32 globally.
  *  AASR_PREC_F64          reserved (f64 matrix cores), not built */
 enum { AASR_PREC_F32 = 0, AASR_PREC_F64 = 1, AASR_PREC_F32_CENTRED = 2, AASR_PREC_BF16X3 = 3 };
 aasr_status aasr_gmm_set_precision(aasr_gmm *h, int prec);
