@@ -996,7 +996,9 @@ static bool launch_bf16(const aasr_gmm *g, const TrackLayout &L, const float *d_
   if (!L.a16.p) return false;
   const ClusterArgs none;
   // AASR_BF16_WIDE=0 selects the 4-wave workgroups
-  static const int wide = getenv("AASR_BF16_WIDE") ? atoi(getenv("AASR_BF16_WIDE")) : 1;
+  static const int wide_env = getenv("AASR_BF16_WIDE") ? atoi(getenv("AASR_BF16_WIDE")) : -1;
+  // small batches (a decoder's per-utterance blocks) fill the chip better with 256-frame workgroups
+  const int wide = wide_env >= 0 ? wide_env : (F >= 8192 ? 1 : 0);
   switch (L.nk16) {
 #define AASR_CASE(N)                                                                               \
   case N:                                                                                          \
