@@ -203,6 +203,18 @@ struct aasr_gmm {
   aasr::DevBuf<int32_t> centred_state_off; // [S+1]
   aasr::DevBuf<int32_t> centred_splits;    // [MAX][MAX+1] state boundaries
   int centred_max_splits = 1;
+  // Outlier routing: when only a minority of the Gaussians break the conditioning limit, those
+  // (outlier[g] != 0) are taken out of the matrix layouts (null rows) and scored in the centred
+  // form over the states that hold them; k_outlier_merge adds the two parts per state.
+  std::vector<uint8_t> outlier;            // per pool Gaussian
+  bool hyb_enabled = false;
+  int64_t hyb_states = 0, hyb_rows = 0;    // states with outliers, outlier components
+  aasr::DevBuf<float> hyb_recs;            // centred records of the outlier components
+  aasr::DevBuf<int32_t> hyb_state_off;     // [hyb_states + 1]
+  aasr::DevBuf<int32_t> hyb_splits;        // [MAX][MAX+1]
+  int hyb_max_splits = 1;
+  aasr::DevBuf<int32_t> hyb_map;           // [hyb_states] -> state index
+  aasr::DevBuf<float> hyb_scratch;         // [frames of a pass][hyb_states]
   // global CMLLR transform applied to the frames before scoring
   aasr::DevBuf<double> xf_a, xf_b;
   aasr::DevBuf<float> d_xframes;

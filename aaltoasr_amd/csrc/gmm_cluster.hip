@@ -430,6 +430,9 @@ void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
     raise(AASR_ERR_UNSUPPORTED,
           "Gaussian clustering needs the fixed-reference track kernels, which this model's "
           "constants rule out");
+  if (g->hyb_enabled)
+    raise(AASR_ERR_UNSUPPORTED,
+          "Gaussian clustering is not built for models with outlier-routed Gaussians (kappa %.0f)", g->kappa);
   std::vector<std::vector<int32_t>> members((size_t)n_clusters);
   std::vector<int32_t> g2c((size_t)m.G, -1);
   for (int64_t i = 0; i < n_pairs; i++) {

@@ -256,6 +256,7 @@ static void pack_rows(const aasr_gmm *g, const std::vector<RowSpec> &rows,
 }
 
 void gmm_build_tracks(aasr_gmm *g, bool grouped);
+static void find_outliers(aasr_gmm *g);
 
 void gmm_build(aasr_gmm *g, const HostModel &model) {
   require_device();
@@ -267,6 +268,9 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
   }
   g->host = model;
   HostModel &m = g->host;
+  g->outlier.clear();
+  g->hyb_enabled = false;
+  g->hyb_states = g->hyb_rows = 0;
   g->dim = m.dim;
   g->G = m.G;
   g->S = m.S;
@@ -336,6 +340,8 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
     g->xf_b.upload(b.data(), b.size());
   }
 
+  find_outliers(g);
+
   // component-expanded rows in state order + segment metadata
   std::vector<RowSpec> rows;
   rows.reserve(m.mix_idx.size());
@@ -357,7 +363,10 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
       per_chunk[(size_t)c].push_back({rb | (rb << 8), (int32_t)s});
       continue;
     }
-    for (int32_t k = a; k < b; k++) rows.push_back({m.mix_idx[k], m.logw((size_t)k)});
+    for (int32_t k = a; k < b; k++) {
+      const bool out_k = !g->outlier.empty() && g->outlier[(size_t)m.mix_idx[k]];
+      rows.push_back({out_k ? (int64_t)-1 : (int64_t)m.mix_idx[k], m.logw((size_t)k)});
+    }
     int64_t r0 = row, r1 = row + (b - a);
     for (int64_t c = r0 / CHUNK_ROWS; c * CHUNK_ROWS < r1; c++) {
       int64_t lo = std::max(r0, c * CHUNK_ROWS), hi = std::min(r1, (c + 1) * CHUNK_ROWS);
@@ -420,10 +429,11 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
 static const double kRefMin = 56.0, kRefMax = 72.0;
 static const double kPeakMax = 120.0;  // max (peak*log2e + ref) accepted
 
-static bool choose_reference(const HostModel &m, double *ref_out) {
+static bool choose_reference(const HostModel &m, const std::vector<uint8_t> &outlier, double *ref_out) {
   const int D = m.dim;
   double max_peak_log2 = -INFINITY;
   for (size_t k = 0; k < m.mix_idx.size(); k++) {
+    if (!outlier.empty() && outlier[(size_t)m.mix_idx[k]]) continue;  // scored in the centred form
     const double *var = &m.var[(size_t)m.mix_idx[k] * D];
     double prod = 1;
     for (int d = 0; d < D; d++) prod *= (var[d] > 0) ? 1 / var[d] : 0;
@@ -548,7 +558,7 @@ void gmm_build_tracks(aasr_gmm *g, bool grouped) {
   L.ok = false;
   L.grouped = grouped;
   double ref = 0;
-  if (!choose_reference(m, &ref)) return;
+  if (!choose_reference(m, g->outlier, &ref)) return;
   L.ref_ln = (float)(ref * 0.69314718055994530942);
   const int64_t rows_real = std::max<int64_t>(1, (int64_t)m.mix_idx.size());
 
@@ -623,6 +633,7 @@ void gmm_build_tracks(aasr_gmm *g, bool grouped) {
     const int64_t p0 = st_pos[(size_t)s];
     const int32_t a = m.mix_off[s], b = m.mix_off[s + 1];
     for (int32_t k = a; k < b; k++) {
+      if (!g->outlier.empty() && g->outlier[(size_t)m.mix_idx[k]]) continue;  // stays a null row
       rows[(size_t)track_row(p0 + (k - a) / 4, h, (k - a) % 4)] =
           RowSpec{m.mix_idx[k], m.logw((size_t)k), ref};
     }
@@ -663,14 +674,71 @@ void gmm_build_tracks(aasr_gmm *g, bool grouped) {
 
 // Operands of the centred-form kernel + the conditioning estimate that decides
 // whether the matrix-core (expanded form) kernels may be used.
-void gmm_build_centred(aasr_gmm *g) {
+// Centred-form operands of a component subset: rows k of the mixture arrays grouped by `off`
+// ([n_states + 1] offsets into `comps`).
+static void build_centred_tables(const HostModel &m, int dimp, const std::vector<int32_t> &comps,
+                                 const std::vector<int32_t> &off, DevBuf<float> &d_recs,
+                                 DevBuf<int32_t> &d_off, DevBuf<int32_t> &d_splits, int *max_splits) {
+  const int D = m.dim;
+  const int rec = 2 * dimp + 4;
+  const size_t rows = comps.size();
+  const int64_t n_states = (int64_t)off.size() - 1;
+  std::vector<float> recs(std::max<size_t>(1, rows) * rec, 0.0f);
+  for (size_t r = 0; r < rows; r++) {
+    const size_t k = (size_t)comps[r];
+    const int64_t gi = m.mix_idx[k];
+    double prod = 1;
+    for (int d = 0; d < D; d++) {
+      double v = m.var[(size_t)gi * D + d];
+      double p = v > 0 ? 1 / v : 0;
+      prod *= p;
+      recs[r * rec + d] = (float)m.mean[(size_t)gi * D + d];
+      recs[r * rec + dimp + d] = (float)(-0.5 * p * kLog2e);
+    }
+    double cst = (prod > 0) ? std::log(std::sqrt(prod)) : prod;
+    double c = cst + m.logw(k);
+    if (std::isnan(c) || c == INFINITY)
+      raise(AASR_ERR_INVALID, "Gaussian %ld has a non-finite constant (precision product overflow)", (long)gi);
+    recs[r * rec + 2 * dimp] = std::isfinite(c) ? (float)(c * kLog2e) : kNullConst;
+  }
+  d_recs.upload(recs.data(), recs.size());
+  d_off.upload(off.data(), off.size());
+  // state-range cut table: row R-1 = R+1 boundaries with near-equal row counts
+  std::vector<int32_t> table((size_t)CENTRED_MAX_SPLITS * (CENTRED_MAX_SPLITS + 1), 0);
+  *max_splits = (int)std::max<int64_t>(1, std::min<int64_t>(CENTRED_MAX_SPLITS, n_states));
+  for (int R = 1; R <= *max_splits; R++) {
+    int32_t *row = &table[(size_t)(R - 1) * (CENTRED_MAX_SPLITS + 1)];
+    int64_t s = 0;
+    row[0] = 0;
+    for (int i = 1; i < R; i++) {
+      int64_t want = (int64_t)((double)rows * i / R);
+      while (s < n_states && off[(size_t)s] < want) s++;
+      if (s <= row[i - 1]) s = row[i - 1] + 1;
+      if (s > n_states) s = n_states;
+      row[i] = (int32_t)s;
+    }
+    row[R] = (int32_t)n_states;
+  }
+  d_splits.upload(table.data(), table.size());
+}
+
+static int centred_dimp_for(int D) {
+  for (int c : {8, 16, 24, 32, 40, 48, 64})
+    if (D <= c) return c;
+  return 0;
+}
+
+// Conditioning of the expanded form, kappa_g = sum_d p (mu - pivot)^2 per Gaussian.  A model
+// whose worst Gaussian exceeds KAPPA_LIMIT is scored entirely in the centred form -- unless the
+// offenders are a minority (at most a quarter of the mixture components): then only they are,
+// over the states that hold them (outlier routing), and the rest keeps the matrix path.
+static void find_outliers(aasr_gmm *g) {
   const HostModel &m = g->host;
   const int D = m.dim;
-  g->centred_ok = false;
-  int dimp = 0;
-  for (int c : {8, 16, 24, 32, 40, 48, 64})
-    if (D <= c) { dimp = c; break; }
-  // conditioning of the expanded form: kappa = max_g sum_d p (mu - pivot)^2
+  g->outlier.clear();
+  g->hyb_enabled = false;
+  g->hyb_states = g->hyb_rows = 0;
+  std::vector<uint8_t> bad((size_t)m.G, 0);
   double kappa = 0;
   for (int64_t i = 0; i < m.G; i++) {
     double k = 0;
@@ -681,49 +749,43 @@ void gmm_build_centred(aasr_gmm *g) {
       k += p * mc * mc;
     }
     kappa = std::max(kappa, k);
+    bad[(size_t)i] = k > KAPPA_LIMIT;
   }
   g->kappa = kappa;
   g->ill_conditioned = kappa > KAPPA_LIMIT;
+  const int dimp = centred_dimp_for(D);
+  static const int routing = getenv("AASR_OUTLIER_ROUTING") ? atoi(getenv("AASR_OUTLIER_ROUTING")) : 1;
+  if (!g->ill_conditioned || !dimp || !routing || g->cl.loaded) return;
+  std::vector<int32_t> comps, off{0}, map;
+  for (int64_t s = 0; s < m.S; s++) {
+    const size_t before = comps.size();
+    for (int32_t k = m.mix_off[s]; k < m.mix_off[s + 1]; k++)
+      if (bad[(size_t)m.mix_idx[k]]) comps.push_back(k);
+    if (comps.size() > before) {
+      off.push_back((int32_t)comps.size());
+      map.push_back((int32_t)s);
+    }
+  }
+  if (comps.empty() || comps.size() * 4 > m.mix_idx.size()) return;  // not a minority: all centred
+  g->outlier = bad;
+  g->hyb_enabled = true;
+  g->ill_conditioned = false;
+  g->hyb_states = (int64_t)map.size();
+  g->hyb_rows = (int64_t)comps.size();
+  build_centred_tables(m, dimp, comps, off, g->hyb_recs, g->hyb_state_off, g->hyb_splits, &g->hyb_max_splits);
+  g->hyb_map.upload(map.data(), map.size());
+}
+
+void gmm_build_centred(aasr_gmm *g) {
+  const HostModel &m = g->host;
+  g->centred_ok = false;
+  const int dimp = centred_dimp_for(m.dim);
   if (!dimp) return;
   g->centred_dimp = dimp;
-  const int rec = 2 * dimp + 4;
-  const size_t rows = m.mix_idx.size();
-  std::vector<float> recs(std::max<size_t>(1, rows) * rec, 0.0f);
-  for (size_t k = 0; k < rows; k++) {
-    const int64_t gi = m.mix_idx[k];
-    double prod = 1;
-    for (int d = 0; d < D; d++) {
-      double v = m.var[(size_t)gi * D + d];
-      double p = v > 0 ? 1 / v : 0;
-      prod *= p;
-      recs[k * rec + d] = (float)m.mean[(size_t)gi * D + d];
-      recs[k * rec + dimp + d] = (float)(-0.5 * p * kLog2e);
-    }
-    double cst = (prod > 0) ? std::log(std::sqrt(prod)) : prod;
-    double c = cst + m.logw(k);
-    if (std::isnan(c) || c == INFINITY)
-      raise(AASR_ERR_INVALID, "Gaussian %ld has a non-finite constant (precision product overflow)", (long)gi);
-    recs[k * rec + 2 * dimp] = std::isfinite(c) ? (float)(c * kLog2e) : kNullConst;
-  }
-  g->centred_recs.upload(recs.data(), recs.size());
-  g->centred_state_off.upload(m.mix_off.data(), m.mix_off.size());
-  // state-range cut table: row R-1 = R+1 boundaries with near-equal row counts
-  std::vector<int32_t> table((size_t)CENTRED_MAX_SPLITS * (CENTRED_MAX_SPLITS + 1), 0);
-  g->centred_max_splits = (int)std::min<int64_t>(CENTRED_MAX_SPLITS, m.S);
-  for (int R = 1; R <= g->centred_max_splits; R++) {
-    int32_t *row = &table[(size_t)(R - 1) * (CENTRED_MAX_SPLITS + 1)];
-    int64_t s = 0;
-    row[0] = 0;
-    for (int i = 1; i < R; i++) {
-      int64_t want = (int64_t)((double)rows * i / R);
-      while (s < m.S && m.mix_off[s] < want) s++;
-      if (s <= row[i - 1]) s = row[i - 1] + 1;
-      if (s > m.S) s = m.S;
-      row[i] = (int32_t)s;
-    }
-    row[R] = (int32_t)m.S;
-  }
-  g->centred_splits.upload(table.data(), table.size());
+  std::vector<int32_t> comps(m.mix_idx.size());
+  for (size_t k = 0; k < comps.size(); k++) comps[k] = (int32_t)k;
+  build_centred_tables(m, dimp, comps, m.mix_off, g->centred_recs, g->centred_state_off, g->centred_splits,
+                       &g->centred_max_splits);
   g->centred_ok = true;
 }
 

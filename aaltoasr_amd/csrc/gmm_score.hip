@@ -1464,15 +1464,23 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
   }
 }
 
+// operand set of the centred kernel: the whole model, or the outlier components only
+struct CentredOps {
+  const float *recs;
+  const int32_t *state_off, *splits;
+  int max_splits;
+  int64_t out_pitch;
+};
+
 template <int DIMP>
-static void launch_centred_t(const aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
-                             hipStream_t stream) {
+static void launch_centred_t(const aasr_gmm *g, const CentredOps &ops, const float *d_frames, int64_t F,
+                             float *d_out, hipStream_t stream) {
   const int64_t blocks = (F + 511) / 512;
   // state-range cuts so that the grid fills the chip evenly (4 workgroups per CU)
   const double slots = 4.0 * (g->num_cus > 0 ? g->num_cus : 256);
   int R = 1;
   double best = 0;
-  for (int r = 1; r <= g->centred_max_splits; r++) {
+  for (int r = 1; r <= ops.max_splits; r++) {
     double xw = (double)blocks * r / slots;
     double eff = xw / std::ceil(xw);
     if (xw < 1.0) eff = xw;  // under-filled chip: more cuts = more parallelism
@@ -1481,24 +1489,69 @@ static void launch_centred_t(const aasr_gmm *g, const float *d_frames, int64_t F
       R = r;
     }
   }
-  const int32_t *split = g->centred_splits.p + (size_t)(R - 1) * (CENTRED_MAX_SPLITS + 1);
+  const int32_t *split = ops.splits + (size_t)(R - 1) * (CENTRED_MAX_SPLITS + 1);
   hipLaunchKernelGGL(k_gmm_diag_score_centred<DIMP>, dim3((unsigned)blocks, (unsigned)R), dim3(256), 0,
-                     stream, d_frames, F, g->dim, g->centred_recs.p, g->centred_state_off.p, split,
-                     d_out, g->S);
+                     stream, d_frames, F, g->dim, ops.recs, ops.state_off, split, d_out, ops.out_pitch);
   AASR_HIP(hipGetLastError());
 }
 
-static bool launch_centred(const aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
-                           hipStream_t stream) {
-  switch (g->centred_dimp) {
-#define AASR_CASE(N)                                          \
-  case N:                                                     \
-    launch_centred_t<N>(g, d_frames, F, d_out, stream);       \
+static bool launch_centred_ops(const aasr_gmm *g, const CentredOps &ops, int dimp, const float *d_frames,
+                               int64_t F, float *d_out, hipStream_t stream) {
+  switch (dimp) {
+#define AASR_CASE(N)                                             \
+  case N:                                                        \
+    launch_centred_t<N>(g, ops, d_frames, F, d_out, stream);     \
     return true;
     AASR_CASE(8) AASR_CASE(16) AASR_CASE(24) AASR_CASE(32) AASR_CASE(40) AASR_CASE(48) AASR_CASE(64)
 #undef AASR_CASE
     default:
       return false;
+  }
+}
+
+static bool launch_centred(const aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
+                           hipStream_t stream) {
+  const CentredOps ops{g->centred_recs.p, g->centred_state_off.p, g->centred_splits.p, g->centred_max_splits,
+                       g->S};
+  return launch_centred_ops(g, ops, g->centred_dimp, d_frames, F, d_out, stream);
+}
+
+// out[f][map[j]] = log(exp(out[f][map[j]]) + exp(part[f][j])): the matrix path's sum over a
+// state's well-conditioned components plus the centred sum over its outliers.  Both inputs
+// carry the 1e-50 floor, which the result keeps.
+__global__ void k_outlier_merge(float *__restrict__ out, int64_t S, const float *__restrict__ part,
+                                int64_t Sb, const int32_t *__restrict__ map, int64_t F) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F * Sb) return;
+  const int64_t f = i / Sb;
+  const int j = (int)(i - f * Sb);
+  float *o = out + f * S + map[j];
+  const float a = *o, b = part[i];
+  const float hi = fmaxf(a, b), lo = fminf(a, b);
+  // both parts carry the floor log(1e-50); a part AT the floor holds nothing
+  float r = hi;
+  if (lo > LOG_TINY_F) r = hi + log1pf(expf(lo - hi));
+  *o = fmaxf(r, LOG_TINY_F);
+}
+
+// Outlier routing (gmm.h): the outlier components of the states that have any, in the centred
+// form, merged into the scores the matrix path has already written.
+static void score_outliers(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, hipStream_t stream) {
+  const int64_t Sb = g->hyb_states;
+  if (Sb <= 0) return;
+  const CentredOps ops{g->hyb_recs.p, g->hyb_state_off.p, g->hyb_splits.p, g->hyb_max_splits, Sb};
+  // passes of at most ~1 GB of partial scores
+  int64_t pass = std::max<int64_t>(512, ((int64_t)(1.0e9 / (double)(Sb * 4))) / 512 * 512);
+  if (pass > F) pass = F;
+  g->hyb_scratch.ensure((size_t)pass * (size_t)Sb);
+  for (int64_t f0 = 0; f0 < F; f0 += pass) {
+    const int64_t n = std::min(pass, F - f0);
+    if (!launch_centred_ops(g, ops, g->centred_dimp, d_frames + f0 * g->dim, n, g->hyb_scratch.p, stream))
+      raise(AASR_ERR_UNSUPPORTED, "no centred kernel instance for dimension %d", g->dim);
+    const int64_t total = n * Sb;
+    hipLaunchKernelGGL(k_outlier_merge, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       d_out + f0 * g->S, g->S, g->hyb_scratch.p, Sb, g->hyb_map.p, n);
+    AASR_HIP(hipGetLastError());
   }
 }
 
@@ -1632,17 +1685,16 @@ void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
                                !(g->layout_mask & 3) ) && g->centred_ok)
     if (launch_centred(g, d_frames, F, d_out, stream)) return;
   // layout choice: grouped tracks > independent tracks > general (LDS-staged)
-  if (g->layout_mask & 1)
-    if (g->paired.ok) {
-      if (g->use_bf16x3 && launch_bf16(g, g->paired, d_frames, F, d_out, stream)) return;
-      if (launch_tracks(g, g->paired, d_frames, F, d_out, stream)) return;
-    }
-  if (g->layout_mask & 2)
-    if (g->tracks.ok) {
-      if (g->use_bf16x3 && launch_bf16(g, g->tracks, d_frames, F, d_out, stream)) return;
-      if (launch_tracks(g, g->tracks, d_frames, F, d_out, stream)) return;
-    }
-  launch<0>(g, g->mix, d_frames, F, d_out, g->S, stream);
+  bool done = false;
+  if (!done && (g->layout_mask & 1) && g->paired.ok)
+    done = (g->use_bf16x3 && launch_bf16(g, g->paired, d_frames, F, d_out, stream)) ||
+           launch_tracks(g, g->paired, d_frames, F, d_out, stream);
+  if (!done && (g->layout_mask & 2) && g->tracks.ok)
+    done = (g->use_bf16x3 && launch_bf16(g, g->tracks, d_frames, F, d_out, stream)) ||
+           launch_tracks(g, g->tracks, d_frames, F, d_out, stream);
+  if (!done) launch<0>(g, g->mix, d_frames, F, d_out, g->S, stream);
+  // the Gaussians the matrix layouts left out (null rows): centred form, merged per state
+  if (g->hyb_enabled) score_outliers(g, d_frames, F, d_out, stream);
 }
 
 void gmm_gauss_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,

@@ -210,3 +210,46 @@ def test_model_cache_round_trip(capi, oracle, tmp_path):
         capi.Gmm.from_cache(str(tmp_path / "bad.aasr"))
     with pytest.raises(capi.AasrError, match="not a model cache"):
         capi.Gmm.from_cache(base + ".gk")
+
+
+def test_outlier_routing_keeps_the_model_on_the_matrix_path(capi, oracle):
+    """A few Gaussians with sigma ~ 0.03 (kappa >> 600) in an otherwise well-conditioned model: they
+    are taken out of the matrix layouts and scored in the centred form, merged per state; the model
+    as a whole stays on the track kernels (both precisions), ragged / empty states included."""
+    import ctypes as C
+    rng = np.random.default_rng(31)
+    mean, var, off, idx, w = synth.make_model(D=39, G=512, S=48, comps=8, seed=13)
+    bad = rng.choice(512, 24, replace=False)
+    var[bad] *= 2e-3
+    # a state made of outliers only, one with a single outlier, the rest mixed by the draw
+    idx[off[5]:off[6]] = bad[:off[6] - off[5]]
+    idx[off[9]] = bad[3]
+    frames = synth.make_frames(300, seed=8)
+    # some frames close to the outliers so that their terms dominate
+    frames[:24] = (mean[bad] + np.sqrt(var[bad]) * rng.standard_normal((24, 39))).astype(np.float32)
+    ref = oracle.DiagModel(mean, var, off, idx, w).score(frames.astype(np.float64))
+    g = capi.Gmm.from_arrays(mean, var, off, idx, w)
+    L = capi.lib()
+    L.aasr_debug_kappa.restype = C.c_double
+    L.aasr_debug_kappa.argtypes = [C.c_void_p]
+    assert L.aasr_debug_kappa(g._h) > 600
+    assert g.active_layout() in (1, 2)                 # not the centred kernel
+    for prec in (3, 0):
+        g.set_precision(prec)
+        for mask in (7, 2, 0):
+            g.set_layouts(mask)
+            got = g.score(frames)
+            err = np.abs(got - ref)
+            assert err.max() <= 1e-4, "prec %d layout %d: max |dll| %.3g at %s" % (
+                prec, mask, err.max(), np.unravel_index(err.argmax(), err.shape))
+    g.set_layouts(4)                                   # the whole model in the centred form agrees too
+    assert np.abs(g.score(frames) - ref).max() <= 2e-4
+    g.close()
+    # a majority of outliers: no routing, the centred kernel takes the model
+    var2 = var.copy()
+    var2[rng.choice(512, 300, replace=False)] *= 2e-3
+    g2 = capi.Gmm.from_arrays(mean, var2, off, idx, w)
+    assert g2.active_layout() == 4
+    ref2 = oracle.DiagModel(mean, var2, off, idx, w).score(frames.astype(np.float64))
+    assert np.abs(g2.score(frames) - ref2).max() <= 2e-4
+    g2.close()
