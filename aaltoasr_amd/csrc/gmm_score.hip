@@ -1413,7 +1413,7 @@ template <int DIMP>
 __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
     const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ recs,
     const int32_t *__restrict__ state_off, const int32_t *__restrict__ split_state,
-    float *__restrict__ out, int64_t S) {
+    float *__restrict__ out, int64_t frame_stride, int64_t state_stride) {
   constexpr int REC = 2 * DIMP + 4;  // [mu x DIMP][p' x DIMP][C, pad, pad, pad]
   // each lane owns TWO frames (f, f + 256): one scalar fetch of a Gaussian's
   // parameters feeds 128 frame x Gaussian pairs per wave
@@ -1459,8 +1459,8 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
     lla = fmaxf(lla, LOG_TINY_F);
     llb = fmaxf(llb, LOG_TINY_F);
     if (r1 <= r0) lla = llb = LOG_TINY_F;
-    if (fa < F) out[fa * S + s] = lla;
-    if (fb < F) out[fb * S + s] = llb;
+    if (fa < F) out[fa * frame_stride + s * state_stride] = lla;
+    if (fb < F) out[fb * frame_stride + s * state_stride] = llb;
   }
 }
 
@@ -1469,7 +1469,7 @@ struct CentredOps {
   const float *recs;
   const int32_t *state_off, *splits;
   int max_splits;
-  int64_t out_pitch;
+  int64_t frame_stride, state_stride;  // out[f * frame_stride + s * state_stride]
 };
 
 template <int DIMP>
@@ -1491,7 +1491,8 @@ static void launch_centred_t(const aasr_gmm *g, const CentredOps &ops, const flo
   }
   const int32_t *split = ops.splits + (size_t)(R - 1) * (CENTRED_MAX_SPLITS + 1);
   hipLaunchKernelGGL(k_gmm_diag_score_centred<DIMP>, dim3((unsigned)blocks, (unsigned)R), dim3(256), 0,
-                     stream, d_frames, F, g->dim, ops.recs, ops.state_off, split, d_out, ops.out_pitch);
+                     stream, d_frames, F, g->dim, ops.recs, ops.state_off, split, d_out, ops.frame_stride,
+                     ops.state_stride);
   AASR_HIP(hipGetLastError());
 }
 
@@ -1512,26 +1513,41 @@ static bool launch_centred_ops(const aasr_gmm *g, const CentredOps &ops, int dim
 static bool launch_centred(const aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                            hipStream_t stream) {
   const CentredOps ops{g->centred_recs.p, g->centred_state_off.p, g->centred_splits.p, g->centred_max_splits,
-                       g->S};
+                       g->S, 1};
   return launch_centred_ops(g, ops, g->centred_dimp, d_frames, F, d_out, stream);
 }
 
-// out[f][map[j]] = log(exp(out[f][map[j]]) + exp(part[f][j])): the matrix path's sum over a
-// state's well-conditioned components plus the centred sum over its outliers.  Both inputs
-// carry the 1e-50 floor, which the result keeps.
-__global__ void k_outlier_merge(float *__restrict__ out, int64_t S, const float *__restrict__ part,
-                                int64_t Sb, const int32_t *__restrict__ map, int64_t F) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= F * Sb) return;
-  const int64_t f = i / Sb;
-  const int j = (int)(i - f * Sb);
-  float *o = out + f * S + map[j];
-  const float a = *o, b = part[i];
-  const float hi = fmaxf(a, b), lo = fminf(a, b);
-  // both parts carry the floor log(1e-50); a part AT the floor holds nothing
-  float r = hi;
-  if (lo > LOG_TINY_F) r = hi + log1pf(expf(lo - hi));
-  *o = fmaxf(r, LOG_TINY_F);
+// out[f][map[j]] = log(exp(out[f][map[j]]) + exp(part[j][f])): the matrix path's sum over a
+// state's well-conditioned components plus the centred sum over its outliers.  `part` is
+// state-major ([Sb][pitch]: the centred kernel's lane = frame stores are coalesced that way); a
+// workgroup moves a 64 x 64 tile through LDS so that the update of `out` walks along a frame row.
+// Both inputs carry the 1e-50 floor, which the result keeps.
+__global__ __launch_bounds__(256) void k_outlier_merge(float *__restrict__ out, int64_t S,
+                                                       const float *__restrict__ part, int64_t pitch,
+                                                       int64_t Sb, const int32_t *__restrict__ map,
+                                                       int64_t F) {
+  __shared__ float tile[64][65];
+  const int64_t f0 = (int64_t)blockIdx.x * 64;
+  const int64_t j0 = (int64_t)blockIdx.y * 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int jj = w; jj < 64; jj += 4) {
+    const int64_t j = j0 + jj, f = f0 + lane;
+    tile[jj][lane] = (j < Sb && f < F) ? part[j * pitch + f] : LOG_TINY_F;
+  }
+  __syncthreads();
+  const int64_t j = j0 + lane;
+  if (j >= Sb) return;
+  const int col = map[j];
+  for (int ff = w; ff < 64; ff += 4) {
+    const int64_t f = f0 + ff;
+    if (f >= F) break;
+    float *o = out + f * S + col;
+    const float a = *o, b = tile[lane][ff];
+    const float hi = fmaxf(a, b), lo = fminf(a, b);
+    float r = hi;
+    if (lo > LOG_TINY_F) r = hi + log1pf(expf(lo - hi));  // a part AT the floor holds nothing
+    *o = fmaxf(r, LOG_TINY_F);
+  }
 }
 
 // Outlier routing (gmm.h): the outlier components of the states that have any, in the centred
@@ -1539,18 +1555,17 @@ __global__ void k_outlier_merge(float *__restrict__ out, int64_t S, const float 
 static void score_outliers(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, hipStream_t stream) {
   const int64_t Sb = g->hyb_states;
   if (Sb <= 0) return;
-  const CentredOps ops{g->hyb_recs.p, g->hyb_state_off.p, g->hyb_splits.p, g->hyb_max_splits, Sb};
   // passes of at most ~1 GB of partial scores
   int64_t pass = std::max<int64_t>(512, ((int64_t)(1.0e9 / (double)(Sb * 4))) / 512 * 512);
-  if (pass > F) pass = F;
+  if (pass > F) pass = (F + 63) / 64 * 64;
   g->hyb_scratch.ensure((size_t)pass * (size_t)Sb);
+  const CentredOps ops{g->hyb_recs.p, g->hyb_state_off.p, g->hyb_splits.p, g->hyb_max_splits, 1, pass};
   for (int64_t f0 = 0; f0 < F; f0 += pass) {
     const int64_t n = std::min(pass, F - f0);
     if (!launch_centred_ops(g, ops, g->centred_dimp, d_frames + f0 * g->dim, n, g->hyb_scratch.p, stream))
       raise(AASR_ERR_UNSUPPORTED, "no centred kernel instance for dimension %d", g->dim);
-    const int64_t total = n * Sb;
-    hipLaunchKernelGGL(k_outlier_merge, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                       d_out + f0 * g->S, g->S, g->hyb_scratch.p, Sb, g->hyb_map.p, n);
+    hipLaunchKernelGGL(k_outlier_merge, dim3((unsigned)((n + 63) / 64), (unsigned)((Sb + 63) / 64)), dim3(256), 0,
+                       stream, d_out + f0 * g->S, g->S, g->hyb_scratch.p, pass, Sb, g->hyb_map.p, n);
     AASR_HIP(hipGetLastError());
   }
 }
