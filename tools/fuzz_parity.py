@@ -27,6 +27,10 @@ for it in range(N):
     G = int(K if not tied else max(4, K // 2))
     mean = rng.standard_normal((G, D)) * rng.uniform(0.3, 2.0)
     var = np.exp(rng.uniform(np.log(0.2), np.log(5.0), (G, D)))
+    if rng.integers(0, 4) == 0 and G >= 8:
+        # a few ill-conditioned Gaussians (kappa >> 600): outlier routing
+        tight = rng.choice(G, max(1, G // 16), replace=False)
+        var[tight] *= 10.0 ** rng.uniform(-3.5, -2.0)
     off = np.zeros(S + 1, np.int32); off[1:] = np.cumsum(n)
     idx = (rng.integers(0, G, K) if tied else np.arange(K)).astype(np.int32)
     w = rng.uniform(0.01, 1.0, K)
