@@ -146,6 +146,7 @@ def _declare(L: C.CDLL) -> None:
                                      C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(i64), C.POINTER(i64)]
     L.aasr_free.argtypes = [vp]
     L.aasr_free.restype = None
+    L.aasr_feat_write_config.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(i64)]
     L.aasr_recipe_read.argtypes = [cp, i32, i32, C.POINTER(C.c_void_p), C.POINTER(i64)]
     L.aasr_audio_read.argtypes = [vp, cp, C.POINTER(C.POINTER(C.c_int16)), C.POINTER(i64),
                                   C.POINTER(i32)]
@@ -360,6 +361,16 @@ class Feat:
     @classmethod
     def from_file(cls, path: str) -> "Feat":
         return cls(open(path).read())
+
+    def write_config(self) -> str:
+        """FeatureGenerator::write_configuration: the graph as .cfg text."""
+        out = C.c_void_p()
+        n = C.c_int64()
+        check(lib().aasr_feat_write_config(self._h, C.byref(out), C.byref(n)))
+        try:
+            return C.string_at(out, n.value).decode()
+        finally:
+            lib().aasr_free(out)
 
     def close(self) -> None:
         if self._h:

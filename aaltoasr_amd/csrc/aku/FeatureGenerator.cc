@@ -26,6 +26,15 @@ void FeatureGenerator::load_configuration(FILE *file) {
   load_configuration_text(text);
 }
 
+void FeatureGenerator::write_configuration(FILE *file) {
+  if (!m_feat) throw std::string("no feature modules defined");
+  char *text = nullptr;
+  int64_t len = 0;
+  check(aasr_feat_write_config(m_feat, &text, &len));
+  fwrite(text, 1, (size_t)len, file);
+  aasr_free(text);
+}
+
 void FeatureGenerator::load_configuration_text(const std::string &text) {
   if (m_feat) {
     fprintf(stdout, "FeatureGenerator: loading a new feature configuration\n");

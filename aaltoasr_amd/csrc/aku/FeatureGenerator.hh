@@ -59,6 +59,8 @@ public:
   void load_configuration(FILE *file);
   void load_configuration_text(const std::string &text);
   void close_configuration();
+  /** aku/FeatureGenerator.cc:222-243 */
+  void write_configuration(FILE *file);
 
   /** aku/FeatureGenerator.cc:30-52: opens a PCM16 WAV (or raw) file */
   void open(const std::string &filename);

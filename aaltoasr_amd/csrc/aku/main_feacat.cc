@@ -8,7 +8,7 @@
 // FILE "-" reads standard input like the reference's io::Stream.  Text output is
 // "%8.4f " per value (aku/feacat.cc:27-31); raw output is float32 with an
 // optional int32 dimension header (-H), the format PreModule reads back.
-// Not built: -w/--write-config, -G/--gaussian-std.
+// Not built: -G/--gaussian-std (needs the reference's ziggurat generator state).
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -41,7 +41,6 @@ int main(int argc, char *argv[]) {
     ('G', "gaussian-std=FLOAT", "arg", "", "Gaussian noise std added to features");
   config.default_parse(argc, argv);
   if (config.arguments.size() != 1) config.print_help(stderr, 1);
-  if (config["write-config"].specified) die("--write-config is not built in this engine yet");
   if (config["gaussian-std"].specified) die("--gaussian-std is not built in this engine yet");
   const bool raw_output = config["raw-output"].specified, header = config["header"].specified;
   const std::string cfg = config["config"].get_str();
@@ -68,6 +67,13 @@ int main(int argc, char *argv[]) {
       fclose(sf);
       speaker_conf.set_speaker(speaker_id);
       if (utt_set) speaker_conf.set_utterance(utterance_id);
+    }
+    if (config["write-config"].specified) {
+      // after the speaker settings, like the reference (aku/feacat.cc:85-87)
+      FILE *wf = fopen(config["write-config"].get_c_str(), "w");
+      if (!wf) throw std::string("could not open ") + config["write-config"].get_str();
+      gen.write_configuration(wf);
+      fclose(wf);
     }
     if (raw_output && header) {
       int dim = gen.dim();

@@ -84,6 +84,7 @@ struct FeatModule {
   // lin_transform
   int src_dim = 0;
   std::vector<float> matrix, bias;
+  std::vector<float> orig_matrix, orig_bias;  // as configured (what write_configuration saves)
   bool matrix_defined = false, bias_defined = false;
   DevBuf<float> d_matrix, d_bias;
   // merge
@@ -105,7 +106,7 @@ struct FeatModule {
   DevBuf<float> sp_coef;
   int sp_stride = 0;
   // quanteq (QuantEqModule, :2078-2141)
-  std::vector<float> q_alpha, q_gamma, q_max;
+  std::vector<float> q_alpha, q_gamma, q_max, quant_train;
   DevBuf<float> d_q_alpha, d_q_gamma, d_q_max;
   // look-around this module itself adds around its sources
   int own_left = 0, own_right = 0;
@@ -154,5 +155,7 @@ void feat_set_parameters(aasr_feat *h, const std::string &module, const std::str
 void feat_set_parameters(aasr_feat *h, const std::string &module, const ModuleConfig &c);
 // FeatureModule::get_parameters of `module` into c (existing keys are replaced)
 void feat_get_parameters(const aasr_feat *h, const std::string &module, ModuleConfig &c);
+// FeatureGenerator::write_configuration (aku/FeatureGenerator.cc:222-243)
+std::string feat_write_configuration(const aasr_feat *h);
 
 }  // namespace aasr

@@ -116,6 +116,18 @@ aasr_status aasr_feat_run_features_f64(aasr_feat *h, const float *features, int6
   });
 }
 
+aasr_status aasr_feat_write_config(const aasr_feat *h, char **text, int64_t *len) {
+  return guarded([&] {
+    if (!h || !text || !len) raise(AASR_ERR_INVALID, "aasr_feat_write_config: null argument");
+    const std::string t = feat_write_configuration(h);
+    char *out = (char *)malloc(t.size() + 1);
+    if (!out) raise(AASR_ERR_INVALID, "aasr_feat_write_config: out of memory");
+    memcpy(out, t.c_str(), t.size() + 1);
+    *text = out;
+    *len = (int64_t)t.size();
+  });
+}
+
 int aasr_feat_input_is_features(const aasr_feat *h) { return h && h->mods[0].type == MOD_PRE ? 1 : 0; }
 int aasr_feat_pre_legacy(const aasr_feat *h) { return h && h->mods[0].type == MOD_PRE ? h->mods[0].legacy_file : 0; }
 int aasr_feat_input_dim(const aasr_feat *h) { return h ? h->mods[0].dim : -1; }

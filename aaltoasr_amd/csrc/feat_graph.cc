@@ -559,6 +559,8 @@ static void configure(aasr_feat *h, FeatModule &m, const ModuleConfig &c) {
       if (m.dim < 1) raise(AASR_ERR_INVALID, "LinTransformModule: Dimension must be > 0");
       m.matrix_defined = !m.matrix.empty();
       m.bias_defined = !m.bias.empty();
+      m.orig_matrix = m.matrix;
+      m.orig_bias = m.bias;
       if (m.matrix_defined && (int)m.matrix.size() != m.dim * m.src_dim)
         raise(AASR_ERR_INVALID, "LinTransformModule: Invalid matrix dimension");
       if (m.bias_defined && (int)m.bias.size() != m.dim)
@@ -662,6 +664,8 @@ static void configure(aasr_feat *h, FeatModule &m, const ModuleConfig &c) {
       // QuantEqModule::set_module_config (aku/FeatureModules.cc:2078-2083); the
       // channel parameters only arrive through set_parameters
       m.dim = src(0).dim;
+      m.quant_train.clear();
+      c.get("quant_train", m.quant_train);
       break;
   }
   if (m.dim <= 0) raise(AASR_ERR_INVALID, "module %s has no output dimension", m.name.c_str());
@@ -782,6 +786,99 @@ void feat_set_parameters(aasr_feat *h, const std::string &module, const std::str
   size_t pos = 0;
   c.read(block, &pos);
   feat_set_parameters(h, module, c);
+}
+
+// FeatureGenerator::write_configuration (aku/FeatureGenerator.cc:222-243) over each module's
+// get_config / get_module_config (aku/FeatureModules.cc:173-179 and per type): "module", the
+// option block in the order the reference sets the keys ("%d" / "%g" values), "sources" last.
+std::string feat_write_configuration(const aasr_feat *h) {
+  std::string out;
+  auto I = [](int v) { return std::to_string(v); };
+  for (const FeatModule &m : h->mods) {
+    ModuleConfig c;
+    c.insert("name", m.name);
+    c.insert("type", m.type_str);
+    switch (m.type) {
+      case MOD_AUDIOFILE:  // :311-325
+        c.set("pre_emph_coef", m.emph);
+        c.insert("sample_rate", I(m.sample_rate));
+        c.set("frame_rate", m.frame_rate);
+        c.insert("window_width", I(m.width));
+        c.insert("copy_borders", I(m.copy_borders));
+        if (m.endian == 1) c.insert("endian", "little");
+        else if (m.endian == 2) c.insert("endian", "big");
+        if (m.raw_audio) c.insert("raw", "1");
+        break;
+      case MOD_PRE:  // :661-669
+        c.insert("sample_rate", I(m.sample_rate));
+        c.set("frame_rate", m.frame_rate);
+        c.insert("dim", I(m.dim));
+        if (m.legacy_file) c.insert("legacy_file", I(m.legacy_file));
+        break;
+      case MOD_FFT:  // :468-473
+        c.insert("magnitude", I(m.magnitude));
+        if (m.take_log) c.insert("log", I(m.take_log));
+        break;
+      case MOD_MEL:  // :769-773
+        if (m.root) c.insert("root", I(m.root));
+        break;
+      case MOD_DCT:  // :934-939
+        c.insert("dim", I(m.dim));
+        c.insert("zeroth", I(m.zeroth));
+        break;
+      case MOD_DELTA:  // :992-996
+        c.insert("width", I(m.delta_width));
+        c.set("normalization", m.delta_norm);
+        break;
+      case MOD_NORMALIZATION:  // :1050-1054
+        c.set("mean", m.mean);
+        c.set("scale", m.scale);
+        break;
+      case MOD_LIN_TRANSFORM:  // :1155-1164: the transformation as configured
+        c.insert("dim", I(m.dim));
+        if (!m.orig_matrix.empty()) c.set("matrix", m.orig_matrix);
+        if (!m.orig_bias.empty()) c.set("bias", m.orig_bias);
+        break;
+      case MOD_MEAN_SUBTRACTOR:  // :1378-1382
+        c.insert("left", I(m.cms_left));
+        c.insert("right", I(m.cms_right));
+        break;
+      case MOD_CONCAT:  // :1467-1471
+        c.insert("left", I(m.own_left));
+        c.insert("right", I(m.own_right));
+        break;
+      case MOD_VTLN:  // :1513-1527
+        if (m.use_pwlin) {
+          c.insert("pwlin_vtln", I(m.use_pwlin));
+          c.set("pwlin_turnpoint", m.pwlin_turn);
+        }
+        if (m.use_slapt) c.insert("slapt", "1");
+        if (m.lanczos) c.insert("lanczos_window", "1");
+        c.insert("sinc_interpolation_rad", I(m.sinc_rad));
+        if (m.all_pass > 0) c.insert("all-pass", I(m.all_pass));
+        break;
+      case MOD_SR_NORM:  // :1947-1952
+        c.insert("in_frames", I(m.in_frames));
+        c.insert("out_frames", I(m.out_frames));
+        c.insert("lanczos_order", I(m.lanczos_order));
+        break;
+      case MOD_QUANTEQ:  // :2071-2074
+        c.set("quant_train", m.quant_train);
+        break;
+      default:  // power, mel_power, merge: no options
+        break;
+    }
+    if (!m.sources.empty()) {
+      std::string v;
+      for (size_t i = 0; i < m.sources.size(); i++) v += (i ? " " : "") + h->mods[(size_t)m.sources[i]].name;
+      c.insert("sources", v);
+    }
+    // ModuleConfig::write with indent 0 (aku/ModuleConfig.cc:204-222)
+    out += "module\n{\n";
+    for (size_t i = 0; i < c.names.size(); i++) out += "  " + c.names[i] + " " + c.values[i] + "\n";
+    out += "}\n\n";
+  }
+  return out;
 }
 
 void feat_get_parameters(const aasr_feat *h, const std::string &module, ModuleConfig &c) {

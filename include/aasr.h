@@ -94,6 +94,10 @@ aasr_status aasr_feat_run_features(aasr_feat *h, const float *features, int64_t 
 aasr_status aasr_feat_run_features_f64(aasr_feat *h, const float *features, int64_t n_values,
                                        int32_t first_frame, int32_t n_frames,
                                        const char *module_name, double *out);
+/* FeatureGenerator::write_configuration (aku/FeatureGenerator.cc:222-243): the graph as .cfg text in
+ * the reference's own layout (every option a module saves, "%g" / "%d" values, "sources" last), so
+ * that re-reading it rebuilds the same graph.  *text is malloc'ed; free it with aasr_free. */
+aasr_status aasr_feat_write_config(const aasr_feat *h, char **text, int64_t *len);
 int aasr_feat_input_is_features(const aasr_feat *h);   /* 1 when the base module is `pre` */
 int aasr_feat_pre_legacy(const aasr_feat *h);          /* its legacy_file option */
 int aasr_feat_input_dim(const aasr_feat *h);           /* dimension of the base module */

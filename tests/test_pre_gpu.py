@@ -75,7 +75,7 @@ def test_feacat_reverse_order_and_errors(golden_dir, tmp_path):
     open(bad, "wb").write(np.int32(12).tobytes() + np.zeros(24, np.float32).tobytes())
     r = subprocess.run([FEACAT, "-c", os.path.join(golden_dir, "pre.feaconf"), bad], capture_output=True, text=True)
     assert r.returncode != 0 and "The file has invalid dimension" in r.stderr
-    r = subprocess.run([FEACAT, "-c", cfg, "-w", "x.cfg", wav], capture_output=True, text=True)
+    r = subprocess.run([FEACAT, "-c", cfg, "-G", "0.1", wav], capture_output=True, text=True)
     assert r.returncode != 0 and "not built" in r.stderr
 
 
@@ -159,3 +159,112 @@ def test_recipe_on_feature_files(capi, oracle, tmp_path):
         got = oracle.lna_decode(open(tmp_path / ("u%d.lna" % i), "rb").read())
         ok = want > -80
         assert got.shape == want.shape and np.abs(got - want)[ok].max() <= 1e-4
+
+
+EXPECTED_MFCC_P_DD_CFG = """module
+{
+  name audiofile
+  type audiofile
+  pre_emph_coef 0.97
+  sample_rate 16000
+  frame_rate 125
+  window_width 256
+  copy_borders 1
+}
+
+module
+{
+  name fft
+  type fft
+  magnitude 1
+  sources audiofile
+}
+
+module
+{
+  name mel
+  type mel
+  sources fft
+}
+
+module
+{
+  name power
+  type power
+  sources fft
+}
+
+module
+{
+  name mfcc
+  type dct
+  dim 12
+  zeroth 0
+  sources mel
+}
+
+module
+{
+  name mfcc_power
+  type merge
+  sources mfcc power
+}
+
+module
+{
+  name delta1
+  type delta
+  width 2
+  normalization 10
+  sources mfcc_power
+}
+
+module
+{
+  name delta2
+  type delta
+  width 2
+  normalization 10
+  sources delta1
+}
+
+module
+{
+  name final
+  type merge
+  sources mfcc_power delta1 delta2
+}
+
+"""
+
+
+def test_write_config_and_the_two_commands_of_mfcc_p_dd_script(capi, golden_dir, tmp_path):
+    """aku/tests/mfcc_p_dd.script:
+         cat short.wav | feacat --start-frame -10 --end-frame 80 --write-config X -c mfcc_p_dd.feaconf -
+         cat short.wav | feacat --start-frame -10 --end-frame 80 -c X -
+    The configuration written by the first command (FeatureGenerator::write_configuration:
+    every option a module saves, defaults made explicit, "sources" last) is what the reference's
+    get_module_config functions produce for this graph, and the concatenated output of the two
+    commands is the reference's mfcc_p_dd.ref."""
+    wav = open(os.path.join(golden_dir, "short.wav"), "rb").read()
+    tmp = str(tmp_path / "mfcc_p_dd.feaconf.tmp")
+    r1 = subprocess.run([FEACAT, "--start-frame", "-10", "--end-frame", "80", "--write-config", tmp,
+                         "-c", os.path.join(golden_dir, "mfcc_p_dd.feaconf"), "-"],
+                        input=wav, capture_output=True, timeout=300)
+    assert r1.returncode == 0, r1.stderr
+    assert open(tmp).read() == EXPECTED_MFCC_P_DD_CFG
+    r2 = subprocess.run([FEACAT, "--start-frame", "-10", "--end-frame", "80", "-c", tmp, "-"],
+                        input=wav, capture_output=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr
+    assert r1.stdout == r2.stdout                      # the written graph is the same graph
+    got = _text((r1.stdout + r2.stdout).decode())
+    ref = np.loadtxt(os.path.join(golden_dir, "mfcc_p_dd.ref"))
+    assert got.shape == ref.shape == (182, 39)
+    assert np.abs(got - ref).max() <= 0.005 + 1e-4
+    # the C ABI gives the same text; writing is idempotent
+    ft = capi.Feat.from_file(tmp)
+    assert ft.write_config() == EXPECTED_MFCC_P_DD_CFG
+    # normalisation / transform values survive the "%g" round trip of a written configuration
+    cms = capi.Feat.from_file(os.path.join(golden_dir, "mfcc_cms_norm.feaconf"))
+    again = capi.Feat(cms.write_config())
+    assert again.write_config() == cms.write_config()
