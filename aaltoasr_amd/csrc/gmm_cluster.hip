@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_cluster_merge(
   const int tid = threadIdx.x;
   int64_t st[kMergeSPT];
   bool live[kMergeSPT];
-  int wc[kMergeSPT][NNZ];
+  unsigned wcp[kMergeSPT][(NNZ + 1) / 2];  // LDS offsets of the clusters, two 16-bit values per register
   float ww[kMergeSPT][NNZ];
 #pragma unroll
   for (int u = 0; u < kMergeSPT; u++) {
@@ -312,14 +312,32 @@ __global__ __launch_bounds__(kMergeThreads) void k_cluster_merge(
     live[u] = st[u] < S;
     const int64_t sc = live[u] ? st[u] : S - 1;
 #pragma unroll
-    for (int j = 0; j < NNZ; j++) {
-      wc[u][j] = j < nnz ? w_cluster[(int64_t)j * S + sc] : 0;
-      ww[u][j] = j < nnz ? w_weight[(int64_t)j * S + sc] : 0.0f;
+    for (int j = 0; j < NNZ; j += 2) {
+      const unsigned c0 = j < nnz ? (unsigned)w_cluster[(int64_t)j * S + sc] : 0u;
+      const unsigned c1 = j + 1 < nnz && j + 1 < NNZ ? (unsigned)w_cluster[(int64_t)(j + 1) * S + sc] : 0u;
+      wcp[u][j / 2] = c0 | (c1 << 16);
     }
+#pragma unroll
+    for (int j = 0; j < NNZ; j++) ww[u][j] = j < nnz ? w_weight[(int64_t)j * S + sc] : 0.0f;
   }
   const int64_t f_begin = (int64_t)blockIdx.y * frames_per_block;
   const int64_t f_end = min(F, f_begin + frames_per_block);
   const float ref_ln = ref * 0.69314718055994530942f;
+  // Software pipeline: the exact parts of step i+1 are requested before step i is computed (every
+  // thread of the workgroup runs in lock step between the two barriers of a step, so nothing else
+  // hides the global-memory latency; 85.7 -> 77.2 ms per clustered pass).  Carrying the centre
+  // values the same way would need 8 more registers than the 128 a 1024-thread workgroup has
+  // (measured with spills: slower).
+  float onext[kMergeSPT][kMergeFrames];
+  auto request = [&](int64_t fg) {
+    const int nf = (int)min((int64_t)kMergeFrames, f_end - fg);
+#pragma unroll
+    for (int u = 0; u < kMergeSPT; u++)
+#pragma unroll
+      for (int k = 0; k < kMergeFrames; k++)
+        onext[u][k] = (live[u] && k < nf) ? out[(fg + k) * S + st[u]] : 0.0f;
+  };
+  if (f_begin < f_end) request(f_begin);
   for (int64_t fg = f_begin; fg < f_end; fg += kMergeFrames) {
     const int nf = (int)min((int64_t)kMergeFrames, f_end - fg);
     __syncthreads();
@@ -327,17 +345,24 @@ __global__ __launch_bounds__(kMergeThreads) void k_cluster_merge(
       const int k = i / C, c = i - k * C;
       cv[c * cstride + k] = k < nf ? cval[(fg + k) * C + c] : 0.0f;
     }
+    float ocur[kMergeSPT][kMergeFrames];
+#pragma unroll
+    for (int u = 0; u < kMergeSPT; u++)
+#pragma unroll
+      for (int k = 0; k < kMergeFrames; k++) ocur[u][k] = onext[u][k];
     __syncthreads();
+    if (fg + kMergeFrames < f_end) request(fg + kMergeFrames);
 #pragma unroll
     for (int u = 0; u < kMergeSPT; u++) {
       if (!live[u]) continue;
       float lin[kMergeFrames];
 #pragma unroll
       for (int k = 0; k < kMergeFrames; k++)
-        lin[k] = k < nf ? exp2f(fmaf(out[(fg + k) * S + st[u]], 1.4426950408889634f, ref)) : 0.0f;
+        lin[k] = k < nf ? exp2f(fmaf(ocur[u][k], 1.4426950408889634f, ref)) : 0.0f;
 #pragma unroll
       for (int j = 0; j < NNZ; j++) {
-        const f32x4 *p = (const f32x4 *)(cv + wc[u][j] * cstride);
+        const unsigned cidx = (j & 1) ? (wcp[u][j / 2] >> 16) : (wcp[u][j / 2] & 0xffffu);
+        const f32x4 *p = (const f32x4 *)(cv + cidx * cstride);
         const f32x4 a = p[0], b = p[1];
         const float w = ww[u][j];
         lin[0] = fmaf(w, a.x, lin[0]);
