@@ -129,8 +129,10 @@ __device__ __forceinline__ double wave_max_f64(double v) {
 
 // One wave per 64 consecutive frames (= one word of the selection masks);
 // lane l holds clusters l, 64 + l, ...  (KPL per lane).
+// four waves per SIMD (<= 128 VGPRs): a 250 k-frame sub-pass is 3906 single-wave workgroups, which
+// then fit the chip's 4096 wave slots in one round (with three per SIMD: 1.27 rounds)
 template <int KPL>
-__global__ __launch_bounds__(64) void k_cluster_select(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cluster_select(
     const double *__restrict__ ll64, int64_t F, int C, int64_t Cs,
     const int32_t *__restrict__ csize, int min_clusters, int min_gaussians, double ref,
     unsigned long long *__restrict__ maskw, float *__restrict__ cval,
@@ -575,10 +577,25 @@ static void launch_centres(aasr_gmm *g, const float *d_frames, int64_t F, hipStr
   ClusterState &cl = g->cl;
   const int groups = cl.Cs / 8;
   const int64_t bx = (F + kCentreThreads - 1) / kCentreThreads;
-  int ny = (int)std::min<int64_t>(groups, std::max<int64_t>(1, 1536 / bx));
+  const int smem = 2 * cl.dimp * 16 * 8 + cl.dimp * kCentreThreads * (int)sizeof(float);
+  // cut the cluster groups over blockIdx.y so that the grid is a whole number of rounds over the
+  // resident workgroup slots (a workgroup walks all its groups: with one cut, 977 workgroups on
+  // 768 slots ran 1.27 rounds at half occupancy)
+  const double slots = (double)(g->num_cus > 0 ? g->num_cus : 256) * std::max(1, (160 * 1024) / std::max(smem, 1));
+  int ny = 1;
+  double best = 0;
+  for (int y = 1; y <= std::min(groups, 16); y++) {
+    const int gy = (groups + y - 1) / y;
+    const int yy = (groups + gy - 1) / gy;
+    const double x = (double)bx * yy / slots;
+    const double eff = x < 1.0 ? x : x / std::ceil(x);
+    if (eff > best + 0.02) {
+      best = eff;
+      ny = yy;
+    }
+  }
   const int gpy = (groups + ny - 1) / ny;
   ny = (groups + gpy - 1) / gpy;
-  const int smem = 2 * cl.dimp * 16 * 8 + cl.dimp * kCentreThreads * (int)sizeof(float);
   static bool attr_set[64] = {false};
   if (!attr_set[g->device & 63]) {
     AASR_HIP(hipFuncSetAttribute((const void *)k_cluster_centres,
