@@ -253,3 +253,16 @@ def test_outlier_routing_keeps_the_model_on_the_matrix_path(capi, oracle):
     ref2 = oracle.DiagModel(mean, var2, off, idx, w).score(frames.astype(np.float64))
     assert np.abs(g2.score(frames) - ref2).max() <= 2e-4
     g2.close()
+
+
+def test_wide_and_narrow_workgroups_give_identical_bits(capi):
+    """Batches of 8192+ frames take the 8-wave bf16x3 kernel, smaller ones the 4-wave one; a file's
+    scores must not depend on how the recipe driver happened to batch it."""
+    model = synth.make_model(D=39, G=1024, S=77, comps=12, seed=3)
+    g = capi.Gmm.from_arrays(*model)
+    g.set_precision(3)
+    fr = synth.make_frames(9000, seed=12)
+    whole = g.score(fr)                                   # 8-wave workgroups
+    parts = np.vstack([g.score(fr[:4000]), g.score(fr[4000:8100]), g.score(fr[8100:])])   # 4-wave
+    assert np.array_equal(whole.view(np.uint32), parts.view(np.uint32))
+    g.close()
