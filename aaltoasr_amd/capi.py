@@ -146,6 +146,9 @@ def _declare(L: C.CDLL) -> None:
                                      C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(i64), C.POINTER(i64)]
     L.aasr_free.argtypes = [vp]
     L.aasr_free.restype = None
+    L.aasr_gmm_score_pitch_ok.argtypes = [vp]
+    L.aasr_gmm_score_dev_pitched.argtypes = [vp, vp, i64, vp, i64, vp]
+    L.aasr_lna_encode_dev_pitched.argtypes = [vp, i64, i64, i32, C.c_int, C.c_int, vp, vp, vp]
     L.aasr_feat_write_config.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(i64)]
     L.aasr_recipe_read.argtypes = [cp, i32, i32, C.POINTER(C.c_void_p), C.POINTER(i64)]
     L.aasr_audio_read.argtypes = [vp, cp, C.POINTER(C.POINTER(C.c_int16)), C.POINTER(i64),
@@ -322,6 +325,15 @@ class Gmm:
         check(lib().aasr_gmm_score_dev(self._h, _ptr(d_frames), d_frames.shape[0], _ptr(d_out),
                                        _stream_handle(stream)))
 
+    def score_pitch_ok(self) -> bool:
+        """Whether score_dev_pitched accepts a row pitch other than the state count."""
+        return bool(lib().aasr_gmm_score_pitch_ok(self._h))
+
+    def score_dev_pitched(self, d_frames, d_out, pitch: int, stream=None) -> None:
+        """d_out: device buffer of frames x pitch floats (pitch >= states)."""
+        check(lib().aasr_gmm_score_dev_pitched(self._h, _ptr(d_frames), d_frames.shape[0], _ptr(d_out),
+                                               pitch, _stream_handle(stream)))
+
     def gauss_loglik(self, frames: np.ndarray) -> np.ndarray:
         frames = np.ascontiguousarray(frames, np.float32)
         out = np.empty((frames.shape[0], self.num_gaussians), np.float32)
@@ -338,10 +350,16 @@ def lna_encode(state_loglik: np.ndarray, normalize: bool = True, lnabytes: int =
     return lp, by
 
 
-def lna_encode_dev(d_loglik, normalize: bool, lnabytes: int, d_lp=None, d_bytes=None, stream=None):
-    F, S = d_loglik.shape
-    check(lib().aasr_lna_encode_dev(_ptr(d_loglik), F, S, int(normalize), lnabytes, _ptr(d_lp),
-                                    _ptr(d_bytes), _stream_handle(stream)))
+def lna_encode_dev(d_loglik, normalize: bool, lnabytes: int, d_lp=None, d_bytes=None, stream=None,
+                   num_states: Optional[int] = None):
+    """d_loglik: [F x S], or [F x pitch] with num_states = S < pitch (padded rows)."""
+    F, P = d_loglik.shape
+    if num_states is None or num_states == P:
+        check(lib().aasr_lna_encode_dev(_ptr(d_loglik), F, P, int(normalize), lnabytes, _ptr(d_lp),
+                                        _ptr(d_bytes), _stream_handle(stream)))
+    else:
+        check(lib().aasr_lna_encode_dev_pitched(_ptr(d_loglik), P, F, num_states, int(normalize), lnabytes,
+                                                _ptr(d_lp), _ptr(d_bytes), _stream_handle(stream)))
 
 
 def lna_header(num_states: int, lnabytes: int) -> bytes:

@@ -46,7 +46,7 @@ void require_device() {
 }
 
 void lna_encode_launch(const float *d_loglik, int64_t F, int S, int normalize,
-                       int lnabytes, float *d_lp, uint8_t *d_bytes, hipStream_t stream);
+                       int lnabytes, float *d_lp, uint8_t *d_bytes, hipStream_t stream, int64_t in_pitch);
 
 }  // namespace aasr
 
@@ -314,7 +314,33 @@ aasr_status aasr_lna_encode_dev(const float *d_state_loglik, int64_t F, int32_t 
     if (S <= 0) raise(AASR_ERR_INVALID, "aasr_lna_encode_dev: S must be positive");
     require_device();
     lna_encode_launch(d_state_loglik, F, S, normalize, lnabytes, d_lp_out, d_bytes_out,
-                      (hipStream_t)stream);
+                      (hipStream_t)stream, S);
+  });
+}
+
+aasr_status aasr_lna_encode_dev_pitched(const float *d_state_loglik, int64_t in_pitch, int64_t F, int32_t S,
+                                        int normalize, int lnabytes, float *d_lp_out,
+                                        uint8_t *d_bytes_out, void *stream) {
+  return guarded([&] {
+    if (lnabytes != 2 && lnabytes != 4)
+      raise(AASR_ERR_INVALID, "lnabytes must be 2 or 4, got %d", lnabytes);
+    if (F > 0 && !d_state_loglik) raise(AASR_ERR_INVALID, "aasr_lna_encode_dev_pitched: null input");
+    if (S <= 0 || in_pitch < S) raise(AASR_ERR_INVALID, "aasr_lna_encode_dev_pitched: need 0 < S <= in_pitch");
+    require_device();
+    lna_encode_launch(d_state_loglik, F, S, normalize, lnabytes, d_lp_out, d_bytes_out,
+                      (hipStream_t)stream, in_pitch);
+  });
+}
+
+int aasr_gmm_score_pitch_ok(const aasr_gmm *h) { return h && gmm_score_pitch_ok(h) ? 1 : 0; }
+
+aasr_status aasr_gmm_score_dev_pitched(aasr_gmm *h, const float *d_frames, int64_t F,
+                                       float *d_state_loglik, int64_t pitch, void *stream) {
+  return guarded([&] {
+    if (!h || (F > 0 && (!d_frames || !d_state_loglik)))
+      raise(AASR_ERR_INVALID, "aasr_gmm_score_dev_pitched: null argument");
+    if (pitch < h->S) raise(AASR_ERR_INVALID, "aasr_gmm_score_dev_pitched: pitch %ld < %ld states", (long)pitch, (long)h->S);
+    gmm_score_launch_pitched(h, d_frames, F, d_state_loglik, pitch, (hipStream_t)stream);
   });
 }
 
@@ -333,7 +359,7 @@ aasr_status aasr_lna_encode(const float *state_loglik, int64_t F, int32_t S, int
     d_in.upload(state_loglik, n);
     if (lp_out) d_lp.alloc(n);
     if (bytes_out) d_by.alloc(n * lnabytes);
-    lna_encode_launch(d_in.p, F, S, normalize, lnabytes, d_lp.p, d_by.p, nullptr);
+    lna_encode_launch(d_in.p, F, S, normalize, lnabytes, d_lp.p, d_by.p, nullptr, S);
     if (lp_out) AASR_HIP(hipMemcpy(lp_out, d_lp.p, n * sizeof(float), hipMemcpyDeviceToHost));
     if (bytes_out) AASR_HIP(hipMemcpy(bytes_out, d_by.p, n * lnabytes, hipMemcpyDeviceToHost));
     AASR_HIP(hipDeviceSynchronize());

@@ -231,6 +231,9 @@ void gmm_build_centred(aasr_gmm *g);
 void gmm_build_fullcov(aasr_gmm *g);
 void gmm_full_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                      hipStream_t stream);
+bool gmm_score_pitch_ok(const aasr_gmm *g);
+void gmm_score_launch_pitched(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, int64_t pitch,
+                              hipStream_t stream);
 void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F,
                       float *d_out, hipStream_t stream);
 void gmm_gauss_launch(aasr_gmm *g, const float *d_frames, int64_t F,

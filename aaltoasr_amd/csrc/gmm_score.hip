@@ -676,7 +676,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
     const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
     const uint16_t *__restrict__ close_mask, const int32_t *__restrict__ sid, int sid_stride,
-    float *__restrict__ out, int64_t S, float ref_ln, int dbg, ClusterArgs cl) {
+    float *__restrict__ out, int64_t S, int64_t pitch, float ref_ln, int dbg, ClusterArgs cl) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int OG = Bf16Smem<NK16, GROUPED>::OG;
   constexpr int kTileBytes = Bf16Smem<NK16, GROUPED>::kTileBytes;
@@ -739,8 +739,8 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   int closes = split_row[4 * blockIdx.y + 1 + (GROUPED ? 0 : h)];
   const int32_t *my_sid = sid + h * sid_stride;
   int next_sid = GROUPED ? 0 : my_sid[closes];
-  float *orow0 = out + (f0 + n) * S;
-  float *orow1 = out + (f0 + 32 + n) * S;
+  float *orow0 = out + (f0 + n) * pitch;  // pitch: row stride of `out` in floats (>= S)
+  float *orow1 = out + (f0 + 32 + n) * pitch;
   const bool ok0 = f0 + n < F, ok1 = f0 + 32 + n < F;
   const float floor_val = CL ? cl.floor_val : LOG_TINY_F;
   // this wave's 64 frames are one word of the selection masks
@@ -922,13 +922,13 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
               if (cnt == OG && f0 + FRAMES_PER_WAVE <= F) {
                 // 4 lanes x 16 B cover the 16-state group; 16 frame rows per instruction
                 const int k4 = lane & 3, r16 = lane >> 2;
-                float *op = out + (f0 + r16) * S + s_base + 4 * k4;
+                float *op = out + (f0 + r16) * pitch + s_base + 4 * k4;
                 const float *ip = ost + r16 * kOS + 4 * k4;
 #pragma unroll
                 for (int i = 0; i < FRAMES_PER_WAVE / 16; i++) {
                   const f32x4 v = *(const f32x4 *)(ip + i * 16 * kOS);
                   typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-                  *(f32x4u *)(op + (int64_t)i * 16 * S) = v;
+                  *(f32x4u *)(op + (int64_t)i * 16 * pitch) = v;
                 }
               } else {
                 constexpr int RPI = 64 / OG;
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
                 for (int i = 0; i < FRAMES_PER_WAVE / RPI; i++) {
                   const int row = i * RPI + lane / OG;
                   const float v = ost[row * kOS + k];
-                  if (k < cnt && f0 + row < F) out[(f0 + row) * S + s_base + k] = v;
+                  if (k < cnt && f0 + row < F) out[(f0 + row) * pitch + s_base + k] = v;
                 }
               }
               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
 
 template <int NK16, bool GROUPED, bool CL, bool WIDE>
 static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
-                          float *d_out, hipStream_t stream, const ClusterArgs &cl) {
+                          float *d_out, hipStream_t stream, const ClusterArgs &cl, int64_t pitch) {
   constexpr int NW = WIDE ? 8 : 4;
   const int64_t blocks = (F + NW * FRAMES_PER_WAVE - 1) / (NW * FRAMES_PER_WAVE);
   const int smem = (WIDE ? 3 : 2) * Bf16Smem<NK16, GROUPED>::kTileBytes +
@@ -981,7 +981,7 @@ static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *
   const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(NW * 64), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, L.a16.p, split_row, L.close.p, L.sid.p, L.sid_stride,
-                     d_out, g->S, L.ref_ln, dbg, cl);
+                     d_out, g->S, pitch, L.ref_ln, dbg, cl);
   AASR_HIP(hipGetLastError());
 }
 
@@ -992,7 +992,8 @@ static constexpr bool wide_ok() {
 }
 
 static bool launch_bf16(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
-                        float *d_out, hipStream_t stream, const ClusterArgs *cl = nullptr) {
+                        float *d_out, hipStream_t stream, const ClusterArgs *cl = nullptr, int64_t pitch = 0) {
+  if (pitch <= 0) pitch = g->S;
   if (!L.a16.p) return false;
   const ClusterArgs none;
   // AASR_BF16_WIDE=0 selects the 4-wave workgroups
@@ -1003,14 +1004,14 @@ static bool launch_bf16(const aasr_gmm *g, const TrackLayout &L, const float *d_
 #define AASR_CASE(N)                                                                               \
   case N:                                                                                          \
     if (cl) { /* 4-wave form: the selection masks are laid out per 256-frame workgroup */          \
-      if (L.grouped) launch_bf16_t<N, true, true, false>(g, L, d_frames, F, d_out, stream, *cl);   \
-      else launch_bf16_t<N, false, true, false>(g, L, d_frames, F, d_out, stream, *cl);            \
+      if (L.grouped) launch_bf16_t<N, true, true, false>(g, L, d_frames, F, d_out, stream, *cl, pitch);   \
+      else launch_bf16_t<N, false, true, false>(g, L, d_frames, F, d_out, stream, *cl, pitch);            \
     } else if (wide && wide_ok<N>()) {                                                             \
-      if (L.grouped) launch_bf16_t<N, true, false, true>(g, L, d_frames, F, d_out, stream, none);  \
-      else launch_bf16_t<N, false, false, true>(g, L, d_frames, F, d_out, stream, none);           \
+      if (L.grouped) launch_bf16_t<N, true, false, true>(g, L, d_frames, F, d_out, stream, none, pitch);  \
+      else launch_bf16_t<N, false, false, true>(g, L, d_frames, F, d_out, stream, none, pitch);           \
     } else {                                                                                       \
-      if (L.grouped) launch_bf16_t<N, true, false, false>(g, L, d_frames, F, d_out, stream, none); \
-      else launch_bf16_t<N, false, false, false>(g, L, d_frames, F, d_out, stream, none);          \
+      if (L.grouped) launch_bf16_t<N, true, false, false>(g, L, d_frames, F, d_out, stream, none, pitch); \
+      else launch_bf16_t<N, false, false, false>(g, L, d_frames, F, d_out, stream, none, pitch);          \
     }                                                                                              \
     return true;
     AASR_CASE(1) AASR_CASE(2) AASR_CASE(3) AASR_CASE(4) AASR_CASE(5) AASR_CASE(6) AASR_CASE(8)
@@ -1672,6 +1673,37 @@ void gmm_tracks_masked_launch(aasr_gmm *g, int which, const float *d_frames, int
   if (g->use_bf16x3 && launch_bf16(g, L, d_frames, F, d_out, stream, &cl)) return;
   if (!launch_tracks(g, L, d_frames, F, d_out, stream, &cl))
     raise(AASR_ERR_UNSUPPORTED, "no track kernel instance for this model");
+}
+
+// Whether scores can be written with a row pitch other than S: the bf16x3 track kernels can
+// (rows padded to a multiple of 16 floats make every 64-byte output group a whole cache line).
+bool gmm_score_pitch_ok(const aasr_gmm *g) {
+  if (g->cl.enabled || g->host.factor_path() || g->hyb_enabled || g->ill_conditioned) return false;
+  if (!g->use_bf16x3 || g->precision != AASR_PREC_BF16X3 || (g->layout_mask & 3) != 3) return false;
+  const TrackLayout &L = g->paired.ok ? g->paired : g->tracks;
+  return L.ok && L.a16.p != nullptr;
+}
+
+void gmm_score_launch_pitched(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, int64_t pitch,
+                              hipStream_t stream) {
+  if (F <= 0) return;
+  if (pitch == g->S) {
+    gmm_score_launch(g, d_frames, F, d_out, stream);
+    return;
+  }
+  if (pitch < g->S || !gmm_score_pitch_ok(g))
+    raise(AASR_ERR_UNSUPPORTED, "a row pitch other than the state count needs the bf16x3 track kernels");
+  if (g->xf_a.p) {
+    g->d_xframes.ensure((size_t)F * g->dim);
+    const int64_t n = F * g->dim;
+    hipLaunchKernelGGL(k_affine_frames, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       d_frames, F, g->dim, g->xf_a.p, g->xf_b.p, g->d_xframes.p);
+    AASR_HIP(hipGetLastError());
+    d_frames = g->d_xframes.p;
+  }
+  const TrackLayout &L = g->paired.ok ? g->paired : g->tracks;
+  if (!launch_bf16(g, L, d_frames, F, d_out, stream, nullptr, pitch))
+    raise(AASR_ERR_UNSUPPORTED, "no bf16x3 kernel instance for this model");
 }
 
 void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,

@@ -66,12 +66,12 @@ __device__ __forceinline__ double wave_reduce_sum(double v) {
 }
 
 __global__ __launch_bounds__(256) void k_state_norm_lna(
-    const float *__restrict__ loglik, int64_t F, int S, int normalize,
+    const float *__restrict__ loglik, int64_t F, int S, int64_t in_pitch, int normalize,
     int lnabytes, float *__restrict__ lp_out, uint8_t *__restrict__ bytes_out) {
   __shared__ double red[8];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int64_t f = blockIdx.x; f < F; f += gridDim.x) {
-    const float *row = loglik + f * (int64_t)S;
+    const float *row = loglik + f * in_pitch;
     double logz = 0.0;
     if (normalize) {
       // pass 1: max of the float-cast log-likelihoods
@@ -161,7 +161,7 @@ __device__ __forceinline__ float cast_f(float ll) {
 
 template <int VPT>
 __global__ __launch_bounds__(256) void k_state_norm_lna_reg(
-    const float *__restrict__ loglik, int64_t F, int S, int normalize, int lnabytes,
+    const float *__restrict__ loglik, int64_t F, int S, int64_t in_pitch, int normalize, int lnabytes,
     float *__restrict__ lp_out, uint8_t *__restrict__ bytes_out) {
   __shared__ double red[8];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_state_norm_lna_reg(
   // load latency behind)
   float vn[VPT];
   {
-    const float *row = loglik + (int64_t)blockIdx.x * (int64_t)S;
+    const float *row = loglik + (int64_t)blockIdx.x * in_pitch;
 #pragma unroll
     for (int j = 0; j < VPT; j++) {
       const int i = tid + 256 * j;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k_state_norm_lna_reg(
 #pragma unroll
     for (int j = 0; j < VPT; j++) v[j] = vn[j];
     if (f + gridDim.x < F) {
-      const float *row = loglik + (f + gridDim.x) * (int64_t)S;
+      const float *row = loglik + (f + gridDim.x) * in_pitch;
 #pragma unroll
       for (int j = 0; j < VPT; j++) {
         const int i = tid + 256 * j;
@@ -226,7 +226,8 @@ __global__ __launch_bounds__(256) void k_state_norm_lna_reg(
 }
 
 void lna_encode_launch(const float *d_loglik, int64_t F, int S, int normalize,
-                       int lnabytes, float *d_lp, uint8_t *d_bytes, hipStream_t stream) {
+                       int lnabytes, float *d_lp, uint8_t *d_bytes, hipStream_t stream, int64_t in_pitch) {
+  if (in_pitch <= 0) in_pitch = S;  // row stride of the input in floats
   if (F <= 0 || S <= 0) return;
   int64_t blocks = F < (1 << 20) ? F : (1 << 20);
   // register-resident variants: a few workgroups per CU, each walking many frames with the next
@@ -236,16 +237,16 @@ void lna_encode_launch(const float *d_loglik, int64_t F, int S, int normalize,
   if (S <= 256 * 16) blocks = std::min<int64_t>(blocks, (int64_t)cus * 32);  // measured: 2.56 ms at 4 per CU, 2.16 at 32, flat above
   if (S <= 256 * 4)
     hipLaunchKernelGGL(k_state_norm_lna_reg<4>, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       d_loglik, F, S, normalize, lnabytes, d_lp, d_bytes);
+                       d_loglik, F, S, in_pitch, normalize, lnabytes, d_lp, d_bytes);
   else if (S <= 256 * 8)
     hipLaunchKernelGGL(k_state_norm_lna_reg<8>, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       d_loglik, F, S, normalize, lnabytes, d_lp, d_bytes);
+                       d_loglik, F, S, in_pitch, normalize, lnabytes, d_lp, d_bytes);
   else if (S <= 256 * 16)
     hipLaunchKernelGGL(k_state_norm_lna_reg<16>, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       d_loglik, F, S, normalize, lnabytes, d_lp, d_bytes);
+                       d_loglik, F, S, in_pitch, normalize, lnabytes, d_lp, d_bytes);
   else
     hipLaunchKernelGGL(k_state_norm_lna, dim3((unsigned)blocks), dim3(256), 0, stream, d_loglik,
-                       F, S, normalize, lnabytes, d_lp, d_bytes);
+                       F, S, in_pitch, normalize, lnabytes, d_lp, d_bytes);
   AASR_HIP(hipGetLastError());
 }
 

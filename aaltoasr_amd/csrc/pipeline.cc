@@ -33,7 +33,7 @@
 namespace aasr {
 
 void lna_encode_launch(const float *d_loglik, int64_t F, int S, int normalize, int lnabytes,
-                       float *d_lp, uint8_t *d_bytes, hipStream_t stream);
+                       float *d_lp, uint8_t *d_bytes, hipStream_t stream, int64_t in_pitch);
 
 // ------------------------------------------------------------------ recipe --
 
@@ -253,11 +253,14 @@ struct BlockRunner {
       AASR_HIP(hipMemcpyAsync(d_pcm.p + ub.pcm_off[k], jobs[k]->pcm.data(),
                               jobs[k]->pcm.size() * sizeof(int16_t), hipMemcpyHostToDevice, nullptr));
     d_fea.ensure((size_t)F * dim);
-    d_ll.ensure((size_t)F * S);
+    // the score matrix never leaves the device: rows padded to whole 64-byte lines where the
+    // scoring kernel can write them that way (every output group then is one full line)
+    const int64_t pitch = gmm_score_pitch_ok(gmm) ? (S + 15) / 16 * 16 : S;
+    d_ll.ensure((size_t)F * pitch);
     d_bytes.ensure((size_t)F * S * lnabytes);
     feat_run_batch(feat, d_pcm.p, ub, (int)feat->mods.size() - 1, d_fea.p, nullptr, nullptr);
-    gmm_score_launch(gmm, d_fea.p, F, d_ll.p, nullptr);
-    lna_encode_launch(d_ll.p, F, (int)S, normalize, lnabytes, nullptr, d_bytes.p, nullptr);
+    gmm_score_launch_pitched(gmm, d_fea.p, F, d_ll.p, pitch, nullptr);
+    lna_encode_launch(d_ll.p, F, (int)S, normalize, lnabytes, nullptr, d_bytes.p, nullptr, pitch);
     const size_t nb = (size_t)F * S * lnabytes;
     if (dst) {
       if (nb > dst_cap) raise(AASR_ERR_INVALID, "internal: result buffer too small");

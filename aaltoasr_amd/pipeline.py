@@ -39,14 +39,18 @@ class FullChainBench:
         self.d_pcm = torch.from_numpy(np.concatenate(utts)).to(device)
         S = gmm.num_states
         self.d_fea = torch.empty((self.total_frames, self.feat.dim), dtype=torch.float32, device=device)
-        self.d_ll = torch.empty((self.total_frames, S), dtype=torch.float32, device=device)
+        # the score matrix stays on the device: rows padded to whole 64-byte lines where the scoring
+        # kernel can write them that way (what the C++ recipe driver does too)
+        self.S = S
+        self.pitch = (S + 15) // 16 * 16 if gmm.score_pitch_ok() else S
+        self.d_ll = torch.empty((self.total_frames, self.pitch), dtype=torch.float32, device=device)
         self.d_bytes = torch.empty((self.total_frames, S * lnabytes), dtype=torch.uint8, device=device)
         self.stream = torch.cuda.current_stream()
 
     def step(self) -> None:
         self.feat.run_batch_dev(self.d_pcm, self.pcm_off, self.frame_off, self.d_fea, self.stream)
-        self.gmm.score_dev(self.d_fea, self.d_ll, self.stream)
-        capi.lna_encode_dev(self.d_ll, True, self.lnabytes, None, self.d_bytes, self.stream)
+        self.gmm.score_dev_pitched(self.d_fea, self.d_ll, self.pitch, self.stream)
+        capi.lna_encode_dev(self.d_ll, True, self.lnabytes, None, self.d_bytes, self.stream, num_states=self.S)
 
     def score_only(self) -> None:
-        self.gmm.score_dev(self.d_fea, self.d_ll, self.stream)
+        self.gmm.score_dev_pitched(self.d_fea, self.d_ll, self.pitch, self.stream)

@@ -253,6 +253,15 @@ aasr_status aasr_gmm_score_dev(aasr_gmm *h, const float *d_frames, int64_t F,
 
 /* PDFPool::precompute_likelihoods (aku/Distributions.cc:2647-2682): the
  * log-likelihood of every pool Gaussian, float32 [F x G]. */
+/* The same with a row pitch (floats between consecutive frame rows, >= S) for callers that keep the
+ * score matrix on the device: rows padded to a multiple of 16 floats turn every 64-byte output
+ * group of the scoring kernel into one whole cache line (1.2 ms of 34 per 10^6 frames x 50 k
+ * Gaussians).  Only the bf16x3 track kernels write pitched rows: aasr_gmm_score_pitch_ok() says
+ * whether this model / precision does; otherwise pitch must equal the state count. */
+int aasr_gmm_score_pitch_ok(const aasr_gmm *h);
+aasr_status aasr_gmm_score_dev_pitched(aasr_gmm *h, const float *d_frames, int64_t F,
+                                       float *d_state_loglik, int64_t pitch, void *stream);
+
 aasr_status aasr_gmm_gauss_loglik(aasr_gmm *h, const float *frames, int64_t F,
                                   float *gauss_loglik);
 aasr_status aasr_gmm_gauss_loglik_dev(aasr_gmm *h, const float *d_frames,
@@ -273,6 +282,10 @@ aasr_status aasr_gmm_gauss_loglik_dev(aasr_gmm *h, const float *d_frames,
 aasr_status aasr_lna_encode(const float *state_loglik, int64_t F, int32_t S,
                             int normalize, int lnabytes, float *lp_out,
                             uint8_t *bytes_out);
+/* device input with a row pitch (see aasr_gmm_score_dev_pitched); outputs are dense */
+aasr_status aasr_lna_encode_dev_pitched(const float *d_state_loglik, int64_t in_pitch, int64_t F,
+                                        int32_t S, int normalize, int lnabytes, float *d_lp_out,
+                                        uint8_t *d_bytes_out, void *stream);
 aasr_status aasr_lna_encode_dev(const float *d_state_loglik, int64_t F,
                                 int32_t S, int normalize, int lnabytes,
                                 float *d_lp_out, uint8_t *d_bytes_out,

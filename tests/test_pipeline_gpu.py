@@ -117,3 +117,32 @@ def test_dimension_mismatch_is_reported(capi, setup):
     g13 = capi.Gmm.from_arrays(*synth.make_model(D=13, G=16, S=2, comps=8))
     with pytest.raises(capi.AasrError, match="Gaussian dimension is 13 but feature dimension is 39"):
         capi.run_utterance(setup["ft"], g13, synth.make_audio(8000))
+
+
+def test_pitched_scores_and_lna_equal_the_dense_path(capi):
+    """aasr_gmm_score_dev_pitched / aasr_lna_encode_dev_pitched (score rows padded to whole cache
+    lines, what the recipe driver and the full-chain bench keep on the device) give the bits of the
+    dense entry points, for the 4-wave and the 8-wave kernel."""
+    import torch
+    from aaltoasr_amd import synth
+    model = synth.make_model(D=39, G=808, S=101, comps=8, seed=9)
+    g = capi.Gmm.from_arrays(*model)
+    assert g.score_pitch_ok()
+    for F in (700, 9001):
+        fr = torch.from_numpy(synth.make_frames(F, seed=F)).cuda()
+        dense = torch.empty((F, 101), dtype=torch.float32, device="cuda")
+        g.score_dev(fr, dense)
+        padded = torch.full((F, 112), -7.0, dtype=torch.float32, device="cuda")
+        g.score_dev_pitched(fr, padded, 112)
+        torch.cuda.synchronize()
+        assert torch.equal(padded[:, :101], dense) and bool((padded[:, 101:] == -7.0).all())
+        by_d = torch.empty((F, 202), dtype=torch.uint8, device="cuda")
+        by_p = torch.empty((F, 202), dtype=torch.uint8, device="cuda")
+        capi.lna_encode_dev(dense, True, 2, None, by_d)
+        capi.lna_encode_dev(padded, True, 2, None, by_p, num_states=101)
+        torch.cuda.synchronize()
+        assert torch.equal(by_d, by_p)
+    g.set_precision(0)                       # the f32 kernels write dense rows only
+    assert not g.score_pitch_ok()
+    with pytest.raises(capi.AasrError):
+        g.score_dev_pitched(fr, padded, 112)
