@@ -45,7 +45,9 @@ def _headers_digest() -> str:
                 paths.append(os.path.join(root, f))
     for p in sorted(paths):
         h.update(open(p, "rb").read())
-    h.update(" ".join(COMMON).encode())
+    # flags without the checkout path: a snapshot of the tree elsewhere (the GPU box) must find its
+    # objects up to date instead of recompiling everything
+    h.update(" ".join(c for c in COMMON if not os.path.isabs(c)).encode())
     return h.hexdigest()
 
 
