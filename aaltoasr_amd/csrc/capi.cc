@@ -199,7 +199,7 @@ aasr_status aasr_gmm_set_precision(aasr_gmm *h, int prec) {
       if (prec == AASR_PREC_F32_CENTRED && !h->centred_ok)
         raise(AASR_ERR_UNSUPPORTED, "the centred kernel is not available for dimension %d", h->dim);
       if (prec == AASR_PREC_BF16X3 && !((h->paired.ok && h->paired.a16.p) || (h->tracks.ok && h->tracks.a16.p) ||
-                                        (h->full.ok && h->full.a16.p)))
+                                        (h->full.ok && h->full.a16.p) || h->class_routing))
         raise(AASR_ERR_UNSUPPORTED, "the bf16x3 kernel is not available for this model");
       h->precision = prec;
       h->use_bf16x3 = (prec == AASR_PREC_BF16X3);

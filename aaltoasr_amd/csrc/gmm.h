@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdint>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "common.h"
@@ -215,6 +216,17 @@ struct aasr_gmm {
   int hyb_max_splits = 1;
   aasr::DevBuf<int32_t> hyb_map;           // [hyb_states] -> state index
   aasr::DevBuf<float> hyb_scratch;         // [frames of a pass][hyb_states]
+  // Class routing (per-class constrained MLLR on diagonal pools): one sub-model per regression
+  // class (its mixture components only, built like any diagonal model), scored on the frames
+  // transformed by that class's [b | A]; k_class_merge adds log|det| and sums the classes per
+  // state.  The sub-models depend on the class membership only, so a speaker change uploads a
+  // handful of matrices instead of re-packing the model.
+  bool class_routing = false;
+  std::vector<int32_t> class_g2t;                         // membership the sub-models were built for
+  std::vector<std::unique_ptr<aasr_gmm>> class_models;    // index = transform id + 1 (0: unadapted), may be null
+  std::vector<aasr::DevBuf<double>> class_a, class_b;     // per class: A [dim x dim], b [dim]
+  std::vector<double> class_logdet;                       // log |prod diag A|; -inf = class contributes nothing
+  aasr::DevBuf<float> class_scratch, class_xframes;
   // global CMLLR transform applied to the frames before scoring
   aasr::DevBuf<double> xf_a, xf_b;
   aasr::DevBuf<float> d_xframes;

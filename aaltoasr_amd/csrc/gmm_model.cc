@@ -257,6 +257,7 @@ static void pack_rows(const aasr_gmm *g, const std::vector<RowSpec> &rows,
 
 void gmm_build_tracks(aasr_gmm *g, bool grouped);
 static void find_outliers(aasr_gmm *g);
+static void build_class_routing(aasr_gmm *g);
 
 void gmm_build(aasr_gmm *g, const HostModel &model) {
   require_device();
@@ -316,6 +317,13 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
   m.logw_bias = 0;
   g->xf_a.release();
   g->xf_b.release();
+  g->class_routing = false;
+  if (m.n_transforms > 0 && !m.global_xform() && !m.any_full()) {
+    build_class_routing(g);
+    return;
+  }
+  g->class_models.clear();
+  g->class_g2t.clear();
   if (m.factor_path()) {
     // full-covariance Gaussians and per-class CMLLR are scored through factor
     // rows by k_gmm_full_score only
@@ -1067,6 +1075,71 @@ void gmm_build_fullcov(aasr_gmm *g) {
     }
   }
   L.ok = true;
+}
+
+// Per-class constrained MLLR on a diagonal pool (ConstrainedMllr, aku/ModelModules.cc:164-232;
+// AdaptedGaussian::compute_likelihood = g(A f + b) * |det|, aku/ModelModules.hh:172-173, det = the
+// product of A's diagonal, aku/LinearAlgebra.cc:73-86): see class_routing in gmm.h.
+static void build_class_routing(aasr_gmm *g) {
+  const HostModel &m = g->host;
+  const int D = m.dim;
+  const int nc = m.n_transforms + 1;
+  g->mix.rows = (int64_t)m.mix_idx.size();
+  g->paired.ok = g->tracks.ok = g->centred_ok = false;
+  g->full.ok = false;
+  g->ill_conditioned = false;
+  if (g->class_g2t != m.g2t || (int)g->class_models.size() != nc) {
+    // sub-models: the components of every state that belong to the class, over the class's own pool
+    g->class_models.clear();
+    g->class_models.resize((size_t)nc);
+    for (int c = 0; c < nc; c++) {
+      const int tid = c - 1;
+      std::vector<int32_t> remap((size_t)m.G, -1);
+      HostModel sm;
+      sm.dim = D;
+      sm.S = m.S;
+      sm.weights_normalized = true;  // the parent's weights are final: no second normalisation
+      sm.mix_off.assign(1, 0);
+      for (int64_t s = 0; s < m.S; s++) {
+        for (int32_t k = m.mix_off[s]; k < m.mix_off[s + 1]; k++) {
+          const int32_t gi = m.mix_idx[k];
+          if (m.g2t[(size_t)gi] != tid) continue;
+          if (remap[(size_t)gi] < 0) {
+            remap[(size_t)gi] = (int32_t)sm.G++;
+            sm.mean.insert(sm.mean.end(), &m.mean[(size_t)gi * D], &m.mean[(size_t)gi * D] + D);
+            sm.var.insert(sm.var.end(), &m.var[(size_t)gi * D], &m.var[(size_t)gi * D] + D);
+          }
+          sm.mix_idx.push_back(remap[(size_t)gi]);
+          sm.mix_w.push_back(m.mix_w[k]);
+        }
+        sm.mix_off.push_back((int32_t)sm.mix_idx.size());
+      }
+      if (sm.mix_idx.empty()) continue;
+      auto sub = std::make_unique<aasr_gmm>();
+      sub->device = g->device;
+      gmm_build(sub.get(), sm);
+      g->class_models[(size_t)c] = std::move(sub);
+    }
+    g->class_g2t = m.g2t;
+  }
+  // this speaker's transforms
+  g->class_a.resize((size_t)nc);
+  g->class_b.resize((size_t)nc);
+  g->class_logdet.assign((size_t)nc, 0.0);
+  for (int c = 1; c < nc; c++) {
+    const double *W = &m.xform[(size_t)(c - 1) * D * (D + 1)];
+    std::vector<double> A((size_t)D * D), b((size_t)D);
+    double det = 1;
+    for (int i = 0; i < D; i++) {
+      b[(size_t)i] = W[(size_t)i * (D + 1)];
+      for (int j = 0; j < D; j++) A[(size_t)i * D + j] = W[(size_t)i * (D + 1) + 1 + j];
+      det *= A[(size_t)i * D + i];
+    }
+    g->class_a[(size_t)c].upload(A.data(), A.size());
+    g->class_b[(size_t)c].upload(b.data(), b.size());
+    g->class_logdet[(size_t)c] = det != 0 ? std::log(std::fabs(det)) : -INFINITY;
+  }
+  g->class_routing = true;
 }
 
 void gmm_build_pool(aasr_gmm *g) {

@@ -1675,10 +1675,79 @@ void gmm_tracks_masked_launch(aasr_gmm *g, int which, const float *d_frames, int
     raise(AASR_ERR_UNSUPPORTED, "no track kernel instance for this model");
 }
 
+// Class routing (gmm.h): out[i] = log(exp(out[i]) + exp(part[i] + logdet)); a value AT the floor
+// holds nothing (a sub-model writes the floor for states it has no component of).
+__global__ void k_class_merge(float *__restrict__ out, const float *__restrict__ part, float logdet,
+                              int first, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = first ? LOG_TINY_F : out[i];
+  float b = part[i];
+  float r = a;
+  if (b > LOG_TINY_F) {
+    b += logdet;
+    if (a > LOG_TINY_F) {
+      const float hi = fmaxf(a, b), lo = fminf(a, b);
+      r = hi + log1pf(expf(lo - hi));
+    } else {
+      r = b;
+    }
+  }
+  out[i] = fmaxf(r, LOG_TINY_F);
+}
+
+__global__ void k_fill_floor(float *__restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = LOG_TINY_F;
+}
+
+static void score_classes(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, hipStream_t stream) {
+  const int64_t S = g->S;
+  int64_t pass = std::max<int64_t>(64, (int64_t)(1.0e9 / (double)(S * 4)));
+  if (pass > F) pass = F;
+  g->class_scratch.ensure((size_t)pass * (size_t)S);
+  g->class_xframes.ensure((size_t)pass * (size_t)g->dim);
+  for (int64_t f0 = 0; f0 < F; f0 += pass) {
+    const int64_t n = std::min(pass, F - f0);
+    const float *fr = d_frames + f0 * g->dim;
+    float *out = d_out + f0 * S;
+    const int64_t total = n * S;
+    bool first = true;
+    for (size_t c = 0; c < g->class_models.size(); c++) {
+      aasr_gmm *sub = g->class_models[c].get();
+      if (!sub) continue;
+      const double logdet = c == 0 ? 0.0 : g->class_logdet[c];
+      if (!(logdet > -INFINITY)) continue;  // det == 0: the adapted Gaussians contribute nothing
+      const float *xf = fr;
+      if (c > 0) {
+        // f' = A f + b (AdaptedFeatureVector::calculate_new_ada_vector, aku/ModelModules.hh:208-212)
+        const int64_t nv = n * g->dim;
+        hipLaunchKernelGGL(k_affine_frames, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, stream, fr, n,
+                           g->dim, g->class_a[c].p, g->class_b[c].p, g->class_xframes.p);
+        AASR_HIP(hipGetLastError());
+        xf = g->class_xframes.p;
+      }
+      sub->precision = g->precision;
+      sub->use_bf16x3 = g->use_bf16x3;
+      sub->layout_mask = g->layout_mask;
+      gmm_score_launch(sub, xf, n, g->class_scratch.p, stream);
+      hipLaunchKernelGGL(k_class_merge, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, out,
+                         g->class_scratch.p, (float)logdet, first ? 1 : 0, total);
+      AASR_HIP(hipGetLastError());
+      first = false;
+    }
+    if (first) {  // no class has anything: every state at the floor
+      hipLaunchKernelGGL(k_fill_floor, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, out, total);
+      AASR_HIP(hipGetLastError());
+    }
+  }
+}
+
 // Whether scores can be written with a row pitch other than S: the bf16x3 track kernels can
 // (rows padded to a multiple of 16 floats make every 64-byte output group a whole cache line).
 bool gmm_score_pitch_ok(const aasr_gmm *g) {
-  if (g->cl.enabled || g->host.factor_path() || g->hyb_enabled || g->ill_conditioned) return false;
+  if (g->cl.enabled || g->host.factor_path() || g->hyb_enabled || g->ill_conditioned || g->class_routing)
+    return false;
   if (!g->use_bf16x3 || g->precision != AASR_PREC_BF16X3 || (g->layout_mask & 3) != 3) return false;
   const TrackLayout &L = g->paired.ok ? g->paired : g->tracks;
   return L.ok && L.a16.p != nullptr;
@@ -1711,6 +1780,10 @@ void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
   if (F <= 0) return;
   if (g->cl.enabled) {
     gmm_cluster_score_launch(g, d_frames, F, d_out, stream);
+    return;
+  }
+  if (g->class_routing) {
+    score_classes(g, d_frames, F, d_out, stream);
     return;
   }
   if (g->host.factor_path()) {
@@ -1746,7 +1819,7 @@ void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
 
 void gmm_gauss_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                       hipStream_t stream) {
-  if (g->host.factor_path() || g->xf_a.p)
+  if (g->host.factor_path() || g->xf_a.p || g->class_routing)
     raise(AASR_ERR_UNSUPPORTED,
           "per-Gaussian log-likelihoods are not built for full-covariance or adapted pools");
   gmm_build_pool(g);
