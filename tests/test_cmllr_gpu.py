@@ -101,3 +101,37 @@ def test_argument_validation(capi):
     g = capi.Gmm.from_arrays(*model)
     with pytest.raises(capi.AasrError, match="out of range"):
         g.set_cmllr(np.full(16, 4, np.int32), _transforms(2, 8, 0))
+
+
+def test_class_routing_across_speaker_changes(capi, oracle):
+    """Per-class transforms go through per-class sub-models that only depend on the class
+    membership: new matrices for the same membership, a new membership, an empty class, a state
+    held by one class only, tied Gaussians, ragged and empty states, then back to global / none."""
+    rng = np.random.default_rng(17)
+    D, G = 13, 96
+    mean, var, _, _, _ = synth.make_model(D=D, G=G, S=4, comps=4, seed=5)
+    n = np.array([3, 0, 9, 1, 16, 5, 2])
+    off = np.concatenate([[0], np.cumsum(n)]).astype(np.int32)
+    idx = rng.integers(0, G, off[-1]).astype(np.int32)          # tied pool
+    w = rng.uniform(0.05, 1.0, off[-1])
+    model = (mean, var, off, idx, w)
+    frames = synth.make_frames(150, D=D, seed=3)
+    g = capi.Gmm.from_arrays(*model)
+    g2t = rng.integers(-1, 3, G).astype(np.int32)
+    g2t[idx[off[2]:off[3]]] = 1                                  # state 2 entirely in class 1
+    for seed in (1, 2):                                          # same membership, new speaker
+        W = _transforms(4, D, seed)                              # class 3 has no Gaussian at all
+        g.set_cmllr(g2t, W)
+        ref = _oracle_adapted(oracle, model, frames, g2t, W)
+        for prec in (3, 0):
+            g.set_precision(prec)
+            assert np.abs(g.score(frames) - ref).max() <= 1e-4
+    g2t2 = rng.integers(-1, 2, G).astype(np.int32)               # new membership
+    W2 = _transforms(2, D, 9)
+    g.set_cmllr(g2t2, W2)
+    assert np.abs(g.score(frames) - _oracle_adapted(oracle, model, frames, g2t2, W2)).max() <= 1e-4
+    g.set_cmllr(np.zeros(G, np.int32), W2[:1])                   # one transform for all: frame transform path
+    assert np.abs(g.score(frames) - _oracle_adapted(oracle, model, frames, np.zeros(G, np.int32), W2[:1])).max() <= 1e-4
+    g.set_cmllr()                                                # unadapted again
+    plain = oracle.DiagModel(*model).score(frames.astype(np.float64))
+    assert np.abs(g.score(frames) - plain).max() <= 1e-4
