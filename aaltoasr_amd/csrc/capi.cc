@@ -219,16 +219,11 @@ aasr_status aasr_gmm_set_cmllr(aasr_gmm *h, int32_t n_transforms,
       raise(AASR_ERR_INVALID, "aasr_gmm_set_cmllr: bad argument");
     if (n_transforms > 0 && h->cl.loaded)
       raise(AASR_ERR_UNSUPPORTED, "model-side CMLLR together with Gaussian clustering is not built");
-    HostModel m = h->host;
-    m.n_transforms = n_transforms;
-    m.g2t.clear();
-    m.xform.clear();
-    if (n_transforms > 0) {
-      m.g2t.assign(gauss_to_transform, gauss_to_transform + m.G);
-      m.xform.assign(W, W + (size_t)n_transforms * m.dim * (m.dim + 1));
-    }
-    h->pool_built = false;
-    gmm_build(h, m);
+    if (n_transforms > 0)
+      for (int64_t i = 0; i < h->G; i++)
+        if (gauss_to_transform[i] < -1 || gauss_to_transform[i] >= n_transforms)
+          raise(AASR_ERR_INVALID, "transform index %d out of range", gauss_to_transform[i]);
+    gmm_set_transforms(h, n_transforms, gauss_to_transform, W);
   });
 }
 

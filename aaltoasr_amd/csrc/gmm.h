@@ -216,6 +216,10 @@ struct aasr_gmm {
   int hyb_max_splits = 1;
   aasr::DevBuf<int32_t> hyb_map;           // [hyb_states] -> state index
   aasr::DevBuf<float> hyb_scratch;         // [frames of a pass][hyb_states]
+  // Global constrained MLLR without re-packing: the rows stay those of the unadapted model
+  // (rows_unbiased) and log|det| is added to every score at the kernels' output (out_bias_ln)
+  bool rows_unbiased = false;
+  double out_bias_ln = 0;
   // Class routing (per-class constrained MLLR on diagonal pools): one sub-model per regression
   // class (its mixture components only, built like any diagonal model), scored on the frames
   // transformed by that class's [b | A]; k_class_merge adds log|det| and sums the classes per
@@ -237,6 +241,9 @@ struct aasr_gmm {
 
 namespace aasr {
 void gmm_build(aasr_gmm *g, const HostModel &m);
+// model-side constrained MLLR (n_transforms = 0 resets): updates in place where it can (a global
+// transform over the unadapted rows; per-class transforms with an unchanged membership), rebuilds otherwise
+void gmm_set_transforms(aasr_gmm *g, int32_t n_transforms, const int32_t *gauss_to_transform, const double *W);
 void gmm_build_pool(aasr_gmm *g);
 void gmm_build_tracks(aasr_gmm *g, bool grouped);
 void gmm_build_centred(aasr_gmm *g);

@@ -272,6 +272,8 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
   g->outlier.clear();
   g->hyb_enabled = false;
   g->hyb_states = g->hyb_rows = 0;
+  g->rows_unbiased = false;
+  g->out_bias_ln = 0;
   g->dim = m.dim;
   g->G = m.G;
   g->S = m.S;
@@ -400,6 +402,7 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
   gmm_build_tracks(g, true);
   if (!g->paired.ok) gmm_build_tracks(g, false);
   gmm_build_centred(g);
+  g->rows_unbiased = m.logw_bias == 0;
   // profiling hook: AASR_LAYOUTS=<mask> restricts the kernels like
   // aasr_debug_set_layouts (1 grouped, 2 independent tracks, 4 centred, 0 general)
   if (const char *e = getenv("AASR_PREC")) {
@@ -1140,6 +1143,64 @@ static void build_class_routing(aasr_gmm *g) {
     g->class_logdet[(size_t)c] = det != 0 ? std::log(std::fabs(det)) : -INFINITY;
   }
   g->class_routing = true;
+}
+
+void gmm_set_transforms(aasr_gmm *g, int32_t n_transforms, const int32_t *gauss_to_transform, const double *W) {
+  HostModel &cur = g->host;
+  const int D = cur.dim;
+  bool global = n_transforms == 1;
+  if (global)
+    for (int64_t i = 0; i < cur.G && global; i++) global = gauss_to_transform[i] == 0;
+  // In place: none / one transform for the whole pool, over rows packed without a bias, on the
+  // kernels that take the bias at their output (the track layouts; no outlier routing).  A
+  // speaker change then costs two small uploads instead of re-packing every row (70 ms at 50 k
+  // Gaussians).
+  if ((n_transforms == 0 || global) && g->rows_unbiased && !cur.any_full() && !g->class_routing &&
+      (g->paired.ok || g->tracks.ok) && !g->ill_conditioned && !g->hyb_enabled) {
+    cur.n_transforms = n_transforms;
+    cur.g2t.clear();
+    cur.xform.clear();
+    g->pool_built = false;
+    if (n_transforms == 0) {
+      g->xf_a.release();
+      g->xf_b.release();
+      g->out_bias_ln = 0;
+      return;
+    }
+    cur.g2t.assign(gauss_to_transform, gauss_to_transform + cur.G);
+    cur.xform.assign(W, W + (size_t)D * (D + 1));
+    std::vector<double> A((size_t)D * D), b((size_t)D);
+    double det = 1;
+    for (int i = 0; i < D; i++) {
+      b[(size_t)i] = W[(size_t)i * (D + 1)];
+      for (int j = 0; j < D; j++) A[(size_t)i * D + j] = W[(size_t)i * (D + 1) + 1 + j];
+      det *= A[(size_t)i * D + i];
+    }
+    g->xf_a.upload(A.data(), A.size());
+    g->xf_b.upload(b.data(), b.size());
+    g->out_bias_ln = std::log(std::fabs(det));  // -inf for a zero diagonal: every state at the floor
+    return;
+  }
+  HostModel m = cur;
+  m.n_transforms = 0;
+  m.g2t.clear();
+  m.xform.clear();
+  g->pool_built = false;
+  if (global && !m.any_full() && !g->rows_unbiased) {
+    // coming from per-class transforms or from rows with a folded bias: build the unadapted rows
+    // once, then take the in-place path if this model can (the usual case)
+    gmm_build(g, m);
+    if (g->rows_unbiased && (g->paired.ok || g->tracks.ok) && !g->ill_conditioned && !g->hyb_enabled) {
+      gmm_set_transforms(g, n_transforms, gauss_to_transform, W);
+      return;
+    }
+  }
+  m.n_transforms = n_transforms;
+  if (n_transforms > 0) {
+    m.g2t.assign(gauss_to_transform, gauss_to_transform + m.G);
+    m.xform.assign(W, W + (size_t)n_transforms * D * (D + 1));
+  }
+  gmm_build(g, m);
 }
 
 void gmm_build_pool(aasr_gmm *g) {

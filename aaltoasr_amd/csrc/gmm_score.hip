@@ -593,7 +593,7 @@ static void launch_tracks_t(const aasr_gmm *g, const TrackLayout &L, const float
   const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(256), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, L.rows.a.p, split_row, L.close.p, L.sid.p, L.sid_stride,
-                     d_out, g->S, L.ref_ln, dbg, cl);
+                     d_out, g->S, L.ref_ln - (float)g->out_bias_ln, dbg, cl);
   AASR_HIP(hipGetLastError());
 }
 
@@ -981,7 +981,7 @@ static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *
   const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(NW * 64), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, L.a16.p, split_row, L.close.p, L.sid.p, L.sid_stride,
-                     d_out, g->S, pitch, L.ref_ln, dbg, cl);
+                     d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, dbg, cl);
   AASR_HIP(hipGetLastError());
 }
 
@@ -1743,6 +1743,19 @@ static void score_classes(aasr_gmm *g, const float *d_frames, int64_t F, float *
   }
 }
 
+// log|det| of an in-place global transform for the kernels that do not take it at their output
+// (diagnostic layouts only: the track kernels fold it into their reference exponent)
+__global__ void k_add_bias(float *__restrict__ out, float bias, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = fmaxf(out[i] + bias, LOG_TINY_F);
+}
+static void add_output_bias(const aasr_gmm *g, float *d_out, int64_t F, hipStream_t stream) {
+  const int64_t n = F * g->S;
+  hipLaunchKernelGGL(k_add_bias, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_out,
+                     (float)g->out_bias_ln, n);
+  AASR_HIP(hipGetLastError());
+}
+
 // Whether scores can be written with a row pitch other than S: the bf16x3 track kernels can
 // (rows padded to a multiple of 16 floats make every 64-byte output group a whole cache line).
 bool gmm_score_pitch_ok(const aasr_gmm *g) {
@@ -1803,7 +1816,10 @@ void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
   // numerically safe path first when the model needs it (or it is forced)
   if ((g->layout_mask & 4) && (g->ill_conditioned || g->precision == AASR_PREC_F32_CENTRED ||
                                !(g->layout_mask & 3) ) && g->centred_ok)
-    if (launch_centred(g, d_frames, F, d_out, stream)) return;
+    if (launch_centred(g, d_frames, F, d_out, stream)) {
+      if (g->out_bias_ln != 0) add_output_bias(g, d_out, F, stream);
+      return;
+    }
   // layout choice: grouped tracks > independent tracks > general (LDS-staged)
   bool done = false;
   if (!done && (g->layout_mask & 1) && g->paired.ok)
@@ -1812,7 +1828,10 @@ void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
   if (!done && (g->layout_mask & 2) && g->tracks.ok)
     done = (g->use_bf16x3 && launch_bf16(g, g->tracks, d_frames, F, d_out, stream)) ||
            launch_tracks(g, g->tracks, d_frames, F, d_out, stream);
-  if (!done) launch<0>(g, g->mix, d_frames, F, d_out, g->S, stream);
+  if (!done) {
+    launch<0>(g, g->mix, d_frames, F, d_out, g->S, stream);
+    if (g->out_bias_ln != 0) add_output_bias(g, d_out, F, stream);  // this kernel has no output bias
+  }
   // the Gaussians the matrix layouts left out (null rows): centred form, merged per state
   if (g->hyb_enabled) score_outliers(g, d_frames, F, d_out, stream);
 }

@@ -311,12 +311,7 @@ static void load_transforms(aasr_spkc *h) {
     if (h->trans.empty()) {
       if (h->device_adapted) {
         note_change(h);
-        HostModel m = g->host;
-        m.n_transforms = 0;
-        m.g2t.clear();
-        m.xform.clear();
-        g->pool_built = false;
-        gmm_build(g, m);
+        gmm_set_transforms(g, 0, nullptr, nullptr);
         h->device_adapted = false;
       }
     } else {
@@ -334,13 +329,8 @@ static void load_transforms(aasr_spkc *h) {
         t++;
       }
       note_change(h);
-      HostModel m = g->host;
-      m.n_transforms = t;
-      m.g2t = g2t;
-      m.xform = W;
       (void)dim;
-      g->pool_built = false;
-      gmm_build(g, m);
+      gmm_set_transforms(g, t, g2t.data(), W.data());
       h->device_adapted = true;
     }
     h->cmllr_loaded = true;

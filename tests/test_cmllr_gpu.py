@@ -135,3 +135,29 @@ def test_class_routing_across_speaker_changes(capi, oracle):
     g.set_cmllr()                                                # unadapted again
     plain = oracle.DiagModel(*model).score(frames.astype(np.float64))
     assert np.abs(g.score(frames) - plain).max() <= 1e-4
+
+
+def test_global_transform_in_place_on_every_kernel(capi, oracle):
+    """A global transform is applied without re-packing the rows: log|det| enters at the kernels'
+    output (the track kernels' reference exponent; an extra pass for the general and the centred
+    kernel), a zero diagonal puts every state at the floor, repeated changes do not accumulate."""
+    D, G = 13, 64
+    model = synth.make_model(D=D, G=G, S=8, comps=8, seed=11)
+    frames = synth.make_frames(90, D=D, seed=2)
+    g = capi.Gmm.from_arrays(*model)
+    g2t = np.zeros(G, np.int32)
+    for seed in (1, 2, 3):
+        W = _transforms(1, D, seed)
+        g.set_cmllr(g2t, W)
+        ref = _oracle_adapted(oracle, model, frames, g2t, W)
+        for prec, mask in ((3, 7), (0, 7), (0, 2), (0, 0), (0, 4)):
+            g.set_precision(prec)
+            g.set_layouts(mask)
+            assert np.abs(g.score(frames) - ref).max() <= 1e-4, (seed, prec, mask)
+        g.set_layouts(7)
+    W0 = _transforms(1, D, 4)
+    W0[0, 3, 4] = 0.0                                  # A[3][3] = 0 -> |det| = 0
+    g.set_cmllr(g2t, W0)
+    assert np.allclose(g.score(frames), np.log(1e-50), atol=1e-5)
+    g.set_cmllr()
+    assert np.abs(g.score(frames) - oracle.DiagModel(*model).score(frames.astype(np.float64))).max() <= 1e-4
