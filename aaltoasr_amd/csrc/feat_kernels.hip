@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void k_lin_transform_tiled(
   double *xs = (double *)smem_raw;                  // [ROWS][src_dim]
   float *ms = (float *)(xs + (size_t)ROWS * src_dim);  // [dim][src_dim + 1]
   const int64_t r0 = (int64_t)blockIdx.x * ROWS;
-  const int mstride = src_dim + 1;
+  const int mstride = src_dim | 1;  // odd row stride: threads of a wave read 64 different banks (40 = 8-way conflicts)
   for (int e = threadIdx.x; e < dim * src_dim; e += 256)
     ms[(e / src_dim) * mstride + (e % src_dim)] = matrix[e];
   for (int e = threadIdx.x; e < ROWS * src_dim; e += 256) {
