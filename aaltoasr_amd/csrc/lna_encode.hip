@@ -241,6 +241,12 @@ void lna_encode_launch(const float *d_loglik, int64_t F, int S, int normalize,
   else if (S <= 256 * 8)
     hipLaunchKernelGGL(k_state_norm_lna_reg<8>, dim3((unsigned)blocks), dim3(256), 0, stream,
                        d_loglik, F, S, in_pitch, normalize, lnabytes, d_lp, d_bytes);
+  else if (S <= 256 * 10)
+    hipLaunchKernelGGL(k_state_norm_lna_reg<10>, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       d_loglik, F, S, in_pitch, normalize, lnabytes, d_lp, d_bytes);
+  else if (S <= 256 * 13)
+    hipLaunchKernelGGL(k_state_norm_lna_reg<13>, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       d_loglik, F, S, in_pitch, normalize, lnabytes, d_lp, d_bytes);
   else if (S <= 256 * 16)
     hipLaunchKernelGGL(k_state_norm_lna_reg<16>, dim3((unsigned)blocks), dim3(256), 0, stream,
                        d_loglik, F, S, in_pitch, normalize, lnabytes, d_lp, d_bytes);
