@@ -93,7 +93,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("table,name", [(PHONE_PROBS, "pp.spec"), (FEACAT, "fc.spec")])
-def test_cli_grammar_matches_reference_parser(tmp_path, table, name):
+def test_cli_grammar_matches_reference_parser(oracle, tmp_path, table, name):   # `oracle`: runs make -C oracle
     if not os.path.exists(REF):
         pytest.skip("oracle/_ref/conf_ref not built (no reference tree)")
     assert os.path.exists(ENG), "oracle/conf_engine missing: run `make -C oracle`"
