@@ -266,3 +266,29 @@ def test_wide_and_narrow_workgroups_give_identical_bits(capi):
     parts = np.vstack([g.score(fr[:4000]), g.score(fr[4000:8100]), g.score(fr[8100:])])   # 4-wave
     assert np.array_equal(whole.view(np.uint32), parts.view(np.uint32))
     g.close()
+
+
+@pytest.mark.parametrize("D", [1, 3, 7, 13, 20, 24, 31, 40, 47, 55, 63])
+def test_wide_kernel_every_instance(capi, oracle, D):
+    """Every K/16 instance of the 8-wave kernel (batches of 8192+ frames), grouped and independent
+    track layouts, against the oracle and bit-for-bit against the 4-wave kernel (smaller batches);
+    dimension 63 has no 8-wave form (LDS) and must still agree."""
+    rng = np.random.default_rng(100 + D)
+    for ragged in (False, True):
+        S = 9
+        n = rng.integers(1, 7, S) if ragged else np.full(S, 4)
+        off = np.concatenate([[0], np.cumsum(n)]).astype(np.int32)
+        G = int(off[-1])
+        mean = rng.standard_normal((G, D))
+        var = np.exp(rng.uniform(np.log(0.3), np.log(3.0), (G, D)))
+        idx = np.arange(G, dtype=np.int32)
+        w = rng.uniform(0.1, 1.0, G)
+        g = capi.Gmm.from_arrays(mean, var, off, idx, w)
+        g.set_precision(3)
+        fr = synth.make_frames(8200, D=D, seed=D)
+        whole = g.score(fr)
+        parts = np.vstack([g.score(fr[:4100]), g.score(fr[4100:])])
+        assert np.array_equal(whole.view(np.uint32), parts.view(np.uint32))
+        ref = oracle.DiagModel(mean, var, off, idx, w).score(fr[:300].astype(np.float64))
+        assert np.abs(whole[:300] - ref).max() <= 1e-4
+        g.close()
