@@ -67,3 +67,20 @@ def test_lna_normalised_rows_sum_to_one(capi):
     ll = rng.uniform(-70.0, -30.0, (16, 3125)).astype(np.float32)
     lp, _ = capi.lna_encode(ll, True, 4)
     assert np.allclose(np.exp(lp.astype(np.float64)).sum(1), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("S", [3, 256, 1024, 1025, 2048, 2049, 2560, 2561, 3125, 3328, 3329, 4096, 4097, 5000])
+def test_every_kernel_instance_by_state_count(capi, oracle, S):
+    """The register-resident kernel has instances for 4 / 8 / 10 / 13 / 16 values per thread and a
+    generic fallback above 4096 states; each boundary, persistent workgroups over more frames than
+    workgroups."""
+    rng = np.random.default_rng(S)
+    F = 37
+    ll = np.maximum(rng.uniform(-70.0, -5.0, (F, S)), LOG_TINY).astype(np.float32)
+    lp_ref, by_ref = _ref(oracle, ll.astype(np.float64), True, 2)
+    lp, by = capi.lna_encode(ll, True, 2)
+    assert np.abs(lp - lp_ref).max() <= 1e-5
+    code = by.reshape(F, S, 2).astype(np.int32)
+    cref = by_ref.reshape(F, S, 2).astype(np.int32)
+    d = np.abs((code[..., 0] * 256 + code[..., 1]) - (cref[..., 0] * 256 + cref[..., 1]))
+    assert d.max() <= 1 and (d == 0).mean() > 0.97
