@@ -84,3 +84,18 @@ def test_every_kernel_instance_by_state_count(capi, oracle, S):
     cref = by_ref.reshape(F, S, 2).astype(np.int32)
     d = np.abs((code[..., 0] * 256 + code[..., 1]) - (cref[..., 0] * 256 + cref[..., 1]))
     assert d.max() <= 1 and (d == 0).mean() > 0.97
+
+
+def test_persistent_workgroups_walk_many_frames(capi, oracle):
+    """More frames than resident workgroups (32 per CU): every workgroup walks several rows with
+    the next one prefetched; every row must still be its own normalisation."""
+    rng = np.random.default_rng(99)
+    F, S = 20011, 130
+    ll = np.maximum(rng.uniform(-60.0, -5.0, (F, S)), LOG_TINY).astype(np.float32)
+    lp, by = capi.lna_encode(ll, True, 2)
+    pick = rng.choice(F, 400, replace=False)
+    pick[:3] = [0, F - 1, 8192]
+    lp_ref, by_ref = _ref(oracle, ll[pick].astype(np.float64), True, 2)
+    assert np.abs(lp[pick] - lp_ref).max() <= 1e-5
+    assert (by[pick] == by_ref).mean() > 0.97
+    assert np.abs(np.exp(lp.astype(np.float64)).sum(axis=1) - 1.0).max() < 1e-4
