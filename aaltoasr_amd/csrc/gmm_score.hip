@@ -1465,6 +1465,11 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
   }
 }
 
+// scratch budget of the routed passes (outlier / class partial scores); tests shrink it to force
+// many passes
+static double g_pass_bytes = 1.0e9;
+extern "C" void aasr_debug_set_pass_bytes(double bytes) { g_pass_bytes = bytes > 0 ? bytes : 1.0e9; }
+
 // operand set of the centred kernel: the whole model, or the outlier components only
 struct CentredOps {
   const float *recs;
@@ -1557,7 +1562,7 @@ static void score_outliers(aasr_gmm *g, const float *d_frames, int64_t F, float 
   const int64_t Sb = g->hyb_states;
   if (Sb <= 0) return;
   // passes of at most ~1 GB of partial scores
-  int64_t pass = std::max<int64_t>(512, ((int64_t)(1.0e9 / (double)(Sb * 4))) / 512 * 512);
+  int64_t pass = std::max<int64_t>(512, ((int64_t)(g_pass_bytes / (double)(Sb * 4))) / 512 * 512);
   if (pass > F) pass = (F + 63) / 64 * 64;
   g->hyb_scratch.ensure((size_t)pass * (size_t)Sb);
   const CentredOps ops{g->hyb_recs.p, g->hyb_state_off.p, g->hyb_splits.p, g->hyb_max_splits, 1, pass};
@@ -1703,7 +1708,7 @@ __global__ void k_fill_floor(float *__restrict__ out, int64_t n) {
 
 static void score_classes(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, hipStream_t stream) {
   const int64_t S = g->S;
-  int64_t pass = std::max<int64_t>(64, (int64_t)(1.0e9 / (double)(S * 4)));
+  int64_t pass = std::max<int64_t>(64, (int64_t)(g_pass_bytes / (double)(S * 4)));
   if (pass > F) pass = F;
   g->class_scratch.ensure((size_t)pass * (size_t)S);
   g->class_xframes.ensure((size_t)pass * (size_t)g->dim);

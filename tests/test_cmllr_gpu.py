@@ -161,3 +161,35 @@ def test_global_transform_in_place_on_every_kernel(capi, oracle):
     assert np.allclose(g.score(frames), np.log(1e-50), atol=1e-5)
     g.set_cmllr()
     assert np.abs(g.score(frames) - oracle.DiagModel(*model).score(frames.astype(np.float64))).max() <= 1e-4
+
+
+def test_routed_scoring_in_many_passes(capi, oracle):
+    """Outlier routing and class routing keep partial scores in a bounded scratch and walk the
+    frames in passes; with the budget shrunk to a few KB the result must not change by a bit."""
+    import ctypes as C
+    L = capi.lib()
+    L.aasr_debug_set_pass_bytes.argtypes = [C.c_double]
+    L.aasr_debug_set_pass_bytes.restype = None
+    rng = np.random.default_rng(41)
+    D, G = 13, 160
+    mean, var, off, idx, w = synth.make_model(D=D, G=G, S=20, comps=8, seed=19)
+    var[rng.choice(G, 8, replace=False)] *= 1e-3                 # outliers
+    frames = synth.make_frames(2100, D=D, seed=7)
+    g = capi.Gmm.from_arrays(mean, var, off, idx, w)
+    try:
+        one = g.score(frames)
+        L.aasr_debug_set_pass_bytes(20000.0)
+        many = g.score(frames)
+        assert np.array_equal(one.view(np.uint32), many.view(np.uint32))
+        L.aasr_debug_set_pass_bytes(0.0)
+        g2t = rng.integers(-1, 3, G).astype(np.int32)
+        W = _transforms(3, D, 6)
+        g.set_cmllr(g2t, W)
+        one = g.score(frames)
+        L.aasr_debug_set_pass_bytes(30000.0)
+        many = g.score(frames)
+        assert np.array_equal(one.view(np.uint32), many.view(np.uint32))
+        ref = _oracle_adapted(oracle, (mean, var, off, idx, w), frames[:200], g2t, W)
+        assert np.abs(many[:200] - ref).max() <= 2e-4
+    finally:
+        L.aasr_debug_set_pass_bytes(0.0)
