@@ -467,10 +467,16 @@ __global__ __launch_bounds__(256) void k_lin_transform_tiled(
 // staged in LDS once; each thread sums its window in frame order.
 template <int ROWS>
 __global__ __launch_bounds__(256) void k_mean_subtract_tiled(
-    DevBatch b, const double *__restrict__ src, SrcMap sm, int span, int64_t rows, int dim,
+    DevBatch b, const double *__restrict__ src, SrcMap sm, int span, int halo_left, int64_t rows, int dim,
     int left, int right, double *__restrict__ dst) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double *xs = (double *)smem_raw;  // [ROWS + left + right][dim]
+  // sums of 8 consecutive frames: a window of left+right+1 rows is then a few singles at its ends
+  // plus whole blocks (151 LDS reads per value became ~30; the kernel was LDS-bandwidth bound).
+  // The blocks sit on ABSOLUTE frame numbers (multiples of 8 within the utterance), so a frame's
+  // value does not depend on how the frame range was tiled or batched; the additions are grouped
+  // differently from the frame-order loop (1e-16 relative).
+  double *bs = xs + (size_t)(ROWS + left + right) * dim;  // [(ROWS + left + right) / 8 + 1][dim]
   const int64_t tile0 = (int64_t)blockIdx.x * ROWS;
   const int64_t tile1 = tile0 + ROWS < rows ? tile0 + ROWS : rows;
   // A tile may straddle utterances: source rows of consecutive module rows are
@@ -487,13 +493,37 @@ __global__ __launch_bounds__(256) void k_mean_subtract_tiled(
     const int n_src = n_seg + left + right;
     for (int e = threadIdx.x; e < n_src * dim; e += 256) xs[e] = src[(s0 - left) * dim + e];
     __syncthreads();
+    // frame number of staged row 0, and the first staged row that starts a block
+    const int64_t key_u = b.frame_off[u] + (int64_t)u * span;
+    const int64_t abs0 = (int64_t)b.first[u] - halo_left + (r0 - key_u) - left;
+    const int i0 = (int)(((-abs0) % 8 + 8) % 8);
+    const int n_blk = n_src > i0 ? (n_src - i0) / 8 : 0;
+    for (int e = threadIdx.x; e < n_blk * dim; e += 256) {
+      const int k = e / dim, d = e - k * dim;
+      const double *c = xs + (size_t)(i0 + 8 * k) * dim + d;
+      double t = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) t += c[(size_t)i * dim];
+      bs[e] = t;
+    }
+    __syncthreads();
     for (int e = threadIdx.x; e < n_seg * dim; e += 256) {
       const int lr = e / dim, d = e - lr * dim;
-      const double *c = xs + (size_t)(lr + left) * dim + d;
+      // staged rows [lr, lr + left + right] are this value's window
+      const int a = lr, b_end = lr + left + right + 1;
+      int ka = a <= i0 ? 0 : (a - i0 + 7) / 8;      // whole blocks [ka, kb): staged rows i0 + 8k ...
+      int kb = b_end <= i0 ? 0 : (b_end - i0) / 8;
+      if (kb > n_blk) kb = n_blk;
       double mean = 0;
-      for (int i = -left; i <= right; i++) mean += c[(ptrdiff_t)i * dim];
+      if (ka >= kb) {
+        for (int i = a; i < b_end; i++) mean += xs[(size_t)i * dim + d];
+      } else {
+        for (int i = a; i < i0 + 8 * ka; i++) mean += xs[(size_t)i * dim + d];
+        for (int k = ka; k < kb; k++) mean += bs[(size_t)k * dim + d];
+        for (int i = i0 + 8 * kb; i < b_end; i++) mean += xs[(size_t)i * dim + d];
+      }
       mean /= (left + right + 1);
-      dst[(r0 + lr) * dim + d] = c[0] - mean;
+      dst[(r0 + lr) * dim + d] = xs[(size_t)(lr + left) * dim + d] - mean;
     }
     __syncthreads();
     r0 = r_end;
@@ -845,10 +875,11 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
       }
       case MOD_MEAN_SUBTRACTOR: {
         constexpr int MS_ROWS = 64;
-        const size_t ms_smem = (size_t)(MS_ROWS + m.cms_left + m.cms_right) * m.dim * 8;
+        const size_t ms_src = (size_t)(MS_ROWS + m.cms_left + m.cms_right);
+        const size_t ms_smem = (ms_src + ms_src / 8 + 1) * m.dim * 8;
         if (ms_smem <= 60 * 1024)
           hipLaunchKernelGGL(k_mean_subtract_tiled<MS_ROWS>, dim3((unsigned)((rows + MS_ROWS - 1) / MS_ROWS)),
-                             dim3(256), ms_smem, stream, db, src, sm, span, rows, m.dim, m.cms_left,
+                             dim3(256), ms_smem, stream, db, src, sm, span, L[i], rows, m.dim, m.cms_left,
                              m.cms_right, dst);
         else
           hipLaunchKernelGGL(k_mean_subtract, dim3(grid_for(nelem)), dim3(256), 0, stream, db, src,
