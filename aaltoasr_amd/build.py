@@ -24,7 +24,7 @@ ARCH = "gfx950"
 # -ffp-contract=off: the feature kernels restate float32/float64 arithmetic of
 # the reference operation by operation; fused multiply-adds would change bits.
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall",
-          "-Wno-unused-function", f"--offload-arch={ARCH}", "-I", os.path.join(HERE, "..", "include")]
+          "-Wno-unused-function", "-Wno-inline-asm", f"--offload-arch={ARCH}", "-I", os.path.join(HERE, "..", "include")]
 
 
 def _sources():
