@@ -146,6 +146,12 @@ def _declare(L: C.CDLL) -> None:
                                      C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(i64), C.POINTER(i64)]
     L.aasr_free.argtypes = [vp]
     L.aasr_free.restype = None
+    L.aasr_feat_get_parameters.argtypes = [vp, cp, C.POINTER(C.c_void_p), C.POINTER(i64)]
+    L.aasr_feat_num_modules.argtypes = [vp]
+    L.aasr_feat_module_name.argtypes = [vp, C.c_int]
+    L.aasr_feat_module_name.restype = cp
+    L.aasr_feat_module_type.argtypes = [vp, C.c_int]
+    L.aasr_feat_module_type.restype = cp
     L.aasr_gmm_score_pitch_ok.argtypes = [vp]
     L.aasr_gmm_score_dev_pitched.argtypes = [vp, vp, i64, vp, i64, vp]
     L.aasr_lna_encode_dev_pitched.argtypes = [vp, i64, i64, i32, C.c_int, C.c_int, vp, vp, vp]
@@ -455,6 +461,22 @@ class Feat:
 
     def set_parameters(self, module: str, block_text: str) -> None:
         check(lib().aasr_feat_set_parameters(self._h, module.encode(), block_text.encode()))
+
+    def get_parameters(self, module: str) -> str:
+        """FeatureModule::get_parameters as a "{ name value ... }" block."""
+        out = C.c_void_p()
+        n = C.c_int64()
+        check(lib().aasr_feat_get_parameters(self._h, module.encode(), C.byref(out), C.byref(n)))
+        try:
+            return C.string_at(out, n.value).decode()
+        finally:
+            lib().aasr_free(out)
+
+    def modules(self):
+        """[(name, type)] in configuration order."""
+        L = lib()
+        return [(L.aasr_feat_module_name(self._h, i).decode(), L.aasr_feat_module_type(self._h, i).decode())
+                for i in range(L.aasr_feat_num_modules(self._h))]
 
 
 def recipe_batch_range(total: int, num_batches: int, batch_index: int):

@@ -41,12 +41,63 @@ void FeatureGenerator::load_configuration_text(const std::string &text) {
     close_configuration();
   }
   check(aasr_feat_create(text.c_str(), &m_feat));
+  m_modules.clear();
+  const int n = aasr_feat_num_modules(m_feat);
+  m_modules.resize((size_t)n);
+  for (int i = 0; i < n; i++) {
+    FeatureModule &m = m_modules[(size_t)i];
+    m.m_gen = this;
+    m.m_name = aasr_feat_module_name(m_feat, i);
+    m.m_type = aasr_feat_module_type(m_feat, i);
+    m.m_dim = aasr_feat_module_dim(m_feat, m.m_name.c_str());
+  }
+}
+
+FeatureModule *FeatureGenerator::module(const std::string &name) {
+  for (FeatureModule &m : m_modules)
+    if (m.m_name == name) return &m;
+  throw std::string("unknown module requested: ") + name;
+}
+
+void FeatureModule::set_parameters(const ModuleConfig &config) {
+  if (aasr_feat_set_parameters(m_gen->handle(), m_name.c_str(), config.text().c_str()) != AASR_OK)
+    throw std::string(aasr_last_error());
+  m_gen->invalidate_block();  // every cached frame downstream is stale
+}
+
+void FeatureModule::get_parameters(ModuleConfig &config) const {
+  char *text = nullptr;
+  int64_t len = 0;
+  if (aasr_feat_get_parameters(m_gen->handle(), m_name.c_str(), &text, &len) != AASR_OK)
+    throw std::string(aasr_last_error());
+  const std::string t(text, (size_t)len);
+  aasr_free(text);
+  ModuleConfig got;
+  got.read_text(t);
+  config = got;
+}
+
+const FeatureVec FeatureModule::at(int frame) {
+  if (m_count == 0 || m_epoch != m_gen->epoch() || frame < m_first || frame >= m_first + m_count) {
+    const std::vector<int16_t> &in = m_gen->input_units();
+    const int n = 256;
+    m_block.resize((size_t)n * m_dim);
+    if (aasr_feat_run_f64(m_gen->handle(), in.data(), (int64_t)in.size(), frame, n, m_name.c_str(),
+                          m_block.data()) != AASR_OK)
+      throw std::string(aasr_last_error());
+    m_first = frame;
+    m_count = n;
+    m_epoch = m_gen->epoch();
+  }
+  return FeatureVec(&m_block[(size_t)(frame - m_first) * m_dim], m_dim, frame, nullptr);
 }
 
 void FeatureGenerator::close_configuration() {
   if (m_feat) aasr_feat_destroy(m_feat);
   m_feat = nullptr;
+  m_modules.clear();
   m_block_count = 0;
+  m_epoch++;
 }
 
 void FeatureGenerator::open(const std::string &filename) {
@@ -59,6 +110,7 @@ void FeatureGenerator::open(const std::string &filename) {
   }
   m_open = true;
   m_block_count = 0;
+  m_epoch++;
   m_eof_on_last_frame = false;
 }
 
@@ -77,6 +129,7 @@ void FeatureGenerator::open(FILE *file, bool) {
   }
   m_open = true;
   m_block_count = 0;
+  m_epoch++;
   m_eof_on_last_frame = false;
 }
 
@@ -85,6 +138,7 @@ void FeatureGenerator::open_pcm(const int16_t *pcm, int64_t n_samples) {
   m_pcm.assign(pcm, pcm + n_samples);
   m_open = true;
   m_block_count = 0;
+  m_epoch++;
   m_eof_on_last_frame = false;
 }
 
@@ -92,6 +146,7 @@ void FeatureGenerator::close() {
   m_open = false;
   m_pcm.clear();
   m_block_count = 0;
+  m_epoch++;
 }
 
 int FeatureGenerator::last_frame() { return aasr_feat_last_frame(m_feat, (int64_t)m_pcm.size()); }

@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include "ModuleConfig.hh"
 #include <vector>
 
 #include "../../../include/aasr.h"
@@ -50,6 +51,30 @@ private:
   const FeatureGenerator *m_owner;
 };
 
+/** One module of the graph with the calls of aku::FeatureModule that users of a generator reach
+ * through FeatureGenerator::module(name) (aku/FeatureModule.hh:47-154): name / type_str / dim,
+ * set_parameters / get_parameters (speaker adaptation, aku/FeatureModules.cc per module) and at(frame),
+ * the module's own output.  The arithmetic runs on the device; this object is a view. */
+class FeatureModule {
+public:
+  const std::string &name() const { return m_name; }
+  const std::string &type_str() const { return m_type; }
+  int dim() const { return m_dim; }
+  void set_parameters(const ModuleConfig &config);
+  void get_parameters(ModuleConfig &config) const;
+  /** this module's feature vector at `frame` (computed through the graph, cached in blocks) */
+  const FeatureVec at(int frame);
+
+private:
+  friend class FeatureGenerator;
+  FeatureGenerator *m_gen = nullptr;
+  std::string m_name, m_type;
+  int m_dim = 0;
+  int m_first = 0, m_count = 0;
+  uint64_t m_epoch = 0;
+  std::vector<double> m_block;
+};
+
 class FeatureGenerator {
 public:
   FeatureGenerator();
@@ -61,6 +86,8 @@ public:
   void close_configuration();
   /** aku/FeatureGenerator.cc:222-243 */
   void write_configuration(FILE *file);
+  /** aku/FeatureGenerator.cc:257-265: throws std::string("unknown module requested: " + name) */
+  FeatureModule *module(const std::string &name);
 
   /** aku/FeatureGenerator.cc:30-52: opens a PCM16 WAV (or raw) file */
   void open(const std::string &filename);
@@ -84,7 +111,14 @@ public:
   uint64_t block_serial() const { return m_block_serial; }
   void set_block_frames(int n) { m_block_frames = n > 0 ? n : 1; }
   /** module parameters changed (SpeakerConfig): cached frames are stale */
-  void invalidate_block() { m_block_count = 0; }
+  void invalidate_block() {
+    m_block_count = 0;
+    m_epoch++;
+  }
+  /** bumped whenever cached frames become stale (parameters, new input) */
+  uint64_t epoch() const { return m_epoch; }
+  /** the open input in the engine's int16 units */
+  const std::vector<int16_t> &input_units() const { return m_pcm; }
 
 private:
   void fill_block(int frame);
@@ -93,6 +127,8 @@ private:
   bool m_open, m_eof_on_last_frame;
   int m_block_first, m_block_count, m_block_frames;
   uint64_t m_block_serial;
+  uint64_t m_epoch = 0;
+  std::vector<FeatureModule> m_modules;
   std::vector<double> m_block;     // [count x dim]
   std::vector<float> m_block_f32;  // same block, float32 (device scoring input)
 };

@@ -23,7 +23,78 @@ static double safe_log(double x) {  // aku/util.hh:132-139
   return x < tiny_for_log ? log(tiny_for_log) : log(x);
 }
 
+// aku_adapter_check modules CFG AUDIO OUT: the FeatureModule view of every module of the graph
+// (FeatureGenerator::module(name): name, type_str, dim, at(frame) for frames -3 .. 20), then the
+// get_parameters -> set_parameters round trip on every module that has parameters and the
+// generator's output after it.  OUT is text: one line per value group.
+static int modules_mode(const char *cfg, const char *audio, const char *out_path) {
+  aku::FeatureGenerator gen;
+  FILE *cf = fopen(cfg, "r");
+  if (!cf) throw std::string("could not open config");
+  gen.load_configuration(cf);
+  fclose(cf);
+  gen.open(audio);
+  FILE *out = fopen(out_path, "w");
+  if (!out) throw std::string("could not open output");
+  FILE *wf = tmpfile();
+  gen.write_configuration(wf);
+  rewind(wf);
+  // module names in configuration order, from the written configuration ("  name X" lines)
+  std::vector<std::string> names;
+  char line[4096];
+  while (fgets(line, sizeof line, wf)) {
+    std::string l(line);
+    if (l.compare(0, 7, "  name ") == 0) names.push_back(l.substr(7, l.size() - 8));
+  }
+  fclose(wf);
+  for (const std::string &nm : names) {
+    aku::FeatureModule *m = gen.module(nm);
+    fprintf(out, "module %s %s %d\n", m->name().c_str(), m->type_str().c_str(), m->dim());
+    for (int f = -3; f <= 20; f++) {
+      const aku::FeatureVec v = m->at(f);
+      for (int i = 0; i < v.dim(); i++) fprintf(out, "%.17g ", v[i]);
+      fprintf(out, "\n");
+    }
+  }
+  bool unknown_thrown = false;
+  try {
+    gen.module("no-such-module");
+  } catch (std::string &e) {
+    unknown_thrown = e == "unknown module requested: no-such-module";
+  }
+  fprintf(out, "unknown %d\n", unknown_thrown ? 1 : 0);
+  for (const std::string &nm : names) {
+    aku::FeatureModule *m = gen.module(nm);
+    aku::ModuleConfig c;
+    m->get_parameters(c);
+    std::vector<float> mean;
+    if (c.get("mean", mean)) {  // a normalization module: shift every mean, read back
+      for (float &x : mean) x += 0.25f;
+      c.set("mean", mean);
+      m->set_parameters(c);
+      aku::ModuleConfig back;
+      m->get_parameters(back);
+      fprintf(out, "params %s %s", nm.c_str(), back.text().c_str());
+    }
+  }
+  for (int f = 0; f <= 5; f++) {
+    const aku::FeatureVec v = gen.generate(f);
+    for (int i = 0; i < v.dim(); i++) fprintf(out, "%.17g ", v[i]);
+    fprintf(out, "\n");
+  }
+  fclose(out);
+  return 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc == 5 && std::string(argv[1]) == "modules") {
+    try {
+      return modules_mode(argv[2], argv[3], argv[4]);
+    } catch (std::string &e) {
+      fprintf(stderr, "exception: %s\n", e.c_str());
+      return 1;
+    }
+  }
   if (argc != 6 && argc != 9 && argc != 10 && argc != 13) {
     fprintf(stderr, "usage: aku_adapter_check CFG MODEL_BASE AUDIO OUT.lna LNABYTES [GCL MINC MING] "
                     "[spkc SPKC SPEAKER UTTERANCE]\n");

@@ -176,4 +176,30 @@ aasr_status aasr_feat_set_parameters(aasr_feat *h, const char *module_name,
   });
 }
 
+aasr_status aasr_feat_get_parameters(const aasr_feat *h, const char *module_name, char **text,
+                                     int64_t *len) {
+  return guarded([&] {
+    if (!h || !module_name || !text || !len)
+      raise(AASR_ERR_INVALID, "aasr_feat_get_parameters: null argument");
+    ModuleConfig c;
+    feat_get_parameters(h, module_name, c);
+    std::string t = "{\n";
+    for (size_t i = 0; i < c.names.size(); i++) t += "  " + c.names[i] + " " + c.values[i] + "\n";
+    t += "}\n";
+    char *out = (char *)malloc(t.size() + 1);
+    if (!out) raise(AASR_ERR_INVALID, "aasr_feat_get_parameters: out of memory");
+    memcpy(out, t.c_str(), t.size() + 1);
+    *text = out;
+    *len = (int64_t)t.size();
+  });
+}
+
+int aasr_feat_num_modules(const aasr_feat *h) { return h ? (int)h->mods.size() : -1; }
+const char *aasr_feat_module_name(const aasr_feat *h, int index) {
+  return h && index >= 0 && index < (int)h->mods.size() ? h->mods[(size_t)index].name.c_str() : nullptr;
+}
+const char *aasr_feat_module_type(const aasr_feat *h, int index) {
+  return h && index >= 0 && index < (int)h->mods.size() ? h->mods[(size_t)index].type_str.c_str() : nullptr;
+}
+
 }  // extern "C"

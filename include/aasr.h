@@ -135,6 +135,15 @@ aasr_status aasr_feat_run_batch_dev(aasr_feat *h, const int16_t *d_pcm,
  * "{ key value ... }" block as in .spkc files. */
 aasr_status aasr_feat_set_parameters(aasr_feat *h, const char *module_name,
                                      const char *params_text);
+/* FeatureModule::get_parameters (aku/FeatureModules.cc, per module): the module's adaptation
+ * parameters as the same kind of block ("%g" values).  *text is malloc'ed; free it with aasr_free. */
+aasr_status aasr_feat_get_parameters(const aasr_feat *h, const char *module_name, char **text,
+                                     int64_t *len);
+/* FeatureGenerator::module(name) bookkeeping: modules in configuration order
+ * (FeatureModule::name / type_str, aku/FeatureModule.hh:47-154); NULL past the end */
+int aasr_feat_num_modules(const aasr_feat *h);
+const char *aasr_feat_module_name(const aasr_feat *h, int index);
+const char *aasr_feat_module_type(const aasr_feat *h, int index);
 
 /* ------------------------------------------------------------------------ */
 /* Acoustic model: replaces aku::HmmSet / PDFPool / Mixture scoring          */

@@ -252,3 +252,42 @@ def test_phone_probs_takes_the_reference_option_grammar(world):
     r = subprocess.run([exe, "-b", world["base"], "-c", world["cfg"], "-r", world["recipe"], "-i10"],
                        capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and r.stderr.startswith("invalid option -1")
+
+
+def test_feature_module_view_of_the_graph(capi, golden_dir, world):
+    """aku::FeatureGenerator::module(name) -> aku::FeatureModule (name, type_str, dim, at(frame),
+    get_parameters / set_parameters through aku::ModuleConfig): what a caller of the reference's
+    plugin API sees is what the C ABI computes for the same module, including border frames, and a
+    parameter change made through the view reaches the generator's output."""
+    import wave
+    cfg = os.path.join(golden_dir, "mfcc_cms_norm.feaconf")
+    wav = os.path.join(golden_dir, "short.wav")
+    out = str(world["dir"] / "modules.txt")
+    r = subprocess.run([os.path.join(BIN, "aku_adapter_check"), "modules", cfg, wav, out],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    with wave.open(wav, "rb") as w:
+        pcm = np.frombuffer(w.readframes(w.getnframes()), "<i2")
+    ft = capi.Feat.from_file(cfg)
+    lines = open(out).read().splitlines()
+    pos = 0
+    for name, typ in ft.modules():
+        head = lines[pos].split()
+        assert head[:3] == ["module", name, typ] and int(head[3]) == ft.module_dim(name)
+        want = ft.run(pcm, -3, 24, module=name, dtype=np.float64)
+        got = np.array([[float(x) for x in lines[pos + 1 + k].split()] for k in range(24)])
+        assert np.array_equal(got, want), name
+        pos += 25
+    assert lines[pos] == "unknown 1"
+    pos += 1
+    # the normalization module's parameters, shifted by the view and read back ("%g" round trip)
+    norm = [n for n, t in ft.modules() if t == "normalization"]
+    assert norm and lines[pos].startswith("params " + norm[0])
+    block = ft.get_parameters(norm[0])
+    mean = [np.float32(x) + np.float32(0.25) for x in block.split("mean", 1)[1].split("\n")[0].split()]
+    shifted = "{\n  mean " + " ".join("%g" % m for m in mean) + "\n" + block.split("\n", 2)[2]
+    ft.set_parameters(norm[0], shifted)
+    assert "  mean " + " ".join("%g" % m for m in mean) in "\n".join(lines[pos:pos + 4])
+    end = [i for i in range(pos, len(lines)) if lines[i] == "}"][0]
+    got = np.array([[float(x) for x in l.split()] for l in lines[end + 1:end + 7]])
+    assert np.array_equal(got, ft.run(pcm, 0, 6, dtype=np.float64))
