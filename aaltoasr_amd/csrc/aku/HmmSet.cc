@@ -103,6 +103,33 @@ int HmmSet::num_states() {
 
 void HmmSet::reset_cache() { m_row = nullptr; }
 
+int HmmSet::num_pool_pdfs() {
+  ensure_model();
+  return aasr_gmm_num_gaussians(m_gmm);
+}
+
+double HmmSet::pool_log_likelihood(const int g, const FeatureVec &f) {
+  ensure_model();
+  const int G = aasr_gmm_num_gaussians(m_gmm);
+  if (g < 0 || g >= G) throw std::string("PDFPool: Gaussian index out of range");
+  std::vector<double> x;
+  f.get(x);
+  if (x != m_pool_x || (int)m_pool_ll.size() != G) {
+    if (f.dim() != aasr_gmm_dim(m_gmm))
+      throw std::string("HmmSet: feature dimension does not match the model");
+    std::vector<float> xf(x.begin(), x.end());
+    m_pool_ll.resize((size_t)G);
+    if (aasr_gmm_gauss_loglik(m_gmm, xf.data(), 1, m_pool_ll.data()) != AASR_OK)
+      throw std::string(aasr_last_error());
+    m_pool_x = x;
+  }
+  return (double)m_pool_ll[(size_t)g];
+}
+
+double HmmSet::pool_likelihood(const int g, const FeatureVec &f) {
+  return std::exp(pool_log_likelihood(g, f));
+}
+
 const float *HmmSet::state_loglik_row(const FeatureVec &f) {
   ensure_model();
   const int S = aasr_gmm_num_states(m_gmm);

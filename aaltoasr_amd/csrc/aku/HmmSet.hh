@@ -50,6 +50,17 @@ public:
   double state_likelihood(const int s, const FeatureVec &f);
   double pdf_likelihood(const int p, const FeatureVec &f) { return state_likelihood(p, f); }
 
+  /** PDFPool::size / compute_likelihood / compute_log_likelihood for one pool Gaussian
+   * (aku/Distributions.hh:262-263, aku/Distributions.cc:2636-2644, 1033-1062): the whole pool is
+   * scored for the frame on first use (aasr_gmm_gauss_loglik) and kept until the frame changes */
+  int num_pool_pdfs();
+  double pool_log_likelihood(const int g, const FeatureVec &f);
+  double pool_likelihood(const int g, const FeatureVec &f);
+
+private:
+  std::vector<float> m_pool_ll;   // per-Gaussian log-likelihoods of m_pool_frame
+  std::vector<double> m_pool_x;   // the frame they belong to (by value)
+public:
   aasr_gmm *handle() {
     ensure_model();
     return m_gmm;

@@ -86,7 +86,38 @@ static int modules_mode(const char *cfg, const char *audio, const char *out_path
   return 0;
 }
 
+// aku_adapter_check pool CFG MODEL_BASE AUDIO OUT: per-Gaussian log-likelihoods (PDFPool view of
+// HmmSet) for two frames, one value per line.
+static int pool_mode(const char *cfg, const char *base, const char *audio, const char *out_path) {
+  aku::FeatureGenerator gen;
+  aku::HmmSet model;
+  FILE *cf = fopen(cfg, "r");
+  if (!cf) throw std::string("could not open config");
+  gen.load_configuration(cf);
+  fclose(cf);
+  model.read_all(base);
+  gen.open(audio);
+  FILE *out = fopen(out_path, "w");
+  if (!out) throw std::string("could not open output");
+  fprintf(out, "%d\n", model.num_pool_pdfs());
+  for (int f : {0, 7}) {
+    const aku::FeatureVec v = gen.generate(f);
+    for (int g = model.num_pool_pdfs() - 1; g >= 0; g--)  // any order, one device pass per frame
+      fprintf(out, "%.9g %.9g\n", model.pool_log_likelihood(g, v), model.pool_likelihood(g, v));
+  }
+  fclose(out);
+  return 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc == 6 && std::string(argv[1]) == "pool") {
+    try {
+      return pool_mode(argv[2], argv[3], argv[4], argv[5]);
+    } catch (std::string &e) {
+      fprintf(stderr, "exception: %s\n", e.c_str());
+      return 1;
+    }
+  }
   if (argc == 5 && std::string(argv[1]) == "modules") {
     try {
       return modules_mode(argv[2], argv[3], argv[4]);

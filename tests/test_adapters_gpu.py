@@ -291,3 +291,23 @@ def test_feature_module_view_of_the_graph(capi, golden_dir, world):
     end = [i for i in range(pos, len(lines)) if lines[i] == "}"][0]
     got = np.array([[float(x) for x in l.split()] for l in lines[end + 1:end + 7]])
     assert np.array_equal(got, ft.run(pcm, 0, 6, dtype=np.float64))
+
+
+def test_pool_likelihood_view(capi, oracle, world):
+    """PDFPool::compute_likelihood / compute_log_likelihood for single Gaussians through the HmmSet
+    adapter (one device pass per frame) against the oracle's per-Gaussian log-likelihoods."""
+    out = str(world["dir"] / "pool.txt")
+    r = subprocess.run([os.path.join(BIN, "aku_adapter_check"), "pool", world["cfg"], world["base"],
+                        str(world["dir"] / "a1.wav"), out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = open(out).read().split("\n")
+    G = int(lines[0])
+    assert G == 256
+    vals = np.array([[float(x) for x in l.split()] for l in lines[1:1 + 2 * G]])
+    fea = world["ft"].run(world["pcms"][1], 0, 8, dtype=np.float64)
+    om = oracle.DiagModel(*world["model"])
+    for k, f in enumerate((0, 7)):
+        ref = om.gauss_loglik(fea[f:f + 1])[0][::-1]
+        got = vals[k * G:(k + 1) * G]
+        assert np.abs(got[:, 0] - ref).max() <= 1e-4
+        assert np.allclose(got[:, 1], np.exp(got[:, 0]), rtol=1e-6)
