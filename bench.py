@@ -50,6 +50,8 @@ def parse_args():
     ap.add_argument("--workload", choices=["gmm", "full"], default=os.environ.get("AASR_BENCH_WORKLOAD", "gmm"))
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step (gmm workload)")
     ap.add_argument("--utts", type=int, default=360, help="10-s utterances per GPU per step (full workload)")
+    ap.add_argument("--out-pitch", choices=["dense", "aligned"], default=os.environ.get("AASR_BENCH_OUT_PITCH", "aligned"),
+                    help="gmm workload: output rows dense [F x S] or padded to whole 64-byte lines")
     ap.add_argument("--cpu-frames", type=int, default=20000, help="frames timed on the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-procs", type=int, default=-1,
                     help="processes of the all-cores CPU baseline (-1 = one per usable core, 0 = skip)")
@@ -160,15 +162,21 @@ def main():
         gen = torch.Generator(device=dev)
         gen.manual_seed(synth.SEED + 17 * rank)
         d_frames = torch.randn((F, DIM), generator=gen, device=dev, dtype=torch.float32)
-        d_out = torch.empty((F, S), device=dev, dtype=torch.float32)
-        workload = "configs[1]: batched diag-GMM log-likelihood, %d x %d-d frames x %d Gaussians (%d states x %d)" % (
-            F, DIM, G, S, COMPS)
+        # output rows either dense (pitch S, what aasr_gmm_score hands to a host caller) or padded to
+        # whole 64-byte lines (pitch S rounded up to 16 floats: the layout the device-resident chain
+        # aasr_gmm_score_dev_pitched -> aasr_lna_encode_dev_pitched uses)
+        pitch = (S + 15) // 16 * 16 if (args.out_pitch == "aligned" and gmm.score_pitch_ok()) else S
+        d_out = torch.empty((F, pitch), device=dev, dtype=torch.float32)
+        workload = "configs[1]: batched diag-GMM log-likelihood, %d x %d-d frames x %d Gaussians (%d states x %d), output row pitch %d floats" % (
+            F, DIM, G, S, COMPS, pitch)
 
-        def step():
-            gmm.score_dev(d_frames, d_out, stream)
-
-        def score_only():
-            gmm.score_dev(d_frames, d_out, stream)
+        if pitch == S:
+            def step():
+                gmm.score_dev(d_frames, d_out, stream)
+        else:
+            def step():
+                gmm.score_dev_pitched(d_frames, d_out, pitch, stream)
+        score_only = step
     else:
         from aaltoasr_amd import pipeline
         runner = pipeline.FullChainBench(gmm, n_utts=args.utts, seconds=10.0, rank=rank, device=dev)
@@ -242,7 +250,7 @@ def main():
         if obs.get("sclk_mhz"):
             adj = peak * obs["sclk_mhz"] / NOMINAL_SCLK_MHZ
             roofline["frac_of_clock_adjusted_peak"] = round(achieved / adj, 4)
-    td = _pmc_traffic(F, args.precision)
+    td = _pmc_traffic(F, args.precision, aligned=(args.workload == "full" or args.out_pitch == "aligned"))
     if td:
         roofline["traffic"] = td["bytes"]
         roofline["traffic_detail"] = td
@@ -318,7 +326,7 @@ def _observe_clock(enqueue, torch):
         return None
 
 
-def _pmc_traffic(frames, precision="f32"):
+def _pmc_traffic(frames, precision="f32", aligned=False):
     """HBM bytes per launch of k_gmm_diag_score from the committed rocprofv3 PMC
     passes (profiles/*_pmc*.json: FETCH_SIZE and WRITE_SIZE in KiB, collected in
     separate passes at 1 000 000 frames/launch; FETCH_SIZE doubled per
@@ -328,6 +336,9 @@ def _pmc_traffic(frames, precision="f32"):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*gmm_%s_pmc*.json" % precision)))
     if not files and precision == "f32":
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*gmm_pmc*.json")))
+    # passes taken with whole-line output rows carry "aligned" in the name
+    picked = [f for f in files if ("aligned" in os.path.basename(f)) == aligned]
+    files = picked or ([] if aligned else files)
     if not files:
         return None
     try:
