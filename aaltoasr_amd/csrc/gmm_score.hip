@@ -40,6 +40,7 @@ namespace aasr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define LN2_F 0.69314718055994530942f
 // log(1e-50): HmmSet clamps state likelihoods at util::tiny_for_log
@@ -656,13 +657,16 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &p1, un
   p3 = a3 | (b3 << 16);
 }
 
-template <int NK16, bool GROUPED>
+template <int NK16, bool GROUPED, bool WIDE = false>
 struct Bf16Smem {
-  static constexpr int OG = 16;  // states per output group (LDS budget: 2 workgroups per CU)
   static constexpr int kTileBytes = NK16 * 3 * 2 * 64 * 16;
-  static constexpr int kOutStride = OG + 4;
+  // States per output group.  4-wave form: 16 (LDS budget of 2 workgroups per CU).  8-wave form: 32
+  // where three tile buffers + eight staging areas of stride 34 still fit 160 KB -- a group is then
+  // a whole 128-byte L2 line of a padded output row, written by one store instruction.
+  static constexpr bool kBig = WIDE && GROUPED && 3 * kTileBytes + 8 * FRAMES_PER_WAVE * 34 * 4 <= 160 * 1024;
+  static constexpr int OG = kBig ? 32 : 16;
+  static constexpr int kOutStride = kBig ? 34 : 20;
   static constexpr int kOutFloatsPerWave = GROUPED ? FRAMES_PER_WAVE * kOutStride : 0;
-  static constexpr int kBytes = 2 * kTileBytes + WAVES_PER_BLOCK * kOutFloatsPerWave * 4;
 };
 
 // WIDE: one workgroup of 8 waves (512 frames) per CU instead of two of 4 waves, so a tile is
@@ -678,10 +682,10 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     const uint16_t *__restrict__ close_mask, const int32_t *__restrict__ sid, int sid_stride,
     float *__restrict__ out, int64_t S, int64_t pitch, float ref_ln, int dbg, ClusterArgs cl) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr int OG = Bf16Smem<NK16, GROUPED>::OG;
-  constexpr int kTileBytes = Bf16Smem<NK16, GROUPED>::kTileBytes;
+  constexpr int OG = Bf16Smem<NK16, GROUPED, WIDE>::OG;
+  constexpr int kTileBytes = Bf16Smem<NK16, GROUPED, WIDE>::kTileBytes;
   constexpr int kTileFloats = kTileBytes / 4;
-  constexpr int kOS = Bf16Smem<NK16, GROUPED>::kOutStride;
+  constexpr int kOS = Bf16Smem<NK16, GROUPED, WIDE>::kOutStride;
   constexpr int KH = 8 * NK16;
   constexpr int NW = WIDE ? 8 : 4;    // waves per workgroup
   constexpr int NBUF = WIDE ? 3 : 2;  // tile buffers
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   const int wave = tid >> 6;
   const int lane = tid & 63;
   const int group = WIDE ? __builtin_amdgcn_readfirstlane(wave >> 2) : 0;
-  float *ost = abuf0 + NBUF * kTileFloats + wave * Bf16Smem<NK16, GROUPED>::kOutFloatsPerWave;
+  float *ost = abuf0 + NBUF * kTileFloats + wave * Bf16Smem<NK16, GROUPED, WIDE>::kOutFloatsPerWave;
   const int n = lane & 31;
   const int h = lane >> 5;  // K half of a slab held by this lane AND its row track
   const int64_t f0 = (int64_t)blockIdx.x * (NW * FRAMES_PER_WAVE) + wave * FRAMES_PER_WAVE;
@@ -919,7 +923,20 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
               const int cnt = (int)(closed - s_base);
               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
               __builtin_amdgcn_wave_barrier();
-              if (cnt == OG && f0 + FRAMES_PER_WAVE <= F) {
+              if (OG == 32 && cnt == OG && f0 + FRAMES_PER_WAVE <= F) {
+                // 8 lanes x 16 B cover the 32-state group; 8 frame rows per instruction
+                const int k4 = lane & 7, r8 = lane >> 3;
+                float *op = out + (f0 + r8) * pitch + s_base + 4 * k4;
+                const float *ip = ost + r8 * kOS + 4 * k4;  // stride 34: 8-byte aligned
+#pragma unroll
+                for (int i = 0; i < FRAMES_PER_WAVE / 8; i++) {
+                  const f32x2 lo = *(const f32x2 *)(ip + i * 8 * kOS);
+                  const f32x2 hi = *(const f32x2 *)(ip + i * 8 * kOS + 2);
+                  const f32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+                  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                  *(f32x4u *)(op + (int64_t)i * 8 * pitch) = v;
+                }
+              } else if (cnt == OG && f0 + FRAMES_PER_WAVE <= F) {
                 // 4 lanes x 16 B cover the 16-state group; 16 frame rows per instruction
                 const int k4 = lane & 3, r16 = lane >> 2;
                 float *op = out + (f0 + r16) * pitch + s_base + 4 * k4;
@@ -956,8 +973,8 @@ static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *
                           float *d_out, hipStream_t stream, const ClusterArgs &cl, int64_t pitch) {
   constexpr int NW = WIDE ? 8 : 4;
   const int64_t blocks = (F + NW * FRAMES_PER_WAVE - 1) / (NW * FRAMES_PER_WAVE);
-  const int smem = (WIDE ? 3 : 2) * Bf16Smem<NK16, GROUPED>::kTileBytes +
-                   NW * Bf16Smem<NK16, GROUPED>::kOutFloatsPerWave * 4;
+  const int smem = (WIDE ? 3 : 2) * Bf16Smem<NK16, GROUPED, WIDE>::kTileBytes +
+                   NW * Bf16Smem<NK16, GROUPED, WIDE>::kOutFloatsPerWave * 4;
   static const int dbg = getenv("AASR_DBG") ? atoi(getenv("AASR_DBG")) : 0;
   static bool attr_set[64] = {false};
   auto kern = k_gmm_diag_score_bf16x3<NK16, GROUPED, CL, WIDE>;
@@ -988,7 +1005,7 @@ static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *
 // the 8-wave form needs three tile buffers + eight staging areas in 160 KB of LDS
 template <int N>
 static constexpr bool wide_ok() {
-  return 3 * Bf16Smem<N, true>::kTileBytes + 8 * Bf16Smem<N, true>::kOutFloatsPerWave * 4 <= 160 * 1024;
+  return 3 * Bf16Smem<N, true, true>::kTileBytes + 8 * Bf16Smem<N, true, true>::kOutFloatsPerWave * 4 <= 160 * 1024;
 }
 
 static bool launch_bf16(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
@@ -1424,7 +1441,7 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
   // The two frames of a lane travel as one <2 x float>: t = x - mu, t*t, fma with p' are
   // v_pk_add / v_pk_mul / v_pk_fma_f32 (two frames per instruction, the scalar operand
   // broadcast) -- 1.5 VALU instructions per frame and dimension instead of 3, same roundings.
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
+
   f32x2 x2[DIMP];
 #pragma unroll
   for (int d = 0; d < DIMP; d++) {

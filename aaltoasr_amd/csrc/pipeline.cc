@@ -255,7 +255,7 @@ struct BlockRunner {
     d_fea.ensure((size_t)F * dim);
     // the score matrix never leaves the device: rows padded to whole 64-byte lines where the
     // scoring kernel can write them that way (every output group then is one full line)
-    const int64_t pitch = gmm_score_pitch_ok(gmm) ? (S + 15) / 16 * 16 : S;
+    const int64_t pitch = gmm_score_pitch_ok(gmm) ? (S + 31) / 32 * 32 : S;
     d_ll.ensure((size_t)F * pitch);
     d_bytes.ensure((size_t)F * S * lnabytes);
     feat_run_batch(feat, d_pcm.p, ub, (int)feat->mods.size() - 1, d_fea.p, nullptr, nullptr);

@@ -42,7 +42,7 @@ class FullChainBench:
         # the score matrix stays on the device: rows padded to whole 64-byte lines where the scoring
         # kernel can write them that way (what the C++ recipe driver does too)
         self.S = S
-        self.pitch = (S + 15) // 16 * 16 if gmm.score_pitch_ok() else S
+        self.pitch = (S + 31) // 32 * 32 if gmm.score_pitch_ok() else S
         self.d_ll = torch.empty((self.total_frames, self.pitch), dtype=torch.float32, device=device)
         self.d_bytes = torch.empty((self.total_frames, S * lnabytes), dtype=torch.uint8, device=device)
         self.stream = torch.cuda.current_stream()

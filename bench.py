@@ -163,9 +163,9 @@ def main():
         gen.manual_seed(synth.SEED + 17 * rank)
         d_frames = torch.randn((F, DIM), generator=gen, device=dev, dtype=torch.float32)
         # output rows either dense (pitch S, what aasr_gmm_score hands to a host caller) or padded to
-        # whole 64-byte lines (pitch S rounded up to 16 floats: the layout the device-resident chain
+        # whole 128-byte lines (pitch S rounded up to 32 floats: the layout the device-resident chain
         # aasr_gmm_score_dev_pitched -> aasr_lna_encode_dev_pitched uses)
-        pitch = (S + 15) // 16 * 16 if (args.out_pitch == "aligned" and gmm.score_pitch_ok()) else S
+        pitch = (S + 31) // 32 * 32 if (args.out_pitch == "aligned" and gmm.score_pitch_ok()) else S
         d_out = torch.empty((F, pitch), device=dev, dtype=torch.float32)
         workload = "configs[1]: batched diag-GMM log-likelihood, %d x %d-d frames x %d Gaussians (%d states x %d), output row pitch %d floats" % (
             F, DIM, G, S, COMPS, pitch)
