@@ -263,9 +263,9 @@ aasr_status aasr_gmm_score_dev(aasr_gmm *h, const float *d_frames, int64_t F,
 /* PDFPool::precompute_likelihoods (aku/Distributions.cc:2647-2682): the
  * log-likelihood of every pool Gaussian, float32 [F x G]. */
 /* The same with a row pitch (floats between consecutive frame rows, >= S) for callers that keep the
- * score matrix on the device: rows padded to a multiple of 16 floats turn every 64-byte output
- * group of the scoring kernel into one whole cache line (1.2 ms of 34 per 10^6 frames x 50 k
- * Gaussians).  Only the bf16x3 track kernels write pitched rows: aasr_gmm_score_pitch_ok() says
+ * score matrix on the device: rows padded to a multiple of 32 floats turn every 128-byte output
+ * group of the scoring kernel into one whole L2 line (1.1 ms of 32.4 per 10^6 frames x 50 k
+ * Gaussians, a quarter less HBM write traffic).  Only the bf16x3 track kernels write pitched rows: aasr_gmm_score_pitch_ok() says
  * whether this model / precision does; otherwise pitch must equal the state count. */
 int aasr_gmm_score_pitch_ok(const aasr_gmm *h);
 aasr_status aasr_gmm_score_dev_pitched(aasr_gmm *h, const float *d_frames, int64_t F,
