@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
     const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
     const float *__restrict__ apack, const int32_t *__restrict__ split_row,
     const uint16_t *__restrict__ close_mask, const int32_t *__restrict__ sid, int sid_stride,
-    float *__restrict__ out, int64_t S, float ref_ln, int dbg, ClusterArgs cl) {
+    float *__restrict__ out, int64_t S, int64_t pitch, float ref_ln, int dbg, ClusterArgs cl) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float *smem = (float *)smem_raw;
   constexpr int OG = TRACK_OUT_GROUP;
@@ -412,8 +412,8 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
   int closes = split_row[4 * blockIdx.y + 1 + (GROUPED ? 0 : h)];
   const int32_t *my_sid = sid + h * sid_stride;
   int next_sid = GROUPED ? 0 : my_sid[closes];
-  float *orow0 = out + (f0 + n) * S;       // !GROUPED: this lane's two output rows
-  float *orow1 = out + (f0 + 32 + n) * S;
+  float *orow0 = out + (f0 + n) * pitch;       // !GROUPED: this lane's two output rows
+  float *orow1 = out + (f0 + 32 + n) * pitch;
   const bool ok0 = f0 + n < F, ok1 = f0 + 32 + n < F;
   const float floor_val = CL ? cl.floor_val : LOG_TINY_F;
   // this wave's 64 frames are one word of the selection masks
@@ -535,14 +535,14 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
                 // full group: each lane moves 4 consecutive states (16 B) of one
                 // frame row; 8 lanes cover the 32-state group, 8 rows per instruction
                 const int k4 = lane & 7, r8 = lane >> 3;
-                float *op = out + (f0 + r8) * S + s_base + 4 * k4;
+                float *op = out + (f0 + r8) * pitch + s_base + 4 * k4;
                 const float *ip = ost + r8 * kOS + 4 * k4;
 #pragma unroll
                 for (int i = 0; i < FRAMES_PER_WAVE / 8; i++) {
                   const f32x4 v = *(const f32x4 *)(ip + i * 8 * kOS);
                   // rows of the [F x S] output are only 4-byte aligned
                   typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-                  *(f32x4u *)(op + (int64_t)i * 8 * S) = v;
+                  *(f32x4u *)(op + (int64_t)i * 8 * pitch) = v;
                 }
               } else {
                 constexpr int RPI = 64 / OG;  // frame rows per store instruction
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
                 for (int i = 0; i < FRAMES_PER_WAVE / RPI; i++) {
                   const int row = i * RPI + lane / OG;
                   const float v = ost[row * kOS + k];
-                  if (k < cnt && f0 + row < F) out[(f0 + row) * S + s_base + k] = v;
+                  if (k < cnt && f0 + row < F) out[(f0 + row) * pitch + s_base + k] = v;
                 }
               }
               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -566,7 +566,8 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
 
 template <int NKK, bool GROUPED, bool CL>
 static void launch_tracks_t(const aasr_gmm *g, const TrackLayout &L, const float *d_frames,
-                            int64_t F, float *d_out, hipStream_t stream, const ClusterArgs &cl) {
+                            int64_t F, float *d_out, hipStream_t stream, const ClusterArgs &cl,
+                            int64_t pitch) {
   const int64_t blocks = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
   const int smem = TrackSmem<NKK, GROUPED>::kBytes;
   static const int dbg = getenv("AASR_DBG") ? atoi(getenv("AASR_DBG")) : 0;
@@ -594,22 +595,24 @@ static void launch_tracks_t(const aasr_gmm *g, const TrackLayout &L, const float
   const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(256), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, L.rows.a.p, split_row, L.close.p, L.sid.p, L.sid_stride,
-                     d_out, g->S, L.ref_ln - (float)g->out_bias_ln, dbg, cl);
+                     d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, dbg, cl);
   AASR_HIP(hipGetLastError());
 }
 
 static bool launch_tracks(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
-                          float *d_out, hipStream_t stream, const ClusterArgs *cl = nullptr) {
+                          float *d_out, hipStream_t stream, const ClusterArgs *cl = nullptr,
+                          int64_t pitch = 0) {
+  if (pitch <= 0) pitch = g->S;
   const ClusterArgs none;
   switch (L.rows.nkk) {
 #define AASR_CASE(N)                                                                        \
   case N:                                                                                   \
     if (cl) {                                                                               \
-      if (L.grouped) launch_tracks_t<N, true, true>(g, L, d_frames, F, d_out, stream, *cl); \
-      else launch_tracks_t<N, false, true>(g, L, d_frames, F, d_out, stream, *cl);          \
+      if (L.grouped) launch_tracks_t<N, true, true>(g, L, d_frames, F, d_out, stream, *cl, pitch); \
+      else launch_tracks_t<N, false, true>(g, L, d_frames, F, d_out, stream, *cl, pitch);          \
     } else {                                                                                \
-      if (L.grouped) launch_tracks_t<N, true, false>(g, L, d_frames, F, d_out, stream, none); \
-      else launch_tracks_t<N, false, false>(g, L, d_frames, F, d_out, stream, none);        \
+      if (L.grouped) launch_tracks_t<N, true, false>(g, L, d_frames, F, d_out, stream, none, pitch); \
+      else launch_tracks_t<N, false, false>(g, L, d_frames, F, d_out, stream, none, pitch);        \
     }                                                                                       \
     return true;
     AASR_CASE(8) AASR_CASE(14) AASR_CASE(20) AASR_CASE(26) AASR_CASE(32) AASR_CASE(40)
@@ -1783,9 +1786,10 @@ static void add_output_bias(const aasr_gmm *g, float *d_out, int64_t F, hipStrea
 bool gmm_score_pitch_ok(const aasr_gmm *g) {
   if (g->cl.enabled || g->host.factor_path() || g->hyb_enabled || g->ill_conditioned || g->class_routing)
     return false;
-  if (!g->use_bf16x3 || g->precision != AASR_PREC_BF16X3 || (g->layout_mask & 3) != 3) return false;
+  if ((g->layout_mask & 3) != 3) return false;
   const TrackLayout &L = g->paired.ok ? g->paired : g->tracks;
-  return L.ok && L.a16.p != nullptr;
+  // both track kernels (f32 and bf16x3) take a row pitch; the centred kernel does not
+  return (g->precision == AASR_PREC_F32 || g->precision == AASR_PREC_BF16X3) && L.ok;
 }
 
 void gmm_score_launch_pitched(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, int64_t pitch,
@@ -1796,7 +1800,7 @@ void gmm_score_launch_pitched(aasr_gmm *g, const float *d_frames, int64_t F, flo
     return;
   }
   if (pitch < g->S || !gmm_score_pitch_ok(g))
-    raise(AASR_ERR_UNSUPPORTED, "a row pitch other than the state count needs the bf16x3 track kernels");
+    raise(AASR_ERR_UNSUPPORTED, "a row pitch other than the state count needs the track kernels");
   if (g->xf_a.p) {
     g->d_xframes.ensure((size_t)F * g->dim);
     const int64_t n = F * g->dim;
@@ -1806,8 +1810,9 @@ void gmm_score_launch_pitched(aasr_gmm *g, const float *d_frames, int64_t F, flo
     d_frames = g->d_xframes.p;
   }
   const TrackLayout &L = g->paired.ok ? g->paired : g->tracks;
-  if (!launch_bf16(g, L, d_frames, F, d_out, stream, nullptr, pitch))
-    raise(AASR_ERR_UNSUPPORTED, "no bf16x3 kernel instance for this model");
+  const bool done = (g->use_bf16x3 && launch_bf16(g, L, d_frames, F, d_out, stream, nullptr, pitch)) ||
+                    launch_tracks(g, L, d_frames, F, d_out, stream, nullptr, pitch);
+  if (!done) raise(AASR_ERR_UNSUPPORTED, "no track kernel instance for this model");
 }
 
 void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,

@@ -265,7 +265,7 @@ aasr_status aasr_gmm_score_dev(aasr_gmm *h, const float *d_frames, int64_t F,
 /* The same with a row pitch (floats between consecutive frame rows, >= S) for callers that keep the
  * score matrix on the device: rows padded to a multiple of 32 floats turn every 128-byte output
  * group of the scoring kernel into one whole L2 line (1.1 ms of 32.4 per 10^6 frames x 50 k
- * Gaussians, a quarter less HBM write traffic).  Only the bf16x3 track kernels write pitched rows: aasr_gmm_score_pitch_ok() says
+ * Gaussians, a quarter less HBM write traffic).  Only the track kernels (f32 and bf16x3) write pitched rows: aasr_gmm_score_pitch_ok() says
  * whether this model / precision does; otherwise pitch must equal the state count. */
 int aasr_gmm_score_pitch_ok(const aasr_gmm *h);
 aasr_status aasr_gmm_score_dev_pitched(aasr_gmm *h, const float *d_frames, int64_t F,

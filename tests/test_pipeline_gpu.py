@@ -132,17 +132,25 @@ def test_pitched_scores_and_lna_equal_the_dense_path(capi):
         fr = torch.from_numpy(synth.make_frames(F, seed=F)).cuda()
         dense = torch.empty((F, 101), dtype=torch.float32, device="cuda")
         g.score_dev(fr, dense)
-        padded = torch.full((F, 112), -7.0, dtype=torch.float32, device="cuda")
-        g.score_dev_pitched(fr, padded, 112)
-        torch.cuda.synchronize()
-        assert torch.equal(padded[:, :101], dense) and bool((padded[:, 101:] == -7.0).all())
+        for pitch in (128, 103, 112):        # whole 128-byte lines, odd, half lines
+            padded = torch.full((F, pitch), -7.0, dtype=torch.float32, device="cuda")
+            g.score_dev_pitched(fr, padded, pitch)
+            torch.cuda.synchronize()
+            assert torch.equal(padded[:, :101], dense) and bool((padded[:, 101:] == -7.0).all())
         by_d = torch.empty((F, 202), dtype=torch.uint8, device="cuda")
         by_p = torch.empty((F, 202), dtype=torch.uint8, device="cuda")
         capi.lna_encode_dev(dense, True, 2, None, by_d)
         capi.lna_encode_dev(padded, True, 2, None, by_p, num_states=101)
         torch.cuda.synchronize()
         assert torch.equal(by_d, by_p)
-    g.set_precision(0)                       # the f32 kernels write dense rows only
+    g.set_precision(0)                       # the f32 track kernel takes a pitch too
+    assert g.score_pitch_ok()
+    g.score_dev(fr, dense)
+    padded = torch.full((F, 128), -7.0, dtype=torch.float32, device="cuda")
+    g.score_dev_pitched(fr, padded, 128)
+    torch.cuda.synchronize()
+    assert torch.equal(padded[:, :101], dense) and bool((padded[:, 101:] == -7.0).all())
+    g.set_precision(2)                       # the centred kernel writes dense rows only
     assert not g.score_pitch_ok()
     with pytest.raises(capi.AasrError):
-        g.score_dev_pitched(fr, padded, 112)
+        g.score_dev_pitched(fr, padded, 128)
