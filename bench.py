@@ -116,26 +116,34 @@ def main():
     if args.cpu_worker > 0:
         cpu_worker(args.cpu_worker)
         return
+    # stdout carries exactly one JSON line: anything native libraries print there (RCCL's version
+    # banner, rocm-smi) is sent to stderr for the life of the process
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # AASR_BENCH_FORCE_DIST=1 takes the multi-rank code path (RCCL init, model broadcast, barrier,
+    # max-over-ranks) at world size 1 too, so it can be exercised on a one-GPU box under torchrun
+    distributed = world > 1 or os.environ.get("AASR_BENCH_FORCE_DIST") == "1"
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: there is no CPU fallback for the product path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if distributed:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from aaltoasr_amd import build, capi, synth
     if rank == 0:
         build.build()
-    if world > 1:
+    if distributed:
         dist.barrier()
     capi.check(capi.lib().aasr_set_device(local_rank))
 
@@ -147,7 +155,7 @@ def main():
         model = dict(zip(names, synth.make_model(D=DIM, G=G, S=S, comps=COMPS)))
     else:
         model = dict.fromkeys(names)
-    if world > 1:
+    if distributed:
         from aaltoasr_amd import shard
         model = shard.broadcast_model(model, src=0, device=dev)
     mean, var, off, idx, w = (model[k] for k in names)
@@ -188,7 +196,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -200,7 +208,7 @@ def main():
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -293,8 +301,9 @@ def main():
                        "states": S, "components_per_state": COMPS, "sharding": "frames/utterances per rank, no collective"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 
