@@ -231,6 +231,8 @@ struct aasr_gmm {
   std::vector<aasr::DevBuf<double>> class_a, class_b;     // per class: A [dim x dim], b [dim]
   std::vector<double> class_logdet;                       // log |prod diag A|; -inf = class contributes nothing
   aasr::DevBuf<float> class_scratch, class_xframes;
+  // device buffers of aasr_run_utterance, kept between calls (pipeline.cc: BlockRunner)
+  std::shared_ptr<void> utt_scratch;
   // global CMLLR transform applied to the frames before scoring
   aasr::DevBuf<double> xf_a, xf_b;
   aasr::DevBuf<float> d_xframes;

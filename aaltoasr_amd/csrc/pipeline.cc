@@ -219,9 +219,11 @@ struct Job {
 };
 
 struct BlockRunner {
-  aasr_feat *feat;
-  aasr_gmm *gmm;
-  int lnabytes, normalize;
+  aasr_feat *feat = nullptr;
+  aasr_gmm *gmm = nullptr;
+  int lnabytes = 2, normalize = 1;
+  BlockRunner() = default;
+  BlockRunner(aasr_feat *f, aasr_gmm *g, int lb, int nz) : feat(f), gmm(g), lnabytes(lb), normalize(nz) {}
   DevBuf<int16_t> d_pcm;
   DevBuf<float> d_fea, d_ll;
   DevBuf<uint8_t> d_bytes;
@@ -555,9 +557,12 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
   }
 }
 
+// One utterance through the whole path.  The packed rows are copied from the device straight into
+// the malloc'ed result (header + rows); the device buffers live on the model handle between calls
+// (a decoder front-end calls this once per utterance: no allocation after the first call of a size).
 void run_utterance(aasr_feat *feat, aasr_gmm *gmm, const int16_t *pcm, int64_t n_samples,
                    int32_t start_frame, int32_t end_frame, int normalize, int lnabytes,
-                   std::vector<uint8_t> *lna, int64_t *frames_out) {
+                   uint8_t **lna_out, int64_t *lna_len, int64_t *frames_out) {
   if (lnabytes != 2 && lnabytes != 4) raise(AASR_ERR_INVALID, "Invalid number of LNA bytes");
   if (gmm->dim != feat->mods.back().dim)
     raise(AASR_ERR_INVALID, "Gaussian dimension is %d but feature dimension is %d.", gmm->dim,
@@ -571,12 +576,28 @@ void run_utterance(aasr_feat *feat, aasr_gmm *gmm, const int16_t *pcm, int64_t n
   int stop = std::min(end_frame, eof_frame);
   j.start = start_frame;
   j.count = stop > start_frame ? stop - start_frame : 0;
-  BlockRunner br{feat, gmm, lnabytes, normalize};
-  std::vector<Job *> jobs{&j};
-  br.run(jobs);
-  lna->resize(5 + br.h_bytes.size());
-  aasr_lna_header((int32_t)gmm->S, lnabytes, lna->data());
-  if (!br.h_bytes.empty()) memcpy(lna->data() + 5, br.h_bytes.data(), br.h_bytes.size());
+  std::shared_ptr<BlockRunner> br = std::static_pointer_cast<BlockRunner>(gmm->utt_scratch);
+  if (!br) {
+    br = std::make_shared<BlockRunner>();
+    gmm->utt_scratch = br;
+  }
+  br->feat = feat;
+  br->gmm = gmm;
+  br->lnabytes = lnabytes;
+  br->normalize = normalize;
+  const size_t nb = (size_t)j.count * (size_t)gmm->S * (size_t)lnabytes;
+  uint8_t *out = (uint8_t *)malloc(5 + nb);
+  if (!out) raise(AASR_ERR_INVALID, "out of memory");
+  try {
+    aasr_lna_header((int32_t)gmm->S, lnabytes, out);
+    std::vector<Job *> jobs{&j};
+    br->run(jobs, out + 5, nb);
+  } catch (...) {
+    free(out);
+    throw;
+  }
+  *lna_out = out;
+  *lna_len = (int64_t)(5 + nb);
   *frames_out = j.count;
 }
 
@@ -632,13 +653,9 @@ aasr_status aasr_run_utterance(aasr_feat *feat, aasr_gmm *gmm, const int16_t *pc
   return guarded([&] {
     if (!feat || !gmm || !pcm || !lna_out || !lna_len)
       raise(AASR_ERR_INVALID, "aasr_run_utterance: null argument");
-    std::vector<uint8_t> lna;
     int64_t frames = 0;
-    run_utterance(feat, gmm, pcm, n_samples, start_frame, end_frame, normalize, lnabytes, &lna, &frames);
-    *lna_out = (uint8_t *)malloc(lna.size());
-    if (!*lna_out) raise(AASR_ERR_INVALID, "out of memory");
-    memcpy(*lna_out, lna.data(), lna.size());
-    *lna_len = (int64_t)lna.size();
+    run_utterance(feat, gmm, pcm, n_samples, start_frame, end_frame, normalize, lnabytes, lna_out, lna_len,
+                  &frames);
     if (frames_out) *frames_out = frames;
   });
 }
