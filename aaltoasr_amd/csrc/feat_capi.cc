@@ -1,6 +1,8 @@
 // feat_capi.cc -- extern "C" entry points of the feature chain (include/aasr.h).
 #include <cstring>
 
+#include <algorithm>
+
 #include "feat.h"
 
 using namespace aasr;
@@ -35,7 +37,26 @@ void run_host(aasr_feat *h, const int16_t *pcm, int64_t n_samples, int32_t first
   const int target = resolve_target(h, module_name);
   const int dim = h->mods[target].dim;
   h->d_pcm.ensure((size_t)n_samples);
-  AASR_HIP(hipMemcpy(h->d_pcm.p, pcm, (size_t)n_samples * sizeof(int16_t), hipMemcpyHostToDevice));
+  // Only the samples the requested frames can reach go to the device (at their absolute offsets): a
+  // caller walking a long file block by block (aku::FeatureGenerator::generate) uploads each part
+  // once instead of the whole file per block.  Reach = the graph's accumulated look-around, frames
+  // the lower end clamped to [0, last_frame] like AudioFileModule's border copy, two frames of slack.
+  int64_t s0 = 0, s1 = n_samples;
+  const FeatModule &a = h->mods[0];
+  if (a.type != MOD_PRE && n_samples >= a.width + 1) {
+    int l = 0, r = 0;
+    feat_halo(h, target, &l, &r);
+    const int64_t last = std::max(0, feat_last_frame(h, n_samples));
+    auto clampf = [&](int64_t f) { return std::min(std::max<int64_t>(f, 0), last); };
+    const int64_t f_lo = clampf((int64_t)first_frame - l - 2);
+    // upper end unclamped (the sample bound does it): without copy_borders, frames past the last
+    // whole one read the tail of the file
+    const int64_t f_hi = std::max<int64_t>(0, (int64_t)first_frame + n_frames - 1 + r + 2);
+    s0 = std::max<int64_t>(0, (int64_t)((double)f_lo * (double)a.advance) - 2);
+    s1 = std::min<int64_t>(n_samples, (int64_t)((double)f_hi * (double)a.advance) + a.width + 4);
+  }
+  if (s1 > s0)
+    AASR_HIP(hipMemcpy(h->d_pcm.p + s0, pcm + s0, (size_t)(s1 - s0) * sizeof(int16_t), hipMemcpyHostToDevice));
   UttBatch b = single(n_samples, first_frame, n_frames);
   const size_t n = (size_t)n_frames * dim;
   if (sizeof(T) == 4) {

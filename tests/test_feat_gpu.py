@@ -343,3 +343,26 @@ def test_adaptation_modules_match_oracle(capi, oracle, vtln_opts, params):
         ch.set_parameters(mod, {})
         ft.set_parameters(mod, "{\n}\n")
     assert np.array_equal(ft.run(pcm, -6, 70, dtype=np.float64), base)
+
+
+def test_block_requests_upload_only_their_samples(capi):
+    """aasr_feat_run sends only the samples a block of frames can reach to the device.  A handle whose
+    device buffer holds another recording everywhere else must give the bits of a handle that saw the
+    whole file: blocks at the start, in the middle, across the end, negative and post-EOF frames."""
+    from aaltoasr_amd import synth
+    cfg = os.path.join(os.path.dirname(__file__), "golden", "mfcc_cms_norm.feaconf")
+    pcm = synth.make_audio(16000 * 40, seed=41)
+    other = synth.make_audio(16000 * 40, seed=42)
+    whole = capi.Feat.from_file(cfg)
+    last = whole.last_frame(len(pcm))
+    ref = whole.run(pcm, -60, last + 1 + 120, dtype=np.float64)      # frames -60 .. last+59
+    part = capi.Feat.from_file(cfg)
+    for first, n in ((-60, 70), (0, 1), (1000, 256), (2499, 3), (last - 100, 160), (last + 5, 20), (-3, last + 10)):
+        part.run(other, 0, last + 1, dtype=np.float64)               # poison the device copy
+        got = part.run(pcm, first, n, dtype=np.float64)
+        assert np.array_equal(got, ref[first + 60:first + 60 + n]), (first, n)
+        for name in ("fft", "mel"):
+            a = part.run(other, 0, 8, module=name)
+            g2 = part.run(pcm, first, min(n, 40), module=name)
+            w2 = whole.run(pcm, first, min(n, 40), module=name)
+            assert np.array_equal(g2, w2), (name, first)
