@@ -115,6 +115,9 @@ def _declare(L: C.CDLL) -> None:
     L.aasr_gmm_expanded_rows.restype = i64
     L.aasr_gmm_write_cache.argtypes = [vp, cp]
     L.aasr_gmm_create_from_cache.argtypes = [cp, C.POINTER(vp)]
+    L.aasr_gmm_create_from_cache_checked.argtypes = [cp, cp, cp, cp, C.POINTER(vp)]
+    L.aasr_recipe_frame_limits.argtypes = [C.c_float, C.c_float, C.c_float, C.POINTER(i32), C.POINTER(i32)]
+    L.aasr_recipe_frame_limits.restype = None
     L.aasr_gmm_set_precision.argtypes = [vp, C.c_int]
     L.aasr_gmm_set_cmllr.argtypes = [vp, i32, vp, vp]
     L.aasr_gmm_read_clustering.argtypes = [vp, cp]
@@ -233,6 +236,14 @@ class Gmm:
     def from_cache(cls, path: str) -> "Gmm":
         h = C.c_void_p()
         check(lib().aasr_gmm_create_from_cache(path.encode(), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_cache_checked(cls, path: str, gk: str, mc: str, ph: Optional[str] = None) -> "Gmm":
+        """The cache, if it was written from exactly these text files (else AasrError 'stale')."""
+        h = C.c_void_p()
+        check(lib().aasr_gmm_create_from_cache_checked(path.encode(), gk.encode(), mc.encode(),
+                                                       ph.encode() if ph else None, C.byref(h)))
         return cls(h.value)
 
     def write_cache(self, path: str) -> None:
@@ -485,6 +496,13 @@ def recipe_batch_range(total: int, num_batches: int, batch_index: int):
     return f.value, n.value
 
 
+def recipe_frame_limits(start_time: float, end_time: float, frame_rate: float):
+    """(start_frame, end_frame) of aku/phone_probs.cc:199-206, float arithmetic."""
+    a, b = C.c_int32(), C.c_int32()
+    lib().aasr_recipe_frame_limits(start_time, end_time, frame_rate, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
 def recipe_read(text, num_batches: int = 0, batch_index: int = 0):
     """Recipe::read on the host: list of (audio, lna, speaker, utterance, start_time, end_time)."""
     out = C.c_void_p()
@@ -498,7 +516,9 @@ def recipe_read(text, num_batches: int = 0, batch_index: int = 0):
     rows = []
     for line in table.split(b"\n")[:-1]:
         f = line.split(b"\x1f")
-        rows.append(tuple(x.decode("latin-1") for x in f[:4]) + (float(f[4]), float(f[5])))
+        # the times are float fields printed with 9 significant digits: exact through float32
+        rows.append(tuple(x.decode("latin-1") for x in f[:4]) +
+                    (float(np.float32(float(f[4]))), float(np.float32(float(f[5])))))
     return rows
 
 

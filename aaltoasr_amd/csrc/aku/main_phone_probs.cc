@@ -8,6 +8,7 @@
 // One process drives one GPU (--device N or
 // HIP_VISIBLE_DEVICES); run N processes with -B N -I k for N GPUs, exactly as
 // the reference scales over CPU cores.
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -89,9 +90,13 @@ int main(int argc, char *argv[]) {
   aasr_gmm *gmm = nullptr;
   if (aasr_feat_create(ss.str().c_str(), &feat) != AASR_OK) die(aasr_last_error());
   // --model-cache FILE (new): binary image of the parsed model; created on the first run
-  if (!model_cache.empty() && aasr_gmm_create_from_cache(model_cache.c_str(), &gmm) == AASR_OK) {
+  // and whenever it does not match the .gk/.mc/.ph named on the command line
+  if (!model_cache.empty() &&
+      aasr_gmm_create_from_cache_checked(model_cache.c_str(), gk.c_str(), mc.c_str(), ph.c_str(), &gmm) == AASR_OK) {
     if (info > 0) printf("Model read from cache %s\n", model_cache.c_str());
   } else {
+    if (!model_cache.empty() && access(model_cache.c_str(), F_OK) == 0)
+      fprintf(stderr, "WARNING: not using the model cache: %s\n", aasr_last_error());
     if (aasr_gmm_create_from_files(gk.c_str(), mc.c_str(), ph.c_str(), &gmm) != AASR_OK)
       die(aasr_last_error());
     if (!model_cache.empty() && aasr_gmm_write_cache(gmm, model_cache.c_str()) != AASR_OK)

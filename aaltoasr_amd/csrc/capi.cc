@@ -150,6 +150,8 @@ aasr_status aasr_gmm_create_from_files(const char *gk_path, const char *mc_path,
       raise(AASR_ERR_INVALID, "aasr_gmm_create_from_files: null argument");
     *out = nullptr;
     HostModel m = read_model_files(gk_path, mc_path, ph_path);
+    model_files_fingerprint(gk_path, mc_path, ph_path, m.src_fp);
+    m.has_src_fp = true;
     aasr_gmm *g = new aasr_gmm();
     try {
       AASR_HIP(hipGetDevice(&g->device));
@@ -174,6 +176,25 @@ aasr_status aasr_gmm_create_from_cache(const char *cache_path, aasr_gmm **out) {
     if (!out || !cache_path) raise(AASR_ERR_INVALID, "aasr_gmm_create_from_cache: null argument");
     *out = nullptr;
     HostModel m = read_model_cache(cache_path);
+    aasr_gmm *g = new aasr_gmm();
+    try {
+      AASR_HIP(hipGetDevice(&g->device));
+      gmm_build(g, m);
+    } catch (...) {
+      delete g;
+      throw;
+    }
+    *out = g;
+  });
+}
+
+aasr_status aasr_gmm_create_from_cache_checked(const char *cache_path, const char *gk_path,
+                                               const char *mc_path, const char *ph_path, aasr_gmm **out) {
+  return guarded([&] {
+    if (!out || !cache_path || !gk_path || !mc_path)
+      raise(AASR_ERR_INVALID, "aasr_gmm_create_from_cache_checked: null argument");
+    *out = nullptr;
+    HostModel m = read_model_cache_checked(cache_path, gk_path, mc_path, ph_path);
     aasr_gmm *g = new aasr_gmm();
     try {
       AASR_HIP(hipGetDevice(&g->device));

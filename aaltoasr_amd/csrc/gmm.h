@@ -53,12 +53,19 @@ struct HostModel {
   std::vector<int32_t> mix_idx;         // [K]
   std::vector<double> mix_w;            // [K] (as read; normalised by the first build)
   bool weights_normalized = false;      // Mixture::normalize_weights already applied
+  // fingerprint of the text files the model was parsed from: (size, FNV-1a of the content) of
+  // .gk, .mc, .ph (zeros for an absent .ph); carried into the binary cache so that a cache is
+  // only trusted for the files it was written from
+  bool has_src_fp = false;
+  uint64_t src_fp[6] = {0, 0, 0, 0, 0, 0};
 };
+void model_files_fingerprint(const char *gk, const char *mc, const char *ph, uint64_t fp[6]);
 
 HostModel read_model_files(const char *gk, const char *mc, const char *ph);
 // model_cache.cc: parsed model <-> one binary blob (magic, sizes, arrays, FNV-1a checksum)
 void write_model_cache(const HostModel &m, const char *path);
 HostModel read_model_cache(const char *path);
+HostModel read_model_cache_checked(const char *path, const char *gk, const char *mc, const char *ph);
 
 // Rows of the streamed operand are processed in tiles of TILE_ROWS; the
 // epilogue reduces them in chunks of CHUNK_ROWS (one 32x32 MFMA block).

@@ -146,9 +146,9 @@ std::vector<RecipeInfo> recipe_read(const std::string &text, int num_batches, in
     get("speaker", info.speaker_id);
     get("utterance", info.utterance_id);
     auto it = kv.find("start-time");
-    if (it != kv.end()) info.start_time = atof(it->second.c_str());
+    if (it != kv.end()) info.start_time = (float)atof(it->second.c_str());
     it = kv.find("end-time");
-    if (it != kv.end()) info.end_time = atof(it->second.c_str());
+    if (it != kv.end()) info.end_time = (float)atof(it->second.c_str());
     infos.push_back(info);
   }
   return infos;
@@ -275,14 +275,21 @@ struct BlockRunner {
   }
 };
 
-static void frame_range(aasr_feat *feat, int64_t n_samples, double start_time, double end_time,
+static void frame_limits(float start_time, float end_time, float fr, int *start_frame, int *end_frame) {
+  // (int)(time * frame_rate) (aku/phone_probs.cc:199-206): both operands are float there
+  // (Recipe::Info::start_time, FeatureGenerator::frame_rate()), so the product is rounded to
+  // float before the truncation -- 2.008 s * 125 is frame 250, not 251
+  volatile float start_prod = start_time * fr, end_prod = end_time * fr;
+  *start_frame = (int)start_prod;
+  *end_frame = (int)end_prod;
+  if (*end_frame == 0) *end_frame = INT_MAX;
+}
+
+static void frame_range(aasr_feat *feat, int64_t n_samples, float start_time, float end_time,
                         int32_t *start, int32_t *count) {
-  // start/end frame = (int)(time * frame_rate) (aku/phone_probs.cc:199-206); the
-  // loop stops at the first frame for which AudioFileModule::eof() holds
-  float fr = feat->mods[0].frame_rate;
-  int start_frame = (int)(start_time * fr);
-  int end_frame = (int)(end_time * fr);
-  if (end_frame == 0) end_frame = INT_MAX;
+  // the loop stops at the first frame for which AudioFileModule::eof() holds
+  int start_frame, end_frame;
+  frame_limits(start_time, end_time, feat->mods[0].frame_rate, &start_frame, &end_frame);
   if (feat->mods[0].type != MOD_PRE && n_samples < feat->mods[0].width + 1)
     raise(AASR_ERR_SHORT_AUDIO, "audio shorter than frame");
   int eof_frame = feat_last_frame(feat, n_samples) + 1;
@@ -369,6 +376,10 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
     }
   } pinned_free{pinned};
 
+  // The reader only looks at the base module (mods[0]: sample rate, byte order, window, frame
+  // rate); set_parameters is a no-op for audiofile / pre (FeatureModule::set_parameters,
+  // aku/FeatureModule.hh:107), so the speaker settings applied by this thread never touch what
+  // the read-ahead uses.
   std::thread reader([&] {
     for (size_t ri = 0; ri < infos.size(); ri++) {
       Item it;
@@ -517,7 +528,15 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
       }
       inq.cv.notify_all();
       if (it.end) break;
-      if (it.error) std::rethrow_exception(it.error);
+      if (it.error) {
+        // the reference has written every LNA before the failing recipe line when it aborts:
+        // finish what is queued, then report the original error
+        try {
+          flush();
+        } catch (...) {
+        }
+        std::rethrow_exception(it.error);
+      }
       const RecipeInfo &info = infos[it.job.info_index];
       if (opt.speakers) {  // aku/phone_probs.cc:191-196
         spkc_set_speaker(opt.speakers, info.speaker_id);
@@ -619,6 +638,14 @@ aasr_status aasr_recipe_batch_range(int32_t num_lines_total, int32_t num_batches
   });
 }
 
+void aasr_recipe_frame_limits(float start_time, float end_time, float frame_rate, int32_t *start_frame,
+                              int32_t *end_frame) {
+  int a, b;
+  aasr::frame_limits(start_time, end_time, frame_rate, &a, &b);
+  if (start_frame) *start_frame = a;
+  if (end_frame) *end_frame = b;
+}
+
 aasr_status aasr_recipe_read(const char *recipe_text, int32_t num_batches, int32_t batch_index,
                              char **table_out, int64_t *table_len) {
   return guarded([&] {
@@ -627,7 +654,7 @@ aasr_status aasr_recipe_read(const char *recipe_text, int32_t num_batches, int32
     char num[64];
     for (const RecipeInfo &i : recipe_read(recipe_text, num_batches, batch_index)) {
       t += i.audio_path + "\x1f" + i.lna_path + "\x1f" + i.speaker_id + "\x1f" + i.utterance_id + "\x1f";
-      snprintf(num, sizeof num, "%.17g\x1f%.17g\n", i.start_time, i.end_time);
+      snprintf(num, sizeof num, "%.9g\x1f%.9g\n", (double)i.start_time, (double)i.end_time);
       t += num;
     }
     char *out = (char *)malloc(t.size() + 1);

@@ -10,7 +10,8 @@ namespace aasr {
 // the fields of aku::Recipe::Info the hot path consumes (aku/Recipe.hh)
 struct RecipeInfo {
   std::string audio_path, lna_path, speaker_id, utterance_id;
-  double start_time = 0, end_time = 0;
+  // float, as Recipe::Info (aku/Recipe.hh:48-49): atof narrowed on assignment
+  float start_time = 0, end_time = 0;
 };
 
 std::string str_clean(const std::string &s, const char *chars);

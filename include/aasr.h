@@ -182,6 +182,14 @@ aasr_status aasr_gmm_create_from_files(const char *gk_path, const char *mc_path,
  * 50 000-Gaussian pool, paid by every per-GPU process of a run) is skipped. */
 aasr_status aasr_gmm_write_cache(const aasr_gmm *h, const char *cache_path);
 aasr_status aasr_gmm_create_from_cache(const char *cache_path, aasr_gmm **out);
+/* The same, for a caller that names the text files too (phone_probs --model-cache):
+ * a cache records (size, content hash) of the .gk/.mc/.ph it was written from and
+ * is refused (AASR_ERR_INVALID, "stale model cache") when they differ from the
+ * files given here -- retraining, or another -b next to the same cache path, then
+ * falls back to aasr_gmm_create_from_files instead of scoring with the old model. */
+aasr_status aasr_gmm_create_from_cache_checked(const char *cache_path, const char *gk_path,
+                                               const char *mc_path, const char *ph_path,
+                                               aasr_gmm **out);
 void aasr_gmm_destroy(aasr_gmm *h);
 
 int aasr_gmm_dim(const aasr_gmm *h);            /* HmmSet::dim()        */
@@ -318,11 +326,20 @@ aasr_status aasr_recipe_batch_range(int32_t num_lines_total, int32_t num_batches
 /* Recipe::read itself (aku/Recipe.cc:23-149), host only: parses recipe text and
  * returns the utterances of one batch as a malloc'ed text table (aasr_free), one
  * line per utterance with the fields audio, lna, speaker, utterance, start-time,
- * end-time separated by 0x1f (times as "%.17g").  Kept from the reference: lines
+ * end-time separated by 0x1f (times are the float fields of Recipe::Info, printed "%.9g").  Kept from the reference: lines
  * are cleaned of " \t\n" only, fields split on blanks and tabs, `key=value`
  * through str::split (a trailing '=' is dropped), keys persist across lines. */
 aasr_status aasr_recipe_read(const char *recipe_text, int32_t num_batches, int32_t batch_index,
                              char **table_out, int64_t *table_len);
+
+/* start/end frame of an utterance as phone_probs derives them from the recipe's
+ * start-time / end-time (aku/phone_probs.cc:199-206): `(int)(time * frame_rate)`
+ * with BOTH operands float (Recipe::Info::start_time is a float field,
+ * aku/Recipe.hh:48-49; FeatureGenerator::frame_rate() returns float), so the
+ * product is rounded to float before truncation; end frame 0 means "to the end"
+ * and is returned as INT32_MAX.  Host only. */
+void aasr_recipe_frame_limits(float start_time, float end_time, float frame_rate,
+                              int32_t *start_frame, int32_t *end_frame);
 
 /* ---------------------------------------------------------------------------
  * Speaker / utterance configuration: aku::SpeakerConfig

@@ -1262,9 +1262,9 @@ def recipe_read(text: str, num_batches: int = 0, batch_index: int = 0,
                 if k in kv:
                     setattr(info, attr, kv[k])
             if "start-time" in kv:
-                info.start_time = _atof(kv["start-time"])
+                info.start_time = float(np.float32(_atof(kv["start-time"])))  # float field, aku/Recipe.hh:48
             if "end-time" in kv:
-                info.end_time = _atof(kv["end-time"])
+                info.end_time = float(np.float32(_atof(kv["end-time"])))
             if "start-line" in kv:
                 info.start_line = _atoi(kv["start-line"])
             if "end-line" in kv:
@@ -1272,6 +1272,16 @@ def recipe_read(text: str, num_batches: int = 0, batch_index: int = 0,
             infos.append(info)
         cur_line += 1
     return infos
+
+
+def recipe_frame_limits(info: "RecipeInfo", frame_rate) -> Tuple[int, int]:
+    """aku/phone_probs.cc:199-206: `(int)(start_time * gen.frame_rate())` with both operands
+    float (aku/Recipe.hh:48-49, aku/FeatureGenerator.hh:84), i.e. a float product truncated
+    toward zero; an end frame of 0 means INT_MAX."""
+    fr = np.float32(frame_rate)
+    start = int(np.float32(info.start_time) * fr)
+    end = int(np.float32(info.end_time) * fr)
+    return start, (end if end != 0 else 2 ** 31 - 1)
 
 
 def _atof(s: str) -> float:

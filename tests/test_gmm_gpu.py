@@ -210,6 +210,28 @@ def test_model_cache_round_trip(capi, oracle, tmp_path):
         capi.Gmm.from_cache(str(tmp_path / "bad.aasr"))
     with pytest.raises(capi.AasrError, match="not a model cache"):
         capi.Gmm.from_cache(base + ".gk")
+    # the cache remembers the text files it was written from: it is refused once they change
+    # (retraining, another -b next to the same cache path) and for a model built in memory
+    g3 = capi.Gmm.from_cache_checked(cache, base + ".gk", base + ".mc", base + ".ph")
+    assert np.array_equal(g1.score(frames), g3.score(frames))
+    oracle.write_gk(base + ".gk", mean + 0.25, var)
+    with pytest.raises(capi.AasrError, match="stale model cache"):
+        capi.Gmm.from_cache_checked(cache, base + ".gk", base + ".mc", base + ".ph")
+    capi.Gmm.from_arrays(mean, var, off, idx, w).write_cache(str(tmp_path / "mem.aasr"))
+    with pytest.raises(capi.AasrError, match="stale model cache"):
+        capi.Gmm.from_cache_checked(str(tmp_path / "mem.aasr"), base + ".gk", base + ".mc", base + ".ph")
+    # index tables of a foreign file are validated, not trusted (checksum recomputed here)
+    good = bytearray(open(cache, "rb").read())
+    hdr = 8 + 4 + 4 + 8 * 3 + 4 + 8 + 6 * 8
+    pos = hdr + 2 * 300 * 20 * 8 + 4          # mix_off[1]
+    good[pos:pos + 4] = (10 ** 6).to_bytes(4, "little")
+    h = 1469598103934665603
+    for byte in good[:-8]:
+        h = ((h ^ byte) * 1099511628211) & (2 ** 64 - 1)
+    good[-8:] = h.to_bytes(8, "little")
+    open(tmp_path / "crafted.aasr", "wb").write(bytes(good))
+    with pytest.raises(capi.AasrError, match="inconsistent mixture tables"):
+        capi.Gmm.from_cache(str(tmp_path / "crafted.aasr"))
 
 
 def test_outlier_routing_keeps_the_model_on_the_matrix_path(capi, oracle):

@@ -154,3 +154,25 @@ def test_pitched_scores_and_lna_equal_the_dense_path(capi):
     assert not g.score_pitch_ok()
     with pytest.raises(capi.AasrError):
         g.score_dev_pitched(fr, padded, 128)
+
+
+def test_recipe_segment_times_use_float_frame_limits(capi, oracle, setup, tmp_path):
+    """start-time=2.008 end-time=8.008 at 125 frames/s: the reference multiplies float by float
+    (aku/phone_probs.cc:199-206, aku/Recipe.hh:48-49) and writes frames 250..1000; double
+    arithmetic would give 251..999."""
+    pcm = synth.make_audio(160000, seed=5)
+    _write_wav(str(tmp_path / "seg.wav"), pcm)
+    recipe = str(tmp_path / "seg.recipe")
+    open(recipe, "w").write("audio=%s lna=seg.lna start-time=2.008 end-time=8.008\n" % (tmp_path / "seg.wav"))
+    st = capi.run_recipe(setup["ft"], setup["gm"], recipe, lnabytes=4, out_dir=str(tmp_path))
+    info = oracle.recipe_read(open(recipe).read())[0]
+    start, end = oracle.recipe_frame_limits(info, setup["ch"].frame_rate())
+    assert (start, end) == (250, 1001) and st.frames == 751
+    data = open(tmp_path / "seg.lna", "rb").read()
+    single, n = capi.run_utterance(setup["ft"], setup["gm"], pcm, start_frame=start, end_frame=end, lnabytes=4)
+    assert n == 751 and data == single
+    lp = np.frombuffer(data[5:], "<f4").reshape(751, 32)
+    lp_ref, _ = _oracle_lna(oracle, setup["ch"], setup["om"], pcm, 4, start=start, end=end)
+    ll_ref = setup["om"].score(setup["ch"].generate(pcm, start, end - start))
+    smooth = (ll_ref > -87.0) | (ll_ref < -104.5)
+    assert np.abs(lp - lp_ref)[smooth].max() <= 1e-4

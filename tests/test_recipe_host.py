@@ -90,3 +90,28 @@ def test_engine_recipe_reader_matches_oracle(capi, oracle):
     got = capi.recipe_read(fixed)
     assert got[1][:2] == ("b.wav", "b.lna") and got[1][2] == "s1" and got[2][4] == 0.5 and got[3][1] == "d.lna"
     assert got[2][3] == "u\r" and got[2][5] == 3.0          # the reference does not strip CR
+
+
+def test_recipe_times_are_float_and_frame_limits_use_float_arithmetic(capi, oracle):
+    """Recipe::Info::start_time / end_time are float fields (aku/Recipe.hh:48-49) and
+    phone_probs multiplies them with the float frame_rate() (aku/phone_probs.cc:199-206): the
+    product is rounded to float before the truncation.  2.008 s * 125 is frame 250 (251 in
+    double), 8.008 s * 125 is 1001 (1000 in double)."""
+    import numpy as np
+    got = capi.recipe_read("audio=a lna=b start-time=2.008 end-time=8.008\n")
+    assert got[0][4] == float(np.float32(2.008)) and got[0][5] == float(np.float32(8.008))
+    assert capi.recipe_frame_limits(2.008, 8.008, 125.0) == (250, 1001)
+    assert int(2.008 * 125.0) == 251 and int(8.008 * 125.0) == 1000     # what double would give
+    assert capi.recipe_frame_limits(0.0, 0.0, 125.0) == (0, 2 ** 31 - 1)
+    info = oracle.recipe_read("audio=a lna=b start-time=2.008 end-time=8.008\n")[0]
+    assert oracle.recipe_frame_limits(info, 125.0) == (250, 1001)
+    # a millisecond sweep: the engine's limits equal the float restatement everywhere, and the
+    # double evaluation would differ on a few hundred of them
+    differ = 0
+    for ms in range(0, 200000, 7):
+        t = "%.3f" % (ms / 1000.0)
+        i = oracle.recipe_read("audio=a lna=b start-time=%s end-time=%s\n" % (t, t))[0]
+        want = oracle.recipe_frame_limits(i, 125.0)
+        assert capi.recipe_frame_limits(float(np.float32(float(t))), float(np.float32(float(t))), 125.0) == want
+        differ += int(int(float(t) * 125.0) != want[0])
+    assert differ > 20
