@@ -315,6 +315,12 @@ class Gmm:
             raise RuntimeError("no clustered scoring pass to report")
         return out
 
+    def cluster_tie_frames(self) -> int:
+        """Diagnostic: frames of the last clustered sub-pass settled by the priority-queue replay."""
+        L = lib()
+        L.aasr_debug_cluster_tie_frames.argtypes = [C.c_void_p]
+        return L.aasr_debug_cluster_tie_frames(self._h)
+
     def set_precision(self, prec: int) -> None:
         """0 = f32, 2 = f32 centred form, 3 = bf16x3 split (default)."""
         check(lib().aasr_gmm_set_precision(self._h, prec))
@@ -494,6 +500,14 @@ def recipe_batch_range(total: int, num_batches: int, batch_index: int):
     f, n = C.c_int32(), C.c_int32()
     check(lib().aasr_recipe_batch_range(total, num_batches, batch_index, C.byref(f), C.byref(n)))
     return f.value, n.value
+
+
+def debug_cluster_heap(on: bool) -> None:
+    """Diagnostic: send every frame's cluster selection through the priority-queue replay."""
+    L = lib()
+    L.aasr_debug_cluster_heap.argtypes = [C.c_int]
+    L.aasr_debug_cluster_heap.restype = None
+    L.aasr_debug_cluster_heap(int(on))
 
 
 def recipe_frame_limits(start_time: float, end_time: float, frame_rate: float):

@@ -179,7 +179,14 @@ struct ClusterState {
   DevBuf<unsigned long long> maskrow;  // [Fc/64][rows_padded] the same per packed row
   DevBuf<float> cval;              // [Fc][C] 2^(log2e*ll_c + ref) of the centres that stand in
   DevBuf<int32_t> n_exact;         // [Fc] clusters evaluated exactly (diagnostic)
+  // frames whose selection threshold falls inside a group of equal centre likelihoods: the
+  // reference's priority queue decides which of them are popped, k_cluster_select_heap replays it
+  DevBuf<int32_t> tie_list;        // [Fs] sub-pass frame indices, tie_list[Fs] = count
+  DevBuf<double> heap_key;         // [C][kHeapThreads]
+  DevBuf<int32_t> heap_idx;        // [C][kHeapThreads]
+  int64_t tie_frames_total = 0;    // frames that took the replay since the clustering was set (diagnostic, updated lazily)
 };
+constexpr int kHeapThreads = 4096;
 
 }  // namespace aasr
 

@@ -36,9 +36,17 @@
 // The matrix work is not reduced (on this machine evaluating every Gaussian is
 // cheaper than gathering per-frame cluster subsets); the point of this path is
 // output parity with recognisers configured with -C/--eval-ming.
-// Ties: equal centre values are all treated alike (the reference pops them in
-// heap order); equal doubles only occur for underflowed zeros, which are
-// evaluated exactly either way.
+// Ties: the reference ranks the centres by their LINEAR likelihood exp(ll) in a
+// std::priority_queue, so centres that underflowed to 0.0 all tie (ll below
+// ln 2^-1075) and so do empty clusters (an "invalid" centre: ll = 0, likelihood
+// 1).  When the loop's stopping point falls inside such a group, which members
+// are popped -- and how many clusters the loop counts -- depends on libstdc++'s
+// heap order.  Denormal likelihoods (ll between ln 2^-1075 and ln 2^-1022) are
+// small multiples of 2^-1074, so different centres tie there too (lin_key).  k_cluster_select detects that case per frame (the histogram
+// selection ends on a group of equal keys of which only a part is needed) and
+// hands the frame to k_cluster_select_heap, which replays push_heap / pop_heap
+// for that frame exactly (one thread per frame).  Not modelled: two different
+// ll whose exp() rounds to the same double (|ll| < 1 and a gap of one ulp).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -56,6 +64,32 @@ static const double kLog2eD = 1.4426950408889634074;
 // exp(x) rounds to 0.0 in double below ln(2^-1075)
 #define AASR_EXP_UNDERFLOW_LL (-745.13321910194122)
 #define AASR_LOG_TINY_F (-115.12925464970228f)
+
+// Ranking key of a centre.  The reference ranks by the double exp(ll) (aku/Distributions.cc
+// :2688-2691).  Where exp(ll) is a normal double, ll itself is used (exp is strictly increasing
+// there to within its last-bit rounding).  Below ln 2^-1022 the result is a denormal -- a small
+// integer multiple q of 2^-1074 -- or 0: different ll share one likelihood, so the key is built
+// from q: -2000 + q 2^-42 (below every normal key; equal likelihoods give equal keys; large q
+// may merge neighbours, which only sends a frame to the exact replay).  Key -2000 <=> exp(ll) == 0.
+#define AASR_KEY_ZERO (-2000.0)
+__device__ __forceinline__ double lin_key(double ll) {
+  if (ll >= -708.39641853226408) return ll;
+  if (ll < AASR_EXP_UNDERFLOW_LL - 1.0) return AASR_KEY_ZERO;
+  // q = exp(ll) / 2^-1074 rounded to an integer, without relying on denormal results of the
+  // device's exp(): exp(ll + 1074 ln 2), the sum carried as s + e (TwoSum) so that the argument
+  // is exact to ~1e-30 and q is as accurate as exp() itself (1 ulp: it differs from the
+  // reference's rounding only when the true value lies within ~1e-16 q of a half integer)
+  const double H = 744.4400719213812, Hlo = 4.422444340918698e-14;
+  const double sum = ll + H;
+  const double bb = sum - ll;
+  const double e = (ll - (sum - bb)) + (H - bb);
+  double q = exp(sum);
+  q += q * (e + Hlo);
+  return AASR_KEY_ZERO + rint(q) * 0x1p-42;  // one ulp of 2000 per quantum: exact for q < 2^41
+}
+
+// diagnostic switch (aasr_debug_cluster_heap): every frame takes the queue replay
+static int g_force_heap = getenv("AASR_CLUSTER_HEAP") ? atoi(getenv("AASR_CLUSTER_HEAP")) : 0;
 
 // ---------------------------------------------------------------- centres --
 // thread = frame (float values parked in LDS, [dimension][thread]); the records
@@ -136,7 +170,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const double *__restrict__ ll64, int64_t F, int C, int64_t Cs,
     const int32_t *__restrict__ csize, int min_clusters, int min_gaussians, double ref,
     unsigned long long *__restrict__ maskw, float *__restrict__ cval,
-    int32_t *__restrict__ n_exact) {
+    int32_t *__restrict__ n_exact, int32_t *__restrict__ tie_list, int64_t tie_cap,
+    int force_heap) {
   __shared__ unsigned long long hist[64];
   __shared__ unsigned long long bits[64][KPL];  // [frame in word][cluster slot] ballots
   const int lane = threadIdx.x;
@@ -161,13 +196,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
     for (int j = 0; j < KPL; j++) {
       const int c = j * 64 + lane;
-      const double x = c < C ? row[c] : 0.0;
+      double x = c < C ? row[c] : 0.0;
+      x = lin_key(x);  // the reference compares exp(ll)
       v[j] = x;
       if (c < C && x == x) cand |= 1ull << j;
     }
     int need_c = min_clusters, need_g = min_gaussians;
-    double T = INFINITY;  // centre >= T  <=>  members evaluated exactly
-    if (need_c > 0 || need_g > 0) {
+    double T = INFINITY;  // key >= T  <=>  members evaluated exactly
+    bool tie = false;     // wave-uniform: the boundary lies inside a group of equal keys
+    if ((need_c > 0 || need_g > 0) && !force_heap) {
       for (int level = 0; level < 64; level++) {
         double lo = INFINITY, hi = -INFINITY;
 #pragma unroll
@@ -184,7 +221,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         const double scale = 64.0 / (hi - lo);
         if (!(hi > lo) || !(scale < 1.0e300)) {  // one value left (single centre or ties)
-          T = lo;
+          int n_tied = 0;
+#pragma unroll
+          for (int j = 0; j < KPL; j++) n_tied += (int)((cand >> j) & 1);
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) n_tied += __shfl_xor(n_tied, o);
+          // every pop takes one cluster: with need_c >= n_tied the whole group goes whatever the
+          // order; otherwise the queue's order among equals decides -> replay
+          if (n_tied == 1 || need_c >= n_tied) T = lo;
+          else tie = true;
           break;
         }
         hist[lane] = 0ull;
@@ -228,6 +273,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         __builtin_amdgcn_wave_barrier();
       }
     }
+    if (force_heap) tie = min_clusters > 0 || min_gaussians > 0;
+    if (tie && lane == 0) {
+      // slot 0 counts; a list that is full (cannot happen: one entry per frame) drops nothing
+      const int at = atomicAdd(&tie_list[tie_cap], 1);
+      if (at < tie_cap) tie_list[at] = (int32_t)f;
+    }
     int exact = 0;
 #pragma unroll
     for (int j = 0; j < KPL; j++) {
@@ -237,10 +288,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       exact += sel ? 1 : 0;
       // a centre whose likelihood is 0.0 in double is not trusted by
       // PDFPool::compute_likelihood: its members are evaluated exactly
-      const bool use_exact = sel || !(v[j] >= AASR_EXP_UNDERFLOW_LL);
+      const bool use_exact = sel || !(v[j] > AASR_KEY_ZERO);
       const unsigned long long bal = __ballot(valid && use_exact);
       if (lane == 0) bits[fi][j] = bal;
-      if (valid) cval[f * C + c] = use_exact ? 0.0f : exp2f((float)(v[j] * kLog2eD + ref));
+      // (the log-likelihood itself is read again: the register holds the ranking key)
+      if (valid) cval[f * C + c] = use_exact ? 0.0f : exp2f((float)(row[c] * kLog2eD + ref));
     }
     if (n_exact) {
 #pragma unroll
@@ -259,6 +311,87 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     if (c < C) maskw[word * (C + 1) + c] = w;
   }
   if (lane == 0) maskw[word * (C + 1) + C] = ~0ull;  // rows in no cluster: always exact
+}
+
+// ------------------------------------------------------------ heap replay --
+// PDFPool::precompute_likelihoods' cluster loop (aku/Distributions.cc:2684-2722) for the frames
+// k_cluster_select could not settle: std::priority_queue<pair<int,double>, vector, cl_compare>
+// (aku/Distributions.hh:291-299) is push_heap per cluster in index order, then top / pop_heap
+// until both minimum counts are met; libstdc++'s __push_heap / __adjust_heap (bits/stl_heap.h)
+// are replayed step by step, so equal likelihoods leave the queue in the reference build's order.
+// One thread per listed frame; the heap lives in global scratch, [position][thread] so that the
+// lanes of a wave touch neighbouring words.  pop_heap parks the popped element at the end of the
+// shrinking array, so afterwards positions >= n hold the clusters that were popped.
+__device__ __forceinline__ void heap_push(double *key, int32_t *idx, int64_t st, int hole, int top,
+                                          double vk, int32_t vi) {
+  int parent = (hole - 1) / 2;
+  while (hole > top && key[parent * st] < vk) {
+    key[hole * st] = key[parent * st];
+    idx[hole * st] = idx[parent * st];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  key[hole * st] = vk;
+  idx[hole * st] = vi;
+}
+
+__global__ __launch_bounds__(64) void k_cluster_select_heap(
+    const double *__restrict__ ll64, int C, int64_t Cs, const int32_t *__restrict__ csize,
+    int min_clusters, int min_gaussians, double ref, unsigned long long *__restrict__ maskw,
+    float *__restrict__ cval, int32_t *__restrict__ n_exact, const int32_t *__restrict__ tie_list,
+    int64_t tie_cap, double *__restrict__ heap_key, int32_t *__restrict__ heap_idx) {
+  const int tid = blockIdx.x * 64 + threadIdx.x;
+  const int64_t st = kHeapThreads;
+  const int count = min((int64_t)tie_list[tie_cap], tie_cap);
+  double *key = heap_key + tid;
+  int32_t *idx = heap_idx + tid;
+  for (int i = tid; i < count; i += kHeapThreads) {
+    const int64_t f = tie_list[i];
+    const double *row = ll64 + f * Cs;
+    for (int c = 0; c < C; c++) {
+      heap_push(key, idx, st, c, 0, lin_key(row[c]), c);
+    }
+    int n = C, clusters_done = 0, gauss_done = 0;
+    while ((clusters_done < min_clusters || gauss_done < min_gaussians) && n > 0) {
+      clusters_done++;
+      gauss_done += csize[idx[0]];
+      // pop_heap: the top goes to the last position, the former last element is sifted from the root
+      const int len = n - 1;
+      if (len >= 1) {
+        const double vk = key[len * st];
+        const int32_t vi = idx[len * st];
+        key[len * st] = key[0];
+        idx[len * st] = idx[0];
+        int hole = 0, child = 0;
+        while (child < (len - 1) / 2) {
+          child = 2 * (child + 1);
+          if (key[child * st] < key[(child - 1) * st]) child--;
+          key[hole * st] = key[child * st];
+          idx[hole * st] = idx[child * st];
+          hole = child;
+        }
+        if ((len & 1) == 0 && child == (len - 2) / 2) {
+          child = 2 * (child + 1);
+          key[hole * st] = key[(child - 1) * st];
+          idx[hole * st] = idx[(child - 1) * st];
+          hole = child - 1;
+        }
+        heap_push(key, idx, st, hole, 0, vk, vi);
+      }
+      n--;
+    }
+    n_exact[f] = clusters_done;
+    const int64_t word = f >> 6;
+    const unsigned long long bit = 1ull << (f & 63);
+    for (int p = 0; p < C; p++) {
+      const int32_t c = idx[p * st];
+      const bool use_exact = p >= n || !(key[p * st] > AASR_KEY_ZERO);
+      unsigned long long *w = maskw + word * (C + 1) + c;
+      if (use_exact) atomicOr(w, bit);
+      else atomicAnd(w, ~bit);
+      cval[f * C + c] = use_exact ? 0.0f : exp2f((float)(row[c] * kLog2eD + ref));
+    }
+  }
 }
 
 // ----------------------------------------------------------------- expand --
@@ -615,10 +748,18 @@ template <int KPL>
 static void launch_select_t(aasr_gmm *g, int64_t s0, int64_t F, hipStream_t stream) {
   ClusterState &cl = g->cl;
   const int64_t words = (F + 63) / 64;
+  const int force_heap = g_force_heap;
+  AASR_HIP(hipMemsetAsync(cl.tie_list.p + cl.Fs, 0, sizeof(int32_t), stream));
   hipLaunchKernelGGL(k_cluster_select<KPL>, dim3((unsigned)words), dim3(64), 0, stream, cl.ll64.p, F,
                      cl.C, (int64_t)cl.Cs, cl.csize.p, cl.min_clusters, cl.min_gaussians, cl.ref_log2,
                      cl.maskw.p + (size_t)(s0 / 64) * (cl.C + 1), cl.cval.p + (size_t)s0 * cl.C,
-                     cl.n_exact.p + s0);
+                     cl.n_exact.p + s0, cl.tie_list.p, cl.Fs, force_heap);
+  AASR_HIP(hipGetLastError());
+  // frames left to the queue replay (normally none: the kernel's threads find an empty list)
+  hipLaunchKernelGGL(k_cluster_select_heap, dim3(kHeapThreads / 64), dim3(64), 0, stream, cl.ll64.p, cl.C,
+                     (int64_t)cl.Cs, cl.csize.p, cl.min_clusters, cl.min_gaussians, cl.ref_log2,
+                     cl.maskw.p + (size_t)(s0 / 64) * (cl.C + 1), cl.cval.p + (size_t)s0 * cl.C,
+                     cl.n_exact.p + s0, cl.tie_list.p, cl.Fs, cl.heap_key.p, cl.heap_idx.p);
   AASR_HIP(hipGetLastError());
 }
 
@@ -689,6 +830,9 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
     cl.maskw.alloc((size_t)(fb / 64) * (cl.C + 1));
     cl.maskrow.alloc((size_t)(fb / 64) * (size_t)L.rows_padded);
     cl.n_exact.alloc((size_t)fb);
+    cl.tie_list.alloc((size_t)fs + 1);
+    cl.heap_key.ensure((size_t)cl.C * kHeapThreads);
+    cl.heap_idx.ensure((size_t)cl.C * kHeapThreads);
     cl.Fc = fb;
     cl.Fs = fs;
   }
@@ -716,6 +860,18 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
 
 // Diagnostic (not part of the public ABI): clusters evaluated exactly for each of
 // the first n frames of the most recent clustered scoring pass.
+// Diagnostic: 1 = every frame's cluster selection goes through the priority-queue replay
+// (k_cluster_select_heap) instead of the histogram selection; the two must agree.
+extern "C" void aasr_debug_cluster_heap(int on) { aasr::g_force_heap = on; }
+// Diagnostic: frames of the last sub-pass that were handed to the replay.
+extern "C" int aasr_debug_cluster_tie_frames(aasr_gmm *g) {
+  if (!g || !g->cl.tie_list.p) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  int32_t n = 0;
+  if (hipMemcpy(&n, g->cl.tie_list.p + g->cl.Fs, sizeof n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return n;
+}
+
 extern "C" int aasr_debug_cluster_exact_counts(aasr_gmm *g, int32_t *out, int64_t n) {
   if (!g || !g->cl.n_exact.p || n > g->cl.Fc) return -1;
   if (hipDeviceSynchronize() != hipSuccess) return -1;

@@ -75,16 +75,71 @@ def test_far_frames_underflowed_centres_fall_back_to_exact(capi, oracle):
     frames = synth.make_frames(256)
     frames[::3] *= 9.0                  # centre ll below -745 for most clusters
     frames[1::3] *= 4.0
-    # Underflowed centres tie at likelihood 0.0; the reference pops ties in heap
-    # order, this engine by log-likelihood, so the NUMBER of clusters popped can
-    # differ -- the scores cannot, because a zero centre is re-evaluated exactly.
-    gm, om, got, want = _check(capi, oracle, model, g2c, 32, 0.0, 0.1, frames, counts=False)
+    # Underflowed centres tie at likelihood 0.0 and the reference pops ties in the order of
+    # its std::priority_queue: frames whose stopping point falls among the zeros are replayed
+    # on the device (k_cluster_select_heap), so the number of clusters popped matches too.
+    gm, om, got, want = _check(capi, oracle, model, g2c, 32, 0.0, 0.1, frames, counts=True)
     zero_centres = np.exp(-0.5 * ((frames[:, None, :].astype(np.float64) - om.c_mean[None]) ** 2
                                   * om.c_prec[None]).sum(-1) + om.c_cst[None]) == 0.0
     assert zero_centres[::3].mean() > 0.5 and not zero_centres[2::3].any()
-    near = np.flatnonzero(~zero_centres.any(1))
-    assert np.array_equal(gm.cluster_exact_counts(len(frames))[near],
-                          om.score_clustered(frames.astype(np.float64), True)[1][near])
+    assert gm.cluster_tie_frames() > 0          # the replay really ran
+
+
+def test_empty_clusters_tie_and_the_queue_order_decides(capi, oracle):
+    """The round-1 fuzz case (tools/fuzz_parity.py seed 1, iteration 26): D = 2, 66 random clusters
+    of which some are empty, --eval-minc 0.1 --eval-ming 0.  An empty cluster is an "invalid"
+    centre with log-likelihood 0 (aku/Distributions.cc:1276-1287), so several clusters tie at
+    likelihood 1.0 and the reference's priority queue (aku/Distributions.hh:291-299,
+    aku/Distributions.cc:2684-2722) pops only as many of them as --eval-minc still needs.  The
+    per-frame number of clusters evaluated exactly must equal the oracle's replay of libstdc++'s
+    heap, for every kernel that carries the masks."""
+    rng = np.random.default_rng(126)
+    D, S, G, C = 2, 38, 244, 66
+    n = rng.integers(1, 12, S)
+    n[-1] += G - n.sum() if n.sum() < G else 0
+    K = int(n.sum())
+    off = np.zeros(S + 1, np.int32)
+    off[1:] = np.cumsum(n)
+    idx = rng.integers(0, G, K).astype(np.int32)
+    w = rng.uniform(0.01, 1.0, K)
+    mean = rng.standard_normal((G, D)) * 1.3
+    var = np.exp(rng.uniform(np.log(0.2), np.log(5.0), (G, D)))
+    g2c = rng.integers(0, C, G)
+    empty = [3, 17, 18, 40, 65, 0, 33]
+    g2c[np.isin(g2c, empty)] = 5
+    g2c[rng.integers(0, G, 20)] = -1
+    frames = (rng.standard_normal((300, D)) * 1.7).astype(np.float32)
+    for minc, ming in ((0.1, 0.0), (0.05, 0.0), (0.1, 0.1), (0.5, 0.3)):
+        gm, om, got, want = _check(capi, oracle, (mean, var, off, idx, w), g2c, C, minc, ming, frames)
+    # the tie is real: some frames stop inside the group of empty clusters
+    gm.set_clustering_min_evals(0.1, 0.0)
+    gm.score(frames)
+    assert 0 < gm.cluster_tie_frames() <= 300
+
+
+def test_histogram_selection_equals_the_queue_replay(capi):
+    """k_cluster_select's histogram selection against the step-by-step replay of the reference's
+    priority queue on the same frames (every frame forced through k_cluster_select_heap): scores
+    bit for bit, counts equal."""
+    model = synth.make_model(D=39, G=4096, S=256, comps=16)
+    g2c = synth.make_clustering(model[0], 200)
+    frames = synth.make_frames(2000)
+    frames[::7] *= 3.0
+    gm = capi.Gmm.from_arrays(*model)
+    gm.set_clustering(200, _pairs(g2c))
+    for minc, ming in ((0.0, 0.25), (0.1, 0.0), (0.3, 0.5)):
+        gm.set_clustering_min_evals(minc, ming)
+        fast = gm.score(frames)
+        fast_n = gm.cluster_exact_counts(len(frames))
+        capi.debug_cluster_heap(True)
+        try:
+            slow = gm.score(frames)
+            slow_n = gm.cluster_exact_counts(len(frames))
+            assert gm.cluster_tie_frames() == len(frames)
+        finally:
+            capi.debug_cluster_heap(False)
+        assert np.array_equal(fast_n, slow_n)
+        assert np.array_equal(fast.view(np.uint32), slow.view(np.uint32))
 
 
 def test_gcl_file_counts_last_pair_twice(capi, oracle, tmp_path):

@@ -166,7 +166,7 @@ def test_recipe_segment_times_use_float_frame_limits(capi, oracle, setup, tmp_pa
     open(recipe, "w").write("audio=%s lna=seg.lna start-time=2.008 end-time=8.008\n" % (tmp_path / "seg.wav"))
     st = capi.run_recipe(setup["ft"], setup["gm"], recipe, lnabytes=4, out_dir=str(tmp_path))
     info = oracle.recipe_read(open(recipe).read())[0]
-    start, end = oracle.recipe_frame_limits(info, setup["ch"].frame_rate())
+    start, end = oracle.recipe_frame_limits(info, setup["ch"].frame_rate)
     assert (start, end) == (250, 1001) and st.frames == 751
     data = open(tmp_path / "seg.lna", "rb").read()
     single, n = capi.run_utterance(setup["ft"], setup["gm"], pcm, start_frame=start, end_frame=end, lnabytes=4)
