@@ -13,25 +13,23 @@ import numpy as np
 
 from . import capi, synth
 
-HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_CFG = os.path.join(HERE, "..", "tests", "golden", "mfcc_cms_norm.feaconf")
-
-
 class FullChainBench:
     def __init__(self, gmm: capi.Gmm, n_utts: int, seconds: float, rank: int, device,
-                 cfg_path: str = DEFAULT_CFG, lnabytes: int = 2):
+                 cfg_text: str = None, lnabytes: int = 2, utts=None):
         import torch
         self.torch = torch
         self.gmm = gmm
-        self.feat = capi.Feat.from_file(cfg_path)
+        self.feat = capi.Feat(cfg_text if cfg_text is not None else synth.make_feature_config())
         self.lnabytes = lnabytes
         sr = self.feat.sample_rate
         n = int(round(seconds * sr))
-        # a handful of distinct seeded utterances, tiled: the audio content does
-        # not change the work, generating 1 h of noise on the host would only
-        # slow the bench start-up
-        base = [synth.make_audio(n, seed=synth.SEED + 1000 * rank + i, sample_rate=sr) for i in range(8)]
-        utts = [base[i % len(base)] for i in range(n_utts)]
+        if utts is None:
+            # a handful of distinct seeded utterances, tiled: the audio content does
+            # not change the work, generating 1 h of noise on the host would only
+            # slow the bench start-up
+            base = [synth.make_audio(n, seed=synth.SEED + 1000 * rank + i, sample_rate=sr) for i in range(8)]
+            utts = [base[i % len(base)] for i in range(n_utts)]
+        self.utts = utts
         frames = [self.feat.last_frame(len(u)) + 1 for u in utts]
         self.pcm_off = np.concatenate([[0], np.cumsum([len(u) for u in utts])]).astype(np.int64)
         self.frame_off = np.concatenate([[0], np.cumsum(frames)]).astype(np.int64)

@@ -77,3 +77,44 @@ def make_audio(n_samples, seed=SEED + 2, sample_rate=16000):
     for fj in (220.0, 1370.0, 3100.0):
         x += 6000.0 * np.sin(2 * np.pi * fj * t)
     return np.clip(np.rint(x), -32767, 32767).astype(np.int16)
+
+
+def make_feature_config(seed=SEED + 4, dim_cep=12, sample_rate=16000):
+    """Text of the production feature graph (the structure of the reference's
+    aku/tests/mfcc_cms_norm.feaconf: audiofile -> fft (power) -> mel + power -> dct ->
+    merge -> delta, delta-delta -> merge -> normalization -> lin_transform -> mean_subtractor)
+    with seeded synthetic normalisation vectors and a seeded well-conditioned 39 x 39
+    transform in place of trained ones."""
+    rng = np.random.default_rng(seed)
+    d = 3 * (dim_cep + 1)
+    mean = np.concatenate([rng.normal(0.0, 4.0, dim_cep), [19.5], np.zeros(2 * (dim_cep + 1))])
+    scale = np.exp(rng.uniform(np.log(0.05), np.log(0.5), d))
+    a = np.eye(d) + 0.15 * rng.standard_normal((d, d))
+    bias = 0.1 * rng.standard_normal(d)
+
+    def vec(v):
+        return " ".join("%.6g" % x for x in np.asarray(v).ravel())
+
+    mods = [
+        ("audiofile", "audiofile", None, [("sample_rate", sample_rate), ("copy_borders", 1), ("pre_emph_coef", 0.97)]),
+        ("fft", "fft", "audiofile", [("magnitude", 0)]),
+        ("mel", "mel", "fft", []),
+        ("power", "power", "fft", []),
+        ("mfcc", "dct", "mel", [("dim", dim_cep)]),
+        ("mfcc_power", "merge", "mfcc power", []),
+        ("delta1", "delta", "mfcc_power", [("width", 2)]),
+        ("delta2", "delta", "delta1", [("width", 3)]),
+        ("mfcc_p_d_dd", "merge", "mfcc_power delta1 delta2", []),
+        ("normalization", "normalization", "mfcc_p_d_dd", [("mean", vec(mean)), ("scale", vec(scale))]),
+        ("transform", "lin_transform", "normalization", [("dim", d), ("matrix", vec(a)), ("bias", vec(bias))]),
+        ("cms", "mean_subtractor", "transform", [("left", 50), ("right", 25)]),
+    ]
+    out = []
+    for name, typ, src, opts in mods:
+        t = "module\n{\n  name %s\n  type %s\n" % (name, typ)
+        for k, v in opts:
+            t += "  %s %s\n" % (k, v)
+        if src:
+            t += "  sources %s\n" % src
+        out.append(t + "}\n")
+    return "\n".join(out)

@@ -72,3 +72,101 @@ def test_lna_rows_are_posteriors_and_codes_follow_them(capi, big):
     code = code[..., 0] * 256 + code[..., 1]
     want = np.where(lp < -36.008, 0xFFFF, (-1820.0 * lp + .5).astype(np.int64) & 0xFFFF)
     assert np.array_equal(code, want)
+
+
+# ---------------------------------------------------------------------------
+# BASELINE configs[2]: 1 h of 16 kHz audio as 360 x 10 s utterances, full MFCC
+# chain + 50 000-Gaussian scoring + 2-byte LNA, one device step
+# ---------------------------------------------------------------------------
+
+def _codes(by, S):
+    c = np.asarray(by).reshape(-1, S, 2).astype(np.int32)
+    return c[..., 0] * 256 + c[..., 1]
+
+
+def test_config2_one_hour_full_chain(capi, oracle):
+    """The whole configs[2] step on the device (449 280 frames), then
+      * three utterances (first, middle, last) end to end against the oracle's restatement of
+        phone_probs (feature chain -> 50 000 Gaussians -> float storage -> normalisation -> 2-byte
+        codes, aku/phone_probs.cc:217-263): log-probabilities within 1e-4 (north_star), codes
+        within one step and >= 99.4 % identical (observed 99.50-99.51 %: an f32-class error of ~5e-6 in lp
+        moves 1820 lp across an integer boundary that often);
+      * every one of the 360 utterances: the rows of the batch step are byte-identical to the
+        utterance run alone (aasr_run_utterance), i.e. batching never changes a result."""
+    import torch
+    from aaltoasr_amd import pipeline
+    model = synth.make_model(D=D, G=G, S=S, comps=COMPS)
+    gmm = capi.Gmm.from_arrays(*model)          # default arithmetic: what bench.py measures
+    cfg = synth.make_feature_config()
+    utts = [synth.make_audio(160000, seed=synth.SEED + 500 + i) for i in range(360)]
+    runner = pipeline.FullChainBench(gmm, 360, 10.0, 0, torch.device("cuda", 0), cfg_text=cfg, utts=utts)
+    assert runner.total_frames == 449280
+    runner.step()
+    torch.cuda.synchronize()
+    off = runner.frame_off
+    ch = oracle.FeatureChain(cfg)
+    om = oracle.DiagModel(*model)
+    equal_frac = []
+    for u in (0, 179, 359):
+        fea = ch.generate(utts[u], 0, 1248)
+        ll_ref, lik = om.score(fea, want_lik=True)
+        lp_ref, by_ref = oracle.lna_encode(lik, True, 2)
+        got = _codes(runner.d_bytes[int(off[u]):int(off[u + 1])].cpu().numpy(), S)
+        want = _codes(by_ref, S)
+        assert np.abs(got - want).max() <= 1
+        equal_frac.append(float((got == want).mean()))
+        data4, n4 = capi.run_utterance(runner.feat, gmm, utts[u], lnabytes=4)
+        assert n4 == 1248
+        lp = np.frombuffer(data4[5:], "<f4").reshape(1248, S)
+        smooth = (ll_ref > -87.0) | (ll_ref < -104.5)     # outside the float-denormal band
+        assert np.abs(lp - lp_ref)[smooth].max() <= 1e-4
+    print("configs[2] LNA codes identical to the oracle's:", equal_frac)
+    assert min(equal_frac) >= 0.994
+    for u in range(360):
+        data, n = capi.run_utterance(runner.feat, gmm, utts[u], lnabytes=2)
+        assert n == 1248
+        rows = runner.d_bytes[int(off[u]):int(off[u + 1])].cpu().numpy().tobytes()
+        assert data[5:] == rows, "utterance %d differs between the batch step and a run of its own" % u
+
+
+# ---------------------------------------------------------------------------
+# BASELINE configs[4]: D = 39, G = 10 000 full-covariance Gaussians, F = 200 000
+# ---------------------------------------------------------------------------
+
+def test_config4_full_covariance_at_workload_size(capi, oracle):
+    """Whole 200 000-frame block on the device in both arithmetic forms; the oracle's
+    exponential-form restatement (aku/Distributions.cc:1412-1446) re-scores sampled frames
+    against all 10 000 Gaussians; partition invariance covers the rest."""
+    import torch
+    Dc, Gc, Sc, Fc = 39, 10000, 625, 200000
+    rng = np.random.default_rng(synth.SEED)
+    mean = rng.standard_normal((Gc, Dc))
+    a = rng.standard_normal((Gc, Dc, Dc)) * 0.3
+    cov = a @ a.transpose(0, 2, 1) + 0.1 * np.eye(Dc)
+    _, _, off, idx, w = synth.make_model(D=Dc, G=Gc, S=Sc, comps=16)
+    g = capi.Gmm.from_full(mean, cov, off, idx, w)
+    frames = synth.make_frames(Fc, D=Dc, seed=78)
+    d_fr = torch.from_numpy(frames).cuda()
+    outs = {}
+    for name, prec in (("f32", 0), ("bf16x3", 3)):
+        g.set_precision(prec)
+        d_out = torch.empty((Fc, Sc), dtype=torch.float32, device="cuda")
+        g.score_dev(d_fr, d_out)
+        torch.cuda.synchronize()
+        outs[name] = d_out
+    pick = np.sort(rng.choice(Fc, 24, replace=False))
+    pick[0], pick[-1] = 0, Fc - 1
+    ref = oracle.FullModel(mean, cov, off, idx, w).score(frames[pick].astype(np.float64))
+    for name in outs:
+        got = outs[name][pick.tolist()].cpu().numpy()
+        vis = ref > -103.97
+        err = np.abs(got - ref)
+        assert err[vis].max() <= 1e-4 and err.max() <= 2e-4, "%s: %.3g / %.3g" % (name, err[vis].max(), err.max())
+    assert (outs["f32"] - outs["bf16x3"]).abs().max().item() <= 2e-4
+    for name, prec in (("f32", 0), ("bf16x3", 3)):
+        g.set_precision(prec)
+        for lo, hi in ((0, 1), (511, 1025), (Fc - 777, Fc)):
+            d_out = torch.empty((hi - lo, Sc), dtype=torch.float32, device="cuda")
+            g.score_dev(d_fr[lo:hi].contiguous(), d_out)
+            torch.cuda.synchronize()
+            assert torch.equal(d_out, outs[name][lo:hi]), (name, lo, hi)
