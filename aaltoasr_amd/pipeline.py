@@ -19,7 +19,8 @@ class FullChainBench:
         import torch
         self.torch = torch
         self.gmm = gmm
-        self.feat = capi.Feat(cfg_text if cfg_text is not None else synth.make_feature_config())
+        self.cfg_text = cfg_text if cfg_text is not None else synth.make_feature_config()
+        self.feat = capi.Feat(self.cfg_text)
         self.lnabytes = lnabytes
         sr = self.feat.sample_rate
         n = int(round(seconds * sr))
@@ -52,3 +53,30 @@ class FullChainBench:
 
     def score_only(self) -> None:
         self.gmm.score_dev_pitched(self.d_fea, self.d_ll, self.pitch, self.stream)
+
+    def features_only(self) -> None:
+        self.feat.run_batch_dev(self.d_pcm, self.pcm_off, self.frame_off, self.d_fea, self.stream)
+
+    def lna_only(self) -> None:
+        capi.lna_encode_dev(self.d_ll, True, self.lnabytes, None, self.d_bytes, self.stream, num_states=self.S)
+
+    def stage_split(self, reps: int = 3) -> dict:
+        """ms per step of each stage run on its own (HIP events on the launch stream)."""
+        torch = self.torch
+        out = {}
+        for name, fn in (("features", self.features_only), ("scoring", self.score_only), ("lna", self.lna_only)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fn()
+            torch.cuda.synchronize()
+            e0.record(self.stream)
+            for _ in range(reps):
+                fn()
+            e1.record(self.stream)
+            torch.cuda.synchronize()
+            out[name] = round(e0.elapsed_time(e1) / reps, 4)
+        return out
+
+    def bytes_written_per_frame(self) -> dict:
+        """Algorithmic HBM bytes each stage stores per frame in this arrangement."""
+        return {"features_f32": self.feat.dim * 4, "state_scores_f32": self.pitch * 4,
+                "lna_codes": self.S * self.lnabytes}

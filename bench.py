@@ -1,31 +1,46 @@
 #!/usr/bin/env python
 """bench.py -- frames/sec of the acoustic-likelihood hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gmm|full]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gmm|full|recipe]
 
-A "step" is one pass of the hot path over one batch of synthetic input that is
-already resident in HBM:
-  gmm  (BASELINE configs[1]): 1 000 000 x 39 float32 frames against a
-        50 000-Gaussian / 3 125-state x 16 diagonal HmmSet -> [F x S] state
-        log-likelihoods (k_gmm_diag_score).
-  full (BASELINE configs[2]): 1 h of 16 kHz int16 audio as 360 x 10 s
-        utterances -> MFCC chain -> same scoring -> 2-byte LNA codes.
-Multi-GPU (launched by torch.distributed.run, one rank per GPU): every rank
-scores its own shard of frames/utterances, no collective on the scoring path;
-value = total frames / max-over-ranks time ("weak" scaling).
+A "step" is one pass of the hot path over one batch of synthetic input:
+  gmm    (BASELINE configs[1], the default `value`): 1 000 000 x 39 float32 frames, resident in
+         HBM, against a 50 000-Gaussian / 3 125-state x 16 diagonal HmmSet -> [F x S] state
+         log-likelihoods (k_gmm_diag_score_bf16x3).  The default run also measures configs[2]
+         (a few steps, reported under config.configs2: ms/step, per-stage split, fraction of LNA
+         bytes identical to the oracle's on a sampled utterance) and a small recipe run with file
+         IO (config.recipe_e2e), so one driver run carries all three.
+  full   (BASELINE configs[2]): 1 h of 16 kHz int16 audio as 360 x 10 s utterances, resident in
+         HBM -> MFCC chain -> same scoring -> 2-byte LNA codes.
+  recipe (BASELINE configs[3]): a recipe of --utts (default 10 000) seeded utterances of
+         U(2 s, 12 s) as WAV files, sliced over the ranks with Recipe::read's rule
+         (aku/Recipe.cc:63-115), read -> features -> scoring -> 2-byte LNA files written; value =
+         total frames / wall time of the slowest rank ("strong" scaling: the recipe is fixed),
+         the device-only rate is reported beside it.
 
-Prints ONE JSON line on rank 0.  The roofline block prices the dominant
-kernel (k_gmm_diag_score) in ALGORITHMIC flops: 4*dim = 156 flop per
-frame x Gaussian pair against the dense FP32 matrix
-peak of 157.3 TFLOP/s (MI355X_MICROARCH.md).  The cpu_baseline block times
-the oracle's reference-shaped scalar double loop on this host.
+Multi-GPU: one process per GPU.  Under torch.distributed.run (WORLD_SIZE set) the rank takes its
+place; without it `--gpus N` (N > 1) starts the N ranks itself by re-executing this file under
+`python -m torch.distributed.run --nproc-per-node N`.  The model is built on rank 0 and broadcast
+once over RCCL; there is no collective on the scoring path.  `n_gpus` in the line is the world
+size RCCL reported, never the flag.
+
+Prints ONE JSON line on rank 0.  The roofline block prices the dominant kernel in ALGORITHMIC
+flops: 4*dim = 156 flop per frame x Gaussian pair against the ceiling of
+the pipe it runs on: dense BF16 matrix peak 2500 TFLOP/s / 6 bf16 products per f32-accurate
+product (`--precision f32`: the dense FP32 matrix peak, 157.3 TFLOP/s); the ratio to the FP32
+matrix peak is reported next to it.  The cpu_baseline block times the oracle's reference-shaped
+scalar double loop on this host (rank 0, N = 1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -35,11 +50,13 @@ sys.path.insert(0, ROOT)
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3
 BF16_MATRIX_PEAK_TFLOPS = 2500.0
+HBM_PEAK_GBS = 8000.0
 DIM = 39
 G = 50000
 S = 3125
 COMPS = 16
 NOMINAL_SCLK_MHZ = 2400.0   # the clock the datasheet peaks are quoted at
+METRIC = "frames/sec GMM log-lik (39-d, 50k Gauss) + MFCC, 1/2/4/8 MI355X"   # BASELINE.json
 
 
 def parse_args():
@@ -47,19 +64,29 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["gmm", "full"], default=os.environ.get("AASR_BENCH_WORKLOAD", "gmm"))
+    ap.add_argument("--workload", choices=["gmm", "full", "recipe"],
+                    default=os.environ.get("AASR_BENCH_WORKLOAD", "gmm"))
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step (gmm workload)")
-    ap.add_argument("--utts", type=int, default=360, help="10-s utterances per GPU per step (full workload)")
+    ap.add_argument("--utts", type=int, default=0,
+                    help="utterances: per GPU per step for `full` (default 360 x 10 s), in the whole "
+                         "recipe for `recipe` (default 10 000 x U(2 s, 12 s))")
     ap.add_argument("--out-pitch", choices=["dense", "aligned"], default=os.environ.get("AASR_BENCH_OUT_PITCH", "aligned"),
-                    help="gmm workload: output rows dense [F x S] or padded to whole 64-byte lines")
+                    help="gmm workload: output rows dense [F x S] or padded to whole 128-byte lines")
     ap.add_argument("--cpu-frames", type=int, default=20000, help="frames timed on the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-procs", type=int, default=-1,
                     help="processes of the all-cores CPU baseline (-1 = one per usable core, 0 = skip)")
     ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--precision", choices=["bf16x3", "f32"], default=os.environ.get("AASR_BENCH_PRECISION", "bf16x3"),
                     help="contraction arithmetic of the scoring kernel (both meet the 1e-4 parity bar)")
+    ap.add_argument("--recipe-dir", default=os.environ.get("AASR_BENCH_RECIPE_DIR", ""),
+                    help="where the recipe workload keeps its WAV inputs and LNA outputs "
+                         "(default: /dev/shm when it has room, else the system temp directory)")
+    ap.add_argument("--secondary", type=int, default=int(os.environ.get("AASR_BENCH_SECONDARY", "1")),
+                    help="gmm workload: also measure configs[2] and a small recipe run (1 = yes)")
     return ap.parse_args()
 
+
+# --------------------------------------------------------------------------- CPU baseline --
 
 def cpu_worker(n_frames):
     """One process of the all-cores CPU baseline: the reference scales over cores by
@@ -95,7 +122,6 @@ def usable_cores():
 
 
 def cpu_all_cores(n_procs, n_frames):
-    import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(n_frames)]
     t0 = time.perf_counter()
     procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
@@ -111,11 +137,154 @@ def cpu_all_cores(n_procs, n_frames):
     return rate, done, time.perf_counter() - t0
 
 
+def cpu_baseline(args, model):
+    from aaltoasr_amd import synth
+    from oracle import oracle as O
+    O.build()
+    om = O.DiagModel(*model)
+    cf = synth.make_frames(args.cpu_frames, DIM, seed=synth.SEED + 99).astype(np.float64)
+    om.cpu_baseline(cf[:50])
+    c0 = time.perf_counter()
+    om.cpu_baseline(cf)
+    cdt = time.perf_counter() - c0
+    cpu = {
+        "value": round(args.cpu_frames / cdt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+        "sample": "%d of the step's frames, same 50k-Gaussian model, oracle/aasr_oracle.c "
+                  "orc_cpu_baseline_score (double, per-frame per-Gaussian exp, linear mixture sum, "
+                  "float-cast normalisation) single thread, %.1f s" % (args.cpu_frames, cdt),
+        "host": _cpu_model(), "host_cores": os.cpu_count(), "usable_cores": usable_cores(),
+    }
+    n_procs = usable_cores() if args.cpu_procs < 0 else args.cpu_procs
+    if n_procs and n_procs > 1:
+        per = max(200, args.cpu_frames // 10)
+        rate, done, wall = cpu_all_cores(n_procs, per)
+        if done:
+            cpu["all_cores"] = {
+                "value": round(rate, 1), "unit": "frames/s", "cores": done,
+                "sample": "%d independent single-thread processes (the reference's -B/-I mode), %d frames "
+                          "each, sum of the per-process rates, %.1f s wall incl. start-up" % (done, per, wall)}
+    return cpu
+
+
+# ------------------------------------------------------------------------ rank start-up --
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args):
+    """`--gpus N` without a launcher: start the N ranks under torch.distributed.run and hand
+    their output through.  Fails loudly when the node has fewer devices."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: this node exposes %d HIP device(s); there is no CPU fallback "
+                         "and a smaller world is never reported as %d GPUs" % (args.gpus, have, args.gpus))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+# ------------------------------------------------------------------------------ recipe --
+
+def _recipe_dir(args, need_bytes):
+    if args.recipe_dir:
+        os.makedirs(args.recipe_dir, exist_ok=True)
+        return tempfile.mkdtemp(prefix="aasr_recipe_", dir=args.recipe_dir)
+    for base in ("/dev/shm", tempfile.gettempdir()):
+        try:
+            if os.path.isdir(base) and os.access(base, os.W_OK) and shutil.disk_usage(base).free > 1.3 * need_bytes:
+                return tempfile.mkdtemp(prefix="aasr_recipe_", dir=base)
+        except OSError:
+            pass
+    raise RuntimeError("no directory with %.1f GB free for the recipe workload (give --recipe-dir)" % (need_bytes / 1e9))
+
+
+def recipe_lengths(n_utts, sample_rate=16000):
+    """Seeded utterance lengths U(2 s, 12 s) in samples."""
+    from aaltoasr_amd import synth
+    rng = np.random.default_rng(synth.SEED + 4000)
+    return (rng.uniform(2.0, 12.0, n_utts) * sample_rate).astype(np.int64)
+
+
+def write_recipe_inputs(workdir, lengths, first, count, sample_rate=16000):
+    """WAV files of utterances [first, first + count): seeded slices of one 60-s pool of the
+    synthetic signal (noise + three sinusoids) -- the audio content does not change the work."""
+    import wave
+    from aaltoasr_amd import synth
+    pool = synth.make_audio(60 * sample_rate, seed=synth.SEED + 4001, sample_rate=sample_rate)
+    rng = np.random.default_rng(synth.SEED + 4002 + first)
+    for i in range(first, first + count):
+        n = int(lengths[i])
+        o = int(rng.integers(0, len(pool) - n))
+        with wave.open(os.path.join(workdir, "u%05d.wav" % i), "wb") as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(sample_rate)
+            w.writeframes(pool[o:o + n].astype("<i2").tobytes())
+
+
+def run_recipe_workload(args, capi, synth, shard, gmm, world, rank, n_utts, steps, warmup, sync_all, workdir=None):
+    """configs[3]: the rank's Recipe::read slice, files in, LNA files out.  Returns a dict
+    with the local figures; the caller aggregates over ranks."""
+    feat = capi.Feat(synth.make_feature_config())
+    lengths = recipe_lengths(n_utts)
+    frames_all = np.array([feat.last_frame(int(n)) + 1 for n in lengths], np.int64)
+    first, count = shard.rank_slice(n_utts, world, rank)
+    my_frames = int(frames_all[first:first + count].sum())
+    out_bytes = my_frames * S * 2
+    in_bytes = int(lengths[first:first + count].sum()) * 2
+    own = workdir is None
+    if own:
+        workdir = _recipe_dir(args, out_bytes + in_bytes)
+    try:
+        os.makedirs(os.path.join(workdir, "lna"), exist_ok=True)
+        write_recipe_inputs(workdir, lengths, first, count)
+        # every rank holds the WHOLE recipe text and lets Recipe::read's -B/-I rule pick its slice,
+        # exactly what N reference processes would do (missing files of other slices are never opened)
+        recipe = os.path.join(workdir, "r%d.recipe" % rank)
+        with open(recipe, "w") as f:
+            for i in range(n_utts):
+                f.write("audio=%s lna=u%05d.lna\n" % (os.path.join(workdir, "u%05d.wav" % i), i))
+        outdir = os.path.join(workdir, "lna")
+
+        def one():
+            return capi.run_recipe(feat, gmm, recipe, lnabytes=2, out_dir=outdir,
+                                   num_batches=world if world > 1 else 0, batch_index=rank + 1 if world > 1 else 0)
+        for _ in range(warmup):
+            one()
+        sync_all()
+        t0 = time.perf_counter()
+        dev_s = 0.0
+        for _ in range(steps):
+            st = one()
+            dev_s += st.seconds_device
+        sync_all()
+        wall = time.perf_counter() - t0
+        assert st.frames == my_frames and st.utterances == count, (st.frames, my_frames, st.utterances, count)
+        return {"frames": my_frames, "utterances": count, "wall_s": wall, "device_s": dev_s, "steps": steps,
+                "dir": os.path.dirname(workdir) if own else workdir, "lna_bytes_per_step": out_bytes,
+                "audio_bytes_per_step": in_bytes}
+    finally:
+        if own:
+            shutil.rmtree(workdir, ignore_errors=True)
+
+
+# -------------------------------------------------------------------------------- main --
+
 def main():
     args = parse_args()
     if args.cpu_worker > 0:
         cpu_worker(args.cpu_worker)
         return
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)
     # stdout carries exactly one JSON line: anything native libraries print there (RCCL's version
     # banner, rocm-smi) is sent to stderr for the life of the process
     sys.stdout.flush()
@@ -124,23 +293,30 @@ def main():
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if env_world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; refusing to "
+                         "report one as the other" % (args.gpus, env_world))
     # AASR_BENCH_FORCE_DIST=1 takes the multi-rank code path (RCCL init, model broadcast, barrier,
     # max-over-ranks) at world size 1 too, so it can be exercised on a one-GPU box under torchrun
-    distributed = world > 1 or os.environ.get("AASR_BENCH_FORCE_DIST") == "1"
+    distributed = env_world > 1 or os.environ.get("AASR_BENCH_FORCE_DIST") == "1"
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: there is no CPU fallback for the product path")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no device (%d visible)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    world = 1
     if distributed:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=env_world, device_id=dev)
+        world = dist.get_world_size()       # what RCCL actually connected
 
-    from aaltoasr_amd import build, capi, synth
+    from aaltoasr_amd import build, capi, shard, synth
     if rank == 0:
         build.build()
     if distributed:
@@ -156,16 +332,60 @@ def main():
     else:
         model = dict.fromkeys(names)
     if distributed:
-        from aaltoasr_amd import shard
         model = shard.broadcast_model(model, src=0, device=dev)
     mean, var, off, idx, w = (model[k] for k in names)
     gmm = capi.Gmm.from_arrays(mean, var, off, idx, w)
     gmm.set_precision(3 if args.precision == "bf16x3" else 0)   # AASR_PREC_BF16X3 / AASR_PREC_F32
     rows = gmm.expanded_rows
-
     stream = torch.cuda.current_stream()
-    feat = None
-    if args.workload == "gmm":
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if not distributed:
+            return x
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(x):
+        if not distributed:
+            return x
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    scaling = "weak"
+    extra_cfg = {}
+    if args.workload == "recipe":
+        # ---- configs[3]: wall clock over files in -> LNA files out; strong scaling
+        n_utts = args.utts or 10000
+        res = run_recipe_workload(args, capi, synth, shard, gmm, world, rank, n_utts, args.steps, args.warmup, sync_all)
+        elapsed = max_over_ranks(res["wall_s"])
+        total_frames = sum_over_ranks(float(res["frames"]))
+        dev_max = max_over_ranks(res["device_s"])
+        F = res["frames"]
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = total_frames * args.steps / elapsed
+        scaling = "strong"
+        workload = ("configs[3]: recipe of %d synthetic utterances U(2 s, 12 s) (%d frames) sliced over %d rank(s) by "
+                    "Recipe::read's rule, WAV files -> MFCC chain -> %d-Gaussian scoring -> 2-byte LNA files (%s), "
+                    "wall clock incl. file reads, PCIe and file writes" % (n_utts, int(total_frames), world, G, res["dir"]))
+        extra_cfg = {"recipe": {"utterances": n_utts, "frames_total": int(total_frames),
+                                "frames_per_s_wall": round(value, 1),
+                                "frames_per_s_device_only": round(total_frames * args.steps / max(dev_max, 1e-9), 1),
+                                "wall_s_per_step": round(elapsed / args.steps, 4),
+                                "device_s_per_step_slowest_rank": round(dev_max / args.steps, 4),
+                                "lna_GB_written_per_step_rank0": round(res["lna_bytes_per_step"] / 1e9, 3)}}
+        feat_runner = None
+
+        def score_only():
+            pass
+    elif args.workload == "gmm":
         F = args.frames
         gen = torch.Generator(device=dev)
         gen.manual_seed(synth.SEED + 17 * rank)
@@ -175,7 +395,7 @@ def main():
         # aasr_gmm_score_dev_pitched -> aasr_lna_encode_dev_pitched uses)
         pitch = (S + 31) // 32 * 32 if (args.out_pitch == "aligned" and gmm.score_pitch_ok()) else S
         d_out = torch.empty((F, pitch), device=dev, dtype=torch.float32)
-        workload = "configs[1]: batched diag-GMM log-likelihood, %d x %d-d frames x %d Gaussians (%d states x %d), output row pitch %d floats" % (
+        workload = "configs[1]: batched diag-GMM log-likelihood, %d x %d-d frames x %d Gaussians (%d states x %d), output row pitch %d floats; no MFCC and no LNA in the timed region (see config.configs2 for the full chain)" % (
             F, DIM, G, S, COMPS, pitch)
 
         if pitch == S:
@@ -187,119 +407,116 @@ def main():
         score_only = step
     else:
         from aaltoasr_amd import pipeline
-        runner = pipeline.FullChainBench(gmm, n_utts=args.utts, seconds=10.0, rank=rank, device=dev)
+        runner = pipeline.FullChainBench(gmm, n_utts=args.utts or 360, seconds=10.0, rank=rank, device=dev)
         F = runner.total_frames
         workload = "configs[2]: MFCC chain + %d-Gaussian scoring + 2-byte LNA, %d x 10 s synthetic 16 kHz utterances (%d frames)" % (
-            G, args.utts, F)
+            G, args.utts or 360, F)
         step = runner.step
         score_only = runner.score_only
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = world * F * args.steps / elapsed
+    if args.workload != "recipe":
+        for _ in range(args.warmup):
+            step()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync_all()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * F * args.steps / elapsed
 
     # ---- dominant-kernel time: HIP events on the launch stream, scoring only
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    kreps = max(1, args.steps)
-    torch.cuda.synchronize()
-    ev0.record(stream)
-    for _ in range(kreps):
-        score_only()
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    k_ms = ev0.elapsed_time(ev1) / kreps
-    algo_flop = 4.0 * DIM * float(F) * float(rows)
-    achieved = algo_flop / (k_ms * 1e-3) / 1e12
-    if args.precision == "f32":
-        kernel, peak, dtype = "k_gmm_diag_score_tracks<40,true>", FP32_MATRIX_PEAK_TFLOPS, "f32"
-        peak_note = "dense FP32 matrix peak (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md"
-    else:
-        # every f32-accurate product is six bf16 matrix products (3-term split of
-        # both operands, terms below 2^-16 dropped), so the ceiling for ALGORITHMIC
-        # flops on the bf16 pipe is the dense bf16 peak / 6
-        # f32-accurate arithmetic: every f32 operand is carried as three bf16 terms (24 significant
-        # bits), six bf16 matrix-core products per f32 product, f32 accumulation; it meets the same
-        # 1e-4 parity bar as the plain f32 kernel (--precision f32)
-        kernel, peak, dtype = ("k_gmm_diag_score_bf16x3<5,true>", BF16_MATRIX_PEAK_TFLOPS / 6.0,
-                               "f32 (3-term bf16 split on the matrix cores, f32 accumulate)")
-        peak_note = ("dense BF16 matrix peak 2500 TFLOP/s / 6 bf16 products per f32-accurate product; "
-                     "executed matrix flops = 6 * 160/156 * achieved")
-    roofline = {
-        "bound": "mfma", "kernel": kernel, "achieved": round(achieved, 3),
-        "peak": round(peak, 2), "unit": "TFLOP/s",
-        "frac": round(achieved / peak, 4), "traffic": None,
-        "kernel_ms": round(k_ms, 4), "algorithmic_flop_per_launch": algo_flop, "peak_note": peak_note,
-        "frac_of_fp32_matrix_peak": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
-    }
-    # clock / power while the kernel runs: the bf16 matrix pipe draws the chip into its
-    # power cap, so the nominal-clock peak above is not what the silicon offers
-    obs = _observe_clock(lambda: [score_only() for _ in range(max(8, int(1500.0 / max(k_ms, 1e-3))))],
-                         torch) if rank == 0 else None
-    if obs:
-        roofline.update(obs)
-        if obs.get("sclk_mhz"):
-            adj = peak * obs["sclk_mhz"] / NOMINAL_SCLK_MHZ
-            roofline["frac_of_clock_adjusted_peak"] = round(achieved / adj, 4)
-    td = _pmc_traffic(F, args.precision, aligned=(args.workload == "full" or args.out_pitch == "aligned"))
-    if td:
-        roofline["traffic"] = td["bytes"]
-        roofline["traffic_detail"] = td
+    roofline = None
+    dtype = "f32"
+    if args.workload != "recipe":
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        kreps = max(1, args.steps)
+        torch.cuda.synchronize()
+        ev0.record(stream)
+        for _ in range(kreps):
+            score_only()
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        k_ms = ev0.elapsed_time(ev1) / kreps
+        algo_flop = 4.0 * DIM * float(F) * float(rows)
+        achieved = algo_flop / (k_ms * 1e-3) / 1e12
+        if args.precision == "f32":
+            kernel, peak, dtype = "k_gmm_diag_score_tracks<40,true>", FP32_MATRIX_PEAK_TFLOPS, "f32"
+            peak_note = "dense FP32 matrix peak (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md"
+        else:
+            # f32-accurate arithmetic: every f32 operand is carried as three bf16 terms (24 significant
+            # bits), six bf16 matrix-core products per f32 product (terms below 2^-16 dropped), f32
+            # accumulation; it meets the same 1e-4 parity bar as the plain f32 kernel (--precision f32).
+            # The ceiling for ALGORITHMIC flops on the bf16 pipe is therefore the dense bf16 peak / 6.
+            kernel, peak, dtype = ("k_gmm_diag_score_bf16x3<5,true>", BF16_MATRIX_PEAK_TFLOPS / 6.0,
+                                   "f32 (3-term bf16 split on the matrix cores, f32 accumulate)")
+            peak_note = ("dense BF16 matrix peak 2500 TFLOP/s / 6 bf16 products per f32-accurate product; "
+                         "executed matrix flops = 6 * 160/156 * achieved")
+        roofline = {
+            "bound": "mfma", "kernel": kernel, "achieved": round(achieved, 3),
+            "peak": round(peak, 2), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None,
+            "kernel_ms": round(k_ms, 4), "algorithmic_flop_per_launch": algo_flop, "peak_note": peak_note,
+            "frac_of_fp32_matrix_peak": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
+        }
+        # clock / power while the kernel runs: the bf16 matrix pipe draws the chip into its
+        # power cap, so the nominal-clock peak above is not what the silicon offers
+        obs = _observe_clock(lambda: [score_only() for _ in range(max(8, int(1500.0 / max(k_ms, 1e-3))))],
+                             torch) if rank == 0 else None
+        if obs:
+            roofline.update(obs)
+            if obs.get("sclk_mhz"):
+                adj = peak * obs["sclk_mhz"] / NOMINAL_SCLK_MHZ
+                roofline["frac_of_clock_adjusted_peak"] = round(achieved / adj, 4)
+        td = _pmc_traffic(F, args.precision, aligned=(args.workload == "full" or args.out_pitch == "aligned"))
+        if td:
+            roofline["traffic"] = td["bytes"]
+            roofline["traffic_detail"] = td
+
+    # ---- secondary measurements of the default run (every rank takes part: they hold barriers)
+    if args.workload == "gmm" and args.secondary:
+        try:
+            del d_out
+            torch.cuda.empty_cache()
+            extra_cfg["configs2"] = _measure_configs2(torch, capi, synth, gmm, rank, dev, stream, sync_all,
+                                                      max_over_ranks, world, mean, var, off, idx, w)
+        except Exception as e:  # the headline must survive a failure of the extras
+            extra_cfg["configs2"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            n_small = 256 * world
+            res = run_recipe_workload(args, capi, synth, shard, gmm, world, rank, n_small, 1, 1, sync_all)
+            wall = max_over_ranks(res["wall_s"])
+            tot = sum_over_ranks(float(res["frames"]))
+            devs = max_over_ranks(res["device_s"])
+            extra_cfg["recipe_e2e"] = {
+                "what": "configs[3] in small: %d utterances U(2 s, 12 s) (256 per rank), WAV files in %s -> 2-byte LNA "
+                        "files, one pass, Recipe::read slices" % (n_small, res["dir"]),
+                "frames": int(tot), "frames_per_s_wall": round(tot / wall, 1),
+                "frames_per_s_device_only": round(tot / max(devs, 1e-9), 1), "wall_s": round(wall, 4),
+                "lna_GB_written_per_rank": round(res["lna_bytes_per_step"] / 1e9, 3)}
+        except Exception as e:
+            extra_cfg["recipe_e2e"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # ---- CPU baseline (rank 0, N=1 only): oracle's reference-shaped loop
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
-        from oracle import oracle as O
-        O.build()
-        om = O.DiagModel(mean, var, off, idx, w)
-        cf = synth.make_frames(args.cpu_frames, DIM, seed=synth.SEED + 99).astype(np.float64)
-        om.cpu_baseline(cf[:50])
-        c0 = time.perf_counter()
-        om.cpu_baseline(cf)
-        cdt = time.perf_counter() - c0
-        cpu = {
-            "value": round(args.cpu_frames / cdt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d of the step's frames, same 50k-Gaussian model, oracle/aasr_oracle.c "
-                      "orc_cpu_baseline_score (double, per-frame per-Gaussian exp, linear mixture sum, "
-                      "float-cast normalisation) single thread, %.1f s" % (args.cpu_frames, cdt),
-            "host": _cpu_model(), "host_cores": os.cpu_count(), "usable_cores": usable_cores(),
-        }
-        n_procs = usable_cores() if args.cpu_procs < 0 else args.cpu_procs
-        if n_procs and n_procs > 1:
-            per = max(200, args.cpu_frames // 10)
-            rate, done, wall = cpu_all_cores(n_procs, per)
-            if done:
-                cpu["all_cores"] = {
-                    "value": round(rate, 1), "unit": "frames/s", "cores": done,
-                    "sample": "%d independent single-thread processes (the reference's -B/-I mode), %d frames "
-                              "each, sum of the per-process rates, %.1f s wall incl. start-up" % (done, per, wall)}
+        cpu = cpu_baseline(args, (mean, var, off, idx, w))
 
     if rank == 0:
+        cfg = {"workload": workload, "frames_per_gpu_per_step": F, "dim": DIM, "gaussians": G,
+               "states": S, "components_per_state": COMPS,
+               "sharding": "frames/utterances per rank, no collective on the scoring path",
+               "rccl_world_size": world if distributed else None, "gpus_flag": args.gpus}
+        cfg.update(extra_cfg)
         line = {
-            "metric": "frames/sec GMM log-lik (39-d, 50k Gauss) + MFCC",
+            "metric": METRIC,
+            "metric_note": "value is the workload named in config.workload; the MFCC-inclusive rate (configs[2]) is config.configs2.frames_per_s",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": workload, "frames_per_gpu_per_step": F, "dim": DIM, "gaussians": G,
-                       "states": S, "components_per_state": COMPS, "sharding": "frames/utterances per rank, no collective"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "scaling": scaling, "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": cfg, "roofline": roofline, "cpu_baseline": cpu,
         }
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
@@ -308,10 +525,51 @@ def main():
         dist.destroy_process_group()
 
 
+def _measure_configs2(torch, capi, synth, gmm, rank, dev, stream, sync_all, max_over_ranks, world,
+                      mean, var, off, idx, w):
+    """BASELINE configs[2] next to the headline: 360 x 10 s utterances per rank, MFCC chain +
+    scoring + 2-byte LNA on the device; ms/step (max over ranks), per-stage split from HIP events,
+    and on rank 0 the fraction of one utterance's LNA bytes that equal the oracle's."""
+    from aaltoasr_amd import pipeline
+    runner = pipeline.FullChainBench(gmm, n_utts=360, seconds=10.0, rank=rank, device=dev)
+    steps = 3
+    runner.step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        runner.step()
+    sync_all()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    split = runner.stage_split(steps)
+    out = {"workload": "configs[2]: MFCC chain + %d-Gaussian scoring + 2-byte LNA, 360 x 10 s utterances per rank (%d frames), device resident" % (G, runner.total_frames),
+           "frames_per_gpu_per_step": runner.total_frames, "steps": steps,
+           "ms_per_step": round(1e3 * elapsed / steps, 4),
+           "frames_per_s": round(world * runner.total_frames * steps / elapsed, 1),
+           "stage_ms": split,
+           "hbm_bytes_written_per_frame": runner.bytes_written_per_frame()}
+    if rank == 0:
+        from oracle import oracle as O
+        O.build()
+        u = 1
+        ch = O.FeatureChain(runner.cfg_text)
+        om = O.DiagModel(mean, var, off, idx, w)
+        nfr = int(runner.frame_off[u + 1] - runner.frame_off[u])
+        fea = ch.generate(runner.utts[u], 0, nfr)
+        _, lik = om.score(fea, want_lik=True)
+        _, by_ref = O.lna_encode(lik, True, 2)
+        got = runner.d_bytes[int(runner.frame_off[u]):int(runner.frame_off[u + 1])].cpu().numpy()
+        a = got.reshape(nfr, S, 2).astype(np.int32)
+        b = np.asarray(by_ref).reshape(nfr, S, 2).astype(np.int32)
+        ca, cb = a[..., 0] * 256 + a[..., 1], b[..., 0] * 256 + b[..., 1]
+        out["lna_check"] = {"utterance": u, "frames": nfr, "codes_equal_fraction": round(float((ca == cb).mean()), 6),
+                            "max_code_difference": int(np.abs(ca - cb).max()),
+                            "against": "oracle restatement of phone_probs (double), same audio and model"}
+    return out
+
+
 def _observe_clock(enqueue, torch):
     """Queues ~1.5 s of scoring launches and reads rocm-smi once while they run."""
     import re
-    import subprocess
     try:
         torch.cuda.synchronize()
         enqueue()
