@@ -160,6 +160,7 @@ def _declare(L: C.CDLL) -> None:
     L.aasr_lna_encode_dev_pitched.argtypes = [vp, i64, i64, i32, C.c_int, C.c_int, vp, vp, vp]
     L.aasr_feat_write_config.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(i64)]
     L.aasr_recipe_read.argtypes = [cp, i32, i32, C.POINTER(C.c_void_p), C.POINTER(i64)]
+    L.aasr_recipe_read_all.argtypes = [cp, i32, i32, i32, C.POINTER(C.c_void_p), C.POINTER(i64)]
     L.aasr_audio_read.argtypes = [vp, cp, C.POINTER(C.POINTER(C.c_int16)), C.POINTER(i64),
                                   C.POINTER(i32)]
 
@@ -533,6 +534,26 @@ def recipe_read(text, num_batches: int = 0, batch_index: int = 0):
         # the times are float fields printed with 9 significant digits: exact through float32
         rows.append(tuple(x.decode("latin-1") for x in f[:4]) +
                     (float(np.float32(float(f[4]))), float(np.float32(float(f[5])))))
+    return rows
+
+
+def recipe_read_all(text, num_batches: int = 0, batch_index: int = 0, cluster_speakers: bool = False):
+    """Recipe::read with every Info field: list of 13-tuples (audio, alt-audio, transcript,
+    alignment, hmmnet, den-hmmnet, lna, start_time, end_time, start_line, end_line, speaker,
+    utterance)."""
+    out = C.c_void_p()
+    n = C.c_int64()
+    raw = text if isinstance(text, bytes) else text.encode()
+    check(lib().aasr_recipe_read_all(raw, num_batches, batch_index, int(cluster_speakers), C.byref(out), C.byref(n)))
+    try:
+        table = C.string_at(out, n.value)
+    finally:
+        lib().aasr_free(out)
+    rows = []
+    for line in table.split(b"\n")[:-1]:
+        f = [x.decode("latin-1") for x in line.split(b"\x1f")]
+        rows.append(tuple(f[:7]) + (float(np.float32(float(f[7]))), float(np.float32(float(f[8]))),
+                                    int(f[9]), int(f[10]), f[11], f[12]))
     return rows
 
 

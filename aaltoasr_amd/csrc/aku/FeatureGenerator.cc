@@ -4,7 +4,11 @@
 #include <climits>
 #include <cstring>
 
+#include <algorithm>
+#include <cerrno>
+
 #include "../pipeline.h"
+#include "FeatureModules.hh"
 
 namespace aku {
 
@@ -12,11 +16,24 @@ static void check(aasr_status st) {
   if (st != AASR_OK) throw std::string(aasr_last_error());
 }
 
+// live generators, for find_block (a handful at most; not thread-safe like the rest of aku)
+static std::vector<const FeatureGenerator *> &registry() {
+  static std::vector<const FeatureGenerator *> r;
+  return r;
+}
+
 FeatureGenerator::FeatureGenerator()
     : m_feat(nullptr), m_open(false), m_eof_on_last_frame(false), m_block_first(0),
-      m_block_count(0), m_block_frames(2048), m_block_serial(0) {}
+      m_block_count(0), m_block_frames(2048), m_block_serial(0) {
+  registry().push_back(this);
+}
 
-FeatureGenerator::~FeatureGenerator() { close_configuration(); }
+FeatureGenerator::~FeatureGenerator() {
+  close();
+  close_configuration();
+  std::vector<const FeatureGenerator *> &r = registry();
+  r.erase(std::remove(r.begin(), r.end(), this), r.end());
+}
 
 void FeatureGenerator::load_configuration(FILE *file) {
   std::string text;
@@ -40,24 +57,153 @@ void FeatureGenerator::load_configuration_text(const std::string &text) {
     fprintf(stdout, "FeatureGenerator: loading a new feature configuration\n");
     close_configuration();
   }
-  check(aasr_feat_create(text.c_str(), &m_feat));
-  m_modules.clear();
+  build(text, false);
+}
+
+// the module blocks of a written configuration: "module" then "{ ... }" (feat_write_configuration)
+static std::vector<ModuleConfig> parse_blocks(const std::string &text) {
+  std::vector<ModuleConfig> out;
+  size_t pos = 0;
+  while ((pos = text.find('{', pos)) != std::string::npos) {
+    const size_t end = text.find('}', pos);
+    if (end == std::string::npos) break;
+    ModuleConfig c;
+    c.read_text(text.substr(pos, end - pos + 1) + "\n");
+    out.push_back(c);
+    pos = end + 1;
+  }
+  return out;
+}
+
+void FeatureGenerator::build(const std::string &text, bool keep_modules) {
+  aasr_feat *h = nullptr;
+  check(aasr_feat_create(text.c_str(), &h));
+  if (m_feat) aasr_feat_destroy(m_feat);
+  m_feat = h;
+  m_block_count = 0;
+  m_epoch++;
   const int n = aasr_feat_num_modules(m_feat);
-  m_modules.resize((size_t)n);
+  if (!keep_modules || (int)m_modules.size() != n) {
+    m_modules.clear();
+    for (int i = 0; i < n; i++) {
+      const std::string type = aasr_feat_module_type(m_feat, i);
+      FeatureModule *m;
+      if (type == "audiofile") m = new AudioFileModule();
+      else if (type == "pre") m = new PreModule();
+      else m = new FeatureModule();
+      m_modules.emplace_back(m);
+    }
+  }
+  // every module's own configuration as the engine writes it (defaults made explicit)
+  char *written = nullptr;
+  int64_t len = 0;
+  check(aasr_feat_write_config(m_feat, &written, &len));
+  const std::vector<ModuleConfig> blocks = parse_blocks(std::string(written, (size_t)len));
+  aasr_free(written);
   for (int i = 0; i < n; i++) {
-    FeatureModule &m = m_modules[(size_t)i];
+    FeatureModule &m = *m_modules[(size_t)i];
     m.m_gen = this;
     m.m_name = aasr_feat_module_name(m_feat, i);
-    m.m_type = aasr_feat_module_type(m_feat, i);
+    m.m_type_str = aasr_feat_module_type(m_feat, i);
     m.m_dim = aasr_feat_module_dim(m_feat, m.m_name.c_str());
+    m.m_count = 0;
+    m.m_sources.clear();
+    m.m_config = (size_t)i < blocks.size() ? blocks[(size_t)i] : ModuleConfig();
+    std::vector<std::string> src;
+    m.m_config.get("sources", src);
+    for (const std::string &sname : src)
+      for (int j = 0; j < i; j++)
+        if (m_modules[(size_t)j]->m_name == sname) m.m_sources.push_back(m_modules[(size_t)j].get());
+    // look-around the module adds itself (aku/FeatureModules.cc: Delta width, MeanSubtractor
+    // left/right, Concat left/right)
+    m.m_own_offset_left = m.m_own_offset_right = 0;
+    int a = 0, b = 0;
+    if (m.m_type_str == "delta") {
+      if (m.m_config.get("width", a)) m.m_own_offset_left = m.m_own_offset_right = a;
+    } else if (m.m_type_str == "mean_subtractor" || m.m_type_str == "concat") {
+      if (m.m_config.get("left", a)) m.m_own_offset_left = a;
+      if (m.m_config.get("right", b)) m.m_own_offset_right = b;
+    }
+    m.m_req_offset_left = m.m_req_offset_right = 0;
+  }
+  // FeatureModule::set_buffer (aku/FeatureModules.cc:38-69): what the consumers ask for, pushed
+  // down to the sources
+  for (int i = n - 1; i >= 0; i--) {
+    FeatureModule &m = *m_modules[(size_t)i];
+    for (FeatureModule *src : m.m_sources) {
+      src->m_req_offset_left = std::max(src->m_req_offset_left, m.m_req_offset_left + m.m_own_offset_left);
+      src->m_req_offset_right = std::max(src->m_req_offset_right, m.m_req_offset_right + m.m_own_offset_right);
+    }
   }
 }
 
+void FeatureGenerator::reconfigure_module(const std::string &name, const ModuleConfig &config) {
+  if (!m_feat) throw std::string("no feature modules defined");
+  std::string text;
+  bool found = false;
+  for (const std::unique_ptr<FeatureModule> &m : m_modules) {
+    ModuleConfig c = m->m_name == name ? config : m->m_config;
+    if (m->m_name == name) {
+      found = true;
+      // name, type and sources are the graph's, not the module's, to change
+      std::string v;
+      if (!c.exists("name")) c.set("name", m->m_name);
+      if (!c.exists("type")) c.set("type", m->m_type_str);
+      if (!c.exists("sources") && m->m_config.get("sources", v)) c.set("sources", v);
+    }
+    text += "module\n" + c.text() + "\n";
+  }
+  if (!found) throw std::string("unknown module requested: ") + name;
+  build(text, true);
+}
+
 FeatureModule *FeatureGenerator::module(const std::string &name) {
-  for (FeatureModule &m : m_modules)
-    if (m.m_name == name) return &m;
+  for (std::unique_ptr<FeatureModule> &m : m_modules)
+    if (m->m_name == name) return m.get();
   throw std::string("unknown module requested: ") + name;
 }
+
+const FeatureGenerator *FeatureGenerator::find_block(const double *p, int *frame) {
+  for (const FeatureGenerator *g : registry()) {
+    if (g->m_block_count == 0 || g->m_block.empty()) continue;
+    const double *lo = g->m_block.data();
+    const int d = aasr_feat_dim(g->m_feat);
+    const double *hi = lo + (size_t)g->m_block_count * d;
+    if (p >= lo && p < hi && (p - lo) % d == 0) {
+      *frame = g->m_block_first + (int)((p - lo) / d);
+      return g;
+    }
+  }
+  return nullptr;
+}
+
+void FeatureGenerator::print_dot_graph(FILE *file) {
+  fprintf(file, "digraph features {\n");
+  fprintf(file, "rankdir=RL;\n");
+  for (std::unique_ptr<FeatureModule> &m : m_modules) m->print_dot_node(file);
+  for (std::unique_ptr<FeatureModule> &m : m_modules)
+    for (FeatureModule *src : m->sources())
+      fprintf(file, "\t%s -> %s;\n", m->name().c_str(), src->name().c_str());
+  fprintf(file, "}\n");
+}
+
+// aku/FeatureModules.cc:202-217.  own / req are the reference's numbers; `init` and `buf` describe
+// its ring buffers (initial fill offsets, slots) -- the engine evaluates whole blocks, so they are
+// printed as the requirement itself and the window it spans.
+void FeatureModule::print_dot_node(FILE *file) {
+  fprintf(file, "  %s [label=\"%s\\nown=%d-%d\\nreq=%d-%d\\ninit=%d-%d\\nbuf=%d\\n\"]\n", m_name.c_str(),
+          m_name.c_str(), m_own_offset_left, m_own_offset_right, m_req_offset_left, m_req_offset_right,
+          m_req_offset_left, m_req_offset_right, m_req_offset_left + m_req_offset_right + 1);
+}
+
+void FeatureModule::get_config(ModuleConfig &config) { config = m_config; }
+
+void FeatureModule::set_config(const ModuleConfig &config) { m_gen->reconfigure_module(m_name, config); }
+
+bool BaseFeaModule::eof(int frame) { return frame >= m_gen->last_frame() + 1; }
+int BaseFeaModule::sample_rate(void) { return m_gen->sample_rate(); }
+float BaseFeaModule::frame_rate(void) { return m_gen->frame_rate(); }
+int BaseFeaModule::last_frame(void) { return m_gen->last_frame(); }
 
 void FeatureModule::set_parameters(const ModuleConfig &config) {
   if (aasr_feat_set_parameters(m_gen->handle(), m_name.c_str(), config.text().c_str()) != AASR_OK)
@@ -65,7 +211,7 @@ void FeatureModule::set_parameters(const ModuleConfig &config) {
   m_gen->invalidate_block();  // every cached frame downstream is stale
 }
 
-void FeatureModule::get_parameters(ModuleConfig &config) const {
+void FeatureModule::get_parameters(ModuleConfig &config) {
   char *text = nullptr;
   int64_t len = 0;
   if (aasr_feat_get_parameters(m_gen->handle(), m_name.c_str(), &text, &len) != AASR_OK)
@@ -114,8 +260,18 @@ void FeatureGenerator::open(const std::string &filename) {
   m_eof_on_last_frame = false;
 }
 
-void FeatureGenerator::open(FILE *file, bool) {
+void FeatureGenerator::open_fd(const int fd, bool) {
+  if (m_file != nullptr) close();
+  FILE *file = fdopen(fd, "rb");
+  if (file == nullptr) throw std::string("could not open fd ") + ": " + strerror(errno);
+  open(file, false, false);
+}
+
+void FeatureGenerator::open(FILE *file, bool dont_fclose, bool) {
   if (!m_feat) throw std::string("no feature modules defined");
+  if (m_file != nullptr) close();
+  m_file = file;
+  m_dont_fclose = dont_fclose;
   std::vector<char> data;
   char buf[65536];
   size_t n;
@@ -143,6 +299,10 @@ void FeatureGenerator::open_pcm(const int16_t *pcm, int64_t n_samples) {
 }
 
 void FeatureGenerator::close() {
+  // aku/FeatureGenerator.cc:86-93: the file handed to open(FILE*, ...) is ours to close unless
+  // the caller kept it
+  if (m_file != nullptr && !m_dont_fclose) fclose(m_file);
+  m_file = nullptr;
   m_open = false;
   m_pcm.clear();
   m_block_count = 0;

@@ -12,6 +12,10 @@ HmmSet::HmmSet()
 HmmSet::~HmmSet() { drop_model(); }
 
 void HmmSet::drop_model() {
+  m_gauss_views.clear();
+  m_mix_views.clear();
+  m_single_x.clear();
+  m_pool_x.clear();
   if (m_gmm) aasr_gmm_destroy(m_gmm);
   m_gmm = nullptr;
   m_owner = nullptr;
@@ -109,13 +113,16 @@ int HmmSet::num_pool_pdfs() {
 }
 
 double HmmSet::pool_log_likelihood(const int g, const FeatureVec &f) {
+  return pool_log_likelihood(g, f.data(), f.dim());
+}
+
+double HmmSet::pool_log_likelihood(const int g, const double *px, int dim) {
   ensure_model();
   const int G = aasr_gmm_num_gaussians(m_gmm);
   if (g < 0 || g >= G) throw std::string("PDFPool: Gaussian index out of range");
-  std::vector<double> x;
-  f.get(x);
+  std::vector<double> x(px, px + dim);
   if (x != m_pool_x || (int)m_pool_ll.size() != G) {
-    if (f.dim() != aasr_gmm_dim(m_gmm))
+    if (dim != aasr_gmm_dim(m_gmm))
       throw std::string("HmmSet: feature dimension does not match the model");
     std::vector<float> xf(x.begin(), x.end());
     m_pool_ll.resize((size_t)G);
@@ -150,16 +157,108 @@ const float *HmmSet::state_loglik_row(const FeatureVec &f) {
       return &m_block_ll[(size_t)(f.frame() - m_first) * S];
     }
   }
-  // a vector that does not come from a cached block: score it alone
-  if (f.dim() != aasr_gmm_dim(m_gmm))
+  return state_loglik_row(f.data(), f.dim());
+}
+
+const float *HmmSet::state_loglik_row(const double *px, int dim) {
+  ensure_model();
+  const int S = aasr_gmm_num_states(m_gmm);
+  // a Vector handed out by a generator (FeatureVec::get_vector()) still lies in its block
+  int frame = 0;
+  const FeatureGenerator *own = FeatureGenerator::find_block(px, &frame);
+  if (own) return state_loglik_row(FeatureVec(px, dim, frame, own));
+  // a vector that does not come from a cached block: score it alone, keep it until the next one
+  if (dim != aasr_gmm_dim(m_gmm))
     throw std::string("HmmSet: feature dimension does not match the model");
-  std::vector<float> x;
-  f.get(x);
+  std::vector<double> xd(px, px + dim);
+  if (xd == m_single_x && (int)m_single_ll.size() == S) return m_single_ll.data();
+  std::vector<float> x(xd.begin(), xd.end());
   m_single_ll.resize(S);
   if (aasr_gmm_score(m_gmm, x.data(), 1, m_single_ll.data()) != AASR_OK)
     throw std::string(aasr_last_error());
+  m_single_x = xd;
   return m_single_ll.data();
 }
+
+// ---- Distributions views ----------------------------------------------------------------
+
+PDFPool *HmmSet::get_pool() {
+  ensure_model();
+  m_pool_view.m_set = this;
+  return &m_pool_view;
+}
+
+PDF *HmmSet::get_pool_pdf(int index) {
+  ensure_model();
+  const int G = aasr_gmm_num_gaussians(m_gmm);
+  if (index < 0 || index >= G) throw std::string("PDFPool: Gaussian index out of range");
+  if ((int)m_gauss_views.size() != G) {
+    m_gauss_views.clear();
+    m_gauss_views.resize((size_t)G);
+  }
+  std::unique_ptr<Gaussian> &v = m_gauss_views[(size_t)index];
+  if (!v) {
+    v.reset(new Gaussian());
+    v->m_set = this;
+    v->m_index = index;
+  }
+  return v.get();
+}
+
+Mixture *HmmSet::get_emission_pdf(int index) {
+  ensure_model();
+  const int S = aasr_gmm_num_states(m_gmm);
+  if (index < 0 || index >= S) throw std::string("HmmSet: state index out of range");
+  if ((int)m_mix_views.size() != S) {
+    m_mix_views.clear();
+    m_mix_views.resize((size_t)S);
+  }
+  std::unique_ptr<Mixture> &v = m_mix_views[(size_t)index];
+  if (!v) {
+    v.reset(new Mixture());
+    v->m_set = this;
+    v->m_index = index;
+    const int n = aasr_gmm_mixture_size(m_gmm, index);
+    std::vector<int32_t> idx((size_t)n);
+    v->m_weights.resize((size_t)n);
+    if (aasr_gmm_mixture_get(m_gmm, index, idx.data(), v->m_weights.data()) != AASR_OK)
+      throw std::string(aasr_last_error());
+    v->m_pointers.assign(idx.begin(), idx.end());
+  }
+  return v.get();
+}
+
+int PDF::dim() const { return m_set->dim(); }
+
+double Gaussian::compute_log_likelihood(const Vector &f) const {
+  return m_set->pool_log_likelihood(m_index, f.addr(), f.size());
+}
+double Gaussian::compute_likelihood(const Vector &f) const { return std::exp(compute_log_likelihood(f)); }
+
+void Gaussian::get_mean(Vector &mean) const {
+  mean.resize(m_set->dim());
+  if (aasr_gmm_gaussian_get(m_set->handle(), m_index, mean.addr(), nullptr) != AASR_OK)
+    throw std::string(aasr_last_error());
+}
+void Gaussian::get_covariance(Vector &covariance) const {
+  covariance.resize(m_set->dim());
+  if (aasr_gmm_gaussian_get(m_set->handle(), m_index, nullptr, covariance.addr()) != AASR_OK)
+    throw std::string(aasr_last_error());
+}
+
+int PDFPool::size() const { return m_set->num_pool_pdfs(); }
+int PDFPool::dim() const { return m_set->dim(); }
+PDF *PDFPool::get_pdf(int index) const { return m_set->get_pool_pdf(index); }
+double PDFPool::compute_likelihood(const Vector &f, int index) {
+  return std::exp(m_set->pool_log_likelihood(index, f.addr(), f.size()));
+}
+void PDFPool::precompute_likelihoods(const Vector &f) { (void)m_set->pool_log_likelihood(0, f.addr(), f.size()); }
+
+PDF *Mixture::get_base_pdf(int index) { return m_set->get_pool_pdf(m_pointers[(size_t)index]); }
+double Mixture::compute_likelihood(const Vector &f) const {
+  return std::exp((double)m_set->state_loglik_row(f.addr(), f.size())[m_index]);
+}
+double Mixture::compute_log_likelihood(const Vector &f) const { return util::safe_log(compute_likelihood(f)); }
 
 void HmmSet::precompute_likelihoods(const FeatureVec &f) {
   reset_cache();

@@ -16,6 +16,10 @@
 #include <string>
 #include <vector>
 
+#include <assert.h>
+#include <memory>
+
+#include "Distributions.hh"
 #include "FeatureGenerator.hh"
 
 namespace aku {
@@ -49,6 +53,19 @@ public:
   void precompute_likelihoods(const FeatureVec &f);
   double state_likelihood(const int s, const FeatureVec &f);
   double pdf_likelihood(const int p, const FeatureVec &f) { return state_likelihood(p, f); }
+
+  /** aku/HmmSet.hh:216-228: the pool, one of its Gaussians, one state's mixture -- views on the
+   * device-resident model (Distributions.hh) */
+  PDFPool *get_pool();
+  PDF *get_pool_pdf(int index);
+  Mixture *get_emission_pdf(int index);
+  /** aku/HmmSet.hh:120: emission pdf of a state (the legacy .ph format: the state's own index) */
+  int emission_pdf_index(int state) const { return state; }
+
+  /** likelihoods for a raw vector (what the PDF / Mixture views call): the row of state
+   * log-likelihoods, from the block cache when `x` is a frame of a generator's block */
+  const float *state_loglik_row(const double *x, int dim);
+  double pool_log_likelihood(const int g, const double *x, int dim);
 
   /** PDFPool::size / compute_likelihood / compute_log_likelihood for one pool Gaussian
    * (aku/Distributions.hh:262-263, aku/Distributions.cc:2636-2644, 1033-1062): the whole pool is
@@ -84,7 +101,12 @@ private:
   int m_first, m_count;
   std::vector<float> m_block_ll;  // [count x S]
   std::vector<float> m_single_ll;  // one frame, for vectors without a block
+  std::vector<double> m_single_x;  // the vector m_single_ll belongs to
   const float *m_row;
+  // Distributions views, created on first use
+  PDFPool m_pool_view;
+  std::vector<std::unique_ptr<Gaussian>> m_gauss_views;
+  std::vector<std::unique_ptr<Mixture>> m_mix_views;
 };
 
 }  // namespace aku

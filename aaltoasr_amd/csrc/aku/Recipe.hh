@@ -1,0 +1,94 @@
+// Recipe.hh -- aku::Recipe (aku/Recipe.hh:36-118) on the engine's recipe reader
+// (aasr_recipe_read_all, csrc/pipeline.cc: the reference's line cleaning, key persistence,
+// batch walk and cluster_speakers rule): read(FILE*, num_batches, batch_index,
+// cluster_speakers), infos with every Info field, clear(), sort_infos().
+// Info::init_phn_files / init_hmmnet_files open the trainers' PhnReader / HmmNetBaumWelch and
+// are not part of the scoring path; they are not declared here.
+#ifndef AKU_AMD_RECIPE_HH
+#define AKU_AMD_RECIPE_HH
+
+#include <algorithm>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string>
+#include <vector>
+
+#include "FeatureGenerator.hh"
+
+namespace aku {
+
+class Recipe {
+public:
+  class Info {
+  public:
+    std::string audio_path;
+    std::string alt_audio_path;
+    std::string transcript_path;
+    std::string alignment_path;
+    std::string hmmnet_path;
+    std::string den_hmmnet_path;
+    std::string lna_path;
+    float start_time;
+    float end_time;
+    int start_line;
+    int end_line;
+    std::string speaker_id;
+    std::string utterance_id;
+
+    Info() : start_time(0), end_time(0), start_line(0), end_line(0) {}
+    bool operator<(const Info &i) const { return (speaker_id < i.speaker_id); }
+  };
+
+  void clear() { infos.clear(); }
+
+  void read(FILE *f, int num_batches, int batch_index, bool cluster_speakers) {
+    std::string text;
+    char buf[4096];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
+    char *table = NULL;
+    int64_t len = 0;
+    if (aasr_recipe_read_all(text.c_str(), num_batches, batch_index, cluster_speakers ? 1 : 0, &table, &len) != AASR_OK)
+      throw std::string(aasr_last_error());
+    const std::string t(table, (size_t)len);
+    aasr_free(table);
+    size_t pos = 0;
+    while (pos < t.size()) {
+      size_t eol = t.find('\n', pos);
+      if (eol == std::string::npos) eol = t.size();
+      std::vector<std::string> f13;
+      size_t a = pos;
+      while (a <= eol) {
+        size_t b = t.find('\x1f', a);
+        if (b == std::string::npos || b > eol) b = eol;
+        f13.push_back(t.substr(a, b - a));
+        a = b + 1;
+      }
+      if (f13.size() == 13) {
+        Info i;
+        i.audio_path = f13[0];
+        i.alt_audio_path = f13[1];
+        i.transcript_path = f13[2];
+        i.alignment_path = f13[3];
+        i.hmmnet_path = f13[4];
+        i.den_hmmnet_path = f13[5];
+        i.lna_path = f13[6];
+        i.start_time = (float)atof(f13[7].c_str());   // "%.9g": exact for a float
+        i.end_time = (float)atof(f13[8].c_str());
+        i.start_line = atoi(f13[9].c_str());
+        i.end_line = atoi(f13[10].c_str());
+        i.speaker_id = f13[11];
+        i.utterance_id = f13[12];
+        infos.push_back(i);
+      }
+      pos = eol + 1;
+    }
+  }
+
+  std::vector<Info> infos;
+  void sort_infos() { std::stable_sort(infos.begin(), infos.end()); }
+};
+
+}  // namespace aku
+
+#endif

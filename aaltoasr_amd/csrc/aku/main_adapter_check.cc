@@ -109,7 +109,59 @@ static int pool_mode(const char *cfg, const char *base, const char *audio, const
   return 0;
 }
 
+// The Distributions surface as the reference's training tools use it: for a frame f
+//   model.get_emission_pdf(s)->compute_likelihood(*f.get_vector())     (aku/logl.cc:58-60 through
+//                                                                         HmmSet::state_likelihood)
+//   mixture->get_base_pdf(k)->compute_likelihood(*f.get_vector()), get_base_pdf_index, size,
+//   get_mixture_coefficient, Gaussian::get_mean / get_covariance        (aku/MllrTrainer.cc:40-56)
+//   model.get_pool()->compute_likelihood(*f.get_vector(), g)
+// plus the same calls on a Vector that is nobody's block (a copy).  One line per value.
+static int dist_mode(const char *cfg, const char *base, const char *audio, const char *out_path) {
+  aku::FeatureGenerator gen;
+  aku::HmmSet model;
+  FILE *cf = fopen(cfg, "r");
+  if (!cf) throw std::string("could not open config");
+  gen.load_configuration(cf);
+  fclose(cf);
+  model.read_all(base);
+  gen.open(audio);
+  FILE *out = fopen(out_path, "w");
+  if (!out) throw std::string("could not open output");
+  fprintf(out, "%d %d\n", model.num_states(), model.get_pool()->size());
+  for (int f : {3, 11}) {
+    aku::FeatureVec fea = gen.generate(f);
+    for (int s = 0; s < model.num_states(); s++) {
+      aku::Mixture *mixture = model.get_emission_pdf(model.emission_pdf_index(s));
+      double by_parts = 0;
+      for (int k = 0; k < mixture->size(); k++) {
+        aku::Gaussian *gaussian = dynamic_cast<aku::Gaussian *>(mixture->get_base_pdf(k));
+        by_parts += mixture->get_mixture_coefficient(k) * gaussian->compute_likelihood(*fea.get_vector());
+      }
+      const aku::Vector own = *fea.get_vector();  // a copy: not a frame of any block
+      fprintf(out, "%.9g %.9g %.9g %.9g %.9g\n", mixture->compute_likelihood(*fea.get_vector()),
+              mixture->compute_log_likelihood(*fea.get_vector()), model.state_likelihood(s, fea), by_parts,
+              mixture->compute_likelihood(own));
+    }
+    aku::Mixture *m0 = model.get_emission_pdf(0);
+    aku::Vector mean, covar;
+    dynamic_cast<aku::Gaussian *>(m0->get_base_pdf(0))->get_mean(mean);
+    dynamic_cast<aku::Gaussian *>(m0->get_base_pdf(0))->get_covariance(covar);
+    fprintf(out, "%d %.17g %.17g %.9g\n", m0->get_base_pdf_index(0), mean(0), covar(covar.size() - 1),
+            model.get_pool()->compute_likelihood(*fea.get_vector(), m0->get_base_pdf_index(0)));
+  }
+  fclose(out);
+  return 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc == 6 && std::string(argv[1]) == "dist") {
+    try {
+      return dist_mode(argv[2], argv[3], argv[4], argv[5]);
+    } catch (std::string &e) {
+      fprintf(stderr, "exception: %s\n", e.c_str());
+      return 1;
+    }
+  }
   if (argc == 6 && std::string(argv[1]) == "pool") {
     try {
       return pool_mode(argv[2], argv[3], argv[4], argv[5]);

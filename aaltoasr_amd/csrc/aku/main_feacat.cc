@@ -8,7 +8,8 @@
 // FILE "-" reads standard input like the reference's io::Stream.  Text output is
 // "%8.4f " per value (aku/feacat.cc:27-31); raw output is float32 with an
 // optional int32 dimension header (-H), the format PreModule reads back.
-// Not built: -G/--gaussian-std (needs the reference's ziggurat generator state).
+// -G/--gaussian-std adds N(0, std) noise to every value (aku/feacat.cc:38-42; the generator's
+// stream is this engine's own, see ziggurat.hh).
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +19,7 @@
 #include "FeatureGenerator.hh"
 #include "conf.hh"
 #include "SpeakerConfig.hh"
+#include "ziggurat.hh"
 
 static void die(const std::string &msg) {
   fprintf(stderr, "exception: %s\n", msg.c_str());
@@ -41,7 +43,7 @@ int main(int argc, char *argv[]) {
     ('G', "gaussian-std=FLOAT", "arg", "", "Gaussian noise std added to features");
   config.default_parse(argc, argv);
   if (config.arguments.size() != 1) config.print_help(stderr, 1);
-  if (config["gaussian-std"].specified) die("--gaussian-std is not built in this engine yet");
+  const double noise_std = config["gaussian-std"].specified ? config["gaussian-std"].get_double() : 0.0;
   const bool raw_output = config["raw-output"].specified, header = config["header"].specified;
   const std::string cfg = config["config"].get_str();
   const std::string speakers = config["speakers"].specified ? config["speakers"].get_str() : "";
@@ -79,7 +81,9 @@ int main(int argc, char *argv[]) {
       int dim = gen.dim();
       fwrite(&dim, sizeof(int), 1, stdout);
     }
-    auto print_feature = [&](const aku::FeatureVec &fea) {
+    auto print_feature = [&](aku::FeatureVec fea) {
+      if (noise_std > 0.0)  // on the generator's block, like the reference writes into its ring buffer
+        for (int i = 0; i < fea.dim(); i++) fea[i] += ziggurat::rnd.rnor() * noise_std;
       if (raw_output) {
         for (int i = 0; i < fea.dim(); i++) {
           float tmp = fea[i];

@@ -207,6 +207,37 @@ aasr_status aasr_gmm_create_from_cache_checked(const char *cache_path, const cha
   });
 }
 
+int32_t aasr_gmm_mixture_size(const aasr_gmm *h, int32_t state) {
+  if (!h || state < 0 || state >= h->S) return -1;
+  return h->host.mix_off[(size_t)state + 1] - h->host.mix_off[(size_t)state];
+}
+
+aasr_status aasr_gmm_mixture_get(const aasr_gmm *h, int32_t state, int32_t *index, double *weight) {
+  return guarded([&] {
+    if (!h || state < 0 || state >= h->S) raise(AASR_ERR_INVALID, "aasr_gmm_mixture_get: bad state index");
+    const HostModel &m = h->host;
+    for (int32_t k = m.mix_off[(size_t)state], j = 0; k < m.mix_off[(size_t)state + 1]; k++, j++) {
+      if (index) index[j] = m.mix_idx[(size_t)k];
+      if (weight) weight[j] = m.mix_w[(size_t)k];
+    }
+  });
+}
+
+aasr_status aasr_gmm_gaussian_get(const aasr_gmm *h, int32_t gaussian, double *mean, double *var) {
+  return guarded([&] {
+    if (!h || gaussian < 0 || gaussian >= h->G) raise(AASR_ERR_INVALID, "aasr_gmm_gaussian_get: bad Gaussian index");
+    const HostModel &m = h->host;
+    const size_t D = (size_t)m.dim;
+    for (size_t d = 0; d < D; d++) {
+      if (mean) mean[d] = m.mean[(size_t)gaussian * D + d];
+      if (var) {
+        const bool full = m.any_full() && m.is_full[(size_t)gaussian];
+        var[d] = full ? m.cov[((size_t)gaussian * D + d) * D + d] : m.var[(size_t)gaussian * D + d];
+      }
+    }
+  });
+}
+
 void aasr_gmm_destroy(aasr_gmm *h) { delete h; }
 int aasr_gmm_dim(const aasr_gmm *h) { return h ? h->dim : -1; }
 int aasr_gmm_num_states(const aasr_gmm *h) { return h ? (int)h->S : -1; }

@@ -111,7 +111,14 @@ std::vector<std::string> str_split(const std::string &s, const char *delims, boo
 // Recipe::read (aku/Recipe.cc:23-149).  Quirk kept: the key=value map is not
 // cleared between lines, so a key missing on a line inherits the value of the
 // previous line that set it -- including lines that belong to other batches.
-std::vector<RecipeInfo> recipe_read(const std::string &text, int num_batches, int batch_index) {
+// The walk is the reference's: a line is parsed, then the batch counter may advance (with
+// cluster_speakers only where the speaker changes), then the line is kept if the counter
+// equals batch_index; the loop stops at the first line of a later batch, so that line is still
+// checked for syntax (aku/Recipe.cc:79-103).
+std::vector<RecipeInfo> recipe_read(const std::string &text, int num_batches, int batch_index,
+                                    bool cluster_speakers) {
+  if (num_batches > 1 && (batch_index < 1 || batch_index > num_batches))
+    raise(AASR_ERR_INVALID, "Invalid batch index");
   std::vector<std::string> lines;
   {
     std::istringstream in(text);
@@ -122,34 +129,67 @@ std::vector<RecipeInfo> recipe_read(const std::string &text, int num_batches, in
       lines.push_back(line);
     }
   }
-  int first = 0, count = 0;
-  recipe_batch_range((int)lines.size(), num_batches, batch_index, &first, &count);
+  int target_lines, batch_remainder = 0;
+  if (num_batches <= 1) {
+    target_lines = (int)lines.size();
+  } else {
+    target_lines = (int)lines.size() / num_batches;
+    batch_remainder = (int)lines.size() % num_batches;
+  }
+  int extra_line = 1;
+  if (target_lines < 1) {
+    target_lines = 1;
+    extra_line = 0;
+  }
+  if (batch_remainder == 0) extra_line = 0;
   std::vector<RecipeInfo> infos;
   std::map<std::string, std::string> kv;
-  // the reference parses a line before it decides that the line opens the next batch, so the
-  // line after the slice is still checked for syntax (aku/Recipe.cc:79-103)
-  for (int i = 0; i < (int)lines.size() && i <= first + count; i++) {
-    for (const std::string &field : str_split(lines[i], " \t", true)) {
+  int cur_index = 1, cur_line = 0;
+  std::string cur_speaker;
+  for (const std::string &line : lines) {
+    for (const std::string &field : str_split(line, " \t", true)) {
       const std::vector<std::string> key_value = str_split(field, "=", false);
-      if (key_value.size() != 2) raise(AASR_ERR_INVALID, "Invalid recipe line: %s", lines[i].c_str());
+      if (key_value.size() != 2) raise(AASR_ERR_INVALID, "Invalid recipe line: %s", line.c_str());
       kv[key_value[0]] = key_value[1];
     }
-    if (i < first) continue;
-    if (i >= first + count) break;
-    RecipeInfo info;
-    auto get = [&](const char *k, std::string &dst) {
-      auto it = kv.find(k);
-      if (it != kv.end()) dst = it->second;
-    };
-    get("audio", info.audio_path);
-    get("lna", info.lna_path);
-    get("speaker", info.speaker_id);
-    get("utterance", info.utterance_id);
-    auto it = kv.find("start-time");
-    if (it != kv.end()) info.start_time = (float)atof(it->second.c_str());
-    it = kv.find("end-time");
-    if (it != kv.end()) info.end_time = (float)atof(it->second.c_str());
-    infos.push_back(info);
+    if (num_batches > 1 && cur_index < num_batches) {
+      auto sp = kv.find("speaker");
+      const std::string new_speaker = sp == kv.end() ? "" : sp->second;
+      if (cur_line >= target_lines + extra_line &&
+          (!cluster_speakers || cur_speaker.empty() || cur_speaker != new_speaker)) {
+        cur_index++;
+        if (cur_index > batch_index) break;
+        cur_line -= target_lines + extra_line;
+        if (cur_index > batch_remainder) extra_line = 0;
+      }
+      cur_speaker = new_speaker;
+    }
+    if (num_batches <= 1 || cur_index == batch_index) {
+      RecipeInfo info;
+      auto get = [&](const char *k, std::string &dst) {
+        auto it = kv.find(k);
+        if (it != kv.end()) dst = it->second;
+      };
+      get("audio", info.audio_path);
+      get("alt-audio", info.alt_audio_path);
+      get("transcript", info.transcript_path);
+      get("alignment", info.alignment_path);
+      get("hmmnet", info.hmmnet_path);
+      get("den-hmmnet", info.den_hmmnet_path);
+      get("lna", info.lna_path);
+      get("speaker", info.speaker_id);
+      get("utterance", info.utterance_id);
+      auto it = kv.find("start-time");
+      if (it != kv.end()) info.start_time = (float)atof(it->second.c_str());
+      it = kv.find("end-time");
+      if (it != kv.end()) info.end_time = (float)atof(it->second.c_str());
+      it = kv.find("start-line");
+      if (it != kv.end()) info.start_line = atoi(it->second.c_str());
+      it = kv.find("end-line");
+      if (it != kv.end()) info.end_line = atoi(it->second.c_str());
+      infos.push_back(info);
+    }
+    cur_line++;
   }
   return infos;
 }
@@ -670,6 +710,29 @@ void aasr_recipe_frame_limits(float start_time, float end_time, float frame_rate
   aasr::frame_limits(start_time, end_time, frame_rate, &a, &b);
   if (start_frame) *start_frame = a;
   if (end_frame) *end_frame = b;
+}
+
+aasr_status aasr_recipe_read_all(const char *recipe_text, int32_t num_batches, int32_t batch_index,
+                                 int32_t cluster_speakers, char **table_out, int64_t *table_len) {
+  return guarded([&] {
+    if (!recipe_text || !table_out || !table_len) raise(AASR_ERR_INVALID, "aasr_recipe_read_all: null argument");
+    std::string t;
+    char num[96];
+    for (const RecipeInfo &i : recipe_read(recipe_text, num_batches, batch_index, cluster_speakers != 0)) {
+      for (const std::string *f : {&i.audio_path, &i.alt_audio_path, &i.transcript_path, &i.alignment_path,
+                                   &i.hmmnet_path, &i.den_hmmnet_path, &i.lna_path})
+        t += *f + "\x1f";
+      snprintf(num, sizeof num, "%.9g\x1f%.9g\x1f%d\x1f%d\x1f", (double)i.start_time, (double)i.end_time,
+               i.start_line, i.end_line);
+      t += num;
+      t += i.speaker_id + "\x1f" + i.utterance_id + "\n";
+    }
+    char *out = (char *)malloc(t.size() + 1);
+    if (!out) raise(AASR_ERR_INVALID, "aasr_recipe_read_all: out of memory");
+    memcpy(out, t.c_str(), t.size() + 1);
+    *table_out = out;
+    *table_len = (int64_t)t.size();
+  });
 }
 
 aasr_status aasr_recipe_read(const char *recipe_text, int32_t num_batches, int32_t batch_index,

@@ -9,7 +9,9 @@ namespace aasr {
 
 // the fields of aku::Recipe::Info the hot path consumes (aku/Recipe.hh)
 struct RecipeInfo {
-  std::string audio_path, lna_path, speaker_id, utterance_id;
+  std::string audio_path, alt_audio_path, transcript_path, alignment_path, hmmnet_path, den_hmmnet_path;
+  std::string lna_path, speaker_id, utterance_id;
+  int start_line = 0, end_line = 0;
   // float, as Recipe::Info (aku/Recipe.hh:48-49): atof narrowed on assignment
   float start_time = 0, end_time = 0;
 };
@@ -17,7 +19,8 @@ struct RecipeInfo {
 std::string str_clean(const std::string &s, const char *chars);
 std::vector<std::string> str_split(const std::string &s, const char *delims, bool group, int num_fields = 0);
 void recipe_batch_range(int total, int num_batches, int batch_index, int *first, int *count);
-std::vector<RecipeInfo> recipe_read(const std::string &text, int num_batches, int batch_index);
+std::vector<RecipeInfo> recipe_read(const std::string &text, int num_batches, int batch_index,
+                                    bool cluster_speakers = false);
 // audio_reader.cc
 std::vector<int16_t> read_audio_file(const std::string &path, bool force_raw, int expect_rate,
                                      bool big_endian = false, int *rate_out = nullptr);

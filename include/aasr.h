@@ -192,6 +192,15 @@ aasr_status aasr_gmm_create_from_cache_checked(const char *cache_path, const cha
                                                aasr_gmm **out);
 void aasr_gmm_destroy(aasr_gmm *h);
 
+/* Model structure for host-side views (aku::Mixture::size / get_base_pdf_index /
+ * get_mixture_coefficient, aku/Distributions.hh:795-812; Gaussian::get_mean /
+ * get_covariance of a diagonal Gaussian): weights are the normalised ones
+ * (Mixture::read -> normalize_weights), index[] / weight[] take
+ * aasr_gmm_mixture_size(h, state) values, mean[] / var[] take dim values. */
+int32_t aasr_gmm_mixture_size(const aasr_gmm *h, int32_t state);
+aasr_status aasr_gmm_mixture_get(const aasr_gmm *h, int32_t state, int32_t *index, double *weight);
+aasr_status aasr_gmm_gaussian_get(const aasr_gmm *h, int32_t gaussian, double *mean, double *var);
+
 int aasr_gmm_dim(const aasr_gmm *h);            /* HmmSet::dim()        */
 int aasr_gmm_num_states(const aasr_gmm *h);     /* HmmSet::num_states() */
 int aasr_gmm_num_gaussians(const aasr_gmm *h);  /* PDFPool::size()      */
@@ -331,6 +340,13 @@ aasr_status aasr_recipe_batch_range(int32_t num_lines_total, int32_t num_batches
  * through str::split (a trailing '=' is dropped), keys persist across lines. */
 aasr_status aasr_recipe_read(const char *recipe_text, int32_t num_batches, int32_t batch_index,
                              char **table_out, int64_t *table_len);
+
+/* The same with every field of Recipe::Info (aku/Recipe.hh:40-52) and the cluster_speakers
+ * flag of Recipe::read (a batch only ends where the speaker changes, aku/Recipe.cc:86-101):
+ * audio, alt-audio, transcript, alignment, hmmnet, den-hmmnet, lna, start-time, end-time,
+ * start-line, end-line, speaker, utterance -- 13 fields separated by 0x1f per line. */
+aasr_status aasr_recipe_read_all(const char *recipe_text, int32_t num_batches, int32_t batch_index,
+                                 int32_t cluster_speakers, char **table_out, int64_t *table_len);
 
 /* start/end frame of an utterance as phone_probs derives them from the recipe's
  * start-time / end-time (aku/phone_probs.cc:199-206): `(int)(time * frame_rate)`

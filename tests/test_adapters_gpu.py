@@ -311,3 +311,35 @@ def test_pool_likelihood_view(capi, oracle, world):
         got = vals[k * G:(k + 1) * G]
         assert np.abs(got[:, 0] - ref).max() <= 1e-4
         assert np.allclose(got[:, 1], np.exp(got[:, 0]), rtol=1e-6)
+
+
+def test_distributions_surface(capi, oracle, world):
+    """HmmSet::get_emission_pdf / get_pool_pdf / get_pool and PDF / Mixture / PDFPool::
+    compute_likelihood(const Vector&) (aku/HmmSet.hh:216-228, aku/Distributions.hh:66-69,145,
+    872-873) called the way aku/MllrTrainer.cc:40-56 and aku/logl.cc:58-60 do: mixture value =
+    state_likelihood = weighted sum of its Gaussians' values = the oracle's, for a block frame
+    and for a free-standing copy of it."""
+    out = str(world["dir"] / "dist.txt")
+    r = subprocess.run([os.path.join(BIN, "aku_adapter_check"), "dist", world["cfg"], world["base"],
+                        str(world["dir"] / "a1.wav"), out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = open(out).read().split("\n")
+    S, G = (int(x) for x in lines[0].split())
+    assert (S, G) == (32, 256)
+    mean, var, off, idx, w = world["model"]
+    fea = world["ft"].run(world["pcms"][1], 0, 12, dtype=np.float64)
+    om = oracle.DiagModel(mean, var, off, idx, w)
+    pos = 1
+    for f in (3, 11):
+        vals = np.array([[float(x) for x in l.split()] for l in lines[pos:pos + S]])
+        ll_ref, lik_ref = om.score(fea[f:f + 1], want_lik=True)
+        lik_ref = np.maximum(lik_ref[0], 1e-50)
+        assert np.allclose(vals[:, 0], lik_ref, rtol=2e-4)            # Mixture::compute_likelihood
+        assert np.abs(vals[:, 1] - np.log(lik_ref)).max() <= 1e-4     # compute_log_likelihood
+        assert np.array_equal(vals[:, 0], vals[:, 2])                 # == HmmSet::state_likelihood
+        assert np.allclose(vals[:, 3], lik_ref, rtol=2e-4)            # sum_k w_k N_k by hand
+        assert np.allclose(vals[:, 4], vals[:, 0], rtol=1e-5)         # a copy of the vector, scored alone
+        g0, m0, c_last, lik_g0 = lines[pos + S].split()
+        assert int(g0) == idx[off[0]] and float(m0) == mean[int(g0), 0] and float(c_last) == var[int(g0), -1]
+        assert abs(np.log(float(lik_g0)) - om.gauss_loglik(fea[f:f + 1])[0][int(g0)]) <= 1e-4
+        pos += S + 1

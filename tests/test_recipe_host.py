@@ -115,3 +115,31 @@ def test_recipe_times_are_float_and_frame_limits_use_float_arithmetic(capi, orac
         assert capi.recipe_frame_limits(float(np.float32(float(t))), float(np.float32(float(t))), 125.0) == want
         differ += int(int(float(t) * 125.0) != want[0])
     assert differ > 20
+
+
+def test_recipe_cluster_speakers_and_all_fields(capi, oracle):
+    """aasr_recipe_read_all: every Recipe::Info field and the cluster_speakers rule (a batch only
+    ends where the speaker changes, aku/Recipe.cc:86-101) against the oracle's Recipe::read."""
+    import numpy as np
+    rng = np.random.default_rng(31)
+    for trial in range(120):
+        lines = []
+        spk = 0
+        for i in range(int(rng.integers(1, 25))):
+            if rng.random() < 0.35:
+                spk += 1
+            f = ["audio=a%d.wav" % i, "lna=l%d" % i]
+            if rng.random() < 0.8:
+                f.append("speaker=s%d" % spk)
+            if rng.random() < 0.3:
+                f += ["transcript=t%d.phn" % i, "alignment=al%d" % i, "hmmnet=h%d" % i, "den-hmmnet=d%d" % i,
+                      "alt-audio=b%d.wav" % i, "start-line=%d" % i, "end-line=%d" % (i + 7), "utterance=u%d" % i]
+            lines.append(" ".join(f))
+        text = "\n".join(lines) + "\n"
+        for n in (0, 2, 3, 5):
+            for b in range(1, max(n, 1) + 1):
+                for cl in (False, True):
+                    want = [(i.audio_path, i.alt_audio_path, i.transcript_path, i.alignment_path, i.hmmnet_path,
+                             i.den_hmmnet_path, i.lna_path, i.start_time, i.end_time, i.start_line, i.end_line,
+                             i.speaker_id, i.utterance_id) for i in oracle.recipe_read(text, n, b, cl)]
+                    assert capi.recipe_read_all(text, n, b, cl) == want, (text, n, b, cl)
