@@ -25,6 +25,12 @@ struct HostModel {
   std::vector<double> cov;
   std::vector<uint8_t> is_full;
   bool any_full() const { return !is_full.empty(); }
+  // per-Gaussian offset added to the log-likelihood constant (natural log; empty = none).
+  // Subspace-constrained Gaussians (SCGMM) are expanded at load time into full-covariance
+  // Gaussians; the reference's constant for them (aku/Distributions.cc:1905-1914: log det P -
+  // psi^T P^-1 psi - d log(2*3.1416), no halves) is not that of the normalised density, the
+  // difference rides here.
+  std::vector<double> gauss_bias;
   // model-side constrained MLLR (ConstrainedMllr / AdaptedGaussian,
   // aku/ModelModules.hh:128-212): Gaussian g scores A_t f + b_t instead of f and
   // its likelihood is multiplied by |prod diag A_t| (the reference's

@@ -12,7 +12,8 @@
 // path, the text files are parsed again instead of scoring with a stale model.
 //
 // Layout (little endian): "AASRGMM1", u32 version (2), i32 dim, i64 G, i64 S, i64 K,
-// u32 flags (bit 0: covariances present, bit 1: source fingerprint present), i64 number of HMMs,
+// u32 flags (bit 0: covariances present, bit 1: source fingerprint present, bit 2: per-Gaussian
+// constant offsets present), i64 number of HMMs,
 // u64 fingerprint[6], then mean[G*dim],
 // var[G*dim] (f64), [cov[G*dim*dim] f64, is_full[G] u8], mix_off[S+1] i32,
 // mix_idx[K] i32, mix_w[K] f64, per HMM {u32 label length, label, u32 states,
@@ -28,7 +29,7 @@ namespace aasr {
 namespace {
 
 const char kMagic[8] = {'A', 'A', 'S', 'R', 'G', 'M', 'M', '1'};
-const uint32_t kVersion = 2;
+const uint32_t kVersion = 3;
 
 uint64_t fnv1a(const char *b, size_t n, uint64_t h = 1469598103934665603ull) {
   for (size_t i = 0; i < n; i++) {
@@ -112,7 +113,7 @@ void write_model_cache(const HostModel &m, const char *path) {
   w.put<int64_t>(m.G);
   w.put<int64_t>(m.S);
   w.put<int64_t>((int64_t)m.mix_idx.size());
-  w.put<uint32_t>((m.any_full() ? 1u : 0u) | (m.has_src_fp ? 2u : 0u));
+  w.put<uint32_t>((m.any_full() ? 1u : 0u) | (m.has_src_fp ? 2u : 0u) | (m.gauss_bias.empty() ? 0u : 4u));
   w.put<int64_t>((int64_t)m.hmm_label.size());
   for (int i = 0; i < 6; i++) w.put<uint64_t>(m.has_src_fp ? m.src_fp[i] : 0ull);
   w.arr(m.mean);
@@ -121,6 +122,7 @@ void write_model_cache(const HostModel &m, const char *path) {
     w.arr(m.cov);
     w.arr(m.is_full);
   }
+  if (!m.gauss_bias.empty()) w.arr(m.gauss_bias);
   w.arr(m.mix_off);
   w.arr(m.mix_idx);
   w.arr(m.mix_w);
@@ -175,6 +177,7 @@ HostModel read_model_cache(const char *path) {
     r.arr(m.cov, gd * m.dim);
     r.arr(m.is_full, (size_t)m.G);
   }
+  if (flags & 4u) r.arr(m.gauss_bias, (size_t)m.G);
   r.arr(m.mix_off, (size_t)m.S + 1);
   r.arr(m.mix_idx, (size_t)K);
   r.arr(m.mix_w, (size_t)K);

@@ -1462,3 +1462,170 @@ def write_gk_full(path: str, mean: np.ndarray, cov: np.ndarray, is_full=None, va
             else:
                 vals += " ".join(repr(float(x)) for x in var[g])
                 f.write("diag " + vals + "\n")
+
+
+# ---------------------------------------------------------------------------
+# subspace Gaussians (G6): PCGMM / SCGMM.  PARITY UNPINNED -- the reference does not compile
+# these (USE_SUBSPACE_COV is never defined, aku/Subspaces.hh needs the un-vendored HCL library)
+# and holds no goldens; this restates the text of aku/Subspaces.cc and aku/Distributions.cc.
+# ---------------------------------------------------------------------------
+
+def map_v2m(vec: np.ndarray) -> np.ndarray:
+    """LinearAlgebra::map_v2m (aku/LinearAlgebra.cc:242-266): inverse of map_m2v, but the factor
+    for the off-diagonal elements is `float a = 1/sqrt(2.0)` -- a FLOAT."""
+    n = len(vec)
+    d = int(0.5 * np.sqrt(1.0 + 8.0 * n) - 0.5)
+    a = float(np.float32(1.0 / np.sqrt(2.0)))
+    m = np.zeros((d, d))
+    pos = 0
+    for i in range(d):
+        for j in range(i + 1):
+            if i == j:
+                m[j, j] = vec[pos]
+            else:
+                m[i, j] = m[j, i] = a * vec[pos]
+            pos += 1
+    return m
+
+
+def _spd_determinant(a: np.ndarray) -> float:
+    """LinearAlgebra::spd_determinant (aku/LinearAlgebra.cc:25-39): (prod diag chol)^2."""
+    c = np.linalg.cholesky(0.5 * (a + a.T))
+    det = 1.0
+    for i in range(c.shape[0]):
+        det *= c[i, i]
+    return det * det
+
+
+class SubspaceModel:
+    """A 'variable' .gk pool with precision_subspace / exponential_subspace / pcgmm / scgmm / diag /
+    full entries (aku/Distributions.cc:2831-2868) + mixtures, scored as
+    PDFPool::precompute_likelihoods' no-clustering branch would (:2663-2682).
+
+    pcgmm  PrecisionConstrainedGaussian::read (:1683-1704): ss_dim, transformed mean m~[dim],
+           lambda[ss_dim]; recompute_constant (:1785-1802): P = sum_b lambda_b S_b,
+           const = log sqrt spd_det(P) - 1/2 m~^T P^-1 m~.  compute_log_likelihood (:1638-1648):
+           q_b = -1/2 f^T S_b f (PrecisionSubspace::precompute, aku/Subspaces.cc:458-469) and
+               double result = m_constant + Blas_Dot_Prod(m_transformed_mean, f);
+                               + m_ps->dotproduct(m_coeffs);
+           -- the ';' after the first line ends the statement, so AS WRITTEN the lambda.q term is
+           dropped and the value is const + m~.f (`pcgmm_as_written=True`).  The default here is
+           the intended density const + m~.f + lambda.q, which is what the engine scores.
+    scgmm  SubspaceConstrainedGaussian::read (:1886-1916): ss_dim, lambda[ss_dim]; psi = sum_b
+           lambda_b psi_b, P = sum_b lambda_b P_b with P_b = map_v2m(Pvec_b) (float 1/sqrt 2),
+           const = log det(P) - psi^T P^-1 psi - d*log(2*3.1416)  (as written: no halves, the
+           literal 3.1416); compute_log_likelihood (:1851-1859) = const + lambda.q with
+           q_b = theta_b . [f ; map_m2v(-1/2 f f^T)] (ExponentialSubspace::precompute,
+           aku/Subspaces.cc:745-768)."""
+
+    def __init__(self, entries, dim, mix_off, mix_idx, mix_w, pcgmm_as_written=False):
+        self.dim = dim
+        self.as_written = pcgmm_as_written
+        self.mix_off = np.ascontiguousarray(mix_off, np.int32)
+        self.mix_idx = np.ascontiguousarray(mix_idx, np.int32)
+        self.mix_w = np.ascontiguousarray(mix_w, np.float64).copy()
+        lib().orc_mixture_normalize(len(self.mix_off) - 1, _p(self.mix_off, C.c_int32), _p(self.mix_w, C.c_double))
+        self.S = len(self.mix_off) - 1
+        self.pspace: Dict[int, np.ndarray] = {}      # ssid -> [K][d][d]
+        self.espace: Dict[int, np.ndarray] = {}      # ssid -> [K][exp_dim] theta
+        self.gauss = []                              # per pool Gaussian: a tuple by kind
+        for e in entries:
+            kind = e[0]
+            if kind == "precision_subspace":
+                self.pspace[e[1]] = np.asarray(e[2], np.float64)
+            elif kind == "exponential_subspace":
+                self.espace[e[1]] = np.asarray(e[2], np.float64)
+            elif kind == "pcgmm":
+                _, ssid, mt, lam = e
+                Sb = self.pspace[ssid]
+                lam = np.asarray(lam, np.float64)
+                mt = np.asarray(mt, np.float64)
+                P = np.zeros((dim, dim))
+                for b in range(len(lam)):
+                    P += lam[b] * Sb[b]
+                const = np.log(np.sqrt(_spd_determinant(P))) - 0.5 * mt @ (np.linalg.inv(P) @ mt)
+                self.gauss.append(("pcgmm", ssid, mt, lam, const))
+            elif kind == "scgmm":
+                _, ssid, lam = e
+                th = self.espace[ssid]
+                lam = np.asarray(lam, np.float64)
+                psi = np.zeros(dim)
+                P = np.zeros((dim, dim))
+                for b in range(len(lam)):
+                    psi += lam[b] * th[b][:dim]
+                    P += lam[b] * map_v2m(th[b][dim:])
+                cov = np.linalg.inv(P)
+                const = np.log(np.prod(np.linalg.eigvalsh(0.5 * (P + P.T))))     # LinearAlgebra::determinant
+                const -= psi @ (cov @ psi)
+                const -= dim * np.log(2 * 3.1416)
+                self.gauss.append(("scgmm", ssid, lam, const))
+            elif kind == "diag":
+                _, mean, var = e
+                mean, var = np.asarray(mean, np.float64), np.asarray(var, np.float64)
+                prec = np.where(var > 0, 1.0 / np.where(var > 0, var, 1.0), 0.0)
+                c = float(np.prod(prec))
+                self.gauss.append(("diag", mean, prec, np.log(np.sqrt(c)) if c > 0 else c))
+            else:
+                raise ValueError("unknown entry " + kind)
+        self.G = len(self.gauss)
+
+    def gauss_loglik(self, frames):
+        frames = np.asarray(frames, np.float64)
+        out = np.empty((frames.shape[0], self.G))
+        d = self.dim
+        for fi, f in enumerate(frames):
+            qp = {k: np.array([-0.5 * (f @ (Sb @ f)) for Sb in v]) for k, v in self.pspace.items()}
+            phi = np.concatenate([f, map_m2v(-0.5 * np.outer(f, f))])
+            qe = {k: v @ phi for k, v in self.espace.items()}
+            for g, e in enumerate(self.gauss):
+                if e[0] == "pcgmm":
+                    ll = e[4] + e[2] @ f
+                    if not self.as_written:
+                        ll += e[3] @ qp[e[1]][:len(e[3])]
+                elif e[0] == "scgmm":
+                    ll = e[3] + e[2] @ qe[e[1]][:len(e[2])]
+                else:
+                    diff = f - e[1]
+                    ll = -0.5 * float((diff * diff * e[2]).sum()) + e[3]
+                out[fi, g] = ll
+        return out
+
+    def score(self, frames):
+        lik = np.exp(self.gauss_loglik(frames))
+        out = np.empty((lik.shape[0], self.S))
+        for s in range(self.S):
+            a, b = self.mix_off[s], self.mix_off[s + 1]
+            l = lik[:, self.mix_idx[a:b]] @ self.mix_w[a:b] if b > a else np.zeros(lik.shape[0])
+            out[:, s] = np.log(np.maximum(l, TINY_FOR_LOG))
+        return out
+
+
+def write_gk_subspace(path: str, dim: int, entries) -> None:
+    """'variable' .gk file with subspace definitions and pcgmm / scgmm / diag Gaussians in the
+    given order (aku/Distributions.cc:2831-2868; PrecisionSubspace::write_subspace,
+    aku/Subspaces.cc:169-182; ExponentialSubspace::write_subspace :1201-1215; Gaussian write
+    methods :1670-1680, 1876-1883)."""
+    n_gauss = sum(1 for e in entries if e[0] in ("pcgmm", "scgmm", "diag"))
+
+    def nums(v):
+        return " ".join(repr(float(x)) for x in np.asarray(v).ravel())
+
+    with open(path, "w") as f:
+        f.write("%d %d variable\n" % (n_gauss, dim))
+        for e in entries:
+            if e[0] == "precision_subspace":
+                b = np.asarray(e[2])
+                f.write("precision_subspace %d %d %d\n" % (e[1], dim, b.shape[0]))
+                for k in range(b.shape[0]):
+                    f.write(nums(b[k]) + "\n")
+            elif e[0] == "exponential_subspace":
+                b = np.asarray(e[2])
+                f.write("exponential_subspace %d %d %d\n" % (e[1], dim, b.shape[0]))
+                for k in range(b.shape[0]):
+                    f.write(nums(b[k]) + "\n")
+            elif e[0] == "pcgmm":
+                f.write("pcgmm %d %d %s %s\n" % (e[1], len(e[3]), nums(e[2]), nums(e[3])))
+            elif e[0] == "scgmm":
+                f.write("scgmm %d %d %s\n" % (e[1], len(e[2]), nums(e[2])))
+            else:
+                f.write("diag %s %s\n" % (nums(e[1]), nums(e[2])))
