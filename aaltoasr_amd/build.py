@@ -23,7 +23,8 @@ ARCH = "gfx950"
 
 # -ffp-contract=off: the feature kernels restate float32/float64 arithmetic of
 # the reference operation by operation; fused multiply-adds would change bits.
-COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall",
+ABLATION = ["-DAASR_ABLATION=1"] if os.environ.get("AASR_BUILD_ABLATION") == "1" else []
+COMMON = ABLATION + ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall",
           "-Wno-unused-function", "-Wno-inline-asm", f"--offload-arch={ARCH}", "-I", os.path.join(HERE, "..", "include")]
 
 

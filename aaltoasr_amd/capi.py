@@ -503,6 +503,15 @@ def recipe_batch_range(total: int, num_batches: int, batch_index: int):
     return f.value, n.value
 
 
+def debug_feat_fusion(on: bool) -> None:
+    """Diagnostic: False = every feature module runs its own kernel (the fused kernels must match it
+    bit for bit)."""
+    L = lib()
+    L.aasr_debug_feat_fusion.argtypes = [C.c_int]
+    L.aasr_debug_feat_fusion.restype = None
+    L.aasr_debug_feat_fusion(int(on))
+
+
 def debug_cluster_heap(on: bool) -> None:
     """Diagnostic: send every frame's cluster selection through the priority-queue replay."""
     L = lib()

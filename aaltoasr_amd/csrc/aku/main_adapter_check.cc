@@ -130,6 +130,7 @@ static int dist_mode(const char *cfg, const char *base, const char *audio, const
   fprintf(out, "%d %d\n", model.num_states(), model.get_pool()->size());
   for (int f : {3, 11}) {
     aku::FeatureVec fea = gen.generate(f);
+    model.reset_cache();  // the caller's duty whenever the frame changes (aku/HmmSet.cc:444-457)
     for (int s = 0; s < model.num_states(); s++) {
       aku::Mixture *mixture = model.get_emission_pdf(model.emission_pdf_index(s));
       double by_parts = 0;

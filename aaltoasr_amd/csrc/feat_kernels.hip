@@ -132,6 +132,122 @@ __device__ __forceinline__ cpx cmul(cpx a, cpx b) {
   return m;
 }
 
+// One butterfly of KissFFT's decimation-in-time stage (vendor/kiss_fft/kiss_fft.c:21-198, radices 2,
+// 3, 4, 5): butterfly index bi of the stage with radix pr and sub-length m, in place in buf.
+__device__ __forceinline__ void kiss_butterfly(cpx *buf, int bi, int pr, int m, int fstride,
+                                               const cpx *__restrict__ tw) {
+    int g = bi / m, j = bi - g * m;
+    cpx *F = buf + g * pr * m;
+    if (pr == 2) {
+      cpx t = cmul(F[m + j], tw[j * fstride]);
+      cpx f0 = F[j];
+      cpx o1;
+      o1.r = f0.r - t.r;
+      o1.i = f0.i - t.i;
+      f0.r += t.r;
+      f0.i += t.i;
+      F[m + j] = o1;
+      F[j] = f0;
+    } else if (pr == 3) {
+      // kf_bfly3 (vendor/kiss_fft/kiss_fft.c:92-135); HALF_OF(x) = x*.5 in double
+      const cpx epi3 = tw[fstride * m];
+      cpx s1 = cmul(F[m + j], tw[j * fstride]);
+      cpx s2 = cmul(F[2 * m + j], tw[2 * j * fstride]);
+      cpx f0 = F[j], s3, s0, o1, o2;
+      s3.r = s1.r + s2.r;  s3.i = s1.i + s2.i;
+      s0.r = s1.r - s2.r;  s0.i = s1.i - s2.i;
+      o1.r = (float)((double)f0.r - (double)s3.r * .5);
+      o1.i = (float)((double)f0.i - (double)s3.i * .5);
+      s0.r *= epi3.i;
+      s0.i *= epi3.i;
+      f0.r += s3.r;
+      f0.i += s3.i;
+      o2.r = o1.r + s0.i;
+      o2.i = o1.i - s0.r;
+      o1.r -= s0.i;
+      o1.i += s0.r;
+      F[j] = f0;
+      F[m + j] = o1;
+      F[2 * m + j] = o2;
+    } else if (pr == 5) {
+      // kf_bfly5 (vendor/kiss_fft/kiss_fft.c:137-198)
+      const cpx ya = tw[fstride * m], yb = tw[fstride * 2 * m];
+      cpx s0 = F[j];
+      cpx s1 = cmul(F[m + j], tw[j * fstride]);
+      cpx s2 = cmul(F[2 * m + j], tw[2 * j * fstride]);
+      cpx s3 = cmul(F[3 * m + j], tw[3 * j * fstride]);
+      cpx s4 = cmul(F[4 * m + j], tw[4 * j * fstride]);
+      cpx s5, s6, s7, s8, s9, s10, s11, s12, f0 = s0, o1, o2, o3, o4;
+      s7.r = s1.r + s4.r;   s7.i = s1.i + s4.i;
+      s10.r = s1.r - s4.r;  s10.i = s1.i - s4.i;
+      s8.r = s2.r + s3.r;   s8.i = s2.i + s3.i;
+      s9.r = s2.r - s3.r;   s9.i = s2.i - s3.i;
+      f0.r += s7.r + s8.r;
+      f0.i += s7.i + s8.i;
+      s5.r = s0.r + s7.r * ya.r + s8.r * yb.r;
+      s5.i = s0.i + s7.i * ya.r + s8.i * yb.r;
+      s6.r = s10.i * ya.i + s9.i * yb.i;
+      s6.i = -(s10.r * ya.i) - s9.r * yb.i;
+      o1.r = s5.r - s6.r;  o1.i = s5.i - s6.i;
+      o4.r = s5.r + s6.r;  o4.i = s5.i + s6.i;
+      s11.r = s0.r + s7.r * yb.r + s8.r * ya.r;
+      s11.i = s0.i + s7.i * yb.r + s8.i * ya.r;
+      s12.r = -(s10.i * yb.i) + s9.i * ya.i;
+      s12.i = s10.r * yb.i - s9.r * ya.i;
+      o2.r = s11.r + s12.r;  o2.i = s11.i + s12.i;
+      o3.r = s11.r - s12.r;  o3.i = s11.i - s12.i;
+      F[j] = f0;
+      F[m + j] = o1;
+      F[2 * m + j] = o2;
+      F[3 * m + j] = o3;
+      F[4 * m + j] = o4;
+    } else {
+      cpx s0 = cmul(F[m + j], tw[j * fstride]);
+      cpx s1 = cmul(F[2 * m + j], tw[2 * j * fstride]);
+      cpx s2 = cmul(F[3 * m + j], tw[3 * j * fstride]);
+      cpx f0 = F[j], s3, s4, s5, o1, o2, o3;
+      s5.r = f0.r - s1.r;  s5.i = f0.i - s1.i;
+      f0.r += s1.r;        f0.i += s1.i;
+      s3.r = s0.r + s2.r;  s3.i = s0.i + s2.i;
+      s4.r = s0.r - s2.r;  s4.i = s0.i - s2.i;
+      o2.r = f0.r - s3.r;  o2.i = f0.i - s3.i;
+      f0.r += s3.r;        f0.i += s3.i;
+      o1.r = s5.r + s4.i;  o1.i = s5.i - s4.r;
+      o3.r = s5.r - s4.i;  o3.i = s5.i + s4.r;
+      F[j] = f0;
+      F[m + j] = o1;
+      F[2 * m + j] = o2;
+      F[3 * m + j] = o3;
+    }
+}
+
+// |X|^2 of one bin in float, then sqrtf / logf as FFTModule::generate applies them
+// (aku/FeatureModules.cc:533-565); sqrt and log evaluated in double and rounded once
+__device__ __forceinline__ float spec_value(float re, float im, int magnitude, int take_log) {
+  float a = re * re;
+  float c = im * im;
+  float v = a + c;
+  if (magnitude) v = (float)sqrt((double)v);  // == correctly rounded sqrtf
+  if (take_log) v = (float)log((double)v);
+  return v;
+}
+
+// kiss_fftr's split of the packed half-length transform into bins k and nc-k (kiss_fftr.c:86-120)
+__device__ __forceinline__ void real_split(const cpx *buf, int nc, int k, const cpx *__restrict__ stw,
+                                           float &re_k, float &im_k, float &re_n, float &im_n) {
+  cpx fpk = buf[k], fpnk, f1k, f2k, t;
+  fpnk.r = buf[nc - k].r;
+  fpnk.i = -buf[nc - k].i;
+  f1k.r = fpk.r + fpnk.r;  f1k.i = fpk.i + fpnk.i;
+  f2k.r = fpk.r - fpnk.r;  f2k.i = fpk.i - fpnk.i;
+  t = cmul(f2k, stw[k - 1]);
+  float ar = f1k.r + t.r, ai = f1k.i + t.i, br = f1k.r - t.r, bi = t.i - f1k.i;
+  re_k = (float)((double)ar * .5);
+  im_k = (float)((double)ai * .5);
+  re_n = (float)((double)br * .5);
+  im_n = (float)((double)bi * .5);
+}
+
 // One wave per frame: Hamming -> packed half-length complex FFT in LDS with
 // KissFFT's butterfly order -> real split -> |X|^2 (/ sqrt / log).
 template <bool FROM_PCM>
@@ -183,123 +299,382 @@ __global__ __launch_bounds__(256) void k_fft(DevBatch b, const int16_t *__restri
     const int pr = fp.radix[s], m = fp.sublen[s];
     const int fstride = nc / (pr * m);
     const int nb = nc / pr;
-    for (int bi = lane; bi < nb; bi += 64) {
-      int g = bi / m, j = bi - g * m;
-      cpx *F = buf + g * pr * m;
-      if (pr == 2) {
-        cpx t = cmul(F[m + j], tw[j * fstride]);
-        cpx f0 = F[j];
-        cpx o1;
-        o1.r = f0.r - t.r;
-        o1.i = f0.i - t.i;
-        f0.r += t.r;
-        f0.i += t.i;
-        F[m + j] = o1;
-        F[j] = f0;
-      } else if (pr == 3) {
-        // kf_bfly3 (vendor/kiss_fft/kiss_fft.c:92-135); HALF_OF(x) = x*.5 in double
-        const cpx epi3 = tw[fstride * m];
-        cpx s1 = cmul(F[m + j], tw[j * fstride]);
-        cpx s2 = cmul(F[2 * m + j], tw[2 * j * fstride]);
-        cpx f0 = F[j], s3, s0, o1, o2;
-        s3.r = s1.r + s2.r;  s3.i = s1.i + s2.i;
-        s0.r = s1.r - s2.r;  s0.i = s1.i - s2.i;
-        o1.r = (float)((double)f0.r - (double)s3.r * .5);
-        o1.i = (float)((double)f0.i - (double)s3.i * .5);
-        s0.r *= epi3.i;
-        s0.i *= epi3.i;
-        f0.r += s3.r;
-        f0.i += s3.i;
-        o2.r = o1.r + s0.i;
-        o2.i = o1.i - s0.r;
-        o1.r -= s0.i;
-        o1.i += s0.r;
-        F[j] = f0;
-        F[m + j] = o1;
-        F[2 * m + j] = o2;
-      } else if (pr == 5) {
-        // kf_bfly5 (vendor/kiss_fft/kiss_fft.c:137-198)
-        const cpx ya = tw[fstride * m], yb = tw[fstride * 2 * m];
-        cpx s0 = F[j];
-        cpx s1 = cmul(F[m + j], tw[j * fstride]);
-        cpx s2 = cmul(F[2 * m + j], tw[2 * j * fstride]);
-        cpx s3 = cmul(F[3 * m + j], tw[3 * j * fstride]);
-        cpx s4 = cmul(F[4 * m + j], tw[4 * j * fstride]);
-        cpx s5, s6, s7, s8, s9, s10, s11, s12, f0 = s0, o1, o2, o3, o4;
-        s7.r = s1.r + s4.r;   s7.i = s1.i + s4.i;
-        s10.r = s1.r - s4.r;  s10.i = s1.i - s4.i;
-        s8.r = s2.r + s3.r;   s8.i = s2.i + s3.i;
-        s9.r = s2.r - s3.r;   s9.i = s2.i - s3.i;
-        f0.r += s7.r + s8.r;
-        f0.i += s7.i + s8.i;
-        s5.r = s0.r + s7.r * ya.r + s8.r * yb.r;
-        s5.i = s0.i + s7.i * ya.r + s8.i * yb.r;
-        s6.r = s10.i * ya.i + s9.i * yb.i;
-        s6.i = -(s10.r * ya.i) - s9.r * yb.i;
-        o1.r = s5.r - s6.r;  o1.i = s5.i - s6.i;
-        o4.r = s5.r + s6.r;  o4.i = s5.i + s6.i;
-        s11.r = s0.r + s7.r * yb.r + s8.r * ya.r;
-        s11.i = s0.i + s7.i * yb.r + s8.i * ya.r;
-        s12.r = -(s10.i * yb.i) + s9.i * ya.i;
-        s12.i = s10.r * yb.i - s9.r * ya.i;
-        o2.r = s11.r + s12.r;  o2.i = s11.i + s12.i;
-        o3.r = s11.r - s12.r;  o3.i = s11.i - s12.i;
-        F[j] = f0;
-        F[m + j] = o1;
-        F[2 * m + j] = o2;
-        F[3 * m + j] = o3;
-        F[4 * m + j] = o4;
-      } else {
-        cpx s0 = cmul(F[m + j], tw[j * fstride]);
-        cpx s1 = cmul(F[2 * m + j], tw[2 * j * fstride]);
-        cpx s2 = cmul(F[3 * m + j], tw[3 * j * fstride]);
-        cpx f0 = F[j], s3, s4, s5, o1, o2, o3;
-        s5.r = f0.r - s1.r;  s5.i = f0.i - s1.i;
-        f0.r += s1.r;        f0.i += s1.i;
-        s3.r = s0.r + s2.r;  s3.i = s0.i + s2.i;
-        s4.r = s0.r - s2.r;  s4.i = s0.i - s2.i;
-        o2.r = f0.r - s3.r;  o2.i = f0.i - s3.i;
-        f0.r += s3.r;        f0.i += s3.i;
-        o1.r = s5.r + s4.i;  o1.i = s5.i - s4.r;
-        o3.r = s5.r - s4.i;  o3.i = s5.i + s4.r;
-        F[j] = f0;
-        F[m + j] = o1;
-        F[2 * m + j] = o2;
-        F[3 * m + j] = o3;
-      }
-    }
+    for (int bi = lane; bi < nb; bi += 64) kiss_butterfly(buf, bi, pr, m, fstride, tw);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
 
   // real split (kiss_fftr.c:86-120) + power spectrum (FeatureModules.cc:533-565)
   double *out = dst + r * (int64_t)(nc + 1);
-  auto emit = [&](int k, float re, float im) {
-    float a = re * re;
-    float c = im * im;
-    float v = a + c;
-    if (fp.magnitude) v = (float)sqrt((double)v);  // == correctly rounded sqrtf
-    if (fp.take_log) v = (float)log((double)v);
-    out[k] = (double)v;
-  };
   const cpx *stw = (const cpx *)fp.stwiddle;
   if (lane == 0) {
     cpx t0 = buf[0];
-    emit(0, t0.r + t0.i, 0.0f);
-    emit(nc, t0.r - t0.i, 0.0f);
+    out[0] = (double)spec_value(t0.r + t0.i, 0.0f, fp.magnitude, fp.take_log);
+    out[nc] = (double)spec_value(t0.r - t0.i, 0.0f, fp.magnitude, fp.take_log);
   }
   for (int k = 1 + lane; k <= nc / 2; k += 64) {
-    cpx fpk = buf[k], fpnk, f1k, f2k, t;
-    fpnk.r = buf[nc - k].r;
-    fpnk.i = -buf[nc - k].i;
-    f1k.r = fpk.r + fpnk.r;  f1k.i = fpk.i + fpnk.i;
-    f2k.r = fpk.r - fpnk.r;  f2k.i = fpk.i - fpnk.i;
-    t = cmul(f2k, stw[k - 1]);
-    float ar = f1k.r + t.r, ai = f1k.i + t.i, br = f1k.r - t.r, bi = t.i - f1k.i;
-    float re_k = (float)((double)ar * .5), im_k = (float)((double)ai * .5);
-    float re_n = (float)((double)br * .5), im_n = (float)((double)bi * .5);
-    if (k != nc - k) emit(k, re_k, im_k);
-    emit(nc - k, re_n, im_n);  // for k == nc-k the later assignment wins
+    float re_k, im_k, re_n, im_n;
+    real_split(buf, nc, k, stw, re_k, im_k, re_n, im_n);
+    if (k != nc - k) out[k] = (double)spec_value(re_k, im_k, fp.magnitude, fp.take_log);
+    out[nc - k] = (double)spec_value(re_n, im_n, fp.magnitude, fp.take_log);  // for k == nc-k the later assignment wins
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// Fused spectral front end: audiofile -> fft -> {mel -> dct, power} -> merge in ONE kernel.
+// The unfused chain writes the (nc+1)-bin spectrum as doubles (0.5 GB per hour of audio) and reads
+// it back twice; here a workgroup takes SPEC_FRAMES frames through every stage in LDS and only the
+// merged cepstra + log power (13 doubles per frame) leave the chip.  All 256 threads stay busy:
+// the FFT stages spread frames x butterflies over the threads, and the serial float
+// accumulations of the reference (PowerModule's left-to-right sum of 129 bins, MelModule's per-bin
+// ramps) run as one task per (frame, bin) side by side instead of one frame per wave.
+// Every operation is the one the single-module kernels perform (same device functions, same
+// order), so the result is bit-identical to the unfused path (tests/test_feat_gpu.py).
+// ---------------------------------------------------------------------------
+// phase ablations of k_spectral_fused (AASR_SPEC_DBG bits: 1 no utterance search, 8 no sample
+// staging, 2 no FFT stages, 4 no mel, 16 no power sum) exist only in AASR_BUILD_ABLATION=1 builds
+#ifndef AASR_ABLATION
+#define AASR_ABLATION 0
+#endif
+#if AASR_ABLATION
+#define AASR_FDBG(bits) (dbg & (bits))
+#else
+#define AASR_FDBG(bits) false
+#endif
+constexpr int SPEC_FRAMES = 16;   // frames per pass of a workgroup
+constexpr int SPEC_TPF = 16;      // threads per frame (a wave = 4 frames)
+
+struct SpectralPrm {
+  FftPrm fp;
+  int mel_dim, mel_root, mel_terms;
+  const int32_t *mel_off, *mel_t;
+  const float *mel_scale, *mel_sum;
+  int dct_dim, zeroth;
+  const float *dct_cos;
+};
+
+// LDS plan shared by the host (size) and the kernel (offsets), in bytes
+struct SpectralLds {
+  size_t bufs, frame_u, melv, powv, ham, perm, tw, stw, moff, mt, msc, msum, dct, prm, total;
+  size_t frame_u_stride;  // per frame: int16 samples first, the float spectrum later
+  __host__ __device__ SpectralLds(int nc, int mel_dim, int mel_terms, int dct_rows) {
+    size_t o = 0;
+    auto take = [&](size_t n) {
+      size_t at = o;
+      o += (n + 15) & ~(size_t)15;
+      return at;
+    };
+    bufs = take((size_t)SPEC_FRAMES * nc * 8);
+    const size_t pcm_b = (size_t)(2 * nc + 2) * 2, spec_b = (size_t)((nc + 1) | 1) * 4;
+    frame_u_stride = ((pcm_b > spec_b ? pcm_b : spec_b) + 7) & ~(size_t)7;
+    frame_u_stride |= 4;  // not a multiple of 8 bytes: rows of different frames start on different banks
+    frame_u = take((size_t)SPEC_FRAMES * frame_u_stride);
+    melv = take((size_t)SPEC_FRAMES * mel_dim * 8);
+    powv = take((size_t)SPEC_FRAMES * 8);
+    ham = take((size_t)2 * nc * 4);
+    perm = take((size_t)nc * 4);
+    tw = take((size_t)nc * 8);
+    stw = take((size_t)(nc / 2 + 1) * 8);
+    moff = take((size_t)(mel_dim + 1) * 4);
+    mt = take((size_t)mel_terms * 4);
+    msc = take((size_t)mel_terms * 4);
+    msum = take((size_t)mel_dim * 4);
+    dct = take((size_t)dct_rows * mel_dim * 4);
+    prm = take((size_t)SPEC_FRAMES * 3 * 8);
+    total = o;
+  }
+};
+
+__global__ __launch_bounds__(256) void k_spectral_fused(DevBatch b, const int16_t *__restrict__ pcm,
+                                                        AudioPrm ap, int L, int R, int64_t rows,
+                                                        SpectralPrm sp, int passes, int dbg,
+                                                        double *__restrict__ dst) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int FB = SPEC_FRAMES, TPF = SPEC_TPF;
+  const int nc = sp.fp.nc, nbins = nc + 1;
+  const int dct_rows = sp.dct_dim - (sp.zeroth ? 1 : 0);
+  const SpectralLds lds(nc, sp.mel_dim, sp.mel_terms, dct_rows);
+  cpx *bufs = (cpx *)(smem_raw + lds.bufs);
+  double *melv = (double *)(smem_raw + lds.melv);
+  double *powv = (double *)(smem_raw + lds.powv);
+  float *t_ham = (float *)(smem_raw + lds.ham);
+  int32_t *t_perm = (int32_t *)(smem_raw + lds.perm);
+  cpx *t_tw = (cpx *)(smem_raw + lds.tw);
+  cpx *t_stw = (cpx *)(smem_raw + lds.stw);
+  int32_t *t_moff = (int32_t *)(smem_raw + lds.moff);
+  int32_t *t_mt = (int32_t *)(smem_raw + lds.mt);
+  float *t_msc = (float *)(smem_raw + lds.msc);
+  float *t_msum = (float *)(smem_raw + lds.msum);
+  float *t_dct = (float *)(smem_raw + lds.dct);
+  int64_t *s_prm = (int64_t *)(smem_raw + lds.prm);  // [FB][3]: window start, utterance offset, samples
+  const int tid = threadIdx.x;
+  const int f = tid / TPF, l = tid - f * TPF;
+
+  // tables: once per workgroup (every later access is an LDS read; the loads of the FFT, mel and
+  // DCT stages used to wait on global memory one after another)
+  for (int i = tid; i < 2 * nc; i += 256) t_ham[i] = sp.fp.hamming[i];
+  for (int i = tid; i < nc; i += 256) {
+    t_perm[i] = sp.fp.perm[i];
+    t_tw[i] = ((const cpx *)sp.fp.twiddle)[i];
+  }
+  for (int i = tid; i < nc / 2; i += 256) t_stw[i] = ((const cpx *)sp.fp.stwiddle)[i];
+  for (int i = tid; i <= sp.mel_dim; i += 256) t_moff[i] = sp.mel_off[i];
+  for (int i = tid; i < sp.mel_terms; i += 256) {
+    t_mt[i] = sp.mel_t[i];
+    t_msc[i] = sp.mel_scale[i];
+  }
+  for (int i = tid; i < sp.mel_dim; i += 256) t_msum[i] = sp.mel_sum[i];
+  for (int i = tid; i < dct_rows * sp.mel_dim; i += 256) t_dct[i] = sp.dct_cos[i];
+
+  cpx *buf = bufs + (size_t)f * nc;
+  char *fu = smem_raw + lds.frame_u + (size_t)f * lds.frame_u_stride;
+  int16_t *spcm = (int16_t *)fu;  // this frame's samples ws .. ws + 2 nc
+  float *spec = (float *)fu;      // later: its nc + 1 spectrum values
+  const int out_dim = sp.dct_dim + 1;
+  const int64_t nblk = (rows + FB - 1) / FB;
+  int u_cur = -1;  // tid < FB: utterance of this thread's row in the previous pass (rows only move forward)
+  for (int pass = 0; pass < passes; pass++) {
+    const int64_t blk = (int64_t)blockIdx.x * passes + pass;
+    if (blk >= nblk) break;  // workgroup-uniform
+    const int64_t r0 = blk * FB;
+    __syncthreads();  // tables staged / previous pass done with s_prm
+    if (tid < FB) {
+      int64_t r = r0 + tid;
+      if (r > rows - 1) r = rows - 1;  // spare frames of the last block repeat the last row (never stored)
+      int u;
+      if (AASR_FDBG(1)) {
+        u = 0;
+      } else if (u_cur < 0) {
+        u = find_utt(b, r, L + R);  // nine dependent loads: only in the first pass
+      } else {
+        u = u_cur;
+        while (u + 1 < b.n_utts && b.frame_off[u + 1] + (int64_t)(u + 1) * (L + R) <= r) u++;
+      }
+      u_cur = u;
+      const int frame = b.first[u] - L + (int)(r - (b.frame_off[u] + (int64_t)u * (L + R)));
+      s_prm[3 * tid] = window_start(b, u, frame, ap);
+      s_prm[3 * tid + 1] = b.pcm_off[u];
+      s_prm[3 * tid + 2] = b.pcm_off[u + 1] - b.pcm_off[u];
+    }
+    __syncthreads();
+    // From here on a frame belongs to 16 threads of one wave: wave-level ordering is enough.
+    {
+      const int64_t ws = s_prm[3 * f], ns = s_prm[3 * f + 2];
+      const int16_t *p = pcm + s_prm[3 * f + 1];
+#pragma unroll 6
+      for (int t = l; t <= (AASR_FDBG(8) ? 0 : 2 * nc); t += TPF) {
+        const int64_t i = ws + t;
+        spcm[t] = (i >= 0 && i < ns) ? p[i] : (int16_t)0;  // zero outside the file (AudioReader)
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // pre-emphasis in float (AudioFileModule::generate), Hamming, packed (even, odd) -> complex in
+    // KissFFT's digit-reversed order
+    for (int o = l; o < nc; o += TPF) {
+      const int s = t_perm[o];
+      const float c0 = (float)spcm[2 * s], c1 = (float)spcm[2 * s + 1], c2 = (float)spcm[2 * s + 2];
+      const float p0 = ap.emph * c0, p1 = ap.emph * c1;
+      const double x0 = (double)(c1 - p0);
+      const double x1 = (double)(c2 - p1);
+      cpx v;
+      v.r = (float)((double)t_ham[2 * s] * x0);
+      v.i = (float)((double)t_ham[2 * s + 1] * x1);
+      buf[o] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int st = AASR_FDBG(2) ? -1 : sp.fp.ns - 1; st >= 0; st--) {
+      const int pr = sp.fp.radix[st], m = sp.fp.sublen[st];
+      const int fstride = nc / (pr * m);
+      const int nb = nc / pr;
+      for (int bi = l; bi < nb; bi += TPF) kiss_butterfly(buf, bi, pr, m, fstride, t_tw);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // real split + power spectrum into spec[0..nc] (overwrites the staged samples)
+    for (int k = l; k <= nc / 2; k += TPF) {
+      if (k == 0) {
+        const cpx t0 = buf[0];
+        spec[0] = spec_value(t0.r + t0.i, 0.0f, sp.fp.magnitude, sp.fp.take_log);
+        spec[nc] = spec_value(t0.r - t0.i, 0.0f, sp.fp.magnitude, sp.fp.take_log);
+      } else {
+        float re_k, im_k, re_n, im_n;
+        real_split(buf, nc, k, t_stw, re_k, im_k, re_n, im_n);
+        if (k != nc - k) spec[k] = spec_value(re_k, im_k, sp.fp.magnitude, sp.fp.take_log);
+        spec[nc - k] = spec_value(re_n, im_n, sp.fp.magnitude, sp.fp.take_log);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // MelModule::generate (aku/FeatureModules.cc:805-849): one bin per thread and round; the last
+    // thread of the frame also carries PowerModule's left-to-right float sum (:874-885)
+    for (int bin = l; bin < (AASR_FDBG(4) ? 0 : sp.mel_dim); bin += TPF) {
+      float val = 0;
+      const int e_end = t_moff[bin + 1];
+      int e = t_moff[bin];
+      // the table and spectrum reads of four terms are issued together; the float accumulation
+      // itself stays term by term, in the reference's order
+      for (; e + 4 <= e_end; e += 4) {
+        const double p0 = (double)t_msc[e] * (double)spec[t_mt[e]];
+        const double p1 = (double)t_msc[e + 1] * (double)spec[t_mt[e + 1]];
+        const double p2 = (double)t_msc[e + 2] * (double)spec[t_mt[e + 2]];
+        const double p3 = (double)t_msc[e + 3] * (double)spec[t_mt[e + 3]];
+        val = (float)((double)val + p0);
+        val = (float)((double)val + p1);
+        val = (float)((double)val + p2);
+        val = (float)((double)val + p3);
+      }
+      for (; e < e_end; e++) val = (float)((double)val + (double)t_msc[e] * (double)spec[t_mt[e]]);
+      const float q = (float)((double)val / (double)t_msum[bin]);
+      double o;
+      if (sp.mel_root) {
+        o = pow((double)q, 0.1);
+      } else {
+        const float a = q + 1.0f;
+        o = (double)(float)log((double)a);
+      }
+      melv[(size_t)f * sp.mel_dim + bin] = o;
+    }
+    if (l == TPF - 1 && !AASR_FDBG(16)) {
+      float power = 0;
+      int i = 0;
+      for (; i + 8 <= nbins; i += 8) {  // eight reads in flight, the additions in order
+        const float v0 = spec[i], v1 = spec[i + 1], v2 = spec[i + 2], v3 = spec[i + 3];
+        const float v4 = spec[i + 4], v5 = spec[i + 5], v6 = spec[i + 6], v7 = spec[i + 7];
+        power = power + v0;
+        power = power + v1;
+        power = power + v2;
+        power = power + v3;
+        power = power + v4;
+        power = power + v5;
+        power = power + v6;
+        power = power + v7;
+      }
+      for (; i < nbins; i++) power = power + spec[i];
+      powv[f] = log((double)power + 1e-10);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // DCTModule::generate (:955-979) into the merged row [cepstra..., log power]
+    if (r0 + f < rows) {
+      const double *data = melv + (size_t)f * sp.mel_dim;
+      for (int i = l; i < out_dim; i += TPF) {
+        double acc;
+        if (i == sp.dct_dim) {
+          acc = powv[f];
+        } else {
+          acc = 0.0;
+          if (sp.zeroth && i == 0) {
+            for (int k = 0; k < sp.mel_dim; k++) acc += data[k];
+          } else {
+            const float *c = t_dct + (size_t)(i - (sp.zeroth ? 1 : 0)) * sp.mel_dim;
+#pragma unroll 4
+            for (int k = 0; k < sp.mel_dim; k++) acc += data[k] * (double)c[k];
+          }
+        }
+        dst[(r0 + f) * out_dim + i] = acc;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Fused temporal stage: delta -> delta-delta -> merge -> normalization -> lin_transform in one
+// kernel.  A workgroup stages the source rows of ROWS frames plus the (w1 + w2)-frame look-around
+// in LDS, forms both difference streams there, normalises the merged 3*dx values and multiplies
+// by the transform; only the transformed rows (the mean subtractor's input, with its own
+// look-around) are written.  Expressions and summation orders are those of k_delta,
+// k_normalization and k_lin_transform_tiled: bit-identical to the unfused chain.
+// ---------------------------------------------------------------------------
+struct TemporalPrm {
+  int dx, w1, w2;
+  float norm1, norm2;
+  const float *mean, *scale;
+  const float *matrix, *bias;  // null: identity / no bias
+  int dim;
+};
+
+template <int ROWS>
+__global__ __launch_bounds__(256) void k_temporal_fused(DevBatch b, const double *__restrict__ src,
+                                                        SrcMap sm, int span, int64_t rows,
+                                                        TemporalPrm tp, double *__restrict__ dst) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int dx = tp.dx, H = tp.w1 + tp.w2, md = 3 * tp.dx;
+  double *xs = (double *)smem_raw;                              // [ROWS + 2H][dx]
+  double *d1 = xs + (size_t)(ROWS + 2 * H) * dx;                // [ROWS + 2 w2][dx]
+  double *nrm = d1 + (size_t)(ROWS + 2 * tp.w2) * dx;           // [ROWS][md]
+  float *ms = (float *)(nrm + (size_t)ROWS * md);               // [dim][md | 1]
+  const int mstride = md | 1;
+  if (tp.matrix)
+    for (int e = threadIdx.x; e < tp.dim * md; e += 256) ms[(e / md) * mstride + (e % md)] = tp.matrix[e];
+  const int64_t tile0 = (int64_t)blockIdx.x * ROWS;
+  const int64_t tile1 = tile0 + ROWS < rows ? tile0 + ROWS : rows;
+  int64_t r0 = tile0;
+  while (r0 < tile1) {  // one utterance segment at a time (see k_mean_subtract_tiled)
+    const int u = find_utt(b, r0, span);
+    const int64_t u_end = b.frame_off[u + 1] + (int64_t)(u + 1) * span;
+    const int64_t r_end = u_end < tile1 ? u_end : tile1;
+    const int64_t s0 = r0 + (int64_t)u * sm.span_diff + sm.shift;  // source row of r0
+    const int n_seg = (int)(r_end - r0);
+    const int n_x = n_seg + 2 * H, n_d1 = n_seg + 2 * tp.w2;
+    for (int e = threadIdx.x; e < n_x * dx; e += 256) xs[e] = src[(s0 - H) * dx + e];
+    __syncthreads();
+    // DeltaModule::generate (aku/FeatureModules.cc:1018-1037) on the source rows
+    for (int e = threadIdx.x; e < n_d1 * dx; e += 256) {
+      const int j = e / dx, i = e - j * dx;
+      const int c = j + tp.w1;
+      double acc = 0;
+      for (int k = 1; k <= tp.w1; k++) {
+        const double left = xs[(size_t)(c - k) * dx + i];
+        const double right = xs[(size_t)(c + k) * dx + i];
+        acc += k * (right - left);
+      }
+      d1[e] = acc / (double)tp.norm1;
+    }
+    __syncthreads();
+    // second difference, merge (source, delta, delta-delta) and NormalizationModule::generate (:1135-1142)
+    for (int e = threadIdx.x; e < n_seg * md; e += 256) {
+      const int lr = e / md, col = e - lr * md;
+      const int part = col / dx, i = col - part * dx;
+      double v;
+      if (part == 0) {
+        v = xs[(size_t)(lr + H) * dx + i];
+      } else if (part == 1) {
+        v = d1[(size_t)(lr + tp.w2) * dx + i];
+      } else {
+        const int c = lr + tp.w2;
+        double acc = 0;
+        for (int k = 1; k <= tp.w2; k++) {
+          const double left = d1[(size_t)(c - k) * dx + i];
+          const double right = d1[(size_t)(c + k) * dx + i];
+          acc += k * (right - left);
+        }
+        v = acc / (double)tp.norm2;
+      }
+      nrm[e] = (v - (double)tp.mean[col]) * (double)tp.scale[col];
+    }
+    __syncthreads();
+    // LinTransformModule::generate (:1243-1269)
+    for (int e = threadIdx.x; e < n_seg * tp.dim; e += 256) {
+      const int lr = e / tp.dim, i = e - lr * tp.dim;
+      const double *x = nrm + (size_t)lr * md;
+      double acc;
+      if (tp.matrix) {
+        const float *mr = ms + (size_t)i * mstride;
+        acc = 0;
+        for (int j = 0; j < md; j++) acc += (double)mr[j] * x[j];
+      } else {
+        acc = x[i];
+      }
+      if (tp.bias) acc += (double)tp.bias[i];
+      dst[(r0 + lr) * tp.dim + i] = acc;
+    }
+    __syncthreads();
+    r0 = r_end;
   }
 }
 
@@ -465,10 +840,12 @@ __global__ __launch_bounds__(256) void k_lin_transform_tiled(
 
 // MeanSubtractorModule, tiled: the block's rows plus the window look-around are
 // staged in LDS once; each thread sums its window in frame order.
-template <int ROWS>
+// OUT = float: the module is the graph's output and writes the caller's float rows itself (no
+// separate narrowing pass).
+template <int ROWS, class OUT>
 __global__ __launch_bounds__(256) void k_mean_subtract_tiled(
     DevBatch b, const double *__restrict__ src, SrcMap sm, int span, int halo_left, int64_t rows, int dim,
-    int left, int right, double *__restrict__ dst) {
+    int left, int right, OUT *__restrict__ dst) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double *xs = (double *)smem_raw;  // [ROWS + left + right][dim]
   // sums of 8 consecutive frames: a window of left+right+1 rows is then a few singles at its ends
@@ -523,7 +900,7 @@ __global__ __launch_bounds__(256) void k_mean_subtract_tiled(
         for (int i = i0 + 8 * kb; i < b_end; i++) mean += xs[(size_t)i * dim + d];
       }
       mean /= (left + right + 1);
-      dst[(r0 + lr) * dim + d] = xs[(size_t)(lr + left) * dim + d] - mean;
+      dst[(r0 + lr) * dim + d] = (OUT)(xs[(size_t)(lr + left) * dim + d] - mean);
     }
     __syncthreads();
     r0 = r_end;
@@ -653,6 +1030,10 @@ __global__ void k_emit(const double *__restrict__ src, int64_t n, T *__restrict_
 
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
+// AASR_FEAT_FUSE=0 (or aasr_debug_feat_fusion(0)) evaluates every module with its own kernel;
+// the fused kernels must reproduce that path bit for bit.
+static int g_feat_fusion = getenv("AASR_FEAT_FUSE") ? atoi(getenv("AASR_FEAT_FUSE")) : 1;
+
 void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int target,
                     float *out_f32, double *out_f64, hipStream_t stream) {
   const int nm = (int)h->mods.size();
@@ -730,16 +1111,128 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
   DevBatch db{n, h->d_frame_off.p, h->d_pcm_off.p, h->d_first.p, h->d_eof.p};
   AudioPrm ap{base.width, base.advance, base.emph, base.copy_borders};
 
+  // ---- fusion plan -------------------------------------------------------------------------
+  // spectral group: audiofile -> F fft -> {M mel -> D dct, P power} -> G merge [D, P], nothing else
+  // reading F, M, D, P and none of them the requested output
+  std::vector<char> skip(nm, 0);
+  int sgF = -1, sgM = -1, sgP = -1, sgD = -1, sgG = -1;
+  int tgX = -1, tgA = -1, tgB = -1, tgN = -1, tgT = -1;
+  if (g_feat_fusion && base.type == MOD_AUDIOFILE && target != 0 && consumers[0] == 1) {
+    for (int gi = 1; gi <= target && sgG < 0; gi++) {
+      const FeatModule &G = h->mods[gi];
+      if (L[gi] < 0 || G.type != MOD_MERGE || G.sources.size() != 2) continue;
+      const int D = G.sources[0], P = G.sources[1];
+      if (h->mods[D].type != MOD_DCT || h->mods[P].type != MOD_POWER) continue;
+      if (consumers[D] != 1 || consumers[P] != 1 || D == target || P == target) continue;
+      const int M = h->mods[D].sources[0], F = h->mods[P].sources[0];
+      if (h->mods[M].type != MOD_MEL || h->mods[F].type != MOD_FFT || h->mods[M].sources[0] != F) continue;
+      if (consumers[M] != 1 || consumers[F] != 2 || M == target || F == target) continue;
+      if (h->mods[F].sources[0] != 0 || G.dim != h->mods[D].dim + 1) continue;
+      const SpectralLds lds(h->mods[F].fft.nc, h->mods[M].dim, (int)h->mods[M].mel_t.n,
+                            h->mods[D].dim - (h->mods[D].zeroth ? 1 : 0));
+      if (lds.total > 64 * 1024) continue;
+      sgF = F; sgM = M; sgP = P; sgD = D; sgG = gi;
+      skip[F] = skip[M] = skip[P] = skip[D] = 1;
+    }
+  }
+  // temporal group: X -> A delta -> B delta, C merge [X, A, B] -> N normalization -> T lin_transform
+  if (g_feat_fusion) {
+    for (int ti = 1; ti <= target && tgT < 0; ti++) {
+      const FeatModule &T = h->mods[ti];
+      if (L[ti] < 0 || T.type != MOD_LIN_TRANSFORM) continue;
+      const int N = T.sources[0];
+      if (h->mods[N].type != MOD_NORMALIZATION || consumers[N] != 1 || N == target) continue;
+      const int C = h->mods[N].sources[0];
+      const FeatModule &Cm = h->mods[C];
+      if (Cm.type != MOD_MERGE || Cm.sources.size() != 3 || consumers[C] != 1 || C == target) continue;
+      const int X = Cm.sources[0], A = Cm.sources[1], B = Cm.sources[2];
+      if (h->mods[A].type != MOD_DELTA || h->mods[B].type != MOD_DELTA) continue;
+      if (h->mods[A].sources[0] != X || h->mods[B].sources[0] != A) continue;
+      if (consumers[A] != 2 || consumers[B] != 1 || consumers[X] != 2 || A == target || B == target) continue;
+      const int dx = h->mods[X].dim;
+      if (h->mods[A].dim != dx || h->mods[B].dim != dx || Cm.dim != 3 * dx || T.src_dim != 3 * dx) continue;
+      if ((int)h->mods[N].mean.size() != 3 * dx || (int)h->mods[N].scale.size() != 3 * dx) continue;
+      const int H = h->mods[A].delta_width + h->mods[B].delta_width;
+      constexpr int TR = 32;
+      const size_t smem = (size_t)(TR + 2 * H) * dx * 8 + (size_t)(TR + 2 * h->mods[B].delta_width) * dx * 8 +
+                          (size_t)TR * 3 * dx * 8 + (size_t)T.dim * ((3 * dx) | 1) * 4;
+      if (smem > 64 * 1024) continue;
+      tgX = X; tgA = A; tgB = B; tgN = N; tgT = ti;
+      skip[A] = skip[B] = skip[C] = skip[N] = 1;
+    }
+  }
+
   auto rows_of = [&](int i) { return total + (int64_t)n * (L[i] + R[i]); };
   auto map_of = [&](int i, int s) {
     return SrcMap{(L[s] + R[s]) - (L[i] + R[i]), L[s] - L[i]};
   };
 
+  bool emitted = false;  // the output module wrote the caller's rows itself
   for (int i = 0; i <= target; i++) {
-    if (L[i] < 0) continue;
+    if (L[i] < 0 || skip[i]) continue;
     FeatModule &m = h->mods[i];
     const int64_t rows = rows_of(i);
     const int span = L[i] + R[i];
+    if (i == sgG) {
+      const FeatModule &F = h->mods[sgF], &M = h->mods[sgM], &D = h->mods[sgD];
+      SpectralPrm sp;
+      sp.fp.nc = F.fft.nc;
+      sp.fp.ns = F.fft.ns;
+      for (int k = 0; k < 16; k++) {
+        sp.fp.radix[k] = F.fft.radix[k];
+        sp.fp.sublen[k] = F.fft.sublen[k];
+      }
+      sp.fp.hamming = F.fft.hamming.p;
+      sp.fp.twiddle = F.fft.twiddle.p;
+      sp.fp.stwiddle = F.fft.stwiddle.p;
+      sp.fp.perm = F.fft.perm.p;
+      sp.fp.magnitude = F.magnitude;
+      sp.fp.take_log = F.take_log;
+      sp.mel_dim = M.dim;
+      sp.mel_root = M.root;
+      sp.mel_off = M.mel_off.p;
+      sp.mel_t = M.mel_t.p;
+      sp.mel_scale = M.mel_scale.p;
+      sp.mel_sum = M.mel_sum.p;
+      sp.dct_dim = D.dim;
+      sp.zeroth = D.zeroth;
+      sp.dct_cos = D.dct_cos.p;
+      sp.mel_terms = (int)M.mel_t.n;
+      const SpectralLds lds(F.fft.nc, M.dim, sp.mel_terms, D.dim - (D.zeroth ? 1 : 0));
+      const int64_t nblk = (rows + SPEC_FRAMES - 1) / SPEC_FRAMES;
+      // a workgroup stages the tables once and walks `passes` blocks of 16 frames; enough
+      // workgroups remain to fill the chip several times over
+      const int passes = (int)std::max<int64_t>(1, std::min<int64_t>(8, nblk / 4096));
+      h->bufs[i].ensure((size_t)rows * m.dim);
+      hipLaunchKernelGGL(k_spectral_fused, dim3((unsigned)((nblk + passes - 1) / passes)), dim3(256), lds.total,
+                         stream, db, d_pcm, ap, L[i], R[i], rows, sp, passes,
+                         getenv("AASR_SPEC_DBG") ? atoi(getenv("AASR_SPEC_DBG")) : 0, h->bufs[i].p);
+      AASR_HIP(hipGetLastError());
+      continue;
+    }
+    if (i == tgT) {
+      const FeatModule &A = h->mods[tgA], &B = h->mods[tgB], &N = h->mods[tgN];
+      TemporalPrm tp;
+      tp.dx = h->mods[tgX].dim;
+      tp.w1 = A.delta_width;
+      tp.w2 = B.delta_width;
+      tp.norm1 = A.delta_norm;
+      tp.norm2 = B.delta_norm;
+      tp.mean = N.d_mean.p;
+      tp.scale = N.d_scale.p;
+      tp.matrix = m.matrix_defined ? m.d_matrix.p : nullptr;
+      tp.bias = m.bias_defined ? m.d_bias.p : nullptr;
+      tp.dim = m.dim;
+      constexpr int TR = 32;
+      const int H = tp.w1 + tp.w2;
+      const size_t smem = (size_t)(TR + 2 * H) * tp.dx * 8 + (size_t)(TR + 2 * tp.w2) * tp.dx * 8 +
+                          (size_t)TR * 3 * tp.dx * 8 + (size_t)m.dim * ((3 * tp.dx) | 1) * 4;
+      h->bufs[i].ensure((size_t)rows * m.dim);
+      hipLaunchKernelGGL(k_temporal_fused<TR>, dim3((unsigned)((rows + TR - 1) / TR)), dim3(256), smem, stream, db,
+                         (const double *)h->bufs[tgX].p, map_of(i, tgX), span, rows, tp, h->bufs[i].p);
+      AASR_HIP(hipGetLastError());
+      continue;
+    }
     // audio frames are produced inside the FFT kernel when nothing else reads them
     if (m.type == MOD_AUDIOFILE && i != target && consumers[0] == 1) {
       bool only_fft = false;
@@ -877,8 +1370,14 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
         constexpr int MS_ROWS = 64;
         const size_t ms_src = (size_t)(MS_ROWS + m.cms_left + m.cms_right);
         const size_t ms_smem = (ms_src + ms_src / 8 + 1) * m.dim * 8;
-        if (ms_smem <= 60 * 1024)
-          hipLaunchKernelGGL(k_mean_subtract_tiled<MS_ROWS>, dim3((unsigned)((rows + MS_ROWS - 1) / MS_ROWS)),
+        if (ms_smem <= 60 * 1024 && i == target && g_feat_fusion && out_f32 && !out_f64) {
+          // the output module: its rows are the caller's rows (no look-around of its own)
+          hipLaunchKernelGGL((k_mean_subtract_tiled<MS_ROWS, float>), dim3((unsigned)((rows + MS_ROWS - 1) / MS_ROWS)),
+                             dim3(256), ms_smem, stream, db, src, sm, span, L[i], rows, m.dim, m.cms_left,
+                             m.cms_right, out_f32);
+          emitted = true;
+        } else if (ms_smem <= 60 * 1024)
+          hipLaunchKernelGGL((k_mean_subtract_tiled<MS_ROWS, double>), dim3((unsigned)((rows + MS_ROWS - 1) / MS_ROWS)),
                              dim3(256), ms_smem, stream, db, src, sm, span, L[i], rows, m.dim, m.cms_left,
                              m.cms_right, dst);
         else
@@ -890,6 +1389,7 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
     AASR_HIP(hipGetLastError());
   }
   const int64_t nout = total * h->mods[target].dim;
+  if (emitted) return;
   if (out_f32)
     hipLaunchKernelGGL(k_emit<float>, dim3(grid_for(nout)), dim3(256), 0, stream,
                        (const double *)h->bufs[target].p, nout, out_f32);
@@ -900,3 +1400,7 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
 }
 
 }  // namespace aasr
+
+// Diagnostic: 0 = every feature module runs its own kernel, 1 = fused kernels where the graph
+// has the production shape (default).  The two paths give identical bits.
+extern "C" void aasr_debug_feat_fusion(int on) { aasr::g_feat_fusion = on; }

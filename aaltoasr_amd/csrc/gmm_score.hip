@@ -49,6 +49,18 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define NEG_BIG_F (-3.0e38f)
 // finished state log-likelihoods are buffered per wave and written OUT_GROUP
 // consecutive states at a time: 32 contiguous bytes per frame row
+// Kernel ablations (AASR_DBG=bits: 1 matrix stream only, 2 no A-fragment reads, 16 no barriers,
+// 256 / 512 no / half of the tile copies, 4 / 8 scheduling experiments) exist only in a build made
+// with AASR_BUILD_ABLATION=1 (-DAASR_ABLATION=1); the product kernels carry none of the branches.
+#ifndef AASR_ABLATION
+#define AASR_ABLATION 0
+#endif
+#if AASR_ABLATION
+#define AASR_DBG(bits) (dbg & (bits))
+#else
+#define AASR_DBG(bits) false
+#endif
+
 constexpr int OUT_GROUP = 8;
 
 template <int NKK>
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    if (dbg & 1) {  // ablation: MFMA only (keep the accumulators live)
+    if (AASR_DBG(1)) {  // ablation: MFMA only (keep the accumulators live)
       asm volatile("" ::"v"(c00), "v"(c01), "v"(c10), "v"(c11));
       continue;
     }
@@ -468,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
     __builtin_amdgcn_s_barrier();
     if (t + 1 < t_end) pair_next = sload_close_pair(close_mask, t + 1);
 
-    if (dbg & 1) {  // ablation: MFMA only
+    if (AASR_DBG(1)) {  // ablation: MFMA only
       asm volatile("" ::"v"(c00), "v"(c01), "v"(c10), "v"(c11));
       continue;
     }
@@ -526,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
             ost[(32 + n) * kOS + slot] = l1;
             const int64_t closed = 2 * (int64_t)pairs_closed < S ? 2 * (int64_t)pairs_closed : S;
             if ((((2 * pairs_closed) & (OG - 1)) == 0 || 2 * (int64_t)pairs_closed >= S) &&
-                !(dbg & 16)) {
+                !AASR_DBG(16)) {
               const int64_t s_base = ((closed - 1) / OG) * OG;
               const int cnt = (int)(closed - s_base);
               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -754,12 +766,12 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   const cl_mask8_ptr mrow = (cl_mask8_ptr)(
       CL ? cl.maskrow + (size_t)__builtin_amdgcn_readfirstlane((int)(f0 >> 6)) * cl.rows_padded : nullptr);
 
-  if (dbg & 4) {  // experiment: de-phase co-resident workgroups
+  if (AASR_DBG(4)) {  // experiment: de-phase co-resident workgroups
     unsigned hsh = ((unsigned)blockIdx.x + 977u * blockIdx.y) * 2654435761u;
     int bucket = (hsh >> 28) & 15;
     for (int i = 0; i < bucket; i++) __builtin_amdgcn_s_sleep(8);
   }
-  if (dbg & 8) {  // experiment: raise priority of every second workgroup
+  if (AASR_DBG(8)) {  // experiment: raise priority of every second workgroup
     if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(2);
   }
   // Close bits of a tile: a VECTOR load issued in the middle of the previous tile's matrix stream
@@ -784,9 +796,9 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     const int bnn = bn + 1 < NBUF ? bn + 1 : 0;        // WIDE: buffer of tile t+2 (held tile t-1)
     float *anext = abuf0 + bn * kTileFloats;
     if (!WIDE) {
-      if (t + 1 < t_end && !(dbg & 256) && !((dbg & 512) && (t & 1)))  // ablations: 256 no tile traffic, 512 half of it
+      if (t + 1 < t_end && !AASR_DBG(256) && !(AASR_DBG(512) && (t & 1)))  // ablations: 256 no tile traffic, 512 half of it
         issue_tile_copy_raw(apf + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane, NW);
-    } else if (group == 1 && t + 2 < t_end) {
+    } else if (group == 1 && t + 2 < t_end && !AASR_DBG(256)) {
       // both groups are past tile t-1 once the lagging group has passed its end-of-tile barrier
       issue_tile_copy_raw(apf + (size_t)(t + 2) * kTileFloats, abuf0 + bnn * kTileFloats, kTileFloats, wave, lane, NW);
     }
@@ -812,8 +824,8 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     for (int j = 0; j < NK16; j++) {
       if (WIDE && j == JMID) {
         // mid-stream barrier = the other group's end-of-tile barrier
-        __builtin_amdgcn_s_barrier();
-        if (group == 0 && t + 2 < t_end)
+        if (!AASR_DBG(16)) __builtin_amdgcn_s_barrier();
+        if (group == 0 && t + 2 < t_end && !AASR_DBG(256))
           issue_tile_copy_raw(apf + (size_t)(t + 2) * kTileFloats, abuf0 + bnn * kTileFloats, kTileFloats, wave, lane, NW);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -837,7 +849,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
         // the aligned word holding tile t+1's bits (the array has a spare element); a 16-bit load
         // would need a zero-extension, which the compiler places -- with its vmcnt wait -- right here
         if (j == (NK16 > 1 ? 1 : 0) && grp == 0) mask_v = ((const uint32_t *)close_mask)[(t + 1) >> 1];
-        if (j + 1 < NK16) {
+        if (j + 1 < NK16 && !AASR_DBG(2)) {
           afr[sp][0] = afrag[(((j + 1) * 3 + sp) * 2 + 0) * 64];
           afr[sp][1] = afrag[(((j + 1) * 3 + sp) * 2 + 1) * 64];
           __builtin_amdgcn_sched_barrier(0);
@@ -851,7 +863,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
         issue_tile_copy_raw(apf + (size_t)(t + 2) * kTileFloats, abuf0 + bnn * kTileFloats, kTileFloats, wave, lane, NW);
     }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(mask_v) : : "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!AASR_DBG(16)) __builtin_amdgcn_s_barrier();
     mask16_next = (unsigned)__builtin_amdgcn_readfirstlane((int)mask_v);
     mask16_next = ((t + 1) & 1) ? mask16_next >> 16 : mask16_next & 0xffffu;
     if (t + 1 < t_end) {
@@ -865,7 +877,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
       __builtin_amdgcn_sched_barrier(0);
     }
 
-    if (dbg & 1) {
+    if (AASR_DBG(1)) {
       asm volatile("" ::"v"(c00), "v"(c01), "v"(c10), "v"(c11));
       continue;
     }

@@ -366,3 +366,75 @@ def test_block_requests_upload_only_their_samples(capi):
             g2 = part.run(pcm, first, min(n, 40), module=name)
             w2 = whole.run(pcm, first, min(n, 40), module=name)
             assert np.array_equal(g2, w2), (name, first)
+
+
+def _fusion_graph(window=0, magnitude=0, root=0, zeroth=0, dct_dim=12, w1=2, w2=3, with_matrix=True,
+                  with_cms=True, sample_rate=16000, frame_rate=125):
+    rng = np.random.default_rng(window + 7 * dct_dim + w1)
+    d = 3 * (dct_dim + 1)
+
+    def vec(v):
+        return " ".join("%.6g" % x for x in np.asarray(v).ravel())
+
+    def mod(name, typ, src=None, **kw):
+        t = "module\n{\n  name %s\n  type %s\n" % (name, typ)
+        for k, v in kw.items():
+            t += "  %s %s\n" % (k, v)
+        return t + ("  sources %s\n" % src if src else "") + "}\n"
+
+    a = dict(sample_rate=sample_rate, frame_rate=frame_rate)
+    if window:
+        a["window_width"] = window
+    cfg = mod("a", "audiofile", **a) + mod("f", "fft", "a", magnitude=magnitude)
+    cfg += mod("m", "mel", "f", root=root) + mod("p", "power", "f")
+    cfg += mod("c", "dct", "m", dim=dct_dim, zeroth=zeroth) + mod("cp", "merge", "c p")
+    cfg += mod("d1", "delta", "cp", width=w1) + mod("d2", "delta", "d1", width=w2) + mod("all", "merge", "cp d1 d2")
+    cfg += mod("nrm", "normalization", "all", mean=vec(rng.normal(0, 2, d)), scale=vec(rng.uniform(0.05, 0.5, d)))
+    lt = dict(dim=d)
+    if with_matrix:
+        lt["matrix"] = vec(np.eye(d) + 0.1 * rng.standard_normal((d, d)))
+        lt["bias"] = vec(0.1 * rng.standard_normal(d))
+    cfg += mod("lt", "lin_transform", "nrm", **lt)
+    if with_cms:
+        cfg += mod("cms", "mean_subtractor", "lt", left=int(rng.integers(0, 60)), right=int(rng.integers(0, 40)))
+    return cfg
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(window=400, magnitude=1, root=1), dict(window=512, zeroth=1, dct_dim=9),
+                                dict(window=320, w1=1, w2=1, with_matrix=False), dict(with_cms=False, w1=3, w2=2),
+                                dict(window=200, sample_rate=8000, frame_rate=100, dct_dim=5)])
+def test_fused_kernels_equal_the_module_by_module_path(capi, oracle, kw):
+    """The fused spectral (audiofile..merge) and temporal (delta..lin_transform) kernels and the
+    mean subtractor writing the float output itself, against every module running its own kernel:
+    identical bits for the output and for every module tap, on a batch of utterances of very
+    different lengths, incl. frames before 0 and past the end; and both agree with the oracle."""
+    import torch
+    cfg = _fusion_graph(**kw)
+    ft = capi.Feat(cfg)
+    sr = ft.sample_rate
+    lens = [sr * 2, 700, sr // 2 + 13, sr * 3 + 7, 513, sr]
+    utts = [synth.make_audio(n, seed=300 + i, sample_rate=sr) for i, n in enumerate(lens)]
+    frames = [ft.last_frame(len(u)) + 1 for u in utts]
+    pcm_off = np.concatenate([[0], np.cumsum([len(u) for u in utts])]).astype(np.int64)
+    frame_off = np.concatenate([[0], np.cumsum(frames)]).astype(np.int64)
+    d_pcm = torch.from_numpy(np.concatenate(utts)).cuda()
+    outs = []
+    for fused in (True, False):
+        capi.debug_feat_fusion(fused)
+        try:
+            d_out = torch.zeros((int(frame_off[-1]), ft.dim), dtype=torch.float32, device="cuda")
+            ft.run_batch_dev(d_pcm, pcm_off, frame_off, d_out)
+            torch.cuda.synchronize()
+            taps = {name: ft.run(utts[0], -9, frames[0] + 15, module=name, dtype=np.float64) for name, _ in ft.modules()}
+            taps["__f32"] = ft.run(utts[3], -30, 90)
+            outs.append((d_out.cpu().numpy(), taps))
+        finally:
+            capi.debug_feat_fusion(True)
+    assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+    for name in outs[0][1]:
+        assert np.array_equal(outs[0][1][name], outs[1][1][name]), name
+    ch = oracle.FeatureChain(cfg)
+    for u in (0, 1, 4):
+        want = ch.generate(utts[u], 0, frames[u])
+        got = outs[0][0][int(frame_off[u]):int(frame_off[u + 1])]
+        assert np.abs(got - want).max() <= FEAT_TOL * max(1.0, np.abs(want).max() / 10)
