@@ -142,7 +142,9 @@ __global__ __launch_bounds__(kCentreThreads) void k_cluster_centres(
       for (int j = 0; j < 8; j++) {
         double ll = acc[j] * -0.5;
         ll += cconst[cg * 8 + j];
-        ll64[f * Cs + (int64_t)cg * 8 + j] = ll;
+        // stored as the ranking key (== ll wherever exp(ll) is a normal double); the selection
+        // kernels never see the rare denormal branch and its exp()
+        ll64[f * Cs + (int64_t)cg * 8 + j] = lin_key(ll);
       }
     }
     __syncthreads();
@@ -196,8 +198,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
     for (int j = 0; j < KPL; j++) {
       const int c = j * 64 + lane;
-      double x = c < C ? row[c] : 0.0;
-      x = lin_key(x);  // the reference compares exp(ll)
+      const double x = c < C ? row[c] : 0.0;  // ranking key (k_cluster_centres): the reference compares exp(ll)
       v[j] = x;
       if (c < C && x == x) cand |= 1ull << j;
     }
@@ -291,8 +292,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       const bool use_exact = sel || !(v[j] > AASR_KEY_ZERO);
       const unsigned long long bal = __ballot(valid && use_exact);
       if (lane == 0) bits[fi][j] = bal;
-      // (the log-likelihood itself is read again: the register holds the ranking key)
-      if (valid) cval[f * C + c] = use_exact ? 0.0f : exp2f((float)(row[c] * kLog2eD + ref));
+      // a key below the normal range stands for a likelihood under 2^-1022: 0.0f either way
+      if (valid) cval[f * C + c] = use_exact ? 0.0f : exp2f((float)(v[j] * kLog2eD + ref));
     }
     if (n_exact) {
 #pragma unroll
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(64) void k_cluster_select_heap(
     const int64_t f = tie_list[i];
     const double *row = ll64 + f * Cs;
     for (int c = 0; c < C; c++) {
-      heap_push(key, idx, st, c, 0, lin_key(row[c]), c);
+      heap_push(key, idx, st, c, 0, row[c], c);
     }
     int n = C, clusters_done = 0, gauss_done = 0;
     while ((clusters_done < min_clusters || gauss_done < min_gaussians) && n > 0) {
@@ -389,32 +390,57 @@ __global__ __launch_bounds__(64) void k_cluster_select_heap(
       unsigned long long *w = maskw + word * (C + 1) + c;
       if (use_exact) atomicOr(w, bit);
       else atomicAnd(w, ~bit);
-      cval[f * C + c] = use_exact ? 0.0f : exp2f((float)(row[c] * kLog2eD + ref));
+      cval[f * C + c] = use_exact ? 0.0f : exp2f((float)(key[p * st] * kLog2eD + ref));
     }
   }
 }
 
 // ----------------------------------------------------------------- expand --
-// Lane masks for the track kernels (see ClusterArgs in gmm_score.hip): for the
-// register pair e of quad q of block mb of a tile, rows r0 = 8q+e (track 0) and
-// r1 = 8q+4+e (track 1) of the block;
-//   left  = frames  0-31 of r0 in lanes 0-31, of r1 in lanes 32-63
-//   right = frames 32-63 of r0 in lanes 0-31, of r1 in lanes 32-63.
+// Per-lane selection bits for the track kernels (see ClusterArgs in gmm_score.hip): for the wave
+// that owns the 64 frames of `word`, lane (n, h) and tile t,
+//   bit ((mb*4 + q)*4 + e)*2 + side  =  selected(row t*64 + 32 mb + 8q + 4h + e, frame 32 side + n).
+// A workgroup takes one word and a run of tiles: the word's cluster masks (C + 1 words, the last
+// one = "in no cluster": all ones) are staged in LDS once, then each thread builds the words of
+// its lane for tile after tile (32 row lookups shared by both sides).
+constexpr int kExpandTiles = 4;  // tiles in flight per workgroup (256 threads = 4 waves, one tile each)
+
 __global__ __launch_bounds__(256) void k_cluster_expand(
     const unsigned long long *__restrict__ maskw, int mask_stride,
-    const int32_t *__restrict__ crow, int64_t rows_padded,
+    const int32_t *__restrict__ crow, int64_t rows_padded, int tiles_per_block,
     unsigned long long *__restrict__ maskrow) {
-  const int64_t pair = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (tile, mb, q, e)
-  if (pair >= rows_padded / 2) return;
+  extern __shared__ unsigned long long cm[];  // [mask_stride] cluster masks, then [4][64] row masks
+  unsigned long long *rm = cm + mask_stride + (threadIdx.x >> 6) * TILE_ROWS;
   const int64_t word = blockIdx.y;
-  const int e = (int)(pair & 3);
-  const int64_t quad = pair >> 2;  // tile*8 + mb*4 + q
-  const int64_t r0 = quad * 8 + e;
-  const unsigned long long m0 = maskw[word * mask_stride + crow[r0]];
-  const unsigned long long m1 = maskw[word * mask_stride + crow[r0 + 4]];
-  unsigned long long *o = maskrow + word * rows_padded + quad * 8 + 2 * e;
-  o[0] = (m0 & 0xffffffffull) | (m1 << 32);
-  o[1] = (m0 >> 32) | (m1 & 0xffffffff00000000ull);
+  for (int c = threadIdx.x; c < mask_stride; c += 256) cm[c] = maskw[word * mask_stride + c];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+  const int64_t n_tiles = rows_padded / TILE_ROWS;
+  const int64_t t0 = (int64_t)blockIdx.x * tiles_per_block;
+  const int64_t t1 = t0 + tiles_per_block < n_tiles ? t0 + tiles_per_block : n_tiles;
+  for (int64_t t = t0 + (threadIdx.x >> 6); t < t1; t += kExpandTiles) {
+    // the tile's 64 row masks, one per lane, then every lane picks its two bits out of the 32
+    // rows of its track (lanes of one half read the same word: an LDS broadcast)
+    rm[lane] = cm[crow[t * TILE_ROWS + lane]];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          // row mask as two dwords: frames 0-31 / 32-63; one bit-field extract each, two inserts
+          const uint2 m = ((const uint2 *)rm)[mb * 32 + 8 * q + 4 * h + e];
+          const unsigned b0 = __builtin_amdgcn_ubfe(m.x, n, 1), b1 = __builtin_amdgcn_ubfe(m.y, n, 1);
+          const int idx = ((mb * 4 + q) * 4 + e) * 2;
+          if (idx < 32) lo |= (b0 << idx) | (b1 << (idx + 1));
+          else hi |= (b0 << (idx - 32)) | (b1 << (idx - 31));
+        }
+    maskrow[word * rows_padded + t * TILE_ROWS + lane] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 // ------------------------------------------------------------------ merge --
@@ -846,9 +872,14 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
       launch_select(g, s0, ns, stream);
     }
     const int64_t words = (n + 63) / 64;
-    hipLaunchKernelGGL(k_cluster_expand, dim3((unsigned)((L.rows_padded / 2 + 255) / 256), (unsigned)words),
-                       dim3(256), 0, stream, cl.maskw.p, cl.C + 1, cl.crow[which].p, L.rows_padded,
-                       cl.maskrow.p);
+    {
+      const int64_t n_tiles = L.rows_padded / TILE_ROWS;
+      const int tpb = (int)std::min<int64_t>(n_tiles, 64);  // the staged cluster masks serve 64 tiles
+      hipLaunchKernelGGL(k_cluster_expand, dim3((unsigned)((n_tiles + tpb - 1) / tpb), (unsigned)words), dim3(256),
+                         (size_t)(cl.C + 1 + kExpandTiles * TILE_ROWS) * 8, stream, cl.maskw.p, cl.C + 1, cl.crow[which].p,
+                         L.rows_padded, tpb,
+                         cl.maskrow.p);
+    }
     AASR_HIP(hipGetLastError());
     gmm_tracks_masked_launch(g, which, fr, n, out, cl.maskrow.p, stream);
     if (cl.nnz <= 8) launch_merge_t<8>(g, out, n, stream);

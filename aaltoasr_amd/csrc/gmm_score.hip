@@ -339,12 +339,13 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score(
 // Gaussian-clustering hook of the track kernels (CL = true; see gmm_cluster.hip).
 // One bit per (packed row, frame): 1 = use the Gaussian's exact value, 0 = the row
 // contributes nothing here (its cluster centre is added by k_cluster_merge).
-// k_cluster_expand stores the bits as ready-made lane masks: a wave's 64 frames
-// are one 64-bit word, and accumulator register 4q+e of a block holds rows 8q+e
-// (lanes 0-31) and 8q+4+e (lanes 32-63) for frames n (left block) / 32+n (right
-// block), so maskrow[word][tile][mb][q] is one 64-byte vector {left_e, right_e :
-// e < 4}.  It is a wave-uniform scalar load, prefetched one quad ahead, and each
-// mask is applied with one v_cndmask -- no mask arithmetic in this kernel.
+// k_cluster_expand stores the bits PER LANE: lane (n, h) of the wave that owns frames
+// f0 .. f0+63 holds, for one tile, the 64 accumulator values {mb, q, e, side}
+// (rows 32 mb + 8q + 4h + e, frames f0 + 32 side + n), so maskrow[word][tile][lane] is one
+// 64-bit word with bit ((mb*4 + q)*4 + e)*2 + side.  A wave fetches its 512 bytes for the NEXT
+// tile with one coalesced vector load issued in the middle of the matrix stream; the first
+// version read ready-made 64-lane masks through the scalar cache (6 GB per 10^6 frames that
+// missed it: +7.6 ms of exposed waits).
 struct ClusterArgs {
   const unsigned long long *maskrow = nullptr;
   int64_t rows_padded = 0;
@@ -354,16 +355,12 @@ struct ClusterArgs {
 // The table is read-only for the whole launch: addressing it through the
 // constant address space lets the compiler use scalar loads (plain global loads
 // are not scalarised in a kernel that also stores).
-typedef unsigned long long u64x8 __attribute__((ext_vector_type(8)));
-typedef const __attribute__((address_space(4))) u64x8 *cl_mask8_ptr;
-
-__device__ __forceinline__ float mask_select(float x, unsigned long long lane_mask) {
-  float r;
-  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(NEG_BIG_F), "v"(x), "s"(lane_mask));
-  return r;
+// value if this lane's bit `idx` (compile-time) of the tile's word is set, a large negative
+// exponent otherwise
+__device__ __forceinline__ float mask_select(float x, unsigned long long bits, int idx) {
+  const unsigned half = idx < 32 ? (unsigned)bits : (unsigned)(bits >> 32);
+  return (half & (1u << (idx & 31))) ? x : NEG_BIG_F;
 }
-
-#define AASR_CL_MASKS(mv, e) const unsigned long long ma_ = (mv)[2 * (e)], mb_ = (mv)[2 * (e) + 1];
 
 template <int NKK, bool GROUPED>
 struct TrackSmem {
@@ -428,9 +425,12 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
   float *orow1 = out + (f0 + 32 + n) * pitch;
   const bool ok0 = f0 + n < F, ok1 = f0 + 32 + n < F;
   const float floor_val = CL ? cl.floor_val : LOG_TINY_F;
-  // this wave's 64 frames are one word of the selection masks
-  const cl_mask8_ptr mrow = (cl_mask8_ptr)(
-      CL ? cl.maskrow + (size_t)__builtin_amdgcn_readfirstlane((int)(f0 >> 6)) * cl.rows_padded : nullptr);
+  // this wave's 64 frames are one word of the selection masks; its per-lane bits of tile t
+  const unsigned long long *mrow =
+      CL ? cl.maskrow + (size_t)(f0 >> 6) * cl.rows_padded + lane : nullptr;
+  unsigned long long bits_next = 0;
+  if (CL && split_row[4 * blockIdx.y] < split_row[4 * blockIdx.y + 4])
+    bits_next = mrow[(size_t)split_row[4 * blockIdx.y] * TILE_ROWS];
 
   // close bits of the next tile are requested (scalar) right after the barrier, one tile ahead
   unsigned pair_next = t_begin < t_end ? sload_close_pair(close_mask, t_begin) : 0u;
@@ -443,11 +443,10 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
     const unsigned mask16 = close16_of_pair(pair_next, t);
     // GROUPED: both tracks carry the same bits -> wave-uniform branch
     const unsigned mask = GROUPED ? (mask16 & 0xffu) : (h ? (mask16 >> 8) : (mask16 & 0xffu));
-    // 8 mask vectors per tile, [mb][q]; the first is fetched before the matrix loop
-    const cl_mask8_ptr mt =
-        CL ? mrow + (size_t)__builtin_amdgcn_readfirstlane((int)t) * (TILE_ROWS / 8) : nullptr;
-    u64x8 mnext;
-    if (CL) mnext = mt[0];
+    // this tile's selection bits arrived during the previous tile; the next tile's are requested
+    // here and waited for by the vmcnt(0) in front of the end-of-tile barrier
+    const unsigned long long bits = bits_next;
+    if (CL && t + 1 < t_end) bits_next = mrow[(size_t)(t + 1) * TILE_ROWS];
 
     f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
     const f32x4 *afrag = (const f32x4 *)acur + lane;
@@ -493,24 +492,13 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
       for (int q = 0; q < 4; q++) {
         // this lane's quad q of the block: accumulator registers 4q .. 4q+3
         float va[4], vb[4];
-        u64x8 mv;
-        if (CL) {
-          // Scalar loads return out of order, so the only wait is lgkmcnt(0): take
-          // this quad's masks first, THEN put the next quad's load in flight (the
-          // asm ties the next index to the wait so the load cannot be hoisted).
-          int nxt = mb * 4 + q + 1;
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(nxt) : : "memory");
-          mv = mnext;
-          if (mb * 4 + q + 1 < 8) mnext = mt[nxt];
-        }
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           va[e] = ca[4 * q + e];
           vb[e] = cb[4 * q + e];
           if (CL) {
-            AASR_CL_MASKS(mv, e)
-            va[e] = mask_select(va[e], ma_);
-            vb[e] = mask_select(vb[e], mb_);
+            va[e] = mask_select(va[e], bits, ((mb * 4 + q) * 4 + e) * 2);
+            vb[e] = mask_select(vb[e], bits, ((mb * 4 + q) * 4 + e) * 2 + 1);
           }
         }
         float e0 = __builtin_amdgcn_exp2f(va[0]) + __builtin_amdgcn_exp2f(va[1]);
@@ -762,9 +750,12 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   float *orow1 = out + (f0 + 32 + n) * pitch;
   const bool ok0 = f0 + n < F, ok1 = f0 + 32 + n < F;
   const float floor_val = CL ? cl.floor_val : LOG_TINY_F;
-  // this wave's 64 frames are one word of the selection masks
-  const cl_mask8_ptr mrow = (cl_mask8_ptr)(
-      CL ? cl.maskrow + (size_t)__builtin_amdgcn_readfirstlane((int)(f0 >> 6)) * cl.rows_padded : nullptr);
+  // this wave's 64 frames are one word of the selection masks; its per-lane bits of tile t
+  const unsigned long long *mrow =
+      CL ? cl.maskrow + (size_t)(f0 >> 6) * cl.rows_padded + lane : nullptr;
+  unsigned long long bits_next = 0;
+  if (CL && split_row[4 * blockIdx.y] < split_row[4 * blockIdx.y + 4])
+    bits_next = mrow[(size_t)split_row[4 * blockIdx.y] * TILE_ROWS];
 
   if (AASR_DBG(4)) {  // experiment: de-phase co-resident workgroups
     unsigned hsh = ((unsigned)blockIdx.x + 977u * blockIdx.y) * 2654435761u;
@@ -805,11 +796,10 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     bi = bn;
     const unsigned mask16 = mask16_next;
     const unsigned mask = GROUPED ? (mask16 & 0xffu) : (h ? (mask16 >> 8) : (mask16 & 0xffu));
-    // 8 mask vectors per tile, [mb][q]; the first is fetched before the matrix loop
-    const cl_mask8_ptr mt =
-        CL ? mrow + (size_t)__builtin_amdgcn_readfirstlane((int)t) * (TILE_ROWS / 8) : nullptr;
-    u64x8 mnext;
-    if (CL) mnext = mt[0];
+    // this tile's selection bits arrived during the previous tile; the next tile's are requested
+    // here and waited for by the vmcnt(0) in front of the end-of-tile barrier
+    const unsigned long long bits = bits_next;
+    if (CL && t + 1 < t_end) bits_next = mrow[(size_t)(t + 1) * TILE_ROWS];
 
     f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
     const u32x4 *afrag = (const u32x4 *)acur + lane;  // [slab][split][mb][64 lanes]
@@ -889,24 +879,13 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         float va[4], vb[4];
-        u64x8 mv;
-        if (CL) {
-          // Scalar loads return out of order, so the only wait is lgkmcnt(0): take
-          // this quad's masks first, THEN put the next quad's load in flight (the
-          // asm ties the next index to the wait so the load cannot be hoisted).
-          int nxt = mb * 4 + q + 1;
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(nxt) : : "memory");
-          mv = mnext;
-          if (mb * 4 + q + 1 < 8) mnext = mt[nxt];
-        }
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           va[e] = ca[4 * q + e];
           vb[e] = cb[4 * q + e];
           if (CL) {
-            AASR_CL_MASKS(mv, e)
-            va[e] = mask_select(va[e], ma_);
-            vb[e] = mask_select(vb[e], mb_);
+            va[e] = mask_select(va[e], bits, ((mb * 4 + q) * 4 + e) * 2);
+            vb[e] = mask_select(vb[e], bits, ((mb * 4 + q) * 4 + e) * 2 + 1);
           }
         }
         float e0 = __builtin_amdgcn_exp2f(va[0]) + __builtin_amdgcn_exp2f(va[1]);
