@@ -88,6 +88,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for name, src in (("phone_probs", "aku/main_phone_probs.cc"),
                       ("aku_adapter_check", "aku/main_adapter_check.cc"),
                       ("feacat", "aku/main_feacat.cc"),
+                      ("plugin_check", "aku/main_plugin_check.cc"),
                       ("acoustics_check", "decoder/main_acoustics_check.cc")):
         srcp = os.path.join(CSRC, src)
         exe = os.path.join(bindir, name)

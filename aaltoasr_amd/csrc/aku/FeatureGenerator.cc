@@ -196,9 +196,101 @@ void FeatureModule::print_dot_node(FILE *file) {
           m_req_offset_left, m_req_offset_right, m_req_offset_left + m_req_offset_right + 1);
 }
 
-void FeatureModule::get_config(ModuleConfig &config) { config = m_config; }
+void FeatureModule::get_config(ModuleConfig &config) {
+  if (m_user) {
+    config.set("name", m_name);
+    config.set("type", m_type_str);
+    get_module_config(config);
+    return;
+  }
+  config = m_config;
+}
 
-void FeatureModule::set_config(const ModuleConfig &config) { m_gen->reconfigure_module(m_name, config); }
+void FeatureModule::set_config(const ModuleConfig &config) {
+  if (m_user) {
+    set_module_config(config);
+    return;
+  }
+  m_gen->reconfigure_module(m_name, config);
+}
+
+// ---- user-defined module types ------------------------------------------------------------
+// One instance per module of the type in a loaded graph: the user's object plus proxy objects
+// standing for its sources (they only know their dimension and, during generate(), the rows the
+// engine handed over).
+struct UserModuleGlue {
+  std::unique_ptr<FeatureModule> mod;
+  std::vector<std::unique_ptr<FeatureModule>> proxies;
+  int left = 0, right = 0;
+
+  static int fail(char *err, int32_t len, const std::string &msg) {
+    if (err && len > 0) snprintf(err, (size_t)len, "%s", msg.c_str());
+    return 1;
+  }
+
+  static int configure(void *user, const char *name, const char *block, int32_t n_sources, const int32_t *source_dims,
+                       int32_t *dim, int32_t *left, int32_t *right, void **instance, char *err, int32_t err_len) {
+    try {
+      std::unique_ptr<UserModuleGlue> g(new UserModuleGlue());
+      g->mod.reset(((FeatureModule * (*)()) user)());
+      g->mod->m_user = true;
+      g->mod->m_name = name;
+      for (int k = 0; k < n_sources; k++) {
+        g->proxies.emplace_back(new FeatureModule());
+        g->proxies.back()->m_user = true;
+        g->proxies.back()->m_dim = source_dims[k];
+        g->mod->m_sources.push_back(g->proxies.back().get());
+      }
+      ModuleConfig c;
+      c.read_text(block);
+      std::string t;
+      if (c.get("type", t)) g->mod->m_type_str = t;
+      g->mod->set_config(c);
+      if (g->mod->m_dim <= 0) return fail(err, err_len, std::string("module ") + name + " did not set its dimension");
+      *dim = g->mod->m_dim;
+      *left = g->left = g->mod->m_own_offset_left;
+      *right = g->right = g->mod->m_own_offset_right;
+      g->mod->m_buffer.m_dim = g->mod->m_dim;
+      *instance = g.release();
+      return 0;
+    } catch (std::string &e) {
+      return fail(err, err_len, e);
+    } catch (std::exception &e) {
+      return fail(err, err_len, e.what());
+    }
+  }
+
+  static int generate(void *instance, int32_t frame, const double *const *sources, double *out, char *err,
+                      int32_t err_len) {
+    UserModuleGlue *g = (UserModuleGlue *)instance;
+    try {
+      for (size_t k = 0; k < g->proxies.size(); k++) {
+        g->proxies[k]->m_eval_rows = sources[k];
+        g->proxies[k]->m_eval_first = frame - g->left;
+        g->proxies[k]->m_eval_count = g->left + g->right + 1;
+      }
+      g->mod->m_buffer.m_row = out;
+      g->mod->m_buffer.m_frame = frame;
+      g->mod->generate(frame);
+      g->mod->m_buffer.m_row = nullptr;
+      return 0;
+    } catch (std::string &e) {
+      return fail(err, err_len, e);
+    } catch (std::exception &e) {
+      return fail(err, err_len, e.what());
+    }
+  }
+
+  static void destroy(void *instance) { delete (UserModuleGlue *)instance; }
+};
+
+void FeatureGenerator::register_user_type(const char *type, FeatureModule *(*factory)()) {
+  aasr_host_module v;
+  v.configure = &UserModuleGlue::configure;
+  v.generate = &UserModuleGlue::generate;
+  v.destroy = &UserModuleGlue::destroy;
+  if (aasr_feat_register_module_type(type, &v, (void *)factory) != AASR_OK) throw std::string(aasr_last_error());
+}
 
 bool BaseFeaModule::eof(int frame) { return frame >= m_gen->last_frame() + 1; }
 int BaseFeaModule::sample_rate(void) { return m_gen->sample_rate(); }
@@ -224,6 +316,12 @@ void FeatureModule::get_parameters(ModuleConfig &config) {
 }
 
 const FeatureVec FeatureModule::at(int frame) {
+  if (m_user) {  // a source of a user module while its generate() runs
+    if (!m_eval_rows || frame < m_eval_first || frame >= m_eval_first + m_eval_count)
+      throw std::string("FeatureModule::at(): frame outside the look-around the module declared "
+                        "(m_own_offset_left / m_own_offset_right)");
+    return FeatureVec(m_eval_rows + (size_t)(frame - m_eval_first) * m_dim, m_dim, frame, nullptr);
+  }
   if (m_count == 0 || m_epoch != m_gen->epoch() || frame < m_first || frame >= m_first + m_count) {
     const std::vector<int16_t> &in = m_gen->input_units();
     const int n = 256;

@@ -64,6 +64,16 @@ public:
   /** aku/FeatureGenerator.cc:389-408: the module structure in DOT format */
   void print_dot_graph(FILE *file);
 
+  /** Makes the module class T usable as `type <T::type_str()>` in feature configurations -- what
+   * adding an `else if` to FeatureGenerator::load_configuration does in the reference
+   * (aku/FeatureGenerator.cc:145-175).  T derives from FeatureModule, has a default constructor
+   * and a static type_str(), and overrides set_module_config / generate (FeatureModule.hh). */
+  template <class T>
+  static void register_module_type() {
+    register_user_type(T::type_str(), []() -> FeatureModule * { return new T(); });
+  }
+  static void register_user_type(const char *type, FeatureModule *(*factory)());
+
   /** handle access for sibling adapters */
   aasr_feat *handle() const { return m_feat; }
   /** float32 features of the cached block that holds `frame` (nullptr if the

@@ -20,6 +20,24 @@
 namespace aku {
 
 class FeatureGenerator;
+class FeatureModule;
+
+/** What a user module's generate(frame) writes into: m_buffer[frame] (the reference's ring buffer,
+ * aku/FeatureBuffer.hh:92-143, reduced to the one slot that is being computed). */
+class FeatureBuffer {
+public:
+  FeatureVec operator[](int frame) {
+    if (!m_row || frame != m_frame) throw std::string("FeatureBuffer: only the frame being generated can be written");
+    return FeatureVec(m_row, m_dim, frame, nullptr);
+  }
+  int dim() const { return m_dim; }
+
+private:
+  friend class FeatureModule;
+  friend struct UserModuleGlue;
+  double *m_row = nullptr;
+  int m_dim = 0, m_frame = 0;
+};
 
 class FeatureModule {
 public:
@@ -46,8 +64,26 @@ public:
   /** aku/FeatureModules.cc:202-217 */
   void print_dot_node(FILE *file);
 
+private:
+  // A user-defined module type overrides these exactly as it would in the reference
+  // (aku/FeatureModule.hh:131-139) and is made known with
+  // FeatureGenerator::register_module_type<T>(): set_module_config checks its sources
+  // (m_sources[k]->dim()) and sets m_dim and m_own_offset_left / _right; generate(frame) reads
+  // m_sources[k]->at(frame + d), |d| within those offsets, and fills m_buffer[frame].  It runs on
+  // the host, once per frame (include/aasr.h: aasr_feat_register_module_type).
+  virtual void set_module_config(const ModuleConfig &config) { (void)config; }
+  virtual void get_module_config(ModuleConfig &config) { (void)config; }
+  virtual void reset_module() {}
+  virtual void generate(int frame) { (void)frame; }
+
 protected:
   friend class FeatureGenerator;
+  friend struct UserModuleGlue;
+  FeatureBuffer m_buffer;
+  // while a user module's generate() runs, its sources serve at() from the rows the engine handed over
+  const double *m_eval_rows = nullptr;
+  int m_eval_first = 0, m_eval_count = 0;
+  bool m_user = false;  // a user module (or one of its source proxies), not a handle of a loaded graph
   FeatureGenerator *m_gen = nullptr;
   std::string m_name, m_type_str;
   int m_dim = 0;

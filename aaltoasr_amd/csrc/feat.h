@@ -13,13 +13,15 @@
 #include <vector>
 
 #include "common.h"
+#include "../../include/aasr.h"
 
 namespace aasr {
 
 enum ModType {
   MOD_AUDIOFILE, MOD_FFT, MOD_MEL, MOD_POWER, MOD_DCT, MOD_DELTA,
   MOD_NORMALIZATION, MOD_LIN_TRANSFORM, MOD_MERGE, MOD_MEAN_SUBTRACTOR,
-  MOD_CONCAT, MOD_VTLN, MOD_SR_NORM, MOD_MEL_POWER, MOD_QUANTEQ, MOD_PRE
+  MOD_CONCAT, MOD_VTLN, MOD_SR_NORM, MOD_MEL_POWER, MOD_QUANTEQ, MOD_PRE,
+  MOD_HOST  // a user-registered type evaluated on the host (aasr_feat_register_module_type)
 };
 
 // One "{ key value ... }" block (aku::ModuleConfig, aku/ModuleConfig.cc).
@@ -108,9 +110,22 @@ struct FeatModule {
   // quanteq (QuantEqModule, :2078-2141)
   std::vector<float> q_alpha, q_gamma, q_max, quant_train;
   DevBuf<float> d_q_alpha, d_q_gamma, d_q_max;
+  // MOD_HOST: index into the registry of user types, the user's instance, the option block as read
+  int host_type = -1;
+  void *host_instance = nullptr;
+  std::vector<std::string> opt_names, opt_values;
   // look-around this module itself adds around its sources
   int own_left = 0, own_right = 0;
 };
+
+// aasr_feat_register_module_type: the callbacks of one user module type (see include/aasr.h)
+struct HostModuleType {
+  std::string name;
+  aasr_host_module vtbl;
+  void *user;
+};
+const std::vector<HostModuleType> &host_module_types();
+int register_host_module_type(const char *name, const aasr_host_module *vtbl, void *user);
 
 }  // namespace aasr
 
@@ -130,6 +145,9 @@ struct aasr_feat {
   hipEvent_t stage_event = nullptr;
   bool stage_busy = false;
   ~aasr_feat() {
+    for (aasr::FeatModule &m : mods)
+      if (m.type == aasr::MOD_HOST && m.host_instance && aasr::host_module_types()[(size_t)m.host_type].vtbl.destroy)
+        aasr::host_module_types()[(size_t)m.host_type].vtbl.destroy(m.host_instance);
     if (stage_host) (void)hipHostFree(stage_host);
     if (stage_event) (void)hipEventDestroy(stage_event);
   }

@@ -215,6 +215,10 @@ aasr_status aasr_feat_get_parameters(const aasr_feat *h, const char *module_name
   });
 }
 
+aasr_status aasr_feat_register_module_type(const char *type_name, const aasr_host_module *vtbl, void *user) {
+  return guarded([&] { (void)register_host_module_type(type_name, vtbl, user); });
+}
+
 int aasr_feat_num_modules(const aasr_feat *h) { return h ? (int)h->mods.size() : -1; }
 const char *aasr_feat_module_name(const aasr_feat *h, int index) {
   return h && index >= 0 && index < (int)h->mods.size() ? h->mods[(size_t)index].name.c_str() : nullptr;

@@ -660,6 +660,29 @@ static void configure(aasr_feat *h, FeatModule &m, const ModuleConfig &c) {
       build_srnorm_table(m);
       break;
     }
+    case MOD_HOST: {
+      // the user's set_module_config: dimension and look-around come from the callback
+      const HostModuleType &ht = host_module_types()[(size_t)m.host_type];
+      m.opt_names = c.names;
+      m.opt_values = c.values;
+      std::string block = "{\n";
+      for (size_t k = 0; k < c.names.size(); k++) block += "  " + c.names[k] + " " + c.values[k] + "\n";
+      block += "}\n";
+      std::vector<int32_t> sdims;
+      for (int sidx : m.sources) sdims.push_back(h->mods[sidx].dim);
+      int32_t dim = 0, left = 0, right = 0;
+      char err[512] = {0};
+      if (!ht.vtbl.configure || !ht.vtbl.generate)
+        raise(AASR_ERR_INVALID, "module type %s was registered without callbacks", ht.name.c_str());
+      if (ht.vtbl.configure(ht.user, m.name.c_str(), block.c_str(), (int32_t)sdims.size(), sdims.data(), &dim, &left,
+                            &right, &m.host_instance, err, (int32_t)sizeof err - 1) != 0)
+        raise(AASR_ERR_INVALID, "%s", err[0] ? err : "user module configuration failed");
+      if (left < 0 || right < 0) raise(AASR_ERR_INVALID, "module %s: negative look-around", m.name.c_str());
+      m.dim = dim;
+      m.own_left = left;
+      m.own_right = right;
+      break;
+    }
     case MOD_QUANTEQ:
       // QuantEqModule::set_module_config (aku/FeatureModules.cc:2078-2083); the
       // channel parameters only arrive through set_parameters
@@ -669,6 +692,30 @@ static void configure(aasr_feat *h, FeatModule &m, const ModuleConfig &c) {
       break;
   }
   if (m.dim <= 0) raise(AASR_ERR_INVALID, "module %s has no output dimension", m.name.c_str());
+}
+
+static std::vector<HostModuleType> &host_registry() {
+  static std::vector<HostModuleType> r;
+  return r;
+}
+const std::vector<HostModuleType> &host_module_types() { return host_registry(); }
+
+int register_host_module_type(const char *name, const aasr_host_module *vtbl, void *user) {
+  static const char *builtin[] = {"audiofile", "fft", "mel", "power", "dct", "delta", "normalization",
+                                  "lin_transform", "merge", "mean_subtractor", "concat", "vtln", "sr_norm",
+                                  "mel_power", "quanteq", "pre"};
+  if (!name || !*name || !vtbl) raise(AASR_ERR_INVALID, "aasr_feat_register_module_type: null argument");
+  for (const char *b : builtin)
+    if (std::string(b) == name) raise(AASR_ERR_INVALID, "module type '%s' is built in", name);
+  std::vector<HostModuleType> &r = host_registry();
+  for (size_t k = 0; k < r.size(); k++)
+    if (r[k].name == name) {  // re-registration replaces the callbacks (handles created earlier keep index k)
+      r[k].vtbl = *vtbl;
+      r[k].user = user;
+      return (int)k;
+    }
+  r.push_back(HostModuleType{name, *vtbl, user});
+  return (int)r.size() - 1;
 }
 
 aasr_feat *feat_create(const std::string &text) {
@@ -718,6 +765,15 @@ aasr_feat *feat_create(const std::string &text) {
           m.type = k.t;
           found = true;
         }
+      if (!found) {
+        const std::vector<HostModuleType> &reg = host_module_types();
+        for (size_t k = 0; k < reg.size(); k++)
+          if (reg[k].name == type) {
+            m.type = MOD_HOST;
+            m.host_type = (int)k;
+            found = true;
+          }
+      }
       if (!found) raise(AASR_ERR_INVALID, "Unknown module type '%s'", type.c_str());
       const bool is_first = h->mods.size() == 1;
       const bool is_base = m.type == MOD_AUDIOFILE || m.type == MOD_PRE;
@@ -739,7 +795,7 @@ aasr_feat *feat_create(const std::string &text) {
           auto it = h->by_name.find(s);
           if (it == h->by_name.end())
             raise(AASR_ERR_INVALID, "unknown source module: %s", s.c_str());
-          if (!m.sources.empty() && m.type != MOD_MERGE)
+          if (!m.sources.empty() && m.type != MOD_MERGE && m.type != MOD_HOST)
             raise(AASR_ERR_INVALID, "Multiple sources are not allowed for module %s", type.c_str());
           m.sources.push_back(it->second);
         }
@@ -864,6 +920,11 @@ std::string feat_write_configuration(const aasr_feat *h) {
         break;
       case MOD_QUANTEQ:  // :2071-2074
         c.set("quant_train", m.quant_train);
+        break;
+      case MOD_HOST:  // a user type: its options as they were read
+        for (size_t k = 0; k < m.opt_names.size(); k++)
+          if (m.opt_names[k] != "name" && m.opt_names[k] != "type" && m.opt_names[k] != "sources")
+            c.insert(m.opt_names[k], m.opt_values[k]);
         break;
       default:  // power, mel_power, merge: no options
         break;

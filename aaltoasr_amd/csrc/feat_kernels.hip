@@ -1366,6 +1366,45 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
                            m.d_q_max.p, dst);
         break;
       }
+      case MOD_HOST: {
+        // A user-registered type (aasr_feat_register_module_type): its frames are computed by the
+        // user's callback on the host.  Sources come down, results go up; everything enqueued so far
+        // has to finish first.  Rows of utterance u: key(u) .. key(u+1)-1 with key(u) = frame_off[u] +
+        // u*span; row r is frame first[u] - L + (r - key(u)), its source row r + u*span_diff + shift.
+        const HostModuleType &ht = host_module_types()[(size_t)m.host_type];
+        AASR_HIP(hipStreamSynchronize(stream));
+        const size_t ns = m.sources.size();
+        std::vector<std::vector<double>> hsrc(ns);
+        std::vector<SrcMap> smap(ns);
+        std::vector<int> sdim(ns);
+        for (size_t k = 0; k < ns; k++) {
+          const int sidx = m.sources[k];
+          sdim[k] = h->mods[sidx].dim;
+          smap[k] = map_of(i, sidx);
+          hsrc[k].resize((size_t)rows_of(sidx) * sdim[k]);
+          AASR_HIP(hipMemcpy(hsrc[k].data(), h->bufs[sidx].p, hsrc[k].size() * sizeof(double), hipMemcpyDeviceToHost));
+        }
+        std::vector<double> hout((size_t)rows * m.dim);
+        std::vector<const double *> ptr(ns);
+        char err[512] = {0};
+        for (int u = 0; u < n; u++) {
+          const int64_t key = ub.frame_off[u] + (int64_t)u * span;
+          const int64_t n_rows = (ub.frame_off[u + 1] - ub.frame_off[u]) + span;
+          for (int64_t lr = 0; lr < n_rows; lr++) {
+            const int64_t r = key + lr;
+            const int frame = ub.first[u] - L[i] + (int)lr;
+            for (size_t k = 0; k < ns; k++) {
+              const int64_t sr = r + (int64_t)u * smap[k].span_diff + smap[k].shift;
+              ptr[k] = hsrc[k].data() + (size_t)(sr - m.own_left) * sdim[k];
+            }
+            if (ht.vtbl.generate(m.host_instance, frame, ptr.data(), hout.data() + (size_t)r * m.dim, err,
+                                 (int32_t)sizeof err - 1) != 0)
+              raise(AASR_ERR_INVALID, "module %s: %s", m.name.c_str(), err[0] ? err : "generate() failed");
+          }
+        }
+        AASR_HIP(hipMemcpy(dst, hout.data(), hout.size() * sizeof(double), hipMemcpyHostToDevice));
+        break;
+      }
       case MOD_MEAN_SUBTRACTOR: {
         constexpr int MS_ROWS = 64;
         const size_t ms_src = (size_t)(MS_ROWS + m.cms_left + m.cms_right);

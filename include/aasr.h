@@ -358,6 +358,34 @@ void aasr_recipe_frame_limits(float start_time, float end_time, float frame_rate
                               int32_t *start_frame, int32_t *end_frame);
 
 /* ---------------------------------------------------------------------------
+ * User-defined feature module types (the plugin side of aku::FeatureModule,
+ * aku/FeatureModule.hh:47-154: a subclass with set_module_config / generate(frame),
+ * one more `else if` in FeatureGenerator::load_configuration, aku/FeatureGenerator.cc:145-175).
+ * A registered type may appear in any .cfg after the base module.  Its frames are
+ * computed by the callback ON THE HOST: when the graph is evaluated, the rows of its
+ * sources are copied from the device, `generate` runs once per frame, the result goes
+ * back to the device and the modules behind it continue there -- an escape hatch for
+ * experiments, not a fast path (the 16 built-in types are kernels).  A built-in
+ * name cannot be taken.  The adapter class aku::FeatureModule
+ * (aaltoasr_amd/csrc/aku/FeatureModule.hh) wraps this for C++ subclasses.
+ *   configure: parse the module's option block ("{\n name value\n ... }\n"), report
+ *     the output dimension and how many frames to the left / right of the current
+ *     one the module reads from its sources; *instance is handed back to the other
+ *     callbacks.  Return 0, or nonzero with a message in err.
+ *   generate: sources[k] points at source k's frames frame-left .. frame+right,
+ *     row-major [left+right+1][source_dims[k]] doubles (frames outside the file are
+ *     the border copies the chain defines); write dim doubles to out. */
+typedef struct aasr_host_module {
+  int (*configure)(void *user, const char *module_name, const char *options_block, int32_t n_sources,
+                   const int32_t *source_dims, int32_t *dim, int32_t *left, int32_t *right, void **instance,
+                   char *err, int32_t err_len);
+  int (*generate)(void *instance, int32_t frame, const double *const *sources, double *out, char *err,
+                  int32_t err_len);
+  void (*destroy)(void *instance);
+} aasr_host_module;
+aasr_status aasr_feat_register_module_type(const char *type_name, const aasr_host_module *vtbl, void *user);
+
+/* ---------------------------------------------------------------------------
  * Speaker / utterance configuration: aku::SpeakerConfig
  * (aku/SpeakerConfig.hh:15-60, aku/SpeakerConfig.cc) -- what phone_probs -S FILE
  * drives (aku/phone_probs.cc:94-95, 191-196).  A .spkc file holds, per speaker
