@@ -28,3 +28,32 @@ def test_world_size_and_gpus_flag_must_agree():
     r = _run(["--gpus", "1"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and r.stdout.strip() == ""
     assert "WORLD_SIZE=2" in r.stderr
+
+
+import json
+
+import pytest
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,key", [(["--frames", "40000", "--steps", "2", "--warmup", "1", "--cpu-frames", "200", "--cpu-procs", "2"], "configs2"),
+                                      (["--workload", "full", "--utts", "24", "--steps", "2", "--warmup", "1", "--cpu-frames", "0"], None),
+                                      (["--workload", "recipe", "--utts", "40", "--steps", "1", "--warmup", "1", "--cpu-frames", "0"], "recipe")])
+def test_bench_line_on_a_gpu(args, key):
+    """One JSON line on stdout with the contract's keys, for each workload (small sizes)."""
+    r = _run(args)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["unit"] == "frames/s" and "workload" in d["config"]
+    if args[0] != "--workload":
+        assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+        assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
+        assert "error" not in d["config"]["configs2"] and "error" not in d["config"]["recipe_e2e"]
+        assert d["config"]["configs2"]["lna_check"]["max_code_difference"] <= 1
+    if key == "recipe":
+        assert d["scaling"] == "strong" and d["config"]["recipe"]["utterances"] == 40
