@@ -1,8 +1,10 @@
 """capi.py -- ctypes binding of libaasr.so (the C ABI in include/aasr.h).
 
-This is plumbing for tests, bench.py and the Python mirror of the aku classes.
-It never falls back to a CPU path: if the shared library is missing it raises,
-and compute calls without a HIP device return AASR_ERR_NO_DEVICE.
+The Python binding of the engine: every function of include/aasr.h with its argument types, plus
+thin handle classes (Feat, Gmm, SpeakerConfig) that mirror aku::FeatureGenerator / HmmSet /
+SpeakerConfig call for call.  Tests, bench.py and the pipeline / shard helpers go through it; it
+holds no arithmetic of its own.  It never falls back to a CPU path: if the shared library is
+missing it raises, and compute calls without a HIP device return AASR_ERR_NO_DEVICE.
 """
 from __future__ import annotations
 

@@ -15,6 +15,8 @@ import wave
 import numpy as np
 import pytest
 
+from conftest import observed
+
 from aaltoasr_amd import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -127,7 +129,8 @@ def test_reference_phone_probs_main_on_the_engine(world, extra):
         else:
             x = np.frombuffer(a[5:], ">u2").astype(np.int64)
             y = np.frombuffer(b[5:], ">u2").astype(np.int64)
-            assert np.abs(x - y).max() <= 1 and (x == y).mean() > 0.99, n
+            assert np.abs(x - y).max() <= 1, n
+            observed('refmain codes equal ' + n, float((x == y).mean()), 0.9995)  # observed 1.0
 
 
 @pytest.mark.gpu

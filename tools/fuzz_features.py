@@ -57,6 +57,19 @@ def run(seed=1, N=40, verbose=False):
         cfg += mod("all", "merge", "cp d1 d2")
         last = "all"
         if rng.integers(0, 2):
+            # the production tail: normalization + lin_transform (with delta, delta-delta and the merge
+            # in front of it this is the shape the fused temporal kernel takes)
+            d3 = 3 * (nd + 1)
+            vec = lambda v: " ".join("%.6g" % x for x in np.asarray(v).ravel())
+            cfg += mod("nrm", "normalization", last, mean=vec(rng.normal(0, 2, d3)), scale=vec(rng.uniform(0.05, 0.5, d3)))
+            lt = dict(dim=d3)
+            if rng.integers(0, 3):
+                lt["matrix"] = vec(np.eye(d3) + 0.1 * rng.standard_normal((d3, d3)))
+            if rng.integers(0, 2):
+                lt["bias"] = vec(0.1 * rng.standard_normal(d3))
+            cfg += mod("lt", "lin_transform", "nrm", **lt)
+            last = "lt"
+        if rng.integers(0, 2):
             cfg += mod("cms", "mean_subtractor", last, left=int(rng.integers(0, 40)), right=int(rng.integers(0, 40)))
             last = "cms"
         if rng.integers(0, 2):
