@@ -43,7 +43,8 @@ class RunOptions(C.Structure):
 
 class RunStats(C.Structure):
     _fields_ = [("utterances", C.c_int64), ("frames", C.c_int64),
-                ("seconds_total", C.c_double), ("seconds_device", C.c_double)]
+                ("seconds_total", C.c_double), ("seconds_device", C.c_double),
+                ("seconds_copy_out", C.c_double)]
 
 
 _lib: Optional[C.CDLL] = None

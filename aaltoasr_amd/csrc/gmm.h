@@ -253,6 +253,7 @@ struct aasr_gmm {
   aasr::DevBuf<float> class_scratch, class_xframes;
   // device buffers of aasr_run_utterance, kept between calls (pipeline.cc: BlockRunner)
   std::shared_ptr<void> utt_scratch;
+  std::shared_ptr<void> recipe_scratch;  // the recipe driver's device buffers, streams and pinned result slots
   // global CMLLR transform applied to the frames before scoring
   aasr::DevBuf<double> xf_a, xf_b;
   aasr::DevBuf<float> d_xframes;

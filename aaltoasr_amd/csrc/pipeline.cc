@@ -224,9 +224,22 @@ std::vector<int16_t> parse_feature_data(const std::vector<char> &data, int dim, 
 }
 
 std::vector<int16_t> read_feature_file(const std::string &path, int dim, bool legacy) {
-  std::ifstream in(path, std::ios::binary);
-  if (!in) raise(AASR_ERR_IO, "could not open file %s", path.c_str());
-  std::vector<char> data((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+  FILE *fp = fopen(path.c_str(), "rb");
+  if (!fp) raise(AASR_ERR_IO, "could not open file %s", path.c_str());
+  std::vector<char> data;
+  char buf[65536];
+  size_t got;
+  if (fseek(fp, 0, SEEK_END) == 0) {
+    const long n = ftell(fp);
+    rewind(fp);
+    if (n > 0) {
+      data.resize((size_t)n);
+      data.resize(fread(data.data(), 1, (size_t)n, fp));
+    }
+  } else {
+    while ((got = fread(buf, 1, sizeof buf, fp)) > 0) data.insert(data.end(), buf, buf + got);
+  }
+  fclose(fp);
   return parse_feature_data(data, dim, legacy);
 }
 
@@ -266,9 +279,82 @@ struct BlockRunner {
   BlockRunner(aasr_feat *f, aasr_gmm *g, int lb, int nz) : feat(f), gmm(g), lnabytes(lb), normalize(nz) {}
   DevBuf<int16_t> d_pcm;
   DevBuf<float> d_fea, d_ll;
-  DevBuf<uint8_t> d_bytes;
+  DevBuf<uint8_t> d_bytes, d_bytes2;
   std::vector<uint8_t> h_bytes;
   double device_seconds = 0;
+  // recipe driver: kernels on one stream, the copy of the packed rows to the host on another, so
+  // block n+1 is computed while block n crosses PCIe (6.25 kB per frame: the copy is the longer leg)
+  hipStream_t s_compute = nullptr, s_copy = nullptr;
+  hipEvent_t ev_start[2] = {nullptr, nullptr}, ev_kernels[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+  double copy_seconds = 0;
+  ~BlockRunner() {
+    for (int i = 0; i < 2; i++) {
+      if (ev_start[i]) (void)hipEventDestroy(ev_start[i]);
+      if (ev_kernels[i]) (void)hipEventDestroy(ev_kernels[i]);
+      if (ev_copied[i]) (void)hipEventDestroy(ev_copied[i]);
+    }
+    if (s_compute) (void)hipStreamDestroy(s_compute);
+    if (s_copy) (void)hipStreamDestroy(s_copy);
+  }
+  void init_streams() {
+    if (s_compute) return;
+    AASR_HIP(hipStreamCreateWithFlags(&s_compute, hipStreamNonBlocking));
+    AASR_HIP(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+      AASR_HIP(hipEventCreate(&ev_start[i]));
+      AASR_HIP(hipEventCreate(&ev_kernels[i]));
+      AASR_HIP(hipEventCreate(&ev_copied[i]));
+    }
+  }
+
+  // Asynchronous form: enqueue block `jobs` (kernels on s_compute writing the rows of slot `slot`,
+  // their copy to `dst` on s_copy); finish(slot) waits for the copy and books the times.
+  void launch(const std::vector<Job *> &jobs, int slot, uint8_t *dst, size_t dst_cap) {
+    init_streams();
+    UttBatch ub;
+    ub.n_utts = (int32_t)jobs.size();
+    ub.frame_off.assign(1, 0);
+    ub.pcm_off.assign(1, 0);
+    for (Job *j : jobs) {
+      ub.first.push_back(j->start);
+      ub.frame_off.push_back(ub.frame_off.back() + j->count);
+      ub.pcm_off.push_back(ub.pcm_off.back() + (int64_t)j->pcm.size());
+    }
+    const int64_t F = ub.frame_off.back();
+    const int dim = feat->mods.back().dim;
+    const int64_t S = gmm->S;
+    const size_t nb = (size_t)F * S * lnabytes;
+    if (nb > dst_cap) raise(AASR_ERR_INVALID, "internal: result buffer too small");
+    DevBuf<uint8_t> &bytes = slot ? d_bytes2 : d_bytes;
+    AASR_HIP(hipEventRecord(ev_start[slot], s_compute));
+    if (F > 0) {
+      // growing a buffer frees the old one: nothing may still be reading it
+      if ((size_t)ub.pcm_off.back() > d_pcm.n || (size_t)F * dim > d_fea.n || nb > bytes.n)
+        AASR_HIP(hipDeviceSynchronize());
+      d_pcm.ensure((size_t)ub.pcm_off.back());
+      for (size_t k = 0; k < jobs.size(); k++)
+        AASR_HIP(hipMemcpyAsync(d_pcm.p + ub.pcm_off[k], jobs[k]->pcm.data(), jobs[k]->pcm.size() * sizeof(int16_t),
+                                hipMemcpyHostToDevice, s_compute));
+      d_fea.ensure((size_t)F * dim);
+      const int64_t pitch = gmm_score_pitch_ok(gmm) ? (S + 31) / 32 * 32 : S;
+      if ((size_t)F * pitch > d_ll.n) AASR_HIP(hipDeviceSynchronize());
+      d_ll.ensure((size_t)F * pitch);
+      bytes.ensure(nb);
+      feat_run_batch(feat, d_pcm.p, ub, (int)feat->mods.size() - 1, d_fea.p, nullptr, s_compute);
+      gmm_score_launch_pitched(gmm, d_fea.p, F, d_ll.p, pitch, s_compute);
+      lna_encode_launch(d_ll.p, F, (int)S, normalize, lnabytes, nullptr, bytes.p, s_compute, pitch);
+    }
+    AASR_HIP(hipEventRecord(ev_kernels[slot], s_compute));
+    AASR_HIP(hipStreamWaitEvent(s_copy, ev_kernels[slot], 0));
+    if (nb) AASR_HIP(hipMemcpyAsync(dst, bytes.p, nb, hipMemcpyDeviceToHost, s_copy));
+    AASR_HIP(hipEventRecord(ev_copied[slot], s_copy));
+  }
+  void finish(int slot) {
+    AASR_HIP(hipEventSynchronize(ev_copied[slot]));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ev_start[slot], ev_kernels[slot]) == hipSuccess) device_seconds += ms * 1e-3;
+    if (hipEventElapsedTime(&ms, ev_kernels[slot], ev_copied[slot]) == hipSuccess) copy_seconds += ms * 1e-3;
+  }
 
   // features + scoring + LNA for a block of jobs; the packed rows [sum count][S*lnabytes]
   // go to `dst` (a pinned buffer of the recipe runner) or, when null, to h_bytes
@@ -374,10 +460,33 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
   if (!out_dir.empty() && out_dir.back() != '/') out_dir += "/";
 
   double t_start = now_s();
-  BlockRunner br{feat, gmm, opt.lnabytes, opt.normalize};
+  // Device buffers, the two streams and the pinned result slots live on the model handle: a second
+  // recipe through the same handle (the bench's passes, a server) pays for none of them again --
+  // pinning 2 x 0.25 GB alone is ~0.15 s.
+  struct RecipeScratch {
+    BlockRunner br;
+    uint8_t *pinned[2] = {nullptr, nullptr};
+    size_t pinned_cap = 0;
+    ~RecipeScratch() {
+      for (int i = 0; i < 2; i++)
+        if (pinned[i]) (void)hipHostFree(pinned[i]);
+    }
+  };
+  std::shared_ptr<RecipeScratch> scratch = std::static_pointer_cast<RecipeScratch>(gmm->recipe_scratch);
+  if (!scratch) {
+    scratch = std::make_shared<RecipeScratch>();
+    gmm->recipe_scratch = scratch;
+  }
+  BlockRunner &br = scratch->br;
+  br.feat = feat;
+  br.gmm = gmm;
+  br.lnabytes = opt.lnabytes;
+  br.normalize = opt.normalize;
+  br.device_seconds = br.copy_seconds = 0;
   const int64_t S = gmm->S;
-  // frames per device block: bounded by the [F x S] float + byte buffers (~2 GiB)
-  const int64_t block_frames = std::max<int64_t>(4096, (int64_t)(2.0e9 / (double)(S * (4 + opt.lnabytes))));
+  // frames per device block: ~0.75 GB of state scores + codes (40 000 frames at S = 3125: five
+  // rounds of the scoring grid; the pinned result slots stay at 0.25 GB each)
+  const int64_t block_frames = std::max<int64_t>(4096, (int64_t)(0.75e9 / (double)(S * (4 + opt.lnabytes))));
 
   // Three stages: a reader thread (recipe order: skip checks, audio files, frame ranges), this
   // thread (speaker settings, device blocks) and a pool of writer threads (LNA files), so file IO
@@ -413,15 +522,8 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
     bool slot_busy[2] = {false, false};
     std::exception_ptr error;
   } outq;
-  uint8_t *pinned[2] = {nullptr, nullptr};
-  size_t pinned_cap = 0;
-  struct PinnedFree {
-    uint8_t **p;
-    ~PinnedFree() {
-      for (int i = 0; i < 2; i++)
-        if (p[i]) (void)hipHostFree(p[i]);
-    }
-  } pinned_free{pinned};
+  uint8_t *(&pinned)[2] = scratch->pinned;
+  size_t &pinned_cap = scratch->pinned_cap;
 
   // The reader only looks at the base module (mods[0]: sample rate, byte order, window, frame
   // rate); set_parameters is a no-op for audiofile / pre (FeatureModule::set_parameters,
@@ -483,7 +585,7 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
     inq.cv.notify_all();
   });
 
-  int n_writers = 8;
+  int n_writers = 16;  // measured on a 16-CPU quota: 8 -> 5.2, 12 -> 5.9, 16 -> 6.5, 24 -> 6.9 M frames/s (fresh files, tmpfs)
   if (const char *e = getenv("AASR_WRITER_THREADS")) n_writers = std::max(1, std::min(64, atoi(e)));
   auto writer_main = [&] {
     for (;;) {
@@ -525,11 +627,49 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
   int next_slot = 0;
   std::exception_ptr failure;
 
+  // AASR_RECIPE_TIMING=1: where the calling thread's time goes (stderr, one line per run)
+  double t_wait_reader = 0, t_wait_slot = 0, t_launch = 0, t_finish = 0;
+  int inflight_slot = -1;
+  std::vector<Job> inflight_jobs;
+  auto retire = [&]() {
+    if (inflight_slot < 0) return;
+    const int slot = inflight_slot;
+    inflight_slot = -1;
+    try {
+      const double t0 = now_s();
+      br.finish(slot);
+      t_finish += now_s() - t0;
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(outq.m);
+      outq.slot_busy[slot] = false;
+      throw;
+    }
+    for (Job &j : inflight_jobs) std::vector<int16_t>().swap(j.pcm);
+    {
+      std::lock_guard<std::mutex> lk(outq.m);
+      outq.blocks[slot] = std::move(inflight_jobs);
+      outq.pending[slot] = outq.blocks[slot].size();
+      size_t off = 0;
+      for (size_t k = 0; k < outq.blocks[slot].size(); k++) {
+        WriteTask t;
+        t.slot = slot;
+        t.job = k;
+        t.offset = off;
+        outq.q.push_back(t);
+        off += (size_t)outq.blocks[slot][k].count * S * opt.lnabytes;
+      }
+      if (outq.blocks[slot].empty()) outq.slot_busy[slot] = false;
+    }
+    inflight_jobs.clear();
+    outq.cv.notify_all();
+  };
   auto flush = [&]() {
     if (pending.empty()) return;
     const size_t need = (size_t)pending_frames * S * opt.lnabytes;
     const int slot = next_slot;
     next_slot ^= 1;
+    if (need > pinned_cap) retire();  // growing the result buffers needs both of them idle
+    const double t_slot0 = now_s();
     {
       std::unique_lock<std::mutex> lk(outq.m);
       outq.cv.wait(lk, [&] { return !outq.slot_busy[slot] && (need <= pinned_cap || !outq.slot_busy[slot ^ 1]); });
@@ -547,31 +687,23 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
     }
     std::vector<Job *> jobs;
     for (Job &j : pending) jobs.push_back(&j);
+    t_wait_slot += now_s() - t_slot0;
     try {
-      br.run(jobs, pinned[slot], pinned_cap);
+      const double t0 = now_s();
+      br.launch(jobs, slot, pinned[slot], pinned_cap);
+      t_launch += now_s() - t0;
     } catch (...) {
       std::lock_guard<std::mutex> lk(outq.m);
       outq.slot_busy[slot] = false;
       throw;
     }
-    for (Job &j : pending) std::vector<int16_t>().swap(j.pcm);
-    {
-      std::lock_guard<std::mutex> lk(outq.m);
-      outq.blocks[slot] = std::move(pending);
-      outq.pending[slot] = outq.blocks[slot].size();
-      size_t off = 0;
-      for (size_t k = 0; k < outq.blocks[slot].size(); k++) {
-        WriteTask t;
-        t.slot = slot;
-        t.job = k;
-        t.offset = off;
-        outq.q.push_back(t);
-        off += (size_t)outq.blocks[slot][k].count * S * opt.lnabytes;
-      }
-    }
+    // the block launched before this one has had the device to itself until now: collect it
+    // (its copy overlaps the kernels just enqueued) and hand its utterances to the writers
+    retire();
+    inflight_slot = slot;
+    inflight_jobs = std::move(pending);
     pending.clear();
     pending_frames = 0;
-    outq.cv.notify_all();
   };
 
   // -S: parameters change between utterances; everything queued so far must be
@@ -580,14 +712,20 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
     aasr_spkc *s;
     ~Unhook() { if (s) spkc_set_before_change(s, nullptr); }
   } unhook{opt.speakers};
-  if (opt.speakers) spkc_set_before_change(opt.speakers, flush);
+  // a parameter change must find the device idle: the block in flight still runs with the old ones
+  if (opt.speakers) spkc_set_before_change(opt.speakers, [&]() {
+    flush();
+    retire();
+  });
 
   try {
     for (;;) {
       Item it;
       {
+        const double t0 = now_s();
         std::unique_lock<std::mutex> lk(inq.m);
         inq.cv.wait(lk, [&] { return !inq.q.empty(); });
+        t_wait_reader += now_s() - t0;
         it = std::move(inq.q.front());
         inq.q.pop_front();
         inq.frames -= it.job.count;
@@ -599,6 +737,7 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
         // finish what is queued, then report the original error
         try {
           flush();
+          retire();
         } catch (...) {
         }
         std::rethrow_exception(it.error);
@@ -615,6 +754,7 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
       pending.push_back(std::move(it.job));
     }
     flush();
+    retire();
   } catch (...) {
     failure = std::current_exception();
   }
@@ -634,11 +774,16 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
   for (std::thread &t : writers) t.join();
   if (failure) std::rethrow_exception(failure);
   if (outq.error) std::rethrow_exception(outq.error);
+  if (getenv("AASR_RECIPE_TIMING"))
+    fprintf(stderr, "recipe timing: total %.3f s; calling thread waited %.3f s for the reader, %.3f s for a result "
+            "slot (pinned allocation, writers), %.3f s enqueueing blocks (incl. pageable uploads), %.3f s for copies\n",
+            now_s() - t_start, t_wait_reader, t_wait_slot, t_launch, t_finish);
   if (stats) {
     stats->utterances = total_utts;
     stats->frames = total_frames;
     stats->seconds_total = now_s() - t_start;
     stats->seconds_device = br.device_seconds;
+    stats->seconds_copy_out = br.copy_seconds;
   }
 }
 

@@ -242,9 +242,8 @@ def run_recipe_workload(args, capi, synth, shard, gmm, world, rank, n_utts, step
     in_bytes = int(lengths[first:first + count].sum()) * 2
     own = workdir is None
     if own:
-        workdir = _recipe_dir(args, out_bytes + in_bytes)
+        workdir = _recipe_dir(args, out_bytes * (steps + warmup) + in_bytes)
     try:
-        os.makedirs(os.path.join(workdir, "lna"), exist_ok=True)
         write_recipe_inputs(workdir, lengths, first, count)
         # every rank holds the WHOLE recipe text and lets Recipe::read's -B/-I rule pick its slice,
         # exactly what N reference processes would do (missing files of other slices are never opened)
@@ -252,23 +251,31 @@ def run_recipe_workload(args, capi, synth, shard, gmm, world, rank, n_utts, step
         with open(recipe, "w") as f:
             for i in range(n_utts):
                 f.write("audio=%s lna=u%05d.lna\n" % (os.path.join(workdir, "u%05d.wav" % i), i))
-        outdir = os.path.join(workdir, "lna")
+        # every pass writes NEW files into its own directory, as a recipe run does (replacing
+        # existing files is a different and much slower file-system path: the old pages are freed
+        # under the rename -- measured 10 GB/s whatever the thread count against 58 GB/s for fresh
+        # files from 8 threads on the same tmpfs, tools/exp_tmpfs.py)
+        passes = [0]
 
         def one():
+            outdir = os.path.join(workdir, "lna", "pass%d" % passes[0])
+            passes[0] += 1
+            os.makedirs(outdir, exist_ok=True)
             return capi.run_recipe(feat, gmm, recipe, lnabytes=2, out_dir=outdir,
                                    num_batches=world if world > 1 else 0, batch_index=rank + 1 if world > 1 else 0)
         for _ in range(warmup):
             one()
         sync_all()
         t0 = time.perf_counter()
-        dev_s = 0.0
+        dev_s = copy_s = 0.0
         for _ in range(steps):
             st = one()
             dev_s += st.seconds_device
+            copy_s += st.seconds_copy_out
         sync_all()
         wall = time.perf_counter() - t0
         assert st.frames == my_frames and st.utterances == count, (st.frames, my_frames, st.utterances, count)
-        return {"frames": my_frames, "utterances": count, "wall_s": wall, "device_s": dev_s, "steps": steps,
+        return {"frames": my_frames, "utterances": count, "wall_s": wall, "device_s": dev_s, "copy_s": copy_s, "steps": steps,
                 "dir": os.path.dirname(workdir) if own else workdir, "lna_bytes_per_step": out_bytes,
                 "audio_bytes_per_step": in_bytes}
     finally:
@@ -380,6 +387,7 @@ def main():
                                 "frames_per_s_device_only": round(total_frames * args.steps / max(dev_max, 1e-9), 1),
                                 "wall_s_per_step": round(elapsed / args.steps, 4),
                                 "device_s_per_step_slowest_rank": round(dev_max / args.steps, 4),
+                                "pcie_copy_out_s_per_step_rank0": round(res["copy_s"] / args.steps, 4),
                                 "lna_GB_written_per_step_rank0": round(res["lna_bytes_per_step"] / 1e9, 3)}}
         feat_runner = None
 

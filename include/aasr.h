@@ -431,7 +431,8 @@ typedef struct aasr_run_stats {
   int64_t utterances;
   int64_t frames;
   double seconds_total;
-  double seconds_device;   /* feature + scoring + LNA kernels */
+  double seconds_device;   /* input upload + feature + scoring + LNA kernels (device events) */
+  double seconds_copy_out; /* packed rows device -> host; overlaps the next block's kernels */
 } aasr_run_stats;
 
 /* phone_probs main loop (aku/phone_probs.cc:145-267) for one recipe slice on
