@@ -118,6 +118,9 @@ def _declare(L: C.CDLL) -> None:
     L.aasr_gmm_expanded_rows.restype = i64
     L.aasr_gmm_write_cache.argtypes = [vp, cp]
     L.aasr_gmm_create_from_cache.argtypes = [cp, C.POINTER(vp)]
+    L.aasr_gmm_score_scratch_floats.argtypes = [vp, i64]
+    L.aasr_gmm_score_scratch_floats.restype = i64
+    L.aasr_gmm_score_lna_dev.argtypes = [vp, vp, i64, C.c_int, C.c_int, vp, vp, vp]
     L.aasr_gmm_create_from_cache_checked.argtypes = [cp, cp, cp, cp, C.POINTER(vp)]
     L.aasr_recipe_frame_limits.argtypes = [C.c_float, C.c_float, C.c_float, C.POINTER(i32), C.POINTER(i32)]
     L.aasr_recipe_frame_limits.restype = None
@@ -351,6 +354,14 @@ class Gmm:
     def score_dev(self, d_frames, d_out, stream=None) -> None:
         check(lib().aasr_gmm_score_dev(self._h, _ptr(d_frames), d_frames.shape[0], _ptr(d_out),
                                        _stream_handle(stream)))
+
+    def score_scratch_floats(self, F: int) -> int:
+        return lib().aasr_gmm_score_scratch_floats(self._h, F)
+
+    def score_lna_dev(self, d_frames, d_scratch, d_bytes, normalize: bool = True, lnabytes: int = 2, stream=None) -> None:
+        """Frames (device) -> packed LNA rows (device) through the engine's own intermediate layout."""
+        check(lib().aasr_gmm_score_lna_dev(self._h, d_frames.data_ptr(), d_frames.shape[0], int(normalize), lnabytes,
+                                           d_scratch.data_ptr(), d_bytes.data_ptr(), _stream_handle(stream)))
 
     def score_pitch_ok(self) -> bool:
         """Whether score_dev_pitched accepts a row pitch other than the state count."""

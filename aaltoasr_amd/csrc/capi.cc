@@ -361,6 +361,26 @@ aasr_status aasr_gmm_gauss_loglik(aasr_gmm *h, const float *frames, int64_t F,
 
 // ---------------------------------------------------------------- LNA -----
 
+int64_t aasr_gmm_score_scratch_floats(const aasr_gmm *h, int64_t F) {
+  if (!h || F < 0) return -1;
+  const int64_t pitch = gmm_score_pitch_ok(h) ? (h->S + 31) / 32 * 32 : h->S;
+  return F * pitch;
+}
+
+aasr_status aasr_gmm_score_lna_dev(aasr_gmm *h, const float *d_frames, int64_t F, int normalize, int lnabytes,
+                                   float *d_scratch, uint8_t *d_bytes_out, void *stream) {
+  return guarded([&] {
+    if (!h || (F > 0 && (!d_frames || !d_scratch || !d_bytes_out)))
+      raise(AASR_ERR_INVALID, "aasr_gmm_score_lna_dev: null argument");
+    if (lnabytes != 2 && lnabytes != 4) raise(AASR_ERR_INVALID, "lnabytes must be 2 or 4, got %d", lnabytes);
+    if (F <= 0) return;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t pitch = gmm_score_pitch_ok(h) ? (h->S + 31) / 32 * 32 : h->S;
+    gmm_score_launch_pitched(h, d_frames, F, d_scratch, pitch, st);
+    lna_encode_launch(d_scratch, F, (int)h->S, normalize, lnabytes, nullptr, d_bytes_out, st, pitch);
+  });
+}
+
 aasr_status aasr_lna_encode_dev(const float *d_state_loglik, int64_t F, int32_t S,
                                 int normalize, int lnabytes, float *d_lp_out,
                                 uint8_t *d_bytes_out, void *stream) {

@@ -316,6 +316,14 @@ aasr_status aasr_lna_encode_dev(const float *d_state_loglik, int64_t F,
                                 int32_t S, int normalize, int lnabytes,
                                 float *d_lp_out, uint8_t *d_bytes_out,
                                 void *stream);
+/* Frames straight to LNA codes on the device: aasr_gmm_score_dev followed by
+ * aasr_lna_encode_dev, except that the engine may keep the state scores in its
+ * own layout in between (rows padded to whole cache lines).  d_scratch takes aasr_gmm_score_scratch_floats(h, F) floats,
+ * d_bytes_out F * num_states * lnabytes bytes.  What the recipe driver runs per block. */
+int64_t aasr_gmm_score_scratch_floats(const aasr_gmm *h, int64_t F);
+aasr_status aasr_gmm_score_lna_dev(aasr_gmm *h, const float *d_frames, int64_t F, int normalize, int lnabytes,
+                                   float *d_scratch, uint8_t *d_bytes_out, void *stream);
+
 /* 5-byte file header: big-endian uint32 S + 1 byte lnabytes
  * (aku/phone_probs.cc:32-43, 213-214) */
 void aasr_lna_header(int32_t num_states, int lnabytes, uint8_t out[5]);

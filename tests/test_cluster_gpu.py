@@ -195,3 +195,42 @@ def test_clustering_errors(capi, tmp_path):
     assert gm.num_clusters == 0
     frames = synth.make_frames(10, D=8)
     assert np.isfinite(gm.score(frames)).all()
+
+
+@pytest.mark.parametrize("S,comps,G,C,nbytes", [(64, 16, 1024, 32, 2), (300, 9, 2700, 120, 4), (3125, 4, 12500, 500, 2)])
+def test_clustered_scoring_to_lna(capi, oracle, golden_dir, S, comps, G, C, nbytes):
+    """Clustered scoring for LNA consumers (run_utterance / the recipe driver / aasr_gmm_score_lna_dev)
+    against the oracle's clustered phone_probs (codes within one step, log-probabilities within
+    1e-4), incl. the register-resident packing instances for S = 64, 300 and 3125."""
+    import os
+    cfg = open(os.path.join(golden_dir, "mfcc_cms_norm.feaconf")).read()
+    model = synth.make_model(D=39, G=G, S=S, comps=comps, seed=S)
+    g2c = synth.make_clustering(model[0], C, iters=2)
+    pairs = _pairs(g2c)
+    ft = capi.Feat(cfg)
+    gm = capi.Gmm.from_arrays(*model)
+    gm.set_clustering(C, pairs)
+    gm.set_clustering_min_evals(0.0, 0.2)
+    pcm = synth.make_audio(20000 + 7 * S, seed=S + 1)
+    fused, n = capi.run_utterance(ft, gm, pcm, lnabytes=nbytes)
+    import torch
+    d_fea = torch.from_numpy(ft.run(pcm, 0, n)).cuda()
+    d_scr = torch.empty(gm.score_scratch_floats(n), dtype=torch.float32, device="cuda")
+    d_by = torch.empty((n, S * nbytes), dtype=torch.uint8, device="cuda")
+    gm.score_lna_dev(d_fea, d_scr, d_by, True, nbytes)
+    torch.cuda.synchronize()
+    assert d_by.cpu().numpy().tobytes() == fused[5:]
+    ch = oracle.FeatureChain(cfg)
+    om = oracle.DiagModel(*model)
+    om.set_clustering(C, pairs, 0.0, 0.2)
+    ll = om.score_clustered(ch.generate(pcm, 0, n))
+    lp_ref, by_ref = oracle.lna_encode(np.maximum(np.exp(ll), 1e-50), True, nbytes)
+    body = np.frombuffer(fused[5:], np.uint8).reshape(n, -1)
+    if nbytes == 4:
+        smooth = (ll > -87.0) | (ll < -104.5)
+        assert np.abs(body.view("<f4") - lp_ref)[smooth].max() <= 1e-4
+    else:
+        a = body.reshape(n, S, 2).astype(int)
+        b = np.asarray(by_ref).reshape(n, S, 2).astype(int)
+        d = np.abs((a[..., 0] * 256 + a[..., 1]) - (b[..., 0] * 256 + b[..., 1]))
+        assert d.max() <= 1 and (d == 0).mean() > 0.99
