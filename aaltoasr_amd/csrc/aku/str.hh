@@ -18,7 +18,7 @@ inline std::string fmt(size_t size, const char *f, ...) {
   std::vector<char> buf(size + 1);
   va_list ap;
   va_start(ap, f);
-  vsnprintf(buf.data(), size, f, ap);
+  vsnprintf(buf.data(), buf.size(), f, ap);
   va_end(ap);
   return std::string(buf.data());
 }

@@ -285,6 +285,7 @@ void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
                         const int32_t *gauss_index, const int32_t *cluster_index);
 void gmm_read_clustering(aasr_gmm *g, const char *path);
 void gmm_set_clustering_min_evals(aasr_gmm *g, double min_clusters, double min_gaussians);
+const float *gmm_adapted_frames(aasr_gmm *g, const float *d_frames, int64_t F, hipStream_t stream);
 void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                               hipStream_t stream);
 void gmm_tracks_masked_launch(aasr_gmm *g, int which, const float *d_frames, int64_t F,

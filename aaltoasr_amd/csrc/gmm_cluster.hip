@@ -601,9 +601,9 @@ void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
     return;
   }
   const HostModel &m = g->host;
-  if (m.factor_path() || m.n_transforms > 0)
+  if (m.any_full() || (m.n_transforms > 0 && !m.global_xform()))
     raise(AASR_ERR_UNSUPPORTED,
-          "Gaussian clustering is built for diagonal, unadapted pools only");
+          "Gaussian clustering is built for diagonal pools, unadapted or under one global CMLLR transform");
   if (n_clusters > 0.3 * (double)m.G)
     raise(AASR_ERR_INVALID,
           "PDFPool::read_clustering(): Number of clusters (%d) seems insensible compared to the "
@@ -823,8 +823,16 @@ static void launch_merge_t(aasr_gmm *g, float *d_out, int64_t F, hipStream_t str
 void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                               hipStream_t stream) {
   ClusterState &cl = g->cl;
-  if (g->host.factor_path() || g->xf_a.p)
-    raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering is built for diagonal, unadapted pools only");
+  if (g->host.factor_path() || g->class_routing)
+    raise(AASR_ERR_UNSUPPORTED,
+          "Gaussian clustering is built for diagonal pools, unadapted or under one global CMLLR transform "
+          "(per-class transforms are not)");
+  // One global constrained-MLLR transform: the pool's Gaussians are AdaptedGaussians -- members are
+  // evaluated on A f + b and scaled by |det| (the track kernels' output bias) -- while the cluster
+  // centres are plain Gaussians on the frame itself (aku/ModelModules.hh:164-173,
+  // aku/Distributions.cc:2688-2691): the centre kernel gets the frames, the masked scoring kernel
+  // the adapted ones.
+  const float *d_members = g->xf_a.p ? gmm_adapted_frames(g, d_frames, F, stream) : d_frames;
   if (g->ill_conditioned)
     raise(AASR_ERR_UNSUPPORTED,
           "Gaussian clustering is not built for models that need the centred kernel (kappa %.0f)",
@@ -865,6 +873,7 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
   for (int64_t f0 = 0; f0 < F; f0 += cl.Fc) {
     const int64_t n = std::min<int64_t>(cl.Fc, F - f0);
     const float *fr = d_frames + f0 * g->dim;
+    const float *fr_members = d_members + f0 * g->dim;
     float *out = d_out + f0 * g->S;
     for (int64_t s0 = 0; s0 < n; s0 += cl.Fs) {
       const int64_t ns = std::min<int64_t>(cl.Fs, n - s0);
@@ -881,7 +890,7 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
                          cl.maskrow.p);
     }
     AASR_HIP(hipGetLastError());
-    gmm_tracks_masked_launch(g, which, fr, n, out, cl.maskrow.p, stream);
+    gmm_tracks_masked_launch(g, which, fr_members, n, out, cl.maskrow.p, stream);
     if (cl.nnz <= 8) launch_merge_t<8>(g, out, n, stream);
     else launch_merge_t<16>(g, out, n, stream);   // weights beyond 16 per state come from L2
   }

@@ -1677,6 +1677,17 @@ extern "C" int aasr_debug_score_occupancy(void) {
 // masks applied and no 1e-50 floor (k_cluster_merge adds the centre terms and
 // floors).
 // which == 0: grouped layout, 1: independent tracks (gmm_cluster_layout()).
+// A f + b for every frame under the model's global transform (into the handle's scratch)
+const float *gmm_adapted_frames(aasr_gmm *g, const float *d_frames, int64_t F, hipStream_t stream) {
+  if (!g->xf_a.p) return d_frames;
+  g->d_xframes.ensure((size_t)F * g->dim);
+  const int64_t n = F * g->dim;
+  hipLaunchKernelGGL(k_affine_frames, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_frames, F, g->dim,
+                     g->xf_a.p, g->xf_b.p, g->d_xframes.p);
+  AASR_HIP(hipGetLastError());
+  return g->d_xframes.p;
+}
+
 void gmm_tracks_masked_launch(aasr_gmm *g, int which, const float *d_frames, int64_t F,
                               float *d_out, const unsigned long long *maskrow,
                               hipStream_t stream) {

@@ -315,8 +315,6 @@ static void load_transforms(aasr_spkc *h) {
         h->device_adapted = false;
       }
     } else {
-      if (g->cl.loaded)
-        raise(AASR_ERR_UNSUPPORTED, "model-side CMLLR together with Gaussian clustering is not built");
       const int dim = g->dim;
       std::vector<int32_t> g2t((size_t)g->G, -1);
       std::vector<double> W;
@@ -327,6 +325,13 @@ static void load_transforms(aasr_spkc *h) {
         for (int32_t gi : gs) g2t[(size_t)gi] = t;
         W.insert(W.end(), kv.second.begin(), kv.second.end());
         t++;
+      }
+      if (g->cl.loaded) {
+        bool global = t == 1;
+        for (size_t gi = 0; gi < g2t.size() && global; gi++) global = g2t[gi] == 0;
+        if (!global)
+          raise(AASR_ERR_UNSUPPORTED, "per-class model-side CMLLR together with Gaussian clustering is not built "
+                                      "(one global transform is)");
       }
       note_change(h);
       (void)dim;

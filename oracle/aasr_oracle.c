@@ -255,6 +255,16 @@ static void orc_heap_pop(orc_clpair *h, int n) /* n = size before the pop */
  * until BOTH min_clusters clusters and min_gaussians Gaussians (cluster sizes,
  * duplicates included) have been done; members of the rest get the centre's
  * likelihood.  n_exact (optional) returns how many clusters were evaluated. */
+static void orc_pool_likelihoods_clustered_x(int dim, int64_t G, const double *mean,
+                                    const double *prec, const double *cst,
+                                    int C, const int32_t *cl_off,
+                                    const int32_t *cl_members,
+                                    const double *c_mean, const double *c_prec,
+                                    const double *c_cst, int min_clusters,
+                                    int min_gaussians, const double *frame,
+                                    const double *member_frame, double member_scale,
+                                    double *gauss_lik, int32_t *n_exact);
+
 void orc_pool_likelihoods_clustered(int dim, int64_t G, const double *mean,
                                     const double *prec, const double *cst,
                                     int C, const int32_t *cl_off,
@@ -262,6 +272,26 @@ void orc_pool_likelihoods_clustered(int dim, int64_t G, const double *mean,
                                     const double *c_mean, const double *c_prec,
                                     const double *c_cst, int min_clusters,
                                     int min_gaussians, const double *frame,
+                                    double *gauss_lik, int32_t *n_exact)
+{
+    orc_pool_likelihoods_clustered_x(dim, G, mean, prec, cst, C, cl_off, cl_members, c_mean,
+                                     c_prec, c_cst, min_clusters, min_gaussians, frame, frame,
+                                     1.0, gauss_lik, n_exact);
+}
+
+/* The same with model-side constrained MLLR in place (ConstrainedMllr::AdaptedGaussian,
+ * aku/ModelModules.hh:164-173): the pool's Gaussians are wrapped, so a member is evaluated on
+ * the adapted vector A f + b and multiplied by |det| (member_frame, member_scale), while the
+ * cluster centres are plain Gaussians evaluated on the frame itself
+ * (aku/Distributions.cc:2688-2691). */
+static void orc_pool_likelihoods_clustered_x(int dim, int64_t G, const double *mean,
+                                    const double *prec, const double *cst,
+                                    int C, const int32_t *cl_off,
+                                    const int32_t *cl_members,
+                                    const double *c_mean, const double *c_prec,
+                                    const double *c_cst, int min_clusters,
+                                    int min_gaussians, const double *frame,
+                                    const double *member_frame, double member_scale,
                                     double *gauss_lik, int32_t *n_exact)
 {
     orc_clpair *heap = (orc_clpair *)malloc(sizeof(orc_clpair) * (size_t)(C > 0 ? C : 1));
@@ -282,8 +312,8 @@ void orc_pool_likelihoods_clustered(int dim, int64_t G, const double *mean,
         int c = heap[0].idx;
         for (int32_t j = cl_off[c]; j < cl_off[c + 1]; j++) {
             int64_t g = cl_members[j];
-            gauss_lik[g] = exp(orc_diag_loglik(dim, frame, mean + g * dim,
-                                               prec + g * dim, cst[g]));
+            gauss_lik[g] = exp(orc_diag_loglik(dim, member_frame, mean + g * dim,
+                                               prec + g * dim, cst[g])) * member_scale;
         }
         clusters_done++;
         gauss_done += cl_off[c + 1] - cl_off[c];
@@ -302,8 +332,47 @@ void orc_pool_likelihoods_clustered(int dim, int64_t G, const double *mean,
     free(heap);
     for (int64_t g = 0; g < G; g++)
         if (!(gauss_lik[g] > 0))
-            gauss_lik[g] = exp(orc_diag_loglik(dim, frame, mean + g * dim,
-                                               prec + g * dim, cst[g]));
+            gauss_lik[g] = exp(orc_diag_loglik(dim, member_frame, mean + g * dim,
+                                               prec + g * dim, cst[g])) * member_scale;
+}
+
+/* orc_score_frames_clustered with one global transform [b | A] (row-major dim x (dim+1)):
+ * AdaptedFeatureVector::calculate_new_ada_vector (aku/ModelModules.hh:208-212) o = b + A f,
+ * determinant = |product of A's diagonal| (full_matrix_determinant, aku/LinearAlgebra.cc:73-86). */
+void orc_score_frames_clustered_adapted(int dim, int64_t G, const double *mean,
+                                const double *prec, const double *cst,
+                                int64_t S, const int32_t *mix_off,
+                                const int32_t *mix_idx, const double *mix_w,
+                                int C, const int32_t *cl_off,
+                                const int32_t *cl_members, const double *c_mean,
+                                const double *c_prec, const double *c_cst,
+                                int min_clusters, int min_gaussians, const double *W, int64_t F,
+                                const double *frames, double *scratch,
+                                double *out_loglik, int32_t *n_exact)
+{
+    double *slik = (double *)malloc(sizeof(double) * (size_t)S);
+    double *xf = (double *)malloc(sizeof(double) * (size_t)dim);
+    double det = 1;
+    for (int i = 0; i < dim; i++)
+        det *= W[(size_t)i * (dim + 1) + 1 + i];
+    det = fabs(det);
+    for (int64_t f = 0; f < F; f++) {
+        for (int i = 0; i < dim; i++) {
+            double acc = W[(size_t)i * (dim + 1)];
+            for (int j = 0; j < dim; j++)
+                acc += W[(size_t)i * (dim + 1) + 1 + j] * frames[f * dim + j];
+            xf[i] = acc;
+        }
+        orc_pool_likelihoods_clustered_x(dim, G, mean, prec, cst, C, cl_off, cl_members, c_mean,
+                                         c_prec, c_cst, min_clusters, min_gaussians,
+                                         frames + f * dim, xf, det, scratch,
+                                         n_exact ? n_exact + f : NULL);
+        orc_state_likelihoods(S, mix_off, mix_idx, mix_w, scratch, slik);
+        for (int64_t s = 0; s < S; s++)
+            out_loglik[f * S + s] = log(slik[s]);
+    }
+    free(xf);
+    free(slik);
 }
 
 /* orc_score_frames with the clustered pool evaluation. */

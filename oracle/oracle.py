@@ -722,6 +722,30 @@ class DiagModel:
             _p(scratch, pd), _p(out, pd), _p(counts, pi))
         return (out, counts) if want_counts else out
 
+    def score_clustered_adapted(self, frames: np.ndarray, W: np.ndarray, want_counts: bool = False):
+        """score_clustered with one global constrained-MLLR transform W = [b | A] on the pool
+        (AdaptedGaussian members, plain cluster centres)."""
+        frames = np.ascontiguousarray(frames, np.float64)
+        W = np.ascontiguousarray(W, np.float64)
+        F = frames.shape[0]
+        out = np.empty((F, self.S))
+        scratch = np.empty(self.G)
+        counts = np.zeros(F, np.int32)
+        pd, pi = C.c_double, C.c_int32
+        L = lib()
+        L.orc_score_frames_clustered_adapted.restype = None
+        L.orc_score_frames_clustered_adapted.argtypes = [
+            C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+            C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_score_frames_clustered_adapted(
+            self.D, self.G, self.mean.ctypes.data, self.prec.ctypes.data, self.cst.ctypes.data, self.S,
+            self.mix_off.ctypes.data, self.mix_idx.ctypes.data, self.mix_w.ctypes.data, self.n_clusters,
+            self.cl_off.ctypes.data, self.cl_members.ctypes.data, self.c_mean.ctypes.data, self.c_prec.ctypes.data,
+            self.c_cst.ctypes.data, self.min_clusters, self.min_gaussians, W.ctypes.data, F, frames.ctypes.data,
+            scratch.ctypes.data, out.ctypes.data, counts.ctypes.data)
+        return (out, counts) if want_counts else out
+
     def cpu_baseline(self, frames: np.ndarray) -> float:
         frames = np.ascontiguousarray(frames, np.float64)
         pd = C.c_double

@@ -234,3 +234,46 @@ def test_clustered_scoring_to_lna(capi, oracle, golden_dir, S, comps, G, C, nbyt
         b = np.asarray(by_ref).reshape(n, S, 2).astype(int)
         d = np.abs((a[..., 0] * 256 + a[..., 1]) - (b[..., 0] * 256 + b[..., 1]))
         assert d.max() <= 1 and (d == 0).mean() > 0.99
+
+
+def test_clustering_under_a_global_cmllr_transform(capi, oracle):
+    """phone_probs -C ... -S ... with a UNIT_NO (global) model transform: the pool's Gaussians are
+    AdaptedGaussians -- members evaluated on A f + b and scaled by |prod diag A|
+    (aku/ModelModules.hh:164-173) -- while the cluster centres are plain Gaussians ranked on the
+    frame itself (aku/Distributions.cc:2688-2691).  Scores and per-frame exact counts against the
+    oracle, whichever of clustering / transform is set first; per-class transforms with
+    clustering are refused."""
+    D = 20
+    model = synth.make_model(D=D, G=1200, S=100, comps=12, seed=31)
+    mean, var, off, idx, w = model
+    g2c = synth.make_clustering(mean, 48)
+    pairs = _pairs(g2c)
+    rng = np.random.default_rng(8)
+    A = np.eye(D) * rng.uniform(0.9, 1.1, D) + 0.03 * rng.standard_normal((D, D))
+    b = 0.2 * rng.standard_normal(D)
+    W = np.hstack([b[:, None], A])
+    frames = synth.make_frames(400, D=D, seed=9)
+    om = oracle.DiagModel(mean, var, off, idx, w)
+    om.set_clustering(48, pairs, 0.05, 0.2)
+    want, want_n = om.score_clustered_adapted(frames.astype(np.float64), W, want_counts=True)
+    plain = om.score_clustered(frames.astype(np.float64))
+    assert np.abs(want - plain).max() > 0.05          # the transform matters
+    g2t = np.zeros(1200, np.int32)
+    for order in ("cluster_first", "transform_first"):
+        gm = capi.Gmm.from_arrays(mean, var, off, idx, w)
+        if order == "transform_first":
+            gm.set_cmllr(g2t, W[None])
+        gm.set_clustering(48, pairs)
+        gm.set_clustering_min_evals(0.05, 0.2)
+        if order == "cluster_first":
+            gm.set_cmllr(g2t, W[None])
+        for prec in (0, 3):
+            gm.set_precision(prec)
+            got = gm.score(frames)
+            assert np.array_equal(gm.cluster_exact_counts(len(frames)), want_n), (order, prec)
+            assert np.abs(got - want).max() <= TOL, (order, prec, np.abs(got - want).max())
+        gm.set_cmllr()                                  # back to the unadapted model
+        assert np.abs(gm.score(frames) - plain).max() <= TOL
+        two = np.concatenate([np.zeros(600, np.int32), np.ones(600, np.int32)])
+        with pytest.raises(capi.AasrError, match="per-class model-side CMLLR together with Gaussian clustering"):
+            gm.set_cmllr(two, np.stack([W, W]))

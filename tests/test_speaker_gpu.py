@@ -310,3 +310,42 @@ def test_reference_style_loop_with_speaker_config(capi, oracle, world):
     got = oracle.lna_decode(open(out, "rb").read())
     ok = want > -60
     assert got.shape == want.shape and np.abs(got - want)[ok].max() <= 1e-4
+
+
+def test_speakers_with_gaussian_clustering(capi, oracle, world, tmp_path):
+    """phone_probs -S SPKC -C GCL, the adapted recognition pass of pyrectool (rectool.py:655-666):
+    speakers with a global (UNIT_NO) model transform over a clustered pool, against the oracle's
+    clustered + adapted scoring; a speaker with per-class transforms is refused loudly."""
+    mean, var, off, idx, w = world["model"]
+    g2c = synth.make_clustering(mean, 12)
+    pairs = [(int(g), int(c)) for g, c in enumerate(g2c)]
+    ch = oracle.FeatureChain(CFG)
+    om = oracle.DiagModel(mean, var, off, idx, w)
+    om.set_clustering(12, pairs, 0.0, 0.25)
+    osc = oracle.SpeakerConfig(ch, om)
+    osc.read_text(open(world["spkc"]).read())
+    ft = capi.Feat.from_file(world["cfg"])
+    gm = capi.Gmm.from_files(world["base"] + ".gk", world["base"] + ".mc", world["base"] + ".ph")
+    gm.set_clustering(12, pairs)
+    gm.set_clustering_min_evals(0.0, 0.25)
+    sc = capi.SpeakerConfig(ft, gm)
+    sc.read_file(world["spkc"])
+    lines = []
+    for i, spk in enumerate(["anna", "bert", "anna"]):
+        lines.append("audio=%s lna=c%d.lna speaker=%s" % (world["dir"] / ("a%d.wav" % i), i, spk))
+    recipe = str(tmp_path / "c.recipe")
+    open(recipe, "w").write("\n".join(lines) + "\n")
+    st = capi.run_recipe(ft, gm, recipe, lnabytes=4, normalize=False, out_dir=str(tmp_path), speakers=sc)
+    assert st.utterances == 3
+    for i, spk in enumerate(["anna", "bert", "anna"]):
+        osc.set_speaker(spk)
+        pcm = world["pcms"][i]
+        n = ch.num_frames(len(pcm))
+        fea = ch.generate(pcm, 0, n)
+        assert len(osc.W) == 1 and (np.asarray(osc.g2t) == 0).all()
+        ll = om.score_clustered_adapted(fea, np.asarray(osc.W[0]))
+        got = oracle.lna_decode(open(tmp_path / ("c%d.lna" % i), "rb").read())
+        ok = ll > -85
+        assert ok.mean() > 0.2 and np.abs(got - ll)[ok].max() <= 1e-4, (i, spk)
+    with pytest.raises(capi.AasrError, match="per-class model-side CMLLR together with Gaussian clustering"):
+        sc.set_speaker("carl")
