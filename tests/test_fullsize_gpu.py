@@ -170,3 +170,51 @@ def test_config4_full_covariance_at_workload_size(capi, oracle):
             g.score_dev(d_fr[lo:hi].contiguous(), d_out)
             torch.cuda.synchronize()
             assert torch.equal(d_out, outs[name][lo:hi]), (name, lo, hi)
+
+
+# ---------------------------------------------------------------------------
+# BASELINE configs[1] at its full workload: 1 000 000 frames x 50 000 Gaussians
+# ---------------------------------------------------------------------------
+
+def test_config1_one_million_frames(capi, oracle):
+    """The bench's default workload as a parity test: the whole 10^6-frame block on the device with
+    the default arithmetic (bf16x3, 8-wave kernel, line-padded rows) and with the f32 kernel; the
+    oracle re-scores 64 sampled frames against all 50 000 Gaussians; the two arithmetics agree
+    everywhere; sub-blocks scored alone (incl. one below the 8 192-frame switch to the 4-wave form)
+    give the same bits as inside the big block."""
+    import torch
+    Fm = 1_000_000
+    model = synth.make_model(D=D, G=G, S=S, comps=COMPS)
+    g = capi.Gmm.from_arrays(*model)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234)
+    d_fr = torch.randn((Fm, D), generator=gen, device="cuda", dtype=torch.float32)
+    pitch = 3136
+    outs = {}
+    for name, prec in (("bf16x3", 3), ("f32", 0)):
+        g.set_precision(prec)
+        d_out = torch.empty((Fm, pitch), dtype=torch.float32, device="cuda")
+        g.score_dev_pitched(d_fr, d_out, pitch)
+        torch.cuda.synchronize()
+        outs[name] = d_out
+    rng = np.random.default_rng(6)
+    pick = np.sort(rng.choice(Fm, 64, replace=False))
+    pick[0], pick[-1] = 0, Fm - 1
+    frames = d_fr[pick.tolist()].cpu().numpy()
+    ref = oracle.DiagModel(*model).score(frames.astype(np.float64))
+    for name in outs:
+        got = outs[name][pick.tolist(), :S].cpu().numpy()
+        err = np.abs(got - ref)
+        vis = ref > -103.97
+        assert err[vis].max() <= 1e-4 and err.max() <= 2e-4, (name, err[vis].max(), err.max())
+    # chunked comparison of the two arithmetics (12.5 GB each: never both as one temporary)
+    worst = 0.0
+    for lo in range(0, Fm, 100_000):
+        worst = max(worst, (outs["f32"][lo:lo + 100_000, :S] - outs["bf16x3"][lo:lo + 100_000, :S]).abs().max().item())
+    assert worst <= 2e-4, worst
+    g.set_precision(3)
+    for lo, hi in ((0, 512), (499_999, 500_300), (Fm - 20_000, Fm)):
+        d_sub = torch.empty((hi - lo, pitch), dtype=torch.float32, device="cuda")
+        g.score_dev_pitched(d_fr[lo:hi].contiguous(), d_sub, pitch)
+        torch.cuda.synchronize()
+        assert torch.equal(d_sub[:, :S], outs["bf16x3"][lo:hi, :S]), (lo, hi)
