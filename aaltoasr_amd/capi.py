@@ -153,6 +153,7 @@ def _declare(L: C.CDLL) -> None:
     L.aasr_run_recipe.argtypes = [vp, vp, cp, C.POINTER(RunOptions), C.POINTER(RunStats)]
     L.aasr_run_utterance.argtypes = [vp, vp, vp, i64, i32, i32, C.c_int, C.c_int,
                                      C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(i64), C.POINTER(i64)]
+    L.aasr_lna_read_file.argtypes = [cp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64), C.POINTER(C.POINTER(C.c_float))]
     L.aasr_free.argtypes = [vp]
     L.aasr_free.restype = None
     L.aasr_feat_get_parameters.argtypes = [vp, cp, C.POINTER(C.c_void_p), C.POINTER(i64)]
@@ -578,6 +579,21 @@ def recipe_read_all(text, num_batches: int = 0, batch_index: int = 0, cluster_sp
         rows.append(tuple(f[:7]) + (float(np.float32(float(f[7]))), float(np.float32(float(f[8]))),
                                     int(f[9]), int(f[10]), f[11], f[12]))
     return rows
+
+
+def lna_read_file(path: str):
+    """LnaReaderCircular's view of an LNA file (1-, 2- or 4-byte): (float32 [frames x states], lnabytes)."""
+    out = C.POINTER(C.c_float)()
+    S = C.c_int32()
+    nb = C.c_int32()
+    F = C.c_int64()
+    check(lib().aasr_lna_read_file(path.encode(), C.byref(S), C.byref(nb), C.byref(F), C.byref(out)))
+    try:
+        n = F.value * S.value
+        lp = np.ctypeslib.as_array(out, shape=(max(n, 1),))[:n].copy().reshape(F.value, S.value)
+    finally:
+        lib().aasr_free(out)
+    return lp, nb.value
 
 
 def audio_read(path: str, feat: Optional["Feat"] = None):

@@ -857,6 +857,48 @@ void aasr_recipe_frame_limits(float start_time, float end_time, float frame_rate
   if (end_frame) *end_frame = b;
 }
 
+aasr_status aasr_lna_read_file(const char *path, int32_t *num_states, int32_t *lnabytes, int64_t *frames,
+                               float **log_probs) {
+  return guarded([&] {
+    if (!path || !num_states || !lnabytes || !frames || !log_probs)
+      raise(AASR_ERR_INVALID, "aasr_lna_read_file: null argument");
+    FILE *f = fopen(path, "rb");
+    if (!f) raise(AASR_ERR_IO, "aasr_lna_read_file: could not open %s", path);
+    unsigned char head[5];
+    if (fread(head, 1, 5, f) != 5) {
+      fclose(f);
+      raise(AASR_ERR_IO, "aasr_lna_read_file: no LNA header in %s", path);
+    }
+    const int64_t S = ((int64_t)head[0] << 24) | (head[1] << 16) | (head[2] << 8) | head[3];
+    const int nb = head[4];
+    if (S <= 0 || S > 0x7fffffff || (nb != 1 && nb != 2 && nb != 4)) {
+      fclose(f);
+      raise(AASR_ERR_INVALID, "aasr_lna_read_file: invalid header in %s", path);
+    }
+    std::vector<unsigned char> raw;
+    std::vector<unsigned char> chunk(1 << 22);
+    size_t got;
+    while ((got = fread(chunk.data(), 1, chunk.size(), f)) > 0) raw.insert(raw.end(), chunk.begin(), chunk.begin() + got);
+    fclose(f);
+    const int64_t F = (int64_t)(raw.size() / (size_t)(S * nb));
+    float *out = (float *)malloc(sizeof(float) * (size_t)std::max<int64_t>(F * S, 1));
+    if (!out) raise(AASR_ERR_INVALID, "aasr_lna_read_file: out of memory");
+    const unsigned char *p = raw.data();
+    const int64_t n = F * S;
+    if (nb == 4) {
+      memcpy(out, p, (size_t)n * 4);  // little-endian floats on a little-endian host
+    } else if (nb == 2) {
+      for (int64_t i = 0; i < n; i++) out[i] = (float)((p[2 * i] * 256 + p[2 * i + 1]) / -1820.0);
+    } else {
+      for (int64_t i = 0; i < n; i++) out[i] = (float)(p[i] / -24.0);
+    }
+    *num_states = (int32_t)S;
+    *lnabytes = nb;
+    *frames = F;
+    *log_probs = out;
+  });
+}
+
 aasr_status aasr_recipe_read_all(const char *recipe_text, int32_t num_batches, int32_t batch_index,
                                  int32_t cluster_speakers, char **table_out, int64_t *table_len) {
   return guarded([&] {

@@ -328,6 +328,14 @@ aasr_status aasr_gmm_score_lna_dev(aasr_gmm *h, const float *d_frames, int64_t F
  * (aku/phone_probs.cc:32-43, 213-214) */
 void aasr_lna_header(int32_t num_states, int lnabytes, uint8_t out[5]);
 
+/* Reads an LNA file the way the recogniser's reader does (decoder/src/LnaReaderCircular.cc:
+ * header :63-96, frame decoding :166-198): 4-byte little-endian floats, 2-byte big-endian codes
+ * (code / -1820.0) or the legacy 1-byte codes (code / -24.0) -- phone_probs never writes the
+ * 1-byte form, old acoustic files hold it.  Host only.  A trailing partial frame is dropped, as
+ * the reader's fread does.  *log_probs is malloc'ed [*frames x *num_states]; free with aasr_free. */
+aasr_status aasr_lna_read_file(const char *path, int32_t *num_states, int32_t *lnabytes, int64_t *frames,
+                               float **log_probs);
+
 /* ------------------------------------------------------------------------ */
 /* Recipe + whole-path driver: replaces the body of phone_probs main()       */
 /* ------------------------------------------------------------------------ */

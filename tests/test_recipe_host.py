@@ -143,3 +143,42 @@ def test_recipe_cluster_speakers_and_all_fields(capi, oracle):
                              i.den_hmmnet_path, i.lna_path, i.start_time, i.end_time, i.start_line, i.end_line,
                              i.speaker_id, i.utterance_id) for i in oracle.recipe_read(text, n, b, cl)]
                     assert capi.recipe_read_all(text, n, b, cl) == want, (text, n, b, cl)
+
+
+@pytest.mark.parametrize("nbytes", [1, 2, 4])
+def test_lna_file_reader_matches_the_reference_reader(capi, oracle, tmp_path, nbytes):
+    """aasr_lna_read_file (1-, 2- and 4-byte LNA, decoder/src/LnaReaderCircular.cc:63-96,166-198)
+    against the recogniser's own reader compiled in place (oracle/_ref/liblna_ref.so): every code
+    value of the 1-byte form, random 2-byte codes incl. 0 and 0xFFFF, raw floats; a trailing
+    partial frame is dropped by both."""
+    import numpy as np
+    rng = np.random.default_rng(5 + nbytes)
+    S, F = 37, 41
+    if nbytes == 1:
+        body = (np.arange(F * S) % 256).astype(np.uint8)
+    elif nbytes == 2:
+        codes = rng.integers(0, 65536, F * S).astype(">u2")
+        codes[:3] = (0, 65535, 1)
+        body = codes.view(np.uint8)
+    else:
+        body = rng.uniform(-80, 0, F * S).astype("<f4").view(np.uint8)
+    path = str(tmp_path / "x.lna")
+    with open(path, "wb") as f:
+        f.write(oracle.lna_header(S, nbytes))
+        f.write(body.tobytes())
+        f.write(b"\x07" * (S * nbytes - 1))     # an incomplete last frame
+    lp, nb = capi.lna_read_file(path)
+    assert nb == nbytes and lp.shape == (F, S) and lp.dtype == np.float32
+    if nbytes == 1:
+        assert np.array_equal(lp.ravel(), (body.astype(np.float64) / -24.0).astype(np.float32))
+    if oracle.ref_lna() is not None:
+        ref = oracle.ref_lna_read(path, F + 5, S, buf_size=8, order=0)
+        assert ref.shape == (F, S) and np.array_equal(lp, ref)
+    elif nbytes != 1:
+        assert np.array_equal(lp, oracle.lna_decode(open(path, "rb").read()).astype(np.float32)[:F])
+    with pytest.raises(capi.AasrError):
+        capi.lna_read_file(str(tmp_path / "missing.lna"))
+    bad = str(tmp_path / "bad.lna")
+    open(bad, "wb").write(b"\x00\x00\x00\x05\x03" + b"\x00" * 30)
+    with pytest.raises(capi.AasrError, match="invalid header"):
+        capi.lna_read_file(bad)
