@@ -154,6 +154,7 @@ def _declare(L: C.CDLL) -> None:
     L.aasr_run_utterance.argtypes = [vp, vp, vp, i64, i32, i32, C.c_int, C.c_int,
                                      C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(i64), C.POINTER(i64)]
     L.aasr_lna_read_file.argtypes = [cp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64), C.POINTER(C.POINTER(C.c_float))]
+    L.aasr_audio_decode.argtypes = [vp, vp, i64, C.POINTER(C.POINTER(C.c_int16)), C.POINTER(i64), C.POINTER(i32)]
     L.aasr_free.argtypes = [vp]
     L.aasr_free.restype = None
     L.aasr_feat_get_parameters.argtypes = [vp, cp, C.POINTER(C.c_void_p), C.POINTER(i64)]
@@ -603,6 +604,21 @@ def audio_read(path: str, feat: Optional["Feat"] = None):
     rate = C.c_int32()
     check(lib().aasr_audio_read(feat._h if feat is not None else None, path.encode(), C.byref(out),
                                 C.byref(n), C.byref(rate)))
+    try:
+        pcm = np.ctypeslib.as_array(out, shape=(max(n.value, 1),))[:n.value].copy()
+    finally:
+        lib().aasr_free(out)
+    return pcm, rate.value
+
+
+def audio_decode(data: bytes, feat: Optional["Feat"] = None):
+    """aasr_audio_decode: the file decoding of audio_read for bytes already in memory."""
+    out = C.POINTER(C.c_int16)()
+    n = C.c_int64()
+    rate = C.c_int32()
+    buf = C.create_string_buffer(data, len(data))
+    check(lib().aasr_audio_decode(feat._h if feat is not None else None, C.cast(buf, C.c_void_p), len(data),
+                                  C.byref(out), C.byref(n), C.byref(rate)))
     try:
         pcm = np.ctypeslib.as_array(out, shape=(max(n.value, 1),))[:n.value].copy()
     finally:

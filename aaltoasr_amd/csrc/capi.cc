@@ -483,4 +483,30 @@ aasr_status aasr_audio_read(const aasr_feat *feat, const char *path, int16_t **p
   });
 }
 
+aasr_status aasr_audio_decode(const aasr_feat *feat, const void *data, int64_t n_bytes, int16_t **pcm,
+                              int64_t *n_samples, int32_t *sample_rate) {
+  return guarded([&] {
+    if ((!data && n_bytes > 0) || n_bytes < 0 || !pcm || !n_samples)
+      raise(AASR_ERR_INVALID, "aasr_audio_decode: invalid argument");
+    int rate = 0;
+    const std::vector<char> bytes((const char *)data, (const char *)data + n_bytes);
+    std::vector<int16_t> v;
+    if (feat && feat->mods[0].type == MOD_PRE) {
+      v = decode_input_data(feat, bytes, "(memory)");
+    } else if (feat) {
+      const FeatModule &b = feat->mods[0];
+      if (b.type != MOD_AUDIOFILE) raise(AASR_ERR_INVALID, "aasr_audio_decode: the graph does not start with an audiofile or pre module");
+      v = decode_audio(bytes, "(memory)", b.raw_audio != 0, b.endian == 2, b.sample_rate, &rate);
+    } else {
+      v = decode_audio(bytes, "(memory)", false, false, 0, &rate);
+    }
+    int16_t *out = (int16_t *)malloc(std::max<size_t>(v.size(), 1) * sizeof(int16_t));
+    if (!out) raise(AASR_ERR_INVALID, "aasr_audio_decode: out of memory");
+    if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(int16_t));
+    *pcm = out;
+    *n_samples = (int64_t)v.size();
+    if (sample_rate) *sample_rate = rate;
+  });
+}
+
 }  // extern "C"

@@ -480,6 +480,13 @@ void aasr_free(void *p);
 aasr_status aasr_audio_read(const aasr_feat *feat, const char *path, int16_t **pcm,
                             int64_t *n_samples, int32_t *sample_rate);
 
+/* The same decoding for input already in memory -- what FeatureGenerator::open(FILE*, ...) /
+ * open_fd (aku/FeatureGenerator.cc:54-84) and PPToolbox::generate_to_fd (aku/PhoneProbsToolbox.cc:
+ * 55-82) read from a descriptor.  For graphs that start with a `pre` module the data is a feature
+ * file and *pcm receives the engine's input units for it (see aasr_feat_input_is_features). */
+aasr_status aasr_audio_decode(const aasr_feat *feat, const void *data, int64_t n_bytes, int16_t **pcm,
+                              int64_t *n_samples, int32_t *sample_rate);
+
 #ifdef __cplusplus
 }
 #endif

@@ -343,3 +343,57 @@ def test_distributions_surface(capi, oracle, world):
         assert int(g0) == idx[off[0]] and float(m0) == mean[int(g0), 0] and float(c_last) == var[int(g0), -1]
         assert abs(np.log(float(lik_g0)) - om.gauss_loglik(fea[f:f + 1])[0][int(g0)]) <= 1e-4
         pos += S + 1
+
+
+@pytest.mark.gpu
+def test_python_pptoolbox_module(capi, world, tmp_path):
+    """The reference's SWIG module (aku/swig/PPToolbox.i:57-75) as a Python module on the C ABI:
+    `import PPToolbox` from the package directory, the reference's call sequence, files and
+    descriptors; the LNA image equals the engine's own run_utterance bytes (2-byte, normalised, as
+    aku/PhoneProbsToolbox.cc:84-131 hard-wires -- that path is compared with the oracle in
+    test_pipeline_gpu.py); errors surface as RuntimeError."""
+    import importlib, sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aaltoasr_amd")
+    sys.path.insert(0, pkg)
+    try:
+        PPToolbox = importlib.import_module("PPToolbox")
+    finally:
+        sys.path.remove(pkg)
+    wav = str(world["dir"] / "a1.wav")
+    t = PPToolbox.PPToolbox()
+    with pytest.raises(RuntimeError):
+        t.generate(wav, str(tmp_path / "x.lna"), False)      # nothing loaded yet
+    t.read_configuration(world["cfg"])
+    t.read_models(world["base"])
+    out = str(tmp_path / "a.lna")
+    t.generate(wav, out, False)
+    want, frames = capi.run_utterance(world["ft"], world["gm"], world["pcms"][1], 0, 0, True, 2)
+    assert open(out, "rb").read() == want and frames > 50
+    # descriptors: audio in through one, LNA out through another; neither is closed by the call
+    fd_in = os.open(wav, os.O_RDONLY)
+    out2 = str(tmp_path / "b.lna")
+    fd_out = os.open(out2, os.O_WRONLY | os.O_CREAT, 0o644)
+    try:
+        t.generate_to_fd(fd_in, fd_out, False)
+        os.fstat(fd_in), os.fstat(fd_out)
+    finally:
+        os.close(fd_in)
+        os.close(fd_out)
+    assert open(out2, "rb").read() == want
+    # clustering through the facade (aku/PhoneProbsToolbox.cc:50-53)
+    gcl = str(tmp_path / "c.gcl")
+    from oracle import oracle as O
+    O.write_gcl(gcl, 16, synth.make_clustering(world["model"][0], 16))
+    t.set_clustering(gcl, 0.2, 0.2)
+    t.generate(wav, out, False)
+    g2 = capi.Gmm.from_files(world["base"] + ".gk", world["base"] + ".mc", world["base"] + ".ph")
+    g2.read_clustering(gcl)
+    g2.set_clustering_min_evals(0.2, 0.2)
+    want_c, _ = capi.run_utterance(world["ft"], g2, world["pcms"][1], 0, 0, True, 2)
+    assert open(out, "rb").read() == want_c and want_c != want
+    with pytest.raises(RuntimeError):
+        t.read_models(str(tmp_path / "missing"))
+    with pytest.raises(RuntimeError):
+        t.generate(str(tmp_path / "missing.wav"), out, False)
+    with pytest.raises(RuntimeError):
+        t.read_configuration(str(tmp_path / "missing.cfg"))
