@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cerrno>
 
+#include "../feat.h"
 #include "../pipeline.h"
 #include "FeatureModules.hh"
 
@@ -365,26 +366,65 @@ void FeatureGenerator::open_fd(const int fd, bool) {
   open(file, false, false);
 }
 
-void FeatureGenerator::open(FILE *file, bool dont_fclose, bool) {
+void FeatureGenerator::open(FILE *file, bool dont_fclose, bool stream) {
   if (!m_feat) throw std::string("no feature modules defined");
   if (m_file != nullptr) close();
   m_file = file;
   m_dont_fclose = dont_fclose;
-  std::vector<char> data;
-  char buf[65536];
-  size_t n;
-  while ((n = fread(buf, 1, sizeof buf, file)) > 0) data.insert(data.end(), buf, buf + n);
-  // sf_open_fd on the stream, headerless PCM16 when no container is recognised
-  // (aku/AudioReader.cc:112-142); feature data for `pre` graphs
-  try {
-    m_pcm = aasr::decode_input_data(m_feat, data, "(stream)");
-  } catch (aasr::Error &e) {
-    throw std::string(e.msg);
+  m_streaming = false;
+  m_stream_eof = false;
+  m_pcm.clear();
+  if (stream && !aasr_feat_input_is_features(m_feat)) {
+    // AudioReader::open(FILE*, rate, close, stream = true): no container probing, raw PCM16 from a
+    // non-seekable stream (aku/AudioReader.cc:112-142); samples are fetched as frames are asked for
+    m_streaming = true;
+    m_stream_big_endian = m_feat->mods[0].endian == 2;
+  } else {
+    std::vector<char> data;
+    char buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, file)) > 0) data.insert(data.end(), buf, buf + n);
+    // sf_open_fd on the stream, headerless PCM16 when no container is recognised
+    // (aku/AudioReader.cc:112-142); feature data for `pre` graphs
+    try {
+      m_pcm = aasr::decode_input_data(m_feat, data, "(stream)");
+    } catch (aasr::Error &e) {
+      throw std::string(e.msg);
+    }
   }
   m_open = true;
   m_block_count = 0;
   m_epoch++;
   m_eof_on_last_frame = false;
+}
+
+// stream mode: read until the samples cover frame `frame` and the graph's look-ahead behind it (so
+// that the frame's value is what it would be with the whole file present), or to the stream's end
+void FeatureGenerator::stream_read_until(int frame) {
+  if (!m_streaming || m_stream_eof) return;
+  int halo_l = 0, halo_r = 0;
+  aasr_feat_halo(m_feat, &halo_l, &halo_r);
+  const int64_t want_frame = frame == INT_MAX ? (int64_t)INT_MAX : (int64_t)frame + halo_r + 1;
+  std::vector<unsigned char> raw;
+  while (!m_stream_eof && (want_frame == INT_MAX || aasr_feat_last_frame(m_feat, (int64_t)m_pcm.size()) < want_frame)) {
+    // samples still missing for that frame: one window advance per frame, at least one window
+    int64_t missing = 4096;
+    if (want_frame != INT_MAX) {
+      const double adv = (double)sample_rate() / (double)frame_rate();
+      const int64_t have_frames = std::max(-1, aasr_feat_last_frame(m_feat, (int64_t)m_pcm.size()));
+      missing = std::max<int64_t>(1, (int64_t)((want_frame - have_frames) * adv));
+    }
+    raw.resize((size_t)missing * 2);
+    const size_t got = fread(raw.data(), 2, (size_t)missing, m_file);
+    const size_t at = m_pcm.size();
+    m_pcm.resize(at + got);
+    for (size_t i = 0; i < got; i++) {
+      const unsigned lo = m_stream_big_endian ? raw[2 * i + 1] : raw[2 * i];
+      const unsigned hi = m_stream_big_endian ? raw[2 * i] : raw[2 * i + 1];
+      m_pcm[at + i] = (int16_t)(lo | (hi << 8));
+    }
+    if (got < (size_t)missing) m_stream_eof = true;
+  }
 }
 
 void FeatureGenerator::open_pcm(const int16_t *pcm, int64_t n_samples) {
@@ -402,25 +442,36 @@ void FeatureGenerator::close() {
   if (m_file != nullptr && !m_dont_fclose) fclose(m_file);
   m_file = nullptr;
   m_open = false;
+  m_streaming = false;
+  m_stream_eof = false;
   m_pcm.clear();
   m_block_count = 0;
   m_epoch++;
 }
 
-int FeatureGenerator::last_frame() { return aasr_feat_last_frame(m_feat, (int64_t)m_pcm.size()); }
+int FeatureGenerator::last_frame() {
+  stream_read_until(INT_MAX);  // stream mode: only the stream's end tells
+  return aasr_feat_last_frame(m_feat, (int64_t)m_pcm.size());
+}
 int FeatureGenerator::sample_rate() { return aasr_feat_sample_rate(m_feat); }
 float FeatureGenerator::frame_rate() { return aasr_feat_frame_rate(m_feat); }
 int FeatureGenerator::dim() { return aasr_feat_dim(m_feat); }
 
 void FeatureGenerator::fill_block(int frame) {
   const int d = dim();
-  m_block.resize((size_t)m_block_frames * d);
-  check(aasr_feat_run_f64(m_feat, m_pcm.data(), (int64_t)m_pcm.size(), frame, m_block_frames,
-                          nullptr, m_block.data()));
+  int frames = m_block_frames;
+  if (m_streaming) {
+    if (!m_stream_eof) stream_read_until(frame + m_stream_block_frames - 1);
+    if (!m_stream_eof) frames = m_stream_block_frames;  // the rest of the stream has not arrived yet
+    // AudioFileModule::generate, frame 0 crossing the end (aku/FeatureModules.cc:405-410)
+    if (aasr_feat_last_frame(m_feat, (int64_t)m_pcm.size()) < 0) throw std::string("audio shorter than frame");
+  }
+  m_block.resize((size_t)frames * d);
+  check(aasr_feat_run_f64(m_feat, m_pcm.data(), (int64_t)m_pcm.size(), frame, frames, nullptr, m_block.data()));
   m_block_f32.resize(m_block.size());
   for (size_t i = 0; i < m_block.size(); i++) m_block_f32[i] = (float)m_block[i];
   m_block_first = frame;
-  m_block_count = m_block_frames;
+  m_block_count = frames;
   m_block_serial++;
 }
 
@@ -430,7 +481,8 @@ const FeatureVec FeatureGenerator::generate(int frame) {
     fill_block(frame);
   // AudioFileModule::eof (aku/FeatureModules.cc:297-303): true from the first
   // frame whose window crosses the end of the file, i.e. last_frame()+1
-  m_eof_on_last_frame = frame >= last_frame() + 1;
+  m_eof_on_last_frame = (!m_streaming || m_stream_eof) &&
+                        frame >= aasr_feat_last_frame(m_feat, (int64_t)m_pcm.size()) + 1;
   return FeatureVec(&m_block[(size_t)(frame - m_block_first) * dim()], dim(), frame, this);
 }
 

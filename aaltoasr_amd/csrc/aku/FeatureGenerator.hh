@@ -45,11 +45,17 @@ public:
   /** aku/FeatureGenerator.hh:35, FeatureGenerator.cc:54-66: fdopen + open(file, false, false).
    * (The reference ignores raw_audio here; so does this.) */
   void open_fd(const int fd, bool raw_audio);
-  /** aku/FeatureGenerator.hh:43, FeatureGenerator.cc:69-84.  The stream is read to its end here
-   * (the engine computes whole blocks); with dont_fclose == false the FILE is closed by close(),
-   * as in the reference.  `stream` (decode-stream.cc:81: stdin) is accepted; the audio still is
-   * consumed at open, not incrementally. */
+  /** aku/FeatureGenerator.hh:43, FeatureGenerator.cc:69-84.  With dont_fclose == false the FILE is
+   * closed by close(), as in the reference.  stream == false: the file is read to its end here (the
+   * engine computes whole blocks).  stream == true (decode-stream.cc:81: stdin): headerless 16-bit
+   * samples in the audiofile module's byte order, as AudioReader::open(FILE*, ..., stream) reads a
+   * non-seekable stream (aku/AudioReader.cc:112-142); the samples are read as generate() needs them
+   * -- a block of set_stream_block_frames() frames plus the graph's look-ahead at a time -- so
+   * frames come out while the producer is still writing.  eof() turns true on the same frame as
+   * for a file. */
   void open(FILE *file, bool dont_fclose, bool stream = false);
+  /** frames computed per device pass in stream mode (default 16 = 0.128 s at 125 frames/s) */
+  void set_stream_block_frames(int n) { m_stream_block_frames = n > 0 ? n : 1; }
   /** in-memory audio (new: lets callers hand over samples they already hold) */
   void open_pcm(const int16_t *pcm, int64_t n_samples);
   void close();
@@ -101,6 +107,9 @@ private:
   void fill_block(int frame);
   void build(const std::string &text, bool keep_modules);
   void read_all(FILE *file);
+  void stream_read_until(int frame);
+  bool m_streaming = false, m_stream_eof = false, m_stream_big_endian = false;
+  int m_stream_block_frames = 16;
   FILE *m_file = nullptr;
   bool m_dont_fclose = false;
   aasr_feat *m_feat;

@@ -155,6 +155,34 @@ static int dist_mode(const char *cfg, const char *base, const char *audio, const
 }
 
 int main(int argc, char **argv) {
+  if (argc == 4 && std::string(argv[1]) == "stream") {
+    // aku_adapter_check stream CFG OUT < raw PCM16: decode-stream.cc's reading loop
+    // (decoder/decode-stream.cc:81, 238-276: gen.open(stdin, true, true); generate(f) until eof()).
+    // Each frame goes to OUT as doubles and "frame N" to stdout, both flushed at once, so the test
+    // can see frames arrive while it is still feeding the pipe.
+    aku::FeatureGenerator gen;
+    FILE *cf = fopen(argv[2], "r");
+    if (!cf) throw std::string("could not open config");
+    gen.load_configuration(cf);
+    fclose(cf);
+    gen.open(stdin, true, true);
+    FILE *out = fopen(argv[3], "wb");
+    if (!out) throw std::string("could not open output");
+    for (int f = 0;; f++) {
+      const aku::FeatureVec v = gen.generate(f);
+      if (gen.eof()) break;
+      for (int i = 0; i < v.dim(); i++) {
+        const double x = v[i];
+        fwrite(&x, sizeof x, 1, out);
+      }
+      fflush(out);
+      printf("frame %d\n", f);
+      fflush(stdout);
+    }
+    fclose(out);
+    gen.close();
+    return 0;
+  }
   if (argc == 6 && std::string(argv[1]) == "dist") {
     try {
       return dist_mode(argv[2], argv[3], argv[4], argv[5]);

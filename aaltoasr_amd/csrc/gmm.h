@@ -85,6 +85,11 @@ constexpr int TRACK_MAX_SPLITS = 16;  // row-range cuts available to the launche
 constexpr int CENTRED_MAX_SPLITS = 32;
 // expanded-form error estimate eps * kappa beyond which the centred kernel is used
 constexpr double KAPPA_LIMIT = 600.0;
+// the same estimate taken as a 2-norm over the dimensions: rounding errors of different dimensions add
+// in quadrature, those of one dimension do not, so a model whose kappa sits in one or two dimensions
+// (low-dimensional models above all) reaches the tolerance at a much smaller sum.  Fuzz seed 104
+// iteration 247: D = 1, kappa 416, a frame 12 sigma out (ll = -71.2), 1.18e-4 in the expanded form.
+constexpr double KAPPA2_LIMIT = 200.0;
 
 // Kernel instances exist for these K/2 values; a model uses the smallest one
 // that holds dim+1 (zero-padded beyond).

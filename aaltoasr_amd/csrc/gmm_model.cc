@@ -922,8 +922,8 @@ static int centred_dimp_for(int D) {
   return 0;
 }
 
-// Conditioning of the expanded form, kappa_g = sum_d p (mu - pivot)^2 per Gaussian.  A model
-// whose worst Gaussian exceeds KAPPA_LIMIT is scored entirely in the centred form -- unless the
+// Conditioning of the expanded form, kappa_g = sum_d p (mu - pivot)^2 per Gaussian (and its 2-norm
+// over d, KAPPA2_LIMIT).  A model whose worst Gaussian exceeds a limit is scored entirely in the centred form -- unless the
 // offenders are a minority (at most a quarter of the mixture components): then only they are,
 // over the states that hold them (outlier routing), and the rest keeps the matrix path.
 static void find_outliers(aasr_gmm *g) {
@@ -934,19 +934,22 @@ static void find_outliers(aasr_gmm *g) {
   g->hyb_states = g->hyb_rows = 0;
   std::vector<uint8_t> bad((size_t)m.G, 0);
   double kappa = 0;
+  bool any_bad = false;
   for (int64_t i = 0; i < m.G; i++) {
-    double k = 0;
+    double k = 0, k2 = 0;
     for (int d = 0; d < D; d++) {
       double v = m.var[(size_t)i * D + d];
       double p = v > 0 ? 1 / v : 0;
       double mc = m.mean[(size_t)i * D + d] - (double)g->pivot[d];
       k += p * mc * mc;
+      k2 += (p * mc * mc) * (p * mc * mc);
     }
     kappa = std::max(kappa, k);
-    bad[(size_t)i] = k > KAPPA_LIMIT;
+    bad[(size_t)i] = k > KAPPA_LIMIT || std::sqrt(k2) > KAPPA2_LIMIT;
+    any_bad = any_bad || bad[(size_t)i];
   }
   g->kappa = kappa;
-  g->ill_conditioned = kappa > KAPPA_LIMIT;
+  g->ill_conditioned = any_bad;
   const int dimp = centred_dimp_for(D);
   static const int routing = getenv("AASR_OUTLIER_ROUTING") ? atoi(getenv("AASR_OUTLIER_ROUTING")) : 1;
   if (!g->ill_conditioned || !dimp || !routing || g->cl.loaded) return;

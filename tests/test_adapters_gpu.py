@@ -397,3 +397,50 @@ def test_python_pptoolbox_module(capi, world, tmp_path):
         t.generate(str(tmp_path / "missing.wav"), out, False)
     with pytest.raises(RuntimeError):
         t.read_configuration(str(tmp_path / "missing.cfg"))
+
+
+@pytest.mark.gpu
+def test_stream_input_is_consumed_incrementally(capi, world, tmp_path):
+    """decode-stream.cc's reading loop (gen.open(stdin, true, true); generate(f) until eof(),
+    decoder/decode-stream.cc:81, 238-276) on the adapter: raw PCM16 arrives through a pipe in two
+    parts; frames of the first part come out while the second has not been written yet (the
+    reference's AudioReader reads a non-seekable stream as frames ask for samples,
+    aku/AudioReader.cc:112-142, 170-213), and every frame equals the whole-file result bit for bit,
+    eof() on the same frame."""
+    import select, time
+    pcm = world["pcms"][0]                      # 5 s
+    out = str(tmp_path / "stream.f64")
+    p = subprocess.Popen([os.path.join(BIN, "aku_adapter_check"), "stream", world["cfg"], out],
+                         stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    try:
+        half = 16000 * 2
+        p.stdin.write(pcm[:half].astype("<i2").tobytes())
+        p.stdin.flush()
+        seen = b""
+        deadline = time.time() + 240
+        # frames whose window and look-ahead lie inside the first 2 s must appear without more input
+        while seen.count(b"\n") < 100 and time.time() < deadline:
+            r, _, _ = select.select([p.stdout], [], [], 1.0)
+            if r:
+                chunk = os.read(p.stdout.fileno(), 65536)
+                if not chunk:
+                    break
+                seen += chunk
+        first_part = seen.count(b"\n")
+        assert first_part >= 100, (first_part, p.poll())
+        assert p.poll() is None                 # still waiting for the rest of the stream
+        p.stdin.write(pcm[half:].astype("<i2").tobytes())
+        p.stdin.close()
+        rest, err = p.stdout.read(), p.stderr.read()
+        assert p.wait(timeout=120) == 0, err.decode()
+    finally:
+        if p.poll() is None:
+            p.kill()
+    total = (seen + rest).count(b"\n")
+    ft = world["ft"]
+    last = ft.last_frame(len(pcm))
+    assert total == last + 1                    # eof() turned true on frame last_frame + 1
+    assert first_part < total
+    got = np.fromfile(out, np.float64).reshape(total, ft.dim)
+    want = ft.run(pcm, 0, total, dtype=np.float64)
+    assert np.array_equal(got, want)

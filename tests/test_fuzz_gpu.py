@@ -4,7 +4,9 @@ every random model / feature graph of these seeds must agree with the oracle -- 
 1e-4 wherever the reference's float storage can hold the likelihood (2e-4 below its flush
 point, where the LNA output is the floor whatever the value: tests/test_lna_gpu.py), clustered
 exact-evaluation counts bit for bit, feature modules to the per-module tolerance.  Seed 1 is
-the sweep whose iteration 26 had differing cluster counts in round 1 (tied empty clusters)."""
+the sweep whose iteration 26 had differing cluster counts in round 1 (tied empty clusters); seed
+104 (iterations 0..249) holds the round-2 find: a one-dimensional model with kappa 416 and a frame
+12 sigma out, 1.18e-4 in the expanded form until the 2-norm conditioning limit routed it."""
 import importlib.util
 import os
 
@@ -21,7 +23,7 @@ def _load(name):
     return mod
 
 
-@pytest.mark.parametrize("seed,n", [(1, 40), (7, 25), (20260928, 25)])
+@pytest.mark.parametrize("seed,n", [(1, 40), (7, 25), (20260928, 25), (104, 250)])
 def test_scoring_sweep(capi, oracle, seed, n):
     worst, fails = _load("fuzz_parity").run(seed, n)
     assert not fails, "\n".join(fails)

@@ -7,7 +7,8 @@ A failure is
   * |score - oracle| > 1e-4 on a state whose likelihood the reference's float storage can hold
     (ll > -103.97: aku/phone_probs.cc:224-262 stores (float)exp(ll), which is 0 below that, so
     the LNA output is the floor whatever the value -- tests/test_lna_gpu.py pins that),
-  * |score - oracle| > 2e-4 anywhere, or
+  * |score - oracle| > 2e-4 below that (a wider, derived bound within ~2 nats of the 1e-50 floor for
+    models whose parts are merged at the floor, see note()), or
   * a per-frame count of exactly evaluated clusters that differs from the oracle's."""
 import ctypes as C
 import os
@@ -19,6 +20,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 VISIBLE_LL = -103.97
 TOL, TOL_FLOOR = 1e-4, 2e-4
+LOG_TINY = float(np.log(1e-50))
 
 
 def run(seed=1, N=40, verbose=False):
@@ -39,7 +41,13 @@ def run(seed=1, N=40, verbose=False):
         vis = want > VISIBLE_LL
         evis = float(d[vis].max()) if vis.any() else 0.0
         worst[key + " (ll > -104)"] = max(worst.get(key + " (ll > -104)", 0.0), evis)
-        if evis > TOL or err > TOL_FLOOR:
+        # below the flush point: 2e-4, or what merging two parts that each carry the 1e-50 floor can
+        # lose (outlier / class routing: a part below the floor counts as nothing, so a sum
+        # s = a + b with a < 1e-50 comes out as b: |err| <= -log(1 - 1e-50 / s))
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            lost = -np.log1p(-np.minimum(np.exp(LOG_TINY - want), 0.5))
+        floor_bad = (~vis) & (d > np.maximum(TOL_FLOOR, 1.05 * lost))
+        if evis > TOL or floor_bad.any():
             at = int(d.argmax())
             fails.append("%s %s err %.3g (visible %.3g) at ll %.1f" % (key, ctx, err, evis, want.ravel()[at]))
             if verbose:
