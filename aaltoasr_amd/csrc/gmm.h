@@ -177,12 +177,15 @@ struct ClusterState {
   DevBuf<int32_t> csize;           // [Cs] members per cluster (0 beyond C)
   DevBuf<int32_t> crow[2];         // cluster of each packed row of the grouped / independent
                                    // track layout (C = no cluster or null row)
+  DevBuf<int32_t> crow_hyb, crow_centred;  // the same for the records of the centred kernel: the
+                                   // outlier components (outlier routing) / every component
   // per-state centre weights W[s][c] = sum of the weights of s's components in
   // cluster c, ELL layout [nnz][S]
   int nnz = 0;
   DevBuf<int32_t> w_cluster;
   DevBuf<float> w_weight;
   double ref_log2 = 0;             // reference exponent shared with the track kernels
+  bool log_merge = false;          // centre values as log2 and k_cluster_merge_log (no common f32 exponent)
   // per-call scratch: pass-wide buffers sized for Fc frames, ll64 for a sub-pass of Fs
   int64_t Fc = 0, Fs = 0;
   DevBuf<double> ll64;             // [Fs][Cs] centre log-likelihoods
@@ -240,6 +243,7 @@ struct aasr_gmm {
   aasr::DevBuf<int32_t> hyb_splits;        // [MAX][MAX+1]
   int hyb_max_splits = 1;
   aasr::DevBuf<int32_t> hyb_map;           // [hyb_states] -> state index
+  std::vector<int32_t> hyb_comps;          // mixture-component index of every outlier record (host)
   aasr::DevBuf<float> hyb_scratch;         // [frames of a pass][hyb_states]
   // Global constrained MLLR without re-packing: the rows stay those of the unadapted model
   // (rows_unbiased) and log|det| is added to every score at the kernels' output (out_bias_ln)
@@ -291,6 +295,10 @@ void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
 void gmm_read_clustering(aasr_gmm *g, const char *path);
 void gmm_set_clustering_min_evals(aasr_gmm *g, double min_clusters, double min_gaussians);
 const float *gmm_adapted_frames(aasr_gmm *g, const float *d_frames, int64_t F, hipStream_t stream);
+void gmm_outliers_masked_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, const int32_t *crow,
+                                const unsigned long long *maskw, int c1, int64_t n_words, hipStream_t stream);
+void gmm_centred_masked_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, const int32_t *crow,
+                               const unsigned long long *maskw, int c1, int64_t n_words, hipStream_t stream);
 void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                               hipStream_t stream);
 void gmm_tracks_masked_launch(aasr_gmm *g, int which, const float *d_frames, int64_t F,

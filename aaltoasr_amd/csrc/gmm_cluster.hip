@@ -33,6 +33,10 @@
 //                      applied to its accumulators (one v_cndmask per register,
 //                      masks fetched with 64-byte scalar loads), no floor;
 //   k_cluster_merge    out = log(max(exact part + sum_c W[s][c] centre_c, 1e-50)).
+// Gaussians the expanded form cannot hold (outlier routing / ill-conditioned models, gmm.h) take their
+// exact values from the centred kernel under the same bits (gmm_outliers_masked_launch /
+// gmm_centred_masked_launch); centres without a common f32 exponent switch the pass to log2 centre
+// values and k_cluster_merge_log.
 // The matrix work is not reduced (on this machine evaluating every Gaussian is
 // cheaper than gathering per-frame cluster subsets); the point of this path is
 // output parity with recognisers configured with -C/--eval-ming.
@@ -176,6 +180,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     int force_heap) {
   __shared__ unsigned long long hist[64];
   __shared__ unsigned long long bits[64][KPL];  // [frame in word][cluster slot] ballots
+  const bool log_vals = ref != ref;  // NaN: centre values as log2 (-inf where exact), for k_cluster_merge_log
   const int lane = threadIdx.x;
   int sz[KPL];
 #pragma unroll
@@ -293,7 +298,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       const unsigned long long bal = __ballot(valid && use_exact);
       if (lane == 0) bits[fi][j] = bal;
       // a key below the normal range stands for a likelihood under 2^-1022: 0.0f either way
-      if (valid) cval[f * C + c] = use_exact ? 0.0f : exp2f((float)(v[j] * kLog2eD + ref));
+      if (valid)
+        cval[f * C + c] = log_vals ? (use_exact ? -INFINITY : (float)(v[j] * kLog2eD))
+                                   : (use_exact ? 0.0f : exp2f((float)(v[j] * kLog2eD + ref)));
     }
     if (n_exact) {
 #pragma unroll
@@ -343,6 +350,7 @@ __global__ __launch_bounds__(64) void k_cluster_select_heap(
     int64_t tie_cap, double *__restrict__ heap_key, int32_t *__restrict__ heap_idx) {
   const int tid = blockIdx.x * 64 + threadIdx.x;
   const int64_t st = kHeapThreads;
+  const bool log_vals = ref != ref;
   const int count = min((int64_t)tie_list[tie_cap], tie_cap);
   double *key = heap_key + tid;
   int32_t *idx = heap_idx + tid;
@@ -390,7 +398,8 @@ __global__ __launch_bounds__(64) void k_cluster_select_heap(
       unsigned long long *w = maskw + word * (C + 1) + c;
       if (use_exact) atomicOr(w, bit);
       else atomicAnd(w, ~bit);
-      cval[f * C + c] = use_exact ? 0.0f : exp2f((float)(key[p * st] * kLog2eD + ref));
+      cval[f * C + c] = log_vals ? (use_exact ? -INFINITY : (float)(key[p * st] * kLog2eD))
+                                 : (use_exact ? 0.0f : exp2f((float)(key[p * st] * kLog2eD + ref)));
     }
   }
 }
@@ -516,10 +525,15 @@ __global__ __launch_bounds__(kMergeThreads) void k_cluster_merge(
 #pragma unroll
     for (int u = 0; u < kMergeSPT; u++) {
       if (!live[u]) continue;
-      float lin[kMergeFrames];
+      // x = log2 of the exact part on the shared reference exponent.  Outlier-routed Gaussians
+      // (centred kernel) can carry constants the track rows' reference was not chosen for: above
+      // 2^60 the exact part is kept in the log domain and the centres' share enters as log2(1 + A 2^-x)
+      float lin[kMergeFrames], xk[kMergeFrames];
 #pragma unroll
-      for (int k = 0; k < kMergeFrames; k++)
-        lin[k] = k < nf ? exp2f(fmaf(ocur[u][k], 1.4426950408889634f, ref)) : 0.0f;
+      for (int k = 0; k < kMergeFrames; k++) {
+        xk[k] = fmaf(ocur[u][k], 1.4426950408889634f, ref);
+        lin[k] = (k < nf && xk[k] <= 60.0f) ? exp2f(xk[k]) : 0.0f;
+      }
 #pragma unroll
       for (int j = 0; j < NNZ; j++) {
         const unsigned cidx = (j & 1) ? (wcp[u][j / 2] >> 16) : (wcp[u][j / 2] & 0xffffu);
@@ -544,7 +558,8 @@ __global__ __launch_bounds__(kMergeThreads) void k_cluster_merge(
 #pragma unroll
       for (int k = 0; k < kMergeFrames; k++)
         if (k < nf) {
-          const float l = fmaf(__log2f(lin[k]), 0.69314718055994530942f, -ref_ln);
+          const float l2 = xk[k] <= 60.0f ? __log2f(lin[k]) : xk[k] + __log2f(1.0f + lin[k] * exp2f(-xk[k]));
+          const float l = fmaf(l2, 0.69314718055994530942f, -ref_ln);
           out[(fg + k) * S + st[u]] = fmaxf(l, AASR_LOG_TINY_F);
         }
     }
@@ -593,6 +608,20 @@ static void build_crow(const aasr_gmm *g, const TrackLayout &L, const ClusterSta
   out.upload(crow.data(), crow.size());
 }
 
+// cluster of every record of the centred kernel's operand (comps = mixture-component indices; empty =
+// every component in order)
+static void build_crow_comps(const aasr_gmm *g, const std::vector<int32_t> &comps, const ClusterState &cl,
+                             DevBuf<int32_t> &out) {
+  const HostModel &m = g->host;
+  const size_t n = comps.empty() ? m.mix_idx.size() : comps.size();
+  std::vector<int32_t> crow(std::max<size_t>(n, 1), cl.C);
+  for (size_t r = 0; r < n; r++) {
+    const int32_t gi = m.mix_idx[comps.empty() ? r : (size_t)comps[r]];
+    if (cl.g2c[(size_t)gi] >= 0) crow[r] = cl.g2c[(size_t)gi];
+  }
+  out.upload(crow.data(), crow.size());
+}
+
 void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
                         const int32_t *gauss_index, const int32_t *cluster_index) {
   ClusterState &cl = g->cl;
@@ -612,13 +641,10 @@ void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
     raise(AASR_ERR_UNSUPPORTED, "more than 4096 clusters are not built (%d asked)", n_clusters);
   if (n_pairs > 0 && (!gauss_index || !cluster_index))
     raise(AASR_ERR_INVALID, "aasr_gmm_set_clustering: null argument");
-  if (!g->paired.ok && !g->tracks.ok)
+  if (!g->paired.ok && !g->tracks.ok && !g->centred_ok)
     raise(AASR_ERR_UNSUPPORTED,
-          "Gaussian clustering needs the fixed-reference track kernels, which this model's "
-          "constants rule out");
-  if (g->hyb_enabled)
-    raise(AASR_ERR_UNSUPPORTED,
-          "Gaussian clustering is not built for models with outlier-routed Gaussians (kappa %.0f)", g->kappa);
+          "Gaussian clustering needs the fixed-reference track kernels or the centred kernel, and this "
+          "model has neither");
   std::vector<std::vector<int32_t>> members((size_t)n_clusters);
   std::vector<int32_t> g2c((size_t)m.G, -1);
   for (int64_t i = 0; i < n_pairs; i++) {
@@ -637,7 +663,12 @@ void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
   n.Cs = (n_clusters + 7) / 8 * 8;
   n.g2c = g2c;
   n.dimp = (m.dim + 7) / 8 * 8;
-  n.ref_log2 = g->paired.ok ? g->paired.ref_log2 : g->tracks.ref_log2;
+  // the linear centre values and the merge share the track kernels' reference exponent.  A model
+  // without track layouts (only the centred kernel scores it), or a centre whose constant does not
+  // fit under that exponent (clusters of variance-floored Gaussians: +121 nats at sigma 0.045), takes
+  // the log-domain merge instead: centre values as log2, per-state (max, sum) -- no range limit.
+  n.log_merge = !g->paired.ok && !g->tracks.ok;
+  n.ref_log2 = g->paired.ok ? g->paired.ref_log2 : g->tracks.ok ? g->tracks.ref_log2 : 0.0;
   n.csize_h.resize((size_t)n.Cs, 0);
   n.c_mean.assign((size_t)n.C * m.dim, 0.0);
   n.c_prec.assign((size_t)n.C * m.dim, 0.0);
@@ -648,9 +679,7 @@ void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
     merge_centre(m, members[(size_t)c], &n.c_mean[(size_t)c * m.dim], &n.c_prec[(size_t)c * m.dim],
                  &n.c_cst[(size_t)c]);
     // the linear centre values share the track kernels' reference exponent
-    if (!(n.c_cst[(size_t)c] * kLog2eD + n.ref_log2 <= 126.0))
-      raise(AASR_ERR_UNSUPPORTED, "cluster %d: centre constant %.1f leaves no f32 headroom", c,
-            n.c_cst[(size_t)c]);
+    if (!(n.c_cst[(size_t)c] * kLog2eD + n.ref_log2 <= 126.0)) n.log_merge = true;
     for (int d = 0; d < m.dim; d++) {
       const size_t at = ((size_t)(c / 8) * n.dimp + d) * 16 + 2 * (size_t)(c % 8);
       rec[at] = n.c_mean[(size_t)c * m.dim + d];
@@ -775,15 +804,16 @@ static void launch_select_t(aasr_gmm *g, int64_t s0, int64_t F, hipStream_t stre
   ClusterState &cl = g->cl;
   const int64_t words = (F + 63) / 64;
   const int force_heap = g_force_heap;
+  const double ref_arg = cl.log_merge ? (double)NAN : cl.ref_log2;
   AASR_HIP(hipMemsetAsync(cl.tie_list.p + cl.Fs, 0, sizeof(int32_t), stream));
   hipLaunchKernelGGL(k_cluster_select<KPL>, dim3((unsigned)words), dim3(64), 0, stream, cl.ll64.p, F,
-                     cl.C, (int64_t)cl.Cs, cl.csize.p, cl.min_clusters, cl.min_gaussians, cl.ref_log2,
+                     cl.C, (int64_t)cl.Cs, cl.csize.p, cl.min_clusters, cl.min_gaussians, ref_arg,
                      cl.maskw.p + (size_t)(s0 / 64) * (cl.C + 1), cl.cval.p + (size_t)s0 * cl.C,
                      cl.n_exact.p + s0, cl.tie_list.p, cl.Fs, force_heap);
   AASR_HIP(hipGetLastError());
   // frames left to the queue replay (normally none: the kernel's threads find an empty list)
   hipLaunchKernelGGL(k_cluster_select_heap, dim3(kHeapThreads / 64), dim3(64), 0, stream, cl.ll64.p, cl.C,
-                     (int64_t)cl.Cs, cl.csize.p, cl.min_clusters, cl.min_gaussians, cl.ref_log2,
+                     (int64_t)cl.Cs, cl.csize.p, cl.min_clusters, cl.min_gaussians, ref_arg,
                      cl.maskw.p + (size_t)(s0 / 64) * (cl.C + 1), cl.cval.p + (size_t)s0 * cl.C,
                      cl.n_exact.p + s0, cl.tie_list.p, cl.Fs, cl.heap_key.p, cl.heap_idx.p);
   AASR_HIP(hipGetLastError());
@@ -796,6 +826,39 @@ static void launch_select(aasr_gmm *g, int64_t s0, int64_t F, hipStream_t stream
   else if (kpl <= 32) launch_select_t<32>(g, s0, F, stream);
   else launch_select_t<64>(g, s0, F, stream);
 }
+
+// The merge in the log domain (ClusterState::log_merge): out = ln(e^out + sum_j w_j 2^cvl[c_j]) with a
+// per-state maximum, for models whose centre values have no common f32 exponent.  Thread = state,
+// blockIdx.y = frame; the frame's C log2 centre values come through the caches.  A fallback: 16 exp2
+// per state and frame.
+__global__ __launch_bounds__(256) void k_cluster_merge_log(float *__restrict__ out, int64_t F, int64_t S,
+                                                           const float *__restrict__ cvl, int C,
+                                                           const int32_t *__restrict__ w_cluster,
+                                                           const float *__restrict__ w_weight, int nnz) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= S) return;
+  for (int64_t f = blockIdx.y; f < F; f += gridDim.y) {
+    const float *cv = cvl + f * C;
+    const float x = out[f * S + s] * 1.4426950408889634f;
+    float m = x;
+    for (int j = 0; j < nnz; j++) {
+      const float w = w_weight[(int64_t)j * S + s];
+      if (w > 0.0f) m = fmaxf(m, __log2f(w) + cv[w_cluster[(int64_t)j * S + s]]);
+    }
+    float l = AASR_LOG_TINY_F;
+    if (m > -INFINITY) {
+      float sum = exp2f(x - m);
+      for (int j = 0; j < nnz; j++) {
+        const float w = w_weight[(int64_t)j * S + s];
+        if (w > 0.0f) sum += exp2f(__log2f(w) + cv[w_cluster[(int64_t)j * S + s]] - m);
+      }
+      l = (m + __log2f(sum)) * 0.69314718055994530942f;
+    }
+    out[f * S + s] = fmaxf(l, AASR_LOG_TINY_F);
+  }
+}
+
+static void launch_merge(aasr_gmm *g, float *d_out, int64_t F, hipStream_t stream);
 
 template <int NNZ>
 static void launch_merge_t(aasr_gmm *g, float *d_out, int64_t F, hipStream_t stream) {
@@ -820,6 +883,18 @@ static void launch_merge_t(aasr_gmm *g, float *d_out, int64_t F, hipStream_t str
   AASR_HIP(hipGetLastError());
 }
 
+static void launch_merge(aasr_gmm *g, float *d_out, int64_t F, hipStream_t stream) {
+  ClusterState &cl = g->cl;
+  if (cl.log_merge) {
+    hipLaunchKernelGGL(k_cluster_merge_log, dim3((unsigned)((g->S + 255) / 256), (unsigned)std::min<int64_t>(F, 8192)),
+                       dim3(256), 0, stream, d_out, F, g->S, cl.cval.p, cl.C, cl.w_cluster.p, cl.w_weight.p, cl.nnz);
+    AASR_HIP(hipGetLastError());
+    return;
+  }
+  if (cl.nnz <= 8) launch_merge_t<8>(g, d_out, F, stream);
+  else launch_merge_t<16>(g, d_out, F, stream);   // weights beyond 16 per state come from L2
+}
+
 void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                               hipStream_t stream) {
   ClusterState &cl = g->cl;
@@ -833,21 +908,34 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
   // aku/Distributions.cc:2688-2691): the centre kernel gets the frames, the masked scoring kernel
   // the adapted ones.
   const float *d_members = g->xf_a.p ? gmm_adapted_frames(g, d_frames, F, stream) : d_frames;
-  if (g->ill_conditioned)
+  // Models the expanded form cannot hold (gmm.h, KAPPA_LIMIT): the exact part of the ill-conditioned
+  // Gaussians -- a minority next to the masked track kernel (outlier routing), or the whole model --
+  // comes from the centred kernel under the same selection bits.  Not combined with a transform (the
+  // determinant would have to ride on the centred records).
+  const bool all_centred = g->ill_conditioned || (!g->paired.ok && !g->tracks.ok);
+  const bool with_outliers = g->hyb_enabled && !all_centred;
+  if ((all_centred || with_outliers) && g->xf_a.p)
     raise(AASR_ERR_UNSUPPORTED,
-          "Gaussian clustering is not built for models that need the centred kernel (kappa %.0f)",
-          g->kappa);
+          "Gaussian clustering under a CMLLR transform is not built for models that need the centred kernel "
+          "(kappa %.0f)", g->kappa);
+  if (all_centred && !g->centred_ok)
+    raise(AASR_ERR_UNSUPPORTED, "no centred kernel instance for dimension %d", g->dim);
   // the layout the exact part runs on: grouped unless it is missing or masked out
   const int which = (g->paired.ok && ((g->layout_mask & 1) || !g->tracks.ok)) ? 0 : 1;
   const TrackLayout &L = which == 0 ? g->paired : g->tracks;
-  if (!L.ok) raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering needs a track layout for this model");
-  if (cl.crow[which].n != L.row_gauss.size()) build_crow(g, L, cl, cl.crow[which]);
+  if (!all_centred && !L.ok) raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering needs a track layout for this model");
+  if (!all_centred && cl.crow[which].n != L.row_gauss.size()) build_crow(g, L, cl, cl.crow[which]);
+  const int64_t mask_rows = all_centred ? 0 : L.rows_padded;  // the centred kernel reads the cluster bits themselves
+  if (with_outliers && cl.crow_hyb.n != std::max<size_t>(g->hyb_comps.size(), 1))
+    build_crow_comps(g, g->hyb_comps, cl, cl.crow_hyb);
+  if (all_centred && cl.crow_centred.n != std::max<size_t>(g->host.mix_idx.size(), 1))
+    build_crow_comps(g, std::vector<int32_t>(), cl, cl.crow_centred);
   // Frames per pass.  The track kernel and the merge run once per pass, so a pass is
   // as large as ~16 GB of scratch allow (1 bit per frame x packed row for the lane
   // masks, 4 B per frame x cluster for the centre values) and a whole number of rounds
   // of the track kernel (2 workgroups of 256 frames per CU); the f64 centre
   // log-likelihoods (8 B per frame x cluster) only live for a sub-pass of <= 2 GB.
-  const double per_frame = (double)L.rows_padded / 8.0 + 4.125 * (double)(cl.C + 1) + 4.0;
+  const double per_frame = (double)mask_rows / 8.0 + 4.125 * (double)(cl.C + 1) + 4.0;
   const int64_t round_frames = 2 * (int64_t)(g->num_cus > 0 ? g->num_cus : 256) * FRAMES_PER_BLOCK;
   const int64_t f_rounded = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK;
   int64_t fb = (int64_t)(16.0e9 / per_frame);
@@ -856,13 +944,13 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
   fb = std::min<int64_t>(fb, f_rounded);
   int64_t fs = (int64_t)(2.0e9 / (8.0 * (double)cl.Cs));
   fs = std::min<int64_t>(fb, std::max<int64_t>(FRAMES_PER_BLOCK, fs / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK));
-  const size_t need_rows = (size_t)(fb / 64) * (size_t)L.rows_padded;
+  const size_t need_rows = (size_t)(fb / 64) * (size_t)mask_rows;
   if (fb > cl.Fc || need_rows > cl.maskrow.n || (size_t)fs * cl.Cs > cl.ll64.n) {
     fb = std::max(fb, cl.Fc);
     cl.ll64.alloc((size_t)fs * cl.Cs);
     cl.cval.alloc((size_t)fb * cl.C);
     cl.maskw.alloc((size_t)(fb / 64) * (cl.C + 1));
-    cl.maskrow.alloc((size_t)(fb / 64) * (size_t)L.rows_padded);
+    cl.maskrow.alloc((size_t)(fb / 64) * (size_t)mask_rows);
     cl.n_exact.alloc((size_t)fb);
     cl.tie_list.alloc((size_t)fs + 1);
     cl.heap_key.ensure((size_t)cl.C * kHeapThreads);
@@ -881,6 +969,11 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
       launch_select(g, s0, ns, stream);
     }
     const int64_t words = (n + 63) / 64;
+    if (all_centred) {
+      gmm_centred_masked_launch(g, fr_members, n, out, cl.crow_centred.p, cl.maskw.p, cl.C + 1, words, stream);
+      launch_merge(g, out, n, stream);
+      continue;
+    }
     {
       const int64_t n_tiles = L.rows_padded / TILE_ROWS;
       const int tpb = (int)std::min<int64_t>(n_tiles, 64);  // the staged cluster masks serve 64 tiles
@@ -891,8 +984,9 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
     }
     AASR_HIP(hipGetLastError());
     gmm_tracks_masked_launch(g, which, fr_members, n, out, cl.maskrow.p, stream);
-    if (cl.nnz <= 8) launch_merge_t<8>(g, out, n, stream);
-    else launch_merge_t<16>(g, out, n, stream);   // weights beyond 16 per state come from L2
+    if (with_outliers)
+      gmm_outliers_masked_launch(g, fr_members, n, out, cl.crow_hyb.p, cl.maskw.p, cl.C + 1, words, stream);
+    launch_merge(g, out, n, stream);
   }
 }
 

@@ -952,7 +952,8 @@ static void find_outliers(aasr_gmm *g) {
   g->ill_conditioned = any_bad;
   const int dimp = centred_dimp_for(D);
   static const int routing = getenv("AASR_OUTLIER_ROUTING") ? atoi(getenv("AASR_OUTLIER_ROUTING")) : 1;
-  if (!g->ill_conditioned || !dimp || !routing || g->cl.loaded) return;
+  g->hyb_comps.clear();
+  if (!g->ill_conditioned || !dimp || !routing) return;
   std::vector<int32_t> comps, off{0}, map;
   for (int64_t s = 0; s < m.S; s++) {
     const size_t before = comps.size();
@@ -971,6 +972,8 @@ static void find_outliers(aasr_gmm *g) {
   g->hyb_rows = (int64_t)comps.size();
   build_centred_tables(m, dimp, comps, off, g->hyb_recs, g->hyb_state_off, g->hyb_splits, &g->hyb_max_splits);
   g->hyb_map.upload(map.data(), map.size());
+  g->hyb_comps = comps;
+  g->cl.crow_hyb = aasr::DevBuf<int32_t>();  // rebuilt on the next clustered pass
 }
 
 void gmm_build_centred(aasr_gmm *g) {

@@ -1421,11 +1421,15 @@ void gmm_full_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out
 // the same lanes as the VALU anyway, so this costs ~1.5x the matrix path, not
 // 16x.  Also the fallback for any model the track layouts cannot hold.
 // ---------------------------------------------------------------------------
-template <int DIMP>
+// CL (Gaussian clustering, gmm_cluster.hip): record r belongs to cluster crow[r]; its value counts
+// for a frame only where the frame's bit of maskw[word][cluster] is set (the cluster is evaluated
+// exactly there), and the result carries no 1e-50 floor (k_cluster_merge applies it).
+template <int DIMP, bool CL>
 __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
     const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ recs,
     const int32_t *__restrict__ state_off, const int32_t *__restrict__ split_state,
-    float *__restrict__ out, int64_t frame_stride, int64_t state_stride) {
+    float *__restrict__ out, int64_t frame_stride, int64_t state_stride,
+    const int32_t *__restrict__ crow, const unsigned long long *__restrict__ maskw, int c1, int64_t n_words) {
   constexpr int REC = 2 * DIMP + 4;  // [mu x DIMP][p' x DIMP][C, pad, pad, pad]
   // each lane owns TWO frames (f, f + 256): one scalar fetch of a Gaussian's
   // parameters feeds 128 frame x Gaussian pairs per wave
@@ -1443,11 +1447,21 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
     x2[d].y = d < dim ? frames[fbc * dim + d] : 0.0f;
   }
   const int s_begin = split_state[blockIdx.y], s_end = split_state[blockIdx.y + 1];
+  // the 64-frame words of this wave's two frame groups (wave-uniform)
+  const int64_t word_a = min((int64_t)blockIdx.x * 8 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), n_words - 1);
+  const int64_t word_b = min(word_a + 4, n_words - 1);
+  const int lane_bit = threadIdx.x & 63;
   for (int s = s_begin; s < s_end; s++) {
     const int r0 = state_off[s], r1 = state_off[s + 1];
     float ma = NEG_BIG_F, sa = 0.0f, mb = NEG_BIG_F, sb = 0.0f;
     for (int r = r0; r < r1; r++) {
       const float *rec = recs + (size_t)r * REC;
+      bool on_a = true, on_b = true;
+      if (CL) {
+        const int c = crow[r];
+        on_a = (maskw[word_a * c1 + c] >> lane_bit) & 1ull;
+        on_b = (maskw[word_b * c1 + c] >> lane_bit) & 1ull;
+      }
       f32x2 acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};  // two chains per frame
 #pragma unroll
       for (int d = 0; d < DIMP; d += 2) {
@@ -1459,7 +1473,11 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
       }
       const float a0 = acc0.x, b0 = acc0.y, a1 = acc1.x, b1 = acc1.y;
       const float c = rec[2 * DIMP];
-      const float la = c + (a0 + a1), lb = c + (b0 + b1);  // log2 units
+      float la = c + (a0 + a1), lb = c + (b0 + b1);  // log2 units
+      if (CL) {
+        la = on_a ? la : NEG_BIG_F;
+        lb = on_b ? lb : NEG_BIG_F;
+      }
       const float na = fmaxf(ma, la), nb = fmaxf(mb, lb);
       sa = sa * __builtin_amdgcn_exp2f(ma - na) + __builtin_amdgcn_exp2f(la - na);
       sb = sb * __builtin_amdgcn_exp2f(mb - nb) + __builtin_amdgcn_exp2f(lb - nb);
@@ -1468,9 +1486,10 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
     }
     float lla = fmaf(ma, LN2_F, __builtin_amdgcn_logf(sa) * LN2_F);
     float llb = fmaf(mb, LN2_F, __builtin_amdgcn_logf(sb) * LN2_F);
-    lla = fmaxf(lla, LOG_TINY_F);
-    llb = fmaxf(llb, LOG_TINY_F);
-    if (r1 <= r0) lla = llb = LOG_TINY_F;
+    const float floor_val = CL ? NEG_BIG_F : LOG_TINY_F;
+    lla = fmaxf(lla, floor_val);
+    llb = fmaxf(llb, floor_val);
+    if (r1 <= r0) lla = llb = floor_val;
     if (fa < F) out[fa * frame_stride + s * state_stride] = lla;
     if (fb < F) out[fb * frame_stride + s * state_stride] = llb;
   }
@@ -1487,6 +1506,11 @@ struct CentredOps {
   const int32_t *state_off, *splits;
   int max_splits;
   int64_t frame_stride, state_stride;  // out[f * frame_stride + s * state_stride]
+  // Gaussian clustering: cluster of every record, selection bits [words][c1]; null = unmasked
+  const int32_t *crow = nullptr;
+  const unsigned long long *maskw = nullptr;
+  int c1 = 0;
+  int64_t n_words = 1;
 };
 
 template <int DIMP>
@@ -1507,9 +1531,14 @@ static void launch_centred_t(const aasr_gmm *g, const CentredOps &ops, const flo
     }
   }
   const int32_t *split = ops.splits + (size_t)(R - 1) * (CENTRED_MAX_SPLITS + 1);
-  hipLaunchKernelGGL(k_gmm_diag_score_centred<DIMP>, dim3((unsigned)blocks, (unsigned)R), dim3(256), 0,
-                     stream, d_frames, F, g->dim, ops.recs, ops.state_off, split, d_out, ops.frame_stride,
-                     ops.state_stride);
+  if (ops.maskw)
+    hipLaunchKernelGGL((k_gmm_diag_score_centred<DIMP, true>), dim3((unsigned)blocks, (unsigned)R), dim3(256), 0,
+                       stream, d_frames, F, g->dim, ops.recs, ops.state_off, split, d_out, ops.frame_stride,
+                       ops.state_stride, ops.crow, ops.maskw, ops.c1, ops.n_words);
+  else
+    hipLaunchKernelGGL((k_gmm_diag_score_centred<DIMP, false>), dim3((unsigned)blocks, (unsigned)R), dim3(256), 0,
+                       stream, d_frames, F, g->dim, ops.recs, ops.state_off, split, d_out, ops.frame_stride,
+                       ops.state_stride, (const int32_t *)nullptr, (const unsigned long long *)nullptr, 0, (int64_t)1);
   AASR_HIP(hipGetLastError());
 }
 
@@ -1538,11 +1567,12 @@ static bool launch_centred(const aasr_gmm *g, const float *d_frames, int64_t F, 
 // state's well-conditioned components plus the centred sum over its outliers.  `part` is
 // state-major ([Sb][pitch]: the centred kernel's lane = frame stores are coalesced that way); a
 // workgroup moves a 64 x 64 tile through LDS so that the update of `out` walks along a frame row.
-// Both inputs carry the 1e-50 floor, which the result keeps.
+// Both inputs carry the 1e-50 floor, which the result keeps (floors = 1); in a clustered pass neither
+// does (floors = 0).
 __global__ __launch_bounds__(256) void k_outlier_merge(float *__restrict__ out, int64_t S,
                                                        const float *__restrict__ part, int64_t pitch,
                                                        int64_t Sb, const int32_t *__restrict__ map,
-                                                       int64_t F) {
+                                                       int64_t F, int floors) {
   __shared__ float tile[64][65];
   const int64_t f0 = (int64_t)blockIdx.x * 64;
   const int64_t j0 = (int64_t)blockIdx.y * 64;
@@ -1562,27 +1592,40 @@ __global__ __launch_bounds__(256) void k_outlier_merge(float *__restrict__ out, 
     const float a = *o, b = tile[lane][ff];
     const float hi = fmaxf(a, b), lo = fminf(a, b);
     float r = hi;
-    if (lo > LOG_TINY_F) r = hi + log1pf(expf(lo - hi));  // a part AT the floor holds nothing
-    *o = fmaxf(r, LOG_TINY_F);
+    if (floors) {
+      if (lo > LOG_TINY_F) r = hi + log1pf(expf(lo - hi));  // a part AT the floor holds nothing
+      r = fmaxf(r, LOG_TINY_F);
+    } else {
+      r = hi + log1pf(expf(lo - hi));  // clustered pass: no floors before k_cluster_merge
+    }
+    *o = r;
   }
 }
 
 // Outlier routing (gmm.h): the outlier components of the states that have any, in the centred
 // form, merged into the scores the matrix path has already written.
-static void score_outliers(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, hipStream_t stream) {
+static void score_outliers(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, hipStream_t stream,
+                           const int32_t *crow = nullptr, const unsigned long long *maskw = nullptr, int c1 = 0,
+                           int64_t n_words = 1) {
   const int64_t Sb = g->hyb_states;
   if (Sb <= 0) return;
   // passes of at most ~1 GB of partial scores
   int64_t pass = std::max<int64_t>(512, ((int64_t)(g_pass_bytes / (double)(Sb * 4))) / 512 * 512);
   if (pass > F) pass = (F + 63) / 64 * 64;
   g->hyb_scratch.ensure((size_t)pass * (size_t)Sb);
-  const CentredOps ops{g->hyb_recs.p, g->hyb_state_off.p, g->hyb_splits.p, g->hyb_max_splits, 1, pass};
-  for (int64_t f0 = 0; f0 < F; f0 += pass) {
+  CentredOps ops{g->hyb_recs.p, g->hyb_state_off.p, g->hyb_splits.p, g->hyb_max_splits, 1, pass};
+  ops.crow = crow;
+  ops.c1 = c1;
+  for (int64_t f0 = 0; f0 < F; f0 += pass) {  // pass is a multiple of 512 frames: whole mask words
     const int64_t n = std::min(pass, F - f0);
+    if (maskw) {
+      ops.maskw = maskw + (f0 / 64) * c1;
+      ops.n_words = n_words - f0 / 64;
+    }
     if (!launch_centred_ops(g, ops, g->centred_dimp, d_frames + f0 * g->dim, n, g->hyb_scratch.p, stream))
       raise(AASR_ERR_UNSUPPORTED, "no centred kernel instance for dimension %d", g->dim);
     hipLaunchKernelGGL(k_outlier_merge, dim3((unsigned)((n + 63) / 64), (unsigned)((Sb + 63) / 64)), dim3(256), 0,
-                       stream, d_out + f0 * g->S, g->S, g->hyb_scratch.p, pass, Sb, g->hyb_map.p, n);
+                       stream, d_out + f0 * g->S, g->S, g->hyb_scratch.p, pass, Sb, g->hyb_map.p, n, maskw ? 0 : 1);
     AASR_HIP(hipGetLastError());
   }
 }
@@ -1700,6 +1743,26 @@ void gmm_tracks_masked_launch(aasr_gmm *g, int which, const float *d_frames, int
   if (g->use_bf16x3 && launch_bf16(g, L, d_frames, F, d_out, stream, &cl)) return;
   if (!launch_tracks(g, L, d_frames, F, d_out, stream, &cl))
     raise(AASR_ERR_UNSUPPORTED, "no track kernel instance for this model");
+}
+
+// Clustered pass over a model with outlier-routed Gaussians: the outlier components in the centred
+// form, masked by their clusters' selection bits, added to what the masked track kernel wrote.
+void gmm_outliers_masked_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, const int32_t *crow,
+                                const unsigned long long *maskw, int c1, int64_t n_words, hipStream_t stream) {
+  score_outliers(g, d_frames, F, d_out, stream, crow, maskw, c1, n_words);
+}
+
+// Clustered pass over a model that is scored in the centred form as a whole.
+void gmm_centred_masked_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, const int32_t *crow,
+                               const unsigned long long *maskw, int c1, int64_t n_words, hipStream_t stream) {
+  if (!g->centred_ok) raise(AASR_ERR_UNSUPPORTED, "no centred kernel instance for dimension %d", g->dim);
+  CentredOps ops{g->centred_recs.p, g->centred_state_off.p, g->centred_splits.p, g->centred_max_splits, g->S, 1};
+  ops.crow = crow;
+  ops.maskw = maskw;
+  ops.c1 = c1;
+  ops.n_words = n_words;
+  if (!launch_centred_ops(g, ops, g->centred_dimp, d_frames, F, d_out, stream))
+    raise(AASR_ERR_UNSUPPORTED, "no centred kernel instance for dimension %d", g->dim);
 }
 
 // Class routing (gmm.h): out[i] = log(exp(out[i]) + exp(part[i] + logdet)); a value AT the floor

@@ -277,3 +277,48 @@ def test_clustering_under_a_global_cmllr_transform(capi, oracle):
         two = np.concatenate([np.zeros(600, np.int32), np.ones(600, np.int32)])
         with pytest.raises(capi.AasrError, match="per-class model-side CMLLR together with Gaussian clustering"):
             gm.set_cmllr(two, np.stack([W, W]))
+
+
+def test_clustering_with_outlier_routed_and_ill_conditioned_models(capi, oracle):
+    """Production recognisers run clustered, and real models hold a few variance-floored Gaussians
+    (kappa > 600: taken out of the matrix layouts, gmm.h).  The outliers' exact values come from the
+    centred kernel under the same per-(cluster, frame) selection bits; a model that is ill-conditioned
+    as a whole runs the centred kernel for every component.  Scores and exact-evaluation counts
+    against the oracle's cluster branch, several thresholds, frames sitting on the outliers, a state
+    made of outliers only, an outlier in no cluster."""
+    import ctypes as C
+    rng = np.random.default_rng(31)
+    mean, var, off, idx, w = synth.make_model(D=39, G=512, S=48, comps=8, seed=13)
+    bad = rng.choice(512, 24, replace=False)
+    var[bad] *= 2e-3
+    idx[off[5]:off[6]] = bad[:off[6] - off[5]]
+    idx[off[9]] = bad[3]
+    frames = synth.make_frames(300, seed=8)
+    frames[:24] = (mean[bad] + np.sqrt(var[bad]) * rng.standard_normal((24, 39))).astype(np.float32)
+    g2c = synth.make_clustering(mean, 32)
+    g2c[bad[0]] = -1                                   # an outlier that belongs to no cluster
+    g2c[7] = -1
+    L = capi.lib()
+    L.aasr_debug_kappa.restype = C.c_double
+    L.aasr_debug_kappa.argtypes = [C.c_void_p]
+    for minc, ming in ((0.0, 0.25), (0.2, 0.0), (0.0, 0.0), (1.0, 1.0)):
+        gm, om, got, want = _check(capi, oracle, (mean, var, off, idx, w), g2c, 32, minc, ming, frames)
+        assert L.aasr_debug_kappa(gm._h) > 600 and gm.active_layout() in (1, 2)   # outlier routing, not all-centred
+        if minc == 1.0:
+            assert np.abs(got - om.score(frames.astype(np.float64))).max() <= TOL
+        gm.close()
+    # a majority of tight Gaussians: the whole model in the centred form, still clustered
+    var2 = var.copy()
+    var2[rng.choice(512, 300, replace=False)] *= 2e-3
+    om = oracle.DiagModel(mean, var2, off, idx, w)
+    gm = capi.Gmm.from_arrays(mean, var2, off, idx, w)
+    assert gm.active_layout() == 4
+    gm.set_clustering(32, _pairs(g2c))
+    for minc, ming in ((0.0, 0.25), (0.3, 0.1), (0.0, 0.0)):
+        om.set_clustering(32, _pairs(g2c), minc, ming)
+        want, want_n = om.score_clustered(frames.astype(np.float64), want_counts=True)
+        gm.set_clustering_min_evals(minc, ming)
+        got = gm.score(frames)
+        assert np.array_equal(gm.cluster_exact_counts(len(frames)), want_n)
+        assert np.abs(got - want).max() <= 2e-4, (minc, ming, np.abs(got - want).max())
+    gm.close()
