@@ -232,6 +232,11 @@ struct aasr_gmm {
   aasr::DevBuf<int32_t> centred_state_off; // [S+1]
   aasr::DevBuf<int32_t> centred_splits;    // [MAX][MAX+1] state boundaries
   int centred_max_splits = 1;
+  // the pool's Gaussians as single-record states (per-Gaussian view of ill-conditioned models)
+  bool pool_centred_built = false;
+  aasr::DevBuf<float> poolc_recs;
+  aasr::DevBuf<int32_t> poolc_state_off, poolc_splits;
+  int poolc_max_splits = 1;
   // Outlier routing: when only a minority of the Gaussians break the conditioning limit, those
   // (outlier[g] != 0) are taken out of the matrix layouts (null rows) and scored in the centred
   // form over the states that hold them; k_outlier_merge adds the two parts per state.
@@ -277,6 +282,7 @@ void gmm_build(aasr_gmm *g, const HostModel &m);
 // transform over the unadapted rows; per-class transforms with an unchanged membership), rebuilds otherwise
 void gmm_set_transforms(aasr_gmm *g, int32_t n_transforms, const int32_t *gauss_to_transform, const double *W);
 void gmm_build_pool(aasr_gmm *g);
+void gmm_build_pool_centred(aasr_gmm *g);
 void gmm_build_tracks(aasr_gmm *g, bool grouped);
 void gmm_build_centred(aasr_gmm *g);
 void gmm_build_fullcov(aasr_gmm *g);

@@ -870,9 +870,11 @@ void gmm_build_tracks(aasr_gmm *g, bool grouped) {
 // whether the matrix-core (expanded form) kernels may be used.
 // Centred-form operands of a component subset: rows k of the mixture arrays grouped by `off`
 // ([n_states + 1] offsets into `comps`).
+// pool = true: `comps` are pool Gaussians with weight 1 (the per-Gaussian view), not mixture components
 static void build_centred_tables(const HostModel &m, int dimp, const std::vector<int32_t> &comps,
                                  const std::vector<int32_t> &off, DevBuf<float> &d_recs,
-                                 DevBuf<int32_t> &d_off, DevBuf<int32_t> &d_splits, int *max_splits) {
+                                 DevBuf<int32_t> &d_off, DevBuf<int32_t> &d_splits, int *max_splits,
+                                 bool pool = false) {
   const int D = m.dim;
   const int rec = 2 * dimp + 4;
   const size_t rows = comps.size();
@@ -880,7 +882,7 @@ static void build_centred_tables(const HostModel &m, int dimp, const std::vector
   std::vector<float> recs(std::max<size_t>(1, rows) * rec, 0.0f);
   for (size_t r = 0; r < rows; r++) {
     const size_t k = (size_t)comps[r];
-    const int64_t gi = m.mix_idx[k];
+    const int64_t gi = pool ? (int64_t)k : (int64_t)m.mix_idx[k];
     double prod = 1;
     for (int d = 0; d < D; d++) {
       double v = m.var[(size_t)gi * D + d];
@@ -890,7 +892,7 @@ static void build_centred_tables(const HostModel &m, int dimp, const std::vector
       recs[r * rec + dimp + d] = (float)(-0.5 * p * kLog2e);
     }
     double cst = (prod > 0) ? std::log(std::sqrt(prod)) : prod;
-    double c = cst + m.logw(k);
+    double c = cst + (pool ? 0.0 : m.logw(k));
     if (std::isnan(c) || c == INFINITY)
       raise(AASR_ERR_INVALID, "Gaussian %ld has a non-finite constant (precision product overflow)", (long)gi);
     recs[r * rec + 2 * dimp] = std::isfinite(c) ? (float)(c * kLog2e) : kNullConst;
@@ -1351,6 +1353,7 @@ void gmm_set_transforms(aasr_gmm *g, int32_t n_transforms, const int32_t *gauss_
     cur.g2t.clear();
     cur.xform.clear();
     g->pool_built = false;
+    g->pool_centred_built = false;
     if (n_transforms == 0) {
       g->xf_a.release();
       g->xf_b.release();
@@ -1376,6 +1379,7 @@ void gmm_set_transforms(aasr_gmm *g, int32_t n_transforms, const int32_t *gauss_
   m.g2t.clear();
   m.xform.clear();
   g->pool_built = false;
+  g->pool_centred_built = false;
   if (global && !m.any_full() && !g->rows_unbiased) {
     // coming from per-class transforms or from rows with a folded bias: build the unadapted rows
     // once, then take the in-place path if this model can (the usual case)
@@ -1391,6 +1395,22 @@ void gmm_set_transforms(aasr_gmm *g, int32_t n_transforms, const int32_t *gauss_
     m.xform.assign(W, W + (size_t)n_transforms * D * (D + 1));
   }
   gmm_build(g, m);
+}
+
+// the pool's Gaussians as one-record "states" of the centred kernel: the per-Gaussian view of a model
+// the expanded form cannot hold
+void gmm_build_pool_centred(aasr_gmm *g) {
+  if (g->pool_centred_built) return;
+  const HostModel &m = g->host;
+  const int dimp = centred_dimp_for(m.dim);
+  if (!dimp) raise(AASR_ERR_UNSUPPORTED, "no centred kernel instance for dimension %d", m.dim);
+  std::vector<int32_t> comps((size_t)m.G), off((size_t)m.G + 1);
+  for (int64_t i = 0; i < m.G; i++) comps[(size_t)i] = (int32_t)i;
+  for (int64_t i = 0; i <= m.G; i++) off[(size_t)i] = (int32_t)i;
+  if (!g->centred_dimp) g->centred_dimp = dimp;
+  build_centred_tables(m, dimp, comps, off, g->poolc_recs, g->poolc_state_off, g->poolc_splits, &g->poolc_max_splits,
+                       true);
+  g->pool_centred_built = true;
 }
 
 void gmm_build_pool(aasr_gmm *g) {

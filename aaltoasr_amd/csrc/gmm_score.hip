@@ -1429,7 +1429,8 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
     const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ recs,
     const int32_t *__restrict__ state_off, const int32_t *__restrict__ split_state,
     float *__restrict__ out, int64_t frame_stride, int64_t state_stride,
-    const int32_t *__restrict__ crow, const unsigned long long *__restrict__ maskw, int c1, int64_t n_words) {
+    const int32_t *__restrict__ crow, const unsigned long long *__restrict__ maskw, int c1, int64_t n_words,
+    float floor_val) {
   constexpr int REC = 2 * DIMP + 4;  // [mu x DIMP][p' x DIMP][C, pad, pad, pad]
   // each lane owns TWO frames (f, f + 256): one scalar fetch of a Gaussian's
   // parameters feeds 128 frame x Gaussian pairs per wave
@@ -1486,7 +1487,6 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
     }
     float lla = fmaf(ma, LN2_F, __builtin_amdgcn_logf(sa) * LN2_F);
     float llb = fmaf(mb, LN2_F, __builtin_amdgcn_logf(sb) * LN2_F);
-    const float floor_val = CL ? NEG_BIG_F : LOG_TINY_F;
     lla = fmaxf(lla, floor_val);
     llb = fmaxf(llb, floor_val);
     if (r1 <= r0) lla = llb = floor_val;
@@ -1511,6 +1511,7 @@ struct CentredOps {
   const unsigned long long *maskw = nullptr;
   int c1 = 0;
   int64_t n_words = 1;
+  float floor_val = LOG_TINY_F;  // NEG_BIG_F: no floor (clustered passes, per-Gaussian view)
 };
 
 template <int DIMP>
@@ -1534,11 +1535,12 @@ static void launch_centred_t(const aasr_gmm *g, const CentredOps &ops, const flo
   if (ops.maskw)
     hipLaunchKernelGGL((k_gmm_diag_score_centred<DIMP, true>), dim3((unsigned)blocks, (unsigned)R), dim3(256), 0,
                        stream, d_frames, F, g->dim, ops.recs, ops.state_off, split, d_out, ops.frame_stride,
-                       ops.state_stride, ops.crow, ops.maskw, ops.c1, ops.n_words);
+                       ops.state_stride, ops.crow, ops.maskw, ops.c1, ops.n_words, NEG_BIG_F);
   else
     hipLaunchKernelGGL((k_gmm_diag_score_centred<DIMP, false>), dim3((unsigned)blocks, (unsigned)R), dim3(256), 0,
                        stream, d_frames, F, g->dim, ops.recs, ops.state_off, split, d_out, ops.frame_stride,
-                       ops.state_stride, (const int32_t *)nullptr, (const unsigned long long *)nullptr, 0, (int64_t)1);
+                       ops.state_stride, (const int32_t *)nullptr, (const unsigned long long *)nullptr, 0, (int64_t)1,
+                       ops.floor_val);
   AASR_HIP(hipGetLastError());
 }
 
@@ -1933,6 +1935,16 @@ void gmm_gauss_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
   if (g->host.factor_path() || g->xf_a.p || g->class_routing)
     raise(AASR_ERR_UNSUPPORTED,
           "per-Gaussian log-likelihoods are not built for full-covariance or adapted pools");
+  if (g->ill_conditioned || g->hyb_enabled) {
+    // variance-floored Gaussians: the expanded form loses eps * kappa, so the whole pool is
+    // evaluated in the centred form (one-record states, no floor)
+    gmm_build_pool_centred(g);
+    CentredOps ops{g->poolc_recs.p, g->poolc_state_off.p, g->poolc_splits.p, g->poolc_max_splits, g->G, 1};
+    ops.floor_val = NEG_BIG_F;
+    if (!launch_centred_ops(g, ops, g->centred_dimp, d_frames, F, d_out, stream))
+      raise(AASR_ERR_UNSUPPORTED, "no centred kernel instance for dimension %d", g->dim);
+    return;
+  }
   gmm_build_pool(g);
   launch<1>(g, g->pool, d_frames, F, d_out, g->G, stream);
 }

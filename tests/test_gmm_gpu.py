@@ -314,3 +314,24 @@ def test_wide_kernel_every_instance(capi, oracle, D):
         ref = oracle.DiagModel(mean, var, off, idx, w).score(fr[:300].astype(np.float64))
         assert np.abs(whole[:300] - ref).max() <= 1e-4
         g.close()
+
+
+def test_gauss_loglik_of_tight_gaussians(capi, oracle):
+    """PDFPool::compute_likelihood(f, index) (aku/Distributions.hh:145) for variance-floored Gaussians:
+    the expanded (matrix) form loses ~eps * kappa there, so per-Gaussian values of an ill-conditioned
+    or outlier-routed pool come from the centred kernel as well -- no 1e-50 floor on this view."""
+    rng = np.random.default_rng(4)
+    mean, var, off, idx, w = synth.make_model(D=39, G=256, S=32, comps=8, seed=3)
+    bad = rng.choice(256, 12, replace=False)
+    var[bad] *= 2e-3
+    frames = synth.make_frames(200, seed=2)
+    frames[:12] = (mean[bad] + np.sqrt(var[bad]) * rng.standard_normal((12, 39))).astype(np.float32)
+    ref = oracle.DiagModel(mean, var, off, idx, w).gauss_loglik(frames.astype(np.float64))
+    g = capi.Gmm.from_arrays(mean, var, off, idx, w)
+    got = g.gauss_loglik(frames)
+    # relative to the magnitude: values reach -1e6 for the tight Gaussians far from a frame
+    err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+    assert err.max() <= 2e-6, err.max()
+    near = ref > -150
+    assert np.abs(got - ref)[near].max() <= 1e-4, np.abs(got - ref)[near].max()
+    assert near[:12, bad].diagonal().all()          # the frames drawn from the tight Gaussians see them
