@@ -91,6 +91,7 @@ void FeatureGenerator::build(const std::string &text, bool keep_modules) {
       FeatureModule *m;
       if (type == "audiofile") m = new AudioFileModule();
       else if (type == "pre") m = new PreModule();
+      else if (type == "vtln") m = new VtlnModule();
       else m = new FeatureModule();
       m_modules.emplace_back(m);
     }
@@ -302,6 +303,34 @@ void FeatureModule::set_parameters(const ModuleConfig &config) {
   if (aasr_feat_set_parameters(m_gen->handle(), m_name.c_str(), config.text().c_str()) != AASR_OK)
     throw std::string(aasr_last_error());
   m_gen->invalidate_block();  // every cached frame downstream is stale
+}
+
+// VtlnModule::set_warp_factor / set_slapt_warp (aku/FeatureModules.cc:1603-1622) through the
+// parameter block; "%.9g" so that the float arrives bit for bit
+void VtlnModule::set_warp_factor(float factor) {
+  char buf[64];
+  snprintf(buf, sizeof buf, "%.9g", (double)factor);
+  ModuleConfig c;
+  c.set("warp_factor", std::string(buf));
+  set_parameters(c);
+}
+void VtlnModule::set_slapt_warp(std::vector<float> &params) {
+  std::string v;
+  char buf[64];
+  for (size_t i = 0; i < params.size(); i++) {
+    snprintf(buf, sizeof buf, i ? " %.9g" : "%.9g", (double)params[i]);
+    v += buf;
+  }
+  ModuleConfig c;
+  c.set("slapt_coef", v);
+  set_parameters(c);
+}
+float VtlnModule::get_warp_factor(void) {
+  ModuleConfig c;
+  get_parameters(c);
+  float wf = 1.0f;
+  c.get("warp_factor", wf);
+  return wf;
 }
 
 void FeatureModule::get_parameters(ModuleConfig &config) {

@@ -1,7 +1,8 @@
 // FeatureModules.hh -- the module classes callers name explicitly: BaseFeaModule
 // (aku/BaseFeaModule.hh:10-27) with eof / sample_rate / frame_rate / last_frame, and its two
-// implementations AudioFileModule (aku/AudioFileModule.hh) and PreModule.  All other module
-// types of a graph are plain FeatureModule handles (their classes have no members callers use).
+// implementations AudioFileModule (aku/AudioFileModule.hh) and PreModule, and VtlnModule with its
+// warp-factor accessors.  All other module types of a graph are plain FeatureModule handles (their
+// classes have no members callers use).
 #ifndef AKU_AMD_FEATUREMODULES_HH
 #define AKU_AMD_FEATUREMODULES_HH
 
@@ -21,6 +22,16 @@ public:
 
 class AudioFileModule : public BaseFeaModule {};
 class PreModule : public BaseFeaModule {};
+
+/** aku/FeatureModules.hh:215-225: the warp factor of a `vtln` module as the VTLN estimation tool
+ * drives it (aku/vtln.cc:70-75); both go through the module's parameter block */
+class VtlnModule : public FeatureModule {
+public:
+  static const char *type_str() { return "vtln"; }
+  void set_warp_factor(float factor);
+  void set_slapt_warp(std::vector<float> &params);
+  float get_warp_factor(void);
+};
 
 }  // namespace aku
 

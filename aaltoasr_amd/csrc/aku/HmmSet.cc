@@ -1,5 +1,6 @@
 // HmmSet.cc -- see HmmSet.hh.
 #include "HmmSet.hh"
+#include "str.hh"
 
 #include <cmath>
 #include <cstdio>
@@ -53,7 +54,138 @@ bool HmmSet::read_ph(const std::string &filename) {
   }
   m_ph = filename;
   drop_model();
+  // the topology (aku/HmmSet.cc:183-205): "PHONE" first, anything else is a ReadError
+  std::ifstream in(filename.c_str());
+  std::string word;
+  in >> word;
+  if (word != "PHONE") throw ReadError();
+  m_hmm_map.clear();
+  m_hmms.clear();
+  m_states.clear();
+  m_transitions.clear();
+  read_legacy_ph(in);
   return true;  // legacy PHONE format is the only one the reference reads too
+}
+
+// aku/HmmSet.cc:208-329.  Per phone: "index states label", the two dummy states' numbers, one pdf
+// index per real state, then per source (dummies included) "source n" and n "target prob" pairs.
+// States are tied by their pdf: the first phone that mentions a pdf defines that state's
+// transitions (target 1 = the sink, stored as the offset that leaves the HMM), later mentions are
+// only checked.  States are then created in pdf order, transitions numbered state by state.
+void HmmSet::read_legacy_ph(std::ifstream &in) {
+  std::string label;
+  int phonemes = 0;
+  std::vector<std::vector<HmmTransition>> state_info;
+  in >> phonemes;
+  m_hmms.reserve(phonemes > 0 ? phonemes : 0);
+  for (int h = 0; h < phonemes; h++) {
+    int index = 0, states = 0;
+    in >> index >> states >> label;
+    if (!in) throw ReadError();
+    states -= 2;  // the dummy entry / exit states
+    Hmm &hmm = add_hmm(label, states);
+    int dummy, pdf;
+    std::vector<bool> load_transitions;
+    in >> dummy >> dummy;
+    for (int s = 0; s < states; s++) {
+      in >> pdf;
+      if (pdf >= (int)state_info.size()) state_info.resize((size_t)pdf + 1);
+      hmm.state(s) = pdf;
+      load_transitions.push_back(state_info[(size_t)pdf].empty());
+    }
+    for (int s = -2; s < states; s++) {
+      int transitions = 0, source = 0;
+      in >> source >> transitions;
+      source -= 2;
+      if (source >= states)
+        throw str::fmt(128, "HmmSet::read_legacy_ph: Invalid source state number %i (only %i states)", source,
+                       states);
+      for (int t = 0; t < transitions; t++) {
+        int target;
+        double prob;
+        in >> target >> prob;
+        if (prob <= 0)
+          throw str::fmt(128,
+                         "HmmSet::read_legacy_ph: Phone %i (%s) transition from %i to %i has nonpositive "
+                         "probability %f.",
+                         index, label.c_str(), source, target, prob);
+        if (source >= 0 && load_transitions[(size_t)source]) {
+          if (target == 1) {
+            target = states - source;  // the sink
+          } else {
+            target -= 2;
+            if (target > states)
+              throw str::fmt(128, "HmmSet::read_legacy_ph: Invalid target state number %i (only %i states)",
+                             source, states);
+            target -= source;  // relative
+          }
+          state_info[(size_t)hmm.state(source)].push_back(HmmTransition(hmm.state(source), target, prob));
+        }
+      }
+      if (source >= 0 && !load_transitions[(size_t)source])
+        for (const HmmTransition &tr : state_info[(size_t)hmm.state(source)])
+          if (source + tr.target_offset > states)
+            throw str::fmt(128,
+                           "HmmSet::read_legacy_ph: Invalid target state number %i on existing state %i (only "
+                           "%i states)",
+                           source, hmm.state(source), states);
+    }
+  }
+  for (int s = 0; s < (int)state_info.size(); s++) {
+    add_state(s);
+    for (const HmmTransition &tr : state_info[(size_t)s]) add_transition(s, tr.target_offset, tr.prob);
+  }
+}
+
+std::string Hmm::get_center_phone() {
+  const size_t minus = label.find_last_of('-'), plus = label.find_first_of('+');
+  std::string c;
+  if (minus != std::string::npos && plus != std::string::npos) {
+    if (plus > minus + 1) c = label.substr(minus + 1, plus - minus - 1);
+  } else if (minus != std::string::npos) {
+    c = label.substr(minus + 1);
+  } else if (plus != std::string::npos) {
+    c = label.substr(0, plus);
+  } else {
+    c = label;
+  }
+  if (c.empty()) throw std::string("Invalid phone label ") + label;
+  return c;
+}
+
+Hmm &HmmSet::new_hmm(const std::string &label) {
+  if (m_hmm_map.count(label)) throw DuplicateHmm();
+  m_hmm_map[label] = (int)m_hmms.size();
+  m_hmms.push_back(Hmm());
+  m_hmms.back().label = label;
+  return m_hmms.back();
+}
+
+Hmm &HmmSet::add_hmm(const std::string &label, int num_states) {
+  Hmm &h = new_hmm(label);
+  h.resize(num_states);
+  return h;
+}
+
+int HmmSet::hmm_index(const std::string &label) const {
+  const auto it = m_hmm_map.find(label);
+  if (it == m_hmm_map.end()) {
+    fprintf(stderr, "HmmSet::hmm_index(): unknown hmm '%s'\n", label.c_str());
+    throw UnknownHmm();
+  }
+  return it->second;
+}
+
+int HmmSet::add_transition(int source, int target, double prob) {
+  const int index = (int)m_transitions.size();
+  m_transitions.push_back(HmmTransition(source, target, prob));
+  m_states[(size_t)source].m_transitions.push_back(index);
+  return index;
+}
+
+int HmmSet::add_state(int pdf_index) {
+  m_states.push_back(HmmState(pdf_index));
+  return (int)m_states.size() - 1;
 }
 
 void HmmSet::read_all(const std::string &base) {
@@ -105,7 +237,10 @@ int HmmSet::num_states() {
   return aasr_gmm_num_states(m_gmm);
 }
 
-void HmmSet::reset_cache() { m_row = nullptr; }
+void HmmSet::reset_cache() {
+  m_row = nullptr;
+  for (ResetCacheInterface *o : m_reset_cache_objects) o->reset_cache();
+}
 
 int HmmSet::num_pool_pdfs() {
   ensure_model();

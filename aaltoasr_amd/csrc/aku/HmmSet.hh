@@ -13,6 +13,9 @@
 #define AKU_AMD_HMMSET_HH
 
 #include <exception>
+#include <fstream>
+#include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -24,6 +27,45 @@
 
 namespace aku {
 
+/** aku/HmmSet.hh:19-82: the topology half of the model -- states with their transitions, phone
+ * HMMs as lists of state indices.  Host-side data read from the .ph file; what the aligners
+ * (aku/Viterbi.cc, aku/PhnReader.cc, aku/HmmNetBaumWelch.cc) walk. */
+class HmmState {
+public:
+  HmmState() {}
+  HmmState(int pdf_index) : emission_pdf(pdf_index) {}
+  inline std::vector<int> &transitions() { return m_transitions; }
+  int emission_pdf = 0;             //!< index of the emission PDF
+  std::vector<int> m_transitions;   //!< indices into HmmSet::transition()
+};
+
+struct HmmTransition {
+  HmmTransition() {}
+  HmmTransition(int source, int target, double prob) : source_index(source), target_offset(target), prob(prob) {}
+  int source_index = 0;   //!< source state
+  int target_offset = 0;  //!< target relative to the source's position in its HMM
+  double prob = 0;
+};
+
+class Hmm {
+public:
+  std::string label;
+  void resize(int states) { m_states.resize(states); }
+  inline int num_states() const { return (int)m_states.size(); }
+  inline int &state(int index) { return m_states[index]; }
+  /** aku/HmmSet.cc:21-40: "a-b+c" -> "b" */
+  std::string get_center_phone();
+
+private:
+  std::vector<int> m_states;
+};
+
+/** aku/HmmSet.hh:86-89 */
+struct ResetCacheInterface {
+  virtual void reset_cache() = 0;
+  virtual ~ResetCacheInterface() {}
+};
+
 class HmmSet {
 public:
   struct OpenError : public std::exception {
@@ -32,6 +74,28 @@ public:
   struct ReadError : public std::exception {
     virtual const char *what() const throw() { return "HmmSet: read error"; }
   };
+  struct DuplicateHmm : public std::exception {
+    virtual const char *what() const throw() { return "HmmSet: duplicate hmm"; }
+  };
+  struct UnknownHmm : public std::exception {
+    virtual const char *what() const throw() { return "HmmSet: unknown hmm"; }
+  };
+
+  /** aku/HmmSet.hh:126-214 -- the HMM inventory of the .ph file (aku/HmmSet.cc:183-329) */
+  Hmm &new_hmm(const std::string &label);
+  Hmm &add_hmm(const std::string &label, int num_states);
+  int num_hmms() const { return (int)m_hmms.size(); }
+  Hmm &hmm(int hmm) { return m_hmms[hmm]; }
+  Hmm &hmm(const std::string &label) { return m_hmms[hmm_index(label)]; }
+  int hmm_index(const std::string &label) const;
+  HmmState &state(int state) { return m_states[state]; }
+  int add_transition(int source, int target, double prob);
+  int add_state(int pdf_index);
+  int num_transitions() const { return (int)m_transitions.size(); }
+  HmmTransition &transition(int t) { return m_transitions[t]; }
+  /** aku/HmmSet.hh:300-302: objects reset together with the likelihood cache */
+  void register_reset_cache_object(ResetCacheInterface *obj) { m_reset_cache_objects.insert(obj); }
+  void unregister_reset_cache_object(ResetCacheInterface *obj) { m_reset_cache_objects.erase(obj); }
 
   HmmSet();
   ~HmmSet();
@@ -60,7 +124,9 @@ public:
   PDF *get_pool_pdf(int index);
   Mixture *get_emission_pdf(int index);
   /** aku/HmmSet.hh:120: emission pdf of a state (the legacy .ph format: the state's own index) */
-  int emission_pdf_index(int state) const { return state; }
+  int emission_pdf_index(int state) const {
+    return state < (int)m_states.size() ? m_states[(size_t)state].emission_pdf : state;
+  }
 
   /** likelihoods for a raw vector (what the PDF / Mixture views call): the row of state
    * log-likelihoods, from the block cache when `x` is a frame of a generator's block */
@@ -93,6 +159,12 @@ public:
 private:
   void ensure_model();
   void drop_model();
+  void read_legacy_ph(std::ifstream &in);
+  std::map<std::string, int> m_hmm_map;
+  std::vector<Hmm> m_hmms;
+  std::vector<HmmState> m_states;
+  std::vector<HmmTransition> m_transitions;
+  std::set<ResetCacheInterface *> m_reset_cache_objects;
   std::string m_gk, m_mc, m_ph;
   aasr_gmm *m_gmm;
   // block cache

@@ -2,8 +2,10 @@
 // (aasr_recipe_read_all, csrc/pipeline.cc: the reference's line cleaning, key persistence,
 // batch walk and cluster_speakers rule): read(FILE*, num_batches, batch_index,
 // cluster_speakers), infos with every Info field, clear(), sort_infos().
-// Info::init_phn_files / init_hmmnet_files open the trainers' PhnReader / HmmNetBaumWelch and
-// are not part of the scoring path; they are not declared here.
+// Info::init_phn_files (aku/Recipe.cc:152-194) is declared when the aligners' PhnReader.hh is on
+// the include path -- i.e. when the reference's own aku/PhnReader.{hh,cc} / aku/Viterbi.{hh,cc} are
+// being compiled against these adapters (oracle/Makefile: align_refmain); init_hmmnet_files (the
+// Baum-Welch trainer) is not declared.
 #ifndef AKU_AMD_RECIPE_HH
 #define AKU_AMD_RECIPE_HH
 
@@ -14,6 +16,12 @@
 #include <vector>
 
 #include "FeatureGenerator.hh"
+#if defined(__has_include)
+#if __has_include("PhnReader.hh")
+#include "PhnReader.hh"
+#define AKU_AMD_HAVE_PHNREADER 1
+#endif
+#endif
 
 namespace aku {
 
@@ -36,6 +44,29 @@ public:
     std::string utterance_id;
 
     Info() : start_time(0), end_time(0), start_line(0), end_line(0) {}
+#ifdef AKU_AMD_HAVE_PHNREADER
+    /** aku/Recipe.cc:152-194: opens the audio (when fea_gen is given) and the transcript or
+     * alignment PHN file, with the recipe line's frame and line limits */
+    PhnReader *init_phn_files(HmmSet *model, bool relative_sample_nums, bool state_num_labels, bool out_phn,
+                              FeatureGenerator *fea_gen, PhnReader *phn_reader) {
+      float frame_rate = 125;
+      if (fea_gen != NULL) fea_gen->open(audio_path);
+      if (phn_reader == NULL) {
+        if (model == NULL)
+          throw std::string("recipe::Info::init_phn_files: HMM model is required if phn_reader==NULL");
+        phn_reader = new PhnReader(model);
+      }
+      phn_reader->set_state_num_labels(state_num_labels);
+      phn_reader->set_relative_sample_numbers(relative_sample_nums);
+      if (fea_gen != NULL) frame_rate = fea_gen->frame_rate();
+      phn_reader->set_frame_rate(frame_rate);
+      phn_reader->open(out_phn ? alignment_path : transcript_path);
+      if (start_time > 0 || end_time > 0)
+        phn_reader->set_frame_limits((int)(start_time * frame_rate), (int)(end_time * frame_rate));
+      if (start_line > 0 || end_line > 0) phn_reader->set_line_limits(start_line, end_line);
+      return phn_reader;
+    }
+#endif
     bool operator<(const Info &i) const { return (speaker_id < i.speaker_id); }
   };
 

@@ -52,4 +52,18 @@ void SpeakerConfig::set_utterance(const std::string &utterance_id) {
   m_cur_utterance = utterance_id;
 }
 
+void SpeakerConfig::write_speaker_file(FILE *file, std::set<std::string> *speakers, std::set<std::string> *utterances) {
+  ensure();
+  std::vector<const char *> sp, ut;
+  if (speakers) for (const std::string &x : *speakers) sp.push_back(x.c_str());
+  if (utterances) for (const std::string &x : *utterances) ut.push_back(x.c_str());
+  char *text = nullptr;
+  int64_t len = 0;
+  if (aasr_spkc_write_text(m_h, sp.data(), speakers ? (int32_t)sp.size() : -1, ut.data(),
+                           utterances ? (int32_t)ut.size() : -1, &text, &len) != AASR_OK)
+    throw std::string(aasr_last_error());
+  fwrite(text, 1, (size_t)len, file);
+  aasr_free(text);
+}
+
 }  // namespace aku

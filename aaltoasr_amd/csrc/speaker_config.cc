@@ -501,4 +501,45 @@ aasr_status aasr_spkc_set_utterance(aasr_spkc *h, const char *utterance_id) {
 
 int64_t aasr_spkc_num_changes(const aasr_spkc *h) { return h ? h->changes : 0; }
 
+aasr_status aasr_spkc_write_text(aasr_spkc *h, const char *const *speakers, int32_t n_speakers,
+                                 const char *const *utterances, int32_t n_utterances, char **text_out,
+                                 int64_t *text_len) {
+  return guarded([&] {
+    if (!h || !text_out || !text_len) raise(AASR_ERR_INVALID, "aasr_spkc_write_text: null argument");
+    // SpeakerConfig::write_speaker_file (aku/SpeakerConfig.cc:156-236): the current speaker's and
+    // utterance's module parameters are fetched first, then default speaker, speakers, default
+    // utterance, utterances -- each filtered by the given set (n < 0: no filter)
+    if (!h->cur_speaker.empty()) retrieve_speaker_config(h, h->cur_speaker);
+    if (!h->cur_utterance.empty()) retrieve_utterance_config(h, h->cur_utterance);
+    auto wanted = [](const char *const *set, int32_t n, const std::string &id) {
+      if (n < 0) return true;
+      for (int32_t i = 0; i < n; i++)
+        if (set && set[i] && id == set[i]) return true;
+      return false;
+    };
+    std::string t;
+    auto block = [&](const char *kind, const std::string &id, const aasr::ModuleMap &mods) {
+      t += std::string(kind) + " " + id + "\n{\n";
+      for (const auto &kv : mods) {
+        t += "  " + kv.first + "\n  {\n";  // ModuleConfig::write(file, 2) (aku/ModuleConfig.cc:204-222)
+        for (size_t i = 0; i < kv.second.names.size(); i++) t += "    " + kv.second.names[i] + " " + kv.second.values[i] + "\n";
+        t += "  }\n\n";
+      }
+      t += "}\n\n";
+    };
+    if (h->default_speaker_set && wanted(speakers, n_speakers, "default")) block("speaker", "default", h->default_speaker);
+    for (const auto &sp : h->speakers)
+      if (wanted(speakers, n_speakers, sp.first)) block("speaker", sp.first, sp.second);
+    if (h->default_utterance_set && wanted(utterances, n_utterances, "default"))
+      block("utterance", "default", h->default_utterance);
+    for (const auto &ut : h->utterances)
+      if (wanted(utterances, n_utterances, ut.first)) block("utterance", ut.first, ut.second);
+    char *out = (char *)malloc(t.size() + 1);
+    if (!out) raise(AASR_ERR_INVALID, "aasr_spkc_write_text: out of memory");
+    memcpy(out, t.c_str(), t.size() + 1);
+    *text_out = out;
+    *text_len = (int64_t)t.size();
+  });
+}
+
 }  // extern "C"

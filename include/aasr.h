@@ -425,6 +425,13 @@ aasr_status aasr_spkc_read_text(aasr_spkc *h, const char *text);
 /* SpeakerConfig::set_speaker / set_utterance; "" (or NULL) selects the default */
 aasr_status aasr_spkc_set_speaker(aasr_spkc *h, const char *speaker_id);
 aasr_status aasr_spkc_set_utterance(aasr_spkc *h, const char *utterance_id);
+/* SpeakerConfig::write_speaker_file (aku/SpeakerConfig.cc:156-236): the speaker file as text, with
+ * the current speaker's / utterance's module parameters fetched back first (what the adaptation
+ * tools -- vtln, mllr -- write after estimating).  speakers / utterances filter the entries by id
+ * ("default" names the default entries); a count < 0 writes all of them.  *text_out is malloc'ed. */
+aasr_status aasr_spkc_write_text(aasr_spkc *h, const char *const *speakers, int32_t n_speakers,
+                                 const char *const *utterances, int32_t n_utterances, char **text_out,
+                                 int64_t *text_len);
 /* number of times a module's device parameters were actually rewritten */
 int64_t aasr_spkc_num_changes(const aasr_spkc *h);
 

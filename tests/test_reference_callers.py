@@ -7,7 +7,12 @@ compiler on stdin, so that `#include "FeatureGenerator.hh"` and friends resolve 
 * GPU (uses oracle/_ref/{phone_probs,feacat}_refmain, the same sources LINKED with libaasr.so by
   oracle/Makefile in the build container; the binaries travel with the snapshot): the reference's
   main() running on the engine writes the same LNA files / feature dumps as the engine's own
-  tools."""
+  tools.
+* GPU: oracle/_ref/align_refmain -- the reference's forced aligner (aku/align.cc, Viterbi.cc,
+  Lattice.cc, PhnReader.cc with their own headers) on the engine's likelihoods -- finds the
+  segmentation a plain dynamic programme over the oracle's state likelihoods finds;
+  oracle/_ref/vtln_refmain -- the reference's VTLN warp-factor estimation (aku/vtln.cc) -- finds the
+  warp factors the data were made with and writes them as a speaker file."""
 import os
 import subprocess
 import wave
@@ -59,7 +64,7 @@ def test_decode_stream_acoustics_compile_against_the_adapters(tmp_path):
 
 @needs_ref
 def test_reference_mains_are_linked_with_the_engine(capi, oracle):
-    for name in ("phone_probs_refmain", "feacat_refmain"):
+    for name in ("phone_probs_refmain", "feacat_refmain", "align_refmain", "vtln_refmain"):
         assert os.access(os.path.join(REFBIN, name), os.X_OK), name
 
 
@@ -151,3 +156,204 @@ def test_reference_feacat_main_on_the_engine(world):
                            capture_output=True, timeout=300).stdout
     d = np.frombuffer(noisy, "<f4") - np.frombuffer(clean, "<f4")
     assert 0.4 < d.std() < 0.6 and abs(d.mean()) < 0.05
+
+
+@pytest.mark.gpu
+def test_reference_forced_aligner_on_the_engine(capi, oracle, tmp_path):
+    """aku/align.cc + Viterbi.cc + Lattice.cc + PhnReader.cc, the reference's text, compiled against
+    the adapters (HmmSet topology from the .ph file, lazy state_likelihood() after reset_cache(),
+    FeatureGenerator::generate / eof, Recipe::Info::init_phn_files) and linked with the engine: the
+    state segmentation of an utterance equals the best left-to-right path computed here from the
+    ORACLE's double-precision state likelihoods (frame 0 pinned to the first state, the end forced
+    to the last, every transition 0.5 as oracle.write_ph writes them)."""
+    exe = os.path.join(REFBIN, "align_refmain")
+    if not os.access(exe, os.X_OK):
+        pytest.skip("oracle/_ref/align_refmain was not built (no reference tree in the build container)")
+    rng = np.random.default_rng(17)
+    cfg_text = synth.make_feature_config()
+    cfg = str(tmp_path / "f.cfg")
+    open(cfg, "w").write(cfg_text)
+    pcm = synth.make_audio(16000 * 3, seed=71)
+    wav = str(tmp_path / "a.wav")
+    _write_wav(wav, pcm)
+    ft = capi.Feat(cfg_text)
+    T = ft.last_frame(len(pcm)) + 1
+    fea = ft.run(pcm, 0, T, dtype=np.float64)
+    # a model that fits the utterance (means drawn from its frames): likelihoods stay inside the float
+    # range the reference's Viterbi stores them in (aku/Viterbi.cc:243-258)
+    S, per = 40, 5
+    mean, var, off, idx, w = synth.make_model(D=39, G=120, S=S, comps=3, seed=23)
+    mean[:] = fea[rng.integers(0, T, 120)] + 0.3 * rng.standard_normal((120, 39))
+    var[:] = rng.uniform(0.6, 1.6, var.shape)
+    base = str(tmp_path / "m")
+    oracle.write_gk(base + ".gk", mean, var)
+    oracle.write_mc(base + ".mc", off, idx, w)
+    oracle.write_ph(base + ".ph", S, states_per_hmm=per)
+    labels = ["h3", "h0", "h7", "h2", "h5", "h1", "h3", "h6"]
+    open(tmp_path / "t.phn", "w").write("".join(l + "\n" for l in labels))
+    out_phn = str(tmp_path / "out.phn")
+    open(tmp_path / "r.recipe", "w").write("audio=%s transcript=%s alignment=%s\n" % (wav, tmp_path / "t.phn", out_phn))
+    r = subprocess.run([exe, "-b", base, "-c", cfg, "-r", str(tmp_path / "r.recipe"), "--beam", "100000", "--sbeam",
+                        "1000", "-i", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = [l.split() for l in open(out_phn).read().splitlines() if l.strip()]
+    # expected path
+    states = [int(l[1:]) * per + j for l in labels for j in range(per)]
+    names = ["%s.%d" % (l, j) for l in labels for j in range(per)]
+    P = len(states)
+    ll = oracle.DiagModel(mean, var, off, idx, w).score(fea)[:, states]         # [T x P]
+    assert ll.max(axis=1).min() > -80                                             # inside float range
+    V = np.full((T, P), -np.inf)
+    back = np.zeros((T, P), np.int64)
+    V[0, 0] = 0.0
+    lh = np.log(0.5)
+    for t in range(1, T):
+        stay = V[t - 1] + lh
+        move = np.concatenate(([-np.inf], V[t - 1, :-1] + lh))
+        back[t] = np.where(move >= stay, np.arange(P) - 1, np.arange(P))
+        V[t] = np.maximum(stay, move) + (ll[t] - ll[t].max())
+    pos = np.zeros(T, np.int64)
+    pos[-1] = P - 1
+    for t in range(T - 1, 0, -1):
+        pos[t - 1] = back[t, pos[t]]
+    assert pos[0] == 0
+    first = [int(np.argmax(pos == p)) for p in range(P)]
+    assert [g[2] for g in got] == names
+    assert [int(g[0]) for g in got] == [f * 128 for f in first]
+    assert [int(g[1]) for g in got[:-1]] == [f * 128 for f in first[1:]]
+    assert "File log likelihood" in r.stderr
+
+
+VTLN_CFG = """module
+{
+  name audiofile
+  type audiofile
+  sample_rate 16000
+}
+module
+{
+  name fft
+  type fft
+  magnitude 0
+  sources audiofile
+}
+module
+{
+  name vtln
+  type vtln
+  sources fft
+}
+module
+{
+  name mel
+  type mel
+  sources vtln
+}
+module
+{
+  name mfcc
+  type dct
+  dim 12
+  sources mel
+}
+module
+{
+  name d1
+  type delta
+  sources mfcc
+}
+module
+{
+  name merged
+  type merge
+  sources mfcc d1
+}
+"""
+
+
+@pytest.mark.gpu
+def test_reference_vtln_estimation_on_the_engine(capi, oracle, tmp_path):
+    """aku/vtln.cc (with aku/PhnReader.cc as its Segmentator), the reference's text, on the engine:
+    per speaker a grid of warp factors through VtlnModule::set_warp_factor, the log-likelihood of a
+    given state segmentation under each (HmmSet::pdf_likelihood), the summary file and the speaker
+    file SpeakerConfig::write_speaker_file writes with the best factors -- against the oracle's
+    feature chain (its vtln restatement) and double-precision state likelihoods."""
+    exe = os.path.join(REFBIN, "vtln_refmain")
+    if not os.access(exe, os.X_OK):
+        pytest.skip("oracle/_ref/vtln_refmain was not built (no reference tree in the build container)")
+    rng = np.random.default_rng(29)
+    cfg = str(tmp_path / "f.cfg")
+    open(cfg, "w").write(VTLN_CFG)
+    D = 24
+    chain = oracle.FeatureChain(VTLN_CFG)
+    speakers = {"spkA": np.float32(1.04), "spkB": np.float32(0.96)}
+    pcms, feats = {}, {}
+    for i, (spk, wf) in enumerate(speakers.items()):
+        pcms[spk] = synth.make_audio(16000 * 2, seed=90 + i)
+        _write_wav(str(tmp_path / (spk + ".wav")), pcms[spk])
+        T = chain.last_frame(len(pcms[spk])) + 1
+        chain.set_parameters("vtln", {"warp_factor": "%.9g" % wf})
+        feats[spk] = chain.generate(pcms[spk], 0, T)
+    # a model drawn from the speakers' features AT their true warp: the grid must find it back
+    S, G = 24, 72
+    mean, var, off, idx, w = synth.make_model(D=D, G=G, S=S, comps=3, seed=31)
+    allf = np.vstack(list(feats.values()))
+    scale = allf.std(axis=0)
+    mean[:] = allf[rng.integers(0, len(allf), G)] + 0.2 * scale * rng.standard_normal((G, D))
+    var[:] = (scale * rng.uniform(0.7, 1.3, (G, D))) ** 2
+    base = str(tmp_path / "m")
+    oracle.write_gk(base + ".gk", mean, var)
+    oracle.write_mc(base + ".mc", off, idx, w)
+    oracle.write_ph(base + ".ph", S, states_per_hmm=3)
+    om = oracle.DiagModel(mean, var, off, idx, w)
+    # per speaker a state segmentation (state-number labels): the best state of each 10-frame stretch
+    seg, lines = {}, []
+    for spk in speakers:
+        T = len(feats[spk]) - 2
+        ll = om.score(feats[spk])
+        st = [int(ll[a:a + 10].sum(axis=0).argmax()) for a in range(0, T, 10)]
+        seg[spk] = (T, st)
+        with open(tmp_path / (spk + ".phn"), "w") as f:
+            for k, s in enumerate(st):
+                f.write("%d %d %d\n" % (k * 10 * 128, min((k + 1) * 10, T) * 128, s))
+        lines.append("audio=%s transcript=%s speaker=%s" % (tmp_path / (spk + ".wav"), tmp_path / (spk + ".phn"), spk))
+    open(tmp_path / "r.recipe", "w").write("\n".join(lines) + "\n")
+    open(tmp_path / "in.spkc", "w").write("speaker default\n{\n  feature vtln\n  {\n  }\n}\n")
+    out_spkc, summ = str(tmp_path / "out.spkc"), str(tmp_path / "sum.txt")
+    r = subprocess.run([exe, "-b", base, "-c", cfg, "-r", str(tmp_path / "r.recipe"), "-v", "vtln", "-S",
+                        str(tmp_path / "in.spkc"), "-o", out_spkc, "-s", summ, "--snl", "--grid-size", "5",
+                        "--grid-rad", "0.04"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # expected: the reference's float grid arithmetic (aku/vtln.cc:70-73, 224-226)
+    grid_start = np.float32(0.04)
+    grid_step = np.float32(2) * grid_start / np.float32(4)
+    grid_start = -grid_start
+    got, cur = {}, None
+    for line in open(summ).read().splitlines():
+        if line.startswith("["):
+            cur = line.strip("[]")
+            got[cur] = []
+        elif line.strip():
+            a, b = line.split(":")
+            got[cur].append((float(a), float(b)))
+    assert set(got) == set(speakers)
+    for spk, true_wf in speakers.items():
+        T, st = seg[spk]
+        want = []
+        for it in range(5):
+            wf = np.float32(np.float32(1) + grid_start + np.float32(it) * grid_step)
+            chain.set_parameters("vtln", {"warp_factor": "%.9g" % wf})
+            f = chain.generate(pcms[spk], 0, T)
+            ll = om.score(f)
+            total = sum(float(ll[t, st[t // 10]]) for t in range(T))
+            want.append((float(wf), total))
+        assert len(got[spk]) == 5
+        for (gw, gl), (ww, wl) in zip(got[spk], want):
+            assert abs(gw - ww) < 5e-4 and abs(gl - wl) <= 2e-3 + 1e-6 * abs(wl), (spk, gw, ww, gl, wl)
+        best = max(want, key=lambda x: x[1])[0]
+        assert abs(best - float(true_wf)) < 1e-6, (spk, want)
+    text = open(out_spkc).read()
+    assert "speaker default" in text
+    for spk, true_wf in speakers.items():
+        block = text.split("speaker %s\n" % spk)[1].split("}\n\n}")[0]
+        assert "feature vtln" in block and ("warp_factor %g" % float(true_wf)) in block, block
