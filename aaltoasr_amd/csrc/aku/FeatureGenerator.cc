@@ -92,6 +92,9 @@ void FeatureGenerator::build(const std::string &text, bool keep_modules) {
       if (type == "audiofile") m = new AudioFileModule();
       else if (type == "pre") m = new PreModule();
       else if (type == "vtln") m = new VtlnModule();
+      else if (type == "normalization") m = new NormalizationModule();
+      else if (type == "lin_transform") m = new LinTransformModule();
+      else if (type == "quanteq") m = new QuantEqModule();
       else m = new FeatureModule();
       m_modules.emplace_back(m);
     }
@@ -325,6 +328,81 @@ void VtlnModule::set_slapt_warp(std::vector<float> &params) {
   c.set("slapt_coef", v);
   set_parameters(c);
 }
+static std::string exact_floats(const std::vector<float> &v) {
+  std::string t;
+  char buf[64];
+  for (size_t i = 0; i < v.size(); i++) {
+    snprintf(buf, sizeof buf, i ? " %.9g" : "%.9g", (double)v[i]);
+    t += buf;
+  }
+  return t;
+}
+
+// one key of the module's parameter block replaced (an empty vector removes it), the others kept
+static void set_one_parameter(FeatureModule *m, const char *key, const std::vector<float> &v) {
+  ModuleConfig cur, next;
+  m->get_parameters(cur);
+  std::vector<std::string> names;
+  cur.get_names(names);
+  for (const std::string &n : names) {
+    if (n == key) continue;
+    std::string val;
+    cur.get(n, val);
+    next.set(n, val);
+  }
+  if (!v.empty()) next.set(key, exact_floats(v));
+  m->set_parameters(next);
+}
+
+// aku/FeatureModules.cc:1123-1133
+void NormalizationModule::set_normalization(const std::vector<float> &mean, const std::vector<float> &scale) {
+  if ((int)mean.size() != m_dim || (int)scale.size() != m_dim)
+    throw std::string("NormalizationModule: The dimension of the new normalization does not match the input dimension");
+  ModuleConfig c;
+  c.set("mean", exact_floats(mean));
+  c.set("scale", exact_floats(scale));
+  set_parameters(c);
+}
+
+// aku/FeatureModules.cc:1273-1322: an empty vector puts the identity / zero bias back
+void LinTransformModule::set_transformation_matrix(std::vector<float> &t) {
+  const int src_dim = m_sources.empty() ? m_dim : m_sources.front()->dim();
+  if (!t.empty() && (int)t.size() != m_dim * src_dim)
+    throw std::string("LinTransformnModule: The dimension of the new transformation matrix does not match the old dimension");
+  set_one_parameter(this, "matrix", t);
+}
+void LinTransformModule::set_transformation_bias(std::vector<float> &b) {
+  if (!b.empty() && (int)b.size() != m_dim)
+    throw std::string("LinTransformnModule: The dimension of the new bias does not match the output dimension");
+  set_one_parameter(this, "bias", b);
+}
+const std::vector<float> *LinTransformModule::get_transformation_matrix(void) {
+  ModuleConfig c;
+  get_parameters(c);
+  m_transform.clear();
+  c.get("matrix", m_transform);
+  return &m_transform;
+}
+const std::vector<float> *LinTransformModule::get_transformation_bias(void) {
+  ModuleConfig c;
+  get_parameters(c);
+  m_bias.clear();
+  c.get("bias", m_bias);
+  return &m_bias;
+}
+
+// aku/FeatureModules.cc:2104-2120
+void QuantEqModule::set_alpha(std::vector<float> &alpha) { set_one_parameter(this, "alpha", alpha); }
+void QuantEqModule::set_gamma(std::vector<float> &gamma) { set_one_parameter(this, "gamma", gamma); }
+void QuantEqModule::set_quant_max(std::vector<float> &quant_max) { set_one_parameter(this, "quant_max", quant_max); }
+std::vector<float> QuantEqModule::get_quant_train(void) {
+  ModuleConfig c;
+  get_config(c);
+  std::vector<float> q;
+  c.get("quant_train", q);
+  return q;
+}
+
 float VtlnModule::get_warp_factor(void) {
   ModuleConfig c;
   get_parameters(c);

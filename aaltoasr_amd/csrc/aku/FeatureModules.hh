@@ -33,6 +33,37 @@ public:
   float get_warp_factor(void);
 };
 
+/** aku/FeatureModules.hh:129-144, 147-171, 279-301: the module classes whose parameters the
+ * estimation tools set directly (feanorm: set_normalization / set_transformation_matrix, quanteq:
+ * set_alpha / set_gamma / set_quant_max).  Each setter goes through the module's parameter block
+ * (floats as "%.9g", i.e. bit for bit); the arithmetic stays on the device. */
+class NormalizationModule : public FeatureModule {
+public:
+  static const char *type_str() { return "normalization"; }
+  void set_normalization(const std::vector<float> &mean, const std::vector<float> &scale);
+};
+
+class LinTransformModule : public FeatureModule {
+public:
+  static const char *type_str() { return "lin_transform"; }
+  const std::vector<float> *get_transformation_matrix(void);
+  const std::vector<float> *get_transformation_bias(void);
+  void set_transformation_matrix(std::vector<float> &t);
+  void set_transformation_bias(std::vector<float> &b);
+
+private:
+  std::vector<float> m_transform, m_bias;  // what the accessors point to
+};
+
+class QuantEqModule : public FeatureModule {
+public:
+  static const char *type_str() { return "quanteq"; }
+  void set_alpha(std::vector<float> &alpha);
+  void set_gamma(std::vector<float> &gamma);
+  void set_quant_max(std::vector<float> &quant_max);
+  std::vector<float> get_quant_train(void);
+};
+
 }  // namespace aku
 
 #endif

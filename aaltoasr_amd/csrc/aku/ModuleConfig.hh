@@ -118,6 +118,8 @@ class ModuleConfig {
     }
   }
   int num_lines_read() const { return m_lines; }
+  /** the option names in insertion order (adapter-side helper) */
+  void get_names(std::vector<std::string> &names) const { names = m_names; }
 
   void write(FILE *file, int indent = 0) const { fputs(text(indent).c_str(), file); }
   /** the block as text (what write() prints) */

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "FeatureGenerator.hh"
+#include "FeatureModules.hh"
 #include "HmmSet.hh"
 #include "SpeakerConfig.hh"
 
@@ -155,6 +156,63 @@ static int dist_mode(const char *cfg, const char *base, const char *audio, const
 }
 
 int main(int argc, char **argv) {
+  if (argc == 5 && std::string(argv[1]) == "setters") {
+    // aku_adapter_check setters CFG AUDIO OUT: the module classes the estimation tools reach through
+    // dynamic_cast (aku/feanorm.cc:72-101, 264, 380; aku/vtln.cc:208): NormalizationModule::
+    // set_normalization, LinTransformModule::set_transformation_matrix / _bias / get_*, VtlnModule::
+    // set_warp_factor / get_warp_factor.  The values are fixed functions of the index so that the
+    // test can apply the same ones to the oracle; OUT = 8 output frames as "%.17g".
+    aku::FeatureGenerator gen;
+    FILE *cf = fopen(argv[2], "r");
+    if (!cf) throw std::string("could not open config");
+    gen.load_configuration(cf);
+    fclose(cf);
+    gen.open(argv[3]);
+    aku::NormalizationModule *norm = dynamic_cast<aku::NormalizationModule *>(gen.module("norm"));
+    aku::LinTransformModule *lin = dynamic_cast<aku::LinTransformModule *>(gen.module("mllr"));
+    aku::VtlnModule *vtln = dynamic_cast<aku::VtlnModule *>(gen.module("vtln"));
+    if (!norm || !lin || !vtln) throw std::string("module classes missing");
+    if (dynamic_cast<aku::VtlnModule *>(gen.module("norm"))) throw std::string("wrong class");
+    const int d = norm->dim();
+    std::vector<float> mean(d), scale(d), mat((size_t)d * d), bias(d);
+    for (int i = 0; i < d; i++) {
+      mean[i] = 0.1f * (float)i - 0.7f;
+      scale[i] = 1.0f / (1.0f + 0.03f * (float)i);
+      bias[i] = 0.01f * (float)(i % 5) - 0.02f;
+      for (int j = 0; j < d; j++) mat[(size_t)i * d + j] = (i == j ? 1.0f : 0.0f) + 0.001f * (float)((i * 7 + j * 3) % 11);
+    }
+    norm->set_normalization(mean, scale);
+    lin->set_transformation_matrix(mat);
+    lin->set_transformation_bias(bias);
+    vtln->set_warp_factor(1.0f + 0.03f);
+    bool dim_thrown = false;
+    try {
+      std::vector<float> bad(3);
+      norm->set_normalization(bad, bad);
+    } catch (std::string &) {
+      dim_thrown = true;
+    }
+    FILE *out = fopen(argv[4], "w");
+    if (!out) throw std::string("could not open output");
+    fprintf(out, "%d %.9g %d %d\n", dim_thrown ? 1 : 0, (double)vtln->get_warp_factor(),
+            (int)lin->get_transformation_matrix()->size(), (int)lin->get_transformation_bias()->size());
+    for (int f = 0; f < 8; f++) {
+      const aku::FeatureVec v = gen.generate(f);
+      for (int i = 0; i < v.dim(); i++) fprintf(out, "%.17g ", v[i]);
+      fprintf(out, "\n");
+    }
+    // an empty matrix puts the identity back (aku/FeatureModules.cc:1276-1285)
+    std::vector<float> none;
+    lin->set_transformation_matrix(none);
+    lin->set_transformation_bias(none);
+    for (int f = 0; f < 2; f++) {
+      const aku::FeatureVec v = gen.generate(f);
+      for (int i = 0; i < v.dim(); i++) fprintf(out, "%.17g ", v[i]);
+      fprintf(out, "\n");
+    }
+    fclose(out);
+    return 0;
+  }
   if (argc == 4 && std::string(argv[1]) == "stream") {
     // aku_adapter_check stream CFG OUT < raw PCM16: decode-stream.cc's reading loop
     // (decoder/decode-stream.cc:81, 238-276: gen.open(stdin, true, true); generate(f) until eof()).

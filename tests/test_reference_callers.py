@@ -40,7 +40,7 @@ def _syntax_check(text, tmp_path):
 
 
 @needs_ref
-@pytest.mark.parametrize("src", ["aku/phone_probs.cc", "aku/feacat.cc"])
+@pytest.mark.parametrize("src", ["aku/phone_probs.cc", "aku/feacat.cc", "aku/feadot.cc", "aku/segfea.cc", "aku/quanteq.cc"])
 def test_reference_tool_sources_compile_against_the_adapters(src, tmp_path):
     _syntax_check(open(os.path.join(REF, src)).read(), tmp_path)
 

@@ -349,3 +349,45 @@ def test_speakers_with_gaussian_clustering(capi, oracle, world, tmp_path):
         assert ok.mean() > 0.2 and np.abs(got - ll)[ok].max() <= 1e-4, (i, spk)
     with pytest.raises(capi.AasrError, match="per-class model-side CMLLR together with Gaussian clustering"):
         sc.set_speaker("carl")
+
+
+def test_module_classes_set_parameters_directly(capi, oracle, world, tmp_path):
+    """NormalizationModule::set_normalization, LinTransformModule::set_transformation_matrix / _bias,
+    VtlnModule::set_warp_factor (aku/FeatureModules.cc:1123-1133, 1273-1322, 1603-1612) reached
+    through dynamic_cast as aku/feanorm.cc and aku/vtln.cc do: the generator's output afterwards is
+    the oracle chain's with the same float parameters; an empty matrix / bias restores the identity."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aaltoasr_amd", "lib", "bin",
+                       "aku_adapter_check")
+    cfg = str(tmp_path / "f.cfg")
+    open(cfg, "w").write(CFG)
+    pcm = synth.make_audio(16000, seed=5)
+    wav = str(tmp_path / "a.wav")
+    import wave
+    with wave.open(wav, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.astype("<i2").tobytes())
+    out = str(tmp_path / "o.txt")
+    r = subprocess.run([exe, "setters", cfg, wav, out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = open(out).read().splitlines()
+    head = lines[0].split()
+    assert head[0] == "1" and abs(float(head[1]) - float(np.float32(1.0) + np.float32(0.03))) < 1e-7
+    assert int(head[2]) == D * D and int(head[3]) == D
+    i = np.arange(D, dtype=np.float32)
+    mean = np.float32(0.1) * i - np.float32(0.7)
+    scale = np.float32(1.0) / (np.float32(1.0) + np.float32(0.03) * i)
+    bias = np.float32(0.01) * (np.arange(D) % 5).astype(np.float32) - np.float32(0.02)
+    mat = np.eye(D, dtype=np.float32) + np.float32(0.001) * ((np.arange(D)[:, None] * 7 + np.arange(D)[None, :] * 3) % 11).astype(np.float32)
+    vec = lambda v: " ".join("%.9g" % x for x in np.asarray(v, np.float32).ravel())
+    chain = oracle.FeatureChain(CFG)
+    chain.set_parameters("norm", {"mean": vec(mean), "scale": vec(scale)})
+    chain.set_parameters("mllr", {"matrix": vec(mat), "bias": vec(bias)})
+    chain.set_parameters("vtln", {"warp_factor": "%.9g" % (np.float32(1.0) + np.float32(0.03))})
+    want = chain.generate(pcm, 0, 8)
+    got = np.array([[float(x) for x in l.split()] for l in lines[1:9]])
+    assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+    chain.set_parameters("mllr", {})
+    want2 = chain.generate(pcm, 0, 2)
+    got2 = np.array([[float(x) for x in l.split()] for l in lines[9:11]])
+    assert np.abs(got2 - want2).max() <= 1e-5 * max(1.0, np.abs(want2).max())
+    assert np.abs(got2 - got[:2]).max() > 1e-3
