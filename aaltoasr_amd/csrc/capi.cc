@@ -273,15 +273,6 @@ aasr_status aasr_gmm_set_cmllr(aasr_gmm *h, int32_t n_transforms,
       for (int64_t i = 0; i < h->G; i++)
         if (gauss_to_transform[i] < -1 || gauss_to_transform[i] >= n_transforms)
           raise(AASR_ERR_INVALID, "transform index %d out of range", gauss_to_transform[i]);
-    if (n_transforms > 0 && h->cl.loaded) {
-      // with Gaussian clustering only one transform for the whole pool is built (the masked track
-      // kernels take the adapted frames and the determinant at their output)
-      bool global = n_transforms == 1;
-      for (int64_t i = 0; i < h->G && global; i++) global = gauss_to_transform[i] == 0;
-      if (!global)
-        raise(AASR_ERR_UNSUPPORTED, "per-class model-side CMLLR together with Gaussian clustering is not built "
-                                    "(one global transform is)");
-    }
     gmm_set_transforms(h, n_transforms, gauss_to_transform, W);
   });
 }

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdint>
 #include <string>
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -249,6 +250,7 @@ struct aasr_gmm {
   int hyb_max_splits = 1;
   aasr::DevBuf<int32_t> hyb_map;           // [hyb_states] -> state index
   std::vector<int32_t> hyb_comps;          // mixture-component index of every outlier record (host)
+  std::vector<int32_t> parent_gauss;       // a class sub-model: parent pool index of each of its Gaussians
   aasr::DevBuf<float> hyb_scratch;         // [frames of a pass][hyb_states]
   // Global constrained MLLR without re-packing: the rows stay those of the unadapted model
   // (rows_unbiased) and log|det| is added to every score at the kernels' output (out_bias_ln)
@@ -301,6 +303,12 @@ void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
 void gmm_read_clustering(aasr_gmm *g, const char *path);
 void gmm_set_clustering_min_evals(aasr_gmm *g, double min_clusters, double min_gaussians);
 const float *gmm_adapted_frames(aasr_gmm *g, const float *d_frames, int64_t F, hipStream_t stream);
+// Clustered pass over per-class transforms: for every class with components, `exact` writes the
+// class sub-model's exact part on the class's adapted frames into a scratch; the parts are added
+// into out with the class's log|det| (no floors).
+void gmm_classes_exact_launch(aasr_gmm *g, const float *d_frames, int64_t n, float *d_out,
+                              const std::function<void(aasr_gmm *, size_t, const float *, float *)> &exact,
+                              hipStream_t stream);
 void gmm_outliers_masked_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, const int32_t *crow,
                                 const unsigned long long *maskw, int c1, int64_t n_words, hipStream_t stream);
 void gmm_centred_masked_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, const int32_t *crow,

@@ -630,9 +630,7 @@ void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
     return;
   }
   const HostModel &m = g->host;
-  if (m.any_full() || (m.n_transforms > 0 && !m.global_xform()))
-    raise(AASR_ERR_UNSUPPORTED,
-          "Gaussian clustering is built for diagonal pools, unadapted or under one global CMLLR transform");
+  if (m.any_full()) raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering is built for diagonal pools");
   if (n_clusters > 0.3 * (double)m.G)
     raise(AASR_ERR_INVALID,
           "PDFPool::read_clustering(): Number of clusters (%d) seems insensible compared to the "
@@ -641,7 +639,7 @@ void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
     raise(AASR_ERR_UNSUPPORTED, "more than 4096 clusters are not built (%d asked)", n_clusters);
   if (n_pairs > 0 && (!gauss_index || !cluster_index))
     raise(AASR_ERR_INVALID, "aasr_gmm_set_clustering: null argument");
-  if (!g->paired.ok && !g->tracks.ok && !g->centred_ok)
+  if (!g->class_routing && !g->paired.ok && !g->tracks.ok && !g->centred_ok)
     raise(AASR_ERR_UNSUPPORTED,
           "Gaussian clustering needs the fixed-reference track kernels or the centred kernel, and this "
           "model has neither");
@@ -716,6 +714,8 @@ void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
   if (g->paired.ok) build_crow(g, g->paired, n, n.crow[0]);
   if (g->tracks.ok) build_crow(g, g->tracks, n, n.crow[1]);
   n.loaded = true;
+  for (auto &sub : g->class_models)
+    if (sub) sub->cl = ClusterState();  // the classes' views of the previous clustering
   // thresholds and the on/off state survive a re-read like the reference's members do
   n.enabled = cl.enabled;
   n.min_clusters = cl.min_clusters;
@@ -895,47 +895,107 @@ static void launch_merge(aasr_gmm *g, float *d_out, int64_t F, hipStream_t strea
   else launch_merge_t<16>(g, d_out, F, stream);   // weights beyond 16 per state come from L2
 }
 
+// What a model's exact part needs besides the selection bits: the cluster of each of ITS rows /
+// records (cl.crow*, built on first use from cl.g2c) and the expanded lane masks (cl.maskrow).
+// Models the expanded form cannot hold (gmm.h, KAPPA_LIMIT): the exact values of the ill-conditioned
+// Gaussians -- a minority next to the masked track kernel (outlier routing), or the whole model --
+// come from the centred kernel under the same bits.
+struct ExactPlan {
+  bool all_centred, with_outliers;
+  int which;
+  int64_t mask_rows;
+};
+
+static ExactPlan exact_part_plan(aasr_gmm *g, ClusterState &cl) {
+  ExactPlan p;
+  p.all_centred = g->ill_conditioned || (!g->paired.ok && !g->tracks.ok);
+  p.with_outliers = g->hyb_enabled && !p.all_centred;
+  if (p.all_centred && !g->centred_ok)
+    raise(AASR_ERR_UNSUPPORTED, "no centred kernel instance for dimension %d", g->dim);
+  // the layout the exact part runs on: grouped unless it is missing or masked out
+  p.which = (g->paired.ok && ((g->layout_mask & 1) || !g->tracks.ok)) ? 0 : 1;
+  const TrackLayout &L = p.which == 0 ? g->paired : g->tracks;
+  if (!p.all_centred && !L.ok) raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering needs a track layout for this model");
+  if (!p.all_centred && cl.crow[p.which].n != L.row_gauss.size()) build_crow(g, L, cl, cl.crow[p.which]);
+  p.mask_rows = p.all_centred ? 0 : L.rows_padded;  // the centred kernel reads the cluster bits themselves
+  if (p.with_outliers && cl.crow_hyb.n != std::max<size_t>(g->hyb_comps.size(), 1))
+    build_crow_comps(g, g->hyb_comps, cl, cl.crow_hyb);
+  if (p.all_centred && cl.crow_centred.n != std::max<size_t>(g->host.mix_idx.size(), 1))
+    build_crow_comps(g, std::vector<int32_t>(), cl, cl.crow_centred);
+  return p;
+}
+
+// out[f][s] = log of the sum over s's components whose cluster is evaluated exactly for frame f (no floor)
+static void exact_part_launch(aasr_gmm *g, ClusterState &cl, const ExactPlan &p, const unsigned long long *maskw,
+                              int c1, int64_t n, const float *fr_members, float *out, hipStream_t stream) {
+  const int64_t words = (n + 63) / 64;
+  if (p.all_centred) {
+    gmm_centred_masked_launch(g, fr_members, n, out, cl.crow_centred.p, maskw, c1, words, stream);
+    return;
+  }
+  const TrackLayout &L = p.which == 0 ? g->paired : g->tracks;
+  // the track kernels read the lane masks of whole workgroups (up to 512 frames = 8 words)
+  cl.maskrow.ensure((size_t)((n + 511) / 512 * 8) * (size_t)L.rows_padded);
+  const int64_t n_tiles = L.rows_padded / TILE_ROWS;
+  const int tpb = (int)std::min<int64_t>(n_tiles, 64);  // the staged cluster masks serve 64 tiles
+  hipLaunchKernelGGL(k_cluster_expand, dim3((unsigned)((n_tiles + tpb - 1) / tpb), (unsigned)words), dim3(256),
+                     (size_t)(c1 + kExpandTiles * TILE_ROWS) * 8, stream, maskw, c1, cl.crow[p.which].p, L.rows_padded, tpb,
+                     cl.maskrow.p);
+  AASR_HIP(hipGetLastError());
+  gmm_tracks_masked_launch(g, p.which, fr_members, n, out, cl.maskrow.p, stream);
+  if (p.with_outliers) gmm_outliers_masked_launch(g, fr_members, n, out, cl.crow_hyb.p, maskw, c1, words, stream);
+}
+
 void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                               hipStream_t stream) {
   ClusterState &cl = g->cl;
-  if (g->host.factor_path() || g->class_routing)
-    raise(AASR_ERR_UNSUPPORTED,
-          "Gaussian clustering is built for diagonal pools, unadapted or under one global CMLLR transform "
-          "(per-class transforms are not)");
+  if (g->host.any_full() || (g->host.factor_path() && !g->class_routing))
+    raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering is built for diagonal pools");
   // One global constrained-MLLR transform: the pool's Gaussians are AdaptedGaussians -- members are
   // evaluated on A f + b and scaled by |det| (the track kernels' output bias) -- while the cluster
   // centres are plain Gaussians on the frame itself (aku/ModelModules.hh:164-173,
   // aku/Distributions.cc:2688-2691): the centre kernel gets the frames, the masked scoring kernel
-  // the adapted ones.
-  const float *d_members = g->xf_a.p ? gmm_adapted_frames(g, d_frames, F, stream) : d_frames;
-  // Models the expanded form cannot hold (gmm.h, KAPPA_LIMIT): the exact part of the ill-conditioned
-  // Gaussians -- a minority next to the masked track kernel (outlier routing), or the whole model --
-  // comes from the centred kernel under the same selection bits.  Not combined with a transform (the
-  // determinant would have to ride on the centred records).
-  const bool all_centred = g->ill_conditioned || (!g->paired.ok && !g->tracks.ok);
-  const bool with_outliers = g->hyb_enabled && !all_centred;
-  if ((all_centred || with_outliers) && g->xf_a.p)
-    raise(AASR_ERR_UNSUPPORTED,
-          "Gaussian clustering under a CMLLR transform is not built for models that need the centred kernel "
-          "(kappa %.0f)", g->kappa);
-  if (all_centred && !g->centred_ok)
-    raise(AASR_ERR_UNSUPPORTED, "no centred kernel instance for dimension %d", g->dim);
-  // the layout the exact part runs on: grouped unless it is missing or masked out
-  const int which = (g->paired.ok && ((g->layout_mask & 1) || !g->tracks.ok)) ? 0 : 1;
-  const TrackLayout &L = which == 0 ? g->paired : g->tracks;
-  if (!all_centred && !L.ok) raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering needs a track layout for this model");
-  if (!all_centred && cl.crow[which].n != L.row_gauss.size()) build_crow(g, L, cl, cl.crow[which]);
-  const int64_t mask_rows = all_centred ? 0 : L.rows_padded;  // the centred kernel reads the cluster bits themselves
-  if (with_outliers && cl.crow_hyb.n != std::max<size_t>(g->hyb_comps.size(), 1))
-    build_crow_comps(g, g->hyb_comps, cl, cl.crow_hyb);
-  if (all_centred && cl.crow_centred.n != std::max<size_t>(g->host.mix_idx.size(), 1))
-    build_crow_comps(g, std::vector<int32_t>(), cl, cl.crow_centred);
+  // the adapted ones.  Per-class transforms (class routing, gmm.h): every class's sub-model gives
+  // its exact part on its own adapted frames, the parts are added with their log|det|, then the
+  // centres' share of ALL components enters in the merge.
+  const bool classes = g->class_routing;
+  const float *d_members = (!classes && g->xf_a.p) ? gmm_adapted_frames(g, d_frames, F, stream) : d_frames;
+  ExactPlan plan{};
+  std::vector<ExactPlan> sub_plans;
+  int64_t mask_rows = 0;
+  if (classes) {
+    sub_plans.resize(g->class_models.size());
+    for (size_t c = 0; c < g->class_models.size(); c++) {
+      aasr_gmm *sub = g->class_models[c].get();
+      if (!sub) continue;
+      if (!sub->cl.loaded || sub->cl.C != cl.C || sub->cl.g2c.size() != (size_t)sub->G) {
+        // the parent's clustering seen from the class's own pool
+        sub->cl = ClusterState();
+        sub->cl.C = cl.C;
+        sub->cl.g2c.resize((size_t)sub->G);
+        for (int64_t i = 0; i < sub->G; i++) sub->cl.g2c[(size_t)i] = cl.g2c[(size_t)sub->parent_gauss[(size_t)i]];
+        sub->cl.loaded = true;
+      }
+      sub->precision = g->precision;
+      sub->use_bf16x3 = g->use_bf16x3;
+      sub->layout_mask = g->layout_mask;
+      sub_plans[c] = exact_part_plan(sub, sub->cl);
+      mask_rows = std::max(mask_rows, sub_plans[c].mask_rows);
+    }
+  } else {
+    plan = exact_part_plan(g, cl);
+    if ((plan.all_centred || plan.with_outliers) && g->xf_a.p)
+      raise(AASR_ERR_UNSUPPORTED,
+            "Gaussian clustering under a CMLLR transform is not built for models that need the centred kernel "
+            "(kappa %.0f)", g->kappa);
+    mask_rows = plan.mask_rows;
+  }
   // Frames per pass.  The track kernel and the merge run once per pass, so a pass is
   // as large as ~16 GB of scratch allow (1 bit per frame x packed row for the lane
   // masks, 4 B per frame x cluster for the centre values) and a whole number of rounds
   // of the track kernel (2 workgroups of 256 frames per CU); the f64 centre
   // log-likelihoods (8 B per frame x cluster) only live for a sub-pass of <= 2 GB.
-  const double per_frame = (double)mask_rows / 8.0 + 4.125 * (double)(cl.C + 1) + 4.0;
+  const double per_frame = (double)mask_rows / 8.0 + 4.125 * (double)(cl.C + 1) + 4.0 + (classes ? 4.0 * (double)g->S : 0.0);
   const int64_t round_frames = 2 * (int64_t)(g->num_cus > 0 ? g->num_cus : 256) * FRAMES_PER_BLOCK;
   const int64_t f_rounded = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK;
   int64_t fb = (int64_t)(16.0e9 / per_frame);
@@ -944,13 +1004,11 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
   fb = std::min<int64_t>(fb, f_rounded);
   int64_t fs = (int64_t)(2.0e9 / (8.0 * (double)cl.Cs));
   fs = std::min<int64_t>(fb, std::max<int64_t>(FRAMES_PER_BLOCK, fs / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK));
-  const size_t need_rows = (size_t)(fb / 64) * (size_t)mask_rows;
-  if (fb > cl.Fc || need_rows > cl.maskrow.n || (size_t)fs * cl.Cs > cl.ll64.n) {
+  if (fb > cl.Fc || (size_t)fs * cl.Cs > cl.ll64.n) {
     fb = std::max(fb, cl.Fc);
     cl.ll64.alloc((size_t)fs * cl.Cs);
     cl.cval.alloc((size_t)fb * cl.C);
     cl.maskw.alloc((size_t)(fb / 64) * (cl.C + 1));
-    cl.maskrow.alloc((size_t)(fb / 64) * (size_t)mask_rows);
     cl.n_exact.alloc((size_t)fb);
     cl.tie_list.alloc((size_t)fs + 1);
     cl.heap_key.ensure((size_t)cl.C * kHeapThreads);
@@ -968,24 +1026,12 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
       launch_centres(g, fr + s0 * g->dim, ns, stream);
       launch_select(g, s0, ns, stream);
     }
-    const int64_t words = (n + 63) / 64;
-    if (all_centred) {
-      gmm_centred_masked_launch(g, fr_members, n, out, cl.crow_centred.p, cl.maskw.p, cl.C + 1, words, stream);
-      launch_merge(g, out, n, stream);
-      continue;
-    }
-    {
-      const int64_t n_tiles = L.rows_padded / TILE_ROWS;
-      const int tpb = (int)std::min<int64_t>(n_tiles, 64);  // the staged cluster masks serve 64 tiles
-      hipLaunchKernelGGL(k_cluster_expand, dim3((unsigned)((n_tiles + tpb - 1) / tpb), (unsigned)words), dim3(256),
-                         (size_t)(cl.C + 1 + kExpandTiles * TILE_ROWS) * 8, stream, cl.maskw.p, cl.C + 1, cl.crow[which].p,
-                         L.rows_padded, tpb,
-                         cl.maskrow.p);
-    }
-    AASR_HIP(hipGetLastError());
-    gmm_tracks_masked_launch(g, which, fr_members, n, out, cl.maskrow.p, stream);
-    if (with_outliers)
-      gmm_outliers_masked_launch(g, fr_members, n, out, cl.crow_hyb.p, cl.maskw.p, cl.C + 1, words, stream);
+    if (classes)
+      gmm_classes_exact_launch(g, fr, n, out, [&](aasr_gmm *sub, size_t c, const float *xf, float *part) {
+        exact_part_launch(sub, sub->cl, sub_plans[c], cl.maskw.p, cl.C + 1, n, xf, part, stream);
+      }, stream);
+    else
+      exact_part_launch(g, cl, plan, cl.maskw.p, cl.C + 1, n, fr_members, out, stream);
     launch_merge(g, out, n, stream);
   }
 }

@@ -1312,6 +1312,9 @@ static void build_class_routing(aasr_gmm *g) {
       if (sm.mix_idx.empty()) continue;
       auto sub = std::make_unique<aasr_gmm>();
       sub->device = g->device;
+      sub->parent_gauss.assign((size_t)sm.G, -1);
+      for (int64_t gi = 0; gi < m.G; gi++)
+        if (remap[(size_t)gi] >= 0) sub->parent_gauss[(size_t)remap[(size_t)gi]] = (int32_t)gi;
       gmm_build(sub.get(), sm);
       g->class_models[(size_t)c] = std::move(sub);
     }

@@ -1770,9 +1770,20 @@ void gmm_centred_masked_launch(aasr_gmm *g, const float *d_frames, int64_t F, fl
 // Class routing (gmm.h): out[i] = log(exp(out[i]) + exp(part[i] + logdet)); a value AT the floor
 // holds nothing (a sub-model writes the floor for states it has no component of).
 __global__ void k_class_merge(float *__restrict__ out, const float *__restrict__ part, float logdet,
-                              int first, int64_t n) {
+                              int first, int64_t n, int floors) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (!floors) {  // clustered pass: exact parts without floors, k_cluster_merge applies it
+    const float b = part[i] + logdet;
+    if (first) {
+      out[i] = b;
+    } else {
+      const float a = out[i];
+      const float hi = fmaxf(a, b), lo = fminf(a, b);
+      out[i] = hi + log1pf(expf(lo - hi));
+    }
+    return;
+  }
   const float a = first ? LOG_TINY_F : out[i];
   float b = part[i];
   float r = a;
@@ -1786,6 +1797,11 @@ __global__ void k_class_merge(float *__restrict__ out, const float *__restrict__
     }
   }
   out[i] = fmaxf(r, LOG_TINY_F);
+}
+
+__global__ void k_fill_value(float *__restrict__ out, float v, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = v;
 }
 
 __global__ void k_fill_floor(float *__restrict__ out, int64_t n) {
@@ -1824,7 +1840,7 @@ static void score_classes(aasr_gmm *g, const float *d_frames, int64_t F, float *
       sub->layout_mask = g->layout_mask;
       gmm_score_launch(sub, xf, n, g->class_scratch.p, stream);
       hipLaunchKernelGGL(k_class_merge, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, out,
-                         g->class_scratch.p, (float)logdet, first ? 1 : 0, total);
+                         g->class_scratch.p, (float)logdet, first ? 1 : 0, total, 1);
       AASR_HIP(hipGetLastError());
       first = false;
     }
@@ -1832,6 +1848,38 @@ static void score_classes(aasr_gmm *g, const float *d_frames, int64_t F, float *
       hipLaunchKernelGGL(k_fill_floor, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, out, total);
       AASR_HIP(hipGetLastError());
     }
+  }
+}
+
+void gmm_classes_exact_launch(aasr_gmm *g, const float *d_frames, int64_t n, float *d_out,
+                              const std::function<void(aasr_gmm *, size_t, const float *, float *)> &exact,
+                              hipStream_t stream) {
+  const int64_t S = g->S, total = n * S;
+  g->class_scratch.ensure((size_t)total);
+  g->class_xframes.ensure((size_t)n * (size_t)g->dim);
+  bool first = true;
+  for (size_t c = 0; c < g->class_models.size(); c++) {
+    aasr_gmm *sub = g->class_models[c].get();
+    if (!sub) continue;
+    const double logdet = c == 0 ? 0.0 : g->class_logdet[c];
+    if (!(logdet > -INFINITY)) continue;  // det == 0: the adapted Gaussians' exact values are 0
+    const float *xf = d_frames;
+    if (c > 0) {
+      const int64_t nv = n * g->dim;
+      hipLaunchKernelGGL(k_affine_frames, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, stream, d_frames, n,
+                         g->dim, g->class_a[c].p, g->class_b[c].p, g->class_xframes.p);
+      AASR_HIP(hipGetLastError());
+      xf = g->class_xframes.p;
+    }
+    exact(sub, c, xf, g->class_scratch.p);
+    hipLaunchKernelGGL(k_class_merge, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_out,
+                       g->class_scratch.p, (float)logdet, first ? 1 : 0, total, 0);
+    AASR_HIP(hipGetLastError());
+    first = false;
+  }
+  if (first) {  // no class has an exact part: nothing but the centres' share
+    hipLaunchKernelGGL(k_fill_value, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_out, NEG_BIG_F, total);
+    AASR_HIP(hipGetLastError());
   }
 }
 

@@ -326,13 +326,6 @@ static void load_transforms(aasr_spkc *h) {
         W.insert(W.end(), kv.second.begin(), kv.second.end());
         t++;
       }
-      if (g->cl.loaded) {
-        bool global = t == 1;
-        for (size_t gi = 0; gi < g2t.size() && global; gi++) global = g2t[gi] == 0;
-        if (!global)
-          raise(AASR_ERR_UNSUPPORTED, "per-class model-side CMLLR together with Gaussian clustering is not built "
-                                      "(one global transform is)");
-      }
       note_change(h);
       (void)dim;
       gmm_set_transforms(g, t, g2t.data(), W.data());

@@ -262,7 +262,8 @@ static void orc_pool_likelihoods_clustered_x(int dim, int64_t G, const double *m
                                     const double *c_mean, const double *c_prec,
                                     const double *c_cst, int min_clusters,
                                     int min_gaussians, const double *frame,
-                                    const double *member_frame, double member_scale,
+                                    const double *member_frames, const double *member_scales,
+                                    const int32_t *g_class,
                                     double *gauss_lik, int32_t *n_exact);
 
 void orc_pool_likelihoods_clustered(int dim, int64_t G, const double *mean,
@@ -274,16 +275,18 @@ void orc_pool_likelihoods_clustered(int dim, int64_t G, const double *mean,
                                     int min_gaussians, const double *frame,
                                     double *gauss_lik, int32_t *n_exact)
 {
+    const double one = 1.0;
     orc_pool_likelihoods_clustered_x(dim, G, mean, prec, cst, C, cl_off, cl_members, c_mean,
                                      c_prec, c_cst, min_clusters, min_gaussians, frame, frame,
-                                     1.0, gauss_lik, n_exact);
+                                     &one, NULL, gauss_lik, n_exact);
 }
 
 /* The same with model-side constrained MLLR in place (ConstrainedMllr::AdaptedGaussian,
  * aku/ModelModules.hh:164-173): the pool's Gaussians are wrapped, so a member is evaluated on
- * the adapted vector A f + b and multiplied by |det| (member_frame, member_scale), while the
- * cluster centres are plain Gaussians evaluated on the frame itself
- * (aku/Distributions.cc:2688-2691). */
+ * the adapted vector A f + b and multiplied by |det|, while the cluster centres are plain
+ * Gaussians evaluated on the frame itself (aku/Distributions.cc:2688-2691).  member_frames holds
+ * one vector per regression class, member_scales its |det|, g_class[g] the class of Gaussian g
+ * (NULL: every Gaussian in class 0). */
 static void orc_pool_likelihoods_clustered_x(int dim, int64_t G, const double *mean,
                                     const double *prec, const double *cst,
                                     int C, const int32_t *cl_off,
@@ -291,7 +294,8 @@ static void orc_pool_likelihoods_clustered_x(int dim, int64_t G, const double *m
                                     const double *c_mean, const double *c_prec,
                                     const double *c_cst, int min_clusters,
                                     int min_gaussians, const double *frame,
-                                    const double *member_frame, double member_scale,
+                                    const double *member_frames, const double *member_scales,
+                                    const int32_t *g_class,
                                     double *gauss_lik, int32_t *n_exact)
 {
     orc_clpair *heap = (orc_clpair *)malloc(sizeof(orc_clpair) * (size_t)(C > 0 ? C : 1));
@@ -312,8 +316,9 @@ static void orc_pool_likelihoods_clustered_x(int dim, int64_t G, const double *m
         int c = heap[0].idx;
         for (int32_t j = cl_off[c]; j < cl_off[c + 1]; j++) {
             int64_t g = cl_members[j];
-            gauss_lik[g] = exp(orc_diag_loglik(dim, member_frame, mean + g * dim,
-                                               prec + g * dim, cst[g])) * member_scale;
+            const int k = g_class ? g_class[g] : 0;
+            gauss_lik[g] = exp(orc_diag_loglik(dim, member_frames + (size_t)k * dim, mean + g * dim,
+                                               prec + g * dim, cst[g])) * member_scales[k];
         }
         clusters_done++;
         gauss_done += cl_off[c + 1] - cl_off[c];
@@ -331,9 +336,11 @@ static void orc_pool_likelihoods_clustered_x(int dim, int64_t G, const double *m
     }
     free(heap);
     for (int64_t g = 0; g < G; g++)
-        if (!(gauss_lik[g] > 0))
-            gauss_lik[g] = exp(orc_diag_loglik(dim, member_frame, mean + g * dim,
-                                               prec + g * dim, cst[g])) * member_scale;
+        if (!(gauss_lik[g] > 0)) {
+            const int k = g_class ? g_class[g] : 0;
+            gauss_lik[g] = exp(orc_diag_loglik(dim, member_frames + (size_t)k * dim, mean + g * dim,
+                                               prec + g * dim, cst[g])) * member_scales[k];
+        }
 }
 
 /* orc_score_frames_clustered with one global transform [b | A] (row-major dim x (dim+1)):
@@ -365,12 +372,68 @@ void orc_score_frames_clustered_adapted(int dim, int64_t G, const double *mean,
         }
         orc_pool_likelihoods_clustered_x(dim, G, mean, prec, cst, C, cl_off, cl_members, c_mean,
                                          c_prec, c_cst, min_clusters, min_gaussians,
-                                         frames + f * dim, xf, det, scratch,
+                                         frames + f * dim, xf, &det, NULL, scratch,
                                          n_exact ? n_exact + f : NULL);
         orc_state_likelihoods(S, mix_off, mix_idx, mix_w, scratch, slik);
         for (int64_t s = 0; s < S; s++)
             out_loglik[f * S + s] = log(slik[s]);
     }
+    free(xf);
+    free(slik);
+}
+
+/* The same with per-class transforms (regression classes): g2t[g] = transform of Gaussian g or -1
+ * (unadapted), W = n_transforms matrices [b | A].  Each member is evaluated on its own class's
+ * adapted vector and scaled by that class's |det|; the centres stay plain. */
+void orc_score_frames_clustered_classes(int dim, int64_t G, const double *mean,
+                                const double *prec, const double *cst,
+                                int64_t S, const int32_t *mix_off,
+                                const int32_t *mix_idx, const double *mix_w,
+                                int C, const int32_t *cl_off,
+                                const int32_t *cl_members, const double *c_mean,
+                                const double *c_prec, const double *c_cst,
+                                int min_clusters, int min_gaussians, int n_transforms,
+                                const int32_t *g2t, const double *W, int64_t F,
+                                const double *frames, double *scratch,
+                                double *out_loglik, int32_t *n_exact)
+{
+    const int K = n_transforms + 1;
+    double *slik = (double *)malloc(sizeof(double) * (size_t)S);
+    double *xf = (double *)malloc(sizeof(double) * (size_t)dim * (size_t)K);
+    double *det = (double *)malloc(sizeof(double) * (size_t)K);
+    int32_t *cls = (int32_t *)malloc(sizeof(int32_t) * (size_t)(G > 0 ? G : 1));
+    for (int64_t g = 0; g < G; g++)
+        cls[g] = g2t[g] + 1;
+    det[0] = 1.0;
+    for (int t = 0; t < n_transforms; t++) {
+        const double *Wt = W + (size_t)t * dim * (dim + 1);
+        double d = 1;
+        for (int i = 0; i < dim; i++)
+            d *= Wt[(size_t)i * (dim + 1) + 1 + i];
+        det[t + 1] = fabs(d);
+    }
+    for (int64_t f = 0; f < F; f++) {
+        for (int i = 0; i < dim; i++)
+            xf[i] = frames[f * dim + i];
+        for (int t = 0; t < n_transforms; t++) {
+            const double *Wt = W + (size_t)t * dim * (dim + 1);
+            for (int i = 0; i < dim; i++) {
+                double acc = Wt[(size_t)i * (dim + 1)];
+                for (int j = 0; j < dim; j++)
+                    acc += Wt[(size_t)i * (dim + 1) + 1 + j] * frames[f * dim + j];
+                xf[(size_t)(t + 1) * dim + i] = acc;
+            }
+        }
+        orc_pool_likelihoods_clustered_x(dim, G, mean, prec, cst, C, cl_off, cl_members, c_mean,
+                                         c_prec, c_cst, min_clusters, min_gaussians,
+                                         frames + f * dim, xf, det, cls, scratch,
+                                         n_exact ? n_exact + f : NULL);
+        orc_state_likelihoods(S, mix_off, mix_idx, mix_w, scratch, slik);
+        for (int64_t s = 0; s < S; s++)
+            out_loglik[f * S + s] = log(slik[s]);
+    }
+    free(cls);
+    free(det);
     free(xf);
     free(slik);
 }

@@ -746,6 +746,31 @@ class DiagModel:
             scratch.ctypes.data, out.ctypes.data, counts.ctypes.data)
         return (out, counts) if want_counts else out
 
+    def score_clustered_classes(self, frames: np.ndarray, g2t, W, want_counts: bool = False):
+        """score_clustered with per-class constrained-MLLR transforms: g2t[g] = transform of Gaussian
+        g (-1: none), W = [T x D x (D+1)] matrices [b | A] (AdaptedGaussian members of each class,
+        plain cluster centres)."""
+        frames = np.ascontiguousarray(frames, np.float64)
+        W = np.ascontiguousarray(W, np.float64)
+        g2t = np.ascontiguousarray(g2t, np.int32)
+        F = frames.shape[0]
+        out = np.empty((F, self.S))
+        scratch = np.empty(self.G)
+        counts = np.zeros(F, np.int32)
+        L = lib()
+        L.orc_score_frames_clustered_classes.restype = None
+        L.orc_score_frames_clustered_classes.argtypes = [
+            C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+            C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_score_frames_clustered_classes(
+            self.D, self.G, self.mean.ctypes.data, self.prec.ctypes.data, self.cst.ctypes.data, self.S,
+            self.mix_off.ctypes.data, self.mix_idx.ctypes.data, self.mix_w.ctypes.data, self.n_clusters,
+            self.cl_off.ctypes.data, self.cl_members.ctypes.data, self.c_mean.ctypes.data, self.c_prec.ctypes.data,
+            self.c_cst.ctypes.data, self.min_clusters, self.min_gaussians, W.shape[0], g2t.ctypes.data,
+            W.ctypes.data, F, frames.ctypes.data, scratch.ctypes.data, out.ctypes.data, counts.ctypes.data)
+        return (out, counts) if want_counts else out
+
     def cpu_baseline(self, frames: np.ndarray) -> float:
         frames = np.ascontiguousarray(frames, np.float64)
         pd = C.c_double

@@ -241,8 +241,7 @@ def test_clustering_under_a_global_cmllr_transform(capi, oracle):
     AdaptedGaussians -- members evaluated on A f + b and scaled by |prod diag A|
     (aku/ModelModules.hh:164-173) -- while the cluster centres are plain Gaussians ranked on the
     frame itself (aku/Distributions.cc:2688-2691).  Scores and per-frame exact counts against the
-    oracle, whichever of clustering / transform is set first; per-class transforms with
-    clustering are refused."""
+    oracle, whichever of clustering / transform is set first."""
     D = 20
     model = synth.make_model(D=D, G=1200, S=100, comps=12, seed=31)
     mean, var, off, idx, w = model
@@ -274,9 +273,61 @@ def test_clustering_under_a_global_cmllr_transform(capi, oracle):
             assert np.abs(got - want).max() <= TOL, (order, prec, np.abs(got - want).max())
         gm.set_cmllr()                                  # back to the unadapted model
         assert np.abs(gm.score(frames) - plain).max() <= TOL
-        two = np.concatenate([np.zeros(600, np.int32), np.ones(600, np.int32)])
-        with pytest.raises(capi.AasrError, match="per-class model-side CMLLR together with Gaussian clustering"):
-            gm.set_cmllr(two, np.stack([W, W]))
+        gm.close()
+
+
+def test_clustering_under_per_class_cmllr_transforms(capi, oracle):
+    """Regression-class transforms (UNIT_GAUSSIAN / UNIT_MIX / UNIT_PHONE speaker files) with -C: the
+    Gaussians of one mixture -- and of one cluster -- may belong to different classes.  Each member is
+    evaluated on its own class's A f + b and scaled by that class's |det|, Gaussians without a
+    transform on the frame itself, the centres are plain (aku/ModelModules.hh:164-173,
+    aku/Distributions.cc:2684-2722).  Scores and exact counts against the oracle in either order of
+    set_clustering / set_cmllr, with a class change in between, a class whose determinant is 0, and
+    back to the unadapted model."""
+    D = 20
+    mean, var, off, idx, w = synth.make_model(D=D, G=1200, S=100, comps=12, seed=31)
+    g2c = synth.make_clustering(mean, 48)
+    g2c[5] = g2c[77] = -1
+    pairs = _pairs(g2c)
+    rng = np.random.default_rng(18)
+
+    def transform(scale=1.0):
+        A = np.eye(D) * rng.uniform(0.9, 1.1, D) * scale + 0.03 * rng.standard_normal((D, D))
+        return np.hstack([0.2 * rng.standard_normal(D)[:, None], A])
+
+    W3 = np.stack([transform(), transform(), transform()])
+    g2t = rng.integers(-1, 3, 1200).astype(np.int32)          # -1: unadapted Gaussians
+    frames = synth.make_frames(400, D=D, seed=9)
+    om = oracle.DiagModel(mean, var, off, idx, w)
+    om.set_clustering(48, pairs, 0.05, 0.2)
+    plain = om.score_clustered(frames.astype(np.float64))
+    want, want_n = om.score_clustered_classes(frames.astype(np.float64), g2t, W3, want_counts=True)
+    assert np.abs(want - plain).max() > 0.05
+    for order in ("cluster_first", "transform_first"):
+        gm = capi.Gmm.from_arrays(mean, var, off, idx, w)
+        if order == "transform_first":
+            gm.set_cmllr(g2t, W3)
+        gm.set_clustering(48, pairs)
+        gm.set_clustering_min_evals(0.05, 0.2)
+        if order == "cluster_first":
+            gm.set_cmllr(g2t, W3)
+        for prec in (0, 3):
+            gm.set_precision(prec)
+            got = gm.score(frames)
+            assert np.array_equal(gm.cluster_exact_counts(len(frames)), want_n), (order, prec)
+            assert np.abs(got - want).max() <= TOL, (order, prec, np.abs(got - want).max())
+        # another speaker: new matrices, a different class membership, one singular class
+        g2t2 = rng.integers(0, 2, 1200).astype(np.int32)
+        W2 = np.stack([transform(), transform()])
+        W2[1, 3, 1 + 3] = 0.0                                # diag product 0: that class's exact values vanish
+        want2, n2 = om.score_clustered_classes(frames.astype(np.float64), g2t2, W2, want_counts=True)
+        gm.set_cmllr(g2t2, W2)
+        got2 = gm.score(frames)
+        assert np.array_equal(gm.cluster_exact_counts(len(frames)), n2)
+        assert np.abs(got2 - want2).max() <= TOL, np.abs(got2 - want2).max()
+        gm.set_cmllr()
+        assert np.abs(gm.score(frames) - plain).max() <= TOL
+        gm.close()
 
 
 def test_clustering_with_outlier_routed_and_ill_conditioned_models(capi, oracle):

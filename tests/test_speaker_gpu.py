@@ -315,7 +315,7 @@ def test_reference_style_loop_with_speaker_config(capi, oracle, world):
 def test_speakers_with_gaussian_clustering(capi, oracle, world, tmp_path):
     """phone_probs -S SPKC -C GCL, the adapted recognition pass of pyrectool (rectool.py:655-666):
     speakers with a global (UNIT_NO) model transform over a clustered pool, against the oracle's
-    clustered + adapted scoring; a speaker with per-class transforms is refused loudly."""
+    clustered + adapted scoring; a speaker with per-class transforms (regression classes) too."""
     mean, var, off, idx, w = world["model"]
     g2c = synth.make_clustering(mean, 12)
     pairs = [(int(g), int(c)) for g, c in enumerate(g2c)]
@@ -347,8 +347,16 @@ def test_speakers_with_gaussian_clustering(capi, oracle, world, tmp_path):
         got = oracle.lna_decode(open(tmp_path / ("c%d.lna" % i), "rb").read())
         ok = ll > -85
         assert ok.mean() > 0.2 and np.abs(got - ll)[ok].max() <= 1e-4, (i, spk)
-    with pytest.raises(capi.AasrError, match="per-class model-side CMLLR together with Gaussian clustering"):
-        sc.set_speaker("carl")
+    # "carl" has per-class transforms (regression classes): the clustered pass takes them as well
+    sc.set_speaker("carl")
+    osc.set_speaker("carl")
+    assert len(osc.W) > 1 or not (np.asarray(osc.g2t) == 0).all()
+    pcm = world["pcms"][1]
+    fea = ch.generate(pcm, 0, ch.num_frames(len(pcm)))
+    want = om.score_clustered_classes(fea, np.asarray(osc.g2t), np.asarray(osc.W))
+    got = gm.score(fea.astype(np.float32))
+    vis = want > -85
+    assert np.abs(got - want)[vis].max() <= 1e-4
 
 
 def test_module_classes_set_parameters_directly(capi, oracle, world, tmp_path):
