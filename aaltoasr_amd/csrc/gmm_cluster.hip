@@ -983,11 +983,9 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
       mask_rows = std::max(mask_rows, sub_plans[c].mask_rows);
     }
   } else {
+    // (a global transform over a model with centred-kernel Gaussians carries |det| in the component
+    // weights -- HostModel::logw_bias -- so rows and centred records already hold it)
     plan = exact_part_plan(g, cl);
-    if ((plan.all_centred || plan.with_outliers) && g->xf_a.p)
-      raise(AASR_ERR_UNSUPPORTED,
-            "Gaussian clustering under a CMLLR transform is not built for models that need the centred kernel "
-            "(kappa %.0f)", g->kappa);
     mask_rows = plan.mask_rows;
   }
   // Frames per pass.  The track kernel and the merge run once per pass, so a pass is

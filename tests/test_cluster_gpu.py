@@ -358,6 +358,24 @@ def test_clustering_with_outlier_routed_and_ill_conditioned_models(capi, oracle)
         if minc == 1.0:
             assert np.abs(got - om.score(frames.astype(np.float64))).max() <= TOL
         gm.close()
+    # the same model under one global CMLLR transform (|det| folded into the weights of rows and
+    # centred records): adapted members, plain centres
+    A = np.eye(39) * rng.uniform(0.95, 1.05, 39) + 0.01 * rng.standard_normal((39, 39))
+    W = np.hstack([0.05 * rng.standard_normal(39)[:, None], A])
+    om = oracle.DiagModel(mean, var, off, idx, w)
+    om.set_clustering(32, _pairs(g2c), 0.0, 0.25)
+    want, want_n = om.score_clustered_adapted(frames.astype(np.float64), W, want_counts=True)
+    gm = capi.Gmm.from_arrays(mean, var, off, idx, w)
+    gm.set_clustering(32, _pairs(g2c))
+    gm.set_clustering_min_evals(0.0, 0.25)
+    gm.set_cmllr(np.zeros(512, np.int32), W[None])
+    for prec in (0, 3):
+        gm.set_precision(prec)
+        got = gm.score(frames)
+        assert np.array_equal(gm.cluster_exact_counts(len(frames)), want_n)
+        vis = want > -104
+        assert np.abs(got - want)[vis].max() <= TOL and np.abs(got - want).max() <= 2e-4, np.abs(got - want).max()
+    gm.close()
     # a majority of tight Gaussians: the whole model in the centred form, still clustered
     var2 = var.copy()
     var2[rng.choice(512, 300, replace=False)] *= 2e-3

@@ -3,7 +3,8 @@ as part of the suite, so that a discrepancy found by a sweep can never sit in a 
 every random model / feature graph of these seeds must agree with the oracle -- scores within
 1e-4 wherever the reference's float storage can hold the likelihood (2e-4 below its flush
 point, where the LNA output is the floor whatever the value: tests/test_lna_gpu.py), clustered
-exact-evaluation counts bit for bit, feature modules to the per-module tolerance.  Seed 1 is
+exact-evaluation counts bit for bit, model-side CMLLR (one global or per-class transforms, plain
+and clustered) likewise, feature modules to the per-module tolerance.  Seed 1 is
 the sweep whose iteration 26 had differing cluster counts in round 1 (tied empty clusters); seed
 104 (iterations 0..249) holds the round-2 find: a one-dimensional model with kappa 416 and a frame
 12 sigma out, 1.18e-4 in the expanded form until the 2-norm conditioning limit routed it."""
@@ -28,6 +29,7 @@ def test_scoring_sweep(capi, oracle, seed, n):
     worst, fails = _load("fuzz_parity").run(seed, n)
     assert not fails, "\n".join(fails)
     assert any(k.startswith("clustered") for k in worst) and any("layouts=4" in k for k in worst)
+    assert any(k.startswith("cmllr") for k in worst) and "cmllr clustered refused" not in worst
     assert max(v for k, v in worst.items() if k.endswith("(ll > -104)")) <= 1e-4
 
 

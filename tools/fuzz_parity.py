@@ -34,7 +34,7 @@ def run(seed=1, N=40, verbose=False):
     worst = {}
     fails = []
 
-    def note(key, got, want, ctx):
+    def note(key, got, want, ctx, floor_slack=0.0):
         d = np.abs(got - want)
         err = float(d.max())
         worst[key] = max(worst.get(key, 0.0), err)
@@ -47,9 +47,20 @@ def run(seed=1, N=40, verbose=False):
         with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
             lost = -np.log1p(-np.minimum(np.exp(LOG_TINY - want), 0.5))
         floor_bad = (~vis) & (d > np.maximum(TOL_FLOOR, 1.05 * lost))
+        if floor_slack > 0:
+            # model-side CMLLR: |det| enters through the kernels' reference exponent (or a class part is
+            # floored before its log|det| is added), so sums within max log|det| (+ log classes) of the
+            # 1e-50 floor may come out AT the floor -- never above the true value
+            slack = want < LOG_TINY + floor_slack
+            floor_bad &= ~(slack & (got >= LOG_TINY - 1e-4) & (got <= want + TOL_FLOOR))
+            # ... and above that band a floored class part of up to |det| 1e-50 may be missing from the sum
+            with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+                lost_c = -np.log1p(-np.minimum(np.exp(LOG_TINY + floor_slack - want), 0.5))
+            floor_bad &= d > np.maximum(TOL_FLOOR, 1.05 * lost_c)
         if evis > TOL or floor_bad.any():
-            at = int(d.argmax())
-            fails.append("%s %s err %.3g (visible %.3g) at ll %.1f" % (key, ctx, err, evis, want.ravel()[at]))
+            at = int(np.argmax(np.where(floor_bad, d, -1.0))) if floor_bad.any() else int(d.argmax())
+            fails.append("%s %s err %.3g (visible %.3g) at ll %.2f (got %.2f)" % (key, ctx, err, evis, want.ravel()[at],
+                                                                                   got.ravel()[at]))
             if verbose:
                 print("FAIL", fails[-1])
 
@@ -128,6 +139,56 @@ def run(seed=1, N=40, verbose=False):
                     fails.append("clustered prec=%d %s: exact-evaluation counts differ" % (prec, cctx))
                     if verbose:
                         print("FAIL", fails[-1])
+        # model-side CMLLR on top (a third of the models): one global or per-class transforms, plain
+        # and clustered, against the oracle's adapted restatements
+        rng2 = np.random.default_rng([seed, it, 7])   # its own stream: the sweeps above keep their draws
+        if rng2.integers(0, 3) == 0 and D <= 40:
+            T = int(rng2.integers(1, 4))
+            Wt = np.stack([np.hstack([0.2 * rng2.standard_normal(D)[:, None],
+                                      np.eye(D) * rng2.uniform(0.85, 1.15, D) + 0.02 * rng2.standard_normal((D, D))])
+                           for _ in range(T)])
+            g2t = (np.zeros(G, np.int32) if T == 1 and rng2.integers(0, 2) else rng2.integers(-1, T, G).astype(np.int32))
+            try:
+                g.set_clustering(0)
+                g.set_cmllr(g2t, Wt)
+            except capi.AasrError as e:
+                if verbose:
+                    print("skip cmllr:", e)
+                continue
+            want_a = O.score_adapted(om, frames.astype(np.float64), g2t, Wt)
+            slack = float(max(abs(np.log(abs(np.prod(np.diag(Wt[t][:, 1:]))))) for t in range(T)) + np.log(T + 1.0) + 0.1)
+            for prec in (0, 3):
+                try:
+                    g.set_precision(prec)
+                except capi.AasrError:
+                    continue
+                note("cmllr T=%d prec=%d" % (T, prec), g.score(frames), want_a, ctx, floor_slack=slack)
+            if Cn >= 1 and Cn <= 0.3 * G:
+                try:
+                    g.set_clustering(Cn, pairs)
+                    g.set_clustering_min_evals(minc, ming)
+                except capi.AasrError as e:
+                    if verbose:
+                        print("skip cmllr clustering:", e)
+                    continue
+                want_ca, cnt_a = om.score_clustered_classes(frames.astype(np.float64), g2t, Wt, want_counts=True)
+                for prec in (0, 3):
+                    try:
+                        g.set_precision(prec)
+                    except capi.AasrError:
+                        continue
+                    try:
+                        got = g.score(frames)
+                    except capi.AasrError as e:
+                        if e.code != capi.AASR_ERR_UNSUPPORTED:
+                            raise
+                        worst["cmllr clustered refused"] = worst.get("cmllr clustered refused", 0) + 1
+                        if verbose:
+                            print("skip cmllr clustering:", e)
+                        break
+                    note("cmllr clustered prec=%d" % prec, got, want_ca, ctx + " T %d C %d" % (T, Cn), floor_slack=slack)
+                    if not np.array_equal(g.cluster_exact_counts(F), cnt_a):
+                        fails.append("cmllr clustered prec=%d %s: exact-evaluation counts differ" % (prec, ctx))
     return worst, fails
 
 
