@@ -263,6 +263,7 @@ struct aasr_gmm {
   // handful of matrices instead of re-packing the model.
   bool class_routing = false;
   std::vector<int32_t> class_g2t;                         // membership the sub-models were built for
+  std::unique_ptr<aasr_gmm> pool_view;   // full-covariance pools: the Gaussians as one-component states (per-Gaussian view)
   std::vector<std::unique_ptr<aasr_gmm>> class_models;    // index = transform id + 1 (0: unadapted), may be null
   std::vector<aasr::DevBuf<double>> class_a, class_b;     // per class: A [dim x dim], b [dim]
   std::vector<double> class_logdet;                       // log |prod diag A|; -inf = class contributes nothing

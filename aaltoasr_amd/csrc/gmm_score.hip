@@ -1980,9 +1980,32 @@ void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
 
 void gmm_gauss_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                       hipStream_t stream) {
-  if (g->host.factor_path() || g->xf_a.p || g->class_routing)
-    raise(AASR_ERR_UNSUPPORTED,
-          "per-Gaussian log-likelihoods are not built for full-covariance or adapted pools");
+  if (g->xf_a.p || g->class_routing || g->host.n_transforms > 0)
+    raise(AASR_ERR_UNSUPPORTED, "per-Gaussian log-likelihoods are not built for adapted pools");
+  if (g->host.any_full()) {
+    // full-covariance pools: every Gaussian as a one-component state of an internal model, scored
+    // by the factor-row kernel (values below the 1e-50 floor come out at the floor)
+    if (!g->pool_view) {
+      HostModel pm = g->host;
+      pm.S = pm.G;
+      pm.mix_off.resize((size_t)pm.G + 1);
+      pm.mix_idx.resize((size_t)pm.G);
+      pm.mix_w.assign((size_t)pm.G, 1.0);
+      for (int64_t i = 0; i <= pm.G; i++) pm.mix_off[(size_t)i] = (int32_t)i;
+      for (int64_t i = 0; i < pm.G; i++) pm.mix_idx[(size_t)i] = (int32_t)i;
+      pm.weights_normalized = true;
+      pm.hmm_label.clear();
+      pm.hmm_states.clear();
+      auto sub = std::make_unique<aasr_gmm>();
+      sub->device = g->device;
+      gmm_build(sub.get(), pm);
+      g->pool_view = std::move(sub);
+    }
+    g->pool_view->precision = g->precision;
+    g->pool_view->use_bf16x3 = g->use_bf16x3;
+    gmm_score_launch(g->pool_view.get(), d_frames, F, d_out, stream);
+    return;
+  }
   if (g->ill_conditioned || g->hyb_enabled) {
     // variance-floored Gaussians: the expanded form loses eps * kappa, so the whole pool is
     // evaluated in the centred form (one-record states, no floor)

@@ -89,3 +89,22 @@ def test_full_gk_files_and_mixed_pool(capi, oracle, tmp_path):
     ref2 = oracle.FullModel(mean, cov, off, idx, w).score(frames.astype(np.float64))
     g2 = capi.Gmm.from_files(base + "_legacy.gk", base + ".mc", None)
     assert np.abs(g2.score(frames) - ref2).max() <= 1e-4
+
+
+def test_per_gaussian_view_of_a_full_covariance_pool(capi, oracle):
+    """PDFPool::compute_likelihood(f, index) (aku/Distributions.hh:145) over full-covariance
+    Gaussians: aasr_gmm_gauss_loglik scores every Gaussian as a one-component state of an internal
+    model; a tied mixture layout on top does not matter to the pool view."""
+    mean, cov, off, idx, w = _full_model(39, 60, 6, 10, seed=12, tied=True)
+    frames = synth.make_frames(120, D=39, seed=4)
+    ref = oracle.FullModel(mean, cov, off, idx, w).gauss_loglik(frames.astype(np.float64))
+    g = capi.Gmm.from_full(mean, cov, off, idx, w)
+    for prec in (0, 3):
+        g.set_precision(prec)
+        got = g.gauss_loglik(frames)
+        assert got.shape == ref.shape
+        vis = ref > np.log(1e-50)
+        assert np.abs(got - ref)[vis].max() <= 1e-4
+        assert np.all(got[~vis] <= np.log(1e-50) + 1e-4)
+    # state scores of the same handle are unaffected
+    assert np.abs(g.score(frames) - oracle.FullModel(mean, cov, off, idx, w).score(frames.astype(np.float64))).max() <= 1e-4
