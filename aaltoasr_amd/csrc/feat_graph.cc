@@ -181,10 +181,8 @@ static void build_fft_plan(FftPlan &p, int window) {
       if (r > root) r = n;
     }
     n /= r;
-    if (r != 2 && r != 3 && r != 4 && r != 5)
-      raise(AASR_ERR_UNSUPPORTED,
-            "FFT window %d needs KissFFT's generic radix-%d butterfly, which is not built "
-            "(radices 2, 3, 4, 5 are)", window, r);
+    if (r > 64)  // kFftMaxRadix (feat_kernels.hip): the generic butterfly's private scratch
+      raise(AASR_ERR_UNSUPPORTED, "FFT window %d has the prime factor %d; radices up to 64 are built", window, r);
     if (ns >= 16) raise(AASR_ERR_UNSUPPORTED, "FFT window %d too long", window);
     p.radix[ns] = r;
     p.sublen[ns] = n;

@@ -221,6 +221,32 @@ __device__ __forceinline__ void kiss_butterfly(cpx *buf, int bi, int pr, int m, 
     }
 }
 
+// kf_bfly_generic (vendor/kiss_fft/kiss_fft.c:198-235) for the odd prime radices above 5: a plain
+// DFT of the p points u, u + m, ..., the twiddle index advanced by fstride * k per term and wrapped
+// once.  One thread per u; the p inputs sit in private memory, which is why only the unfused FFT
+// kernel's <GEN = true> instance carries this path (feat_graph.cc limits p to kFftMaxRadix).
+constexpr int kFftMaxRadix = 64;
+__device__ __noinline__ void kiss_butterfly_generic(cpx *buf, int bi, int pr, int m, int fstride,
+                                                    const cpx *__restrict__ tw) {
+  const int g = bi / m, u = bi - g * m;
+  const int n = fstride * pr * m;
+  cpx *F = buf + g * pr * m;
+  cpx scratch[kFftMaxRadix];
+  for (int q1 = 0, k = u; q1 < pr; q1++, k += m) scratch[q1] = F[k];
+  for (int q1 = 0, k = u; q1 < pr; q1++, k += m) {
+    int twidx = 0;
+    cpx acc = scratch[0];
+    for (int q = 1; q < pr; q++) {
+      twidx += fstride * k;
+      if (twidx >= n) twidx -= n;
+      const cpx t = cmul(scratch[q], tw[twidx]);
+      acc.r += t.r;
+      acc.i += t.i;
+    }
+    F[k] = acc;
+  }
+}
+
 // |X|^2 of one bin in float, then sqrtf / logf as FFTModule::generate applies them
 // (aku/FeatureModules.cc:533-565); sqrt and log evaluated in double and rounded once
 __device__ __forceinline__ float spec_value(float re, float im, int magnitude, int take_log) {
@@ -250,7 +276,7 @@ __device__ __forceinline__ void real_split(const cpx *buf, int nc, int k, const 
 
 // One wave per frame: Hamming -> packed half-length complex FFT in LDS with
 // KissFFT's butterfly order -> real split -> |X|^2 (/ sqrt / log).
-template <bool FROM_PCM>
+template <bool FROM_PCM, bool GEN>
 __global__ __launch_bounds__(256) void k_fft(DevBatch b, const int16_t *__restrict__ pcm,
                                              AudioPrm ap, const double *__restrict__ src,
                                              SrcMap sm, int L, int R, int64_t rows, FftPrm fp,
@@ -299,7 +325,11 @@ __global__ __launch_bounds__(256) void k_fft(DevBatch b, const int16_t *__restri
     const int pr = fp.radix[s], m = fp.sublen[s];
     const int fstride = nc / (pr * m);
     const int nb = nc / pr;
-    for (int bi = lane; bi < nb; bi += 64) kiss_butterfly(buf, bi, pr, m, fstride, tw);
+    if (GEN && pr > 5) {
+      for (int bi = lane; bi < nb; bi += 64) kiss_butterfly_generic(buf, bi, pr, m, fstride, tw);
+    } else {
+      for (int bi = lane; bi < nb; bi += 64) kiss_butterfly(buf, bi, pr, m, fstride, tw);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -1128,6 +1158,9 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
       if (h->mods[M].type != MOD_MEL || h->mods[F].type != MOD_FFT || h->mods[M].sources[0] != F) continue;
       if (consumers[M] != 1 || consumers[F] != 2 || M == target || F == target) continue;
       if (h->mods[F].sources[0] != 0 || G.dim != h->mods[D].dim + 1) continue;
+      bool generic_radix = false;  // the fused kernel carries the radix 2/3/4/5 butterflies only
+      for (int st = 0; st < h->mods[F].fft.ns; st++) generic_radix = generic_radix || h->mods[F].fft.radix[st] > 5;
+      if (generic_radix) continue;
       const SpectralLds lds(h->mods[F].fft.nc, h->mods[M].dim, (int)h->mods[M].mel_t.n,
                             h->mods[D].dim - (h->mods[D].zeroth ? 1 : 0));
       if (lds.total > 64 * 1024) continue;
@@ -1271,13 +1304,22 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
         fp.take_log = m.take_log;
         const size_t smem = (size_t)4 * fp.nc * sizeof(float) * 2;
         const unsigned blocks = (unsigned)((rows + 3) / 4);
-        if (s0 == 0 && consumers[0] == 1 && target != 0) {
-          hipLaunchKernelGGL(k_fft<true>, dim3(blocks), dim3(256), smem, stream, db, d_pcm, ap,
-                             (const double *)nullptr, sm, L[i], R[i], rows, fp, dst);
-        } else {
-          hipLaunchKernelGGL(k_fft<false>, dim3(blocks), dim3(256), smem, stream, db, d_pcm, ap,
-                             src, sm, L[i], R[i], rows, fp, dst);
-        }
+        bool gen = false;
+        for (int st = 0; st < fp.ns; st++) gen = gen || fp.radix[st] > 5;
+        const bool from_pcm = s0 == 0 && consumers[0] == 1 && target != 0;
+        const double *fsrc = from_pcm ? (const double *)nullptr : src;
+        if (from_pcm && gen)
+          hipLaunchKernelGGL((k_fft<true, true>), dim3(blocks), dim3(256), smem, stream, db, d_pcm, ap, fsrc, sm, L[i],
+                             R[i], rows, fp, dst);
+        else if (from_pcm)
+          hipLaunchKernelGGL((k_fft<true, false>), dim3(blocks), dim3(256), smem, stream, db, d_pcm, ap, fsrc, sm, L[i],
+                             R[i], rows, fp, dst);
+        else if (gen)
+          hipLaunchKernelGGL((k_fft<false, true>), dim3(blocks), dim3(256), smem, stream, db, d_pcm, ap, fsrc, sm, L[i],
+                             R[i], rows, fp, dst);
+        else
+          hipLaunchKernelGGL((k_fft<false, false>), dim3(blocks), dim3(256), smem, stream, db, d_pcm, ap, fsrc, sm, L[i],
+                             R[i], rows, fp, dst);
         break;
       }
       case MOD_MEL:

@@ -593,8 +593,10 @@ static inline orc_cpx orc_cmul(orc_cpx a, orc_cpx b)
 }
 
 /* radix schedule of kf_factor (vendor/kiss_fft/kiss_fft.c:309-331): powers of
- * 4, then 2, then odd primes.  Radices 2, 3, 4 and 5 are restated (the generic
- * butterfly for larger primes is not); returns the number of stages or -1. */
+ * 4, then 2, then odd primes.  Radices 2, 3, 4 and 5 have their own butterflies,
+ * larger primes (up to ORC_FFT_MAX_RADIX, a scratch-size limit of this restatement) the
+ * generic one; returns the number of stages or -1. */
+#define ORC_FFT_MAX_RADIX 64
 static int orc_fft_plan(int n, int *radix, int *sublen)
 {
     int ns = 0, p = 4;
@@ -607,7 +609,7 @@ static int orc_fft_plan(int n, int *radix, int *sublen)
             if (p > root) p = n;
         }
         n /= p;
-        if (p != 2 && p != 3 && p != 4 && p != 5) return -1;
+        if (p > ORC_FFT_MAX_RADIX) return -1;
         radix[ns] = p;
         sublen[ns] = n;
         ns++;
@@ -698,6 +700,30 @@ static void orc_cfft(int n, const orc_cpx *in, orc_cpx *out, const orc_cpx *tw,
                     s12.i = s10.r * yb.i - s9.r * ya.i;
                     F[2 * m + j].r = s11.r + s12.r;  F[2 * m + j].i = s11.i + s12.i;
                     F[3 * m + j].r = s11.r - s12.r;  F[3 * m + j].i = s11.i - s12.i;
+                }
+            } else if (p != 4) {
+                /* kf_bfly_generic (vendor/kiss_fft/kiss_fft.c:198-235): a plain DFT of the p points
+                 * u, u+m, ..., the twiddle index advanced by fstride*k per term and wrapped once */
+                orc_cpx scratch[ORC_FFT_MAX_RADIX];
+                for (int u = 0; u < m; u++) {
+                    int k = u;
+                    for (int q1 = 0; q1 < p; q1++) {
+                        scratch[q1] = F[k];
+                        k += m;
+                    }
+                    k = u;
+                    for (int q1 = 0; q1 < p; q1++) {
+                        int twidx = 0;
+                        F[k] = scratch[0];
+                        for (int q = 1; q < p; q++) {
+                            twidx += fstride * k;
+                            if (twidx >= n) twidx -= n;
+                            orc_cpx t = orc_cmul(scratch[q], tw[twidx]);
+                            F[k].r += t.r;
+                            F[k].i += t.i;
+                        }
+                        k += m;
+                    }
                 }
             } else {
                 for (int j = 0; j < m; j++) {

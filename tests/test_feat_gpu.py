@@ -174,9 +174,14 @@ module
 
 
 @pytest.mark.parametrize("rate,frame_rate,width", [(16000, 100, 0), (16000, 100, 400), (8000, 100, 200),
-                                                   (16000, 125, 240), (44100, 100, 1000)])
+                                                   (16000, 125, 240), (44100, 100, 1000),
+                                                   (11025, 100, 220), (22050, 100, 442), (16000, 100, 364),
+                                                   (16000, 125, 276)])
 def test_non_power_of_two_windows(capi, oracle, rate, frame_rate, width):
-    """25-ms style windows need KissFFT's radix-3/5 butterflies (kf_bfly3 / kf_bfly5)."""
+    """25-ms style windows need KissFFT's radix-3/5 butterflies (kf_bfly3 / kf_bfly5); half lengths
+    with prime factors 7, 11, 13, 17, 23 (220, 442, 364, 276 samples) its generic butterfly
+    (kf_bfly_generic) -- the oracle's FFT is pinned bit for bit on the vendored KissFFT for all of
+    them (tests/test_oracle_golden.py)."""
     cfg = "module\n{\n name a\n type audiofile\n sample_rate %d\n frame_rate %d\n%s}\n" % (
         rate, frame_rate, (" window_width %d\n" % width) if width else "")
     cfg += "module\n{\n name f\n type fft\n magnitude 0\n sources a\n}\n"
