@@ -96,6 +96,7 @@ def _declare(L: C.CDLL) -> None:
     L.aasr_feat_halo.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.aasr_feat_halo.restype = None
     L.aasr_feat_last_frame.argtypes = [vp, i64]
+    L.aasr_feat_eof_frame.argtypes = [vp, i64]
     L.aasr_feat_run.argtypes = [vp, vp, i64, i32, i32, cp, vp]
     L.aasr_feat_run_dev.argtypes = [vp, vp, i64, i32, i32, vp, vp]
     L.aasr_feat_run_f64.argtypes = [vp, vp, i64, i32, i32, cp, vp]
@@ -463,6 +464,10 @@ class Feat:
 
     def last_frame(self, n_samples: int) -> int:
         return lib().aasr_feat_last_frame(self._h, n_samples)
+
+    def eof_frame(self, n_samples: int) -> int:
+        """first frame whose window crosses the end of the input = frames a whole-file run emits"""
+        return lib().aasr_feat_eof_frame(self._h, n_samples)
 
     def run(self, pcm: np.ndarray, first_frame: int, n_frames: int, module: Optional[str] = None,
             dtype=np.float32) -> np.ndarray:

@@ -297,7 +297,7 @@ void FeatureGenerator::register_user_type(const char *type, FeatureModule *(*fac
   if (aasr_feat_register_module_type(type, &v, (void *)factory) != AASR_OK) throw std::string(aasr_last_error());
 }
 
-bool BaseFeaModule::eof(int frame) { return frame >= m_gen->last_frame() + 1; }
+bool BaseFeaModule::eof(int frame) { return frame >= m_gen->eof_frame(); }
 int BaseFeaModule::sample_rate(void) { return m_gen->sample_rate(); }
 float BaseFeaModule::frame_rate(void) { return m_gen->frame_rate(); }
 int BaseFeaModule::last_frame(void) { return m_gen->last_frame(); }
@@ -513,12 +513,12 @@ void FeatureGenerator::stream_read_until(int frame) {
   aasr_feat_halo(m_feat, &halo_l, &halo_r);
   const int64_t want_frame = frame == INT_MAX ? (int64_t)INT_MAX : (int64_t)frame + halo_r + 1;
   std::vector<unsigned char> raw;
-  while (!m_stream_eof && (want_frame == INT_MAX || aasr_feat_last_frame(m_feat, (int64_t)m_pcm.size()) < want_frame)) {
+  while (!m_stream_eof && (want_frame == INT_MAX || aasr_feat_eof_frame(m_feat, (int64_t)m_pcm.size()) - 1 < want_frame)) {
     // samples still missing for that frame: one window advance per frame, at least one window
     int64_t missing = 4096;
     if (want_frame != INT_MAX) {
       const double adv = (double)sample_rate() / (double)frame_rate();
-      const int64_t have_frames = std::max(-1, aasr_feat_last_frame(m_feat, (int64_t)m_pcm.size()));
+      const int64_t have_frames = std::max(-1, aasr_feat_eof_frame(m_feat, (int64_t)m_pcm.size()) - 1);
       missing = std::max<int64_t>(1, (int64_t)((want_frame - have_frames) * adv));
     }
     raw.resize((size_t)missing * 2);
@@ -560,6 +560,10 @@ int FeatureGenerator::last_frame() {
   stream_read_until(INT_MAX);  // stream mode: only the stream's end tells
   return aasr_feat_last_frame(m_feat, (int64_t)m_pcm.size());
 }
+int FeatureGenerator::eof_frame() {
+  stream_read_until(INT_MAX);
+  return aasr_feat_eof_frame(m_feat, (int64_t)m_pcm.size());
+}
 int FeatureGenerator::sample_rate() { return aasr_feat_sample_rate(m_feat); }
 float FeatureGenerator::frame_rate() { return aasr_feat_frame_rate(m_feat); }
 int FeatureGenerator::dim() { return aasr_feat_dim(m_feat); }
@@ -571,7 +575,7 @@ void FeatureGenerator::fill_block(int frame) {
     if (!m_stream_eof) stream_read_until(frame + m_stream_block_frames - 1);
     if (!m_stream_eof) frames = m_stream_block_frames;  // the rest of the stream has not arrived yet
     // AudioFileModule::generate, frame 0 crossing the end (aku/FeatureModules.cc:405-410)
-    if (aasr_feat_last_frame(m_feat, (int64_t)m_pcm.size()) < 0) throw std::string("audio shorter than frame");
+    if (aasr_feat_eof_frame(m_feat, (int64_t)m_pcm.size()) < 1) throw std::string("audio shorter than frame");
   }
   m_block.resize((size_t)frames * d);
   check(aasr_feat_run_f64(m_feat, m_pcm.data(), (int64_t)m_pcm.size(), frame, frames, nullptr, m_block.data()));
@@ -587,9 +591,9 @@ const FeatureVec FeatureGenerator::generate(int frame) {
   if (m_block_count == 0 || frame < m_block_first || frame >= m_block_first + m_block_count)
     fill_block(frame);
   // AudioFileModule::eof (aku/FeatureModules.cc:297-303): true from the first
-  // frame whose window crosses the end of the file, i.e. last_frame()+1
+  // frame whose window crosses the end of the file (aasr_feat_eof_frame)
   m_eof_on_last_frame = (!m_streaming || m_stream_eof) &&
-                        frame >= aasr_feat_last_frame(m_feat, (int64_t)m_pcm.size()) + 1;
+                        frame >= aasr_feat_eof_frame(m_feat, (int64_t)m_pcm.size());
   return FeatureVec(&m_block[(size_t)(frame - m_block_first) * dim()], dim(), frame, this);
 }
 

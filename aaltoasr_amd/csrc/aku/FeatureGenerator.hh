@@ -63,6 +63,8 @@ public:
   const FeatureVec generate(int frame);
   bool eof() const { return m_eof_on_last_frame; }
   int last_frame();
+  /** first frame whose window crosses the end of the input (what eof() reports against) */
+  int eof_frame();
   int sample_rate();
   float frame_rate();
   int dim();

@@ -164,6 +164,7 @@ struct UttBatch {
 
 aasr_feat *feat_create(const std::string &cfg_text);
 int feat_last_frame(const aasr_feat *h, int64_t n_samples);
+int feat_eof_frame(const aasr_feat *h, int64_t n_samples);
 void feat_halo(const aasr_feat *h, int target, int *left, int *right);
 // Evaluates module `target` for the batch; exactly one of out_f32 / out_f64
 // (device pointers, [total_frames x dim]) is written.

@@ -46,7 +46,7 @@ void run_host(aasr_feat *h, const int16_t *pcm, int64_t n_samples, int32_t first
   if (a.type != MOD_PRE && n_samples >= a.width + 1) {
     int l = 0, r = 0;
     feat_halo(h, target, &l, &r);
-    const int64_t last = std::max(0, feat_last_frame(h, n_samples));
+    const int64_t last = std::max(0, feat_eof_frame(h, n_samples) - 1);
     auto clampf = [&](int64_t f) { return std::min(std::max<int64_t>(f, 0), last); };
     const int64_t f_lo = clampf((int64_t)first_frame - l - 2);
     // upper end unclamped (the sample bound does it): without copy_borders, frames past the last
@@ -103,6 +103,7 @@ void aasr_feat_halo(const aasr_feat *h, int *left, int *right) {
 int aasr_feat_last_frame(const aasr_feat *h, int64_t n_samples) {
   return h ? feat_last_frame(h, n_samples) : -1;
 }
+int aasr_feat_eof_frame(const aasr_feat *h, int64_t n_samples) { return h ? feat_eof_frame(h, n_samples) : -1; }
 
 aasr_status aasr_feat_run(aasr_feat *h, const int16_t *pcm, int64_t n_samples,
                           int32_t first_frame, int32_t n_frames, const char *module_name,
@@ -179,10 +180,10 @@ aasr_status aasr_feat_run_batch_dev(aasr_feat *h, const int16_t *d_pcm, const in
     for (int u = 0; u < n_utts; u++) {
       int64_t ns = pcm_off[u + 1] - pcm_off[u];
       int64_t nf = frame_off[u + 1] - frame_off[u];
-      if (nf != (int64_t)feat_last_frame(h, ns) + 1)
+      if (nf != (int64_t)feat_eof_frame(h, ns))
         raise(AASR_ERR_INVALID,
-              "utterance %d: frame_off says %ld frames but %ld samples give last_frame()+1 = %d",
-              u, (long)nf, (long)ns, feat_last_frame(h, ns) + 1);
+              "utterance %d: frame_off says %ld frames but %ld samples give %d (aasr_feat_eof_frame)",
+              u, (long)nf, (long)ns, feat_eof_frame(h, ns));
     }
     feat_run_batch(h, d_pcm, b, (int)h->mods.size() - 1, d_out, nullptr, (hipStream_t)stream);
   });

@@ -819,6 +819,22 @@ int feat_last_frame(const aasr_feat *h, int64_t n_samples) {
   return (int)(((int)n_samples - a.width - 1) / a.advance);
 }
 
+// The frame at which a sequential reader meets the end of the input: the first frame whose window
+// [ws, ws + width + 1), ws = (int)(frame * advance) in float, crosses it (AudioFileModule::generate,
+// aku/FeatureModules.cc:399-413 sets m_eof_frame = frame there; phone_probs stops at that frame and
+// the border copy repeats frame m_eof_frame - 1).  Equal to last_frame() + 1 for an integral
+// advance below 2^24 samples; the float formula of last_frame() can be one off beyond that and
+// with a fractional advance.
+int feat_eof_frame(const aasr_feat *h, int64_t n_samples) {
+  const FeatModule &a = h->mods[0];
+  if (a.type == MOD_PRE) return feat_last_frame(h, n_samples) + 1;
+  if (n_samples < a.width + 1) return 0;
+  int g = std::max(1, feat_last_frame(h, n_samples) + 1);
+  while (g > 1 && (int64_t)(int)((float)(g - 1) * a.advance) + a.width + 1 > n_samples) g--;
+  while ((int64_t)(int)((float)g * a.advance) + a.width + 1 <= n_samples) g++;
+  return g;
+}
+
 void feat_halo(const aasr_feat *h, int target, int *left, int *right) {
   // longest accumulated look-around from `target` down to the base module
   std::vector<int> L(h->mods.size(), -1), R(h->mods.size(), -1);

@@ -35,7 +35,7 @@ struct DevBatch {
   const int64_t *frame_off;  // [n+1]
   const int64_t *pcm_off;    // [n+1]
   const int32_t *first;      // [n]
-  const int32_t *eof_frame;  // [n] last_frame()+1
+  const int32_t *eof_frame;  // [n] feat_eof_frame(): first frame whose window crosses the end
 };
 
 // largest u with key(u) = frame_off[u] + u*span <= r
@@ -1100,7 +1100,7 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
       raise(AASR_ERR_SHORT_AUDIO, "audio shorter than frame");
     if (ns > INT32_MAX)
       raise(AASR_ERR_UNSUPPORTED, "utterance longer than 2^31 samples");
-    eof[u] = feat_last_frame(h, ns) + 1;
+    eof[u] = feat_eof_frame(h, ns);
     if (eof[u] < 1) raise(AASR_ERR_SHORT_AUDIO, "audio shorter than frame");
   }
   h->d_frame_off.ensure(n + 1);

@@ -418,7 +418,7 @@ static void frame_range(aasr_feat *feat, int64_t n_samples, float start_time, fl
   frame_limits(start_time, end_time, feat->mods[0].frame_rate, &start_frame, &end_frame);
   if (feat->mods[0].type != MOD_PRE && n_samples < feat->mods[0].width + 1)
     raise(AASR_ERR_SHORT_AUDIO, "audio shorter than frame");
-  int eof_frame = feat_last_frame(feat, n_samples) + 1;
+  int eof_frame = feat_eof_frame(feat, n_samples);
   int stop = std::min(end_frame, eof_frame);
   *start = start_frame;
   *count = stop > start_frame ? stop - start_frame : 0;
@@ -801,7 +801,7 @@ void run_utterance(aasr_feat *feat, aasr_gmm *gmm, const int16_t *pcm, int64_t n
     raise(AASR_ERR_SHORT_AUDIO, "audio shorter than frame");
   Job j;
   j.pcm.assign(pcm, pcm + n_samples);
-  int eof_frame = feat_last_frame(feat, n_samples) + 1;
+  int eof_frame = feat_eof_frame(feat, n_samples);
   if (end_frame <= 0) end_frame = INT_MAX;
   int stop = std::min(end_frame, eof_frame);
   j.start = start_frame;

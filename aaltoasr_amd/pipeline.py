@@ -31,7 +31,7 @@ class FullChainBench:
             base = [synth.make_audio(n, seed=synth.SEED + 1000 * rank + i, sample_rate=sr) for i in range(8)]
             utts = [base[i % len(base)] for i in range(n_utts)]
         self.utts = utts
-        frames = [self.feat.last_frame(len(u)) + 1 for u in utts]
+        frames = [self.feat.eof_frame(len(u)) for u in utts]
         self.pcm_off = np.concatenate([[0], np.cumsum([len(u) for u in utts])]).astype(np.int64)
         self.frame_off = np.concatenate([[0], np.cumsum(frames)]).astype(np.int64)
         self.total_frames = int(self.frame_off[-1])

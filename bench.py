@@ -235,7 +235,7 @@ def run_recipe_workload(args, capi, synth, shard, gmm, world, rank, n_utts, step
     with the local figures; the caller aggregates over ranks."""
     feat = capi.Feat(synth.make_feature_config())
     lengths = recipe_lengths(n_utts)
-    frames_all = np.array([feat.last_frame(int(n)) + 1 for n in lengths], np.int64)
+    frames_all = np.array([feat.eof_frame(int(n)) for n in lengths], np.int64)
     first, count = shard.rank_slice(n_utts, world, rank)
     my_frames = int(frames_all[first:first + count].sum())
     out_bytes = my_frames * S * 2

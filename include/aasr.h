@@ -80,6 +80,12 @@ void aasr_feat_halo(const aasr_feat *h, int *left, int *right);
  * n_samples; the whole-file frame count phone_probs emits is last_frame+1
  * (aku/phone_probs.cc:217-221). */
 int aasr_feat_last_frame(const aasr_feat *h, int64_t n_samples);
+/* The frame at which a sequential reader of n_samples meets the end: the first frame whose window
+ * crosses it (AudioFileModule::generate, aku/FeatureModules.cc:399-413 sets m_eof_frame there).
+ * phone_probs emits frames 0 .. eof_frame - 1 and the border copy repeats frame eof_frame - 1.
+ * Equal to last_frame() + 1 except where last_frame()'s float formula is off by one (inputs
+ * beyond 2^24 samples, fractional window advances). */
+int aasr_feat_eof_frame(const aasr_feat *h, int64_t n_samples);
 
 /* Graphs whose first module is a `pre` module (PreModule,
  * aku/FeatureModules.cc:572-755) take float feature frames instead of audio:

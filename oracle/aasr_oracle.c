@@ -534,6 +534,26 @@ int orc_last_frame(int64_t n_samples, int window_width, float window_advance)
     return (int)(((int)n_samples - window_width - 1) / window_advance);
 }
 
+/* The frame at which a sequential reader meets the end of the file: the first frame whose
+ * window [ws, ws + width + 1) with ws = (int)(frame * window_advance) (float product) crosses it
+ * (AudioFileModule::generate, aku/FeatureModules.cc:399-413: "EOF during this frame?" sets
+ * m_eof_frame = frame; phone_probs stops there, the border copy repeats frame m_eof_frame - 1).
+ * For an integral advance and fewer than 2^24 samples this is last_frame() + 1; the float formula
+ * of last_frame() can be one off beyond that (one hour in one file: last_frame() = 449 998, the
+ * reader stops at frame 449 998, i.e. 449 998 frames) and with a fractional advance. */
+int orc_eof_frame(int64_t n_samples, int window_width, float window_advance)
+{
+    if (n_samples < window_width + 1)
+        return 0;
+    int g = orc_last_frame(n_samples, window_width, window_advance) + 1;
+    if (g < 1) g = 1;
+    while (g > 1 && (int64_t)(int)((float)(g - 1) * window_advance) + window_width + 1 > n_samples)
+        g--;
+    while ((int64_t)(int)((float)g * window_advance) + window_width + 1 <= n_samples)
+        g++;
+    return g;
+}
+
 static inline int16_t orc_sample(const int16_t *pcm, int64_t n, int64_t i)
 {
     /* AudioReader::read_from_file zero-fills outside the file
@@ -545,14 +565,14 @@ static inline int16_t orc_sample(const int16_t *pcm, int64_t n, int64_t i)
  * first_frame .. first_frame+n_frames-1.  out is [n_frames x window_width].
  *  - window_start = (int)(frame * window_advance)   (float product)
  *  - copy_borders: frames < 0 return frame 0's vector; frames >= eof_frame
- *    (= last_frame()+1, :417) return the last whole frame's vector.
+ *    (orc_eof_frame) return the last whole frame's vector.
  *  - y[t] = x[ws+t+1] - emph * x[ws+t] evaluated in FLOAT (short - float*short)
  * Returns 0, or -1 for "audio shorter than frame" (:408-409). */
 int orc_audio_frames(const int16_t *pcm, int64_t n_samples, float window_advance,
                      int window_width, float emph, int copy_borders,
                      int first_frame, int n_frames, double *out)
 {
-    int eof_frame = orc_last_frame(n_samples, window_width, window_advance) + 1;
+    int eof_frame = orc_eof_frame(n_samples, window_width, window_advance);
     if (n_samples < window_width + 1)
         return -1;
     for (int j = 0; j < n_frames; j++) {

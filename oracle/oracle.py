@@ -75,6 +75,8 @@ def _declare(L: C.CDLL) -> None:
     L.orc_default_window_width.argtypes = [i32, f]
     L.orc_last_frame.restype = i32
     L.orc_last_frame.argtypes = [i64, i32, f]
+    L.orc_eof_frame.restype = i32
+    L.orc_eof_frame.argtypes = [i64, i32, f]
     L.orc_audio_frames.restype = i32
     L.orc_audio_frames.argtypes = [pi16, i64, f, i32, f, i32, i32, i32, pd]
     L.orc_rfft.restype = i32
@@ -489,9 +491,14 @@ class FeatureChain:
         return lib().orc_last_frame(int(n_samples), p["width"], float(p["advance"]))
 
     def num_frames(self, n_samples: int) -> int:
-        """frames phone_probs emits for a whole file: 0..last_frame
-        (aku/phone_probs.cc:217-221 with AudioFileModule::eof)."""
-        return self.last_frame(n_samples) + 1
+        """frames phone_probs emits for a whole file: it stops at the first frame whose window
+        crosses the end (aku/phone_probs.cc:217-221 with AudioFileModule::eof; orc_eof_frame) --
+        last_frame() + 1 except where that float formula is off (files beyond 2^24 samples,
+        fractional window advances)."""
+        if self.base.type == "pre":
+            return self.last_frame(n_samples) + 1
+        p = self.base.prm
+        return lib().orc_eof_frame(int(n_samples), p["width"], float(p["advance"]))
 
     def halo(self) -> Tuple[int, int]:
         """(left, right) base-module frames needed around one output frame."""

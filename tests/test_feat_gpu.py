@@ -443,3 +443,34 @@ def test_fused_kernels_equal_the_module_by_module_path(capi, oracle, kw):
         want = ch.generate(utts[u], 0, frames[u])
         got = outs[0][0][int(frame_off[u]):int(frame_off[u + 1])]
         assert np.abs(got - want).max() <= FEAT_TOL * max(1.0, np.abs(want).max() / 10)
+
+
+def test_eof_frame_matches_the_sequential_reader(capi, oracle):
+    """aasr_feat_eof_frame = the frame at which AudioFileModule::generate meets the end of the file
+    (aku/FeatureModules.cc:399-413), i.e. how many frames phone_probs emits: equal to the oracle's
+    brute-force-checked orc_eof_frame for integral and fractional window advances and for lengths
+    beyond 2^24 samples, where last_frame()'s float formula is one off; a whole-file run emits
+    exactly that many frames."""
+    rng = np.random.default_rng(3)
+    parted = 0
+    for rate, fr, width in ((16000, 125, 0), (11025, 100, 220), (22050, 100, 442), (11025, 125, 200), (44100, 100, 1000)):
+        cfg = "module\n{\n name a\n type audiofile\n sample_rate %d\n frame_rate %d\n%s}\n" % (
+            rate, fr, (" window_width %d\n" % width) if width else "")
+        cfg += "module\n{\n name f\n type fft\n magnitude 0\n sources a\n}\n"
+        ft = capi.Feat(cfg)
+        ch = oracle.FeatureChain(cfg)
+        for n in list(rng.integers(2000, 300000, 40)) + list(rng.integers((1 << 24) - 2000, (1 << 24) + 200000, 20)) + [57600000]:
+            n = int(n)
+            assert ft.eof_frame(n) == ch.num_frames(n), (rate, fr, width, n)
+            assert ft.last_frame(n) == ch.last_frame(n)
+            parted += ft.eof_frame(n) != ft.last_frame(n) + 1
+    assert parted > 0
+    # a fractional advance where the two differ: the run emits eof_frame frames, the last one whole
+    cfg = "module\n{\n name a\n type audiofile\n sample_rate 11025\n frame_rate 125\n window_width 200\n}\n"
+    cfg += "module\n{\n name f\n type fft\n magnitude 0\n sources a\n}\n"
+    ft = capi.Feat(cfg)
+    ch = oracle.FeatureChain(cfg)
+    n = next(int(k) for k in range(30000, 31000) if ft.eof_frame(int(k)) != ft.last_frame(int(k)) + 1)
+    pcm = synth.make_audio(n, seed=2, sample_rate=11025)
+    T = ft.eof_frame(n)
+    assert np.array_equal(ft.run(pcm, 0, T + 3, dtype=np.float64), ch.generate(pcm, 0, T + 3))

@@ -129,6 +129,48 @@ def test_config2_one_hour_full_chain(capi, oracle):
         assert data[5:] == rows, "utterance %d differs between the batch step and a run of its own" % u
 
 
+def test_one_hour_as_a_single_file(capi, oracle):
+    """SURVEY 8(d)'s stress case of configs[2]: the hour as ONE utterance (57.6 M samples, 449 998
+    frames), far beyond the 2^24 samples below which float32 sample arithmetic is trivially exact
+    (window_start = (int)(frame * window_advance) stays exact because the advance is 128).  The
+    whole file through aasr_run_utterance (features -> scoring -> 4-byte LNA) with a small model;
+    stretches at the start, across 2^24 samples, in the middle and at the very end against the
+    oracle's chain + scoring + normalisation; the base module's frames beyond the end repeat the last one."""
+    n_samples = 3600 * 16000
+    rng = np.random.default_rng(44)
+    pcm = np.empty(n_samples, np.int16)
+    for a in range(0, n_samples, 1 << 22):          # seeded noise + tones in chunks (bounded memory)
+        b = min(a + (1 << 22), n_samples)
+        t = np.arange(a, b, dtype=np.float64) / 16000.0
+        x = 2000.0 * rng.standard_normal(b - a) + 6000.0 * (np.sin(2 * np.pi * 220 * t) + np.sin(2 * np.pi * 1370 * t)
+                                                             + np.sin(2 * np.pi * 3100 * t))
+        pcm[a:b] = np.clip(np.rint(x), -32767, 32767).astype(np.int16)
+    cfg = synth.make_feature_config()
+    model = synth.make_model(D=D, G=2048, S=128, comps=16)
+    gmm = capi.Gmm.from_arrays(*model)
+    feat = capi.Feat(cfg)
+    # AudioFileModule::last_frame()'s float formula says 449 998 here ((float)57599743 rounds up), the
+    # sequential reader meets the end AT frame 449 998: 449 998 frames, as SURVEY 8(d) counts them
+    assert feat.last_frame(n_samples) == 449998 and feat.eof_frame(n_samples) == 449998
+    assert oracle.FeatureChain(cfg).num_frames(n_samples) == 449998
+    data, n = capi.run_utterance(feat, gmm, pcm, lnabytes=4)
+    assert n == 449998 and len(data) == 5 + n * 128 * 4
+    lp = np.frombuffer(data[5:], "<f4").reshape(n, 128)
+    ch = oracle.FeatureChain(cfg)
+    om = oracle.DiagModel(*model)
+    for first in (0, (1 << 24) // 128 - 40, 225000, n - 90):
+        cnt = min(80, n - first)
+        # the oracle's chain is a pure function of the frame index and the samples around it
+        fea = ch.generate(pcm, first, cnt)
+        ll_ref, lik = om.score(fea, want_lik=True)
+        lp_ref, _ = oracle.lna_encode(lik, True, 4)
+        smooth = (ll_ref > -87.0) | (ll_ref < -104.5)
+        assert np.abs(lp[first:first + cnt] - lp_ref)[smooth].max() <= 1e-4, first
+    base = feat.run(pcm, n - 2, 6, module="audiofile", dtype=np.float64)
+    assert np.array_equal(base[2:], np.repeat(base[1:2], 4, 0))       # copy_borders: frames from eof on repeat eof - 1
+    assert np.array_equal(base, ch.generate(pcm, n - 2, 6, module="audiofile"))
+
+
 # ---------------------------------------------------------------------------
 # BASELINE configs[4]: D = 39, G = 10 000 full-covariance Gaussians, F = 200 000
 # ---------------------------------------------------------------------------

@@ -353,3 +353,29 @@ def test_lna_files_read_by_the_reference_decoder_reader(oracle, tmp_path, nbytes
         inside = lp > -36.0
         assert np.abs(got - lp)[inside].max() <= 0.5 / 1820 + 1e-6
         assert np.all(got[~inside] <= -36.0)
+
+
+def test_eof_frame_is_where_a_sequential_reader_meets_the_end(oracle):
+    """orc_eof_frame against the definition (first frame whose window [ws, ws + width + 1), ws =
+    (int)(float(frame) * advance), crosses the end; aku/FeatureModules.cc:399-413) by brute force:
+    integral and fractional advances, lengths around 2^24 samples where last_frame()'s float formula
+    goes off by one."""
+    L = oracle.lib()
+    rng = np.random.default_rng(12)
+    cases = [(128.0, 256), (160.0, 400), (110.25, 220), (220.5, 442), (441.0, 1000), (88.2, 200), (64.0, 128)]
+    differs = 0
+    for adv, width in cases:
+        adv32 = np.float32(adv)
+        lens = list(rng.integers(width + 1, 200000, 60)) + list(rng.integers((1 << 24) - 3000, (1 << 24) + 300000, 40)) \
+            + [57600000, width + 1, width + 2]
+        for n in lens:
+            n = int(n)
+            got = L.orc_eof_frame(n, width, float(adv32))
+            f = max(0, got - 3)
+            while int(np.float32(f) * adv32) + width + 1 <= n:
+                f += 1
+            assert got == f, (adv, width, n, got, f)
+            assert int(np.float32(max(got - 1, 0)) * adv32) + width + 1 <= n or got == 0
+            differs += got != L.orc_last_frame(n, width, float(adv32)) + 1
+    assert differs > 0          # the two do part ways (fractional advances, long files)
+    assert L.orc_eof_frame(100, 256, 128.0) == 0
