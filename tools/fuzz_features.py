@@ -28,9 +28,10 @@ def run(seed=1, N=40, verbose=False):
     worst = {}
     fails = []
     for it in range(N):
-        sr = int(rng.choice([8000, 16000, 16000, 22050]))
+        sr = int(rng.choice([8000, 16000, 16000, 22050, 11025]))
         fr = float(rng.choice([100, 125, 125, 160]))
-        width = int(rng.choice([0, 0, 256, 320, 400, 512, 200, 240]))
+        # 220, 276, 364, 442: half lengths with prime factors 11, 23, 13, 17 (KissFFT's generic butterfly)
+        width = int(rng.choice([0, 0, 256, 320, 400, 512, 200, 240, 220, 276, 364, 442]))
         kw = dict(sample_rate=sr, frame_rate=fr)
         if width:
             kw["window_width"] = width
