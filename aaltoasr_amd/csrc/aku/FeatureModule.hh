@@ -22,21 +22,43 @@ namespace aku {
 class FeatureGenerator;
 class FeatureModule;
 
-/** What a user module's generate(frame) writes into: m_buffer[frame] (the reference's ring buffer,
- * aku/FeatureBuffer.hh:92-143, reduced to the one slot that is being computed). */
+/** aku/FeatureBuffer.hh:92-143.  Two uses: (a) a circular store of feature vectors a caller keeps for
+ * itself -- resize(num_frames, dim), then operator[](frame) addresses slot frame mod num_frames, as
+ * HmmNetBaumWelch does with the frames of its window (aku/HmmNetBaumWelch.cc:806-835); (b) what a
+ * user module's generate(frame) writes into, m_buffer[frame], reduced to the one slot that is being
+ * computed. */
 class FeatureBuffer {
 public:
-  FeatureVec operator[](int frame) {
-    if (!m_row || frame != m_frame) throw std::string("FeatureBuffer: only the frame being generated can be written");
-    return FeatureVec(m_row, m_dim, frame, nullptr);
+  FeatureBuffer() {}
+  void resize(int num_frames, int dim) {
+    assert(num_frames > 0 && dim > 0);
+    m_num_frames = num_frames;
+    m_dim = dim;
+    m_store.assign((size_t)num_frames * dim, 0.0);
+    m_row = nullptr;
   }
+  void clear(void) { resize(1, 1); }
   int dim() const { return m_dim; }
+  int num_frames() const { return m_num_frames; }
+  const FeatureVec operator[](int frame) const {
+    if (m_store.empty()) throw std::string("FeatureBuffer: empty");
+    return FeatureVec(&m_store[(size_t)util::modulo(frame, m_num_frames) * m_dim], m_dim, frame, nullptr);
+  }
+  FeatureVec operator[](int frame) {
+    if (m_row) {  // (b): the slot of the frame being generated
+      if (frame != m_frame) throw std::string("FeatureBuffer: only the frame being generated can be written");
+      return FeatureVec(m_row, m_dim, frame, nullptr);
+    }
+    if (m_store.empty()) throw std::string("FeatureBuffer: only the frame being generated can be written");
+    return FeatureVec(&m_store[(size_t)util::modulo(frame, m_num_frames) * m_dim], m_dim, frame, nullptr);
+  }
 
 private:
   friend class FeatureModule;
   friend struct UserModuleGlue;
   double *m_row = nullptr;
-  int m_dim = 0, m_frame = 0;
+  int m_dim = 0, m_frame = 0, m_num_frames = 0;
+  std::vector<double> m_store;
 };
 
 class FeatureModule {

@@ -4,8 +4,8 @@
 // cluster_speakers), infos with every Info field, clear(), sort_infos().
 // Info::init_phn_files (aku/Recipe.cc:152-194) is declared when the aligners' PhnReader.hh is on
 // the include path -- i.e. when the reference's own aku/PhnReader.{hh,cc} / aku/Viterbi.{hh,cc} are
-// being compiled against these adapters (oracle/Makefile: align_refmain); init_hmmnet_files (the
-// Baum-Welch trainer) is not declared.
+// being compiled against these adapters (oracle/Makefile: align_refmain); init_hmmnet_files
+// (:197-229) likewise when aku/HmmNetBaumWelch.hh is (logl_refmain).
 #ifndef AKU_AMD_RECIPE_HH
 #define AKU_AMD_RECIPE_HH
 
@@ -20,6 +20,10 @@
 #if __has_include("PhnReader.hh")
 #include "PhnReader.hh"
 #define AKU_AMD_HAVE_PHNREADER 1
+#endif
+#if __has_include("HmmNetBaumWelch.hh")
+#include "HmmNetBaumWelch.hh"
+#define AKU_AMD_HAVE_HMMNETBW 1
 #endif
 #endif
 
@@ -65,6 +69,31 @@ public:
         phn_reader->set_frame_limits((int)(start_time * frame_rate), (int)(end_time * frame_rate));
       if (start_line > 0 || end_line > 0) phn_reader->set_line_limits(start_line, end_line);
       return phn_reader;
+    }
+#endif
+#ifdef AKU_AMD_HAVE_HMMNETBW
+    /** aku/Recipe.cc:197-229: opens the audio and the (numerator or denominator) HMM network, with the
+     * recipe line's frame limits */
+    HmmNetBaumWelch *init_hmmnet_files(HmmSet *model, bool den_hmmnet, FeatureGenerator *fea_gen,
+                                       HmmNetBaumWelch *hnbw) {
+      fea_gen->open(audio_path);
+      if (hnbw == NULL) {
+        if (model == NULL)
+          throw std::string("Recipe::Info::init_hmmnet_files: HMM model is required if hnbw==NULL");
+        hnbw = new HmmNetBaumWelch(*fea_gen, *model);
+      }
+      if (den_hmmnet) {
+        hnbw->open(den_hmmnet_path);
+      } else {
+        if (hmmnet_path.empty())
+          throw std::string("Recipe::Info::init_hmmnet_files: hmmnet not specified in recipe.");
+        hnbw->open(hmmnet_path);
+      }
+      if (start_time > 0 || end_time > 0) {
+        const float frame_rate = fea_gen->frame_rate();
+        hnbw->set_frame_limits((int)(start_time * frame_rate), (int)(end_time * frame_rate));
+      }
+      return hnbw;
     }
 #endif
     bool operator<(const Info &i) const { return (speaker_id < i.speaker_id); }

@@ -23,6 +23,29 @@ inline int modulo(int a, int b) {
 template <class T>
 inline T sqr(T a) { return a * a; }
 
+/** aku/util.hh:62-130: maximum, and log(e^a + e^b) in natural and decimal logarithms */
+template <typename T>
+T max(const T &a, const T &b) {
+  if (a < b) return b;
+  return a;
+}
+inline float logaddf(float a, float b) {
+  float delta = a - b;
+  if (delta > 0) {
+    b = a;
+    delta = -delta;
+  }
+  return b + log1pf(expf(delta));
+}
+inline double logadd(double a, double b) {
+  double delta = a - b;
+  if (delta > 0) {
+    b = a;
+    delta = -delta;
+  }
+  return b + log1p(exp(delta));
+}
+
 }  // namespace util
 
 #endif

@@ -64,7 +64,7 @@ def test_decode_stream_acoustics_compile_against_the_adapters(tmp_path):
 
 @needs_ref
 def test_reference_mains_are_linked_with_the_engine(capi, oracle):
-    for name in ("phone_probs_refmain", "feacat_refmain", "align_refmain", "vtln_refmain"):
+    for name in ("phone_probs_refmain", "feacat_refmain", "align_refmain", "vtln_refmain", "logl_refmain"):
         assert os.access(os.path.join(REFBIN, name), os.X_OK), name
 
 
@@ -357,3 +357,79 @@ def test_reference_vtln_estimation_on_the_engine(capi, oracle, tmp_path):
     for spk, true_wf in speakers.items():
         block = text.split("speaker %s\n" % spk)[1].split("}\n\n}")[0]
         assert "feature vtln" in block and ("warp_factor %g" % float(true_wf)) in block, block
+
+
+@pytest.mark.gpu
+def test_reference_logl_with_both_segmentators_on_the_engine(capi, oracle, tmp_path):
+    """aku/logl.cc on the engine with (a) PhnReader over a given state segmentation -- the sum of the
+    oracle's state log-likelihoods along it -- and (b) HmmNetBaumWelch (aku/HmmNetBaumWelch.cc, the
+    trainers' forward-backward engine, its own FeatureBuffer of frames and lazy
+    HmmSet::state_likelihood calls) over a left-to-right HMM network: the total log-likelihood of
+    the forward algorithm, and with -V the best path's, both computed here from the oracle's
+    double-precision state likelihoods."""
+    exe = os.path.join(REFBIN, "logl_refmain")
+    if not os.access(exe, os.X_OK):
+        pytest.skip("oracle/_ref/logl_refmain was not built (no reference tree in the build container)")
+    rng = np.random.default_rng(41)
+    cfg_text = synth.make_feature_config()
+    cfg = str(tmp_path / "f.cfg")
+    open(cfg, "w").write(cfg_text)
+    pcm = synth.make_audio(16000 * 2, seed=73)
+    wav = str(tmp_path / "a.wav")
+    _write_wav(wav, pcm)
+    ft = capi.Feat(cfg_text)
+    T = ft.eof_frame(len(pcm))
+    fea = ft.run(pcm, 0, T, dtype=np.float64)
+    S, per = 30, 3
+    mean, var, off, idx, w = synth.make_model(D=39, G=90, S=S, comps=3, seed=27)
+    mean[:] = fea[rng.integers(0, T, 90)] + 0.3 * rng.standard_normal((90, 39))
+    var[:] = rng.uniform(0.6, 1.6, var.shape)
+    base = str(tmp_path / "m")
+    oracle.write_gk(base + ".gk", mean, var)
+    oracle.write_mc(base + ".mc", off, idx, w)
+    oracle.write_ph(base + ".ph", S, states_per_hmm=per)
+    ll = oracle.DiagModel(mean, var, off, idx, w).score(fea)            # [T x S], floored at log 1e-50
+    # (a) a state segmentation with state-number labels
+    seg = [int(ll[a:a + 12].sum(axis=0).argmax()) for a in range(0, T, 12)]
+    with open(tmp_path / "seg.phn", "w") as f:
+        for k, s in enumerate(seg):
+            f.write("%d %d %d\n" % (k * 12 * 128, min((k + 1) * 12, T) * 128, s))
+    open(tmp_path / "a.recipe", "w").write("audio=%s transcript=%s\n" % (wav, tmp_path / "seg.phn"))
+    r = subprocess.run([exe, "-b", base, "-c", cfg, "-r", str(tmp_path / "a.recipe"), "--snl", "-i", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = float(r.stdout.strip().splitlines()[-1].split(":")[-1])
+    want = sum(float(ll[t, seg[t // 12]]) for t in range(T))
+    assert abs(got - want) <= 2e-3 + 1e-6 * abs(want), (got, want)
+    # (b) a left-to-right network over 8 HMMs: node i emits state q_i on both of its arcs; the
+    # transition indices are the model's (state s: self = 2 s, next = 2 s + 1, both 0.5)
+    q = [h * per + j for h in (3, 0, 7, 2, 5, 1, 9, 6) for j in range(per)]
+    P = len(q)
+    with open(tmp_path / "net.hmmnet", "w") as f:
+        # the initial node may have no in-arcs (no self loop): an epsilon arc leads to the first state
+        f.write("#FSTBasic MaxPlus\nI 0\nF %d\nT 0 1\n" % (P + 1))
+        for i, s in enumerate(q):
+            f.write("T %d %d %d\n" % (i + 1, i + 1, 2 * s))
+            f.write("T %d %d %d\n" % (i + 1, i + 2, 2 * s + 1))
+    open(tmp_path / "b.recipe", "w").write("audio=%s hmmnet=%s\n" % (wav, tmp_path / "net.hmmnet"))
+    lq = ll[:, q]
+    lh = np.log(0.5)
+    alpha = np.full(P + 1, -np.inf)
+    best = np.full(P + 1, -np.inf)
+    alpha[0] = best[0] = 0.0
+    for t in range(T):
+        stay = alpha[:P] + lh + lq[t]
+        na = np.full(P + 1, -np.inf)
+        na[:P] = stay
+        na[1:] = np.logaddexp(na[1:], alpha[:P] + lh + lq[t])
+        alpha = na
+        nb = np.full(P + 1, -np.inf)
+        nb[:P] = best[:P] + lh + lq[t]
+        nb[1:] = np.maximum(nb[1:], best[:P] + lh + lq[t])
+        best = nb
+    for flags, want in (([], alpha[P]), (["-V"], best[P])):
+        r = subprocess.run([exe, "-b", base, "-c", cfg, "-r", str(tmp_path / "b.recipe"), "-H", "-F", "1e9", "-W", "1e9",
+                            "-i", "1"] + flags, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got = float(r.stdout.strip().splitlines()[-1].split(":")[-1])
+        assert abs(got - want) <= 5e-3 + 1e-6 * abs(want), (flags, got, want, r.stdout[-500:], r.stderr[-500:])
