@@ -1145,7 +1145,7 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
   // spectral group: audiofile -> F fft -> {M mel -> D dct, P power} -> G merge [D, P], nothing else
   // reading F, M, D, P and none of them the requested output
   std::vector<char> skip(nm, 0);
-  int sgF = -1, sgM = -1, sgP = -1, sgD = -1, sgG = -1;
+  int sgF = -1, sgM = -1, sgD = -1, sgG = -1;
   int tgX = -1, tgA = -1, tgB = -1, tgN = -1, tgT = -1;
   if (g_feat_fusion && base.type == MOD_AUDIOFILE && target != 0 && consumers[0] == 1) {
     for (int gi = 1; gi <= target && sgG < 0; gi++) {
@@ -1164,7 +1164,7 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
       const SpectralLds lds(h->mods[F].fft.nc, h->mods[M].dim, (int)h->mods[M].mel_t.n,
                             h->mods[D].dim - (h->mods[D].zeroth ? 1 : 0));
       if (lds.total > 64 * 1024) continue;
-      sgF = F; sgM = M; sgP = P; sgD = D; sgG = gi;
+      sgF = F; sgM = M; sgD = D; sgG = gi;
       skip[F] = skip[M] = skip[P] = skip[D] = 1;
     }
   }
