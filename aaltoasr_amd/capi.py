@@ -156,6 +156,7 @@ def _declare(L: C.CDLL) -> None:
                                      C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(i64), C.POINTER(i64)]
     L.aasr_lna_read_file.argtypes = [cp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64), C.POINTER(C.POINTER(C.c_float))]
     L.aasr_audio_decode.argtypes = [vp, vp, i64, C.POINTER(C.POINTER(C.c_int16)), C.POINTER(i64), C.POINTER(i32)]
+    L.aasr_gmm_score_f64.argtypes = [vp, vp, i64, vp]
     L.aasr_free.argtypes = [vp]
     L.aasr_free.restype = None
     L.aasr_feat_get_parameters.argtypes = [vp, cp, C.POINTER(C.c_void_p), C.POINTER(i64)]
@@ -295,6 +296,13 @@ class Gmm:
         W = np.ascontiguousarray(W, np.float64)
         g2t = np.ascontiguousarray(gauss_to_transform, np.int32)
         check(lib().aasr_gmm_set_cmllr(self._h, W.shape[0], _ptr(g2t), _ptr(W)))
+
+    def score_f64(self, frames: np.ndarray) -> np.ndarray:
+        """AASR_PREC_F64: double frames [F x D] -> double log state likelihoods [F x S]."""
+        frames = np.ascontiguousarray(frames, np.float64)
+        out = np.empty((frames.shape[0], self.num_states), np.float64)
+        check(lib().aasr_gmm_score_f64(self._h, _ptr(frames), frames.shape[0], _ptr(out)))
+        return out
 
     def read_clustering(self, path: str) -> None:
         """HmmSet::read_clustering (.gcl file)."""

@@ -257,9 +257,34 @@ aasr_status aasr_gmm_set_precision(aasr_gmm *h, int prec) {
       h->use_bf16x3 = (prec == AASR_PREC_BF16X3);
       return;
     }
-    if (prec == AASR_PREC_F64)
-      raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 contraction is not built yet");
+    if (prec == AASR_PREC_F64) {
+      if (h->host.any_full())
+        raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 is built for diagonal pools");
+      h->precision = prec;
+      h->use_bf16x3 = false;
+      return;
+    }
     raise(AASR_ERR_INVALID, "unknown precision %d", prec);
+  });
+}
+
+aasr_status aasr_gmm_score_f64_dev(aasr_gmm *h, const double *d_frames, int64_t F, double *d_state_loglik, void *stream) {
+  return guarded([&] {
+    if (!h || (F > 0 && (!d_frames || !d_state_loglik))) raise(AASR_ERR_INVALID, "aasr_gmm_score_f64_dev: null argument");
+    gmm_score_f64_launch(h, d_frames, F, d_state_loglik, 0, (hipStream_t)stream);
+  });
+}
+
+aasr_status aasr_gmm_score_f64(aasr_gmm *h, const double *frames, int64_t F, double *state_loglik) {
+  return guarded([&] {
+    if (!h || (F > 0 && (!frames || !state_loglik))) raise(AASR_ERR_INVALID, "aasr_gmm_score_f64: null argument");
+    if (F <= 0) return;
+    DevBuf<double> d_x, d_o;
+    d_x.upload(frames, (size_t)F * h->dim);
+    d_o.alloc((size_t)F * h->S);
+    gmm_score_f64_launch(h, d_x.p, F, d_o.p, 0, nullptr);
+    AASR_HIP(hipDeviceSynchronize());
+    AASR_HIP(hipMemcpy(state_loglik, d_o.p, (size_t)F * h->S * sizeof(double), hipMemcpyDeviceToHost));
   });
 }
 

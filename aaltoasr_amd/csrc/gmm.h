@@ -233,6 +233,11 @@ struct aasr_gmm {
   aasr::DevBuf<int32_t> centred_state_off; // [S+1]
   aasr::DevBuf<int32_t> centred_splits;    // [MAX][MAX+1] state boundaries
   int centred_max_splits = 1;
+  // AASR_PREC_F64: double records [mean][precision][constant, weight] per mixture component
+  bool f64_built = false;
+  int f64_dimp = 0;
+  aasr::DevBuf<double> f64_recs, f64_x, f64_out;
+  aasr::DevBuf<int32_t> f64_state_off;
   // the pool's Gaussians as single-record states (per-Gaussian view of ill-conditioned models)
   bool pool_centred_built = false;
   aasr::DevBuf<float> poolc_recs;
@@ -286,6 +291,9 @@ void gmm_build(aasr_gmm *g, const HostModel &m);
 void gmm_set_transforms(aasr_gmm *g, int32_t n_transforms, const int32_t *gauss_to_transform, const double *W);
 void gmm_build_pool(aasr_gmm *g);
 void gmm_build_pool_centred(aasr_gmm *g);
+void gmm_build_f64(aasr_gmm *g);
+void gmm_score_f64_launch(aasr_gmm *g, const double *d_frames, int64_t F, double *d_out, int linear,
+                          hipStream_t stream);
 void gmm_build_tracks(aasr_gmm *g, bool grouped);
 void gmm_build_centred(aasr_gmm *g);
 void gmm_build_fullcov(aasr_gmm *g);

@@ -591,6 +591,7 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
   if (const char *e = getenv("AASR_PREC")) {
     g->use_bf16x3 = atoi(e) == AASR_PREC_BF16X3;
     g->precision = g->use_bf16x3 ? AASR_PREC_BF16X3 : AASR_PREC_F32;
+    if (atoi(e) == AASR_PREC_F64 && !m.any_full()) g->precision = AASR_PREC_F64;  // the tools' switch to the reference's arithmetic
   }
   if (const char *e = getenv("AASR_LAYOUTS")) {
     g->layout_mask = atoi(e);
@@ -1357,6 +1358,7 @@ void gmm_set_transforms(aasr_gmm *g, int32_t n_transforms, const int32_t *gauss_
     cur.xform.clear();
     g->pool_built = false;
     g->pool_centred_built = false;
+    g->f64_built = false;
     if (n_transforms == 0) {
       g->xf_a.release();
       g->xf_b.release();
@@ -1383,6 +1385,7 @@ void gmm_set_transforms(aasr_gmm *g, int32_t n_transforms, const int32_t *gauss_
   m.xform.clear();
   g->pool_built = false;
   g->pool_centred_built = false;
+  g->f64_built = false;
   if (global && !m.any_full() && !g->rows_unbiased) {
     // coming from per-class transforms or from rows with a folded bias: build the unadapted rows
     // once, then take the in-place path if this model can (the usual case)
@@ -1414,6 +1417,38 @@ void gmm_build_pool_centred(aasr_gmm *g) {
   build_centred_tables(m, dimp, comps, off, g->poolc_recs, g->poolc_state_off, g->poolc_splits, &g->poolc_max_splits,
                        true);
   g->pool_centred_built = true;
+}
+
+// AASR_PREC_F64 operands: per mixture component the reference's own quantities in double --
+// mean, precision (1 / variance, 0 for a non-positive variance), the constant log sqrt(prod
+// precision) (0 when the product is not positive: the "invalid" Gaussian,
+// aku/Distributions.cc:1117-1135) and the normalised mixture weight.
+void gmm_build_f64(aasr_gmm *g) {
+  if (g->f64_built) return;
+  const HostModel &m = g->host;
+  const int D = m.dim;
+  const int dimp = centred_dimp_for(D);
+  if (!dimp) raise(AASR_ERR_UNSUPPORTED, "no f64 kernel instance for dimension %d", D);
+  const int rec = 2 * dimp + 2;
+  const size_t K = m.mix_idx.size();
+  std::vector<double> recs(std::max<size_t>(K, 1) * rec, 0.0);
+  for (size_t k = 0; k < K; k++) {
+    const int64_t gi = m.mix_idx[k];
+    double prod = 1;
+    for (int d = 0; d < D; d++) {
+      const double v = m.var[(size_t)gi * D + d];
+      const double p = v > 0 ? 1 / v : 0;
+      prod *= p;
+      recs[k * rec + d] = m.mean[(size_t)gi * D + d];
+      recs[k * rec + dimp + d] = p;
+    }
+    recs[k * rec + 2 * dimp] = prod > 0 ? std::log(std::sqrt(prod)) : prod;
+    recs[k * rec + 2 * dimp + 1] = m.mix_w[k];
+  }
+  g->f64_recs.upload(recs.data(), recs.size());
+  g->f64_state_off.upload(m.mix_off.data(), m.mix_off.size());
+  g->f64_dimp = dimp;
+  g->f64_built = true;
 }
 
 void gmm_build_pool(aasr_gmm *g) {

@@ -1495,6 +1495,95 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
   }
 }
 
+// ---------------------------------------------------------------------------
+// AASR_PREC_F64: the reference's own arithmetic, operation by operation, in double
+// (DiagonalGaussian::compute_log_likelihood, aku/Distributions.cc:1040-1062: ll += d*d*p over the
+// dimensions, ll *= -0.5, ll += constant; compute_likelihood :1033-1037 = exp; Mixture::
+// compute_likelihood :2078-2086: l += w * lik in component order; HmmSet's 1e-50 clamp
+// :497-498).  The build has -ffp-contract=off, so every product and sum is rounded separately as
+// in the reference's x86-64 build; what is left against the oracle is the device's exp() and
+// log() (<= 1 ulp).  One lane per frame (its vector in VGPRs as doubles), the Gaussian records are
+// wave-uniform and arrive through the scalar cache.  A verification / training-side mode:
+// ~6 f64 operations per frame, Gaussian and dimension on the vector ALU.
+// ---------------------------------------------------------------------------
+template <int DIMP>
+__global__ __launch_bounds__(256) void k_gmm_diag_score_f64(const double *__restrict__ frames, int64_t F, int dim,
+                                                            const double *__restrict__ recs,
+                                                            const int32_t *__restrict__ state_off, int64_t S,
+                                                            double *__restrict__ out, int linear) {
+  constexpr int REC = 2 * DIMP + 2;  // [mean x DIMP][precision x DIMP][constant, weight]
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t fc = f < F ? f : F - 1;
+  double x[DIMP];
+#pragma unroll
+  for (int d = 0; d < DIMP; d++) x[d] = d < dim ? frames[fc * dim + d] : 0.0;
+  const int64_t s_per = (S + gridDim.y - 1) / gridDim.y;
+  const int64_t s_begin = (int64_t)blockIdx.y * s_per, s_end = min(S, s_begin + s_per);
+  for (int64_t s = s_begin; s < s_end; s++) {
+    const int r0 = state_off[s], r1 = state_off[s + 1];
+    double l = 0;
+    for (int r = r0; r < r1; r++) {
+      const double *rec = recs + (size_t)r * REC;
+      double ll = 0;
+#pragma unroll
+      for (int d = 0; d < DIMP; d++) {
+        const double t = x[d] - rec[d];
+        ll += t * t * rec[DIMP + d];
+      }
+      ll *= -0.5;
+      ll += rec[2 * DIMP];
+      l += rec[2 * DIMP + 1] * exp(ll);
+    }
+    if (l < 1e-50) l = 1e-50;  // also NaN-free: comparisons with NaN are false, as in the reference
+    if (f < F) out[f * S + s] = linear ? l : log(l);
+  }
+}
+
+__global__ void k_f32_to_f64(const float *__restrict__ in, double *__restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (double)in[i];
+}
+__global__ void k_f64_to_f32(const double *__restrict__ in, float *__restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)in[i];
+}
+
+void gmm_score_f64_launch(aasr_gmm *g, const double *d_frames, int64_t F, double *d_out, int linear,
+                          hipStream_t stream) {
+  if (F <= 0) return;
+  if (g->host.any_full() || g->host.n_transforms > 0 || g->cl.enabled || g->class_routing)
+    raise(AASR_ERR_UNSUPPORTED,
+          "AASR_PREC_F64 is built for diagonal pools without model transforms or Gaussian clustering");
+  gmm_build_f64(g);
+  const int64_t blocks = (F + 255) / 256;
+  // state-range cuts so that small batches still fill the chip
+  int64_t cuts = std::max<int64_t>(1, std::min<int64_t>(g->S, (4 * (int64_t)(g->num_cus > 0 ? g->num_cus : 256) + blocks - 1) / blocks));
+  if (cuts > 65535) cuts = 65535;
+#define AASR_CASE(N)                                                                                              \
+  case N:                                                                                                         \
+    hipLaunchKernelGGL(k_gmm_diag_score_f64<N>, dim3((unsigned)blocks, (unsigned)cuts), dim3(256), 0, stream,     \
+                       d_frames, F, g->dim, g->f64_recs.p, g->f64_state_off.p, g->S, d_out, linear);              \
+    break;
+  switch (g->f64_dimp) {
+    AASR_CASE(8) AASR_CASE(16) AASR_CASE(24) AASR_CASE(32) AASR_CASE(40) AASR_CASE(48) AASR_CASE(64)
+    default:
+      raise(AASR_ERR_UNSUPPORTED, "no f64 kernel instance for dimension %d", g->dim);
+  }
+#undef AASR_CASE
+  AASR_HIP(hipGetLastError());
+}
+
+// float entry points under AASR_PREC_F64: frames widened, scores rounded once at the end
+static void score_f64_for_f32_callers(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, hipStream_t stream) {
+  const int64_t nx = F * g->dim, ns = F * g->S;
+  g->f64_x.ensure((size_t)nx);
+  g->f64_out.ensure((size_t)ns);
+  hipLaunchKernelGGL(k_f32_to_f64, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, stream, d_frames, g->f64_x.p, nx);
+  gmm_score_f64_launch(g, g->f64_x.p, F, g->f64_out.p, 0, stream);
+  hipLaunchKernelGGL(k_f64_to_f32, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, g->f64_out.p, d_out, ns);
+  AASR_HIP(hipGetLastError());
+}
+
 // scratch budget of the routed passes (outlier / class partial scores); tests shrink it to force
 // many passes
 static double g_pass_bytes = 1.0e9;
@@ -1899,7 +1988,8 @@ static void add_output_bias(const aasr_gmm *g, float *d_out, int64_t F, hipStrea
 // Whether scores can be written with a row pitch other than S: the bf16x3 track kernels can
 // (rows padded to a multiple of 16 floats make every 64-byte output group a whole cache line).
 bool gmm_score_pitch_ok(const aasr_gmm *g) {
-  if (g->cl.enabled || g->host.factor_path() || g->hyb_enabled || g->ill_conditioned || g->class_routing)
+  if (g->cl.enabled || g->host.factor_path() || g->hyb_enabled || g->ill_conditioned || g->class_routing ||
+      g->precision == AASR_PREC_F64)
     return false;
   if ((g->layout_mask & 3) != 3) return false;
   const TrackLayout &L = g->paired.ok ? g->paired : g->tracks;
@@ -1933,6 +2023,10 @@ void gmm_score_launch_pitched(aasr_gmm *g, const float *d_frames, int64_t F, flo
 void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                       hipStream_t stream) {
   if (F <= 0) return;
+  if (g->precision == AASR_PREC_F64) {
+    score_f64_for_f32_callers(g, d_frames, F, d_out, stream);
+    return;
+  }
   if (g->cl.enabled) {
     gmm_cluster_score_launch(g, d_frames, F, d_out, stream);
     return;

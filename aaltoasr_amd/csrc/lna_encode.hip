@@ -126,6 +126,47 @@ __global__ __launch_bounds__(256) void k_state_norm_lna_reg(
   }
 }
 
+// AASR_PREC_F64: the tail of the phone_probs frame loop as written (aku/phone_probs.cc:224-233), from the
+// LINEAR state likelihoods in double: obs = (float) lik; Z = sum of (double) obs (Z == 0 or -N: 1);
+// obs = (float) safe_log(obs / Z) with the division and the logarithm in double.  Against the
+// reference only the order of the Z sum (a tree here, i = 0, 1, ... there) and the device's log()
+// can differ, by ~1e-16 relative before the rounding to float.
+__global__ __launch_bounds__(256) void k_state_norm_lna_f64(const double *__restrict__ lik, int64_t F, int S,
+                                                            int normalize, int lnabytes, float *__restrict__ lp_out,
+                                                            uint8_t *__restrict__ bytes_out) {
+  __shared__ double red[4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int64_t f = blockIdx.x; f < F; f += gridDim.x) {
+    const double *row = lik + f * (int64_t)S;
+    double z = 1.0;
+    if (normalize) {
+      double part = 0.0;
+      for (int i = tid; i < S; i += 256) part += (double)(float)row[i];
+      part = wave_reduce_sum(part);
+      __syncthreads();  // red[] of the previous frame has been read
+      if (lane == 0) red[wave] = part;
+      __syncthreads();
+      z = (red[0] + red[1]) + (red[2] + red[3]);
+      if (z == 0) z = 1.0;
+    }
+    for (int i = tid; i < S; i += 256) {
+      const float o = (float)row[i];
+      const double q = (double)o / z;
+      const float lp = (float)(q < 1e-50 ? LOG_TINY_D : log(q));
+      lna_store(lp, lnabytes, f * (int64_t)S + i, lp_out, bytes_out);
+    }
+  }
+}
+
+void lna_encode_f64_launch(const double *d_lik, int64_t F, int S, int normalize, int lnabytes, float *d_lp,
+                           uint8_t *d_bytes, hipStream_t stream) {
+  if (F <= 0 || S <= 0) return;
+  const int64_t blocks = std::min<int64_t>(F, 8192);
+  hipLaunchKernelGGL(k_state_norm_lna_f64, dim3((unsigned)blocks), dim3(256), 0, stream, d_lik, F, S, normalize, lnabytes,
+                     d_lp, d_bytes);
+  AASR_HIP(hipGetLastError());
+}
+
 void lna_encode_launch(const float *d_loglik, int64_t F, int S, int normalize,
                        int lnabytes, float *d_lp, uint8_t *d_bytes, hipStream_t stream, int64_t in_pitch) {
   if (in_pitch <= 0) in_pitch = S;  // row stride of the input in floats

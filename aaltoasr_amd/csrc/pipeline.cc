@@ -32,6 +32,8 @@
 
 namespace aasr {
 
+void lna_encode_f64_launch(const double *d_lik, int64_t F, int S, int normalize, int lnabytes, float *d_lp,
+                           uint8_t *d_bytes, hipStream_t stream);
 void lna_encode_launch(const float *d_loglik, int64_t F, int S, int normalize, int lnabytes,
                        float *d_lp, uint8_t *d_bytes, hipStream_t stream, int64_t in_pitch);
 
@@ -279,6 +281,7 @@ struct BlockRunner {
   BlockRunner(aasr_feat *f, aasr_gmm *g, int lb, int nz) : feat(f), gmm(g), lnabytes(lb), normalize(nz) {}
   DevBuf<int16_t> d_pcm;
   DevBuf<float> d_fea, d_ll;
+  DevBuf<double> d_fea64, d_lik64;  // AASR_PREC_F64: double features, linear state likelihoods
   DevBuf<uint8_t> d_bytes, d_bytes2;
   std::vector<uint8_t> h_bytes;
   double device_seconds = 0;
@@ -340,9 +343,19 @@ struct BlockRunner {
       if ((size_t)F * pitch > d_ll.n) AASR_HIP(hipDeviceSynchronize());
       d_ll.ensure((size_t)F * pitch);
       bytes.ensure(nb);
-      feat_run_batch(feat, d_pcm.p, ub, (int)feat->mods.size() - 1, d_fea.p, nullptr, s_compute);
-      gmm_score_launch_pitched(gmm, d_fea.p, F, d_ll.p, pitch, s_compute);
-      lna_encode_launch(d_ll.p, F, (int)S, normalize, lnabytes, nullptr, bytes.p, s_compute, pitch);
+      if (gmm->precision == AASR_PREC_F64) {
+        // the reference's arithmetic end to end: double features, double scoring, the LNA tail as written
+        if ((size_t)F * dim > d_fea64.n || (size_t)F * S > d_lik64.n) AASR_HIP(hipDeviceSynchronize());
+        d_fea64.ensure((size_t)F * dim);
+        d_lik64.ensure((size_t)F * S);
+        feat_run_batch(feat, d_pcm.p, ub, (int)feat->mods.size() - 1, nullptr, d_fea64.p, s_compute);
+        gmm_score_f64_launch(gmm, d_fea64.p, F, d_lik64.p, 1, s_compute);
+        lna_encode_f64_launch(d_lik64.p, F, (int)S, normalize, lnabytes, nullptr, bytes.p, s_compute);
+      } else {
+        feat_run_batch(feat, d_pcm.p, ub, (int)feat->mods.size() - 1, d_fea.p, nullptr, s_compute);
+        gmm_score_launch_pitched(gmm, d_fea.p, F, d_ll.p, pitch, s_compute);
+        lna_encode_launch(d_ll.p, F, (int)S, normalize, lnabytes, nullptr, bytes.p, s_compute, pitch);
+      }
     }
     AASR_HIP(hipEventRecord(ev_kernels[slot], s_compute));
     AASR_HIP(hipStreamWaitEvent(s_copy, ev_kernels[slot], 0));
@@ -386,9 +399,17 @@ struct BlockRunner {
     const int64_t pitch = gmm_score_pitch_ok(gmm) ? (S + 31) / 32 * 32 : S;
     d_ll.ensure((size_t)F * pitch);
     d_bytes.ensure((size_t)F * S * lnabytes);
-    feat_run_batch(feat, d_pcm.p, ub, (int)feat->mods.size() - 1, d_fea.p, nullptr, nullptr);
-    gmm_score_launch_pitched(gmm, d_fea.p, F, d_ll.p, pitch, nullptr);
-    lna_encode_launch(d_ll.p, F, (int)S, normalize, lnabytes, nullptr, d_bytes.p, nullptr, pitch);
+    if (gmm->precision == AASR_PREC_F64) {
+      d_fea64.ensure((size_t)F * dim);
+      d_lik64.ensure((size_t)F * S);
+      feat_run_batch(feat, d_pcm.p, ub, (int)feat->mods.size() - 1, nullptr, d_fea64.p, nullptr);
+      gmm_score_f64_launch(gmm, d_fea64.p, F, d_lik64.p, 1, nullptr);
+      lna_encode_f64_launch(d_lik64.p, F, (int)S, normalize, lnabytes, nullptr, d_bytes.p, nullptr);
+    } else {
+      feat_run_batch(feat, d_pcm.p, ub, (int)feat->mods.size() - 1, d_fea.p, nullptr, nullptr);
+      gmm_score_launch_pitched(gmm, d_fea.p, F, d_ll.p, pitch, nullptr);
+      lna_encode_launch(d_ll.p, F, (int)S, normalize, lnabytes, nullptr, d_bytes.p, nullptr, pitch);
+    }
     const size_t nb = (size_t)F * S * lnabytes;
     if (dst) {
       if (nb > dst_cap) raise(AASR_ERR_INVALID, "internal: result buffer too small");

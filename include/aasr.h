@@ -271,7 +271,13 @@ int32_t aasr_gmm_num_clusters(const aasr_gmm *h);
  *                         covariance and per-class CMLLR models (ill-conditioned
  *                         models still take the centred form).  The environment
  *                         variable AASR_PREC=0 selects AASR_PREC_F32 globally.
- *  AASR_PREC_F64          reserved (f64 matrix cores), not built */
+ *  AASR_PREC_F64          the reference's own arithmetic in double, operation by operation (diagonal
+ *                         pools without model transforms or clustering): a verification / training-side
+ *                         mode, ~4 M frames/s at 50 k Gaussians.  Float entry points widen the frames
+ *                         and round the scores once; aasr_gmm_score_f64 takes and returns doubles;
+ *                         aasr_run_utterance / aasr_run_recipe then run the whole path in double
+ *                         (features, scoring, the LNA tail as written) -- AASR_PREC=1 in the
+ *                         environment selects it for the command-line tools. */
 enum { AASR_PREC_F32 = 0, AASR_PREC_F64 = 1, AASR_PREC_F32_CENTRED = 2, AASR_PREC_BF16X3 = 3 };
 aasr_status aasr_gmm_set_precision(aasr_gmm *h, int prec);
 
@@ -280,6 +286,9 @@ aasr_status aasr_gmm_set_precision(aasr_gmm *h, int prec);
  * state_loglik float32 [F x S] = log(max(sum_k w_k exp(ll_k), 1e-50)). */
 aasr_status aasr_gmm_score(aasr_gmm *h, const float *frames, int64_t F,
                            float *state_loglik);
+/* AASR_PREC_F64 with double frames in and double log state likelihoods out (any precision setting) */
+aasr_status aasr_gmm_score_f64(aasr_gmm *h, const double *frames, int64_t F, double *state_loglik);
+aasr_status aasr_gmm_score_f64_dev(aasr_gmm *h, const double *d_frames, int64_t F, double *d_state_loglik, void *stream);
 aasr_status aasr_gmm_score_dev(aasr_gmm *h, const float *d_frames, int64_t F,
                                float *d_state_loglik, void *stream);
 
