@@ -247,6 +247,43 @@ __device__ __noinline__ void kiss_butterfly_generic(cpx *buf, int bi, int pr, in
   }
 }
 
+// logf as glibc computes it (sysdeps/ieee754/flt-32/e_logf.c and logf_data.c of glibc 2.27 and later,
+// from ARM's optimized-routines; the reference's MelModule / FFTModule call logf, aku/FeatureModules.cc:
+// 564, 846): x = 2^k z with z in [0x3f330000, 2 x that), a 16-entry table of c near the centre of z's
+// sub-interval (invc ~ 1/c, logc ~ ln c), r = z * invc - 1, ln x = k ln2 + logc + r + r^2 (A2 + A1 r +
+// A0 r^2), everything in double, rounded to float at the end.  The result is within 0.82 ulp but not
+// always the correctly rounded one -- which a (float) log((double) x) would be -- and that last bit
+// used to show as ~1e-6 in a few frames' features.  Non-finite, non-positive and subnormal arguments
+// (which the feature chain does not produce: it takes log(val / sum + 1)) go the double way.
+__device__ __forceinline__ float glibc_logf(float x) {
+  const double T[16][2] = {
+      {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
+      {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},  {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
+      {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
+      {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
+      {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, {0x1p+0, 0x0p+0},
+      {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
+      {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},
+      {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+  const double Ln2 = 0x1.62e42fefa39efp-1;
+  const double A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2;
+  const uint32_t ix = __float_as_uint(x);
+  if (ix == 0x3f800000u) return 0.0f;
+  if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) return (float)log((double)x);
+  const uint32_t tmp = ix - 0x3f330000u;
+  const int i = (int)((tmp >> 19) & 15u);
+  const int k = (int32_t)tmp >> 23;
+  const uint32_t iz = ix - (tmp & 0xff800000u);
+  const double z = (double)__uint_as_float(iz);
+  const double r = z * T[i][0] - 1.0;
+  const double y0 = T[i][1] + (double)k * Ln2;
+  const double r2 = r * r;
+  double y = A1 * r + A2;
+  y = A0 * r2 + y;
+  y = y * r2 + (y0 + r);
+  return (float)y;
+}
+
 // |X|^2 of one bin in float, then sqrtf / logf as FFTModule::generate applies them
 // (aku/FeatureModules.cc:533-565); sqrt and log evaluated in double and rounded once
 __device__ __forceinline__ float spec_value(float re, float im, int magnitude, int take_log) {
@@ -254,7 +291,7 @@ __device__ __forceinline__ float spec_value(float re, float im, int magnitude, i
   float c = im * im;
   float v = a + c;
   if (magnitude) v = (float)sqrt((double)v);  // == correctly rounded sqrtf
-  if (take_log) v = (float)log((double)v);
+  if (take_log) v = glibc_logf(v);
   return v;
 }
 
@@ -563,7 +600,7 @@ __global__ __launch_bounds__(256) void k_spectral_fused(DevBatch b, const int16_
         o = pow((double)q, 0.1);
       } else {
         const float a = q + 1.0f;
-        o = (double)(float)log((double)a);
+        o = (double)glibc_logf(a);
       }
       melv[(size_t)f * sp.mel_dim + bin] = o;
     }
@@ -727,7 +764,7 @@ __global__ void k_mel(DevBatch b, const double *__restrict__ src, SrcMap sm, int
     o = pow((double)q, 0.1);
   } else {
     float a = q + 1.0f;
-    o = (double)(float)log((double)a);
+    o = (double)glibc_logf(a);
   }
   dst[idx] = o;
 }
