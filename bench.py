@@ -489,7 +489,8 @@ def main():
             del d_out
             torch.cuda.empty_cache()
             extra_cfg["configs2"] = _measure_configs2(torch, capi, synth, gmm, rank, dev, stream, sync_all,
-                                                      max_over_ranks, world, mean, var, off, idx, w)
+                                                      max_over_ranks, world, mean, var, off, idx, w,
+                                                      3 if args.precision == "bf16x3" else 0)
         except Exception as e:  # the headline must survive a failure of the extras
             extra_cfg["configs2"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:
@@ -534,7 +535,7 @@ def main():
 
 
 def _measure_configs2(torch, capi, synth, gmm, rank, dev, stream, sync_all, max_over_ranks, world,
-                      mean, var, off, idx, w):
+                      mean, var, off, idx, w, restore_precision=3):
     """BASELINE configs[2] next to the headline: 360 x 10 s utterances per rank, MFCC chain +
     scoring + 2-byte LNA on the device; ms/step (max over ranks), per-stage split from HIP events,
     and on rank 0 the fraction of one utterance's LNA bytes that equal the oracle's."""
@@ -572,6 +573,17 @@ def _measure_configs2(torch, capi, synth, gmm, rank, dev, stream, sync_all, max_
         out["lna_check"] = {"utterance": u, "frames": nfr, "codes_equal_fraction": round(float((ca == cb).mean()), 6),
                             "max_code_difference": int(np.abs(ca - cb).max()),
                             "against": "oracle restatement of phone_probs (double), same audio and model"}
+        # the same utterance with the engine in AASR_PREC_F64 (the reference's arithmetic in double): what
+        # is left of the difference above when float rounding is taken away
+        try:
+            from aaltoasr_amd import capi as A
+            gmm.set_precision(1)
+            data, n64 = A.run_utterance(runner.feat, gmm, runner.utts[u], lnabytes=2)
+            gmm.set_precision(restore_precision)
+            c = np.frombuffer(data[5:], np.uint8).reshape(n64, S, 2).astype(np.int32)
+            out["lna_check"]["codes_equal_fraction_f64_mode"] = round(float(((c[..., 0] * 256 + c[..., 1]) == cb).mean()), 6)
+        except Exception as e:
+            out["lna_check"]["codes_equal_fraction_f64_mode"] = "failed: %s" % e
     return out
 
 
