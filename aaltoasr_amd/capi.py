@@ -157,6 +157,7 @@ def _declare(L: C.CDLL) -> None:
     L.aasr_lna_read_file.argtypes = [cp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64), C.POINTER(C.POINTER(C.c_float))]
     L.aasr_audio_decode.argtypes = [vp, vp, i64, C.POINTER(C.POINTER(C.c_int16)), C.POINTER(i64), C.POINTER(i32)]
     L.aasr_gmm_score_f64.argtypes = [vp, vp, i64, vp]
+    L.aasr_gmm_get_precision.argtypes = [vp]
     L.aasr_free.argtypes = [vp]
     L.aasr_free.restype = None
     L.aasr_feat_get_parameters.argtypes = [vp, cp, C.POINTER(C.c_void_p), C.POINTER(i64)]

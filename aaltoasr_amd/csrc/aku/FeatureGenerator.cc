@@ -597,6 +597,13 @@ const FeatureVec FeatureGenerator::generate(int frame) {
   return FeatureVec(&m_block[(size_t)(frame - m_block_first) * dim()], dim(), frame, this);
 }
 
+const double *FeatureGenerator::block_f64(int frame, int *first, int *count) const {
+  if (m_block_count == 0 || frame < m_block_first || frame >= m_block_first + m_block_count) return nullptr;
+  *first = m_block_first;
+  *count = m_block_count;
+  return m_block.data();
+}
+
 const float *FeatureGenerator::block_f32(int frame, int *first, int *count) const {
   if (m_block_count == 0 || frame < m_block_first || frame >= m_block_first + m_block_count)
     return nullptr;

@@ -87,6 +87,8 @@ public:
   /** float32 features of the cached block that holds `frame` (nullptr if the
    * frame is not cached); used by HmmSet to score whole blocks */
   const float *block_f32(int frame, int *first, int *count) const;
+  /** the same block in double (AASR_PREC_F64 scoring) */
+  const double *block_f64(int frame, int *first, int *count) const;
   uint64_t block_serial() const { return m_block_serial; }
   void set_block_frames(int n) { m_block_frames = n > 0 ? n : 1; }
   /** module parameters changed (SpeakerConfig): cached frames are stale */

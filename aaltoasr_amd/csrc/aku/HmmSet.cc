@@ -217,6 +217,7 @@ void HmmSet::read_clustering(const std::string &filename) {
     throw std::string(aasr_last_error());
   m_count = 0;  // cached block rows were scored without the clustering
   m_row = nullptr;
+  m_row64 = nullptr;
 }
 
 void HmmSet::set_clustering_min_evals(double min_clusters, double min_gaussians) {
@@ -225,6 +226,7 @@ void HmmSet::set_clustering_min_evals(double min_clusters, double min_gaussians)
     throw std::string(aasr_last_error());
   m_count = 0;
   m_row = nullptr;
+  m_row64 = nullptr;
 }
 
 int HmmSet::dim() {
@@ -239,6 +241,7 @@ int HmmSet::num_states() {
 
 void HmmSet::reset_cache() {
   m_row = nullptr;
+  m_row64 = nullptr;
   for (ResetCacheInterface *o : m_reset_cache_objects) o->reset_cache();
 }
 
@@ -282,8 +285,18 @@ const float *HmmSet::state_loglik_row(const FeatureVec &f) {
     if (blk) {
       if (m_owner != own || m_serial != own->block_serial() || m_count == 0) {
         m_block_ll.resize((size_t)count * S);
-        if (aasr_gmm_score(m_gmm, blk, count, m_block_ll.data()) != AASR_OK)
-          throw std::string(aasr_last_error());
+        int f1 = 0, c1 = 0;
+        const double *blk64 = aasr_gmm_get_precision(m_gmm) == AASR_PREC_F64 ? own->block_f64(f.frame(), &f1, &c1) : nullptr;
+        if (blk64) {  // double features in, double log-likelihoods out; the float rows are their roundings
+          m_block_ll64.resize((size_t)count * S);
+          if (aasr_gmm_score_f64(m_gmm, blk64, count, m_block_ll64.data()) != AASR_OK)
+            throw std::string(aasr_last_error());
+          for (size_t i = 0; i < m_block_ll64.size(); i++) m_block_ll[i] = (float)m_block_ll64[i];
+        } else {
+          m_block_ll64.clear();
+          if (aasr_gmm_score(m_gmm, blk, count, m_block_ll.data()) != AASR_OK)
+            throw std::string(aasr_last_error());
+        }
         m_owner = own;
         m_serial = own->block_serial();
         m_first = first;
@@ -309,8 +322,16 @@ const float *HmmSet::state_loglik_row(const double *px, int dim) {
   if (xd == m_single_x && (int)m_single_ll.size() == S) return m_single_ll.data();
   std::vector<float> x(xd.begin(), xd.end());
   m_single_ll.resize(S);
-  if (aasr_gmm_score(m_gmm, x.data(), 1, m_single_ll.data()) != AASR_OK)
-    throw std::string(aasr_last_error());
+  if (aasr_gmm_get_precision(m_gmm) == AASR_PREC_F64) {
+    m_single_ll64.resize(S);
+    if (aasr_gmm_score_f64(m_gmm, xd.data(), 1, m_single_ll64.data()) != AASR_OK)
+      throw std::string(aasr_last_error());
+    for (int i = 0; i < S; i++) m_single_ll[(size_t)i] = (float)m_single_ll64[(size_t)i];
+  } else {
+    m_single_ll64.clear();
+    if (aasr_gmm_score(m_gmm, x.data(), 1, m_single_ll.data()) != AASR_OK)
+      throw std::string(aasr_last_error());
+  }
   m_single_x = xd;
   return m_single_ll.data();
 }
@@ -395,16 +416,29 @@ double Mixture::compute_likelihood(const Vector &f) const {
 }
 double Mixture::compute_log_likelihood(const Vector &f) const { return util::safe_log(compute_likelihood(f)); }
 
+// the double row that belongs to a float row handed out by state_loglik_row (AASR_PREC_F64), or null
+const double *HmmSet::row64_for(const float *row) {
+  if (!row) return nullptr;
+  if (!m_block_ll64.empty() && row >= m_block_ll.data() && row < m_block_ll.data() + m_block_ll.size())
+    return m_block_ll64.data() + (row - m_block_ll.data());
+  if (!m_single_ll64.empty() && row == m_single_ll.data()) return m_single_ll64.data();
+  return nullptr;
+}
+
 void HmmSet::precompute_likelihoods(const FeatureVec &f) {
   reset_cache();
   m_row = state_loglik_row(f);
+  m_row64 = row64_for(m_row);
 }
 
 double HmmSet::state_likelihood(const int s, const FeatureVec &f) {
-  if (!m_row) m_row = state_loglik_row(f);  // lazy style: reset_cache() then single states
+  if (!m_row) {  // lazy style: reset_cache() then single states
+    m_row = state_loglik_row(f);
+    m_row64 = row64_for(m_row);
+  }
   if (s < 0 || s >= aasr_gmm_num_states(m_gmm)) throw std::string("HmmSet: state index out of range");
   // the row holds log(max(lik, 1e-50)) (aku/HmmSet.cc:497-498)
-  return std::exp((double)m_row[s]);
+  return std::exp(m_row64 ? m_row64[s] : (double)m_row[s]);
 }
 
 }  // namespace aku

@@ -153,6 +153,7 @@ public:
   void invalidate_block() {
     m_count = 0;
     m_row = nullptr;
+    m_row64 = nullptr;
   }
   /** log state likelihoods of the cached block row for f (S floats) */
   const float *state_loglik_row(const FeatureVec &f);
@@ -173,6 +174,11 @@ private:
   uint64_t m_serial;
   int m_first, m_count;
   std::vector<float> m_block_ll;  // [count x S]
+  // AASR_PREC_F64 (aasr_gmm_set_precision / AASR_PREC=1): the same rows in double, what
+  // state_likelihood() then returns -- the aligners and trainers get the reference's arithmetic
+  std::vector<double> m_block_ll64, m_single_ll64;
+  const double *m_row64 = nullptr;
+  const double *row64_for(const float *row);
   std::vector<float> m_single_ll;  // one frame, for vectors without a block
   std::vector<double> m_single_x;  // the vector m_single_ll belongs to
   const float *m_row;

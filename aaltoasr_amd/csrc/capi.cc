@@ -244,6 +244,8 @@ int aasr_gmm_num_states(const aasr_gmm *h) { return h ? (int)h->S : -1; }
 int aasr_gmm_num_gaussians(const aasr_gmm *h) { return h ? (int)h->G : -1; }
 int64_t aasr_gmm_expanded_rows(const aasr_gmm *h) { return h ? h->mix.rows : -1; }
 
+int aasr_gmm_get_precision(const aasr_gmm *h) { return h ? h->precision : -1; }
+
 aasr_status aasr_gmm_set_precision(aasr_gmm *h, int prec) {
   return guarded([&] {
     if (!h) raise(AASR_ERR_INVALID, "null handle");

@@ -280,6 +280,7 @@ int32_t aasr_gmm_num_clusters(const aasr_gmm *h);
  *                         environment selects it for the command-line tools. */
 enum { AASR_PREC_F32 = 0, AASR_PREC_F64 = 1, AASR_PREC_F32_CENTRED = 2, AASR_PREC_BF16X3 = 3 };
 aasr_status aasr_gmm_set_precision(aasr_gmm *h, int prec);
+int aasr_gmm_get_precision(const aasr_gmm *h);
 
 /* HmmSet::precompute_likelihoods + state_likelihood for a block of frames
  * (aku/HmmSet.cc:484-501, aku/HmmSet.hh:309): frames float32 [F x dim];

@@ -433,3 +433,10 @@ def test_reference_logl_with_both_segmentators_on_the_engine(capi, oracle, tmp_p
         assert r.returncode == 0, r.stderr[-2000:]
         got = float(r.stdout.strip().splitlines()[-1].split(":")[-1])
         assert abs(got - want) <= 5e-3 + 1e-6 * abs(want), (flags, got, want, r.stdout[-500:], r.stderr[-500:])
+        # AASR_PREC=1: the adapters score in double (state_likelihood() returns the reference's value), and
+        # the tool prints the oracle's total to its six decimals
+        r = subprocess.run([exe, "-b", base, "-c", cfg, "-r", str(tmp_path / "b.recipe"), "-H", "-F", "1e9", "-W", "1e9",
+                            "-i", "1"] + flags, capture_output=True, text=True, timeout=600, env=dict(os.environ, AASR_PREC="1"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        got64 = float(r.stdout.strip().splitlines()[-1].split(":")[-1])
+        assert abs(got64 - want) <= 2e-6 + 1e-12 * abs(want), (flags, got64, want)
