@@ -273,7 +273,7 @@ int32_t aasr_gmm_num_clusters(const aasr_gmm *h);
  *                         variable AASR_PREC=0 selects AASR_PREC_F32 globally.
  *  AASR_PREC_F64          the reference's own arithmetic in double, operation by operation (diagonal
  *                         pools without model transforms or clustering): a verification / training-side
- *                         mode, ~4 M frames/s at 50 k Gaussians.  Float entry points widen the frames
+ *                         mode, ~1.2 M frames/s at 50 k Gaussians.  Float entry points widen the frames
  *                         and round the scores once; aasr_gmm_score_f64 takes and returns doubles;
  *                         aasr_run_utterance / aasr_run_recipe then run the whole path in double
  *                         (features, scoring, the LNA tail as written) -- AASR_PREC=1 in the
