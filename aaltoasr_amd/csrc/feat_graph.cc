@@ -281,32 +281,75 @@ static void build_vtln_tables(FeatModule &m) {
   std::vector<int32_t> start((size_t)dim, 0), len((size_t)dim, 0);
   std::vector<float> coef;
   if (m.all_pass) {
-    if (m.use_slapt)
-      raise(AASR_ERR_UNSUPPORTED, "VtlnModule: all-pass with slapt is not built in this engine yet");
-    // create_all_pass_blin_transform + set_all_pass_transform (:1716-1756, 1870-1905):
-    // final = IDCT * (bilinear series * DCT); the reference multiplies with BLAS dgemm
-    // (summation order unpinned), plain k-ascending loops here.
+    // create_all_pass_blin_transform / create_all_pass_slapt_transform + set_all_pass_transform
+    // (:1716-1756, 1758-1868, 1870-1905): final = IDCT * (warp series * DCT); the reference multiplies
+    // with BLAS dgemm (summation order unpinned), plain k-ascending loops here.
     const size_t n = (size_t)dim;
-    std::vector<double> q1(n, 0.0), q(n, 0.0), qn(n, 0.0), tr(n * n, 0.0), dct(n * n), tmp(n * n);
-    double alpha = m.warp_factor - 1;
+    std::vector<double> tr(n * n, 0.0), dct(n * n), tmp(n * n);
     double temp;
-    q1[0] = -alpha;
-    temp = 1 - alpha * alpha;
-    for (int i = 1; i < dim; i++) {
-      q1[i] = temp;
-      temp *= alpha;
-    }
-    q[0] = 1;
-    tr[0] = 1;
-    for (int i = 1; i < dim; i++) {
-      for (int j = 0; j < dim; j++) {
-        temp = 0;
-        for (int k = 0; k <= j; k++) temp += q[k] * q1[j - k];
-        qn[j] = temp;
+    if (m.use_slapt) {
+      // exp(f1) as a Taylor sum of convolution powers of f1 (terms 0..10) -> two-sided sequence q;
+      // row i of the transform from the i-th convolution power of q folded about its centre
+      auto conv_at = [](const std::vector<double> &a, const std::vector<double> &b, int j) {
+        int high1 = j, low1 = 0, low2 = j;
+        if (high1 >= (int)a.size()) high1 = (int)a.size() - 1;
+        if (low2 >= (int)b.size()) {
+          low1 = j - (int)b.size() + 1;
+          low2 = (int)b.size() - 1;
+        }
+        double t = 0;
+        for (int k = 0; k < high1 - low1 + 1; k++) t += a[(size_t)(low1 + k)] * b[(size_t)(low2 - k)];
+        return t;
+      };
+      const int order = (int)m.slapt_params.size();
+      std::vector<double> f1((size_t)(2 * order + 1), 0.0), q((size_t)(2 * dim + 1), 0.0), cur(1, 1.0), fn;
+      for (int i = 0; i < order; i++) {
+        f1[(size_t)i] = -m.slapt_params[(size_t)(order - i - 1)] * M_PI / 2;
+        f1[(size_t)(i + order + 1)] = m.slapt_params[(size_t)i] * M_PI / 2;
       }
-      q = qn;
-      tr[i] = 2 * q[0];
-      for (int j = 1; j < dim; j++) tr[j * n + i] = q[j];
+      int cur_center = 0;
+      double cur_m = 1;
+      for (int i = 0; i <= 10; i++) {
+        if (i > 0) cur_m = cur_m / (double)i;
+        const int low1 = std::max(0, dim - cur_center), high1 = std::min(2 * dim + 1, dim + cur_center + 1);
+        for (int j = low1; j < high1; j++) q[(size_t)j] = q[(size_t)j] + cur_m * cur[(size_t)(j - (dim + 1) + cur_center + 1)];
+        fn.assign(f1.size() + cur.size() - 1, 0.0);
+        for (int j = 0; j < (int)fn.size(); j++) fn[(size_t)j] = conv_at(cur, f1, j);
+        cur = fn;
+        cur_center = ((int)cur.size() - 1) / 2;
+      }
+      q.pop_back();  // "make the initial sequence symmetric"
+      q.pop_back();
+      const std::vector<double> q1 = q;
+      std::vector<double> qn(q.size(), 0.0);
+      tr[0] = 1;
+      for (int i = 1; i < dim; i++) {
+        tr[(size_t)i] = 2 * q[(size_t)(dim - 1)];
+        for (int j = 1; j < dim; j++) tr[(size_t)j * n + i] = q[(size_t)(dim + j - 1)] + q[(size_t)(dim - j - 1)];
+        for (int j = dim - 1; j < 3 * dim - 2; j++) qn[(size_t)(j - dim + 1)] = conv_at(q, q1, j);
+        q = qn;
+      }
+    } else {
+      std::vector<double> q1(n, 0.0), q(n, 0.0), qn(n, 0.0);
+      double alpha = m.warp_factor - 1;
+      q1[0] = -alpha;
+      temp = 1 - alpha * alpha;
+      for (int i = 1; i < dim; i++) {
+        q1[i] = temp;
+        temp *= alpha;
+      }
+      q[0] = 1;
+      tr[0] = 1;
+      for (int i = 1; i < dim; i++) {
+        for (int j = 0; j < dim; j++) {
+          temp = 0;
+          for (int k = 0; k <= j; k++) temp += q[k] * q1[j - k];
+          qn[j] = temp;
+        }
+        q = qn;
+        tr[i] = 2 * q[0];
+        for (int j = 1; j < dim; j++) tr[j * n + i] = q[j];
+      }
     }
     for (int i = 0; i < dim; i++)
       for (int j = 0; j < dim; j++) dct[i * n + j] = cos(i * (j + 0.5) * M_PI / dim);

@@ -1194,6 +1194,80 @@ static void orc_vtln_allpass_finish(int dim, const double *trmat, float *coef)
     free(tmp);
 }
 
+/* VtlnModule::create_all_pass_slapt_transform (aku/FeatureModules.cc:1758-1868): the series
+ * exp(f1) as a truncated Taylor sum of convolution powers of f1 (terms 0..10), its symmetric
+ * two-sided sequence q, then row i of the transform from the i-th convolution power of q folded
+ * about its centre.  Restated index by index. */
+static void orc_conv_window(const double *a, int na, const double *b, int nb, int j, double *out)
+{
+    int high1 = j, low1 = 0, low2 = j;
+    if (high1 >= na) high1 = na - 1;
+    if (low2 >= nb) {
+        low1 = j - nb + 1;
+        low2 = nb - 1;
+    }
+    int len = high1 - low1 + 1;
+    double temp = 0;
+    for (int k = 0; k < len; k++)
+        temp += a[low1 + k] * b[low2 - k];
+    *out = temp;
+}
+
+void orc_vtln_allpass_slapt(int dim, const float *params, int order, float *coef)
+{
+    size_t n = (size_t)dim;
+    int nf1 = 2 * order + 1;
+    double *f1 = (double *)calloc((size_t)nf1, sizeof(double));
+    for (int i = 0; i < order; i++) {
+        f1[i] = -params[order - i - 1] * M_PI / 2;
+        f1[i + order + 1] = params[i] * M_PI / 2;
+    }
+    f1[order] = 0;
+    int nq = 2 * dim + 1;
+    double *q = (double *)calloc((size_t)nq, sizeof(double));
+    int ncur = 1, cur_center = 0;
+    double *cur = (double *)calloc(1, sizeof(double));
+    cur[0] = 1;
+    double cur_m = 1;
+    for (int i = 0; i <= 10; i++) {
+        if (i > 0)
+            cur_m = cur_m / (double)i;
+        int low1 = dim - cur_center > 0 ? dim - cur_center : 0;
+        int high1 = dim + cur_center + 1 < 2 * dim + 1 ? dim + cur_center + 1 : 2 * dim + 1;
+        for (int j = low1; j < high1; j++)
+            q[j] = q[j] + cur_m * cur[j - (dim + 1) + cur_center + 1];
+        int nfn = nf1 + ncur - 1;
+        double *fn = (double *)calloc((size_t)nfn, sizeof(double));
+        for (int j = 0; j < nfn; j++)
+            orc_conv_window(cur, ncur, f1, nf1, j, &fn[j]);
+        free(cur);
+        cur = fn;
+        ncur = nfn;
+        cur_center = (ncur - 1) / 2;
+    }
+    nq -= 2; /* "make the initial sequence symmetric": the last two entries are dropped */
+    double *q1 = (double *)malloc(sizeof(double) * (size_t)nq);
+    memcpy(q1, q, sizeof(double) * (size_t)nq);
+    double *tr = (double *)calloc(n * n, sizeof(double));
+    double *qn = (double *)calloc((size_t)nq, sizeof(double));
+    tr[0] = 1;
+    for (int i = 1; i < dim; i++) {
+        tr[i] = 2 * q[dim - 1];
+        for (int j = 1; j < dim; j++)
+            tr[j * n + i] = q[dim + j - 1] + q[dim - j - 1];
+        for (int j = dim - 1; j < 3 * dim - 2; j++)
+            orc_conv_window(q, nq, q1, nq, j, &qn[j - dim + 1]);
+        memcpy(q, qn, sizeof(double) * (size_t)nq);
+    }
+    orc_vtln_allpass_finish(dim, tr, coef);
+    free(f1);
+    free(q);
+    free(q1);
+    free(qn);
+    free(cur);
+    free(tr);
+}
+
 /* VtlnModule::create_all_pass_blin_transform (:1716-1756) */
 void orc_vtln_allpass_blin(int dim, float warp, float *coef)
 {

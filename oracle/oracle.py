@@ -376,10 +376,13 @@ class FeatureChain:
                         len(slapt), _p(bins, pf))
         p["bins"] = bins
         if p["all_pass"]:
-            if p["slapt"]:
-                raise ValueError("VtlnModule: all-pass with slapt is not restated")
             coef = np.zeros((dim, dim), np.float32)
-            L.orc_vtln_allpass_blin(dim, float(warp), _p(coef, pf))
+            if p["slapt"]:
+                L.orc_vtln_allpass_slapt.restype = None
+                L.orc_vtln_allpass_slapt.argtypes = [C.c_int32, C.POINTER(pf), C.c_int32, C.POINTER(pf)]
+                L.orc_vtln_allpass_slapt(dim, _p(slapt, pf), len(slapt), _p(coef, pf))
+            else:
+                L.orc_vtln_allpass_blin(dim, float(warp), _p(coef, pf))
             p["start"], p["len"], p["coef"] = np.zeros(dim, np.int32), np.full(dim, dim, np.int32), coef
         elif p["rad"] > 0:
             w = 2 * p["rad"] + 1

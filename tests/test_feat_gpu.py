@@ -222,8 +222,8 @@ def test_config_errors(capi):
         return ei.value
     assert "Unknown module type" in err("module\n{\n name a\n type nosuch\n}\n").msg
     assert "PreModule: Must set dimension" in err("module\n{\n name a\n type pre\n}\n").msg
-    assert err("module\n{\n name a\n type audiofile\n sample_rate 16000\n}\nmodule\n{\n name f\n type fft\n sources a\n}\n"
-               "module\n{\n name v\n type vtln\n all-pass 1\n slapt 1\n lanczos_window 0\n sources f\n}\n").code == capi.AASR_ERR_UNSUPPORTED
+    assert "pwlin_vtln and slapt" in err("module\n{\n name a\n type audiofile\n sample_rate 16000\n}\nmodule\n{\n name f\n type fft\n sources a\n}\n"
+                                         "module\n{\n name v\n type vtln\n pwlin_vtln 1\n slapt 1\n sources f\n}\n").msg
     assert "first module should be a base module" in err("module\n{\n name a\n type fft\n}\n").msg
     assert "Must set sample rate" in err("module\n{\n name a\n type audiofile\n}\n").msg
     assert "value redefined" in err("module\n{\n name a\n name b\n type audiofile\n}\n").msg
@@ -313,6 +313,7 @@ def _block(opts):
     ("sinc_interpolation_rad 0", {"warp_factor": "1.07"}),           # linear interpolation
     ("lanczos_window 0\n  sinc_interpolation_rad 5", {"warp_factor": "0.95"}),
     ("all-pass 1", {"warp_factor": "1.05"}),
+    ("all-pass 1\n  slapt 1", {"slapt_coef": "0.015 -0.004"}),     # aku/FeatureModules.cc:1758-1868
 ])
 def test_adaptation_modules_match_oracle(capi, oracle, vtln_opts, params):
     """vtln / sr_norm / quanteq / concat / mel_power (the modules SpeakerConfig
