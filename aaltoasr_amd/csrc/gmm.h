@@ -236,7 +236,8 @@ struct aasr_gmm {
   // AASR_PREC_F64: double records [mean][precision][constant, weight] per mixture component
   bool f64_built = false;
   int f64_dimp = 0;
-  aasr::DevBuf<double> f64_recs, f64_x, f64_out;
+  aasr::DevBuf<double> f64_recs, f64_x, f64_out, f64_A, f64_b, f64_xframes;
+  double f64_det = 1.0;          // |prod diag A| of a global transform
   aasr::DevBuf<int32_t> f64_state_off;
   // the pool's Gaussians as single-record states (per-Gaussian view of ill-conditioned models)
   bool pool_centred_built = false;

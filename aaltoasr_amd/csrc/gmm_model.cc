@@ -1447,6 +1447,21 @@ void gmm_build_f64(aasr_gmm *g) {
   }
   g->f64_recs.upload(recs.data(), recs.size());
   g->f64_state_off.upload(m.mix_off.data(), m.mix_off.size());
+  g->f64_det = 1.0;
+  if (m.n_transforms > 0 && m.global_xform()) {
+    // W = [b | A] (ConstrainedMllr::load_transform); determinant = the product of A's diagonal
+    // (full_matrix_determinant, aku/LinearAlgebra.cc:73-86)
+    std::vector<double> A((size_t)D * D), b((size_t)D);
+    double det = 1;
+    for (int i = 0; i < D; i++) {
+      b[(size_t)i] = m.xform[(size_t)i * (D + 1)];
+      for (int j = 0; j < D; j++) A[(size_t)i * D + j] = m.xform[(size_t)i * (D + 1) + 1 + j];
+      det *= A[(size_t)i * D + i];
+    }
+    g->f64_A.upload(A.data(), A.size());
+    g->f64_b.upload(b.data(), b.size());
+    g->f64_det = std::fabs(det);
+  }
   g->f64_dimp = dimp;
   g->f64_built = true;
 }

@@ -1510,7 +1510,7 @@ template <int DIMP>
 __global__ __launch_bounds__(256) void k_gmm_diag_score_f64(const double *__restrict__ frames, int64_t F, int dim,
                                                             const double *__restrict__ recs,
                                                             const int32_t *__restrict__ state_off, int64_t S,
-                                                            double *__restrict__ out, int linear) {
+                                                            double *__restrict__ out, int linear, double det) {
   constexpr int REC = 2 * DIMP + 2;  // [mean x DIMP][precision x DIMP][constant, weight]
   const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t fc = f < F ? f : F - 1;
@@ -1532,7 +1532,8 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_f64(const double *__rest
       }
       ll *= -0.5;
       ll += rec[2 * DIMP];
-      l += rec[2 * DIMP + 1] * exp(ll);
+      // AdaptedGaussian::compute_likelihood = g(A f + b) * |det| (aku/ModelModules.hh:172-173); det = 1 unadapted
+      l += rec[2 * DIMP + 1] * (exp(ll) * det);
     }
     if (l < 1e-50) l = 1e-50;  // also NaN-free: comparisons with NaN are false, as in the reference
     if (f < F) out[f * S + s] = linear ? l : log(l);
@@ -1548,13 +1549,36 @@ __global__ void k_f64_to_f32(const double *__restrict__ in, float *__restrict__ 
   if (i < n) out[i] = (float)in[i];
 }
 
+// o = b + A f in double, the reference's order (AdaptedFeatureVector::calculate_new_ada_vector,
+// aku/ModelModules.hh:208-212)
+__global__ void k_affine_frames_f64(const double *__restrict__ x, int64_t F, int dim, const double *__restrict__ A,
+                                    const double *__restrict__ b, double *__restrict__ y) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= F * dim) return;
+  const int64_t f = idx / dim;
+  const int i = (int)(idx - f * dim);
+  double acc = b[i];
+  for (int j = 0; j < dim; j++) acc += A[(size_t)i * dim + j] * x[f * dim + j];
+  y[idx] = acc;
+}
+
 void gmm_score_f64_launch(aasr_gmm *g, const double *d_frames, int64_t F, double *d_out, int linear,
                           hipStream_t stream) {
   if (F <= 0) return;
-  if (g->host.any_full() || g->host.n_transforms > 0 || g->cl.enabled || g->class_routing)
+  if (g->host.any_full() || (g->host.n_transforms > 0 && !g->host.global_xform()) || g->cl.enabled)
     raise(AASR_ERR_UNSUPPORTED,
-          "AASR_PREC_F64 is built for diagonal pools without model transforms or Gaussian clustering");
+          "AASR_PREC_F64 is built for diagonal pools without per-class model transforms or Gaussian clustering");
   gmm_build_f64(g);
+  double det = 1.0;
+  if (g->host.n_transforms > 0) {  // one global transform: adapted frames, |prod diag A| on every Gaussian
+    const int64_t nv = F * g->dim;
+    g->f64_xframes.ensure((size_t)nv);
+    hipLaunchKernelGGL(k_affine_frames_f64, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, stream, d_frames, F,
+                       g->dim, g->f64_A.p, g->f64_b.p, g->f64_xframes.p);
+    AASR_HIP(hipGetLastError());
+    d_frames = g->f64_xframes.p;
+    det = g->f64_det;
+  }
   const int64_t blocks = (F + 255) / 256;
   // state-range cuts so that small batches still fill the chip
   int64_t cuts = std::max<int64_t>(1, std::min<int64_t>(g->S, (4 * (int64_t)(g->num_cus > 0 ? g->num_cus : 256) + blocks - 1) / blocks));
@@ -1562,7 +1586,7 @@ void gmm_score_f64_launch(aasr_gmm *g, const double *d_frames, int64_t F, double
 #define AASR_CASE(N)                                                                                              \
   case N:                                                                                                         \
     hipLaunchKernelGGL(k_gmm_diag_score_f64<N>, dim3((unsigned)blocks, (unsigned)cuts), dim3(256), 0, stream,     \
-                       d_frames, F, g->dim, g->f64_recs.p, g->f64_state_off.p, g->S, d_out, linear);              \
+                       d_frames, F, g->dim, g->f64_recs.p, g->f64_state_off.p, g->S, d_out, linear, det);         \
     break;
   switch (g->f64_dimp) {
     AASR_CASE(8) AASR_CASE(16) AASR_CASE(24) AASR_CASE(32) AASR_CASE(40) AASR_CASE(48) AASR_CASE(64)

@@ -43,8 +43,16 @@ def test_f64_scores_equal_the_oracle(capi, oracle, D, G, S, comps, tied):
     except capi.AasrError:
         g.set_precision(0)
     assert np.abs(g.score(f32) - want32).max() <= 2e-4
-    # refused where it is not built
-    g.set_cmllr(np.zeros(G, np.int32), np.hstack([np.zeros((D, 1)), np.eye(D)])[None])
+    # one global CMLLR transform: adapted frames and |prod diag A| in double as well
+    A = np.eye(D) * rng.uniform(0.9, 1.1, D) + 0.02 * rng.standard_normal((D, D))
+    W = np.hstack([0.1 * rng.standard_normal(D)[:, None], A])
+    g.set_cmllr(np.zeros(G, np.int32), W[None])
+    want_a = oracle.score_adapted(om, frames, np.zeros(G, np.int32), W[None])
+    got_a = g.score_f64(frames)
+    assert np.abs(got_a - want_a).max() <= 1e-10 * max(1.0, np.abs(want_a).max())
+    # refused where it is not built: per-class transforms
+    g2t = (np.arange(G) % 2).astype(np.int32)
+    g.set_cmllr(g2t, np.stack([W, W]))
     with pytest.raises(capi.AasrError, match="AASR_PREC_F64 is built for diagonal pools without"):
         g.score_f64(frames)
 
