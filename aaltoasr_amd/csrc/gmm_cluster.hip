@@ -103,18 +103,19 @@ static int g_force_heap = getenv("AASR_CLUSTER_HEAP") ? atoi(getenv("AASR_CLUSTE
 // operand load of a group and spills.
 constexpr int kCentreThreads = 256;
 
+template <typename XT>  // float frames, or double (AASR_PREC_F64)
 __global__ __launch_bounds__(kCentreThreads) void k_cluster_centres(
-    const float *__restrict__ frames, int64_t F, int dim, int dimp,
+    const XT *__restrict__ frames, int64_t F, int dim, int dimp,
     const double *__restrict__ rec, const double *__restrict__ cconst, int groups,
     int groups_per_y, double *__restrict__ ll64, int64_t Cs) {
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   typedef double f64x2 __attribute__((ext_vector_type(2)));
   double *pbuf = (double *)smem_c;                              // [2][dimp][8][2]
-  float *xs = (float *)(smem_c + (size_t)2 * dimp * 16 * 8);    // [dimp][kCentreThreads]
+  XT *xs = (XT *)(smem_c + (size_t)2 * dimp * 16 * 8);          // [dimp][kCentreThreads]
   const int tid = threadIdx.x;
   const int64_t f = (int64_t)blockIdx.x * kCentreThreads + tid;
   const int64_t fc = f < F ? f : F - 1;
-  for (int d = 0; d < dimp; d++) xs[d * kCentreThreads + tid] = d < dim ? frames[fc * dim + d] : 0.0f;
+  for (int d = 0; d < dimp; d++) xs[d * kCentreThreads + tid] = d < dim ? frames[fc * dim + d] : (XT)0;
   const int g_begin = blockIdx.y * groups_per_y;
   const int g_end = min(groups, g_begin + groups_per_y);
   const int rec_doubles = dimp * 16;
@@ -761,11 +762,12 @@ void gmm_set_clustering_min_evals(aasr_gmm *g, double min_clusters, double min_g
   cl.enabled = true;
 }
 
-static void launch_centres(aasr_gmm *g, const float *d_frames, int64_t F, hipStream_t stream) {
+template <typename XT>
+static void launch_centres(aasr_gmm *g, const XT *d_frames, int64_t F, hipStream_t stream) {
   ClusterState &cl = g->cl;
   const int groups = cl.Cs / 8;
   const int64_t bx = (F + kCentreThreads - 1) / kCentreThreads;
-  const int smem = 2 * cl.dimp * 16 * 8 + cl.dimp * kCentreThreads * (int)sizeof(float);
+  const int smem = 2 * cl.dimp * 16 * 8 + cl.dimp * kCentreThreads * (int)sizeof(XT);
   // cut the cluster groups over blockIdx.y so that the grid is a whole number of rounds over the
   // resident workgroup slots (a workgroup walks all its groups: with one cut, 977 workgroups on
   // 768 slots ran 1.27 rounds at half occupancy)
@@ -784,14 +786,14 @@ static void launch_centres(aasr_gmm *g, const float *d_frames, int64_t F, hipStr
   }
   const int gpy = (groups + ny - 1) / ny;
   ny = (groups + gpy - 1) / gpy;
-  static bool attr_set[64] = {false};
+  static bool attr_set[64] = {false};  // one flag array per instantiation (XT)
   if (!attr_set[g->device & 63]) {
-    AASR_HIP(hipFuncSetAttribute((const void *)k_cluster_centres,
+    AASR_HIP(hipFuncSetAttribute((const void *)k_cluster_centres<XT>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 2 * 64 * 16 * 8 + 64 * kCentreThreads * 4));
+                                 2 * 64 * 16 * 8 + 64 * kCentreThreads * (int)sizeof(XT)));
     attr_set[g->device & 63] = true;
   }
-  hipLaunchKernelGGL(k_cluster_centres, dim3((unsigned)bx, (unsigned)ny), dim3(kCentreThreads), smem,
+  hipLaunchKernelGGL(k_cluster_centres<XT>, dim3((unsigned)bx, (unsigned)ny), dim3(kCentreThreads), smem,
                      stream, d_frames, F, g->dim, cl.dimp, cl.rec.p, cl.cconst.p, groups, gpy,
                      cl.ll64.p, (int64_t)cl.Cs);
   AASR_HIP(hipGetLastError());
@@ -1031,6 +1033,40 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
     else
       exact_part_launch(g, cl, plan, cl.maskw.p, cl.C + 1, n, fr_members, out, stream);
     launch_merge(g, out, n, stream);
+  }
+}
+
+// AASR_PREC_F64 with Gaussian clustering: the reference's cluster branch in double end to end --
+// centres on the double frames, the same selection kernels, then the f64 scoring kernel taking for
+// every component either its exact likelihood (x |det| under a global transform) or its cluster
+// centre's (PDFPool::precompute_likelihoods, aku/Distributions.cc:2684-2722).  Per sub-pass, while
+// the centre keys live.
+void gmm_cluster_score_f64_launch(aasr_gmm *g, const double *d_frames, const double *d_members, int64_t F,
+                                  double *d_out, int linear, double det, hipStream_t stream) {
+  ClusterState &cl = g->cl;
+  if (cl.crow_centred.n != std::max<size_t>(g->host.mix_idx.size(), 1))
+    build_crow_comps(g, std::vector<int32_t>(), cl, cl.crow_centred);
+  const int64_t f_rounded = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK;
+  int64_t fs = (int64_t)(2.0e9 / (8.0 * (double)cl.Cs));
+  fs = std::min<int64_t>(f_rounded, std::max<int64_t>(FRAMES_PER_BLOCK, fs / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK));
+  if (fs > cl.Fc || (size_t)fs * cl.Cs > cl.ll64.n) {  // pass == sub-pass here
+    const int64_t fb = std::max(fs, cl.Fc);
+    cl.ll64.alloc((size_t)fb * cl.Cs);
+    cl.cval.alloc((size_t)fb * cl.C);
+    cl.maskw.alloc((size_t)(fb / 64) * (cl.C + 1));
+    cl.n_exact.alloc((size_t)fb);
+    cl.tie_list.alloc((size_t)fb + 1);
+    cl.heap_key.ensure((size_t)cl.C * kHeapThreads);
+    cl.heap_idx.ensure((size_t)cl.C * kHeapThreads);
+    cl.Fc = fb;
+    cl.Fs = fb;
+  }
+  for (int64_t f0 = 0; f0 < F; f0 += cl.Fs) {
+    const int64_t n = std::min<int64_t>(cl.Fs, F - f0);
+    launch_centres(g, d_frames + f0 * g->dim, n, stream);
+    launch_select(g, 0, n, stream);
+    gmm_f64_masked_launch(g, d_members + f0 * g->dim, n, d_out + f0 * g->S, linear, det, cl.crow_centred.p,
+                          cl.maskw.p, cl.C + 1, cl.ll64.p, (int64_t)cl.Cs, cl.C, stream);
   }
 }
 

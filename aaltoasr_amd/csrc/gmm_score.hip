@@ -1506,11 +1506,18 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
 // wave-uniform and arrive through the scalar cache.  A verification / training-side mode:
 // ~6 f64 operations per frame, Gaussian and dimension on the vector ALU.
 // ---------------------------------------------------------------------------
-template <int DIMP>
+// CL: Gaussian clustering -- component r belongs to cluster crow[r]; where the frame's bit of
+// maskw[word][cluster] is clear the component takes its centre's likelihood, recovered from the
+// ranking key the centre kernel stored (key == ll where exp(ll) is a normal double, else the
+// denormal's integer multiple of 2^-1074, gmm_cluster.hip lin_key).
+template <int DIMP, bool CL>
 __global__ __launch_bounds__(256) void k_gmm_diag_score_f64(const double *__restrict__ frames, int64_t F, int dim,
                                                             const double *__restrict__ recs,
                                                             const int32_t *__restrict__ state_off, int64_t S,
-                                                            double *__restrict__ out, int linear, double det) {
+                                                            double *__restrict__ out, int linear, double det,
+                                                            const int32_t *__restrict__ crow,
+                                                            const unsigned long long *__restrict__ maskw, int c1,
+                                                            const double *__restrict__ ll64, int64_t Cs, int C) {
   constexpr int REC = 2 * DIMP + 2;  // [mean x DIMP][precision x DIMP][constant, weight]
   const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t fc = f < F ? f : F - 1;
@@ -1533,7 +1540,16 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_f64(const double *__rest
       ll *= -0.5;
       ll += rec[2 * DIMP];
       // AdaptedGaussian::compute_likelihood = g(A f + b) * |det| (aku/ModelModules.hh:172-173); det = 1 unadapted
-      l += rec[2 * DIMP + 1] * (exp(ll) * det);
+      double lik = exp(ll) * det;
+      if (CL) {
+        const int c = crow[r];
+        const bool on = (maskw[(fc >> 6) * c1 + c] >> (fc & 63)) & 1ull;
+        if (!on) {  // c < C here: the "no cluster" column C is all ones
+          const double key = ll64[fc * Cs + (c < C ? c : 0)];
+          lik = key > -1000.0 ? exp(key) : ldexp((key + 2000.0) * 4398046511104.0, -1074);
+        }
+      }
+      l += rec[2 * DIMP + 1] * lik;
     }
     if (l < 1e-50) l = 1e-50;  // also NaN-free: comparisons with NaN are false, as in the reference
     if (f < F) out[f * S + s] = linear ? l : log(l);
@@ -1565,10 +1581,10 @@ __global__ void k_affine_frames_f64(const double *__restrict__ x, int64_t F, int
 void gmm_score_f64_launch(aasr_gmm *g, const double *d_frames, int64_t F, double *d_out, int linear,
                           hipStream_t stream) {
   if (F <= 0) return;
-  if (g->host.any_full() || (g->host.n_transforms > 0 && !g->host.global_xform()) || g->cl.enabled)
-    raise(AASR_ERR_UNSUPPORTED,
-          "AASR_PREC_F64 is built for diagonal pools without per-class model transforms or Gaussian clustering");
+  if (g->host.any_full() || (g->host.n_transforms > 0 && !g->host.global_xform()))
+    raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 is built for diagonal pools without per-class model transforms");
   gmm_build_f64(g);
+  const double *d_raw = d_frames;
   double det = 1.0;
   if (g->host.n_transforms > 0) {  // one global transform: adapted frames, |prod diag A| on every Gaussian
     const int64_t nv = F * g->dim;
@@ -1579,14 +1595,31 @@ void gmm_score_f64_launch(aasr_gmm *g, const double *d_frames, int64_t F, double
     d_frames = g->f64_xframes.p;
     det = g->f64_det;
   }
+  if (g->cl.enabled) {
+    gmm_cluster_score_f64_launch(g, d_raw, d_frames, F, d_out, linear, det, stream);
+    return;
+  }
+  gmm_f64_masked_launch(g, d_frames, F, d_out, linear, det, nullptr, nullptr, 0, nullptr, 0, 0, stream);
+}
+
+void gmm_f64_masked_launch(aasr_gmm *g, const double *d_frames, int64_t F, double *d_out, int linear, double det,
+                           const int32_t *crow, const unsigned long long *maskw, int c1, const double *ll64,
+                           int64_t Cs, int C, hipStream_t stream) {
+  gmm_build_f64(g);
   const int64_t blocks = (F + 255) / 256;
   // state-range cuts so that small batches still fill the chip
   int64_t cuts = std::max<int64_t>(1, std::min<int64_t>(g->S, (4 * (int64_t)(g->num_cus > 0 ? g->num_cus : 256) + blocks - 1) / blocks));
   if (cuts > 65535) cuts = 65535;
 #define AASR_CASE(N)                                                                                              \
   case N:                                                                                                         \
-    hipLaunchKernelGGL(k_gmm_diag_score_f64<N>, dim3((unsigned)blocks, (unsigned)cuts), dim3(256), 0, stream,     \
-                       d_frames, F, g->dim, g->f64_recs.p, g->f64_state_off.p, g->S, d_out, linear, det);         \
+    if (maskw)                                                                                                    \
+      hipLaunchKernelGGL((k_gmm_diag_score_f64<N, true>), dim3((unsigned)blocks, (unsigned)cuts), dim3(256), 0,   \
+                         stream, d_frames, F, g->dim, g->f64_recs.p, g->f64_state_off.p, g->S, d_out, linear, det, \
+                         crow, maskw, c1, ll64, Cs, C);                                                           \
+    else                                                                                                          \
+      hipLaunchKernelGGL((k_gmm_diag_score_f64<N, false>), dim3((unsigned)blocks, (unsigned)cuts), dim3(256), 0,  \
+                         stream, d_frames, F, g->dim, g->f64_recs.p, g->f64_state_off.p, g->S, d_out, linear, det, \
+                         crow, maskw, c1, ll64, Cs, C);                                                           \
     break;
   switch (g->f64_dimp) {
     AASR_CASE(8) AASR_CASE(16) AASR_CASE(24) AASR_CASE(32) AASR_CASE(40) AASR_CASE(48) AASR_CASE(64)

@@ -91,3 +91,48 @@ def test_f64_lna_files_are_the_oracles(capi, oracle, nbytes, normalize):
     got3 = np.frombuffer(data3[5:], np.uint8).reshape(n, 64, nbytes)
     vals3 = (got3 == by_ref.reshape(n, 64, nbytes)).all(axis=2).mean()
     assert vals3 < vals or vals == 1.0
+
+
+def test_f64_with_gaussian_clustering_is_the_oracles_cluster_branch(capi, oracle):
+    """The production configuration (-C ... --eval-ming 0.25) in AASR_PREC_F64: centres on the double
+    frames, the same selection, every component either exact or its centre's likelihood
+    (aku/Distributions.cc:2684-2722) -- state log-likelihoods to 1e-12, exact-evaluation counts equal,
+    the LNA file of an utterance byte-identical to the oracle's clustered phone_probs; also under one
+    global CMLLR transform (adapted members, plain centres)."""
+    rng = np.random.default_rng(9)
+    mean, var, off, idx, w = synth.make_model(D=39, G=1152, S=96, comps=12, seed=8)
+    g2c = synth.make_clustering(mean, 40)
+    g2c[3] = g2c[500] = -1
+    pairs = [(int(a), int(c)) for a, c in enumerate(g2c) if c >= 0]
+    frames = synth.make_frames(300, seed=6).astype(np.float64)
+    frames[:5] *= 40.0                                   # far frames: centres underflow, members go exact
+    om = oracle.DiagModel(mean, var, off, idx, w)
+    g = capi.Gmm.from_arrays(mean, var, off, idx, w)
+    g.set_clustering(40, pairs)
+    for minc, ming in ((0.0, 0.25), (0.2, 0.0), (0.0, 0.0)):
+        om.set_clustering(40, pairs, minc, ming)
+        g.set_clustering_min_evals(minc, ming)
+        want, want_n = om.score_clustered(frames, want_counts=True)
+        got = g.score_f64(frames)
+        assert np.array_equal(g.cluster_exact_counts(len(frames)), want_n)
+        assert np.abs(got - want).max() <= 1e-10 * max(1.0, np.abs(want).max()), (minc, ming)
+    A = np.eye(39) * rng.uniform(0.9, 1.1, 39) + 0.02 * rng.standard_normal((39, 39))
+    W = np.hstack([0.1 * rng.standard_normal(39)[:, None], A])
+    g.set_cmllr(np.zeros(1152, np.int32), W[None])
+    want_a, n_a = om.score_clustered_adapted(frames, W, want_counts=True)
+    got_a = g.score_f64(frames)
+    assert np.array_equal(g.cluster_exact_counts(len(frames)), n_a)
+    assert np.abs(got_a - want_a).max() <= 1e-10 * max(1.0, np.abs(want_a).max())
+    g.set_cmllr()
+    # an utterance through the whole path
+    cfg = open(os.path.join(GOLDEN, "mfcc_cms_norm.feaconf")).read()
+    pcm = synth.make_audio(16000 * 3, seed=78)
+    ft = capi.Feat(cfg)
+    g.set_precision(1)
+    data, n = capi.run_utterance(ft, g, pcm, lnabytes=2)
+    fea = oracle.FeatureChain(cfg).generate(pcm, 0, n)
+    ll = om.score_clustered(fea)
+    _, by_ref = oracle.lna_encode(np.exp(ll), True, 2)
+    got = np.frombuffer(data[5:], np.uint8).reshape(n, 96, 2)
+    same = (got == by_ref.reshape(n, 96, 2)).all(axis=2).mean()
+    assert same >= 0.9999, same
