@@ -104,6 +104,12 @@ def run(seed=1, N=40, verbose=False):
                 note("score layouts=%d prec=%d" % (layouts, prec), g.score(frames), want, ctx)
         g.set_layouts(7)
         g.set_precision(0)
+        # AASR_PREC_F64: the reference's arithmetic in double (device exp / log are the only difference)
+        f64 = g.score_f64(frames.astype(np.float64))
+        e64 = float(np.abs(f64 - want).max())
+        worst["f64"] = max(worst.get("f64", 0.0), e64)
+        if e64 > 1e-9 * max(1.0, float(np.abs(want).max())):
+            fails.append("f64 %s err %.3g" % (ctx, e64))
         Cn = int(rng.integers(1, max(2, int(0.3 * G)))) if G >= 4 else 0
         if Cn >= 1 and Cn <= 0.3 * G:
             g2c = rng.integers(0, Cn, G)
@@ -119,6 +125,11 @@ def run(seed=1, N=40, verbose=False):
                 if verbose:
                     print("skip clustering:", e)
                 continue
+            f64 = g.score_f64(frames.astype(np.float64))
+            e64 = float(np.abs(f64 - wantc).max())
+            worst["f64 clustered"] = max(worst.get("f64 clustered", 0.0), e64)
+            if e64 > 1e-9 * max(1.0, float(np.abs(wantc).max())) or not np.array_equal(g.cluster_exact_counts(F), cnt):
+                fails.append("f64 clustered %s C %d minc %g ming %g err %.3g" % (ctx, Cn, minc, ming, e64))
             for prec in (0, 3):
                 try:
                     g.set_precision(prec)
