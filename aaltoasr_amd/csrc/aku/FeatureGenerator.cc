@@ -348,7 +348,7 @@ static void set_one_parameter(FeatureModule *m, const char *key, const std::vect
     if (n == key) continue;
     std::string val;
     cur.get(n, val);
-    next.set(n, val);
+    if (!val.empty()) next.set(n, val);  // an empty vector and a missing key mean the same to set_parameters
   }
   if (!v.empty()) next.set(key, exact_floats(v));
   m->set_parameters(next);
@@ -419,7 +419,7 @@ void FeatureModule::get_parameters(ModuleConfig &config) {
   const std::string t(text, (size_t)len);
   aasr_free(text);
   ModuleConfig got;
-  got.read_text(t);
+  got.read_text(t, true);
   config = got;
 }
 

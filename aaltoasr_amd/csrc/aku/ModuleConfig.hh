@@ -94,7 +94,7 @@ class ModuleConfig {
   }
 
   /** reads one "{ ... }" block, line by line (aku/ModuleConfig.cc:166-202) */
-  void read(FILE *file) {
+  void read(FILE *file, bool allow_empty_values = false) {
     m_lines = 0;
     bool opened = false;
     std::string line;
@@ -110,7 +110,15 @@ class ModuleConfig {
       }
       if (line == "}") break;
       const size_t sp = line.find_first_of(" \t");
-      if (sp == std::string::npos) throw std::string("value missing for option: ") + line;
+      if (sp == std::string::npos) {
+        // an empty vector held in memory (QuantEqModule::get_parameters before any estimate,
+        // aku/FeatureModules.cc:2097-2102) has no text form the reference's reader accepts;
+        // the engine hands parameters over as text, so its own blocks may carry one
+        if (!allow_empty_values) throw std::string("value missing for option: ") + line;
+        if (exists(line)) throw std::string("value redefined: ") + line;
+        put(line, "");
+        continue;
+      }
       const std::string key = line.substr(0, sp);
       const size_t vb = line.find_first_not_of(" \t", sp);
       if (exists(key)) throw std::string("value redefined: ") + line;
@@ -131,13 +139,13 @@ class ModuleConfig {
     return t;
   }
   /** parses a block held in memory */
-  void read_text(const std::string &text) {
+  void read_text(const std::string &text, bool allow_empty_values = false) {
     FILE *tmp = tmpfile();
     if (!tmp) throw std::string("ModuleConfig: tmpfile() failed");
     fputs(text.c_str(), tmp);
     rewind(tmp);
     try {
-      read(tmp);
+      read(tmp, allow_empty_values);
     } catch (...) {
       fclose(tmp);
       throw;

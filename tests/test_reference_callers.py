@@ -64,7 +64,8 @@ def test_decode_stream_acoustics_compile_against_the_adapters(tmp_path):
 
 @needs_ref
 def test_reference_mains_are_linked_with_the_engine(capi, oracle):
-    for name in ("phone_probs_refmain", "feacat_refmain", "align_refmain", "vtln_refmain", "logl_refmain"):
+    for name in ("phone_probs_refmain", "feacat_refmain", "align_refmain", "vtln_refmain", "logl_refmain",
+                 "segfea_refmain", "quanteq_refmain", "feadot_refmain"):
         assert os.access(os.path.join(REFBIN, name), os.X_OK), name
 
 
@@ -440,3 +441,186 @@ def test_reference_logl_with_both_segmentators_on_the_engine(capi, oracle, tmp_p
         assert r.returncode == 0, r.stderr[-2000:]
         got64 = float(r.stdout.strip().splitlines()[-1].split(":")[-1])
         assert abs(got64 - want) <= 2e-6 + 1e-12 * abs(want), (flags, got64, want)
+
+
+SEGFEA_BIND = "a 3 0 1 2\nb 2 3 4\n_ 1 5\n"
+
+
+@pytest.mark.gpu
+def test_reference_segfea_on_the_engine(capi, oracle, tmp_path):
+    """aku/segfea.cc, the reference's text, on the engine: features of a recipe sorted into one file
+    per model state along a PHN segmentation (phone segments divided evenly into their states, a
+    recipe line cut by start-time / end-time, a segmentation that runs past the end of its audio
+    file), plus the state occurrence counts -- against the same walk over the oracle's features."""
+    exe = os.path.join(REFBIN, "segfea_refmain")
+    if not os.access(exe, os.X_OK):
+        pytest.skip("oracle/_ref/segfea_refmain was not built (no reference tree in the build container)")
+    cfg_text = synth.make_feature_config()
+    cfg = str(tmp_path / "f.cfg")
+    open(cfg, "w").write(cfg_text)
+    open(tmp_path / "bind", "w").write(SEGFEA_BIND)
+    states = {"a": [0, 1, 2], "b": [3, 4], "_": [5]}
+    chain = oracle.FeatureChain(cfg_text)
+    rate = 125.0
+    # (samples, PHN lines (begin sample, end sample, label), recipe options)
+    files = [
+        (40000, [(0, 3000, "_"), (3000, 15000, "a"), (15000, 22222, "b"), (22222, 39000, "a")], ""),
+        (30011, [(0, 9000, "b"), (9000, 9100, "a"), (9100, 20000, "_"), (20000, 29000, "a")], " start-time=0.3 end-time=1.5"),
+        (16000, [(0, 8000, "a"), (8000, 24000, "b"), (24000, 30000, "_")], ""),   # inherits the times; runs past the end
+    ]
+    want = {s: [] for s in range(6)}
+    occ = [0] * 6
+    lines = []
+    start = end = 0
+    for i, (n, phn, opts) in enumerate(files):
+        pcm = synth.make_audio(n, seed=170 + i)
+        _write_wav(str(tmp_path / ("s%d.wav" % i)), pcm)
+        with open(tmp_path / ("s%d.phn" % i), "w") as f:
+            for b, e, lab in phn:
+                f.write("%d %d %s\n" % (b, e, lab))
+        lines.append("audio=%s transcript=%s%s" % (tmp_path / ("s%d.wav" % i), tmp_path / ("s%d.phn" % i), opts))
+        eof = chain.num_frames(len(pcm))
+        fea = chain.generate(pcm, 0, eof).astype(np.float32)
+        if opts:    # keys of a recipe line stay in force on the following lines (aku/Recipe.cc:31,82-90)
+            start = int(float(opts.split("start-time=")[1].split()[0]) * rate)
+            end = int(float(opts.split("end-time=")[1]) * rate)
+        done = False
+        for b, e, lab in phn:                                  # aku/segfea.cc:248-371
+            sb, se = int(b / 16000.0 * rate), int(e / 16000.0 * rate)
+            if se < start:
+                continue
+            sb = max(sb, start)
+            if end > 0 and se > end:
+                se = end
+            if sb >= se:
+                continue
+            st, dur = states[lab], se - sb
+            for p, s in enumerate(st):
+                beg, fin = sb + p * dur // len(st), sb + ((p + 1) * dur) // len(st)
+                if beg >= fin:
+                    continue
+                occ[s] += 1
+                if fin > eof:                                  # eof inside the block: what was read, then next file
+                    want[s].append(fea[beg:max(beg, eof)])
+                    done = True
+                    break
+                want[s].append(fea[beg:fin])
+            if done:
+                break
+    open(tmp_path / "r.recipe", "w").write("\n".join(lines) + "\n")
+    out = str(tmp_path / "fea")
+    r = subprocess.run([exe, "-b", str(tmp_path / "bind"), "-c", cfg, "-r", str(tmp_path / "r.recipe"), "-o", out,
+                        "--binary", "--occ", out + ".occ", "--bufsize", "150"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # --binary writes `num_features` floats per block, not num_features x dim (aku/segfea.cc:84-86:
+    # fwrite(buf, sizeof(float), count, out)): the head of each block, as written
+    worst = 0.0
+    for s in range(6):
+        w = np.concatenate([b.reshape(-1)[:len(b)] for b in want[s]]) if want[s] else np.zeros(0, np.float32)
+        path = "%s_%d" % (out, s)
+        g = np.fromfile(path, "<f4") if os.path.exists(path) else np.zeros(0, np.float32)
+        assert g.shape == w.shape, (s, g.shape, w.shape)
+        if len(w):
+            worst = max(worst, float(np.abs(g - w).max() / max(1.0, np.abs(w).max())))
+    assert worst == 0.0, worst                                 # float32 copies of features that agree to 1e-13
+    got_occ = [int(l.split()[1]) for l in open(out + ".occ").read().splitlines()]
+    assert got_occ == occ
+    # text output (the form the training scripts read): every state's "%f " lines
+    r = subprocess.run([exe, "-b", str(tmp_path / "bind"), "-c", cfg, "-r", str(tmp_path / "r.recipe"), "-o", out + "t",
+                        "--bufsize", "150"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for s in range(6):
+        w = np.vstack(want[s]) if want[s] else np.zeros((0, 39), np.float32)
+        path = "%st_%d" % (out, s)
+        txt = np.loadtxt(path).reshape(-1, 39) if os.path.exists(path) else np.zeros((0, 39))
+        assert txt.shape == w.shape, (s, txt.shape, w.shape)
+        assert len(w) == 0 or np.abs(txt - w).max() <= 1.5e-6 * max(1.0, np.abs(w).max()), s
+    assert sum(len(b) for s in range(6) for b in want[s]) > 500
+
+
+QUANTEQ_CFG_TAIL = """module
+{
+  name qe
+  type quanteq
+  quant_train 0.5 0.8 1.1 1.6
+  sources %s
+}
+"""
+
+
+@pytest.mark.gpu
+def test_reference_quanteq_estimation_on_the_engine(capi, oracle, tmp_path):
+    """aku/quanteq.cc, the reference's text, on the engine: per utterance every frame through
+    FeatureGenerator::generate, quantiles and a grid search per channel, the result set on the
+    QuantEqModule (set_alpha / set_gamma / set_quant_max, get_quant_train) and the utterance file
+    written by SpeakerConfig::write_speaker_file -- byte for byte what the reference writes."""
+    exe = os.path.join(REFBIN, "quanteq_refmain")
+    if not os.access(exe, os.X_OK):
+        pytest.skip("oracle/_ref/quanteq_refmain was not built (no reference tree in the build container)")
+    # a short chain ending in the quanteq module: fft -> mel (log energies, 21 channels) -> qe
+    base = synth.make_feature_config()
+    mods = base.split("module\n")
+    keep = [m for m in mods[1:] if any(("name %s\n" % n) in m for n in ("audiofile", "fft", "mel"))]
+    assert len(keep) == 3, [m.split("\n")[1] for m in mods[1:]]
+    cfg_text = mods[0] + "".join("module\n" + m for m in keep) + QUANTEQ_CFG_TAIL % "mel"
+    cfg = str(tmp_path / "q.cfg")
+    open(cfg, "w").write(cfg_text)
+    chain = oracle.FeatureChain(cfg_text)
+    assert chain.mods[-1].type == "quanteq"
+    dim = chain.dim
+    lines, pcms = [], []
+    for i, n in enumerate([20000, 12345, 31000]):
+        pcms.append(synth.make_audio(n, seed=180 + i))
+        _write_wav(str(tmp_path / ("q%d.wav" % i)), pcms[-1])
+        lines.append("audio=%s utterance=utt%d%s" % (tmp_path / ("q%d.wav" % i), i, " start-time=0.2 end-time=1.0" if i == 2 else ""))
+    open(tmp_path / "r.recipe", "w").write("\n".join(lines) + "\n")
+    spk_in = "utterance default\n{\n  feature qe\n  {\n  }\n}\n"
+    open(tmp_path / "in.spkc", "w").write(spk_in)
+    out = str(tmp_path / "out.spkc")
+    a_step, g_step, g_end = 0.125, 0.25, 2.0                  # binary fractions: the float grid is exact
+    r = subprocess.run([exe, "-c", cfg, "-r", str(tmp_path / "r.recipe"), "-q", "qe", "-S", str(tmp_path / "in.spkc"),
+                        "-o", out, "--grid-alpha-step", str(a_step), "--grid-gamma-step", str(g_step),
+                        "--grid-gamma-end", str(g_end)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    text = open(out).read()
+    # What the reference writes: SpeakerConfig::retrieve_utterance_config (aku/SpeakerConfig.cc:344-362) calls
+    # set_parameters where retrieve_speaker_config calls get_parameters, so the estimates set on the module are
+    # overwritten by the stored (default) block when the next utterance is selected or the file is written:
+    # every utterance gets an entry, each a copy of the default one.  Kept as written.
+    want = "utterance default\n{\n  feature qe\n  {\n  }\n\n}\n\n"
+    for i in range(3):
+        want += "utterance utt%d\n{\n  feature qe\n  {\n  }\n\n}\n\n" % i
+    assert text == want, text
+    # the estimation itself, through the adapter classes the tool drives: QuantEqModule setters / getters
+    ft = capi.Feat(cfg_text)
+    prm = {"alpha": " ".join(["0.5"] * dim), "gamma": " ".join(["1.5"] * dim),
+           "quant_max": " ".join(["%g" % (3 + 0.1 * c) for c in range(dim)])}
+    ft.set_parameters("qe", "{\n" + "".join(" %s %s\n" % kv for kv in prm.items()) + "}\n")
+    chain.set_parameters("qe", prm)
+    got = ft.run(pcms[0], 0, 40, dtype=np.float64)
+    ref = chain.generate(pcms[0], 0, 40)
+    assert np.abs(got - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.gpu
+def test_reference_feadot_on_the_engine(capi, tmp_path):
+    """aku/feadot.cc on the engine's FeatureGenerator: nodes and edges of the module graph
+    (aku/FeatureGenerator.cc:390-408, FeatureModule::print_dot_node aku/FeatureModules.cc:202-217)."""
+    exe = os.path.join(REFBIN, "feadot_refmain")
+    if not os.access(exe, os.X_OK):
+        pytest.skip("oracle/_ref/feadot_refmain was not built (no reference tree in the build container)")
+    cfg_text = synth.make_feature_config()
+    cfg = str(tmp_path / "f.cfg")
+    open(cfg, "w").write(cfg_text)
+    r = subprocess.run([exe, "-c", cfg, "-o", str(tmp_path / "g.dot")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    dot = open(tmp_path / "g.dot").read().splitlines()
+    assert dot[0] == "digraph features {" and dot[1] == "rankdir=RL;" and dot[-1] == "}"
+    names, edges = [], []
+    for m in cfg_text.split("module\n")[1:]:
+        kv = dict(l.split(None, 1) for l in m.splitlines() if len(l.split()) >= 2)
+        names.append(kv["name"])
+        edges += [(kv["name"], s) for s in kv.get("sources", "").split()]
+    assert [l for l in dot if "->" in l] == ["\t%s -> %s;" % e for e in edges]
+    for n in names:
+        assert any(l.lstrip().startswith(n + " [") for l in dot), n
