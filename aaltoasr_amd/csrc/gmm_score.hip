@@ -1014,7 +1014,7 @@ static bool launch_bf16(const aasr_gmm *g, const TrackLayout &L, const float *d_
   switch (L.nk16) {
 #define AASR_CASE(N)                                                                               \
   case N:                                                                                          \
-    if (cl) { /* 4-wave form: the selection masks are laid out per 256-frame workgroup */          \
+    if (cl) { /* 4-wave form: the 8-wave one with masks needs 254 VGPRs + spills, measured slower */ \
       if (L.grouped) launch_bf16_t<N, true, true, false>(g, L, d_frames, F, d_out, stream, *cl, pitch);   \
       else launch_bf16_t<N, false, true, false>(g, L, d_frames, F, d_out, stream, *cl, pitch);            \
     } else if (wide && wide_ok<N>()) {                                                             \
