@@ -229,7 +229,7 @@ struct aasr_gmm {
   bool centred_ok = false, ill_conditioned = false;
   double kappa = 0;           // conditioning estimate of the expanded form
   int centred_dimp = 0;
-  aasr::DevBuf<float> centred_recs;        // [rows][2*dimp+4]
+  aasr::DevBuf<float> centred_recs;        // [rows][3*dimp+4]
   aasr::DevBuf<int32_t> centred_state_off; // [S+1]
   aasr::DevBuf<int32_t> centred_splits;    // [MAX][MAX+1] state boundaries
   int centred_max_splits = 1;

@@ -877,7 +877,7 @@ static void build_centred_tables(const HostModel &m, int dimp, const std::vector
                                  DevBuf<int32_t> &d_off, DevBuf<int32_t> &d_splits, int *max_splits,
                                  bool pool = false) {
   const int D = m.dim;
-  const int rec = 2 * dimp + 4;
+  const int rec = 3 * dimp + 4;  // [mu_hi][p'][C, pad x 3][mu_lo], k_gmm_diag_score_centred
   const size_t rows = comps.size();
   const int64_t n_states = (int64_t)off.size() - 1;
   std::vector<float> recs(std::max<size_t>(1, rows) * rec, 0.0f);
@@ -889,7 +889,9 @@ static void build_centred_tables(const HostModel &m, int dimp, const std::vector
       double v = m.var[(size_t)gi * D + d];
       double p = v > 0 ? 1 / v : 0;
       prod *= p;
-      recs[r * rec + d] = (float)m.mean[(size_t)gi * D + d];
+      const double mu = m.mean[(size_t)gi * D + d];
+      recs[r * rec + d] = (float)mu;
+      recs[r * rec + 2 * dimp + 4 + d] = (float)(mu - (double)(float)mu);
       recs[r * rec + dimp + d] = (float)(-0.5 * p * kLog2e);
     }
     double cst = (prod > 0) ? std::log(std::sqrt(prod)) : prod;

@@ -1431,7 +1431,9 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
     float *__restrict__ out, int64_t frame_stride, int64_t state_stride,
     const int32_t *__restrict__ crow, const unsigned long long *__restrict__ maskw, int c1, int64_t n_words,
     float floor_val) {
-  constexpr int REC = 2 * DIMP + 4;  // [mu x DIMP][p' x DIMP][C, pad, pad, pad]
+  // [mu x DIMP][p' x DIMP][C, pad, pad, pad][mu_lo x DIMP]: the mean as a float pair, mu = mu_hi + mu_lo
+  // to 2^-48 -- a mean rounded to one float costs p t ulp(mu)/2, 1e-4 at 14 sigma from a sigma = 0.01 Gaussian
+  constexpr int REC = 3 * DIMP + 4;
   // each lane owns TWO frames (f, f + 256): one scalar fetch of a Gaussian's
   // parameters feeds 128 frame x Gaussian pairs per wave
   const int64_t fa = (int64_t)blockIdx.x * 512 + threadIdx.x;
@@ -1467,8 +1469,10 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
 #pragma unroll
       for (int d = 0; d < DIMP; d += 2) {
         const float mu0 = rec[d], mu1 = rec[d + 1];
+        const float ml0 = rec[2 * DIMP + 4 + d], ml1 = rec[2 * DIMP + 4 + d + 1];
         const float p0 = rec[DIMP + d], p1 = rec[DIMP + d + 1];
-        const f32x2 t0 = x2[d] - (f32x2){mu0, mu0}, t1 = x2[d + 1] - (f32x2){mu1, mu1};
+        const f32x2 t0 = (x2[d] - (f32x2){mu0, mu0}) - (f32x2){ml0, ml0};
+        const f32x2 t1 = (x2[d + 1] - (f32x2){mu1, mu1}) - (f32x2){ml1, ml1};
         acc0 = __builtin_elementwise_fma(t0 * t0, (f32x2){p0, p0}, acc0);
         acc1 = __builtin_elementwise_fma(t1 * t1, (f32x2){p1, p1}, acc1);
       }

@@ -164,6 +164,35 @@ def test_ill_conditioned_model_takes_the_centred_kernel(capi, oracle):
     assert used == {4}
 
 
+def test_centred_kernel_keeps_double_means(capi, oracle):
+    """Means arrive as doubles (a .gk file's digits); rounded to one float a mean costs
+    p |x - mu| ulp(mu)/2 -- 1e-4 at 14 sigma from a sigma = 0.012 Gaussian around 2.3 (fuzz_parity
+    seed 811) -- so the centred records carry mu as a float pair and only roundings relative to
+    x - mu are left."""
+    rng = np.random.default_rng(811)
+    D, G, S = 2, 96, 12
+    mean = rng.standard_normal((G, D)) * 2.0 + np.array([2.0, -3.0])     # not float32-representable
+    var = np.exp(rng.uniform(np.log(5e-5), np.log(5e-4), (G, D)))
+    off = np.arange(0, G + 1, G // S).astype(np.int32)
+    idx = np.arange(G, dtype=np.int32)
+    w = rng.uniform(0.1, 1.0, G)
+    # frames 8..15 sigma away from one Gaussian each
+    pick = rng.integers(0, G, 600)
+    frames = (mean[pick] + np.sqrt(var[pick]) * rng.uniform(8, 15, (600, 1)) * rng.choice([-1.0, 1.0], (600, D))
+              / np.sqrt(D)).astype(np.float32)
+    want = oracle.DiagModel(mean, var, off, idx, w).score(frames.astype(np.float64))
+    g = capi.Gmm.from_arrays(mean, var, off, idx, w)
+    assert g.active_layout() == 4
+    got = g.score(frames)
+    vis = want > -103.97
+    assert vis.sum() > 300
+    err = np.abs(got - want)[vis].max()
+    # with float means the same comparison gives ~2e-4 (the oracle on rounded means differs by that much)
+    rounded = oracle.DiagModel(mean.astype(np.float32).astype(np.float64), var, off, idx, w).score(frames.astype(np.float64))
+    assert np.abs(rounded - want)[vis].max() > 1e-4
+    assert err <= 6e-5, err
+
+
 def test_block_partition_invariance(capi):
     """Scoring is per-frame: any split of the frame block gives identical bits."""
     model = synth.make_model(D=39, G=256, S=32, comps=8)
