@@ -1,4 +1,4 @@
-"""Fixed-seed slices of the randomised parity sweeps (tools/fuzz_parity.py, tools/fuzz_features.py)
+"""Fixed-seed slices of the randomised parity sweeps (tools/fuzz_parity.py, tools/fuzz_features.py, tools/fuzz_fullcov.py)
 as part of the suite, so that a discrepancy found by a sweep can never sit in a scratch log:
 every random model / feature graph of these seeds must agree with the oracle -- scores within
 1e-4 wherever the reference's float storage can hold the likelihood (2e-4 below its flush
@@ -39,3 +39,12 @@ def test_feature_graph_sweep(capi, oracle, seed, n):
     worst, fails = _load("fuzz_features").run(seed, n)
     assert not fails, "\n".join(fails)
     assert {"fft", "mel", "dct", "delta", "merge"} <= set(worst)
+
+
+@pytest.mark.parametrize("seed,n", [(1, 60), (3, 40)])
+def test_full_covariance_sweep(capi, oracle, seed, n):
+    """tools/fuzz_fullcov.py: random full-covariance pools (spectra over two decades, non-SPD entries, ragged /
+    tied / zero-weight mixtures), both precisions, against oracle.FullModel."""
+    worst, fails = _load("fuzz_fullcov").run(seed, n)
+    assert not fails, "\n".join(fails)
+    assert worst["refused"] <= 1 and worst["full prec=0"] <= 1e-4 and worst["full prec=3"] <= 1e-4

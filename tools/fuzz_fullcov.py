@@ -1,0 +1,86 @@
+"""Randomised sweep of the full-covariance path (k_gmm_full_score / _bf16x3) against oracle.FullModel:
+random dimensions, pool sizes, ragged / tied / zero-weight mixtures, covariance spectra spanning two
+decades, some non-SPD ("invalid") covariances, frames 0.5-2.5 sigma wide.  A failure is |dll| > 1e-4 on a
+state the reference's float storage can hold (ll > -103.97), > 2e-4 below.  `python tools/fuzz_fullcov.py
+SEED N`; exits non-zero on a failure."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def run(seed=1, N=40, verbose=False):
+    from aaltoasr_amd import capi
+    from oracle import oracle as O
+    O.build()
+    rng = np.random.default_rng(seed)
+    worst, fails, refused = {}, [], 0
+    for it in range(N):
+        D = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 24, 39, 47, 63]))
+        S = int(rng.integers(1, 24))
+        n = rng.integers(int(rng.integers(0, 2)), int(rng.integers(1, 12)) + 1, S)
+        if n.sum() == 0:
+            n[0] = 1
+        K = int(n.sum())
+        tied = bool(rng.integers(0, 2))
+        G = int(K if not tied else max(2, K // 2))
+        mean = rng.standard_normal((G, D)) * rng.uniform(0.3, 2.0)
+        cov = np.empty((G, D, D))
+        lo, hi = np.log(rng.uniform(0.03, 0.5)), np.log(rng.uniform(0.6, 5.0))
+        for g in range(G):
+            q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+            ev = np.exp(rng.uniform(lo, hi, D))
+            cov[g] = (q * ev) @ q.T
+            cov[g] = 0.5 * (cov[g] + cov[g].T)
+        if rng.integers(0, 5) == 0 and D >= 2:
+            bad = int(rng.integers(0, G))
+            cov[bad] = -cov[bad]                              # not SPD: the reference's invalid Gaussian
+        off = np.zeros(S + 1, np.int32)
+        off[1:] = np.cumsum(n)
+        idx = (rng.integers(0, G, K) if tied else np.arange(K)).astype(np.int32)
+        w = rng.uniform(0.01, 1.0, K)
+        if rng.integers(0, 3) == 0 and K > 2:
+            w[rng.integers(0, K)] = 0.0
+        F = int(rng.integers(1, 300))
+        frames = (rng.standard_normal((F, D)) * rng.uniform(0.5, 2.5)).astype(np.float32)
+        ctx = "seed %d it %d D %d S %d G %d tied %d F %d" % (seed, it, D, S, G, tied, F)
+        want = O.FullModel(mean, cov, off, idx, w).score(frames.astype(np.float64))
+        try:
+            g = capi.Gmm.from_full(mean, cov, off, idx, w)
+        except capi.AasrError as e:
+            refused += 1
+            if verbose:
+                print("refused:", ctx, e)
+            continue
+        for prec in (0, 3):
+            try:
+                g.set_precision(prec)
+            except capi.AasrError:
+                continue
+            got = g.score(frames)
+            d = np.abs(got - want)
+            vis = want > -103.97
+            key = "full prec=%d" % prec
+            evis = float(d[vis].max()) if vis.any() else 0.0
+            eall = float(d.max())
+            worst[key] = max(worst.get(key, 0.0), evis)
+            worst[key + " (all)"] = max(worst.get(key + " (all)", 0.0), eall)
+            if evis > 1e-4 or eall > 2e-4:
+                at = int(d.argmax())
+                fails.append("%s %s err %.3g (visible %.3g) at ll %.2f (got %.2f)" % (
+                    key, ctx, eall, evis, want.ravel()[at], got.ravel()[at]))
+                if verbose:
+                    print("FAIL", fails[-1])
+    worst["refused"] = refused
+    return worst, fails
+
+
+if __name__ == "__main__":
+    worst, fails = run(int(sys.argv[1]) if len(sys.argv) > 1 else 1,
+                       int(sys.argv[2]) if len(sys.argv) > 2 else 40, verbose=True)
+    for k, v in worst.items():
+        print("%-28s %s" % (k, ("%.3g" % v) if isinstance(v, float) else v))
+    print("failures: %d" % len(fails))
+    sys.exit(1 if fails else 0)
