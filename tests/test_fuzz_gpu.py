@@ -48,3 +48,13 @@ def test_full_covariance_sweep(capi, oracle, seed, n):
     worst, fails = _load("fuzz_fullcov").run(seed, n)
     assert not fails, "\n".join(fails)
     assert worst["refused"] <= 1 and worst["full prec=0"] <= 1e-4 and worst["full prec=3"] <= 1e-4
+
+
+@pytest.mark.parametrize("seed,n", [(1, 30), (19, 40)])
+def test_recipe_driver_sweep(capi, oracle, seed, n):
+    """tools/fuzz_recipe.py: random recipes (segment times that stay in force, -B / -I slices, tiny files, 2- / 4-byte,
+    -N, clustered models) through aasr_run_recipe against the oracle's phone_probs restatement, and every file
+    against the same utterance run alone."""
+    worst, fails = _load("fuzz_recipe").run(seed, n)
+    assert not fails, "\n".join(fails)
+    assert worst["files"] >= n and worst["code"] <= 1 and worst["lp"] <= 1e-4
