@@ -1,4 +1,4 @@
-"""Fixed-seed slices of the randomised parity sweeps (tools/fuzz_parity.py, tools/fuzz_features.py, tools/fuzz_fullcov.py)
+"""Fixed-seed slices of the randomised parity sweeps (tools/fuzz_parity.py, fuzz_features.py, fuzz_fullcov.py, fuzz_recipe.py, fuzz_speakers.py)
 as part of the suite, so that a discrepancy found by a sweep can never sit in a scratch log:
 every random model / feature graph of these seeds must agree with the oracle -- scores within
 1e-4 wherever the reference's float storage can hold the likelihood (2e-4 below its flush
@@ -58,3 +58,12 @@ def test_recipe_driver_sweep(capi, oracle, seed, n):
     worst, fails = _load("fuzz_recipe").run(seed, n)
     assert not fails, "\n".join(fails)
     assert worst["files"] >= n and worst["code"] <= 1 and worst["lp"] <= 1e-4
+
+
+@pytest.mark.parametrize("seed,n", [(1, 12)])
+def test_speaker_configuration_sweep(capi, oracle, seed, n):
+    """tools/fuzz_speakers.py: random .spkc files (VTLN, normalisation, feature transform, model-side CMLLR as a
+    global transform or per mixture / Gaussian groups, utterance entries, defaults) through phone_probs -S."""
+    worst, fails = _load("fuzz_speakers").run(seed, n)
+    assert not fails, "\n".join(fails)
+    assert worst["files"] >= n and worst["visible"] > 10000 and worst["ll"] <= 1e-4
