@@ -155,6 +155,71 @@ static int dist_mode(const char *cfg, const char *base, const char *audio, const
   return 0;
 }
 
+// random [seed steps block]: the per-frame API driven out of order -- frames forwards, backwards and far apart,
+// before 0 and past the end, the eager style (precompute_likelihoods, every state) and the lazy one
+// (reset_cache, a few states), a module tap in between -- with a small adapter block so that almost every
+// call lands on a block edge.  One text line per value; tests compare them with the batch entry points.
+static int random_mode(const char *cfg, const char *base, const char *audio, const char *out_path, unsigned seed,
+                       int steps, int block) {
+  aku::FeatureGenerator gen;
+  aku::HmmSet model;
+  FILE *cf = fopen(cfg, "r");
+  if (!cf) throw std::string("could not open config");
+  gen.load_configuration(cf);
+  fclose(cf);
+  model.read_all(base);
+  gen.set_block_frames(block);
+  gen.open(audio);
+  FILE *out = fopen(out_path, "w");
+  if (!out) throw std::string("could not open output");
+  unsigned long long x = seed * 2654435761ull + 12345;
+  auto rnd = [&](int n) {
+    x = x * 6364136223846793005ull + 1442695040888963407ull;
+    return (int)((x >> 33) % (unsigned long long)n);
+  };
+  const int S = model.num_states();
+  int f = 0, last = 400;
+  for (int i = 0; i < steps; i++) {
+    switch (rnd(6)) {
+      case 0: f += 1; break;
+      case 1: f -= 1 + rnd(3); break;
+      case 2: f = rnd(last + 12) - 6; break;
+      case 3: f += block - 1 + rnd(3); break;
+      case 4: f = last - rnd(8) + 3; break;
+      default: break;  // the same frame again
+    }
+    if (f < -8) f = -8;
+    const aku::FeatureVec fea = gen.generate(f);
+    const bool eof = gen.eof();
+    fprintf(out, "F %d %d", f, eof ? 1 : 0);
+    for (int d = 0; d < fea.dim(); d++) fprintf(out, " %a", fea[d]);
+    fprintf(out, "\n");
+    if (eof && f < last) last = f;
+    const int style = rnd(3);
+    if (style == 0) {
+      model.reset_cache();
+      model.precompute_likelihoods(fea);
+      fprintf(out, "E %d", f);
+      for (int s = 0; s < S; s++) fprintf(out, " %a", model.state_likelihood(s, fea));
+      fprintf(out, "\n");
+    } else if (style == 1) {
+      model.reset_cache();
+      for (int k = 0; k < 3; k++) {
+        const int s = rnd(S);
+        fprintf(out, "L %d %d %a\n", f, s, model.state_likelihood(s, fea));
+      }
+    } else {
+      const aku::FeatureVec tap = gen.module("mfcc")->at(f);
+      fprintf(out, "T %d", f);
+      for (int d = 0; d < tap.dim(); d++) fprintf(out, " %a", tap[d]);
+      fprintf(out, "\n");
+    }
+  }
+  fclose(out);
+  gen.close();
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc == 5 && std::string(argv[1]) == "setters") {
     // aku_adapter_check setters CFG AUDIO OUT: the module classes the estimation tools reach through
@@ -240,6 +305,14 @@ int main(int argc, char **argv) {
     fclose(out);
     gen.close();
     return 0;
+  }
+  if (argc == 9 && std::string(argv[1]) == "random") {
+    try {
+      return random_mode(argv[2], argv[3], argv[4], argv[5], (unsigned)atoi(argv[6]), atoi(argv[7]), atoi(argv[8]));
+    } catch (std::string &e) {
+      fprintf(stderr, "exception: %s\n", e.c_str());
+      return 1;
+    }
   }
   if (argc == 6 && std::string(argv[1]) == "dist") {
     try {

@@ -1,6 +1,7 @@
 """The aku-shaped C++ surface on the GPU: the reference tool's command line
 (phone_probs) and the reference's own per-frame calling sequence written
 against aku::FeatureGenerator / aku::HmmSet adapters."""
+import math
 import os
 import subprocess
 import wave
@@ -444,3 +445,43 @@ def test_stream_input_is_consumed_incrementally(capi, world, tmp_path):
     got = np.fromfile(out, np.float64).reshape(total, ft.dim)
     want = ft.run(pcm, 0, total, dtype=np.float64)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("seed,block", [(1, 7), (2, 64), (3, 1), (4, 2048)])
+def test_per_frame_api_in_random_order(capi, world, seed, block):
+    """The adapters' per-frame surface driven out of order (aku_adapter_check random): frames forwards,
+    backwards, far apart, before 0 and past the end of the file; eager and lazy likelihood calls; a module
+    tap in between -- with adapter blocks of 1 / 7 / 64 / 2048 frames.  Every value equals the batch entry
+    points' (features bit for bit; likelihood = exp of the batch log-likelihood as the adapter returns it)."""
+    out = str(world["dir"] / ("random_%d.txt" % seed))
+    wav = str(world["dir"] / "a2.wav")                     # 30 000 samples: 233 frames
+    r = subprocess.run([os.path.join(BIN, "aku_adapter_check"), "random", world["cfg"], world["base"], wav, out,
+                        str(seed), "600", str(block)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    pcm = world["pcms"][2]
+    ft, gm = world["ft"], world["gm"]
+    eof = ft.eof_frame(len(pcm))
+    rows = [line.split() for line in open(out)]
+    lo, hi = min(int(t[1]) for t in rows), max(int(t[1]) for t in rows) + 1
+    assert hi > eof + 2
+    fea = ft.run(pcm, lo, hi - lo, dtype=np.float64)
+    tap = ft.run(pcm, lo, hi - lo, module="mfcc", dtype=np.float64)
+    ll = gm.score(fea.astype(np.float32))
+    seen = {"F": 0, "E": 0, "L": 0, "T": 0}
+    for t in rows:
+        seen[t[0]] += 1
+        f = int(t[1])
+        if t[0] == "F":
+            assert int(t[2]) == (1 if f >= eof else 0), t[:3]
+            got = np.array([float.fromhex(x) for x in t[3:]])
+            assert np.array_equal(got, fea[f - lo]), (f, np.abs(got - fea[f - lo]).max())
+        elif t[0] == "T":
+            got = np.array([float.fromhex(x) for x in t[2:]])
+            assert np.array_equal(got, tap[f - lo]), f
+        elif t[0] == "E":
+            got = np.array([float.fromhex(x) for x in t[2:]])
+            assert np.array_equal(got, np.array([math.exp(float(v)) for v in ll[f - lo]])), f   # libm's exp, as std::exp
+        else:
+            s = int(t[2])
+            assert float.fromhex(t[3]) == math.exp(float(ll[f - lo, s])), (f, s)
+    assert seen["F"] == 600 and min(seen.values()) > 100
