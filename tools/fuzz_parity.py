@@ -23,7 +23,7 @@ TOL, TOL_FLOOR = 1e-4, 2e-4
 LOG_TINY = float(np.log(1e-50))
 
 
-def run(seed=1, N=40, verbose=False):
+def run(seed=1, N=40, verbose=False, big=False):
     from aaltoasr_amd import capi
     from oracle import oracle as O
     O.build()
@@ -69,6 +69,10 @@ def run(seed=1, N=40, verbose=False):
         S = int(rng.integers(1, 70))
         lo = int(rng.integers(0, 3))
         hi = int(rng.integers(max(1, lo), 30))
+        if big:   # production-sized state inventories (many tiles, several row cuts per launch)
+            D = int(rng.choice([13, 24, 39, 39, 39, 47]))
+            S = int(rng.integers(300, 3600))
+            hi = int(rng.integers(max(1, lo), 48))
         tied = bool(rng.integers(0, 2))
         n = rng.integers(lo, hi + 1, S)
         if n.sum() == 0:
@@ -88,6 +92,8 @@ def run(seed=1, N=40, verbose=False):
         if rng.integers(0, 3) == 0 and K > 2:
             w[rng.integers(0, K)] = 0.0                       # a zero weight
         F = int(rng.integers(1, 400))
+        if big:
+            F = int(rng.integers(1, 4)) * 256 + int(rng.integers(0, 256))
         frames = (rng.standard_normal((F, D)) * rng.uniform(0.5, 2.5)).astype(np.float32)
         om = O.DiagModel(mean, var, off, idx, w)
         want = om.score(frames.astype(np.float64))
@@ -205,7 +211,8 @@ def run(seed=1, N=40, verbose=False):
 
 if __name__ == "__main__":
     worst, fails = run(int(sys.argv[1]) if len(sys.argv) > 1 else 1,
-                       int(sys.argv[2]) if len(sys.argv) > 2 else 40, verbose=True)
+                       int(sys.argv[2]) if len(sys.argv) > 2 else 40, verbose=True,
+                       big=len(sys.argv) > 3 and sys.argv[3] == "big")
     for k in sorted(worst):
         print("%-40s worst |err| %.3g" % (k, worst[k]))
     print("failures:", len(fails))
