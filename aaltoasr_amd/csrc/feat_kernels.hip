@@ -116,9 +116,18 @@ __global__ void k_pre_frames(DevBatch b, const float *__restrict__ in, int dim, 
   dst[idx] = (double)in[b.pcm_off[u] / 2 + (int64_t)frame * dim + j];
 }
 
+// floor(e / d) for 0 <= e < 65536 and 1 <= d < 65536 without the ~25-instruction integer division:
+// magic = floor(2^32 / d) + 1 (fast_magic), one v_mul_hi_u32; d = 1 has no 32-bit magic and is passed through
+__host__ __device__ __forceinline__ unsigned fast_magic(int d) { return d > 1 ? 0xFFFFFFFFu / (unsigned)d + 1u : 0u; }
+__device__ __forceinline__ int fast_div(int e, unsigned magic) {
+  return magic ? (int)__umulhi((unsigned)e, magic) : e;
+}
+
 struct FftPrm {
   int nc, ns;
   int radix[16], sublen[16];
+  unsigned sub_magic[16];  // fast_magic(sublen[s])
+  int fstride[16];         // nc / (radix[s] * sublen[s])
   const float *hamming, *twiddle, *stwiddle;
   const int32_t *perm;
   int magnitude, take_log;
@@ -134,9 +143,9 @@ __device__ __forceinline__ cpx cmul(cpx a, cpx b) {
 
 // One butterfly of KissFFT's decimation-in-time stage (vendor/kiss_fft/kiss_fft.c:21-198, radices 2,
 // 3, 4, 5): butterfly index bi of the stage with radix pr and sub-length m, in place in buf.
-__device__ __forceinline__ void kiss_butterfly(cpx *buf, int bi, int pr, int m, int fstride,
+__device__ __forceinline__ void kiss_butterfly(cpx *buf, int bi, int pr, int m, unsigned m_magic, int fstride,
                                                const cpx *__restrict__ tw) {
-    int g = bi / m, j = bi - g * m;
+    int g = fast_div(bi, m_magic), j = bi - g * m;
     cpx *F = buf + g * pr * m;
     if (pr == 2) {
       cpx t = cmul(F[m + j], tw[j * fstride]);
@@ -360,12 +369,12 @@ __global__ __launch_bounds__(256) void k_fft(DevBatch b, const int16_t *__restri
   const cpx *tw = (const cpx *)fp.twiddle;
   for (int s = fp.ns - 1; s >= 0; s--) {
     const int pr = fp.radix[s], m = fp.sublen[s];
-    const int fstride = nc / (pr * m);
-    const int nb = nc / pr;
+    const int fstride = fp.fstride[s];
+    const int nb = fstride * m;  // nc / pr
     if (GEN && pr > 5) {
       for (int bi = lane; bi < nb; bi += 64) kiss_butterfly_generic(buf, bi, pr, m, fstride, tw);
     } else {
-      for (int bi = lane; bi < nb; bi += 64) kiss_butterfly(buf, bi, pr, m, fstride, tw);
+      for (int bi = lane; bi < nb; bi += 64) kiss_butterfly(buf, bi, pr, m, fp.sub_magic[s], fstride, tw);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -554,9 +563,9 @@ __global__ __launch_bounds__(256) void k_spectral_fused(DevBatch b, const int16_
     __builtin_amdgcn_wave_barrier();
     for (int st = AASR_FDBG(2) ? -1 : sp.fp.ns - 1; st >= 0; st--) {
       const int pr = sp.fp.radix[st], m = sp.fp.sublen[st];
-      const int fstride = nc / (pr * m);
-      const int nb = nc / pr;
-      for (int bi = l; bi < nb; bi += TPF) kiss_butterfly(buf, bi, pr, m, fstride, t_tw);
+      const int fstride = sp.fp.fstride[st];
+      const int nb = fstride * m;  // nc / pr
+      for (int bi = l; bi < nb; bi += TPF) kiss_butterfly(buf, bi, pr, m, sp.fp.sub_magic[st], fstride, t_tw);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
@@ -671,6 +680,7 @@ __global__ __launch_bounds__(256) void k_temporal_fused(DevBatch b, const double
                                                         TemporalPrm tp, double *__restrict__ dst) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int dx = tp.dx, H = tp.w1 + tp.w2, md = 3 * tp.dx;
+  const unsigned dx_magic = fast_magic(dx), md_magic = fast_magic(md), dim_magic = fast_magic(tp.dim);
   double *xs = (double *)smem_raw;                              // [ROWS + 2H][dx]
   double *d1 = xs + (size_t)(ROWS + 2 * H) * dx;                // [ROWS + 2 w2][dx]
   double *nrm = d1 + (size_t)(ROWS + 2 * tp.w2) * dx;           // [ROWS][md]
@@ -692,7 +702,7 @@ __global__ __launch_bounds__(256) void k_temporal_fused(DevBatch b, const double
     __syncthreads();
     // DeltaModule::generate (aku/FeatureModules.cc:1018-1037) on the source rows
     for (int e = threadIdx.x; e < n_d1 * dx; e += 256) {
-      const int j = e / dx, i = e - j * dx;
+      const int j = fast_div(e, dx_magic), i = e - j * dx;
       const int c = j + tp.w1;
       double acc = 0;
       for (int k = 1; k <= tp.w1; k++) {
@@ -705,8 +715,8 @@ __global__ __launch_bounds__(256) void k_temporal_fused(DevBatch b, const double
     __syncthreads();
     // second difference, merge (source, delta, delta-delta) and NormalizationModule::generate (:1135-1142)
     for (int e = threadIdx.x; e < n_seg * md; e += 256) {
-      const int lr = e / md, col = e - lr * md;
-      const int part = col / dx, i = col - part * dx;
+      const int lr = fast_div(e, md_magic), col = e - lr * md;
+      const int part = fast_div(col, dx_magic), i = col - part * dx;
       double v;
       if (part == 0) {
         v = xs[(size_t)(lr + H) * dx + i];
@@ -727,7 +737,7 @@ __global__ __launch_bounds__(256) void k_temporal_fused(DevBatch b, const double
     __syncthreads();
     // LinTransformModule::generate (:1243-1269)
     for (int e = threadIdx.x; e < n_seg * tp.dim; e += 256) {
-      const int lr = e / tp.dim, i = e - lr * tp.dim;
+      const int lr = fast_div(e, dim_magic), i = e - lr * tp.dim;
       const double *x = nrm + (size_t)lr * md;
       double acc;
       if (tp.matrix) {
@@ -921,6 +931,7 @@ __global__ __launch_bounds__(256) void k_mean_subtract_tiled(
   // value does not depend on how the frame range was tiled or batched; the additions are grouped
   // differently from the frame-order loop (1e-16 relative).
   double *bs = xs + (size_t)(ROWS + left + right) * dim;  // [(ROWS + left + right) / 8 + 1][dim]
+  const unsigned dim_magic = fast_magic(dim);              // element indices stay below 65536 (LDS-sized tiles)
   const int64_t tile0 = (int64_t)blockIdx.x * ROWS;
   const int64_t tile1 = tile0 + ROWS < rows ? tile0 + ROWS : rows;
   // A tile may straddle utterances: source rows of consecutive module rows are
@@ -943,7 +954,7 @@ __global__ __launch_bounds__(256) void k_mean_subtract_tiled(
     const int i0 = (int)(((-abs0) % 8 + 8) % 8);
     const int n_blk = n_src > i0 ? (n_src - i0) / 8 : 0;
     for (int e = threadIdx.x; e < n_blk * dim; e += 256) {
-      const int k = e / dim, d = e - k * dim;
+      const int k = fast_div(e, dim_magic), d = e - k * dim;
       const double *c = xs + (size_t)(i0 + 8 * k) * dim + d;
       double t = 0;
 #pragma unroll
@@ -952,7 +963,7 @@ __global__ __launch_bounds__(256) void k_mean_subtract_tiled(
     }
     __syncthreads();
     for (int e = threadIdx.x; e < n_seg * dim; e += 256) {
-      const int lr = e / dim, d = e - lr * dim;
+      const int lr = fast_div(e, dim_magic), d = e - lr * dim;
       // staged rows [lr, lr + left + right] are this value's window
       const int a = lr, b_end = lr + left + right + 1;
       int ka = a <= i0 ? 0 : (a - i0 + 7) / 8;      // whole blocks [ka, kb): staged rows i0 + 8k ...
@@ -1251,6 +1262,8 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
       for (int k = 0; k < 16; k++) {
         sp.fp.radix[k] = F.fft.radix[k];
         sp.fp.sublen[k] = F.fft.sublen[k];
+        sp.fp.sub_magic[k] = fast_magic(F.fft.sublen[k]);
+        sp.fp.fstride[k] = k < F.fft.ns ? F.fft.nc / (F.fft.radix[k] * F.fft.sublen[k]) : 0;
       }
       sp.fp.hamming = F.fft.hamming.p;
       sp.fp.twiddle = F.fft.twiddle.p;
@@ -1332,6 +1345,8 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
         for (int k = 0; k < 16; k++) {
           fp.radix[k] = m.fft.radix[k];
           fp.sublen[k] = m.fft.sublen[k];
+          fp.sub_magic[k] = fast_magic(m.fft.sublen[k]);
+          fp.fstride[k] = k < m.fft.ns ? m.fft.nc / (m.fft.radix[k] * m.fft.sublen[k]) : 0;
         }
         fp.hamming = m.fft.hamming.p;
         fp.twiddle = m.fft.twiddle.p;

@@ -512,9 +512,13 @@ __global__ __launch_bounds__(kMergeThreads) void k_cluster_merge(
   for (int64_t fg = f_begin; fg < f_end; fg += kMergeFrames) {
     const int nf = (int)min((int64_t)kMergeFrames, f_end - fg);
     __syncthreads();
-    for (int i = tid; i < kMergeFrames * C; i += kMergeThreads) {
-      const int k = i / C, c = i - k * C;
-      cv[c * cstride + k] = k < nf ? cval[(fg + k) * C + c] : 0.0f;
+    // frame-major so that no thread divides by C: the kMergeFrames loads of a cluster are independent
+    for (int c = tid; c < C; c += kMergeThreads) {
+      float v[kMergeFrames];
+#pragma unroll
+      for (int k = 0; k < kMergeFrames; k++) v[k] = k < nf ? cval[(fg + k) * C + c] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < kMergeFrames; k++) cv[c * cstride + k] = v[k];
     }
     float ocur[kMergeSPT][kMergeFrames];
 #pragma unroll
