@@ -157,14 +157,62 @@ __global__ __launch_bounds__(kCentreThreads) void k_cluster_centres(
 }
 
 // ----------------------------------------------------------------- select --
+// Wave-wide reductions and the bucket scan on the DPP data path (row shifts / mirrors / broadcasts
+// inside the VALU) instead of ds_bpermute: a __shfl_xor reduction of a double is 12 dependent LDS-crossbar
+// round trips, and the selection loop is a chain of three such reductions per level and frame.
+//   0xB1 / 0x4E quad_perm [1,0,3,2] / [2,3,0,1], 0x141 row_half_mirror, 0x140 row_mirror: after the four
+//   steps every lane holds its 16-lane row's result; 0x142 row_bcast:15 (rows 1, 3) and 0x143 row_bcast:31
+//   (rows 2, 3) carry it across rows, so lane 63 ends with the wave's; v_readlane broadcasts it.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+  const unsigned long long o = __builtin_bit_cast(unsigned long long, old), x = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)o, (int)(unsigned)x, CTRL, ROW_MASK, 0xF, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(o >> 32), (int)(unsigned)(x >> 32), CTRL, ROW_MASK, 0xF, false);
+  return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
+}
+__device__ __forceinline__ double readlane63_f64(double v) {
+  const unsigned long long x = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), 63);
+  return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
+}
 __device__ __forceinline__ double wave_min_f64(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
-  return v;
+  v = fmin(v, dpp_f64<0xB1, 0xF>(v, v));
+  v = fmin(v, dpp_f64<0x4E, 0xF>(v, v));
+  v = fmin(v, dpp_f64<0x141, 0xF>(v, v));
+  v = fmin(v, dpp_f64<0x140, 0xF>(v, v));
+  v = fmin(v, dpp_f64<0x142, 0xA>(v, v));
+  v = fmin(v, dpp_f64<0x143, 0xC>(v, v));
+  return readlane63_f64(v);
 }
 __device__ __forceinline__ double wave_max_f64(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  v = fmax(v, dpp_f64<0xB1, 0xF>(v, v));
+  v = fmax(v, dpp_f64<0x4E, 0xF>(v, v));
+  v = fmax(v, dpp_f64<0x141, 0xF>(v, v));
+  v = fmax(v, dpp_f64<0x140, 0xF>(v, v));
+  v = fmax(v, dpp_f64<0x142, 0xA>(v, v));
+  v = fmax(v, dpp_f64<0x143, 0xC>(v, v));
+  return readlane63_f64(v);
+}
+// wave-wide sum of an int (result in every lane)
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+// inclusive prefix sum over the lanes of an unsigned (Hillis-Steele inside the 16-lane rows with zero
+// fill: 0x111 / 0x112 / 0x114 / 0x118 = row_shr 1 / 2 / 4 / 8, then the row totals across rows)
+__device__ __forceinline__ unsigned wave_scan_u32(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
   return v;
 }
 
@@ -190,6 +238,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     sz[j] = c < C ? csize[c] : 0;
   }
   const int64_t word = blockIdx.x;
+  // the next frame's keys are requested while this frame is selected (a frame's loop is one long
+  // dependent chain: nothing else hides the load)
+  constexpr bool kPrefetch = KPL <= 16;  // 2 x KPL doubles: beyond 1024 clusters the registers are not there
+  double vn[kPrefetch ? KPL : 1];
+  if (kPrefetch) {
+#pragma unroll
+    for (int j = 0; j < KPL; j++) {
+      const int c = j * 64 + lane;
+      vn[j] = (c < C && word * 64 < F) ? ll64[word * 64 * Cs + c] : 0.0;
+    }
+  }
   for (int fi = 0; fi < 64; fi++) {
     const int64_t f = word * 64 + fi;
     if (f >= F) {  // wave-uniform
@@ -198,15 +257,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (lane == 0) bits[fi][j] = 0ull;
       continue;
     }
-    const double *row = ll64 + f * Cs;
     double v[KPL];
     unsigned long long cand = 0;
 #pragma unroll
     for (int j = 0; j < KPL; j++) {
       const int c = j * 64 + lane;
-      const double x = c < C ? row[c] : 0.0;  // ranking key (k_cluster_centres): the reference compares exp(ll)
+      // ranking key (k_cluster_centres): the reference compares exp(ll)
+      const double x = kPrefetch ? vn[kPrefetch ? j : 0] : (c < C ? ll64[f * Cs + c] : 0.0);
       v[j] = x;
       if (c < C && x == x) cand |= 1ull << j;
+    }
+    if (kPrefetch && fi + 1 < 64 && f + 1 < F) {
+      const double *row = ll64 + (f + 1) * Cs;
+#pragma unroll
+      for (int j = 0; j < KPL; j++) {
+        const int c = j * 64 + lane;
+        vn[kPrefetch ? j : 0] = c < C ? row[c] : 0.0;
+      }
     }
     int need_c = min_clusters, need_g = min_gaussians;
     double T = INFINITY;  // key >= T  <=>  members evaluated exactly
@@ -231,8 +298,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           int n_tied = 0;
 #pragma unroll
           for (int j = 0; j < KPL; j++) n_tied += (int)((cand >> j) & 1);
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) n_tied += __shfl_xor(n_tied, o);
+          n_tied = wave_sum_i32(n_tied);
           // every pop takes one cluster: with need_c >= n_tied the whole group goes whatever the
           // order; otherwise the queue's order among equals decides -> replay
           if (n_tied == 1 || need_c >= n_tied) T = lo;
@@ -252,12 +318,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const unsigned long long h = hist[lane];
-        unsigned long long cum = h;  // inclusive prefix over buckets 0..lane
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const unsigned long long t = __shfl_up(cum, o);
-          if (lane >= o) cum += t;
-        }
+        // inclusive prefix over buckets 0..lane; counts and sizes are separate 32-bit fields (no carry between them)
+        const unsigned long long cum =
+            ((unsigned long long)wave_scan_u32((unsigned)(h >> 32)) << 32) | wave_scan_u32((unsigned)h);
         const long long cumc = (long long)(cum >> 32), cumg = (long long)(cum & 0xffffffffull);
         const bool sat = (need_c - cumc <= 0) && (need_g - cumg <= 0);
         const unsigned long long ballot = __ballot(sat);
@@ -304,8 +367,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                                    : (use_exact ? 0.0f : exp2f((float)(v[j] * kLog2eD + ref)));
     }
     if (n_exact) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) exact += __shfl_xor(exact, o);
+      exact = wave_sum_i32(exact);
       if (lane == 0) n_exact[f] = exact;
     }
   }
