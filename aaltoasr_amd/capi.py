@@ -301,6 +301,7 @@ class Gmm:
     def score_f64(self, frames: np.ndarray) -> np.ndarray:
         """AASR_PREC_F64: double frames [F x D] -> double log state likelihoods [F x S]."""
         frames = np.ascontiguousarray(frames, np.float64)
+        self._check_frames(frames)
         out = np.empty((frames.shape[0], self.num_states), np.float64)
         check(lib().aasr_gmm_score_f64(self._h, _ptr(frames), frames.shape[0], _ptr(out)))
         return out
@@ -357,8 +358,14 @@ class Gmm:
         L.aasr_debug_active_layout.argtypes = [C.c_void_p]
         return L.aasr_debug_active_layout(self._h)
 
+    def _check_frames(self, frames) -> None:
+        # the C ABI takes a pointer and a frame count: the row width is the caller's promise
+        if frames.ndim != 2 or frames.shape[1] != self.dim:
+            raise ValueError("frames must be [F x %d], got %s" % (self.dim, tuple(frames.shape)))
+
     def score(self, frames: np.ndarray) -> np.ndarray:
         frames = np.ascontiguousarray(frames, np.float32)
+        self._check_frames(frames)
         out = np.empty((frames.shape[0], self.num_states), np.float32)
         check(lib().aasr_gmm_score(self._h, _ptr(frames), frames.shape[0], _ptr(out)))
         return out
@@ -386,6 +393,7 @@ class Gmm:
 
     def gauss_loglik(self, frames: np.ndarray) -> np.ndarray:
         frames = np.ascontiguousarray(frames, np.float32)
+        self._check_frames(frames)
         out = np.empty((frames.shape[0], self.num_gaussians), np.float32)
         check(lib().aasr_gmm_gauss_loglik(self._h, _ptr(frames), frames.shape[0], _ptr(out)))
         return out
