@@ -478,6 +478,13 @@ def main():
             if obs.get("sclk_mhz"):
                 adj = peak * obs["sclk_mhz"] / NOMINAL_SCLK_MHZ
                 roofline["frac_of_clock_adjusted_peak"] = round(achieved / adj, 4)
+        if args.precision != "f32":
+            probe = _pipe_probe()
+            if probe:
+                executed = achieved * 6.0 * 160.0 / 156.0
+                probe["executed_TFLOPs"] = round(executed, 1)
+                probe["frac_of_probe"] = round(executed / probe["TFLOPs_random_operands"], 4)
+                roofline["matrix_pipe_probe"] = probe
         td = _pmc_traffic(F, args.precision, aligned=(args.workload == "full" or args.out_pitch == "aligned"))
         if td:
             roofline["traffic"] = td["bytes"]
@@ -611,6 +618,26 @@ def _observe_clock(enqueue, torch):
         except Exception:
             pass
         return None
+
+
+def _pipe_probe():
+    """The matrix pipe's own rate under the board's power cap, measured by tools/mfma_peak (back-to-back
+    v_mfma_f32_32x32x16_bf16 on register operands, no memory traffic) and committed as
+    profiles/r2_mfma_peak_probe.txt: all-zero operands reach the datasheet rate, operands with random mantissas
+    and exponents -- what a three-term split feeds the pipe -- do not.  A recorded figure, not measured in this run."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_mfma_peak_probe.txt")
+    try:
+        rates = {}
+        for line in open(path):
+            for key, tag in (("all-zero operands", "zeros"), ("random mantissas and exponents", "random")):
+                if line.startswith(key) and tag not in rates:
+                    rates[tag] = float(line[len(key):].split()[0])
+        if "random" in rates and "zeros" in rates:
+            return {"TFLOPs_zero_operands": rates["zeros"], "TFLOPs_random_operands": rates["random"],
+                    "source": "profiles/r2_mfma_peak_probe.txt (tools/mfma_peak/run.sh), recorded on one box"}
+    except OSError:
+        pass
+    return None
 
 
 def _pmc_traffic(frames, precision="f32", aligned=False):
