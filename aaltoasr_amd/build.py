@@ -98,6 +98,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError("building %s failed:\n%s\n%s" % (name, r.stdout, r.stderr))
+    # the stand-alone matrix-pipe probe (tools/mfma_peak): a measuring instrument for bench.py, no part of the library
+    probe_src = os.path.join(os.path.dirname(HERE), "tools", "mfma_peak", "mfma_peak.hip")
+    probe = os.path.join(bindir, "mfma_peak")
+    if os.path.exists(probe_src) and (force or not os.path.exists(probe) or os.path.getmtime(probe) < os.path.getmtime(probe_src)):
+        r = subprocess.run([HIPCC, f"--offload-arch={ARCH}", "-O3", "-o", probe, probe_src], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("building mfma_peak failed:\n%s\n%s" % (r.stdout, r.stderr))
     if verbose:
         print("built", LIB)
     return LIB

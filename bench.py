@@ -479,11 +479,11 @@ def main():
                 adj = peak * obs["sclk_mhz"] / NOMINAL_SCLK_MHZ
                 roofline["frac_of_clock_adjusted_peak"] = round(achieved / adj, 4)
         if args.precision != "f32":
-            probe = _pipe_probe()
+            probe = _pipe_probe(run=(rank == 0 and world == 1))
             if probe:
                 executed = achieved * 6.0 * 160.0 / 156.0
                 probe["executed_TFLOPs"] = round(executed, 1)
-                probe["frac_of_probe"] = round(executed / probe["TFLOPs_random_operands"], 4)
+                probe["frac_of_probe"] = round(executed / probe["TFLOPs_" + probe["reference"]], 4)
                 roofline["matrix_pipe_probe"] = probe
         td = _pmc_traffic(F, args.precision, aligned=(args.workload == "full" or args.out_pitch == "aligned"))
         if td:
@@ -620,24 +620,41 @@ def _observe_clock(enqueue, torch):
         return None
 
 
-def _pipe_probe():
-    """The matrix pipe's own rate under the board's power cap, measured by tools/mfma_peak (back-to-back
-    v_mfma_f32_32x32x16_bf16 on register operands, no memory traffic) and committed as
-    profiles/r2_mfma_peak_probe.txt: all-zero operands reach the datasheet rate, operands with random mantissas
-    and exponents -- what a three-term split feeds the pipe -- do not.  A recorded figure, not measured in this run."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_mfma_peak_probe.txt")
-    try:
-        rates = {}
-        for line in open(path):
-            for key, tag in (("all-zero operands", "zeros"), ("random mantissas and exponents", "random")):
-                if line.startswith(key) and tag not in rates:
-                    rates[tag] = float(line[len(key):].split()[0])
-        if "random" in rates and "zeros" in rates:
-            return {"TFLOPs_zero_operands": rates["zeros"], "TFLOPs_random_operands": rates["random"],
-                    "source": "profiles/r2_mfma_peak_probe.txt (tools/mfma_peak/run.sh), recorded on one box"}
-    except OSError:
-        pass
-    return None
+def _pipe_probe(run=True):
+    """The matrix pipe's own rate under the board's power cap: tools/mfma_peak (back-to-back
+    v_mfma_f32_32x32x16_bf16 on register operands, no memory traffic; built by build() as
+    aaltoasr_amd/lib/bin/mfma_peak) run on THIS box right after the timed region -- all-zero operands reach the
+    datasheet rate, operands shaped like the three terms of a split do not, and the boxes of a pool differ by a few
+    per cent.  Falls back to the figures recorded in profiles/r2_mfma_peak_probe.txt."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    text, source = None, None
+    exe = os.path.join(here, "aaltoasr_amd", "lib", "bin", "mfma_peak")
+    if run and os.access(exe, os.X_OK):
+        try:
+            r = subprocess.run([exe, "40"], capture_output=True, text=True, timeout=120,
+                               env=dict(os.environ, MFMA_PEAK_CLASSES="1"))
+            if r.returncode == 0:
+                text, source = r.stdout, "tools/mfma_peak run on this box after the timed region (40 ms launches)"
+        except (OSError, subprocess.SubprocessError):
+            pass
+    if text is None:
+        try:
+            text = open(os.path.join(here, "profiles", "r2_mfma_peak_probe.txt")).read()
+            source = "profiles/r2_mfma_peak_probe.txt (recorded on another box)"
+        except OSError:
+            return None
+    rates = {}
+    for line in text.splitlines():
+        for key, tag in (("all-zero operands", "zeros"), ("random mantissas and exponents", "random"),
+                         ("split-term classes, mixed order", "split_terms")):
+            if line.startswith(key) and tag not in rates:
+                rates[tag] = float(line[len(key):].split()[0])
+    if "zeros" not in rates or ("split_terms" not in rates and "random" not in rates):
+        return None
+    out = {"TFLOPs_zero_operands": rates["zeros"], "TFLOPs_random_operands": rates.get("random"),
+           "TFLOPs_split_term_operands": rates.get("split_terms"), "source": source}
+    out["reference"] = "split_term_operands" if "split_terms" in rates else "random_operands"
+    return out
 
 
 def _pmc_traffic(frames, precision="f32", aligned=False):
