@@ -12,7 +12,9 @@ compiler on stdin, so that `#include "FeatureGenerator.hh"` and friends resolve 
   Lattice.cc, PhnReader.cc with their own headers) on the engine's likelihoods -- finds the
   segmentation a plain dynamic programme over the oracle's state likelihoods finds;
   oracle/_ref/vtln_refmain -- the reference's VTLN warp-factor estimation (aku/vtln.cc) -- finds the
-  warp factors the data were made with and writes them as a speaker file."""
+  warp factors the data were made with and writes them as a speaker file;
+  oracle/_ref/logl_refmain (aku/logl.cc with PhnReader and HmmNetBaumWelch), segfea_refmain, quanteq_refmain and
+  feadot_refmain -- the remaining feature / likelihood clients -- likewise, as-written quirks included."""
 import os
 import subprocess
 import wave
