@@ -67,3 +67,10 @@ def test_speaker_configuration_sweep(capi, oracle, seed, n):
     worst, fails = _load("fuzz_speakers").run(seed, n)
     assert not fails, "\n".join(fails)
     assert worst["files"] >= n and worst["visible"] > 10000 and worst["ll"] <= 1e-4
+
+
+def test_subspace_pool_sweep(capi, oracle):
+    """tools/fuzz_subspace.py: random PCGMM / SCGMM / mixed 'variable' pools (parity unpinned, as tests/test_subspace_gpu.py)."""
+    worst, fails = _load("fuzz_subspace").run(2, 30)
+    assert not fails, "\n".join(fails)
+    assert max(worst["pcgmm"], worst["scgmm"], worst["mixed"]) <= 1e-4
