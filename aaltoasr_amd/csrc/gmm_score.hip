@@ -359,7 +359,11 @@ struct ClusterArgs {
 // exponent otherwise
 __device__ __forceinline__ float mask_select(float x, unsigned long long bits, int idx) {
   const unsigned half = idx < 32 ? (unsigned)bits : (unsigned)(bits >> 32);
-  return (half & (1u << (idx & 31))) ? x : NEG_BIG_F;
+  // two instructions per value: the bit sign-extended to a lane mask (v_bfe_i32), then a bitfield
+  // insert picks x or the constant (v_bfi_b32) -- and / compare / select is three
+  const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)half, idx & 31, 1);
+  const unsigned r = (__builtin_bit_cast(unsigned, x) & m) | (__builtin_bit_cast(unsigned, NEG_BIG_F) & ~m);
+  return __builtin_bit_cast(float, r);
 }
 
 template <int NKK, bool GROUPED>
