@@ -239,6 +239,11 @@ struct aasr_gmm {
   aasr::DevBuf<double> f64_recs, f64_x, f64_out, f64_A, f64_b, f64_xframes;
   double f64_det = 1.0;          // |prod diag A| of a global transform
   aasr::DevBuf<int32_t> f64_state_off;
+  // per-class model transforms under AASR_PREC_F64: class of every record (0 = unadapted), the classes' [A | b] and
+  // |prod diag A|, the frames of every class as [class][dim][frame]
+  int f64_classes = 0;
+  aasr::DevBuf<int32_t> f64_rec_class;
+  aasr::DevBuf<double> f64_class_A, f64_class_b, f64_class_det, f64_class_x;
   // the pool's Gaussians as single-record states (per-Gaussian view of ill-conditioned models)
   bool pool_centred_built = false;
   aasr::DevBuf<float> poolc_recs;

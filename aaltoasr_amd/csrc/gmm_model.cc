@@ -1464,6 +1464,31 @@ void gmm_build_f64(aasr_gmm *g) {
     g->f64_b.upload(b.data(), b.size());
     g->f64_det = std::fabs(det);
   }
+  g->f64_classes = 0;
+  if (m.n_transforms > 0 && !m.global_xform()) {
+    // regression classes: class c = transform c - 1 (class 0: Gaussians without one); per class
+    // W = [b | A] and |prod diag A| as above, per record the class of its Gaussian
+    const int nc = m.n_transforms + 1;
+    std::vector<double> A((size_t)nc * D * D, 0.0), b((size_t)nc * D, 0.0), det((size_t)nc, 1.0);
+    for (int i = 0; i < D; i++) A[(size_t)i * D + i] = 1.0;  // class 0: identity
+    for (int t = 0; t < m.n_transforms; t++) {
+      const double *W = &m.xform[(size_t)t * D * (D + 1)];
+      double dt = 1;
+      for (int i = 0; i < D; i++) {
+        b[(size_t)(t + 1) * D + i] = W[(size_t)i * (D + 1)];
+        for (int j = 0; j < D; j++) A[((size_t)(t + 1) * D + i) * D + j] = W[(size_t)i * (D + 1) + 1 + j];
+        dt *= W[(size_t)i * (D + 1) + 1 + i];
+      }
+      det[(size_t)t + 1] = std::fabs(dt);
+    }
+    std::vector<int32_t> rc(std::max<size_t>(K, 1), 0);
+    for (size_t k = 0; k < K; k++) rc[k] = m.g2t[(size_t)m.mix_idx[k]] + 1;
+    g->f64_class_A.upload(A.data(), A.size());
+    g->f64_class_b.upload(b.data(), b.size());
+    g->f64_class_det.upload(det.data(), det.size());
+    g->f64_rec_class.upload(rc.data(), rc.size());
+    g->f64_classes = nc;
+  }
   g->f64_dimp = dimp;
   g->f64_built = true;
 }

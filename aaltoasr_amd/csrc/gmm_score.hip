@@ -1586,12 +1586,104 @@ __global__ void k_affine_frames_f64(const double *__restrict__ x, int64_t F, int
   y[idx] = acc;
 }
 
+// Per-class model transforms under AASR_PREC_F64 (regression classes: ConstrainedMllr, aku/ModelModules.cc:164-232).
+// Every component is an AdaptedGaussian of its class: g(A_c f + b_c) |det_c|, summed in COMPONENT order as
+// Mixture::compute_likelihood does -- so the frames of every class are laid out [class][dimension][frame] and a
+// record reads its class's values straight from there (coalesced over the lanes, one load per dimension and record):
+// a verification mode, an order of magnitude slower than the single-transform kernel.
+__global__ void k_affine_frames_f64_classes(const double *__restrict__ x, int64_t F, int dim, int classes,
+                                            const double *__restrict__ A, const double *__restrict__ b,
+                                            double *__restrict__ y) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (class, i, f), f fastest
+  if (idx >= (int64_t)classes * dim * F) return;
+  const int64_t f = idx % F;
+  const int64_t ci = idx / F;
+  const int i = (int)(ci % dim), c = (int)(ci / dim);
+  if (c == 0) {
+    y[idx] = x[f * dim + i];
+    return;
+  }
+  // o = b + A f in the reference's order (AdaptedFeatureVector::calculate_new_ada_vector, aku/ModelModules.hh:208-212)
+  const double *Ac = A + ((size_t)c * dim + i) * dim;
+  double acc = b[(size_t)c * dim + i];
+  for (int j = 0; j < dim; j++) acc += Ac[j] * x[f * dim + j];
+  y[idx] = acc;
+}
+
+template <int DIMP>
+__global__ __launch_bounds__(256) void k_gmm_diag_score_f64_classes(
+    const double *__restrict__ xc, int64_t F, int dim, const double *__restrict__ recs,
+    const int32_t *__restrict__ rec_class, const double *__restrict__ class_det,
+    const int32_t *__restrict__ state_off, int64_t S, double *__restrict__ out, int linear) {
+  constexpr int REC = 2 * DIMP + 2;
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t fc = f < F ? f : F - 1;
+  const int64_t s_per = (S + gridDim.y - 1) / gridDim.y;
+  const int64_t s_begin = (int64_t)blockIdx.y * s_per, s_end = min(S, s_begin + s_per);
+  for (int64_t s = s_begin; s < s_end; s++) {
+    const int r0 = state_off[s], r1 = state_off[s + 1];
+    double l = 0;
+    for (int r = r0; r < r1; r++) {
+      const double *rec = recs + (size_t)r * REC;
+      const int c = rec_class[r];
+      const double *x = xc + (size_t)c * dim * F + fc;
+      double ll = 0;
+      for (int d = 0; d < dim; d++) {
+        const double t = x[(size_t)d * F] - rec[d];
+        ll += t * t * rec[DIMP + d];
+      }
+      ll *= -0.5;
+      ll += rec[2 * DIMP];
+      l += rec[2 * DIMP + 1] * (exp(ll) * class_det[c]);
+    }
+    if (l < 1e-50) l = 1e-50;
+    if (f < F) out[f * S + s] = linear ? l : log(l);
+  }
+}
+
+static void score_f64_classes_launch(aasr_gmm *g, const double *d_frames, int64_t F, double *d_out, int linear,
+                                     hipStream_t stream) {
+  const int nc = g->f64_classes;
+  // passes of at most ~1 GB of class frames
+  int64_t pass = std::max<int64_t>(256, (int64_t)(1.0e9 / ((double)nc * g->dim * 8)));
+  if (pass > F) pass = F;
+  g->f64_class_x.ensure((size_t)nc * g->dim * (size_t)pass);
+  for (int64_t f0 = 0; f0 < F; f0 += pass) {
+    const int64_t n = std::min(pass, F - f0);
+    const int64_t nv = (int64_t)nc * g->dim * n;
+    hipLaunchKernelGGL(k_affine_frames_f64_classes, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, stream,
+                       d_frames + f0 * g->dim, n, g->dim, nc, g->f64_class_A.p, g->f64_class_b.p, g->f64_class_x.p);
+    AASR_HIP(hipGetLastError());
+    const int64_t blocks = (n + 255) / 256;
+    int64_t cuts = std::max<int64_t>(1, std::min<int64_t>(g->S, (4 * (int64_t)(g->num_cus > 0 ? g->num_cus : 256) + blocks - 1) / blocks));
+    if (cuts > 65535) cuts = 65535;
+#define AASR_CASE(N)                                                                                             \
+  case N:                                                                                                        \
+    hipLaunchKernelGGL((k_gmm_diag_score_f64_classes<N>), dim3((unsigned)blocks, (unsigned)cuts), dim3(256), 0,  \
+                       stream, g->f64_class_x.p, n, g->dim, g->f64_recs.p, g->f64_rec_class.p, g->f64_class_det.p, \
+                       g->f64_state_off.p, g->S, d_out + f0 * g->S, linear);                                     \
+    break;
+    switch (g->f64_dimp) {
+      AASR_CASE(8) AASR_CASE(16) AASR_CASE(24) AASR_CASE(32) AASR_CASE(40) AASR_CASE(48) AASR_CASE(64)
+      default:
+        raise(AASR_ERR_UNSUPPORTED, "no f64 kernel instance for dimension %d", g->dim);
+    }
+#undef AASR_CASE
+    AASR_HIP(hipGetLastError());
+  }
+}
+
 void gmm_score_f64_launch(aasr_gmm *g, const double *d_frames, int64_t F, double *d_out, int linear,
                           hipStream_t stream) {
   if (F <= 0) return;
-  if (g->host.any_full() || (g->host.n_transforms > 0 && !g->host.global_xform()))
-    raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 is built for diagonal pools without per-class model transforms");
+  if (g->host.any_full()) raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 is built for diagonal pools");
   gmm_build_f64(g);
+  if (g->f64_classes > 0) {
+    if (g->cl.enabled)
+      raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 with per-class model transforms is built without Gaussian clustering");
+    score_f64_classes_launch(g, d_frames, F, d_out, linear, stream);
+    return;
+  }
   const double *d_raw = d_frames;
   double det = 1.0;
   if (g->host.n_transforms > 0) {  // one global transform: adapted frames, |prod diag A| on every Gaussian

@@ -50,11 +50,27 @@ def test_f64_scores_equal_the_oracle(capi, oracle, D, G, S, comps, tied):
     want_a = oracle.score_adapted(om, frames, np.zeros(G, np.int32), W[None])
     got_a = g.score_f64(frames)
     assert np.abs(got_a - want_a).max() <= 1e-10 * max(1.0, np.abs(want_a).max())
-    # refused where it is not built: per-class transforms
-    g2t = (np.arange(G) % 2).astype(np.int32)
-    g.set_cmllr(g2t, np.stack([W, W]))
-    with pytest.raises(capi.AasrError, match="AASR_PREC_F64 is built for diagonal pools without"):
-        g.score_f64(frames)
+    # per-class transforms (regression classes): every component evaluates its class's A f + b, scaled by its
+    # |prod diag A|, summed in component order; Gaussians without a transform stay plain
+    A2 = np.eye(D) * rng.uniform(0.8, 1.2, D) + 0.03 * rng.standard_normal((D, D))
+    W2 = np.hstack([0.2 * rng.standard_normal(D)[:, None], A2])
+    g2t = (np.arange(G) % 3).astype(np.int32) - 1        # -1: unadapted
+    g.set_cmllr(g2t, np.stack([W, W2]))
+    want_c = oracle.score_adapted(om, frames, g2t, np.stack([W, W2]))
+    got_c = g.score_f64(frames)
+    assert np.abs(got_c - want_c).max() <= 1e-10 * max(1.0, np.abs(want_c).max())
+    assert np.abs(got_c - want_a).max() > 1e-3           # and it is a different model
+    # the float entry point under the mode rounds those values once
+    g.set_precision(1)
+    assert np.abs(g.score(frames.astype(np.float32)) - oracle.score_adapted(
+        om, frames.astype(np.float32).astype(np.float64), g2t, np.stack([W, W2]))).max() <= 2e-5
+    g.set_precision(0)
+    # refused where it is not built: per-class transforms together with Gaussian clustering
+    if G >= 16:
+        g.set_clustering(4, [(i, i % 4) for i in range(G)])
+        g.set_clustering_min_evals(0.0, 0.25)
+        with pytest.raises(capi.AasrError, match="without Gaussian clustering"):
+            g.score_f64(frames)
 
 
 @pytest.mark.parametrize("nbytes,normalize", [(2, True), (4, True), (4, False)])

@@ -31,6 +31,7 @@ def test_scoring_sweep(capi, oracle, seed, n):
     assert any(k.startswith("clustered") for k in worst) and any("layouts=4" in k for k in worst)
     assert any(k.startswith("cmllr") for k in worst) and "cmllr clustered refused" not in worst
     assert worst["f64"] <= 1e-12 and worst.get("f64 clustered", 0.0) <= 1e-12       # AASR_PREC_F64: the oracle's values
+    assert worst.get("f64 cmllr", 0.0) <= 1e-11
     assert max(v for k, v in worst.items() if k.endswith("(ll > -104)")) <= 1e-4
 
 

@@ -180,6 +180,13 @@ def run(seed=1, N=40, verbose=False, big=False):
                 except capi.AasrError:
                     continue
                 note("cmllr T=%d prec=%d" % (T, prec), g.score(frames), want_a, ctx, floor_slack=slack)
+            # AASR_PREC_F64 under the same transform(s): the oracle's values
+            e64 = float(np.abs(g.score_f64(frames.astype(np.float64)) - want_a).max())
+            worst["f64 cmllr"] = max(worst.get("f64 cmllr", 0.0), e64)
+            if e64 > 1e-9 * max(1.0, float(np.abs(want_a).max())):
+                fails.append("f64 cmllr T=%d %s err %.3g" % (T, ctx, e64))
+                if verbose:
+                    print("FAIL", fails[-1])
             if Cn >= 1 and Cn <= 0.3 * G:
                 try:
                     g.set_clustering(Cn, pairs)
