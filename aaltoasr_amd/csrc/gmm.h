@@ -303,6 +303,9 @@ void gmm_cluster_score_f64_launch(aasr_gmm *g, const double *d_frames, const dou
 void gmm_f64_masked_launch(aasr_gmm *g, const double *d_members, int64_t F, double *d_out, int linear, double det,
                            const int32_t *crow, const unsigned long long *maskw, int c1, const double *ll64,
                            int64_t Cs, int C, hipStream_t stream);
+void gmm_f64_classes_masked_launch(aasr_gmm *g, const double *d_frames, int64_t n, double *d_out, int linear,
+                                   const int32_t *crow, const unsigned long long *maskw, int c1, const double *ll64,
+                                   int64_t Cs, int C, hipStream_t stream);
 void gmm_score_f64_launch(aasr_gmm *g, const double *d_frames, int64_t F, double *d_out, int linear,
                           hipStream_t stream);
 void gmm_build_tracks(aasr_gmm *g, bool grouped);

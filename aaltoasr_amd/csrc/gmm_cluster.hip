@@ -1131,8 +1131,12 @@ void gmm_cluster_score_f64_launch(aasr_gmm *g, const double *d_frames, const dou
     const int64_t n = std::min<int64_t>(cl.Fs, F - f0);
     launch_centres(g, d_frames + f0 * g->dim, n, stream);
     launch_select(g, 0, n, stream);
-    gmm_f64_masked_launch(g, d_members + f0 * g->dim, n, d_out + f0 * g->S, linear, det, cl.crow_centred.p,
-                          cl.maskw.p, cl.C + 1, cl.ll64.p, (int64_t)cl.Cs, cl.C, stream);
+    if (g->f64_classes > 0)  // regression classes: members on their class's frames (made from the raw ones)
+      gmm_f64_classes_masked_launch(g, d_frames + f0 * g->dim, n, d_out + f0 * g->S, linear, cl.crow_centred.p,
+                                    cl.maskw.p, cl.C + 1, cl.ll64.p, (int64_t)cl.Cs, cl.C, stream);
+    else
+      gmm_f64_masked_launch(g, d_members + f0 * g->dim, n, d_out + f0 * g->S, linear, det, cl.crow_centred.p,
+                            cl.maskw.p, cl.C + 1, cl.ll64.p, (int64_t)cl.Cs, cl.C, stream);
   }
 }
 

@@ -1610,11 +1610,13 @@ __global__ void k_affine_frames_f64_classes(const double *__restrict__ x, int64_
   y[idx] = acc;
 }
 
-template <int DIMP>
+template <int DIMP, bool CL>
 __global__ __launch_bounds__(256) void k_gmm_diag_score_f64_classes(
     const double *__restrict__ xc, int64_t F, int dim, const double *__restrict__ recs,
     const int32_t *__restrict__ rec_class, const double *__restrict__ class_det,
-    const int32_t *__restrict__ state_off, int64_t S, double *__restrict__ out, int linear) {
+    const int32_t *__restrict__ state_off, int64_t S, double *__restrict__ out, int linear,
+    const int32_t *__restrict__ crow, const unsigned long long *__restrict__ maskw, int c1,
+    const double *__restrict__ ll64, int64_t Cs, int C) {
   constexpr int REC = 2 * DIMP + 2;
   const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t fc = f < F ? f : F - 1;
@@ -1634,43 +1636,71 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_f64_classes(
       }
       ll *= -0.5;
       ll += rec[2 * DIMP];
-      l += rec[2 * DIMP + 1] * (exp(ll) * class_det[c]);
+      double lik = exp(ll) * class_det[c];
+      if (CL) {  // as k_gmm_diag_score_f64: an unselected cluster's members take the (plain) centre's likelihood
+        const int cc = crow[r];
+        const bool on = (maskw[(fc >> 6) * c1 + cc] >> (fc & 63)) & 1ull;
+        if (!on) {
+          const double key = ll64[fc * Cs + (cc < C ? cc : 0)];
+          lik = key > -1000.0 ? exp(key) : ldexp((key + 2000.0) * 4398046511104.0, -1074);
+        }
+      }
+      l += rec[2 * DIMP + 1] * lik;
     }
     if (l < 1e-50) l = 1e-50;
     if (f < F) out[f * S + s] = linear ? l : log(l);
   }
 }
 
+// one pass of at most `n` frames: class frames, then the kernel (masked when the selection tables are given)
+static void f64_classes_pass(aasr_gmm *g, const double *d_frames, int64_t n, double *d_out, int linear,
+                             const int32_t *crow, const unsigned long long *maskw, int c1, const double *ll64,
+                             int64_t Cs, int C, hipStream_t stream) {
+  const int nc = g->f64_classes;
+  g->f64_class_x.ensure((size_t)nc * g->dim * (size_t)n);
+  const int64_t nv = (int64_t)nc * g->dim * n;
+  hipLaunchKernelGGL(k_affine_frames_f64_classes, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, stream, d_frames, n,
+                     g->dim, nc, g->f64_class_A.p, g->f64_class_b.p, g->f64_class_x.p);
+  AASR_HIP(hipGetLastError());
+  const int64_t blocks = (n + 255) / 256;
+  int64_t cuts = std::max<int64_t>(1, std::min<int64_t>(g->S, (4 * (int64_t)(g->num_cus > 0 ? g->num_cus : 256) + blocks - 1) / blocks));
+  if (cuts > 65535) cuts = 65535;
+#define AASR_ARGS g->f64_class_x.p, n, g->dim, g->f64_recs.p, g->f64_rec_class.p, g->f64_class_det.p, \
+                  g->f64_state_off.p, g->S, d_out, linear, crow, maskw, c1, ll64, Cs, C
+#define AASR_CASE(N)                                                                                              \
+  case N:                                                                                                         \
+    if (maskw)                                                                                                    \
+      hipLaunchKernelGGL((k_gmm_diag_score_f64_classes<N, true>), dim3((unsigned)blocks, (unsigned)cuts), dim3(256), 0, stream, AASR_ARGS); \
+    else                                                                                                          \
+      hipLaunchKernelGGL((k_gmm_diag_score_f64_classes<N, false>), dim3((unsigned)blocks, (unsigned)cuts), dim3(256), 0, stream, AASR_ARGS); \
+    break;
+  switch (g->f64_dimp) {
+    AASR_CASE(8) AASR_CASE(16) AASR_CASE(24) AASR_CASE(32) AASR_CASE(40) AASR_CASE(48) AASR_CASE(64)
+    default:
+      raise(AASR_ERR_UNSUPPORTED, "no f64 kernel instance for dimension %d", g->dim);
+  }
+#undef AASR_CASE
+#undef AASR_ARGS
+  AASR_HIP(hipGetLastError());
+}
+
 static void score_f64_classes_launch(aasr_gmm *g, const double *d_frames, int64_t F, double *d_out, int linear,
                                      hipStream_t stream) {
-  const int nc = g->f64_classes;
   // passes of at most ~1 GB of class frames
-  int64_t pass = std::max<int64_t>(256, (int64_t)(1.0e9 / ((double)nc * g->dim * 8)));
+  int64_t pass = std::max<int64_t>(256, (int64_t)(1.0e9 / ((double)g->f64_classes * g->dim * 8)));
   if (pass > F) pass = F;
-  g->f64_class_x.ensure((size_t)nc * g->dim * (size_t)pass);
   for (int64_t f0 = 0; f0 < F; f0 += pass) {
     const int64_t n = std::min(pass, F - f0);
-    const int64_t nv = (int64_t)nc * g->dim * n;
-    hipLaunchKernelGGL(k_affine_frames_f64_classes, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, stream,
-                       d_frames + f0 * g->dim, n, g->dim, nc, g->f64_class_A.p, g->f64_class_b.p, g->f64_class_x.p);
-    AASR_HIP(hipGetLastError());
-    const int64_t blocks = (n + 255) / 256;
-    int64_t cuts = std::max<int64_t>(1, std::min<int64_t>(g->S, (4 * (int64_t)(g->num_cus > 0 ? g->num_cus : 256) + blocks - 1) / blocks));
-    if (cuts > 65535) cuts = 65535;
-#define AASR_CASE(N)                                                                                             \
-  case N:                                                                                                        \
-    hipLaunchKernelGGL((k_gmm_diag_score_f64_classes<N>), dim3((unsigned)blocks, (unsigned)cuts), dim3(256), 0,  \
-                       stream, g->f64_class_x.p, n, g->dim, g->f64_recs.p, g->f64_rec_class.p, g->f64_class_det.p, \
-                       g->f64_state_off.p, g->S, d_out + f0 * g->S, linear);                                     \
-    break;
-    switch (g->f64_dimp) {
-      AASR_CASE(8) AASR_CASE(16) AASR_CASE(24) AASR_CASE(32) AASR_CASE(40) AASR_CASE(48) AASR_CASE(64)
-      default:
-        raise(AASR_ERR_UNSUPPORTED, "no f64 kernel instance for dimension %d", g->dim);
-    }
-#undef AASR_CASE
-    AASR_HIP(hipGetLastError());
+    f64_classes_pass(g, d_frames + f0 * g->dim, n, d_out + f0 * g->S, linear, nullptr, nullptr, 0, nullptr, 0, 0, stream);
   }
+}
+
+// clustered sub-pass under per-class transforms (called by gmm_cluster_score_f64_launch with the RAW frames)
+void gmm_f64_classes_masked_launch(aasr_gmm *g, const double *d_frames, int64_t n, double *d_out, int linear,
+                                   const int32_t *crow, const unsigned long long *maskw, int c1, const double *ll64,
+                                   int64_t Cs, int C, hipStream_t stream) {
+  gmm_build_f64(g);
+  f64_classes_pass(g, d_frames, n, d_out, linear, crow, maskw, c1, ll64, Cs, C, stream);
 }
 
 void gmm_score_f64_launch(aasr_gmm *g, const double *d_frames, int64_t F, double *d_out, int linear,
@@ -1679,9 +1709,8 @@ void gmm_score_f64_launch(aasr_gmm *g, const double *d_frames, int64_t F, double
   if (g->host.any_full()) raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 is built for diagonal pools");
   gmm_build_f64(g);
   if (g->f64_classes > 0) {
-    if (g->cl.enabled)
-      raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 with per-class model transforms is built without Gaussian clustering");
-    score_f64_classes_launch(g, d_frames, F, d_out, linear, stream);
+    if (g->cl.enabled) gmm_cluster_score_f64_launch(g, d_frames, d_frames, F, d_out, linear, 1.0, stream);
+    else score_f64_classes_launch(g, d_frames, F, d_out, linear, stream);
     return;
   }
   const double *d_raw = d_frames;

@@ -272,8 +272,8 @@ int32_t aasr_gmm_num_clusters(const aasr_gmm *h);
  *                         models still take the centred form).  The environment
  *                         variable AASR_PREC=0 selects AASR_PREC_F32 globally.
  *  AASR_PREC_F64          the reference's own arithmetic in double, operation by operation (diagonal
- *                         pools; unadapted or under one global CMLLR transform, with or without clustering; per-class
- *                         transforms without clustering): a verification / training-side
+ *                         pools; unadapted, under one global CMLLR transform or under per-class transforms, with or
+ *                         without clustering): a verification / training-side
  *                         mode, ~1.2 M frames/s at 50 k Gaussians.  Float entry points widen the frames
  *                         and round the scores once; aasr_gmm_score_f64 takes and returns doubles;
  *                         aasr_run_utterance / aasr_run_recipe then run the whole path in double

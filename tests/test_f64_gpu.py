@@ -65,12 +65,17 @@ def test_f64_scores_equal_the_oracle(capi, oracle, D, G, S, comps, tied):
     assert np.abs(g.score(frames.astype(np.float32)) - oracle.score_adapted(
         om, frames.astype(np.float32).astype(np.float64), g2t, np.stack([W, W2]))).max() <= 2e-5
     g.set_precision(0)
-    # refused where it is not built: per-class transforms together with Gaussian clustering
+    # ... and together with Gaussian clustering: the selection on the raw frames (plain centres), the members of
+    # selected clusters on their class's frames
     if G >= 16:
-        g.set_clustering(4, [(i, i % 4) for i in range(G)])
+        pairs = [(i, i % 4) for i in range(G) if i % 7]
+        om.set_clustering(4, pairs, 0.0, 0.25)
+        g.set_clustering(4, pairs)
         g.set_clustering_min_evals(0.0, 0.25)
-        with pytest.raises(capi.AasrError, match="without Gaussian clustering"):
-            g.score_f64(frames)
+        want_cc, n_cc = om.score_clustered_classes(frames, g2t, np.stack([W, W2]), want_counts=True)
+        got_cc = g.score_f64(frames)
+        assert np.array_equal(g.cluster_exact_counts(len(frames)), n_cc)
+        assert np.abs(got_cc - want_cc).max() <= 1e-10 * max(1.0, np.abs(want_cc).max())
 
 
 @pytest.mark.parametrize("nbytes,normalize", [(2, True), (4, True), (4, False)])

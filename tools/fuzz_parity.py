@@ -196,6 +196,12 @@ def run(seed=1, N=40, verbose=False, big=False):
                         print("skip cmllr clustering:", e)
                     continue
                 want_ca, cnt_a = om.score_clustered_classes(frames.astype(np.float64), g2t, Wt, want_counts=True)
+                e64 = float(np.abs(g.score_f64(frames.astype(np.float64)) - want_ca).max())
+                worst["f64 cmllr clustered"] = max(worst.get("f64 cmllr clustered", 0.0), e64)
+                if e64 > 1e-9 * max(1.0, float(np.abs(want_ca).max())) or not np.array_equal(g.cluster_exact_counts(F), cnt_a):
+                    fails.append("f64 cmllr clustered T=%d %s C %d err %.3g" % (T, ctx, Cn, e64))
+                    if verbose:
+                        print("FAIL", fails[-1])
                 for prec in (0, 3):
                     try:
                         g.set_precision(prec)
