@@ -480,38 +480,62 @@ __global__ __launch_bounds__(256) void k_cluster_expand(
     const unsigned long long *__restrict__ maskw, int mask_stride,
     const int32_t *__restrict__ crow, int64_t rows_padded, int tiles_per_block,
     unsigned long long *__restrict__ maskrow) {
-  extern __shared__ unsigned long long cm[];  // [mask_stride] cluster masks, then [4][64] row masks
-  unsigned long long *rm = cm + mask_stride + (threadIdx.x >> 6) * TILE_ROWS;
+  extern __shared__ unsigned long long cm[];  // [mask_stride] cluster masks of this 64-frame word
   const int64_t word = blockIdx.y;
   for (int c = threadIdx.x; c < mask_stride; c += 256) cm[c] = maskw[word * mask_stride + c];
   __syncthreads();
-  const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+  const int lane = threadIdx.x & 63, h = lane >> 5;
   const int64_t n_tiles = rows_padded / TILE_ROWS;
   const int64_t t0 = (int64_t)blockIdx.x * tiles_per_block;
   const int64_t t1 = t0 + tiles_per_block < n_tiles ? t0 + tiles_per_block : n_tiles;
   for (int64_t t = t0 + (threadIdx.x >> 6); t < t1; t += kExpandTiles) {
-    // the tile's 64 row masks, one per lane, then every lane picks its two bits out of the 32
-    // rows of its track (lanes of one half read the same word: an LDS broadcast)
-    rm[lane] = cm[crow[t * TILE_ROWS + lane]];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    unsigned lo = 0, hi = 0;
+    // Lane r fetches the 64 frame bits of tile row r; a 64 x 64 bit transpose over the lanes (block swaps of
+    // 32, 16, ... 1: six exchanges per dword instead of 32 LDS reads + 64 bit extracts per lane) leaves lane c
+    // with the 64 row bits of frame c.  Lane (n, h) then needs frames n and 32 + n -- its own column and
+    // lane ^ 32's -- restricted to the rows 8q + 4h + e of its track: nibble h of every byte, the rows of block
+    // mb = 1 shifted into the free nibbles.  Bit layout of the word: side * 32 + 8q + 4mb + e.
+    const unsigned long long r64 = cm[crow[t * TILE_ROWS + lane]];
+    unsigned lo = (unsigned)r64, hi = (unsigned)(r64 >> 32);
+    {
+      const bool lower = lane & 32;
+      const unsigned recv = (unsigned)__shfl_xor((int)(lower ? lo : hi), 32);
+      if (lower) lo = recv;
+      else hi = recv;
+    }
 #pragma unroll
-    for (int mb = 0; mb < 2; mb++)
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          // row mask as two dwords: frames 0-31 / 32-63; one bit-field extract each, two inserts
-          const uint2 m = ((const uint2 *)rm)[mb * 32 + 8 * q + 4 * h + e];
-          const unsigned b0 = __builtin_amdgcn_ubfe(m.x, n, 1), b1 = __builtin_amdgcn_ubfe(m.y, n, 1);
-          const int idx = ((mb * 4 + q) * 4 + e) * 2;
-          if (idx < 32) lo |= (b0 << idx) | (b1 << (idx + 1));
-          else hi |= (b0 << (idx - 32)) | (b1 << (idx - 31));
-        }
-    maskrow[word * rows_padded + t * TILE_ROWS + lane] = (unsigned long long)lo | ((unsigned long long)hi << 32);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    for (int step = 0; step < 5; step++) {
+      const int j = 16 >> step;
+      const unsigned m = j == 16 ? 0x0000FFFFu : j == 8 ? 0x00FF00FFu : j == 4 ? 0x0F0F0F0Fu : j == 2 ? 0x33333333u : 0x55555555u;
+      const bool lower = lane & j;
+      const unsigned keep = lower ? ~m : m;
+      // partner lane ^ j: quad permutes for 1 and 2, a rotation by 8 inside the 16-lane row for 8 (DPP, no LDS
+      // crossbar round trip); 4 and 16 have no DPP form on gfx9 and go through ds_bpermute
+      unsigned plo, phi;
+      if (j == 1) {
+        plo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xF, 0xF, false);
+        phi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xF, 0xF, false);
+      } else if (j == 2) {
+        plo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x4E, 0xF, 0xF, false);
+        phi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0x4E, 0xF, 0xF, false);
+      } else if (j == 8) {
+        plo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x128, 0xF, 0xF, false);
+        phi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0x128, 0xF, 0xF, false);
+      } else {
+        plo = (unsigned)__shfl_xor((int)lo, j);
+        phi = (unsigned)__shfl_xor((int)hi, j);
+      }
+      plo &= keep;
+      phi &= keep;
+      lo = (lo & keep) | (lower ? plo >> j : plo << j);
+      hi = (hi & keep) | (lower ? phi >> j : phi << j);
+    }
+    const unsigned olo = (unsigned)__shfl_xor((int)lo, 32), ohi = (unsigned)__shfl_xor((int)hi, 32);
+    const unsigned alo = h ? olo : lo, ahi = h ? ohi : hi;   // frame n
+    const unsigned blo = h ? lo : olo, bhi = h ? hi : ohi;   // frame 32 + n
+    const int sh = 4 * h;
+    const unsigned pa = ((alo >> sh) & 0x0F0F0F0Fu) | (((ahi >> sh) & 0x0F0F0F0Fu) << 4);
+    const unsigned pb = ((blo >> sh) & 0x0F0F0F0Fu) | (((bhi >> sh) & 0x0F0F0F0Fu) << 4);
+    maskrow[word * rows_padded + t * TILE_ROWS + lane] = (unsigned long long)pa | ((unsigned long long)pb << 32);
   }
 }
 
@@ -1007,7 +1031,7 @@ static void exact_part_launch(aasr_gmm *g, ClusterState &cl, const ExactPlan &p,
   const int64_t n_tiles = L.rows_padded / TILE_ROWS;
   const int tpb = (int)std::min<int64_t>(n_tiles, 64);  // the staged cluster masks serve 64 tiles
   hipLaunchKernelGGL(k_cluster_expand, dim3((unsigned)((n_tiles + tpb - 1) / tpb), (unsigned)words), dim3(256),
-                     (size_t)(c1 + kExpandTiles * TILE_ROWS) * 8, stream, maskw, c1, cl.crow[p.which].p, L.rows_padded, tpb,
+                     (size_t)c1 * 8, stream, maskw, c1, cl.crow[p.which].p, L.rows_padded, tpb,
                      cl.maskrow.p);
   AASR_HIP(hipGetLastError());
   gmm_tracks_masked_launch(g, p.which, fr_members, n, out, cl.maskrow.p, stream);

@@ -501,8 +501,8 @@ __global__ __launch_bounds__(256, 2) void k_gmm_diag_score_tracks(
           va[e] = ca[4 * q + e];
           vb[e] = cb[4 * q + e];
           if (CL) {
-            va[e] = mask_select(va[e], bits, ((mb * 4 + q) * 4 + e) * 2);
-            vb[e] = mask_select(vb[e], bits, ((mb * 4 + q) * 4 + e) * 2 + 1);
+            va[e] = mask_select(va[e], bits, 8 * q + 4 * mb + e);        // k_cluster_expand's bit layout
+            vb[e] = mask_select(vb[e], bits, 32 + 8 * q + 4 * mb + e);
           }
         }
         float e0 = __builtin_amdgcn_exp2f(va[0]) + __builtin_amdgcn_exp2f(va[1]);
@@ -888,8 +888,8 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
           va[e] = ca[4 * q + e];
           vb[e] = cb[4 * q + e];
           if (CL) {
-            va[e] = mask_select(va[e], bits, ((mb * 4 + q) * 4 + e) * 2);
-            vb[e] = mask_select(vb[e], bits, ((mb * 4 + q) * 4 + e) * 2 + 1);
+            va[e] = mask_select(va[e], bits, 8 * q + 4 * mb + e);        // k_cluster_expand's bit layout
+            vb[e] = mask_select(vb[e], bits, 32 + 8 * q + 4 * mb + e);
           }
         }
         float e0 = __builtin_amdgcn_exp2f(va[0]) + __builtin_amdgcn_exp2f(va[1]);
