@@ -216,6 +216,44 @@ __device__ __forceinline__ unsigned wave_scan_u32(unsigned v) {
   return v;
 }
 
+// 64 x 64 bit transpose over the lanes of a wave: lane r enters with row r (lo = columns 0-31, hi = 32-63) and
+// leaves with column r (lo = rows 0-31, hi = rows 32-63).  Block swaps of 32, 16, ... 1 between lane pairs.
+__device__ __forceinline__ void wave_bit_transpose64(unsigned &lo, unsigned &hi, int lane) {
+  {
+    const bool lower = lane & 32;
+    const unsigned recv = (unsigned)__shfl_xor((int)(lower ? lo : hi), 32);
+    if (lower) lo = recv;
+    else hi = recv;
+  }
+#pragma unroll
+  for (int step = 0; step < 5; step++) {
+    const int j = 16 >> step;
+    const unsigned m = j == 16 ? 0x0000FFFFu : j == 8 ? 0x00FF00FFu : j == 4 ? 0x0F0F0F0Fu : j == 2 ? 0x33333333u : 0x55555555u;
+    const bool lower = lane & j;
+    const unsigned keep = lower ? ~m : m;
+    // partner lane ^ j: quad permutes for 1 and 2, a rotation by 8 inside the 16-lane row for 8 (DPP, no LDS
+    // crossbar round trip); 4 and 16 have no DPP form on gfx9 and go through ds_bpermute
+    unsigned plo, phi;
+    if (j == 1) {
+      plo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xF, 0xF, false);
+      phi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xF, 0xF, false);
+    } else if (j == 2) {
+      plo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x4E, 0xF, 0xF, false);
+      phi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0x4E, 0xF, 0xF, false);
+    } else if (j == 8) {
+      plo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x128, 0xF, 0xF, false);
+      phi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0x128, 0xF, 0xF, false);
+    } else {
+      plo = (unsigned)__shfl_xor((int)lo, j);
+      phi = (unsigned)__shfl_xor((int)hi, j);
+    }
+    plo &= keep;
+    phi &= keep;
+    lo = (lo & keep) | (lower ? plo >> j : plo << j);
+    hi = (hi & keep) | (lower ? phi >> j : phi << j);
+  }
+}
+
 // One wave per 64 consecutive frames (= one word of the selection masks);
 // lane l holds clusters l, 64 + l, ...  (KPL per lane).
 // four waves per SIMD (<= 128 VGPRs): a 250 k-frame sub-pass is 3906 single-wave workgroups, which
@@ -377,8 +415,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
   for (int j = 0; j < KPL; j++) {
     const int c = j * 64 + lane;
-    unsigned long long w = 0;
-    for (int fi = 0; fi < 64; fi++) w |= ((bits[fi][j] >> lane) & 1ull) << fi;
+    // lane fi holds the ballot of frame fi (bit l = cluster 64 j + l); transposed, lane l holds its cluster's frames
+    const unsigned long long bw = bits[lane][j];
+    unsigned tlo = (unsigned)bw, thi = (unsigned)(bw >> 32);
+    wave_bit_transpose64(tlo, thi, lane);
+    const unsigned long long w = (unsigned long long)tlo | ((unsigned long long)thi << 32);
     if (c < C) maskw[word * (C + 1) + c] = w;
   }
   if (lane == 0) maskw[word * (C + 1) + C] = ~0ull;  // rows in no cluster: always exact
@@ -496,39 +537,7 @@ __global__ __launch_bounds__(256) void k_cluster_expand(
     // mb = 1 shifted into the free nibbles.  Bit layout of the word: side * 32 + 8q + 4mb + e.
     const unsigned long long r64 = cm[crow[t * TILE_ROWS + lane]];
     unsigned lo = (unsigned)r64, hi = (unsigned)(r64 >> 32);
-    {
-      const bool lower = lane & 32;
-      const unsigned recv = (unsigned)__shfl_xor((int)(lower ? lo : hi), 32);
-      if (lower) lo = recv;
-      else hi = recv;
-    }
-#pragma unroll
-    for (int step = 0; step < 5; step++) {
-      const int j = 16 >> step;
-      const unsigned m = j == 16 ? 0x0000FFFFu : j == 8 ? 0x00FF00FFu : j == 4 ? 0x0F0F0F0Fu : j == 2 ? 0x33333333u : 0x55555555u;
-      const bool lower = lane & j;
-      const unsigned keep = lower ? ~m : m;
-      // partner lane ^ j: quad permutes for 1 and 2, a rotation by 8 inside the 16-lane row for 8 (DPP, no LDS
-      // crossbar round trip); 4 and 16 have no DPP form on gfx9 and go through ds_bpermute
-      unsigned plo, phi;
-      if (j == 1) {
-        plo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xF, 0xF, false);
-        phi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xF, 0xF, false);
-      } else if (j == 2) {
-        plo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x4E, 0xF, 0xF, false);
-        phi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0x4E, 0xF, 0xF, false);
-      } else if (j == 8) {
-        plo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x128, 0xF, 0xF, false);
-        phi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0x128, 0xF, 0xF, false);
-      } else {
-        plo = (unsigned)__shfl_xor((int)lo, j);
-        phi = (unsigned)__shfl_xor((int)hi, j);
-      }
-      plo &= keep;
-      phi &= keep;
-      lo = (lo & keep) | (lower ? plo >> j : plo << j);
-      hi = (hi & keep) | (lower ? phi >> j : phi << j);
-    }
+    wave_bit_transpose64(lo, hi, lane);
     const unsigned olo = (unsigned)__shfl_xor((int)lo, 32), ohi = (unsigned)__shfl_xor((int)hi, 32);
     const unsigned alo = h ? olo : lo, ahi = h ? ohi : hi;   // frame n
     const unsigned blo = h ? lo : olo, bhi = h ? hi : ohi;   // frame 32 + n
