@@ -15,7 +15,9 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIBDIR = os.path.join(HERE, "lib")
+# AASR_BUILD_ABLATION=1 builds the library with the kernels' ablation branches and the recipe driver's device
+# stub into its own directory (lib_ablation/, loaded with AASR_LIBDIR=...): the product library carries neither
+LIBDIR = os.path.join(HERE, "lib_ablation" if os.environ.get("AASR_BUILD_ABLATION") == "1" else "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libaasr.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

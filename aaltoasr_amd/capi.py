@@ -16,7 +16,8 @@ from typing import Optional
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libaasr.so")
+# AASR_LIBDIR: another build of the same library (the ablation build of tools/, aaltoasr_amd/lib_ablation)
+LIB_PATH = os.path.join(os.environ.get("AASR_LIBDIR") or os.path.join(HERE, "lib"), "libaasr.so")
 HEADER_PATH = os.path.join(HERE, "..", "include", "aasr.h")
 
 AASR_OK = 0
@@ -45,6 +46,16 @@ class RunStats(C.Structure):
     _fields_ = [("utterances", C.c_int64), ("frames", C.c_int64),
                 ("seconds_total", C.c_double), ("seconds_device", C.c_double),
                 ("seconds_copy_out", C.c_double)]
+
+
+class RecipeTiming(C.Structure):
+    _fields_ = [("seconds_total", C.c_double), ("wait_reader", C.c_double), ("wait_result_slot", C.c_double),
+                ("enqueue", C.c_double), ("wait_copies", C.c_double), ("device", C.c_double),
+                ("copy_out", C.c_double), ("writer_threads", C.c_int32), ("usable_cores", C.c_int32),
+                ("host_share", C.c_int32)]
+
+    def as_dict(self) -> dict:
+        return {k: (round(getattr(self, k), 4) if t is C.c_double else int(getattr(self, k))) for k, t in self._fields_}
 
 
 _lib: Optional[C.CDLL] = None
@@ -152,6 +163,10 @@ def _declare(L: C.CDLL) -> None:
     L.aasr_spkc_num_changes.restype = i64
     L.aasr_recipe_batch_range.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
     L.aasr_run_recipe.argtypes = [vp, vp, cp, C.POINTER(RunOptions), C.POINTER(RunStats)]
+    L.aasr_set_host_share.argtypes = [i32]
+    L.aasr_host_usable_cores.argtypes = []
+    L.aasr_host_usable_cores.restype = i32
+    L.aasr_recipe_last_timing.argtypes = [vp, C.POINTER(RecipeTiming)]
     L.aasr_run_utterance.argtypes = [vp, vp, vp, i64, i32, i32, C.c_int, C.c_int,
                                      C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(i64), C.POINTER(i64)]
     L.aasr_lna_read_file.argtypes = [cp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64), C.POINTER(C.POINTER(C.c_float))]
@@ -709,3 +724,13 @@ def run_recipe(feat: Feat, gmm: Gmm, recipe_path: str, lnabytes: int = 2, normal
     st = RunStats()
     check(lib().aasr_run_recipe(feat._h, gmm._h, recipe_path.encode(), C.byref(opt), C.byref(st)))
     return st
+
+
+def recipe_last_timing(gmm: Gmm) -> dict:
+    t = RecipeTiming()
+    check(lib().aasr_recipe_last_timing(gmm._h, C.byref(t)))
+    return t.as_dict()
+
+
+def set_host_share(processes: int) -> None:
+    check(lib().aasr_set_host_share(int(processes)))

@@ -89,6 +89,8 @@ void HmmSet::read_legacy_ph(std::ifstream &in) {
     in >> dummy >> dummy;
     for (int s = 0; s < states; s++) {
       in >> pdf;
+      // (the reference indexes with whatever it read: a negative or garbage index is a ReadError here)
+      if (!in || pdf < 0 || pdf > (1 << 24)) throw ReadError();
       if (pdf >= (int)state_info.size()) state_info.resize((size_t)pdf + 1);
       hmm.state(s) = pdf;
       load_transitions.push_back(state_info[(size_t)pdf].empty());

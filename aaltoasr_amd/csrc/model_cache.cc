@@ -11,11 +11,11 @@
 // match the files the caller names: after retraining, or with another -b next to the same cache
 // path, the text files are parsed again instead of scoring with a stale model.
 //
-// Layout (little endian): "AASRGMM1", u32 version (2), i32 dim, i64 G, i64 S, i64 K,
+// Layout (little endian): "AASRGMM1", u32 version (3), i32 dim, i64 G, i64 S, i64 K,
 // u32 flags (bit 0: covariances present, bit 1: source fingerprint present, bit 2: per-Gaussian
 // constant offsets present), i64 number of HMMs,
 // u64 fingerprint[6], then mean[G*dim],
-// var[G*dim] (f64), [cov[G*dim*dim] f64, is_full[G] u8], mix_off[S+1] i32,
+// var[G*dim] (f64), [cov[G*dim*dim] f64, is_full[G] u8], [gauss_bias[G] f64], mix_off[S+1] i32,
 // mix_idx[K] i32, mix_w[K] f64, per HMM {u32 label length, label, u32 states,
 // i32 pdf[states]}, and a 64-bit FNV-1a checksum of everything before it.
 #include <cstdio>

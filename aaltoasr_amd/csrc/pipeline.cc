@@ -10,7 +10,11 @@
 // bytes come back in one copy per block.
 #include <sys/stat.h>
 
+#include <sched.h>
+
 #include <algorithm>
+#include <array>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <cstdio>
@@ -238,7 +242,10 @@ std::vector<int16_t> read_feature_file(const std::string &path, int dim, bool le
       data.resize((size_t)n);
       data.resize(fread(data.data(), 1, (size_t)n, fp));
     }
-  } else {
+  }
+  // not seekable, or a stream whose size reads as 0 (procfs, character devices): chunked read
+  if (data.empty()) {
+    clearerr(fp);
     while ((got = fread(buf, 1, sizeof buf, fp)) > 0) data.insert(data.end(), buf, buf + got);
   }
   fclose(fp);
@@ -262,6 +269,55 @@ std::vector<int16_t> decode_input_data(const aasr_feat *feat, const std::vector<
 
 // ------------------------------------------------------------------ driver --
 
+// How many engine processes share this host's cores (one per GPU of the node).  The recipe driver's
+// helper threads are sized from usable_cores / share: eight ranks that each start the thread count
+// tuned for a rank that owns the host oversubscribe the CPU quota eight times over.
+static std::atomic<int> g_host_share{0};
+
+int host_usable_cores() {
+  // affinity mask capped by the cgroup CPU quota (the GPU boxes expose 256 logical CPUs and
+  // schedule 16 of them)
+  int n = 0;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+  if (n <= 0) n = (int)std::max(1u, std::thread::hardware_concurrency());
+  auto quota = [&](const char *path_max, const char *path_q, const char *path_p) {
+    if (FILE *fp = fopen(path_max, "r")) {  // cgroup v2: "<quota|max> <period>"
+      char q[64];
+      long long period = 0;
+      if (fscanf(fp, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0)
+        n = std::min(n, (int)std::max<long long>(1, atoll(q) / period));
+      fclose(fp);
+      return;
+    }
+    long long q = -1, per = 0;
+    if (FILE *fp = fopen(path_q, "r")) {
+      if (fscanf(fp, "%lld", &q) != 1) q = -1;
+      fclose(fp);
+    }
+    if (FILE *fp = fopen(path_p, "r")) {
+      if (fscanf(fp, "%lld", &per) != 1) per = 0;
+      fclose(fp);
+    }
+    if (q > 0 && per > 0) n = std::min(n, (int)std::max<long long>(1, q / per));
+  };
+  quota("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+  return std::max(1, n);
+}
+
+int host_share() {
+  int n = g_host_share.load();
+  if (n <= 0)
+    for (const char *name : {"AASR_LOCAL_RANKS", "LOCAL_WORLD_SIZE"})
+      if (const char *e = getenv(name))
+        if (atoi(e) > 0) {
+          n = atoi(e);
+          break;
+        }
+  return std::max(1, n);
+}
+
 static double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -272,6 +328,20 @@ struct Job {
   int32_t start, count;  // frames start .. start+count-1
   std::string out_file;
 };
+
+// Rehearsal of N ranks on a box with ONE GPU (tools/rehearse_ranks.py): with AASR_RECIPE_STUB=1 an ABLATION build
+// (AASR_BUILD_ABLATION=1, aaltoasr_amd/lib_ablation) skips the block's kernels and its device -> host copy, so
+// that what is timed is the host side of a rank alone -- file reads, uploads, the writer pool -- without N ranks
+// queueing on one device and one PCIe link.  The files written hold whatever the pinned slots held: the product
+// library has no such switch.
+static bool stub_device() {
+#if defined(AASR_ABLATION) && AASR_ABLATION
+  static const bool on = getenv("AASR_RECIPE_STUB") && atoi(getenv("AASR_RECIPE_STUB")) == 1;
+  return on;
+#else
+  return false;
+#endif
+}
 
 struct BlockRunner {
   aasr_feat *feat = nullptr;
@@ -351,7 +421,7 @@ struct BlockRunner {
         feat_run_batch(feat, d_pcm.p, ub, (int)feat->mods.size() - 1, nullptr, d_fea64.p, s_compute);
         gmm_score_f64_launch(gmm, d_fea64.p, F, d_lik64.p, 1, s_compute);
         lna_encode_f64_launch(d_lik64.p, F, (int)S, normalize, lnabytes, nullptr, bytes.p, s_compute);
-      } else {
+      } else if (!stub_device()) {
         feat_run_batch(feat, d_pcm.p, ub, (int)feat->mods.size() - 1, d_fea.p, nullptr, s_compute);
         gmm_score_launch_pitched(gmm, d_fea.p, F, d_ll.p, pitch, s_compute);
         lna_encode_launch(d_ll.p, F, (int)S, normalize, lnabytes, nullptr, bytes.p, s_compute, pitch);
@@ -359,7 +429,7 @@ struct BlockRunner {
     }
     AASR_HIP(hipEventRecord(ev_kernels[slot], s_compute));
     AASR_HIP(hipStreamWaitEvent(s_copy, ev_kernels[slot], 0));
-    if (nb) AASR_HIP(hipMemcpyAsync(dst, bytes.p, nb, hipMemcpyDeviceToHost, s_copy));
+    if (nb && !stub_device()) AASR_HIP(hipMemcpyAsync(dst, bytes.p, nb, hipMemcpyDeviceToHost, s_copy));
     AASR_HIP(hipEventRecord(ev_copied[slot], s_copy));
   }
   void finish(int slot) {
@@ -419,6 +489,18 @@ struct BlockRunner {
       AASR_HIP(hipMemcpy(h_bytes.data(), d_bytes.p, nb, hipMemcpyDeviceToHost));
     }
     device_seconds += now_s() - t0;
+  }
+};
+
+// The recipe driver's state that outlives a call (kept on the model handle).
+struct RecipeScratch {
+  BlockRunner br;
+  uint8_t *pinned[2] = {nullptr, nullptr};
+  size_t pinned_cap = 0;
+  std::array<double, 10> timing{};  // aasr_recipe_last_timing
+  ~RecipeScratch() {
+    for (int i = 0; i < 2; i++)
+      if (pinned[i]) (void)hipHostFree(pinned[i]);
   }
 };
 
@@ -484,15 +566,6 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
   // Device buffers, the two streams and the pinned result slots live on the model handle: a second
   // recipe through the same handle (the bench's passes, a server) pays for none of them again --
   // pinning 2 x 0.25 GB alone is ~0.15 s.
-  struct RecipeScratch {
-    BlockRunner br;
-    uint8_t *pinned[2] = {nullptr, nullptr};
-    size_t pinned_cap = 0;
-    ~RecipeScratch() {
-      for (int i = 0; i < 2; i++)
-        if (pinned[i]) (void)hipHostFree(pinned[i]);
-    }
-  };
   std::shared_ptr<RecipeScratch> scratch = std::static_pointer_cast<RecipeScratch>(gmm->recipe_scratch);
   if (!scratch) {
     scratch = std::make_shared<RecipeScratch>();
@@ -606,7 +679,11 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
     inq.cv.notify_all();
   });
 
-  int n_writers = 16;  // measured on a 16-CPU quota: 8 -> 5.2, 12 -> 5.9, 16 -> 6.5, 24 -> 6.9 M frames/s (fresh files, tmpfs)
+  // One writer per usable core of this rank's share of the host (measured on a 16-CPU quota with one rank: 8 -> 5.2,
+  // 12 -> 5.9, 16 -> 6.5, 24 -> 6.9 M frames/s, fresh files on tmpfs: a writer is a core's worth of page allocation +
+  // copy, 2.7 GB/s).  N ranks on one host (aasr_set_host_share / LOCAL_WORLD_SIZE) divide the cores between them;
+  // a constant 16 per rank put 128 writers on a 16-CPU quota at eight ranks.
+  int n_writers = std::max(2, std::min(32, host_usable_cores() / host_share()));
   if (const char *e = getenv("AASR_WRITER_THREADS")) n_writers = std::max(1, std::min(64, atoi(e)));
   auto writer_main = [&] {
     for (;;) {
@@ -778,6 +855,11 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
     retire();
   } catch (...) {
     failure = std::current_exception();
+    // blocks may still be in flight: their uploads read the jobs' pageable PCM buffers and their kernels write
+    // the scratch that stays on the handle -- nothing may be queued when those go out of scope or a later
+    // recipe starts on the same handle
+    if (br.s_compute) (void)hipStreamSynchronize(br.s_compute);
+    if (br.s_copy) (void)hipStreamSynchronize(br.s_copy);
   }
   {  // stop the helpers (the writer first finishes what was queued)
     std::lock_guard<std::mutex> lk(inq.m);
@@ -795,6 +877,8 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
   for (std::thread &t : writers) t.join();
   if (failure) std::rethrow_exception(failure);
   if (outq.error) std::rethrow_exception(outq.error);
+  scratch->timing = {now_s() - t_start, t_wait_reader, t_wait_slot, t_launch, t_finish, br.device_seconds,
+                     br.copy_seconds, (double)n_writers, (double)host_usable_cores(), (double)host_share()};
   if (getenv("AASR_RECIPE_TIMING"))
     fprintf(stderr, "recipe timing: total %.3f s; calling thread waited %.3f s for the reader, %.3f s for a result "
             "slot (pinned allocation, writers), %.3f s enqueueing blocks (incl. pageable uploads), %.3f s for copies\n",
@@ -967,6 +1051,34 @@ aasr_status aasr_run_recipe(aasr_feat *feat, aasr_gmm *gmm, const char *recipe_p
   return guarded([&] {
     if (!feat || !gmm || !recipe_path || !opt) raise(AASR_ERR_INVALID, "aasr_run_recipe: null argument");
     run_recipe(feat, gmm, recipe_path, *opt, stats);
+  });
+}
+
+aasr_status aasr_set_host_share(int32_t processes) {
+  return guarded([&] {
+    if (processes < 0) raise(AASR_ERR_INVALID, "aasr_set_host_share: negative process count");
+    g_host_share.store(processes);
+  });
+}
+
+int32_t aasr_host_usable_cores(void) { return (int32_t)host_usable_cores(); }
+
+aasr_status aasr_recipe_last_timing(const aasr_gmm *gmm, aasr_recipe_timing *out) {
+  return guarded([&] {
+    if (!gmm || !out) raise(AASR_ERR_INVALID, "aasr_recipe_last_timing: null argument");
+    std::shared_ptr<RecipeScratch> sc = std::static_pointer_cast<RecipeScratch>(gmm->recipe_scratch);
+    if (!sc) raise(AASR_ERR_INVALID, "aasr_recipe_last_timing: no recipe has run on this handle");
+    const std::array<double, 10> &t = sc->timing;
+    out->seconds_total = t[0];
+    out->wait_reader = t[1];
+    out->wait_result_slot = t[2];
+    out->enqueue = t[3];
+    out->wait_copies = t[4];
+    out->device = t[5];
+    out->copy_out = t[6];
+    out->writer_threads = (int32_t)t[7];
+    out->usable_cores = (int32_t)t[8];
+    out->host_share = (int32_t)t[9];
   });
 }
 

@@ -76,6 +76,10 @@ class FullChainBench:
             out[name] = round(e0.elapsed_time(e1) / reps, 4)
         return out
 
+    def release(self) -> None:
+        """Drops the device buffers (the bench measures another workload afterwards)."""
+        self.d_pcm = self.d_fea = self.d_ll = self.d_bytes = None
+
     def bytes_written_per_frame(self) -> dict:
         """Algorithmic HBM bytes each stage stores per frame in this arrangement."""
         return {"features_f32": self.feat.dim * 4, "state_scores_f32": self.pitch * 4,

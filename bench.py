@@ -4,14 +4,15 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gmm|full|recipe]
 
 A "step" is one pass of the hot path over one batch of synthetic input:
-  gmm    (BASELINE configs[1], the default `value`): 1 000 000 x 39 float32 frames, resident in
-         HBM, against a 50 000-Gaussian / 3 125-state x 16 diagonal HmmSet -> [F x S] state
-         log-likelihoods (k_gmm_diag_score_bf16x3).  The default run also measures configs[2]
-         (a few steps, reported under config.configs2: ms/step, per-stage split, fraction of LNA
-         bytes identical to the oracle's on a sampled utterance) and a small recipe run with file
-         IO (config.recipe_e2e), so one driver run carries all three.
-  full   (BASELINE configs[2]): 1 h of 16 kHz int16 audio as 360 x 10 s utterances, resident in
-         HBM -> MFCC chain -> same scoring -> 2-byte LNA codes.
+  full   (BASELINE configs[2], the default `value` -- the metric's own "GMM log-lik + MFCC"
+         workload): 1 h of 16 kHz int16 audio as 360 x 10 s utterances (449 280 frames), resident
+         in HBM -> MFCC chain -> 50 000-Gaussian / 3 125-state x 16 diagonal HmmSet scoring ->
+         2-byte LNA codes.  The default run also reports the per-stage split, the HBM rooflines
+         of the feature chain and the LNA pass (roofline.stages), the fraction of LNA codes equal
+         to the oracle's on a sampled utterance, configs[1] (config.configs1) and a small recipe
+         run with file IO (config.recipe_e2e), so one driver run carries all of them.
+  gmm    (BASELINE configs[1]): 1 000 000 x 39 float32 frames, resident in HBM, against the same
+         model -> [F x S] state log-likelihoods (k_gmm_diag_score_bf16x3); no MFCC, no LNA.
   recipe (BASELINE configs[3]): a recipe of --utts (default 10 000) seeded utterances of
          U(2 s, 12 s) as WAV files, sliced over the ranks with Recipe::read's rule
          (aku/Recipe.cc:63-115), read -> features -> scoring -> 2-byte LNA files written; value =
@@ -62,11 +63,11 @@ METRIC = "frames/sec GMM log-lik (39-d, 50k Gauss) + MFCC, 1/2/4/8 MI355X"   # B
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=["gmm", "full", "recipe"],
-                    default=os.environ.get("AASR_BENCH_WORKLOAD", "gmm"))
-    ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step (gmm workload)")
+                    default=os.environ.get("AASR_BENCH_WORKLOAD", "full"))
+    ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step (gmm workload, and the configs[1] figure of the default run)")
     ap.add_argument("--utts", type=int, default=0,
                     help="utterances: per GPU per step for `full` (default 360 x 10 s), in the whole "
                          "recipe for `recipe` (default 10 000 x U(2 s, 12 s))")
@@ -82,7 +83,8 @@ def parse_args():
                     help="where the recipe workload keeps its WAV inputs and LNA outputs "
                          "(default: /dev/shm when it has room, else the system temp directory)")
     ap.add_argument("--secondary", type=int, default=int(os.environ.get("AASR_BENCH_SECONDARY", "1")),
-                    help="gmm workload: also measure configs[2] and a small recipe run (1 = yes)")
+                    help="full / gmm workloads: also measure the other single-GPU config (configs[1] resp. configs[2]) "
+                         "and a small recipe run (1 = yes)")
     return ap.parse_args()
 
 
@@ -417,8 +419,9 @@ def main():
         from aaltoasr_amd import pipeline
         runner = pipeline.FullChainBench(gmm, n_utts=args.utts or 360, seconds=10.0, rank=rank, device=dev)
         F = runner.total_frames
-        workload = "configs[2]: MFCC chain + %d-Gaussian scoring + 2-byte LNA, %d x 10 s synthetic 16 kHz utterances (%d frames)" % (
-            G, args.utts or 360, F)
+        workload = ("configs[2]: full MFCC chain (FFT -> mel -> log -> DCT -> delta/delta-delta, CMS, normalisation) + %d-Gaussian "
+                    "scoring + 2-byte LNA codes on 1 h of synthetic 16 kHz audio as %d x 10 s utterances (%d frames), "
+                    "int16 samples resident in HBM" % (G, args.utts or 360, F))
         step = runner.step
         score_only = runner.score_only
 
@@ -491,6 +494,25 @@ def main():
             roofline["traffic_detail"] = td
 
     # ---- secondary measurements of the default run (every rank takes part: they hold barriers)
+    if args.workload == "full" and args.secondary:
+        # the per-stage split of the timed workload and its HBM-bound stages priced against 8 TB/s
+        try:
+            split = runner.stage_split(max(3, min(args.steps, 10)))
+            extra_cfg["stage_ms"] = split
+            extra_cfg["hbm_bytes_written_per_frame"] = runner.bytes_written_per_frame()
+            roofline["stages"] = _stage_rooflines(runner, split)
+            if rank == 0:
+                extra_cfg["lna_check"] = _lna_check(runner, gmm, mean, var, off, idx, w,
+                                                    3 if args.precision == "bf16x3" else 0)
+        except Exception as e:
+            extra_cfg["stage_ms"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            runner.release()
+            torch.cuda.empty_cache()
+            extra_cfg["configs1"] = _measure_configs1(torch, synth, gmm, rank, dev, stream, sync_all, max_over_ranks,
+                                                      world, args)
+        except Exception as e:
+            extra_cfg["configs1"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if args.workload == "gmm" and args.secondary:
         try:
             del d_out
@@ -500,6 +522,7 @@ def main():
                                                       3 if args.precision == "bf16x3" else 0)
         except Exception as e:  # the headline must survive a failure of the extras
             extra_cfg["configs2"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if args.workload in ("gmm", "full") and args.secondary:
         try:
             n_small = 256 * world
             res = run_recipe_workload(args, capi, synth, shard, gmm, world, rank, n_small, 1, 1, sync_all)
@@ -528,7 +551,8 @@ def main():
         cfg.update(extra_cfg)
         line = {
             "metric": METRIC,
-            "metric_note": "value is the workload named in config.workload; the MFCC-inclusive rate (configs[2]) is config.configs2.frames_per_s",
+            "metric_note": "value is the workload named in config.workload (default: configs[2], the metric's MFCC-inclusive chain); "
+                           "the GMM-only rate of configs[1] is config.configs1.frames_per_s",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": dtype, "data": "synthetic",
@@ -541,14 +565,96 @@ def main():
         dist.destroy_process_group()
 
 
+def _lna_check(runner, gmm, mean, var, off, idx, w, restore_precision=3):
+    """Fraction of one utterance's 2-byte LNA codes (as the timed configs[2] step left them on the
+    device) that equal the oracle's restatement of phone_probs on the same audio and model."""
+    from oracle import oracle as O
+    from aaltoasr_amd import capi as A
+    O.build()
+    u = 1
+    ch = O.FeatureChain(runner.cfg_text)
+    om = O.DiagModel(mean, var, off, idx, w)
+    nfr = int(runner.frame_off[u + 1] - runner.frame_off[u])
+    fea = ch.generate(runner.utts[u], 0, nfr)
+    _, lik = om.score(fea, want_lik=True)
+    _, by_ref = O.lna_encode(lik, True, 2)
+    got = runner.d_bytes[int(runner.frame_off[u]):int(runner.frame_off[u + 1])].cpu().numpy()
+    a = got.reshape(nfr, S, 2).astype(np.int32)
+    b = np.asarray(by_ref).reshape(nfr, S, 2).astype(np.int32)
+    ca, cb = a[..., 0] * 256 + a[..., 1], b[..., 0] * 256 + b[..., 1]
+    out = {"utterance": u, "frames": nfr, "codes_equal_fraction": round(float((ca == cb).mean()), 6),
+           "max_code_difference": int(np.abs(ca - cb).max()),
+           "against": "oracle restatement of phone_probs (double), same audio and model"}
+    # the same utterance with the engine in AASR_PREC_F64 (the reference's arithmetic in double): what
+    # is left of the difference above when float rounding is taken away
+    try:
+        gmm.set_precision(1)
+        data, n64 = A.run_utterance(runner.feat, gmm, runner.utts[u], lnabytes=2)
+        c = np.frombuffer(data[5:], np.uint8).reshape(n64, S, 2).astype(np.int32)
+        out["codes_equal_fraction_f64_mode"] = round(float(((c[..., 0] * 256 + c[..., 1]) == cb).mean()), 6)
+    except Exception as e:
+        out["codes_equal_fraction_f64_mode"] = "failed: %s" % e
+    finally:
+        gmm.set_precision(restore_precision)
+    return out
+
+
+def _stage_rooflines(runner, split):
+    """The two HBM-bound stages of configs[2] against the 8 TB/s HBM peak, in ALGORITHMIC bytes
+    (SURVEY.md section 8d): feature chain 256 B of new samples in + 156 B of float features out per
+    frame; LNA pass S * (4 in + B out) bytes per frame."""
+    F = runner.total_frames
+    out = []
+    for name, kernels, bpf in (("features", "k_spectral_fused + k_temporal_fused + k_mean_subtract_tiled", 412),
+                               ("lna", "k_state_norm_lna", runner.S * (4 + runner.lnabytes))):
+        ms = split.get(name)
+        if not ms:
+            continue
+        gbs = F * bpf / (ms * 1e-3) / 1e9
+        out.append({"stage": name, "kernels": kernels, "bound": "hbm", "algorithmic_bytes_per_frame": bpf,
+                    "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "stage_ms": ms})
+    return out
+
+
+def _measure_configs1(torch, synth, gmm, rank, dev, stream, sync_all, max_over_ranks, world, args, steps=5):
+    """BASELINE configs[1] next to the headline: 1 000 000 resident frames x 50 000 Gaussians, scoring only."""
+    F = args.frames
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(synth.SEED + 17 * rank)
+    d_frames = torch.randn((F, DIM), generator=gen, device=dev, dtype=torch.float32)
+    pitch = (S + 31) // 32 * 32 if (args.out_pitch == "aligned" and gmm.score_pitch_ok()) else S
+    d_out = torch.empty((F, pitch), device=dev, dtype=torch.float32)
+
+    def step():
+        if pitch == S:
+            gmm.score_dev(d_frames, d_out, stream)
+        else:
+            gmm.score_dev_pitched(d_frames, d_out, pitch, stream)
+    step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync_all()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    ms = 1e3 * elapsed / steps
+    flop = 4.0 * DIM * float(F) * float(gmm.expanded_rows)
+    return {"workload": "configs[1]: batched diag-GMM log-likelihood only, %d x %d-d frames x %d Gaussians per rank, "
+                        "output row pitch %d floats" % (F, DIM, G, pitch),
+            "frames_per_gpu_per_step": F, "steps": steps, "ms_per_step": round(ms, 4),
+            "frames_per_s": round(world * F * steps / elapsed, 1),
+            "algorithmic_TFLOPs": round(flop / (ms * 1e-3) / 1e12, 2)}
+
+
 def _measure_configs2(torch, capi, synth, gmm, rank, dev, stream, sync_all, max_over_ranks, world,
                       mean, var, off, idx, w, restore_precision=3):
-    """BASELINE configs[2] next to the headline: 360 x 10 s utterances per rank, MFCC chain +
+    """BASELINE configs[2] next to a `--workload gmm` run: 360 x 10 s utterances per rank, MFCC chain +
     scoring + 2-byte LNA on the device; ms/step (max over ranks), per-stage split from HIP events,
     and on rank 0 the fraction of one utterance's LNA bytes that equal the oracle's."""
     from aaltoasr_amd import pipeline
     runner = pipeline.FullChainBench(gmm, n_utts=360, seconds=10.0, rank=rank, device=dev)
-    steps = 3
+    steps = 5
     runner.step()
     sync_all()
     t0 = time.perf_counter()
@@ -564,33 +670,7 @@ def _measure_configs2(torch, capi, synth, gmm, rank, dev, stream, sync_all, max_
            "stage_ms": split,
            "hbm_bytes_written_per_frame": runner.bytes_written_per_frame()}
     if rank == 0:
-        from oracle import oracle as O
-        O.build()
-        u = 1
-        ch = O.FeatureChain(runner.cfg_text)
-        om = O.DiagModel(mean, var, off, idx, w)
-        nfr = int(runner.frame_off[u + 1] - runner.frame_off[u])
-        fea = ch.generate(runner.utts[u], 0, nfr)
-        _, lik = om.score(fea, want_lik=True)
-        _, by_ref = O.lna_encode(lik, True, 2)
-        got = runner.d_bytes[int(runner.frame_off[u]):int(runner.frame_off[u + 1])].cpu().numpy()
-        a = got.reshape(nfr, S, 2).astype(np.int32)
-        b = np.asarray(by_ref).reshape(nfr, S, 2).astype(np.int32)
-        ca, cb = a[..., 0] * 256 + a[..., 1], b[..., 0] * 256 + b[..., 1]
-        out["lna_check"] = {"utterance": u, "frames": nfr, "codes_equal_fraction": round(float((ca == cb).mean()), 6),
-                            "max_code_difference": int(np.abs(ca - cb).max()),
-                            "against": "oracle restatement of phone_probs (double), same audio and model"}
-        # the same utterance with the engine in AASR_PREC_F64 (the reference's arithmetic in double): what
-        # is left of the difference above when float rounding is taken away
-        try:
-            from aaltoasr_amd import capi as A
-            gmm.set_precision(1)
-            data, n64 = A.run_utterance(runner.feat, gmm, runner.utts[u], lnabytes=2)
-            gmm.set_precision(restore_precision)
-            c = np.frombuffer(data[5:], np.uint8).reshape(n64, S, 2).astype(np.int32)
-            out["lna_check"]["codes_equal_fraction_f64_mode"] = round(float(((c[..., 0] * 256 + c[..., 1]) == cb).mean()), 6)
-        except Exception as e:
-            out["lna_check"]["codes_equal_fraction_f64_mode"] = "failed: %s" % e
+        out["lna_check"] = _lna_check(runner, gmm, mean, var, off, idx, w, restore_precision)
     return out
 
 

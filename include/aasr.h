@@ -481,6 +481,33 @@ aasr_status aasr_run_recipe(aasr_feat *feat, aasr_gmm *gmm,
                             const char *recipe_path,
                             const aasr_run_options *opt, aasr_run_stats *stats);
 
+/* One engine process per GPU: `processes` of them share this host's cores.  The reference scales
+ * out the same way -- N independent phone_probs processes on recipe slices (-B n -I k,
+ * aku/Recipe.cc:63-115, aku/phone_probs.cc:136-141) -- each single-threaded; here a process runs
+ * reader / writer helper threads, and their number is usable_cores / processes (0 = take
+ * AASR_LOCAL_RANKS or torchrun's LOCAL_WORLD_SIZE from the environment, else 1). */
+aasr_status aasr_set_host_share(int32_t processes);
+/* cores this process may use: affinity mask capped by the cgroup CPU quota */
+int32_t aasr_host_usable_cores(void);
+
+/* Where the last aasr_run_recipe on this model handle spent its wall time (seconds): what the
+ * calling thread waited for, what the two device streams were busy with, and the helper-thread
+ * sizing that was in force.  Diagnostics for multi-rank runs; the reference has no counterpart
+ * (its loop is serial, aku/phone_probs.cc:145-267). */
+typedef struct aasr_recipe_timing {
+  double seconds_total;
+  double wait_reader;       /* calling thread idle: next utterance not read yet           */
+  double wait_result_slot;  /* ... idle: both pinned result slots still being written out */
+  double enqueue;           /* ... enqueueing a block (incl. pageable uploads)            */
+  double wait_copies;       /* ... waiting for a block's device -> host copy              */
+  double device;            /* compute stream busy (upload + features + scoring + LNA)    */
+  double copy_out;          /* copy stream busy (packed rows device -> host)              */
+  int32_t writer_threads;
+  int32_t usable_cores;
+  int32_t host_share;
+} aasr_recipe_timing;
+aasr_status aasr_recipe_last_timing(const aasr_gmm *gmm, aasr_recipe_timing *out);
+
 /* PPToolbox::generate_from_file_to_fd equivalent for one utterance
  * (aku/PhoneProbsToolbox.cc:135-208: lnabytes 2, normalised): returns a
  * malloc'ed LNA image (header + frames) the caller frees with aasr_free. */

@@ -34,6 +34,37 @@ def golden_dir():
     return GOLDEN
 
 
+TOL_LL = 1e-4                     # north_star: LNA log-likelihoods within 1e-4 of the reference CPU path
+LL_FLUSH = -150.0 * 0.6931471805599453   # ln 2^-150: below it the reference's float storage of the
+                                         # likelihood (phone_probs.cc:224-236) holds 0.0 and the LNA entry is the floor
+CODES_EQUAL_MIN = 0.98            # 2-byte code equality: never more than one step apart, and at least this share
+                                  # identical (a different v_exp_f32 / libm rounding moves a fraction of a per cent)
+
+
+def assert_ll(got, want, what=""):
+    """The parity contract on state log-likelihoods: |got - want| <= 1e-4 wherever the reference's
+    float storage of the likelihood holds a value (ll > ln 2^-150).  Below that the reference emits
+    the floor whatever the digits of ll, so there the assertion is the observable one: the engine's
+    value flushes as well -- as a float likelihood it is 0 or at most the one denormal quantum that a
+    1e-4 move across the edge produces."""
+    import numpy as np
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert np.isfinite(got).all(), what
+    err = np.abs(got - want)
+    vis = want > LL_FLUSH
+    if vis.any():
+        worst = err[vis].max()
+        assert worst <= TOL_LL, "%s: max |dll| %.3g at %s" % (
+            what, worst, np.unravel_index(np.where(vis, err, -1.0).argmax(), err.shape))
+    if (~vis).any():
+        lik32 = np.exp(got[~vis]).astype(np.float32)
+        assert (lik32 <= np.float32(2.0 ** -149)).all(), \
+            "%s: a value the reference flushes to the floor is visible here (max ll %.6f)" % (what, got[~vis].max())
+    return float(err[vis].max()) if vis.any() else 0.0
+
+
 def observed(label, value, bound):
     """Assert `value >= bound` and, with AASR_PRINT_OBSERVED=1, print what was observed (used to keep
     the thresholds of the LNA code-equality tests at what the hardware actually delivers)."""

@@ -335,10 +335,10 @@ def test_distributions_surface(capi, oracle, world):
         vals = np.array([[float(x) for x in l.split()] for l in lines[pos:pos + S]])
         ll_ref, lik_ref = om.score(fea[f:f + 1], want_lik=True)
         lik_ref = np.maximum(lik_ref[0], 1e-50)
-        assert np.allclose(vals[:, 0], lik_ref, rtol=2e-4)            # Mixture::compute_likelihood
+        assert np.allclose(vals[:, 0], lik_ref, rtol=1.0001e-4, atol=0)  # = 1e-4 on the logarithm; Mixture::compute_likelihood
         assert np.abs(vals[:, 1] - np.log(lik_ref)).max() <= 1e-4     # compute_log_likelihood
         assert np.array_equal(vals[:, 0], vals[:, 2])                 # == HmmSet::state_likelihood
-        assert np.allclose(vals[:, 3], lik_ref, rtol=2e-4)            # sum_k w_k N_k by hand
+        assert np.allclose(vals[:, 3], lik_ref, rtol=1.0001e-4, atol=0)  # sum_k w_k N_k by hand
         assert np.allclose(vals[:, 4], vals[:, 0], rtol=1e-5)         # a copy of the vector, scored alone
         g0, m0, c_last, lik_g0 = lines[pos + S].split()
         assert int(g0) == idx[off[0]] and float(m0) == mean[int(g0), 0] and float(c_last) == var[int(g0), -1]

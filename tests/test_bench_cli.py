@@ -35,12 +35,20 @@ import json
 import pytest
 
 
+def _have_device():
+    import torch
+    return torch.cuda.is_available() and torch.cuda.device_count() > 0
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("args,key", [(["--frames", "40000", "--steps", "2", "--warmup", "1", "--cpu-frames", "200", "--cpu-procs", "2"], "configs2"),
-                                      (["--workload", "full", "--utts", "24", "--steps", "2", "--warmup", "1", "--cpu-frames", "0"], None),
+@pytest.mark.parametrize("args,key", [(["--utts", "24", "--frames", "40000", "--steps", "2", "--warmup", "1", "--cpu-frames", "200", "--cpu-procs", "2"], "default"),
+                                      (["--workload", "gmm", "--frames", "40000", "--steps", "2", "--warmup", "1", "--cpu-frames", "0"], "gmm"),
                                       (["--workload", "recipe", "--utts", "40", "--steps", "1", "--warmup", "1", "--cpu-frames", "0"], "recipe")])
 def test_bench_line_on_a_gpu(args, key):
-    """One JSON line on stdout with the contract's keys, for each workload (small sizes)."""
+    """One JSON line on stdout with the contract's keys, for each workload (small sizes).  The default
+    workload is BASELINE configs[2] -- the metric's own "GMM log-lik + MFCC" chain."""
+    if not _have_device():
+        pytest.skip("no HIP device on this host (bench.py has no CPU fallback)")
     r = _run(args)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -50,10 +58,19 @@ def test_bench_line_on_a_gpu(args, key):
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["unit"] == "frames/s" and "workload" in d["config"]
-    if args[0] != "--workload":
+    if key == "default":
+        assert d["config"]["workload"].startswith("configs[2]")
         assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+        stages = {e["stage"]: e for e in d["roofline"]["stages"]}
+        assert set(stages) == {"features", "lna"}
+        assert all(e["bound"] == "hbm" and 0 < e["frac"] < 1 for e in stages.values())
         assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
-        assert "error" not in d["config"]["configs2"] and "error" not in d["config"]["recipe_e2e"]
+        assert "error" not in d["config"]["configs1"] and "error" not in d["config"]["recipe_e2e"]
+        assert d["config"]["configs1"]["frames_per_s"] > 0
+        assert d["config"]["lna_check"]["max_code_difference"] <= 1
+    if key == "gmm":
+        assert d["config"]["workload"].startswith("configs[1]")
+        assert "error" not in d["config"]["configs2"]
         assert d["config"]["configs2"]["lna_check"]["max_code_difference"] <= 1
     if key == "recipe":
         assert d["scaling"] == "strong" and d["config"]["recipe"]["utterances"] == 40

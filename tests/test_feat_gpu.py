@@ -174,8 +174,10 @@ module
         got = ft.run(pcm, -3, 110, module=name, dtype=np.float64)
         scale = max(1.0, np.abs(want[np.isfinite(want)]).max())
         both = np.isfinite(want) & np.isfinite(got)
+        # the non-finite pattern (log of an empty mel bin) is asserted equal, the finite entries to FEAT_TOL
         assert (np.isfinite(want) == np.isfinite(got)).all(), name
-        assert np.abs(got - want)[both].max() <= 1e-5 * scale, name
+        assert np.array_equal(want[~both], got[~both], equal_nan=True), name
+        assert np.abs(got[both] - want[both]).max() <= FEAT_TOL * scale, name
 
 
 @pytest.mark.parametrize("rate,frame_rate,width", [(16000, 100, 0), (16000, 100, 400), (8000, 100, 200),

@@ -6,6 +6,8 @@ rows summing to one, LNA codes consistent with their own log-probabilities)."""
 import numpy as np
 import pytest
 
+from conftest import CODES_EQUAL_MIN, LL_FLUSH, TOL_LL, assert_ll
+
 from aaltoasr_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -121,7 +123,7 @@ def test_config2_one_hour_full_chain(capi, oracle):
         smooth = (ll_ref > -87.0) | (ll_ref < -104.5)     # outside the float-denormal band
         assert np.abs(lp - lp_ref)[smooth].max() <= 1e-4
     print("configs[2] LNA codes identical to the oracle's:", equal_frac)
-    assert min(equal_frac) >= 0.994
+    assert min(equal_frac) >= CODES_EQUAL_MIN     # observed 0.9950; never more than one step apart (above)
     for u in range(360):
         data, n = capi.run_utterance(runner.feat, gmm, utts[u], lnabytes=2)
         assert n == 1248
@@ -201,10 +203,13 @@ def test_config4_full_covariance_at_workload_size(capi, oracle):
     ref = oracle.FullModel(mean, cov, off, idx, w).score(frames[pick].astype(np.float64))
     for name in outs:
         got = outs[name][pick.tolist()].cpu().numpy()
-        vis = ref > -103.97
-        err = np.abs(got - ref)
-        assert err[vis].max() <= 1e-4 and err.max() <= 2e-4, "%s: %.3g / %.3g" % (name, err[vis].max(), err.max())
-    assert (outs["f32"] - outs["bf16x3"]).abs().max().item() <= 2e-4
+        assert_ll(got, ref, name)
+    # the two arithmetics against each other over the whole block, same contract: where the f32 kernel's value
+    # is one the reference's float storage holds they agree to 1e-4, elsewhere both flush
+    a, b = outs["f32"], outs["bf16x3"]
+    vis = a > LL_FLUSH
+    assert ((a - b).abs() * vis).max().item() <= TOL_LL
+    assert (b[~vis] <= LL_FLUSH + 1.1).all()     # at most the one denormal quantum
     for name, prec in (("f32", 0), ("bf16x3", 3)):
         g.set_precision(prec)
         for lo, hi in ((0, 1), (511, 1025), (Fc - 777, Fc)):
@@ -246,14 +251,16 @@ def test_config1_one_million_frames(capi, oracle):
     ref = oracle.DiagModel(*model).score(frames.astype(np.float64))
     for name in outs:
         got = outs[name][pick.tolist(), :S].cpu().numpy()
-        err = np.abs(got - ref)
-        vis = ref > -103.97
-        assert err[vis].max() <= 1e-4 and err.max() <= 2e-4, (name, err[vis].max(), err.max())
+        assert_ll(got, ref, name)
     # chunked comparison of the two arithmetics (12.5 GB each: never both as one temporary)
+    # same contract as against the oracle: 1e-4 wherever the value is one the reference's float storage holds
     worst = 0.0
     for lo in range(0, Fm, 100_000):
-        worst = max(worst, (outs["f32"][lo:lo + 100_000, :S] - outs["bf16x3"][lo:lo + 100_000, :S]).abs().max().item())
-    assert worst <= 2e-4, worst
+        a, b = outs["f32"][lo:lo + 100_000, :S], outs["bf16x3"][lo:lo + 100_000, :S]
+        vis = a > LL_FLUSH
+        worst = max(worst, ((a - b).abs() * vis).max().item())
+        assert (b[~vis] <= LL_FLUSH + 1.1).all()
+    assert worst <= TOL_LL, worst
     g.set_precision(3)
     for lo, hi in ((0, 512), (499_999, 500_300), (Fm - 20_000, Fm)):
         d_sub = torch.empty((hi - lo, pitch), dtype=torch.float32, device="cuda")

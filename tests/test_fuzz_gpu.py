@@ -1,8 +1,8 @@
 """Fixed-seed slices of the randomised parity sweeps (tools/fuzz_parity.py, fuzz_features.py, fuzz_fullcov.py, fuzz_recipe.py, fuzz_speakers.py)
 as part of the suite, so that a discrepancy found by a sweep can never sit in a scratch log:
 every random model / feature graph of these seeds must agree with the oracle -- scores within
-1e-4 wherever the reference's float storage can hold the likelihood (2e-4 below its flush
-point, where the LNA output is the floor whatever the value: tests/test_lna_gpu.py), clustered
+1e-4 wherever the reference's float storage can hold the likelihood (below its flush point,
+where the LNA output is the floor whatever the value, the engine's value must flush too), clustered
 exact-evaluation counts bit for bit, model-side CMLLR (one global or per-class transforms, plain
 and clustered) likewise, feature modules to the per-module tolerance.  Seed 1 is
 the sweep whose iteration 26 had differing cluster counts in round 1 (tied empty clusters); seed

@@ -5,6 +5,8 @@ log-likelihoods (BASELINE.json north_star)."""
 import numpy as np
 import pytest
 
+from conftest import assert_ll
+
 from aaltoasr_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -18,7 +20,7 @@ TOL = 1e-4
 LAYOUTS = [7, 2, 0, 4]
 
 
-def _check(capi, oracle, model, frames, tol=TOL, layouts=LAYOUTS):
+def _check(capi, oracle, model, frames, layouts=LAYOUTS):
     mean, var, off, idx, w = model
     ref = oracle.DiagModel(mean, var, off, idx, w).score(frames.astype(np.float64))
     g = capi.Gmm.from_arrays(mean, var, off, idx, w)
@@ -29,22 +31,13 @@ def _check(capi, oracle, model, frames, tol=TOL, layouts=LAYOUTS):
         g.set_layouts(mask)
         used.add(g.active_layout())
         got = g.score(frames)
-        assert got.shape == ref.shape
-        assert np.isfinite(got).all()
-        err = np.abs(got.astype(np.float64) - ref)
-        assert err.max() <= tol, "layout %d (kernel %d): max |dll| %.3g at %s" % (
-            mask, g.active_layout(), err.max(), np.unravel_index(err.argmax(), err.shape))
-        worst = max(worst, err.max())
+        worst = max(worst, assert_ll(got, ref, "layout %d (kernel %d)" % (mask, g.active_layout())))
     # the bf16x3 split kernel on whichever track layout the model has
     g.set_layouts(7)
     if g.active_layout() in (1, 2):
         g.set_precision(3)
         got = g.score(frames)
-        err = np.abs(got.astype(np.float64) - ref)
-        assert np.isfinite(got).all()
-        assert err.max() <= tol, "bf16x3 on layout %d: max |dll| %.3g at %s" % (
-            g.active_layout(), err.max(), np.unravel_index(err.argmax(), err.shape))
-        worst = max(worst, err.max())
+        worst = max(worst, assert_ll(got, ref, "bf16x3 on layout %d" % g.active_layout()))
         g.set_precision(0)
     g.close()
     return worst, used
@@ -107,7 +100,7 @@ def test_floor_and_far_frames(capi, oracle):
     fr[:16] *= 3.0
     fr[16:32] *= 6.0
     fr[32:48] += 4.0
-    _check(capi, oracle, model, fr, tol=2e-4)
+    _check(capi, oracle, model, fr)
 
 
 def test_zero_variance_dimension(capi, oracle):
@@ -160,7 +153,7 @@ def test_ill_conditioned_model_takes_the_centred_kernel(capi, oracle):
     mean, var, off, idx, w = synth.make_model(D=39, G=64, S=8, comps=8, seed=21)
     var = var * 1e-3
     frames = (mean[np.arange(40) % 64] + 0.03 * synth.make_frames(40, seed=5)).astype(np.float32)
-    worst, used = _check(capi, oracle, (mean, var, off, idx, w), frames, tol=2e-4, layouts=[7, 4])
+    worst, used = _check(capi, oracle, (mean, var, off, idx, w), frames, layouts=[7, 4])
     assert used == {4}
 
 
@@ -294,7 +287,7 @@ def test_outlier_routing_keeps_the_model_on_the_matrix_path(capi, oracle):
             assert err.max() <= 1e-4, "prec %d layout %d: max |dll| %.3g at %s" % (
                 prec, mask, err.max(), np.unravel_index(err.argmax(), err.shape))
     g.set_layouts(4)                                   # the whole model in the centred form agrees too
-    assert np.abs(g.score(frames) - ref).max() <= 2e-4
+    assert_ll(g.score(frames), ref, "whole model in the centred form")
     g.close()
     # a majority of outliers: no routing, the centred kernel takes the model
     var2 = var.copy()
@@ -302,7 +295,7 @@ def test_outlier_routing_keeps_the_model_on_the_matrix_path(capi, oracle):
     g2 = capi.Gmm.from_arrays(mean, var2, off, idx, w)
     assert g2.active_layout() == 4
     ref2 = oracle.DiagModel(mean, var2, off, idx, w).score(frames.astype(np.float64))
-    assert np.abs(g2.score(frames) - ref2).max() <= 2e-4
+    assert_ll(g2.score(frames), ref2, "majority of outliers")
     g2.close()
 
 

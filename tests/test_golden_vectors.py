@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import observed
+from conftest import CODES_EQUAL_MIN, observed
 
 from aaltoasr_amd import synth
 
@@ -50,7 +50,7 @@ def test_engine_matches_committed_vectors(capi, vec, golden_dir, oracle):
             ref = vec["cfg0_lna2_bytes"].reshape(200, 32, 2).astype(np.int32)
             d = np.abs((code[..., 0] * 256 + code[..., 1]) - (ref[..., 0] * 256 + ref[..., 1]))[ok]
             assert d.max() <= 1
-            observed('golden_vectors codes equal', float((d == 0).mean()), 0.99)  # observed 0.9917
+            observed('golden_vectors codes equal', float((d == 0).mean()), CODES_EQUAL_MIN)  # observed 0.9917
     g = capi.Gmm.from_arrays(*synth.make_model(D=39, G=2048, S=128, tied=True, comps_range=(1, 23)))
     assert np.abs(g.score(synth.make_frames(120, seed=77)) - vec["tied_state_loglik"]).max() <= 1e-4
     model = synth.make_model(D=39, G=2048, S=128, comps=16)

@@ -37,7 +37,7 @@ def test_lna_matches_oracle(capi, oracle, normalize, nbytes):
     assert np.abs(lp - lp_ref)[ok].max() <= 1e-5
     # inside the band the quantum index may differ by one step at a rounding tie
     q = np.abs(lp - lp_ref)[~ok]
-    observed('lna denormal band within 1e-5', float((q <= 1e-5).mean()), 0.999)  # observed 1.0
+    observed('lna denormal band within 1e-5', float((q <= 1e-5).mean()), 0.99)  # observed 1.0
     if nbytes == 4:
         assert np.array_equal(by.view(np.float32), lp)
     else:
@@ -47,7 +47,7 @@ def test_lna_matches_oracle(capi, oracle, normalize, nbytes):
         cref = cref[..., 0] * 256 + cref[..., 1]
         d = np.abs(code - cref)[ok]
         assert d.max() <= 1                      # |dlp| 1e-5 * 1820 << 1 code
-        observed('lna codes equal nb%d norm%d' % (nbytes, normalize), float((d == 0).mean()), 0.9995)  # observed 1.0
+        observed('lna codes equal nb%d norm%d' % (nbytes, normalize), float((d == 0).mean()), 0.995)  # observed 1.0
     assert np.allclose(lp[6], LOG_TINY, atol=1e-5)
 
 
@@ -86,7 +86,7 @@ def test_every_kernel_instance_by_state_count(capi, oracle, S):
     cref = by_ref.reshape(F, S, 2).astype(np.int32)
     d = np.abs((code[..., 0] * 256 + code[..., 1]) - (cref[..., 0] * 256 + cref[..., 1]))
     assert d.max() <= 1
-    observed('lna codes equal S=%d' % S, float((d == 0).mean()), 0.9995)  # observed 0.99992 - 1.0
+    observed('lna codes equal S=%d' % S, float((d == 0).mean()), 0.995)  # observed 0.99992 - 1.0
 
 
 def test_persistent_workgroups_walk_many_frames(capi, oracle):
@@ -100,7 +100,7 @@ def test_persistent_workgroups_walk_many_frames(capi, oracle):
     pick[:3] = [0, F - 1, 8192]
     lp_ref, by_ref = _ref(oracle, ll[pick].astype(np.float64), True, 2)
     assert np.abs(lp[pick] - lp_ref).max() <= 1e-5
-    observed('lna bytes equal persistent', float((by[pick] == by_ref).mean()), 0.9995)  # observed 0.99998
+    observed('lna bytes equal persistent', float((by[pick] == by_ref).mean()), 0.995)  # observed 0.99998
     assert np.abs(np.exp(lp.astype(np.float64)).sum(axis=1) - 1.0).max() < 1e-4
 
 

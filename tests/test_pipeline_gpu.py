@@ -8,7 +8,7 @@ import wave
 import numpy as np
 import pytest
 
-from conftest import observed
+from conftest import CODES_EQUAL_MIN, observed
 
 from aaltoasr_amd import synth
 
@@ -63,7 +63,7 @@ def test_config1_utterance_lna(capi, oracle, setup, nbytes):
         cref = by_ref.reshape(623, 32, 2).astype(int)
         cref = cref[..., 0] * 256 + cref[..., 1]
         assert np.abs(code - cref).max() <= 1
-        observed('pipeline config1 codes equal', float((code == cref).mean()), 0.995)  # observed 0.9965: f32-class scores in front of the packing
+        observed('pipeline config1 codes equal', float((code == cref).mean()), CODES_EQUAL_MIN)  # observed 0.9965: f32-class scores in front of the packing
     dec = oracle.lna_decode(data)
     assert dec.shape == (623, 32)
 

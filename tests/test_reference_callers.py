@@ -138,7 +138,7 @@ def test_reference_phone_probs_main_on_the_engine(world, extra):
             x = np.frombuffer(a[5:], ">u2").astype(np.int64)
             y = np.frombuffer(b[5:], ">u2").astype(np.int64)
             assert np.abs(x - y).max() <= 1, n
-            observed('refmain codes equal ' + n, float((x == y).mean()), 0.9995)  # observed 1.0
+            observed('refmain codes equal ' + n, float((x == y).mean()), 0.995)  # observed 1.0
 
 
 @pytest.mark.gpu

@@ -1,7 +1,7 @@
 """Randomised sweep of the full-covariance path (k_gmm_full_score / _bf16x3) against oracle.FullModel:
 random dimensions, pool sizes, ragged / tied / zero-weight mixtures, covariance spectra spanning two
 decades, some non-SPD ("invalid") covariances, frames 0.5-2.5 sigma wide.  A failure is |dll| > 1e-4 on a
-state the reference's float storage can hold (ll > -103.97), > 2e-4 below.  `python tools/fuzz_fullcov.py
+state the reference's float storage can hold (ll > -103.97), or a value below that which would not flush there.  `python tools/fuzz_fullcov.py
 SEED N`; exits non-zero on a failure."""
 import os
 import sys
@@ -67,7 +67,9 @@ def run(seed=1, N=40, verbose=False):
             eall = float(d.max())
             worst[key] = max(worst.get(key, 0.0), evis)
             worst[key + " (all)"] = max(worst.get(key + " (all)", 0.0), eall)
-            if evis > 1e-4 or eall > 2e-4:
+            with np.errstate(under="ignore"):
+                flushes = (np.exp(got[~vis].astype(np.float64)).astype(np.float32) <= np.float32(2.0 ** -149)).all()
+            if evis > 1e-4 or not flushes:
                 at = int(d.argmax())
                 fails.append("%s %s err %.3g (visible %.3g) at ll %.2f (got %.2f)" % (
                     key, ctx, eall, evis, want.ravel()[at], got.ravel()[at]))

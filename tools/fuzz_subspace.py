@@ -52,11 +52,14 @@ def run(seed=1, N=20, verbose=False):
                     g.set_precision(prec)
                 except capi.AasrError:
                     continue
-                err = np.abs(g.score(frames) - ref)
+                got = g.score(frames)
+                err = np.abs(got - ref)
                 vis = ref > -103.97
                 evis = float(err[vis].max()) if vis.any() else 0.0
                 worst[kind] = max(worst[kind], evis)
-                if evis > 1e-4 or float(err.max()) > 2e-4:
+                with np.errstate(under="ignore"):
+                    flushes = (np.exp(got[~vis].astype(np.float64)).astype(np.float32) <= np.float32(2.0 ** -149)).all()
+                if evis > 1e-4 or not flushes:
                     fails.append("%s prec %d: %.3g (visible %.3g)" % (ctx, prec, float(err.max()), evis))
                     if verbose:
                         print("FAIL", fails[-1])
