@@ -1,0 +1,122 @@
+#!/usr/bin/env python
+"""exp_fp16_split.py -- the 2-term fp16 split (3 matrix products instead of the 6 of the 3-term bf16 split)
+judged at the level the parity contract is stated on: STATE log-likelihoods (round-2 review, item 5).
+
+Host emulation, no device: the expanded quadratic form of aaltoasr_amd/csrc/gmm_model.cc (pivot = mean of the
+pool means, K = 2 dim + 1, log2 units, mixture weight folded into the constant) with both operands carried as
+fp16 pairs hi + lo, the three products hi*hi, hi*lo, lo*hi accumulated in float32 (numpy's float32 matmul; the
+matrix cores round once per 16 products, this rounds more often, so the emulation is if anything pessimistic by
+the accumulation's share), then the mixture sum in double.  Reference: the same model in double, the reference's
+arithmetic (aku/Distributions.cc:1040-1062, 2078-2086).  The 3-term bf16 split is emulated the same way for
+comparison.
+
+Kill criterion (review): worst visible |d ll_state| > 5e-5 on 10^7 sampled states.
+
+    python tools/exp_fp16_split.py [frames=3200] [tied=0] [var_lo=0.25] [var_hi=4.0]
+"""
+import sys
+import os
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from aaltoasr_amd import synth  # noqa: E402
+
+LOG2E = 1.4426950408889634
+
+
+def split_fp16(x32, scale=1.0):
+    """x ~ (hi + lo) / scale with hi, lo fp16 (kept as float32 values)."""
+    xs = x32 * np.float32(scale)
+    hi = xs.astype(np.float16).astype(np.float32)
+    lo = (xs - hi).astype(np.float16).astype(np.float32)
+    return hi, lo
+
+
+def to_bf16(x32):
+    u = x32.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16     # round to nearest even
+    return r.astype(np.uint32).view(np.float32)
+
+
+def split_bf16x3(x32):
+    a1 = to_bf16(x32)
+    r = x32 - a1
+    a2 = to_bf16(r)
+    a3 = to_bf16(r - a2)
+    return a1, a2, a3
+
+
+def main():
+    F = int(sys.argv[1]) if len(sys.argv) > 1 else 3200
+    tied = bool(int(sys.argv[2])) if len(sys.argv) > 2 else False
+    var_lo = float(sys.argv[3]) if len(sys.argv) > 3 else 0.25
+    var_hi = float(sys.argv[4]) if len(sys.argv) > 4 else 4.0
+    D, G, S, COMPS = 39, 50000, 3125, 16
+    mean, var, off, idx, w = synth.make_model(D=D, G=G, S=S, comps=COMPS, tied=tied, var_lo=var_lo, var_hi=var_hi)
+    frames = synth.make_frames(F, D, seed=synth.SEED + 1234)
+    prec = 1.0 / var
+    c = 0.5 * np.log(prec).sum(1)                       # log sqrt(prod p), Distributions.cc:1273-1288
+    pivot = mean.mean(0)
+    mu = mean - pivot
+    # component-expanded rows [K_rows = sum comps][2 D + 1], log2 units, weight folded in
+    a_lin = (prec * mu * LOG2E)[idx]
+    a_quad = (-0.5 * prec * LOG2E)[idx]
+    const = ((c - 0.5 * (prec * mu * mu).sum(1))[idx] + np.log(w)) * LOG2E
+    kappa = (prec * mu * mu).sum(1).max()
+    A = np.concatenate([a_lin, a_quad, const[:, None]], 1).astype(np.float32)      # [rows][79]
+    xp = (frames.astype(np.float64) - pivot).astype(np.float32)
+    B = np.concatenate([xp, xp * xp, np.ones((F, 1), np.float32)], 1)              # [F][79]
+    # scale the quadratic columns so that x'^2 sits where fp16 has its full 11 bits (a power of two: exact)
+    Ah, Al = split_fp16(A)
+    Bh, Bl = split_fp16(B)
+    A1, A2, A3 = split_bf16x3(A)
+    B1, B2, B3 = split_bf16x3(B)
+    ln2 = 1.0 / LOG2E
+    worst = {"fp16x2": 0.0, "bf16x3": 0.0, "f32": 0.0}
+    worst_g = dict(worst)
+    n_states = 0
+    vis_cut = -103.97
+    hist = {k: np.zeros(8, np.int64) for k in worst}
+    edges = np.array([0, 1e-6, 3e-6, 1e-5, 2e-5, 3e-5, 5e-5, 1e-4, np.inf])
+    for lo in range(0, F, 200):
+        hi = min(F, lo + 200)
+        x64 = frames[lo:hi].astype(np.float64)
+        # reference: per component ll in double, then the linear mixture sum
+        ll_ref = np.empty((hi - lo, len(idx)))
+        for r0 in range(0, len(idx), 10000):
+            g = idx[r0:r0 + 10000]
+            d = x64[:, None, :] - mean[g][None]
+            ll_ref[:, r0:r0 + 10000] = c[g] - 0.5 * (d * d * prec[g][None]).sum(2) + np.log(w[r0:r0 + 10000])
+        def state(llc):                                  # natural-log component scores incl. log w -> state ll
+            m = np.maximum.reduceat(llc, off[:-1], axis=1)
+            e = np.exp(llc - np.repeat(m, np.diff(off), axis=1))
+            return m + np.log(np.add.reduceat(e, off[:-1], axis=1))
+        st_ref = np.maximum(state(ll_ref), np.log(1e-50))
+        vis = st_ref > vis_cut
+        n_states += int(vis.sum())
+        got = {
+            "fp16x2": (Bl[lo:hi] @ Ah.T + Bh[lo:hi] @ Al.T) + Bh[lo:hi] @ Ah.T,
+            "bf16x3": ((B1[lo:hi] @ A3.T + B2[lo:hi] @ A2.T + B3[lo:hi] @ A1.T) + (B1[lo:hi] @ A2.T + B2[lo:hi] @ A1.T))
+                      + B1[lo:hi] @ A1.T,
+            "f32": B[lo:hi] @ A.T,
+        }
+        for k, v in got.items():
+            llc = v.astype(np.float64) * ln2
+            pair_vis = ll_ref > -115.0
+            worst_g[k] = max(worst_g[k], float(np.abs(llc - ll_ref)[pair_vis].max()))
+            st = np.maximum(state(llc), np.log(1e-50))
+            e = np.abs(st - st_ref)[vis]
+            worst[k] = max(worst[k], float(e.max()))
+            hist[k] += np.histogram(e, edges)[0]
+        print("frames %5d  states %9d  worst state |dll|  fp16x2 %.3g  bf16x3 %.3g  f32 %.3g   (per component: %.3g / %.3g / %.3g)"
+              % (hi, n_states, worst["fp16x2"], worst["bf16x3"], worst["f32"], worst_g["fp16x2"], worst_g["bf16x3"],
+                 worst_g["f32"]), flush=True)
+    print("model: tied=%s var in [%.3g, %.3g], kappa = %.1f" % (tied, var_lo, var_hi, kappa))
+    print("error histogram over visible states, bin edges", list(edges))
+    for k in hist:
+        print("  %-7s" % k, list(hist[k]))
+
+
+if __name__ == "__main__":
+    main()
