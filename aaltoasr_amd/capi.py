@@ -173,6 +173,7 @@ def _declare(L: C.CDLL) -> None:
     L.aasr_audio_decode.argtypes = [vp, vp, i64, C.POINTER(C.POINTER(C.c_int16)), C.POINTER(i64), C.POINTER(i32)]
     L.aasr_gmm_score_f64.argtypes = [vp, vp, i64, vp]
     L.aasr_gmm_get_precision.argtypes = [vp]
+    L.aasr_gmm_effective_precision.argtypes = [vp]
     L.aasr_free.argtypes = [vp]
     L.aasr_free.restype = None
     L.aasr_feat_get_parameters.argtypes = [vp, cp, C.POINTER(C.c_void_p), C.POINTER(i64)]
@@ -357,8 +358,13 @@ class Gmm:
         return L.aasr_debug_cluster_tie_frames(self._h)
 
     def set_precision(self, prec: int) -> None:
-        """0 = f32, 2 = f32 centred form, 3 = bf16x3 split (default)."""
+        """0 = f32, 1 = f64, 2 = f32 centred form, 3 = bf16x3 split, 4 = f16x2 split where the model is
+        eligible, else bf16x3 (default)."""
         check(lib().aasr_gmm_set_precision(self._h, prec))
+
+    def effective_precision(self) -> int:
+        """The arithmetic the diagonal scoring path actually runs under the current setting."""
+        return int(lib().aasr_gmm_effective_precision(self._h))
 
     def set_layouts(self, mask: int) -> None:
         """Diagnostic: restrict the scoring kernels the launcher may pick (bit 0

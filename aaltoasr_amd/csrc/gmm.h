@@ -91,6 +91,14 @@ constexpr double KAPPA_LIMIT = 600.0;
 // (low-dimensional models above all) reaches the tolerance at a much smaller sum.  Fuzz seed 104
 // iteration 247: D = 1, kappa 416, a frame 12 sigma out (ll = -71.2), 1.18e-4 in the expanded form.
 constexpr double KAPPA2_LIMIT = 200.0;
+// The two-term fp16 split (AASR_PREC_F16X2) carries 22 bits per operand instead of 24: its error in the
+// expanded form is 1.4-1.8x that of the bf16x3 / f32 forms at the same conditioning (tools/exp_fp16_split.py:
+// 3.4e-5 against 1.9e-5 on 10^7 states at kappa 165; 1.24e-4 against 8.6e-5 at kappa 885), so a layout is
+// packed for it only when every Gaussian on the matrix path stays below limits tighter by that factor.
+constexpr double KAPPA_LIMIT_F16 = 330.0;
+constexpr double KAPPA2_LIMIT_F16 = 110.0;
+// |x - pivot| beyond this is clamped in the f16x2 kernel's frame operand (the square must stay below 65504)
+constexpr float kF16Clamp = 240.0f;
 
 // Kernel instances exist for these K/2 values; a model uses the smallest one
 // that holds dim+1 (zero-padded beyond).
@@ -124,6 +132,10 @@ struct TrackLayout {
   // the same rows split into three bf16 terms for k_gmm_diag_score_bf16x3:
   // [tile][K/16 slabs][3 splits][2 row blocks][64 lanes][8 bf16]
   DevBuf<uint16_t> a16;
+  // ... and into two fp16 terms for the f16x2 form of the same kernel (AASR_PREC_F16X2), only when the rows
+  // are eligible (conditioning below KAPPA_LIMIT_F16, values and clamp inside the fp16 range):
+  // [tile][K/16 slabs][2 splits][2 row blocks][64 lanes][8 fp16]; the constant rides in K slots dim and KH + dim
+  DevBuf<uint16_t> a16h;
   int nk16 = 0;              // K/16 (K = 2*KH, KH = 8*nk16 >= dim+1)
   DevBuf<uint16_t> close;    // per tile: bit p (+8 for track 1) = a state closes after quad p
   DevBuf<int32_t> sid;       // [2][sid_stride] state index of the k-th close on each track
@@ -209,7 +221,8 @@ struct aasr_gmm {
   int device = 0;
   int dim = 0;
   int64_t G = 0, S = 0;
-  int precision = AASR_PREC_BF16X3;  // default: the kernel bench.py reports (falls back to f32 rows where no bf16 layout exists)
+  int precision = AASR_PREC_F16X2;  // default: the kernel bench.py reports -- two fp16 terms where the model's conditioning
+                                    // allows it, three bf16 terms otherwise (f32 rows where no split layout exists)
   aasr::HostModel host;             // kept for lazy f64 build / adapters
   std::vector<float> pivot;         // per-dimension centring pivot
   aasr::DevBuf<float> d_pivot;
@@ -224,7 +237,8 @@ struct aasr_gmm {
   aasr::FullLayout full;
   int num_cus = 0;
   int layout_mask = 7;        // see aasr_debug_set_layouts()
-  bool use_bf16x3 = true;     // score with the 3-way bf16 split kernel (AASR_PREC_BF16X3)
+  bool use_bf16x3 = true;     // score with the split-operand kernels (AASR_PREC_BF16X3 / AASR_PREC_F16X2)
+  double kappa_matrix = 0, kappa2_matrix = 0;  // conditioning estimates over the Gaussians that stay on the matrix path
   // centred-form (numerically safe) kernel operands
   bool centred_ok = false, ill_conditioned = false;
   double kappa = 0;           // conditioning estimate of the expanded form

@@ -589,8 +589,8 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
   // profiling hook: AASR_LAYOUTS=<mask> restricts the kernels like
   // aasr_debug_set_layouts (1 grouped, 2 independent tracks, 4 centred, 0 general)
   if (const char *e = getenv("AASR_PREC")) {
-    g->use_bf16x3 = atoi(e) == AASR_PREC_BF16X3;
-    g->precision = g->use_bf16x3 ? AASR_PREC_BF16X3 : AASR_PREC_F32;
+    g->use_bf16x3 = atoi(e) == AASR_PREC_BF16X3 || atoi(e) == AASR_PREC_F16X2;
+    g->precision = g->use_bf16x3 ? atoi(e) : AASR_PREC_F32;
     if (atoi(e) == AASR_PREC_F64 && !m.any_full()) g->precision = AASR_PREC_F64;  // the tools' switch to the reference's arithmetic
   }
   if (const char *e = getenv("AASR_LAYOUTS")) {
@@ -740,6 +740,77 @@ static void pack_bf16x3(int D, const std::vector<double> &coef64, int64_t tiles,
   L.nk16 = nk16;
 }
 
+// Two-term fp16 split of the same rows for the f16x2 form (AASR_PREC_F16X2): same K order and tile layout with two
+// splits; the constant's remainder after its two terms goes to K slot KH + D (the frame operand is 1 there too).
+// Returns false -- and packs nothing -- when a value leaves the fp16 range, or when a frame component clamped at
+// kF16Clamp from the pivot could still be visible above the 1e-50 floor for some row (the clamp must never change
+// a result the reference's float storage holds).
+static bool pack_f16x2(const aasr_gmm *g, const std::vector<RowSpec> &rows, const std::vector<double> &coef64,
+                       int64_t tiles, TrackLayout &L) {
+  const HostModel &m = g->host;
+  const int D = m.dim;
+  const int nk16 = L.nk16;
+  L.a16h = DevBuf<uint16_t>();
+  if (nk16 <= 0) return false;
+  const int KH = 8 * nk16;
+  if (KH + D >= 2 * KH) return false;  // no spare slot for the constant's remainder
+  const size_t tile_elems = (size_t)nk16 * 2 * 2 * 64 * 8;
+  std::vector<uint16_t> a((size_t)tiles * tile_elems, 0);
+  const size_t stride = 2 * (size_t)D + 1;
+  auto bits = [](_Float16 h) {
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+  };
+  for (int64_t r = 0; r < tiles * TILE_ROWS; r++) {
+    const double *c = &coef64[(size_t)r * stride];
+    const RowSpec &rs = rows[(size_t)r];
+    if (rs.g >= 0) {
+      // clamp guarantee: peak - 1/2 p (clamp - |mu'|)^2 far below the floor in every dimension
+      double prod = 1;
+      for (int d = 0; d < D; d++) {
+        const double v = m.var[(size_t)rs.g * D + d];
+        prod *= v > 0 ? 1 / v : 0;
+      }
+      const double peak = (prod > 0 ? std::log(std::sqrt(prod)) : prod) + rs.logw;
+      for (int d = 0; d < D; d++) {
+        const double v = m.var[(size_t)rs.g * D + d];
+        const double p = v > 0 ? 1 / v : 0;
+        const double reach = (double)kF16Clamp - std::fabs(m.mean[(size_t)rs.g * D + d] - (double)g->pivot[d]);
+        if (!(reach > 0) || !(peak - 0.5 * p * reach * reach < -160.0)) return false;
+      }
+    }
+    const int64_t t = r / TILE_ROWS;
+    const int jrow = (int)(r % TILE_ROWS);
+    const int mb = jrow / 32, m32 = jrow % 32;
+    double const_rem = 0;
+    for (int k = 0; k < 2 * KH; k++) {
+      double v = 0;
+      if (k < KH) {
+        if (k < D) v = c[2 * k];
+        else if (k == D) v = c[2 * D];
+      } else if (k - KH < D) {
+        v = c[2 * (k - KH) + 1];
+      } else if (k - KH == D) {
+        v = const_rem;
+      }
+      if (!(std::fabs(v) < 60000.0)) return false;
+      const _Float16 h1 = (_Float16)v;
+      const _Float16 h2 = (_Float16)(v - (double)h1);
+      if (k == D) const_rem = (v - (double)h1) - (double)h2;
+      const uint16_t hs[2] = {bits(h1), bits(h2)};
+      const int slab = k / 16, hk = (k % 16) / 8, i = k % 8;
+      const int lane = hk * 32 + m32;
+      for (int sp = 0; sp < 2; sp++) {
+        size_t idx = (size_t)t * tile_elems + ((((size_t)slab * 2 + sp) * 2 + mb) * 64 + lane) * 8 + i;
+        a[idx] = hs[sp];
+      }
+    }
+  }
+  L.a16h.upload(a.data(), a.size());
+  return true;
+}
+
 static inline int64_t track_row(int64_t pos, int h, int e) {
   // quad position `pos` of track h, element e -> row in the tile-major layout
   int64_t t = pos / 8;
@@ -857,6 +928,11 @@ void gmm_build_tracks(aasr_gmm *g, bool grouped) {
   std::vector<double> coef64;
   pack_rows(g, rows, L.rows, &coef64);
   pack_bf16x3(m.dim, coef64, tiles, L);
+  static const int f16_env = getenv("AASR_F16X2") ? atoi(getenv("AASR_F16X2")) : 1;   // 0: never pack the f16x2 form
+  if (f16_env && g->kappa_matrix <= KAPPA_LIMIT_F16 && g->kappa2_matrix <= KAPPA2_LIMIT_F16)
+    pack_f16x2(g, rows, coef64, tiles, L);
+  else
+    L.a16h = DevBuf<uint16_t>();
   L.rows.rows = (int64_t)m.mix_idx.size();  // real rows (algorithmic work)
   close_mask.push_back(0);  // the kernels read the bits as aligned 32-bit words (scalar loads)
   L.close.upload(close_mask.data(), close_mask.size());
@@ -938,7 +1014,7 @@ static void find_outliers(aasr_gmm *g) {
   g->hyb_enabled = false;
   g->hyb_states = g->hyb_rows = 0;
   std::vector<uint8_t> bad((size_t)m.G, 0);
-  double kappa = 0;
+  double kappa = 0, kappa_in = 0, kappa2_in = 0;
   bool any_bad = false;
   for (int64_t i = 0; i < m.G; i++) {
     double k = 0, k2 = 0;
@@ -952,8 +1028,14 @@ static void find_outliers(aasr_gmm *g) {
     kappa = std::max(kappa, k);
     bad[(size_t)i] = k > KAPPA_LIMIT || std::sqrt(k2) > KAPPA2_LIMIT;
     any_bad = any_bad || bad[(size_t)i];
+    if (!bad[(size_t)i]) {
+      kappa_in = std::max(kappa_in, k);
+      kappa2_in = std::max(kappa2_in, std::sqrt(k2));
+    }
   }
   g->kappa = kappa;
+  g->kappa_matrix = kappa_in;
+  g->kappa2_matrix = kappa2_in;
   g->ill_conditioned = any_bad;
   const int dimp = centred_dimp_for(D);
   static const int routing = getenv("AASR_OUTLIER_ROUTING") ? atoi(getenv("AASR_OUTLIER_ROUTING")) : 1;

@@ -664,9 +664,40 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &p1, un
   p3 = a3 | (b3 << 16);
 }
 
-template <int NK16, bool GROUPED, bool WIDE = false>
+// ---------------------------------------------------------------------------
+// f16x2 variant (AASR_PREC_F16X2): the same kernel with both operands carried as TWO fp16 terms
+// (hi = fp16(x), lo = fp16(x - hi): 22 significant bits) and the three products hi*hi, hi*lo, lo*hi
+// accumulated in f32 by v_mfma_f32_32x32x16_f16 -- half the matrix instructions of the bf16x3 form.
+// What it gives up is 2 bits per operand: measured on 10^7 states of the configs[1] model the worst
+// state-level error is 3.4e-5 against 1.9e-5 (tools/exp_fp16_split.py), and the error grows with the
+// model's conditioning estimate as the other forms' does, so it is only chosen below tighter limits
+// (KAPPA_LIMIT_F16, gmm.h); models above them keep the bf16x3 form.  The constant rides in TWO K slots
+// (k = dim and k = KH + dim, the frame operand is 1 in both): 44 bits, so the largest term of the sum
+// loses nothing.  fp16 range: the frame operand is clamped to |x - pivot| <= kF16Clamp (its square stays
+// finite); load-time eligibility guarantees that a frame that far out is at the 1e-50 floor either way.
+// ---------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+template <int NS>
+__device__ __forceinline__ f32x16 mfma_split(const u32x4 &a, const u32x4 &b, const f32x16 &c) {
+  if constexpr (NS == 3)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// two-term fp16 split of two floats, packed pairwise (lo half = first value)
+__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned &p1, unsigned &p2) {
+  const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+  const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
+  p1 = __builtin_bit_cast(unsigned, (f16x2){h0, h1});
+  p2 = __builtin_bit_cast(unsigned, (f16x2){l0, l1});
+}
+
+template <int NK16, bool GROUPED, bool WIDE = false, int NS = 3>
 struct Bf16Smem {
-  static constexpr int kTileBytes = NK16 * 3 * 2 * 64 * 16;
+  static constexpr int kTileBytes = NK16 * NS * 2 * 64 * 16;
   // States per output group.  4-wave form: 16 (LDS budget of 2 workgroups per CU).  8-wave form: 32
   // where three tile buffers + eight staging areas of stride 34 still fit 160 KB -- a group is then
   // a whole 128-byte L2 line of a padded output row, written by one store instruction.
@@ -682,17 +713,17 @@ struct Bf16Smem {
 // groups run the same tile sequence half a tile apart (group 1 lags by one barrier; every wave
 // passes two barriers per tile, one in the middle of its stream), which puts one group's
 // epilogue under the other group's matrix stream; three tile buffers make the lag legal.
-template <int NK16, bool GROUPED, bool CL, bool WIDE>
+template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS>
 __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_score_bf16x3(
     const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
     const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
     const uint16_t *__restrict__ close_mask, const int32_t *__restrict__ sid, int sid_stride,
     float *__restrict__ out, int64_t S, int64_t pitch, float ref_ln, int dbg, ClusterArgs cl) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr int OG = Bf16Smem<NK16, GROUPED, WIDE>::OG;
-  constexpr int kTileBytes = Bf16Smem<NK16, GROUPED, WIDE>::kTileBytes;
+  constexpr int OG = Bf16Smem<NK16, GROUPED, WIDE, NS>::OG;
+  constexpr int kTileBytes = Bf16Smem<NK16, GROUPED, WIDE, NS>::kTileBytes;
   constexpr int kTileFloats = kTileBytes / 4;
-  constexpr int kOS = Bf16Smem<NK16, GROUPED, WIDE>::kOutStride;
+  constexpr int kOS = Bf16Smem<NK16, GROUPED, WIDE, NS>::kOutStride;
   constexpr int KH = 8 * NK16;
   constexpr int NW = WIDE ? 8 : 4;    // waves per workgroup
   constexpr int NBUF = WIDE ? 3 : 2;  // tile buffers
@@ -702,13 +733,13 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   const int wave = tid >> 6;
   const int lane = tid & 63;
   const int group = WIDE ? __builtin_amdgcn_readfirstlane(wave >> 2) : 0;
-  float *ost = abuf0 + NBUF * kTileFloats + wave * Bf16Smem<NK16, GROUPED, WIDE>::kOutFloatsPerWave;
+  float *ost = abuf0 + NBUF * kTileFloats + wave * Bf16Smem<NK16, GROUPED, WIDE, NS>::kOutFloatsPerWave;
   const int n = lane & 31;
   const int h = lane >> 5;  // K half of a slab held by this lane AND its row track
   const int64_t f0 = (int64_t)blockIdx.x * (NW * FRAMES_PER_WAVE) + wave * FRAMES_PER_WAVE;
 
   // ---- frame operand: lane (n, h) holds k = 16*j + 8*h + i, i < 8, of slab j
-  u32x4 bq[NK16][3][2];
+  u32x4 bq[NK16][NS][2];
 #pragma unroll
   for (int nb = 0; nb < 2; nb++) {
     int64_t f = f0 + nb * 32 + n;
@@ -723,16 +754,26 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
         const int d = k < KH ? k : k - KH;
         const int dc = d < dim ? d : 0;
         const float xc = xr[dc] - pivot[dc];
-        float val = k < KH ? xc : xc * xc;
-        if (d >= dim) val = (k == dim) ? 1.0f : 0.0f;
+        float xq = xc;
+        if (NS == 2) xq = fminf(fmaxf(xc, -kF16Clamp), kF16Clamp);  // fp16 range (see the f16x2 note above)
+        float val = k < KH ? xq : xq * xq;
+        if (d >= dim) val = (k == dim || (NS == 2 && k == KH + dim)) ? 1.0f : 0.0f;
         v[i] = val;
       }
-      unsigned w1[4], w2[4], w3[4];
+      if constexpr (NS == 3) {
+        unsigned w1[4], w2[4], w3[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) split3_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i], w3[i]);
-      bq[j][0][nb] = u32x4{w1[0], w1[1], w1[2], w1[3]};
-      bq[j][1][nb] = u32x4{w2[0], w2[1], w2[2], w2[3]};
-      bq[j][2][nb] = u32x4{w3[0], w3[1], w3[2], w3[3]};
+        for (int i = 0; i < 4; i++) split3_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i], w3[i]);
+        bq[j][0][nb] = u32x4{w1[0], w1[1], w1[2], w1[3]};
+        bq[j][1][nb] = u32x4{w2[0], w2[1], w2[2], w2[3]};
+        bq[j][2][nb] = u32x4{w3[0], w3[1], w3[2], w3[3]};
+      } else {
+        unsigned w1[4], w2[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) split2_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i]);
+        bq[j][0][nb] = u32x4{w1[0], w1[1], w1[2], w1[3]};
+        bq[j][1][nb] = u32x4{w2[0], w2[1], w2[2], w2[3]};
+      }
     }
   }
 
@@ -776,10 +817,10 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   // scalar load anywhere in the loop turns every LDS wait of the stream into lgkmcnt(0).
   unsigned mask16_next = t_begin < t_end ? (unsigned)__builtin_amdgcn_readfirstlane((int)close_mask[t_begin]) : 0u;
   unsigned mask_v = 0;
-  u32x4 afr[3][2];  // A fragments of the current slab, [split][row block]
+  u32x4 afr[NS][2];  // A fragments of the current slab, [split][row block]
   if (t_begin < t_end) {
 #pragma unroll
-    for (int sp = 2; sp >= 0; sp--) {
+    for (int sp = NS - 1; sp >= 0; sp--) {
       afr[sp][0] = ((const u32x4 *)abuf0 + lane)[(sp * 2 + 0) * 64];
       afr[sp][1] = ((const u32x4 *)abuf0 + lane)[(sp * 2 + 1) * 64];
     }
@@ -824,28 +865,24 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int grp = 0; grp < 3; grp++) {
-        const int sp = 2 - grp;        // A split used by this group: a3, a2, a1
+      for (int grp = 0; grp < NS; grp++) {
+        const int sp = NS - 1 - grp;   // A split used by this group: a3, a2, a1 (f16x2: a2, a1)
         const int nprod = grp + 1;     // paired with b1 | b2 b1 | b3 b2 b1
 #pragma unroll
         for (int c = 0; c < nprod; c++) {
           const int sb = nprod - 1 - c;
-          const bf16x8 a_m0 = __builtin_bit_cast(bf16x8, afr[sp][0]);
-          const bf16x8 a_m1 = __builtin_bit_cast(bf16x8, afr[sp][1]);
-          const bf16x8 b_n0 = __builtin_bit_cast(bf16x8, bq[j][sb][0]);
-          const bf16x8 b_n1 = __builtin_bit_cast(bf16x8, bq[j][sb][1]);
-          c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m0, b_n0, c00, 0, 0, 0);
-          c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m0, b_n1, c01, 0, 0, 0);
-          c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m1, b_n0, c10, 0, 0, 0);
-          c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m1, b_n1, c11, 0, 0, 0);
+          c00 = mfma_split<NS>(afr[sp][0], bq[j][sb][0], c00);
+          c01 = mfma_split<NS>(afr[sp][0], bq[j][sb][1], c01);
+          c10 = mfma_split<NS>(afr[sp][1], bq[j][sb][0], c10);
+          c11 = mfma_split<NS>(afr[sp][1], bq[j][sb][1], c11);
         }
         __builtin_amdgcn_sched_barrier(0);
         // the aligned word holding tile t+1's bits (the array has a spare element); a 16-bit load
         // would need a zero-extension, which the compiler places -- with its vmcnt wait -- right here
         if (j == (NK16 > 1 ? 1 : 0) && grp == 0) mask_v = ((const uint32_t *)close_mask)[(t + 1) >> 1];
         if (j + 1 < NK16 && !AASR_DBG(2)) {
-          afr[sp][0] = afrag[(((j + 1) * 3 + sp) * 2 + 0) * 64];
-          afr[sp][1] = afrag[(((j + 1) * 3 + sp) * 2 + 1) * 64];
+          afr[sp][0] = afrag[(((j + 1) * NS + sp) * 2 + 0) * 64];
+          afr[sp][1] = afrag[(((j + 1) * NS + sp) * 2 + 1) * 64];
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -864,7 +901,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
       // slab 0 of the next tile: in flight while the epilogue runs
       const u32x4 *nfrag = (const u32x4 *)anext + lane;
 #pragma unroll
-      for (int sp = 2; sp >= 0; sp--) {
+      for (int sp = NS - 1; sp >= 0; sp--) {
         afr[sp][0] = nfrag[(sp * 2 + 0) * 64];
         afr[sp][1] = nfrag[(sp * 2 + 1) * 64];
       }
@@ -966,16 +1003,16 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   if (WIDE && group == 0) __builtin_amdgcn_s_barrier();  // pairs with the lagging group's last end-of-tile barrier
 }
 
-template <int NK16, bool GROUPED, bool CL, bool WIDE>
+template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS>
 static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
                           float *d_out, hipStream_t stream, const ClusterArgs &cl, int64_t pitch) {
   constexpr int NW = WIDE ? 8 : 4;
   const int64_t blocks = (F + NW * FRAMES_PER_WAVE - 1) / (NW * FRAMES_PER_WAVE);
-  const int smem = (WIDE ? 3 : 2) * Bf16Smem<NK16, GROUPED, WIDE>::kTileBytes +
-                   NW * Bf16Smem<NK16, GROUPED, WIDE>::kOutFloatsPerWave * 4;
+  const int smem = (WIDE ? 3 : 2) * Bf16Smem<NK16, GROUPED, WIDE, NS>::kTileBytes +
+                   NW * Bf16Smem<NK16, GROUPED, WIDE, NS>::kOutFloatsPerWave * 4;
   static const int dbg = getenv("AASR_DBG") ? atoi(getenv("AASR_DBG")) : 0;
   static bool attr_set[64] = {false};
-  auto kern = k_gmm_diag_score_bf16x3<NK16, GROUPED, CL, WIDE>;
+  auto kern = k_gmm_diag_score_bf16x3<NK16, GROUPED, CL, WIDE, NS>;
   if (!attr_set[g->device & 63]) {
     AASR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set[g->device & 63] = true;
@@ -995,38 +1032,46 @@ static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *
   if (force_r >= 1 && force_r <= L.max_splits) R = force_r;
   const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(NW * 64), smem, stream, d_frames, F,
-                     g->dim, g->d_pivot.p, L.a16.p, split_row, L.close.p, L.sid.p, L.sid_stride,
+                     g->dim, g->d_pivot.p, NS == 3 ? L.a16.p : L.a16h.p, split_row, L.close.p, L.sid.p, L.sid_stride,
                      d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, dbg, cl);
   AASR_HIP(hipGetLastError());
 }
 
 // the 8-wave form needs three tile buffers + eight staging areas in 160 KB of LDS
-template <int N>
+template <int N, int NS>
 static constexpr bool wide_ok() {
-  return 3 * Bf16Smem<N, true, true>::kTileBytes + 8 * Bf16Smem<N, true, true>::kOutFloatsPerWave * 4 <= 160 * 1024;
+  return 3 * Bf16Smem<N, true, true, NS>::kTileBytes + 8 * Bf16Smem<N, true, true, NS>::kOutFloatsPerWave * 4 <= 160 * 1024;
 }
 
-static bool launch_bf16(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
-                        float *d_out, hipStream_t stream, const ClusterArgs *cl = nullptr, int64_t pitch = 0) {
+// NS = 3: three bf16 terms (AASR_PREC_BF16X3); NS = 2: two fp16 terms (AASR_PREC_F16X2)
+template <int NS>
+static bool launch_split(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
+                         float *d_out, hipStream_t stream, const ClusterArgs *cl = nullptr, int64_t pitch = 0) {
   if (pitch <= 0) pitch = g->S;
-  if (!L.a16.p) return false;
+  if (NS == 3 ? !L.a16.p : !L.a16h.p) return false;
   const ClusterArgs none;
   // AASR_BF16_WIDE=0 selects the 4-wave workgroups
   static const int wide_env = getenv("AASR_BF16_WIDE") ? atoi(getenv("AASR_BF16_WIDE")) : -1;
   // small batches (a decoder's per-utterance blocks) fill the chip better with 256-frame workgroups
   const int wide = wide_env >= 0 ? wide_env : (F >= 8192 ? 1 : 0);
+  // masked (clustered) runs: the bf16x3 8-wave form with masks needs 254 VGPRs + spills and was measured
+  // slower, so it keeps 4-wave workgroups; the f16x2 form holds a third fewer operand registers
+  const bool wide_cl = NS == 2;
   switch (L.nk16) {
 #define AASR_CASE(N)                                                                               \
   case N:                                                                                          \
-    if (cl) { /* 4-wave form: the 8-wave one with masks needs 254 VGPRs + spills, measured slower */ \
-      if (L.grouped) launch_bf16_t<N, true, true, false>(g, L, d_frames, F, d_out, stream, *cl, pitch);   \
-      else launch_bf16_t<N, false, true, false>(g, L, d_frames, F, d_out, stream, *cl, pitch);            \
-    } else if (wide && wide_ok<N>()) {                                                             \
-      if (L.grouped) launch_bf16_t<N, true, false, true>(g, L, d_frames, F, d_out, stream, none, pitch);  \
-      else launch_bf16_t<N, false, false, true>(g, L, d_frames, F, d_out, stream, none, pitch);           \
+    if (cl && wide && wide_cl && wide_ok<N, NS>()) {                                               \
+      if (L.grouped) launch_bf16_t<N, true, true, true, NS>(g, L, d_frames, F, d_out, stream, *cl, pitch);    \
+      else launch_bf16_t<N, false, true, true, NS>(g, L, d_frames, F, d_out, stream, *cl, pitch);             \
+    } else if (cl) {                                                                               \
+      if (L.grouped) launch_bf16_t<N, true, true, false, NS>(g, L, d_frames, F, d_out, stream, *cl, pitch);   \
+      else launch_bf16_t<N, false, true, false, NS>(g, L, d_frames, F, d_out, stream, *cl, pitch);            \
+    } else if (wide && wide_ok<N, NS>()) {                                                         \
+      if (L.grouped) launch_bf16_t<N, true, false, true, NS>(g, L, d_frames, F, d_out, stream, none, pitch);  \
+      else launch_bf16_t<N, false, false, true, NS>(g, L, d_frames, F, d_out, stream, none, pitch);           \
     } else {                                                                                       \
-      if (L.grouped) launch_bf16_t<N, true, false, false>(g, L, d_frames, F, d_out, stream, none, pitch); \
-      else launch_bf16_t<N, false, false, false>(g, L, d_frames, F, d_out, stream, none, pitch);          \
+      if (L.grouped) launch_bf16_t<N, true, false, false, NS>(g, L, d_frames, F, d_out, stream, none, pitch); \
+      else launch_bf16_t<N, false, false, false, NS>(g, L, d_frames, F, d_out, stream, none, pitch);          \
     }                                                                                              \
     return true;
     AASR_CASE(1) AASR_CASE(2) AASR_CASE(3) AASR_CASE(4) AASR_CASE(5) AASR_CASE(6) AASR_CASE(8)
@@ -1034,6 +1079,14 @@ static bool launch_bf16(const aasr_gmm *g, const TrackLayout &L, const float *d_
     default:
       return false;
   }
+}
+
+// the split-operand kernel the handle's precision asks for (f16x2 only where the layout is eligible)
+static bool launch_bf16(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
+                        float *d_out, hipStream_t stream, const ClusterArgs *cl = nullptr, int64_t pitch = 0) {
+  if (g->precision == AASR_PREC_F16X2 && L.a16h.p && launch_split<2>(g, L, d_frames, F, d_out, stream, cl, pitch))
+    return true;
+  return launch_split<3>(g, L, d_frames, F, d_out, stream, cl, pitch);
 }
 
 // ---------------------------------------------------------------------------
@@ -2180,7 +2233,7 @@ bool gmm_score_pitch_ok(const aasr_gmm *g) {
   if ((g->layout_mask & 3) != 3) return false;
   const TrackLayout &L = g->paired.ok ? g->paired : g->tracks;
   // both track kernels (f32 and bf16x3) take a row pitch; the centred kernel does not
-  return (g->precision == AASR_PREC_F32 || g->precision == AASR_PREC_BF16X3) && L.ok;
+  return (g->precision == AASR_PREC_F32 || g->precision == AASR_PREC_BF16X3 || g->precision == AASR_PREC_F16X2) && L.ok;
 }
 
 void gmm_score_launch_pitched(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, int64_t pitch,

@@ -77,8 +77,9 @@ def parse_args():
     ap.add_argument("--cpu-procs", type=int, default=-1,
                     help="processes of the all-cores CPU baseline (-1 = one per usable core, 0 = skip)")
     ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)
-    ap.add_argument("--precision", choices=["bf16x3", "f32"], default=os.environ.get("AASR_BENCH_PRECISION", "bf16x3"),
-                    help="contraction arithmetic of the scoring kernel (both meet the 1e-4 parity bar)")
+    ap.add_argument("--precision", choices=["f16x2", "bf16x3", "f32"], default=os.environ.get("AASR_BENCH_PRECISION", "f16x2"),
+                    help="contraction arithmetic of the scoring kernel (all meet the 1e-4 parity bar; f16x2 is the "
+                         "library default for models whose conditioning allows it)")
     ap.add_argument("--recipe-dir", default=os.environ.get("AASR_BENCH_RECIPE_DIR", ""),
                     help="where the recipe workload keeps its WAV inputs and LNA outputs "
                          "(default: /dev/shm when it has room, else the system temp directory)")
@@ -344,7 +345,11 @@ def main():
         model = shard.broadcast_model(model, src=0, device=dev)
     mean, var, off, idx, w = (model[k] for k in names)
     gmm = capi.Gmm.from_arrays(mean, var, off, idx, w)
-    gmm.set_precision(3 if args.precision == "bf16x3" else 0)   # AASR_PREC_BF16X3 / AASR_PREC_F32
+    PREC = {"f16x2": 4, "bf16x3": 3, "f32": 0}[args.precision]   # AASR_PREC_F16X2 / AASR_PREC_BF16X3 / AASR_PREC_F32
+    gmm.set_precision(PREC)
+    if args.precision == "f16x2" and gmm.effective_precision() != 4:
+        raise SystemExit("bench.py: the synthetic model was not packed for the f16x2 kernel (effective precision %d)"
+                         % gmm.effective_precision())
     rows = gmm.expanded_rows
     stream = torch.cuda.current_stream()
 
@@ -456,15 +461,27 @@ def main():
         if args.precision == "f32":
             kernel, peak, dtype = "k_gmm_diag_score_tracks<40,true>", FP32_MATRIX_PEAK_TFLOPS, "f32"
             peak_note = "dense FP32 matrix peak (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md"
-        else:
+            products = 1.0
+        elif args.precision == "bf16x3":
             # f32-accurate arithmetic: every f32 operand is carried as three bf16 terms (24 significant
             # bits), six bf16 matrix-core products per f32 product (terms below 2^-16 dropped), f32
             # accumulation; it meets the same 1e-4 parity bar as the plain f32 kernel (--precision f32).
             # The ceiling for ALGORITHMIC flops on the bf16 pipe is therefore the dense bf16 peak / 6.
-            kernel, peak, dtype = ("k_gmm_diag_score_bf16x3<5,true>", BF16_MATRIX_PEAK_TFLOPS / 6.0,
+            kernel, peak, dtype = ("k_gmm_diag_score_bf16x3<5,true,false,true,3>", BF16_MATRIX_PEAK_TFLOPS / 6.0,
                                    "f32 (3-term bf16 split on the matrix cores, f32 accumulate)")
             peak_note = ("dense BF16 matrix peak 2500 TFLOP/s / 6 bf16 products per f32-accurate product; "
                          "executed matrix flops = 6 * 160/156 * achieved")
+            products = 6.0
+        else:
+            # two fp16 terms per operand (22 significant bits), three fp16 matrix-core products per product
+            # (lo*lo dropped), f32 accumulation: same 1e-4 parity bar (state-level worst 3.4e-5 on 10^7 states,
+            # tools/exp_fp16_split.py), chosen per model by its conditioning.  Ceiling for ALGORITHMIC flops:
+            # the dense fp16 peak / 3.
+            kernel, peak, dtype = ("k_gmm_diag_score_bf16x3<5,true,false,true,2>", BF16_MATRIX_PEAK_TFLOPS / 3.0,
+                                   "f32 (2-term fp16 split on the matrix cores, f32 accumulate)")
+            peak_note = ("dense FP16 matrix peak 2500 TFLOP/s / 3 fp16 products per product; "
+                         "executed matrix flops = 3 * 160/156 * achieved")
+            products = 3.0
         roofline = {
             "bound": "mfma", "kernel": kernel, "achieved": round(achieved, 3),
             "peak": round(peak, 2), "unit": "TFLOP/s",
@@ -484,7 +501,7 @@ def main():
         if args.precision != "f32":
             probe = _pipe_probe(run=(rank == 0 and world == 1))
             if probe:
-                executed = achieved * 6.0 * 160.0 / 156.0
+                executed = achieved * products * 160.0 / 156.0
                 probe["executed_TFLOPs"] = round(executed, 1)
                 probe["frac_of_probe"] = round(executed / probe["TFLOPs_" + probe["reference"]], 4)
                 roofline["matrix_pipe_probe"] = probe
@@ -503,7 +520,7 @@ def main():
             roofline["stages"] = _stage_rooflines(runner, split)
             if rank == 0:
                 extra_cfg["lna_check"] = _lna_check(runner, gmm, mean, var, off, idx, w,
-                                                    3 if args.precision == "bf16x3" else 0)
+                                                    PREC)
         except Exception as e:
             extra_cfg["stage_ms"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:
@@ -519,7 +536,7 @@ def main():
             torch.cuda.empty_cache()
             extra_cfg["configs2"] = _measure_configs2(torch, capi, synth, gmm, rank, dev, stream, sync_all,
                                                       max_over_ranks, world, mean, var, off, idx, w,
-                                                      3 if args.precision == "bf16x3" else 0)
+                                                      PREC)
         except Exception as e:  # the headline must survive a failure of the extras
             extra_cfg["configs2"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if args.workload in ("gmm", "full") and args.secondary:

@@ -264,13 +264,21 @@ int32_t aasr_gmm_num_clusters(const aasr_gmm *h);
  *                         switched to the centred form automatically
  *  AASR_PREC_F32_CENTRED  always the centred form (x-mu)^2*p on the vector ALU,
  *                         the reference's own arithmetic shape in f32
- *  AASR_PREC_BF16X3       default: both operands split into three bf16 terms, six
+ *  AASR_PREC_BF16X3       both operands split into three bf16 terms, six
  *                         bf16 matrix-core products per f32 product accumulated
  *                         in f32: f32-class accuracy (same 1e-4 parity bar) at
  *                         ~1.8x the speed of the f32 kernel; diagonal, full-
  *                         covariance and per-class CMLLR models (ill-conditioned
  *                         models still take the centred form).  The environment
  *                         variable AASR_PREC=0 selects AASR_PREC_F32 globally.
+ *  AASR_PREC_F16X2        default: both operands as two fp16 terms (22 bits), three
+ *                         fp16 matrix-core products per product -- half the matrix
+ *                         instructions of BF16X3 at 1.4-1.8x its rounding error, so it
+ *                         is used only for diagonal models whose conditioning estimate
+ *                         leaves that room (same 1e-4 bar, tighter limits: gmm.h
+ *                         KAPPA_LIMIT_F16); every other model, and the full-covariance
+ *                         path, runs as under AASR_PREC_BF16X3.
+ *                         aasr_gmm_effective_precision tells which form a model got.
  *  AASR_PREC_F64          the reference's own arithmetic in double, operation by operation (diagonal
  *                         pools; unadapted, under one global CMLLR transform or under per-class transforms, with or
  *                         without clustering): a verification / training-side
@@ -279,9 +287,11 @@ int32_t aasr_gmm_num_clusters(const aasr_gmm *h);
  *                         aasr_run_utterance / aasr_run_recipe then run the whole path in double
  *                         (features, scoring, the LNA tail as written) -- AASR_PREC=1 in the
  *                         environment selects it for the command-line tools. */
-enum { AASR_PREC_F32 = 0, AASR_PREC_F64 = 1, AASR_PREC_F32_CENTRED = 2, AASR_PREC_BF16X3 = 3 };
+enum { AASR_PREC_F32 = 0, AASR_PREC_F64 = 1, AASR_PREC_F32_CENTRED = 2, AASR_PREC_BF16X3 = 3, AASR_PREC_F16X2 = 4 };
 aasr_status aasr_gmm_set_precision(aasr_gmm *h, int prec);
 int aasr_gmm_get_precision(const aasr_gmm *h);
+/* the arithmetic the diagonal scoring path of this model actually runs under the current setting */
+int aasr_gmm_effective_precision(const aasr_gmm *h);
 
 /* HmmSet::precompute_likelihoods + state_likelihood for a block of frames
  * (aku/HmmSet.cc:484-501, aku/HmmSet.hh:309): frames float32 [F x dim];

@@ -33,7 +33,7 @@ def _check(capi, oracle, model, g2c, C, minc, ming, frames, pairs=None, tol=TOL,
     # layouts, f32 and bf16x3 contraction
     for layouts in (7, 2):
         gm.set_layouts(layouts)
-        for prec in (0, 3):
+        for prec in (0, 3, 4):
             gm.set_precision(prec)
             got = gm.score(frames)
             got_n = gm.cluster_exact_counts(len(frames))
@@ -268,7 +268,7 @@ def test_clustering_under_a_global_cmllr_transform(capi, oracle):
         gm.set_clustering_min_evals(0.05, 0.2)
         if order == "cluster_first":
             gm.set_cmllr(g2t, W[None])
-        for prec in (0, 3):
+        for prec in (0, 3, 4):
             gm.set_precision(prec)
             got = gm.score(frames)
             assert np.array_equal(gm.cluster_exact_counts(len(frames)), want_n), (order, prec)
@@ -313,7 +313,7 @@ def test_clustering_under_per_class_cmllr_transforms(capi, oracle):
         gm.set_clustering_min_evals(0.05, 0.2)
         if order == "cluster_first":
             gm.set_cmllr(g2t, W3)
-        for prec in (0, 3):
+        for prec in (0, 3, 4):
             gm.set_precision(prec)
             got = gm.score(frames)
             assert np.array_equal(gm.cluster_exact_counts(len(frames)), want_n), (order, prec)
@@ -371,7 +371,7 @@ def test_clustering_with_outlier_routed_and_ill_conditioned_models(capi, oracle)
     gm.set_clustering(32, _pairs(g2c))
     gm.set_clustering_min_evals(0.0, 0.25)
     gm.set_cmllr(np.zeros(512, np.int32), W[None])
-    for prec in (0, 3):
+    for prec in (0, 3, 4):
         gm.set_precision(prec)
         got = gm.score(frames)
         assert np.array_equal(gm.cluster_exact_counts(len(frames)), want_n)

@@ -125,7 +125,7 @@ def test_class_routing_across_speaker_changes(capi, oracle):
         W = _transforms(4, D, seed)                              # class 3 has no Gaussian at all
         g.set_cmllr(g2t, W)
         ref = _oracle_adapted(oracle, model, frames, g2t, W)
-        for prec in (3, 0):
+        for prec in (4, 3, 0):
             g.set_precision(prec)
             assert np.abs(g.score(frames) - ref).max() <= 1e-4
     g2t2 = rng.integers(-1, 2, G).astype(np.int32)               # new membership

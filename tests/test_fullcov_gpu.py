@@ -99,7 +99,7 @@ def test_per_gaussian_view_of_a_full_covariance_pool(capi, oracle):
     frames = synth.make_frames(120, D=39, seed=4)
     ref = oracle.FullModel(mean, cov, off, idx, w).gauss_loglik(frames.astype(np.float64))
     g = capi.Gmm.from_full(mean, cov, off, idx, w)
-    for prec in (0, 3):
+    for prec in (0, 3, 4):
         g.set_precision(prec)
         got = g.gauss_loglik(frames)
         assert got.shape == ref.shape

@@ -24,8 +24,9 @@ def big(capi, oracle):
     g = capi.Gmm.from_arrays(*model)
     d_fr = torch.from_numpy(frames).cuda()
     outs = {}
-    for name, prec in (("f32", 0), ("bf16x3", 3)):
+    for name, prec in (("f32", 0), ("bf16x3", 3), ("f16x2", 4)):
         g.set_precision(prec)
+        assert g.effective_precision() == prec
         d_out = torch.empty((F, S), dtype=torch.float32, device="cuda")
         g.score_dev(d_fr, d_out)
         torch.cuda.synchronize()
@@ -34,7 +35,7 @@ def big(capi, oracle):
     return dict(model=model, frames=frames, g=g, outs=outs, om=oracle.DiagModel(*model), d_fr=d_fr)
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "f16x2"])
 def test_sampled_frames_against_oracle(big, prec):
     rng = np.random.default_rng(5)
     pick = np.sort(rng.choice(F, 48, replace=False))
@@ -45,9 +46,10 @@ def test_sampled_frames_against_oracle(big, prec):
     assert err.max() <= 1e-4, "%s: max |dll| %.3g" % (prec, err.max())
 
 
-def test_f32_and_bf16x3_agree_everywhere(big):
-    d = (big["outs"]["f32"] - big["outs"]["bf16x3"]).abs().max().item()
-    assert d <= 1e-4
+@pytest.mark.parametrize("other", ["bf16x3", "f16x2"])
+def test_f32_and_the_split_forms_agree_everywhere(big, other):
+    d = (big["outs"]["f32"] - big["outs"][other]).abs().max().item()
+    assert d <= 1e-4, (other, d)
 
 
 def test_partition_invariance_at_full_model_size(big):
@@ -238,8 +240,9 @@ def test_config1_one_million_frames(capi, oracle):
     d_fr = torch.randn((Fm, D), generator=gen, device="cuda", dtype=torch.float32)
     pitch = 3136
     outs = {}
-    for name, prec in (("bf16x3", 3), ("f32", 0)):
+    for name, prec in (("f16x2", 4), ("bf16x3", 3), ("f32", 0)):
         g.set_precision(prec)
+        assert g.effective_precision() == prec
         d_out = torch.empty((Fm, pitch), dtype=torch.float32, device="cuda")
         g.score_dev_pitched(d_fr, d_out, pitch)
         torch.cuda.synchronize()
@@ -254,16 +257,19 @@ def test_config1_one_million_frames(capi, oracle):
         assert_ll(got, ref, name)
     # chunked comparison of the two arithmetics (12.5 GB each: never both as one temporary)
     # same contract as against the oracle: 1e-4 wherever the value is one the reference's float storage holds
-    worst = 0.0
-    for lo in range(0, Fm, 100_000):
-        a, b = outs["f32"][lo:lo + 100_000, :S], outs["bf16x3"][lo:lo + 100_000, :S]
-        vis = a > LL_FLUSH
-        worst = max(worst, ((a - b).abs() * vis).max().item())
-        assert (b[~vis] <= LL_FLUSH + 1.1).all()
-    assert worst <= TOL_LL, worst
-    g.set_precision(3)
-    for lo, hi in ((0, 512), (499_999, 500_300), (Fm - 20_000, Fm)):
-        d_sub = torch.empty((hi - lo, pitch), dtype=torch.float32, device="cuda")
-        g.score_dev_pitched(d_fr[lo:hi].contiguous(), d_sub, pitch)
-        torch.cuda.synchronize()
-        assert torch.equal(d_sub[:, :S], outs["bf16x3"][lo:hi, :S]), (lo, hi)
+    for other in ("bf16x3", "f16x2"):
+        worst = 0.0
+        for lo in range(0, Fm, 100_000):
+            a, b = outs["f32"][lo:lo + 100_000, :S], outs[other][lo:lo + 100_000, :S]
+            vis = a > LL_FLUSH
+            worst = max(worst, ((a - b).abs() * vis).max().item())
+            assert (b[~vis] <= LL_FLUSH + 1.1).all()
+        print("configs[1], 10^6 frames: f32 against %s, worst visible |dll| %.3g" % (other, worst))
+        assert worst <= TOL_LL, (other, worst)
+    for name, prec in (("bf16x3", 3), ("f16x2", 4)):
+        g.set_precision(prec)
+        for lo, hi in ((0, 512), (499_999, 500_300), (Fm - 20_000, Fm)):
+            d_sub = torch.empty((hi - lo, pitch), dtype=torch.float32, device="cuda")
+            g.score_dev_pitched(d_fr[lo:hi].contiguous(), d_sub, pitch)
+            torch.cuda.synchronize()
+            assert torch.equal(d_sub[:, :S], outs[name][lo:hi, :S]), (name, lo, hi)

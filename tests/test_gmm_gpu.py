@@ -32,12 +32,15 @@ def _check(capi, oracle, model, frames, layouts=LAYOUTS):
         used.add(g.active_layout())
         got = g.score(frames)
         worst = max(worst, assert_ll(got, ref, "layout %d (kernel %d)" % (mask, g.active_layout())))
-    # the bf16x3 split kernel on whichever track layout the model has
+    # the split-operand kernels (three bf16 terms; two fp16 terms where the model is eligible, else the
+    # setting falls back to bf16x3) on whichever track layout the model has
     g.set_layouts(7)
     if g.active_layout() in (1, 2):
-        g.set_precision(3)
-        got = g.score(frames)
-        worst = max(worst, assert_ll(got, ref, "bf16x3 on layout %d" % g.active_layout()))
+        for prec in (3, 4):
+            g.set_precision(prec)
+            got = g.score(frames)
+            worst = max(worst, assert_ll(got, ref, "precision %d (runs as %d) on layout %d" % (
+                prec, g.effective_precision(), g.active_layout())))
         g.set_precision(0)
     g.close()
     return worst, used
@@ -278,7 +281,7 @@ def test_outlier_routing_keeps_the_model_on_the_matrix_path(capi, oracle):
     L.aasr_debug_kappa.argtypes = [C.c_void_p]
     assert L.aasr_debug_kappa(g._h) > 600
     assert g.active_layout() in (1, 2)                 # not the centred kernel
-    for prec in (3, 0):
+    for prec in (4, 3, 0):
         g.set_precision(prec)
         for mask in (7, 2, 0):
             g.set_layouts(mask)
@@ -304,11 +307,13 @@ def test_wide_and_narrow_workgroups_give_identical_bits(capi):
     scores must not depend on how the recipe driver happened to batch it."""
     model = synth.make_model(D=39, G=1024, S=77, comps=12, seed=3)
     g = capi.Gmm.from_arrays(*model)
-    g.set_precision(3)
     fr = synth.make_frames(9000, seed=12)
-    whole = g.score(fr)                                   # 8-wave workgroups
-    parts = np.vstack([g.score(fr[:4000]), g.score(fr[4000:8100]), g.score(fr[8100:])])   # 4-wave
-    assert np.array_equal(whole.view(np.uint32), parts.view(np.uint32))
+    for prec in (3, 4):
+        g.set_precision(prec)
+        assert g.effective_precision() == prec
+        whole = g.score(fr)                                   # 8-wave workgroups
+        parts = np.vstack([g.score(fr[:4000]), g.score(fr[4000:8100]), g.score(fr[8100:])])   # 4-wave
+        assert np.array_equal(whole.view(np.uint32), parts.view(np.uint32))
     g.close()
 
 
@@ -328,13 +333,14 @@ def test_wide_kernel_every_instance(capi, oracle, D):
         idx = np.arange(G, dtype=np.int32)
         w = rng.uniform(0.1, 1.0, G)
         g = capi.Gmm.from_arrays(mean, var, off, idx, w)
-        g.set_precision(3)
         fr = synth.make_frames(8200, D=D, seed=D)
-        whole = g.score(fr)
-        parts = np.vstack([g.score(fr[:4100]), g.score(fr[4100:])])
-        assert np.array_equal(whole.view(np.uint32), parts.view(np.uint32))
         ref = oracle.DiagModel(mean, var, off, idx, w).score(fr[:300].astype(np.float64))
-        assert np.abs(whole[:300] - ref).max() <= 1e-4
+        for prec in (3, 4):
+            g.set_precision(prec)
+            whole = g.score(fr)
+            parts = np.vstack([g.score(fr[:4100]), g.score(fr[4100:])])
+            assert np.array_equal(whole.view(np.uint32), parts.view(np.uint32))
+            assert np.abs(whole[:300] - ref).max() <= 1e-4, (prec, g.effective_precision())
         g.close()
 
 
@@ -357,3 +363,31 @@ def test_gauss_loglik_of_tight_gaussians(capi, oracle):
     near = ref > -150
     assert np.abs(got - ref)[near].max() <= 1e-4, np.abs(got - ref)[near].max()
     assert near[:12, bad].diagonal().all()          # the frames drawn from the tight Gaussians see them
+
+
+def test_f16x2_is_chosen_by_conditioning_and_clamps_far_frames(capi, oracle):
+    """AASR_PREC_F16X2 (the default): the two-term fp16 form runs only for models whose conditioning estimate is
+    below its own, tighter limits -- others fall back to the three-term bf16 form under the same setting -- and a
+    frame beyond the fp16 clamp (|x - pivot| > 240, its square would overflow) comes out at the floor as in the oracle."""
+    L = capi.lib()
+    L.aasr_debug_kappa.restype = C.c_double
+    L.aasr_debug_kappa.argtypes = [C.c_void_p]
+    model = synth.make_model(D=39, G=512, S=32, comps=16, seed=71)
+    g = capi.Gmm.from_arrays(*model)
+    assert g.effective_precision() == 4 and L.aasr_debug_kappa(g._h) < 330
+    fr = synth.make_frames(200, seed=72)
+    fr[5, 7] = 300.0
+    fr[6, :] = -1000.0
+    fr[7, 38] = 239.0
+    ref = oracle.DiagModel(*model).score(fr.astype(np.float64))
+    assert_ll(g.score(fr), ref, "f16x2 with frames beyond the clamp")
+    assert np.all(g.score(fr)[5:7] == np.float32(np.log(1e-50)))
+    g.close()
+    # tighter Gaussians: kappa between the f16x2 and the bf16x3 limits -> same setting, bf16x3 kernel
+    mean, var, off, idx, w = synth.make_model(D=39, G=512, S=32, comps=16, seed=71, var_lo=0.08, var_hi=0.5)
+    g = capi.Gmm.from_arrays(mean, var, off, idx, w)
+    assert 330 < L.aasr_debug_kappa(g._h) < 600 and g.active_layout() in (1, 2)
+    assert g.effective_precision() == 3
+    fr = synth.make_frames(200, seed=73)
+    assert_ll(g.score(fr), oracle.DiagModel(mean, var, off, idx, w).score(fr.astype(np.float64)), "fallback")
+    g.close()

@@ -63,7 +63,7 @@ def _files(oracle, tmp_path, name, d, entries, S, comps, seed):
 
 
 def _check(capi, g, ref, frames, tol=1e-4):
-    for prec in (0, 3):
+    for prec in (0, 3, 4):
         g.set_precision(prec)
         got = g.score(frames)
         vis = ref > -103.97
@@ -128,7 +128,7 @@ def test_pcgmm_at_a_larger_size_sampled(capi, oracle, tmp_path):
     om = oracle.SubspaceModel(entries, d, off, idx, w)
     pick = np.sort(rng.choice(F, 12, replace=False))
     ref = om.score(frames[pick].astype(np.float64))
-    for prec in (0, 3):
+    for prec in (0, 3, 4):
         g.set_precision(prec)
         got = g.score(frames)[pick]
         vis = ref > -103.97

@@ -31,14 +31,16 @@ def run(label, reps=3):
     print("%-34s %8.2f ms/pass  %6.2f M frames/s" % (label, ms, F / ms / 1e3), flush=True)
 
 
-run("exact, f32 tracks kernel")
-g.set_precision(3)
-run("exact, bf16x3 tracks kernel")
+NAMES = {0: "f32", 3: "bf16x3", 4: "f16x2"}
+PRECS = [int(x) for x in os.environ.get("PRECS", "0,3,4").split(",")]
+for prec in PRECS:
+    g.set_precision(prec)
+    run("exact, %s tracks kernel" % NAMES[prec])
 g.set_clustering(C, [(i, int(c)) for i, c in enumerate(g2c)])
-for prec in (0, 3):
+for prec in PRECS:
     g.set_precision(prec)
     for minc, ming in ((0.0, 0.1), (0.0, 0.25)):
         g.set_clustering_min_evals(minc, ming)
-        run("clustered %s C=%d ming=%.2f" % ("bf16x3" if prec else "f32", C, ming))
+        run("clustered %s C=%d ming=%.2f" % (NAMES[prec], C, ming))
         n = g.cluster_exact_counts(1000)
         print("   clusters evaluated exactly per frame: mean %.1f" % n.mean())

@@ -54,7 +54,7 @@ def run(seed=1, N=40, verbose=False):
             if verbose:
                 print("refused:", ctx, e)
             continue
-        for prec in (0, 3):
+        for prec in (0, 3, 4):
             try:
                 g.set_precision(prec)
             except capi.AasrError:

@@ -19,7 +19,7 @@ for it in range(int(sys.argv[2])):
     g = capi.Gmm.from_arrays(mean, var, off, idx, w)
     k = L.aasr_debug_kappa(g._h)
     e = []
-    for prec in (0, 3):
+    for prec in (0, 3, 4):
         g.set_precision(prec)
         vis = want > -110
         e.append(float(np.abs(g.score(frames) - want)[vis].max()) if vis.any() else 0.0)

@@ -93,7 +93,7 @@ def run(seed=1, N=40, verbose=False, big=False):
             seed, it, D, S, G, tied, F, L.aasr_debug_kappa(g._h))
         for layouts in (7, 2, 0, 4):
             g.set_layouts(layouts)
-            for prec in (0, 3):
+            for prec in (0, 3, 4):
                 try:
                     g.set_precision(prec)
                 except capi.AasrError:
@@ -127,7 +127,7 @@ def run(seed=1, N=40, verbose=False, big=False):
             worst["f64 clustered"] = max(worst.get("f64 clustered", 0.0), e64)
             if e64 > 1e-9 * max(1.0, float(np.abs(wantc).max())) or not np.array_equal(g.cluster_exact_counts(F), cnt):
                 fails.append("f64 clustered %s C %d minc %g ming %g err %.3g" % (ctx, Cn, minc, ming, e64))
-            for prec in (0, 3):
+            for prec in (0, 3, 4):
                 try:
                     g.set_precision(prec)
                 except capi.AasrError:          # no bf16x3 rows for this model (centred form only)
@@ -165,7 +165,7 @@ def run(seed=1, N=40, verbose=False, big=False):
                 continue
             want_a = O.score_adapted(om, frames.astype(np.float64), g2t, Wt)
             slack = float(max(abs(np.log(abs(np.prod(np.diag(Wt[t][:, 1:]))))) for t in range(T)) + np.log(T + 1.0) + 0.1)
-            for prec in (0, 3):
+            for prec in (0, 3, 4):
                 try:
                     g.set_precision(prec)
                 except capi.AasrError:
@@ -193,7 +193,7 @@ def run(seed=1, N=40, verbose=False, big=False):
                     fails.append("f64 cmllr clustered T=%d %s C %d err %.3g" % (T, ctx, Cn, e64))
                     if verbose:
                         print("FAIL", fails[-1])
-                for prec in (0, 3):
+                for prec in (0, 3, 4):
                     try:
                         g.set_precision(prec)
                     except capi.AasrError:

@@ -47,7 +47,7 @@ def run(seed=1, N=20, verbose=False):
                 if verbose:
                     print("refused:", ctx, str(e)[:100])
                 continue
-            for prec in (0, 3):
+            for prec in (0, 3, 4):
                 try:
                     g.set_precision(prec)
                 except capi.AasrError:
