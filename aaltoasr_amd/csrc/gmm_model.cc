@@ -794,7 +794,9 @@ static bool pack_f16x2(const aasr_gmm *g, const std::vector<RowSpec> &rows, cons
       } else if (k - KH == D) {
         v = const_rem;
       }
-      if (!(std::fabs(v) < 60000.0)) return false;
+      // null / zero-weight rows carry kNullConst: any constant whose 2^x is zero in f32 does
+      if (k == D && v <= -1.0e29) v = -60000.0;
+      if (!(std::fabs(v) <= 60000.0)) return false;
       const _Float16 h1 = (_Float16)v;
       const _Float16 h2 = (_Float16)(v - (double)h1);
       if (k == D) const_rem = (v - (double)h1) - (double)h2;

@@ -100,8 +100,9 @@ __device__ __forceinline__ void issue_tile_copy_raw(const float *__restrict__ gt
   const int chunks = tile_floats / 4;
   for (int c0 = wave * 64; c0 < chunks; c0 += nwaves * 64) {
     const float *src = gtile + (size_t)(c0 + lane) * 4;
-    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(
-        (int)(unsigned)(size_t)(__attribute__((address_space(3))) float *)(lds_buf + (size_t)c0 * 4));
+    // the LDS offset is the low half of the generic address (the aperture sits in the high half): no
+    // addrspacecast, whose null check the compiler mis-selects in some instantiations
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_buf + (size_t)c0 * 4));
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(dst), "v"(src) : "memory", "m0");
   }
 }
@@ -727,7 +728,17 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   constexpr int KH = 8 * NK16;
   constexpr int NW = WIDE ? 8 : 4;    // waves per workgroup
   constexpr int NBUF = WIDE ? 3 : 2;  // tile buffers
-  constexpr int JMID = (NK16 + 1) / 2;  // WIDE: slabs before the mid-stream barrier
+  // WIDE: slabs before the mid-stream barrier.  Between two barriers one wave of a SIMD runs the slabs behind its
+  // mid-stream barrier while its partner runs an epilogue FOLLOWED BY the slabs in front of it, so the partner's
+  // stretch is epilogue + JMID slabs of matrix time against (NK16 - JMID) slabs here.  With 30 MFMAs per slab
+  // (bf16x3) the epilogue (~1500 cycles: 64 v_exp_f32 at quarter rate + the adds) is the smaller part and the even
+  // split is fine; with 12 (f16x2) it is four slabs' worth, so it is paired with ONE slab: 1500 + 384 against 1536
+  // cycles and a matrix pipe that is busy 1920 of them (measured: JMID = 3 leaves 59.6 M cycles per launch
+  // for 22.9 M of matrix work, the critical wave being epilogue + 36 MFMAs long).
+  constexpr int JMID = NS == 2 ? 1 : (NK16 + 1) / 2;
+  // f16x2: the fragments of slab j + 1 are requested at the top of slab j into a second register set (12 MFMAs =
+  // 384 cycles ahead); the rolling refill of the three-term form would leave them 4 MFMAs
+  constexpr int NAB = NS == 2 ? 2 : 1;
   float *abuf0 = (float *)smem_raw;
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
@@ -817,12 +828,12 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   // scalar load anywhere in the loop turns every LDS wait of the stream into lgkmcnt(0).
   unsigned mask16_next = t_begin < t_end ? (unsigned)__builtin_amdgcn_readfirstlane((int)close_mask[t_begin]) : 0u;
   unsigned mask_v = 0;
-  u32x4 afr[NS][2];  // A fragments of the current slab, [split][row block]
+  u32x4 afr[NAB][NS][2];  // A fragments of the current slab, [register set][split][row block]
   if (t_begin < t_end) {
 #pragma unroll
     for (int sp = NS - 1; sp >= 0; sp--) {
-      afr[sp][0] = ((const u32x4 *)abuf0 + lane)[(sp * 2 + 0) * 64];
-      afr[sp][1] = ((const u32x4 *)abuf0 + lane)[(sp * 2 + 1) * 64];
+      afr[0][sp][0] = ((const u32x4 *)abuf0 + lane)[(sp * 2 + 0) * 64];
+      afr[0][sp][1] = ((const u32x4 *)abuf0 + lane)[(sp * 2 + 1) * 64];
     }
   }
   int bi = 0;  // buffer of the current tile
@@ -846,6 +857,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     const unsigned long long bits = bits_next;
     if (CL && t + 1 < t_end) bits_next = mrow[(size_t)(t + 1) * TILE_ROWS];
 
+    if (AASR_DBG(32)) __builtin_amdgcn_s_setprio(3);
     f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
     const u32x4 *afrag = (const u32x4 *)acur + lane;  // [slab][split][mb][64 lanes]
     // Rolling A-fragment prefetch.  The products of a slab are ordered by the A split they use,
@@ -864,6 +876,16 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
           issue_tile_copy_raw(apf + (size_t)(t + 2) * kTileFloats, abuf0 + bnn * kTileFloats, kTileFloats, wave, lane, NW);
         __builtin_amdgcn_sched_barrier(0);
       }
+      constexpr int kNoSet = 0;
+      const int cur = NAB == 2 ? (j & 1) : kNoSet;
+      if (NAB == 2 && j + 1 < NK16 && !AASR_DBG(2)) {
+#pragma unroll
+        for (int sp = NS - 1; sp >= 0; sp--) {
+          afr[cur ^ 1][sp][0] = afrag[(((j + 1) * NS + sp) * 2 + 0) * 64];
+          afr[cur ^ 1][sp][1] = afrag[(((j + 1) * NS + sp) * 2 + 1) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int grp = 0; grp < NS; grp++) {
         const int sp = NS - 1 - grp;   // A split used by this group: a3, a2, a1 (f16x2: a2, a1)
@@ -871,18 +893,18 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
 #pragma unroll
         for (int c = 0; c < nprod; c++) {
           const int sb = nprod - 1 - c;
-          c00 = mfma_split<NS>(afr[sp][0], bq[j][sb][0], c00);
-          c01 = mfma_split<NS>(afr[sp][0], bq[j][sb][1], c01);
-          c10 = mfma_split<NS>(afr[sp][1], bq[j][sb][0], c10);
-          c11 = mfma_split<NS>(afr[sp][1], bq[j][sb][1], c11);
+          c00 = mfma_split<NS>(afr[cur][sp][0], bq[j][sb][0], c00);
+          c01 = mfma_split<NS>(afr[cur][sp][0], bq[j][sb][1], c01);
+          c10 = mfma_split<NS>(afr[cur][sp][1], bq[j][sb][0], c10);
+          c11 = mfma_split<NS>(afr[cur][sp][1], bq[j][sb][1], c11);
         }
         __builtin_amdgcn_sched_barrier(0);
         // the aligned word holding tile t+1's bits (the array has a spare element); a 16-bit load
         // would need a zero-extension, which the compiler places -- with its vmcnt wait -- right here
         if (j == (NK16 > 1 ? 1 : 0) && grp == 0) mask_v = ((const uint32_t *)close_mask)[(t + 1) >> 1];
-        if (j + 1 < NK16 && !AASR_DBG(2)) {
-          afr[sp][0] = afrag[(((j + 1) * NS + sp) * 2 + 0) * 64];
-          afr[sp][1] = afrag[(((j + 1) * NS + sp) * 2 + 1) * 64];
+        if (NAB == 1 && j + 1 < NK16 && !AASR_DBG(2)) {
+          afr[kNoSet][sp][0] = afrag[(((j + 1) * NS + sp) * 2 + 0) * 64];
+          afr[kNoSet][sp][1] = afrag[(((j + 1) * NS + sp) * 2 + 1) * 64];
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -902,8 +924,8 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
       const u32x4 *nfrag = (const u32x4 *)anext + lane;
 #pragma unroll
       for (int sp = NS - 1; sp >= 0; sp--) {
-        afr[sp][0] = nfrag[(sp * 2 + 0) * 64];
-        afr[sp][1] = nfrag[(sp * 2 + 1) * 64];
+        afr[0][sp][0] = nfrag[(sp * 2 + 0) * 64];
+        afr[0][sp][1] = nfrag[(sp * 2 + 1) * 64];
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -912,6 +934,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
       asm volatile("" ::"v"(c00), "v"(c01), "v"(c10), "v"(c11));
       continue;
     }
+    if (AASR_DBG(32)) __builtin_amdgcn_s_setprio(0);   // experiment: the epilogue yields to the partner's matrix stream
 
 #pragma unroll
     for (int mb = 0; mb < 2; mb++) {
@@ -1003,6 +1026,342 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   if (WIDE && group == 0) __builtin_amdgcn_s_barrier();  // pairs with the lagging group's last end-of-tile barrier
 }
 
+
+// ---------------------------------------------------------------------------
+// Software-pipelined form of the split-operand kernel (the f16x2 arithmetic runs on it).
+//
+// With three fp16 products per K slab a wave-tile is 60 MFMAs = 1 920 matrix cycles, and its epilogue -- 64
+// v_exp_f32 at quarter rate, the adds, the close logic -- is ~1 600 VALU cycles: no longer the small part.  The
+// phase-shifted wave groups of the kernel above only hide an epilogue under the PARTNER wave's matrix stream, and
+// measured that hides about half of it (rocprofv3: 37.9 M cycles per 10^6-frame launch for 22.9 M of matrix work,
+// VALU co-executing under 41 % of the MFMA cycles; s_setprio either way changes nothing).  What does hide is VALU
+// placed between a wave's OWN MFMAs: an MFMA occupies the matrix pipe for 32 cycles, the in-order wave issues its
+// next instructions meanwhile.  So the tile is processed as two half tiles (its two 32-row blocks), and the matrix
+// stream of one block carries the exponentials of the other:
+//
+//     H0(t): 30 MFMAs into block 0 of tile t     ||  2^x and quad sums of block 1 of tile t-1
+//            close logic of block 1, tile t-1          (branches, log, staging, stores: not interleaved)
+//     H1(t): 30 MFMAs into block 1 of tile t     ||  2^x and quad sums of block 0 of tile t
+//            s_waitcnt vmcnt(0); s_barrier; close logic of block 0, tile t
+//
+// Same 64 accumulator registers (a block is consumed before it is accumulated into again), two accumulator
+// chains per phase instead of four (dependent MFMAs 64 cycles apart), one barrier per tile, two tile buffers, all
+// waves of a workgroup in step -- no wave groups.  A fragments of the next slab are requested one slab (6 MFMAs)
+// ahead into a second register set.  Everything else (operand layout, track epilogue, output groups, row cuts,
+// selection masks) is the kernel above; results are bit-identical between the 4- and 8-wave forms.
+// ---------------------------------------------------------------------------
+template <int NK16, bool GROUPED, bool WIDE, int NS>
+struct PlSmem {
+  static constexpr int kTileBytes = NK16 * NS * 2 * 64 * 16;
+  static constexpr bool kBig = WIDE && GROUPED && 2 * kTileBytes + 8 * FRAMES_PER_WAVE * 34 * 4 <= 160 * 1024;
+  static constexpr int OG = kBig ? 32 : 16;
+  static constexpr int kOutStride = kBig ? 34 : 20;
+  static constexpr int kOutFloatsPerWave = GROUPED ? FRAMES_PER_WAVE * kOutStride : 0;
+  static constexpr int kBytes = 2 * kTileBytes + (WIDE ? 8 : 4) * kOutFloatsPerWave * 4;
+};
+
+template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS>
+__global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_score_pl(
+    const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
+    const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
+    const uint16_t *__restrict__ close_mask, const int32_t *__restrict__ sid, int sid_stride,
+    float *__restrict__ out, int64_t S, int64_t pitch, float ref_ln, int dbg, ClusterArgs cl) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  typedef PlSmem<NK16, GROUPED, WIDE, NS> SM;
+  constexpr int OG = SM::OG;
+  constexpr int kTileFloats = SM::kTileBytes / 4;
+  constexpr int kOS = SM::kOutStride;
+  constexpr int KH = 8 * NK16;
+  constexpr int NW = WIDE ? 8 : 4;
+  constexpr int NPROD = NS * (NS + 1) / 2;       // products kept per slab: 3 (f16x2), 6 (bf16x3)
+  constexpr int MPH = NK16 * NPROD * 2;          // MFMAs per phase (one 32-row block, two frame blocks)
+  float *abuf0 = (float *)smem_raw;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  float *ost = abuf0 + 2 * kTileFloats + wave * SM::kOutFloatsPerWave;
+  const int n = lane & 31;
+  const int h = lane >> 5;  // K half of a slab held by this lane AND its row track
+  const int64_t f0 = (int64_t)blockIdx.x * (NW * FRAMES_PER_WAVE) + wave * FRAMES_PER_WAVE;
+
+  // ---- frame operand: lane (n, h) holds k = 16*j + 8*h + i, i < 8, of slab j
+  u32x4 bq[NK16][NS][2];
+#pragma unroll
+  for (int nb = 0; nb < 2; nb++) {
+    int64_t f = f0 + nb * 32 + n;
+    if (f > F - 1) f = F - 1;
+    const float *xr = frames + f * dim;
+#pragma unroll
+    for (int j = 0; j < NK16; j++) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int k = 16 * j + 8 * h + i;
+        const int d = k < KH ? k : k - KH;
+        const int dc = d < dim ? d : 0;
+        const float xc = xr[dc] - pivot[dc];
+        float xq = xc;
+        if (NS == 2) xq = fminf(fmaxf(xc, -kF16Clamp), kF16Clamp);  // fp16 range (see the f16x2 note above)
+        float val = k < KH ? xq : xq * xq;
+        if (d >= dim) val = (k == dim || (NS == 2 && k == KH + dim)) ? 1.0f : 0.0f;
+        v[i] = val;
+      }
+      if constexpr (NS == 3) {
+        unsigned w1[4], w2[4], w3[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) split3_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i], w3[i]);
+        bq[j][0][nb] = u32x4{w1[0], w1[1], w1[2], w1[3]};
+        bq[j][1][nb] = u32x4{w2[0], w2[1], w2[2], w2[3]};
+        bq[j][2][nb] = u32x4{w3[0], w3[1], w3[2], w3[3]};
+      } else {
+        unsigned w1[4], w2[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) split2_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i]);
+        bq[j][0][nb] = u32x4{w1[0], w1[1], w1[2], w1[3]};
+        bq[j][1][nb] = u32x4{w2[0], w2[1], w2[2], w2[3]};
+      }
+    }
+  }
+
+  const int64_t t_begin = split_row[4 * blockIdx.y];
+  const int64_t t_end = split_row[4 * blockIdx.y + 4];
+  const float *apf = (const float *)apack;
+  if (t_begin < t_end) issue_tile_copy_raw(apf + (size_t)t_begin * kTileFloats, abuf0, kTileFloats, wave, lane, NW);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  float s0 = 0.0f, s1 = 0.0f;
+  int closes = split_row[4 * blockIdx.y + 1 + (GROUPED ? 0 : h)];
+  const int32_t *my_sid = sid + h * sid_stride;
+  int next_sid = GROUPED ? 0 : my_sid[closes];
+  float *orow0 = out + (f0 + n) * pitch;  // pitch: row stride of `out` in floats (>= S)
+  float *orow1 = out + (f0 + 32 + n) * pitch;
+  const bool ok0 = f0 + n < F, ok1 = f0 + 32 + n < F;
+  const float floor_val = CL ? cl.floor_val : LOG_TINY_F;
+  const unsigned long long *mrow =
+      CL ? cl.maskrow + (size_t)(f0 >> 6) * cl.rows_padded + lane : nullptr;
+
+  // close logic of one 32-row block: P[nb][q] = this lane's sum of 2^x over quad q for frame block nb
+  auto commit = [&](const float (&P)[2][4], unsigned nib) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      s0 += P[0][q];
+      s1 += P[1][q];
+      if ((nib >> q) & 1) {
+        float l0 = fmaf(__builtin_amdgcn_logf(s0), LN2_F, -ref_ln);
+        float l1 = fmaf(__builtin_amdgcn_logf(s1), LN2_F, -ref_ln);
+        l0 = fmaxf(l0, floor_val);
+        l1 = fmaxf(l1, floor_val);
+        s0 = 0.0f;
+        s1 = 0.0f;
+        closes++;
+        if (!GROUPED) {
+          if (ok0) orow0[next_sid] = l0;
+          if (ok1) orow1[next_sid] = l1;
+          next_sid = my_sid[closes];
+        } else {
+          const int pairs_closed = closes;
+          const int slot = ((2 * (pairs_closed - 1)) & (OG - 1)) + h;
+          ost[n * kOS + slot] = l0;
+          ost[(32 + n) * kOS + slot] = l1;
+          const int64_t closed = 2 * (int64_t)pairs_closed < S ? 2 * (int64_t)pairs_closed : S;
+          if (((2 * pairs_closed) & (OG - 1)) == 0 || 2 * (int64_t)pairs_closed >= S) {
+            const int64_t s_base = ((closed - 1) / OG) * OG;
+            const int cnt = (int)(closed - s_base);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (OG == 32 && cnt == OG && f0 + FRAMES_PER_WAVE <= F) {
+              // 8 lanes x 16 B cover the 32-state group; 8 frame rows per instruction
+              const int k4 = lane & 7, r8 = lane >> 3;
+              float *op = out + (f0 + r8) * pitch + s_base + 4 * k4;
+              const float *ip = ost + r8 * kOS + 4 * k4;  // stride 34: 8-byte aligned
+#pragma unroll
+              for (int i = 0; i < FRAMES_PER_WAVE / 8; i++) {
+                const f32x2 lo = *(const f32x2 *)(ip + i * 8 * kOS);
+                const f32x2 hi = *(const f32x2 *)(ip + i * 8 * kOS + 2);
+                const f32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                *(f32x4u *)(op + (int64_t)i * 8 * pitch) = v;
+              }
+            } else if (cnt == OG && f0 + FRAMES_PER_WAVE <= F) {
+              // 4 lanes x 16 B cover the 16-state group; 16 frame rows per instruction
+              const int k4 = lane & 3, r16 = lane >> 2;
+              float *op = out + (f0 + r16) * pitch + s_base + 4 * k4;
+              const float *ip = ost + r16 * kOS + 4 * k4;
+#pragma unroll
+              for (int i = 0; i < FRAMES_PER_WAVE / 16; i++) {
+                const f32x4 v = *(const f32x4 *)(ip + i * 16 * kOS);
+                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                *(f32x4u *)(op + (int64_t)i * 16 * pitch) = v;
+              }
+            } else {
+              constexpr int RPI = 64 / OG;
+              const int k = lane & (OG - 1);
+#pragma unroll 4
+              for (int i = 0; i < FRAMES_PER_WAVE / RPI; i++) {
+                const int row = i * RPI + lane / OG;
+                const float v = ost[row * kOS + k];
+                if (k < cnt && f0 + row < F) out[(f0 + row) * pitch + s_base + k] = v;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+      }
+    }
+  };
+
+  // element `k` (0..31) of a block's exponentials: frame block nb = k / 16, quad q, element e; the quad's four
+  // values are summed pairwise as the kernel above does, (x0 + x1) + (x2 + x3)
+  float t0 = 0.0f, t1 = 0.0f;
+  auto epi_step = [&](int k, int mb, const f32x16 &c0, const f32x16 &c1, unsigned long long bits, float (&P)[2][4]) {
+    const int nb = k >> 4, q = (k >> 2) & 3, e = k & 3;
+    float v = nb ? c1[4 * q + e] : c0[4 * q + e];
+    if (CL) v = mask_select(v, bits, 32 * nb + 8 * q + 4 * mb + e);  // k_cluster_expand's bit layout
+    // pinned where it is written: left as a builtin the compiler sinks all 32 exponentials of a phase into the
+    // close logic that consumes P, i.e. out from under the matrix stream (s_nop: a VALU read of a transcendental's
+    // result needs one wait state, and the hazard recogniser does not look inside assembly)
+    float x;
+    asm volatile("v_exp_f32 %0, %1\n\ts_nop 0" : "=v"(x) : "v"(v));
+    if (e == 0) t0 = x;
+    else if (e == 1) t0 += x;
+    else if (e == 2) t1 = x;
+    else P[nb][q] = t0 + (t1 + x);
+  };
+
+  // one phase: the MFMAs of 32-row block MB of the tile in `acur` into (n0, n1), carrying the exponentials of the
+  // other block's accumulators (o0, o1, selection bits obits) into P
+  u32x4 afr[2][NS];  // A fragments [register set][split] of the block being accumulated
+  auto load_frags = [&](const float *tile, int j, int mb, int set) {
+    const u32x4 *afrag = (const u32x4 *)tile + lane;  // [slab][split][mb][64 lanes]
+#pragma unroll
+    for (int sp = NS - 1; sp >= 0; sp--) afr[set][sp] = afrag[((j * NS + sp) * 2 + mb) * 64];
+  };
+
+  f32x16 cA0 = {0}, cA1 = {0}, cB0 = {0}, cB1 = {0};
+  unsigned long long bits_cur = 0, bits_prev = 0;
+  unsigned mask_cur = 0, mask_prev = 0;
+  unsigned mask_v = 0;
+  if (t_begin < t_end) {
+    mask_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)close_mask[t_begin]);
+    if (CL) bits_cur = mrow[(size_t)t_begin * TILE_ROWS];
+    load_frags(abuf0, 0, 0, 0);
+  }
+  int bi = 0;
+  for (int64_t t = t_begin; t < t_end; t++) {
+    float *acur = abuf0 + bi * kTileFloats;
+    float *anext = abuf0 + (bi ^ 1) * kTileFloats;
+    bi ^= 1;
+    // every wave has passed the barrier that ended tile t-1: its buffer is free for tile t+1
+    if (t + 1 < t_end) issue_tile_copy_raw(apf + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane, NW);
+    // close bits and selection bits of tile t+1: vector loads waited for by the vmcnt(0) in front of the barrier
+    // (an aligned 32-bit word: the array has a spare element; through inline assembly so that it stays a VECTOR
+    // load -- as a scalar load it would turn every LDS wait of the stream into lgkmcnt(0))
+    {
+      const uint32_t *mp = (const uint32_t *)close_mask + ((t + 1) >> 1);
+      asm volatile("global_load_dword %0, %1, off" : "=v"(mask_v) : "v"(mp) : "memory");
+    }
+    unsigned long long bits_next = 0;
+    if (CL && t + 1 < t_end) bits_next = mrow[(size_t)(t + 1) * TILE_ROWS];
+
+    float P[2][4];
+    // ---------------- H0: block 0 of tile t  ||  exponentials of block 1 of tile t-1
+    {
+      int mi = 0;
+#pragma unroll
+      for (int j = 0; j < NK16; j++) {
+        const int cur = j & 1;
+        if (j + 1 < NK16) load_frags(acur, j + 1, 0, cur ^ 1);
+        else load_frags(acur, 0, 1, cur ^ 1);     // slab 0 of block 1, for H1
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int grp = 0; grp < NS; grp++) {
+          const int sp = NS - 1 - grp;
+#pragma unroll
+          for (int c = 0; c <= grp; c++) {
+            const int sb = grp - c;
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) {
+              if (j == 0 && grp == 0 && c == 0) {
+                const f32x16 z = {0};
+                if (nb == 0) cA0 = mfma_split<NS>(afr[cur][sp], bq[j][sb][0], z);
+                else cA1 = mfma_split<NS>(afr[cur][sp], bq[j][sb][1], z);
+              } else {
+                if (nb == 0) cA0 = mfma_split<NS>(afr[cur][sp], bq[j][sb][0], cA0);
+                else cA1 = mfma_split<NS>(afr[cur][sp], bq[j][sb][1], cA1);
+              }
+#pragma unroll
+              for (int k = mi * 32 / MPH; k < (mi + 1) * 32 / MPH; k++) epi_step(k, 1, cB0, cB1, bits_prev, P);
+              mi++;
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+      }
+    }
+    if (t > t_begin) commit(P, (GROUPED ? mask_prev : (h ? mask_prev >> 8 : mask_prev)) >> 4 & 0xfu);
+    // ---------------- H1: block 1 of tile t  ||  exponentials of block 0 of tile t
+    {
+      int mi = 0;
+      constexpr int set0 = NK16 & 1;   // the register set H0 left slab 0 of block 1 in
+#pragma unroll
+      for (int j = 0; j < NK16; j++) {
+        const int cur = (j + set0) & 1;
+        if (j + 1 < NK16) {
+          load_frags(acur, j + 1, 1, cur ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int grp = 0; grp < NS; grp++) {
+          const int sp = NS - 1 - grp;
+#pragma unroll
+          for (int c = 0; c <= grp; c++) {
+            const int sb = grp - c;
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) {
+              if (j == 0 && grp == 0 && c == 0) {
+                const f32x16 z = {0};
+                if (nb == 0) cB0 = mfma_split<NS>(afr[cur][sp], bq[j][sb][0], z);
+                else cB1 = mfma_split<NS>(afr[cur][sp], bq[j][sb][1], z);
+              } else {
+                if (nb == 0) cB0 = mfma_split<NS>(afr[cur][sp], bq[j][sb][0], cB0);
+                else cB1 = mfma_split<NS>(afr[cur][sp], bq[j][sb][1], cB1);
+              }
+#pragma unroll
+              for (int k = mi * 32 / MPH; k < (mi + 1) * 32 / MPH; k++) epi_step(k, 0, cA0, cA1, bits_cur, P);
+              mi++;
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+      }
+    }
+    // end of tile: every wave is done reading `acur`, every wave's share of tile t+1 has landed
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(mask_v) : : "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < t_end) {
+      load_frags(anext, 0, 0, 0);   // slab 0 of the next tile's block 0: in flight during the close logic
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    commit(P, (GROUPED ? mask_cur : (h ? mask_cur >> 8 : mask_cur)) & 0xfu);
+    mask_prev = mask_cur;
+    bits_prev = bits_cur;
+    {
+      const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)mask_v);
+      mask_cur = ((t + 1) & 1) ? w >> 16 : w & 0xffffu;
+    }
+    bits_cur = bits_next;
+  }
+  // drain: block 1 of the last tile
+  if (t_begin < t_end) {
+    float P[2][4];
+#pragma unroll
+    for (int k = 0; k < 32; k++) epi_step(k, 1, cB0, cB1, bits_prev, P);
+    commit(P, (GROUPED ? mask_prev : (h ? mask_prev >> 8 : mask_prev)) >> 4 & 0xfu);
+  }
+}
+
 template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS>
 static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
                           float *d_out, hipStream_t stream, const ClusterArgs &cl, int64_t pitch) {
@@ -1037,13 +1396,47 @@ static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *
   AASR_HIP(hipGetLastError());
 }
 
+template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS>
+static void launch_pl_t(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
+                        float *d_out, hipStream_t stream, const ClusterArgs &cl, int64_t pitch) {
+  constexpr int NW = WIDE ? 8 : 4;
+  const int64_t blocks = (F + NW * FRAMES_PER_WAVE - 1) / (NW * FRAMES_PER_WAVE);
+  const int smem = PlSmem<NK16, GROUPED, WIDE, NS>::kBytes;
+  static bool attr_set[64] = {false};
+  auto kern = k_gmm_diag_score_pl<NK16, GROUPED, CL, WIDE, NS>;
+  if (!attr_set[g->device & 63]) {
+    AASR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set[g->device & 63] = true;
+  }
+  static const int force_r = getenv("AASR_SPLITS") ? atoi(getenv("AASR_SPLITS")) : 0;
+  const double slots = (WIDE ? 1.0 : 2.0) * (g->num_cus > 0 ? g->num_cus : 256);
+  int R = 1;
+  double best_eff = 0;
+  for (int r = 1; r <= L.max_splits; r++) {
+    double x = (double)blocks * r / slots;
+    double eff = x / std::ceil(x);
+    if (eff > best_eff + 0.005) {
+      best_eff = eff;
+      R = r;
+    }
+  }
+  if (force_r >= 1 && force_r <= L.max_splits) R = force_r;
+  const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(NW * 64), smem, stream, d_frames, F,
+                     g->dim, g->d_pivot.p, NS == 3 ? L.a16.p : L.a16h.p, split_row, L.close.p, L.sid.p, L.sid_stride,
+                     d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, 0, cl);
+  AASR_HIP(hipGetLastError());
+}
+
 // the 8-wave form needs three tile buffers + eight staging areas in 160 KB of LDS
 template <int N, int NS>
 static constexpr bool wide_ok() {
+  if (NS == 2) return PlSmem<N, true, true, NS>::kBytes <= 160 * 1024;
   return 3 * Bf16Smem<N, true, true, NS>::kTileBytes + 8 * Bf16Smem<N, true, true, NS>::kOutFloatsPerWave * 4 <= 160 * 1024;
 }
 
-// NS = 3: three bf16 terms (AASR_PREC_BF16X3); NS = 2: two fp16 terms (AASR_PREC_F16X2)
+// NS = 3: three bf16 terms (AASR_PREC_BF16X3) on the wave-group kernel; NS = 2: two fp16 terms (AASR_PREC_F16X2) on
+// the software-pipelined kernel
 template <int NS>
 static bool launch_split(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
                          float *d_out, hipStream_t stream, const ClusterArgs *cl = nullptr, int64_t pitch = 0) {
@@ -1054,28 +1447,35 @@ static bool launch_split(const aasr_gmm *g, const TrackLayout &L, const float *d
   static const int wide_env = getenv("AASR_BF16_WIDE") ? atoi(getenv("AASR_BF16_WIDE")) : -1;
   // small batches (a decoder's per-utterance blocks) fill the chip better with 256-frame workgroups
   const int wide = wide_env >= 0 ? wide_env : (F >= 8192 ? 1 : 0);
-  // masked (clustered) runs: the bf16x3 8-wave form with masks needs 254 VGPRs + spills and was measured
-  // slower, so it keeps 4-wave workgroups; the f16x2 form holds a third fewer operand registers
-  const bool wide_cl = NS == 2;
   switch (L.nk16) {
-#define AASR_CASE(N)                                                                               \
-  case N:                                                                                          \
-    if (cl && wide && wide_cl && wide_ok<N, NS>()) {                                               \
-      if (L.grouped) launch_bf16_t<N, true, true, true, NS>(g, L, d_frames, F, d_out, stream, *cl, pitch);    \
-      else launch_bf16_t<N, false, true, true, NS>(g, L, d_frames, F, d_out, stream, *cl, pitch);             \
-    } else if (cl) {                                                                               \
-      if (L.grouped) launch_bf16_t<N, true, true, false, NS>(g, L, d_frames, F, d_out, stream, *cl, pitch);   \
-      else launch_bf16_t<N, false, true, false, NS>(g, L, d_frames, F, d_out, stream, *cl, pitch);            \
-    } else if (wide && wide_ok<N, NS>()) {                                                         \
-      if (L.grouped) launch_bf16_t<N, true, false, true, NS>(g, L, d_frames, F, d_out, stream, none, pitch);  \
-      else launch_bf16_t<N, false, false, true, NS>(g, L, d_frames, F, d_out, stream, none, pitch);           \
-    } else {                                                                                       \
-      if (L.grouped) launch_bf16_t<N, true, false, false, NS>(g, L, d_frames, F, d_out, stream, none, pitch); \
-      else launch_bf16_t<N, false, false, false, NS>(g, L, d_frames, F, d_out, stream, none, pitch);          \
-    }                                                                                              \
+#define AASR_LAUNCH(N, GR, CLF, WD, CLA)                                                   \
+  do {                                                                                     \
+    if constexpr (NS == 2) launch_pl_t<N, GR, CLF, WD, NS>(g, L, d_frames, F, d_out, stream, CLA, pitch);   \
+    else launch_bf16_t<N, GR, CLF, WD, NS>(g, L, d_frames, F, d_out, stream, CLA, pitch);  \
+  } while (0)
+#define AASR_CASE(N)                                                                       \
+  case N:                                                                                  \
+    if (cl && NS == 2 && wide && wide_ok<N, NS>()) {                                       \
+      /* masked (clustered) runs: the bf16x3 8-wave form with masks needs 254 VGPRs + spills and was */ \
+      /* measured slower, so it keeps 4-wave workgroups; the f16x2 kernel has the registers          */ \
+      if constexpr (NS == 2) {                                                             \
+        if (L.grouped) AASR_LAUNCH(N, true, true, true, *cl);                              \
+        else AASR_LAUNCH(N, false, true, true, *cl);                                       \
+      }                                                                                    \
+    } else if (cl) {                                                                       \
+      if (L.grouped) AASR_LAUNCH(N, true, true, false, *cl);                               \
+      else AASR_LAUNCH(N, false, true, false, *cl);                                        \
+    } else if (wide && wide_ok<N, NS>()) {                                                 \
+      if (L.grouped) AASR_LAUNCH(N, true, false, true, none);                              \
+      else AASR_LAUNCH(N, false, false, true, none);                                       \
+    } else {                                                                               \
+      if (L.grouped) AASR_LAUNCH(N, true, false, false, none);                             \
+      else AASR_LAUNCH(N, false, false, false, none);                                      \
+    }                                                                                      \
     return true;
     AASR_CASE(1) AASR_CASE(2) AASR_CASE(3) AASR_CASE(4) AASR_CASE(5) AASR_CASE(6) AASR_CASE(8)
 #undef AASR_CASE
+#undef AASR_LAUNCH
     default:
       return false;
   }

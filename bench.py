@@ -477,7 +477,7 @@ def main():
             # (lo*lo dropped), f32 accumulation: same 1e-4 parity bar (state-level worst 3.4e-5 on 10^7 states,
             # tools/exp_fp16_split.py), chosen per model by its conditioning.  Ceiling for ALGORITHMIC flops:
             # the dense fp16 peak / 3.
-            kernel, peak, dtype = ("k_gmm_diag_score_bf16x3<5,true,false,true,2>", BF16_MATRIX_PEAK_TFLOPS / 3.0,
+            kernel, peak, dtype = ("k_gmm_diag_score_pl<5,true,false,true,2>", BF16_MATRIX_PEAK_TFLOPS / 3.0,
                                    "f32 (2-term fp16 split on the matrix cores, f32 accumulate)")
             peak_note = ("dense FP16 matrix peak 2500 TFLOP/s / 3 fp16 products per product; "
                          "executed matrix flops = 3 * 160/156 * achieved")

@@ -369,6 +369,7 @@ def test_f16x2_is_chosen_by_conditioning_and_clamps_far_frames(capi, oracle):
     """AASR_PREC_F16X2 (the default): the two-term fp16 form runs only for models whose conditioning estimate is
     below its own, tighter limits -- others fall back to the three-term bf16 form under the same setting -- and a
     frame beyond the fp16 clamp (|x - pivot| > 240, its square would overflow) comes out at the floor as in the oracle."""
+    import ctypes as C
     L = capi.lib()
     L.aasr_debug_kappa.restype = C.c_double
     L.aasr_debug_kappa.argtypes = [C.c_void_p]
