@@ -6,7 +6,9 @@ root=$(pwd); out=$root/gpurun_out/kstats_$name; rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- bash -c "cd $root && $*" > $out/log.txt 2>&1
 cd $root
-f=$(find $out -name "*kernel_stats.csv" | head -1)
+# the command may start helper processes with kernels of their own (bench.py's matrix-pipe probe): take the
+# summary of the process that ran the engine's kernels
+f=$(grep -l "aasr::" $(find $out -name "*kernel_stats.csv") | head -1)
 cp "$f" $root/gpurun_out/kstats_$name.csv
 python - "$root/gpurun_out/kstats_$name.csv" <<'PY'
 import csv, sys
