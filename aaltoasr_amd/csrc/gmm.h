@@ -187,6 +187,9 @@ struct ClusterState {
   int dimp = 0;                    // dimension padded to a multiple of 8
   DevBuf<double> rec;              // [Cs/8][dimp][8][2] (mean, precision) of the centres
   DevBuf<double> cconst;           // [Cs] constants
+  DevBuf<double> rec_fma, cconst_fma;  // the same centres in the expanded form (p mu, -p/2), c - 1/2 sum p mu^2
+  DevBuf<double> bpack;            // ... packed as f64 MFMA operands: [tile of 16][k step][64 lanes]
+  int mfma_ks = 0;                 // k steps of 4 covering 2 dim + 1
   DevBuf<int32_t> csize;           // [Cs] members per cluster (0 beyond C)
   DevBuf<int32_t> crow[2];         // cluster of each packed row of the grouped / independent
                                    // track layout (C = no cluster or null row)

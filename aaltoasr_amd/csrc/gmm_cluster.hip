@@ -58,6 +58,7 @@
 #include <cstdlib>
 #include <fstream>
 #include <map>
+#include <type_traits>
 #include <sstream>
 
 #include "gmm.h"
@@ -151,6 +152,140 @@ __global__ __launch_bounds__(kCentreThreads) void k_cluster_centres(
         // kernels never see the rare denormal branch and its exp()
         ll64[f * Cs + (int64_t)cg * 8 + j] = lin_key(ll);
       }
+    }
+    __syncthreads();
+  }
+}
+
+// The same centre log-likelihoods for FLOAT frames in the expanded form, ll = c' + sum_d x (a + b x) with
+// a = p mu, b = -p/2, c' = c - 1/2 sum p mu^2 (all formed in double on the host): two f64 FMAs per frame,
+// cluster and dimension instead of the reference order's four operations, and the records of dimension d + 1
+// requested while dimension d is computed (the reference-order kernel waits out an LDS round trip per
+// dimension: it sat at 42 % of its f64 rate).  Against the reference order the key moves by ~1e-13 relative
+// (cancellation at f64 precision), which can re-order two centres only when their likelihoods agree to twelve
+// digits; structured ties -- duplicate, empty and underflowing centres -- come out identical as before, because
+// identical parameters give identical arithmetic.  AASR_PREC_F64 keeps the reference-order kernel.
+__global__ __launch_bounds__(kCentreThreads) void k_cluster_centres_fma(
+    const float *__restrict__ frames, int64_t F, int dim, int dimp, const double *__restrict__ rec,
+    const double *__restrict__ cconst, int groups, int groups_per_y, double *__restrict__ ll64, int64_t Cs) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  double *pbuf = (double *)smem_c;                                 // [2][dimp][8][2]
+  float *xs = (float *)(smem_c + (size_t)2 * dimp * 16 * 8);       // [dimp][kCentreThreads]
+  const int tid = threadIdx.x;
+  const int64_t f = (int64_t)blockIdx.x * kCentreThreads + tid;
+  const int64_t fc = f < F ? f : F - 1;
+  for (int d = 0; d < dimp; d++) xs[d * kCentreThreads + tid] = d < dim ? frames[fc * dim + d] : 0.0f;
+  const int g_begin = blockIdx.y * groups_per_y;
+  const int g_end = min(groups, g_begin + groups_per_y);
+  const int rec_doubles = dimp * 16;
+  for (int i = tid; i < rec_doubles; i += kCentreThreads) pbuf[i] = rec[(size_t)g_begin * rec_doubles + i];
+  __syncthreads();
+  for (int cg = g_begin; cg < g_end; cg++) {
+    const double *cur = pbuf + ((cg - g_begin) & 1) * rec_doubles;
+    double *nxt = pbuf + ((cg - g_begin + 1) & 1) * rec_doubles;
+    if (cg + 1 < g_end)
+      for (int i = tid; i < rec_doubles; i += kCentreThreads) nxt[i] = rec[(size_t)(cg + 1) * rec_doubles + i];
+    double acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0.0;
+    f64x2 r0[8], r1[8];
+    float x0 = xs[tid], x1 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r0[j] = ((const f64x2 *)cur)[j];
+#pragma unroll 1
+    for (int d = 0; d < dimp; d += 2) {   // dimp is a multiple of 8
+      x1 = xs[(d + 1) * kCentreThreads + tid];
+#pragma unroll
+      for (int j = 0; j < 8; j++) r1[j] = ((const f64x2 *)(cur + (d + 1) * 16))[j];
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const double x = (double)x0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] = __builtin_fma(x, __builtin_fma(r0[j].y, x, r0[j].x), acc[j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (d + 2 < dimp) {
+        x0 = xs[(d + 2) * kCentreThreads + tid];
+#pragma unroll
+        for (int j = 0; j < 8; j++) r0[j] = ((const f64x2 *)(cur + (d + 2) * 16))[j];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const double x = (double)x1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] = __builtin_fma(x, __builtin_fma(r1[j].y, x, r1[j].x), acc[j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (f < F) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) ll64[f * Cs + (int64_t)cg * 8 + j] = lin_key(acc[j] + cconst[cg * 8 + j]);
+    }
+    __syncthreads();
+  }
+}
+
+// The expanded form is a dense contraction over K = 2 dim + 1, so it also runs on the f64 MATRIX pipe
+// (v_mfma_f64_16x16x4_f64: the same 78.6 TFLOP/s as the f64 vector rate on this part, but an operand is fetched
+// once per 16 x 16 block instead of once per frame, cluster and dimension -- the vector kernels above are bound by
+// their LDS broadcast reads, 16 bytes per pair and dimension on a pipe the whole CU shares).  A wave keeps the
+// K x 32 operand of its 32 frames in registers (x, x^2 exact in double, 1), the coefficient tiles of 16 clusters
+// stream through LDS ([k step][lane] doubles, host-packed: one MFMA operand is 512 contiguous bytes), 8 waves =
+// 256 frames per workgroup.  Same keys as k_cluster_centres_fma to ~1e-13 (another summation order).
+constexpr int kMfmaCentreWaves = 8;
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+template <int KS>   // k steps of 4: 4 KS >= 2 dim + 1
+__global__ __launch_bounds__(64 * kMfmaCentreWaves) void k_cluster_centres_mfma(
+    const float *__restrict__ frames, int64_t F, int dim, const double *__restrict__ bpack, int tiles,
+    int tiles_per_y, double *__restrict__ ll64, int64_t Cs) {
+  __shared__ __attribute__((aligned(16))) double btile[2][KS * 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int64_t f0 = (int64_t)blockIdx.x * (32 * kMfmaCentreWaves) + wave * 32;
+  double a[2][KS];
+#pragma unroll
+  for (int nb = 0; nb < 2; nb++) {
+    int64_t f = f0 + nb * 16 + i16;
+    if (f > F - 1) f = F - 1;
+    const float *xr = frames + f * dim;
+#pragma unroll
+    for (int q = 0; q < KS; q++) {
+      const int K = 4 * q + kq;
+      double v = 0.0;
+      if (K < dim) v = (double)xr[K];
+      else if (K < 2 * dim) {
+        const double x = (double)xr[K - dim];
+        v = x * x;
+      } else if (K == 2 * dim) v = 1.0;
+      a[nb][q] = v;
+    }
+  }
+  const int t_begin = blockIdx.y * tiles_per_y;
+  const int t_end = min(tiles, t_begin + tiles_per_y);
+  constexpr int kTileDoubles = KS * 64;
+  for (int i = tid; i < kTileDoubles; i += 64 * kMfmaCentreWaves) btile[0][i] = bpack[(size_t)t_begin * kTileDoubles + i];
+  __syncthreads();
+  for (int t = t_begin; t < t_end; t++) {
+    const double *cur = btile[(t - t_begin) & 1];
+    double *nxt = btile[(t - t_begin + 1) & 1];
+    if (t + 1 < t_end)
+      for (int i = tid; i < kTileDoubles; i += 64 * kMfmaCentreWaves) nxt[i] = bpack[(size_t)(t + 1) * kTileDoubles + i];
+    f64x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < KS; q++) {
+      const double b = cur[q * 64 + lane];
+      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][q], b, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][q], b, c1, 0, 0, 0);
+    }
+    // D[i = 4 r + lane / 16][j = lane % 16] (register r of the f64 16x16 result): frame f0 + 16 nb + 4 r + kq,
+    // cluster 16 t + i16
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int64_t fa = f0 + 4 * r + kq, fb = fa + 16;
+      const bool col = (int64_t)t * 16 + i16 < Cs;   // Cs is a multiple of 8: the last tile may be half a tile
+      if (col && fa < F) ll64[fa * Cs + (int64_t)t * 16 + i16] = lin_key(c0[r]);
+      if (col && fb < F) ll64[fb * Cs + (int64_t)t * 16 + i16] = lin_key(c1[r]);
     }
     __syncthreads();
   }
@@ -786,6 +921,37 @@ void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
   }
   n.rec.upload(rec.data(), rec.size());
   n.cconst.upload(n.c_cst.data(), n.c_cst.size());
+  {  // expanded-form records (a, b) = (p mu, -p / 2) and constants c - 1/2 sum p mu^2 for k_cluster_centres_fma
+    std::vector<double> rec2(rec.size(), 0.0), cst2((size_t)n.Cs, 0.0);
+    for (int c = 0; c < n.C; c++) {
+      double q = 0;
+      for (int d = 0; d < m.dim; d++) {
+        const double mu = n.c_mean[(size_t)c * m.dim + d], pr = n.c_prec[(size_t)c * m.dim + d];
+        const size_t at = ((size_t)(c / 8) * n.dimp + d) * 16 + 2 * (size_t)(c % 8);
+        rec2[at] = pr * mu;
+        rec2[at + 1] = -0.5 * pr;
+        q += pr * mu * mu;
+      }
+      cst2[(size_t)c] = n.c_cst[(size_t)c] - 0.5 * q;
+    }
+    n.rec_fma.upload(rec2.data(), rec2.size());
+    n.cconst_fma.upload(cst2.data(), cst2.size());
+    // k_cluster_centres_mfma: [tile of 16 clusters][k step][lane] = coefficient K = 4 q + lane / 16 of cluster
+    // 16 t + lane % 16 (K < dim: p mu; < 2 dim: -p / 2; == 2 dim: the constant; Cs is a multiple of 8, the tiles
+    // round up to 16 with zero columns that land in the padding of a row of ll64 or are skipped)
+    n.mfma_ks = (2 * m.dim + 1 + 3) / 4;
+    const int tiles16 = (n.Cs + 15) / 16;
+    std::vector<double> bp((size_t)tiles16 * n.mfma_ks * 64, 0.0);
+    for (int c = 0; c < n.C; c++)
+      for (int K = 0; K <= 2 * m.dim; K++) {
+        double v;
+        if (K < m.dim) v = n.c_prec[(size_t)c * m.dim + K] * n.c_mean[(size_t)c * m.dim + K];
+        else if (K < 2 * m.dim) v = -0.5 * n.c_prec[(size_t)c * m.dim + (K - m.dim)];
+        else v = cst2[(size_t)c];
+        bp[((size_t)(c / 16) * n.mfma_ks + K / 4) * 64 + (size_t)(K % 4) * 16 + (c % 16)] = v;
+      }
+    n.bpack.upload(bp.data(), bp.size());
+  }
   n.csize.upload(n.csize_h.data(), n.csize_h.size());
   // W[s][c]: weight of state s carried by cluster c (components outside every cluster are
   // always exact and carry none)
@@ -861,6 +1027,46 @@ void gmm_set_clustering_min_evals(aasr_gmm *g, double min_clusters, double min_g
   cl.enabled = true;
 }
 
+template <int KS>
+static void launch_centres_mfma_t(aasr_gmm *g, const float *d_frames, int64_t F, hipStream_t stream) {
+  ClusterState &cl = g->cl;
+  const int tiles = (int)((cl.Cs + 15) / 16);
+  const int64_t bx = (F + 32 * kMfmaCentreWaves - 1) / (32 * kMfmaCentreWaves);
+  // cut the cluster tiles over blockIdx.y so that the grid fills the chip in whole rounds (2 workgroups of 8
+  // waves per CU)
+  const double slots = 2.0 * (double)(g->num_cus > 0 ? g->num_cus : 256);
+  int ny = 1;
+  double best = 0;
+  for (int y = 1; y <= std::min(tiles, 16); y++) {
+    const int ty = (tiles + y - 1) / y;
+    const int yy = (tiles + ty - 1) / ty;
+    const double x = (double)bx * yy / slots;
+    const double eff = x < 1.0 ? x : x / std::ceil(x);
+    if (eff > best + 0.02) {
+      best = eff;
+      ny = yy;
+    }
+  }
+  const int tpy = (tiles + ny - 1) / ny;
+  ny = (tiles + tpy - 1) / tpy;
+  hipLaunchKernelGGL(k_cluster_centres_mfma<KS>, dim3((unsigned)bx, (unsigned)ny), dim3(64 * kMfmaCentreWaves), 0, stream,
+                     d_frames, F, g->dim, cl.bpack.p, tiles, tpy, cl.ll64.p, (int64_t)cl.Cs);
+  AASR_HIP(hipGetLastError());
+}
+
+static bool launch_centres_mfma(aasr_gmm *g, const float *d_frames, int64_t F, hipStream_t stream) {
+  switch (g->cl.mfma_ks) {
+#define AASR_CASE(N)                                        \
+  case N:                                                   \
+    launch_centres_mfma_t<N>(g, d_frames, F, stream);       \
+    return true;
+    AASR_CASE(7) AASR_CASE(14) AASR_CASE(20) AASR_CASE(21) AASR_CASE(24) AASR_CASE(32)
+#undef AASR_CASE
+    default:
+      return false;   // other dimensions keep the vector kernel
+  }
+}
+
 template <typename XT>
 static void launch_centres(aasr_gmm *g, const XT *d_frames, int64_t F, hipStream_t stream) {
   ClusterState &cl = g->cl;
@@ -891,6 +1097,26 @@ static void launch_centres(aasr_gmm *g, const XT *d_frames, int64_t F, hipStream
                                  hipFuncAttributeMaxDynamicSharedMemorySize,
                                  2 * 64 * 16 * 8 + 64 * kCentreThreads * (int)sizeof(XT)));
     attr_set[g->device & 63] = true;
+  }
+  // float frames: the expanded FMA form (AASR_CLUSTER_CENTRES_REF=1 keeps the reference operation order)
+  static const int ref_order = getenv("AASR_CLUSTER_CENTRES_REF") ? atoi(getenv("AASR_CLUSTER_CENTRES_REF")) : 0;
+  if constexpr (std::is_same<XT, float>::value) {
+    if (!ref_order && cl.rec_fma.p) {
+      static bool attr_fma[64] = {false};
+      if (!attr_fma[g->device & 63]) {
+        AASR_HIP(hipFuncSetAttribute((const void *)k_cluster_centres_fma, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     2 * 64 * 16 * 8 + 64 * kCentreThreads * (int)sizeof(float)));
+        attr_fma[g->device & 63] = true;
+      }
+      // the matrix-pipe form where an instance exists for the dimension
+      static const int use_mfma = getenv("AASR_CLUSTER_CENTRES_MFMA") ? atoi(getenv("AASR_CLUSTER_CENTRES_MFMA")) : 1;
+      if (use_mfma && cl.bpack.p && launch_centres_mfma(g, d_frames, F, stream)) return;
+      hipLaunchKernelGGL(k_cluster_centres_fma, dim3((unsigned)bx, (unsigned)ny), dim3(kCentreThreads), smem, stream,
+                         d_frames, F, g->dim, cl.dimp, cl.rec_fma.p, cl.cconst_fma.p, groups, gpy, cl.ll64.p,
+                         (int64_t)cl.Cs);
+      AASR_HIP(hipGetLastError());
+      return;
+    }
   }
   hipLaunchKernelGGL(k_cluster_centres<XT>, dim3((unsigned)bx, (unsigned)ny), dim3(kCentreThreads), smem,
                      stream, d_frames, F, g->dim, cl.dimp, cl.rec.p, cl.cconst.p, groups, gpy,
