@@ -17,7 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # AASR_BUILD_ABLATION=1 builds the library with the kernels' ablation branches and the recipe driver's device
 # stub into its own directory (lib_ablation/, loaded with AASR_LIBDIR=...): the product library carries neither
-LIBDIR = os.path.join(HERE, "lib_ablation" if os.environ.get("AASR_BUILD_ABLATION") == "1" else "lib")
+LIBDIR = os.path.join(HERE, "lib_ablation" if (os.environ.get("AASR_BUILD_ABLATION") == "1" or
+                                              os.environ.get("AASR_BUILD_DEFINES")) else "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libaasr.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -26,6 +27,8 @@ ARCH = "gfx950"
 # -ffp-contract=off: the feature kernels restate float32/float64 arithmetic of
 # the reference operation by operation; fused multiply-adds would change bits.
 ABLATION = ["-DAASR_ABLATION=1"] if os.environ.get("AASR_BUILD_ABLATION") == "1" else []
+if os.environ.get("AASR_BUILD_DEFINES"):   # experiment builds: extra -D flags, into the ablation directory
+    ABLATION = ["-D" + d for d in os.environ["AASR_BUILD_DEFINES"].split(",")]
 COMMON = ABLATION + ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall",
           "-Wno-unused-function", "-Wno-inline-asm", f"--offload-arch={ARCH}", "-I", os.path.join(HERE, "..", "include")]
 

@@ -1053,11 +1053,12 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
 template <int NK16, bool GROUPED, bool WIDE, int NS>
 struct PlSmem {
   static constexpr int kTileBytes = NK16 * NS * 2 * 64 * 16;
-  static constexpr bool kBig = WIDE && GROUPED && 2 * kTileBytes + 8 * FRAMES_PER_WAVE * 34 * 4 <= 160 * 1024;
+  static constexpr int NBUF = WIDE ? 3 : 2;   // tile buffers (the 8-wave form's lagging group needs the third)
+  static constexpr bool kBig = WIDE && GROUPED && NBUF * kTileBytes + 8 * FRAMES_PER_WAVE * 34 * 4 <= 160 * 1024;
   static constexpr int OG = kBig ? 32 : 16;
   static constexpr int kOutStride = kBig ? 34 : 20;
   static constexpr int kOutFloatsPerWave = GROUPED ? FRAMES_PER_WAVE * kOutStride : 0;
-  static constexpr int kBytes = 2 * kTileBytes + (WIDE ? 8 : 4) * kOutFloatsPerWave * 4;
+  static constexpr int kBytes = NBUF * kTileBytes + (WIDE ? 8 : 4) * kOutFloatsPerWave * 4;
 };
 
 template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS>
@@ -1079,7 +1080,19 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const int lane = tid & 63;
-  float *ost = abuf0 + 2 * kTileFloats + wave * SM::kOutFloatsPerWave;
+  constexpr int NBUF = SM::NBUF;
+  float *ost = abuf0 + NBUF * kTileFloats + wave * SM::kOutFloatsPerWave;
+  // 8-wave form: waves 4-7 pass the tile's barrier in the MIDDLE of their H0 instead of at the end of H1, so they run
+  // three quarters of a tile behind waves 0-3 -- the two waves of a SIMD then never sit in their close logic (or at
+  // the barrier) at the same time, one of them always has MFMAs to issue.  Three tile buffers make the lag legal: the
+  // copy of tile t + 2 is issued by every wave right behind its barrier t (all waves are past tile t - 1 there) and
+  // has landed at barrier t + 1, before the lagging group's first read of it.
+#ifdef AASR_PL_NOLAG
+  const int group = 0;
+#else
+  const int group = WIDE ? __builtin_amdgcn_readfirstlane(wave >> 2) : 0;
+#endif
+  constexpr int JB = NK16 / 2;   // slab of H0 in front of which the lagging group's barrier sits
   const int n = lane & 31;
   const int h = lane >> 5;  // K half of a slab held by this lane AND its row track
   const int64_t f0 = (int64_t)blockIdx.x * (NW * FRAMES_PER_WAVE) + wave * FRAMES_PER_WAVE;
@@ -1127,6 +1140,8 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   const int64_t t_end = split_row[4 * blockIdx.y + 4];
   const float *apf = (const float *)apack;
   if (t_begin < t_end) issue_tile_copy_raw(apf + (size_t)t_begin * kTileFloats, abuf0, kTileFloats, wave, lane, NW);
+  if (t_begin + 1 < t_end)
+    issue_tile_copy_raw(apf + (size_t)(t_begin + 1) * kTileFloats, abuf0 + kTileFloats, kTileFloats, wave, lane, NW);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -1143,6 +1158,10 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
 
   // close logic of one 32-row block: P[nb][q] = this lane's sum of 2^x over quad q for frame block nb
   auto commit = [&](const float (&P)[2][4], unsigned nib) {
+    if (AASR_DBG(128)) {   // ablation: no close logic
+      asm volatile("" ::"v"(P[0][0]), "v"(P[0][1]), "v"(P[0][2]), "v"(P[0][3]), "v"(P[1][0]), "v"(P[1][1]), "v"(P[1][2]), "v"(P[1][3]));
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       s0 += P[0][q];
@@ -1223,11 +1242,16 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     // close logic that consumes P, i.e. out from under the matrix stream (s_nop: a VALU read of a transcendental's
     // result needs one wait state, and the hazard recogniser does not look inside assembly)
     float x;
-    asm volatile("v_exp_f32 %0, %1\n\ts_nop 0" : "=v"(x) : "v"(v));
+    if (AASR_DBG(64)) asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(v));   // ablation: no transcendentals
+    else asm volatile("v_exp_f32 %0, %1\n\ts_nop 0" : "=v"(x) : "v"(v));
+    // the pair sums ride in the stream as well (left to the compiler they gather behind the phase's last MFMA)
     if (e == 0) t0 = x;
-    else if (e == 1) t0 += x;
+    else if (e == 1) asm volatile("v_add_f32 %0, %1, %2" : "=v"(t0) : "v"(t0), "v"(x));
     else if (e == 2) t1 = x;
-    else P[nb][q] = t0 + (t1 + x);
+    else {
+      asm volatile("v_add_f32 %0, %1, %2" : "=v"(t1) : "v"(t1), "v"(x));
+      asm volatile("v_add_f32 %0, %1, %2" : "=v"(P[nb][q]) : "v"(t0), "v"(t1));
+    }
   };
 
   // one phase: the MFMAs of 32-row block MB of the tile in `acur` into (n0, n1), carrying the exponentials of the
@@ -1251,10 +1275,18 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   int bi = 0;
   for (int64_t t = t_begin; t < t_end; t++) {
     float *acur = abuf0 + bi * kTileFloats;
-    float *anext = abuf0 + (bi ^ 1) * kTileFloats;
-    bi ^= 1;
-    // every wave has passed the barrier that ended tile t-1: its buffer is free for tile t+1
-    if (t + 1 < t_end) issue_tile_copy_raw(apf + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane, NW);
+    const int bn = bi + 1 < NBUF ? bi + 1 : 0, bnn = bn + 1 < NBUF ? bn + 1 : 0;
+    float *anext = abuf0 + bn * kTileFloats;
+    // tile t + 2 goes where tile t - 1 was (three buffers), or into tile t's own buffer when every wave is done
+    // with it at the barrier (two buffers, no lagging group)
+    float *anext2 = abuf0 + bnn * kTileFloats;
+    bi = bn;
+    // barrier t of this wave: its share of tile t + 1 has landed, and every wave is past tile t - 1
+    auto tile_barrier = [&]() {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(mask_v) : : "memory");
+      if (!AASR_DBG(16)) __builtin_amdgcn_s_barrier();
+      if (t + 2 < t_end) issue_tile_copy_raw(apf + (size_t)(t + 2) * kTileFloats, anext2, kTileFloats, wave, lane, NW);
+    };
     // close bits and selection bits of tile t+1: vector loads waited for by the vmcnt(0) in front of the barrier
     // (an aligned 32-bit word: the array has a spare element; through inline assembly so that it stays a VECTOR
     // load -- as a scalar load it would turn every LDS wait of the stream into lgkmcnt(0))
@@ -1272,6 +1304,10 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
 #pragma unroll
       for (int j = 0; j < NK16; j++) {
         const int cur = j & 1;
+        if (WIDE && j == JB) {
+          if (group == 1) tile_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if (j + 1 < NK16) load_frags(acur, j + 1, 0, cur ^ 1);
         else load_frags(acur, 0, 1, cur ^ 1);     // slab 0 of block 1, for H1
         __builtin_amdgcn_sched_barrier(0);
@@ -1337,9 +1373,9 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
         }
       }
     }
-    // end of tile: every wave is done reading `acur`, every wave's share of tile t+1 has landed
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(mask_v) : : "memory");
-    __builtin_amdgcn_s_barrier();
+    // end of tile: the leading group's barrier
+    if (!WIDE || group == 0) tile_barrier();
+    else asm volatile("" : "+v"(mask_v));
     if (t + 1 < t_end) {
       load_frags(anext, 0, 0, 0);   // slab 0 of the next tile's block 0: in flight during the close logic
       __builtin_amdgcn_sched_barrier(0);
@@ -1402,6 +1438,7 @@ static void launch_pl_t(const aasr_gmm *g, const TrackLayout &L, const float *d_
   constexpr int NW = WIDE ? 8 : 4;
   const int64_t blocks = (F + NW * FRAMES_PER_WAVE - 1) / (NW * FRAMES_PER_WAVE);
   const int smem = PlSmem<NK16, GROUPED, WIDE, NS>::kBytes;
+  static const int dbg = getenv("AASR_DBG") ? atoi(getenv("AASR_DBG")) : 0;
   static bool attr_set[64] = {false};
   auto kern = k_gmm_diag_score_pl<NK16, GROUPED, CL, WIDE, NS>;
   if (!attr_set[g->device & 63]) {
@@ -1424,7 +1461,7 @@ static void launch_pl_t(const aasr_gmm *g, const TrackLayout &L, const float *d_
   const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(NW * 64), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, NS == 3 ? L.a16.p : L.a16h.p, split_row, L.close.p, L.sid.p, L.sid_stride,
-                     d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, 0, cl);
+                     d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, dbg, cl);
   AASR_HIP(hipGetLastError());
 }
 
