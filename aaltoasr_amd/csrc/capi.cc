@@ -249,6 +249,7 @@ int aasr_gmm_get_precision(const aasr_gmm *h) { return h ? h->precision : -1; }
 int aasr_gmm_effective_precision(const aasr_gmm *h) {
   if (!h) return -1;
   if (h->precision != AASR_PREC_F16X2 && h->precision != AASR_PREC_BF16X3) return h->precision;
+  if (!h->dim_parts.empty()) return AASR_PREC_F32;   // parts are scored per Gaussian by the f32 pool kernels
   // what the diagonal matrix path runs: the centred / general forms and the factor-row kernels have no f16x2 form
   if (h->ill_conditioned || h->host.factor_path()) return h->host.factor_path() ? AASR_PREC_BF16X3 : AASR_PREC_F32_CENTRED;
   const aasr::TrackLayout &L = h->paired.ok ? h->paired : h->tracks;
@@ -263,13 +264,14 @@ aasr_status aasr_gmm_set_precision(aasr_gmm *h, int prec) {
       if (prec == AASR_PREC_F32_CENTRED && !h->centred_ok)
         raise(AASR_ERR_UNSUPPORTED, "the centred kernel is not available for dimension %d", h->dim);
       if ((prec == AASR_PREC_BF16X3 || prec == AASR_PREC_F16X2) && !((h->paired.ok && h->paired.a16.p) || (h->tracks.ok && h->tracks.a16.p) ||
-                                        (h->full.ok && h->full.a16.p) || h->class_routing))
+                                        (h->full.ok && h->full.a16.p) || h->class_routing || !h->dim_parts.empty()))
         raise(AASR_ERR_UNSUPPORTED, "the split-operand (bf16x3 / f16x2) kernels are not available for this model");
       h->precision = prec;
       h->use_bf16x3 = (prec == AASR_PREC_BF16X3 || prec == AASR_PREC_F16X2);
       return;
     }
     if (prec == AASR_PREC_F64) {
+      if (!h->dim_parts.empty()) raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 is built for feature dimensions <= 63");
       if (h->host.any_full())
         raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 is built for diagonal pools");
       h->precision = prec;

@@ -291,6 +291,15 @@ struct aasr_gmm {
   // handful of matrices instead of re-packing the model.
   bool class_routing = false;
   std::vector<int32_t> class_g2t;                         // membership the sub-models were built for
+  // Feature dimension > 63 (the matrix kernels keep a frame's K operand in registers: K = 2 dim + 1 <= 128): the
+  // diagonal density factorises over the dimensions, so the model is cut into parts of <= 63 dimensions, each a pool
+  // of one-component "states" scored per Gaussian by the kernels above, and k_dim_split_combine adds a component's
+  // parts and forms the mixture sums.  A slower path (per-Gaussian scores cross HBM) for models the reference allows.
+  std::vector<std::unique_ptr<aasr_gmm>> dim_parts;
+  std::vector<int32_t> dim_part_off;          // first dimension of every part, + dim
+  aasr::DevBuf<float> dim_part_x, dim_part_ll;  // a part's frame columns; [parts][chunk frames][G] scores
+  aasr::DevBuf<int32_t> dim_mix_off, dim_mix_idx;
+  aasr::DevBuf<float> dim_mix_logw;
   std::unique_ptr<aasr_gmm> pool_view;   // full-covariance pools: the Gaussians as one-component states (per-Gaussian view)
   std::vector<std::unique_ptr<aasr_gmm>> class_models;    // index = transform id + 1 (0: unadapted), may be null
   std::vector<aasr::DevBuf<double>> class_a, class_b;     // per class: A [dim x dim], b [dim]
@@ -313,6 +322,7 @@ void gmm_build(aasr_gmm *g, const HostModel &m);
 // transform over the unadapted rows; per-class transforms with an unchanged membership), rebuilds otherwise
 void gmm_set_transforms(aasr_gmm *g, int32_t n_transforms, const int32_t *gauss_to_transform, const double *W);
 void gmm_build_pool(aasr_gmm *g);
+void gmm_dim_split_score(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, bool per_gaussian, hipStream_t stream);
 void gmm_build_pool_centred(aasr_gmm *g);
 void gmm_build_f64(aasr_gmm *g);
 void gmm_cluster_score_f64_launch(aasr_gmm *g, const double *d_frames, const double *d_members, int64_t F,

@@ -859,6 +859,7 @@ static void build_crow_comps(const aasr_gmm *g, const std::vector<int32_t> &comp
 
 void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
                         const int32_t *gauss_index, const int32_t *cluster_index) {
+  if (!g->dim_parts.empty()) raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering is built for feature dimensions <= 63");
   ClusterState &cl = g->cl;
   if (n_clusters <= 0) {
     cl = ClusterState();

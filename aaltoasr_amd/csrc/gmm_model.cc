@@ -442,6 +442,46 @@ void gmm_build_tracks(aasr_gmm *g, bool grouped);
 static void find_outliers(aasr_gmm *g);
 static void build_class_routing(aasr_gmm *g);
 
+// dim > 63: parts of <= 63 dimensions as pools of one-component states (see aasr_gmm::dim_parts)
+static void build_dim_split(aasr_gmm *g) {
+  const HostModel &m = g->host;
+  const int D = m.dim;
+  const int n_parts = (D + 62) / 63;
+  const int per = (D + n_parts - 1) / n_parts;
+  g->dim_part_off.clear();
+  for (int p = 0; p < n_parts; p++) g->dim_part_off.push_back(std::min(D, p * per));
+  g->dim_part_off.push_back(D);
+  for (int p = 0; p < n_parts; p++) {
+    const int d0 = g->dim_part_off[(size_t)p], d1 = g->dim_part_off[(size_t)p + 1];
+    HostModel pm;
+    pm.dim = d1 - d0;
+    pm.G = m.G;
+    pm.S = m.G;
+    pm.mean.resize((size_t)m.G * pm.dim);
+    pm.var.resize((size_t)m.G * pm.dim);
+    for (int64_t i = 0; i < m.G; i++)
+      for (int d = d0; d < d1; d++) {
+        pm.mean[(size_t)i * pm.dim + (d - d0)] = m.mean[(size_t)i * D + d];
+        pm.var[(size_t)i * pm.dim + (d - d0)] = m.var[(size_t)i * D + d];
+      }
+    pm.mix_off.resize((size_t)m.G + 1);
+    pm.mix_idx.resize((size_t)m.G);
+    pm.mix_w.assign((size_t)m.G, 1.0);
+    for (int64_t i = 0; i <= m.G; i++) pm.mix_off[(size_t)i] = (int32_t)i;
+    for (int64_t i = 0; i < m.G; i++) pm.mix_idx[(size_t)i] = (int32_t)i;
+    pm.weights_normalized = true;
+    auto sub = std::make_unique<aasr_gmm>();
+    sub->device = g->device;
+    gmm_build(sub.get(), pm);
+    g->dim_parts.push_back(std::move(sub));
+  }
+  std::vector<float> logw(m.mix_idx.size());
+  for (size_t k = 0; k < m.mix_idx.size(); k++) logw[k] = (float)m.logw(k);
+  g->dim_mix_off.upload(m.mix_off.data(), m.mix_off.size());
+  g->dim_mix_idx.upload(m.mix_idx.data(), std::max<size_t>(1, m.mix_idx.size()));
+  g->dim_mix_logw.upload(logw.data(), std::max<size_t>(1, logw.size()));
+}
+
 void gmm_build(aasr_gmm *g, const HostModel &model) {
   require_device();
   {
@@ -464,8 +504,9 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
     raise(AASR_ERR_INVALID, "empty model (dim %d, %ld Gaussians, %ld states)", m.dim, (long)m.G, (long)m.S);
   if ((int64_t)m.mix_off.size() != m.S + 1)
     raise(AASR_ERR_INVALID, "mix_off must hold num_states+1 entries");
-  if (m.dim + 1 > 64)
-    raise(AASR_ERR_UNSUPPORTED, "feature dimension %d > 63 is not built in this engine yet", m.dim);
+  g->dim_parts.clear();
+  if (m.dim + 1 > 64 && (m.any_full() || m.n_transforms > 0))
+    raise(AASR_ERR_UNSUPPORTED, "feature dimension %d > 63 is built for unadapted diagonal pools only", m.dim);
   for (size_t k = 0; k < m.mix_idx.size(); k++)
     if (m.mix_idx[k] < 0 || m.mix_idx[k] >= m.G)
       raise(AASR_ERR_INVALID, "mixture component %zu points at Gaussian %d outside the pool of %ld",
@@ -479,6 +520,10 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
       for (int32_t k = m.mix_off[s]; k < m.mix_off[s + 1]; k++) m.mix_w[k] /= sum;
     }
     m.weights_normalized = true;
+  }
+  if (m.dim + 1 > 64) {
+    build_dim_split(g);
+    return;
   }
   // centring pivot: per-dimension mean of the pool means, rounded to float so
   // the device subtracts exactly the value the constants were built with
@@ -1428,6 +1473,8 @@ static void build_class_routing(aasr_gmm *g) {
 }
 
 void gmm_set_transforms(aasr_gmm *g, int32_t n_transforms, const int32_t *gauss_to_transform, const double *W) {
+  if (!g->dim_parts.empty() && n_transforms > 0)
+    raise(AASR_ERR_UNSUPPORTED, "model-side CMLLR is built for feature dimensions <= 63");
   HostModel &cur = g->host;
   const int D = cur.dim;
   bool global = n_transforms == 1;

@@ -2197,6 +2197,7 @@ void gmm_score_f64_launch(aasr_gmm *g, const double *d_frames, int64_t F, double
                           hipStream_t stream) {
   if (F <= 0) return;
   if (g->host.any_full()) raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 is built for diagonal pools");
+  if (!g->dim_parts.empty()) raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 is built for feature dimensions <= 63");
   gmm_build_f64(g);
   if (g->f64_classes > 0) {
     if (g->cl.enabled) gmm_cluster_score_f64_launch(g, d_frames, d_frames, F, d_out, linear, 1.0, stream);
@@ -2664,6 +2665,7 @@ static void add_output_bias(const aasr_gmm *g, float *d_out, int64_t F, hipStrea
 // Whether scores can be written with a row pitch other than S: the bf16x3 track kernels can
 // (rows padded to a multiple of 16 floats make every 64-byte output group a whole cache line).
 bool gmm_score_pitch_ok(const aasr_gmm *g) {
+  if (!g->dim_parts.empty()) return false;
   if (g->cl.enabled || g->host.factor_path() || g->hyb_enabled || g->ill_conditioned || g->class_routing ||
       g->precision == AASR_PREC_F64)
     return false;
@@ -2696,9 +2698,90 @@ void gmm_score_launch_pitched(aasr_gmm *g, const float *d_frames, int64_t F, flo
   if (!done) raise(AASR_ERR_UNSUPPORTED, "no track kernel instance for this model");
 }
 
+// ---------------------------------------------------------------------------
+// Feature dimension > 63: the model as parts of <= 63 dimensions (aasr_gmm::dim_parts).  ll_g(x) = sum over the
+// parts of the part's own diagonal Gaussian (constants included: log sqrt prod p factorises too), so every part
+// scores its column range per Gaussian -- no floor, natural log -- and k_dim_split_combine adds them per mixture
+// component and forms log max(sum_k w_k e^ll, 1e-50) with a running maximum.  Frames are taken in chunks so that the
+// per-Gaussian scores of all parts stay below ~1.5 GB.
+// ---------------------------------------------------------------------------
+__global__ void k_slice_columns(const float *__restrict__ x, int64_t F, int dim, int d0, int dp, float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F * dp) return;
+  const int64_t f = i / dp;
+  const int d = (int)(i - f * dp);
+  out[i] = x[f * dim + d0 + d];
+}
+
+__global__ __launch_bounds__(256) void k_dim_split_combine(const float *__restrict__ part_ll, int parts, int64_t Fc,
+                                                           int64_t G, const int32_t *__restrict__ mix_off,
+                                                           const int32_t *__restrict__ mix_idx,
+                                                           const float *__restrict__ mix_logw, int64_t S,
+                                                           float *__restrict__ out, int per_gaussian) {
+  const int64_t n = per_gaussian ? G : S;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Fc * n) return;
+  const int64_t f = i / n, s = i - f * n;
+  if (per_gaussian) {
+    float v = 0.0f;
+    for (int p = 0; p < parts; p++) v += part_ll[((int64_t)p * Fc + f) * G + s];
+    out[i] = v;
+    return;
+  }
+  float m = NEG_BIG_F, sum = 0.0f;
+  for (int32_t k = mix_off[s]; k < mix_off[s + 1]; k++) {
+    const float lw = mix_logw[k];
+    if (!(lw > NEG_BIG_F)) continue;   // zero weight
+    float v = lw;
+    const int64_t gi = mix_idx[k];
+    for (int p = 0; p < parts; p++) v += part_ll[((int64_t)p * Fc + f) * G + gi];
+    const float mn = fmaxf(m, v);
+    sum = sum * __expf(m - mn) + __expf(v - mn);
+    m = mn;
+  }
+  const float ll = sum > 0.0f ? m + __logf(sum) : LOG_TINY_F;
+  out[i] = fmaxf(ll, LOG_TINY_F);
+}
+
+void gmm_dim_split_score(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, bool per_gaussian,
+                         hipStream_t stream) {
+  const int parts = (int)g->dim_parts.size();
+  const int64_t chunk = std::max<int64_t>(64, std::min<int64_t>(F, (int64_t)(1.5e9 / (4.0 * (double)g->G * parts))));
+  int max_dp = 0;
+  for (int p = 0; p < parts; p++) max_dp = std::max(max_dp, g->dim_part_off[(size_t)p + 1] - g->dim_part_off[(size_t)p]);
+  if ((size_t)chunk * max_dp > g->dim_part_x.n || (size_t)parts * chunk * g->G > g->dim_part_ll.n)
+    AASR_HIP(hipDeviceSynchronize());   // growing frees the old buffers
+  g->dim_part_x.ensure((size_t)chunk * max_dp);
+  g->dim_part_ll.ensure((size_t)parts * chunk * g->G);
+  const int64_t n_out = per_gaussian ? g->G : g->S;
+  for (int64_t f0 = 0; f0 < F; f0 += chunk) {
+    const int64_t fc = std::min(chunk, F - f0);
+    for (int p = 0; p < parts; p++) {
+      const int d0 = g->dim_part_off[(size_t)p], dp = g->dim_part_off[(size_t)p + 1] - d0;
+      const int64_t n = fc * dp;
+      hipLaunchKernelGGL(k_slice_columns, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_frames + f0 * g->dim,
+                         fc, g->dim, d0, dp, g->dim_part_x.p);
+      AASR_HIP(hipGetLastError());
+      g->dim_parts[(size_t)p]->precision = g->precision == AASR_PREC_F64 ? AASR_PREC_F32 : g->precision;
+      gmm_gauss_launch(g->dim_parts[(size_t)p].get(), g->dim_part_x.p, fc, g->dim_part_ll.p + (size_t)p * fc * g->G, stream);
+    }
+    const int64_t n = fc * n_out;
+    hipLaunchKernelGGL(k_dim_split_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g->dim_part_ll.p, parts,
+                       fc, g->G, g->dim_mix_off.p, g->dim_mix_idx.p, g->dim_mix_logw.p, g->S, d_out + f0 * n_out,
+                       per_gaussian ? 1 : 0);
+    AASR_HIP(hipGetLastError());
+  }
+}
+
 void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                       hipStream_t stream) {
   if (F <= 0) return;
+  if (!g->dim_parts.empty()) {
+    if (g->precision == AASR_PREC_F64) raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 is built for feature dimensions <= 63");
+    if (g->cl.enabled) raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering is built for feature dimensions <= 63");
+    gmm_dim_split_score(g, d_frames, F, d_out, false, stream);
+    return;
+  }
   if (g->precision == AASR_PREC_F64) {
     score_f64_for_f32_callers(g, d_frames, F, d_out, stream);
     return;
@@ -2750,6 +2833,10 @@ void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
 
 void gmm_gauss_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                       hipStream_t stream) {
+  if (!g->dim_parts.empty()) {
+    gmm_dim_split_score(g, d_frames, F, d_out, true, stream);
+    return;
+  }
   if (g->xf_a.p || g->class_routing || g->host.n_transforms > 0)
     raise(AASR_ERR_UNSUPPORTED, "per-Gaussian log-likelihoods are not built for adapted pools");
   if (g->host.any_full()) {

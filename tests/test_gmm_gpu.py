@@ -392,3 +392,33 @@ def test_f16x2_is_chosen_by_conditioning_and_clamps_far_frames(capi, oracle):
     fr = synth.make_frames(200, seed=73)
     assert_ll(g.score(fr), oracle.DiagModel(mean, var, off, idx, w).score(fr.astype(np.float64)), "fallback")
     g.close()
+
+
+@pytest.mark.parametrize("D", [64, 65, 80, 100, 126, 127, 200])
+def test_dimensions_beyond_63(capi, oracle, D):
+    """Feature dimension > 63 (the reference reads any `dim`, aku/Distributions.cc:1131-1150; ConcatModule,
+    aku/FeatureModules.cc:1461-1501, produces wide vectors): the diagonal density factorises over the dimensions,
+    so the model is scored as parts of <= 63 dimensions and the parts are added per mixture component."""
+    rng = np.random.default_rng(300 + D)
+    mean, var, off, idx, w = synth.make_model(D=D, G=160, S=14, comps_range=(0, 14), seed=D, tied=True)
+    w[off[3]] = 0.0                                            # a zero-weight component
+    frames = synth.make_frames(90, D=D, seed=400 + D)
+    frames[:8] = (mean[idx[:8]] + 0.3 * rng.standard_normal((8, D))).astype(np.float32)   # some frames on Gaussians
+    frames[8:12] *= 4.0                                        # some far out (the 1e-50 floor)
+    om = oracle.DiagModel(mean, var, off, idx, w)
+    ref = om.score(frames.astype(np.float64))
+    g = capi.Gmm.from_arrays(mean, var, off, idx, w)
+    for prec in (4, 3, 0):
+        g.set_precision(prec)
+        assert_ll(g.score(frames), ref, "D = %d, precision %d" % (D, prec))
+    # per-Gaussian log-likelihoods: the parts added, no floor
+    gl = g.gauss_loglik(frames[:20])
+    want = om.gauss_loglik(frames[:20].astype(np.float64))
+    vis = want > -200
+    assert np.abs(gl - want)[vis].max() <= 1e-4 * np.maximum(1.0, np.abs(want[vis]) / 100).max()
+    # what is not built for wide vectors says so
+    with pytest.raises(capi.AasrError):
+        g.set_clustering(4, [(i, i % 4) for i in range(160)])
+    with pytest.raises(capi.AasrError):
+        g.set_precision(1)
+    g.close()
