@@ -1432,6 +1432,9 @@ static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *
   AASR_HIP(hipGetLastError());
 }
 
+#ifndef AASR_PL_BF16X3
+#define AASR_PL_BF16X3 0   // experiment: the three-term bf16 arithmetic on the pipelined kernel as well
+#endif
 template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS>
 static void launch_pl_t(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
                         float *d_out, hipStream_t stream, const ClusterArgs &cl, int64_t pitch) {
@@ -1487,7 +1490,7 @@ static bool launch_split(const aasr_gmm *g, const TrackLayout &L, const float *d
   switch (L.nk16) {
 #define AASR_LAUNCH(N, GR, CLF, WD, CLA)                                                   \
   do {                                                                                     \
-    if constexpr (NS == 2) launch_pl_t<N, GR, CLF, WD, NS>(g, L, d_frames, F, d_out, stream, CLA, pitch);   \
+    if constexpr (NS == 2 || AASR_PL_BF16X3) launch_pl_t<N, GR, CLF, WD, NS>(g, L, d_frames, F, d_out, stream, CLA, pitch);   \
     else launch_bf16_t<N, GR, CLF, WD, NS>(g, L, d_frames, F, d_out, stream, CLA, pitch);  \
   } while (0)
 #define AASR_CASE(N)                                                                       \

@@ -117,9 +117,11 @@ __device__ __forceinline__ void lna_row_from_registers(const float (&v)[VPT], in
     const int i = tid + 256 * j;
     if (i < S) {
       const double vd = v[j] >= LN_FLT_MIN_F ? (double)v[j] : float_cast_loglik(v[j]);
-      double lpd = vd - logz;
-      if (!(lpd >= LOG_TINY_D)) lpd = LOG_TINY_D;
-      lna_store((float)lpd, lnabytes, f * (int64_t)S + i, lp_out, bytes_out);
+      // safe_log's floor after the rounding to float instead of before it (rounding is monotone and
+      // (float)log(1e-50) is the floor's own float, -inf - logz stays -inf): one f32 max for a double compare +
+      // two selects -- the pass is bound by its vector instructions, not by HBM
+      const float lp = fmaxf((float)(vd - logz), (float)LOG_TINY_D);
+      lna_store(lp, lnabytes, f * (int64_t)S + i, lp_out, bytes_out);
     }
   }
 }
