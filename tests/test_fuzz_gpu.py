@@ -24,7 +24,9 @@ def _load(name):
     return mod
 
 
-@pytest.mark.parametrize("seed,n", [(1, 40), (7, 25), (20260928, 25), (104, 250)])
+# seed 3002 (iterations 0..299) holds round 3's find: a one-dimensional model at kappa2 = 110, 8.85e-5 off with the two-term
+# fp16 form under its first conditioning limit (now 80: the model takes the three-term form)
+@pytest.mark.parametrize("seed,n", [(1, 40), (7, 25), (20260928, 25), (104, 250), (3002, 300)])
 def test_scoring_sweep(capi, oracle, seed, n):
     worst, fails = _load("fuzz_parity").run(seed, n)
     assert not fails, "\n".join(fails)

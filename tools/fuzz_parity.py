@@ -19,7 +19,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 VISIBLE_LL = -103.97
-TOL = 1e-4
+TOL = float(os.environ.get("AASR_FUZZ_TOL", "1e-4"))   # the contract; a lower value lists the closest calls
 LOG_TINY = float(np.log(1e-50))
 
 
