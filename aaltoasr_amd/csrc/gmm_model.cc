@@ -976,7 +976,8 @@ void gmm_build_tracks(aasr_gmm *g, bool grouped) {
   pack_rows(g, rows, L.rows, &coef64);
   pack_bf16x3(m.dim, coef64, tiles, L);
   static const int f16_env = getenv("AASR_F16X2") ? atoi(getenv("AASR_F16X2")) : 1;   // 0: never pack the f16x2 form
-  if (f16_env && g->kappa_matrix <= KAPPA_LIMIT_F16 && g->kappa2_matrix <= KAPPA2_LIMIT_F16)
+  if (f16_env && g->kappa_matrix <= KAPPA_LIMIT_F16 &&
+      g->kappa2_matrix <= (m.dim < 8 ? KAPPA2_LIMIT_F16_LOWDIM : KAPPA2_LIMIT_F16))
     pack_f16x2(g, rows, coef64, tiles, L);
   else
     L.a16h = DevBuf<uint16_t>();
