@@ -89,6 +89,48 @@ __device__ __forceinline__ void lna_row_from_registers(const float (&v)[VPT], in
                                                        bool store, float *__restrict__ lp_out,
                                                        uint8_t *__restrict__ bytes_out) {
   double logz = 0.0;
+  // Fast path (2-byte codes, no float output wanted): when the frame's best state is a normal float and within 51 nats
+  // of 1.0 -- every real frame -- the float-denormal band of the reference's storage (ll in [ln 2^-150, ln 2^-126)) can
+  // neither reach the maximum, nor move Z (its terms are below 2^-52 of the largest, the sum is formed from float
+  // exponentials anyway), nor produce a code other than FF FF (lp < -87.3 + 51 < -36.008, and a value the reference
+  // flushes to the floor gives FF FF as well).  So the quantisation detour -- ~25 vector instructions per value that
+  // every wave executes as soon as ONE of its 64 states sits in the band, half of this VALU-bound kernel's work
+  // (rocprofv3: VALU busy 78 % of the cycles) -- is skipped and the raw values are used.  Anything else (4-byte output,
+  // lp_out, a frame whose best state is below e^-51) takes the exact path below.
+  if (lnabytes == 2 && !lp_out) {   // uniform over the grid
+    float mr = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < VPT; j++) mr = fmaxf(mr, v[j]);
+    mr = wave_reduce_max(mr);
+    if (lane == 0) red[wave] = (double)mr;
+    __syncthreads();
+    mr = (float)fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    __syncthreads();
+    if (mr >= -51.0f) {   // uniform over the group: the barriers below are passed by all of it
+      double z = 0.0;
+      if (normalize) {
+#pragma unroll
+        for (int j = 0; j < VPT; j++) z += (double)__builtin_amdgcn_exp2f((v[j] - mr) * 1.44269504088896340736f);
+      }
+      z = wave_reduce_sum(z);
+      if (lane == 0) red[4 + wave] = z;
+      __syncthreads();
+      z = (red[4] + red[5]) + (red[6] + red[7]);
+      __syncthreads();
+      if (normalize) logz = (double)mr + log(z);
+      if (!store) return;
+#pragma unroll
+      for (int j = 0; j < VPT; j++) {
+        const int i = tid + 256 * j;
+        if (i < S) {
+          // band and flushed values: lp < -36.008 either way; the others exactly as the exact path
+          const float lp = fmaxf((float)((double)v[j] - logz), (float)LOG_TINY_D);
+          lna_store(lp, 2, f * (int64_t)S + i, nullptr, bytes_out);
+        }
+      }
+      return;
+    }
+  }
   if (normalize) {  // uniform over the workgroup
     float m = -INFINITY;
 #pragma unroll
