@@ -102,7 +102,11 @@ constexpr double KAPPA2_LIMIT = 200.0;
 // 8 dimensions get the limit that keeps that case at the 5e-5 the other forms show.
 constexpr double KAPPA_LIMIT_F16 = 330.0;
 constexpr double KAPPA2_LIMIT_F16 = 80.0;
+#ifdef AASR_F16_LOWDIM80   // experiment build
+constexpr double KAPPA2_LIMIT_F16_LOWDIM = 80.0;
+#else
 constexpr double KAPPA2_LIMIT_F16_LOWDIM = 45.0;   // dim < 8
+#endif
 // |x - pivot| beyond this is clamped in the f16x2 kernel's frame operand (the square must stay below 65504)
 constexpr float kF16Clamp = 240.0f;
 
@@ -142,6 +146,7 @@ struct TrackLayout {
   // are eligible (conditioning below KAPPA_LIMIT_F16, values and clamp inside the fp16 range):
   // [tile][K/16 slabs][2 splits][2 row blocks][64 lanes][8 fp16]; the constant rides in K slots dim and KH + dim
   DevBuf<uint16_t> a16h;
+  DevBuf<float> f16tab;      // f16x2: [2 KH] per-column scales of the frame operand (2^s_k), [KH] clamp of |x - pivot|
   int nk16 = 0;              // K/16 (K = 2*KH, KH = 8*nk16 >= dim+1)
   DevBuf<uint16_t> close;    // per tile: bit p (+8 for track 1) = a state closes after quad p
   DevBuf<int32_t> sid;       // [2][sid_stride] state index of the k-th close on each track

@@ -1066,7 +1066,8 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
     const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
     const uint16_t *__restrict__ close_mask, const int32_t *__restrict__ sid, int sid_stride,
-    float *__restrict__ out, int64_t S, int64_t pitch, float ref_ln, int dbg, ClusterArgs cl) {
+    float *__restrict__ out, int64_t S, int64_t pitch, float ref_ln, int dbg, ClusterArgs cl,
+    const float *__restrict__ f16tab) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   typedef PlSmem<NK16, GROUPED, WIDE, NS> SM;
   constexpr int OG = SM::OG;
@@ -1114,9 +1115,13 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
         const int dc = d < dim ? d : 0;
         const float xc = xr[dc] - pivot[dc];
         float xq = xc;
-        if (NS == 2) xq = fminf(fmaxf(xc, -kF16Clamp), kF16Clamp);  // fp16 range (see the f16x2 note above)
+        if (NS == 2) {  // fp16 range: the dimension's clamp (see the f16x2 note above and pack_f16x2)
+          const float lim = f16tab[2 * KH + dc];
+          xq = fminf(fmaxf(xc, -lim), lim);
+        }
         float val = k < KH ? xq : xq * xq;
         if (d >= dim) val = (k == dim || (NS == 2 && k == KH + dim)) ? 1.0f : 0.0f;
+        if (NS == 2) val *= f16tab[k];   // the column's power-of-two scale (the rows carry its inverse): exact
         v[i] = val;
       }
       if constexpr (NS == 3) {
@@ -1263,6 +1268,8 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     for (int sp = NS - 1; sp >= 0; sp--) afr[set][sp] = afrag[((j * NS + sp) * 2 + mb) * 64];
   };
 
+  int lane_zero = 0;
+  asm volatile("" : "+v"(lane_zero));   // a zero the compiler cannot see through
   f32x16 cA0 = {0}, cA1 = {0}, cB0 = {0}, cB1 = {0};
   unsigned long long bits_cur = 0, bits_prev = 0;
   unsigned mask_cur = 0, mask_prev = 0;
@@ -1287,13 +1294,13 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
       if (!AASR_DBG(16)) __builtin_amdgcn_s_barrier();
       if (t + 2 < t_end) issue_tile_copy_raw(apf + (size_t)(t + 2) * kTileFloats, anext2, kTileFloats, wave, lane, NW);
     };
-    // close bits and selection bits of tile t+1: vector loads waited for by the vmcnt(0) in front of the barrier
-    // (an aligned 32-bit word: the array has a spare element; through inline assembly so that it stays a VECTOR
-    // load -- as a scalar load it would turn every LDS wait of the stream into lgkmcnt(0))
-    {
-      const uint32_t *mp = (const uint32_t *)close_mask + ((t + 1) >> 1);
-      asm volatile("global_load_dword %0, %1, off" : "=v"(mask_v) : "v"(mp) : "memory");
-    }
+    // close bits and selection bits of tile t+1: vector loads waited for by the vmcnt(0) in front of the barrier (an
+    // aligned 32-bit word: the array has a spare element).  It has to stay a VECTOR load -- as a scalar load it would turn
+    // every LDS wait of the stream into lgkmcnt(0) -- and it has to stay a load the COMPILER knows: the first version
+    // issued it through inline assembly, and the compiler, for which the result was ready at the asm statement, copied
+    // the register before the value had landed (one wave group's close bits were garbage in ~1 workgroup of 6 000 per
+    // launch, found by the 10^6-frame test).  The opaque zero keeps the address a vector value.
+    mask_v = ((const uint32_t *)close_mask)[((t + 1) >> 1) + lane_zero];
     unsigned long long bits_next = 0;
     if (CL && t + 1 < t_end) bits_next = mrow[(size_t)(t + 1) * TILE_ROWS];
 
@@ -1464,7 +1471,7 @@ static void launch_pl_t(const aasr_gmm *g, const TrackLayout &L, const float *d_
   const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(NW * 64), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, NS == 3 ? L.a16.p : L.a16h.p, split_row, L.close.p, L.sid.p, L.sid_stride,
-                     d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, dbg, cl);
+                     d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, dbg, cl, NS == 2 ? L.f16tab.p : nullptr);
   AASR_HIP(hipGetLastError());
 }
 
