@@ -1061,10 +1061,14 @@ static bool launch_centres_mfma(aasr_gmm *g, const float *d_frames, int64_t F, h
   case N:                                                   \
     launch_centres_mfma_t<N>(g, d_frames, F, stream);       \
     return true;
-    AASR_CASE(7) AASR_CASE(14) AASR_CASE(20) AASR_CASE(21) AASR_CASE(24) AASR_CASE(32)
+    // k steps of 4 covering K = 2 dim + 1: every dimension up to 63
+    AASR_CASE(1) AASR_CASE(2) AASR_CASE(3) AASR_CASE(4) AASR_CASE(5) AASR_CASE(6) AASR_CASE(7) AASR_CASE(8)
+    AASR_CASE(9) AASR_CASE(10) AASR_CASE(11) AASR_CASE(12) AASR_CASE(13) AASR_CASE(14) AASR_CASE(15) AASR_CASE(16)
+    AASR_CASE(17) AASR_CASE(18) AASR_CASE(19) AASR_CASE(20) AASR_CASE(21) AASR_CASE(22) AASR_CASE(23) AASR_CASE(24)
+    AASR_CASE(25) AASR_CASE(26) AASR_CASE(27) AASR_CASE(28) AASR_CASE(29) AASR_CASE(30) AASR_CASE(31) AASR_CASE(32)
 #undef AASR_CASE
     default:
-      return false;   // other dimensions keep the vector kernel
+      return false;   // (the vector kernel)
   }
 }
 
