@@ -178,6 +178,8 @@ struct FullLayout {
   // [tile][K/16 slabs][3 splits][2 row blocks][64 lanes][8 bf16], K index = column
   DevBuf<uint16_t> a16;
   int nk16 = 0;
+  std::vector<int32_t> row_gauss;   // host: pool Gaussian of every packed row, -1 = unused row (Gaussian clustering)
+  int64_t rows_padded = 0;
   // per tile and track, by quad position: constant of the component / index of the state that
   // closes there ([tiles][2][8]) -- the bf16x3 kernel fetches them with the tile instead of
   // chasing gconst / sid through dependent loads in its epilogue
@@ -204,6 +206,7 @@ struct ClusterState {
   DevBuf<int32_t> csize;           // [Cs] members per cluster (0 beyond C)
   DevBuf<int32_t> crow[2];         // cluster of each packed row of the grouped / independent
                                    // track layout (C = no cluster or null row)
+  DevBuf<int32_t> crow_full;       // ... of the factor rows of a full-covariance pool
   DevBuf<int32_t> crow_hyb, crow_centred;  // the same for the records of the centred kernel: the
                                    // outlier components (outlier routing) / every component
   // per-state centre weights W[s][c] = sum of the weights of s's components in
@@ -379,4 +382,6 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
 void gmm_tracks_masked_launch(aasr_gmm *g, int which, const float *d_frames, int64_t F,
                               float *d_out, const unsigned long long *maskrow,
                               hipStream_t stream);
+void gmm_full_masked_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
+                            const unsigned long long *maskrow, hipStream_t stream);
 }  // namespace aasr

@@ -817,7 +817,10 @@ static void merge_centre(const HostModel &m, const std::vector<int32_t> &members
     double nm = 0, nc = 0;
     for (int32_t g : members) {
       const double mu = m.mean[(size_t)g * D + d];
-      const double var = m.var[(size_t)g * D + d];
+      // Gaussian::merge reads every member's covariance (get_covariance) and the diagonal target keeps the
+      // diagonal of the result: for a full-covariance member that is the diagonal of its matrix
+      const double var = (m.any_full() && m.is_full[(size_t)g]) ? m.cov[((size_t)g * D + d) * D + d]
+                                                                 : m.var[(size_t)g * D + d];
       nc += 1.0 * (var + mu * mu);
       nm += 1.0 * mu;
     }
@@ -866,7 +869,8 @@ void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
     return;
   }
   const HostModel &m = g->host;
-  if (m.any_full()) raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering is built for diagonal pools");
+  if (m.any_full() && m.n_transforms > 0)
+    raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering over an adapted full-covariance pool is not built");
   if (n_clusters > 0.3 * (double)m.G)
     raise(AASR_ERR_INVALID,
           "PDFPool::read_clustering(): Number of clusters (%d) seems insensible compared to the "
@@ -875,7 +879,7 @@ void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
     raise(AASR_ERR_UNSUPPORTED, "more than 4096 clusters are not built (%d asked)", n_clusters);
   if (n_pairs > 0 && (!gauss_index || !cluster_index))
     raise(AASR_ERR_INVALID, "aasr_gmm_set_clustering: null argument");
-  if (!g->class_routing && !g->paired.ok && !g->tracks.ok && !g->centred_ok)
+  if (!g->class_routing && !g->paired.ok && !g->tracks.ok && !g->centred_ok && !(m.any_full() && g->full.ok))
     raise(AASR_ERR_UNSUPPORTED,
           "Gaussian clustering needs the fixed-reference track kernels or the centred kernel, and this "
           "model has neither");
@@ -1233,6 +1237,7 @@ static void launch_merge(aasr_gmm *g, float *d_out, int64_t F, hipStream_t strea
 // Gaussians -- a minority next to the masked track kernel (outlier routing), or the whole model --
 // come from the centred kernel under the same bits.
 struct ExactPlan {
+  bool full = false;   // full-covariance pool: the factor-row kernel with masks
   bool all_centred, with_outliers;
   int which;
   int64_t mask_rows;
@@ -1240,6 +1245,24 @@ struct ExactPlan {
 
 static ExactPlan exact_part_plan(aasr_gmm *g, ClusterState &cl) {
   ExactPlan p;
+  if (g->host.any_full()) {
+    // the reference's cluster branch does not look at the type of the pool's Gaussians (aku/Distributions.cc:
+    // 2684-2722): diagonal centres, exact members -- here the members' factor rows with selection masks
+    if (!g->full.ok) raise(AASR_ERR_UNSUPPORTED, "full-covariance layout was not built for this model");
+    p.full = true;
+    p.all_centred = p.with_outliers = false;
+    p.which = 0;
+    if (cl.crow_full.n != g->full.row_gauss.size()) {
+      std::vector<int32_t> crow(g->full.row_gauss.size(), cl.C);
+      for (size_t r = 0; r < crow.size(); r++) {
+        const int32_t gi = g->full.row_gauss[r];
+        if (gi >= 0 && cl.g2c[(size_t)gi] >= 0) crow[r] = cl.g2c[(size_t)gi];
+      }
+      cl.crow_full.upload(crow.data(), crow.size());
+    }
+    p.mask_rows = g->full.rows_padded;
+    return p;
+  }
   p.all_centred = g->ill_conditioned || (!g->paired.ok && !g->tracks.ok);
   p.with_outliers = g->hyb_enabled && !p.all_centred;
   if (p.all_centred && !g->centred_ok)
@@ -1261,6 +1284,17 @@ static ExactPlan exact_part_plan(aasr_gmm *g, ClusterState &cl) {
 static void exact_part_launch(aasr_gmm *g, ClusterState &cl, const ExactPlan &p, const unsigned long long *maskw,
                               int c1, int64_t n, const float *fr_members, float *out, hipStream_t stream) {
   const int64_t words = (n + 63) / 64;
+  if (p.full) {
+    const int64_t rows_padded = g->full.rows_padded;
+    cl.maskrow.ensure((size_t)((n + 511) / 512 * 8) * (size_t)rows_padded);
+    const int64_t n_tiles = rows_padded / TILE_ROWS;
+    const int tpb = (int)std::min<int64_t>(n_tiles, 64);
+    hipLaunchKernelGGL(k_cluster_expand, dim3((unsigned)((n_tiles + tpb - 1) / tpb), (unsigned)words), dim3(256),
+                       (size_t)c1 * 8, stream, maskw, c1, cl.crow_full.p, rows_padded, tpb, cl.maskrow.p);
+    AASR_HIP(hipGetLastError());
+    gmm_full_masked_launch(g, fr_members, n, out, cl.maskrow.p, stream);
+    return;
+  }
   if (p.all_centred) {
     gmm_centred_masked_launch(g, fr_members, n, out, cl.crow_centred.p, maskw, c1, words, stream);
     return;
@@ -1281,8 +1315,10 @@ static void exact_part_launch(aasr_gmm *g, ClusterState &cl, const ExactPlan &p,
 void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                               hipStream_t stream) {
   ClusterState &cl = g->cl;
-  if (g->host.any_full() || (g->host.factor_path() && !g->class_routing))
-    raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering is built for diagonal pools");
+  if (!g->host.any_full() && g->host.factor_path() && !g->class_routing)
+    raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering over per-class transforms needs the class sub-models");
+  if (g->host.any_full() && g->host.n_transforms > 0)
+    raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering over an adapted full-covariance pool is not built");
   // One global constrained-MLLR transform: the pool's Gaussians are AdaptedGaussians -- members are
   // evaluated on A f + b and scaled by |det| (the track kernels' output bias) -- while the cluster
   // centres are plain Gaussians on the frame itself (aku/ModelModules.hh:164-173,

@@ -1321,6 +1321,8 @@ void gmm_build_fullcov(aasr_gmm *g) {
   cand[4].push_back(kg[1]);
 
   std::vector<double> coef((size_t)tiles * TILE_ROWS * K2, 0.0);
+  L.row_gauss.assign((size_t)tiles * TILE_ROWS, -1);
+  L.rows_padded = tiles * TILE_ROWS;
   std::vector<uint32_t> close((size_t)tiles, 0);
   std::vector<float> gc[2];
   std::vector<int32_t> sid[2];
@@ -1345,6 +1347,7 @@ void gmm_build_fullcov(aasr_gmm *g) {
       const double *W = &Wall[(size_t)gi * D * D];
       for (int i = 0; i < D; i++) {
         const int64_t row = track_row(p + i / 4, h, i % 4);
+        L.row_gauss[(size_t)row] = (int32_t)gi;
         double *cr = &coef[(size_t)row * K2];
         double bias = Beta[(size_t)gi * D + i];  // + W v: frames arrive pivot-centred
         for (int d = 0; d < D; d++) {

@@ -1546,12 +1546,16 @@ static bool launch_bf16(const aasr_gmm *g, const TrackLayout &L, const float *d_
 // 2^(C_g - |y|^2 + ref) and adds it to its state's running sum.  Two
 // independent row tracks, results stored per state.
 // ---------------------------------------------------------------------------
-template <int NKK>
+// CL (Gaussian clustering over a full-covariance pool, gmm_cluster.hip): a component counts for a frame only where
+// the selection bit of its rows is set (all rows of a component belong to one cluster; the bit of its last row is
+// tested where the component closes), and the result carries no 1e-50 floor (k_cluster_merge applies it).
+template <int NKK, bool CL>
 __global__ __launch_bounds__(256, 2) void k_gmm_full_score(
     const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
     const float *__restrict__ apack, const int32_t *__restrict__ split_row,
     const uint32_t *__restrict__ close_mask, const float *__restrict__ gconst, int g_stride,
-    const int32_t *__restrict__ sid, int s_stride, float *__restrict__ out, int64_t S, float ref_ln) {
+    const int32_t *__restrict__ sid, int s_stride, float *__restrict__ out, int64_t S, float ref_ln,
+    ClusterArgs cl) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float *smem = (float *)smem_raw;
   constexpr int kTileFloats = (NKK / 2) * 64 * 4;
@@ -1599,6 +1603,9 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score(
   float *orow0 = out + (f0 + n) * S;
   float *orow1 = out + (f0 + 32 + n) * S;
   const bool ok0 = f0 + n < F, ok1 = f0 + 32 + n < F;
+  const float floor_val = CL ? cl.floor_val : LOG_TINY_F;
+  const unsigned long long *mrow = CL ? cl.maskrow + (size_t)(f0 >> 6) * cl.rows_padded + lane : nullptr;
+  const int etest = (dim - 1) & 3;   // element of a component's last quad that holds its last row
 
   for (int64_t t = t_begin; t < t_end; t++) {
     const int par = (int)((t - t_begin) & 1);
@@ -1606,6 +1613,8 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score(
     float *anext = par ? abuf0 : abuf1;
     if (t + 1 < t_end)
       issue_tile_copy(apack + (size_t)(t + 1) * kTileFloats, anext, kTileFloats, wave, lane);
+    unsigned long long bits = 0;
+    if (CL) bits = mrow[(size_t)t * TILE_ROWS];   // k_cluster_expand's per-lane word of this tile
     const unsigned m32 = sload_close32(close_mask, t);
     const unsigned gmask = h ? ((m32 >> 8) & 0xffu) : (m32 & 0xffu);
     const unsigned smask = h ? ((m32 >> 24) & 0xffu) : ((m32 >> 16) & 0xffu);
@@ -1645,8 +1654,14 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score(
           q1 = fmaf(cb[4 * q + e], cb[4 * q + e], q1);
         }
         if ((gmask >> (mb * 4 + q)) & 1) {
-          s0 += __builtin_amdgcn_exp2f(next_gc - q0);
-          s1 += __builtin_amdgcn_exp2f(next_gc - q1);
+          float e0 = __builtin_amdgcn_exp2f(next_gc - q0);
+          float e1 = __builtin_amdgcn_exp2f(next_gc - q1);
+          if (CL) {
+            e0 = ((bits >> (8 * q + 4 * mb + etest)) & 1ull) ? e0 : 0.0f;
+            e1 = ((bits >> (32 + 8 * q + 4 * mb + etest)) & 1ull) ? e1 : 0.0f;
+          }
+          s0 += e0;
+          s1 += e1;
           q0 = 0.0f;
           q1 = 0.0f;
           kg++;
@@ -1654,8 +1669,8 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score(
           if ((smask >> (mb * 4 + q)) & 1) {
             float l0 = fmaf(__builtin_amdgcn_logf(s0), LN2_F, -ref_ln);
             float l1 = fmaf(__builtin_amdgcn_logf(s1), LN2_F, -ref_ln);
-            l0 = fmaxf(l0, LOG_TINY_F);
-            l1 = fmaxf(l1, LOG_TINY_F);
+            l0 = fmaxf(l0, floor_val);
+            l1 = fmaxf(l1, floor_val);
             if (ok0) orow0[next_sid] = l0;
             if (ok1) orow1[next_sid] = l1;
             s0 = 0.0f;
@@ -1862,9 +1877,9 @@ static void launch_full_bf16_t(const aasr_gmm *g, const float *d_frames, int64_t
   AASR_HIP(hipGetLastError());
 }
 
-template <int NKK>
+template <int NKK, bool CL = false>
 static void launch_full_t(const aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
-                          hipStream_t stream) {
+                          hipStream_t stream, const ClusterArgs &cl = ClusterArgs()) {
   const FullLayout &L = g->full;
   const int64_t blocks = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
   const int smem = 2 * (NKK / 2) * 64 * 4 * 4;
@@ -1881,9 +1896,9 @@ static void launch_full_t(const aasr_gmm *g, const float *d_frames, int64_t F, f
     }
   }
   const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 8;
-  hipLaunchKernelGGL(k_gmm_full_score<NKK>, dim3((unsigned)blocks, (unsigned)R), dim3(256), smem, stream,
+  hipLaunchKernelGGL((k_gmm_full_score<NKK, CL>), dim3((unsigned)blocks, (unsigned)R), dim3(256), smem, stream,
                      d_frames, F, g->dim, g->d_pivot.p, L.rows.a.p, split_row, L.close.p, L.gconst.p,
-                     L.g_stride, L.sid.p, L.s_stride, d_out, g->S, L.ref_ln);
+                     L.g_stride, L.sid.p, L.s_stride, d_out, g->S, L.ref_ln, cl);
   AASR_HIP(hipGetLastError());
 }
 
@@ -1903,6 +1918,27 @@ void gmm_full_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out
 #define AASR_CASE(N)                                   \
   case N:                                              \
     launch_full_t<N>(g, d_frames, F, d_out, stream);   \
+    return;
+    AASR_CASE(8) AASR_CASE(14) AASR_CASE(20) AASR_CASE(26) AASR_CASE(32)
+#undef AASR_CASE
+    default:
+      raise(AASR_ERR_UNSUPPORTED, "no full-covariance kernel instance for K/2 = %d", g->full.rows.nkk);
+  }
+}
+
+// Gaussian clustering over a full-covariance pool: the exact part of every state on the f32 factor-row kernel with
+// the selection masks (the bf16x3 form has no masked instance), no floor -- k_cluster_merge_log adds the centres.
+void gmm_full_masked_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
+                            const unsigned long long *maskrow, hipStream_t stream) {
+  if (!g->full.ok) raise(AASR_ERR_UNSUPPORTED, "full-covariance layout was not built for this model");
+  ClusterArgs cl;
+  cl.maskrow = maskrow;
+  cl.rows_padded = g->full.rows_padded;
+  cl.floor_val = NEG_BIG_F;
+  switch (g->full.rows.nkk) {
+#define AASR_CASE(N)                                                  \
+  case N:                                                             \
+    launch_full_t<N, true>(g, d_frames, F, d_out, stream, cl);        \
     return;
     AASR_CASE(8) AASR_CASE(14) AASR_CASE(20) AASR_CASE(26) AASR_CASE(32)
 #undef AASR_CASE

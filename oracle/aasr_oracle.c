@@ -263,7 +263,7 @@ static void orc_pool_likelihoods_clustered_x(int dim, int64_t G, const double *m
                                     const double *c_cst, int min_clusters,
                                     int min_gaussians, const double *frame,
                                     const double *member_frames, const double *member_scales,
-                                    const int32_t *g_class,
+                                    const int32_t *g_class, const double *exact_lik,
                                     double *gauss_lik, int32_t *n_exact);
 
 void orc_pool_likelihoods_clustered(int dim, int64_t G, const double *mean,
@@ -278,7 +278,23 @@ void orc_pool_likelihoods_clustered(int dim, int64_t G, const double *mean,
     const double one = 1.0;
     orc_pool_likelihoods_clustered_x(dim, G, mean, prec, cst, C, cl_off, cl_members, c_mean,
                                      c_prec, c_cst, min_clusters, min_gaussians, frame, frame,
-                                     &one, NULL, gauss_lik, n_exact);
+                                     &one, NULL, NULL, gauss_lik, n_exact);
+}
+
+/* The cluster branch does not look at the type of the pool's Gaussians (aku/Distributions.cc:2684-2722 calls
+ * compute_likelihood through the PDF interface): exact_lik[g] is the likelihood of pool Gaussian g for this frame,
+ * whatever its covariance structure (full-covariance pools, tests/test_fullcov_gpu.py); the centres are the diagonal
+ * Gaussians of orc_cluster_centres. */
+void orc_pool_likelihoods_clustered_pre(int dim, int64_t G, int C, const int32_t *cl_off,
+                                        const int32_t *cl_members, const double *c_mean,
+                                        const double *c_prec, const double *c_cst, int min_clusters,
+                                        int min_gaussians, const double *frame, const double *exact_lik,
+                                        double *gauss_lik, int32_t *n_exact)
+{
+    const double one = 1.0;
+    orc_pool_likelihoods_clustered_x(dim, G, NULL, NULL, NULL, C, cl_off, cl_members, c_mean, c_prec, c_cst,
+                                     min_clusters, min_gaussians, frame, frame, &one, NULL, exact_lik,
+                                     gauss_lik, n_exact);
 }
 
 /* The same with model-side constrained MLLR in place (ConstrainedMllr::AdaptedGaussian,
@@ -295,7 +311,7 @@ static void orc_pool_likelihoods_clustered_x(int dim, int64_t G, const double *m
                                     const double *c_cst, int min_clusters,
                                     int min_gaussians, const double *frame,
                                     const double *member_frames, const double *member_scales,
-                                    const int32_t *g_class,
+                                    const int32_t *g_class, const double *exact_lik,
                                     double *gauss_lik, int32_t *n_exact)
 {
     orc_clpair *heap = (orc_clpair *)malloc(sizeof(orc_clpair) * (size_t)(C > 0 ? C : 1));
@@ -317,8 +333,9 @@ static void orc_pool_likelihoods_clustered_x(int dim, int64_t G, const double *m
         for (int32_t j = cl_off[c]; j < cl_off[c + 1]; j++) {
             int64_t g = cl_members[j];
             const int k = g_class ? g_class[g] : 0;
-            gauss_lik[g] = exp(orc_diag_loglik(dim, member_frames + (size_t)k * dim, mean + g * dim,
-                                               prec + g * dim, cst[g])) * member_scales[k];
+            gauss_lik[g] = exact_lik ? exact_lik[g]
+                                     : exp(orc_diag_loglik(dim, member_frames + (size_t)k * dim, mean + g * dim,
+                                                           prec + g * dim, cst[g])) * member_scales[k];
         }
         clusters_done++;
         gauss_done += cl_off[c + 1] - cl_off[c];
@@ -338,8 +355,9 @@ static void orc_pool_likelihoods_clustered_x(int dim, int64_t G, const double *m
     for (int64_t g = 0; g < G; g++)
         if (!(gauss_lik[g] > 0)) {
             const int k = g_class ? g_class[g] : 0;
-            gauss_lik[g] = exp(orc_diag_loglik(dim, member_frames + (size_t)k * dim, mean + g * dim,
-                                               prec + g * dim, cst[g])) * member_scales[k];
+            gauss_lik[g] = exact_lik ? exact_lik[g]
+                                     : exp(orc_diag_loglik(dim, member_frames + (size_t)k * dim, mean + g * dim,
+                                                           prec + g * dim, cst[g])) * member_scales[k];
         }
 }
 
@@ -372,7 +390,7 @@ void orc_score_frames_clustered_adapted(int dim, int64_t G, const double *mean,
         }
         orc_pool_likelihoods_clustered_x(dim, G, mean, prec, cst, C, cl_off, cl_members, c_mean,
                                          c_prec, c_cst, min_clusters, min_gaussians,
-                                         frames + f * dim, xf, &det, NULL, scratch,
+                                         frames + f * dim, xf, &det, NULL, NULL, scratch,
                                          n_exact ? n_exact + f : NULL);
         orc_state_likelihoods(S, mix_off, mix_idx, mix_w, scratch, slik);
         for (int64_t s = 0; s < S; s++)
@@ -426,7 +444,7 @@ void orc_score_frames_clustered_classes(int dim, int64_t G, const double *mean,
         }
         orc_pool_likelihoods_clustered_x(dim, G, mean, prec, cst, C, cl_off, cl_members, c_mean,
                                          c_prec, c_cst, min_clusters, min_gaussians,
-                                         frames + f * dim, xf, det, cls, scratch,
+                                         frames + f * dim, xf, det, cls, NULL, scratch,
                                          n_exact ? n_exact + f : NULL);
         orc_state_likelihoods(S, mix_off, mix_idx, mix_w, scratch, slik);
         for (int64_t s = 0; s < S; s++)

@@ -1505,6 +1505,65 @@ class FullModel:
         return out
 
 
+def _fullmodel_set_clustering(self, n_clusters: int, pairs, eval_minc: float = 0.0, eval_ming: float = 0.1):
+    """PDFPool::read_clustering over a full-covariance pool (aku/Distributions.cc:3114-3170): the centres are
+    DiagonalGaussians merged from the members' means and the DIAGONALS of their covariances (Gaussian::merge,
+    :853-898, reads get_covariance() and the diagonal target keeps the diagonal of the result)."""
+    members = [[] for _ in range(n_clusters)]
+    for g, c in pairs:
+        members[c].append(g)
+    self.cl_off = np.zeros(n_clusters + 1, np.int32)
+    self.cl_off[1:] = np.cumsum([len(m) for m in members])
+    self.cl_members = np.array([g for m in members for g in m], np.int32)
+    self.n_clusters = n_clusters
+    self.c_mean = np.zeros((n_clusters, self.D))
+    self.c_prec = np.zeros((n_clusters, self.D))
+    self.c_cst = np.zeros(n_clusters)
+    covdiag = np.ascontiguousarray(np.einsum("gii->gi", self.cov))
+    pd = C.c_double
+    lib().orc_cluster_centres(self.D, n_clusters, _p(self.cl_off, C.c_int32), _p(self.cl_members, C.c_int32),
+                              _p(self.mean, pd), _p(covdiag, pd), _p(self.c_mean, pd), _p(self.c_prec, pd),
+                              _p(self.c_cst, pd))
+    self.min_clusters = int(eval_minc * n_clusters)
+    self.min_gaussians = int(eval_ming * self.G)
+
+
+def _fullmodel_score_clustered(self, frames: np.ndarray, want_counts: bool = False):
+    """[F x S] log state likelihood with the cluster branch of PDFPool::precompute_likelihoods
+    (aku/Distributions.cc:2684-2722), which reaches the members through the PDF interface: diagonal centres
+    ranked per frame, full-covariance members evaluated exactly for the best clusters, the centre's likelihood
+    for the rest (and the > 0 access rule of compute_likelihood, :2636-2644)."""
+    frames = np.ascontiguousarray(frames, np.float64)
+    F = frames.shape[0]
+    exact = np.ascontiguousarray(np.exp(self.gauss_loglik(frames)))
+    out = np.empty((F, self.S))
+    counts = np.zeros(F, np.int32)
+    glik = np.empty(self.G)
+    L = lib()
+    pd, pi = C.c_double, C.c_int32
+    L.orc_pool_likelihoods_clustered_pre.restype = None
+    L.orc_pool_likelihoods_clustered_pre.argtypes = [C.c_int, C.c_int64, C.c_int, C.POINTER(pi), C.POINTER(pi),
+                                                     C.POINTER(pd), C.POINTER(pd), C.POINTER(pd), C.c_int, C.c_int,
+                                                     C.POINTER(pd), C.POINTER(pd), C.POINTER(pd), C.POINTER(pi)]
+    cnt = np.zeros(1, np.int32)
+    for f in range(F):
+        L.orc_pool_likelihoods_clustered_pre(self.D, self.G, self.n_clusters, _p(self.cl_off, pi),
+                                             _p(self.cl_members, pi), _p(self.c_mean, pd), _p(self.c_prec, pd),
+                                             _p(self.c_cst, pd), self.min_clusters, self.min_gaussians,
+                                             _p(np.ascontiguousarray(frames[f]), pd), _p(np.ascontiguousarray(exact[f]), pd),
+                                             _p(glik, pd), _p(cnt, pi))
+        counts[f] = cnt[0]
+        for s in range(self.S):
+            a, b = self.mix_off[s], self.mix_off[s + 1]
+            l = float(glik[self.mix_idx[a:b]] @ self.mix_w[a:b]) if b > a else 0.0
+            out[f, s] = np.log(max(l, TINY_FOR_LOG))
+    return (out, counts) if want_counts else out
+
+
+FullModel.set_clustering = _fullmodel_set_clustering
+FullModel.score_clustered = _fullmodel_score_clustered
+
+
 def write_gk_full(path: str, mean: np.ndarray, cov: np.ndarray, is_full=None, var=None,
                   legacy: bool = False) -> None:
     """'variable' .gk with 'full' (mean + d*d covariance) and 'diag' entries, or

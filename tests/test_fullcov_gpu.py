@@ -5,6 +5,8 @@ against the oracle's exponential-form restatement
 import numpy as np
 import pytest
 
+from conftest import assert_ll
+
 from aaltoasr_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -108,3 +110,38 @@ def test_per_gaussian_view_of_a_full_covariance_pool(capi, oracle):
         assert np.all(got[~vis] <= np.log(1e-50) + 1e-4)
     # state scores of the same handle are unaffected
     assert np.abs(g.score(frames) - oracle.FullModel(mean, cov, off, idx, w).score(frames.astype(np.float64))).max() <= 1e-4
+
+
+@pytest.mark.parametrize("D,G,S,comps,C,minc,ming", [(8, 96, 12, 8, 8, 0.0, 0.25), (13, 128, 16, 8, 12, 0.2, 0.1),
+                                                     (39, 160, 20, 8, 16, 0.0, 0.3), (24, 90, 15, 6, 9, 0.5, 0.0),
+                                                     (39, 160, 20, 8, 16, 1.0, 1.0)])
+def test_clustering_over_a_full_covariance_pool(capi, oracle, D, G, S, comps, C, minc, ming):
+    """-C GCL --eval-minc / --eval-ming on a full-covariance pool: the reference's cluster branch reaches the pool's
+    Gaussians through the PDF interface (aku/Distributions.cc:2684-2722) and read_clustering merges any Gaussian
+    type into diagonal centres (:3151-3169, Gaussian::merge :853-898), so it works for full covariances as for
+    diagonal ones: centres from the members' means and covariance diagonals, exact members where their cluster is
+    selected, the centre's value elsewhere.  Scores to 1e-4, exact-evaluation counts bit for bit."""
+    rng = np.random.default_rng(7000 + D + C)
+    mean = rng.standard_normal((G, D))
+    a = rng.standard_normal((G, D, D)) * 0.35
+    cov = a @ a.transpose(0, 2, 1) + 0.15 * np.eye(D)
+    _, _, off, idx, w = synth.make_model(D=D, G=G, S=S, comps=comps, seed=D)
+    g2c = synth.make_clustering(mean, C, seed=5)
+    g2c[rng.integers(0, G, 5)] = -1                      # some Gaussians in no cluster: always exact
+    pairs = [(int(i), int(c)) for i, c in enumerate(g2c) if c >= 0]
+    frames = synth.make_frames(150, D=D, seed=7100 + D)
+    frames[:10] = (mean[:10] + 0.2 * rng.standard_normal((10, D))).astype(np.float32)
+    om = oracle.FullModel(mean, cov, off, idx, w)
+    om.set_clustering(C, pairs, minc, ming)
+    want, want_n = om.score_clustered(frames.astype(np.float64), want_counts=True)
+    g = capi.Gmm.from_full(mean, cov, off, idx, w)
+    g.set_clustering(C, pairs)
+    g.set_clustering_min_evals(minc, ming)
+    for prec in (0, 3, 4):
+        g.set_precision(prec)
+        got = g.score(frames)
+        assert np.array_equal(g.cluster_exact_counts(len(frames)), want_n)
+        assert_ll(got, want, "clustered full covariance, precision %d" % prec)
+    if minc == 1.0:   # everything exact: the unclustered scores
+        assert_ll(g.score(frames), om.score(frames.astype(np.float64)), "all clusters exact")
+    g.close()
