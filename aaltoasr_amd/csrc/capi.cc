@@ -360,7 +360,7 @@ aasr_status aasr_gmm_score(aasr_gmm *h, const float *frames, int64_t F, float *s
     // Host callers get dense [F x S] rows, but on the device the rows are padded to whole 128-byte
     // lines where the kernel supports a pitch (every output group then is one full cache line:
     // 1.00x write traffic instead of 1.32x for S = 3125); the 2-D copy back drops the padding.
-    const int64_t pitch = gmm_score_pitch_ok(h) && !h->cl.enabled ? (h->S + 31) / 32 * 32 : h->S;
+    const int64_t pitch = gmm_score_pitch_ok(h) ? (h->S + 31) / 32 * 32 : h->S;
     h->d_out.ensure((size_t)F * pitch);
     if (pitch != h->S) {
       gmm_score_launch_pitched(h, h->d_frames.p, F, h->d_out.p, pitch, nullptr);

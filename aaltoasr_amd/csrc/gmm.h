@@ -378,10 +378,11 @@ void gmm_outliers_masked_launch(aasr_gmm *g, const float *d_frames, int64_t F, f
 void gmm_centred_masked_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, const int32_t *crow,
                                const unsigned long long *maskw, int c1, int64_t n_words, hipStream_t stream);
 void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
-                              hipStream_t stream);
+                              hipStream_t stream, int64_t pitch = 0);
+bool gmm_cluster_pitch_ok(const aasr_gmm *g);
 void gmm_tracks_masked_launch(aasr_gmm *g, int which, const float *d_frames, int64_t F,
                               float *d_out, const unsigned long long *maskrow,
-                              hipStream_t stream);
+                              hipStream_t stream, int64_t pitch = 0);
 void gmm_full_masked_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                             const unsigned long long *maskrow, hipStream_t stream);
 }  // namespace aasr

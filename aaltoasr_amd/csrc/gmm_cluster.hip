@@ -690,14 +690,13 @@ __global__ __launch_bounds__(256) void k_cluster_expand(
 // one 16-byte LDS read serves four frames of a (state, cluster) pair; every
 // thread keeps the centre weights of its two states in registers.
 constexpr int kMergeFrames = 8;
-constexpr int kMergeThreads = 1024;
 constexpr int kMergeSPT = 2;  // states per thread
 
-template <int NNZ>
-__global__ __launch_bounds__(kMergeThreads) void k_cluster_merge(
+template <int NNZ, int kMergeThreads>
+__global__ __launch_bounds__(kMergeThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cluster_merge(
     float *__restrict__ out, int64_t F, int64_t S, const float *__restrict__ cval, int C,
     const int32_t *__restrict__ w_cluster, const float *__restrict__ w_weight, int nnz,
-    float ref, int frames_per_block, int cstride) {
+    float ref, int frames_per_block, int cstride, int64_t pitch) {
   // [C][cstride]: cstride = 12 floats spreads the 16-byte reads of different
   // clusters over all banks (8 would put every read on 4 bank groups)
   extern __shared__ __attribute__((aligned(16))) float cv[];
@@ -736,7 +735,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_cluster_merge(
     for (int u = 0; u < kMergeSPT; u++)
 #pragma unroll
       for (int k = 0; k < kMergeFrames; k++)
-        onext[u][k] = (live[u] && k < nf) ? out[(fg + k) * S + st[u]] : 0.0f;
+        onext[u][k] = (live[u] && k < nf) ? out[(fg + k) * pitch + st[u]] : 0.0f;
   };
   if (f_begin < f_end) request(f_begin);
   for (int64_t fg = f_begin; fg < f_end; fg += kMergeFrames) {
@@ -795,7 +794,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_cluster_merge(
         if (k < nf) {
           const float l2 = xk[k] <= 60.0f ? __log2f(lin[k]) : xk[k] + __log2f(1.0f + lin[k] * exp2f(-xk[k]));
           const float l = fmaf(l2, 0.69314718055994530942f, -ref_ln);
-          out[(fg + k) * S + st[u]] = fmaxf(l, AASR_LOG_TINY_F);
+          out[(fg + k) * pitch + st[u]] = fmaxf(l, AASR_LOG_TINY_F);
         }
     }
   }
@@ -1170,12 +1169,12 @@ static void launch_select(aasr_gmm *g, int64_t s0, int64_t F, hipStream_t stream
 __global__ __launch_bounds__(256) void k_cluster_merge_log(float *__restrict__ out, int64_t F, int64_t S,
                                                            const float *__restrict__ cvl, int C,
                                                            const int32_t *__restrict__ w_cluster,
-                                                           const float *__restrict__ w_weight, int nnz) {
+                                                           const float *__restrict__ w_weight, int nnz, int64_t pitch) {
   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (s >= S) return;
   for (int64_t f = blockIdx.y; f < F; f += gridDim.y) {
     const float *cv = cvl + f * C;
-    const float x = out[f * S + s] * 1.4426950408889634f;
+    const float x = out[f * pitch + s] * 1.4426950408889634f;
     float m = x;
     for (int j = 0; j < nnz; j++) {
       const float w = w_weight[(int64_t)j * S + s];
@@ -1190,18 +1189,18 @@ __global__ __launch_bounds__(256) void k_cluster_merge_log(float *__restrict__ o
       }
       l = (m + __log2f(sum)) * 0.69314718055994530942f;
     }
-    out[f * S + s] = fmaxf(l, AASR_LOG_TINY_F);
+    out[f * pitch + s] = fmaxf(l, AASR_LOG_TINY_F);
   }
 }
 
-static void launch_merge(aasr_gmm *g, float *d_out, int64_t F, hipStream_t stream);
+static void launch_merge(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hipStream_t stream);
 
-template <int NNZ>
-static void launch_merge_t(aasr_gmm *g, float *d_out, int64_t F, hipStream_t stream) {
+template <int NNZ, int kMergeThreads>
+static void launch_merge_t(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hipStream_t stream) {
   ClusterState &cl = g->cl;
   const int64_t bx = (g->S + kMergeThreads * kMergeSPT - 1) / (kMergeThreads * kMergeSPT);
   // enough workgroups to fill the chip, each walking a contiguous run of frames
-  int64_t by = std::max<int64_t>(1, std::min<int64_t>((F + kMergeFrames - 1) / kMergeFrames, 1024 / bx));
+  int64_t by = std::max<int64_t>(1, std::min<int64_t>((F + kMergeFrames - 1) / kMergeFrames, (1024 * (1024 / kMergeThreads)) / bx));
   int fpb = (int)((F + by - 1) / by);
   fpb = (fpb + kMergeFrames - 1) / kMergeFrames * kMergeFrames;
   by = (F + fpb - 1) / fpb;
@@ -1209,26 +1208,29 @@ static void launch_merge_t(aasr_gmm *g, float *d_out, int64_t F, hipStream_t str
   const int smem = cstride * cl.C * (int)sizeof(float);
   static bool attr_set[64] = {false};
   if (!attr_set[g->device & 63]) {
-    AASR_HIP(hipFuncSetAttribute((const void *)k_cluster_merge<NNZ>,
+    AASR_HIP(hipFuncSetAttribute((const void *)k_cluster_merge<NNZ, kMergeThreads>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
     attr_set[g->device & 63] = true;
   }
-  hipLaunchKernelGGL(k_cluster_merge<NNZ>, dim3((unsigned)bx, (unsigned)by), dim3(kMergeThreads), smem,
+  hipLaunchKernelGGL((k_cluster_merge<NNZ, kMergeThreads>), dim3((unsigned)bx, (unsigned)by), dim3(kMergeThreads), smem,
                      stream, d_out, F, g->S, cl.cval.p, cl.C, cl.w_cluster.p, cl.w_weight.p, cl.nnz,
-                     (float)cl.ref_log2, fpb, cstride);
+                     (float)cl.ref_log2, fpb, cstride, pitch);
   AASR_HIP(hipGetLastError());
 }
 
-static void launch_merge(aasr_gmm *g, float *d_out, int64_t F, hipStream_t stream) {
+static void launch_merge(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hipStream_t stream) {
   ClusterState &cl = g->cl;
   if (cl.log_merge) {
     hipLaunchKernelGGL(k_cluster_merge_log, dim3((unsigned)((g->S + 255) / 256), (unsigned)std::min<int64_t>(F, 8192)),
-                       dim3(256), 0, stream, d_out, F, g->S, cl.cval.p, cl.C, cl.w_cluster.p, cl.w_weight.p, cl.nnz);
+                       dim3(256), 0, stream, d_out, F, g->S, cl.cval.p, cl.C, cl.w_cluster.p, cl.w_weight.p, cl.nnz, pitch);
     AASR_HIP(hipGetLastError());
     return;
   }
-  if (cl.nnz <= 8) launch_merge_t<8>(g, d_out, F, stream);
-  else launch_merge_t<16>(g, d_out, F, stream);   // weights beyond 16 per state come from L2
+  static const int threads = getenv("AASR_MERGE_THREADS") ? atoi(getenv("AASR_MERGE_THREADS")) : 1024;
+  if (cl.nnz <= 8) launch_merge_t<8, 1024>(g, d_out, F, pitch, stream);
+  else if (threads == 512) launch_merge_t<16, 512>(g, d_out, F, pitch, stream);
+  else if (threads == 256) launch_merge_t<16, 256>(g, d_out, F, pitch, stream);
+  else launch_merge_t<16, 1024>(g, d_out, F, pitch, stream);   // weights beyond 16 per state come from L2
 }
 
 // What a model's exact part needs besides the selection bits: the cluster of each of ITS rows /
@@ -1282,7 +1284,7 @@ static ExactPlan exact_part_plan(aasr_gmm *g, ClusterState &cl) {
 
 // out[f][s] = log of the sum over s's components whose cluster is evaluated exactly for frame f (no floor)
 static void exact_part_launch(aasr_gmm *g, ClusterState &cl, const ExactPlan &p, const unsigned long long *maskw,
-                              int c1, int64_t n, const float *fr_members, float *out, hipStream_t stream) {
+                              int c1, int64_t n, const float *fr_members, float *out, hipStream_t stream, int64_t pitch = 0) {
   const int64_t words = (n + 63) / 64;
   if (p.full) {
     const int64_t rows_padded = g->full.rows_padded;
@@ -1308,13 +1310,24 @@ static void exact_part_launch(aasr_gmm *g, ClusterState &cl, const ExactPlan &p,
                      (size_t)c1 * 8, stream, maskw, c1, cl.crow[p.which].p, L.rows_padded, tpb,
                      cl.maskrow.p);
   AASR_HIP(hipGetLastError());
-  gmm_tracks_masked_launch(g, p.which, fr_members, n, out, cl.maskrow.p, stream);
+  gmm_tracks_masked_launch(g, p.which, fr_members, n, out, cl.maskrow.p, stream, pitch);
   if (p.with_outliers) gmm_outliers_masked_launch(g, fr_members, n, out, cl.crow_hyb.p, maskw, c1, words, stream);
 }
 
+// A row pitch (state rows padded to whole cache lines, gmm_score_pitch_ok) is carried by the plain plan only: one
+// masked track kernel and the merge.  Class sub-models, outlier routing, the centred and full-covariance kernels write
+// dense rows.
+bool gmm_cluster_pitch_ok(const aasr_gmm *g) {
+  return g->cl.enabled && !g->class_routing && !g->host.any_full() && !g->host.factor_path() && !g->hyb_enabled &&
+         !g->ill_conditioned && (g->paired.ok || g->tracks.ok);
+}
+
 void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
-                              hipStream_t stream) {
+                              hipStream_t stream, int64_t pitch) {
   ClusterState &cl = g->cl;
+  if (pitch <= 0) pitch = g->S;
+  if (pitch != g->S && !gmm_cluster_pitch_ok(g))
+    raise(AASR_ERR_UNSUPPORTED, "a row pitch under Gaussian clustering needs the plain track plan");
   if (!g->host.any_full() && g->host.factor_path() && !g->class_routing)
     raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering over per-class transforms needs the class sub-models");
   if (g->host.any_full() && g->host.n_transforms > 0)
@@ -1360,7 +1373,7 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
   // as large as ~16 GB of scratch allow (1 bit per frame x packed row for the lane
   // masks, 4 B per frame x cluster for the centre values) and a whole number of rounds
   // of the track kernel (2 workgroups of 256 frames per CU); the f64 centre
-  // log-likelihoods (8 B per frame x cluster) only live for a sub-pass of <= 2 GB.
+  // log-likelihoods (8 B per frame x cluster) only live for a sub-pass of <= 8.6 GB (10^6 frames x 1000 clusters in one go: 42.7 ms per pass instead of 45.0 with five sub-passes of 2 GB, whose launches each end in a partly filled round of the one-wave selection workgroups; smaller sub-passes are worse still: 512 MB 52 ms, 256 MB 61 ms).
   const double per_frame = (double)mask_rows / 8.0 + 4.125 * (double)(cl.C + 1) + 4.0 + (classes ? 4.0 * (double)g->S : 0.0);
   const int64_t round_frames = 2 * (int64_t)(g->num_cus > 0 ? g->num_cus : 256) * FRAMES_PER_BLOCK;
   const int64_t f_rounded = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK;
@@ -1368,7 +1381,8 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
   if (fb >= round_frames) fb = fb / round_frames * round_frames;
   else fb = std::max<int64_t>(FRAMES_PER_BLOCK, fb / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK);
   fb = std::min<int64_t>(fb, f_rounded);
-  int64_t fs = (int64_t)(2.0e9 / (8.0 * (double)cl.Cs));
+  static const double sub_bytes = getenv("AASR_CLUSTER_SUB_BYTES") ? atof(getenv("AASR_CLUSTER_SUB_BYTES")) : 8.6e9;
+  int64_t fs = (int64_t)(sub_bytes / (8.0 * (double)cl.Cs));
   fs = std::min<int64_t>(fb, std::max<int64_t>(FRAMES_PER_BLOCK, fs / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK));
   if (fb > cl.Fc || (size_t)fs * cl.Cs > cl.ll64.n) {
     fb = std::max(fb, cl.Fc);
@@ -1386,7 +1400,7 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
     const int64_t n = std::min<int64_t>(cl.Fc, F - f0);
     const float *fr = d_frames + f0 * g->dim;
     const float *fr_members = d_members + f0 * g->dim;
-    float *out = d_out + f0 * g->S;
+    float *out = d_out + f0 * pitch;
     for (int64_t s0 = 0; s0 < n; s0 += cl.Fs) {
       const int64_t ns = std::min<int64_t>(cl.Fs, n - s0);
       launch_centres(g, fr + s0 * g->dim, ns, stream);
@@ -1397,8 +1411,8 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
         exact_part_launch(sub, sub->cl, sub_plans[c], cl.maskw.p, cl.C + 1, n, xf, part, stream);
       }, stream);
     else
-      exact_part_launch(g, cl, plan, cl.maskw.p, cl.C + 1, n, fr_members, out, stream);
-    launch_merge(g, out, n, stream);
+      exact_part_launch(g, cl, plan, cl.maskw.p, cl.C + 1, n, fr_members, out, stream, pitch);
+    launch_merge(g, out, n, pitch, stream);
   }
 }
 
@@ -1413,7 +1427,8 @@ void gmm_cluster_score_f64_launch(aasr_gmm *g, const double *d_frames, const dou
   if (cl.crow_centred.n != std::max<size_t>(g->host.mix_idx.size(), 1))
     build_crow_comps(g, std::vector<int32_t>(), cl, cl.crow_centred);
   const int64_t f_rounded = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK;
-  int64_t fs = (int64_t)(2.0e9 / (8.0 * (double)cl.Cs));
+  static const double sub_bytes = getenv("AASR_CLUSTER_SUB_BYTES") ? atof(getenv("AASR_CLUSTER_SUB_BYTES")) : 8.6e9;
+  int64_t fs = (int64_t)(sub_bytes / (8.0 * (double)cl.Cs));
   fs = std::min<int64_t>(f_rounded, std::max<int64_t>(FRAMES_PER_BLOCK, fs / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK));
   if (fs > cl.Fc || (size_t)fs * cl.Cs > cl.ll64.n) {  // pass == sub-pass here
     const int64_t fb = std::max(fs, cl.Fc);

@@ -2547,15 +2547,15 @@ const float *gmm_adapted_frames(aasr_gmm *g, const float *d_frames, int64_t F, h
 
 void gmm_tracks_masked_launch(aasr_gmm *g, int which, const float *d_frames, int64_t F,
                               float *d_out, const unsigned long long *maskrow,
-                              hipStream_t stream) {
+                              hipStream_t stream, int64_t pitch) {
   const TrackLayout &L = which == 0 ? g->paired : g->tracks;
   if (!L.ok) raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering needs a track layout for this model");
   ClusterArgs cl;
   cl.maskrow = maskrow;
   cl.rows_padded = L.rows_padded;
   cl.floor_val = NEG_BIG_F;
-  if (g->use_bf16x3 && launch_bf16(g, L, d_frames, F, d_out, stream, &cl)) return;
-  if (!launch_tracks(g, L, d_frames, F, d_out, stream, &cl))
+  if (g->use_bf16x3 && launch_bf16(g, L, d_frames, F, d_out, stream, &cl, pitch)) return;
+  if (!launch_tracks(g, L, d_frames, F, d_out, stream, &cl, pitch))
     raise(AASR_ERR_UNSUPPORTED, "no track kernel instance for this model");
 }
 
@@ -2712,9 +2712,10 @@ static void add_output_bias(const aasr_gmm *g, float *d_out, int64_t F, hipStrea
 // (rows padded to a multiple of 16 floats make every 64-byte output group a whole cache line).
 bool gmm_score_pitch_ok(const aasr_gmm *g) {
   if (!g->dim_parts.empty()) return false;
-  if (g->cl.enabled || g->host.factor_path() || g->hyb_enabled || g->ill_conditioned || g->class_routing ||
+  if (g->host.factor_path() || g->hyb_enabled || g->ill_conditioned || g->class_routing ||
       g->precision == AASR_PREC_F64)
     return false;
+  if (g->cl.enabled && !gmm_cluster_pitch_ok(g)) return false;
   if ((g->layout_mask & 3) != 3) return false;
   const TrackLayout &L = g->paired.ok ? g->paired : g->tracks;
   // both track kernels (f32 and bf16x3) take a row pitch; the centred kernel does not
@@ -2730,6 +2731,10 @@ void gmm_score_launch_pitched(aasr_gmm *g, const float *d_frames, int64_t F, flo
   }
   if (pitch < g->S || !gmm_score_pitch_ok(g))
     raise(AASR_ERR_UNSUPPORTED, "a row pitch other than the state count needs the track kernels");
+  if (g->cl.enabled) {
+    gmm_cluster_score_launch(g, d_frames, F, d_out, stream, pitch);
+    return;
+  }
   if (g->xf_a.p) {
     g->d_xframes.ensure((size_t)F * g->dim);
     const int64_t n = F * g->dim;

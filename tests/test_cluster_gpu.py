@@ -69,6 +69,29 @@ def test_tied_pool_ragged_states_unclustered_gaussians(capi, oracle):
     _check(capi, oracle, model, g2c, 40, 0.1, 0.2, synth.make_frames(300, D=24))
 
 
+def test_clustered_rows_padded_to_whole_lines_equal_the_dense_rows(capi):
+    """aasr_gmm_score_dev_pitched under clustering (the plain plan: masked track kernel + merge carry the row pitch):
+    bit for bit the dense call's values, the padding untouched by the merge."""
+    import torch
+    model = synth.make_model(D=39, G=1500, S=125, comps=12)
+    g2c = synth.make_clustering(model[0], 50)
+    gm = capi.Gmm.from_arrays(*model)
+    gm.set_clustering(50, _pairs(g2c))
+    gm.set_clustering_min_evals(0.0, 0.25)
+    d_fr = torch.from_numpy(synth.make_frames(1500)).cuda()
+    for prec in (0, 3, 4):
+        gm.set_precision(prec)
+        assert gm.score_pitch_ok()
+        dense = torch.empty((1500, 125), device="cuda")
+        gm.score_dev(d_fr, dense)
+        padded = torch.full((1500, 128), 7.0, device="cuda")
+        gm.score_dev_pitched(d_fr, padded, 128)
+        torch.cuda.synchronize()
+        assert torch.equal(padded[:, :125], dense), prec
+    gm.set_precision(1)   # AASR_PREC_F64 writes dense rows
+    assert not gm.score_pitch_ok()
+
+
 def test_far_frames_underflowed_centres_fall_back_to_exact(capi, oracle):
     """Centre likelihood 0.0 in double -> PDFPool::compute_likelihood re-evaluates
     (aku/Distributions.cc:2636-2644)."""
