@@ -75,6 +75,42 @@ def run(seed=1, N=40, verbose=False):
                     key, ctx, eall, evis, want.ravel()[at], got.ravel()[at]))
                 if verbose:
                     print("FAIL", fails[-1])
+        # Gaussian clustering over the pool (the cluster branch does not look at the Gaussians' type): random
+        # clusters incl. empty ones and Gaussians in none, random minimum counts; scores and exact-evaluation counts
+        if rng.integers(0, 2) == 0 and G >= 2:
+            C = int(rng.integers(1, max(1, min(G // 3, 40)) + 1))   # read_clustering refuses C > G / 2
+            g2c = rng.integers(-1, C, G)
+            pairs = [(int(i), int(c)) for i, c in enumerate(g2c) if c >= 0]
+            minc, ming = float(rng.choice([0.0, 0.1, 0.3, 1.0])), float(rng.choice([0.0, 0.25, 0.5]))
+            om = O.FullModel(mean, cov, off, idx, w)
+            try:
+                om.set_clustering(C, pairs, minc, ming)
+                g.set_clustering(C, pairs)
+                g.set_clustering_min_evals(minc, ming)
+            except (capi.AasrError, ValueError) as e:
+                if verbose:
+                    print("clustering refused:", ctx, e)
+                continue
+            want_c, want_n = om.score_clustered(frames.astype(np.float64), want_counts=True)
+            for prec in (0, 3, 4):
+                try:
+                    g.set_precision(prec)
+                except capi.AasrError:
+                    continue
+                got = g.score(frames)
+                got_n = g.cluster_exact_counts(F)
+                d = np.abs(got - want_c)
+                vis = want_c > -103.97
+                key = "full clustered prec=%d" % prec
+                evis = float(d[vis].max()) if vis.any() else 0.0
+                worst[key] = max(worst.get(key, 0.0), evis)
+                with np.errstate(under="ignore"):
+                    flushes = (np.exp(got[~vis].astype(np.float64)).astype(np.float32) <= np.float32(2.0 ** -149)).all()
+                if evis > 1e-4 or not flushes or not np.array_equal(got_n, want_n):
+                    fails.append("%s %s C %d minc %.2f ming %.2f err %.3g counts equal %s" % (
+                        key, ctx, C, minc, ming, evis, np.array_equal(got_n, want_n)))
+                    if verbose:
+                        print("FAIL", fails[-1])
     worst["refused"] = refused
     return worst, fails
 
