@@ -690,6 +690,8 @@ __global__ __launch_bounds__(256) void k_cluster_expand(
 // one 16-byte LDS read serves four frames of a (state, cluster) pair; every
 // thread keeps the centre weights of its two states in registers.
 constexpr int kMergeFrames = 8;
+// k_cluster_expand stages one 64-frame word of every cluster's mask in LDS (8 bytes per cluster, 160 KB per workgroup)
+constexpr int kMaxClusters = 16384;
 constexpr int kMergeSPT = 2;  // states per thread
 
 template <int NNZ, int kMergeThreads>
@@ -874,8 +876,8 @@ void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
     raise(AASR_ERR_INVALID,
           "PDFPool::read_clustering(): Number of clusters (%d) seems insensible compared to the "
           "number of Gaussians (%ld).", n_clusters, (long)m.G);
-  if (n_clusters > 64 * 64)
-    raise(AASR_ERR_UNSUPPORTED, "more than 4096 clusters are not built (%d asked)", n_clusters);
+  if (n_clusters > kMaxClusters)
+    raise(AASR_ERR_UNSUPPORTED, "more than %d clusters are not built (%d asked)", kMaxClusters, n_clusters);
   if (n_pairs > 0 && (!gauss_index || !cluster_index))
     raise(AASR_ERR_INVALID, "aasr_gmm_set_clustering: null argument");
   if (!g->class_routing && !g->paired.ok && !g->tracks.ok && !g->centred_ok && !(m.any_full() && g->full.ok))
@@ -905,6 +907,9 @@ void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
   // fit under that exponent (clusters of variance-floored Gaussians: +121 nats at sigma 0.045), takes
   // the log-domain merge instead: centre values as log2, per-state (max, sum) -- no range limit.
   n.log_merge = !g->paired.ok && !g->tracks.ok;
+  // the linear merge stages a frame group's centre values in LDS, [cluster][8 frames]: beyond 4 608 clusters they do
+  // not fit, and the log-domain merge reads them through the caches
+  if ((size_t)n_clusters * kMergeFrames * sizeof(float) > 144 * 1024) n.log_merge = true;
   n.ref_log2 = g->paired.ok ? g->paired.ref_log2 : g->tracks.ok ? g->tracks.ref_log2 : 0.0;
   n.csize_h.resize((size_t)n.Cs, 0);
   n.c_mean.assign((size_t)n.C * m.dim, 0.0);
@@ -1154,8 +1159,38 @@ static void launch_select_t(aasr_gmm *g, int64_t s0, int64_t F, hipStream_t stre
   AASR_HIP(hipGetLastError());
 }
 
+// More than 64 x 64 clusters: a lane of the selection wave cannot hold its share of a frame's keys.  Every frame then
+// takes the queue replay (k_cluster_select_heap, one thread per frame: exact, an order of magnitude slower -- the
+// reference's own clusterings have ~1 000 clusters); the masks start out empty with the "in no cluster" column set.
+__global__ void k_cluster_all_to_replay(unsigned long long *__restrict__ maskw, int64_t words, int c1,
+                                        int32_t *__restrict__ tie_list, int64_t tie_cap, int64_t F) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < words * c1) maskw[i] = (i % c1 == c1 - 1) ? ~0ull : 0ull;
+  if (i < F) tie_list[i] = (int32_t)i;
+  if (i == 0) tie_list[tie_cap] = (int32_t)F;
+}
+
+static void launch_select_replay(aasr_gmm *g, int64_t s0, int64_t F, hipStream_t stream) {
+  ClusterState &cl = g->cl;
+  const int64_t words = (F + 63) / 64;
+  const double ref_arg = cl.log_merge ? (double)NAN : cl.ref_log2;
+  const int64_t n = std::max<int64_t>(words * (cl.C + 1), F);
+  hipLaunchKernelGGL(k_cluster_all_to_replay, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                     cl.maskw.p + (size_t)(s0 / 64) * (cl.C + 1), words, cl.C + 1, cl.tie_list.p, cl.Fs, F);
+  AASR_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_cluster_select_heap, dim3(kHeapThreads / 64), dim3(64), 0, stream, cl.ll64.p, cl.C,
+                     (int64_t)cl.Cs, cl.csize.p, cl.min_clusters, cl.min_gaussians, ref_arg,
+                     cl.maskw.p + (size_t)(s0 / 64) * (cl.C + 1), cl.cval.p + (size_t)s0 * cl.C,
+                     cl.n_exact.p + s0, cl.tie_list.p, cl.Fs, cl.heap_key.p, cl.heap_idx.p);
+  AASR_HIP(hipGetLastError());
+}
+
 static void launch_select(aasr_gmm *g, int64_t s0, int64_t F, hipStream_t stream) {
   const int kpl = (g->cl.C + 63) / 64;
+  if (kpl > 64) {
+    launch_select_replay(g, s0, F, stream);
+    return;
+  }
   if (kpl <= 4) launch_select_t<4>(g, s0, F, stream);
   else if (kpl <= 16) launch_select_t<16>(g, s0, F, stream);
   else if (kpl <= 32) launch_select_t<32>(g, s0, F, stream);
@@ -1282,6 +1317,18 @@ static ExactPlan exact_part_plan(aasr_gmm *g, ClusterState &cl) {
   return p;
 }
 
+static void launch_expand(aasr_gmm *g, const unsigned long long *maskw, int c1, const int32_t *crow, int64_t rows_padded,
+                          int64_t n_tiles, int tpb, int64_t words, unsigned long long *maskrow, hipStream_t stream) {
+  static bool attr_set[64] = {false};
+  if ((size_t)c1 * 8 > 48 * 1024 && !attr_set[g->device & 63]) {
+    AASR_HIP(hipFuncSetAttribute((const void *)k_cluster_expand, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set[g->device & 63] = true;
+  }
+  hipLaunchKernelGGL(k_cluster_expand, dim3((unsigned)((n_tiles + tpb - 1) / tpb), (unsigned)words), dim3(256),
+                     (size_t)c1 * 8, stream, maskw, c1, crow, rows_padded, tpb, maskrow);
+  AASR_HIP(hipGetLastError());
+}
+
 // out[f][s] = log of the sum over s's components whose cluster is evaluated exactly for frame f (no floor)
 static void exact_part_launch(aasr_gmm *g, ClusterState &cl, const ExactPlan &p, const unsigned long long *maskw,
                               int c1, int64_t n, const float *fr_members, float *out, hipStream_t stream, int64_t pitch = 0) {
@@ -1291,9 +1338,7 @@ static void exact_part_launch(aasr_gmm *g, ClusterState &cl, const ExactPlan &p,
     cl.maskrow.ensure((size_t)((n + 511) / 512 * 8) * (size_t)rows_padded);
     const int64_t n_tiles = rows_padded / TILE_ROWS;
     const int tpb = (int)std::min<int64_t>(n_tiles, 64);
-    hipLaunchKernelGGL(k_cluster_expand, dim3((unsigned)((n_tiles + tpb - 1) / tpb), (unsigned)words), dim3(256),
-                       (size_t)c1 * 8, stream, maskw, c1, cl.crow_full.p, rows_padded, tpb, cl.maskrow.p);
-    AASR_HIP(hipGetLastError());
+    launch_expand(g, maskw, c1, cl.crow_full.p, rows_padded, n_tiles, tpb, words, cl.maskrow.p, stream);
     gmm_full_masked_launch(g, fr_members, n, out, cl.maskrow.p, stream);
     return;
   }
@@ -1306,10 +1351,7 @@ static void exact_part_launch(aasr_gmm *g, ClusterState &cl, const ExactPlan &p,
   cl.maskrow.ensure((size_t)((n + 511) / 512 * 8) * (size_t)L.rows_padded);
   const int64_t n_tiles = L.rows_padded / TILE_ROWS;
   const int tpb = (int)std::min<int64_t>(n_tiles, 64);  // the staged cluster masks serve 64 tiles
-  hipLaunchKernelGGL(k_cluster_expand, dim3((unsigned)((n_tiles + tpb - 1) / tpb), (unsigned)words), dim3(256),
-                     (size_t)c1 * 8, stream, maskw, c1, cl.crow[p.which].p, L.rows_padded, tpb,
-                     cl.maskrow.p);
-  AASR_HIP(hipGetLastError());
+  launch_expand(g, maskw, c1, cl.crow[p.which].p, L.rows_padded, n_tiles, tpb, words, cl.maskrow.p, stream);
   gmm_tracks_masked_launch(g, p.which, fr_members, n, out, cl.maskrow.p, stream, pitch);
   if (p.with_outliers) gmm_outliers_masked_launch(g, fr_members, n, out, cl.crow_hyb.p, maskw, c1, words, stream);
 }

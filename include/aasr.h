@@ -248,8 +248,9 @@ aasr_status aasr_gmm_set_cmllr(aasr_gmm *h, int32_t n_transforms,
  * file twice (its while(in) loop runs once more on stale operands), which
  * weights that Gaussian double in its centre and in the Gaussian count.
  * aasr_gmm_set_clustering takes the pairs literally (n_clusters = 0 removes the
- * clustering).  Built for diagonal, unadapted pools with at most 4096 clusters;
- * more than 0.3 * pool size clusters is rejected like the reference does. */
+ * clustering).  Built for diagonal pools (any constrained-MLLR adaptation) and unadapted full-covariance pools, up to
+ * 16384 clusters (beyond 4096 every frame takes the slower replay of the reference's priority queue); more than
+ * 0.3 * pool size clusters is rejected like the reference does. */
 aasr_status aasr_gmm_read_clustering(aasr_gmm *h, const char *gcl_path);
 aasr_status aasr_gmm_set_clustering(aasr_gmm *h, int32_t n_clusters, int64_t n_pairs,
                                     const int32_t *gauss_index, const int32_t *cluster_index);

@@ -200,6 +200,18 @@ def test_many_clusters_multi_pass(capi, oracle):
     _check(capi, oracle, model, g2c, 1500, 0.05, 0.2, synth.make_frames(130, D=13))
 
 
+def test_more_clusters_than_a_selection_wave_holds(capi, oracle):
+    """> 4096 clusters: every frame takes the replay of the reference's priority queue (k_cluster_select_heap) and the
+    log-domain merge; scores and counts as the oracle's."""
+    rng = np.random.default_rng(41)
+    model = synth.make_model(D=6, G=15000, S=500, comps=30)
+    C = 4300
+    g2c = rng.integers(0, C, 15000)
+    g2c[rng.integers(0, 15000, 40)] = -1
+    frames = synth.make_frames(70, D=6)
+    _check(capi, oracle, model, g2c, C, 0.02, 0.1, frames)
+
+
 def test_clustering_errors(capi, tmp_path):
     mean, var, off, idx, w = synth.make_model(D=8, G=100, S=10, comps=10)
     gm = capi.Gmm.from_arrays(mean, var, off, idx, w)
