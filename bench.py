@@ -317,13 +317,23 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: there is no CPU fallback for the product path")
+    # Rehearsal switches (not what the driver runs): AASR_BENCH_SHARE_GPU=1 puts every rank on device 0 and
+    # AASR_BENCH_BACKEND=gloo carries the few collectives over TCP -- RCCL refuses two ranks on one device, and a
+    # one-GPU box is all there is to check that an N-rank run of this file goes through without a mismatched barrier
+    backend = os.environ.get("AASR_BENCH_BACKEND", "nccl")
+    if os.environ.get("AASR_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit("bench.py: rank %d has no device (%d visible)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
     world = 1
     if distributed:
-        dist.init_process_group("nccl", rank=rank, world_size=env_world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=env_world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=env_world)
         world = dist.get_world_size()       # what RCCL actually connected
 
     from aaltoasr_amd import build, capi, shard, synth
@@ -342,7 +352,7 @@ def main():
     else:
         model = dict.fromkeys(names)
     if distributed:
-        model = shard.broadcast_model(model, src=0, device=dev)
+        model = shard.broadcast_model(model, src=0, device=dev if backend == "nccl" else None)
     mean, var, off, idx, w = (model[k] for k in names)
     gmm = capi.Gmm.from_arrays(mean, var, off, idx, w)
     PREC = {"f16x2": 4, "bf16x3": 3, "f32": 0}[args.precision]   # AASR_PREC_F16X2 / AASR_PREC_BF16X3 / AASR_PREC_F32
@@ -362,14 +372,14 @@ def main():
     def max_over_ranks(x):
         if not distributed:
             return x
-        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        t = torch.tensor([x], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def sum_over_ranks(x):
         if not distributed:
             return x
-        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        t = torch.tensor([x], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
@@ -566,6 +576,9 @@ def main():
                "sharding": "frames/utterances per rank, no collective on the scoring path",
                "rccl_world_size": world if distributed else None, "gpus_flag": args.gpus}
         cfg.update(extra_cfg)
+        if backend != "nccl" or os.environ.get("AASR_BENCH_SHARE_GPU") == "1":
+            cfg["rehearsal"] = ("NOT a multi-GPU measurement: %d ranks, backend %s, %s" % (
+                world, backend, "all on device 0" if os.environ.get("AASR_BENCH_SHARE_GPU") == "1" else "one device each"))
         line = {
             "metric": METRIC,
             "metric_note": "value is the workload named in config.workload (default: configs[2], the metric's MFCC-inclusive chain); "

@@ -74,3 +74,29 @@ def test_bench_line_on_a_gpu(args, key):
         assert d["config"]["configs2"]["lna_check"]["max_code_difference"] <= 1
     if key == "recipe":
         assert d["scaling"] == "strong" and d["config"]["recipe"]["utterances"] == 40
+
+
+@pytest.mark.gpu
+def test_two_ranks_go_through_the_whole_default_run():
+    """What a one-GPU box can check of `--gpus N`: the file under torch.distributed.run with two ranks -- both on
+    device 0 and the collectives over gloo (AASR_BENCH_SHARE_GPU / AASR_BENCH_BACKEND: RCCL refuses two ranks on one
+    device) -- reaches the end of the default run, secondary measurements included, with every barrier matched, and
+    rank 0 prints the one line with n_gpus = 2.  The line says that it is a rehearsal."""
+    if not _have_device():
+        pytest.skip("no HIP device on this host")
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    e.update({"AASR_BENCH_SHARE_GPU": "1", "AASR_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--utts", "24", "--frames", "40000",
+           "--steps", "2", "--warmup", "1", "--cpu-frames", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=e, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert "NOT a multi-GPU measurement" in d["config"]["rehearsal"]
+    assert "error" not in d["config"]["configs1"] and "error" not in d["config"]["recipe_e2e"]
+    assert d["config"]["recipe_e2e"]["what"].startswith("configs[3] in small: 512 utterances")
