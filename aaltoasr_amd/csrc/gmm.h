@@ -218,7 +218,9 @@ struct ClusterState {
   bool log_merge = false;          // centre values as log2 and k_cluster_merge_log (no common f32 exponent)
   // per-call scratch: pass-wide buffers sized for Fc frames, ll64 for a sub-pass of Fs
   int64_t Fc = 0, Fs = 0;
-  DevBuf<double> ll64;             // [Fs][Cs] centre log-likelihoods
+  DevBuf<double> ll64;             // [Fs][Cs] centre log-likelihoods (ranking keys); on the float-key path: the rows of the frames left to the replay
+  DevBuf<float> key32;             // [Fs][Cs] the keys as floats (k_cluster_select<KPL, float>)
+  DevBuf<int32_t> pend_list;       // [Fs + 1] frames the float selection left open (k_cluster_select_pending); last slot = count
   DevBuf<unsigned long long> maskw;  // [Fc/64][C+1] bit f = frame f takes the exact values
   DevBuf<unsigned long long> maskrow;  // [Fc/64][rows_padded] the same per packed row
   DevBuf<float> cval;              // [Fc][C] 2^(log2e*ll_c + ref) of the centres that stand in

@@ -93,6 +93,19 @@ __device__ __forceinline__ double lin_key(double ll) {
   return AASR_KEY_ZERO + rint(q) * 0x1p-42;  // one ulp of 2000 per quantum: exact for q < 2^41
 }
 
+// The same key as a float, for the selection's fast path (k_cluster_select<KPL, float>): rounding is monotone, so
+// sorting by the float keys orders the centres as the doubles do except inside groups the rounding made equal --
+// and a group of equal keys at the stopping point is what sends a frame to the replay anyway, which then ranks by
+// the doubles.  Normal range: (float)ll == (float)lin_key(ll).  Denormal band: -1900 + log2(q) (q = the likelihood
+// in units of 2^-1074; below every normal key, above the zero key, monotone in q); zero likelihood: the zero key.
+__device__ __forceinline__ float lin_key32(double ll) {
+  if (ll >= -708.39641853226408) return (float)ll;
+  const double k = lin_key(ll);
+  if (!(k > AASR_KEY_ZERO)) return (float)AASR_KEY_ZERO;
+  const double q = (k - AASR_KEY_ZERO) * 0x1p42;   // exact: the integer q
+  return -1900.0f + __log2f((float)q);
+}
+
 // diagnostic switch (aasr_debug_cluster_heap): every frame takes the queue replay
 static int g_force_heap = getenv("AASR_CLUSTER_HEAP") ? atoi(getenv("AASR_CLUSTER_HEAP")) : 0;
 
@@ -235,20 +248,27 @@ __global__ __launch_bounds__(kCentreThreads) void k_cluster_centres_fma(
 // 256 frames per workgroup.  Same keys as k_cluster_centres_fma to ~1e-13 (another summation order).
 constexpr int kMfmaCentreWaves = 8;
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+// Where the keys go: as doubles [frame][Cs] (key32 null, list null); as floats [frame][Cs] (key32 set: the selection's
+// fast path); or -- list mode -- the doubles of the frames tie_list[0 .. count) only, row i for list entry i (the frames
+// the float selection could not settle: k_cluster_select_heap ranks them by the exact keys; a workgroup walks the list
+// in strides, the count is read on the device).  Same arithmetic in all three.
 template <int KS>   // k steps of 4: 4 KS >= 2 dim + 1
 __global__ __launch_bounds__(64 * kMfmaCentreWaves) void k_cluster_centres_mfma(
     const float *__restrict__ frames, int64_t F, int dim, const double *__restrict__ bpack, int tiles,
-    int tiles_per_y, double *__restrict__ ll64, int64_t Cs) {
+    int tiles_per_y, double *__restrict__ ll64, int64_t Cs, float *__restrict__ key32,
+    const int32_t *__restrict__ list, int64_t list_cap) {
   __shared__ __attribute__((aligned(16))) double btile[2][KS * 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i16 = lane & 15, kq = lane >> 4;
-  const int64_t f0 = (int64_t)blockIdx.x * (32 * kMfmaCentreWaves) + wave * 32;
+  if (list) F = min((int64_t)list[list_cap], list_cap);
+  for (int64_t chunk = blockIdx.x; chunk * (32 * kMfmaCentreWaves) < F; chunk += gridDim.x) {
+  const int64_t f0 = chunk * (32 * kMfmaCentreWaves) + wave * 32;
   double a[2][KS];
 #pragma unroll
   for (int nb = 0; nb < 2; nb++) {
     int64_t f = f0 + nb * 16 + i16;
     if (f > F - 1) f = F - 1;
-    const float *xr = frames + f * dim;
+    const float *xr = frames + (list ? (int64_t)list[f] : f) * dim;
 #pragma unroll
     for (int q = 0; q < KS; q++) {
       const int K = 4 * q + kq;
@@ -284,11 +304,17 @@ __global__ __launch_bounds__(64 * kMfmaCentreWaves) void k_cluster_centres_mfma(
     for (int r = 0; r < 4; r++) {
       const int64_t fa = f0 + 4 * r + kq, fb = fa + 16;
       const bool col = (int64_t)t * 16 + i16 < Cs;   // Cs is a multiple of 8: the last tile may be half a tile
-      if (col && fa < F) ll64[fa * Cs + (int64_t)t * 16 + i16] = lin_key(c0[r]);
-      if (col && fb < F) ll64[fb * Cs + (int64_t)t * 16 + i16] = lin_key(c1[r]);
+      if (key32) {
+        if (col && fa < F) key32[fa * Cs + (int64_t)t * 16 + i16] = lin_key32(c0[r]);
+        if (col && fb < F) key32[fb * Cs + (int64_t)t * 16 + i16] = lin_key32(c1[r]);
+      } else {
+        if (col && fa < F) ll64[fa * Cs + (int64_t)t * 16 + i16] = lin_key(c0[r]);
+        if (col && fb < F) ll64[fb * Cs + (int64_t)t * 16 + i16] = lin_key(c1[r]);
+      }
     }
     __syncthreads();
   }
+  }   // chunk
 }
 
 // ----------------------------------------------------------------- select --
@@ -329,6 +355,33 @@ __device__ __forceinline__ double wave_max_f64(double v) {
   v = fmax(v, dpp_f64<0x143, 0xC>(v, v));
   return readlane63_f64(v);
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                               CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_min_f32(float v) {
+  v = fminf(v, dpp_f32<0xB1, 0xF>(v, v));
+  v = fminf(v, dpp_f32<0x4E, 0xF>(v, v));
+  v = fminf(v, dpp_f32<0x141, 0xF>(v, v));
+  v = fminf(v, dpp_f32<0x140, 0xF>(v, v));
+  v = fminf(v, dpp_f32<0x142, 0xA>(v, v));
+  v = fminf(v, dpp_f32<0x143, 0xC>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+  v = fmaxf(v, dpp_f32<0xB1, 0xF>(v, v));
+  v = fmaxf(v, dpp_f32<0x4E, 0xF>(v, v));
+  v = fmaxf(v, dpp_f32<0x141, 0xF>(v, v));
+  v = fmaxf(v, dpp_f32<0x140, 0xF>(v, v));
+  v = fmaxf(v, dpp_f32<0x142, 0xA>(v, v));
+  v = fmaxf(v, dpp_f32<0x143, 0xC>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ double wave_min_key(double v) { return wave_min_f64(v); }
+__device__ __forceinline__ double wave_max_key(double v) { return wave_max_f64(v); }
+__device__ __forceinline__ float wave_min_key(float v) { return wave_min_f32(v); }
+__device__ __forceinline__ float wave_max_key(float v) { return wave_max_f32(v); }
 // wave-wide sum of an int (result in every lane)
 __device__ __forceinline__ int wave_sum_i32(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);
@@ -393,9 +446,93 @@ __device__ __forceinline__ void wave_bit_transpose64(unsigned &lo, unsigned &hi,
 // lane l holds clusters l, 64 + l, ...  (KPL per lane).
 // four waves per SIMD (<= 128 VGPRs): a 250 k-frame sub-pass is 3906 single-wave workgroups, which
 // then fit the chip's 4096 wave slots in one round (with three per SIMD: 1.27 rounds)
-template <int KPL>
+// The stopping point of one frame: the threshold T such that the clusters with key >= T are the ones the reference's
+// priority queue pops until min_clusters and min_gaussians are both met (aku/Distributions.cc:2684-2722) -- a radix
+// selection over the wave: 64 buckets between the candidates' extremes, cluster counts and Gaussian counts per bucket
+// in one 64-bit LDS histogram, the bucket that holds the stopping point becomes the next level's range.  tie: the
+// stopping point lies inside a group of equal keys that is not taken as a whole (the queue's order among equals
+// decides).  v: lane l holds the keys of clusters l, 64 + l, ...; cand: the valid ones; wave-uniform control flow.
+template <int KPL, typename KT>
+__device__ __forceinline__ void select_threshold(const KT (&v)[KPL], unsigned long long cand, const int (&sz)[KPL], int lane,
+                                                 unsigned long long *hist, int need_c, int need_g, KT &T, bool &tie) {
+  for (int level = 0; level < 64; level++) {
+    KT lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < KPL; j++)
+      if ((cand >> j) & 1) {
+        lo = v[j] < lo ? v[j] : lo;
+        hi = v[j] > hi ? v[j] : hi;
+      }
+    lo = wave_min_key(lo);
+    hi = wave_max_key(hi);
+    if (!(hi >= lo)) {  // no candidate left: the request exceeds what is there
+      T = -INFINITY;
+      break;
+    }
+    const KT scale = (KT)64 / (hi - lo);
+    if (!(hi > lo) || !(scale < (sizeof(KT) == 8 ? (KT)1.0e300 : (KT)1.0e37f))) {  // one value left (single centre or ties)
+      int n_tied = 0;
+#pragma unroll
+      for (int j = 0; j < KPL; j++) n_tied += (int)((cand >> j) & 1);
+      n_tied = wave_sum_i32(n_tied);
+      // every pop takes one cluster: with need_c >= n_tied the whole group goes whatever the
+      // order; otherwise the queue's order among equals decides -> replay
+      if (n_tied == 1 || need_c >= n_tied) T = lo;
+      else tie = true;
+      break;
+    }
+    hist[lane] = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < KPL; j++)
+      if ((cand >> j) & 1) {
+        int b = (int)((hi - v[j]) * scale);
+        b = b > 63 ? 63 : b;
+        atomicAdd(&hist[b], (1ull << 32) | (unsigned long long)(unsigned)sz[j]);
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long h = hist[lane];
+    // inclusive prefix over buckets 0..lane; counts and sizes are separate 32-bit fields (no carry between them)
+    const unsigned long long cum =
+        ((unsigned long long)wave_scan_u32((unsigned)(h >> 32)) << 32) | wave_scan_u32((unsigned)h);
+    const long long cumc = (long long)(cum >> 32), cumg = (long long)(cum & 0xffffffffull);
+    const bool sat = (need_c - cumc <= 0) && (need_g - cumg <= 0);
+    const unsigned long long ballot = __ballot(sat);
+    if (ballot == 0ull) {
+      T = -INFINITY;
+      break;
+    }
+    const int B = __ffsll((long long)ballot) - 1;
+    const unsigned long long excl = __shfl(cum - h, B);
+    need_c -= (int)(excl >> 32);
+    need_g -= (int)(excl & 0xffffffffull);
+    // the boundary lies in bucket B: better buckets are taken, worse ones are not
+#pragma unroll
+    for (int j = 0; j < KPL; j++)
+      if ((cand >> j) & 1) {
+        int b = (int)((hi - v[j]) * scale);
+        b = b > 63 ? 63 : b;
+        if (b != B) cand &= ~(1ull << j);
+      }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// what the merge reads for (frame, cluster): 0 / -inf where the members are evaluated exactly, else the centre's
+// likelihood on the track kernels' reference exponent (or as log2: ClusterState::log_merge)
+__device__ __forceinline__ float centre_value(float key, bool use_exact, bool log_vals, double ref) {
+  if (log_vals) return use_exact ? -INFINITY : (float)((double)key * kLog2eD);
+  return use_exact ? 0.0f : exp2f((float)((double)key * kLog2eD + ref));
+}
+
+// KT: the ranking keys as doubles (k_cluster_centres*), or as floats (lin_key32; half the bytes, half the registers,
+// f32 reductions and bucket arithmetic) -- then a frame whose stopping point falls into a group of equal keys goes to
+// the replay even where the doubles would have settled it, and the replay ranks by the doubles.
+template <int KPL, typename KT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cluster_select(
-    const double *__restrict__ ll64, int64_t F, int C, int64_t Cs,
+    const KT *__restrict__ ll64, int64_t F, int C, int64_t Cs,
     const int32_t *__restrict__ csize, int min_clusters, int min_gaussians, double ref,
     unsigned long long *__restrict__ maskw, float *__restrict__ cval,
     int32_t *__restrict__ n_exact, int32_t *__restrict__ tie_list, int64_t tie_cap,
@@ -413,13 +550,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   const int64_t word = blockIdx.x;
   // the next frame's keys are requested while this frame is selected (a frame's loop is one long
   // dependent chain: nothing else hides the load)
-  constexpr bool kPrefetch = KPL <= 16;  // 2 x KPL doubles: beyond 1024 clusters the registers are not there
-  double vn[kPrefetch ? KPL : 1];
+  constexpr bool kPrefetch = KPL * sizeof(KT) <= 16 * sizeof(double);  // 2 x KPL keys: beyond that the registers are not there
+  KT vn[kPrefetch ? KPL : 1];
   if (kPrefetch) {
 #pragma unroll
     for (int j = 0; j < KPL; j++) {
       const int c = j * 64 + lane;
-      vn[j] = (c < C && word * 64 < F) ? ll64[word * 64 * Cs + c] : 0.0;
+      vn[j] = (c < C && word * 64 < F) ? ll64[word * 64 * Cs + c] : (KT)0;
     }
   }
   for (int fi = 0; fi < 64; fi++) {
@@ -430,92 +567,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (lane == 0) bits[fi][j] = 0ull;
       continue;
     }
-    double v[KPL];
+    KT v[KPL];
     unsigned long long cand = 0;
 #pragma unroll
     for (int j = 0; j < KPL; j++) {
       const int c = j * 64 + lane;
       // ranking key (k_cluster_centres): the reference compares exp(ll)
-      const double x = kPrefetch ? vn[kPrefetch ? j : 0] : (c < C ? ll64[f * Cs + c] : 0.0);
+      const KT x = kPrefetch ? vn[kPrefetch ? j : 0] : (c < C ? ll64[f * Cs + c] : (KT)0);
       v[j] = x;
       if (c < C && x == x) cand |= 1ull << j;
     }
     if (kPrefetch && fi + 1 < 64 && f + 1 < F) {
-      const double *row = ll64 + (f + 1) * Cs;
+      const KT *row = ll64 + (f + 1) * Cs;
 #pragma unroll
       for (int j = 0; j < KPL; j++) {
         const int c = j * 64 + lane;
-        vn[kPrefetch ? j : 0] = c < C ? row[c] : 0.0;
+        vn[kPrefetch ? j : 0] = c < C ? row[c] : (KT)0;
       }
     }
     int need_c = min_clusters, need_g = min_gaussians;
-    double T = INFINITY;  // key >= T  <=>  members evaluated exactly
+    KT T = INFINITY;  // key >= T  <=>  members evaluated exactly
     bool tie = false;     // wave-uniform: the boundary lies inside a group of equal keys
-    if ((need_c > 0 || need_g > 0) && !force_heap) {
-      for (int level = 0; level < 64; level++) {
-        double lo = INFINITY, hi = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < KPL; j++)
-          if ((cand >> j) & 1) {
-            lo = fmin(lo, v[j]);
-            hi = fmax(hi, v[j]);
-          }
-        lo = wave_min_f64(lo);
-        hi = wave_max_f64(hi);
-        if (!(hi >= lo)) {  // no candidate left: the request exceeds what is there
-          T = -INFINITY;
-          break;
-        }
-        const double scale = 64.0 / (hi - lo);
-        if (!(hi > lo) || !(scale < 1.0e300)) {  // one value left (single centre or ties)
-          int n_tied = 0;
-#pragma unroll
-          for (int j = 0; j < KPL; j++) n_tied += (int)((cand >> j) & 1);
-          n_tied = wave_sum_i32(n_tied);
-          // every pop takes one cluster: with need_c >= n_tied the whole group goes whatever the
-          // order; otherwise the queue's order among equals decides -> replay
-          if (n_tied == 1 || need_c >= n_tied) T = lo;
-          else tie = true;
-          break;
-        }
-        hist[lane] = 0ull;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int j = 0; j < KPL; j++)
-          if ((cand >> j) & 1) {
-            int b = (int)((hi - v[j]) * scale);
-            b = b > 63 ? 63 : b;
-            atomicAdd(&hist[b], (1ull << 32) | (unsigned long long)(unsigned)sz[j]);
-          }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const unsigned long long h = hist[lane];
-        // inclusive prefix over buckets 0..lane; counts and sizes are separate 32-bit fields (no carry between them)
-        const unsigned long long cum =
-            ((unsigned long long)wave_scan_u32((unsigned)(h >> 32)) << 32) | wave_scan_u32((unsigned)h);
-        const long long cumc = (long long)(cum >> 32), cumg = (long long)(cum & 0xffffffffull);
-        const bool sat = (need_c - cumc <= 0) && (need_g - cumg <= 0);
-        const unsigned long long ballot = __ballot(sat);
-        if (ballot == 0ull) {
-          T = -INFINITY;
-          break;
-        }
-        const int B = __ffsll((long long)ballot) - 1;
-        const unsigned long long excl = __shfl(cum - h, B);
-        need_c -= (int)(excl >> 32);
-        need_g -= (int)(excl & 0xffffffffull);
-        // the boundary lies in bucket B: better buckets are taken, worse ones are not
-#pragma unroll
-        for (int j = 0; j < KPL; j++)
-          if ((cand >> j) & 1) {
-            int b = (int)((hi - v[j]) * scale);
-            b = b > 63 ? 63 : b;
-            if (b != B) cand &= ~(1ull << j);
-          }
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
+    if ((need_c > 0 || need_g > 0) && !force_heap) select_threshold<KPL, KT>(v, cand, sz, lane, hist, need_c, need_g, T, tie);
     if (force_heap) tie = min_clusters > 0 || min_gaussians > 0;
     if (tie && lane == 0) {
       // slot 0 counts; a list that is full (cannot happen: one entry per frame) drops nothing
@@ -534,10 +607,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       const bool use_exact = sel || !(v[j] > AASR_KEY_ZERO);
       const unsigned long long bal = __ballot(valid && use_exact);
       if (lane == 0) bits[fi][j] = bal;
-      // a key below the normal range stands for a likelihood under 2^-1022: 0.0f either way
-      if (valid)
-        cval[f * C + c] = log_vals ? (use_exact ? -INFINITY : (float)(v[j] * kLog2eD))
-                                   : (use_exact ? 0.0f : exp2f((float)(v[j] * kLog2eD + ref)));
+      // a key below the normal range stands for a likelihood under 2^-1022: 0.0f either way.  The value is a
+      // function of the key AS A FLOAT in both instances, so that the replay -- which holds the doubles of the same
+      // arithmetic -- writes the same bits as the float selection
+      if (valid) cval[f * C + c] = centre_value((float)v[j], use_exact, log_vals, ref);
     }
     if (n_exact) {
       exact = wave_sum_i32(exact);
@@ -558,6 +631,87 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     if (c < C) maskw[word * (C + 1) + c] = w;
   }
   if (lane == 0) maskw[word * (C + 1) + C] = ~0ull;  // rows in no cluster: always exact
+}
+
+// Frames the FLOAT selection left open -- a group of equal float keys at the stopping point, which for two centres
+// within a float ulp of each other is an artefact of the rounding (~2e-4 of the frames of configs[1]; sending them
+// to the replay would cost its launch-long 3 ms as soon as one frame is listed).  The selection again on doubles, one
+// wave per listed frame: the keys are computed here (the expanded form of k_cluster_centres_fma), the outputs of the
+// frame rewritten (its mask bits with atomics, as the replay does; the centre values from the float keys, so that they
+// are the same function of the same number on every path).  Groups equal in double as well -- duplicate, empty,
+// underflowing centres -- go on to tie_list and the replay.
+template <int KPL>
+__global__ __launch_bounds__(64) void k_cluster_select_pending(
+    const float *__restrict__ frames, int dim, int dimp, const double *__restrict__ rec_fma,
+    const double *__restrict__ cconst_fma, const float *__restrict__ key32, int C, int64_t Cs,
+    const int32_t *__restrict__ csize, int min_clusters, int min_gaussians, double ref,
+    unsigned long long *__restrict__ maskw, float *__restrict__ cval, int32_t *__restrict__ n_exact,
+    const int32_t *__restrict__ pend_list, int64_t pend_cap, int32_t *__restrict__ tie_list, int64_t tie_cap,
+    int force_heap) {
+  __shared__ unsigned long long hist[64];
+  const bool log_vals = ref != ref;
+  const int lane = threadIdx.x;
+  const int count = (int)min((int64_t)pend_list[pend_cap], pend_cap);
+  if ((int)blockIdx.x >= count) return;
+  int sz[KPL];
+#pragma unroll
+  for (int j = 0; j < KPL; j++) {
+    const int c = j * 64 + lane;
+    sz[j] = c < C ? csize[c] : 0;
+  }
+  for (int i = blockIdx.x; i < count; i += gridDim.x) {
+    const int64_t f = pend_list[i];
+    const float *xr = frames + f * dim;
+    double v[KPL];
+    unsigned long long cand = 0;
+#pragma unroll
+    for (int j = 0; j < KPL; j++) {
+      const int c = j * 64 + lane;
+      v[j] = 0.0;
+      if (c < C) {
+        const double *r = rec_fma + ((size_t)(c / 8) * dimp) * 16 + 2 * (size_t)(c % 8);
+        double acc = 0.0;
+        for (int d = 0; d < dim; d++) {
+          const double x = (double)xr[d];
+          acc = __builtin_fma(x, __builtin_fma(r[(size_t)d * 16 + 1], x, r[(size_t)d * 16]), acc);
+        }
+        v[j] = lin_key(acc + cconst_fma[c]);
+        if (v[j] == v[j]) cand |= 1ull << j;
+      }
+    }
+    int need_c = min_clusters, need_g = min_gaussians;
+    double T = INFINITY;
+    bool tie = false;
+    if ((need_c > 0 || need_g > 0) && !force_heap) select_threshold<KPL, double>(v, cand, sz, lane, hist, need_c, need_g, T, tie);
+    if (force_heap) tie = min_clusters > 0 || min_gaussians > 0;
+    if (tie) {   // wave-uniform
+      if (lane == 0) {
+        const int at = atomicAdd(&tie_list[tie_cap], 1);
+        if (at < tie_cap) tie_list[at] = (int32_t)f;
+      }
+      continue;
+    }
+    const int64_t word = f >> 6;
+    const unsigned long long bit = 1ull << (f & 63);
+    int exact = 0;
+#pragma unroll
+    for (int j = 0; j < KPL; j++) {
+      const int c = j * 64 + lane;
+      if (c < C) {
+        const bool sel = v[j] >= T;
+        exact += sel ? 1 : 0;
+        const bool use_exact = sel || !(v[j] > AASR_KEY_ZERO);
+        unsigned long long *w = maskw + word * (C + 1) + c;
+        if (use_exact) atomicOr(w, bit);
+        else atomicAnd(w, ~bit);
+        cval[f * C + c] = centre_value(key32[f * Cs + c], use_exact, log_vals, ref);
+      }
+    }
+    if (n_exact) {
+      exact = wave_sum_i32(exact);
+      if (lane == 0) n_exact[f] = exact;
+    }
+  }
 }
 
 // ------------------------------------------------------------ heap replay --
@@ -586,7 +740,7 @@ __global__ __launch_bounds__(64) void k_cluster_select_heap(
     const double *__restrict__ ll64, int C, int64_t Cs, const int32_t *__restrict__ csize,
     int min_clusters, int min_gaussians, double ref, unsigned long long *__restrict__ maskw,
     float *__restrict__ cval, int32_t *__restrict__ n_exact, const int32_t *__restrict__ tie_list,
-    int64_t tie_cap, double *__restrict__ heap_key, int32_t *__restrict__ heap_idx) {
+    int64_t tie_cap, double *__restrict__ heap_key, int32_t *__restrict__ heap_idx, int rows_by_position) {
   const int tid = blockIdx.x * 64 + threadIdx.x;
   const int64_t st = kHeapThreads;
   const bool log_vals = ref != ref;
@@ -595,7 +749,8 @@ __global__ __launch_bounds__(64) void k_cluster_select_heap(
   int32_t *idx = heap_idx + tid;
   for (int i = tid; i < count; i += kHeapThreads) {
     const int64_t f = tie_list[i];
-    const double *row = ll64 + f * Cs;
+    // the float selection's leftovers: row i of the list-mode centre pass holds the doubles of list entry i
+    const double *row = ll64 + (rows_by_position ? (int64_t)i : f) * Cs;
     for (int c = 0; c < C; c++) {
       heap_push(key, idx, st, c, 0, row[c], c);
     }
@@ -637,8 +792,7 @@ __global__ __launch_bounds__(64) void k_cluster_select_heap(
       unsigned long long *w = maskw + word * (C + 1) + c;
       if (use_exact) atomicOr(w, bit);
       else atomicAnd(w, ~bit);
-      cval[f * C + c] = log_vals ? (use_exact ? -INFINITY : (float)(key[p * st] * kLog2eD))
-                                 : (use_exact ? 0.0f : exp2f((float)(key[p * st] * kLog2eD + ref)));
+      cval[f * C + c] = centre_value((float)key[p * st], use_exact, log_vals, ref);
     }
   }
 }
@@ -1036,8 +1190,9 @@ void gmm_set_clustering_min_evals(aasr_gmm *g, double min_clusters, double min_g
   cl.enabled = true;
 }
 
+// keys: 0 doubles per frame, 1 floats per frame (cl.key32), 2 list mode (the frames of cl.tie_list, doubles by position)
 template <int KS>
-static void launch_centres_mfma_t(aasr_gmm *g, const float *d_frames, int64_t F, hipStream_t stream) {
+static void launch_centres_mfma_t(aasr_gmm *g, const float *d_frames, int64_t F, hipStream_t stream, int keys) {
   ClusterState &cl = g->cl;
   const int tiles = (int)((cl.Cs + 15) / 16);
   const int64_t bx = (F + 32 * kMfmaCentreWaves - 1) / (32 * kMfmaCentreWaves);
@@ -1058,16 +1213,25 @@ static void launch_centres_mfma_t(aasr_gmm *g, const float *d_frames, int64_t F,
   }
   const int tpy = (tiles + ny - 1) / ny;
   ny = (tiles + tpy - 1) / tpy;
-  hipLaunchKernelGGL(k_cluster_centres_mfma<KS>, dim3((unsigned)bx, (unsigned)ny), dim3(64 * kMfmaCentreWaves), 0, stream,
-                     d_frames, F, g->dim, cl.bpack.p, tiles, tpy, cl.ll64.p, (int64_t)cl.Cs);
+  if (keys == 2) {
+    // normally an empty list: few workgroups, each walking the list in strides of the grid
+    const int64_t gx = std::min<int64_t>(bx, std::max<int64_t>(1, (int64_t)slots / ny));
+    hipLaunchKernelGGL(k_cluster_centres_mfma<KS>, dim3((unsigned)gx, (unsigned)ny), dim3(64 * kMfmaCentreWaves), 0,
+                       stream, d_frames, F, g->dim, cl.bpack.p, tiles, tpy, cl.ll64.p, (int64_t)cl.Cs, (float *)nullptr,
+                       cl.tie_list.p, (int64_t)cl.Fs);
+  } else {
+    hipLaunchKernelGGL(k_cluster_centres_mfma<KS>, dim3((unsigned)bx, (unsigned)ny), dim3(64 * kMfmaCentreWaves), 0,
+                       stream, d_frames, F, g->dim, cl.bpack.p, tiles, tpy, cl.ll64.p, (int64_t)cl.Cs,
+                       keys == 1 ? cl.key32.p : (float *)nullptr, (const int32_t *)nullptr, (int64_t)0);
+  }
   AASR_HIP(hipGetLastError());
 }
 
-static bool launch_centres_mfma(aasr_gmm *g, const float *d_frames, int64_t F, hipStream_t stream) {
+static bool launch_centres_mfma(aasr_gmm *g, const float *d_frames, int64_t F, hipStream_t stream, int keys = 0) {
   switch (g->cl.mfma_ks) {
 #define AASR_CASE(N)                                        \
   case N:                                                   \
-    launch_centres_mfma_t<N>(g, d_frames, F, stream);       \
+    launch_centres_mfma_t<N>(g, d_frames, F, stream, keys); \
     return true;
     // k steps of 4 covering K = 2 dim + 1: every dimension up to 63
     AASR_CASE(1) AASR_CASE(2) AASR_CASE(3) AASR_CASE(4) AASR_CASE(5) AASR_CASE(6) AASR_CASE(7) AASR_CASE(8)
@@ -1139,23 +1303,40 @@ static void launch_centres(aasr_gmm *g, const XT *d_frames, int64_t F, hipStream
 
 // sub-pass [s0, s0 + F) of the current pass: masks, centre values and counts land at
 // their place in the pass-wide buffers (s0 is a multiple of 64)
+// d_tie_frames: the float-key fast path -- the frames of this sub-pass, so that the leftovers' exact keys can be
+// computed (list-mode centre pass) before the replay; null: the keys are doubles in cl.ll64, one row per frame
 template <int KPL>
-static void launch_select_t(aasr_gmm *g, int64_t s0, int64_t F, hipStream_t stream) {
+static void launch_select_t(aasr_gmm *g, int64_t s0, int64_t F, hipStream_t stream, const float *d_tie_frames) {
   ClusterState &cl = g->cl;
   const int64_t words = (F + 63) / 64;
   const int force_heap = g_force_heap;
   const double ref_arg = cl.log_merge ? (double)NAN : cl.ref_log2;
   AASR_HIP(hipMemsetAsync(cl.tie_list.p + cl.Fs, 0, sizeof(int32_t), stream));
-  hipLaunchKernelGGL(k_cluster_select<KPL>, dim3((unsigned)words), dim3(64), 0, stream, cl.ll64.p, F,
-                     cl.C, (int64_t)cl.Cs, cl.csize.p, cl.min_clusters, cl.min_gaussians, ref_arg,
-                     cl.maskw.p + (size_t)(s0 / 64) * (cl.C + 1), cl.cval.p + (size_t)s0 * cl.C,
-                     cl.n_exact.p + s0, cl.tie_list.p, cl.Fs, force_heap);
-  AASR_HIP(hipGetLastError());
+  if (d_tie_frames) {
+    AASR_HIP(hipMemsetAsync(cl.pend_list.p + cl.Fs, 0, sizeof(int32_t), stream));
+    hipLaunchKernelGGL((k_cluster_select<KPL, float>), dim3((unsigned)words), dim3(64), 0, stream, cl.key32.p, F,
+                       cl.C, (int64_t)cl.Cs, cl.csize.p, cl.min_clusters, cl.min_gaussians, ref_arg,
+                       cl.maskw.p + (size_t)(s0 / 64) * (cl.C + 1), cl.cval.p + (size_t)s0 * cl.C,
+                       cl.n_exact.p + s0, cl.pend_list.p, cl.Fs, force_heap);
+    AASR_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_cluster_select_pending<KPL>, dim3(256), dim3(64), 0, stream, d_tie_frames, g->dim, cl.dimp,
+                       cl.rec_fma.p, cl.cconst_fma.p, cl.key32.p, cl.C, (int64_t)cl.Cs, cl.csize.p, cl.min_clusters,
+                       cl.min_gaussians, ref_arg, cl.maskw.p + (size_t)(s0 / 64) * (cl.C + 1), cl.cval.p + (size_t)s0 * cl.C,
+                       cl.n_exact.p + s0, cl.pend_list.p, (int64_t)cl.Fs, cl.tie_list.p, (int64_t)cl.Fs, force_heap);
+    AASR_HIP(hipGetLastError());
+    if (!launch_centres_mfma(g, d_tie_frames, F, stream, 2)) raise(AASR_ERR_UNSUPPORTED, "no matrix centre kernel");
+  } else {
+    hipLaunchKernelGGL((k_cluster_select<KPL, double>), dim3((unsigned)words), dim3(64), 0, stream, cl.ll64.p, F,
+                       cl.C, (int64_t)cl.Cs, cl.csize.p, cl.min_clusters, cl.min_gaussians, ref_arg,
+                       cl.maskw.p + (size_t)(s0 / 64) * (cl.C + 1), cl.cval.p + (size_t)s0 * cl.C,
+                       cl.n_exact.p + s0, cl.tie_list.p, cl.Fs, force_heap);
+    AASR_HIP(hipGetLastError());
+  }
   // frames left to the queue replay (normally none: the kernel's threads find an empty list)
   hipLaunchKernelGGL(k_cluster_select_heap, dim3(kHeapThreads / 64), dim3(64), 0, stream, cl.ll64.p, cl.C,
                      (int64_t)cl.Cs, cl.csize.p, cl.min_clusters, cl.min_gaussians, ref_arg,
                      cl.maskw.p + (size_t)(s0 / 64) * (cl.C + 1), cl.cval.p + (size_t)s0 * cl.C,
-                     cl.n_exact.p + s0, cl.tie_list.p, cl.Fs, cl.heap_key.p, cl.heap_idx.p);
+                     cl.n_exact.p + s0, cl.tie_list.p, cl.Fs, cl.heap_key.p, cl.heap_idx.p, d_tie_frames ? 1 : 0);
   AASR_HIP(hipGetLastError());
 }
 
@@ -1181,20 +1362,31 @@ static void launch_select_replay(aasr_gmm *g, int64_t s0, int64_t F, hipStream_t
   hipLaunchKernelGGL(k_cluster_select_heap, dim3(kHeapThreads / 64), dim3(64), 0, stream, cl.ll64.p, cl.C,
                      (int64_t)cl.Cs, cl.csize.p, cl.min_clusters, cl.min_gaussians, ref_arg,
                      cl.maskw.p + (size_t)(s0 / 64) * (cl.C + 1), cl.cval.p + (size_t)s0 * cl.C,
-                     cl.n_exact.p + s0, cl.tie_list.p, cl.Fs, cl.heap_key.p, cl.heap_idx.p);
+                     cl.n_exact.p + s0, cl.tie_list.p, cl.Fs, cl.heap_key.p, cl.heap_idx.p, 0);
   AASR_HIP(hipGetLastError());
 }
 
-static void launch_select(aasr_gmm *g, int64_t s0, int64_t F, hipStream_t stream) {
+static void launch_select(aasr_gmm *g, int64_t s0, int64_t F, hipStream_t stream, const float *d_tie_frames = nullptr) {
   const int kpl = (g->cl.C + 63) / 64;
   if (kpl > 64) {
     launch_select_replay(g, s0, F, stream);
     return;
   }
-  if (kpl <= 4) launch_select_t<4>(g, s0, F, stream);
-  else if (kpl <= 16) launch_select_t<16>(g, s0, F, stream);
-  else if (kpl <= 32) launch_select_t<32>(g, s0, F, stream);
-  else launch_select_t<64>(g, s0, F, stream);
+  if (kpl <= 4) launch_select_t<4>(g, s0, F, stream, d_tie_frames);
+  else if (kpl <= 16) launch_select_t<16>(g, s0, F, stream, d_tie_frames);
+  else if (kpl <= 32) launch_select_t<32>(g, s0, F, stream, d_tie_frames);
+  else launch_select_t<64>(g, s0, F, stream, d_tie_frames);
+}
+
+// The float-key fast path of a sub-pass: float frames, a matrix centre kernel for the dimension, at most 64 x 64
+// clusters (AASR_CLUSTER_KEYS64=1 keeps the doubles throughout).
+static bool cluster_fast_keys(const aasr_gmm *g) {
+  static const int keys64 = getenv("AASR_CLUSTER_KEYS64") ? atoi(getenv("AASR_CLUSTER_KEYS64")) : 0;
+  static const int ref_order = getenv("AASR_CLUSTER_CENTRES_REF") ? atoi(getenv("AASR_CLUSTER_CENTRES_REF")) : 0;
+  static const int use_mfma = getenv("AASR_CLUSTER_CENTRES_MFMA") ? atoi(getenv("AASR_CLUSTER_CENTRES_MFMA")) : 1;
+  const ClusterState &cl = g->cl;
+  return !keys64 && !ref_order && use_mfma && cl.bpack.p && cl.rec_fma.p && cl.mfma_ks >= 1 && cl.mfma_ks <= 32 &&
+         (cl.C + 63) / 64 <= 64;
 }
 
 // The merge in the log domain (ClusterState::log_merge): out = ln(e^out + sum_j w_j 2^cvl[c_j]) with a
@@ -1429,6 +1621,10 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
   if (fb > cl.Fc || (size_t)fs * cl.Cs > cl.ll64.n) {
     fb = std::max(fb, cl.Fc);
     cl.ll64.alloc((size_t)fs * cl.Cs);
+    if (cluster_fast_keys(g)) {
+      cl.key32.alloc((size_t)fs * cl.Cs);
+      cl.pend_list.alloc((size_t)fs + 1);
+    }
     cl.cval.alloc((size_t)fb * cl.C);
     cl.maskw.alloc((size_t)(fb / 64) * (cl.C + 1));
     cl.n_exact.alloc((size_t)fb);
@@ -1445,8 +1641,13 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
     float *out = d_out + f0 * pitch;
     for (int64_t s0 = 0; s0 < n; s0 += cl.Fs) {
       const int64_t ns = std::min<int64_t>(cl.Fs, n - s0);
-      launch_centres(g, fr + s0 * g->dim, ns, stream);
-      launch_select(g, s0, ns, stream);
+      if (cluster_fast_keys(g) && cl.key32.n >= (size_t)ns * cl.Cs) {
+        launch_centres_mfma(g, fr + s0 * g->dim, ns, stream, 1);
+        launch_select(g, s0, ns, stream, fr + s0 * g->dim);
+      } else {
+        launch_centres(g, fr + s0 * g->dim, ns, stream);
+        launch_select(g, s0, ns, stream);
+      }
     }
     if (classes)
       gmm_classes_exact_launch(g, fr, n, out, [&](aasr_gmm *sub, size_t c, const float *xf, float *part) {

@@ -53,4 +53,4 @@ for prec in PRECS:
         g.set_clustering_min_evals(minc, ming)
         run("clustered %s C=%d ming=%.2f" % (NAMES[prec], C, ming))
         n = g.cluster_exact_counts(1000)
-        print("   clusters evaluated exactly per frame: mean %.1f" % n.mean())
+        print("   clusters evaluated exactly per frame: mean %.1f; frames left to the queue replay in the last sub-pass: %d" % (n.mean(), g.cluster_tie_frames()))
