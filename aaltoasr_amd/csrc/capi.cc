@@ -250,8 +250,10 @@ int aasr_gmm_effective_precision(const aasr_gmm *h) {
   if (!h) return -1;
   if (h->precision != AASR_PREC_F16X2 && h->precision != AASR_PREC_BF16X3) return h->precision;
   if (!h->dim_parts.empty()) return AASR_PREC_F32;   // parts are scored per Gaussian by the f32 pool kernels
-  // what the diagonal matrix path runs: the centred / general forms and the factor-row kernels have no f16x2 form
-  if (h->ill_conditioned || h->host.factor_path()) return h->host.factor_path() ? AASR_PREC_BF16X3 : AASR_PREC_F32_CENTRED;
+  // what the matrix path runs: the centred / general forms have no f16x2 form
+  if (h->host.factor_path())   // the factor-row kernels: three bf16 terms, or two fp16 terms where the pool qualifies
+    return (h->precision == AASR_PREC_F16X2 && h->full.a16h.p) ? AASR_PREC_F16X2 : AASR_PREC_BF16X3;
+  if (h->ill_conditioned) return AASR_PREC_F32_CENTRED;
   const aasr::TrackLayout &L = h->paired.ok ? h->paired : h->tracks;
   if (!L.ok || !L.a16.p) return AASR_PREC_F32;
   return (h->precision == AASR_PREC_F16X2 && L.a16h.p) ? AASR_PREC_F16X2 : AASR_PREC_BF16X3;

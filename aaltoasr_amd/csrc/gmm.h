@@ -163,6 +163,11 @@ struct TrackLayout {
 // ceil(dim/4) consecutive quads of one track with the rows of
 // sqrt(log2e/2) * R^-1 (Sigma = R R^T), so that the accumulator holds
 // y = R^-1 (x - mu) and the quadratic form is a sum of squares.
+// Two-term fp16 form of the factor rows: worst visible state error ~3.7e-5 at kappa = 2 400 and 9.8e-5 at 24 000
+// (host emulation, tools/exp_fullcov_f16.py), the three-term form ~2x below it.
+#define FULL_KAPPA_LIMIT_F16 1500.0
+constexpr float kFullF16Clamp = 30000.0f;   // |x - pivot| beyond this is clamped in the f16x2 factor-row kernel
+
 struct FullLayout {
   bool ok = false;
   PackedRows rows;
@@ -178,6 +183,11 @@ struct FullLayout {
   // [tile][K/16 slabs][3 splits][2 row blocks][64 lanes][8 bf16], K index = column
   DevBuf<uint16_t> a16;
   int nk16 = 0;
+  // ... and as two fp16 terms (AASR_PREC_F16X2; [tile][slab][2 splits][2 row blocks][64 lanes][8 fp16]): packed only
+  // where the pool's conditioning estimate kappa = max_g |R^-1 (mu - pivot)|^2 (in the rows' log2 scaling) is below
+  // FULL_KAPPA_LIMIT_F16 and every coefficient is inside the fp16 range
+  DevBuf<uint16_t> a16h;
+  double kappa = 0.0;
   std::vector<int32_t> row_gauss;   // host: pool Gaussian of every packed row, -1 = unused row (Gaussian clustering)
   int64_t rows_padded = 0;
   // per tile and track, by quad position: constant of the component / index of the state that

@@ -1442,6 +1442,57 @@ void gmm_build_fullcov(aasr_gmm *g) {
       }
       L.a16.upload(a.data(), a.size());
       L.nk16 = nk16;
+      // two-term fp16 split (AASR_PREC_F16X2), where the pool qualifies: conditioning estimate below the limit, every
+      // coefficient inside the fp16 range, and every coordinate weighs enough in some row of every Gaussian that a
+      // frame clamped to +-kFullF16Clamp there is far below the floor (|y| >= 64: q >= 4096 in log2 units)
+      L.a16h = DevBuf<uint16_t>();
+      static const bool f16_env = !(getenv("AASR_F16X2") && atoi(getenv("AASR_F16X2")) == 0);
+      std::vector<double> kap((size_t)m.G, 0.0), colmax((size_t)m.G * D, 0.0);
+      double amax = 0;
+      for (int64_t r = 0; r < tiles * TILE_ROWS; r++) {
+        const int32_t gi = r < (int64_t)L.row_gauss.size() ? L.row_gauss[(size_t)r] : -1;
+        for (int k = 0; k <= D; k++) amax = std::max(amax, std::fabs(coef[(size_t)r * K2 + k]));
+        if (gi < 0) continue;
+        const double b = coef[(size_t)r * K2 + D];
+        kap[(size_t)gi] += b * b;
+        for (int k = 0; k < D; k++)
+          colmax[(size_t)gi * D + k] = std::max(colmax[(size_t)gi * D + k], std::fabs(coef[(size_t)r * K2 + k]));
+      }
+      L.kappa = 0;
+      bool heavy = true;
+      std::vector<char> seen((size_t)m.G, 0);
+      for (int32_t gi : L.row_gauss)
+        if (gi >= 0) seen[(size_t)gi] = 1;
+      for (int64_t gi = 0; gi < m.G; gi++) {
+        if (!seen[(size_t)gi]) continue;
+        L.kappa = std::max(L.kappa, kap[(size_t)gi]);
+        bool all_zero = true;   // the reference's "invalid" Gaussian: zero rows, constant 0
+        for (int k = 0; k < D; k++) all_zero = all_zero && colmax[(size_t)gi * D + k] == 0.0;
+        if (all_zero) continue;
+        for (int k = 0; k < D; k++) heavy = heavy && colmax[(size_t)gi * D + k] * (double)kFullF16Clamp >= 64.0;
+      }
+      if (f16_env && L.kappa <= FULL_KAPPA_LIMIT_F16 && amax < 60000.0 && heavy) {
+        const size_t tile_h = (size_t)nk16 * 2 * 2 * 64 * 8;
+        std::vector<uint16_t> ah((size_t)tiles * tile_h, 0);
+        for (int64_t r = 0; r < tiles * TILE_ROWS; r++) {
+          const int64_t t = r / TILE_ROWS;
+          const int jrow = (int)(r % TILE_ROWS);
+          const int mb = jrow / 32, m32 = jrow % 32;
+          for (int k = 0; k <= D; k++) {
+            const double x = coef[(size_t)r * K2 + k];   // split on the host in double
+            const _Float16 hi = (_Float16)x;
+            const _Float16 lo = (_Float16)(x - (double)hi);
+            uint16_t hs[2];
+            memcpy(&hs[0], &hi, 2);
+            memcpy(&hs[1], &lo, 2);
+            const int slab = k / 16, hk = (k % 16) / 8, i = k % 8;
+            const int lane = hk * 32 + m32;
+            for (int sp = 0; sp < 2; sp++)
+              ah[(size_t)t * tile_h + ((((size_t)slab * 2 + sp) * 2 + mb) * 64 + lane) * 8 + i] = hs[sp];
+          }
+        }
+        L.a16h.upload(ah.data(), ah.size());
+      }
     }
   }
   L.ok = true;

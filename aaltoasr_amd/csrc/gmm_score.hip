@@ -1691,14 +1691,17 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score(
 // copy through inline assembly, close bits requested mid-stream one tile ahead).
 // K = dim + 1 padded to a multiple of 16, K index = column of R^-1 | bias.
 // ---------------------------------------------------------------------------
-template <int NK16>
+// NS = 2 (AASR_PREC_F16X2): rows and frames as two fp16 terms, three products per slab -- half the matrix
+// instructions.  State-level error ~2x the three-term form's at the same conditioning (tools/exp_fullcov_f16.py), so
+// a pool takes it only below FULL_KAPPA_LIMIT_F16 (gmm.h); the frame operand is clamped to +-kFullF16Clamp.
+template <int NK16, int NS>
 __global__ __launch_bounds__(256, 2) void k_gmm_full_score_bf16x3(
     const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
     const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
     const uint32_t *__restrict__ close_mask, const float *__restrict__ gc_tile,
     const int32_t *__restrict__ sid_tile, float *__restrict__ out, int64_t S, float ref_ln) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr int kTileFloats = NK16 * 3 * 2 * 64 * 16 / 4;
+  constexpr int kTileFloats = NK16 * NS * 2 * 64 * 16 / 4;
   float *abuf0 = (float *)smem_raw;
   float *abuf1 = abuf0 + kTileFloats;
   const int tid = threadIdx.x;
@@ -1709,7 +1712,7 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score_bf16x3(
   const int64_t f0 = (int64_t)blockIdx.x * FRAMES_PER_BLOCK + wave * FRAMES_PER_WAVE;
 
   // frame operand: lane (n, h) holds k = 16*j + 8*h + i, i < 8: x'_k (k < dim), 1 (k == dim), 0 beyond
-  u32x4 bq[NK16][3][2];
+  u32x4 bq[NK16][NS][2];
 #pragma unroll
   for (int nb = 0; nb < 2; nb++) {
     int64_t f = f0 + nb * 32 + n;
@@ -1723,16 +1726,20 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score_bf16x3(
         const int k = 16 * j + 8 * h + i;
         const int kc = k < dim ? k : 0;
         float val = xr[kc] - pivot[kc];
+        if (NS == 2) val = fminf(fmaxf(val, -kFullF16Clamp), kFullF16Clamp);   // fp16 range
         if (k == dim) val = 1.0f;
         if (k > dim) val = 0.0f;
         v[i] = val;
       }
       unsigned w1[4], w2[4], w3[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) split3_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i], w3[i]);
+      for (int i = 0; i < 4; i++) {
+        if constexpr (NS == 3) split3_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i], w3[i]);
+        else split2_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i]);
+      }
       bq[j][0][nb] = u32x4{w1[0], w1[1], w1[2], w1[3]};
       bq[j][1][nb] = u32x4{w2[0], w2[1], w2[2], w2[3]};
-      bq[j][2][nb] = u32x4{w3[0], w3[1], w3[2], w3[3]};
+      if constexpr (NS == 3) bq[j][2][nb] = u32x4{w3[0], w3[1], w3[2], w3[3]};
     }
   }
 
@@ -1755,10 +1762,10 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score_bf16x3(
 
   unsigned m32_next = t_begin < t_end ? (unsigned)__builtin_amdgcn_readfirstlane((int)close_mask[t_begin]) : 0u;
   unsigned mask_v = 0;
-  u32x4 afr[3][2];
+  u32x4 afr[NS][2];
   if (t_begin < t_end) {
 #pragma unroll
-    for (int sp = 2; sp >= 0; sp--) {
+    for (int sp = NS - 1; sp >= 0; sp--) {
       afr[sp][0] = ((const u32x4 *)abuf0 + lane)[(sp * 2 + 0) * 64];
       afr[sp][1] = ((const u32x4 *)abuf0 + lane)[(sp * 2 + 1) * 64];
     }
@@ -1783,26 +1790,22 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score_bf16x3(
 #pragma unroll
     for (int j = 0; j < NK16; j++) {
 #pragma unroll
-      for (int grp = 0; grp < 3; grp++) {
-        const int sp = 2 - grp;     // a3 | a2 | a1
-        const int nprod = grp + 1;  // b1 | b2 b1 | b3 b2 b1
+      for (int grp = 0; grp < NS; grp++) {
+        const int sp = NS - 1 - grp;  // a3 | a2 | a1
+        const int nprod = grp + 1;    // b1 | b2 b1 | b3 b2 b1
 #pragma unroll
         for (int c = 0; c < nprod; c++) {
           const int sb = nprod - 1 - c;
-          const bf16x8 a_m0 = __builtin_bit_cast(bf16x8, afr[sp][0]);
-          const bf16x8 a_m1 = __builtin_bit_cast(bf16x8, afr[sp][1]);
-          const bf16x8 b_n0 = __builtin_bit_cast(bf16x8, bq[j][sb][0]);
-          const bf16x8 b_n1 = __builtin_bit_cast(bf16x8, bq[j][sb][1]);
-          c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m0, b_n0, c00, 0, 0, 0);
-          c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m0, b_n1, c01, 0, 0, 0);
-          c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m1, b_n0, c10, 0, 0, 0);
-          c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m1, b_n1, c11, 0, 0, 0);
+          c00 = mfma_split<NS>(afr[sp][0], bq[j][sb][0], c00);
+          c01 = mfma_split<NS>(afr[sp][0], bq[j][sb][1], c01);
+          c10 = mfma_split<NS>(afr[sp][1], bq[j][sb][0], c10);
+          c11 = mfma_split<NS>(afr[sp][1], bq[j][sb][1], c11);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (j == 0 && grp == 0) mask_v = close_mask[t + 1];  // the array has one spare element
         if (j + 1 < NK16) {
-          afr[sp][0] = afrag[(((j + 1) * 3 + sp) * 2 + 0) * 64];
-          afr[sp][1] = afrag[(((j + 1) * 3 + sp) * 2 + 1) * 64];
+          afr[sp][0] = afrag[(((j + 1) * NS + sp) * 2 + 0) * 64];
+          afr[sp][1] = afrag[(((j + 1) * NS + sp) * 2 + 1) * 64];
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -1813,7 +1816,7 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score_bf16x3(
     if (t + 1 < t_end) {
       const u32x4 *nfrag = (const u32x4 *)anext + lane;
 #pragma unroll
-      for (int sp = 2; sp >= 0; sp--) {
+      for (int sp = NS - 1; sp >= 0; sp--) {
         afr[sp][0] = nfrag[(sp * 2 + 0) * 64];
         afr[sp][1] = nfrag[(sp * 2 + 1) * 64];
       }
@@ -1852,12 +1855,12 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score_bf16x3(
   }
 }
 
-template <int NK16>
+template <int NK16, int NS = 3>
 static void launch_full_bf16_t(const aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                                hipStream_t stream) {
   const FullLayout &L = g->full;
   const int64_t blocks = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
-  const int smem = 2 * NK16 * 3 * 2 * 64 * 16;
+  const int smem = 2 * NK16 * NS * 2 * 64 * 16;
   const double slots = 2.0 * (g->num_cus > 0 ? g->num_cus : 256);
   int R = 1;
   double best_eff = 0;
@@ -1871,9 +1874,9 @@ static void launch_full_bf16_t(const aasr_gmm *g, const float *d_frames, int64_t
     }
   }
   const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 8;
-  hipLaunchKernelGGL(k_gmm_full_score_bf16x3<NK16>, dim3((unsigned)blocks, (unsigned)R), dim3(256), smem,
-                     stream, d_frames, F, g->dim, g->d_pivot.p, L.a16.p, split_row, L.close.p, L.gc_tile.p,
-                     L.sid_tile.p, d_out, g->S, L.ref_ln);
+  hipLaunchKernelGGL((k_gmm_full_score_bf16x3<NK16, NS>), dim3((unsigned)blocks, (unsigned)R), dim3(256), smem,
+                     stream, d_frames, F, g->dim, g->d_pivot.p, NS == 2 ? L.a16h.p : L.a16.p, split_row, L.close.p,
+                     L.gc_tile.p, L.sid_tile.p, d_out, g->S, L.ref_ln);
   AASR_HIP(hipGetLastError());
 }
 
@@ -1905,6 +1908,15 @@ static void launch_full_t(const aasr_gmm *g, const float *d_frames, int64_t F, f
 void gmm_full_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                      hipStream_t stream) {
   if (!g->full.ok) raise(AASR_ERR_UNSUPPORTED, "full-covariance layout was not built for this model");
+  if (g->use_bf16x3 && g->precision == AASR_PREC_F16X2 && g->full.a16h.p) {
+    switch (g->full.nk16) {
+      case 1: launch_full_bf16_t<1, 2>(g, d_frames, F, d_out, stream); return;
+      case 2: launch_full_bf16_t<2, 2>(g, d_frames, F, d_out, stream); return;
+      case 3: launch_full_bf16_t<3, 2>(g, d_frames, F, d_out, stream); return;
+      case 4: launch_full_bf16_t<4, 2>(g, d_frames, F, d_out, stream); return;
+      default: break;
+    }
+  }
   if (g->use_bf16x3 && g->full.a16.p) {
     switch (g->full.nk16) {
       case 1: launch_full_bf16_t<1>(g, d_frames, F, d_out, stream); return;

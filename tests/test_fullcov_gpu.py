@@ -24,12 +24,16 @@ def _full_model(D, G, S, comps, seed, tied=False):
 
 
 def _score_both(g, frames):
-    """f32 matrix kernel, then the same rows on the bf16 pipe (three-term split)."""
+    """f32 matrix kernel, then the same rows on the bf16 pipe (three-term split), then AASR_PREC_F16X2 (two fp16
+    terms where the pool's conditioning allows it, else the three-term rows again)."""
+    g.set_precision(0)
     a = g.score(frames)
     g.set_precision(3)
     b = g.score(frames)
+    g.set_precision(4)
+    c = g.score(frames)
     g.set_precision(0)
-    return a, b
+    return a, b, c
 
 
 @pytest.mark.parametrize("D,G,S,comps,F", [(8, 64, 8, 8, 70), (13, 48, 12, 4, 130), (15, 40, 5, 8, 64),
@@ -144,4 +148,36 @@ def test_clustering_over_a_full_covariance_pool(capi, oracle, D, G, S, comps, C,
         assert_ll(got, want, "clustered full covariance, precision %d" % prec)
     if minc == 1.0:   # everything exact: the unclustered scores
         assert_ll(g.score(frames), om.score(frames.astype(np.float64)), "all clusters exact")
+    g.close()
+
+
+def test_f16x2_factor_rows_are_chosen_by_conditioning_and_clamp_far_frames(capi, oracle):
+    """AASR_PREC_F16X2 on a full-covariance pool: two fp16 terms per operand where the pool's conditioning estimate is
+    below FULL_KAPPA_LIMIT_F16 (aasr_gmm_effective_precision says which form runs), the three-term rows otherwise;
+    a frame beyond the fp16 clamp is at the floor either way."""
+    rng = np.random.default_rng(99)
+    D, G, S = 24, 300, 30
+    mean = rng.standard_normal((G, D))
+    a = rng.standard_normal((G, D, D)) * 0.3
+    cov = a @ a.transpose(0, 2, 1) + 0.15 * np.eye(D)
+    _, _, off, idx, w = synth.make_model(D=D, G=G, S=S, comps=10, seed=4)
+    frames = synth.make_frames(400, D=D, seed=5)
+    frames[:40] = (mean[:40] + 0.3 * rng.standard_normal((40, D))).astype(np.float32)
+    frames[100] = 9.0e4                      # beyond the clamp: the 1e-50 floor
+    frames[101, 3] = -4.0e4
+    want = oracle.FullModel(mean, cov, off, idx, w).score(frames.astype(np.float64))
+    assert (want[100] == want[100].min()).all() and want[100, 0] < -115.0
+    g = capi.Gmm.from_full(mean, cov, off, idx, w)
+    g.set_precision(4)
+    assert g.effective_precision() == 4
+    assert_ll(g.score(frames), want, "well-conditioned pool, two fp16 terms")
+    g.close()
+    # means twice as far apart, deviations five times smaller: kappa ~ |R^-1 (mu - pivot)|^2 grows a hundredfold
+    mean2, cov2 = mean * 2.0, cov * 0.04
+    g = capi.Gmm.from_full(mean2, cov2, off, idx, w)
+    g.set_precision(4)
+    assert g.effective_precision() == 3
+    f2 = (mean2[rng.integers(0, G, 200)] + 0.2 * rng.standard_normal((200, D))).astype(np.float32)
+    assert_ll(g.score(f2), oracle.FullModel(mean2, cov2, off, idx, w).score(f2.astype(np.float64)),
+              "ill-conditioned pool keeps the three-term rows")
     g.close()

@@ -194,8 +194,10 @@ def test_config4_full_covariance_at_workload_size(capi, oracle):
     frames = synth.make_frames(Fc, D=Dc, seed=78)
     d_fr = torch.from_numpy(frames).cuda()
     outs = {}
-    for name, prec in (("f32", 0), ("bf16x3", 3)):
+    for name, prec in (("f32", 0), ("bf16x3", 3), ("f16x2", 4)):
         g.set_precision(prec)
+        if prec == 4:
+            assert g.effective_precision() == 4      # the pool qualifies for the two-term fp16 rows
         d_out = torch.empty((Fc, Sc), dtype=torch.float32, device="cuda")
         g.score_dev(d_fr, d_out)
         torch.cuda.synchronize()
@@ -208,11 +210,13 @@ def test_config4_full_covariance_at_workload_size(capi, oracle):
         assert_ll(got, ref, name)
     # the two arithmetics against each other over the whole block, same contract: where the f32 kernel's value
     # is one the reference's float storage holds they agree to 1e-4, elsewhere both flush
-    a, b = outs["f32"], outs["bf16x3"]
+    a = outs["f32"]
     vis = a > LL_FLUSH
-    assert ((a - b).abs() * vis).max().item() <= TOL_LL
-    assert (b[~vis] <= LL_FLUSH + 1.1).all()     # at most the one denormal quantum
-    for name, prec in (("f32", 0), ("bf16x3", 3)):
+    for other in ("bf16x3", "f16x2"):
+        b = outs[other]
+        assert ((a - b).abs() * vis).max().item() <= TOL_LL, other
+        assert (b[~vis] <= LL_FLUSH + 1.1).all(), other     # at most the one denormal quantum
+    for name, prec in (("f32", 0), ("bf16x3", 3), ("f16x2", 4)):
         g.set_precision(prec)
         for lo, hi in ((0, 1), (511, 1025), (Fc - 777, Fc)):
             d_out = torch.empty((hi - lo, Sc), dtype=torch.float32, device="cuda")

@@ -15,7 +15,7 @@ a = rng.standard_normal((G, D, D)) * 0.3
 cov = a @ a.transpose(0, 2, 1) + 0.1 * np.eye(D)
 _, _, off, idx, w = synth.make_model(D=D, G=G, S=S, comps=COMPS)
 g = capi.Gmm.from_full(mean, cov, off, idx, w)
-PREC = int(sys.argv[1]) if len(sys.argv) > 1 else 3   # 3: bf16x3 (three-term split), 0: f32 matrix kernel
+PREC = int(sys.argv[1]) if len(sys.argv) > 1 else 4   # 4: f16x2 (two fp16 terms), 3: bf16x3 (three-term split), 0: f32 matrix kernel
 g.set_precision(PREC)
 d_fr = torch.randn((F, D), device="cuda")
 d_out = torch.empty((F, S), device="cuda")
@@ -30,5 +30,5 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 3
 flop = float(D * (D + 3)) * F * G
-print(("bf16x3 " if PREC == 3 else "f32 ") + "full-cov: %.2f ms/launch, %.2f M frames/s, %.1f TFLOP/s algorithmic (%.3f of 157.3)" % (
+print({4: "f16x2 (effective %d) " % g.effective_precision(), 3: "bf16x3 ", 0: "f32 "}[PREC] + "full-cov: %.2f ms/launch, %.2f M frames/s, %.1f TFLOP/s algorithmic (%.3f of 157.3)" % (
     ms, F / ms / 1e3, flop / ms / 1e9, flop / ms / 1e9 / 157.3))

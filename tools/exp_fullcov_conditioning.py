@@ -32,4 +32,4 @@ for shrink in (1.0, 1e-1, 1e-2, 1e-3, 1e-4):
     for prec in (0, 3, 4):
         gm.set_precision(prec)
         out.append(float(np.abs(gm.score(frames) - ref)[vis].max()))
-    print("shrink %.0e: visible %d, worst |dll| f32 %.3g bf16x3 %.3g" % (shrink, int(vis.sum()), out[0], out[1]))
+    print("shrink %.0e: visible %d, worst |dll| f32 %.3g bf16x3 %.3g f16x2 %.3g (effective precision %d, kappa %s)" % (shrink, int(vis.sum()), out[0], out[1], out[2], gm.effective_precision(), "-"))
