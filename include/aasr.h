@@ -275,10 +275,11 @@ int32_t aasr_gmm_num_clusters(const aasr_gmm *h);
  *  AASR_PREC_F16X2        default: both operands as two fp16 terms (22 bits), three
  *                         fp16 matrix-core products per product -- half the matrix
  *                         instructions of BF16X3 at 1.4-1.8x its rounding error, so it
- *                         is used only for diagonal models whose conditioning estimate
- *                         leaves that room (same 1e-4 bar, tighter limits: gmm.h
- *                         KAPPA_LIMIT_F16); every other model, and the full-covariance
- *                         path, runs as under AASR_PREC_BF16X3.
+ *                         is used only for models whose conditioning estimate leaves
+ *                         that room (same 1e-4 bar, tighter limits: gmm.h
+ *                         KAPPA_LIMIT_F16 for diagonal pools, FULL_KAPPA_LIMIT_F16 for the
+ *                         factor rows of full-covariance / subspace pools); every other
+ *                         model runs as under AASR_PREC_BF16X3.
  *                         aasr_gmm_effective_precision tells which form a model got.
  *  AASR_PREC_F64          the reference's own arithmetic in double, operation by operation (diagonal
  *                         pools; unadapted, under one global CMLLR transform or under per-class transforms, with or
@@ -291,7 +292,7 @@ int32_t aasr_gmm_num_clusters(const aasr_gmm *h);
 enum { AASR_PREC_F32 = 0, AASR_PREC_F64 = 1, AASR_PREC_F32_CENTRED = 2, AASR_PREC_BF16X3 = 3, AASR_PREC_F16X2 = 4 };
 aasr_status aasr_gmm_set_precision(aasr_gmm *h, int prec);
 int aasr_gmm_get_precision(const aasr_gmm *h);
-/* the arithmetic the diagonal scoring path of this model actually runs under the current setting */
+/* the arithmetic the matrix scoring path of this model actually runs under the current setting */
 int aasr_gmm_effective_precision(const aasr_gmm *h);
 
 /* HmmSet::precompute_likelihoods + state_likelihood for a block of frames
