@@ -540,6 +540,12 @@ def main():
                                                       world, args)
         except Exception as e:
             extra_cfg["configs1"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0:
+            try:
+                torch.cuda.empty_cache()
+                extra_cfg["configs4"] = _measure_configs4(torch, capi, synth, dev, stream)
+            except Exception as e:
+                extra_cfg["configs4"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if args.workload == "gmm" and args.secondary:
         try:
             del d_out
@@ -675,6 +681,40 @@ def _measure_configs1(torch, synth, gmm, rank, dev, stream, sync_all, max_over_r
             "frames_per_gpu_per_step": F, "steps": steps, "ms_per_step": round(ms, 4),
             "frames_per_s": round(world * F * steps / elapsed, 1),
             "algorithmic_TFLOPs": round(flop / (ms * 1e-3) / 1e12, 2)}
+
+
+def _measure_configs4(torch, capi, synth, dev, stream, steps=5):
+    """BASELINE configs[4] next to the headline (rank 0, no collective inside): 10 000 full-covariance Gaussians of 39
+    dimensions (625 states x 16), 200 000 resident frames, state log-likelihoods out; the library's default arithmetic
+    (two fp16 terms where the pool's conditioning allows it -- `effective_precision` says which rows ran)."""
+    D4, G4, S4, F4 = 39, 10000, 625, 200000
+    rng = np.random.default_rng(synth.SEED)
+    mean = rng.standard_normal((G4, D4))
+    a = rng.standard_normal((G4, D4, D4)) * 0.3
+    cov = a @ a.transpose(0, 2, 1) + 0.1 * np.eye(D4)
+    _, _, off, idx, w = synth.make_model(D=D4, G=G4, S=S4, comps=16)
+    g4 = capi.Gmm.from_full(mean, cov, off, idx, w)
+    try:
+        d_fr = torch.randn((F4, D4), device=dev, dtype=torch.float32)
+        d_out = torch.empty((F4, S4), device=dev, dtype=torch.float32)
+        for _ in range(2):
+            g4.score_dev(d_fr, d_out, stream)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(steps):
+            g4.score_dev(d_fr, d_out, stream)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        flop = float(D4 * (D4 + 3)) * F4 * G4          # SURVEY 8(d): d(d+3) flop per frame x Gaussian pair
+        return {"workload": "configs[4]: %d full-covariance Gaussians x %d-d, %d states, %d resident frames, scoring only"
+                            % (G4, D4, S4, F4),
+                "frames_per_gpu_per_step": F4, "steps": steps, "ms_per_step": round(ms, 4),
+                "frames_per_s": round(F4 / (ms * 1e-3), 1), "algorithmic_TFLOPs": round(flop / (ms * 1e-3) / 1e12, 2),
+                "effective_precision": {0: "f32", 3: "bf16x3", 4: "f16x2"}.get(g4.effective_precision(), "?")}
+    finally:
+        g4.close()
 
 
 def _measure_configs2(torch, capi, synth, gmm, rank, dev, stream, sync_all, max_over_ranks, world,

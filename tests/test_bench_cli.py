@@ -67,6 +67,7 @@ def test_bench_line_on_a_gpu(args, key):
         assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
         assert "error" not in d["config"]["configs1"] and "error" not in d["config"]["recipe_e2e"]
         assert d["config"]["configs1"]["frames_per_s"] > 0
+        assert "error" not in d["config"]["configs4"] and d["config"]["configs4"]["effective_precision"] == "f16x2"
         assert d["config"]["lna_check"]["max_code_difference"] <= 1
     if key == "gmm":
         assert d["config"]["workload"].startswith("configs[1]")
