@@ -89,8 +89,12 @@ def test_two_ranks_go_through_the_whole_default_run():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         e.pop(k, None)
     e.update({"AASR_BENCH_SHARE_GPU": "1", "AASR_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    import socket
+    with socket.socket() as sk:     # a port nobody holds right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--utts", "24", "--frames", "40000",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--utts", "24", "--frames", "40000",
            "--steps", "2", "--warmup", "1", "--cpu-frames", "0"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=e, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
