@@ -1694,12 +1694,14 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score(
 // NS = 2 (AASR_PREC_F16X2): rows and frames as two fp16 terms, three products per slab -- half the matrix
 // instructions.  State-level error ~2x the three-term form's at the same conditioning (tools/exp_fullcov_f16.py), so
 // a pool takes it only below FULL_KAPPA_LIMIT_F16 (gmm.h); the frame operand is clamped to +-kFullF16Clamp.
-template <int NK16, int NS>
+// CL (Gaussian clustering over a full-covariance pool): a component counts for a frame only where its cluster's bit of
+// the tile's per-lane word (k_cluster_expand) is set; no floor on the states -- the merge adds the centres.
+template <int NK16, int NS, bool CL = false>
 __global__ __launch_bounds__(256, 2) void k_gmm_full_score_bf16x3(
     const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
     const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
     const uint32_t *__restrict__ close_mask, const float *__restrict__ gc_tile,
-    const int32_t *__restrict__ sid_tile, float *__restrict__ out, int64_t S, float ref_ln) {
+    const int32_t *__restrict__ sid_tile, float *__restrict__ out, int64_t S, float ref_ln, ClusterArgs cl) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int kTileFloats = NK16 * NS * 2 * 64 * 16 / 4;
   float *abuf0 = (float *)smem_raw;
@@ -1759,6 +1761,9 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score_bf16x3(
   float *orow0 = out + (f0 + n) * S;
   float *orow1 = out + (f0 + 32 + n) * S;
   const bool ok0 = f0 + n < F, ok1 = f0 + 32 + n < F;
+  const float floor_val = CL ? cl.floor_val : LOG_TINY_F;
+  const unsigned long long *mrow = CL ? cl.maskrow + (size_t)(f0 >> 6) * cl.rows_padded + lane : nullptr;
+  const int etest = (dim - 1) & 3;   // element of a component's last quad that holds its last row
 
   unsigned m32_next = t_begin < t_end ? (unsigned)__builtin_amdgcn_readfirstlane((int)close_mask[t_begin]) : 0u;
   unsigned mask_v = 0;
@@ -1781,6 +1786,8 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score_bf16x3(
     const i32x4 sda = sdt[4 * t], sdb = sdt[4 * t + 1];
     const float gcv[8] = {gca.x, gca.y, gca.z, gca.w, gcb.x, gcb.y, gcb.z, gcb.w};
     const int sdv[8] = {sda.x, sda.y, sda.z, sda.w, sdb.x, sdb.y, sdb.z, sdb.w};
+    unsigned long long bits = 0;
+    if (CL) bits = mrow[(size_t)t * TILE_ROWS];   // k_cluster_expand's per-lane word of this tile
     const unsigned m32 = m32_next;
     const unsigned gmask = h ? ((m32 >> 8) & 0xffu) : (m32 & 0xffu);
     const unsigned smask = h ? ((m32 >> 24) & 0xffu) : ((m32 >> 16) & 0xffu);
@@ -1835,15 +1842,21 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score_bf16x3(
           q1 = fmaf(cb[4 * q + e], cb[4 * q + e], q1);
         }
         if ((gmask >> (mb * 4 + q)) & 1) {
-          s0 += __builtin_amdgcn_exp2f(gcv[mb * 4 + q] - q0);
-          s1 += __builtin_amdgcn_exp2f(gcv[mb * 4 + q] - q1);
+          float e0 = __builtin_amdgcn_exp2f(gcv[mb * 4 + q] - q0);
+          float e1 = __builtin_amdgcn_exp2f(gcv[mb * 4 + q] - q1);
+          if (CL) {
+            e0 = ((bits >> (8 * q + 4 * mb + etest)) & 1ull) ? e0 : 0.0f;
+            e1 = ((bits >> (32 + 8 * q + 4 * mb + etest)) & 1ull) ? e1 : 0.0f;
+          }
+          s0 += e0;
+          s1 += e1;
           q0 = 0.0f;
           q1 = 0.0f;
           if ((smask >> (mb * 4 + q)) & 1) {
             float l0 = fmaf(__builtin_amdgcn_logf(s0), LN2_F, -ref_ln);
             float l1 = fmaf(__builtin_amdgcn_logf(s1), LN2_F, -ref_ln);
-            l0 = fmaxf(l0, LOG_TINY_F);
-            l1 = fmaxf(l1, LOG_TINY_F);
+            l0 = fmaxf(l0, floor_val);
+            l1 = fmaxf(l1, floor_val);
             if (ok0) orow0[sdv[mb * 4 + q]] = l0;
             if (ok1) orow1[sdv[mb * 4 + q]] = l1;
             s0 = 0.0f;
@@ -1855,9 +1868,9 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score_bf16x3(
   }
 }
 
-template <int NK16, int NS = 3>
+template <int NK16, int NS = 3, bool CL = false>
 static void launch_full_bf16_t(const aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
-                               hipStream_t stream) {
+                               hipStream_t stream, const ClusterArgs &cl = ClusterArgs()) {
   const FullLayout &L = g->full;
   const int64_t blocks = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
   const int smem = 2 * NK16 * NS * 2 * 64 * 16;
@@ -1874,9 +1887,9 @@ static void launch_full_bf16_t(const aasr_gmm *g, const float *d_frames, int64_t
     }
   }
   const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 8;
-  hipLaunchKernelGGL((k_gmm_full_score_bf16x3<NK16, NS>), dim3((unsigned)blocks, (unsigned)R), dim3(256), smem,
+  hipLaunchKernelGGL((k_gmm_full_score_bf16x3<NK16, NS, CL>), dim3((unsigned)blocks, (unsigned)R), dim3(256), smem,
                      stream, d_frames, F, g->dim, g->d_pivot.p, NS == 2 ? L.a16h.p : L.a16.p, split_row, L.close.p,
-                     L.gc_tile.p, L.sid_tile.p, d_out, g->S, L.ref_ln);
+                     L.gc_tile.p, L.sid_tile.p, d_out, g->S, L.ref_ln, cl);
   AASR_HIP(hipGetLastError());
 }
 
@@ -1939,7 +1952,7 @@ void gmm_full_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out
 }
 
 // Gaussian clustering over a full-covariance pool: the exact part of every state on the f32 factor-row kernel with
-// the selection masks (the bf16x3 form has no masked instance), no floor -- k_cluster_merge_log adds the centres.
+// the selection masks (the fp16 / bf16 matrix forms where the rows are packed for them, else the f32 kernel), no floor -- the merge adds the centres.
 void gmm_full_masked_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
                             const unsigned long long *maskrow, hipStream_t stream) {
   if (!g->full.ok) raise(AASR_ERR_UNSUPPORTED, "full-covariance layout was not built for this model");
@@ -1947,6 +1960,25 @@ void gmm_full_masked_launch(aasr_gmm *g, const float *d_frames, int64_t F, float
   cl.maskrow = maskrow;
   cl.rows_padded = g->full.rows_padded;
   cl.floor_val = NEG_BIG_F;
+  // the matrix-pipe forms of the rows (two fp16 / three bf16 terms) with the masks, where they are packed
+  if (g->use_bf16x3 && g->precision == AASR_PREC_F16X2 && g->full.a16h.p) {
+    switch (g->full.nk16) {
+      case 1: launch_full_bf16_t<1, 2, true>(g, d_frames, F, d_out, stream, cl); return;
+      case 2: launch_full_bf16_t<2, 2, true>(g, d_frames, F, d_out, stream, cl); return;
+      case 3: launch_full_bf16_t<3, 2, true>(g, d_frames, F, d_out, stream, cl); return;
+      case 4: launch_full_bf16_t<4, 2, true>(g, d_frames, F, d_out, stream, cl); return;
+      default: break;
+    }
+  }
+  if (g->use_bf16x3 && g->full.a16.p) {
+    switch (g->full.nk16) {
+      case 1: launch_full_bf16_t<1, 3, true>(g, d_frames, F, d_out, stream, cl); return;
+      case 2: launch_full_bf16_t<2, 3, true>(g, d_frames, F, d_out, stream, cl); return;
+      case 3: launch_full_bf16_t<3, 3, true>(g, d_frames, F, d_out, stream, cl); return;
+      case 4: launch_full_bf16_t<4, 3, true>(g, d_frames, F, d_out, stream, cl); return;
+      default: break;
+    }
+  }
   switch (g->full.rows.nkk) {
 #define AASR_CASE(N)                                                  \
   case N:                                                             \
