@@ -212,6 +212,35 @@ def test_more_clusters_than_a_selection_wave_holds(capi, oracle):
     _check(capi, oracle, model, g2c, C, 0.02, 0.1, frames)
 
 
+def test_centres_within_a_float_ulp_of_each_other_are_ranked_by_their_doubles(capi, oracle):
+    """The selection ranks float keys (half the bytes and registers of the doubles); two centres whose log-likelihoods
+    round to the same float are told apart by k_cluster_select_pending on doubles, as the reference's double-precision
+    queue does -- here every cluster has a twin 1e-7 away and the minimum cluster count is odd, so the stopping point
+    keeps falling between twins.  Counts and scores as the oracle's; nothing is left to the queue replay (the twins are
+    not equal in double)."""
+    rng = np.random.default_rng(77)
+    D, C2, per = 12, 30, 8                       # 30 clusters + their 30 twins, 8 Gaussians each
+    G = 2 * C2 * per
+    base_mean = rng.standard_normal((C2 * per, D)) * 1.5
+    base_var = np.exp(rng.uniform(np.log(0.3), np.log(2.0), (C2 * per, D)))
+    mean = np.concatenate([base_mean, base_mean * (1.0 + 1e-7) + 1e-7])
+    var = np.concatenate([base_var, base_var])
+    g2c = np.concatenate([np.repeat(np.arange(C2), per), C2 + np.repeat(np.arange(C2), per)])
+    S = 48
+    n = np.full(S, G // S)
+    off = np.concatenate([[0], np.cumsum(n)]).astype(np.int32)
+    idx = rng.permutation(G).astype(np.int32)
+    w = rng.uniform(0.1, 1.0, G)
+    frames = (rng.standard_normal((400, D)) * 1.2).astype(np.float32)
+    for minc, ming in ((0.15, 0.0), (0.05, 0.0), (0.0, 0.113)):
+        gm, om, got, want = _check(capi, oracle, (mean, var, off, idx, w), g2c, 2 * C2, minc, ming, frames)
+        assert gm.cluster_tie_frames() == 0
+    # the float keys of twins do coincide for most frames: the second kernel is what kept the counts right
+    ll = (-0.5 * ((frames[:, None, :].astype(np.float64) - om.c_mean[None]) ** 2 * om.c_prec[None]).sum(-1) + om.c_cst[None])
+    same = (ll[:, :C2].astype(np.float32) == ll[:, C2:].astype(np.float32)) & (ll[:, :C2] != ll[:, C2:])
+    assert same.mean() > 0.3
+
+
 def test_clustering_errors(capi, tmp_path):
     mean, var, off, idx, w = synth.make_model(D=8, G=100, S=10, comps=10)
     gm = capi.Gmm.from_arrays(mean, var, off, idx, w)
