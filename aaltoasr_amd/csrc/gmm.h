@@ -164,8 +164,11 @@ struct TrackLayout {
 // sqrt(log2e/2) * R^-1 (Sigma = R R^T), so that the accumulator holds
 // y = R^-1 (x - mu) and the quadratic form is a sum of squares.
 // Two-term fp16 form of the factor rows: worst visible state error ~3.7e-5 at kappa = 2 400 and 9.8e-5 at 24 000
-// (host emulation, tools/exp_fullcov_f16.py), the three-term form ~2x below it.
-#define FULL_KAPPA_LIMIT_F16 1500.0
+// (host emulation on 13-dimensional pools, tools/exp_fullcov_f16.py), the three-term form ~2x below it.  The error of a
+// row goes with sqrt(kappa) (the two terms of y = R^-1 x' - R^-1 mu' that cancel are that large) times y itself, and a
+// low-dimensional pool has no other rows to average it with: at 1 500 the sweeps' worst was 6.8e-5, hence 600.
+#define FULL_KAPPA_LIMIT_F16 600.0
+#define FULL_KAPPA_LIMIT_F16_LOWDIM 40.0    // fewer than 8 dimensions (6.8e-5 on a 2-dimensional pool at kappa < 600, 5.7e-5 below 150)
 constexpr float kFullF16Clamp = 30000.0f;   // |x - pivot| beyond this is clamped in the f16x2 factor-row kernel
 
 struct FullLayout {

@@ -1471,7 +1471,7 @@ void gmm_build_fullcov(aasr_gmm *g) {
         if (all_zero) continue;
         for (int k = 0; k < D; k++) heavy = heavy && colmax[(size_t)gi * D + k] * (double)kFullF16Clamp >= 64.0;
       }
-      if (f16_env && L.kappa <= FULL_KAPPA_LIMIT_F16 && amax < 60000.0 && heavy) {
+      if (f16_env && L.kappa <= (D < 8 ? FULL_KAPPA_LIMIT_F16_LOWDIM : FULL_KAPPA_LIMIT_F16) && amax < 60000.0 && heavy) {
         const size_t tile_h = (size_t)nk16 * 2 * 2 * 64 * 8;
         std::vector<uint16_t> ah((size_t)tiles * tile_h, 0);
         for (int64_t r = 0; r < tiles * TILE_ROWS; r++) {

@@ -67,6 +67,8 @@ def run(seed=1, N=40, verbose=False):
             eall = float(d.max())
             worst[key] = max(worst.get(key, 0.0), evis)
             worst[key + " (all)"] = max(worst.get(key + " (all)", 0.0), eall)
+            if verbose and evis > float(os.environ.get("AASR_FUZZ_TOL", "1.0")):
+                print("NOTE %s %s visible %.3g effective precision %d" % (key, ctx, evis, g.effective_precision()))
             with np.errstate(under="ignore"):
                 flushes = (np.exp(got[~vis].astype(np.float64)).astype(np.float32) <= np.float32(2.0 ** -149)).all()
             if evis > 1e-4 or not flushes:
