@@ -166,8 +166,9 @@ struct TrackLayout {
 // Two-term fp16 form of the factor rows: worst visible state error ~3.7e-5 at kappa = 2 400 and 9.8e-5 at 24 000
 // (host emulation on 13-dimensional pools, tools/exp_fullcov_f16.py), the three-term form ~2x below it.  The error of a
 // row goes with sqrt(kappa) (the two terms of y = R^-1 x' - R^-1 mu' that cancel are that large) times y itself, and a
-// low-dimensional pool has no other rows to average it with: at 1 500 the sweeps' worst was 6.8e-5, hence 600.
-#define FULL_KAPPA_LIMIT_F16 600.0
+// low-dimensional pool has no other rows to average it with: at 1 500 the sweeps' worst was 6.8e-5, at 600 still 6.2e-5
+// (a 63-dimensional pool, one of 2 000), hence 300.
+#define FULL_KAPPA_LIMIT_F16 300.0
 #define FULL_KAPPA_LIMIT_F16_LOWDIM 40.0    // fewer than 8 dimensions (6.8e-5 on a 2-dimensional pool at kappa < 600, 5.7e-5 below 150)
 constexpr float kFullF16Clamp = 30000.0f;   // |x - pivot| beyond this is clamped in the f16x2 factor-row kernel
 
