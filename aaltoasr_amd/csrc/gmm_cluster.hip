@@ -289,8 +289,19 @@ __global__ __launch_bounds__(64 * kMfmaCentreWaves) void k_cluster_centres_mfma(
   for (int t = t_begin; t < t_end; t++) {
     const double *cur = btile[(t - t_begin) & 1];
     double *nxt = btile[(t - t_begin + 1) & 1];
-    if (t + 1 < t_end)
-      for (int i = tid; i < kTileDoubles; i += 64 * kMfmaCentreWaves) nxt[i] = bpack[(size_t)(t + 1) * kTileDoubles + i];
+    // the next tile: requested here, parked in registers under the matrix instructions, written to LDS behind them
+    // (load and LDS store side by side, the wait for the load sat in FRONT of the matrix loop: a global-memory
+    // latency per tile, the matrix pipe 57 % busy)
+    constexpr int kPre = (kTileDoubles + 64 * kMfmaCentreWaves - 1) / (64 * kMfmaCentreWaves);
+    double pre[kPre];
+    if (t + 1 < t_end) {
+#pragma unroll
+      for (int u = 0; u < kPre; u++) {
+        const int i = tid + u * 64 * kMfmaCentreWaves;
+        pre[u] = i < kTileDoubles ? bpack[(size_t)(t + 1) * kTileDoubles + i] : 0.0;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     f64x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < KS; q++) {
@@ -298,6 +309,17 @@ __global__ __launch_bounds__(64 * kMfmaCentreWaves) void k_cluster_centres_mfma(
       c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][q], b, c0, 0, 0, 0);
       c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][q], b, c1, 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < t_end) {
+#pragma unroll
+      for (int u = 0; u < kPre; u++) {
+        const int i = tid + u * 64 * kMfmaCentreWaves;
+        if (i < kTileDoubles) nxt[i] = pre[u];
+      }
+    }
+    // the buffer swap's barrier sits HERE, not behind the stores of the keys: every wave is through its matrix loop
+    // (nobody reads `cur` any more, `nxt` is complete), and the stores drain under the next tile's instructions
+    __syncthreads();
     // D[i = 4 r + lane / 16][j = lane % 16] (register r of the f64 16x16 result): frame f0 + 16 nb + 4 r + kq,
     // cluster 16 t + i16
 #pragma unroll
@@ -312,8 +334,8 @@ __global__ __launch_bounds__(64 * kMfmaCentreWaves) void k_cluster_centres_mfma(
         if (col && fb < F) ll64[fb * Cs + (int64_t)t * 16 + i16] = lin_key(c1[r]);
       }
     }
-    __syncthreads();
   }
+  __syncthreads();   // the next chunk refills btile[0]
   }   // chunk
 }
 
