@@ -1567,13 +1567,39 @@ static void build_class_routing(aasr_gmm *g) {
 }
 
 void gmm_set_transforms(aasr_gmm *g, int32_t n_transforms, const int32_t *gauss_to_transform, const double *W) {
-  if (!g->dim_parts.empty() && n_transforms > 0)
-    raise(AASR_ERR_UNSUPPORTED, "model-side CMLLR is built for feature dimensions <= 63");
   HostModel &cur = g->host;
   const int D = cur.dim;
   bool global = n_transforms == 1;
   if (global)
     for (int64_t i = 0; i < cur.G && global; i++) global = gauss_to_transform[i] == 0;
+  if (!g->dim_parts.empty()) {
+    // feature dimension > 63 (the model as parts, gmm_dim_split_score): one transform for the whole pool is the frames
+    // transformed once and |det| on every component; regression classes are not built there
+    if (n_transforms > 0 && !global)
+      raise(AASR_ERR_UNSUPPORTED, "per-class model-side CMLLR is built for feature dimensions <= 63");
+    cur.n_transforms = n_transforms;
+    cur.g2t.clear();
+    cur.xform.clear();
+    if (n_transforms == 0) {
+      g->xf_a.release();
+      g->xf_b.release();
+      g->out_bias_ln = 0;
+      return;
+    }
+    cur.g2t.assign(gauss_to_transform, gauss_to_transform + cur.G);
+    cur.xform.assign(W, W + (size_t)D * (D + 1));
+    std::vector<double> A((size_t)D * D), b((size_t)D);
+    double det = 1;
+    for (int i = 0; i < D; i++) {
+      b[(size_t)i] = W[(size_t)i * (D + 1)];
+      for (int j = 0; j < D; j++) A[(size_t)i * D + j] = W[(size_t)i * (D + 1) + 1 + j];
+      det *= A[(size_t)i * D + i];   // the reference's "determinant": the product of the diagonal (LinearAlgebra.cc:73-86)
+    }
+    g->xf_a.upload(A.data(), A.size());
+    g->xf_b.upload(b.data(), b.size());
+    g->out_bias_ln = std::log(std::fabs(det));
+    return;
+  }
   // In place: none / one transform for the whole pool, over rows packed without a bias, on the
   // kernels that take the bias at their output (the track layouts; no outlier routing).  A
   // speaker change then costs two small uploads instead of re-packing every row (70 ms at 50 k

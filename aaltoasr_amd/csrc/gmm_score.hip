@@ -2812,7 +2812,7 @@ __global__ __launch_bounds__(256) void k_dim_split_combine(const float *__restri
                                                            int64_t G, const int32_t *__restrict__ mix_off,
                                                            const int32_t *__restrict__ mix_idx,
                                                            const float *__restrict__ mix_logw, int64_t S,
-                                                           float *__restrict__ out, int per_gaussian) {
+                                                           float *__restrict__ out, int per_gaussian, float bias_ln) {
   const int64_t n = per_gaussian ? G : S;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Fc * n) return;
@@ -2827,7 +2827,7 @@ __global__ __launch_bounds__(256) void k_dim_split_combine(const float *__restri
   for (int32_t k = mix_off[s]; k < mix_off[s + 1]; k++) {
     const float lw = mix_logw[k];
     if (!(lw > NEG_BIG_F)) continue;   // zero weight
-    float v = lw;
+    float v = lw + bias_ln;   // log |det| of the pool's one constrained-MLLR transform (AdaptedGaussian), else 0
     const int64_t gi = mix_idx[k];
     for (int p = 0; p < parts; p++) v += part_ll[((int64_t)p * Fc + f) * G + gi];
     const float mn = fmaxf(m, v);
@@ -2849,6 +2849,16 @@ void gmm_dim_split_score(aasr_gmm *g, const float *d_frames, int64_t F, float *d
   g->dim_part_x.ensure((size_t)chunk * max_dp);
   g->dim_part_ll.ensure((size_t)parts * chunk * g->G);
   const int64_t n_out = per_gaussian ? g->G : g->S;
+  if (g->xf_a.p) {
+    // one transform for the whole pool: the Gaussians are evaluated on A f + b (k_affine_frames handles any dimension)
+    if (per_gaussian) raise(AASR_ERR_UNSUPPORTED, "per-Gaussian log-likelihoods are not built for adapted pools");
+    g->d_xframes.ensure((size_t)F * g->dim);
+    const int64_t n = F * g->dim;
+    hipLaunchKernelGGL(k_affine_frames, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_frames, F, g->dim,
+                       g->xf_a.p, g->xf_b.p, g->d_xframes.p);
+    AASR_HIP(hipGetLastError());
+    d_frames = g->d_xframes.p;
+  }
   for (int64_t f0 = 0; f0 < F; f0 += chunk) {
     const int64_t fc = std::min(chunk, F - f0);
     for (int p = 0; p < parts; p++) {
@@ -2863,7 +2873,7 @@ void gmm_dim_split_score(aasr_gmm *g, const float *d_frames, int64_t F, float *d
     const int64_t n = fc * n_out;
     hipLaunchKernelGGL(k_dim_split_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g->dim_part_ll.p, parts,
                        fc, g->G, g->dim_mix_off.p, g->dim_mix_idx.p, g->dim_mix_logw.p, g->S, d_out + f0 * n_out,
-                       per_gaussian ? 1 : 0);
+                       per_gaussian ? 1 : 0, g->xf_a.p ? (float)g->out_bias_ln : 0.0f);
     AASR_HIP(hipGetLastError());
   }
 }

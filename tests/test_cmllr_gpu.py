@@ -46,7 +46,7 @@ def _transforms(n, D, seed):
     return W
 
 
-@pytest.mark.parametrize("D,G,S,comps", [(13, 64, 8, 8), (39, 128, 16, 8)])
+@pytest.mark.parametrize("D,G,S,comps", [(13, 64, 8, 8), (39, 128, 16, 8), (80, 96, 12, 8), (130, 60, 10, 6)])
 def test_global_transform(capi, oracle, D, G, S, comps):
     model = synth.make_model(D=D, G=G, S=S, comps=comps, seed=D)
     frames = synth.make_frames(150, D=D, seed=3)
@@ -61,6 +61,9 @@ def test_global_transform(capi, oracle, D, G, S, comps):
     assert np.abs(got - plain).max() > 1e-2       # the transform does something
     g.set_cmllr()                                   # reset_transform
     assert np.array_equal(g.score(frames), plain)
+    if D > 63:   # the model as dimension parts: one transform for the pool is built, regression classes are refused
+        with pytest.raises(capi.AasrError):
+            g.set_cmllr((np.arange(G) % 2).astype(np.int32), _transforms(2, D, seed=2))
 
 
 @pytest.mark.parametrize("D,G,S,comps", [(13, 64, 8, 8), (39, 96, 12, 8)])
