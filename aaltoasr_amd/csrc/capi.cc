@@ -273,7 +273,8 @@ aasr_status aasr_gmm_set_precision(aasr_gmm *h, int prec) {
       return;
     }
     if (prec == AASR_PREC_F64) {
-      if (!h->dim_parts.empty()) raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 is built for feature dimensions <= 63");
+      if (!h->dim_parts.empty() && h->dim > 192)
+        raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 is built for feature dimensions <= 192");
       if (h->host.any_full())
         raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 is built for diagonal pools");
       h->precision = prec;

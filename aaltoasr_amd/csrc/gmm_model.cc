@@ -1580,6 +1580,7 @@ void gmm_set_transforms(aasr_gmm *g, int32_t n_transforms, const int32_t *gauss_
     cur.n_transforms = n_transforms;
     cur.g2t.clear();
     cur.xform.clear();
+    g->f64_built = false;
     if (n_transforms == 0) {
       g->xf_a.release();
       g->xf_b.release();
@@ -1680,7 +1681,8 @@ void gmm_build_f64(aasr_gmm *g) {
   if (g->f64_built) return;
   const HostModel &m = g->host;
   const int D = m.dim;
-  const int dimp = centred_dimp_for(D);
+  // the frame vector lives in registers as doubles: instances up to 192 dimensions (384 of a lane's 512 VGPRs)
+  const int dimp = D <= 64 ? centred_dimp_for(D) : D <= 96 ? 96 : D <= 128 ? 128 : D <= 192 ? 192 : 0;
   if (!dimp) raise(AASR_ERR_UNSUPPORTED, "no f64 kernel instance for dimension %d", D);
   const int rec = 2 * dimp + 2;
   const size_t K = m.mix_idx.size();

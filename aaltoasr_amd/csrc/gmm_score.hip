@@ -2287,7 +2287,8 @@ void gmm_score_f64_launch(aasr_gmm *g, const double *d_frames, int64_t F, double
                           hipStream_t stream) {
   if (F <= 0) return;
   if (g->host.any_full()) raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 is built for diagonal pools");
-  if (!g->dim_parts.empty()) raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 is built for feature dimensions <= 63");
+  if (!g->dim_parts.empty() && (g->cl.enabled || (g->host.n_transforms > 0 && !g->host.global_xform())))
+    raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 with clustering or regression classes is built for feature dimensions <= 63");
   gmm_build_f64(g);
   if (g->f64_classes > 0) {
     if (g->cl.enabled) gmm_cluster_score_f64_launch(g, d_frames, d_frames, F, d_out, linear, 1.0, stream);
@@ -2331,12 +2332,22 @@ void gmm_f64_masked_launch(aasr_gmm *g, const double *d_frames, int64_t F, doubl
                          stream, d_frames, F, g->dim, g->f64_recs.p, g->f64_state_off.p, g->S, d_out, linear, det, \
                          crow, maskw, c1, ll64, Cs, C);                                                           \
     break;
+  // wide models (64 < dimension <= 192): the unmasked instance only
+#define AASR_WIDE(N)                                                                                              \
+  case N:                                                                                                         \
+    if (maskw) raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 with clustering is built for feature dimensions <= 63"); \
+    hipLaunchKernelGGL((k_gmm_diag_score_f64<N, false>), dim3((unsigned)blocks, (unsigned)cuts), dim3(256), 0,    \
+                       stream, d_frames, F, g->dim, g->f64_recs.p, g->f64_state_off.p, g->S, d_out, linear, det,  \
+                       crow, maskw, c1, ll64, Cs, C);                                                             \
+    break;
   switch (g->f64_dimp) {
     AASR_CASE(8) AASR_CASE(16) AASR_CASE(24) AASR_CASE(32) AASR_CASE(40) AASR_CASE(48) AASR_CASE(64)
+    AASR_WIDE(96) AASR_WIDE(128) AASR_WIDE(192)
     default:
       raise(AASR_ERR_UNSUPPORTED, "no f64 kernel instance for dimension %d", g->dim);
   }
 #undef AASR_CASE
+#undef AASR_WIDE
   AASR_HIP(hipGetLastError());
 }
 
@@ -2882,8 +2893,11 @@ void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
                       hipStream_t stream) {
   if (F <= 0) return;
   if (!g->dim_parts.empty()) {
-    if (g->precision == AASR_PREC_F64) raise(AASR_ERR_UNSUPPORTED, "AASR_PREC_F64 is built for feature dimensions <= 63");
     if (g->cl.enabled) raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering is built for feature dimensions <= 63");
+    if (g->precision == AASR_PREC_F64) {   // the reference's arithmetic in double: instances up to 192 dimensions
+      score_f64_for_f32_callers(g, d_frames, F, d_out, stream);
+      return;
+    }
     gmm_dim_split_score(g, d_frames, F, d_out, false, stream);
     return;
   }

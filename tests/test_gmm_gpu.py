@@ -419,6 +419,16 @@ def test_dimensions_beyond_63(capi, oracle, D):
     # what is not built for wide vectors says so
     with pytest.raises(capi.AasrError):
         g.set_clustering(4, [(i, i % 4) for i in range(160)])
-    with pytest.raises(capi.AasrError):
+    # AASR_PREC_F64 (the reference's arithmetic in double) has instances up to 192 dimensions
+    if D <= 192:
         g.set_precision(1)
+        got = g.score(frames)
+        vis = ref > np.log(1e-50)
+        assert np.abs(got - ref)[vis].max() <= 2e-6 * np.maximum(1.0, np.abs(ref[vis])).max()   # rounded to float once
+        assert_ll(got, ref, "D = %d in double" % D)
+        got64 = g.score_f64(frames.astype(np.float64))
+        assert np.abs(got64 - ref).max() <= 1e-9 * np.maximum(1.0, np.abs(ref)).max()
+    else:
+        with pytest.raises(capi.AasrError):
+            g.set_precision(1)
     g.close()
