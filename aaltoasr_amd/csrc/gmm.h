@@ -234,6 +234,7 @@ struct ClusterState {
   int64_t Fc = 0, Fs = 0;
   DevBuf<double> ll64;             // [Fs][Cs] centre log-likelihoods (ranking keys); on the float-key path: the rows of the frames left to the replay
   DevBuf<float> key32;             // [Fs][Cs] the keys as floats (k_cluster_select<KPL, float>)
+  DevBuf<int32_t> crow_gauss;      // [G] cluster of every pool Gaussian, C = none (models scored as dimension parts)
   DevBuf<int32_t> pend_list;       // [Fs + 1] frames the float selection left open (k_cluster_select_pending); last slot = count
   DevBuf<unsigned long long> maskw;  // [Fc/64][C+1] bit f = frame f takes the exact values
   DevBuf<unsigned long long> maskrow;  // [Fc/64][rows_padded] the same per packed row
@@ -352,7 +353,10 @@ void gmm_build(aasr_gmm *g, const HostModel &m);
 // transform over the unadapted rows; per-class transforms with an unchanged membership), rebuilds otherwise
 void gmm_set_transforms(aasr_gmm *g, int32_t n_transforms, const int32_t *gauss_to_transform, const double *W);
 void gmm_build_pool(aasr_gmm *g);
-void gmm_dim_split_score(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, bool per_gaussian, hipStream_t stream);
+// maskw / c1 / gclus (Gaussian clustering): a component counts for a frame only where its cluster's selection bit is set;
+// no floor then (the merge adds the centres)
+void gmm_dim_split_score(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, bool per_gaussian, hipStream_t stream,
+                         const unsigned long long *maskw = nullptr, int c1 = 0, const int32_t *gclus = nullptr);
 void gmm_build_pool_centred(aasr_gmm *g);
 void gmm_build_f64(aasr_gmm *g);
 void gmm_cluster_score_f64_launch(aasr_gmm *g, const double *d_frames, const double *d_members, int64_t F,

@@ -184,21 +184,22 @@ __global__ __launch_bounds__(kCentreThreads) void k_cluster_centres_fma(
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   typedef double f64x2 __attribute__((ext_vector_type(2)));
   double *pbuf = (double *)smem_c;                                 // [2][dimp][8][2]
-  float *xs = (float *)(smem_c + (size_t)2 * dimp * 16 * 8);       // [dimp][kCentreThreads]
+  float *xs = (float *)(smem_c + (size_t)2 * dimp * 16 * 8);       // [dimp][nt]
   const int tid = threadIdx.x;
-  const int64_t f = (int64_t)blockIdx.x * kCentreThreads + tid;
+  const int nt = blockDim.x;   // 256, or 64 for models of more than 64 dimensions (LDS: dimp x nt floats)
+  const int64_t f = (int64_t)blockIdx.x * nt + tid;
   const int64_t fc = f < F ? f : F - 1;
-  for (int d = 0; d < dimp; d++) xs[d * kCentreThreads + tid] = d < dim ? frames[fc * dim + d] : 0.0f;
+  for (int d = 0; d < dimp; d++) xs[d * nt + tid] = d < dim ? frames[fc * dim + d] : 0.0f;
   const int g_begin = blockIdx.y * groups_per_y;
   const int g_end = min(groups, g_begin + groups_per_y);
   const int rec_doubles = dimp * 16;
-  for (int i = tid; i < rec_doubles; i += kCentreThreads) pbuf[i] = rec[(size_t)g_begin * rec_doubles + i];
+  for (int i = tid; i < rec_doubles; i += nt) pbuf[i] = rec[(size_t)g_begin * rec_doubles + i];
   __syncthreads();
   for (int cg = g_begin; cg < g_end; cg++) {
     const double *cur = pbuf + ((cg - g_begin) & 1) * rec_doubles;
     double *nxt = pbuf + ((cg - g_begin + 1) & 1) * rec_doubles;
     if (cg + 1 < g_end)
-      for (int i = tid; i < rec_doubles; i += kCentreThreads) nxt[i] = rec[(size_t)(cg + 1) * rec_doubles + i];
+      for (int i = tid; i < rec_doubles; i += nt) nxt[i] = rec[(size_t)(cg + 1) * rec_doubles + i];
     double acc[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) acc[j] = 0.0;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(kCentreThreads) void k_cluster_centres_fma(
     for (int j = 0; j < 8; j++) r0[j] = ((const f64x2 *)cur)[j];
 #pragma unroll 1
     for (int d = 0; d < dimp; d += 2) {   // dimp is a multiple of 8
-      x1 = xs[(d + 1) * kCentreThreads + tid];
+      x1 = xs[(d + 1) * nt + tid];
 #pragma unroll
       for (int j = 0; j < 8; j++) r1[j] = ((const f64x2 *)(cur + (d + 1) * 16))[j];
       __builtin_amdgcn_sched_barrier(0);
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(kCentreThreads) void k_cluster_centres_fma(
       }
       __builtin_amdgcn_sched_barrier(0);
       if (d + 2 < dimp) {
-        x0 = xs[(d + 2) * kCentreThreads + tid];
+        x0 = xs[(d + 2) * nt + tid];
 #pragma unroll
         for (int j = 0; j < 8; j++) r0[j] = ((const f64x2 *)(cur + (d + 2) * 16))[j];
       }
@@ -1039,7 +1040,8 @@ static void build_crow_comps(const aasr_gmm *g, const std::vector<int32_t> &comp
 
 void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
                         const int32_t *gauss_index, const int32_t *cluster_index) {
-  if (!g->dim_parts.empty()) raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering is built for feature dimensions <= 63");
+  if (!g->dim_parts.empty() && (g->host.n_transforms > 0 || ((g->host.dim + 7) / 8 * 8) * (2 * 16 * 8 + 64 * 4) > 160 * 1024))
+    raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering on a model of %d dimensions: unadapted pools of up to ~300 dimensions", g->host.dim);
   ClusterState &cl = g->cl;
   if (n_clusters <= 0) {
     cl = ClusterState();
@@ -1056,7 +1058,7 @@ void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
     raise(AASR_ERR_UNSUPPORTED, "more than %d clusters are not built (%d asked)", kMaxClusters, n_clusters);
   if (n_pairs > 0 && (!gauss_index || !cluster_index))
     raise(AASR_ERR_INVALID, "aasr_gmm_set_clustering: null argument");
-  if (!g->class_routing && !g->paired.ok && !g->tracks.ok && !g->centred_ok && !(m.any_full() && g->full.ok))
+  if (g->dim_parts.empty() && !g->class_routing && !g->paired.ok && !g->tracks.ok && !g->centred_ok && !(m.any_full() && g->full.ok))
     raise(AASR_ERR_UNSUPPORTED,
           "Gaussian clustering needs the fixed-reference track kernels or the centred kernel, and this "
           "model has neither");
@@ -1300,11 +1302,29 @@ static void launch_centres(aasr_gmm *g, const XT *d_frames, int64_t F, hipStream
   // float frames: the expanded FMA form (AASR_CLUSTER_CENTRES_REF=1 keeps the reference operation order)
   static const int ref_order = getenv("AASR_CLUSTER_CENTRES_REF") ? atoi(getenv("AASR_CLUSTER_CENTRES_REF")) : 0;
   if constexpr (std::is_same<XT, float>::value) {
+    if (cl.dimp > 64) {
+      // feature dimension > 63 (no matrix instance: K = 2 dim + 1 > 128): the expanded FMA form with one wave per
+      // workgroup, so that a frame column of any length fits LDS
+      if (!cl.rec_fma.p) raise(AASR_ERR_UNSUPPORTED, "no centre kernel for dimension %d", g->dim);
+      const int nt = 64;
+      const int smem_w = 2 * cl.dimp * 16 * 8 + cl.dimp * nt * (int)sizeof(float);
+      if (smem_w > 160 * 1024) raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering: dimension %d does not fit the centre kernel", g->dim);
+      static bool attr_wide[64] = {false};
+      if (!attr_wide[g->device & 63]) {
+        AASR_HIP(hipFuncSetAttribute((const void *)k_cluster_centres_fma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_wide[g->device & 63] = true;
+      }
+      const int64_t bxw = (F + nt - 1) / nt;
+      hipLaunchKernelGGL(k_cluster_centres_fma, dim3((unsigned)bxw, 1), dim3(nt), smem_w, stream, d_frames, F, g->dim, cl.dimp,
+                         cl.rec_fma.p, cl.cconst_fma.p, groups, groups, cl.ll64.p, (int64_t)cl.Cs);
+      AASR_HIP(hipGetLastError());
+      return;
+    }
     if (!ref_order && cl.rec_fma.p) {
       static bool attr_fma[64] = {false};
       if (!attr_fma[g->device & 63]) {
         AASR_HIP(hipFuncSetAttribute((const void *)k_cluster_centres_fma, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     2 * 64 * 16 * 8 + 64 * kCentreThreads * (int)sizeof(float)));
+                                     160 * 1024));
         attr_fma[g->device & 63] = true;
       }
       // the matrix-pipe form where an instance exists for the dimension
@@ -1407,7 +1427,7 @@ static bool cluster_fast_keys(const aasr_gmm *g) {
   static const int ref_order = getenv("AASR_CLUSTER_CENTRES_REF") ? atoi(getenv("AASR_CLUSTER_CENTRES_REF")) : 0;
   static const int use_mfma = getenv("AASR_CLUSTER_CENTRES_MFMA") ? atoi(getenv("AASR_CLUSTER_CENTRES_MFMA")) : 1;
   const ClusterState &cl = g->cl;
-  return !keys64 && !ref_order && use_mfma && cl.bpack.p && cl.rec_fma.p && cl.mfma_ks >= 1 && cl.mfma_ks <= 32 &&
+  return !keys64 && !ref_order && use_mfma && cl.dimp <= 64 && cl.bpack.p && cl.rec_fma.p && cl.mfma_ks >= 1 && cl.mfma_ks <= 32 &&
          (cl.C + 63) / 64 <= 64;
 }
 
@@ -1488,6 +1508,7 @@ static void launch_merge(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hi
 // Gaussians -- a minority next to the masked track kernel (outlier routing), or the whole model --
 // come from the centred kernel under the same bits.
 struct ExactPlan {
+  bool dimsplit = false;   // feature dimension > 63: the dimension parts per Gaussian, the masks applied where they are added
   bool full = false;   // full-covariance pool: the factor-row kernel with masks
   bool all_centred, with_outliers;
   int which;
@@ -1496,6 +1517,18 @@ struct ExactPlan {
 
 static ExactPlan exact_part_plan(aasr_gmm *g, ClusterState &cl) {
   ExactPlan p;
+  if (!g->dim_parts.empty()) {
+    p.dimsplit = true;
+    p.all_centred = p.with_outliers = false;
+    p.which = 0;
+    p.mask_rows = 0;
+    if (cl.crow_gauss.n != (size_t)g->G) {
+      std::vector<int32_t> cg((size_t)g->G);
+      for (int64_t i = 0; i < g->G; i++) cg[(size_t)i] = cl.g2c[(size_t)i] >= 0 ? cl.g2c[(size_t)i] : cl.C;
+      cl.crow_gauss.upload(cg.data(), cg.size());
+    }
+    return p;
+  }
   if (g->host.any_full()) {
     // the reference's cluster branch does not look at the type of the pool's Gaussians (aku/Distributions.cc:
     // 2684-2722): diagonal centres, exact members -- here the members' factor rows with selection masks
@@ -1547,6 +1580,10 @@ static void launch_expand(aasr_gmm *g, const unsigned long long *maskw, int c1, 
 static void exact_part_launch(aasr_gmm *g, ClusterState &cl, const ExactPlan &p, const unsigned long long *maskw,
                               int c1, int64_t n, const float *fr_members, float *out, hipStream_t stream, int64_t pitch = 0) {
   const int64_t words = (n + 63) / 64;
+  if (p.dimsplit) {
+    gmm_dim_split_score(g, fr_members, n, out, false, stream, maskw, c1, cl.crow_gauss.p);
+    return;
+  }
   if (p.full) {
     const int64_t rows_padded = g->full.rows_padded;
     cl.maskrow.ensure((size_t)((n + 511) / 512 * 8) * (size_t)rows_padded);

@@ -2823,7 +2823,9 @@ __global__ __launch_bounds__(256) void k_dim_split_combine(const float *__restri
                                                            int64_t G, const int32_t *__restrict__ mix_off,
                                                            const int32_t *__restrict__ mix_idx,
                                                            const float *__restrict__ mix_logw, int64_t S,
-                                                           float *__restrict__ out, int per_gaussian, float bias_ln) {
+                                                           float *__restrict__ out, int per_gaussian, float bias_ln,
+                                                           const unsigned long long *__restrict__ maskw, int c1,
+                                                           const int32_t *__restrict__ gclus, int64_t f_first) {
   const int64_t n = per_gaussian ? G : S;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Fc * n) return;
@@ -2840,17 +2842,25 @@ __global__ __launch_bounds__(256) void k_dim_split_combine(const float *__restri
     if (!(lw > NEG_BIG_F)) continue;   // zero weight
     float v = lw + bias_ln;   // log |det| of the pool's one constrained-MLLR transform (AdaptedGaussian), else 0
     const int64_t gi = mix_idx[k];
+    if (maskw) {   // Gaussian clustering: only the members of clusters selected for this frame are evaluated exactly
+      const int64_t fa = f_first + f;
+      if (!((maskw[(fa >> 6) * c1 + gclus[gi]] >> (fa & 63)) & 1ull)) continue;
+    }
     for (int p = 0; p < parts; p++) v += part_ll[((int64_t)p * Fc + f) * G + gi];
     const float mn = fmaxf(m, v);
     sum = sum * __expf(m - mn) + __expf(v - mn);
     m = mn;
+  }
+  if (maskw) {   // the exact part alone, no floor: the merge adds the centres' share
+    out[i] = sum > 0.0f ? m + __logf(sum) : NEG_BIG_F;
+    return;
   }
   const float ll = sum > 0.0f ? m + __logf(sum) : LOG_TINY_F;
   out[i] = fmaxf(ll, LOG_TINY_F);
 }
 
 void gmm_dim_split_score(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, bool per_gaussian,
-                         hipStream_t stream) {
+                         hipStream_t stream, const unsigned long long *maskw, int c1, const int32_t *gclus) {
   const int parts = (int)g->dim_parts.size();
   const int64_t chunk = std::max<int64_t>(64, std::min<int64_t>(F, (int64_t)(1.5e9 / (4.0 * (double)g->G * parts))));
   int max_dp = 0;
@@ -2884,7 +2894,7 @@ void gmm_dim_split_score(aasr_gmm *g, const float *d_frames, int64_t F, float *d
     const int64_t n = fc * n_out;
     hipLaunchKernelGGL(k_dim_split_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g->dim_part_ll.p, parts,
                        fc, g->G, g->dim_mix_off.p, g->dim_mix_idx.p, g->dim_mix_logw.p, g->S, d_out + f0 * n_out,
-                       per_gaussian ? 1 : 0, g->xf_a.p ? (float)g->out_bias_ln : 0.0f);
+                       per_gaussian ? 1 : 0, g->xf_a.p ? (float)g->out_bias_ln : 0.0f, maskw, c1, gclus, f0);
     AASR_HIP(hipGetLastError());
   }
 }
@@ -2893,7 +2903,12 @@ void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
                       hipStream_t stream) {
   if (F <= 0) return;
   if (!g->dim_parts.empty()) {
-    if (g->cl.enabled) raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering is built for feature dimensions <= 63");
+    if (g->cl.enabled) {
+      if (g->precision == AASR_PREC_F64 || g->xf_a.p)
+        raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering on a model of more than 63 dimensions: unadapted pools, float arithmetic");
+      gmm_cluster_score_launch(g, d_frames, F, d_out, stream);
+      return;
+    }
     if (g->precision == AASR_PREC_F64) {   // the reference's arithmetic in double: instances up to 192 dimensions
       score_f64_for_f32_callers(g, d_frames, F, d_out, stream);
       return;

@@ -416,9 +416,22 @@ def test_dimensions_beyond_63(capi, oracle, D):
     want = om.gauss_loglik(frames[:20].astype(np.float64))
     vis = want > -200
     assert np.abs(gl - want)[vis].max() <= 1e-4 * np.maximum(1.0, np.abs(want[vis]) / 100).max()
-    # what is not built for wide vectors says so
-    with pytest.raises(capi.AasrError):
-        g.set_clustering(4, [(i, i % 4) for i in range(160)])
+    # Gaussian clustering on the wide model: centres from the vector kernel, the selection masks applied where the
+    # parts are added per component, log-domain merge; scores and exact-evaluation counts as the oracle's
+    if D <= 200:
+        g.set_precision(4)
+        g2c = synth.make_clustering(mean, 12, seed=3)
+        g2c[::19] = -1
+        pairs = [(int(i), int(c)) for i, c in enumerate(g2c) if c >= 0]
+        for minc, ming in ((0.0, 0.25), (0.3, 0.0), (1.0, 1.0)):
+            om.set_clustering(12, pairs, minc, ming)
+            want_c, want_n = om.score_clustered(frames.astype(np.float64), want_counts=True)
+            g.set_clustering(12, pairs)
+            g.set_clustering_min_evals(minc, ming)
+            got_c = g.score(frames)
+            assert np.array_equal(g.cluster_exact_counts(len(frames)), want_n), (D, minc, ming)
+            assert_ll(got_c, want_c, "D = %d clustered (%g, %g)" % (D, minc, ming))
+        g.set_clustering(0, [])
     # AASR_PREC_F64 (the reference's arithmetic in double) has instances up to 192 dimensions
     if D <= 192:
         g.set_precision(1)
