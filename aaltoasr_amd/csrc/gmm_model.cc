@@ -505,8 +505,8 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
   if ((int64_t)m.mix_off.size() != m.S + 1)
     raise(AASR_ERR_INVALID, "mix_off must hold num_states+1 entries");
   g->dim_parts.clear();
-  if (m.dim + 1 > 64 && (m.any_full() || m.n_transforms > 0))
-    raise(AASR_ERR_UNSUPPORTED, "feature dimension %d > 63 is built for unadapted diagonal pools only", m.dim);
+  if (m.dim + 1 > 64 && m.any_full())
+    raise(AASR_ERR_UNSUPPORTED, "feature dimension %d > 63 is built for diagonal pools only", m.dim);
   for (size_t k = 0; k < m.mix_idx.size(); k++)
     if (m.mix_idx[k] < 0 || m.mix_idx[k] >= m.G)
       raise(AASR_ERR_INVALID, "mixture component %zu points at Gaussian %d outside the pool of %ld",
@@ -521,8 +521,40 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
     }
     m.weights_normalized = true;
   }
+  if (m.n_transforms > 0) {
+    if ((int64_t)m.g2t.size() != m.G ||
+        (int64_t)m.xform.size() != (int64_t)m.n_transforms * m.dim * (m.dim + 1))
+      raise(AASR_ERR_INVALID, "transform arrays do not match the model");
+    for (int32_t t : m.g2t)
+      if (t < -1 || t >= m.n_transforms) raise(AASR_ERR_INVALID, "transform index %d out of range", t);
+  }
   if (m.dim + 1 > 64) {
+    // the model as dimension parts (gmm_dim_split_score).  Regression classes: every class is such a model over its
+    // own Gaussians and adapted frames (class routing); one transform for the whole pool: the frames transformed once
+    m.logw_bias = 0;
+    g->xf_a.release();
+    g->xf_b.release();
+    g->class_routing = false;
+    if (m.n_transforms > 0 && !m.global_xform()) {
+      build_class_routing(g);
+      return;
+    }
+    g->class_models.clear();
+    g->class_g2t.clear();
     build_dim_split(g);
+    if (m.n_transforms > 0) {
+      const int D = m.dim;
+      std::vector<double> A((size_t)D * D), b((size_t)D);
+      double det = 1;
+      for (int i = 0; i < D; i++) {
+        b[(size_t)i] = m.xform[(size_t)i * (D + 1)];
+        for (int j = 0; j < D; j++) A[(size_t)i * D + j] = m.xform[(size_t)i * (D + 1) + 1 + j];
+        det *= A[(size_t)i * D + i];
+      }
+      g->xf_a.upload(A.data(), A.size());
+      g->xf_b.upload(b.data(), b.size());
+      g->out_bias_ln = std::log(std::fabs(det));
+    }
     return;
   }
   // centring pivot: per-dimension mean of the pool means, rounded to float so
@@ -537,13 +569,6 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
   if (m.any_full() &&
       ((int64_t)m.cov.size() != m.G * m.dim * m.dim || (int64_t)m.is_full.size() != m.G))
     raise(AASR_ERR_INVALID, "covariance array does not match the pool size");
-  if (m.n_transforms > 0) {
-    if ((int64_t)m.g2t.size() != m.G ||
-        (int64_t)m.xform.size() != (int64_t)m.n_transforms * m.dim * (m.dim + 1))
-      raise(AASR_ERR_INVALID, "transform arrays do not match the model");
-    for (int32_t t : m.g2t)
-      if (t < -1 || t >= m.n_transforms) raise(AASR_ERR_INVALID, "transform index %d out of range", t);
-  }
   m.logw_bias = 0;
   g->xf_a.release();
   g->xf_b.release();
@@ -1575,8 +1600,15 @@ void gmm_set_transforms(aasr_gmm *g, int32_t n_transforms, const int32_t *gauss_
   if (!g->dim_parts.empty()) {
     // feature dimension > 63 (the model as parts, gmm_dim_split_score): one transform for the whole pool is the frames
     // transformed once and |det| on every component; regression classes are not built there
-    if (n_transforms > 0 && !global)
-      raise(AASR_ERR_UNSUPPORTED, "per-class model-side CMLLR is built for feature dimensions <= 63");
+    if (n_transforms > 0 && !global) {   // regression classes: rebuild as class sub-models (gmm_build)
+      HostModel m = cur;
+      m.n_transforms = n_transforms;
+      m.g2t.assign(gauss_to_transform, gauss_to_transform + m.G);
+      m.xform.assign(W, W + (size_t)n_transforms * D * (D + 1));
+      g->pool_built = g->pool_centred_built = g->f64_built = false;
+      gmm_build(g, m);
+      return;
+    }
     cur.n_transforms = n_transforms;
     cur.g2t.clear();
     cur.xform.clear();

@@ -61,12 +61,18 @@ def test_global_transform(capi, oracle, D, G, S, comps):
     assert np.abs(got - plain).max() > 1e-2       # the transform does something
     g.set_cmllr()                                   # reset_transform
     assert np.array_equal(g.score(frames), plain)
-    if D > 63:   # the model as dimension parts: one transform for the pool is built, regression classes are refused
-        with pytest.raises(capi.AasrError):
-            g.set_cmllr((np.arange(G) % 2).astype(np.int32), _transforms(2, D, seed=2))
+    if D > 63:   # the model as dimension parts: regression classes become class sub-models of the same kind, and back
+        g2 = (np.arange(G) % 3 - 1).astype(np.int32)
+        W2 = _transforms(2, D, seed=2)
+        g.set_cmllr(g2, W2)
+        assert_ll(g.score(frames), _oracle_adapted(oracle, model, frames, g2, W2), "regression classes, D = %d" % D)
+        g.set_cmllr(g2t, W)
+        assert_ll(g.score(frames), ref, "back to one transform, D = %d" % D)
+        g.set_cmllr()
+        assert np.array_equal(g.score(frames), plain)
 
 
-@pytest.mark.parametrize("D,G,S,comps", [(13, 64, 8, 8), (39, 96, 12, 8)])
+@pytest.mark.parametrize("D,G,S,comps", [(13, 64, 8, 8), (39, 96, 12, 8), (80, 96, 12, 8)])
 def test_regression_classes_and_unadapted_gaussians(capi, oracle, D, G, S, comps):
     """Three regression classes assigned per Gaussian (UNIT_GAUSSIAN style), some
     Gaussians left unadapted: components of one mixture use different transforms."""
@@ -79,9 +85,9 @@ def test_regression_classes_and_unadapted_gaussians(capi, oracle, D, G, S, comps
     g = capi.Gmm.from_arrays(*model)
     g.set_cmllr(g2t, W)
     got = g.score(frames)
-    assert np.abs(got - ref).max() <= 1e-4
+    assert_ll(got, ref, "regression classes")
     g.set_precision(3)      # the per-class factor rows on the bf16 pipe (k_gmm_full_score_bf16x3)
-    assert np.abs(g.score(frames) - ref).max() <= 1e-4
+    assert_ll(g.score(frames), ref, "regression classes, three-term rows")
 
 
 def test_zero_diagonal_kills_the_adapted_gaussians(capi, oracle):
