@@ -356,7 +356,8 @@ void gmm_build_pool(aasr_gmm *g);
 // maskw / c1 / gclus (Gaussian clustering): a component counts for a frame only where its cluster's selection bit is set;
 // no floor then (the merge adds the centres)
 void gmm_dim_split_score(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, bool per_gaussian, hipStream_t stream,
-                         const unsigned long long *maskw = nullptr, int c1 = 0, const int32_t *gclus = nullptr);
+                         const unsigned long long *maskw = nullptr, int c1 = 0, const int32_t *gclus = nullptr,
+                         bool frames_adapted = false);
 void gmm_build_pool_centred(aasr_gmm *g);
 void gmm_build_f64(aasr_gmm *g);
 void gmm_cluster_score_f64_launch(aasr_gmm *g, const double *d_frames, const double *d_members, int64_t F,

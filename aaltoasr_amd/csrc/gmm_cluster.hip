@@ -1040,8 +1040,8 @@ static void build_crow_comps(const aasr_gmm *g, const std::vector<int32_t> &comp
 
 void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
                         const int32_t *gauss_index, const int32_t *cluster_index) {
-  if (!g->dim_parts.empty() && (g->host.n_transforms > 0 || ((g->host.dim + 7) / 8 * 8) * (2 * 16 * 8 + 64 * 4) > 160 * 1024))
-    raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering on a model of %d dimensions: unadapted pools of up to ~300 dimensions", g->host.dim);
+  if (!g->dim_parts.empty() && ((g->host.dim + 7) / 8 * 8) * (2 * 16 * 8 + 64 * 4) > 160 * 1024)
+    raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering on a model of %d dimensions: up to ~300 dimensions", g->host.dim);
   ClusterState &cl = g->cl;
   if (n_clusters <= 0) {
     cl = ClusterState();
@@ -1581,7 +1581,8 @@ static void exact_part_launch(aasr_gmm *g, ClusterState &cl, const ExactPlan &p,
                               int c1, int64_t n, const float *fr_members, float *out, hipStream_t stream, int64_t pitch = 0) {
   const int64_t words = (n + 63) / 64;
   if (p.dimsplit) {
-    gmm_dim_split_score(g, fr_members, n, out, false, stream, maskw, c1, cl.crow_gauss.p);
+    // the members' frames arrive adapted where the pool has one transform (gmm_cluster_score_launch)
+    gmm_dim_split_score(g, fr_members, n, out, false, stream, maskw, c1, cl.crow_gauss.p, g->xf_a.p != nullptr);
     return;
   }
   if (p.full) {

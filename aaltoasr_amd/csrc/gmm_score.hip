@@ -2860,7 +2860,8 @@ __global__ __launch_bounds__(256) void k_dim_split_combine(const float *__restri
 }
 
 void gmm_dim_split_score(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, bool per_gaussian,
-                         hipStream_t stream, const unsigned long long *maskw, int c1, const int32_t *gclus) {
+                         hipStream_t stream, const unsigned long long *maskw, int c1, const int32_t *gclus,
+                         bool frames_adapted) {
   const int parts = (int)g->dim_parts.size();
   const int64_t chunk = std::max<int64_t>(64, std::min<int64_t>(F, (int64_t)(1.5e9 / (4.0 * (double)g->G * parts))));
   int max_dp = 0;
@@ -2870,7 +2871,7 @@ void gmm_dim_split_score(aasr_gmm *g, const float *d_frames, int64_t F, float *d
   g->dim_part_x.ensure((size_t)chunk * max_dp);
   g->dim_part_ll.ensure((size_t)parts * chunk * g->G);
   const int64_t n_out = per_gaussian ? g->G : g->S;
-  if (g->xf_a.p) {
+  if (g->xf_a.p && !frames_adapted) {
     // one transform for the whole pool: the Gaussians are evaluated on A f + b (k_affine_frames handles any dimension)
     if (per_gaussian) raise(AASR_ERR_UNSUPPORTED, "per-Gaussian log-likelihoods are not built for adapted pools");
     g->d_xframes.ensure((size_t)F * g->dim);
@@ -2904,8 +2905,8 @@ void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
   if (F <= 0) return;
   if (!g->dim_parts.empty()) {
     if (g->cl.enabled) {
-      if (g->precision == AASR_PREC_F64 || g->xf_a.p)
-        raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering on a model of more than 63 dimensions: unadapted pools, float arithmetic");
+      if (g->precision == AASR_PREC_F64)
+        raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering on a model of more than 63 dimensions: float arithmetic only");
       gmm_cluster_score_launch(g, d_frames, F, d_out, stream);
       return;
     }

@@ -302,14 +302,14 @@ def test_clustered_scoring_to_lna(capi, oracle, golden_dir, S, comps, G, C, nbyt
         assert d.max() <= 1 and (d == 0).mean() >= CODES_EQUAL_MIN
 
 
-def test_clustering_under_a_global_cmllr_transform(capi, oracle):
+@pytest.mark.parametrize("D", [20, 80])
+def test_clustering_under_a_global_cmllr_transform(capi, oracle, D):
     """phone_probs -C ... -S ... with a UNIT_NO (global) model transform: the pool's Gaussians are
     AdaptedGaussians -- members evaluated on A f + b and scaled by |prod diag A|
     (aku/ModelModules.hh:164-173) -- while the cluster centres are plain Gaussians ranked on the
     frame itself (aku/Distributions.cc:2688-2691).  Scores and per-frame exact counts against the
     oracle, whichever of clustering / transform is set first."""
-    D = 20
-    model = synth.make_model(D=D, G=1200, S=100, comps=12, seed=31)
+    model = synth.make_model(D=D, G=1200, S=100, comps=12, seed=31)   # D = 80: the model as dimension parts
     mean, var, off, idx, w = model
     g2c = synth.make_clustering(mean, 48)
     pairs = _pairs(g2c)
@@ -336,13 +336,14 @@ def test_clustering_under_a_global_cmllr_transform(capi, oracle):
             gm.set_precision(prec)
             got = gm.score(frames)
             assert np.array_equal(gm.cluster_exact_counts(len(frames)), want_n), (order, prec)
-            assert np.abs(got - want).max() <= TOL, (order, prec, np.abs(got - want).max())
+            assert_ll(got, want, "%s, precision %d" % (order, prec))
         gm.set_cmllr()                                  # back to the unadapted model
-        assert np.abs(gm.score(frames) - plain).max() <= TOL
+        assert_ll(gm.score(frames), plain, "back to the unadapted model")
         gm.close()
 
 
-def test_clustering_under_per_class_cmllr_transforms(capi, oracle):
+@pytest.mark.parametrize("D", [20, 80])
+def test_clustering_under_per_class_cmllr_transforms(capi, oracle, D):
     """Regression-class transforms (UNIT_GAUSSIAN / UNIT_MIX / UNIT_PHONE speaker files) with -C: the
     Gaussians of one mixture -- and of one cluster -- may belong to different classes.  Each member is
     evaluated on its own class's A f + b and scaled by that class's |det|, Gaussians without a
@@ -350,7 +351,6 @@ def test_clustering_under_per_class_cmllr_transforms(capi, oracle):
     aku/Distributions.cc:2684-2722).  Scores and exact counts against the oracle in either order of
     set_clustering / set_cmllr, with a class change in between, a class whose determinant is 0, and
     back to the unadapted model."""
-    D = 20
     mean, var, off, idx, w = synth.make_model(D=D, G=1200, S=100, comps=12, seed=31)
     g2c = synth.make_clustering(mean, 48)
     g2c[5] = g2c[77] = -1
@@ -381,7 +381,7 @@ def test_clustering_under_per_class_cmllr_transforms(capi, oracle):
             gm.set_precision(prec)
             got = gm.score(frames)
             assert np.array_equal(gm.cluster_exact_counts(len(frames)), want_n), (order, prec)
-            assert np.abs(got - want).max() <= TOL, (order, prec, np.abs(got - want).max())
+            assert_ll(got, want, "%s, precision %d" % (order, prec))
         # another speaker: new matrices, a different class membership, one singular class
         g2t2 = rng.integers(0, 2, 1200).astype(np.int32)
         W2 = np.stack([transform(), transform()])
@@ -390,9 +390,9 @@ def test_clustering_under_per_class_cmllr_transforms(capi, oracle):
         gm.set_cmllr(g2t2, W2)
         got2 = gm.score(frames)
         assert np.array_equal(gm.cluster_exact_counts(len(frames)), n2)
-        assert np.abs(got2 - want2).max() <= TOL, np.abs(got2 - want2).max()
+        assert_ll(got2, want2, "second speaker")
         gm.set_cmllr()
-        assert np.abs(gm.score(frames) - plain).max() <= TOL
+        assert_ll(gm.score(frames), plain, "back to the unadapted model")
         gm.close()
 
 
