@@ -78,3 +78,11 @@ def test_subspace_pool_sweep(capi, oracle):
     worst, fails = _load("fuzz_subspace").run(2, 30)
     assert not fails, "\n".join(fails)
     assert max(worst["pcgmm"], worst["scgmm"], worst["mixed"]) <= 1e-4
+
+
+def test_wide_model_sweep(capi, oracle):
+    """tools/fuzz_wide.py: models of feature dimension 64 ... 200 (scored as dimension parts) -- plain, AASR_PREC_F64,
+    clustered, under one transform or regression classes, clustered under them."""
+    worst, fails = _load("fuzz_wide").run(3, 25)
+    assert not fails, fails[:5]
+

@@ -6,4 +6,5 @@ timeout 600 python tools/fuzz_features.py 9401 400 2>&1 | grep -i "failures\|FAI
 timeout 600 python tools/fuzz_recipe.py 9501 200 2>&1 | grep -i "failures\|FAIL" | tail -5 >> gpurun_out/soak/recipe.log
 timeout 600 python tools/fuzz_speakers.py 9601 80 2>&1 | grep -i "failures\|FAIL" | tail -5 >> gpurun_out/soak/speakers.log
 timeout 600 python tools/fuzz_subspace.py 9701 100 2>&1 | grep -i "failures\|FAIL" | tail -5 >> gpurun_out/soak/subspace.log
+timeout 600 python tools/fuzz_wide.py 9801 200 2>&1 | grep -i "failures\|FAIL" | tail -5 >> gpurun_out/soak/wide.log
 tail -n 20 gpurun_out/soak/*.log
