@@ -345,6 +345,9 @@ struct aasr_gmm {
   aasr::ClusterState cl;
   // staging for the host-buffer entry points
   aasr::DevBuf<float> d_frames, d_out;
+  // frame operand of the split-term kernels (k_frame_operand): the K x 64 operand of every block of 64 frames, formed
+  // once per launch; per-launch scratch, hence mutable
+  mutable aasr::DevBuf<uint32_t> fop_scratch;
 };
 
 namespace aasr {

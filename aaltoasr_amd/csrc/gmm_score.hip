@@ -1067,13 +1067,12 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
     const uint16_t *__restrict__ close_mask, const int32_t *__restrict__ sid, int sid_stride,
     float *__restrict__ out, int64_t S, int64_t pitch, float ref_ln, int dbg, ClusterArgs cl,
-    const float *__restrict__ f16tab) {
+    const u32x4 *__restrict__ fop) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   typedef PlSmem<NK16, GROUPED, WIDE, NS> SM;
   constexpr int OG = SM::OG;
   constexpr int kTileFloats = SM::kTileBytes / 4;
   constexpr int kOS = SM::kOutStride;
-  constexpr int KH = 8 * NK16;
   constexpr int NW = WIDE ? 8 : 4;
   constexpr int NPROD = NS * (NS + 1) / 2;       // products kept per slab: 3 (f16x2), 6 (bf16x3)
   constexpr int MPH = NK16 * NPROD * 2;          // MFMAs per phase (one 32-row block, two frame blocks)
@@ -1098,55 +1097,29 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   const int h = lane >> 5;  // K half of a slab held by this lane AND its row track
   const int64_t f0 = (int64_t)blockIdx.x * (NW * FRAMES_PER_WAVE) + wave * FRAMES_PER_WAVE;
 
-  // ---- frame operand: lane (n, h) holds k = 16*j + 8*h + i, i < 8, of slab j
-  u32x4 bq[NK16][NS][2];
-#pragma unroll
-  for (int nb = 0; nb < 2; nb++) {
-    int64_t f = f0 + nb * 32 + n;
-    if (f > F - 1) f = F - 1;
-    const float *xr = frames + f * dim;
-#pragma unroll
-    for (int j = 0; j < NK16; j++) {
-      float v[8];
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const int k = 16 * j + 8 * h + i;
-        const int d = k < KH ? k : k - KH;
-        const int dc = d < dim ? d : 0;
-        const float xc = xr[dc] - pivot[dc];
-        float xq = xc;
-        if (NS == 2) {  // fp16 range: the dimension's clamp (see the f16x2 note above and pack_f16x2)
-          const float lim = f16tab[2 * KH + dc];
-          xq = fminf(fmaxf(xc, -lim), lim);
-        }
-        float val = k < KH ? xq : xq * xq;
-        if (d >= dim) val = (k == dim || (NS == 2 && k == KH + dim)) ? 1.0f : 0.0f;
-        if (NS == 2) val *= f16tab[k];   // the column's power-of-two scale (the rows carry its inverse): exact
-        v[i] = val;
-      }
-      if constexpr (NS == 3) {
-        unsigned w1[4], w2[4], w3[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) split3_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i], w3[i]);
-        bq[j][0][nb] = u32x4{w1[0], w1[1], w1[2], w1[3]};
-        bq[j][1][nb] = u32x4{w2[0], w2[1], w2[2], w2[3]};
-        bq[j][2][nb] = u32x4{w3[0], w3[1], w3[2], w3[3]};
-      } else {
-        unsigned w1[4], w2[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) split2_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i]);
-        bq[j][0][nb] = u32x4{w1[0], w1[1], w1[2], w1[3]};
-        bq[j][1][nb] = u32x4{w2[0], w2[1], w2[2], w2[3]};
-      }
-    }
-  }
-
+  // The first two tiles are requested before anything else: they land while the frame operand is being built.
   const int64_t t_begin = split_row[4 * blockIdx.y];
   const int64_t t_end = split_row[4 * blockIdx.y + 4];
   const float *apf = (const float *)apack;
   if (t_begin < t_end) issue_tile_copy_raw(apf + (size_t)t_begin * kTileFloats, abuf0, kTileFloats, wave, lane, NW);
   if (t_begin + 1 < t_end)
     issue_tile_copy_raw(apf + (size_t)(t_begin + 1) * kTileFloats, abuf0 + kTileFloats, kTileFloats, wave, lane, NW);
+
+  // ---- frame operand: lane (n, h) holds k = 16*j + 8*h + i, i < 8, of slab j -- split into its terms ONCE per launch by
+  // k_frame_operand (below the kernel) and fetched here with 16-byte loads, 64 lanes x 16 B contiguous per instruction.
+  // Built in place (one 4-byte load per K slot at a lane-dependent address, ~2 000 instructions) it cost every workgroup
+  // ~20 us -- six tiles' time in front of every row cut, paid R times per frame.
+  u32x4 bq[NK16][NS][2];
+  {
+    const u32x4 *bw = fop + ((size_t)blockIdx.x * NW + wave) * (NK16 * NS * 2 * 64) + lane;
+#pragma unroll
+    for (int j = 0; j < NK16; j++)
+#pragma unroll
+      for (int sp = 0; sp < NS; sp++)
+#pragma unroll
+        for (int nb = 0; nb < 2; nb++) bq[j][sp][nb] = bw[((j * NS + sp) * 2 + nb) * 64];
+  }
+
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -1405,6 +1378,102 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   }
 }
 
+// ---------------------------------------------------------------------------
+// Frame operand of the split-term kernels, formed once per launch: for every block of 64 frames the K x 64 operand in
+// the register layout of k_gmm_diag_score_pl -- [block][slab j][term][frame half nb][lane (n, h)] x 8 halves, K slot
+// k = 16 j + 8 h + i -- so that a wave's prologue is NK16 * NS * 2 coalesced 16-byte loads.  Per value the arithmetic of
+// the former in-kernel prologue: (x - pivot), the dimension's clamp and the column's power-of-two scale (f16x2), the
+// square for k >= KH, 1 in the constant's slot(s), then the two fp16 / three bf16 terms.  Frames past the end repeat the
+// last one (their results are never stored).  One thread per (frame, slab, K half).
+// ---------------------------------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__(256) void k_frame_operand(const float *__restrict__ frames, int64_t F, int dim,
+                                                       const float *__restrict__ pivot, const float *__restrict__ f16tab,
+                                                       int nk16, u32x4 *__restrict__ out, int64_t n_units) {
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = (int)(tid & 63);
+  const int64_t unit = tid >> 6;   // (block of 64 frames, frame half, slab)
+  if (unit >= n_units) return;
+  const int j = (int)(unit % nk16);
+  const int nb = (int)((unit / nk16) & 1);
+  const int64_t blk = unit / (2 * nk16);
+  const int n = lane & 31, h = lane >> 5;
+  const int KH = 8 * nk16;
+  int64_t f = blk * 64 + nb * 32 + n;
+  if (f > F - 1) f = F - 1;
+  const float *xr = frames + f * dim;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int k = 16 * j + 8 * h + i;
+    const int d = k < KH ? k : k - KH;
+    const int dc = d < dim ? d : 0;
+    const float xc = xr[dc] - pivot[dc];
+    float xq = xc;
+    if (NS == 2) {  // fp16 range: the dimension's clamp (see the f16x2 note above and pack_f16x2)
+      const float lim = f16tab[2 * KH + dc];
+      xq = fminf(fmaxf(xc, -lim), lim);
+    }
+    float val = k < KH ? xq : xq * xq;
+    if (d >= dim) val = (k == dim || (NS == 2 && k == KH + dim)) ? 1.0f : 0.0f;
+    if (NS == 2) val *= f16tab[k];   // the column's power-of-two scale (the rows carry its inverse): exact
+    v[i] = val;
+  }
+  u32x4 *o = out + ((size_t)(blk * nk16 + j) * NS * 2 + nb) * 64 + lane;   // + term * 2 * 64
+  if constexpr (NS == 3) {
+    unsigned w1[4], w2[4], w3[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) split3_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i], w3[i]);
+    o[0] = u32x4{w1[0], w1[1], w1[2], w1[3]};
+    o[2 * 64] = u32x4{w2[0], w2[1], w2[2], w2[3]};
+    o[4 * 64] = u32x4{w3[0], w3[1], w3[2], w3[3]};
+  } else {
+    unsigned w1[4], w2[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) split2_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i]);
+    o[0] = u32x4{w1[0], w1[1], w1[2], w1[3]};
+    o[2 * 64] = u32x4{w2[0], w2[1], w2[2], w2[3]};
+  }
+}
+
+// frame operand of `blocks64` blocks of 64 frames into the handle's scratch (grown as needed)
+template <int NS>
+static const u32x4 *frame_operand(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
+                                  int64_t blocks64, hipStream_t stream) {
+  const size_t per_block = (size_t)L.nk16 * NS * 2 * 64;   // u32x4 per 64 frames
+  if (blocks64 * per_block * 4 > g->fop_scratch.n) {
+    AASR_HIP(hipDeviceSynchronize());   // growing frees the old buffer
+    g->fop_scratch.ensure(blocks64 * per_block * 4);
+  }
+  const int64_t n_units = blocks64 * 2 * L.nk16;
+  hipLaunchKernelGGL(k_frame_operand<NS>, dim3((unsigned)((n_units * 64 + 255) / 256)), dim3(256), 0, stream, d_frames, F,
+                     g->dim, g->d_pivot.p, NS == 2 ? L.f16tab.p : nullptr, L.nk16, (u32x4 *)g->fop_scratch.p, n_units);
+  AASR_HIP(hipGetLastError());
+  return (const u32x4 *)g->fop_scratch.p;
+}
+
+// Row cuts of a launch: `blocks` frame blocks x R cuts are dealt to `slots` resident workgroups in rounds; a workgroup
+// costs its tiles plus a fixed part (launch, frame operand, first tile's latency, drain), `overhead` in units of one
+// tile's time.  Measured on configs[2] (878 blocks of 512 frames, 782 tiles, 256 slots; ms of the scoring kernel at
+// R = 2 / 4 / 8 / 16: 8.51 / 8.68 / 8.94 / 9.20): the fixed part was 6.6 tiles with the operand built in the kernel.
+// The former rule -- the R whose last round is fullest -- took R = 9 there (8.86 ms).
+static int pick_row_cuts(int64_t blocks, double slots, int64_t tiles, int max_splits, double overhead) {
+  static const int force_r = getenv("AASR_SPLITS") ? atoi(getenv("AASR_SPLITS")) : 0;
+  static const double force_c = getenv("AASR_CUT_OVERHEAD") ? atof(getenv("AASR_CUT_OVERHEAD")) : -1.0;
+  if (force_r >= 1 && force_r <= max_splits) return force_r;
+  if (force_c >= 0) overhead = force_c;
+  int R = 1;
+  double best = 1e300;
+  for (int r = 1; r <= max_splits; r++) {
+    const double cost = std::ceil((double)blocks * r / slots) * ((double)tiles / r + overhead);
+    if (cost < best * 0.999) {
+      best = cost;
+      R = r;
+    }
+  }
+  return R;
+}
+
 template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS>
 static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
                           float *d_out, hipStream_t stream, const ClusterArgs &cl, int64_t pitch) {
@@ -1419,19 +1488,8 @@ static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *
     AASR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set[g->device & 63] = true;
   }
-  static const int force_r = getenv("AASR_SPLITS") ? atoi(getenv("AASR_SPLITS")) : 0;
-  const double slots = (WIDE ? 1.0 : 2.0) * (g->num_cus > 0 ? g->num_cus : 256);
-  int R = 1;
-  double best_eff = 0;
-  for (int r = 1; r <= L.max_splits; r++) {
-    double x = (double)blocks * r / slots;
-    double eff = x / std::ceil(x);
-    if (eff > best_eff + 0.005) {
-      best_eff = eff;
-      R = r;
-    }
-  }
-  if (force_r >= 1 && force_r <= L.max_splits) R = force_r;
+  const int R = pick_row_cuts(blocks, (WIDE ? 1.0 : 2.0) * (g->num_cus > 0 ? g->num_cus : 256), L.rows_padded / TILE_ROWS,
+                              L.max_splits, 6.0);
   const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(NW * 64), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, NS == 3 ? L.a16.p : L.a16h.p, split_row, L.close.p, L.sid.p, L.sid_stride,
@@ -1455,23 +1513,13 @@ static void launch_pl_t(const aasr_gmm *g, const TrackLayout &L, const float *d_
     AASR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set[g->device & 63] = true;
   }
-  static const int force_r = getenv("AASR_SPLITS") ? atoi(getenv("AASR_SPLITS")) : 0;
-  const double slots = (WIDE ? 1.0 : 2.0) * (g->num_cus > 0 ? g->num_cus : 256);
-  int R = 1;
-  double best_eff = 0;
-  for (int r = 1; r <= L.max_splits; r++) {
-    double x = (double)blocks * r / slots;
-    double eff = x / std::ceil(x);
-    if (eff > best_eff + 0.005) {
-      best_eff = eff;
-      R = r;
-    }
-  }
-  if (force_r >= 1 && force_r <= L.max_splits) R = force_r;
+  const int R = pick_row_cuts(blocks, (WIDE ? 1.0 : 2.0) * (g->num_cus > 0 ? g->num_cus : 256), L.rows_padded / TILE_ROWS,
+                              L.max_splits, 3.0);
   const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
+  const u32x4 *fop = frame_operand<NS>(g, L, d_frames, F, blocks * NW, stream);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(NW * 64), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, NS == 3 ? L.a16.p : L.a16h.p, split_row, L.close.p, L.sid.p, L.sid_stride,
-                     d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, dbg, cl, NS == 2 ? L.f16tab.p : nullptr);
+                     d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, dbg, cl, fop);
   AASR_HIP(hipGetLastError());
 }
 

@@ -6,7 +6,7 @@ rows summing to one, LNA codes consistent with their own log-probabilities)."""
 import numpy as np
 import pytest
 
-from conftest import CODES_EQUAL_MIN, LL_FLUSH, TOL_LL, assert_ll
+from conftest import CODES_EQUAL_MIN, LL_FLUSH, TOL_LL, assert_ll, assert_lp_denormal_band
 
 from aaltoasr_amd import synth
 
@@ -111,6 +111,7 @@ def test_config2_one_hour_full_chain(capi, oracle):
     ch = oracle.FeatureChain(cfg)
     om = oracle.DiagModel(*model)
     equal_frac = []
+    n_band = 0
     for u in (0, 179, 359):
         fea = ch.generate(utts[u], 0, 1248)
         ll_ref, lik = om.score(fea, want_lik=True)
@@ -124,7 +125,10 @@ def test_config2_one_hour_full_chain(capi, oracle):
         lp = np.frombuffer(data4[5:], "<f4").reshape(1248, S)
         smooth = (ll_ref > -87.0) | (ll_ref < -104.5)     # outside the float-denormal band
         assert np.abs(lp - lp_ref)[smooth].max() <= 1e-4
-    print("configs[2] LNA codes identical to the oracle's:", equal_frac)
+        # ... and inside it what the contract allows: within one denormal quantum of the reference's float
+        n_band += assert_lp_denormal_band(lp, lik, "configs[2] utterance %d" % u)
+    print("configs[2] LNA codes identical to the oracle's:", equal_frac, "denormal-band values checked:", n_band)
+    assert n_band > 1000      # the 50 000-Gaussian model puts a share of every frame's states into the band
     assert min(equal_frac) >= CODES_EQUAL_MIN     # observed 0.9950; never more than one step apart (above)
     for u in range(360):
         data, n = capi.run_utterance(runner.feat, gmm, utts[u], lnabytes=2)
@@ -170,6 +174,7 @@ def test_one_hour_as_a_single_file(capi, oracle):
         lp_ref, _ = oracle.lna_encode(lik, True, 4)
         smooth = (ll_ref > -87.0) | (ll_ref < -104.5)
         assert np.abs(lp[first:first + cnt] - lp_ref)[smooth].max() <= 1e-4, first
+        assert_lp_denormal_band(lp[first:first + cnt], lik, "one-hour file, frames from %d" % first)
     base = feat.run(pcm, n - 2, 6, module="audiofile", dtype=np.float64)
     assert np.array_equal(base[2:], np.repeat(base[1:2], 4, 0))       # copy_borders: frames from eof on repeat eof - 1
     assert np.array_equal(base, ch.generate(pcm, n - 2, 6, module="audiofile"))

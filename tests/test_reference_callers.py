@@ -67,7 +67,7 @@ def test_decode_stream_acoustics_compile_against_the_adapters(tmp_path):
 @needs_ref
 def test_reference_mains_are_linked_with_the_engine(capi, oracle):
     for name in ("phone_probs_refmain", "feacat_refmain", "align_refmain", "vtln_refmain", "logl_refmain",
-                 "segfea_refmain", "quanteq_refmain", "feadot_refmain"):
+                 "segfea_refmain", "quanteq_refmain", "feadot_refmain", "random_feature_test_refmain"):
         assert os.access(os.path.join(REFBIN, name), os.X_OK), name
 
 
@@ -159,6 +159,36 @@ def test_reference_feacat_main_on_the_engine(world):
                            capture_output=True, timeout=300).stdout
     d = np.frombuffer(noisy, "<f4") - np.frombuffer(clean, "<f4")
     assert 0.4 < d.std() < 0.6 and abs(d.mean()) < 0.05
+
+
+@needs_ref
+def test_random_feature_test_source_compiles_against_the_adapters(tmp_path):
+    """aku/tests/random_feature_test.cc, text unchanged; it predates `namespace aku`, so the using-directive arrives
+    through oracle/ref_prelude_aku.hh (see oracle/Makefile)."""
+    text = open(os.path.join(REF, "aku", "tests", "random_feature_test.cc")).read()
+    r = subprocess.run(["g++", "-std=gnu++17", "-fsyntax-only", "-include", os.path.join(ROOT, "oracle", "ref_prelude_aku.hh"),
+                        "-x", "c++", "-I", AKU, "-"], input=text, capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    assert r.returncode == 0, r.stderr[-4000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [None, "1", "20260929"])
+def test_reference_random_feature_test_on_the_engine(seed, tmp_path):
+    """The fourth script of aku/tests/run_tests.sh: `./random_feature_test short.wav mfcc_p_dd.feaconf -10 80 1000`
+    (random_feature_test.script) must print random_feature_test.ref's one line.  The reference's main() fills a
+    FeatureBuffer with frames -10..79 in order and then regenerates 1000 frames in random order through the per-frame
+    API -- block misses, refills and the negative frames included -- and compares with `!=`: every regenerated value
+    has to be the same double.  Without a seed argument the program seeds itself from times(), as the script does."""
+    gold = os.path.join(ROOT, "tests", "golden")
+    cmd = [os.path.join(REFBIN, "random_feature_test_refmain"), os.path.join(gold, "short.wav"),
+           os.path.join(gold, "mfcc_p_dd.feaconf"), "-10", "80", "1000"] + ([seed] if seed else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-500:])
+    assert r.stdout == open(os.path.join(gold, "random_feature_test.ref")).read()
+    # a wider range than the script's: past the end of the 1.1 s file (border copies) and far before its start
+    cmd[3:6] = ["-40", "160", "3000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    assert r.returncode == 0 and r.stdout == "test successful\n", (r.stdout[-500:], r.stderr[-500:])
 
 
 @pytest.mark.gpu

@@ -150,7 +150,7 @@ def world(capi, oracle, tmp_path_factory):
                 model=(mean, var, model[2], model[3], model[4]))
 
 
-def _oracle_lna(oracle, world, spkc_text=None):
+def _oracle_lna(oracle, world, spkc_text=None, recipe=None):
     """What the reference loop produces for every recipe line (4-byte LNA values)."""
     ch = oracle.FeatureChain(CFG)
     om = oracle.DiagModel(*world["model"])
@@ -159,8 +159,8 @@ def _oracle_lna(oracle, world, spkc_text=None):
     outs = []
     # Recipe::read keeps a key's value on later lines that do not repeat it
     # (aku/Recipe.cc:31,82-90): the utterance=u7 of line 3 also applies to lines 4 and 5
-    infos = oracle.recipe_read(open(world["recipe"]).read())
-    assert [i.utterance_id for i in infos] == ["", "", "u7", "u7", "u7"]
+    infos = oracle.recipe_read(open(recipe or world["recipe"]).read())
+    assert [i.utterance_id for i in infos] == (["", "", "u7", "u7", "u7"] if recipe is None else [""] * 5)
     for pcm, info in zip(world["pcms"], infos):
         spk, utt = info.speaker_id, info.utterance_id
         sc.set_speaker(spk)
@@ -399,3 +399,67 @@ def test_module_classes_set_parameters_directly(capi, oracle, world, tmp_path):
     got2 = np.array([[float(x) for x in l.split()] for l in lines[9:11]])
     assert np.abs(got2 - want2).max() <= 1e-5 * max(1.0, np.abs(want2).max())
     assert np.abs(got2 - got[:2]).max() > 1e-3
+
+
+SHIPPED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spkc")
+
+
+@pytest.mark.parametrize("name", ["default_vtln.spkc", "default_mllr.spkc", "default_vtln+mllr.spkc",
+                                  "aku_scripts_vtln_default.spkc"])
+def test_speaker_files_the_reference_ships(capi, oracle, world, name, tmp_path):
+    """The speaker files that come with the reference (pyrectool/default_vtln.spkc, default_mllr.spkc,
+    default_vtln+mllr.spkc, aku/scripts/vtln_default.spkc; copied as data to tests/golden/spkc): a `speaker default` entry
+    with empty `feature vtln { }` / `feature mllr { }` / bare `vtln { }` blocks -- what pyrectool hands to phone_probs -S
+    before any adaptation has been estimated.  Every recipe speaker is unknown and takes the default entry, an empty block
+    resets its module (warp factor 1, identity transform), so the run has to give the oracle's SpeakerConfig loop on the same
+    file AND the unadapted run, file for file."""
+    text = open(os.path.join(SHIPPED, name)).read()
+    # the files hold no utterance entries: a recipe that names an utterance is refused, as in the reference
+    # ("Unknown utterance u7, and default utterance settings are missing", aku/SpeakerConfig.cc), so the recipe here
+    # carries speaker keys only
+    recipe = str(tmp_path / "r.recipe")
+    open(recipe, "w").write("".join("audio=%s lna=%s speaker=%s\n" % (world["dir"] / ("a%d.wav" % i), world["dir"] / ("a%d.lna" % i), w[0])
+                                    for i, w in enumerate(world["who"])))
+    want = _oracle_lna(oracle, world, spkc_text=text, recipe=recipe)
+    ft = capi.Feat.from_file(world["cfg"])
+    gm = capi.Gmm.from_files(world["base"] + ".gk", world["base"] + ".mc", world["base"] + ".ph")
+    sc = capi.SpeakerConfig(ft, gm)
+    sc.read_file(os.path.join(SHIPPED, name))
+    out = tmp_path / "spk"
+    os.makedirs(out)
+    st = capi.run_recipe(ft, gm, recipe, lnabytes=4, normalize=False, afname=True, out_dir=str(out), speakers=sc)
+    assert st.utterances == 5
+    with pytest.raises(capi.AasrError, match="Unknown utterance u7, and default utterance settings are missing"):
+        capi.run_recipe(ft, gm, world["recipe"], lnabytes=4, normalize=False, afname=True, out_dir=str(out), speakers=sc)
+    plain = tmp_path / "plain"
+    os.makedirs(plain)
+    ft2 = capi.Feat.from_file(world["cfg"])
+    gm2 = capi.Gmm.from_files(world["base"] + ".gk", world["base"] + ".mc", world["base"] + ".ph")
+    capi.run_recipe(ft2, gm2, recipe, lnabytes=4, normalize=False, afname=True, out_dir=str(plain))
+    for i, (fea, ll) in enumerate(want):
+        raw = open(out / ("a%d.lna" % i), "rb").read()
+        got = oracle.lna_decode(raw)
+        assert got.shape == ll.shape
+        ok = ll > -85
+        assert ok.mean() > 0.2 and np.abs(got - ll)[ok].max() <= 1e-4, (name, i)
+        assert raw == open(plain / ("a%d.lna" % i), "rb").read(), (name, i)
+    # the same file through the command-line tool, as pyrectool passes it (rectool.py:655-666)
+    cli = tmp_path / "cli"
+    os.makedirs(cli)
+    r = subprocess.run([os.path.join(BIN, "phone_probs"), "-b", world["base"], "-c", world["cfg"], "-r", recipe,
+                        "-a", "-o", str(cli), "--lnabytes=4", "-N", "-i", "1", "-S", os.path.join(SHIPPED, name)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for i in range(5):
+        assert open(cli / ("a%d.lna" % i), "rb").read() == open(out / ("a%d.lna" % i), "rb").read(), (name, i)
+
+
+def test_a_shipped_speaker_file_names_a_module_the_graph_lacks(capi, world):
+    """aku/scripts/vtln_default.spkc against a feature graph without a `vtln` module: the reference throws
+    "SpeakerConfig: unknown module requested: vtln" while reading the file (aku/SpeakerConfig.cc)."""
+    cfg = CFG.replace('module\n{\n  name vtln\n  type vtln\n  sources fft\n}\n', '').replace("sources vtln", "sources fft")
+    assert "vtln" not in cfg
+    ft = capi.Feat(cfg)
+    sc = capi.SpeakerConfig(ft)
+    with pytest.raises(capi.AasrError, match="unknown module requested: vtln"):
+        sc.read_file(os.path.join(SHIPPED, "aku_scripts_vtln_default.spkc"))
