@@ -174,6 +174,7 @@ def _declare(L: C.CDLL) -> None:
     L.aasr_gmm_score_f64.argtypes = [vp, vp, i64, vp]
     L.aasr_gmm_get_precision.argtypes = [vp]
     L.aasr_gmm_effective_precision.argtypes = [vp]
+    L.aasr_gmm_precision_states.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.aasr_free.argtypes = [vp]
     L.aasr_free.restype = None
     L.aasr_feat_get_parameters.argtypes = [vp, cp, C.POINTER(C.c_void_p), C.POINTER(i64)]
@@ -362,9 +363,19 @@ class Gmm:
         eligible, else bf16x3 (default)."""
         check(lib().aasr_gmm_set_precision(self._h, prec))
 
+    def get_precision(self) -> int:
+        return int(lib().aasr_gmm_get_precision(self._h))
+
     def effective_precision(self) -> int:
         """The arithmetic the diagonal scoring path actually runs under the current setting."""
         return int(lib().aasr_gmm_effective_precision(self._h))
+
+    def precision_states(self):
+        """(states the two-term fp16 rows cover under the current setting, states the load-time probe took out of
+        that form): per-state precision routing, aasr_gmm_precision_states."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(lib().aasr_gmm_precision_states(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def set_layouts(self, mask: int) -> None:
         """Diagnostic: restrict the scoring kernels the launcher may pick (bit 0

@@ -134,10 +134,27 @@ struct PackedRows {
   DevBuf<double> a64;
 };
 
+// A run of whole tiles of a mixed layout with its own row-cut table (per-state precision routing, gmm_build_mixed()).
+struct TrackSection {
+  int64_t tile_begin = 0, tile_end = 0;
+  int64_t states = 0;
+  DevBuf<int32_t> splits;    // [MAX_SPLITS][MAX_SPLITS+1][4], absolute tile indices
+  int max_splits = 1;
+};
+
 // Two-track row layout for the in-register epilogue (see gmm_build_tracks()).
 struct TrackLayout {
   bool ok = false;
   bool grouped = false;
+  // mixed layouts: section 0 = the states scored with two fp16 terms (a16h covers its tiles), section 1 = the others
+  // (three bf16 terms, a16 covers all tiles); `mapped` (grouped form): output columns, flush points and column masks of
+  // every state pair come from `pmap` ([2 tracks][pmap_stride][2], k_gmm_diag_score_pl<..., MAPPED>)
+  int n_sections = 0;
+  TrackSection sec[2];
+  bool mapped = false;
+  DevBuf<int32_t> pmap;
+  int32_t pmap_stride = 0;
+  int64_t states_f16 = 0;    // states the two-term fp16 rows cover (0: no a16h)
   PackedRows rows;
   // the same rows split into three bf16 terms for k_gmm_diag_score_bf16x3:
   // [tile][K/16 slabs][3 splits][2 row blocks][64 lanes][8 bf16]
@@ -218,7 +235,7 @@ struct ClusterState {
   DevBuf<double> bpack;            // ... packed as f64 MFMA operands: [tile of 16][k step][64 lanes]
   int mfma_ks = 0;                 // k steps of 4 covering 2 dim + 1
   DevBuf<int32_t> csize;           // [Cs] members per cluster (0 beyond C)
-  DevBuf<int32_t> crow[2];         // cluster of each packed row of the grouped / independent
+  DevBuf<int32_t> crow[3];         // cluster of each packed row of the grouped / independent / mixed
                                    // track layout (C = no cluster or null row)
   DevBuf<int32_t> crow_full;       // ... of the factor rows of a full-covariance pool
   DevBuf<int32_t> crow_hyb, crow_centred;  // the same for the records of the centred kernel: the
@@ -266,6 +283,10 @@ struct aasr_gmm {
   // track layouts for the in-register epilogue (built when eligible)
   aasr::TrackLayout paired;   // grouped: states 2j/2j+1 side by side
   aasr::TrackLayout tracks;   // independent tracks (built when `paired` is not)
+  aasr::TrackLayout mixed;    // per-state precision routing: built when only part of the states qualify for f16x2
+  int64_t f16_bad_state = -1; // builder scratch: the state whose rows failed the fp16 range / clamp conditions
+  std::vector<uint8_t> f16_state_ok;   // per state: eligible for the two-term fp16 form (conditioning limits, probe)
+  int64_t f16_probe_moved = 0;         // states the load-time probe (gmm_probe_f16x2) took out of the fp16 form
   // full-covariance path (k_gmm_full_score): rows are the rows of R^-1 of
   // every component, see gmm_build_fullcov()
   aasr::FullLayout full;
@@ -374,6 +395,8 @@ void gmm_f64_classes_masked_launch(aasr_gmm *g, const double *d_frames, int64_t 
 void gmm_score_f64_launch(aasr_gmm *g, const double *d_frames, int64_t F, double *d_out, int linear,
                           hipStream_t stream);
 void gmm_build_tracks(aasr_gmm *g, bool grouped);
+void gmm_build_mixed(aasr_gmm *g, std::vector<uint8_t> &f16_ok);
+void gmm_probe_f16x2(aasr_gmm *g);
 void gmm_build_centred(aasr_gmm *g);
 void gmm_build_fullcov(aasr_gmm *g);
 void gmm_full_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,

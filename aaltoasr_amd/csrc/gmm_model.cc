@@ -376,7 +376,7 @@ struct RowSpec {
 // with K index k = 2*kk + h:  kk<dim: h=0 -> p*mu'*log2e, h=1 -> -p/2*log2e;
 // kk==dim: h=0 -> constant*log2e; everything else 0.
 static void pack_rows(const aasr_gmm *g, const std::vector<RowSpec> &rows,
-                      PackedRows &out, std::vector<double> *a64_host) {
+                      PackedRows &out, std::vector<double> *a64_host, bool upload_f32 = true) {
   const HostModel &m = g->host;
   const int D = m.dim;
   const int nkk = pick_nkk(D);
@@ -439,6 +439,7 @@ static void pack_rows(const aasr_gmm *g, const std::vector<RowSpec> &rows,
 }
 
 void gmm_build_tracks(aasr_gmm *g, bool grouped);
+static void f16x2_state_eligibility(const aasr_gmm *g, std::vector<uint8_t> &ok);
 static void find_outliers(aasr_gmm *g);
 static void build_class_routing(aasr_gmm *g);
 
@@ -652,8 +653,21 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
   g->mix.chunk_seg_begin.upload(chunk_seg_begin.data(), chunk_seg_begin.size());
   g->mix.seg_desc.upload(seg_desc.data(), seg_desc.size());
   g->mix.seg_out.upload(seg_out.data(), seg_out.size());
+  g->f16_bad_state = -1;
   gmm_build_tracks(g, true);
   if (!g->paired.ok) gmm_build_tracks(g, false);
+  // per-state precision routing: where the model as a whole does not get the two-term fp16 rows, the states that
+  // qualify on their own still do (the mixed layout); AASR_PREC_F16X2 then runs both sections
+  g->mixed = TrackLayout();
+  g->cl.crow[2] = DevBuf<int32_t>();
+  f16x2_state_eligibility(g, g->f16_state_ok);
+  {
+    const TrackLayout &L0 = g->paired.ok ? g->paired : g->tracks;
+    if (L0.ok && L0.a16.p && !L0.a16h.p) {
+      if (g->f16_bad_state >= 0) g->f16_state_ok[(size_t)g->f16_bad_state] = 0;   // range / clamp failure of one state's rows
+      gmm_build_mixed(g, g->f16_state_ok);
+    }
+  }
   gmm_build_centred(g);
   g->rows_unbiased = m.logw_bias == 0;
   // profiling hook: AASR_LAYOUTS=<mask> restricts the kernels like
@@ -667,6 +681,7 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
     g->layout_mask = atoi(e);
     if ((g->layout_mask & 2) && !g->tracks.ok) gmm_build_tracks(g, false);
   }
+  gmm_probe_f16x2(g);   // load-time guard of the two-term fp16 rows
 }
 
 // Track layouts for the in-register epilogue (k_gmm_diag_score_tracks).
@@ -718,16 +733,16 @@ static bool choose_reference(const HostModel &m, const std::vector<uint8_t> &out
 // round on the 256 CUs).  cand_* list the legal cut points (tile index and the
 // number of states each track has closed before it); row R-1 of the table holds
 // R+1 entries {tile, closes track 0, closes track 1, 0}.
-static void build_split_table(TrackLayout &L, int64_t tiles, const std::vector<int64_t> &cand_tile,
-                              const std::vector<int64_t> &cand_k0,
+static void build_split_table(DevBuf<int32_t> &splits, int *max_splits, int64_t tiles,
+                              const std::vector<int64_t> &cand_tile, const std::vector<int64_t> &cand_k0,
                               const std::vector<int64_t> &cand_k1) {
   std::vector<int32_t> table((size_t)TRACK_MAX_SPLITS * (TRACK_MAX_SPLITS + 1) * 4, 0);
-  L.max_splits = 1;
+  *max_splits = 1;
   for (int R = 1; R <= TRACK_MAX_SPLITS; R++) {
     std::vector<size_t> pick{0};
     bool ok = true;
     for (int i = 1; i < R && ok; i++) {
-      double want = (double)tiles * i / R;
+      double want = (double)cand_tile.front() + (double)tiles * i / R;
       size_t best = pick.back();
       double bd = 1e300;
       for (size_t c = pick.back() + 1; c + 1 < cand_tile.size(); c++) {
@@ -748,9 +763,9 @@ static void build_split_table(TrackLayout &L, int64_t tiles, const std::vector<i
       row[4 * i + 1] = (int32_t)cand_k0[pick[i]];
       row[4 * i + 2] = (int32_t)cand_k1[pick[i]];
     }
-    L.max_splits = R;
+    *max_splits = R;
   }
-  L.splits.upload(table.data(), table.size());
+  splits.upload(table.data(), table.size());
 }
 
 // Three-term bf16 split of the coefficient rows for the bf16x3 kernel.  coef64
@@ -811,17 +826,20 @@ static void pack_bf16x3(int D, const std::vector<double> &coef64, int64_t tiles,
 }
 
 // Two-term fp16 split of the same rows for the f16x2 form (AASR_PREC_F16X2): same K order and tile layout with two
-// splits; the constant's remainder after its two terms goes to K slot KH + D (the frame operand is 1 there too).
-// Returns false -- and packs nothing -- when a value leaves the fp16 range, or when a frame component clamped at
-// kF16Clamp from the pivot could still be visible above the 1e-50 floor for some row (the clamp must never change
-// a result the reference's float storage holds).
-static bool pack_f16x2(const aasr_gmm *g, const std::vector<RowSpec> &rows, const std::vector<double> &coef64,
-                       int64_t tiles, TrackLayout &L) {
+// splits; the constant's remainder after its two terms goes to K slot KH + D (the frame operand is 1 in both).
+// Covers the tiles [0, tiles) of the layout -- the whole layout, or the first section of a mixed one; rows with
+// rs.g < 0 (and every row of a state that is not in `st_ok`, when given) are null rows.  Returns false -- and packs
+// nothing -- when a value leaves the fp16 range, or when a frame component clamped at kF16Clamp from the pivot could
+// still be visible above the 1e-50 floor for some row (the clamp must never change a result the reference's float
+// storage holds); `bad_state` then names the state of the first offending row (-1: no single state to blame).
+static bool pack_f16x2(const aasr_gmm *g, const std::vector<RowSpec> &rows, const std::vector<int32_t> &row_state,
+                       const std::vector<double> &coef64, int64_t tiles, TrackLayout &L, int64_t *bad_state) {
   const HostModel &m = g->host;
   const int D = m.dim;
   const int nk16 = L.nk16;
   L.a16h = DevBuf<uint16_t>();
   L.f16tab = DevBuf<float>();
+  *bad_state = -1;
   if (nk16 <= 0) return false;
   const int KH = 8 * nk16;
   if (KH + D >= 2 * KH) return false;  // no spare slot for the constant's remainder
@@ -867,7 +885,9 @@ static bool pack_f16x2(const aasr_gmm *g, const std::vector<RowSpec> &rows, cons
   for (int k = 0; k < 2 * KH; k++) {
     int e = 0;
     if (max_a[(size_t)k] > 0) e = (int)std::ceil(std::log2(max_a[(size_t)k] / 128.0));
-    e = std::max(-14, std::min(14, e));
+    // the constant's column carries the null rows' -60000 as well: its scale must leave 2^(-60000 * 2^s) = 0 in f32
+    // (a model whose live constants are all tiny would otherwise get s = -14 and a null row worth 2^-3.7)
+    e = std::max(k == D ? -8 : -14, std::min(14, e));
     sk[(size_t)k] = e;
     tab[(size_t)k] = (float)std::ldexp(1.0, e);
   }
@@ -892,7 +912,10 @@ static bool pack_f16x2(const aasr_gmm *g, const std::vector<RowSpec> &rows, cons
         const double v = m.var[(size_t)rs.g * D + d];
         const double p = v > 0 ? 1 / v : 0;
         const double reach = (double)tab[(size_t)2 * KH + d] - std::fabs(m.mean[(size_t)rs.g * D + d] - (double)g->pivot[d]);
-        if (!(reach > 0) || !(peak - 0.5 * p * reach * reach < -160.0)) return false;
+        if (!(reach > 0) || !(peak - 0.5 * p * reach * reach < -160.0)) {
+          *bad_state = row_state[(size_t)r];
+          return false;
+        }
       }
     }
     const int64_t t = r / TILE_ROWS;
@@ -903,7 +926,10 @@ static bool pack_f16x2(const aasr_gmm *g, const std::vector<RowSpec> &rows, cons
       double v = std::ldexp(coef_of(c, k, const_rem), k == KH + D ? 0 : -sk[(size_t)k]);
       // null / zero-weight rows carry kNullConst: any constant whose 2^x is zero in f32 does
       if (k == D && c[2 * D] <= -1.0e29) v = -60000.0;
-      if (!(std::fabs(v) <= 60000.0)) return false;
+      if (!(std::fabs(v) <= 60000.0)) {
+        *bad_state = rs.g >= 0 ? row_state[(size_t)r] : -1;
+        return false;
+      }
       const _Float16 h1 = (_Float16)v;
       const _Float16 h2 = (_Float16)(v - (double)h1);
       // what the two terms left of the constant goes to slot KH + D in that slot's own scale
@@ -929,105 +955,181 @@ static inline int64_t track_row(int64_t pos, int h, int e) {
   return t * TILE_ROWS + mb * 32 + 8 * q + 4 * h + e;
 }
 
-void gmm_build_tracks(aasr_gmm *g, bool grouped) {
+// Which states the two-term fp16 form may score (gmm.h, KAPPA_LIMIT_F16): every Gaussian of the state that stays on
+// the matrix path is below the conditioning limits.  Range and clamp conditions are checked when the rows are packed.
+static void f16x2_state_eligibility(const aasr_gmm *g, std::vector<uint8_t> &ok) {
   const HostModel &m = g->host;
-  TrackLayout &L = grouped ? g->paired : g->tracks;
+  const int D = m.dim;
+  const double lim2 = m.dim < 8 ? KAPPA2_LIMIT_F16_LOWDIM : KAPPA2_LIMIT_F16;
+  std::vector<uint8_t> g_ok((size_t)m.G, 1);
+  for (int64_t i = 0; i < m.G; i++) {
+    if (!g->outlier.empty() && g->outlier[(size_t)i]) continue;   // a null row in every matrix layout
+    double k = 0, k2 = 0;
+    for (int d = 0; d < D; d++) {
+      const double v = m.var[(size_t)i * D + d];
+      const double p = v > 0 ? 1 / v : 0;
+      const double mc = m.mean[(size_t)i * D + d] - (double)g->pivot[d];
+      k += p * mc * mc;
+      k2 += (p * mc * mc) * (p * mc * mc);
+    }
+    g_ok[(size_t)i] = k <= KAPPA_LIMIT_F16 && std::sqrt(k2) <= lim2;
+  }
+  ok.assign((size_t)m.S, 1);
+  for (int64_t s = 0; s < m.S; s++)
+    for (int32_t k = m.mix_off[s]; k < m.mix_off[s + 1]; k++)
+      if (!g_ok[(size_t)m.mix_idx[k]]) ok[(size_t)s] = 0;
+}
+
+// Builds the grouped (paired), the independent or -- `f16_ok` given -- the MIXED layout:
+//
+//   mixed: per-state precision routing.  The states whose Gaussians all qualify for the two-term fp16 form
+//   (f16_ok[s]) make up section 0, the others section 1; a section is a run of whole tiles of the same layout, with its
+//   own row-cut table, and is scored by its own launch (f16x2 rows for section 0, bf16x3 rows for section 1).  In the
+//   grouped form the states of a section are a subset of the model's, so pairs are formed from neighbours IN THE
+//   SECTION that share a group of 16 output columns (a lone state takes a pair with an empty partner track), and the
+//   kernel takes a pair's output columns, its flush points and the mask of the columns its section owns from the
+//   pair table `pmap` (k_gmm_diag_score_pl<..., MAPPED>).  A model in which one Gaussian breaks the fp16 limits then
+//   costs that Gaussian's STATE the three-term arithmetic, not the whole model.
+static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const std::vector<uint8_t> *f16_ok) {
+  const HostModel &m = g->host;
   L.ok = false;
   L.grouped = grouped;
+  L.mapped = false;
+  L.n_sections = 0;
+  L.states_f16 = 0;
   double ref = 0;
   if (!choose_reference(m, g->outlier, &ref)) return;
   L.ref_ln = (float)(ref * 0.69314718055994530942);
   const int64_t rows_real = std::max<int64_t>(1, (int64_t)m.mix_idx.size());
+  const bool mixed = f16_ok != nullptr;
 
-  // ---- placement: (track, first quad, quads) per state
+  // ---- the sections' states, ascending
+  std::vector<int64_t> order[2];
+  for (int64_t s = 0; s < m.S; s++) order[mixed && !(*f16_ok)[(size_t)s] ? 1 : 0].push_back(s);
+  const int n_sec = mixed ? 2 : 1;
+  if (mixed && (order[0].empty() || order[1].empty())) return;   // nothing to route
+
+  // ---- placement: (track, first quad) per state; close events; cut candidates per section
   std::vector<int8_t> st_track((size_t)m.S);
   std::vector<int64_t> st_pos((size_t)m.S);
   int64_t len[2] = {0, 0};
-  std::vector<int64_t> cand_tile{0}, cand_k0{0}, cand_k1{0};
   int64_t closed[2] = {0, 0};
+  struct Cand { std::vector<int64_t> tile, k0, k1; };
+  Cand cand[2];
+  struct PairEv { int64_t s0, s1, last; bool f16, f32; };   // grouped: the pair's states, its last quad, its flush flags
+  std::vector<PairEv> pairs;
+  int64_t sec_tile[3] = {0, 0, 0};
+  int64_t quads_used = 0;   // quad positions before the sections were rounded up to whole tiles
   auto quads_of = [&](int64_t s) {
     return std::max<int64_t>(1, ((int64_t)(m.mix_off[s + 1] - m.mix_off[s]) + 3) / 4);
   };
-  if (grouped) {
-    for (int64_t j = 0; 2 * j < m.S; j++) {
-      int64_t q = quads_of(2 * j);
-      if (2 * j + 1 < m.S) q = std::max(q, quads_of(2 * j + 1));
-      for (int h = 0; h < 2 && 2 * j + h < m.S; h++) {
-        st_track[(size_t)(2 * j + h)] = (int8_t)h;
-        st_pos[(size_t)(2 * j + h)] = len[0];
+  for (int sc = 0; sc < n_sec; sc++) {
+    const std::vector<int64_t> &st = order[sc];
+    cand[sc].tile.push_back(std::max(len[0], len[1]) / 8);
+    cand[sc].k0.push_back(closed[0]);
+    cand[sc].k1.push_back(closed[1]);
+    if (grouped) {
+      size_t i = 0;
+      while (i < st.size()) {
+        const int64_t a = st[i];
+        int64_t b = -1;
+        if (i + 1 < st.size() && (st[i + 1] >> 4) == (a >> 4)) b = st[i + 1];
+        const size_t nxt = i + (b >= 0 ? 2 : 1);
+        int64_t q = quads_of(a);
+        if (b >= 0) q = std::max(q, quads_of(b));
+        st_track[(size_t)a] = 0;
+        st_pos[(size_t)a] = len[0];
+        if (b >= 0) {
+          st_track[(size_t)b] = 1;
+          st_pos[(size_t)b] = len[0];
+        }
+        len[0] += q;
+        len[1] = len[0];
+        closed[0]++;
+        closed[1]++;
+        const bool end = nxt >= st.size();
+        const bool f16 = end || (st[nxt] >> 4) != (a >> 4);
+        const bool f32 = end || (st[nxt] >> 5) != (a >> 5);
+        pairs.push_back({a, b, len[0] - 1, f16, f32});
+        if (len[0] % 8 == 0 && f32 && !end) {
+          cand[sc].tile.push_back(len[0] / 8);
+          cand[sc].k0.push_back(closed[0]);
+          cand[sc].k1.push_back(closed[1]);
+        }
+        i = nxt;
       }
-      len[0] += q;
-      len[1] = len[0];
-      closed[0]++;
-      closed[1]++;
-      if (len[0] % 8 == 0 && (2 * closed[0]) % TRACK_OUT_GROUP == 0) {
-        cand_tile.push_back(len[0] / 8);
-        cand_k0.push_back(closed[0]);
-        cand_k1.push_back(closed[1]);
+    } else {
+      // cut candidates are created by padding both tracks to a tile boundary
+      // roughly every 1/32 of the expected length
+      int64_t total_quads = 0;
+      for (int64_t s : st) total_quads += quads_of(s);
+      const int64_t sync_every = std::max<int64_t>(64, total_quads / 2 / 32);
+      int64_t next_sync = std::max(len[0], len[1]) + sync_every;
+      for (size_t i = 0; i < st.size(); i++) {
+        const int64_t s = st[i];
+        int h = len[1] < len[0] ? 1 : 0;
+        st_track[(size_t)s] = (int8_t)h;
+        st_pos[(size_t)s] = len[h];
+        len[h] += quads_of(s);
+        closed[h]++;
+        if (std::min(len[0], len[1]) >= next_sync && i + 1 < st.size()) {
+          int64_t top = (std::max(len[0], len[1]) + 7) / 8 * 8;
+          len[0] = len[1] = top;
+          cand[sc].tile.push_back(top / 8);
+          cand[sc].k0.push_back(closed[0]);
+          cand[sc].k1.push_back(closed[1]);
+          next_sync = top + sync_every;
+        }
       }
     }
-    if ((double)(len[0] * 8) > 1.25 * (double)rows_real + 64) return;  // too much padding
-  } else {
-    // cut candidates are created by padding both tracks to a tile boundary
-    // roughly every 1/32 of the expected length
-    int64_t total_quads = 0;
-    for (int64_t s = 0; s < m.S; s++) total_quads += quads_of(s);
-    const int64_t sync_every = std::max<int64_t>(64, total_quads / 2 / 32);
-    int64_t next_sync = sync_every;
-    for (int64_t s = 0; s < m.S; s++) {
-      int h = len[1] < len[0] ? 1 : 0;
-      st_track[(size_t)s] = (int8_t)h;
-      st_pos[(size_t)s] = len[h];
-      len[h] += quads_of(s);
-      closed[h]++;
-      if (std::min(len[0], len[1]) >= next_sync && s + 1 < m.S) {
-        int64_t top = (std::max(len[0], len[1]) + 7) / 8 * 8;
-        len[0] = len[1] = top;
-        cand_tile.push_back(top / 8);
-        cand_k0.push_back(closed[0]);
-        cand_k1.push_back(closed[1]);
-        next_sync = top + sync_every;
-      }
+    // a section ends on a tile boundary
+    quads_used += std::max(len[0], len[1]) - sec_tile[sc] * 8;
+    const int64_t top = (std::max(len[0], len[1]) + 7) / 8 * 8;
+    len[0] = len[1] = top;
+    int64_t end_tile = top / 8;
+    if (sc == n_sec - 1) end_tile = std::max<int64_t>(1, end_tile);
+    if (cand[sc].tile.back() == end_tile && cand[sc].tile.size() > 1) {  // the end is always the last boundary
+      cand[sc].tile.pop_back();
+      cand[sc].k0.pop_back();
+      cand[sc].k1.pop_back();
     }
+    cand[sc].tile.push_back(end_tile);
+    cand[sc].k0.push_back(closed[0]);
+    cand[sc].k1.push_back(closed[1]);
+    sec_tile[sc + 1] = end_tile;
   }
-  const int64_t quads = std::max(len[0], len[1]);
-  const int64_t tiles = std::max<int64_t>(1, (quads + 7) / 8);
-  if (cand_tile.back() == tiles) {  // the end is always the last boundary
-    cand_tile.pop_back();
-    cand_k0.pop_back();
-    cand_k1.pop_back();
-  }
-  cand_tile.push_back(tiles);
-  cand_k0.push_back(closed[0]);
-  cand_k1.push_back(closed[1]);
+  const int64_t tiles = std::max<int64_t>(1, sec_tile[n_sec]);
+  if (grouped && (double)(quads_used * 8) > 1.25 * (double)rows_real + 64 * n_sec) return;  // too much padding
 
-  // ---- rows, close bits, per-track state lists
+  // ---- rows, close bits, per-track state lists / pair table
   std::vector<RowSpec> rows((size_t)tiles * TILE_ROWS, RowSpec{-1, 0.0, 0.0});
+  std::vector<int32_t> row_state((size_t)tiles * TILE_ROWS, -1);
   std::vector<uint16_t> close_mask((size_t)tiles, 0);
   std::vector<int32_t> sid[2];
-  for (int64_t s = 0; s < m.S; s++) {
-    const int h = st_track[(size_t)s];
-    const int64_t p0 = st_pos[(size_t)s];
-    const int32_t a = m.mix_off[s], b = m.mix_off[s + 1];
-    for (int32_t k = a; k < b; k++) {
-      if (!g->outlier.empty() && g->outlier[(size_t)m.mix_idx[k]]) continue;  // stays a null row
-      rows[(size_t)track_row(p0 + (k - a) / 4, h, (k - a) % 4)] =
-          RowSpec{m.mix_idx[k], m.logw((size_t)k), ref};
+  for (int sc = 0; sc < n_sec; sc++)
+    for (int64_t s : order[sc]) {
+      const int h = st_track[(size_t)s];
+      const int64_t p0 = st_pos[(size_t)s];
+      const int32_t a = m.mix_off[s], b = m.mix_off[s + 1];
+      for (int32_t k = a; k < b; k++) {
+        if (!g->outlier.empty() && g->outlier[(size_t)m.mix_idx[k]]) continue;  // stays a null row
+        const int64_t r = track_row(p0 + (k - a) / 4, h, (k - a) % 4);
+        rows[(size_t)r] = RowSpec{m.mix_idx[k], m.logw((size_t)k), ref};
+        row_state[(size_t)r] = (int32_t)s;
+      }
+      if (!grouped) {
+        const int64_t last = p0 + quads_of(s) - 1;
+        close_mask[(size_t)(last / 8)] |= (uint16_t)(1u << (last % 8 + 8 * h));
+        sid[h].push_back((int32_t)s);
+      }
     }
-    int64_t q = quads_of(s);
-    if (grouped) {
-      // the pair closes where its longer member ends
-      int64_t partner = s ^ 1;
-      if (partner < m.S) q = std::max(q, quads_of(partner));
+  if (grouped) {
+    // a pair closes where its longer member ends; both tracks carry the bit (the kernels read track 0's)
+    for (const PairEv &pe : pairs) {
+      close_mask[(size_t)(pe.last / 8)] |= (uint16_t)((1u << (pe.last % 8)) | (1u << (pe.last % 8 + 8)));
+      sid[0].push_back((int32_t)pe.s0);
+      if (pe.s1 >= 0) sid[1].push_back((int32_t)pe.s1);
     }
-    const int64_t last = p0 + q - 1;
-    close_mask[(size_t)(last / 8)] |= (uint16_t)(1u << (last % 8 + 8 * h));
-    sid[h].push_back((int32_t)s);
-  }
-  if (grouped && (m.S & 1)) {
-    // odd state count: track 1 of the last pair is all padding but must close too
-    int64_t last = st_pos[(size_t)(m.S - 1)] + quads_of(m.S - 1) - 1;
-    close_mask[(size_t)(last / 8)] |= (uint16_t)(1u << (last % 8 + 8));
   }
   const size_t ns = std::max(sid[0].size(), sid[1].size()) + 1;
   std::vector<int32_t> sid_flat(2 * ns, 0);
@@ -1035,16 +1137,59 @@ void gmm_build_tracks(aasr_gmm *g, bool grouped) {
     for (size_t k = 0; k < sid[h].size(); k++) sid_flat[h * ns + k] = sid[h][k];
   L.sid_stride = (int32_t)ns;
   L.sid.upload(sid_flat.data(), sid_flat.size());
-  build_split_table(L, tiles, cand_tile, cand_k0, cand_k1);
+  if (mixed && grouped) {
+    // pair table [2 tracks][pairs + 1][2]: {column | flags, columns of the pair's 32-group that its SECTION owns}
+    std::vector<uint32_t> gmask[2];
+    for (int sc = 0; sc < 2; sc++) {
+      gmask[sc].assign((size_t)(m.S + 31) / 32, 0u);
+      for (int64_t s : order[sc]) gmask[sc][(size_t)(s >> 5)] |= 1u << (s & 31);
+    }
+    const size_t np = pairs.size() + 1;
+    std::vector<int32_t> pm(2 * np * 2, 0);
+    for (size_t e = 0; e < pairs.size(); e++) {
+      const PairEv &pe = pairs[e];
+      const int sc = (*f16_ok)[(size_t)pe.s0] ? 0 : 1;
+      const int32_t fl = (pe.f16 ? (1 << 29) : 0) | (pe.f32 ? (1 << 30) : 0);
+      const int32_t msk = (int32_t)gmask[sc][(size_t)(pe.s0 >> 5)];
+      pm[(0 * np + e) * 2] = (int32_t)pe.s0 | fl;
+      pm[(0 * np + e) * 2 + 1] = msk;
+      pm[(1 * np + e) * 2] = (pe.s1 >= 0 ? (int32_t)pe.s1 : ((int32_t)pe.s0 | (1 << 28))) | fl;
+      pm[(1 * np + e) * 2 + 1] = msk;
+    }
+    L.pmap.upload(pm.data(), pm.size());
+    L.pmap_stride = (int32_t)np;
+    L.mapped = true;
+  }
+  // row-cut tables: the whole layout (or, mixed, one per section)
+  if (!mixed) {
+    build_split_table(L.splits, &L.max_splits, tiles, cand[0].tile, cand[0].k0, cand[0].k1);
+  } else {
+    L.n_sections = 2;
+    for (int sc = 0; sc < 2; sc++) {
+      L.sec[sc].tile_begin = sec_tile[sc];
+      L.sec[sc].tile_end = sec_tile[sc + 1];
+      L.sec[sc].states = (int64_t)order[sc].size();
+      build_split_table(L.sec[sc].splits, &L.sec[sc].max_splits, sec_tile[sc + 1] - sec_tile[sc], cand[sc].tile,
+                        cand[sc].k0, cand[sc].k1);
+    }
+    L.states_f16 = (int64_t)order[0].size();
+  }
   std::vector<double> coef64;
-  pack_rows(g, rows, L.rows, &coef64);
+  pack_rows(g, rows, L.rows, &coef64, /*upload_f32=*/!mixed);
   pack_bf16x3(m.dim, coef64, tiles, L);
   static const int f16_env = getenv("AASR_F16X2") ? atoi(getenv("AASR_F16X2")) : 1;   // 0: never pack the f16x2 form
-  if (f16_env && g->kappa_matrix <= KAPPA_LIMIT_F16 &&
-      g->kappa2_matrix <= (m.dim < 8 ? KAPPA2_LIMIT_F16_LOWDIM : KAPPA2_LIMIT_F16))
-    pack_f16x2(g, rows, coef64, tiles, L);
-  else
-    L.a16h = DevBuf<uint16_t>();
+  L.a16h = DevBuf<uint16_t>();
+  int64_t bad_state = -1;
+  if (mixed) {
+    if (!L.a16.p || !pack_f16x2(g, rows, row_state, coef64, sec_tile[1], L, &bad_state)) {
+      g->f16_bad_state = bad_state;   // the caller may move that state to the other section and try again
+      return;
+    }
+  } else if (f16_env && g->kappa_matrix <= KAPPA_LIMIT_F16 &&
+             g->kappa2_matrix <= (m.dim < 8 ? KAPPA2_LIMIT_F16_LOWDIM : KAPPA2_LIMIT_F16)) {
+    if (pack_f16x2(g, rows, row_state, coef64, tiles, L, &bad_state)) L.states_f16 = m.S;
+    else g->f16_bad_state = bad_state;
+  }
   L.rows.rows = (int64_t)m.mix_idx.size();  // real rows (algorithmic work)
   close_mask.push_back(0);  // the kernels read the bits as aligned 32-bit words (scalar loads)
   L.close.upload(close_mask.data(), close_mask.size());
@@ -1053,6 +1198,28 @@ void gmm_build_tracks(aasr_gmm *g, bool grouped) {
   L.row_gauss.resize(rows.size());
   for (size_t r = 0; r < rows.size(); r++) L.row_gauss[r] = (int32_t)rows[r].g;
   L.ok = true;
+}
+
+void gmm_build_tracks(aasr_gmm *g, bool grouped) { build_track_layout(g, grouped ? g->paired : g->tracks, grouped, nullptr); }
+
+// The mixed layout (per-state precision routing), built when the model as a whole does not qualify for the two-term fp16
+// form but some of its states do: grouped where the padding allows, independent tracks otherwise.  A state whose rows fail
+// the range / clamp conditions at packing time is moved to the three-term section and the layout is built again.
+void gmm_build_mixed(aasr_gmm *g, std::vector<uint8_t> &f16_ok) {
+  g->mixed.ok = false;
+  static const int f16_env = getenv("AASR_F16X2") ? atoi(getenv("AASR_F16X2")) : 1;
+  static const int mixed_env = getenv("AASR_MIXED") ? atoi(getenv("AASR_MIXED")) : 1;   // 0: whole-model precision as before
+  if (!f16_env || !mixed_env) return;
+  for (int attempt = 0; attempt < 64; attempt++) {
+    int64_t n_ok = 0;
+    for (uint8_t v : f16_ok) n_ok += v;
+    if (n_ok == 0 || n_ok == (int64_t)f16_ok.size()) return;
+    g->f16_bad_state = -1;
+    build_track_layout(g, g->mixed, g->paired.ok, &f16_ok);
+    if (g->mixed.ok) return;
+    if (g->f16_bad_state < 0 || !f16_ok[(size_t)g->f16_bad_state]) return;
+    f16_ok[(size_t)g->f16_bad_state] = 0;
+  }
 }
 
 // Operands of the centred-form kernel + the conditioning estimate that decides

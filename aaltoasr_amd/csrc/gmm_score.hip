@@ -1061,7 +1061,18 @@ struct PlSmem {
   static constexpr int kBytes = NBUF * kTileBytes + (WIDE ? 8 : 4) * kOutFloatsPerWave * 4;
 };
 
-template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS>
+// MAPPED (GROUPED only; mixed layouts, gmm.h TrackLayout::mapped): the states of a layout section are a SUBSET of the
+// model's states, so a pair's output columns come from a table instead of its ordinal: per close event and track
+// `sid` holds {column | flags, mask of the columns this section owns in the column's group of 32}.  A staged group is
+// flushed when the table says the next pair belongs to another group; a flush writes whole 16-byte pieces where the
+// section owns all four columns and single values elsewhere -- the other section's columns of the same line are never
+// touched, so the order of the two sections' launches does not matter.
+constexpr int kMapCol = 0xffffff;      // column field
+constexpr int kMapEmpty = 1 << 28;     // this track holds no state in this pair (column: the partner's)
+constexpr int kMapFlush16 = 1 << 29;   // last pair of its group of 16 columns in this section / cut
+constexpr int kMapFlush32 = 1 << 30;   // ... of its group of 32
+
+template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS, bool MAPPED = false>
 __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_score_pl(
     const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
     const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
@@ -1127,6 +1138,10 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   int closes = split_row[4 * blockIdx.y + 1 + (GROUPED ? 0 : h)];
   const int32_t *my_sid = sid + h * sid_stride;
   int next_sid = GROUPED ? 0 : my_sid[closes];
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  const i32x2 *my_map = (const i32x2 *)sid + (size_t)h * sid_stride;   // MAPPED: `sid` is the pair table, stride in entries
+  i32x2 next_ent = {0, 0};
+  if (MAPPED) next_ent = my_map[closes];
   float *orow0 = out + (f0 + n) * pitch;  // pitch: row stride of `out` in floats (>= S)
   float *orow1 = out + (f0 + 32 + n) * pitch;
   const bool ok0 = f0 + n < F, ok1 = f0 + 32 + n < F;
@@ -1156,6 +1171,58 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
           if (ok0) orow0[next_sid] = l0;
           if (ok1) orow1[next_sid] = l1;
           next_sid = my_sid[closes];
+        } else if (MAPPED) {
+          const i32x2 ent = next_ent;
+          next_ent = my_map[closes];   // the next pair's entry: in flight during the phase that follows
+          const int col = ent.x & kMapCol;
+          const int slot = (ent.x & kMapEmpty) ? OG : (col & (OG - 1));   // an empty track stages into the spare slot
+          ost[n * kOS + slot] = l0;
+          ost[(32 + n) * kOS + slot] = l1;
+          if (ent.x & (OG == 32 ? kMapFlush32 : kMapFlush16)) {   // the same on both tracks: wave-uniform
+            const int64_t s_base = col & ~(OG - 1);
+            const unsigned M = OG == 32 ? (unsigned)ent.y : ((unsigned)ent.y >> (col & 16)) & 0xffffu;
+            const bool whole = s_base + OG <= S && f0 + FRAMES_PER_WAVE <= F;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+            // the loops stay rolled: this code is inlined at every close of the kernel, and the instruction cache is
+            // what an unrolled flush with its per-piece branches would cost (the unmapped kernel's straight-line
+            // 16-byte flush is the common case there; here a section rarely owns a whole line)
+            if (whole) {
+              constexpr int LPR = OG / 4;            // lanes per frame row, 4 columns each
+              constexpr int RPI = 64 / LPR;          // rows per step
+              const int k4 = lane & (LPR - 1), r0 = lane / LPR;
+              float *op = out + (f0 + r0) * pitch + s_base + 4 * k4;
+              const float *ip = ost + r0 * kOS + 4 * k4;   // stride 34 or 20: 8-byte aligned
+              const unsigned nibm = (M >> (4 * k4)) & 15u;
+#pragma unroll 1
+              for (int i = 0; i < FRAMES_PER_WAVE / RPI; i++) {
+                const f32x2 lo = *(const f32x2 *)(ip + i * RPI * kOS);
+                const f32x2 hi = *(const f32x2 *)(ip + i * RPI * kOS + 2);
+                float *o = op + (int64_t)i * RPI * pitch;
+                if (nibm == 15u) {
+                  const f32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+                  *(f32x4u *)o = v;
+                } else {
+                  if (nibm & 1u) o[0] = lo[0];
+                  if (nibm & 2u) o[1] = lo[1];
+                  if (nibm & 4u) o[2] = hi[0];
+                  if (nibm & 8u) o[3] = hi[1];
+                }
+              }
+            } else {
+              constexpr int RPI = 64 / OG;
+              const int k = lane & (OG - 1);
+#pragma unroll 1
+              for (int i = 0; i < FRAMES_PER_WAVE / RPI; i++) {
+                const int row = i * RPI + lane / OG;
+                const float v = ost[row * kOS + k];
+                if (((M >> k) & 1u) && s_base + k < S && f0 + row < F) out[(f0 + row) * pitch + s_base + k] = v;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
         } else {
           const int pairs_closed = closes;
           const int slot = ((2 * (pairs_closed - 1)) & (OG - 1)) + h;
@@ -1474,8 +1541,9 @@ static int pick_row_cuts(int64_t blocks, double slots, int64_t tiles, int max_sp
   return R;
 }
 
+// `sec`: the section of a mixed layout to score (its tiles and row-cut table), nullptr: the whole layout
 template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS>
-static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
+static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const TrackSection *sec, const float *d_frames, int64_t F,
                           float *d_out, hipStream_t stream, const ClusterArgs &cl, int64_t pitch) {
   constexpr int NW = WIDE ? 8 : 4;
   const int64_t blocks = (F + NW * FRAMES_PER_WAVE - 1) / (NW * FRAMES_PER_WAVE);
@@ -1488,9 +1556,10 @@ static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *
     AASR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set[g->device & 63] = true;
   }
-  const int R = pick_row_cuts(blocks, (WIDE ? 1.0 : 2.0) * (g->num_cus > 0 ? g->num_cus : 256), L.rows_padded / TILE_ROWS,
-                              L.max_splits, 6.0);
-  const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
+  const int R = pick_row_cuts(blocks, (WIDE ? 1.0 : 2.0) * (g->num_cus > 0 ? g->num_cus : 256),
+                              sec ? sec->tile_end - sec->tile_begin : L.rows_padded / TILE_ROWS,
+                              sec ? sec->max_splits : L.max_splits, 6.0);
+  const int32_t *split_row = (sec ? sec->splits.p : L.splits.p) + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(NW * 64), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, NS == 3 ? L.a16.p : L.a16h.p, split_row, L.close.p, L.sid.p, L.sid_stride,
                      d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, dbg, cl);
@@ -1500,25 +1569,27 @@ static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *
 #ifndef AASR_PL_BF16X3
 #define AASR_PL_BF16X3 0   // experiment: the three-term bf16 arithmetic on the pipelined kernel as well
 #endif
-template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS>
-static void launch_pl_t(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
+template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS, bool MAPPED = false>
+static void launch_pl_t(const aasr_gmm *g, const TrackLayout &L, const TrackSection *sec, const float *d_frames, int64_t F,
                         float *d_out, hipStream_t stream, const ClusterArgs &cl, int64_t pitch) {
   constexpr int NW = WIDE ? 8 : 4;
   const int64_t blocks = (F + NW * FRAMES_PER_WAVE - 1) / (NW * FRAMES_PER_WAVE);
   const int smem = PlSmem<NK16, GROUPED, WIDE, NS>::kBytes;
   static const int dbg = getenv("AASR_DBG") ? atoi(getenv("AASR_DBG")) : 0;
   static bool attr_set[64] = {false};
-  auto kern = k_gmm_diag_score_pl<NK16, GROUPED, CL, WIDE, NS>;
+  auto kern = k_gmm_diag_score_pl<NK16, GROUPED, CL, WIDE, NS, MAPPED>;
   if (!attr_set[g->device & 63]) {
     AASR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set[g->device & 63] = true;
   }
-  const int R = pick_row_cuts(blocks, (WIDE ? 1.0 : 2.0) * (g->num_cus > 0 ? g->num_cus : 256), L.rows_padded / TILE_ROWS,
-                              L.max_splits, 3.0);
-  const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
+  const int R = pick_row_cuts(blocks, (WIDE ? 1.0 : 2.0) * (g->num_cus > 0 ? g->num_cus : 256),
+                              sec ? sec->tile_end - sec->tile_begin : L.rows_padded / TILE_ROWS,
+                              sec ? sec->max_splits : L.max_splits, 3.0);
+  const int32_t *split_row = (sec ? sec->splits.p : L.splits.p) + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
   const u32x4 *fop = frame_operand<NS>(g, L, d_frames, F, blocks * NW, stream);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(NW * 64), smem, stream, d_frames, F,
-                     g->dim, g->d_pivot.p, NS == 3 ? L.a16.p : L.a16h.p, split_row, L.close.p, L.sid.p, L.sid_stride,
+                     g->dim, g->d_pivot.p, NS == 3 ? L.a16.p : L.a16h.p, split_row, L.close.p,
+                     MAPPED ? L.pmap.p : L.sid.p, MAPPED ? L.pmap_stride : L.sid_stride,
                      d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, dbg, cl, fop);
   AASR_HIP(hipGetLastError());
 }
@@ -1530,23 +1601,37 @@ static constexpr bool wide_ok() {
   return 3 * Bf16Smem<N, true, true, NS>::kTileBytes + 8 * Bf16Smem<N, true, true, NS>::kOutFloatsPerWave * 4 <= 160 * 1024;
 }
 
+template <int N, int NS>
+static constexpr bool wide_ok_pl() {
+  return PlSmem<N, true, true, NS>::kBytes <= 160 * 1024;
+}
+
 // NS = 3: three bf16 terms (AASR_PREC_BF16X3) on the wave-group kernel; NS = 2: two fp16 terms (AASR_PREC_F16X2) on
 // the software-pipelined kernel
 template <int NS>
 static bool launch_split(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
-                         float *d_out, hipStream_t stream, const ClusterArgs *cl = nullptr, int64_t pitch = 0) {
+                         float *d_out, hipStream_t stream, const ClusterArgs *cl = nullptr, int64_t pitch = 0,
+                         int section = -1) {
   if (pitch <= 0) pitch = g->S;
   if (NS == 3 ? !L.a16.p : !L.a16h.p) return false;
+  const TrackSection *sec = section >= 0 ? &L.sec[section] : nullptr;
+  if (sec && sec->tile_end <= sec->tile_begin) return true;   // an empty section
+  if (L.mapped && !L.grouped) return false;
   const ClusterArgs none;
   // AASR_BF16_WIDE=0 selects the 4-wave workgroups
   static const int wide_env = getenv("AASR_BF16_WIDE") ? atoi(getenv("AASR_BF16_WIDE")) : -1;
   // small batches (a decoder's per-utterance blocks) fill the chip better with 256-frame workgroups
   const int wide = wide_env >= 0 ? wide_env : (F >= 8192 ? 1 : 0);
   switch (L.nk16) {
+  // mapped (mixed, grouped) layouts run both arithmetic forms on the pipelined kernel, whose epilogue reads the pair table
 #define AASR_LAUNCH(N, GR, CLF, WD, CLA)                                                   \
   do {                                                                                     \
-    if constexpr (NS == 2 || AASR_PL_BF16X3) launch_pl_t<N, GR, CLF, WD, NS>(g, L, d_frames, F, d_out, stream, CLA, pitch);   \
-    else launch_bf16_t<N, GR, CLF, WD, NS>(g, L, d_frames, F, d_out, stream, CLA, pitch);  \
+    if (L.mapped) {                                                                        \
+      if constexpr (GR) launch_pl_t<N, true, CLF, WD, NS, true>(g, L, sec, d_frames, F, d_out, stream, CLA, pitch); \
+    } else if constexpr (NS == 2 || AASR_PL_BF16X3)                                        \
+      launch_pl_t<N, GR, CLF, WD, NS>(g, L, sec, d_frames, F, d_out, stream, CLA, pitch);   \
+    else                                                                                   \
+      launch_bf16_t<N, GR, CLF, WD, NS>(g, L, sec, d_frames, F, d_out, stream, CLA, pitch); \
   } while (0)
 #define AASR_CASE(N)                                                                       \
   case N:                                                                                  \
@@ -1560,7 +1645,7 @@ static bool launch_split(const aasr_gmm *g, const TrackLayout &L, const float *d
     } else if (cl) {                                                                       \
       if (L.grouped) AASR_LAUNCH(N, true, true, false, *cl);                               \
       else AASR_LAUNCH(N, false, true, false, *cl);                                        \
-    } else if (wide && wide_ok<N, NS>()) {                                                 \
+    } else if (wide && (L.mapped ? wide_ok_pl<N, NS>() : wide_ok<N, NS>())) {              \
       if (L.grouped) AASR_LAUNCH(N, true, false, true, none);                              \
       else AASR_LAUNCH(N, false, false, true, none);                                       \
     } else {                                                                               \
@@ -1579,9 +1664,115 @@ static bool launch_split(const aasr_gmm *g, const TrackLayout &L, const float *d
 // the split-operand kernel the handle's precision asks for (f16x2 only where the layout is eligible)
 static bool launch_bf16(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
                         float *d_out, hipStream_t stream, const ClusterArgs *cl = nullptr, int64_t pitch = 0) {
+  if (L.n_sections == 2) {
+    // a mixed layout: the states that qualify in two fp16 terms, the others in three bf16 terms -- one launch per
+    // section, disjoint output columns
+    if (g->precision == AASR_PREC_F16X2)
+      return launch_split<2>(g, L, d_frames, F, d_out, stream, cl, pitch, 0) &&
+             launch_split<3>(g, L, d_frames, F, d_out, stream, cl, pitch, 1);
+    return launch_split<3>(g, L, d_frames, F, d_out, stream, cl, pitch, 0) &&
+           launch_split<3>(g, L, d_frames, F, d_out, stream, cl, pitch, 1);
+  }
   if (g->precision == AASR_PREC_F16X2 && L.a16h.p && launch_split<2>(g, L, d_frames, F, d_out, stream, cl, pitch))
     return true;
   return launch_split<3>(g, L, d_frames, F, d_out, stream, cl, pitch);
+}
+
+// the layout the split-operand kernels run under the handle's precision: the mixed one where AASR_PREC_F16X2 can only
+// have part of the states (gmm_build_mixed), else the grouped / independent layout
+static const TrackLayout *split_layout(const aasr_gmm *g) {
+  if (g->precision == AASR_PREC_F16X2 && g->use_bf16x3 && g->mixed.ok && (g->layout_mask & 3) == 3) return &g->mixed;
+  return nullptr;
+}
+
+// ---------------------------------------------------------------------------
+// Load-time guard of the two-term fp16 form.  Which states get it is decided by conditioning limits that were set
+// from sweeps (gmm.h, KAPPA_LIMIT_F16): a bound in the statistical sense, not a proof.  So every model that got fp16
+// rows is probed once when it is built: a few hundred frames placed on its own Gaussians -- 0.5 to 2.5 sigma out in
+// every dimension, and one dimension at a time pushed to +-6 sigma -- are scored by the f16x2 path and by the exact-f32
+// matrix kernel on the same layout family, and a state whose visible values differ by more than 5e-5 (half the 1e-4
+// contract) loses the fp16 rows: it moves to the three-term section of the mixed layout (per-state precision routing),
+// the rest of the model keeps the fast form.  AASR_F16_PROBE=0 switches the guard off.
+// ---------------------------------------------------------------------------
+void gmm_probe_f16x2(aasr_gmm *g) {
+  static const int probe_env = getenv("AASR_F16_PROBE") ? atoi(getenv("AASR_F16_PROBE")) : 1;
+  static const float probe_tol = getenv("AASR_F16_PROBE_TOL") ? (float)atof(getenv("AASR_F16_PROBE_TOL")) : 5.0e-5f;  // test hook
+  g->f16_probe_moved = 0;
+  if (!probe_env || !g->dim_parts.empty() || g->class_routing || g->host.factor_path() || g->ill_conditioned) return;
+  const HostModel &m = g->host;
+  const int D = m.dim;
+  const int64_t S = m.S, K = (int64_t)m.mix_idx.size();
+  if (K == 0) return;
+  const int P = (int)std::max<int64_t>(32, std::min<int64_t>(192, 4000000 / std::max<int64_t>(1, S)));
+  for (int round = 0; round < 2; round++) {
+    TrackLayout &L0 = g->paired.ok ? g->paired : g->tracks;
+    if (!L0.ok || !L0.rows.a.p) return;
+    const TrackLayout *LF = g->mixed.ok ? &g->mixed : (L0.a16h.p ? &L0 : nullptr);
+    if (!LF) return;
+    // probe frames (deterministic): frame i sits on mixture component (i * step) % K
+    std::vector<float> fr((size_t)P * D);
+    uint64_t st = 0x9e3779b97f4a7c15ull + (uint64_t)round * 77;
+    auto uni = [&]() {   // xorshift64*, uniform in (0, 1)
+      st ^= st >> 12; st ^= st << 25; st ^= st >> 27;
+      return ((st * 0x2545f4914f6cdd1dull) >> 11) * (1.0 / 9007199254740992.0) + 1e-17;
+    };
+    const int64_t step = std::max<int64_t>(1, K / P) | 1;
+    for (int i = 0; i < P; i++) {
+      const int64_t k = ((int64_t)i * step + round) % K;
+      const int64_t gi = m.mix_idx[(size_t)k];
+      static const double amps[4] = {0.5, 1.0, 1.5, 2.5};
+      const double amp = i < P * 2 / 3 ? amps[i & 3] : 1.0;
+      const int far_d = i < P * 2 / 3 ? -1 : (int)(uni() * D) % D;
+      for (int d = 0; d < D; d++) {
+        const double v = m.var[(size_t)gi * D + d];
+        const double sd = v > 0 ? std::sqrt(v) : 0.0;
+        // a normal deviate from twelve uniforms is plenty here
+        double z = -6.0;
+        for (int u = 0; u < 12; u++) z += uni();
+        double x = m.mean[(size_t)gi * D + d] + amp * sd * z;
+        if (d == far_d) x = m.mean[(size_t)gi * D + d] + ((i & 1) ? 6.0 : -6.0) * sd;
+        fr[(size_t)i * D + d] = (float)x;
+      }
+    }
+    DevBuf<float> d_fr, d_a, d_b;
+    d_fr.upload(fr.data(), fr.size());
+    d_a.alloc((size_t)P * S);
+    d_b.alloc((size_t)P * S);
+    const int prec = g->precision;
+    const bool use = g->use_bf16x3;
+    g->precision = AASR_PREC_F16X2;
+    g->use_bf16x3 = true;
+    const bool ok_a = launch_bf16(g, *LF, d_fr.p, P, d_a.p, nullptr);
+    g->precision = prec;
+    g->use_bf16x3 = use;
+    const bool ok_b = ok_a && launch_tracks(g, L0, d_fr.p, P, d_b.p, nullptr);
+    if (!ok_a || !ok_b) return;
+    std::vector<float> a((size_t)P * S), b((size_t)P * S);
+    AASR_HIP(hipMemcpy(a.data(), d_a.p, a.size() * 4, hipMemcpyDeviceToHost));
+    AASR_HIP(hipMemcpy(b.data(), d_b.p, b.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> bad((size_t)S, 0);
+    int64_t n_bad = 0;
+    for (int i = 0; i < P; i++)
+      for (int64_t s2 = 0; s2 < S; s2++) {
+        const float x = a[(size_t)i * S + s2], y = b[(size_t)i * S + s2];
+        if (y > -103.0f && !(std::fabs(x - y) <= probe_tol) && g->f16_state_ok[(size_t)s2] && !bad[(size_t)s2]) {
+          bad[(size_t)s2] = 1;
+          n_bad++;
+        }
+      }
+    if (n_bad == 0) return;
+    g->f16_probe_moved += n_bad;
+    for (int64_t s2 = 0; s2 < S; s2++)
+      if (bad[(size_t)s2]) g->f16_state_ok[(size_t)s2] = 0;
+    // the whole-model fp16 rows are gone; what still qualifies goes to the mixed layout
+    g->paired.a16h = DevBuf<uint16_t>();
+    g->paired.states_f16 = 0;
+    g->tracks.a16h = DevBuf<uint16_t>();
+    g->tracks.states_f16 = 0;
+    g->mixed = TrackLayout();
+    g->cl.crow[2] = DevBuf<int32_t>();
+    gmm_build_mixed(g, g->f16_state_ok);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -2614,6 +2805,7 @@ extern "C" int aasr_debug_active_layout(const aasr_gmm *g) {
   if ((g->layout_mask & 4) && (g->ill_conditioned || g->precision == AASR_PREC_F32_CENTRED ||
                                !(g->layout_mask & 3)) && g->centred_ok)
     return 4;
+  if (const TrackLayout *LM = split_layout(g)) return LM->grouped ? 1 : 2;   // the mixed layout, in either form
   if ((g->layout_mask & 1) && g->paired.ok) return 1;
   if ((g->layout_mask & 2) && g->tracks.ok) return 2;
   return 0;
@@ -2651,7 +2843,7 @@ const float *gmm_adapted_frames(aasr_gmm *g, const float *d_frames, int64_t F, h
 void gmm_tracks_masked_launch(aasr_gmm *g, int which, const float *d_frames, int64_t F,
                               float *d_out, const unsigned long long *maskrow,
                               hipStream_t stream, int64_t pitch) {
-  const TrackLayout &L = which == 0 ? g->paired : g->tracks;
+  const TrackLayout &L = which == 2 ? g->mixed : which == 0 ? g->paired : g->tracks;
   if (!L.ok) raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering needs a track layout for this model");
   ClusterArgs cl;
   cl.maskrow = maskrow;
@@ -2847,7 +3039,9 @@ void gmm_score_launch_pitched(aasr_gmm *g, const float *d_frames, int64_t F, flo
     d_frames = g->d_xframes.p;
   }
   const TrackLayout &L = g->paired.ok ? g->paired : g->tracks;
-  const bool done = (g->use_bf16x3 && launch_bf16(g, L, d_frames, F, d_out, stream, nullptr, pitch)) ||
+  const TrackLayout *LM = split_layout(g);
+  const bool done = (LM && launch_bf16(g, *LM, d_frames, F, d_out, stream, nullptr, pitch)) ||
+                    (g->use_bf16x3 && launch_bf16(g, L, d_frames, F, d_out, stream, nullptr, pitch)) ||
                     launch_tracks(g, L, d_frames, F, d_out, stream, nullptr, pitch);
   if (!done) raise(AASR_ERR_UNSUPPORTED, "no track kernel instance for this model");
 }
@@ -2998,8 +3192,9 @@ void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
       if (g->out_bias_ln != 0) add_output_bias(g, d_out, F, stream);
       return;
     }
-  // layout choice: grouped tracks > independent tracks > general (LDS-staged)
+  // layout choice: (mixed, where f16x2 covers part of the states) > grouped tracks > independent tracks > general (LDS-staged)
   bool done = false;
+  if (const TrackLayout *LM = split_layout(g)) done = launch_bf16(g, *LM, d_frames, F, d_out, stream);
   if (!done && (g->layout_mask & 1) && g->paired.ok)
     done = (g->use_bf16x3 && launch_bf16(g, g->paired, d_frames, F, d_out, stream)) ||
            launch_tracks(g, g->paired, d_frames, F, d_out, stream);

@@ -42,6 +42,23 @@ def make_model(D=39, G=256, S=32, comps=8, seed=SEED, tied=False, var_lo=0.25, v
     return mean, var, off, idx, w
 
 
+def push_states_over_the_f16_limits(model, states, kappa2=120.0):
+    """Per-state precision routing test models: in every state of `states` the first component's Gaussian is moved away
+    from the pool's pivot (the mean of the means) until its conditioning estimate sqrt(sum_d (p (mu - pivot)^2)^2) is
+    `kappa2` -- above the two-term fp16 form's limit (80), below the matrix path's (200), with the sum itself below its
+    limits as well for the synthetic models' variances.  Returns a new model tuple (disjoint pools: only those states
+    are affected)."""
+    mean, var, off, idx, w = model
+    mean = np.array(mean, np.float64)
+    pivot = mean.mean(0).astype(np.float32).astype(np.float64)
+    for s in states:
+        g = int(idx[off[s]])
+        mc = mean[g] - pivot
+        k2 = np.sqrt((((mc * mc) / var[g]) ** 2).sum())
+        mean[g] = pivot + mc * np.sqrt(kappa2 / k2)
+    return mean, var, off, idx, w
+
+
 def make_clustering(mean, n_clusters, seed=SEED + 3, iters=4):
     """Deterministic k-means on the Gaussian means (what aku's gcluster produces in
     spirit): returns gauss_to_cluster [G] int32 with every cluster non-empty."""

@@ -294,6 +294,16 @@ aasr_status aasr_gmm_set_precision(aasr_gmm *h, int prec);
 int aasr_gmm_get_precision(const aasr_gmm *h);
 /* the arithmetic the matrix scoring path of this model actually runs under the current setting */
 int aasr_gmm_effective_precision(const aasr_gmm *h);
+/* Per-state precision routing (new; no aku counterpart -- the reference scores everything in double,
+ * aku/Distributions.cc:1040-1062).  States are independent output columns (Mixture::compute_likelihood,
+ * aku/Distributions.cc:2078-2086), so under AASR_PREC_F16X2 a diagonal model whose Gaussians do not ALL satisfy the
+ * two-term form's conditioning limits is scored in two sections: the states whose Gaussians all qualify with two fp16
+ * terms, the others with three bf16 terms (one Gaussian over the limit costs its state the slower arithmetic, not the
+ * model).  states_f16x2: how many of the model's states the two-term rows cover under the current setting (0 ... S);
+ * states_probe_moved: how many the load-time probe took out of that form (a few hundred frames on the model's own
+ * Gaussians, incl. +-6 sigma, scored in f16x2 and in exact f32 when the model is created; a state that differs by more
+ * than 5e-5 is scored with three terms).  Either pointer may be null. */
+aasr_status aasr_gmm_precision_states(const aasr_gmm *h, int64_t *states_f16x2, int64_t *states_probe_moved);
 
 /* HmmSet::precompute_likelihoods + state_likelihood for a block of frames
  * (aku/HmmSet.cc:484-501, aku/HmmSet.hh:309): frames float32 [F x dim];

@@ -1,0 +1,156 @@
+"""Per-state precision routing (gmm_build_mixed, k_gmm_diag_score_pl<..., MAPPED>): under AASR_PREC_F16X2 a model whose
+Gaussians do not ALL satisfy the two-term fp16 form's conditioning limits is scored in two sections -- the states whose
+Gaussians all qualify with two fp16 terms, the rest with three bf16 terms -- instead of dropping the whole model to the
+slower arithmetic.  States are independent output columns (Mixture::compute_likelihood, aku/Distributions.cc:2078-2086),
+so the parity bar is the usual one: every state log-likelihood within 1e-4 of the oracle's (aku/HmmSet.cc:484-501)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import assert_ll
+
+from aaltoasr_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _routed(capi, oracle, model, bad, frames, grouped=None, clustered=False):
+    """Scores `frames` in every precision; returns the f16x2 scores.  `bad`: the states expected in the three-term section."""
+    S = len(model[2]) - 1
+    ref = oracle.DiagModel(*model).score(frames.astype(np.float64))
+    g = capi.Gmm.from_arrays(*model)
+    assert g.get_precision() == 4 and g.effective_precision() == 4
+    n16, moved = g.precision_states()
+    assert n16 == S - len(bad) and moved == 0, (n16, moved, S, len(bad))
+    if grouped is not None:
+        assert g.active_layout() == (1 if grouped else 2)
+    got4 = g.score(frames)
+    assert_ll(got4, ref, "mixed layout, f16x2 + bf16x3 sections")
+    for prec in (3, 0):
+        g.set_precision(prec)
+        assert g.effective_precision() == prec and g.precision_states()[0] == 0
+        assert_ll(g.score(frames), ref, "precision %d on the routed model" % prec)
+    g.set_precision(4)
+    assert np.array_equal(g.score(frames), got4)       # back on the mixed layout: the same bits
+    g.close()
+    return got4, ref
+
+
+@pytest.mark.parametrize("share", ["one", 0.01, 0.1, 0.5, "all-but-one"])
+def test_routed_states_match_the_oracle(capi, oracle, share):
+    """configs[1]'s layout in miniature (16 components per state, disjoint pool, grouped tracks) with one state, 1 %, 10 %,
+    50 % and all but one of the states holding a Gaussian over the fp16 limits; frame counts on both sides of the 8-wave
+    form's threshold and not a multiple of a wave's 64 frames."""
+    S = 300
+    base = synth.make_model(D=39, G=S * 16, S=S, comps=16, seed=411)
+    rng = np.random.default_rng(5)
+    if share == "one":
+        bad = [137]
+    elif share == "all-but-one":
+        bad = [s for s in range(S) if s != 31]
+    else:
+        bad = sorted(rng.choice(S, max(1, int(round(share * S))), replace=False).tolist())
+    model = synth.push_states_over_the_f16_limits(base, bad)
+    for F in (70, 9001):
+        _routed(capi, oracle, model, bad, synth.make_frames(F, seed=412 + F), grouped=True)
+
+
+def test_routed_states_at_group_edges_and_small_models(capi, oracle):
+    """Pairs are formed inside groups of 16 output columns and flushed per group of 32 (or 16): states next to the group
+    boundaries, whole groups on one side, an odd state count, fewer states than one group."""
+    for S, bad in ((97, [0, 15, 16, 31, 32, 33, 63, 64, 96]), (64, list(range(32, 64))), (64, list(range(0, 32)) + [40]),
+                   (5, [2]), (33, [32]), (3125 // 25, [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])):
+        base = synth.make_model(D=39, G=S * 8, S=S, comps=8, seed=420 + S)
+        model = synth.push_states_over_the_f16_limits(base, bad)
+        _routed(capi, oracle, model, bad, synth.make_frames(333, seed=421), grouped=True)
+
+
+def test_routed_states_on_independent_tracks_and_other_dimensions(capi, oracle):
+    """Ragged mixtures take the independent-track layout (states stored one by one): its sections need no pair table.
+    Other feature dimensions pick other kernel instances."""
+    base = synth.make_model(D=39, G=4000, S=150, comps_range=(1, 40), seed=430)
+    bad = [3, 4, 77, 149]
+    model = synth.push_states_over_the_f16_limits(base, bad)
+    _routed(capi, oracle, model, bad, synth.make_frames(700, seed=431), grouped=False)
+    for D in (13, 24, 47):
+        base = synth.make_model(D=D, G=96 * 8, S=96, comps=8, seed=432 + D)
+        bad = [0, 50, 51, 95]
+        model = synth.push_states_over_the_f16_limits(base, bad, kappa2=100.0)
+        _routed(capi, oracle, model, bad, synth.make_frames(400, D=D, seed=433), grouped=True)
+
+
+def test_routed_model_with_padded_rows_and_device_pointers(capi, oracle):
+    """aasr_gmm_score_dev_pitched on a routed model: rows padded to whole 128-byte lines, bit for bit the dense values,
+    the padding untouched (the two sections write disjoint columns of the same lines)."""
+    import torch
+    S = 100
+    bad = [7, 8, 40, 99]
+    model = synth.push_states_over_the_f16_limits(synth.make_model(D=39, G=S * 16, S=S, comps=16, seed=440), bad)
+    g = capi.Gmm.from_arrays(*model)
+    assert g.precision_states()[0] == S - len(bad) and g.score_pitch_ok()
+    fr = synth.make_frames(9000, seed=441)
+    dense = g.score(fr)
+    d_fr = torch.from_numpy(fr).cuda()
+    for pitch in (128, 103):
+        padded = torch.full((len(fr), pitch), -7.0, dtype=torch.float32, device="cuda")
+        g.score_dev_pitched(d_fr, padded, pitch)
+        torch.cuda.synchronize()
+        out = padded.cpu().numpy()
+        assert np.array_equal(out[:, :S], dense) and np.all(out[:, S:] == -7.0), pitch
+    g.close()
+
+
+def test_routed_model_under_gaussian_clustering(capi, oracle):
+    """The masked (clustered) pass on the mixed layout: scores and exact-evaluation counts as the oracle's cluster branch
+    (aku/Distributions.cc:2684-2722)."""
+    S = 128
+    bad = [5, 6, 64, 100, 127]
+    model = synth.push_states_over_the_f16_limits(synth.make_model(D=39, G=S * 16, S=S, comps=16, seed=450), bad)
+    g2c = synth.make_clustering(model[0], 64)
+    pairs = [(int(a), int(c)) for a, c in enumerate(g2c) if c >= 0]
+    frames = synth.make_frames(500, seed=451)
+    om = oracle.DiagModel(*model)
+    om.set_clustering(64, pairs, 0.0, 0.25)
+    want, want_n = om.score_clustered(frames.astype(np.float64), want_counts=True)
+    gm = capi.Gmm.from_arrays(*model)
+    assert gm.precision_states()[0] == S - len(bad)
+    gm.set_clustering(64, pairs)
+    gm.set_clustering_min_evals(0.0, 0.25)
+    got = gm.score(frames)
+    assert np.array_equal(gm.cluster_exact_counts(len(frames)), want_n)
+    assert np.abs(got - want).max() <= 1e-4
+    gm.close()
+
+
+def test_probe_guard_moves_states_that_fail_it(capi, oracle, tmp_path):
+    """The load-time probe (gmm_probe_f16x2): with its tolerance forced to nothing (AASR_F16_PROBE_TOL, a test hook)
+    every probed state fails and is scored with three terms instead -- the model still matches the oracle, and
+    aasr_gmm_precision_states reports the move.  (In-process the guard runs on every model of the suite at 5e-5.)"""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from aaltoasr_amd import capi, synth
+from oracle import oracle as O
+capi.check(capi.lib().aasr_set_device(0))
+model = synth.make_model(D=39, G=64 * 16, S=64, comps=16, seed=460)
+g = capi.Gmm.from_arrays(*model)
+n16, moved = g.precision_states()
+fr = synth.make_frames(300, seed=461)
+err = float(np.abs(g.score(fr) - O.DiagModel(*model).score(fr.astype(np.float64))).max())
+print("RESULT", n16, moved, g.effective_precision(), err)
+''' % ROOT
+    out = {}
+    for tol in ("", "1e-9"):
+        env = dict(os.environ)
+        if tol:
+            env["AASR_F16_PROBE_TOL"] = tol
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tol] = r.stdout.split("RESULT")[1].split()
+    assert out[""][:3] == ["64", "0", "4"] and float(out[""][3]) <= 1e-4
+    n16, moved = int(out["1e-9"][0]), int(out["1e-9"][1])
+    assert moved > 32 and n16 == 64 - moved and float(out["1e-9"][3]) <= 1e-4, out
