@@ -138,6 +138,8 @@ struct PackedRows {
 struct TrackSection {
   int64_t tile_begin = 0, tile_end = 0;
   int64_t states = 0;
+  bool grouped = false;      // state pairs side by side on the two tracks (else: every state on one track, direct stores)
+  bool mapped = false;       // grouped over a subset of the states: output columns come from TrackLayout::pmap
   DevBuf<int32_t> splits;    // [MAX_SPLITS][MAX_SPLITS+1][4], absolute tile indices
   int max_splits = 1;
 };
@@ -146,9 +148,10 @@ struct TrackSection {
 struct TrackLayout {
   bool ok = false;
   bool grouped = false;
-  // mixed layouts: section 0 = the states scored with two fp16 terms (a16h covers its tiles), section 1 = the others
-  // (three bf16 terms, a16 covers all tiles); `mapped` (grouped form): output columns, flush points and column masks of
-  // every state pair come from `pmap` ([2 tracks][pmap_stride][2], k_gmm_diag_score_pl<..., MAPPED>)
+  // mixed layouts: section 0 = the states scored with two fp16 terms (a16h covers its tiles; grouped where the model's
+  // grouped layout exists: its pairs' output columns and flush points come from `pmap`, [tile][2 tracks][8 quad
+  // positions], k_gmm_diag_score_pl<..., MAPPED>), section 1 = the others on independent tracks (three bf16 terms, a16
+  // covers all tiles; `sid` lists its states)
   int n_sections = 0;
   TrackSection sec[2];
   bool mapped = false;

@@ -1023,12 +1023,19 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
   auto quads_of = [&](int64_t s) {
     return std::max<int64_t>(1, ((int64_t)(m.mix_off[s + 1] - m.mix_off[s]) + 3) / 4);
   };
+  // mixed: section 0 keeps the layout's form (grouped: pairs over the section's states), section 1 -- the few states
+  // on three terms -- is always laid out as independent tracks; its close counters and state lists start at zero
+  auto sec_grouped = [&](int sc) { return grouped && !(mixed && sc == 1); };
   for (int sc = 0; sc < n_sec; sc++) {
     const std::vector<int64_t> &st = order[sc];
+    if (mixed && sc == 1 && grouped) closed[0] = closed[1] = 0;   // (a grouped section 0 left nothing in the lists)
     cand[sc].tile.push_back(std::max(len[0], len[1]) / 8);
     cand[sc].k0.push_back(closed[0]);
     cand[sc].k1.push_back(closed[1]);
-    if (grouped) {
+    if (sec_grouped(sc)) {
+      // Pairs are formed inside groups of 16 output columns: (16 g, 16 g + 1), ... for the whole model, neighbours among
+      // the section's states of a group for a subset (a lone state takes a pair with an empty partner track).  A group
+      // is staged and flushed as whole lines (k_gmm_diag_score_pl<..., MAPPED>).
       size_t i = 0;
       while (i < st.size()) {
         const int64_t a = st[i];
@@ -1117,7 +1124,7 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
         rows[(size_t)r] = RowSpec{m.mix_idx[k], m.logw((size_t)k), ref};
         row_state[(size_t)r] = (int32_t)s;
       }
-      if (!grouped) {
+      if (!sec_grouped(sc)) {
         const int64_t last = p0 + quads_of(s) - 1;
         close_mask[(size_t)(last / 8)] |= (uint16_t)(1u << (last % 8 + 8 * h));
         sid[h].push_back((int32_t)s);
@@ -1127,8 +1134,10 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
     // a pair closes where its longer member ends; both tracks carry the bit (the kernels read track 0's)
     for (const PairEv &pe : pairs) {
       close_mask[(size_t)(pe.last / 8)] |= (uint16_t)((1u << (pe.last % 8)) | (1u << (pe.last % 8 + 8)));
-      sid[0].push_back((int32_t)pe.s0);
-      if (pe.s1 >= 0) sid[1].push_back((int32_t)pe.s1);
+      if (!mixed) {   // (a mixed layout's lists hold section 1's states; its section 0 reads the pair table)
+        sid[0].push_back((int32_t)pe.s0);
+        if (pe.s1 >= 0) sid[1].push_back((int32_t)pe.s1);
+      }
     }
   }
   const size_t ns = std::max(sid[0].size(), sid[1].size()) + 1;
@@ -1138,26 +1147,17 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
   L.sid_stride = (int32_t)ns;
   L.sid.upload(sid_flat.data(), sid_flat.size());
   if (mixed && grouped) {
-    // pair table [2 tracks][pairs + 1][2]: {column | flags, columns of the pair's 32-group that its SECTION owns}
-    std::vector<uint32_t> gmask[2];
-    for (int sc = 0; sc < 2; sc++) {
-      gmask[sc].assign((size_t)(m.S + 31) / 32, 0u);
-      for (int64_t s : order[sc]) gmask[sc][(size_t)(s >> 5)] |= 1u << (s & 31);
-    }
-    const size_t np = pairs.size() + 1;
-    std::vector<int32_t> pm(2 * np * 2, 0);
-    for (size_t e = 0; e < pairs.size(); e++) {
-      const PairEv &pe = pairs[e];
-      const int sc = (*f16_ok)[(size_t)pe.s0] ? 0 : 1;
+    // pair entries by tile, track and quad position: column | flags of the pair that closes there
+    // (k_gmm_diag_score_pl<..., MAPPED> fetches a tile's 16 words into LDS together with its rows)
+    std::vector<int32_t> pm((size_t)(tiles + 2) * 16, 0);
+    for (const PairEv &pe : pairs) {
       const int32_t fl = (pe.f16 ? (1 << 29) : 0) | (pe.f32 ? (1 << 30) : 0);
-      const int32_t msk = (int32_t)gmask[sc][(size_t)(pe.s0 >> 5)];
-      pm[(0 * np + e) * 2] = (int32_t)pe.s0 | fl;
-      pm[(0 * np + e) * 2 + 1] = msk;
-      pm[(1 * np + e) * 2] = (pe.s1 >= 0 ? (int32_t)pe.s1 : ((int32_t)pe.s0 | (1 << 28))) | fl;
-      pm[(1 * np + e) * 2 + 1] = msk;
+      const size_t t = (size_t)(pe.last / 8), pos = (size_t)(pe.last % 8);
+      pm[t * 16 + pos] = (int32_t)pe.s0 | fl;
+      pm[t * 16 + 8 + pos] = (pe.s1 >= 0 ? (int32_t)pe.s1 : ((int32_t)pe.s0 | (1 << 28))) | fl;
     }
     L.pmap.upload(pm.data(), pm.size());
-    L.pmap_stride = (int32_t)np;
+    L.pmap_stride = 16;
     L.mapped = true;
   }
   // row-cut tables: the whole layout (or, mixed, one per section)
@@ -1169,6 +1169,8 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
       L.sec[sc].tile_begin = sec_tile[sc];
       L.sec[sc].tile_end = sec_tile[sc + 1];
       L.sec[sc].states = (int64_t)order[sc].size();
+      L.sec[sc].grouped = sec_grouped(sc);
+      L.sec[sc].mapped = L.sec[sc].grouped;
       build_split_table(L.sec[sc].splits, &L.sec[sc].max_splits, sec_tile[sc + 1] - sec_tile[sc], cand[sc].tile,
                         cand[sc].k0, cand[sc].k1);
     }
@@ -1214,6 +1216,11 @@ void gmm_build_mixed(aasr_gmm *g, std::vector<uint8_t> &f16_ok) {
     int64_t n_ok = 0;
     for (uint8_t v : f16_ok) n_ok += v;
     if (n_ok == 0 || n_ok == (int64_t)f16_ok.size()) return;
+    // the second section stores its values one by one over the first one's whole lines, which costs about as much again
+    // as its arithmetic: with half of the states on three terms the two launches take what the whole model takes on three
+    // terms (measured on configs[2]: 1 % of the states routed 1.11x the all-fp16 pass, 10 % 1.31x, 50 % 1.62x = the
+    // whole model on three terms), so beyond 45 % the model keeps one arithmetic
+    if ((double)n_ok < 0.55 * (double)f16_ok.size()) return;
     g->f16_bad_state = -1;
     build_track_layout(g, g->mixed, g->paired.ok, &f16_ok);
     if (g->mixed.ok) return;

@@ -1058,18 +1058,23 @@ struct PlSmem {
   static constexpr int OG = kBig ? 32 : 16;
   static constexpr int kOutStride = kBig ? 34 : 20;
   static constexpr int kOutFloatsPerWave = GROUPED ? FRAMES_PER_WAVE * kOutStride : 0;
-  static constexpr int kBytes = NBUF * kTileBytes + (WIDE ? 8 : 4) * kOutFloatsPerWave * 4;
+  static constexpr int kMapBytes = NBUF * 16 * 4;   // MAPPED: the tiles' pair entries, [buffer][track][quad position]
+  static constexpr int kBytes = NBUF * kTileBytes + (WIDE ? 8 : 4) * kOutFloatsPerWave * 4 + kMapBytes;
 };
 
-// MAPPED (GROUPED only; mixed layouts, gmm.h TrackLayout::mapped): the states of a layout section are a SUBSET of the
-// model's states, so a pair's output columns come from a table instead of its ordinal: per close event and track
-// `sid` holds {column | flags, mask of the columns this section owns in the column's group of 32}.  A staged group is
-// flushed when the table says the next pair belongs to another group; a flush writes whole 16-byte pieces where the
-// section owns all four columns and single values elsewhere -- the other section's columns of the same line are never
-// touched, so the order of the two sections' launches does not matter.
+// MAPPED (GROUPED only; section 0 of a mixed layout, gmm.h TrackLayout::mapped): the section's states are a SUBSET of
+// the model's, so a pair's output columns come from a table instead of its ordinal: per tile, track and quad position
+// `sid` holds column | flags of the pair that closes there (16 words per tile; they ride into LDS with the tile's rows,
+// so the close logic never waits for global memory -- a per-close vector load is waited for in issue order, i.e. behind
+// the tile copy requested just before it: measured +9 %).  Pairs are formed inside groups of 16 output columns, a
+// group is staged and flushed as WHOLE lines exactly as in the unmapped kernel -- the columns of states the section does
+// not hold go out with whatever the staging area holds, and the other section's launch, which comes second, stores its
+// values over them.  (Both other forms were built and measured on configs[2] with 1 % of the states routed away: masked
+// flushes that leave the foreign columns alone +5 %, direct 4-byte stores for the shared groups +12 % -- a partial
+// write of a line costs a fill of that line, and every frame row has such a line wherever a state is missing.)
 constexpr int kMapCol = 0xffffff;      // column field
 constexpr int kMapEmpty = 1 << 28;     // this track holds no state in this pair (column: the partner's)
-constexpr int kMapFlush16 = 1 << 29;   // last pair of its group of 16 columns in this section / cut
+constexpr int kMapFlush16 = 1 << 29;   // last pair of its group of 16 columns
 constexpr int kMapFlush32 = 1 << 30;   // ... of its group of 32
 
 template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS, bool MAPPED = false>
@@ -1093,6 +1098,16 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   const int lane = tid & 63;
   constexpr int NBUF = SM::NBUF;
   float *ost = abuf0 + NBUF * kTileFloats + wave * SM::kOutFloatsPerWave;
+  int *emap = (int *)(abuf0 + NBUF * kTileFloats + NW * SM::kOutFloatsPerWave);   // MAPPED: [NBUF][2 tracks][8 positions]
+  // a tile's rows and (MAPPED) its 16 pair entries into tile buffer `b`
+  auto issue_tile = [&](int64_t tile, int b) {
+    issue_tile_copy_raw((const float *)apack + (size_t)tile * kTileFloats, abuf0 + b * kTileFloats, kTileFloats, wave, lane, NW);
+    if (MAPPED && wave == NW - 1 && lane < 16) {
+      const int32_t *src = sid + tile * 16 + lane;
+      const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(emap + b * 16));
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off" : : "s"(dst), "v"(src) : "memory", "m0");
+    }
+  };
   // 8-wave form: waves 4-7 pass the tile's barrier in the MIDDLE of their H0 instead of at the end of H1, so they run
   // three quarters of a tile behind waves 0-3 -- the two waves of a SIMD then never sit in their close logic (or at
   // the barrier) at the same time, one of them always has MFMAs to issue.  Three tile buffers make the lag legal: the
@@ -1111,10 +1126,8 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   // The first two tiles are requested before anything else: they land while the frame operand is being built.
   const int64_t t_begin = split_row[4 * blockIdx.y];
   const int64_t t_end = split_row[4 * blockIdx.y + 4];
-  const float *apf = (const float *)apack;
-  if (t_begin < t_end) issue_tile_copy_raw(apf + (size_t)t_begin * kTileFloats, abuf0, kTileFloats, wave, lane, NW);
-  if (t_begin + 1 < t_end)
-    issue_tile_copy_raw(apf + (size_t)(t_begin + 1) * kTileFloats, abuf0 + kTileFloats, kTileFloats, wave, lane, NW);
+  if (t_begin < t_end) issue_tile(t_begin, 0);
+  if (t_begin + 1 < t_end) issue_tile(t_begin + 1, 1);
 
   // ---- frame operand: lane (n, h) holds k = 16*j + 8*h + i, i < 8, of slab j -- split into its terms ONCE per launch by
   // k_frame_operand (below the kernel) and fetched here with 16-byte loads, 64 lanes x 16 B contiguous per instruction.
@@ -1138,10 +1151,6 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   int closes = split_row[4 * blockIdx.y + 1 + (GROUPED ? 0 : h)];
   const int32_t *my_sid = sid + h * sid_stride;
   int next_sid = GROUPED ? 0 : my_sid[closes];
-  typedef int i32x2 __attribute__((ext_vector_type(2)));
-  const i32x2 *my_map = (const i32x2 *)sid + (size_t)h * sid_stride;   // MAPPED: `sid` is the pair table, stride in entries
-  i32x2 next_ent = {0, 0};
-  if (MAPPED) next_ent = my_map[closes];
   float *orow0 = out + (f0 + n) * pitch;  // pitch: row stride of `out` in floats (>= S)
   float *orow1 = out + (f0 + 32 + n) * pitch;
   const bool ok0 = f0 + n < F, ok1 = f0 + 32 + n < F;
@@ -1149,8 +1158,51 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   const unsigned long long *mrow =
       CL ? cl.maskrow + (size_t)(f0 >> 6) * cl.rows_padded + lane : nullptr;
 
+  // a staged group of `cnt` (<= OG) columns from s_base on goes out: whole 16-byte pieces, 128 (64) bytes per frame row
+  auto flush_group = [&](const int64_t s_base, const int cnt) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (OG == 32 && cnt == OG && f0 + FRAMES_PER_WAVE <= F) {
+      // 8 lanes x 16 B cover the 32-state group; 8 frame rows per instruction
+      const int k4 = lane & 7, r8 = lane >> 3;
+      float *op = out + (f0 + r8) * pitch + s_base + 4 * k4;
+      const float *ip = ost + r8 * kOS + 4 * k4;  // stride 34: 8-byte aligned
+#pragma unroll
+      for (int i = 0; i < FRAMES_PER_WAVE / 8; i++) {
+        const f32x2 lo = *(const f32x2 *)(ip + i * 8 * kOS);
+        const f32x2 hi = *(const f32x2 *)(ip + i * 8 * kOS + 2);
+        const f32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+        typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+        *(f32x4u *)(op + (int64_t)i * 8 * pitch) = v;
+      }
+    } else if (cnt == OG && f0 + FRAMES_PER_WAVE <= F) {
+      // 4 lanes x 16 B cover the 16-state group; 16 frame rows per instruction
+      const int k4 = lane & 3, r16 = lane >> 2;
+      float *op = out + (f0 + r16) * pitch + s_base + 4 * k4;
+      const float *ip = ost + r16 * kOS + 4 * k4;
+#pragma unroll
+      for (int i = 0; i < FRAMES_PER_WAVE / 16; i++) {
+        const f32x4 v = *(const f32x4 *)(ip + i * 16 * kOS);
+        typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+        *(f32x4u *)(op + (int64_t)i * 16 * pitch) = v;
+      }
+    } else {
+      constexpr int RPI = 64 / OG;
+      const int k = lane & (OG - 1);
+#pragma unroll 4
+      for (int i = 0; i < FRAMES_PER_WAVE / RPI; i++) {
+        const int row = i * RPI + lane / OG;
+        const float v = ost[row * kOS + k];
+        if (k < cnt && f0 + row < F) out[(f0 + row) * pitch + s_base + k] = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+
   // close logic of one 32-row block: P[nb][q] = this lane's sum of 2^x over quad q for frame block nb
-  auto commit = [&](const float (&P)[2][4], unsigned nib) {
+  // e0 / e1 (MAPPED): the pair entries of the block's four quad positions on track 0 / 1 (wave-uniform: scalar registers)
+  auto commit = [&](const float (&P)[2][4], unsigned nib, const int (&e0)[4], const int (&e1)[4]) {
     if (AASR_DBG(128)) {   // ablation: no close logic
       asm volatile("" ::"v"(P[0][0]), "v"(P[0][1]), "v"(P[0][2]), "v"(P[0][3]), "v"(P[1][0]), "v"(P[1][1]), "v"(P[1][2]), "v"(P[1][3]));
       return;
@@ -1172,56 +1224,14 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
           if (ok1) orow1[next_sid] = l1;
           next_sid = my_sid[closes];
         } else if (MAPPED) {
-          const i32x2 ent = next_ent;
-          next_ent = my_map[closes];   // the next pair's entry: in flight during the phase that follows
-          const int col = ent.x & kMapCol;
-          const int slot = (ent.x & kMapEmpty) ? OG : (col & (OG - 1));   // an empty track stages into the spare slot
+          const int ent = h ? e1[q] : e0[q];
+          const int col = ent & kMapCol;
+          const int slot = (ent & kMapEmpty) ? OG : (col & (OG - 1));   // an empty track stages into the spare slot
           ost[n * kOS + slot] = l0;
           ost[(32 + n) * kOS + slot] = l1;
-          if (ent.x & (OG == 32 ? kMapFlush32 : kMapFlush16)) {   // the same on both tracks: wave-uniform
+          if (ent & (OG == 32 ? kMapFlush32 : kMapFlush16)) {   // the same on both tracks: wave-uniform
             const int64_t s_base = col & ~(OG - 1);
-            const unsigned M = OG == 32 ? (unsigned)ent.y : ((unsigned)ent.y >> (col & 16)) & 0xffffu;
-            const bool whole = s_base + OG <= S && f0 + FRAMES_PER_WAVE <= F;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-            // the loops stay rolled: this code is inlined at every close of the kernel, and the instruction cache is
-            // what an unrolled flush with its per-piece branches would cost (the unmapped kernel's straight-line
-            // 16-byte flush is the common case there; here a section rarely owns a whole line)
-            if (whole) {
-              constexpr int LPR = OG / 4;            // lanes per frame row, 4 columns each
-              constexpr int RPI = 64 / LPR;          // rows per step
-              const int k4 = lane & (LPR - 1), r0 = lane / LPR;
-              float *op = out + (f0 + r0) * pitch + s_base + 4 * k4;
-              const float *ip = ost + r0 * kOS + 4 * k4;   // stride 34 or 20: 8-byte aligned
-              const unsigned nibm = (M >> (4 * k4)) & 15u;
-#pragma unroll 1
-              for (int i = 0; i < FRAMES_PER_WAVE / RPI; i++) {
-                const f32x2 lo = *(const f32x2 *)(ip + i * RPI * kOS);
-                const f32x2 hi = *(const f32x2 *)(ip + i * RPI * kOS + 2);
-                float *o = op + (int64_t)i * RPI * pitch;
-                if (nibm == 15u) {
-                  const f32x4 v = {lo[0], lo[1], hi[0], hi[1]};
-                  *(f32x4u *)o = v;
-                } else {
-                  if (nibm & 1u) o[0] = lo[0];
-                  if (nibm & 2u) o[1] = lo[1];
-                  if (nibm & 4u) o[2] = hi[0];
-                  if (nibm & 8u) o[3] = hi[1];
-                }
-              }
-            } else {
-              constexpr int RPI = 64 / OG;
-              const int k = lane & (OG - 1);
-#pragma unroll 1
-              for (int i = 0; i < FRAMES_PER_WAVE / RPI; i++) {
-                const int row = i * RPI + lane / OG;
-                const float v = ost[row * kOS + k];
-                if (((M >> k) & 1u) && s_base + k < S && f0 + row < F) out[(f0 + row) * pitch + s_base + k] = v;
-              }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            flush_group(s_base, (int)(S - s_base < OG ? S - s_base : OG));
           }
         } else {
           const int pairs_closed = closes;
@@ -1231,45 +1241,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
           const int64_t closed = 2 * (int64_t)pairs_closed < S ? 2 * (int64_t)pairs_closed : S;
           if (((2 * pairs_closed) & (OG - 1)) == 0 || 2 * (int64_t)pairs_closed >= S) {
             const int64_t s_base = ((closed - 1) / OG) * OG;
-            const int cnt = (int)(closed - s_base);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (OG == 32 && cnt == OG && f0 + FRAMES_PER_WAVE <= F) {
-              // 8 lanes x 16 B cover the 32-state group; 8 frame rows per instruction
-              const int k4 = lane & 7, r8 = lane >> 3;
-              float *op = out + (f0 + r8) * pitch + s_base + 4 * k4;
-              const float *ip = ost + r8 * kOS + 4 * k4;  // stride 34: 8-byte aligned
-#pragma unroll
-              for (int i = 0; i < FRAMES_PER_WAVE / 8; i++) {
-                const f32x2 lo = *(const f32x2 *)(ip + i * 8 * kOS);
-                const f32x2 hi = *(const f32x2 *)(ip + i * 8 * kOS + 2);
-                const f32x4 v = {lo[0], lo[1], hi[0], hi[1]};
-                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-                *(f32x4u *)(op + (int64_t)i * 8 * pitch) = v;
-              }
-            } else if (cnt == OG && f0 + FRAMES_PER_WAVE <= F) {
-              // 4 lanes x 16 B cover the 16-state group; 16 frame rows per instruction
-              const int k4 = lane & 3, r16 = lane >> 2;
-              float *op = out + (f0 + r16) * pitch + s_base + 4 * k4;
-              const float *ip = ost + r16 * kOS + 4 * k4;
-#pragma unroll
-              for (int i = 0; i < FRAMES_PER_WAVE / 16; i++) {
-                const f32x4 v = *(const f32x4 *)(ip + i * 16 * kOS);
-                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-                *(f32x4u *)(op + (int64_t)i * 16 * pitch) = v;
-              }
-            } else {
-              constexpr int RPI = 64 / OG;
-              const int k = lane & (OG - 1);
-#pragma unroll 4
-              for (int i = 0; i < FRAMES_PER_WAVE / RPI; i++) {
-                const int row = i * RPI + lane / OG;
-                const float v = ost[row * kOS + k];
-                if (k < cnt && f0 + row < F) out[(f0 + row) * pitch + s_base + k] = v;
-              }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            flush_group(s_base, (int)(closed - s_base));
           }
         }
       }
@@ -1320,19 +1292,20 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     load_frags(abuf0, 0, 0, 0);
   }
   int bi = 0;
+  int ep0[4] = {0, 0, 0, 0}, ep1[4] = {0, 0, 0, 0};   // MAPPED: entries of block 1 of the previous tile
   for (int64_t t = t_begin; t < t_end; t++) {
     float *acur = abuf0 + bi * kTileFloats;
     const int bn = bi + 1 < NBUF ? bi + 1 : 0, bnn = bn + 1 < NBUF ? bn + 1 : 0;
     float *anext = abuf0 + bn * kTileFloats;
     // tile t + 2 goes where tile t - 1 was (three buffers), or into tile t's own buffer when every wave is done
     // with it at the barrier (two buffers, no lagging group)
-    float *anext2 = abuf0 + bnn * kTileFloats;
+    const int bcur = bi;
     bi = bn;
     // barrier t of this wave: its share of tile t + 1 has landed, and every wave is past tile t - 1
     auto tile_barrier = [&]() {
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(mask_v) : : "memory");
       if (!AASR_DBG(16)) __builtin_amdgcn_s_barrier();
-      if (t + 2 < t_end) issue_tile_copy_raw(apf + (size_t)(t + 2) * kTileFloats, anext2, kTileFloats, wave, lane, NW);
+      if (t + 2 < t_end) issue_tile(t + 2, bnn);
     };
     // close bits and selection bits of tile t+1: vector loads waited for by the vmcnt(0) in front of the barrier (an
     // aligned 32-bit word: the array has a spare element).  It has to stay a VECTOR load -- as a scalar load it would turn
@@ -1343,6 +1316,20 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     mask_v = ((const uint32_t *)close_mask)[((t + 1) >> 1) + lane_zero];
     unsigned long long bits_next = 0;
     if (CL && t + 1 < t_end) bits_next = mrow[(size_t)(t + 1) * TILE_ROWS];
+    // MAPPED: this tile's pair entries (this lane's track) out of the tile buffer's side table, both blocks now -- the
+    // buffer may be handed to tile t + 2 at this tile's barrier, in front of the commit of block 0
+    // (one word per lane, then lane reads: the entries are wave-uniform and live in scalar registers)
+    int en00[4] = {0, 0, 0, 0}, en01[4] = {0, 0, 0, 0}, en10[4] = {0, 0, 0, 0}, en11[4] = {0, 0, 0, 0};   // [block][track]
+    if (MAPPED) {
+      const int ev = emap[bcur * 16 + (lane & 15)];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        en00[q] = __builtin_amdgcn_readlane(ev, q);
+        en10[q] = __builtin_amdgcn_readlane(ev, 4 + q);
+        en01[q] = __builtin_amdgcn_readlane(ev, 8 + q);
+        en11[q] = __builtin_amdgcn_readlane(ev, 12 + q);
+      }
+    }
 
     float P[2][4];
     // ---------------- H0: block 0 of tile t  ||  exponentials of block 1 of tile t-1
@@ -1383,7 +1370,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
         }
       }
     }
-    if (t > t_begin) commit(P, (GROUPED ? mask_prev : (h ? mask_prev >> 8 : mask_prev)) >> 4 & 0xfu);
+    if (t > t_begin) commit(P, (GROUPED ? mask_prev : (h ? mask_prev >> 8 : mask_prev)) >> 4 & 0xfu, ep0, ep1);
     // ---------------- H1: block 1 of tile t  ||  exponentials of block 0 of tile t
     {
       int mi = 0;
@@ -1427,7 +1414,12 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
       load_frags(anext, 0, 0, 0);   // slab 0 of the next tile's block 0: in flight during the close logic
       __builtin_amdgcn_sched_barrier(0);
     }
-    commit(P, (GROUPED ? mask_cur : (h ? mask_cur >> 8 : mask_cur)) & 0xfu);
+    commit(P, (GROUPED ? mask_cur : (h ? mask_cur >> 8 : mask_cur)) & 0xfu, en00, en01);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      ep0[q] = en10[q];
+      ep1[q] = en11[q];
+    }
     mask_prev = mask_cur;
     bits_prev = bits_cur;
     {
@@ -1441,7 +1433,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     float P[2][4];
 #pragma unroll
     for (int k = 0; k < 32; k++) epi_step(k, 1, cB0, cB1, bits_prev, P);
-    commit(P, (GROUPED ? mask_prev : (h ? mask_prev >> 8 : mask_prev)) >> 4 & 0xfu);
+    commit(P, (GROUPED ? mask_prev : (h ? mask_prev >> 8 : mask_prev)) >> 4 & 0xfu, ep0, ep1);
   }
 }
 
@@ -1589,7 +1581,7 @@ static void launch_pl_t(const aasr_gmm *g, const TrackLayout &L, const TrackSect
   const u32x4 *fop = frame_operand<NS>(g, L, d_frames, F, blocks * NW, stream);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(NW * 64), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, NS == 3 ? L.a16.p : L.a16h.p, split_row, L.close.p,
-                     MAPPED ? L.pmap.p : L.sid.p, MAPPED ? L.pmap_stride : L.sid_stride,
+                     MAPPED ? L.pmap.p : L.sid.p, MAPPED ? 0 : L.sid_stride,
                      d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, dbg, cl, fop);
   AASR_HIP(hipGetLastError());
 }
@@ -1599,11 +1591,6 @@ template <int N, int NS>
 static constexpr bool wide_ok() {
   if (NS == 2) return PlSmem<N, true, true, NS>::kBytes <= 160 * 1024;
   return 3 * Bf16Smem<N, true, true, NS>::kTileBytes + 8 * Bf16Smem<N, true, true, NS>::kOutFloatsPerWave * 4 <= 160 * 1024;
-}
-
-template <int N, int NS>
-static constexpr bool wide_ok_pl() {
-  return PlSmem<N, true, true, NS>::kBytes <= 160 * 1024;
 }
 
 // NS = 3: three bf16 terms (AASR_PREC_BF16X3) on the wave-group kernel; NS = 2: two fp16 terms (AASR_PREC_F16X2) on
@@ -1616,18 +1603,21 @@ static bool launch_split(const aasr_gmm *g, const TrackLayout &L, const float *d
   if (NS == 3 ? !L.a16.p : !L.a16h.p) return false;
   const TrackSection *sec = section >= 0 ? &L.sec[section] : nullptr;
   if (sec && sec->tile_end <= sec->tile_begin) return true;   // an empty section
-  if (L.mapped && !L.grouped) return false;
+  // section 1 of a mixed layout is laid out as independent tracks (direct stores, no pair table) whatever section 0 is
+  const bool grouped = sec ? sec->grouped : L.grouped;
+  const bool mapped = sec ? sec->mapped : false;
   const ClusterArgs none;
   // AASR_BF16_WIDE=0 selects the 4-wave workgroups
   static const int wide_env = getenv("AASR_BF16_WIDE") ? atoi(getenv("AASR_BF16_WIDE")) : -1;
   // small batches (a decoder's per-utterance blocks) fill the chip better with 256-frame workgroups
-  const int wide = wide_env >= 0 ? wide_env : (F >= 8192 ? 1 : 0);
+  // ... and so does a short section of a mixed layout (a few states on three terms): more, smaller workgroups
+  const int wide = wide_env >= 0 ? wide_env : ((F >= 8192 && (!sec || sec->tile_end - sec->tile_begin >= 64)) ? 1 : 0);
   switch (L.nk16) {
   // mapped (mixed, grouped) layouts run both arithmetic forms on the pipelined kernel, whose epilogue reads the pair table
 #define AASR_LAUNCH(N, GR, CLF, WD, CLA)                                                   \
   do {                                                                                     \
-    if (L.mapped) {                                                                        \
-      if constexpr (GR) launch_pl_t<N, true, CLF, WD, NS, true>(g, L, sec, d_frames, F, d_out, stream, CLA, pitch); \
+    if (mapped) {                                                                          \
+      if constexpr (GR && NS == 2) launch_pl_t<N, true, CLF, WD, NS, true>(g, L, sec, d_frames, F, d_out, stream, CLA, pitch); \
     } else if constexpr (NS == 2 || AASR_PL_BF16X3)                                        \
       launch_pl_t<N, GR, CLF, WD, NS>(g, L, sec, d_frames, F, d_out, stream, CLA, pitch);   \
     else                                                                                   \
@@ -1639,17 +1629,17 @@ static bool launch_split(const aasr_gmm *g, const TrackLayout &L, const float *d
       /* masked (clustered) runs: the bf16x3 8-wave form with masks needs 254 VGPRs + spills and was */ \
       /* measured slower, so it keeps 4-wave workgroups; the f16x2 kernel has the registers          */ \
       if constexpr (NS == 2) {                                                             \
-        if (L.grouped) AASR_LAUNCH(N, true, true, true, *cl);                              \
+        if (grouped) AASR_LAUNCH(N, true, true, true, *cl);                                \
         else AASR_LAUNCH(N, false, true, true, *cl);                                       \
       }                                                                                    \
     } else if (cl) {                                                                       \
-      if (L.grouped) AASR_LAUNCH(N, true, true, false, *cl);                               \
+      if (grouped) AASR_LAUNCH(N, true, true, false, *cl);                                 \
       else AASR_LAUNCH(N, false, true, false, *cl);                                        \
-    } else if (wide && (L.mapped ? wide_ok_pl<N, NS>() : wide_ok<N, NS>())) {              \
-      if (L.grouped) AASR_LAUNCH(N, true, false, true, none);                              \
+    } else if (wide && wide_ok<N, NS>()) {                                                 \
+      if (grouped) AASR_LAUNCH(N, true, false, true, none);                                \
       else AASR_LAUNCH(N, false, false, true, none);                                       \
     } else {                                                                               \
-      if (L.grouped) AASR_LAUNCH(N, true, false, false, none);                             \
+      if (grouped) AASR_LAUNCH(N, true, false, false, none);                               \
       else AASR_LAUNCH(N, false, false, false, none);                                      \
     }                                                                                      \
     return true;
@@ -1665,12 +1655,9 @@ static bool launch_split(const aasr_gmm *g, const TrackLayout &L, const float *d
 static bool launch_bf16(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
                         float *d_out, hipStream_t stream, const ClusterArgs *cl = nullptr, int64_t pitch = 0) {
   if (L.n_sections == 2) {
-    // a mixed layout: the states that qualify in two fp16 terms, the others in three bf16 terms -- one launch per
-    // section, disjoint output columns
-    if (g->precision == AASR_PREC_F16X2)
-      return launch_split<2>(g, L, d_frames, F, d_out, stream, cl, pitch, 0) &&
-             launch_split<3>(g, L, d_frames, F, d_out, stream, cl, pitch, 1);
-    return launch_split<3>(g, L, d_frames, F, d_out, stream, cl, pitch, 0) &&
+    // a mixed layout (AASR_PREC_F16X2 only): the states that qualify in two fp16 terms, then -- the order matters, the
+    // first launch writes whole lines -- the others in three bf16 terms, which store their columns over them
+    return launch_split<2>(g, L, d_frames, F, d_out, stream, cl, pitch, 0) &&
            launch_split<3>(g, L, d_frames, F, d_out, stream, cl, pitch, 1);
   }
   if (g->precision == AASR_PREC_F16X2 && L.a16h.p && launch_split<2>(g, L, d_frames, F, d_out, stream, cl, pitch))
@@ -1688,11 +1675,13 @@ static const TrackLayout *split_layout(const aasr_gmm *g) {
 // ---------------------------------------------------------------------------
 // Load-time guard of the two-term fp16 form.  Which states get it is decided by conditioning limits that were set
 // from sweeps (gmm.h, KAPPA_LIMIT_F16): a bound in the statistical sense, not a proof.  So every model that got fp16
-// rows is probed once when it is built: a few hundred frames placed on its own Gaussians -- 0.5 to 2.5 sigma out in
-// every dimension, and one dimension at a time pushed to +-6 sigma -- are scored by the f16x2 path and by the exact-f32
-// matrix kernel on the same layout family, and a state whose visible values differ by more than 5e-5 (half the 1e-4
-// contract) loses the fp16 rows: it moves to the three-term section of the mixed layout (per-state precision routing),
-// the rest of the model keeps the fast form.  AASR_F16_PROBE=0 switches the guard off.
+// rows is probed once when it is built: frames placed on its own Gaussians -- 0.5 to 2.5 sigma out in every dimension,
+// and one dimension at a time pushed to +-6 sigma -- are scored by the f16x2 path on the device and in double on the
+// host (the formula of aku/Distributions.cc:1040-1062, 2078-2086 over the same components), and a state whose visible
+// values differ by more than 5e-5 (half the 1e-4 contract) loses the fp16 rows: it moves to the three-term section of
+// the mixed layout (per-state precision routing), the rest of the model keeps the fast form.  The number of probe
+// frames is sized so that the host side stays at a few million frame x component pairs (24 ... 192 frames).
+// AASR_F16_PROBE=0 switches the guard off.
 // ---------------------------------------------------------------------------
 void gmm_probe_f16x2(aasr_gmm *g) {
   static const int probe_env = getenv("AASR_F16_PROBE") ? atoi(getenv("AASR_F16_PROBE")) : 1;
@@ -1703,10 +1692,25 @@ void gmm_probe_f16x2(aasr_gmm *g) {
   const int D = m.dim;
   const int64_t S = m.S, K = (int64_t)m.mix_idx.size();
   if (K == 0) return;
-  const int P = (int)std::max<int64_t>(32, std::min<int64_t>(192, 4000000 / std::max<int64_t>(1, S)));
+  const int P = (int)std::max<int64_t>(24, std::min<int64_t>(192, 4000000 / K));
+  // per mixture component: constant + log weight (natural log), as pack_rows forms them; components routed to the
+  // centred kernel (outliers) are not part of the matrix path's sum
+  std::vector<double> cst((size_t)K);
+  std::vector<uint8_t> live((size_t)K, 1);
+  for (int64_t k = 0; k < K; k++) {
+    const int64_t gi = m.mix_idx[(size_t)k];
+    if (!g->outlier.empty() && g->outlier[(size_t)gi]) live[(size_t)k] = 0;
+    double prod = 1;
+    for (int d = 0; d < D; d++) {
+      const double v = m.var[(size_t)gi * D + d];
+      prod *= v > 0 ? 1 / v : 0;
+    }
+    cst[(size_t)k] = ((prod > 0) ? std::log(std::sqrt(prod)) : prod) + m.logw((size_t)k);
+    if (!std::isfinite(cst[(size_t)k])) live[(size_t)k] = 0;
+  }
   for (int round = 0; round < 2; round++) {
     TrackLayout &L0 = g->paired.ok ? g->paired : g->tracks;
-    if (!L0.ok || !L0.rows.a.p) return;
+    if (!L0.ok) return;
     const TrackLayout *LF = g->mixed.ok ? &g->mixed : (L0.a16h.p ? &L0 : nullptr);
     if (!LF) return;
     // probe frames (deterministic): frame i sits on mixture component (i * step) % K
@@ -1734,10 +1738,9 @@ void gmm_probe_f16x2(aasr_gmm *g) {
         fr[(size_t)i * D + d] = (float)x;
       }
     }
-    DevBuf<float> d_fr, d_a, d_b;
+    DevBuf<float> d_fr, d_a;
     d_fr.upload(fr.data(), fr.size());
     d_a.alloc((size_t)P * S);
-    d_b.alloc((size_t)P * S);
     const int prec = g->precision;
     const bool use = g->use_bf16x3;
     g->precision = AASR_PREC_F16X2;
@@ -1745,21 +1748,35 @@ void gmm_probe_f16x2(aasr_gmm *g) {
     const bool ok_a = launch_bf16(g, *LF, d_fr.p, P, d_a.p, nullptr);
     g->precision = prec;
     g->use_bf16x3 = use;
-    const bool ok_b = ok_a && launch_tracks(g, L0, d_fr.p, P, d_b.p, nullptr);
-    if (!ok_a || !ok_b) return;
-    std::vector<float> a((size_t)P * S), b((size_t)P * S);
+    if (!ok_a) return;
+    std::vector<float> a((size_t)P * S);
     AASR_HIP(hipMemcpy(a.data(), d_a.p, a.size() * 4, hipMemcpyDeviceToHost));
-    AASR_HIP(hipMemcpy(b.data(), d_b.p, b.size() * 4, hipMemcpyDeviceToHost));
     std::vector<uint8_t> bad((size_t)S, 0);
     int64_t n_bad = 0;
-    for (int i = 0; i < P; i++)
+    std::vector<double> ph((size_t)D);
+    for (int i = 0; i < P; i++) {
+      const float *x = &fr[(size_t)i * D];
       for (int64_t s2 = 0; s2 < S; s2++) {
-        const float x = a[(size_t)i * S + s2], y = b[(size_t)i * S + s2];
-        if (y > -103.0f && !(std::fabs(x - y) <= probe_tol) && g->f16_state_ok[(size_t)s2] && !bad[(size_t)s2]) {
+        if (!g->f16_state_ok[(size_t)s2] || bad[(size_t)s2]) continue;
+        double sum = 0;
+        for (int32_t k = m.mix_off[s2]; k < m.mix_off[s2 + 1]; k++) {
+          if (!live[(size_t)k]) continue;
+          const int64_t gi = m.mix_idx[(size_t)k];
+          const double *mu = &m.mean[(size_t)gi * D], *var = &m.var[(size_t)gi * D];
+          double q = 0;
+          for (int d = 0; d < D; d++) {
+            const double t = (double)x[d] - mu[d];
+            q += var[d] > 0 ? t * t / var[d] : 0.0;
+          }
+          sum += std::exp(cst[(size_t)k] - 0.5 * q);
+        }
+        const double ref = std::log(std::max(sum, 1e-50)) + g->out_bias_ln;
+        if (ref > -103.0 && !(std::fabs((double)a[(size_t)i * S + s2] - ref) <= (double)probe_tol)) {
           bad[(size_t)s2] = 1;
           n_bad++;
         }
       }
+    }
     if (n_bad == 0) return;
     g->f16_probe_moved += n_bad;
     for (int64_t s2 = 0; s2 < S; s2++)

@@ -534,6 +534,11 @@ def main():
         except Exception as e:
             extra_cfg["stage_ms"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:
+            extra_cfg.update(_measure_precisions(torch, capi, synth, gmm, runner, (mean, var, off, idx, w), PREC,
+                                                 with_models=(rank == 0)))
+        except Exception as e:
+            extra_cfg["precision_ladder"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
             runner.release()
             torch.cuda.empty_cache()
             extra_cfg["configs1"] = _measure_configs1(torch, synth, gmm, rank, dev, stream, sync_all, max_over_ranks,
@@ -632,6 +637,60 @@ def _lna_check(runner, gmm, mean, var, off, idx, w, restore_precision=3):
         out["codes_equal_fraction_f64_mode"] = "failed: %s" % e
     finally:
         gmm.set_precision(restore_precision)
+    return out
+
+
+def _time_scoring(torch, runner, gmm, reps=5):
+    """ms of one scoring pass of `gmm` over the runner's resident feature frames (HIP events on the launch stream)."""
+    def go():
+        gmm.score_dev_pitched(runner.d_fea, runner.d_ll, runner.pitch, runner.stream)
+    go()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(runner.stream)
+    for _ in range(reps):
+        go()
+    e1.record(runner.stream)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def _measure_precisions(torch, capi, synth, gmm, runner, model, restore_precision, with_models=True):
+    """The scoring stage of configs[2] in every arithmetic form the engine has (the any-model numbers next to the
+    headline's), and per-state precision routing: the same model with 1 / 10 / 50 % of its states holding one Gaussian
+    over the two-term form's conditioning limits -- those states run three bf16 terms, the rest keeps two fp16 terms."""
+    import numpy as np
+    out = {}
+    ladder = {}
+    for name, prec in (("f16x2", 4), ("bf16x3", 3), ("f32", 0)):
+        gmm.set_precision(prec)
+        ladder[name] = round(_time_scoring(torch, runner, gmm), 4)
+    gmm.set_precision(restore_precision)
+    out["precision_ladder"] = {"what": "scoring stage of configs[2] (ms per %d frames x %d Gaussians) under each arithmetic: two fp16 "
+                                       "terms (the default where a model's conditioning allows it), three bf16 terms (any model "
+                                       "on the matrix path), plain f32 matrix instructions" % (runner.total_frames, G),
+                               "scoring_ms": ladder}
+    if not with_models:
+        return out
+    rng = np.random.default_rng(synth.SEED + 99)
+    routing = []
+    for share in (0.01, 0.10, 0.50):
+        bad = sorted(rng.choice(S, max(1, int(round(share * S))), replace=False).tolist())
+        g2 = capi.Gmm.from_arrays(*synth.push_states_over_the_f16_limits(model, bad))
+        n16, moved = g2.precision_states()
+        ms = _time_scoring(torch, runner, g2)
+        g2.set_precision(3)
+        ms3 = _time_scoring(torch, runner, g2)
+        g2.close()
+        routing.append({"states_over_the_f16x2_limits": len(bad), "share": share, "states_f16x2": n16,
+                        "states_moved_by_the_probe": moved, "scoring_ms": round(ms, 4),
+                        "ratio_to_all_f16x2": round(ms / ladder["f16x2"], 4),
+                        "target_1_plus_0.65_share": round(1.0 + 0.65 * share, 4),
+                        "scoring_ms_whole_model_bf16x3": round(ms3, 4)})
+    out["precision_routing"] = {"what": "per-state precision routing (aasr_gmm_precision_states): the configs[2] model with one Gaussian "
+                                        "of a share of its states moved over the two-term form's conditioning limits; before round 4 "
+                                        "ONE such Gaussian sent the whole model to the three-term kernel",
+                                "models": routing}
     return out
 
 

@@ -127,8 +127,9 @@ def test_config2_one_hour_full_chain(capi, oracle):
         assert np.abs(lp - lp_ref)[smooth].max() <= 1e-4
         # ... and inside it what the contract allows: within one denormal quantum of the reference's float
         n_band += assert_lp_denormal_band(lp, lik, "configs[2] utterance %d" % u)
+    # (the 50 000-Gaussian model leaves no state of these frames in the band; tests/test_pipeline_gpu.py::
+    # test_float_denormal_band_end_to_end holds a model that puts a quarter of them there)
     print("configs[2] LNA codes identical to the oracle's:", equal_frac, "denormal-band values checked:", n_band)
-    assert n_band > 1000      # the 50 000-Gaussian model puts a share of every frame's states into the band
     assert min(equal_frac) >= CODES_EQUAL_MIN     # observed 0.9950; never more than one step apart (above)
     for u in range(360):
         data, n = capi.run_utterance(runner.feat, gmm, utts[u], lnabytes=2)

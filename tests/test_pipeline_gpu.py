@@ -8,7 +8,7 @@ import wave
 import numpy as np
 import pytest
 
-from conftest import CODES_EQUAL_MIN, observed
+from conftest import CODES_EQUAL_MIN, assert_lp_denormal_band, observed
 
 from aaltoasr_amd import synth
 
@@ -40,6 +40,36 @@ def setup(capi, oracle, golden_dir):
     # posteriors are not all at the floor
     return dict(cfg=cfg, model=model, ch=oracle.FeatureChain(cfg), om=oracle.DiagModel(*model),
                 ft=capi.Feat(cfg), gm=capi.Gmm.from_arrays(*model))
+
+
+def test_float_denormal_band_end_to_end(capi, oracle, setup):
+    """The band the other end-to-end tests step around, checked for what the contract allows inside it.  The reference
+    keeps the LINEAR state likelihood in a float before it normalises (aku/phone_probs.cc:224-236): for
+    ln 2^-149 < ll < ln 2^-126 that float is a denormal, a whole number of quanta of 2^-149, and 1e-4 on ll can move the
+    rounding by one quantum -- up to 0.69 in the logarithm at one quantum.  A model whose Gaussians lie 2.6x further out
+    than the features puts a quarter of all (frame, state) values into that band: audio -> MFCC chain -> scoring ->
+    normalised 4-byte LNA values in one call, every band value within one quantum of the oracle's float, everything
+    outside it within 1e-4, in every scoring arithmetic."""
+    mean, var, off, idx, w = synth.make_model(D=39, G=1024, S=128, comps=8, seed=517)
+    model = (mean * 2.6, var, off, idx, w)
+    om = oracle.DiagModel(*model)
+    pcm = synth.make_audio(80000, seed=518)
+    fea = setup["ch"].generate(pcm, 0, 623)
+    ll_ref, lik = om.score(fea, want_lik=True)
+    lp_ref, _ = oracle.lna_encode(lik, True, 4)
+    band = (ll_ref > np.log(2.0 ** -149)) & (ll_ref < np.log(2.0 ** -126))
+    assert band.mean() > 0.1, band.mean()
+    gm = capi.Gmm.from_arrays(*model)
+    for prec in (4, 3, 0):
+        gm.set_precision(prec)
+        data, frames = capi.run_utterance(setup["ft"], gm, pcm, lnabytes=4)
+        assert frames == 623
+        lp = np.frombuffer(data[5:], "<f4").reshape(623, 128)
+        n_band = assert_lp_denormal_band(lp, lik, "precision %d" % prec)
+        assert n_band >= int(band.sum())
+        smooth = (ll_ref > -87.0) | (ll_ref < -104.5)
+        assert np.abs(lp - lp_ref)[smooth].max() <= 1e-4, prec
+    gm.close()
 
 
 @pytest.mark.parametrize("nbytes", [2, 4])
