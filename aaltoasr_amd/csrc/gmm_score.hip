@@ -1050,6 +1050,15 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
 // ahead into a second register set.  Everything else (operand layout, track epilogue, output groups, row cuts,
 // selection masks) is the kernel above; results are bit-identical between the 4- and 8-wave forms.
 // ---------------------------------------------------------------------------
+// Work decomposition of a pipelined-kernel launch (see pick_cut_plan).
+struct CutPlan {
+  int n_main = 0;        // workgroups of the coarse part: blocks_main frame blocks x r_main cuts
+  int blocks_main = 1;
+  int blocks_rem = 1;    // frame blocks of the fine part
+  int r_main = 1, r_rem = 0;
+  const int32_t *split_rem = nullptr;   // cut table row of the fine part
+};
+
 template <int NK16, bool GROUPED, bool WIDE, int NS>
 struct PlSmem {
   static constexpr int kTileBytes = NK16 * NS * 2 * 64 * 16;
@@ -1083,9 +1092,24 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
     const uint16_t *__restrict__ close_mask, const int32_t *__restrict__ sid, int sid_stride,
     float *__restrict__ out, int64_t S, int64_t pitch, float ref_ln, int dbg, ClusterArgs cl,
-    const u32x4 *__restrict__ fop) {
+    const u32x4 *__restrict__ fop, CutPlan plan) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   typedef PlSmem<NK16, GROUPED, WIDE, NS> SM;
+  // work item -> (frame block, row cut): the first n_main workgroups take the coarse cuts of the frame blocks that fill
+  // whole rounds of the chip, the rest the fine cuts of the remaining blocks (pick_cut_plan); within either part the cut
+  // is the slow index, so the workgroups resident at one time stream the same rows
+  int blk, cut;
+  if ((int)blockIdx.x < plan.n_main) {
+    cut = (int)blockIdx.x / plan.blocks_main;
+    blk = (int)blockIdx.x - cut * plan.blocks_main;
+  } else {
+    const int b = (int)blockIdx.x - plan.n_main;
+    cut = b / plan.blocks_rem;
+    blk = plan.blocks_main + (b - cut * plan.blocks_rem);
+    split_row = plan.split_rem;
+  }
+  blk = __builtin_amdgcn_readfirstlane(blk);
+  cut = __builtin_amdgcn_readfirstlane(cut);
   constexpr int OG = SM::OG;
   constexpr int kTileFloats = SM::kTileBytes / 4;
   constexpr int kOS = SM::kOutStride;
@@ -1121,11 +1145,11 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   constexpr int JB = NK16 / 2;   // slab of H0 in front of which the lagging group's barrier sits
   const int n = lane & 31;
   const int h = lane >> 5;  // K half of a slab held by this lane AND its row track
-  const int64_t f0 = (int64_t)blockIdx.x * (NW * FRAMES_PER_WAVE) + wave * FRAMES_PER_WAVE;
+  const int64_t f0 = (int64_t)blk * (NW * FRAMES_PER_WAVE) + wave * FRAMES_PER_WAVE;
 
   // The first two tiles are requested before anything else: they land while the frame operand is being built.
-  const int64_t t_begin = split_row[4 * blockIdx.y];
-  const int64_t t_end = split_row[4 * blockIdx.y + 4];
+  const int64_t t_begin = split_row[4 * cut];
+  const int64_t t_end = split_row[4 * cut + 4];
   if (t_begin < t_end) issue_tile(t_begin, 0);
   if (t_begin + 1 < t_end) issue_tile(t_begin + 1, 1);
 
@@ -1135,7 +1159,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   // ~20 us -- six tiles' time in front of every row cut, paid R times per frame.
   u32x4 bq[NK16][NS][2];
   {
-    const u32x4 *bw = fop + ((size_t)blockIdx.x * NW + wave) * (NK16 * NS * 2 * 64) + lane;
+    const u32x4 *bw = fop + ((size_t)blk * NW + wave) * (NK16 * NS * 2 * 64) + lane;
 #pragma unroll
     for (int j = 0; j < NK16; j++)
 #pragma unroll
@@ -1148,7 +1172,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   __syncthreads();
 
   float s0 = 0.0f, s1 = 0.0f;
-  int closes = split_row[4 * blockIdx.y + 1 + (GROUPED ? 0 : h)];
+  int closes = split_row[4 * cut + 1 + (GROUPED ? 0 : h)];
   const int32_t *my_sid = sid + h * sid_stride;
   int next_sid = GROUPED ? 0 : my_sid[closes];
   float *orow0 = out + (f0 + n) * pitch;  // pitch: row stride of `out` in floats (>= S)
@@ -1534,6 +1558,56 @@ static int pick_row_cuts(int64_t blocks, double slots, int64_t tiles, int max_sp
 }
 
 // `sec`: the section of a mixed layout to score (its tiles and row-cut table), nullptr: the whole layout
+// Two-level plan: the workgroups of a launch run in rounds of `slots`, and a uniform R leaves the last round partly
+// empty (configs[2]: 878 blocks x 2 cuts = 6.86 rounds of 256).  So the frame blocks that fill whole rounds at a coarse
+// cut count go first, and the remaining blocks are cut finer so that THEIR last round is nearly full too: configs[2]
+// 768 blocks x 2 cuts (6 rounds) + 110 blocks x 16 cuts (6.9 short rounds) instead of 7 long ones.  Same cost model as
+// pick_row_cuts; falls back to the uniform plan when that is no better.
+static CutPlan pick_cut_plan(int64_t blocks, double slots_d, int64_t tiles, int max_splits, double overhead,
+                             const int32_t *splits_base) {
+  static const int force_r = getenv("AASR_SPLITS") ? atoi(getenv("AASR_SPLITS")) : 0;
+  static const double force_c = getenv("AASR_CUT_OVERHEAD") ? atof(getenv("AASR_CUT_OVERHEAD")) : -1.0;
+  static const int two_level = getenv("AASR_TWO_LEVEL") ? atoi(getenv("AASR_TWO_LEVEL")) : 1;
+  if (force_c >= 0) overhead = force_c;
+  const int64_t slots = (int64_t)slots_d;
+  CutPlan best;
+  double best_cost = 1e300;
+  auto row = [&](int r) { return splits_base + (size_t)(r - 1) * (TRACK_MAX_SPLITS + 1) * 4; };
+  for (int r1 = 1; r1 <= max_splits; r1++) {
+    if (force_r >= 1 && force_r <= max_splits && r1 != force_r) continue;
+    // uniform
+    const double uni = std::ceil((double)blocks * r1 / slots_d) * ((double)tiles / r1 + overhead);
+    if (uni < best_cost * 0.999) {
+      best_cost = uni;
+      best = CutPlan();
+      best.n_main = (int)(blocks * r1);
+      best.blocks_main = (int)blocks;
+      best.r_main = r1;
+    }
+    if (!two_level || (force_r >= 1 && force_r <= max_splits)) continue;
+    // whole rounds at r1, the rest at r2
+    const int64_t rounds = blocks * r1 / slots;
+    if (rounds < 1 || (rounds * slots) % r1 != 0) continue;
+    const int64_t bm = rounds * slots / r1;
+    const int64_t rem = blocks - bm;
+    if (rem <= 0) continue;
+    for (int r2 = r1 + 1; r2 <= max_splits; r2++) {
+      const double cost = (double)rounds * ((double)tiles / r1 + overhead) +
+                          std::ceil((double)rem * r2 / slots_d) * ((double)tiles / r2 + overhead);
+      if (cost < best_cost * 0.995) {
+        best_cost = cost;
+        best.n_main = (int)(bm * r1);
+        best.blocks_main = (int)bm;
+        best.blocks_rem = (int)rem;
+        best.r_main = r1;
+        best.r_rem = r2;
+        best.split_rem = row(r2);
+      }
+    }
+  }
+  return best;
+}
+
 template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS>
 static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const TrackSection *sec, const float *d_frames, int64_t F,
                           float *d_out, hipStream_t stream, const ClusterArgs &cl, int64_t pitch) {
@@ -1574,15 +1648,17 @@ static void launch_pl_t(const aasr_gmm *g, const TrackLayout &L, const TrackSect
     AASR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set[g->device & 63] = true;
   }
-  const int R = pick_row_cuts(blocks, (WIDE ? 1.0 : 2.0) * (g->num_cus > 0 ? g->num_cus : 256),
-                              sec ? sec->tile_end - sec->tile_begin : L.rows_padded / TILE_ROWS,
-                              sec ? sec->max_splits : L.max_splits, 3.0);
-  const int32_t *split_row = (sec ? sec->splits.p : L.splits.p) + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
+  const int32_t *splits_base = sec ? sec->splits.p : L.splits.p;
+  const CutPlan plan = pick_cut_plan(blocks, (WIDE ? 1.0 : 2.0) * (g->num_cus > 0 ? g->num_cus : 256),
+                                     sec ? sec->tile_end - sec->tile_begin : L.rows_padded / TILE_ROWS,
+                                     sec ? sec->max_splits : L.max_splits, 3.0, splits_base);
+  const int32_t *split_row = splits_base + (size_t)(plan.r_main - 1) * (TRACK_MAX_SPLITS + 1) * 4;
   const u32x4 *fop = frame_operand<NS>(g, L, d_frames, F, blocks * NW, stream);
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(NW * 64), smem, stream, d_frames, F,
+  const unsigned n_items = (unsigned)(plan.n_main + (plan.r_rem ? plan.blocks_rem * plan.r_rem : 0));
+  hipLaunchKernelGGL(kern, dim3(n_items), dim3(NW * 64), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, NS == 3 ? L.a16.p : L.a16h.p, split_row, L.close.p,
                      MAPPED ? L.pmap.p : L.sid.p, MAPPED ? 0 : L.sid_stride,
-                     d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, dbg, cl, fop);
+                     d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, dbg, cl, fop, plan);
   AASR_HIP(hipGetLastError());
 }
 

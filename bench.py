@@ -9,10 +9,15 @@ A "step" is one pass of the hot path over one batch of synthetic input:
          in HBM -> MFCC chain -> 50 000-Gaussian / 3 125-state x 16 diagonal HmmSet scoring ->
          2-byte LNA codes.  The default run also reports the per-stage split, the HBM rooflines
          of the feature chain and the LNA pass (roofline.stages), the fraction of LNA codes equal
-         to the oracle's on a sampled utterance, configs[1] (config.configs1) and a small recipe
-         run with file IO (config.recipe_e2e), so one driver run carries all of them.
+         to the oracle's on a sampled utterance, the scoring stage under every arithmetic the engine
+         has (config.precision_ladder: f16x2 / bf16x3 / f32) and under per-state precision routing
+         (config.precision_routing: 1 / 10 / 40 % of the states over the f16x2 limits), the clustered
+         pass pyrectool runs (config.clustered), configs[1] (config.configs1), configs[4]
+         (config.configs4) and configs[3] at full size -- the 10 000-utterance recipe, WAV files in,
+         2-byte and 4-byte LNA files out (config.recipe_e2e; a 256-utterance miniature when /dev/shm
+         has no room) -- so one driver run carries all of them.
   gmm    (BASELINE configs[1]): 1 000 000 x 39 float32 frames, resident in HBM, against the same
-         model -> [F x S] state log-likelihoods (k_gmm_diag_score_bf16x3); no MFCC, no LNA.
+         model -> [F x S] state log-likelihoods (k_gmm_diag_score_pl, two fp16 terms); no MFCC, no LNA.
   recipe (BASELINE configs[3]): a recipe of --utts (default 10 000) seeded utterances of
          U(2 s, 12 s) as WAV files, sliced over the ranks with Recipe::read's rule
          (aku/Recipe.cc:63-115), read -> features -> scoring -> 2-byte LNA files written; value =
@@ -27,10 +32,13 @@ size RCCL reported, never the flag.
 
 Prints ONE JSON line on rank 0.  The roofline block prices the dominant kernel in ALGORITHMIC
 flops: 4*dim = 156 flop per frame x Gaussian pair against the ceiling of
-the pipe it runs on: dense BF16 matrix peak 2500 TFLOP/s / 6 bf16 products per f32-accurate
-product (`--precision f32`: the dense FP32 matrix peak, 157.3 TFLOP/s); the ratio to the FP32
-matrix peak is reported next to it.  The cpu_baseline block times the oracle's reference-shaped
-scalar double loop on this host (rank 0, N = 1 only).
+the pipe it runs on -- default (`--precision f16x2`): the dense FP16 matrix peak 2500 TFLOP/s / 3
+fp16 products per product; `--precision bf16x3`: the dense BF16 peak / 6; `--precision f32`: the
+dense FP32 matrix peak, 157.3 TFLOP/s -- with the ratio to the FP32 matrix peak next to it.
+roofline.kernel_ms is timed with HIP events around the scoring call, i.e. it holds the launch of
+k_gmm_diag_score_pl AND the k_frame_operand launch in front of it (the frame operand of the
+split-term kernel, formed once per step: ~0.08 ms of the ~8.5).  The cpu_baseline block times the
+oracle's reference-shaped scalar double loop on this host (rank 0, N = 1 only).
 """
 from __future__ import annotations
 
@@ -231,6 +239,78 @@ def write_recipe_inputs(workdir, lengths, first, count, sample_rate=16000):
             w.setsampwidth(2)
             w.setframerate(sample_rate)
             w.writeframes(pool[o:o + n].astype("<i2").tobytes())
+
+
+def run_recipe_e2e(args, capi, synth, shard, gmm, world, rank, sync_all, max_over_ranks, sum_over_ranks):
+    """configs[3] inside the default run: the 10 000-utterance recipe (8.73 M frames; WAV files in, LNA files out, every
+    rank its Recipe::read slice) once with 2-byte LNA files and once with the 4-byte files pyrectool asks for
+    (pyrectool/rectool.py:655-666 passes --lnabytes=4) -- when the box has room for them in /dev/shm (55 / 109 GB per
+    pass), else a 256-utterances-per-rank miniature.  One untimed small pass first (device buffers, pinned slots)."""
+    feat = capi.Feat(synth.make_feature_config())
+    n_full = 10000
+    lengths_full = recipe_lengths(n_full)
+    frames_full = int(sum(feat.eof_frame(int(n)) for n in lengths_full))
+    need = frames_full * S * 4 + int(lengths_full.sum()) * 2
+    roomy = False
+    try:
+        roomy = (not args.recipe_dir and os.access("/dev/shm", os.W_OK) and
+                 shutil.disk_usage("/dev/shm").free > 1.25 * need) or \
+                (args.recipe_dir and shutil.disk_usage(args.recipe_dir).free > 1.25 * need)
+    except OSError:
+        pass
+    if os.environ.get("AASR_BENCH_RECIPE_SMALL") == "1":
+        roomy = False
+    # every rank must take the same branch
+    roomy = max_over_ranks(0.0 if roomy else 1.0) == 0.0
+    n_utts = n_full if roomy else 256 * world
+    lengths = recipe_lengths(n_utts)
+    frames_all = np.array([feat.eof_frame(int(n)) for n in lengths], np.int64)
+    first, count = shard.rank_slice(n_utts, world, rank)
+    my_frames = int(frames_all[first:first + count].sum())
+    workdir = _recipe_dir(args, my_frames * S * 4 + int(lengths[first:first + count].sum()) * 2)
+    out = {"what": "configs[3]%s: %d utterances U(2 s, 12 s) (%d frames), WAV files in %s -> LNA files, one pass each, "
+                   "Recipe::read slices over %d rank(s)" % ("" if roomy else " in small", n_utts, int(frames_all.sum()),
+                                                            os.path.dirname(workdir), world),
+           "full_size": bool(roomy), "utterances": n_utts, "frames": int(frames_all.sum())}
+    try:
+        write_recipe_inputs(workdir, lengths, first, count)
+        recipe = os.path.join(workdir, "r%d.recipe" % rank)
+        with open(recipe, "w") as f:
+            for i in range(n_utts):
+                f.write("audio=%s lna=u%05d.lna\n" % (os.path.join(workdir, "u%05d.wav" % i), i))
+        warm = os.path.join(workdir, "w%d.recipe" % rank)
+        with open(warm, "w") as f:
+            for i in range(first, first + min(count, 64)):
+                f.write("audio=%s lna=u%05d.lna\n" % (os.path.join(workdir, "u%05d.wav" % i), i))
+
+        def one(path, lnabytes, outdir, sliced):
+            os.makedirs(outdir, exist_ok=True)
+            return capi.run_recipe(feat, gmm, path, lnabytes=lnabytes, out_dir=outdir,
+                                   num_batches=world if (sliced and world > 1) else 0,
+                                   batch_index=rank + 1 if (sliced and world > 1) else 0)
+        for nb in (2, 4):
+            one(warm, nb, os.path.join(workdir, "lna", "warm%d" % nb), False)
+            shutil.rmtree(os.path.join(workdir, "lna"), ignore_errors=True)
+            sync_all()
+            t0 = time.perf_counter()
+            st = one(recipe, nb, os.path.join(workdir, "lna", "b%d" % nb), True)
+            sync_all()
+            wall = max_over_ranks(time.perf_counter() - t0)
+            assert st.frames == my_frames and st.utterances == count, (st.frames, my_frames, st.utterances, count)
+            tot = sum_over_ranks(float(my_frames))
+            devs = max_over_ranks(st.seconds_device)
+            out["lnabytes_%d" % nb] = {"frames_per_s_wall": round(tot / wall, 1), "wall_s": round(wall, 4),
+                                       "frames_per_s_device_only": round(tot / max(devs, 1e-9), 1),
+                                       "pcie_copy_out_s_rank0": round(st.seconds_copy_out, 4),
+                                       "lna_GB_written_per_rank": round(my_frames * S * nb / 1e9, 3)}
+            shutil.rmtree(os.path.join(workdir, "lna"), ignore_errors=True)
+        # the keys the round-3 line carried, for the 2-byte pass
+        out["frames_per_s_wall"] = out["lnabytes_2"]["frames_per_s_wall"]
+        out["frames_per_s_device_only"] = out["lnabytes_2"]["frames_per_s_device_only"]
+        out["wall_s"] = out["lnabytes_2"]["wall_s"]
+        return out
+    finally:
+        shutil.rmtree(workdir, ignore_errors=True)
 
 
 def run_recipe_workload(args, capi, synth, shard, gmm, world, rank, n_utts, steps, warmup, sync_all, workdir=None):
@@ -548,6 +628,12 @@ def main():
         if rank == 0:
             try:
                 torch.cuda.empty_cache()
+                extra_cfg["clustered"] = _measure_clustered(torch, capi, synth, (mean, var, off, idx, w), dev, stream,
+                                                            args.frames)
+            except Exception as e:
+                extra_cfg["clustered"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                torch.cuda.empty_cache()
                 extra_cfg["configs4"] = _measure_configs4(torch, capi, synth, dev, stream)
             except Exception as e:
                 extra_cfg["configs4"] = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -562,17 +648,9 @@ def main():
             extra_cfg["configs2"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if args.workload in ("gmm", "full") and args.secondary:
         try:
-            n_small = 256 * world
-            res = run_recipe_workload(args, capi, synth, shard, gmm, world, rank, n_small, 1, 1, sync_all)
-            wall = max_over_ranks(res["wall_s"])
-            tot = sum_over_ranks(float(res["frames"]))
-            devs = max_over_ranks(res["device_s"])
-            extra_cfg["recipe_e2e"] = {
-                "what": "configs[3] in small: %d utterances U(2 s, 12 s) (256 per rank), WAV files in %s -> 2-byte LNA "
-                        "files, one pass, Recipe::read slices" % (n_small, res["dir"]),
-                "frames": int(tot), "frames_per_s_wall": round(tot / wall, 1),
-                "frames_per_s_device_only": round(tot / max(devs, 1e-9), 1), "wall_s": round(wall, 4),
-                "lna_GB_written_per_rank": round(res["lna_bytes_per_step"] / 1e9, 3)}
+            torch.cuda.empty_cache()
+            extra_cfg["recipe_e2e"] = run_recipe_e2e(args, capi, synth, shard, gmm, world, rank, sync_all, max_over_ranks,
+                                                     sum_over_ranks)
         except Exception as e:
             extra_cfg["recipe_e2e"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
@@ -657,8 +735,9 @@ def _time_scoring(torch, runner, gmm, reps=5):
 
 def _measure_precisions(torch, capi, synth, gmm, runner, model, restore_precision, with_models=True):
     """The scoring stage of configs[2] in every arithmetic form the engine has (the any-model numbers next to the
-    headline's), and per-state precision routing: the same model with 1 / 10 / 50 % of its states holding one Gaussian
-    over the two-term form's conditioning limits -- those states run three bf16 terms, the rest keeps two fp16 terms."""
+    headline's), and per-state precision routing: the same model with 1 / 10 / 40 % of its states holding one Gaussian
+    over the two-term form's conditioning limits -- those states run three bf16 terms, the rest keeps two fp16 terms
+    (a model with more than 45 % of such states keeps one arithmetic: routing would cost as much)."""
     import numpy as np
     out = {}
     ladder = {}
@@ -674,7 +753,7 @@ def _measure_precisions(torch, capi, synth, gmm, runner, model, restore_precisio
         return out
     rng = np.random.default_rng(synth.SEED + 99)
     routing = []
-    for share in (0.01, 0.10, 0.50):
+    for share in (0.01, 0.10, 0.40):
         bad = sorted(rng.choice(S, max(1, int(round(share * S))), replace=False).tolist())
         g2 = capi.Gmm.from_arrays(*synth.push_states_over_the_f16_limits(model, bad))
         n16, moved = g2.precision_states()
@@ -740,6 +819,45 @@ def _measure_configs1(torch, synth, gmm, rank, dev, stream, sync_all, max_over_r
             "frames_per_gpu_per_step": F, "steps": steps, "ms_per_step": round(ms, 4),
             "frames_per_s": round(world * F * steps / elapsed, 1),
             "algorithmic_TFLOPs": round(flop / (ms * 1e-3) / 1e12, 2)}
+
+
+def _measure_clustered(torch, capi, synth, model, dev, stream, frames, steps=3):
+    """What production recognisers run (pyrectool passes -C ... --eval-ming 0.25, rectool.py:662-664): the configs[1]
+    block scored with Gaussian clustering on -- 1000 clusters, int(0.25 G) Gaussians evaluated exactly per frame, the
+    rest at their cluster centre's value (aku/Distributions.cc:2684-2722).  A fresh handle on rank 0."""
+    C_ = 1000
+    g2c = synth.make_clustering(model[0], C_, iters=2)
+    g = capi.Gmm.from_arrays(*model)
+    g.set_clustering(C_, [(i, int(c)) for i, c in enumerate(g2c)])
+    g.set_clustering_min_evals(0.0, 0.25)
+    F = frames
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(synth.SEED + 23)
+    d_frames = torch.randn((F, DIM), generator=gen, device=dev, dtype=torch.float32)
+    pitch = (S + 31) // 32 * 32 if g.score_pitch_ok() else S
+    d_out = torch.empty((F, pitch), device=dev, dtype=torch.float32)
+
+    def step():
+        if pitch == S:
+            g.score_dev(d_frames, d_out, stream)
+        else:
+            g.score_dev_pitched(d_frames, d_out, pitch, stream)
+    step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(steps):
+        step()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    n_exact = g.cluster_exact_counts(min(F, 2000))
+    g.close()
+    return {"what": "configs[1] with Gaussian clustering: %d frames x %d Gaussians in %d clusters, --eval-minc 0 --eval-ming 0.25 "
+                    "(centres, selection, masked scoring, merge), output row pitch %d floats" % (F, G, C_, pitch),
+            "clusters": C_, "eval_ming": 0.25, "frames": F, "ms_per_pass": round(ms, 3),
+            "ms_per_million_frames": round(ms * 1e6 / F, 3), "frames_per_s": round(F / ms * 1e3, 1),
+            "clusters_evaluated_exactly_per_frame_mean": round(float(n_exact.mean()), 1)}
 
 
 def _measure_configs4(torch, capi, synth, dev, stream, steps=5):

@@ -11,9 +11,10 @@ def _run(args, env=None):
     e = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         e.pop(k, None)
+    e["AASR_BENCH_RECIPE_SMALL"] = "1"      # the 256-utterance recipe instead of the 10 000-utterance one (55 + 109 GB of files)
     e.update(env or {})
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
-                          env=e, timeout=300)
+                          env=e, timeout=600)
 
 
 def test_gpus_flag_is_never_silently_reduced():
@@ -67,7 +68,14 @@ def test_bench_line_on_a_gpu(args, key):
         assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
         assert "error" not in d["config"]["configs1"] and "error" not in d["config"]["recipe_e2e"]
         assert d["config"]["configs1"]["frames_per_s"] > 0
+        assert d["config"]["recipe_e2e"]["lnabytes_2"]["frames_per_s_wall"] > 0 and d["config"]["recipe_e2e"]["lnabytes_4"]["frames_per_s_wall"] > 0
+        lad = d["config"]["precision_ladder"]["scoring_ms"]
+        assert 0 < lad["f16x2"] < lad["bf16x3"] < lad["f32"]
+        routed = d["config"]["precision_routing"]["models"]
+        assert [m["share"] for m in routed] == [0.01, 0.1, 0.4]
+        assert all(0 < m["states_f16x2"] < 3125 and m["scoring_ms"] < m["scoring_ms_whole_model_bf16x3"] for m in routed)
         assert "error" not in d["config"]["configs4"] and d["config"]["configs4"]["effective_precision"] == "f16x2"
+        assert d["config"]["clustered"]["ms_per_million_frames"] > 0 and d["config"]["clustered"]["eval_ming"] == 0.25
         assert d["config"]["lna_check"]["max_code_difference"] <= 1
     if key == "gmm":
         assert d["config"]["workload"].startswith("configs[1]")
@@ -88,7 +96,8 @@ def test_two_ranks_go_through_the_whole_default_run():
     e = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         e.pop(k, None)
-    e.update({"AASR_BENCH_SHARE_GPU": "1", "AASR_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    e.update({"AASR_BENCH_SHARE_GPU": "1", "AASR_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+              "AASR_BENCH_RECIPE_SMALL": "1"})
     import socket
     with socket.socket() as sk:     # a port nobody holds right now
         sk.bind(("127.0.0.1", 0))

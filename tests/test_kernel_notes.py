@@ -1,0 +1,54 @@
+"""The scoring kernels' register budget, read from the code object's notes (no GPU needed).
+
+k_gmm_diag_score_pl sits at the register wall of the two-waves-per-SIMD form: the frame operand (80 VGPRs), two
+accumulator sets (64), two fragment sets.  Round 3's bench instance had grown to 256 VGPRs + 24 spilled ones (all in
+its prologue); since the frame operand is formed by k_frame_operand and only loaded here, the instances have no scratch
+at all -- and a spill that enters the tile loop would cost far more than the few percent any scheduling change gains,
+silently.  So the build fails this test when the bench instance (or any two-term instance the default paths launch)
+starts to use scratch memory."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def notes(capi):
+    import kernel_notes
+    obj = os.path.join(ROOT, "aaltoasr_amd", "lib", "obj", "gmm_score.hip.o")
+    assert os.path.exists(obj)
+    return kernel_notes.kernel_notes(obj)
+
+
+def _get(notes, name):
+    hits = [v for k, v in notes.items() if k.endswith(name)]
+    assert len(hits) == 1, (name, len(hits))
+    return hits[0]
+
+
+def test_bench_instance_has_no_scratch(notes):
+    # configs[1] / configs[2]: 39 dimensions (NK16 = 5), grouped tracks, unmasked, 8-wave form, two fp16 terms
+    k = _get(notes, "k_gmm_diag_score_pl<5, true, false, true, 2, false>")
+    assert k["scratch"] == 0 and k["spill_vgpr"] == 0 and k["spill_sgpr"] == 0, k
+    assert k["vgpr"] <= 232 and k["agpr"] == 0, k          # 206 when this was written; 256 is the wall
+
+
+@pytest.mark.parametrize("inst", [
+    "k_gmm_diag_score_pl<5, true, true, true, 2, false>",    # the clustered (masked) pass
+    "k_gmm_diag_score_pl<5, true, false, false, 2, false>",  # small batches: 4-wave form
+    "k_gmm_diag_score_pl<5, true, false, true, 2, true>",    # per-state precision routing: section 0 of a mixed layout
+    "k_gmm_diag_score_pl<5, true, true, true, 2, true>",
+    "k_gmm_diag_score_pl<5, false, false, true, 2, false>",  # independent tracks
+])
+def test_two_term_instances_of_the_default_paths_have_no_scratch(notes, inst):
+    k = _get(notes, inst)
+    assert k["scratch"] == 0 and k["spill_vgpr"] == 0, (inst, k)
+
+
+def test_every_dimension_instance_of_the_bench_form_has_no_scratch(notes):
+    bad = {n: k for n, k in notes.items()
+           if "k_gmm_diag_score_pl<" in n and n.endswith(", 2, false>") and (k["scratch"] or k["spill_vgpr"])}
+    assert not bad, bad
