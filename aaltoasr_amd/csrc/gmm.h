@@ -190,7 +190,7 @@ struct TrackLayout {
 // (a 63-dimensional pool, one of 2 000), hence 300.
 #define FULL_KAPPA_LIMIT_F16 300.0
 #define FULL_KAPPA_LIMIT_F16_LOWDIM 40.0    // fewer than 8 dimensions (6.8e-5 on a 2-dimensional pool at kappa < 600, 5.7e-5 below 150)
-constexpr float kFullF16Clamp = 30000.0f;   // |x - pivot| beyond this is clamped in the f16x2 factor-row kernel
+constexpr float kFullF16Clamp = 30000.0f;   // the SCALED |x - pivot| beyond this is clamped in the f16x2 factor-row kernel
 
 struct FullLayout {
   bool ok = false;
@@ -211,6 +211,7 @@ struct FullLayout {
   // where the pool's conditioning estimate kappa = max_g |R^-1 (mu - pivot)|^2 (in the rows' log2 scaling) is below
   // FULL_KAPPA_LIMIT_F16 and every coefficient is inside the fp16 range
   DevBuf<uint16_t> a16h;
+  DevBuf<float> f16scale;   // f16x2: [dim] power-of-two scale of every frame-operand column (the rows carry the inverse)
   double kappa = 0.0;
   std::vector<int32_t> row_gauss;   // host: pool Gaussian of every packed row, -1 = unused row (Gaussian clustering)
   int64_t rows_padded = 0;

@@ -1643,20 +1643,43 @@ void gmm_build_fullcov(aasr_gmm *g) {
       L.nk16 = nk16;
       // two-term fp16 split (AASR_PREC_F16X2), where the pool qualifies: conditioning estimate below the limit, every
       // coefficient inside the fp16 range, and every coordinate weighs enough in some row of every Gaussian that a
-      // frame clamped to +-kFullF16Clamp there is far below the floor (|y| >= 64: q >= 4096 in log2 units)
+      // frame clamped to +-kFullF16Clamp there is far below the floor (|y| >= 64: q >= 4096 in log2 units).
+      // Per-column power-of-two scales: an fp16 `lo` term below 2^-14 is a subnormal with an ABSOLUTE error of 3e-8, which
+      // the other operand multiplies.  With unnormalised features (variance 10^3: coefficients ~ 1/sigma = 0.03, frame
+      // components ~ 100) every coefficient's `lo` term is subnormal and y = R^-1 (x - mu) is off by 3e-6 per column --
+      // 2e-4 in the state once |y| ~ 10 multiplies it.  Column k of the rows is therefore multiplied by 2^s_k, s_k chosen
+      // so that the pool's largest coefficient of the column sits at ~1, and the kernel multiplies the frame operand by
+      // 2^-s_k (exact): coefficients and frame components then both sit around 2^0 whatever the features' scale, as they
+      // do for normalised features, where the two-term rows were measured.  (Scaling the coefficients up to 128, the
+      // diagonal form's choice, pushes the FRAME operand into the subnormals instead: measured fivefold worse.)
       L.a16h = DevBuf<uint16_t>();
+      L.f16scale = DevBuf<float>();
       static const bool f16_env = !(getenv("AASR_F16X2") && atoi(getenv("AASR_F16X2")) == 0);
-      std::vector<double> kap((size_t)m.G, 0.0), colmax((size_t)m.G * D, 0.0);
-      double amax = 0;
+      std::vector<double> kap((size_t)m.G, 0.0), colmax((size_t)m.G * D, 0.0), poolmax((size_t)D, 0.0);
       for (int64_t r = 0; r < tiles * TILE_ROWS; r++) {
         const int32_t gi = r < (int64_t)L.row_gauss.size() ? L.row_gauss[(size_t)r] : -1;
-        for (int k = 0; k <= D; k++) amax = std::max(amax, std::fabs(coef[(size_t)r * K2 + k]));
         if (gi < 0) continue;
         const double b = coef[(size_t)r * K2 + D];
         kap[(size_t)gi] += b * b;
-        for (int k = 0; k < D; k++)
-          colmax[(size_t)gi * D + k] = std::max(colmax[(size_t)gi * D + k], std::fabs(coef[(size_t)r * K2 + k]));
+        for (int k = 0; k < D; k++) {
+          const double w = std::fabs(coef[(size_t)r * K2 + k]);
+          colmax[(size_t)gi * D + k] = std::max(colmax[(size_t)gi * D + k], w);
+          poolmax[(size_t)k] = std::max(poolmax[(size_t)k], w);
+        }
       }
+      std::vector<int> sk((size_t)D, 0);
+      std::vector<float> scale((size_t)(16 * nk16), 1.0f);
+      for (int k = 0; k < D; k++) {
+        int e = 0;
+        if (poolmax[(size_t)k] > 0) e = (int)std::lround(-std::log2(poolmax[(size_t)k]));
+        e = std::max(-14, std::min(14, e));
+        sk[(size_t)k] = e;
+        scale[(size_t)k] = (float)std::ldexp(1.0, -e);   // the frame operand's factor
+      }
+      double amax = 0;
+      for (int64_t r = 0; r < tiles * TILE_ROWS; r++)
+        for (int k = 0; k <= D; k++)
+          amax = std::max(amax, std::fabs(std::ldexp(coef[(size_t)r * K2 + k], k < D ? sk[(size_t)k] : 0)));
       L.kappa = 0;
       bool heavy = true;
       std::vector<char> seen((size_t)m.G, 0);
@@ -1668,7 +1691,8 @@ void gmm_build_fullcov(aasr_gmm *g) {
         bool all_zero = true;   // the reference's "invalid" Gaussian: zero rows, constant 0
         for (int k = 0; k < D; k++) all_zero = all_zero && colmax[(size_t)gi * D + k] == 0.0;
         if (all_zero) continue;
-        for (int k = 0; k < D; k++) heavy = heavy && colmax[(size_t)gi * D + k] * (double)kFullF16Clamp >= 64.0;
+        for (int k = 0; k < D; k++)
+          heavy = heavy && std::ldexp(colmax[(size_t)gi * D + k], sk[(size_t)k]) * (double)kFullF16Clamp >= 64.0;
       }
       if (f16_env && L.kappa <= (D < 8 ? FULL_KAPPA_LIMIT_F16_LOWDIM : FULL_KAPPA_LIMIT_F16) && amax < 60000.0 && heavy) {
         const size_t tile_h = (size_t)nk16 * 2 * 2 * 64 * 8;
@@ -1678,7 +1702,7 @@ void gmm_build_fullcov(aasr_gmm *g) {
           const int jrow = (int)(r % TILE_ROWS);
           const int mb = jrow / 32, m32 = jrow % 32;
           for (int k = 0; k <= D; k++) {
-            const double x = coef[(size_t)r * K2 + k];   // split on the host in double
+            const double x = std::ldexp(coef[(size_t)r * K2 + k], k < D ? sk[(size_t)k] : 0);   // split on the host in double
             const _Float16 hi = (_Float16)x;
             const _Float16 lo = (_Float16)(x - (double)hi);
             uint16_t hs[2];
@@ -1691,6 +1715,7 @@ void gmm_build_fullcov(aasr_gmm *g) {
           }
         }
         L.a16h.upload(ah.data(), ah.size());
+        L.f16scale.upload(scale.data(), scale.size());
       }
     }
   }

@@ -720,6 +720,9 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
     const uint16_t *__restrict__ close_mask, const int32_t *__restrict__ sid, int sid_stride,
     float *__restrict__ out, int64_t S, int64_t pitch, float ref_ln, int dbg, ClusterArgs cl) {
+  // three bf16 terms only: the two-term fp16 arithmetic (per-column scales, per-dimension clamps: pack_f16x2) lives in
+  // k_gmm_diag_score_pl; the NS == 2 paths below are what is left of its first home and know neither
+  static_assert(NS == 3, "k_gmm_diag_score_bf16x3 is instantiated for the three-term form only");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int OG = Bf16Smem<NK16, GROUPED, WIDE, NS>::OG;
   constexpr int kTileBytes = Bf16Smem<NK16, GROUPED, WIDE, NS>::kTileBytes;
@@ -2033,7 +2036,8 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score_bf16x3(
     const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
     const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
     const uint32_t *__restrict__ close_mask, const float *__restrict__ gc_tile,
-    const int32_t *__restrict__ sid_tile, float *__restrict__ out, int64_t S, float ref_ln, ClusterArgs cl) {
+    const int32_t *__restrict__ sid_tile, float *__restrict__ out, int64_t S, float ref_ln, ClusterArgs cl,
+    const float *__restrict__ f16scale) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int kTileFloats = NK16 * NS * 2 * 64 * 16 / 4;
   float *abuf0 = (float *)smem_raw;
@@ -2060,7 +2064,8 @@ __global__ __launch_bounds__(256, 2) void k_gmm_full_score_bf16x3(
         const int k = 16 * j + 8 * h + i;
         const int kc = k < dim ? k : 0;
         float val = xr[kc] - pivot[kc];
-        if (NS == 2) val = fminf(fmaxf(val, -kFullF16Clamp), kFullF16Clamp);   // fp16 range
+        // two fp16 terms: the column's power-of-two scale (the factor rows carry its inverse: exact), then the fp16 range
+        if (NS == 2) val = fminf(fmaxf(val * f16scale[kc], -kFullF16Clamp), kFullF16Clamp);
         if (k == dim) val = 1.0f;
         if (k > dim) val = 0.0f;
         v[i] = val;
@@ -2221,7 +2226,7 @@ static void launch_full_bf16_t(const aasr_gmm *g, const float *d_frames, int64_t
   const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 8;
   hipLaunchKernelGGL((k_gmm_full_score_bf16x3<NK16, NS, CL>), dim3((unsigned)blocks, (unsigned)R), dim3(256), smem,
                      stream, d_frames, F, g->dim, g->d_pivot.p, NS == 2 ? L.a16h.p : L.a16.p, split_row, L.close.p,
-                     L.gc_tile.p, L.sid_tile.p, d_out, g->S, L.ref_ln, cl);
+                     L.gc_tile.p, L.sid_tile.p, d_out, g->S, L.ref_ln, cl, NS == 2 ? L.f16scale.p : nullptr);
   AASR_HIP(hipGetLastError());
 }
 
@@ -3171,26 +3176,28 @@ __global__ __launch_bounds__(256) void k_dim_split_combine(const float *__restri
     out[i] = v;
     return;
   }
-  float m = NEG_BIG_F, sum = 0.0f;
+  // the parts' log-likelihoods are added in double: at several hundred dimensions |ll| ~ 10^3, where a float sum's
+  // rounding alone (6e-5 per addition) reaches the 1e-4 bar; only differences to the running maximum go through expf
+  double m = -3.0e38, sum = 0.0;
   for (int32_t k = mix_off[s]; k < mix_off[s + 1]; k++) {
     const float lw = mix_logw[k];
     if (!(lw > NEG_BIG_F)) continue;   // zero weight
-    float v = lw + bias_ln;   // log |det| of the pool's one constrained-MLLR transform (AdaptedGaussian), else 0
+    double v = (double)lw + (double)bias_ln;   // log |det| of the pool's one constrained-MLLR transform (AdaptedGaussian), else 0
     const int64_t gi = mix_idx[k];
     if (maskw) {   // Gaussian clustering: only the members of clusters selected for this frame are evaluated exactly
       const int64_t fa = f_first + f;
       if (!((maskw[(fa >> 6) * c1 + gclus[gi]] >> (fa & 63)) & 1ull)) continue;
     }
-    for (int p = 0; p < parts; p++) v += part_ll[((int64_t)p * Fc + f) * G + gi];
-    const float mn = fmaxf(m, v);
-    sum = sum * __expf(m - mn) + __expf(v - mn);
+    for (int p = 0; p < parts; p++) v += (double)part_ll[((int64_t)p * Fc + f) * G + gi];
+    const double mn = fmax(m, v);
+    sum = sum * (double)__expf((float)(m - mn)) + (double)__expf((float)(v - mn));
     m = mn;
   }
   if (maskw) {   // the exact part alone, no floor: the merge adds the centres' share
-    out[i] = sum > 0.0f ? m + __logf(sum) : NEG_BIG_F;
+    out[i] = sum > 0.0 ? (float)(m + (double)__logf((float)sum)) : NEG_BIG_F;
     return;
   }
-  const float ll = sum > 0.0f ? m + __logf(sum) : LOG_TINY_F;
+  const float ll = sum > 0.0 ? (float)(m + (double)__logf((float)sum)) : LOG_TINY_F;
   out[i] = fmaxf(ll, LOG_TINY_F);
 }
 

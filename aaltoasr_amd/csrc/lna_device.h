@@ -80,9 +80,12 @@ __device__ __forceinline__ float cast_f(float ll) {
 
 // One frame's normalisation and packing for a group of 256 threads that hold the row in
 // registers (v[j] = state tid + 256 j, -inf beyond S): max, Z / e^max in double, log, pack.
-// `red` is the group's 8 doubles of LDS; the four __syncthreads() are executed unconditionally so
-// that several groups of one workgroup (k_cluster_merge_lna: four frames side by side) may call
-// this together.  tid / wave / lane are relative to the group.
+// `red` is the group's 8 doubles of LDS.  ONE group per workgroup: the number of __syncthreads() a call passes depends
+// on the frame (4 on the fast path below, 6 when the fast path's test fails, 2 for 4-byte output), so two groups of one
+// workgroup working on different frames would meet different barrier counts.  (An earlier form executed four
+// unconditional barriers so that several groups -- k_cluster_merge_lna, since removed: four frames side by side --
+// could call it together; whoever revives that has to make the count uniform again.)  tid / wave / lane are relative
+// to the group, which is the workgroup.
 template <int VPT>
 __device__ __forceinline__ void lna_row_from_registers(const float (&v)[VPT], int S, int tid, int wave, int lane,
                                                        double *red, int normalize, int lnabytes, int64_t f,

@@ -54,6 +54,44 @@ def test_full_covariance_sweep(capi, oracle, seed, n):
     assert worst["refused"] <= 1 and worst["full prec=0"] <= 1e-4 and worst["full prec=3"] <= 1e-4
 
 
+@pytest.mark.parametrize("seed,n", [(11, 60), (12, 60)])
+def test_full_covariance_sweep_over_feature_scales(capi, oracle, seed, n):
+    """The same sweep with the pools moved to other units (feature standard deviations 0.01 ... 100, i.e. variances up to
+    10^4): coefficients ~ 1 / scale against frame components ~ scale.  Without per-column scales the two-term fp16 rows'
+    `lo` terms are subnormals there (3e-8 absolute, times the other operand); with them a pool scores as its normalised
+    twin does.  The pools must still GET the two-term rows (a refusal would pass trivially)."""
+    mod = _load("fuzz_fullcov")
+    worst, fails = mod.run(seed, n, scales=True)
+    assert not fails, "\n".join(fails)
+    # (pools in very small units are refused at creation as before: their constants, + D log(1 / scale), leave the
+    # in-register epilogue no f32 exponent headroom -- DESIGN "full covariance")
+    assert worst["full prec=4"] <= 1e-4 and worst["full prec=3"] <= 1e-4 and worst["refused"] <= n // 3
+
+
+def test_unnormalised_full_covariance_pool_keeps_the_two_term_rows(capi, oracle):
+    """configs[4]'s pool in miniature with features of standard deviation 40: AASR_PREC_F16X2 still runs the fp16 factor
+    rows (aasr_gmm_effective_precision) and agrees with the oracle as the pool in unit scale does."""
+    import numpy as np
+    from aaltoasr_amd import synth
+    from conftest import assert_ll
+    Dc, Gc, Sc = 39, 256, 16
+    rng = np.random.default_rng(77)
+    mean = rng.standard_normal((Gc, Dc))
+    a = rng.standard_normal((Gc, Dc, Dc)) * 0.3
+    cov = a @ a.transpose(0, 2, 1) + 0.1 * np.eye(Dc)
+    _, _, off, idx, w = synth.make_model(D=Dc, G=Gc, S=Sc, comps=16)
+    frames = synth.make_frames(500, D=Dc, seed=78)
+    for fs in (1.0, 40.0, 300.0):
+        g = capi.Gmm.from_full(mean * fs, cov * fs * fs, off, idx, w)
+        g.set_precision(4)
+        assert g.effective_precision() == 4, fs
+        fr = (frames.astype(np.float64) * fs).astype(np.float32)
+        want = oracle.FullModel(mean * fs, cov * fs * fs, off, idx, w).score(fr.astype(np.float64))
+        worst = assert_ll(g.score(fr), want, "feature scale %g" % fs)
+        assert worst <= 6e-5, (fs, worst)
+        g.close()
+
+
 @pytest.mark.parametrize("seed,n", [(1, 30), (19, 40)])
 def test_recipe_driver_sweep(capi, oracle, seed, n):
     """tools/fuzz_recipe.py: random recipes (segment times that stay in force, -B / -I slices, tiny files, 2- / 4-byte,

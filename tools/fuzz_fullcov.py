@@ -11,11 +11,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(seed=1, N=40, verbose=False):
+def run(seed=1, N=40, verbose=False, scales=False):
     from aaltoasr_amd import capi
     from oracle import oracle as O
     O.build()
     rng = np.random.default_rng(seed)
+    rng_scale = np.random.default_rng(seed + 7777)   # scales=True: unnormalised features, standard deviations 0.01 ... 100
     worst, fails, refused = {}, [], 0
     for it in range(N):
         D = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 24, 39, 47, 63]))
@@ -45,7 +46,16 @@ def run(seed=1, N=40, verbose=False):
             w[rng.integers(0, K)] = 0.0
         F = int(rng.integers(1, 300))
         frames = (rng.standard_normal((F, D)) * rng.uniform(0.5, 2.5)).astype(np.float32)
-        ctx = "seed %d it %d D %d S %d G %d tied %d F %d" % (seed, it, D, S, G, tied, F)
+        fs = 1.0
+        if scales:
+            # the same pool in other units: x -> fs x (feature variances 1e-4 ... 1e4).  The factor rows then hold
+            # coefficients ~ 1 / fs and the frames components ~ fs -- where the two-term fp16 rows' `lo` terms fall into
+            # the subnormals unless the columns are rescaled (gmm_build_fullcov)
+            fs = float(np.exp(rng_scale.uniform(np.log(0.01), np.log(100.0))))
+            mean = mean * fs
+            cov = cov * fs * fs
+            frames = (frames.astype(np.float64) * fs).astype(np.float32)
+        ctx = "seed %d it %d D %d S %d G %d tied %d F %d scale %.3g" % (seed, it, D, S, G, tied, F, fs)
         want = O.FullModel(mean, cov, off, idx, w).score(frames.astype(np.float64))
         try:
             g = capi.Gmm.from_full(mean, cov, off, idx, w)
@@ -119,7 +129,8 @@ def run(seed=1, N=40, verbose=False):
 
 if __name__ == "__main__":
     worst, fails = run(int(sys.argv[1]) if len(sys.argv) > 1 else 1,
-                       int(sys.argv[2]) if len(sys.argv) > 2 else 40, verbose=True)
+                       int(sys.argv[2]) if len(sys.argv) > 2 else 40, verbose=True,
+                       scales=os.environ.get("AASR_FUZZ_SCALES") == "1")
     for k, v in worst.items():
         print("%-28s %s" % (k, ("%.3g" % v) if isinstance(v, float) else v))
     print("failures: %d" % len(fails))
