@@ -17,8 +17,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # AASR_BUILD_ABLATION=1 builds the library with the kernels' ablation branches and the recipe driver's device
 # stub into its own directory (lib_ablation/, loaded with AASR_LIBDIR=...): the product library carries neither
-LIBDIR = os.path.join(HERE, "lib_ablation" if (os.environ.get("AASR_BUILD_ABLATION") == "1" or
-                                              os.environ.get("AASR_BUILD_DEFINES")) else "lib")
+LIBDIR = os.path.join(HERE, os.environ.get("AASR_BUILD_LIBDIR") or
+                      ("lib_ablation" if (os.environ.get("AASR_BUILD_ABLATION") == "1" or os.environ.get("AASR_BUILD_DEFINES"))
+                       else "lib"))   # AASR_BUILD_LIBDIR: the directory of an experiment build (several side by side)
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libaasr.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -370,6 +370,14 @@ class Gmm:
         """The arithmetic the diagonal scoring path actually runs under the current setting."""
         return int(lib().aasr_gmm_effective_precision(self._h))
 
+    def frame_operand_ms(self, d_frames, reps: int = 10, stream=None) -> float:
+        """Diagnostic: ms of one k_frame_operand launch for these frames under the current setting (< 0: not applicable)."""
+        L = lib()
+        L.aasr_debug_frame_operand_ms.restype = C.c_double
+        L.aasr_debug_frame_operand_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        return float(L.aasr_debug_frame_operand_ms(self._h, C.c_void_p(d_frames.data_ptr()), d_frames.shape[0], reps,
+                                                   C.c_void_p(stream.cuda_stream if stream is not None else 0)))
+
     def precision_states(self):
         """(states the two-term fp16 rows cover under the current setting, states the load-time probe took out of
         that form): per-state precision routing, aasr_gmm_precision_states."""

@@ -1145,7 +1145,14 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
 #else
   const int group = WIDE ? __builtin_amdgcn_readfirstlane(wave >> 2) : 0;
 #endif
-  constexpr int JB = NK16 / 2;   // slab of H0 in front of which the lagging group's barrier sits
+  // slab of H0 in front of which the lagging group's barrier sits: early in the phase, so that the lagging waves run
+  // nearly a whole tile behind (configs[2], NK16 = 5, ms of the scoring stage on one box: slab 0 8.45, slab 1 8.43,
+  // slab 2 -- the middle, rounds 3's choice -- 8.51, slab 3 8.61)
+#ifdef AASR_PL_JB
+  constexpr int JB = AASR_PL_JB < NK16 ? AASR_PL_JB : NK16 / 4;
+#else
+  constexpr int JB = NK16 / 4;
+#endif
   const int n = lane & 31;
   const int h = lane >> 5;  // K half of a slab held by this lane AND its row track
   const int64_t f0 = (int64_t)blk * (NW * FRAMES_PER_WAVE) + wave * FRAMES_PER_WAVE;
@@ -1288,7 +1295,9 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     float x;
     if (AASR_DBG(64)) asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(v));   // ablation: no transcendentals
     else asm volatile("v_exp_f32 %0, %1\n\ts_nop 0" : "=v"(x) : "v"(v));
-    // the pair sums ride in the stream as well (left to the compiler they gather behind the phase's last MFMA)
+    // the pair sums ride in the stream as well (left to the compiler they gather behind the phase's last MFMA).
+    // (Round 4: the additions run one element behind the exponentials, so that no instruction reads a transcendental's
+    // result right behind it and the s_nop can go -- measured 1 % SLOWER, 8.60 against 8.51 ms on configs[2]; kept as is.)
     if (e == 0) t0 = x;
     else if (e == 1) asm volatile("v_add_f32 %0, %1, %2" : "=v"(t0) : "v"(t0), "v"(x));
     else if (e == 2) t1 = x;
@@ -2909,6 +2918,31 @@ extern "C" int aasr_debug_active_layout(const aasr_gmm *g) {
   return 0;
 }
 extern "C" double aasr_debug_kappa(const aasr_gmm *g) { return g ? g->kappa : -1.0; }
+
+// Diagnostic (bench.py): milliseconds of ONE k_frame_operand launch over F frames for the layout and arithmetic a scoring
+// call would use now -- the launch that precedes k_gmm_diag_score_pl in every scoring call, so that the bench can price
+// the scoring kernel on its own duration (HIP events around the call see both).  < 0: the current path forms its frame
+// operand inside the kernel.
+extern "C" double aasr_debug_frame_operand_ms(aasr_gmm *g, const float *d_frames, int64_t F, int reps, void *stream_v) {
+  if (!g || F <= 0 || reps <= 0) return -1.0;
+  hipStream_t stream = (hipStream_t)stream_v;
+  const TrackLayout &L = g->paired.ok ? g->paired : g->tracks;
+  if (!L.ok || !g->use_bf16x3 || g->precision != AASR_PREC_F16X2 || !L.a16h.p || g->cl.enabled) return -1.0;
+  const int NW = F >= 8192 ? 8 : 4;
+  const int64_t blocks64 = (F + NW * FRAMES_PER_WAVE - 1) / (NW * FRAMES_PER_WAVE) * NW;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.0;
+  frame_operand<2>(g, L, d_frames, F, blocks64, stream);
+  (void)hipEventRecord(e0, stream);
+  for (int i = 0; i < reps; i++) frame_operand<2>(g, L, d_frames, F, blocks64, stream);
+  (void)hipEventRecord(e1, stream);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return (double)ms / reps;
+}
 
 // Diagnostic (not part of the public ABI): resident workgroups per CU the
 // runtime predicts for the NKK=40 scoring kernel.
