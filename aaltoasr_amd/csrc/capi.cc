@@ -45,8 +45,6 @@ void require_device() {
           e != hipSuccess ? hipGetErrorString(e) : "0 devices");
 }
 
-void lna_encode_launch(const float *d_loglik, int64_t F, int S, int normalize,
-                       int lnabytes, float *d_lp, uint8_t *d_bytes, hipStream_t stream, int64_t in_pitch);
 
 }  // namespace aasr
 
@@ -418,8 +416,7 @@ aasr_status aasr_gmm_gauss_loglik(aasr_gmm *h, const float *frames, int64_t F,
 
 int64_t aasr_gmm_score_scratch_floats(const aasr_gmm *h, int64_t F) {
   if (!h || F < 0) return -1;
-  const int64_t pitch = gmm_score_pitch_ok(h) ? (h->S + 31) / 32 * 32 : h->S;
-  return F * pitch;
+  return F * gmm_engine_pitch(h);
 }
 
 aasr_status aasr_gmm_score_lna_dev(aasr_gmm *h, const float *d_frames, int64_t F, int normalize, int lnabytes,
@@ -430,9 +427,9 @@ aasr_status aasr_gmm_score_lna_dev(aasr_gmm *h, const float *d_frames, int64_t F
     if (lnabytes != 2 && lnabytes != 4) raise(AASR_ERR_INVALID, "lnabytes must be 2 or 4, got %d", lnabytes);
     if (F <= 0) return;
     hipStream_t st = (hipStream_t)stream;
-    const int64_t pitch = gmm_score_pitch_ok(h) ? (h->S + 31) / 32 * 32 : h->S;
-    gmm_score_launch_pitched(h, d_frames, F, d_scratch, pitch, st);
-    lna_encode_launch(d_scratch, F, (int)h->S, normalize, lnabytes, nullptr, d_bytes_out, st, pitch);
+    const int64_t pitch = gmm_engine_pitch(h);
+    gmm_score_launch_engine(h, d_frames, F, d_scratch, pitch, st);
+    lna_encode_launch(d_scratch, F, (int)h->S, normalize, lnabytes, nullptr, d_bytes_out, st, pitch, gmm_engine_colmap(h));
   });
 }
 

@@ -289,6 +289,13 @@ struct aasr_gmm {
   aasr::TrackLayout tracks;   // independent tracks (built when `paired` is not)
   aasr::TrackLayout mixed;    // per-state precision routing: built when only part of the states qualify for f16x2
   int64_t f16_bad_state = -1; // builder scratch: the state whose rows failed the fp16 range / clamp conditions
+  // Engine-internal score layout of a routed model (gmm_score_launch_engine): the states of the mixed layout's second
+  // section as a model of their own (own pivot, own layouts: whole-line stores), scored into spare columns behind the
+  // S state columns; engine consumers (the LNA pass) read a score row through routed_colmap
+  std::unique_ptr<aasr_gmm> routed_sub;
+  aasr::DevBuf<int32_t> routed_colmap;   // [S] column of every state in the engine layout
+  int64_t routed_alias_base = 0;         // first spare column (S rounded up to 32)
+  bool is_routed_sub = false;
   std::vector<uint8_t> f16_state_ok;   // per state: eligible for the two-term fp16 form (conditioning limits, probe)
   int64_t f16_probe_moved = 0;         // states the load-time probe (gmm_probe_f16x2) took out of the fp16 form
   // full-covariance path (k_gmm_full_score): rows are the rows of R^-1 of
@@ -401,6 +408,13 @@ void gmm_score_f64_launch(aasr_gmm *g, const double *d_frames, int64_t F, double
 void gmm_build_tracks(aasr_gmm *g, bool grouped);
 void gmm_build_mixed(aasr_gmm *g, std::vector<uint8_t> &f16_ok);
 void gmm_probe_f16x2(aasr_gmm *g);
+void gmm_build_routed_sub(aasr_gmm *g);
+// the engine's own score layout: rows of gmm_engine_pitch() floats; state s in column gmm_engine_colmap()[s] (nullptr: s)
+int64_t gmm_engine_pitch(const aasr_gmm *g);
+const int32_t *gmm_engine_colmap(const aasr_gmm *g);
+void gmm_score_launch_engine(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, int64_t pitch, hipStream_t stream);
+void lna_encode_launch(const float *d_loglik, int64_t F, int S, int normalize, int lnabytes, float *d_lp,
+                       uint8_t *d_bytes, hipStream_t stream, int64_t in_pitch, const int32_t *d_colmap = nullptr);
 void gmm_build_centred(aasr_gmm *g);
 void gmm_build_fullcov(aasr_gmm *g);
 void gmm_full_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,

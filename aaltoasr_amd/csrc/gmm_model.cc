@@ -682,6 +682,54 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
     if ((g->layout_mask & 2) && !g->tracks.ok) gmm_build_tracks(g, false);
   }
   gmm_probe_f16x2(g);   // load-time guard of the two-term fp16 rows
+  gmm_build_routed_sub(g);
+}
+
+// The second section of a routed model as a model of its own (aasr_gmm::routed_sub): its states, the Gaussians they use,
+// its own pivot -- so that the engine's own paths can score it into spare columns with whole-line stores instead of
+// storing its values one by one over the first section's lines (gmm_score_launch_engine).
+void gmm_build_routed_sub(aasr_gmm *g) {
+  g->routed_sub.reset();
+  g->routed_colmap = DevBuf<int32_t>();
+  static const int alias_env = getenv("AASR_ROUTED_ALIAS") ? atoi(getenv("AASR_ROUTED_ALIAS")) : 1;
+  const HostModel &m = g->host;
+  if (!alias_env || g->is_routed_sub || !g->mixed.ok || !g->mixed.sec[0].mapped || m.n_transforms > 0 || m.S > 4096 ||
+      !g->outlier.empty())
+    return;
+  HostModel sm;
+  sm.dim = m.dim;
+  std::vector<int32_t> gmap((size_t)m.G, -1), colmap((size_t)m.S);
+  const int64_t base = (m.S + 31) / 32 * 32;
+  sm.mix_off.push_back(0);
+  for (int64_t s = 0; s < m.S; s++) {
+    if (g->f16_state_ok[(size_t)s]) {
+      colmap[(size_t)s] = (int32_t)s;
+      continue;
+    }
+    colmap[(size_t)s] = (int32_t)(base + sm.S);
+    for (int32_t k = m.mix_off[s]; k < m.mix_off[s + 1]; k++) {
+      const int32_t gi = m.mix_idx[k];
+      if (gmap[(size_t)gi] < 0) {
+        gmap[(size_t)gi] = (int32_t)sm.G++;
+        sm.mean.insert(sm.mean.end(), m.mean.begin() + (size_t)gi * m.dim, m.mean.begin() + (size_t)(gi + 1) * m.dim);
+        sm.var.insert(sm.var.end(), m.var.begin() + (size_t)gi * m.dim, m.var.begin() + (size_t)(gi + 1) * m.dim);
+      }
+      sm.mix_idx.push_back(gmap[(size_t)gi]);
+      sm.mix_w.push_back(m.mix_w[(size_t)k]);
+    }
+    sm.mix_off.push_back((int32_t)sm.mix_idx.size());
+    sm.S++;
+  }
+  if (sm.S == 0 || sm.G == 0) return;
+  sm.weights_normalized = true;
+  auto sub = std::make_unique<aasr_gmm>();
+  sub->device = g->device;
+  sub->is_routed_sub = true;
+  gmm_build(sub.get(), sm);
+  if (!gmm_score_pitch_ok(sub.get())) return;   // (needs a track layout: whole-line stores are the point)
+  g->routed_sub = std::move(sub);
+  g->routed_alias_base = base;
+  g->routed_colmap.upload(colmap.data(), colmap.size());
 }
 
 // Track layouts for the in-register epilogue (k_gmm_diag_score_tracks).

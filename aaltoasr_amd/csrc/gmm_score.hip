@@ -3149,6 +3149,42 @@ bool gmm_score_pitch_ok(const aasr_gmm *g) {
   return (g->precision == AASR_PREC_F32 || g->precision == AASR_PREC_BF16X3 || g->precision == AASR_PREC_F16X2) && L.ok;
 }
 
+// ---------------------------------------------------------------------------
+// The engine's own score layout (recipe driver, aasr_run_utterance, aasr_gmm_score_lna_dev: scores that only the LNA
+// pass reads).  A routed model's second section stores 4 bytes per (frame, state) over lines the first section wrote,
+// which costs about as much again as its arithmetic (a partial write of a line costs a fill).  Here its states are
+// scored as a model of their own (routed_sub) into spare columns behind the S state columns -- whole lines -- and the
+// LNA pass reads a score row through a column map.  Anything that merges by state column (clustering, outlier routing,
+// class routing, in-place transforms) keeps the public layout.
+// ---------------------------------------------------------------------------
+static bool engine_alias(const aasr_gmm *g) {
+  return g->routed_sub && split_layout(g) == &g->mixed && !g->cl.enabled && !g->hyb_enabled && !g->class_routing &&
+         !g->xf_a.p && g->out_bias_ln == 0 && g->dim_parts.empty() && gmm_score_pitch_ok(g);
+}
+
+int64_t gmm_engine_pitch(const aasr_gmm *g) {
+  if (!gmm_score_pitch_ok(g)) return g->S;
+  const int64_t base = (g->S + 31) / 32 * 32;
+  return engine_alias(g) ? base + (g->routed_sub->S + 31) / 32 * 32 : base;
+}
+
+const int32_t *gmm_engine_colmap(const aasr_gmm *g) { return engine_alias(g) ? g->routed_colmap.p : nullptr; }
+
+void gmm_score_launch_engine(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, int64_t pitch,
+                             hipStream_t stream) {
+  if (F <= 0) return;
+  if (!engine_alias(g) || pitch < gmm_engine_pitch(g)) {
+    gmm_score_launch_pitched(g, d_frames, F, d_out, pitch, stream);
+    return;
+  }
+  if (!launch_split<2>(g, g->mixed, d_frames, F, d_out, stream, nullptr, pitch, 0))
+    raise(AASR_ERR_UNSUPPORTED, "no kernel instance for the first section of the routed model");
+  aasr_gmm *sub = g->routed_sub.get();
+  sub->precision = g->precision;
+  sub->use_bf16x3 = g->use_bf16x3;
+  gmm_score_launch_pitched(sub, d_frames, F, d_out + g->routed_alias_base, pitch, stream);
+}
+
 void gmm_score_launch_pitched(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, int64_t pitch,
                               hipStream_t stream) {
   if (F <= 0) return;

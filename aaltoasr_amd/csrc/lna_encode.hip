@@ -95,9 +95,17 @@ __global__ __launch_bounds__(256) void k_state_norm_lna(
 template <int VPT>
 __global__ __launch_bounds__(256) void k_state_norm_lna_reg(
     const float *__restrict__ loglik, int64_t F, int S, int64_t in_pitch, int normalize, int lnabytes,
-    float *__restrict__ lp_out, uint8_t *__restrict__ bytes_out) {
+    float *__restrict__ lp_out, uint8_t *__restrict__ bytes_out, const int32_t *__restrict__ colmap) {
   __shared__ double red[8];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // colmap (engine-internal score layout of a routed model, gmm_engine_colmap): state i sits in column colmap[i] of a
+  // score row; the same for every frame, so a thread looks its columns up once
+  int col[VPT];
+#pragma unroll
+  for (int j = 0; j < VPT; j++) {
+    const int i = tid + 256 * j;
+    col[j] = (colmap && i < S) ? colmap[i] : i;
+  }
   // a workgroup walks frames blockIdx.x, + gridDim.x, ...; the next frame's row is requested
   // before this one is reduced (the four barriers of a frame leave nothing else to hide the
   // load latency behind)
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(256) void k_state_norm_lna_reg(
 #pragma unroll
     for (int j = 0; j < VPT; j++) {
       const int i = tid + 256 * j;
-      vn[j] = (i < S && (int64_t)blockIdx.x < F) ? row[i] : -INFINITY;
+      vn[j] = (i < S && (int64_t)blockIdx.x < F) ? row[col[j]] : -INFINITY;
     }
   }
   for (int64_t f = blockIdx.x; f < F; f += gridDim.x) {
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(256) void k_state_norm_lna_reg(
 #pragma unroll
       for (int j = 0; j < VPT; j++) {
         const int i = tid + 256 * j;
-        vn[j] = i < S ? row[i] : -INFINITY;
+        vn[j] = i < S ? row[col[j]] : -INFINITY;
       }
     }
     lna_row_from_registers<VPT>(v, S, tid, wave, lane, red, normalize, lnabytes, f, true, lp_out, bytes_out);
@@ -168,9 +176,11 @@ void lna_encode_f64_launch(const double *d_lik, int64_t F, int S, int normalize,
 }
 
 void lna_encode_launch(const float *d_loglik, int64_t F, int S, int normalize,
-                       int lnabytes, float *d_lp, uint8_t *d_bytes, hipStream_t stream, int64_t in_pitch) {
+                       int lnabytes, float *d_lp, uint8_t *d_bytes, hipStream_t stream, int64_t in_pitch,
+                       const int32_t *d_colmap) {
   if (in_pitch <= 0) in_pitch = S;  // row stride of the input in floats
   if (F <= 0 || S <= 0) return;
+  if (d_colmap && S > 256 * 16) raise(AASR_ERR_UNSUPPORTED, "a column map needs the register-resident LNA kernels (S <= 4096)");
   int64_t blocks = F < (1 << 20) ? F : (1 << 20);
   // register-resident variants: a few workgroups per CU, each walking many frames with the next
   // row prefetched
@@ -179,19 +189,19 @@ void lna_encode_launch(const float *d_loglik, int64_t F, int S, int normalize,
   if (S <= 256 * 16) blocks = std::min<int64_t>(blocks, (int64_t)cus * 32);  // measured: 2.56 ms at 4 per CU, 2.16 at 32, flat above
   if (S <= 256 * 4)
     hipLaunchKernelGGL(k_state_norm_lna_reg<4>, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       d_loglik, F, S, in_pitch, normalize, lnabytes, d_lp, d_bytes);
+                       d_loglik, F, S, in_pitch, normalize, lnabytes, d_lp, d_bytes, d_colmap);
   else if (S <= 256 * 8)
     hipLaunchKernelGGL(k_state_norm_lna_reg<8>, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       d_loglik, F, S, in_pitch, normalize, lnabytes, d_lp, d_bytes);
+                       d_loglik, F, S, in_pitch, normalize, lnabytes, d_lp, d_bytes, d_colmap);
   else if (S <= 256 * 10)
     hipLaunchKernelGGL(k_state_norm_lna_reg<10>, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       d_loglik, F, S, in_pitch, normalize, lnabytes, d_lp, d_bytes);
+                       d_loglik, F, S, in_pitch, normalize, lnabytes, d_lp, d_bytes, d_colmap);
   else if (S <= 256 * 13)
     hipLaunchKernelGGL(k_state_norm_lna_reg<13>, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       d_loglik, F, S, in_pitch, normalize, lnabytes, d_lp, d_bytes);
+                       d_loglik, F, S, in_pitch, normalize, lnabytes, d_lp, d_bytes, d_colmap);
   else if (S <= 256 * 16)
     hipLaunchKernelGGL(k_state_norm_lna_reg<16>, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       d_loglik, F, S, in_pitch, normalize, lnabytes, d_lp, d_bytes);
+                       d_loglik, F, S, in_pitch, normalize, lnabytes, d_lp, d_bytes, d_colmap);
   else
     hipLaunchKernelGGL(k_state_norm_lna, dim3((unsigned)blocks), dim3(256), 0, stream, d_loglik,
                        F, S, in_pitch, normalize, lnabytes, d_lp, d_bytes);

@@ -38,8 +38,6 @@ namespace aasr {
 
 void lna_encode_f64_launch(const double *d_lik, int64_t F, int S, int normalize, int lnabytes, float *d_lp,
                            uint8_t *d_bytes, hipStream_t stream);
-void lna_encode_launch(const float *d_loglik, int64_t F, int S, int normalize, int lnabytes,
-                       float *d_lp, uint8_t *d_bytes, hipStream_t stream, int64_t in_pitch);
 
 // ------------------------------------------------------------------ recipe --
 
@@ -409,7 +407,7 @@ struct BlockRunner {
         AASR_HIP(hipMemcpyAsync(d_pcm.p + ub.pcm_off[k], jobs[k]->pcm.data(), jobs[k]->pcm.size() * sizeof(int16_t),
                                 hipMemcpyHostToDevice, s_compute));
       d_fea.ensure((size_t)F * dim);
-      const int64_t pitch = gmm_score_pitch_ok(gmm) ? (S + 31) / 32 * 32 : S;
+      const int64_t pitch = gmm_engine_pitch(gmm);
       if ((size_t)F * pitch > d_ll.n) AASR_HIP(hipDeviceSynchronize());
       d_ll.ensure((size_t)F * pitch);
       bytes.ensure(nb);
@@ -423,8 +421,8 @@ struct BlockRunner {
         lna_encode_f64_launch(d_lik64.p, F, (int)S, normalize, lnabytes, nullptr, bytes.p, s_compute);
       } else if (!stub_device()) {
         feat_run_batch(feat, d_pcm.p, ub, (int)feat->mods.size() - 1, d_fea.p, nullptr, s_compute);
-        gmm_score_launch_pitched(gmm, d_fea.p, F, d_ll.p, pitch, s_compute);
-        lna_encode_launch(d_ll.p, F, (int)S, normalize, lnabytes, nullptr, bytes.p, s_compute, pitch);
+        gmm_score_launch_engine(gmm, d_fea.p, F, d_ll.p, pitch, s_compute);
+        lna_encode_launch(d_ll.p, F, (int)S, normalize, lnabytes, nullptr, bytes.p, s_compute, pitch, gmm_engine_colmap(gmm));
       }
     }
     AASR_HIP(hipEventRecord(ev_kernels[slot], s_compute));
@@ -466,7 +464,7 @@ struct BlockRunner {
     d_fea.ensure((size_t)F * dim);
     // the score matrix never leaves the device: rows padded to whole 64-byte lines where the
     // scoring kernel can write them that way (every output group then is one full line)
-    const int64_t pitch = gmm_score_pitch_ok(gmm) ? (S + 31) / 32 * 32 : S;
+    const int64_t pitch = gmm_engine_pitch(gmm);
     d_ll.ensure((size_t)F * pitch);
     d_bytes.ensure((size_t)F * S * lnabytes);
     if (gmm->precision == AASR_PREC_F64) {
@@ -477,8 +475,8 @@ struct BlockRunner {
       lna_encode_f64_launch(d_lik64.p, F, (int)S, normalize, lnabytes, nullptr, d_bytes.p, nullptr);
     } else {
       feat_run_batch(feat, d_pcm.p, ub, (int)feat->mods.size() - 1, d_fea.p, nullptr, nullptr);
-      gmm_score_launch_pitched(gmm, d_fea.p, F, d_ll.p, pitch, nullptr);
-      lna_encode_launch(d_ll.p, F, (int)S, normalize, lnabytes, nullptr, d_bytes.p, nullptr, pitch);
+      gmm_score_launch_engine(gmm, d_fea.p, F, d_ll.p, pitch, nullptr);
+      lna_encode_launch(d_ll.p, F, (int)S, normalize, lnabytes, nullptr, d_bytes.p, nullptr, pitch, gmm_engine_colmap(gmm));
     }
     const size_t nb = (size_t)F * S * lnabytes;
     if (dst) {

@@ -746,6 +746,25 @@ def _time_scoring(torch, runner, gmm, reps=5):
     return e0.elapsed_time(e1) / reps
 
 
+def _time_engine_path(torch, runner, gmm, reps=5):
+    """ms of frames -> 2-byte LNA codes through the engine's own score layout (aasr_gmm_score_lna_dev: what the recipe
+    driver and aasr_run_utterance run after the feature chain) over the runner's resident feature frames."""
+    F = runner.total_frames
+    d_scr = torch.empty(gmm.score_scratch_floats(F), dtype=torch.float32, device=runner.d_fea.device)
+
+    def go():
+        gmm.score_lna_dev(runner.d_fea, d_scr, runner.d_bytes, True, 2, runner.stream)
+    go()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(runner.stream)
+    for _ in range(reps):
+        go()
+    e1.record(runner.stream)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
 def _measure_precisions(torch, capi, synth, gmm, runner, model, restore_precision, with_models=True):
     """The scoring stage of configs[2] in every arithmetic form the engine has (the any-model numbers next to the
     headline's), and per-state precision routing: the same model with 1 / 10 / 40 % of its states holding one Gaussian
@@ -758,6 +777,7 @@ def _measure_precisions(torch, capi, synth, gmm, runner, model, restore_precisio
         gmm.set_precision(prec)
         ladder[name] = round(_time_scoring(torch, runner, gmm), 4)
     gmm.set_precision(restore_precision)
+    base_engine = _time_engine_path(torch, runner, gmm)
     out["precision_ladder"] = {"what": "scoring stage of configs[2] (ms per %d frames x %d Gaussians) under each arithmetic: two fp16 "
                                        "terms (the default where a model's conditioning allows it), three bf16 terms (any model "
                                        "on the matrix path), plain f32 matrix instructions" % (runner.total_frames, G),
@@ -771,6 +791,7 @@ def _measure_precisions(torch, capi, synth, gmm, runner, model, restore_precisio
         g2 = capi.Gmm.from_arrays(*synth.push_states_over_the_f16_limits(model, bad))
         n16, moved = g2.precision_states()
         ms = _time_scoring(torch, runner, g2)
+        ms_engine = _time_engine_path(torch, runner, g2)
         g2.set_precision(3)
         ms3 = _time_scoring(torch, runner, g2)
         g2.close()
@@ -778,10 +799,18 @@ def _measure_precisions(torch, capi, synth, gmm, runner, model, restore_precisio
                         "states_moved_by_the_probe": moved, "scoring_ms": round(ms, 4),
                         "ratio_to_all_f16x2": round(ms / ladder["f16x2"], 4),
                         "target_1_plus_0.65_share": round(1.0 + 0.65 * share, 4),
+                        "engine_path_scoring_plus_lna_ms": round(ms_engine, 4),
+                        "engine_path_scoring_ms_minus_all_f16x2": round(ms_engine - base_engine, 4),
+                        "engine_path_scoring_ratio": round((ladder["f16x2"] + ms_engine - base_engine) / ladder["f16x2"], 4),
                         "scoring_ms_whole_model_bf16x3": round(ms3, 4)})
     out["precision_routing"] = {"what": "per-state precision routing (aasr_gmm_precision_states): the configs[2] model with one Gaussian "
                                         "of a share of its states moved over the two-term form's conditioning limits; before round 4 "
-                                        "ONE such Gaussian sent the whole model to the three-term kernel",
+                                        "ONE such Gaussian sent the whole model to the three-term kernel.  scoring_ms: the public score "
+                                        "layout (columns = states: the routed states' values are stored one by one over the others' "
+                                        "lines); engine_path_*: frames -> LNA codes on the engine's own layout (the routed states "
+                                        "scored as a model of their own into spare columns, the LNA pass reads through a column map), "
+                                        "what phone_probs / aasr_run_recipe run -- its ratio prices the scoring stage as all-f16x2 ms "
+                                        "+ the extra ms of the whole path.  all-f16x2 engine path: %.4f ms" % base_engine,
                                 "models": routing}
     return out
 

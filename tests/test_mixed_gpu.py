@@ -165,3 +165,66 @@ print("RESULT", n16, moved, g.effective_precision(), err)
     assert out[""][:3] == ["64", "0", "4"] and float(out[""][3]) <= 1e-4
     n16, moved = int(out["1e-9"][0]), int(out["1e-9"][1])
     assert moved > 32 and n16 == 64 - moved and float(out["1e-9"][3]) <= 1e-4, out
+
+
+def test_routed_model_on_the_engines_own_score_layout(capi, oracle):
+    """aasr_gmm_score_lna_dev / aasr_run_utterance on a routed model: the second section is scored as a model of its own
+    into spare columns behind the state columns (whole-line stores) and the LNA pass reads the rows through a column map.
+    The packed bytes must be the ones the public layout gives -- aasr_gmm_score (columns = states) followed by
+    aasr_lna_encode -- except where the sub-model's own pivot moves a value by rounding (2-byte codes at most one step,
+    > 99 % identical), and within the usual bounds of the oracle's."""
+    import torch
+    S = 200
+    bad = sorted(np.random.default_rng(3).choice(S, 20, replace=False).tolist())
+    model = synth.push_states_over_the_f16_limits(synth.make_model(D=39, G=S * 16, S=S, comps=16, seed=480), bad)
+    g = capi.Gmm.from_arrays(*model)
+    assert g.precision_states()[0] == S - len(bad)
+    F = 9000
+    fr = synth.make_frames(F, seed=481)
+    n_scratch = g.score_scratch_floats(F)
+    assert n_scratch >= F * (224 + 32)        # 200 states -> 224 columns, + one line of spare columns for the 20 states
+    d_fr = torch.from_numpy(fr).cuda()
+    d_scr = torch.empty(n_scratch, dtype=torch.float32, device="cuda")
+    public = g.score(fr)
+    ref_ll, lik = oracle.DiagModel(*model).score(fr.astype(np.float64), want_lik=True)
+    assert_ll(public, ref_ll, "public layout")
+    for nb in (2, 4):
+        d_by = torch.empty((F, S * nb), dtype=torch.uint8, device="cuda")
+        g.score_lna_dev(d_fr, d_scr, d_by, True, nb)
+        torch.cuda.synchronize()
+        got = d_by.cpu().numpy()
+        _, want = capi.lna_encode(public, True, nb)
+        lp_ref, by_ref = oracle.lna_encode(lik, True, nb)
+        if nb == 2:
+            a = got.reshape(F, S, 2).astype(np.int32)
+            b = want.reshape(F, S, 2).astype(np.int32)
+            ca, cb = a[..., 0] * 256 + a[..., 1], b[..., 0] * 256 + b[..., 1]
+            assert np.abs(ca - cb).max() <= 1 and (ca == cb).mean() > 0.99
+            # (the normaliser sums over all states, so a rounding-level move of the routed states' values can flip a code
+            # of any state; without normalisation the first section's states -- same kernel, same rows -- give the same bits)
+            d_raw = torch.empty((F, S * 2), dtype=torch.uint8, device="cuda")
+            g.score_lna_dev(d_fr, d_scr, d_raw, False, 2)
+            torch.cuda.synchronize()
+            good = [s for s in range(S) if s not in bad]
+            raw = d_raw.cpu().numpy().reshape(F, S, 2)
+            assert np.array_equal(raw[:, good], capi.lna_encode(public, False, 2)[1].reshape(F, S, 2)[:, good])
+            o = by_ref.reshape(F, S, 2).astype(np.int32)
+            co = o[..., 0] * 256 + o[..., 1]
+            assert np.abs(ca - co).max() <= 1
+        else:
+            lp = got.view("<f4").reshape(F, S)
+            lp_pub = want.view("<f4").reshape(F, S)
+            vis = ref_ll > -85
+            assert np.abs(lp - lp_pub)[vis].max() <= 8e-5    # (the sub-model has its own pivot and may run two fp16 terms where the public layout runs three bf16 terms)
+            assert np.abs(lp - lp_ref)[vis].max() <= 1e-4
+    # clustering merges by state column: the engine layout steps aside, the bytes stay right
+    g2c = synth.make_clustering(model[0], 64)
+    g.set_clustering(64, [(int(a), int(c)) for a, c in enumerate(g2c)])
+    g.set_clustering_min_evals(1.0, 1.0)
+    d_by = torch.empty((F, S * 2), dtype=torch.uint8, device="cuda")
+    g.score_lna_dev(d_fr, d_scr, d_by, True, 2)
+    torch.cuda.synchronize()
+    a = d_by.cpu().numpy().reshape(F, S, 2).astype(np.int32)
+    o = oracle.lna_encode(lik, True, 2)[1].reshape(F, S, 2).astype(np.int32)
+    assert np.abs((a[..., 0] * 256 + a[..., 1]) - (o[..., 0] * 256 + o[..., 1])).max() <= 1
+    g.close()
