@@ -91,6 +91,10 @@ def run(seed=1, N=40, verbose=False, big=False):
         g = capi.Gmm.from_arrays(mean, var, off, idx, w)
         ctx = "seed %d it %d D %d S %d G %d tied %d F %d kappa %.0f" % (
             seed, it, D, S, G, tied, F, L.aasr_debug_kappa(g._h))
+        # per-state precision routing: how many of the sweep's models get a mixed layout, how many states the probe moves
+        n16, moved = g.precision_states()
+        worst["models routed (mixed layout)"] = worst.get("models routed (mixed layout)", 0) + (1 if 0 < n16 < S else 0)
+        worst["states moved by the f16x2 probe"] = worst.get("states moved by the f16x2 probe", 0) + moved
         for layouts in (7, 2, 0, 4):
             g.set_layouts(layouts)
             for prec in (0, 3, 4):
