@@ -674,6 +674,13 @@ struct TemporalPrm {
   int dim;
 };
 
+// frame rows per workgroup of k_temporal_fused
+#ifdef AASR_TR
+constexpr int kTemporalRows = AASR_TR;
+#else
+constexpr int kTemporalRows = 32;
+#endif
+
 template <int ROWS>
 __global__ __launch_bounds__(256) void k_temporal_fused(DevBatch b, const double *__restrict__ src,
                                                         SrcMap sm, int span, int64_t rows,
@@ -687,7 +694,10 @@ __global__ __launch_bounds__(256) void k_temporal_fused(DevBatch b, const double
   float *ms = (float *)(nrm + (size_t)ROWS * md);               // [dim][md | 1]
   const int mstride = md | 1;
   if (tp.matrix)
-    for (int e = threadIdx.x; e < tp.dim * md; e += 256) ms[(e / md) * mstride + (e % md)] = tp.matrix[e];
+    for (int e = threadIdx.x; e < tp.dim * md; e += 256) {
+      const int r = fast_div(e, md_magic);   // (a 32-bit division is ~25 instructions; this loop runs once per workgroup)
+      ms[r * mstride + (e - r * md)] = tp.matrix[e];
+    }
   const int64_t tile0 = (int64_t)blockIdx.x * ROWS;
   const int64_t tile1 = tile0 + ROWS < rows ? tile0 + ROWS : rows;
   int64_t r0 = tile0;
@@ -1234,7 +1244,7 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
       if (h->mods[A].dim != dx || h->mods[B].dim != dx || Cm.dim != 3 * dx || T.src_dim != 3 * dx) continue;
       if ((int)h->mods[N].mean.size() != 3 * dx || (int)h->mods[N].scale.size() != 3 * dx) continue;
       const int H = h->mods[A].delta_width + h->mods[B].delta_width;
-      constexpr int TR = 32;
+      constexpr int TR = kTemporalRows;
       const size_t smem = (size_t)(TR + 2 * H) * dx * 8 + (size_t)(TR + 2 * h->mods[B].delta_width) * dx * 8 +
                           (size_t)TR * 3 * dx * 8 + (size_t)T.dim * ((3 * dx) | 1) * 4;
       if (smem > 64 * 1024) continue;
@@ -1306,7 +1316,7 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
       tp.matrix = m.matrix_defined ? m.d_matrix.p : nullptr;
       tp.bias = m.bias_defined ? m.d_bias.p : nullptr;
       tp.dim = m.dim;
-      constexpr int TR = 32;
+      constexpr int TR = kTemporalRows;
       const int H = tp.w1 + tp.w2;
       const size_t smem = (size_t)(TR + 2 * H) * tp.dx * 8 + (size_t)(TR + 2 * tp.w2) * tp.dx * 8 +
                           (size_t)TR * 3 * tp.dx * 8 + (size_t)m.dim * ((3 * tp.dx) | 1) * 4;
@@ -1500,7 +1510,11 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
         break;
       }
       case MOD_MEAN_SUBTRACTOR: {
+#ifdef AASR_MS_ROWS
+        constexpr int MS_ROWS = AASR_MS_ROWS;
+#else
         constexpr int MS_ROWS = 64;
+#endif
         const size_t ms_src = (size_t)(MS_ROWS + m.cms_left + m.cms_right);
         const size_t ms_smem = (ms_src + ms_src / 8 + 1) * m.dim * 8;
         if (ms_smem <= 60 * 1024 && i == target && g_feat_fusion && out_f32 && !out_f64) {
