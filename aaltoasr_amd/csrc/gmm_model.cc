@@ -496,6 +496,12 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
   g->outlier.clear();
   g->hyb_enabled = false;
   g->hyb_states = g->hyb_rows = 0;
+  // per-state precision routing belongs to the plain diagonal build below: nothing of an earlier build may survive a
+  // rebuild that takes another path (class routing, dimension parts, factor rows)
+  g->mixed = TrackLayout();
+  g->routed_sub.reset();
+  g->routed_colmap = DevBuf<int32_t>();
+  g->f16_probe_moved = 0;
   g->rows_unbiased = false;
   g->out_bias_ln = 0;
   g->dim = m.dim;

@@ -357,7 +357,9 @@ aasr_status aasr_lna_encode_dev(const float *d_state_loglik, int64_t F,
                                 void *stream);
 /* Frames straight to LNA codes on the device: aasr_gmm_score_dev followed by
  * aasr_lna_encode_dev, except that the engine may keep the state scores in its
- * own layout in between (rows padded to whole cache lines).  d_scratch takes aasr_gmm_score_scratch_floats(h, F) floats,
+ * own layout in between (rows padded to whole cache lines; the states a routed model scores with three terms --
+ * aasr_gmm_precision_states -- in spare columns behind the others, read back through a column map).  d_scratch takes
+ * aasr_gmm_score_scratch_floats(h, F) floats (ask again after a change of clustering / transforms: it only shrinks),
  * d_bytes_out F * num_states * lnabytes bytes.  What the recipe driver runs per block. */
 int64_t aasr_gmm_score_scratch_floats(const aasr_gmm *h, int64_t F);
 aasr_status aasr_gmm_score_lna_dev(aasr_gmm *h, const float *d_frames, int64_t F, int normalize, int lnabytes,

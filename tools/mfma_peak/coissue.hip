@@ -57,9 +57,9 @@ __global__ __launch_bounds__(512) void k_coissue(const unsigned *__restrict__ pa
 
 template <int E, int A, int CH>
 static double run(int waves_per_simd, int cus, const unsigned *d_pat, float *d_out, double target_ms) {
-  // workgroups of 8 waves: one per CU for 2 waves per SIMD, two per CU for 4
-  const int threads = 512;
-  cus = cus * waves_per_simd / 2;
+  // workgroups of 8 waves: one per CU for 2 waves per SIMD, two per CU for 4; ONE wave per SIMD: workgroups of 4 waves
+  const int threads = waves_per_simd == 1 ? 256 : 512;
+  if (waves_per_simd > 1) cus = cus * waves_per_simd / 2;
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
@@ -81,7 +81,7 @@ static double run(int waves_per_simd, int cus, const unsigned *d_pat, float *d_o
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     CHECK(hipEventElapsedTime(&ms, e0, e1));
-    if (rep >= 1) sum += (double)cus * 8 * iters * 16.0 * 32768.0 / (ms * 1e-3) / 1e12;
+    if (rep >= 1) sum += (double)cus * (threads / 64) * iters * 16.0 * 32768.0 / (ms * 1e-3) / 1e12;
   }
   return sum / (reps - 1);
 }
@@ -118,5 +118,17 @@ int main(int argc, char **argv) {
   ROW(1, 3, 2, "1 v_exp_f32 + 3 v_add_f32, 2 chains (its masked instance)")
   ROW(1, 2, 4, "1 v_exp_f32 + 2 v_add_f32, 4 chains")
   ROW(2, 4, 2, "2 v_exp_f32 + 4 v_add_f32, 2 chains")
+  // round 4: would ONE wave per SIMD (512 registers: 128 frames per wave, accumulators in AGPRs) keep the pipe fed?
+  printf("one wave per SIMD (4-wave workgroups, one per CU):\n");
+#define ROW1(E, A, CH, label)                                                          \
+  {                                                                                    \
+    const double t1 = run<E, A, CH>(1, cus, d_pat, d_out, target_ms);                  \
+    printf("%-58s %7.0f TF   (%.2f of 2500)\n", label, t1, t1 / 2500);                 \
+  }
+  ROW1(0, 0, 4, "nothing, 4 chains")
+  ROW1(0, 0, 2, "nothing, 2 chains")
+  ROW1(1, 2, 4, "1 v_exp_f32 + 2 v_add_f32, 4 chains")
+  ROW1(1, 3, 4, "1 v_exp_f32 + 3 v_add_f32, 4 chains (+ an accumulator read)")
+  ROW1(1, 3, 2, "1 v_exp_f32 + 3 v_add_f32, 2 chains")
   return 0;
 }
