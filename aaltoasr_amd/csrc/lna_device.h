@@ -86,7 +86,10 @@ __device__ __forceinline__ float cast_f(float ll) {
 // unconditional barriers so that several groups -- k_cluster_merge_lna, since removed: four frames side by side --
 // could call it together; whoever revives that has to make the count uniform again.)  tid / wave / lane are relative
 // to the group, which is the workgroup.
-template <int VPT>
+// JSAFE: elements j < JSAFE (states tid + 256 j) are known to lie below S -- the launcher picks the smallest VPT that
+// covers S, so S > 256 * (the next smaller VPT) -- and need no range test: the compiler otherwise keeps one execution
+// mask per element (spilled to lanes of a vector register, read back with two v_readlane per use)
+template <int VPT, int JSAFE = 0>
 __device__ __forceinline__ void lna_row_from_registers(const float (&v)[VPT], int S, int tid, int wave, int lane,
                                                        double *red, int normalize, int lnabytes, int64_t f,
                                                        bool store, float *__restrict__ lp_out,
@@ -125,7 +128,7 @@ __device__ __forceinline__ void lna_row_from_registers(const float (&v)[VPT], in
 #pragma unroll
       for (int j = 0; j < VPT; j++) {
         const int i = tid + 256 * j;
-        if (i < S) {
+        if (j < JSAFE || i < S) {
           // band and flushed values: lp < -36.008 either way; the others exactly as the exact path
           const float lp = fmaxf((float)((double)v[j] - logz), (float)LOG_TINY_D);
           lna_store(lp, 2, f * (int64_t)S + i, nullptr, bytes_out);
@@ -160,7 +163,7 @@ __device__ __forceinline__ void lna_row_from_registers(const float (&v)[VPT], in
 #pragma unroll
   for (int j = 0; j < VPT; j++) {
     const int i = tid + 256 * j;
-    if (i < S) {
+    if (j < JSAFE || i < S) {
       const double vd = v[j] >= LN_FLT_MIN_F ? (double)v[j] : float_cast_loglik(v[j]);
       // safe_log's floor after the rounding to float instead of before it (rounding is monotone and
       // (float)log(1e-50) is the floor's own float, -inf - logz stays -inf): one f32 max for a double compare +

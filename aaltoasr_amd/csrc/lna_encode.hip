@@ -98,13 +98,15 @@ __global__ __launch_bounds__(256) void k_state_norm_lna_reg(
     float *__restrict__ lp_out, uint8_t *__restrict__ bytes_out, const int32_t *__restrict__ colmap) {
   __shared__ double red[8];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // the launcher takes the smallest instance that covers S: S > 256 * (the next smaller instance's VPT)
+  constexpr int JSAFE = VPT == 4 ? 0 : VPT == 8 ? 4 : VPT == 10 ? 8 : VPT == 13 ? 10 : VPT == 16 ? 13 : 0;
   // colmap (engine-internal score layout of a routed model, gmm_engine_colmap): state i sits in column colmap[i] of a
   // score row; the same for every frame, so a thread looks its columns up once
   int col[VPT];
 #pragma unroll
   for (int j = 0; j < VPT; j++) {
     const int i = tid + 256 * j;
-    col[j] = (colmap && i < S) ? colmap[i] : i;
+    col[j] = (colmap && (j < JSAFE || i < S)) ? colmap[i] : i;
   }
   // a workgroup walks frames blockIdx.x, + gridDim.x, ...; the next frame's row is requested
   // before this one is reduced (the four barriers of a frame leave nothing else to hide the
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256) void k_state_norm_lna_reg(
 #pragma unroll
     for (int j = 0; j < VPT; j++) {
       const int i = tid + 256 * j;
-      vn[j] = (i < S && (int64_t)blockIdx.x < F) ? row[col[j]] : -INFINITY;
+      vn[j] = ((j < JSAFE || i < S) && (int64_t)blockIdx.x < F) ? row[col[j]] : -INFINITY;
     }
   }
   for (int64_t f = blockIdx.x; f < F; f += gridDim.x) {
@@ -127,10 +129,10 @@ __global__ __launch_bounds__(256) void k_state_norm_lna_reg(
 #pragma unroll
       for (int j = 0; j < VPT; j++) {
         const int i = tid + 256 * j;
-        vn[j] = i < S ? row[col[j]] : -INFINITY;
+        vn[j] = (j < JSAFE || i < S) ? row[col[j]] : -INFINITY;
       }
     }
-    lna_row_from_registers<VPT>(v, S, tid, wave, lane, red, normalize, lnabytes, f, true, lp_out, bytes_out);
+    lna_row_from_registers<VPT, JSAFE>(v, S, tid, wave, lane, red, normalize, lnabytes, f, true, lp_out, bytes_out);
   }
 }
 
