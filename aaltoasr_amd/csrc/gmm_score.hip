@@ -1498,21 +1498,56 @@ __global__ __launch_bounds__(256) void k_frame_operand(const float *__restrict__
   if (f > F - 1) f = F - 1;
   const float *xr = frames + f * dim;
   float v[8];
+  // the thread's 8 K slots are 8 consecutive dimensions d0 .. d0 + 7 (linear terms for k < KH, quadratic from KH on: a
+  // slab half never straddles KH).  Where they all exist the frame components, pivots, clamps and scales come as two
+  // 16-byte loads each (rows are 4-byte aligned; the tables' loads are the same for every lane of a K half)
+  const int k0 = 16 * j + 8 * h;
+  const int d0 = k0 < KH ? k0 : k0 - KH;
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  if (d0 + 8 <= dim) {   // uniform per K half
+    float x[8], pv[8], lim[8], sc[8];
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const int k = 16 * j + 8 * h + i;
-    const int d = k < KH ? k : k - KH;
-    const int dc = d < dim ? d : 0;
-    const float xc = xr[dc] - pivot[dc];
-    float xq = xc;
-    if (NS == 2) {  // fp16 range: the dimension's clamp (see the f16x2 note above and pack_f16x2)
-      const float lim = f16tab[2 * KH + dc];
-      xq = fminf(fmaxf(xc, -lim), lim);
+    for (int q = 0; q < 2; q++) {
+      const f32x4u a = *(const f32x4u *)(xr + d0 + 4 * q), b = *(const f32x4u *)(pivot + d0 + 4 * q);
+      f32x4u c = {0, 0, 0, 0}, e = {1, 1, 1, 1};
+      if (NS == 2) {
+        c = *(const f32x4u *)(f16tab + 2 * KH + d0 + 4 * q);
+        e = *(const f32x4u *)(f16tab + k0 + 4 * q);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        x[4 * q + i] = a[i];
+        pv[4 * q + i] = b[i];
+        lim[4 * q + i] = c[i];
+        sc[4 * q + i] = e[i];
+      }
     }
-    float val = k < KH ? xq : xq * xq;
-    if (d >= dim) val = (k == dim || (NS == 2 && k == KH + dim)) ? 1.0f : 0.0f;
-    if (NS == 2) val *= f16tab[k];   // the column's power-of-two scale (the rows carry its inverse): exact
-    v[i] = val;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const float xc = x[i] - pv[i];
+      float xq = xc;
+      if (NS == 2) xq = fminf(fmaxf(xc, -lim[i]), lim[i]);   // fp16 range: the dimension's clamp (pack_f16x2)
+      float val = k0 < KH ? xq : xq * xq;
+      if (NS == 2) val *= sc[i];   // the column's power-of-two scale (the rows carry its inverse): exact
+      v[i] = val;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int k = k0 + i;
+      const int d = k < KH ? k : k - KH;
+      const int dc = d < dim ? d : 0;
+      const float xc = xr[dc] - pivot[dc];
+      float xq = xc;
+      if (NS == 2) {  // fp16 range: the dimension's clamp (see the f16x2 note above and pack_f16x2)
+        const float lim = f16tab[2 * KH + dc];
+        xq = fminf(fmaxf(xc, -lim), lim);
+      }
+      float val = k < KH ? xq : xq * xq;
+      if (d >= dim) val = (k == dim || (NS == 2 && k == KH + dim)) ? 1.0f : 0.0f;
+      if (NS == 2) val *= f16tab[k];   // the column's power-of-two scale (the rows carry its inverse): exact
+      v[i] = val;
+    }
   }
   u32x4 *o = out + ((size_t)(blk * nk16 + j) * NS * 2 + nb) * 64 + lane;   // + term * 2 * 64
   if constexpr (NS == 3) {

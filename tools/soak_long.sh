@@ -2,7 +2,7 @@
 # the sweeps of tools/soak.sh at ten times the size (about 20 GPU-minutes); gpurun_out/soak_long/*.log
 mkdir -p gpurun_out/soak_long
 B=${1:-10000}
-for i in 1 2 3 4 5 6; do timeout 1500 python tools/fuzz_parity.py $((B + i)) 500 2>&1 | grep -i "failures\|FAIL" | tail -5 >> gpurun_out/soak_long/parity.log; done
+for i in 1 2 3 4 5 6; do timeout 1500 python tools/fuzz_parity.py $((B + i)) 500 2>&1 | grep -i "failures\|FAIL\|routed\|probe" | tail -8 >> gpurun_out/soak_long/parity.log; done
 timeout 1500 python tools/fuzz_parity.py $((B + 50)) 100 big 2>&1 | grep -i "failures\|FAIL" | tail -5 >> gpurun_out/soak_long/parity_big.log
 for i in 1 2 3 4; do AASR_FUZZ_TOL=6e-5 timeout 1500 python tools/fuzz_fullcov.py $((B + 100 + i)) 500 2>&1 | grep "NOTE\|prec=\|failures" >> gpurun_out/soak_long/fullcov.log; done
 for i in 1 2; do timeout 1500 python tools/fuzz_features.py $((B + 200 + i)) 500 2>&1 | grep -i "failures\|FAIL" | tail -5 >> gpurun_out/soak_long/features.log; done
