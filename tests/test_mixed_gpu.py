@@ -228,3 +228,41 @@ def test_routed_model_on_the_engines_own_score_layout(capi, oracle):
     o = oracle.lna_encode(lik, True, 2)[1].reshape(F, S, 2).astype(np.int32)
     assert np.abs((a[..., 0] * 256 + a[..., 1]) - (o[..., 0] * 256 + o[..., 1])).max() <= 1
     g.close()
+
+
+def test_routed_model_under_a_global_transform_and_through_the_model_cache(capi, oracle, tmp_path):
+    """A global constrained-MLLR transform set on a routed model (updated in place: adapted frames, log|det| at the kernels'
+    output -- both sections), taken off again; and the same model through the binary model cache (aasr_gmm_write_cache /
+    create_from_cache): the routing is rebuilt from the parsed model, the scores are the same bits."""
+    S, D = 96, 39
+    bad = [3, 40, 41, 77]
+    model = synth.push_states_over_the_f16_limits(synth.make_model(D=D, G=S * 8, S=S, comps=8, seed=490), bad)
+    fr = synth.make_frames(500, seed=491)
+    g = capi.Gmm.from_arrays(*model)
+    assert g.precision_states()[0] == S - len(bad)
+    plain = g.score(fr)
+    rng = np.random.default_rng(492)
+    A = np.eye(D) * rng.uniform(0.95, 1.05, D) + 0.01 * rng.standard_normal((D, D))
+    b = 0.1 * rng.standard_normal(D)
+    W = np.hstack([b[:, None], A])
+    g.set_cmllr(np.zeros(S * 8, np.int32), W[None])
+    want = oracle.score_adapted(oracle.DiagModel(*model), fr.astype(np.float64), np.zeros(S * 8, np.int32), W[None])
+    assert_ll(g.score(fr), want, "routed model under a global transform")
+    g.set_cmllr(None, None)
+    assert np.array_equal(g.score(fr), plain)
+    base = str(tmp_path / "m")
+    oracle.write_gk(base + ".gk", model[0], model[1])
+    oracle.write_mc(base + ".mc", model[2], model[3], model[4])
+    oracle.write_ph(base + ".ph", S)
+    g1 = capi.Gmm.from_files(base + ".gk", base + ".mc", base + ".ph")
+    n16 = g1.precision_states()[0]
+    assert 0 < n16 < S
+    ref = oracle.DiagModel(*oracle.read_gk(base + ".gk"), model[2], model[3], model[4]).score(fr.astype(np.float64))
+    got1 = g1.score(fr)
+    assert_ll(got1, ref, "routed model from files")
+    cache = str(tmp_path / "m.cache")
+    g1.write_cache(cache)
+    g2 = capi.Gmm.from_cache(cache)
+    assert g2.precision_states()[0] == n16 and np.array_equal(g2.score(fr), got1)
+    for h in (g, g1, g2):
+        h.close()
