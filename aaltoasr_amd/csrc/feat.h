@@ -73,6 +73,7 @@ struct FeatModule {
   // mel
   int root = 0;
   DevBuf<int32_t> mel_off, mel_t;   // CSR over bins: source index t per term
+  DevBuf<int32_t> mel_order;        // the bins by falling term count (the fused kernel deals them to lanes in this order)
   DevBuf<float> mel_scale, mel_sum;  // per term scale, per bin float sum
   // dct
   int zeroth = 0;

@@ -9,6 +9,7 @@
 // mel edges, DCT cosines, KissFFT twiddles) are computed HERE on the host with
 // the same expressions, so the device never evaluates cosf/log10f/pow itself.
 #include <climits>
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -533,6 +534,15 @@ static void configure(aasr_feat *h, FeatModule &m, const ModuleConfig &c) {
       m.mel_t.upload(tt.data(), tt.size());
       m.mel_scale.upload(sc.data(), sc.size());
       m.mel_sum.upload(sums.data(), sums.size());
+      {
+        // k_spectral_fused gives a frame's bins to its 16 lanes in rounds; a round lasts as long as its longest bin, so
+        // the bins go out by falling term count (the 16 longest together, the short ones in the last round)
+        std::vector<int32_t> order((size_t)m.dim);
+        for (int b = 0; b < m.dim; b++) order[(size_t)b] = b;
+        std::stable_sort(order.begin(), order.end(),
+                         [&](int32_t a, int32_t b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
+        m.mel_order.upload(order.data(), order.size());
+      }
       break;
     }
     case MOD_POWER:

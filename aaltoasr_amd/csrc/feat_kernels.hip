@@ -424,7 +424,7 @@ constexpr int SPEC_TPF = 16;      // threads per frame (a wave = 4 frames)
 struct SpectralPrm {
   FftPrm fp;
   int mel_dim, mel_root, mel_terms;
-  const int32_t *mel_off, *mel_t;
+  const int32_t *mel_off, *mel_t, *mel_order;
   const float *mel_scale, *mel_sum;
   int dct_dim, zeroth;
   const float *dct_cos;
@@ -432,7 +432,7 @@ struct SpectralPrm {
 
 // LDS plan shared by the host (size) and the kernel (offsets), in bytes
 struct SpectralLds {
-  size_t bufs, frame_u, melv, powv, ham, perm, tw, stw, moff, mt, msc, msum, dct, prm, total;
+  size_t bufs, frame_u, melv, powv, ham, perm, tw, stw, moff, mt, msc, msum, mord, dct, prm, total;
   size_t frame_u_stride;  // per frame: int16 samples first, the float spectrum later
   __host__ __device__ SpectralLds(int nc, int mel_dim, int mel_terms, int dct_rows) {
     size_t o = 0;
@@ -456,6 +456,7 @@ struct SpectralLds {
     mt = take((size_t)mel_terms * 4);
     msc = take((size_t)mel_terms * 4);
     msum = take((size_t)mel_dim * 4);
+    mord = take((size_t)mel_dim * 4);
     dct = take((size_t)dct_rows * mel_dim * 4);
     prm = take((size_t)SPEC_FRAMES * 3 * 8);
     total = o;
@@ -482,6 +483,7 @@ __global__ __launch_bounds__(256) void k_spectral_fused(DevBatch b, const int16_
   int32_t *t_mt = (int32_t *)(smem_raw + lds.mt);
   float *t_msc = (float *)(smem_raw + lds.msc);
   float *t_msum = (float *)(smem_raw + lds.msum);
+  int32_t *t_mord = (int32_t *)(smem_raw + lds.mord);
   float *t_dct = (float *)(smem_raw + lds.dct);
   int64_t *s_prm = (int64_t *)(smem_raw + lds.prm);  // [FB][3]: window start, utterance offset, samples
   const int tid = threadIdx.x;
@@ -500,12 +502,14 @@ __global__ __launch_bounds__(256) void k_spectral_fused(DevBatch b, const int16_
     t_mt[i] = sp.mel_t[i];
     t_msc[i] = sp.mel_scale[i];
   }
-  for (int i = tid; i < sp.mel_dim; i += 256) t_msum[i] = sp.mel_sum[i];
+  for (int i = tid; i < sp.mel_dim; i += 256) {
+    t_msum[i] = sp.mel_sum[i];
+    t_mord[i] = sp.mel_order[i];
+  }
   for (int i = tid; i < dct_rows * sp.mel_dim; i += 256) t_dct[i] = sp.dct_cos[i];
 
   cpx *buf = bufs + (size_t)f * nc;
   char *fu = smem_raw + lds.frame_u + (size_t)f * lds.frame_u_stride;
-  int16_t *spcm = (int16_t *)fu;  // this frame's samples ws .. ws + 2 nc
   float *spec = (float *)fu;      // later: its nc + 1 spectrum values
   const int out_dim = sp.dct_dim + 1;
   const int64_t nblk = (rows + FB - 1) / FB;
@@ -535,29 +539,37 @@ __global__ __launch_bounds__(256) void k_spectral_fused(DevBatch b, const int16_
     }
     __syncthreads();
     // From here on a frame belongs to 16 threads of one wave: wave-level ordering is enough.
+    // pre-emphasis in float (AudioFileModule::generate), Hamming, packed (even, odd) -> complex in KissFFT's
+    // digit-reversed order.  A lane fetches the three samples of each of its points straight from global memory (a frame's
+    // 514 bytes stay in the L1 cache, neighbouring frames share half of them): staging the window in LDS first cost 17
+    // loads with a 64-bit range test each + as many LDS writes, 72 us of the kernel's 634.  Only a frame whose window
+    // crosses an end of its file (zero outside, AudioReader) takes the range tests.
     {
       const int64_t ws = s_prm[3 * f], ns = s_prm[3 * f + 2];
       const int16_t *p = pcm + s_prm[3 * f + 1];
-#pragma unroll 6
-      for (int t = l; t <= (AASR_FDBG(8) ? 0 : 2 * nc); t += TPF) {
-        const int64_t i = ws + t;
-        spcm[t] = (i >= 0 && i < ns) ? p[i] : (int16_t)0;  // zero outside the file (AudioReader)
+      const bool inside = ws >= 0 && ws + 2 * nc < ns;   // uniform over the frame's 16 lanes
+      for (int o = l; o < ((AASR_FDBG(32) || AASR_FDBG(8)) ? 0 : nc); o += TPF) {
+        const int s = t_perm[o];
+        float c0, c1, c2;
+        if (inside) {
+          const int16_t *q = p + ws + 2 * s;
+          c0 = (float)q[0];
+          c1 = (float)q[1];
+          c2 = (float)q[2];
+        } else {
+          const int64_t i = ws + 2 * s;
+          c0 = (i >= 0 && i < ns) ? (float)p[i] : 0.0f;
+          c1 = (i + 1 >= 0 && i + 1 < ns) ? (float)p[i + 1] : 0.0f;
+          c2 = (i + 2 >= 0 && i + 2 < ns) ? (float)p[i + 2] : 0.0f;
+        }
+        const float p0 = ap.emph * c0, p1 = ap.emph * c1;
+        const double x0 = (double)(c1 - p0);
+        const double x1 = (double)(c2 - p1);
+        cpx v;
+        v.r = (float)((double)t_ham[2 * s] * x0);
+        v.i = (float)((double)t_ham[2 * s + 1] * x1);
+        buf[o] = v;
       }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // pre-emphasis in float (AudioFileModule::generate), Hamming, packed (even, odd) -> complex in
-    // KissFFT's digit-reversed order
-    for (int o = l; o < nc; o += TPF) {
-      const int s = t_perm[o];
-      const float c0 = (float)spcm[2 * s], c1 = (float)spcm[2 * s + 1], c2 = (float)spcm[2 * s + 2];
-      const float p0 = ap.emph * c0, p1 = ap.emph * c1;
-      const double x0 = (double)(c1 - p0);
-      const double x1 = (double)(c2 - p1);
-      cpx v;
-      v.r = (float)((double)t_ham[2 * s] * x0);
-      v.i = (float)((double)t_ham[2 * s + 1] * x1);
-      buf[o] = v;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -570,7 +582,7 @@ __global__ __launch_bounds__(256) void k_spectral_fused(DevBatch b, const int16_
       __builtin_amdgcn_wave_barrier();
     }
     // real split + power spectrum into spec[0..nc] (overwrites the staged samples)
-    for (int k = l; k <= nc / 2; k += TPF) {
+    for (int k = l; k <= (AASR_FDBG(64) ? -1 : nc / 2); k += TPF) {
       if (k == 0) {
         const cpx t0 = buf[0];
         spec[0] = spec_value(t0.r + t0.i, 0.0f, sp.fp.magnitude, sp.fp.take_log);
@@ -586,7 +598,8 @@ __global__ __launch_bounds__(256) void k_spectral_fused(DevBatch b, const int16_
     __builtin_amdgcn_wave_barrier();
     // MelModule::generate (aku/FeatureModules.cc:805-849): one bin per thread and round; the last
     // thread of the frame also carries PowerModule's left-to-right float sum (:874-885)
-    for (int bin = l; bin < (AASR_FDBG(4) ? 0 : sp.mel_dim); bin += TPF) {
+    for (int slot = l; slot < (AASR_FDBG(4) ? 0 : sp.mel_dim); slot += TPF) {
+      const int bin = t_mord[slot];   // by falling term count: a round lasts as long as its longest bin
       float val = 0;
       const int e_end = t_moff[bin + 1];
       int e = t_moff[bin];
@@ -634,7 +647,7 @@ __global__ __launch_bounds__(256) void k_spectral_fused(DevBatch b, const int16_
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // DCTModule::generate (:955-979) into the merged row [cepstra..., log power]
-    if (r0 + f < rows) {
+    if (r0 + f < rows && !AASR_FDBG(128)) {
       const double *data = melv + (size_t)f * sp.mel_dim;
       for (int i = l; i < out_dim; i += TPF) {
         double acc;
@@ -1287,6 +1300,7 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
       sp.mel_t = M.mel_t.p;
       sp.mel_scale = M.mel_scale.p;
       sp.mel_sum = M.mel_sum.p;
+      sp.mel_order = M.mel_order.p;
       sp.dct_dim = D.dim;
       sp.zeroth = D.zeroth;
       sp.dct_cos = D.dct_cos.p;
