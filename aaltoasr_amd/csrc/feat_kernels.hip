@@ -697,20 +697,38 @@ constexpr int kTemporalRows = 32;
 template <int ROWS>
 __global__ __launch_bounds__(256) void k_temporal_fused(DevBatch b, const double *__restrict__ src,
                                                         SrcMap sm, int span, int64_t rows,
-                                                        TemporalPrm tp, double *__restrict__ dst) {
+                                                        TemporalPrm tp, int dbg, double *__restrict__ dst) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int dx = tp.dx, H = tp.w1 + tp.w2, md = 3 * tp.dx;
-  const unsigned dx_magic = fast_magic(dx), md_magic = fast_magic(md), dim_magic = fast_magic(tp.dim);
+  const unsigned dx_magic = fast_magic(dx), dim_magic = fast_magic(tp.dim);
   double *xs = (double *)smem_raw;                              // [ROWS + 2H][dx]
   double *d1 = xs + (size_t)(ROWS + 2 * H) * dx;                // [ROWS + 2 w2][dx]
   double *nrm = d1 + (size_t)(ROWS + 2 * tp.w2) * dx;           // [ROWS][md]
-  float *ms = (float *)(nrm + (size_t)ROWS * md);               // [dim][md | 1]
-  const int mstride = md | 1;
-  if (tp.matrix)
-    for (int e = threadIdx.x; e < tp.dim * md; e += 256) {
-      const int r = fast_div(e, md_magic);   // (a 32-bit division is ~25 instructions; this loop runs once per workgroup)
-      ms[r * mstride + (e - r * md)] = tp.matrix[e];
+  // the transform, transposed and in groups of three output rows: mt[j][g] = (m[3g][j], m[3g+1][j], m[3g+2][j], 0), so
+  // one 16-byte LDS read serves three products.  The product loop was bound by the LDS pipe (a b64 and a b32 read per
+  // product, 115 us of the kernel's 227): a thread now forms a 3 x 2 block of outputs (three transform rows, two
+  // frames) from one b128 and two b64 reads per step, every output's products and additions in the same order.
+  float4 *mt = (float4 *)(smem_raw + ((((size_t)(2 * ROWS + 2 * H + 2 * tp.w2) * dx + (size_t)ROWS * md) * 8 + 15) & ~(size_t)15));  // [md][ngrp]
+  const int ngrp = (tp.dim + 2) / 3;
+  const unsigned ngrp_magic = fast_magic(ngrp);
+  if (tp.matrix && !AASR_FDBG(8))
+    for (int e = threadIdx.x; e < md * ngrp; e += 256) {
+      const int j = fast_div(e, ngrp_magic), g = e - j * ngrp;
+      float4 v;
+      v.x = tp.matrix[(size_t)(3 * g) * md + j];
+      v.y = 3 * g + 1 < tp.dim ? tp.matrix[(size_t)(3 * g + 1) * md + j] : 0.0f;
+      v.z = 3 * g + 2 < tp.dim ? tp.matrix[(size_t)(3 * g + 2) * md + j] : 0.0f;
+      v.w = 0.0f;
+      mt[e] = v;
     }
+  // normalisation vectors and the bias: LDS copies (a global load per value and round stood in the dependent chain)
+  float *nmean = (float *)(mt + (size_t)md * ngrp), *nscale = nmean + md, *nbias = nscale + md;
+  for (int e = threadIdx.x; e < md; e += 256) {
+    nmean[e] = tp.mean[e];
+    nscale[e] = tp.scale[e];
+  }
+  if (tp.bias)
+    for (int e = threadIdx.x; e < tp.dim; e += 256) nbias[e] = tp.bias[e];
   const int64_t tile0 = (int64_t)blockIdx.x * ROWS;
   const int64_t tile1 = tile0 + ROWS < rows ? tile0 + ROWS : rows;
   int64_t r0 = tile0;
@@ -724,7 +742,7 @@ __global__ __launch_bounds__(256) void k_temporal_fused(DevBatch b, const double
     for (int e = threadIdx.x; e < n_x * dx; e += 256) xs[e] = src[(s0 - H) * dx + e];
     __syncthreads();
     // DeltaModule::generate (aku/FeatureModules.cc:1018-1037) on the source rows
-    for (int e = threadIdx.x; e < n_d1 * dx; e += 256) {
+    for (int e = threadIdx.x; e < (AASR_FDBG(4) ? 0 : n_d1 * dx); e += 256) {
       const int j = fast_div(e, dx_magic), i = e - j * dx;
       const int c = j + tp.w1;
       double acc = 0;
@@ -737,41 +755,78 @@ __global__ __launch_bounds__(256) void k_temporal_fused(DevBatch b, const double
     }
     __syncthreads();
     // second difference, merge (source, delta, delta-delta) and NormalizationModule::generate (:1135-1142)
-    for (int e = threadIdx.x; e < n_seg * md; e += 256) {
-      const int lr = fast_div(e, md_magic), col = e - lr * md;
-      const int part = fast_div(col, dx_magic), i = col - part * dx;
-      double v;
-      if (part == 0) {
-        v = xs[(size_t)(lr + H) * dx + i];
-      } else if (part == 1) {
-        v = d1[(size_t)(lr + tp.w2) * dx + i];
-      } else {
-        const int c = lr + tp.w2;
-        double acc = 0;
-        for (int k = 1; k <= tp.w2; k++) {
-          const double left = d1[(size_t)(c - k) * dx + i];
-          const double right = d1[(size_t)(c + k) * dx + i];
-          acc += k * (right - left);
-        }
-        v = acc / (double)tp.norm2;
+    // (one thread forms a frame's three values of one source column: no divergence between the three parts)
+    for (int e = threadIdx.x; e < (AASR_FDBG(2) ? 0 : n_seg * dx); e += 256) {
+      const int lr = fast_div(e, dx_magic), i = e - lr * dx;
+      const double v0 = xs[(size_t)(lr + H) * dx + i];
+      const double v1 = d1[(size_t)(lr + tp.w2) * dx + i];
+      const int c = lr + tp.w2;
+      double acc = 0;
+      for (int k = 1; k <= tp.w2; k++) {
+        const double left = d1[(size_t)(c - k) * dx + i];
+        const double right = d1[(size_t)(c + k) * dx + i];
+        acc += k * (right - left);
       }
-      nrm[e] = (v - (double)tp.mean[col]) * (double)tp.scale[col];
+      const double v2 = acc / (double)tp.norm2;
+      double *o = nrm + (size_t)lr * md + i;
+      o[0] = (v0 - (double)nmean[i]) * (double)nscale[i];
+      o[dx] = (v1 - (double)nmean[dx + i]) * (double)nscale[dx + i];
+      o[2 * dx] = (v2 - (double)nmean[2 * dx + i]) * (double)nscale[2 * dx + i];
     }
     __syncthreads();
     // LinTransformModule::generate (:1243-1269)
-    for (int e = threadIdx.x; e < n_seg * tp.dim; e += 256) {
-      const int lr = fast_div(e, dim_magic), i = e - lr * tp.dim;
-      const double *x = nrm + (size_t)lr * md;
-      double acc;
-      if (tp.matrix) {
-        const float *mr = ms + (size_t)i * mstride;
-        acc = 0;
-        for (int j = 0; j < md; j++) acc += (double)mr[j] * x[j];
-      } else {
-        acc = x[i];
+    if (tp.matrix) {
+      const int npair = (n_seg + 1) / 2;
+      for (int it = threadIdx.x; it < ngrp * npair; it += 256) {
+        const int rp = fast_div(it, ngrp_magic), g = it - rp * ngrp;
+        const int la = 2 * rp, lb = 2 * rp + 1 < n_seg ? 2 * rp + 1 : la;
+        const double *xa = nrm + (size_t)la * md, *xb = nrm + (size_t)lb * md;
+        const float4 *mg = mt + g;
+        double a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
+        if (!AASR_FDBG(1)) {
+#pragma unroll 3
+          for (int j = 0; j < md; j++) {
+            const float4 m = mg[j * ngrp];
+            const double va = xa[j], vb = xb[j];
+            const double m0 = (double)m.x, m1 = (double)m.y, m2 = (double)m.z;
+            a0 += m0 * va;
+            a1 += m1 * va;
+            a2 += m2 * va;
+            b0 += m0 * vb;
+            b1 += m1 * vb;
+            b2 += m2 * vb;
+          }
+        }
+        const int i0 = 3 * g;
+        if (tp.bias) {
+          const double c0 = (double)nbias[i0];
+          const double c1 = i0 + 1 < tp.dim ? (double)nbias[i0 + 1] : 0.0;
+          const double c2 = i0 + 2 < tp.dim ? (double)nbias[i0 + 2] : 0.0;
+          a0 += c0;
+          b0 += c0;
+          a1 += c1;
+          b1 += c1;
+          a2 += c2;
+          b2 += c2;
+        }
+        double *da = dst + (r0 + la) * tp.dim + i0;
+        da[0] = a0;
+        if (i0 + 1 < tp.dim) da[1] = a1;
+        if (i0 + 2 < tp.dim) da[2] = a2;
+        if (lb != la) {
+          double *db = dst + (r0 + lb) * tp.dim + i0;
+          db[0] = b0;
+          if (i0 + 1 < tp.dim) db[1] = b1;
+          if (i0 + 2 < tp.dim) db[2] = b2;
+        }
       }
-      if (tp.bias) acc += (double)tp.bias[i];
-      dst[(r0 + lr) * tp.dim + i] = acc;
+    } else {
+      for (int e = threadIdx.x; e < n_seg * tp.dim; e += 256) {
+        const int lr = fast_div(e, dim_magic), i = e - lr * tp.dim;
+        double acc = nrm[(size_t)lr * md + i];
+        if (tp.bias) acc += (double)nbias[i];
+        dst[(r0 + lr) * tp.dim + i] = acc;
+      }
     }
     __syncthreads();
     r0 = r_end;
@@ -945,7 +1000,7 @@ __global__ __launch_bounds__(256) void k_lin_transform_tiled(
 template <int ROWS, class OUT>
 __global__ __launch_bounds__(256) void k_mean_subtract_tiled(
     DevBatch b, const double *__restrict__ src, SrcMap sm, int span, int halo_left, int64_t rows, int dim,
-    int left, int right, OUT *__restrict__ dst) {
+    int left, int right, int dbg, OUT *__restrict__ dst) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double *xs = (double *)smem_raw;  // [ROWS + left + right][dim]
   // sums of 8 consecutive frames: a window of left+right+1 rows is then a few singles at its ends
@@ -969,14 +1024,14 @@ __global__ __launch_bounds__(256) void k_mean_subtract_tiled(
     const int64_t s0 = r0 + (int64_t)u * sm.span_diff + sm.shift;  // source row of r0
     const int n_seg = (int)(r_end - r0);
     const int n_src = n_seg + left + right;
-    for (int e = threadIdx.x; e < n_src * dim; e += 256) xs[e] = src[(s0 - left) * dim + e];
+    for (int e = threadIdx.x; e < (AASR_FDBG(4) ? 0 : n_src * dim); e += 256) xs[e] = src[(s0 - left) * dim + e];
     __syncthreads();
     // frame number of staged row 0, and the first staged row that starts a block
     const int64_t key_u = b.frame_off[u] + (int64_t)u * span;
     const int64_t abs0 = (int64_t)b.first[u] - halo_left + (r0 - key_u) - left;
     const int i0 = (int)(((-abs0) % 8 + 8) % 8);
     const int n_blk = n_src > i0 ? (n_src - i0) / 8 : 0;
-    for (int e = threadIdx.x; e < n_blk * dim; e += 256) {
+    for (int e = threadIdx.x; e < (AASR_FDBG(2) ? 0 : n_blk * dim); e += 256) {
       const int k = fast_div(e, dim_magic), d = e - k * dim;
       const double *c = xs + (size_t)(i0 + 8 * k) * dim + d;
       double t = 0;
@@ -993,7 +1048,8 @@ __global__ __launch_bounds__(256) void k_mean_subtract_tiled(
       int kb = b_end <= i0 ? 0 : (b_end - i0) / 8;
       if (kb > n_blk) kb = n_blk;
       double mean = 0;
-      if (ka >= kb) {
+      if (AASR_FDBG(1)) {
+      } else if (ka >= kb) {
         for (int i = a; i < b_end; i++) mean += xs[(size_t)i * dim + d];
       } else {
         for (int i = a; i < i0 + 8 * ka; i++) mean += xs[(size_t)i * dim + d];
@@ -1333,10 +1389,12 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
       constexpr int TR = kTemporalRows;
       const int H = tp.w1 + tp.w2;
       const size_t smem = (size_t)(TR + 2 * H) * tp.dx * 8 + (size_t)(TR + 2 * tp.w2) * tp.dx * 8 +
-                          (size_t)TR * 3 * tp.dx * 8 + (size_t)m.dim * ((3 * tp.dx) | 1) * 4;
+                          (size_t)TR * 3 * tp.dx * 8 + 16 + (size_t)(3 * tp.dx) * ((m.dim + 2) / 3) * 16 +
+                          (size_t)(6 * tp.dx + m.dim) * 4;
       h->bufs[i].ensure((size_t)rows * m.dim);
       hipLaunchKernelGGL(k_temporal_fused<TR>, dim3((unsigned)((rows + TR - 1) / TR)), dim3(256), smem, stream, db,
-                         (const double *)h->bufs[tgX].p, map_of(i, tgX), span, rows, tp, h->bufs[i].p);
+                         (const double *)h->bufs[tgX].p, map_of(i, tgX), span, rows, tp,
+                         getenv("AASR_TEMP_DBG") ? atoi(getenv("AASR_TEMP_DBG")) : 0, h->bufs[i].p);
       AASR_HIP(hipGetLastError());
       continue;
     }
@@ -1529,18 +1587,19 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
 #else
         constexpr int MS_ROWS = 64;
 #endif
+        const int ms_dbg = getenv("AASR_CMS_DBG") ? atoi(getenv("AASR_CMS_DBG")) : 0;
         const size_t ms_src = (size_t)(MS_ROWS + m.cms_left + m.cms_right);
         const size_t ms_smem = (ms_src + ms_src / 8 + 1) * m.dim * 8;
         if (ms_smem <= 60 * 1024 && i == target && g_feat_fusion && out_f32 && !out_f64) {
           // the output module: its rows are the caller's rows (no look-around of its own)
           hipLaunchKernelGGL((k_mean_subtract_tiled<MS_ROWS, float>), dim3((unsigned)((rows + MS_ROWS - 1) / MS_ROWS)),
                              dim3(256), ms_smem, stream, db, src, sm, span, L[i], rows, m.dim, m.cms_left,
-                             m.cms_right, out_f32);
+                             m.cms_right, ms_dbg, out_f32);
           emitted = true;
         } else if (ms_smem <= 60 * 1024)
           hipLaunchKernelGGL((k_mean_subtract_tiled<MS_ROWS, double>), dim3((unsigned)((rows + MS_ROWS - 1) / MS_ROWS)),
                              dim3(256), ms_smem, stream, db, src, sm, span, L[i], rows, m.dim, m.cms_left,
-                             m.cms_right, dst);
+                             m.cms_right, ms_dbg, dst);
         else
           hipLaunchKernelGGL(k_mean_subtract, dim3(grid_for(nelem)), dim3(256), 0, stream, db, src,
                              sm, span, rows, m.dim, m.cms_left, m.cms_right, dst);
