@@ -54,6 +54,9 @@ struct FftPlan {
   DevBuf<int32_t> perm;    // [nc] digit-reversed source index
 };
 
+// rows before a mean subtractor's window that its kernel reads: the window sum is anchored on absolute multiples of 8
+constexpr int kCmsLead = 7;
+
 struct FeatModule {
   std::string name, type_str;
   ModType type;
@@ -117,6 +120,7 @@ struct FeatModule {
   std::vector<std::string> opt_names, opt_values;
   // look-around this module itself adds around its sources
   int own_left = 0, own_right = 0;
+  int lead_left = 0;   // rows of left look-around the module's kernel wants beyond own_left (mean subtractor: kCmsLead)
 };
 
 // aasr_feat_register_module_type: the callbacks of one user module type (see include/aasr.h)

@@ -647,6 +647,7 @@ static void configure(aasr_feat *h, FeatModule &m, const ModuleConfig &c) {
         raise(AASR_ERR_INVALID, "MeanSubtractorModule: context widths must be >= 0");
       m.own_left = m.cms_left;
       m.own_right = m.cms_right;
+      m.lead_left = kCmsLead;
       break;
     }
     case MOD_CONCAT: {
@@ -896,7 +897,7 @@ void feat_halo(const aasr_feat *h, int target, int *left, int *right) {
     if (L[i] < 0) continue;
     const FeatModule &m = h->mods[i];
     for (int s : m.sources) {
-      L[s] = std::max(L[s], L[i] + m.own_left);
+      L[s] = std::max(L[s], L[i] + m.own_left + m.lead_left);
       R[s] = std::max(R[s], R[i] + m.own_right);
     }
   }

@@ -993,23 +993,27 @@ __global__ __launch_bounds__(256) void k_lin_transform_tiled(
   }
 }
 
-// MeanSubtractorModule, tiled: the block's rows plus the window look-around are
-// staged in LDS once; each thread sums its window in frame order.
+// MeanSubtractorModule, tiled: the block's rows plus the window look-around are staged in LDS once.
 // OUT = float: the module is the graph's output and writes the caller's float rows itself (no
 // separate narrowing pass).
+// A window sum is formed in full only at frames whose ABSOLUTE number (within the utterance) is a multiple of 8 -- from
+// single rows at its two ends and sums of 8 consecutive rows (blocks on absolute multiples of 8 too) in between -- and
+// slid from there: S(t+1) = (S(t) + x[t+1+right]) - x[t-left].  Every value is a function of the frame's absolute
+// number alone, not of how the frame range was tiled or batched; the additions are grouped differently from the
+// reference's frame-order loop (1e-15 relative, in double, below the float output's rounding).  The source provides
+// kCmsLead rows more of left look-around so that the anchor of an utterance chunk's first frames has its window.
+// (One LDS read per row of the window stood behind every output value: 151 reads, then ~21 with the block sums --
+// 87 us of the kernel's 195; anchor + slide is 42 reads per 8 values.)
 template <int ROWS, class OUT>
 __global__ __launch_bounds__(256) void k_mean_subtract_tiled(
     DevBatch b, const double *__restrict__ src, SrcMap sm, int span, int halo_left, int64_t rows, int dim,
     int left, int right, int dbg, OUT *__restrict__ dst) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double *xs = (double *)smem_raw;  // [ROWS + left + right][dim]
-  // sums of 8 consecutive frames: a window of left+right+1 rows is then a few singles at its ends
-  // plus whole blocks (151 LDS reads per value became ~30; the kernel was LDS-bandwidth bound).
-  // The blocks sit on ABSOLUTE frame numbers (multiples of 8 within the utterance), so a frame's
-  // value does not depend on how the frame range was tiled or batched; the additions are grouped
-  // differently from the frame-order loop (1e-16 relative).
-  double *bs = xs + (size_t)(ROWS + left + right) * dim;  // [(ROWS + left + right) / 8 + 1][dim]
+  constexpr int LEAD = kCmsLead;
+  double *xs = (double *)smem_raw;  // [ROWS + LEAD + left + right][dim]
+  double *bs = xs + (size_t)(ROWS + LEAD + left + right) * dim;  // [(ROWS + LEAD + left + right) / 8 + 1][dim]
   const unsigned dim_magic = fast_magic(dim);              // element indices stay below 65536 (LDS-sized tiles)
+  const int W = left + right + 1;
   const int64_t tile0 = (int64_t)blockIdx.x * ROWS;
   const int64_t tile1 = tile0 + ROWS < rows ? tile0 + ROWS : rows;
   // A tile may straddle utterances: source rows of consecutive module rows are
@@ -1023,13 +1027,13 @@ __global__ __launch_bounds__(256) void k_mean_subtract_tiled(
     const int64_t r_end = u_end < tile1 ? u_end : tile1;
     const int64_t s0 = r0 + (int64_t)u * sm.span_diff + sm.shift;  // source row of r0
     const int n_seg = (int)(r_end - r0);
-    const int n_src = n_seg + left + right;
-    for (int e = threadIdx.x; e < (AASR_FDBG(4) ? 0 : n_src * dim); e += 256) xs[e] = src[(s0 - left) * dim + e];
+    const int n_src = n_seg + LEAD + left + right;
+    for (int e = threadIdx.x; e < (AASR_FDBG(4) ? 0 : n_src * dim); e += 256) xs[e] = src[(s0 - left - LEAD) * dim + e];
     __syncthreads();
-    // frame number of staged row 0, and the first staged row that starts a block
+    // absolute frame number of output row 0 of the segment; staged row 0 is frame absf0 - left - LEAD
     const int64_t key_u = b.frame_off[u] + (int64_t)u * span;
-    const int64_t abs0 = (int64_t)b.first[u] - halo_left + (r0 - key_u) - left;
-    const int i0 = (int)(((-abs0) % 8 + 8) % 8);
+    const int64_t absf0 = (int64_t)b.first[u] - halo_left + (r0 - key_u);
+    const int i0 = (int)(((-(absf0 - left - LEAD)) % 8 + 8) % 8);   // first staged row that starts a block
     const int n_blk = n_src > i0 ? (n_src - i0) / 8 : 0;
     for (int e = threadIdx.x; e < (AASR_FDBG(2) ? 0 : n_blk * dim); e += 256) {
       const int k = fast_div(e, dim_magic), d = e - k * dim;
@@ -1040,24 +1044,35 @@ __global__ __launch_bounds__(256) void k_mean_subtract_tiled(
       bs[e] = t;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < n_seg * dim; e += 256) {
-      const int lr = fast_div(e, dim_magic), d = e - lr * dim;
-      // staged rows [lr, lr + left + right] are this value's window
-      const int a = lr, b_end = lr + left + right + 1;
+    // chunks of 8 output rows on absolute multiples of 8: chunk k holds segment rows 8k - off .. 8k - off + 7
+    const int off = (int)((absf0 % 8 + 8) % 8);
+    const int n_chunk = (n_seg + off + 7) / 8;
+    for (int e = threadIdx.x; e < n_chunk * dim; e += 256) {
+      const int k = fast_div(e, dim_magic), d = e - k * dim;
+      const int la = 8 * k - off;                 // the anchor's segment row (>= -7)
+      // staged rows [a, b_end) are the anchor's window
+      const int a = la + LEAD, b_end = a + W;
       int ka = a <= i0 ? 0 : (a - i0 + 7) / 8;      // whole blocks [ka, kb): staged rows i0 + 8k ...
       int kb = b_end <= i0 ? 0 : (b_end - i0) / 8;
       if (kb > n_blk) kb = n_blk;
-      double mean = 0;
+      double sum = 0;
       if (AASR_FDBG(1)) {
       } else if (ka >= kb) {
-        for (int i = a; i < b_end; i++) mean += xs[(size_t)i * dim + d];
+        for (int i = a; i < b_end; i++) sum += xs[(size_t)i * dim + d];
       } else {
-        for (int i = a; i < i0 + 8 * ka; i++) mean += xs[(size_t)i * dim + d];
-        for (int k = ka; k < kb; k++) mean += bs[(size_t)k * dim + d];
-        for (int i = i0 + 8 * kb; i < b_end; i++) mean += xs[(size_t)i * dim + d];
+        for (int i = a; i < i0 + 8 * ka; i++) sum += xs[(size_t)i * dim + d];
+        for (int kk = ka; kk < kb; kk++) sum += bs[(size_t)kk * dim + d];
+        for (int i = i0 + 8 * kb; i < b_end; i++) sum += xs[(size_t)i * dim + d];
       }
-      mean /= (left + right + 1);
-      dst[(r0 + lr) * dim + d] = (OUT)(xs[(size_t)(lr + left) * dim + d] - mean);
+      const int l_end = la + 8 < n_seg ? la + 8 : n_seg;
+      for (int lr = la; lr < l_end; lr++) {
+        if (lr >= 0) {
+          const double mean = sum / W;
+          dst[(r0 + lr) * dim + d] = (OUT)(xs[(size_t)(lr + LEAD + left) * dim + d] - mean);
+        }
+        if (lr + 1 < l_end && !AASR_FDBG(1))
+          sum = (sum + xs[(size_t)(lr + LEAD + W) * dim + d]) - xs[(size_t)(lr + LEAD) * dim + d];
+      }
     }
     __syncthreads();
     r0 = r_end;
@@ -1207,7 +1222,7 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
     if (L[i] < 0) continue;
     const FeatModule &m = h->mods[i];
     for (int s : m.sources) {
-      L[s] = std::max(L[s], L[i] + m.own_left);
+      L[s] = std::max(L[s], L[i] + m.own_left + m.lead_left);
       R[s] = std::max(R[s], R[i] + m.own_right);
       consumers[s]++;
     }
@@ -1588,7 +1603,7 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
         constexpr int MS_ROWS = 64;
 #endif
         const int ms_dbg = getenv("AASR_CMS_DBG") ? atoi(getenv("AASR_CMS_DBG")) : 0;
-        const size_t ms_src = (size_t)(MS_ROWS + m.cms_left + m.cms_right);
+        const size_t ms_src = (size_t)(MS_ROWS + kCmsLead + m.cms_left + m.cms_right);
         const size_t ms_smem = (ms_src + ms_src / 8 + 1) * m.dim * 8;
         if (ms_smem <= 60 * 1024 && i == target && g_feat_fusion && out_f32 && !out_f64) {
           // the output module: its rows are the caller's rows (no look-around of its own)

@@ -73,7 +73,9 @@ int aasr_feat_sample_rate(const aasr_feat *h);
 int aasr_feat_module_dim(const aasr_feat *h, const char *module_name);
 /* base-module frames of look-around one output frame needs (left, right):
  * the sum of DeltaModule / MeanSubtractorModule offsets along the graph
- * (aku/FeatureModules.cc:1014-1015, 1390-1400) */
+ * (aku/FeatureModules.cc:1014-1015, 1390-1400), plus 7 frames on the left per
+ * mean subtractor: its kernel anchors the window sum on frame numbers that are
+ * multiples of 8 and slides it from there, so it reads up to 7 rows before the window */
 void aasr_feat_halo(const aasr_feat *h, int *left, int *right);
 
 /* AudioFileModule::last_frame (aku/FeatureModules.cc:305-308) for a file of

@@ -67,7 +67,8 @@ def test_synthetic_audio_and_float_output(capi, oracle, golden_dir):
     ch = oracle.FeatureChain(cfg)
     ft = capi.Feat(cfg)
     n = ft.last_frame(len(pcm)) + 1
-    assert n == 623 and ft.halo() == (55, 30)
+    # the graph's look-around (55, 30) + the 7 rows the mean subtractor's kernel reads before its window (kCmsLead)
+    assert n == 623 and ft.halo() == (55 + 7, 30) and ch.halo() == (55, 30)
     want = ch.generate(pcm, 0, n)
     got64 = ft.run(pcm, 0, n, dtype=np.float64)
     got32 = ft.run(pcm, 0, n)
