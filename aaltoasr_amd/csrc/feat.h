@@ -140,8 +140,9 @@ struct aasr_feat {
   std::map<std::string, int> by_name;
   // scratch, grown on demand
   std::vector<aasr::DevBuf<double>> bufs;  // one per module
-  aasr::DevBuf<int64_t> d_frame_off, d_pcm_off, d_nsamp;
-  aasr::DevBuf<int32_t> d_first, d_eof;
+  // batch descriptors, one device block in the layout of the pinned staging block (one upload per call, not four):
+  // frame_off[n + 1], pcm_off[n + 1] (int64), first[n], eof[n] (int32)
+  aasr::DevBuf<char> d_desc;
   aasr::DevBuf<int16_t> d_pcm;
   aasr::DevBuf<float> d_out_f32;
   aasr::DevBuf<double> d_out_f64;

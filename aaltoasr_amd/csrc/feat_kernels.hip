@@ -49,6 +49,35 @@ __device__ __forceinline__ int find_utt(const DevBatch &b, int64_t r, int span) 
   return lo;
 }
 
+// The same for a workgroup's first row (r uniform: the loads are scalar): the bisection is nine DEPENDENT loads at 360
+// utterances, 16 us of k_temporal_fused's 165.  First guess = utterances of equal length (the usual shape of a
+// batch), corrected by a walk of at most three; the bisection finishes on what the walk left when lengths differ a lot.
+__device__ __forceinline__ int find_utt_near(const DevBatch &b, int64_t r, int span, int64_t rows) {
+  const int n = b.n_utts;
+  int u = (int)((float)r * (float)n / (float)rows);
+  u = u < 0 ? 0 : (u > n - 1 ? n - 1 : u);
+  int lo = 0, hi = n - 1;
+  for (int step = 0; step < 3; step++) {
+    const int64_t k0 = b.frame_off[u] + (int64_t)u * span;
+    const int64_t k1 = b.frame_off[u + 1] + (int64_t)(u + 1) * span;
+    if (k0 > r && u > 0) {
+      hi = u - 1;
+      u--;
+    } else if (k1 <= r && u < n - 1) {
+      lo = u + 1;
+      u++;
+    } else {
+      return u;
+    }
+  }
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    int64_t key = b.frame_off[mid] + (int64_t)mid * span;
+    if (key <= r) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
 // translation of a module row to its source's row (same frame)
 struct SrcMap {
   int span_diff;  // (Ls+Rs) - (L+R)
@@ -526,7 +555,7 @@ __global__ __launch_bounds__(256) void k_spectral_fused(DevBatch b, const int16_
       if (AASR_FDBG(1)) {
         u = 0;
       } else if (u_cur < 0) {
-        u = find_utt(b, r, L + R);  // nine dependent loads: only in the first pass
+        u = find_utt_near(b, r, L + R, rows);  // only in the first pass
       } else {
         u = u_cur;
         while (u + 1 < b.n_utts && b.frame_off[u + 1] + (int64_t)(u + 1) * (L + R) <= r) u++;
@@ -733,13 +762,13 @@ __global__ __launch_bounds__(256) void k_temporal_fused(DevBatch b, const double
   const int64_t tile1 = tile0 + ROWS < rows ? tile0 + ROWS : rows;
   int64_t r0 = tile0;
   while (r0 < tile1) {  // one utterance segment at a time (see k_mean_subtract_tiled)
-    const int u = find_utt(b, r0, span);
-    const int64_t u_end = b.frame_off[u + 1] + (int64_t)(u + 1) * span;
+    const int u = AASR_FDBG(64) ? 0 : find_utt_near(b, r0, span, rows);
+    const int64_t u_end = AASR_FDBG(64) ? rows : b.frame_off[u + 1] + (int64_t)(u + 1) * span;
     const int64_t r_end = u_end < tile1 ? u_end : tile1;
     const int64_t s0 = r0 + (int64_t)u * sm.span_diff + sm.shift;  // source row of r0
     const int n_seg = (int)(r_end - r0);
     const int n_x = n_seg + 2 * H, n_d1 = n_seg + 2 * tp.w2;
-    for (int e = threadIdx.x; e < n_x * dx; e += 256) xs[e] = src[(s0 - H) * dx + e];
+    for (int e = threadIdx.x; e < (AASR_FDBG(16) ? 0 : n_x * dx); e += 256) xs[e] = src[(s0 - H) * dx + e];
     __syncthreads();
     // DeltaModule::generate (aku/FeatureModules.cc:1018-1037) on the source rows
     for (int e = threadIdx.x; e < (AASR_FDBG(4) ? 0 : n_d1 * dx); e += 256) {
@@ -809,6 +838,7 @@ __global__ __launch_bounds__(256) void k_temporal_fused(DevBatch b, const double
           a2 += c2;
           b2 += c2;
         }
+        if (AASR_FDBG(32) && a0 != 12345.0) continue;
         double *da = dst + (r0 + la) * tp.dim + i0;
         da[0] = a0;
         if (i0 + 1 < tp.dim) da[1] = a1;
@@ -1022,7 +1052,7 @@ __global__ __launch_bounds__(256) void k_mean_subtract_tiled(
   // key(u) = frame_off[u] + u*span).
   int64_t r0 = tile0;
   while (r0 < tile1) {
-    const int u = find_utt(b, r0, span);
+    const int u = find_utt_near(b, r0, span, rows);
     const int64_t u_end = b.frame_off[u + 1] + (int64_t)(u + 1) * span;
     const int64_t r_end = u_end < tile1 ? u_end : tile1;
     const int64_t s0 = r0 + (int64_t)u * sm.span_diff + sm.shift;  // source row of r0
@@ -1245,10 +1275,6 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
     eof[u] = feat_eof_frame(h, ns);
     if (eof[u] < 1) raise(AASR_ERR_SHORT_AUDIO, "audio shorter than frame");
   }
-  h->d_frame_off.ensure(n + 1);
-  h->d_pcm_off.ensure(n + 1);
-  h->d_first.ensure(n);
-  h->d_eof.ensure(n);
   // descriptors travel through a pinned staging block owned by the handle; an
   // event guards its reuse so calls can be enqueued back to back
   const size_t stage_bytes = (size_t)(n + 1) * 16 + (size_t)n * 8;
@@ -1273,14 +1299,14 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
     memcpy(s_po, ub.pcm_off.data(), (n + 1) * sizeof(int64_t));
     memcpy(s_first, ub.first.data(), n * sizeof(int32_t));
     memcpy(s_eof, eof.data(), n * sizeof(int32_t));
-    AASR_HIP(hipMemcpyAsync(h->d_frame_off.p, s_fo, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
-    AASR_HIP(hipMemcpyAsync(h->d_pcm_off.p, s_po, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
-    AASR_HIP(hipMemcpyAsync(h->d_first.p, s_first, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    AASR_HIP(hipMemcpyAsync(h->d_eof.p, s_eof, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    h->d_desc.ensure(stage_bytes);
+    AASR_HIP(hipMemcpyAsync(h->d_desc.p, sp, stage_bytes, hipMemcpyHostToDevice, stream));
     AASR_HIP(hipEventRecord(h->stage_event, stream));
     h->stage_busy = true;
   }
-  DevBatch db{n, h->d_frame_off.p, h->d_pcm_off.p, h->d_first.p, h->d_eof.p};
+  const int64_t *d_fo = (const int64_t *)h->d_desc.p;
+  const int32_t *d_first = (const int32_t *)(d_fo + 2 * (size_t)(n + 1));
+  DevBatch db{n, d_fo, d_fo + (n + 1), d_first, d_first + n};
   AudioPrm ap{base.width, base.advance, base.emph, base.copy_borders};
 
   // ---- fusion plan -------------------------------------------------------------------------

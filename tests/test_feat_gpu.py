@@ -107,6 +107,28 @@ def test_batch_equals_per_utterance(capi, golden_dir):
         assert np.array_equal(got[a:b], ft.run(u, 0, int(b - a)))
 
 
+def test_batch_of_very_unequal_utterances(capi, golden_dir):
+    """The kernels find a workgroup's utterance from an equal-length first guess + a short walk, a bisection when that
+    fails (find_utt_near): one long utterance among many short ones, at either end, puts most workgroups on the
+    bisection."""
+    import torch
+    ft = capi.Feat(_cfg(golden_dir, "mfcc_cms_norm"))
+    short = [synth.make_audio(1200 + 37 * i, seed=100 + i) for i in range(40)]
+    long_one = synth.make_audio(160000, seed=99)
+    for utts in ([long_one] + short, short + [long_one], short[:20] + [long_one] + short[20:]):
+        frames = [ft.last_frame(len(u)) + 1 for u in utts]
+        pcm_off = np.concatenate([[0], np.cumsum([len(u) for u in utts])])
+        frame_off = np.concatenate([[0], np.cumsum(frames)])
+        d_pcm = torch.from_numpy(np.concatenate(utts)).cuda()
+        d_out = torch.empty((int(frame_off[-1]), 39), dtype=torch.float32, device="cuda")
+        ft.run_batch_dev(d_pcm, pcm_off, frame_off, d_out)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        for k in (0, 1, 19, 20, 21, 39, 40):
+            a, b = int(frame_off[k]), int(frame_off[k + 1])
+            assert np.array_equal(got[a:b], ft.run(utts[k], 0, b - a)), k
+
+
 def test_options_copy_borders_window_magnitude(capi, oracle):
     cfg = """module
 {
