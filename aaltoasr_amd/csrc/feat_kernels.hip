@@ -170,6 +170,35 @@ __device__ __forceinline__ cpx cmul(cpx a, cpx b) {
   return m;
 }
 
+// kf_bfly2 / kf_bfly4 on values (vendor/kiss_fft/kiss_fft.c:21-90): shared by the LDS stages below and by the two
+// stages k_spectral_fused runs in registers, so both perform the same operations in the same order
+__device__ __forceinline__ void bfly2_values(cpx &f0, cpx &f1, cpx w) {
+  const cpx t = cmul(f1, w);
+  cpx o1;
+  o1.r = f0.r - t.r;
+  o1.i = f0.i - t.i;
+  f0.r += t.r;
+  f0.i += t.i;
+  f1 = o1;
+}
+__device__ __forceinline__ void bfly4_values(cpx &f0, cpx &f1, cpx &f2, cpx &f3, cpx w1, cpx w2, cpx w3) {
+  const cpx s0 = cmul(f1, w1);
+  const cpx s1 = cmul(f2, w2);
+  const cpx s2 = cmul(f3, w3);
+  cpx s3, s4, s5, o1, o2, o3;
+  s5.r = f0.r - s1.r;  s5.i = f0.i - s1.i;
+  f0.r += s1.r;        f0.i += s1.i;
+  s3.r = s0.r + s2.r;  s3.i = s0.i + s2.i;
+  s4.r = s0.r - s2.r;  s4.i = s0.i - s2.i;
+  o2.r = f0.r - s3.r;  o2.i = f0.i - s3.i;
+  f0.r += s3.r;        f0.i += s3.i;
+  o1.r = s5.r + s4.i;  o1.i = s5.i - s4.r;
+  o3.r = s5.r - s4.i;  o3.i = s5.i + s4.r;
+  f1 = o1;
+  f2 = o2;
+  f3 = o3;
+}
+
 // One butterfly of KissFFT's decimation-in-time stage (vendor/kiss_fft/kiss_fft.c:21-198, radices 2,
 // 3, 4, 5): butterfly index bi of the stage with radix pr and sub-length m, in place in buf.
 __device__ __forceinline__ void kiss_butterfly(cpx *buf, int bi, int pr, int m, unsigned m_magic, int fstride,
@@ -177,14 +206,9 @@ __device__ __forceinline__ void kiss_butterfly(cpx *buf, int bi, int pr, int m, 
     int g = fast_div(bi, m_magic), j = bi - g * m;
     cpx *F = buf + g * pr * m;
     if (pr == 2) {
-      cpx t = cmul(F[m + j], tw[j * fstride]);
-      cpx f0 = F[j];
-      cpx o1;
-      o1.r = f0.r - t.r;
-      o1.i = f0.i - t.i;
-      f0.r += t.r;
-      f0.i += t.i;
-      F[m + j] = o1;
+      cpx f0 = F[j], f1 = F[m + j];
+      bfly2_values(f0, f1, tw[j * fstride]);
+      F[m + j] = f1;
       F[j] = f0;
     } else if (pr == 3) {
       // kf_bfly3 (vendor/kiss_fft/kiss_fft.c:92-135); HALF_OF(x) = x*.5 in double
@@ -240,22 +264,12 @@ __device__ __forceinline__ void kiss_butterfly(cpx *buf, int bi, int pr, int m, 
       F[3 * m + j] = o3;
       F[4 * m + j] = o4;
     } else {
-      cpx s0 = cmul(F[m + j], tw[j * fstride]);
-      cpx s1 = cmul(F[2 * m + j], tw[2 * j * fstride]);
-      cpx s2 = cmul(F[3 * m + j], tw[3 * j * fstride]);
-      cpx f0 = F[j], s3, s4, s5, o1, o2, o3;
-      s5.r = f0.r - s1.r;  s5.i = f0.i - s1.i;
-      f0.r += s1.r;        f0.i += s1.i;
-      s3.r = s0.r + s2.r;  s3.i = s0.i + s2.i;
-      s4.r = s0.r - s2.r;  s4.i = s0.i - s2.i;
-      o2.r = f0.r - s3.r;  o2.i = f0.i - s3.i;
-      f0.r += s3.r;        f0.i += s3.i;
-      o1.r = s5.r + s4.i;  o1.i = s5.i - s4.r;
-      o3.r = s5.r - s4.i;  o3.i = s5.i + s4.r;
+      cpx f0 = F[j], f1 = F[m + j], f2 = F[2 * m + j], f3 = F[3 * m + j];
+      bfly4_values(f0, f1, f2, f3, tw[j * fstride], tw[2 * j * fstride], tw[3 * j * fstride]);
       F[j] = f0;
-      F[m + j] = o1;
-      F[2 * m + j] = o2;
-      F[3 * m + j] = o3;
+      F[m + j] = f1;
+      F[2 * m + j] = f2;
+      F[3 * m + j] = f3;
     }
 }
 
@@ -503,7 +517,6 @@ __global__ __launch_bounds__(256) void k_spectral_fused(DevBatch b, const int16_
   const SpectralLds lds(nc, sp.mel_dim, sp.mel_terms, dct_rows);
   cpx *bufs = (cpx *)(smem_raw + lds.bufs);
   double *melv = (double *)(smem_raw + lds.melv);
-  double *powv = (double *)(smem_raw + lds.powv);
   float *t_ham = (float *)(smem_raw + lds.ham);
   int32_t *t_perm = (int32_t *)(smem_raw + lds.perm);
   cpx *t_tw = (cpx *)(smem_raw + lds.tw);
@@ -577,7 +590,7 @@ __global__ __launch_bounds__(256) void k_spectral_fused(DevBatch b, const int16_
       const int64_t ws = s_prm[3 * f], ns = s_prm[3 * f + 2];
       const int16_t *p = pcm + s_prm[3 * f + 1];
       const bool inside = ws >= 0 && ws + 2 * nc < ns;   // uniform over the frame's 16 lanes
-      for (int o = l; o < ((AASR_FDBG(32) || AASR_FDBG(8)) ? 0 : nc); o += TPF) {
+      auto point = [&](int o) {
         const int s = t_perm[o];
         float c0, c1, c2;
         if (inside) {
@@ -597,8 +610,9 @@ __global__ __launch_bounds__(256) void k_spectral_fused(DevBatch b, const int16_
         cpx v;
         v.r = (float)((double)t_ham[2 * s] * x0);
         v.i = (float)((double)t_ham[2 * s + 1] * x1);
-        buf[o] = v;
-      }
+        return v;
+      };
+      for (int o = l; o < ((AASR_FDBG(32) || AASR_FDBG(8)) ? 0 : nc); o += TPF) buf[o] = point(o);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -623,10 +637,33 @@ __global__ __launch_bounds__(256) void k_spectral_fused(DevBatch b, const int16_
         spec[nc - k] = spec_value(re_n, im_n, sp.fp.magnitude, sp.fp.take_log);
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // MelModule::generate (aku/FeatureModules.cc:805-849): one bin per thread and round; the last
-    // thread of the frame also carries PowerModule's left-to-right float sum (:874-885)
+    // PowerModule's left-to-right float sum (aku/FeatureModules.cc:874-885) is a chain of 129 dependent additions per
+    // frame.  One wave forms it for all 16 frames of the pass, a frame per lane (the waves take turns): carried by the
+    // last lane of every frame it cost each of the four waves the same ~260 instructions with 4 lanes active -- 13 % of
+    // this VALU-bound kernel (rocprofv3: vector unit busy 71 % of the cycles, 65 % of the lanes on average).  The
+    // barrier makes every frame's spectrum visible; the next pass's first barrier keeps it until the sums are done.
+    __syncthreads();
+    if ((tid >> 6) == (pass & 3) && (tid & 63) < FB && !AASR_FDBG(16)) {
+      const int ff = tid & 63;
+      const float *sf = (const float *)(smem_raw + lds.frame_u + (size_t)ff * lds.frame_u_stride);
+      float power = 0;
+      int i = 0;
+      for (; i + 8 <= nbins; i += 8) {  // eight reads in flight, the additions in order
+        const float v0 = sf[i], v1 = sf[i + 1], v2 = sf[i + 2], v3 = sf[i + 3];
+        const float v4 = sf[i + 4], v5 = sf[i + 5], v6 = sf[i + 6], v7 = sf[i + 7];
+        power = power + v0;
+        power = power + v1;
+        power = power + v2;
+        power = power + v3;
+        power = power + v4;
+        power = power + v5;
+        power = power + v6;
+        power = power + v7;
+      }
+      for (; i < nbins; i++) power = power + sf[i];
+      if (r0 + ff < rows && !AASR_FDBG(128)) dst[(r0 + ff) * out_dim + sp.dct_dim] = log((double)power + 1e-10);
+    }
+    // MelModule::generate (aku/FeatureModules.cc:805-849): one bin per thread and round
     for (int slot = l; slot < (AASR_FDBG(4) ? 0 : sp.mel_dim); slot += TPF) {
       const int bin = t_mord[slot];   // by falling term count: a round lasts as long as its longest bin
       float val = 0;
@@ -655,42 +692,19 @@ __global__ __launch_bounds__(256) void k_spectral_fused(DevBatch b, const int16_
       }
       melv[(size_t)f * sp.mel_dim + bin] = o;
     }
-    if (l == TPF - 1 && !AASR_FDBG(16)) {
-      float power = 0;
-      int i = 0;
-      for (; i + 8 <= nbins; i += 8) {  // eight reads in flight, the additions in order
-        const float v0 = spec[i], v1 = spec[i + 1], v2 = spec[i + 2], v3 = spec[i + 3];
-        const float v4 = spec[i + 4], v5 = spec[i + 5], v6 = spec[i + 6], v7 = spec[i + 7];
-        power = power + v0;
-        power = power + v1;
-        power = power + v2;
-        power = power + v3;
-        power = power + v4;
-        power = power + v5;
-        power = power + v6;
-        power = power + v7;
-      }
-      for (; i < nbins; i++) power = power + spec[i];
-      powv[f] = log((double)power + 1e-10);
-    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // DCTModule::generate (:955-979) into the merged row [cepstra..., log power]
     if (r0 + f < rows && !AASR_FDBG(128)) {
       const double *data = melv + (size_t)f * sp.mel_dim;
-      for (int i = l; i < out_dim; i += TPF) {
-        double acc;
-        if (i == sp.dct_dim) {
-          acc = powv[f];
+      for (int i = l; i < sp.dct_dim; i += TPF) {   // column dct_dim (the log power) is written by the summing wave
+        double acc = 0.0;
+        if (sp.zeroth && i == 0) {
+          for (int k = 0; k < sp.mel_dim; k++) acc += data[k];
         } else {
-          acc = 0.0;
-          if (sp.zeroth && i == 0) {
-            for (int k = 0; k < sp.mel_dim; k++) acc += data[k];
-          } else {
-            const float *c = t_dct + (size_t)(i - (sp.zeroth ? 1 : 0)) * sp.mel_dim;
+          const float *c = t_dct + (size_t)(i - (sp.zeroth ? 1 : 0)) * sp.mel_dim;
 #pragma unroll 4
-            for (int k = 0; k < sp.mel_dim; k++) acc += data[k] * (double)c[k];
-          }
+          for (int k = 0; k < sp.mel_dim; k++) acc += data[k] * (double)c[k];
         }
         dst[(r0 + f) * out_dim + i] = acc;
       }
