@@ -473,6 +473,9 @@ struct SpectralPrm {
   const float *dct_cos;
 };
 
+// the float tables stay floats in LDS: staged as doubles (no conversion per use) the kernel ran 6 % SLOWER (measured:
+// 510 -> 540 us; the extra 4 KB per workgroup cost more than ~80 conversions per pass saved)
+typedef float spec_tbl_t;
 // LDS plan shared by the host (size) and the kernel (offsets), in bytes
 struct SpectralLds {
   size_t bufs, frame_u, melv, powv, ham, perm, tw, stw, moff, mt, msc, msum, mord, dct, prm, total;
@@ -490,17 +493,17 @@ struct SpectralLds {
     frame_u_stride |= 4;  // not a multiple of 8 bytes: rows of different frames start on different banks
     frame_u = take((size_t)SPEC_FRAMES * frame_u_stride);
     melv = take((size_t)SPEC_FRAMES * mel_dim * 8);
-    powv = take((size_t)SPEC_FRAMES * 8);
-    ham = take((size_t)2 * nc * 4);
+    powv = 0;
+    ham = take((size_t)2 * nc * sizeof(spec_tbl_t));
     perm = take((size_t)nc * 4);
     tw = take((size_t)nc * 8);
     stw = take((size_t)(nc / 2 + 1) * 8);
     moff = take((size_t)(mel_dim + 1) * 4);
     mt = take((size_t)mel_terms * 4);
-    msc = take((size_t)mel_terms * 4);
+    msc = take((size_t)mel_terms * sizeof(spec_tbl_t));
     msum = take((size_t)mel_dim * 4);
     mord = take((size_t)mel_dim * 4);
-    dct = take((size_t)dct_rows * mel_dim * 4);
+    dct = take((size_t)dct_rows * mel_dim * sizeof(spec_tbl_t));
     prm = take((size_t)SPEC_FRAMES * 3 * 8);
     total = o;
   }
@@ -517,23 +520,23 @@ __global__ __launch_bounds__(256) void k_spectral_fused(DevBatch b, const int16_
   const SpectralLds lds(nc, sp.mel_dim, sp.mel_terms, dct_rows);
   cpx *bufs = (cpx *)(smem_raw + lds.bufs);
   double *melv = (double *)(smem_raw + lds.melv);
-  float *t_ham = (float *)(smem_raw + lds.ham);
+  spec_tbl_t *t_ham = (spec_tbl_t *)(smem_raw + lds.ham);
   int32_t *t_perm = (int32_t *)(smem_raw + lds.perm);
   cpx *t_tw = (cpx *)(smem_raw + lds.tw);
   cpx *t_stw = (cpx *)(smem_raw + lds.stw);
   int32_t *t_moff = (int32_t *)(smem_raw + lds.moff);
   int32_t *t_mt = (int32_t *)(smem_raw + lds.mt);
-  float *t_msc = (float *)(smem_raw + lds.msc);
+  spec_tbl_t *t_msc = (spec_tbl_t *)(smem_raw + lds.msc);
   float *t_msum = (float *)(smem_raw + lds.msum);
   int32_t *t_mord = (int32_t *)(smem_raw + lds.mord);
-  float *t_dct = (float *)(smem_raw + lds.dct);
+  spec_tbl_t *t_dct = (spec_tbl_t *)(smem_raw + lds.dct);
   int64_t *s_prm = (int64_t *)(smem_raw + lds.prm);  // [FB][3]: window start, utterance offset, samples
   const int tid = threadIdx.x;
   const int f = tid / TPF, l = tid - f * TPF;
 
   // tables: once per workgroup (every later access is an LDS read; the loads of the FFT, mel and
   // DCT stages used to wait on global memory one after another)
-  for (int i = tid; i < 2 * nc; i += 256) t_ham[i] = sp.fp.hamming[i];
+  for (int i = tid; i < 2 * nc; i += 256) t_ham[i] = (spec_tbl_t)sp.fp.hamming[i];
   for (int i = tid; i < nc; i += 256) {
     t_perm[i] = sp.fp.perm[i];
     t_tw[i] = ((const cpx *)sp.fp.twiddle)[i];
@@ -542,13 +545,13 @@ __global__ __launch_bounds__(256) void k_spectral_fused(DevBatch b, const int16_
   for (int i = tid; i <= sp.mel_dim; i += 256) t_moff[i] = sp.mel_off[i];
   for (int i = tid; i < sp.mel_terms; i += 256) {
     t_mt[i] = sp.mel_t[i];
-    t_msc[i] = sp.mel_scale[i];
+    t_msc[i] = (spec_tbl_t)sp.mel_scale[i];
   }
   for (int i = tid; i < sp.mel_dim; i += 256) {
     t_msum[i] = sp.mel_sum[i];
     t_mord[i] = sp.mel_order[i];
   }
-  for (int i = tid; i < dct_rows * sp.mel_dim; i += 256) t_dct[i] = sp.dct_cos[i];
+  for (int i = tid; i < dct_rows * sp.mel_dim; i += 256) t_dct[i] = (spec_tbl_t)sp.dct_cos[i];
 
   cpx *buf = bufs + (size_t)f * nc;
   char *fu = smem_raw + lds.frame_u + (size_t)f * lds.frame_u_stride;
@@ -625,17 +628,18 @@ __global__ __launch_bounds__(256) void k_spectral_fused(DevBatch b, const int16_
       __builtin_amdgcn_wave_barrier();
     }
     // real split + power spectrum into spec[0..nc] (overwrites the staged samples)
-    for (int k = l; k <= (AASR_FDBG(64) ? -1 : nc / 2); k += TPF) {
-      if (k == 0) {
-        const cpx t0 = buf[0];
-        spec[0] = spec_value(t0.r + t0.i, 0.0f, sp.fp.magnitude, sp.fp.take_log);
-        spec[nc] = spec_value(t0.r - t0.i, 0.0f, sp.fp.magnitude, sp.fp.take_log);
-      } else {
-        float re_k, im_k, re_n, im_n;
-        real_split(buf, nc, k, t_stw, re_k, im_k, re_n, im_n);
-        if (k != nc - k) spec[k] = spec_value(re_k, im_k, sp.fp.magnitude, sp.fp.take_log);
-        spec[nc - k] = spec_value(re_n, im_n, sp.fp.magnitude, sp.fp.take_log);
-      }
+    // (k = 0 needs no split; lane 0 takes k = nc / 2 in its place, so nc / 2 + 1 values are four rounds of 16, not five)
+    if (l == 0 && !AASR_FDBG(64)) {
+      const cpx t0 = buf[0];
+      spec[0] = spec_value(t0.r + t0.i, 0.0f, sp.fp.magnitude, sp.fp.take_log);
+      spec[nc] = spec_value(t0.r - t0.i, 0.0f, sp.fp.magnitude, sp.fp.take_log);
+    }
+    for (int k0 = l; k0 < (AASR_FDBG(64) ? 0 : nc / 2); k0 += TPF) {
+      const int k = k0 == 0 ? nc / 2 : k0;
+      float re_k, im_k, re_n, im_n;
+      real_split(buf, nc, k, t_stw, re_k, im_k, re_n, im_n);
+      if (k != nc - k) spec[k] = spec_value(re_k, im_k, sp.fp.magnitude, sp.fp.take_log);
+      spec[nc - k] = spec_value(re_n, im_n, sp.fp.magnitude, sp.fp.take_log);
     }
     // PowerModule's left-to-right float sum (aku/FeatureModules.cc:874-885) is a chain of 129 dependent additions per
     // frame.  One wave forms it for all 16 frames of the pass, a frame per lane (the waves take turns): carried by the
@@ -702,7 +706,7 @@ __global__ __launch_bounds__(256) void k_spectral_fused(DevBatch b, const int16_
         if (sp.zeroth && i == 0) {
           for (int k = 0; k < sp.mel_dim; k++) acc += data[k];
         } else {
-          const float *c = t_dct + (size_t)(i - (sp.zeroth ? 1 : 0)) * sp.mel_dim;
+          const spec_tbl_t *c = t_dct + (size_t)(i - (sp.zeroth ? 1 : 0)) * sp.mel_dim;
 #pragma unroll 4
           for (int k = 0; k < sp.mel_dim; k++) acc += data[k] * (double)c[k];
         }
