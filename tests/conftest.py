@@ -37,7 +37,7 @@ def golden_dir():
 TOL_LL = 1e-4                     # north_star: LNA log-likelihoods within 1e-4 of the reference CPU path
 LL_FLUSH = -150.0 * 0.6931471805599453   # ln 2^-150: below it the reference's float storage of the
                                          # likelihood (phone_probs.cc:224-236) holds 0.0 and the LNA entry is the floor
-CODES_EQUAL_MIN = 0.98            # 2-byte code equality: never more than one step apart, and at least this share
+CODES_EQUAL_MIN = 0.99            # 2-byte code equality: never more than one step apart, and at least this share
                                   # identical (a different v_exp_f32 / libm rounding moves a fraction of a per cent)
 
 
