@@ -1052,8 +1052,8 @@ __global__ __launch_bounds__(256) void k_lin_transform_tiled(
 // kCmsLead rows more of left look-around so that the anchor of an utterance chunk's first frames has its window.
 // (One LDS read per row of the window stood behind every output value: 151 reads, then ~21 with the block sums --
 // 87 us of the kernel's 195; anchor + slide is 42 reads per 8 values.)
-template <int ROWS, class OUT>
-__global__ __launch_bounds__(256) void k_mean_subtract_tiled(
+template <int ROWS, class OUT, int NT = 256>
+__global__ __launch_bounds__(NT) void k_mean_subtract_tiled(
     DevBatch b, const double *__restrict__ src, SrcMap sm, int span, int halo_left, int64_t rows, int dim,
     int left, int right, int dbg, OUT *__restrict__ dst) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1076,14 +1076,14 @@ __global__ __launch_bounds__(256) void k_mean_subtract_tiled(
     const int64_t s0 = r0 + (int64_t)u * sm.span_diff + sm.shift;  // source row of r0
     const int n_seg = (int)(r_end - r0);
     const int n_src = n_seg + LEAD + left + right;
-    for (int e = threadIdx.x; e < (AASR_FDBG(4) ? 0 : n_src * dim); e += 256) xs[e] = src[(s0 - left - LEAD) * dim + e];
+    for (int e = threadIdx.x; e < (AASR_FDBG(4) ? 0 : n_src * dim); e += NT) xs[e] = src[(s0 - left - LEAD) * dim + e];
     __syncthreads();
     // absolute frame number of output row 0 of the segment; staged row 0 is frame absf0 - left - LEAD
     const int64_t key_u = b.frame_off[u] + (int64_t)u * span;
     const int64_t absf0 = (int64_t)b.first[u] - halo_left + (r0 - key_u);
     const int i0 = (int)(((-(absf0 - left - LEAD)) % 8 + 8) % 8);   // first staged row that starts a block
     const int n_blk = n_src > i0 ? (n_src - i0) / 8 : 0;
-    for (int e = threadIdx.x; e < (AASR_FDBG(2) ? 0 : n_blk * dim); e += 256) {
+    for (int e = threadIdx.x; e < (AASR_FDBG(2) ? 0 : n_blk * dim); e += NT) {
       const int k = fast_div(e, dim_magic), d = e - k * dim;
       const double *c = xs + (size_t)(i0 + 8 * k) * dim + d;
       double t = 0;
@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(256) void k_mean_subtract_tiled(
     // chunks of 8 output rows on absolute multiples of 8: chunk k holds segment rows 8k - off .. 8k - off + 7
     const int off = (int)((absf0 % 8 + 8) % 8);
     const int n_chunk = (n_seg + off + 7) / 8;
-    for (int e = threadIdx.x; e < n_chunk * dim; e += 256) {
+    for (int e = threadIdx.x; e < n_chunk * dim; e += NT) {
       const int k = fast_div(e, dim_magic), d = e - k * dim;
       const int la = 8 * k - off;                 // the anchor's segment row (>= -7)
       // staged rows [a, b_end) are the anchor's window
@@ -1641,27 +1641,41 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
         break;
       }
       case MOD_MEAN_SUBTRACTOR: {
-#ifdef AASR_MS_ROWS
-        constexpr int MS_ROWS = AASR_MS_ROWS;
-#else
-        constexpr int MS_ROWS = 64;
-#endif
         const int ms_dbg = getenv("AASR_CMS_DBG") ? atoi(getenv("AASR_CMS_DBG")) : 0;
-        const size_t ms_src = (size_t)(MS_ROWS + kCmsLead + m.cms_left + m.cms_right);
-        const size_t ms_smem = (ms_src + ms_src / 8 + 1) * m.dim * 8;
-        if (ms_smem <= 60 * 1024 && i == target && g_feat_fusion && out_f32 && !out_f64) {
+        // tile: 128 rows x 512 threads where two such workgroups fit a CU's LDS (the look-around is re-read once per
+        // tile: 2.3x the rows at 64, 1.6x at 128 -- 134 -> 90 us on the production graph), 64 x 256 where three of
+        // those fit, 128 x 512 alone on a CU for wide windows (the reference's default 75 + 75 at 39 columns: 100 KB);
+        // the untiled kernel beyond that
+        auto smem_of = [&](int tile_rows) {
+          const size_t n = (size_t)(tile_rows + kCmsLead + m.cms_left + m.cms_right);
+          return (n + n / 8 + 1) * m.dim * 8;
+        };
+        int tile_rows = 0;
+        if (smem_of(128) <= 78 * 1024) tile_rows = 128;
+        else if (smem_of(64) <= 52 * 1024) tile_rows = 64;
+        else if (smem_of(128) <= 156 * 1024) tile_rows = 128;
+        else if (smem_of(64) <= 156 * 1024) tile_rows = 64;
+        const bool emit_f32 = i == target && g_feat_fusion && out_f32 && !out_f64;
+        auto launch = [&](auto kern, int rows_per, int nt, auto *out) {
+          const size_t smem = smem_of(rows_per);
+          if (smem > 64 * 1024)
+            AASR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+          hipLaunchKernelGGL(kern, dim3((unsigned)((rows + rows_per - 1) / rows_per)), dim3(nt), smem, stream, db, src, sm,
+                             span, L[i], rows, m.dim, m.cms_left, m.cms_right, ms_dbg, out);
+        };
+        if (tile_rows >= 128) {
           // the output module: its rows are the caller's rows (no look-around of its own)
-          hipLaunchKernelGGL((k_mean_subtract_tiled<MS_ROWS, float>), dim3((unsigned)((rows + MS_ROWS - 1) / MS_ROWS)),
-                             dim3(256), ms_smem, stream, db, src, sm, span, L[i], rows, m.dim, m.cms_left,
-                             m.cms_right, ms_dbg, out_f32);
-          emitted = true;
-        } else if (ms_smem <= 60 * 1024)
-          hipLaunchKernelGGL((k_mean_subtract_tiled<MS_ROWS, double>), dim3((unsigned)((rows + MS_ROWS - 1) / MS_ROWS)),
-                             dim3(256), ms_smem, stream, db, src, sm, span, L[i], rows, m.dim, m.cms_left,
-                             m.cms_right, ms_dbg, dst);
-        else
+          if (emit_f32) launch(k_mean_subtract_tiled<128, float, 512>, 128, 512, out_f32);
+          else launch(k_mean_subtract_tiled<128, double, 512>, 128, 512, dst);
+          emitted = emit_f32;
+        } else if (tile_rows > 0) {
+          if (emit_f32) launch(k_mean_subtract_tiled<64, float, 256>, 64, 256, out_f32);
+          else launch(k_mean_subtract_tiled<64, double, 256>, 64, 256, dst);
+          emitted = emit_f32;
+        } else {
           hipLaunchKernelGGL(k_mean_subtract, dim3(grid_for(nelem)), dim3(256), 0, stream, db, src,
                              sm, span, rows, m.dim, m.cms_left, m.cms_right, dst);
+        }
         break;
       }
     }

@@ -129,6 +129,24 @@ def test_batch_of_very_unequal_utterances(capi, golden_dir):
             assert np.array_equal(got[a:b], ft.run(utts[k], 0, b - a)), k
 
 
+@pytest.mark.parametrize("left,right", [(75, 75), (3, 200), (400, 400), (0, 0)])
+def test_mean_subtractor_windows(capi, oracle, left, right):
+    """The mean subtractor's kernel picks its tile by the window (128 rows x 512 threads, 64 x 256, 128 x 512 alone on a CU
+    for the reference's default 75 + 75, the untiled kernel beyond): each against the oracle."""
+    cfg = synth.make_feature_config().replace("left 50", "left %d" % left).replace("right 25", "right %d" % right)
+    assert "left %d" % left in cfg
+    pcm = synth.make_audio(56000, seed=3)
+    ch = oracle.FeatureChain(cfg)
+    ft = capi.Feat(cfg)
+    n = ft.last_frame(len(pcm)) + 1
+    want = ch.generate(pcm, -5, n + 9)
+    got = ft.run(pcm, -5, n + 9, dtype=np.float64)
+    assert np.abs(got - want).max() <= FEAT_TOL
+    # a frame's value does not depend on the partition of the range
+    part = np.vstack([ft.run(pcm, -5, 133, dtype=np.float64), ft.run(pcm, 128, n + 9 - 133, dtype=np.float64)])
+    assert np.array_equal(got.view(np.uint64), part.view(np.uint64))
+
+
 def test_options_copy_borders_window_magnitude(capi, oracle):
     cfg = """module
 {
