@@ -738,11 +738,17 @@ struct TemporalPrm {
 #ifdef AASR_TR
 constexpr int kTemporalRows = AASR_TR;
 #else
-constexpr int kTemporalRows = 32;
+constexpr int kTemporalRows = 64;   // x 512 threads: 156 -> 146 us against 32 x 256 (64 x 256 was slower than both)
 #endif
 
-template <int ROWS>
-__global__ __launch_bounds__(256) void k_temporal_fused(DevBatch b, const double *__restrict__ src,
+// LDS bytes of k_temporal_fused: source rows, first differences, normalised rows, the transposed transform, vectors
+static inline size_t temporal_smem(int tile_rows, int dx, int H, int w2, int dim) {
+  return (size_t)(tile_rows + 2 * H) * dx * 8 + (size_t)(tile_rows + 2 * w2) * dx * 8 + (size_t)tile_rows * 3 * dx * 8 + 16 +
+         (size_t)(3 * dx) * ((dim + 2) / 3) * 16 + (size_t)(6 * dx + dim) * 4;
+}
+
+template <int ROWS, int NT>
+__global__ __launch_bounds__(NT) void k_temporal_fused(DevBatch b, const double *__restrict__ src,
                                                         SrcMap sm, int span, int64_t rows,
                                                         TemporalPrm tp, int dbg, double *__restrict__ dst) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -759,7 +765,7 @@ __global__ __launch_bounds__(256) void k_temporal_fused(DevBatch b, const double
   const int ngrp = (tp.dim + 2) / 3;
   const unsigned ngrp_magic = fast_magic(ngrp);
   if (tp.matrix && !AASR_FDBG(8))
-    for (int e = threadIdx.x; e < md * ngrp; e += 256) {
+    for (int e = threadIdx.x; e < md * ngrp; e += NT) {
       const int j = fast_div(e, ngrp_magic), g = e - j * ngrp;
       float4 v;
       v.x = tp.matrix[(size_t)(3 * g) * md + j];
@@ -770,12 +776,12 @@ __global__ __launch_bounds__(256) void k_temporal_fused(DevBatch b, const double
     }
   // normalisation vectors and the bias: LDS copies (a global load per value and round stood in the dependent chain)
   float *nmean = (float *)(mt + (size_t)md * ngrp), *nscale = nmean + md, *nbias = nscale + md;
-  for (int e = threadIdx.x; e < md; e += 256) {
+  for (int e = threadIdx.x; e < md; e += NT) {
     nmean[e] = tp.mean[e];
     nscale[e] = tp.scale[e];
   }
   if (tp.bias)
-    for (int e = threadIdx.x; e < tp.dim; e += 256) nbias[e] = tp.bias[e];
+    for (int e = threadIdx.x; e < tp.dim; e += NT) nbias[e] = tp.bias[e];
   const int64_t tile0 = (int64_t)blockIdx.x * ROWS;
   const int64_t tile1 = tile0 + ROWS < rows ? tile0 + ROWS : rows;
   int64_t r0 = tile0;
@@ -786,10 +792,10 @@ __global__ __launch_bounds__(256) void k_temporal_fused(DevBatch b, const double
     const int64_t s0 = r0 + (int64_t)u * sm.span_diff + sm.shift;  // source row of r0
     const int n_seg = (int)(r_end - r0);
     const int n_x = n_seg + 2 * H, n_d1 = n_seg + 2 * tp.w2;
-    for (int e = threadIdx.x; e < (AASR_FDBG(16) ? 0 : n_x * dx); e += 256) xs[e] = src[(s0 - H) * dx + e];
+    for (int e = threadIdx.x; e < (AASR_FDBG(16) ? 0 : n_x * dx); e += NT) xs[e] = src[(s0 - H) * dx + e];
     __syncthreads();
     // DeltaModule::generate (aku/FeatureModules.cc:1018-1037) on the source rows
-    for (int e = threadIdx.x; e < (AASR_FDBG(4) ? 0 : n_d1 * dx); e += 256) {
+    for (int e = threadIdx.x; e < (AASR_FDBG(4) ? 0 : n_d1 * dx); e += NT) {
       const int j = fast_div(e, dx_magic), i = e - j * dx;
       const int c = j + tp.w1;
       double acc = 0;
@@ -803,7 +809,7 @@ __global__ __launch_bounds__(256) void k_temporal_fused(DevBatch b, const double
     __syncthreads();
     // second difference, merge (source, delta, delta-delta) and NormalizationModule::generate (:1135-1142)
     // (one thread forms a frame's three values of one source column: no divergence between the three parts)
-    for (int e = threadIdx.x; e < (AASR_FDBG(2) ? 0 : n_seg * dx); e += 256) {
+    for (int e = threadIdx.x; e < (AASR_FDBG(2) ? 0 : n_seg * dx); e += NT) {
       const int lr = fast_div(e, dx_magic), i = e - lr * dx;
       const double v0 = xs[(size_t)(lr + H) * dx + i];
       const double v1 = d1[(size_t)(lr + tp.w2) * dx + i];
@@ -824,7 +830,7 @@ __global__ __launch_bounds__(256) void k_temporal_fused(DevBatch b, const double
     // LinTransformModule::generate (:1243-1269)
     if (tp.matrix) {
       const int npair = (n_seg + 1) / 2;
-      for (int it = threadIdx.x; it < ngrp * npair; it += 256) {
+      for (int it = threadIdx.x; it < ngrp * npair; it += NT) {
         const int rp = fast_div(it, ngrp_magic), g = it - rp * ngrp;
         const int la = 2 * rp, lb = 2 * rp + 1 < n_seg ? 2 * rp + 1 : la;
         const double *xa = nrm + (size_t)la * md, *xb = nrm + (size_t)lb * md;
@@ -869,7 +875,7 @@ __global__ __launch_bounds__(256) void k_temporal_fused(DevBatch b, const double
         }
       }
     } else {
-      for (int e = threadIdx.x; e < n_seg * tp.dim; e += 256) {
+      for (int e = threadIdx.x; e < n_seg * tp.dim; e += NT) {
         const int lr = fast_div(e, dim_magic), i = e - lr * tp.dim;
         double acc = nrm[(size_t)lr * md + i];
         if (tp.bias) acc += (double)nbias[i];
@@ -1373,9 +1379,7 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
       if ((int)h->mods[N].mean.size() != 3 * dx || (int)h->mods[N].scale.size() != 3 * dx) continue;
       const int H = h->mods[A].delta_width + h->mods[B].delta_width;
       constexpr int TR = kTemporalRows;
-      const size_t smem = (size_t)(TR + 2 * H) * dx * 8 + (size_t)(TR + 2 * h->mods[B].delta_width) * dx * 8 +
-                          (size_t)TR * 3 * dx * 8 + (size_t)T.dim * ((3 * dx) | 1) * 4;
-      if (smem > 64 * 1024) continue;
+      if (temporal_smem(TR, dx, H, h->mods[B].delta_width, T.dim) > 64 * 1024) continue;
       tgX = X; tgA = A; tgB = B; tgN = N; tgT = ti;
       skip[A] = skip[B] = skip[C] = skip[N] = 1;
     }
@@ -1447,11 +1451,12 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
       tp.dim = m.dim;
       constexpr int TR = kTemporalRows;
       const int H = tp.w1 + tp.w2;
-      const size_t smem = (size_t)(TR + 2 * H) * tp.dx * 8 + (size_t)(TR + 2 * tp.w2) * tp.dx * 8 +
-                          (size_t)TR * 3 * tp.dx * 8 + 16 + (size_t)(3 * tp.dx) * ((m.dim + 2) / 3) * 16 +
-                          (size_t)(6 * tp.dx + m.dim) * 4;
+      const size_t smem = temporal_smem(TR, tp.dx, H, tp.w2, m.dim);
       h->bufs[i].ensure((size_t)rows * m.dim);
-      hipLaunchKernelGGL(k_temporal_fused<TR>, dim3((unsigned)((rows + TR - 1) / TR)), dim3(256), smem, stream, db,
+      constexpr int TNT = TR >= 128 ? 1024 : TR >= 64 ? 512 : 256;
+      if (smem > 64 * 1024)
+        AASR_HIP(hipFuncSetAttribute((const void *)k_temporal_fused<TR, TNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL((k_temporal_fused<TR, TNT>), dim3((unsigned)((rows + TR - 1) / TR)), dim3(TNT), smem, stream, db,
                          (const double *)h->bufs[tgX].p, map_of(i, tgX), span, rows, tp,
                          getenv("AASR_TEMP_DBG") ? atoi(getenv("AASR_TEMP_DBG")) : 0, h->bufs[i].p);
       AASR_HIP(hipGetLastError());
