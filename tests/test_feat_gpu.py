@@ -129,6 +129,46 @@ def test_batch_of_very_unequal_utterances(capi, golden_dir):
             assert np.array_equal(got[a:b], ft.run(utts[k], 0, b - a)), k
 
 
+@pytest.mark.parametrize("dim_cep,out_dim", [(12, 39), (12, 26), (12, 40), (10, 33), (7, 25), (4, 1)])
+def test_temporal_kernel_shapes(capi, oracle, dim_cep, out_dim):
+    """k_temporal_fused forms the transform in blocks of three output rows x two frames: output dimensions that are
+    not multiples of three, non-square transforms and other source widths, against the oracle (and the fused path
+    against the module-by-module one)."""
+    rng = np.random.default_rng(dim_cep * 100 + out_dim)
+    cfg = synth.make_feature_config(dim_cep=dim_cep)
+    d = 3 * (dim_cep + 1)
+    a = 0.2 * rng.standard_normal((out_dim, d)) + np.eye(out_dim, d)
+    bias = 0.1 * rng.standard_normal(out_dim)
+    lines = cfg.split("\n")
+    out = []
+    for ln in lines:
+        t = ln.strip()
+        if t.startswith("matrix "):
+            ln = "  matrix " + " ".join("%.6g" % x for x in a.ravel())
+        elif t.startswith("bias "):
+            ln = "  bias " + " ".join("%.6g" % x for x in bias)
+        elif t == "dim %d" % d:
+            ln = "  dim %d" % out_dim
+        out.append(ln)
+    cfg = "\n".join(out)
+    pcm = synth.make_audio(30000, seed=out_dim)
+    ch = oracle.FeatureChain(cfg)
+    ft = capi.Feat(cfg)
+    assert ft.dim == ch.dim == out_dim
+    n = ft.last_frame(len(pcm)) + 1
+    want = ch.generate(pcm, -3, n + 6)
+    got = ft.run(pcm, -3, n + 6, dtype=np.float64)
+    assert np.abs(got - want).max() <= FEAT_TOL
+    capi.debug_feat_fusion(False)
+    try:
+        unfused = ft.run(pcm, -3, n + 6, dtype=np.float64)
+    finally:
+        capi.debug_feat_fusion(True)
+    # the temporal kernel is bit-identical to the chain of module kernels; the tiled mean subtractor groups its window
+    # sums differently from the frame-order loop (1e-15 relative)
+    assert np.abs(got - unfused).max() <= 1e-12 * max(1.0, np.abs(unfused).max())
+
+
 @pytest.mark.parametrize("left,right", [(75, 75), (3, 200), (400, 400), (0, 0)])
 def test_mean_subtractor_windows(capi, oracle, left, right):
     """The mean subtractor's kernel picks its tile by the window (128 rows x 512 threads, 64 x 256, 128 x 512 alone on a CU
