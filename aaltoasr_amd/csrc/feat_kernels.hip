@@ -451,8 +451,12 @@ __global__ __launch_bounds__(256) void k_fft(DevBatch b, const int16_t *__restri
 // Every operation is the one the single-module kernels perform (same device functions, same
 // order), so the result is bit-identical to the unfused path (tests/test_feat_gpu.py).
 // ---------------------------------------------------------------------------
-// phase ablations of k_spectral_fused (AASR_SPEC_DBG bits: 1 no utterance search, 8 no sample
-// staging, 2 no FFT stages, 4 no mel, 16 no power sum) exist only in AASR_BUILD_ABLATION=1 builds
+// phase ablations exist only in AASR_BUILD_ABLATION=1 builds (tools/ablate_spectral.sh, tools/ablate_temporal.sh):
+//   k_spectral_fused, AASR_SPEC_DBG bits: 1 no utterance search, 8 / 32 no sample fetch + window, 2 no FFT stages,
+//     64 no real split, 4 no mel, 16 no power sum, 128 no DCT / stores
+//   k_temporal_fused, AASR_TEMP_DBG: 1 no transform products, 2 no second difference / normalisation, 4 no first
+//     difference, 8 no matrix staging, 16 no row loads, 32 no stores, 64 no utterance search
+//   k_mean_subtract_tiled, AASR_CMS_DBG: 1 no window sums, 2 no block sums, 4 no staging
 #ifndef AASR_ABLATION
 #define AASR_ABLATION 0
 #endif
