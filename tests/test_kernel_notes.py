@@ -52,3 +52,18 @@ def test_every_dimension_instance_of_the_bench_form_has_no_scratch(notes):
     bad = {n: k for n, k in notes.items()
            if "k_gmm_diag_score_pl<" in n and n.endswith(", 2, false>") and (k["scratch"] or k["spill_vgpr"])}
     assert not bad, bad
+
+
+def test_feature_kernels_keep_four_waves_per_simd():
+    """k_spectral_fused is bound by vector issue with four workgroups per CU (four waves per SIMD): 128 VGPRs is the
+    wall (round 4 measured a variant at 133: one workgroup fewer per CU), and nothing of the three production kernels
+    may sit in scratch memory."""
+    import kernel_notes
+    obj = os.path.join(ROOT, "aaltoasr_amd", "lib", "obj", "feat_kernels.hip.o")
+    assert os.path.exists(obj)
+    notes = kernel_notes.kernel_notes(obj)
+    spectral = [v for k, v in notes.items() if k.endswith("k_spectral_fused")]
+    assert len(spectral) == 1 and spectral[0]["vgpr"] <= 128 and spectral[0]["scratch"] == 0, spectral
+    for name in ("k_temporal_fused<64, 512>", "k_mean_subtract_tiled<128, float, 512>", "k_mean_subtract_tiled<64, float, 256>"):
+        hits = [v for k, v in notes.items() if k.endswith(name)]
+        assert len(hits) == 1 and hits[0]["scratch"] == 0 and hits[0]["spill_vgpr"] == 0 and hits[0]["vgpr"] <= 128, (name, hits)
