@@ -357,10 +357,12 @@ __device__ __forceinline__ void real_split(const cpx *buf, int nc, int k, const 
   f2k.r = fpk.r - fpnk.r;  f2k.i = fpk.i - fpnk.i;
   t = cmul(f2k, stw[k - 1]);
   float ar = f1k.r + t.r, ai = f1k.i + t.i, br = f1k.r - t.r, bi = t.i - f1k.i;
-  re_k = (float)((double)ar * .5);
-  im_k = (float)((double)ai * .5);
-  re_n = (float)((double)br * .5);
-  im_n = (float)((double)bi * .5);
+  // HALF_OF(x) = x * .5 promotes to double in the reference; halving is exact, so the float product is the same value
+  // (one rounding of the exact result, subnormal results included) at a third of the instructions
+  re_k = ar * .5f;
+  im_k = ai * .5f;
+  re_n = br * .5f;
+  im_n = bi * .5f;
 }
 
 // One wave per frame: Hamming -> packed half-length complex FFT in LDS with
@@ -612,11 +614,11 @@ __global__ __launch_bounds__(256) void k_spectral_fused(DevBatch b, const int16_
           c2 = (i + 2 >= 0 && i + 2 < ns) ? (float)p[i + 2] : 0.0f;
         }
         const float p0 = ap.emph * c0, p1 = ap.emph * c1;
-        const double x0 = (double)(c1 - p0);
-        const double x1 = (double)(c2 - p1);
+        // (float)((double) window * (double) sample) as the reference writes it: the product of two floats is exact in
+        // double (48 bits), so its rounding to float IS the float product -- one instruction instead of four
         cpx v;
-        v.r = (float)((double)t_ham[2 * s] * x0);
-        v.i = (float)((double)t_ham[2 * s + 1] * x1);
+        v.r = t_ham[2 * s] * (c1 - p0);
+        v.i = t_ham[2 * s + 1] * (c2 - p1);
         return v;
       };
       for (int o = l; o < ((AASR_FDBG(32) || AASR_FDBG(8)) ? 0 : nc); o += TPF) buf[o] = point(o);
