@@ -1150,11 +1150,12 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
 #endif
   // slab of H0 in front of which the lagging group's barrier sits: early in the phase, so that the lagging waves run
   // nearly a whole tile behind (configs[2], NK16 = 5, ms of the scoring stage on one box: slab 0 8.45, slab 1 8.43,
-  // slab 2 -- the middle, rounds 3's choice -- 8.51, slab 3 8.61)
+  // slab 2 -- the middle, rounds 3's choice -- 8.51, slab 3 8.61; with the issue priority of the matrix phases, below:
+  // slab 0 8.47, slab 1 8.55, slab 2 8.53 -- the barrier in front of the phase)
 #ifdef AASR_PL_JB
-  constexpr int JB = AASR_PL_JB < NK16 ? AASR_PL_JB : NK16 / 4;
+  constexpr int JB = AASR_PL_JB < NK16 ? AASR_PL_JB : 0;
 #else
-  constexpr int JB = NK16 / 4;
+  constexpr int JB = 0;
 #endif
   const int n = lane & 31;
   const int h = lane >> 5;  // K half of a slab held by this lane AND its row track
