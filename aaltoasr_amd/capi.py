@@ -378,6 +378,41 @@ class Gmm:
         return float(L.aasr_debug_frame_operand_ms(self._h, C.c_void_p(d_frames.data_ptr()), d_frames.shape[0], reps,
                                                    C.c_void_p(stream.cuda_stream if stream is not None else 0)))
 
+    def engine_parts(self):
+        """The model's engine parts (multi-pivot internal models, aasr_debug_engine_parts): a dict with `cols` (columns of
+        an engine score row) and `parts`, a list of {arith (2: two fp16 terms, 3: three bf16 terms, 0: ordinary model),
+        states, pivot_groups, rows}; None when the model is scored by its own layouts."""
+        L = lib()
+        L.aasr_debug_engine_parts.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int]
+        out = (C.c_int64 * 14)()
+        n = L.aasr_debug_engine_parts(self._h, out, 14)
+        if n <= 0:
+            return None
+        return {"cols": int(out[1]),
+                "parts": [{"arith": int(out[2 + 4 * i]), "states": int(out[3 + 4 * i]), "pivot_groups": int(out[4 + 4 * i]),
+                           "rows": int(out[5 + 4 * i])} for i in range(n)]}
+
+    def engine_layout(self, part: int = 0):
+        """(colmap [S], col0, begin [P], real_end [P], pivots [P, dim]) of engine part `part` (aasr_debug_engine_layout);
+        None when there is no such part."""
+        L = lib()
+        L.aasr_debug_engine_layout.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        colmap = np.zeros(self.num_states, np.int32)
+        begin = np.zeros(64, np.int32)
+        real_end = np.zeros(64, np.int32)
+        piv = np.zeros((64, self.dim), np.float32)
+        col0 = C.c_int64(0)
+        n = L.aasr_debug_engine_layout(self._h, part, _ptr(colmap), _ptr(begin), _ptr(real_end), _ptr(piv), C.byref(col0))
+        if n < 0:
+            return None
+        return colmap, int(col0.value), begin[:n].copy(), real_end[:n].copy(), piv[:n].copy()
+
+    def engine_plan_note(self) -> str:
+        L = lib()
+        L.aasr_debug_engine_plan_note.argtypes = [C.c_void_p]
+        L.aasr_debug_engine_plan_note.restype = C.c_char_p
+        return L.aasr_debug_engine_plan_note(self._h).decode("utf-8", "replace")
+
     def precision_states(self):
         """(states the two-term fp16 rows cover under the current setting, states the load-time probe took out of
         that form): per-state precision routing, aasr_gmm_precision_states."""

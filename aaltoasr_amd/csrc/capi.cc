@@ -251,6 +251,7 @@ int aasr_gmm_effective_precision(const aasr_gmm *h) {
   // what the matrix path runs: the centred / general forms have no f16x2 form
   if (h->host.factor_path())   // the factor-row kernels: three bf16 terms, or two fp16 terms where the pool qualifies
     return (h->precision == AASR_PREC_F16X2 && h->full.a16h.p) ? AASR_PREC_F16X2 : AASR_PREC_BF16X3;
+  if (aasr::gmm_engine_parts_active(h)) return AASR_PREC_F16X2;   // multi-pivot engine parts: part 0 is on two fp16 terms
   if (h->ill_conditioned) return AASR_PREC_F32_CENTRED;
   const aasr::TrackLayout &L = h->paired.ok ? h->paired : h->tracks;
   if (!L.ok || !L.a16.p) return AASR_PREC_F32;
@@ -263,7 +264,18 @@ aasr_status aasr_gmm_precision_states(const aasr_gmm *h, int64_t *states_f16x2, 
   return guarded([&] {
     if (!h) raise(AASR_ERR_INVALID, "null handle");
     int64_t n = 0;
-    if (aasr_gmm_effective_precision(h) == AASR_PREC_F16X2 && !h->host.factor_path()) {
+    if (aasr::gmm_engine_parts_active(h)) {
+      for (const auto &part : h->engine_parts) {
+        if (part.arith == 2) n += part.states;
+        else if (part.arith == 0) {   // the remainder is a model of its own: it may hold two-term states around its pivot
+          int64_t k = 0;
+          part.model->precision = h->precision;
+          part.model->use_bf16x3 = h->use_bf16x3;
+          aasr_gmm_precision_states(part.model.get(), &k, nullptr);
+          n += k;
+        }
+      }
+    } else if (aasr_gmm_effective_precision(h) == AASR_PREC_F16X2 && !h->host.factor_path()) {
       const aasr::TrackLayout &L = h->paired.ok ? h->paired : h->tracks;
       n = (h->mixed.ok && (h->layout_mask & 3) == 3) ? h->mixed.states_f16 : L.states_f16;
     }

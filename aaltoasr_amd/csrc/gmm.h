@@ -65,6 +65,19 @@ struct HostModel {
   // only trusted for the files it was written from
   bool has_src_fp = false;
   uint64_t src_fp[6] = {0, 0, 0, 0, 0, 0};
+  // Pivot groups -- engine-internal models only (gmm_plan_engine_parts): the states are sorted into groups, the rows of
+  // group p are expanded around pg_pivot[p] instead of the pool's one pivot.  Group p holds the states
+  // [pg_begin[p], pg_real_end[p]); the states up to pg_begin[p + 1] -- a multiple of 32, so that every group starts on a
+  // whole line of the score matrix -- are padding columns without components, never scored, never read.
+  std::vector<int32_t> pg_begin, pg_real_end;   // [P + 1], [P]
+  std::vector<float> pg_pivot;                  // [P][dim]
+  int pg_arith = 0;                             // 2: two fp16 terms, 3: three bf16 terms (0: no pivot groups)
+  int n_pg() const { return pg_arith ? (int)pg_real_end.size() : 0; }
+  int pg_of_state(int64_t s) const {
+    int p = 0;
+    while (p + 1 < (int)pg_real_end.size() && s >= pg_begin[(size_t)p + 1]) p++;
+    return p;
+  }
 };
 void model_files_fingerprint(const char *gk, const char *mc, const char *ph, uint64_t fp[6]);
 
@@ -83,6 +96,8 @@ constexpr int WAVES_PER_BLOCK = 4;
 constexpr int FRAMES_PER_BLOCK = FRAMES_PER_WAVE * WAVES_PER_BLOCK;
 constexpr int TRACK_OUT_GROUP = 32;   // states written per frame row at a time (grouped)
 constexpr int TRACK_MAX_SPLITS = 16;  // row-range cuts available to the launcher
+constexpr int PG_MAX = 32;            // pivot groups of a multi-pivot layout
+constexpr int PG_MAX_SPLITS = 48;     // ... and the cuts of its table (every group is at least one cut)
 constexpr int CENTRED_MAX_SPLITS = 32;
 // expanded-form error estimate eps * kappa beyond which the centred kernel is used
 constexpr double KAPPA_LIMIT = 600.0;
@@ -171,8 +186,15 @@ struct TrackLayout {
   DevBuf<uint16_t> close;    // per tile: bit p (+8 for track 1) = a state closes after quad p
   DevBuf<int32_t> sid;       // [2][sid_stride] state index of the k-th close on each track
   int32_t sid_stride = 0;
-  DevBuf<int32_t> splits;    // [MAX_SPLITS][MAX_SPLITS+1][4]: tile, closes track 0, closes track 1
+  DevBuf<int32_t> splits;    // [MAX_SPLITS][MAX_SPLITS+1][4]: tile, closes track 0, closes track 1, pivot group of the cut
   int max_splits = 1;
+  // multi-pivot layouts (HostModel::pg_*; grouped only): the groups are runs of whole tiles, a row cut lies inside one
+  // group; the frame operand has one image per group (k_frame_operand), the cut table says which a workgroup takes
+  int n_pg = 0;              // 0 / 1: the model's one pivot
+  int split_cap = TRACK_MAX_SPLITS;   // rows of the cut table (PG_MAX_SPLITS for multi-pivot layouts)
+  DevBuf<float> pg_pivot;    // [n_pg][dim]
+  DevBuf<float> pg_tab;      // f16x2: [n_pg][3 KH] the groups' own column scales and clamps (f16tab's layout)
+  DevBuf<int32_t> pg_colend; // [n_pg] one past the group's last output column
   int64_t rows_padded = 0;
   float ref_ln = 0.0f;       // reference exponent * ln 2
   double ref_log2 = 0;       // the reference exponent itself
@@ -296,6 +318,25 @@ struct aasr_gmm {
   aasr::DevBuf<int32_t> routed_colmap;   // [S] column of every state in the engine layout
   int64_t routed_alias_base = 0;         // first spare column (S rounded up to 32)
   bool is_routed_sub = false;
+  // Engine parts (gmm_plan_engine_parts; supersede the mixed layout + routed_sub where they exist): the model as up to
+  // three internal models over disjoint sets of its states -- [0] the states that qualify for two fp16 terms around the
+  // pivot of their GROUP (a multi-pivot model: pivot groups, HostModel::pg_*), [1] the same for three bf16 terms, [2]
+  // whatever is left, as an ordinary model (one pivot; outlier routing, centred form ...) -- each scored into its own
+  // column range of the engine's score rows; engine_colmap says where a state's column is.
+  struct EnginePart {
+    std::unique_ptr<aasr_gmm> model;
+    int64_t col0 = 0;        // first column of the part in an engine score row
+    int64_t cols = 0;        // columns it occupies (a multiple of 32)
+    int arith = 0;           // 2 / 3: pivot-group model in that arithmetic, 0: ordinary model
+    int64_t states = 0;      // real states
+  };
+  std::vector<EnginePart> engine_parts;
+  std::string engine_plan_note;          // what the planner did and why (aasr_debug_engine_plan_note)
+  aasr::DevBuf<int32_t> engine_colmap;   // [S]
+  std::vector<int32_t> engine_colmap_h;
+  int64_t engine_cols = 0;
+  bool is_engine_part = false;
+  mutable aasr::DevBuf<float> engine_scratch, engine_part_scratch;   // public-layout callers: engine rows of a chunk of frames
   std::vector<uint8_t> f16_state_ok;   // per state: eligible for the two-term fp16 form (conditioning limits, probe)
   int64_t f16_probe_moved = 0;         // states the load-time probe (gmm_probe_f16x2) took out of the fp16 form
   // full-covariance path (k_gmm_full_score): rows are the rows of R^-1 of
@@ -409,6 +450,8 @@ void gmm_build_tracks(aasr_gmm *g, bool grouped);
 void gmm_build_mixed(aasr_gmm *g, std::vector<uint8_t> &f16_ok);
 void gmm_probe_f16x2(aasr_gmm *g);
 void gmm_build_routed_sub(aasr_gmm *g);
+void gmm_plan_engine_parts(aasr_gmm *g);
+bool gmm_engine_parts_active(const aasr_gmm *g);
 // the engine's own score layout: rows of gmm_engine_pitch() floats; state s in column gmm_engine_colmap()[s] (nullptr: s)
 int64_t gmm_engine_pitch(const aasr_gmm *g);
 const int32_t *gmm_engine_colmap(const aasr_gmm *g);

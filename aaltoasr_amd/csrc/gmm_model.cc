@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstdarg>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -368,6 +369,7 @@ struct RowSpec {
   int64_t g;        // pool Gaussian, < 0 for a null (padding) row
   double logw;      // log mixture weight (natural), -inf for zero weight
   double bias = 0;  // added to the constant in log2 units (paired layout reference)
+  int pg = 0;       // pivot group of the row's state (multi-pivot layouts; the model's one pivot otherwise)
 };
 
 // Write rows into the [tiles][nkk/2][64][4] layout the kernel streams:
@@ -404,7 +406,7 @@ static void pack_rows(const aasr_gmm *g, const std::vector<RowSpec> &rows,
       double cst = (prod > 0) ? std::log(std::sqrt(prod)) : prod;
       for (int d = 0; d < D; d++) {
         double p = (var[d] > 0) ? 1 / var[d] : 0;
-        double muc = mu[d] - (double)g->pivot[d];
+        double muc = mu[d] - (double)g->pivot[(size_t)rs.pg * D + d];
         coef[2 * d] = p * muc * kLog2e;
         coef[2 * d + 1] = -0.5 * p * kLog2e;
         quad += p * muc * muc;
@@ -442,6 +444,7 @@ void gmm_build_tracks(aasr_gmm *g, bool grouped);
 static void f16x2_state_eligibility(const aasr_gmm *g, std::vector<uint8_t> &ok);
 static void find_outliers(aasr_gmm *g);
 static void build_class_routing(aasr_gmm *g);
+static void build_pg_model(aasr_gmm *g);
 
 // dim > 63: parts of <= 63 dimensions as pools of one-component states (see aasr_gmm::dim_parts)
 static void build_dim_split(aasr_gmm *g) {
@@ -534,6 +537,14 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
       raise(AASR_ERR_INVALID, "transform arrays do not match the model");
     for (int32_t t : m.g2t)
       if (t < -1 || t >= m.n_transforms) raise(AASR_ERR_INVALID, "transform index %d out of range", t);
+  }
+  g->engine_parts.clear();
+  g->engine_colmap = DevBuf<int32_t>();
+  g->engine_colmap_h.clear();
+  g->engine_cols = 0;
+  if (m.n_pg() > 0) {
+    build_pg_model(g);
+    return;
   }
   if (m.dim + 1 > 64) {
     // the model as dimension parts (gmm_dim_split_score).  Regression classes: every class is such a model over its
@@ -689,6 +700,7 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
   }
   gmm_probe_f16x2(g);   // load-time guard of the two-term fp16 rows
   gmm_build_routed_sub(g);
+  gmm_plan_engine_parts(g);
 }
 
 // The second section of a routed model as a model of its own (aasr_gmm::routed_sub): its states, the Gaussians they use,
@@ -736,6 +748,407 @@ void gmm_build_routed_sub(aasr_gmm *g) {
   g->routed_sub = std::move(sub);
   g->routed_alias_base = base;
   g->routed_colmap.upload(colmap.data(), colmap.size());
+}
+
+// ---------------------------------------------------------------------------
+// Multi-pivot models and engine parts.
+//
+// The expanded form  log2e ll = C + sum_d [p mu'] x' + [-p/2] x'^2  (x' = x - pivot) loses eps * kappa, kappa = sum_d p mu'^2
+// (gmm.h, KAPPA_LIMIT_F16): how far a Gaussian's mean lies from the PIVOT in units of its own standard deviation.  One
+// pivot for the whole pool -- the mean of the means -- is enough for the BASELINE model (means N(0, 1), variances >= 0.25),
+// not for a model fitted to data: the tied states of a trained model partition the feature space, a state's Gaussians
+// sit around the state's own centre with variances down to the floor (aku's --minvar), and against the pool's centre
+// most of them exceed the two-term limits (synth.fit_model on the bench's own features: 39-57 % of the states qualify
+// around one pivot, 91-96 % around 8, 97-99 % around 16).  The pivot is a property of the FRAME OPERAND, and a workgroup
+// of the scoring kernel streams one contiguous run of rows past the operand it holds: so the states are sorted into
+// PIVOT GROUPS, every group a run of whole tiles expanded around its own pivot, the frame operand gets one image per
+// group (k_frame_operand, 320 B per frame and group), and a row cut never straddles two groups (build_split_table_pg).
+// The output columns follow the sorted order (every group starts on a whole 128-byte line), consumers read a score row
+// through a column map (gmm_engine_colmap); public-layout callers get the columns gathered back (gmm_score.hip).
+// ---------------------------------------------------------------------------
+static void build_pg_model(aasr_gmm *g) {
+  HostModel &m = g->host;
+  const int P = m.n_pg(), D = m.dim;
+  if (P < 1 || P > PG_MAX || (int)m.pg_begin.size() != P + 1 || (int64_t)m.pg_pivot.size() != (int64_t)P * D ||
+      m.pg_begin[0] != 0 || m.pg_begin[(size_t)P] != m.S || (m.pg_arith != 2 && m.pg_arith != 3))
+    raise(AASR_ERR_INVALID, "malformed pivot groups");
+  for (int p = 0; p < P; p++)
+    if (m.pg_begin[(size_t)p] % 32 != 0 || m.pg_real_end[(size_t)p] <= m.pg_begin[(size_t)p] ||
+        m.pg_real_end[(size_t)p] > m.pg_begin[(size_t)p + 1])
+      raise(AASR_ERR_INVALID, "malformed pivot group %d", p);
+  if (m.n_transforms > 0 || m.any_full() || D + 1 > 64)
+    raise(AASR_ERR_UNSUPPORTED, "pivot groups are built for plain diagonal models of up to 63 dimensions");
+  g->pivot = m.pg_pivot;
+  g->d_pivot.upload(g->pivot.data(), g->pivot.size());
+  m.logw_bias = 0;
+  g->xf_a.release();
+  g->xf_b.release();
+  g->class_routing = false;
+  g->class_models.clear();
+  g->class_g2t.clear();
+  g->full.ok = false;
+  g->ill_conditioned = false;
+  g->centred_ok = false;
+  // conditioning of every component around its group's pivot
+  double kmax = 0, k2max = 0;
+  for (int64_t s = 0; s < m.S; s++) {
+    const float *pv = &m.pg_pivot[(size_t)m.pg_of_state(s) * D];
+    for (int32_t k = m.mix_off[s]; k < m.mix_off[s + 1]; k++) {
+      const int64_t gi = m.mix_idx[(size_t)k];
+      double kk = 0, k2 = 0;
+      for (int d = 0; d < D; d++) {
+        const double v = m.var[(size_t)gi * D + d];
+        const double pr = v > 0 ? 1 / v : 0;
+        const double mc = m.mean[(size_t)gi * D + d] - (double)pv[d];
+        kk += pr * mc * mc;
+        k2 += (pr * mc * mc) * (pr * mc * mc);
+      }
+      kmax = std::max(kmax, kk);
+      k2max = std::max(k2max, std::sqrt(k2));
+    }
+  }
+  g->kappa = g->kappa_matrix = kmax;
+  g->kappa2_matrix = k2max;
+  g->mix = PackedRows();
+  g->mix.rows = (int64_t)m.mix_idx.size();
+  g->paired = TrackLayout();
+  g->tracks = TrackLayout();
+  g->f16_bad_state = -1;
+  g->f16_state_ok.assign((size_t)m.S, 1);
+  gmm_build_tracks(g, true);
+  if (!g->paired.ok || (m.pg_arith == 2 ? !g->paired.a16h.p : !g->paired.a16.p))
+    raise(AASR_ERR_UNSUPPORTED, "no grouped layout for the pivot groups (state %ld)", (long)g->f16_bad_state);
+  g->precision = m.pg_arith == 2 ? AASR_PREC_F16X2 : AASR_PREC_BF16X3;
+  g->use_bf16x3 = true;
+  g->rows_unbiased = true;
+  if (m.pg_arith == 2) gmm_probe_f16x2(g);   // marks the states it rejects in f16_state_ok (the planner moves them)
+}
+
+namespace {
+struct PgLimits { double k, k2; };
+
+// worst conditioning of state s around pivot pv, relative to the limits (<= 1: every component qualifies)
+double pg_state_ratio(const HostModel &m, int64_t s, const float *pv, const PgLimits &lim) {
+  const int D = m.dim;
+  double worst = 0;
+  for (int32_t k = m.mix_off[s]; k < m.mix_off[s + 1]; k++) {
+    const int64_t gi = m.mix_idx[(size_t)k];
+    const double *mu = &m.mean[(size_t)gi * D], *var = &m.var[(size_t)gi * D];
+    double kk = 0, k2 = 0;
+    for (int d = 0; d < D; d++) {
+      const double pr = var[d] > 0 ? 1 / var[d] : 0;
+      const double mc = mu[d] - (double)pv[d];
+      const double t = pr * mc * mc;
+      kk += t;
+      k2 += t * t;
+    }
+    worst = std::max(worst, std::max(kk / lim.k, std::sqrt(k2) / lim.k2));
+    if (!(worst == worst)) return 1e300;
+  }
+  return worst;
+}
+
+// mean of the means of the Gaussians of `states` (one count per component), as floats
+void pg_centre(const HostModel &m, const std::vector<int64_t> &states, std::vector<float> &out) {
+  const int D = m.dim;
+  std::vector<double> acc((size_t)D, 0.0);
+  double n = 0;
+  for (int64_t s : states)
+    for (int32_t k = m.mix_off[s]; k < m.mix_off[s + 1]; k++) {
+      const double *mu = &m.mean[(size_t)m.mix_idx[(size_t)k] * D];
+      for (int d = 0; d < D; d++) acc[(size_t)d] += mu[d];
+      n += 1;
+    }
+  out.assign((size_t)D, 0.0f);
+  if (n > 0)
+    for (int d = 0; d < D; d++) out[(size_t)d] = (float)(acc[(size_t)d] / n);
+}
+
+struct PgPlan {
+  std::vector<float> pivots;              // [P][D]
+  std::vector<std::vector<int64_t>> groups;   // member states, ascending
+  std::vector<int64_t> rejected;          // candidates that fit no group
+};
+
+// Greedy placement of pivots: start from the centre of all candidates; while states fail, try the centre of the worst
+// failing state that qualifies around its OWN centre as a further pivot and keep it when the rows it rescues pay for
+// one more image of the frame operand (`rows_per_pivot`).  Every state then goes to the pivot it is best conditioned
+// around; group centres are re-fitted once where that loses no state.
+PgPlan pg_plan(const HostModel &m, const std::vector<int64_t> &cand, const PgLimits &lim, double rows_per_pivot, int max_groups) {
+  const int D = m.dim;
+  PgPlan plan;
+  if (cand.empty()) return plan;
+  const size_t n = cand.size();
+  std::vector<float> pv;
+  pg_centre(m, cand, pv);
+  plan.pivots = pv;
+  std::vector<double> best(n);
+  std::vector<int> grp(n, 0);
+  std::vector<int64_t> comps(n);
+  for (size_t i = 0; i < n; i++) {
+    best[i] = pg_state_ratio(m, cand[i], pv.data(), lim);
+    comps[i] = m.mix_off[cand[i] + 1] - m.mix_off[cand[i]];
+  }
+  std::vector<uint8_t> tried(n, 0);
+  int P = 1;
+  while (P < max_groups) {
+    // the worst failing state that has not been tried as a pivot
+    size_t pick = n;
+    double worst = 1.0;
+    int64_t fail_rows = 0;
+    for (size_t i = 0; i < n; i++) {
+      if (best[i] <= 1.0) continue;
+      fail_rows += comps[i];
+      if (!tried[i] && best[i] > worst) { worst = best[i]; pick = i; }
+    }
+    if (pick == n) break;
+    tried[pick] = 1;
+    std::vector<float> c;
+    pg_centre(m, std::vector<int64_t>{cand[pick]}, c);
+    if (pg_state_ratio(m, cand[pick], c.data(), lim) > 1.0) continue;   // fails around its own centre: not for this part
+    std::vector<double> r(n);
+    int64_t rescued = 0;
+    for (size_t i = 0; i < n; i++) {
+      r[i] = pg_state_ratio(m, cand[i], c.data(), lim);
+      if (best[i] > 1.0 && r[i] <= 1.0) rescued += comps[i];
+    }
+    // the last failing rows are worth more than their share: they also cost a launch of their own
+    const double bonus = rescued == fail_rows ? 4.0 : 1.0;
+    if ((double)rescued * bonus < rows_per_pivot) continue;
+    plan.pivots.insert(plan.pivots.end(), c.begin(), c.end());
+    for (size_t i = 0; i < n; i++)
+      if (r[i] < best[i] && (best[i] > 1.0 || r[i] <= 0.5 * best[i])) { best[i] = r[i]; grp[i] = P; }
+    P++;
+  }
+  // re-fit every group's pivot to its members' centre where no member is lost
+  for (int p = 0; p < P; p++) {
+    std::vector<int64_t> mem;
+    std::vector<size_t> idx;
+    for (size_t i = 0; i < n; i++)
+      if (grp[i] == p && best[i] <= 1.0) { mem.push_back(cand[i]); idx.push_back(i); }
+    if (mem.empty()) continue;
+    std::vector<float> c;
+    pg_centre(m, mem, c);
+    std::vector<double> r(mem.size());
+    bool ok = true;
+    for (size_t j = 0; j < mem.size() && ok; j++) {
+      r[j] = pg_state_ratio(m, mem[j], c.data(), lim);
+      ok = r[j] <= 1.0;
+    }
+    if (!ok) continue;
+    std::copy(c.begin(), c.end(), plan.pivots.begin() + (size_t)p * D);
+    for (size_t j = 0; j < mem.size(); j++) best[idx[j]] = r[j];
+  }
+  // states that still fail may fit a re-fitted pivot
+  for (size_t i = 0; i < n; i++) {
+    if (best[i] <= 1.0) continue;
+    for (int p = 0; p < P; p++) {
+      const double r = pg_state_ratio(m, cand[i], &plan.pivots[(size_t)p * D], lim);
+      if (r < best[i]) { best[i] = r; grp[i] = p; }
+    }
+  }
+  std::vector<std::vector<int64_t>> groups((size_t)P);
+  for (size_t i = 0; i < n; i++) {
+    if (best[i] <= 1.0) groups[(size_t)grp[i]].push_back(cand[i]);
+    else plan.rejected.push_back(cand[i]);
+  }
+  std::vector<float> piv2;
+  for (int p = 0; p < P; p++) {
+    if (groups[(size_t)p].empty()) continue;
+    plan.groups.push_back(groups[(size_t)p]);
+    piv2.insert(piv2.end(), plan.pivots.begin() + (size_t)p * D, plan.pivots.begin() + (size_t)(p + 1) * D);
+  }
+  plan.pivots = piv2;
+  return plan;
+}
+
+// the states `groups` list (in that order; groups padded to whole lines of 32 columns) as a model of their own
+HostModel pg_sub_model(const HostModel &m, const std::vector<std::vector<int64_t>> &groups, std::vector<int32_t> *col_of_state) {
+  HostModel sm;
+  sm.dim = m.dim;
+  std::vector<int32_t> gmap((size_t)m.G, -1);
+  sm.mix_off.push_back(0);
+  auto add_state = [&](int64_t s) {
+    if (s >= 0) {
+      if (col_of_state) (*col_of_state)[(size_t)s] = (int32_t)sm.S;
+      for (int32_t k = m.mix_off[s]; k < m.mix_off[s + 1]; k++) {
+        const int32_t gi = m.mix_idx[(size_t)k];
+        if (gmap[(size_t)gi] < 0) {
+          gmap[(size_t)gi] = (int32_t)sm.G++;
+          sm.mean.insert(sm.mean.end(), m.mean.begin() + (size_t)gi * m.dim, m.mean.begin() + (size_t)(gi + 1) * m.dim);
+          sm.var.insert(sm.var.end(), m.var.begin() + (size_t)gi * m.dim, m.var.begin() + (size_t)(gi + 1) * m.dim);
+        }
+        sm.mix_idx.push_back(gmap[(size_t)gi]);
+        sm.mix_w.push_back(m.mix_w[(size_t)k]);
+      }
+    }
+    sm.mix_off.push_back((int32_t)sm.mix_idx.size());
+    sm.S++;
+  };
+  for (size_t p = 0; p < groups.size(); p++) {
+    sm.pg_begin.push_back((int32_t)sm.S);
+    for (int64_t s : groups[p]) add_state(s);
+    sm.pg_real_end.push_back((int32_t)sm.S);
+    if (p + 1 < groups.size())
+      while (sm.S % 32) add_state(-1);   // padding columns: the next group starts on a whole line
+  }
+  sm.pg_begin.push_back((int32_t)sm.S);
+  sm.weights_normalized = true;
+  return sm;
+}
+}  // namespace
+
+// Splits the model into engine parts (aasr_gmm::engine_parts) when its own layouts cannot score every state with two
+// fp16 terms around the pool's one pivot.
+void gmm_plan_engine_parts(aasr_gmm *g) {
+  g->engine_parts.clear();
+  g->engine_colmap = DevBuf<int32_t>();
+  g->engine_colmap_h.clear();
+  g->engine_cols = 0;
+  g->engine_plan_note.clear();
+  std::string &note = g->engine_plan_note;
+  auto say = [&](const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    note += buf;
+  };
+  const HostModel &m = g->host;
+  if (g->is_routed_sub || g->is_engine_part || m.n_pg() > 0 || m.n_transforms > 0 || m.any_full() || !g->dim_parts.empty() ||
+      g->class_routing || m.S < 2 || m.mix_idx.empty())
+    return;
+  {
+    const TrackLayout &L0 = g->paired.ok ? g->paired : g->tracks;
+    if (L0.ok && L0.a16h.p) return;   // the whole model on two fp16 terms around one pivot: nothing to gain
+  }
+  const int D = m.dim;
+  const double rows_total = (double)m.mix_idx.size();
+  // one more image of the frame operand costs what ~240 rows cost per frame (k_frame_operand: 0.03 ms per 449 280 frames
+  // and image against 8.5 ms for 50 000 rows, + a tile of padding); a row on two terms instead of three saves 0.65 of
+  // a row, on three terms instead of the centred form several rows
+  // AASR_PG_PIVOT_COST (test hook): the rows one more pivot has to rescue, instead of the cost model's figure
+  static const double pivot_cost_env = getenv("AASR_PG_PIVOT_COST") ? atof(getenv("AASR_PG_PIVOT_COST")) : -1.0;
+  const double cost2 = pivot_cost_env >= 0 ? pivot_cost_env : 240.0 / 0.65;
+  const double cost3 = pivot_cost_env >= 0 ? pivot_cost_env : 240.0 / 4.0;
+  static const double lim_scale = getenv("AASR_PG_LIMIT_SCALE") ? atof(getenv("AASR_PG_LIMIT_SCALE")) : 1.0;   // EXPERIMENT
+  const PgLimits lim2{lim_scale * KAPPA_LIMIT_F16, lim_scale * (D < 8 ? KAPPA2_LIMIT_F16_LOWDIM : KAPPA2_LIMIT_F16)};
+  const PgLimits lim3{lim_scale * KAPPA_LIMIT, lim_scale * KAPPA2_LIMIT};
+  std::vector<int64_t> cand;
+  for (int64_t s = 0; s < m.S; s++) cand.push_back(s);
+  std::vector<aasr_gmm::EnginePart> parts;
+  std::vector<int32_t> colmap((size_t)m.S, -1);
+  int64_t col0 = 0;
+  int64_t probe_moved = 0;
+  auto build_part = [&](const std::vector<std::vector<int64_t>> &groups, const std::vector<float> &pivots, int arith,
+                        std::vector<int64_t> *probe_rejects) -> bool {
+    std::vector<int32_t> cols((size_t)m.S, -1);
+    HostModel sm = pg_sub_model(m, groups, &cols);
+    sm.pg_pivot = pivots;
+    sm.pg_arith = arith;
+    auto sub = std::make_unique<aasr_gmm>();
+    sub->device = g->device;
+    sub->is_engine_part = true;
+    try {
+      gmm_build(sub.get(), sm);
+    } catch (const Error &e) {
+      if (e.code != AASR_ERR_UNSUPPORTED) throw;
+      say("[arith %d, %zu groups: %s] ", arith, groups.size(), e.msg.c_str());
+      if (probe_rejects && sub->f16_bad_state >= 0) {   // a state whose rows left the fp16 range: out, try again
+        for (int64_t s = 0; s < m.S; s++)
+          if (cols[(size_t)s] == (int32_t)sub->f16_bad_state) probe_rejects->push_back(s);
+      }
+      return false;
+    }
+    if (probe_rejects) {
+      for (int64_t s = 0; s < m.S; s++)
+        if (cols[(size_t)s] >= 0 && !sub->f16_state_ok[(size_t)cols[(size_t)s]]) probe_rejects->push_back(s);
+      if (!probe_rejects->empty()) return false;
+    }
+    aasr_gmm::EnginePart part;
+    part.col0 = col0;
+    part.cols = (sub->S + 31) / 32 * 32;
+    part.arith = arith;
+    for (const auto &gr : groups) part.states += (int64_t)gr.size();
+    for (int64_t s = 0; s < m.S; s++)
+      if (cols[(size_t)s] >= 0) colmap[(size_t)s] = (int32_t)(col0 + cols[(size_t)s]);
+    col0 += part.cols;
+    part.model = std::move(sub);
+    parts.push_back(std::move(part));
+    return true;
+  };
+  // part 0: two fp16 terms
+  {
+    std::vector<int64_t> pool = cand, out;
+    for (int attempt = 0; attempt < 4 && !pool.empty(); attempt++) {
+      PgPlan plan = pg_plan(m, pool, lim2, cost2, PG_MAX);
+      say("[two terms, attempt %d: %zu candidates -> %zu groups, %zu rejected] ", attempt, pool.size(), plan.groups.size(),
+          plan.rejected.size());
+      out.insert(out.end(), plan.rejected.begin(), plan.rejected.end());
+      if (plan.groups.empty()) { pool.clear(); break; }
+      std::vector<int64_t> rejects;
+      if (build_part(plan.groups, plan.pivots, 2, &rejects)) { pool.clear(); break; }
+      if (rejects.empty()) {   // no layout at all: these states take the next part
+        for (const auto &gr : plan.groups) out.insert(out.end(), gr.begin(), gr.end());
+        pool.clear();
+        break;
+      }
+      probe_moved += (int64_t)rejects.size();
+      std::vector<uint8_t> rej((size_t)m.S, 0);
+      for (int64_t s : rejects) rej[(size_t)s] = 1;
+      out.insert(out.end(), rejects.begin(), rejects.end());
+      pool.clear();
+      for (const auto &gr : plan.groups)
+        for (int64_t s : gr)
+          if (!rej[(size_t)s]) pool.push_back(s);
+      std::sort(pool.begin(), pool.end());
+    }
+    std::sort(out.begin(), out.end());
+    cand = out;
+  }
+  if (parts.empty()) return;   // nothing qualifies for two terms around any pivot: the model's own paths
+  // part 1: three bf16 terms
+  if (!cand.empty()) {
+    PgPlan plan = pg_plan(m, cand, lim3, cost3, PG_MAX);
+    say("[three terms: %zu candidates -> %zu groups, %zu rejected] ", cand.size(), plan.groups.size(), plan.rejected.size());
+    if (!plan.groups.empty() && build_part(plan.groups, plan.pivots, 3, nullptr)) {
+      cand = plan.rejected;
+      std::sort(cand.begin(), cand.end());
+    }
+  }
+  // part 2: whatever is left, as an ordinary model
+  if (!cand.empty()) {
+    std::vector<int32_t> cols((size_t)m.S, -1);
+    HostModel sm = pg_sub_model(m, std::vector<std::vector<int64_t>>{cand}, &cols);
+    sm.pg_begin.clear();
+    sm.pg_real_end.clear();
+    auto sub = std::make_unique<aasr_gmm>();
+    sub->device = g->device;
+    sub->is_routed_sub = true;
+    sub->is_engine_part = true;
+    gmm_build(sub.get(), sm);
+    aasr_gmm::EnginePart part;
+    part.col0 = col0;
+    part.cols = (sub->S + 31) / 32 * 32;
+    part.arith = 0;
+    part.states = (int64_t)cand.size();
+    for (int64_t s = 0; s < m.S; s++)
+      if (cols[(size_t)s] >= 0) colmap[(size_t)s] = (int32_t)(col0 + cols[(size_t)s]);
+    col0 += part.cols;
+    part.model = std::move(sub);
+    parts.push_back(std::move(part));
+  }
+  for (int64_t s = 0; s < m.S; s++)
+    if (colmap[(size_t)s] < 0) raise(AASR_ERR_INVALID, "engine parts: state %ld has no column", (long)s);
+  g->engine_parts = std::move(parts);
+  g->engine_cols = col0;
+  g->engine_colmap_h = colmap;
+  g->engine_colmap.upload(colmap.data(), colmap.size());
+  g->f16_probe_moved += probe_moved;
+  // the mixed layout's own spare-column arrangement is superseded
+  g->routed_sub.reset();
+  g->routed_colmap = DevBuf<int32_t>();
 }
 
 // Track layouts for the in-register epilogue (k_gmm_diag_score_tracks).
@@ -822,10 +1235,73 @@ static void build_split_table(DevBuf<int32_t> &splits, int *max_splits, int64_t 
   splits.upload(table.data(), table.size());
 }
 
+// The same for a multi-pivot layout: every pivot group is a run of whole tiles that starts at a legal cut point
+// (cand_pg >= 0 there: the group's index), a cut must not straddle two groups, so the table has rows for R = P ...
+// PG_MAX_SPLITS only; the R - P cuts beyond the groups' own go, one at a time, to the group whose pieces are longest.
+// Entry [3] of a cut is the pivot group of the piece that starts there.
+static void build_split_table_pg(TrackLayout &L, const std::vector<int64_t> &cand_tile, const std::vector<int64_t> &cand_k0,
+                                 const std::vector<int64_t> &cand_k1, const std::vector<int> &cand_pg, int P) {
+  const int cap = PG_MAX_SPLITS;
+  std::vector<int32_t> table((size_t)cap * (cap + 1) * 4, 0);
+  std::vector<size_t> gs;   // candidate index where each group starts, + the last candidate
+  for (size_t c = 0; c + 1 < cand_tile.size(); c++)
+    if (cand_pg[c] >= 0) gs.push_back(c);
+  gs.push_back(cand_tile.size() - 1);
+  L.max_splits = 0;
+  L.split_cap = cap;
+  if ((int)gs.size() != P + 1) return;
+  for (int R = P; R <= cap; R++) {
+    std::vector<int> n((size_t)P, 1);
+    bool ok = true;
+    for (int extra = 0; extra < R - P && ok; extra++) {
+      int best = -1;
+      double bl = 0;
+      for (int gi = 0; gi < P; gi++) {
+        if ((size_t)n[(size_t)gi] >= gs[(size_t)gi + 1] - gs[(size_t)gi]) continue;   // no cut point left inside
+        const double len = (double)(cand_tile[gs[(size_t)gi + 1]] - cand_tile[gs[(size_t)gi]]) / n[(size_t)gi];
+        if (len > bl) { bl = len; best = gi; }
+      }
+      if (best < 0) ok = false;
+      else n[(size_t)best]++;
+    }
+    if (!ok) break;
+    std::vector<size_t> pick;
+    for (int gi = 0; gi < P && ok; gi++) {
+      const size_t c0 = gs[(size_t)gi], c1 = gs[(size_t)gi + 1];
+      const double t0 = (double)cand_tile[c0], span = (double)(cand_tile[c1] - cand_tile[c0]);
+      pick.push_back(c0);
+      for (int i = 1; i < n[(size_t)gi] && ok; i++) {
+        const double want = t0 + span * i / n[(size_t)gi];
+        size_t best = pick.back();
+        double bd = 1e300;
+        for (size_t c = pick.back() + 1; c < c1; c++) {
+          const double d = std::fabs((double)cand_tile[c] - want);
+          if (d < bd) { bd = d; best = c; }
+        }
+        if (best == pick.back()) ok = false;
+        pick.push_back(best);
+      }
+    }
+    if (!ok) break;
+    pick.push_back(cand_tile.size() - 1);
+    int32_t *row = &table[(size_t)(R - 1) * (cap + 1) * 4];
+    int cur_pg = 0;
+    for (int i = 0; i <= R; i++) {
+      if (cand_pg[pick[(size_t)i]] >= 0) cur_pg = cand_pg[pick[(size_t)i]];
+      row[4 * i] = (int32_t)cand_tile[pick[(size_t)i]];
+      row[4 * i + 1] = (int32_t)cand_k0[pick[(size_t)i]];
+      row[4 * i + 2] = (int32_t)cand_k1[pick[(size_t)i]];
+      row[4 * i + 3] = cur_pg;
+    }
+    L.max_splits = R;
+  }
+  L.splits.upload(table.data(), table.size());
+}
+
 // Three-term bf16 split of the coefficient rows for the bf16x3 kernel.  coef64
 // is [rows][2*D+1] in the f32 kernel's K order (k = 2d linear, 2d+1 quadratic,
-// 2D constant); the bf16 kernel uses K = 2*KH with k < KH: linear d = k, constant
-// at k = D; k >= KH: quadratic d = k - KH.
+// 2D constant); the split-term kernels put the constant first (k = 0; the f16x2
+// form keeps its remainder at k = 1) and the dimensions' pairs behind it.
 static inline uint16_t bf16_rne(float x, float *back) {
   uint32_t u;
   memcpy(&u, &x, 4);
@@ -855,13 +1331,8 @@ static void pack_bf16x3(int D, const std::vector<double> &coef64, int64_t tiles,
     const int jrow = (int)(r % TILE_ROWS);
     const int mb = jrow / 32, m32 = jrow % 32;
     for (int k = 0; k < 2 * KH; k++) {
-      double v = 0;
-      if (k < KH) {
-        if (k < D) v = c[2 * k];
-        else if (k == D) v = c[2 * D];
-      } else if (k - KH < D) {
-        v = c[2 * (k - KH) + 1];
-      }
+      // K order of the split-term kernels: the constant, (f16x2: its remainder,) then coef64's own interleaved order
+      const double v = k == 0 ? c[2 * D] : (k >= 2 && k - 2 < 2 * D ? c[k - 2] : 0.0);
       float x = (float)v, b1, b2, b3;
       uint16_t h1 = bf16_rne(x, &b1);
       uint16_t h2 = bf16_rne(x - b1, &b2);
@@ -880,7 +1351,7 @@ static void pack_bf16x3(int D, const std::vector<double> &coef64, int64_t tiles,
 }
 
 // Two-term fp16 split of the same rows for the f16x2 form (AASR_PREC_F16X2): same K order and tile layout with two
-// splits; the constant's remainder after its two terms goes to K slot KH + D (the frame operand is 1 in both).
+// splits; the constant's remainder after its two terms goes to K slot 1 (the frame operand is 1 in both).
 // Covers the tiles [0, tiles) of the layout -- the whole layout, or the first section of a mixed one; rows with
 // rs.g < 0 (and every row of a state that is not in `st_ok`, when given) are null rows.  Returns false -- and packs
 // nothing -- when a value leaves the fp16 range, or when a frame component clamped at kF16Clamp from the pivot could
@@ -896,7 +1367,7 @@ static bool pack_f16x2(const aasr_gmm *g, const std::vector<RowSpec> &rows, cons
   *bad_state = -1;
   if (nk16 <= 0) return false;
   const int KH = 8 * nk16;
-  if (KH + D >= 2 * KH) return false;  // no spare slot for the constant's remainder
+  if (2 * D + 1 >= 2 * KH) return false;  // no spare slot for the constant's remainder
   const size_t tile_elems = (size_t)nk16 * 2 * 2 * 64 * 8;
   std::vector<uint16_t> a((size_t)tiles * tile_elems, 0);
   const size_t stride = 2 * (size_t)D + 1;
@@ -905,17 +1376,11 @@ static bool pack_f16x2(const aasr_gmm *g, const std::vector<RowSpec> &rows, cons
     memcpy(&u, &h, 2);
     return u;
   };
+  const int KC = 0, KR = 1;   // K slots of the constant and of its remainder; dimension d: 2 + 2 d (linear), 3 + 2 d (quadratic)
   auto coef_of = [&](const double *c, int k, double const_rem) {
-    double v = 0;
-    if (k < KH) {
-      if (k < D) v = c[2 * k];
-      else if (k == D) v = c[2 * D];
-    } else if (k - KH < D) {
-      v = c[2 * (k - KH) + 1];
-    } else if (k - KH == D) {
-      v = const_rem;
-    }
-    return v;
+    if (k == KC) return c[2 * D];
+    if (k == KR) return const_rem;
+    return k - 2 < 2 * D ? c[k - 2] : 0.0;
   };
   // Per-column power-of-two scales: column k of the rows is divided by 2^s_k and the frame operand multiplied by it
   // (exact).  An fp16 `lo` term is a subnormal when its value is below 0.25, and a subnormal carries an ABSOLUTE error
@@ -923,37 +1388,45 @@ static bool pack_f16x2(const aasr_gmm *g, const std::vector<RowSpec> &rows, cons
   // that was 1.6e-4 (tools/fuzz_parity.py 3102, iteration 78).  Scaling every column so that its largest coefficient
   // sits at 128 bounds that product: 3e-8 x 128 from a subnormal frame term, 3e-8 x (largest term / 128) from a
   // subnormal coefficient next to a large one.
-  std::vector<double> max_a((size_t)2 * KH, 0.0);
+  const int NG = std::max(1, m.n_pg());   // pivot groups: every group has its own column scales and clamps
+  std::vector<double> max_a((size_t)NG * 2 * KH, 0.0);
   for (int64_t r = 0; r < tiles * TILE_ROWS; r++) {
     if (rows[(size_t)r].g < 0) continue;
     const double *c = &coef64[(size_t)r * stride];
     if (!(c[2 * D] > -1.0e29)) continue;   // zero-weight row: its constant is the null marker
+    double *ma = &max_a[(size_t)rows[(size_t)r].pg * 2 * KH];
     for (int k = 0; k < 2 * KH; k++) {
       double v = std::fabs(coef_of(c, k, 0.0));
-      if (k == KH + D) v = std::fabs(c[2 * D]) * 0x1p-22;   // the constant's remainder after two fp16 terms
-      max_a[(size_t)k] = std::max(max_a[(size_t)k], v);
+      if (k == KR) v = std::fabs(c[2 * D]) * 0x1p-22;   // the constant's remainder after two fp16 terms
+      ma[(size_t)k] = std::max(ma[(size_t)k], v);
     }
   }
-  std::vector<int> sk((size_t)2 * KH, 0);
-  std::vector<float> tab((size_t)3 * KH, 0.0f);   // [2 KH] frame-operand scales 2^s_k, [KH] clamp of |x - pivot|
-  for (int k = 0; k < 2 * KH; k++) {
-    int e = 0;
-    if (max_a[(size_t)k] > 0) e = (int)std::ceil(std::log2(max_a[(size_t)k] / 128.0));
-    // the constant's column carries the null rows' -60000 as well: its scale must leave 2^(-60000 * 2^s) = 0 in f32
-    // (a model whose live constants are all tiny would otherwise get s = -14 and a null row worth 2^-3.7)
-    e = std::max(k == D ? -8 : -14, std::min(14, e));
-    sk[(size_t)k] = e;
-    tab[(size_t)k] = (float)std::ldexp(1.0, e);
-  }
-  for (int d = 0; d < D; d++) {
-    // one clamp per dimension keeps x' 2^s and x'^2 2^s inside the fp16 range
-    const double x_lin = 60000.0 * std::ldexp(1.0, -sk[(size_t)d]);
-    const double x_quad = std::sqrt(60000.0 * std::ldexp(1.0, -sk[(size_t)(KH + d)]));
-    tab[(size_t)2 * KH + d] = (float)(0.99 * std::min((double)kF16Clamp, std::min(x_lin, x_quad)));
+  std::vector<int> sk((size_t)NG * 2 * KH, 0);
+  std::vector<float> tab((size_t)NG * 3 * KH, 0.0f);   // per group: [2 KH] frame-operand scales 2^s_k, [KH] clamp of |x - pivot|
+  for (int gi = 0; gi < NG; gi++) {
+    int *skg = &sk[(size_t)gi * 2 * KH];
+    float *tabg = &tab[(size_t)gi * 3 * KH];
+    for (int k = 0; k < 2 * KH; k++) {
+      int e = 0;
+      if (max_a[(size_t)gi * 2 * KH + k] > 0) e = (int)std::ceil(std::log2(max_a[(size_t)gi * 2 * KH + k] / 128.0));
+      // the constant's column carries the null rows' -60000 as well: its scale must leave 2^(-60000 * 2^s) = 0 in f32
+      // (a model whose live constants are all tiny would otherwise get s = -14 and a null row worth 2^-3.7)
+      e = std::max(k == KC ? -8 : -14, std::min(14, e));
+      skg[(size_t)k] = e;
+      tabg[(size_t)k] = (float)std::ldexp(1.0, e);
+    }
+    for (int d = 0; d < D; d++) {
+      // one clamp per dimension keeps x' 2^s and x'^2 2^s inside the fp16 range
+      const double x_lin = 60000.0 * std::ldexp(1.0, -skg[(size_t)(2 + 2 * d)]);
+      const double x_quad = std::sqrt(60000.0 * std::ldexp(1.0, -skg[(size_t)(3 + 2 * d)]));
+      tabg[(size_t)2 * KH + d] = (float)(0.99 * std::min((double)kF16Clamp, std::min(x_lin, x_quad)));
+    }
   }
   for (int64_t r = 0; r < tiles * TILE_ROWS; r++) {
     const double *c = &coef64[(size_t)r * stride];
     const RowSpec &rs = rows[(size_t)r];
+    const int *skg = &sk[(size_t)rs.pg * 2 * KH];
+    const float *tabg = &tab[(size_t)rs.pg * 3 * KH];
     if (rs.g >= 0) {
       // clamp guarantee: peak - 1/2 p (clamp - |mu'|)^2 far below the floor in every dimension
       double prod = 1;
@@ -965,7 +1438,8 @@ static bool pack_f16x2(const aasr_gmm *g, const std::vector<RowSpec> &rows, cons
       for (int d = 0; d < D; d++) {
         const double v = m.var[(size_t)rs.g * D + d];
         const double p = v > 0 ? 1 / v : 0;
-        const double reach = (double)tab[(size_t)2 * KH + d] - std::fabs(m.mean[(size_t)rs.g * D + d] - (double)g->pivot[d]);
+        const double reach = (double)tabg[(size_t)2 * KH + d] -
+                             std::fabs(m.mean[(size_t)rs.g * D + d] - (double)g->pivot[(size_t)rs.pg * D + d]);
         if (!(reach > 0) || !(peak - 0.5 * p * reach * reach < -160.0)) {
           *bad_state = row_state[(size_t)r];
           return false;
@@ -977,17 +1451,17 @@ static bool pack_f16x2(const aasr_gmm *g, const std::vector<RowSpec> &rows, cons
     const int mb = jrow / 32, m32 = jrow % 32;
     double const_rem = 0;
     for (int k = 0; k < 2 * KH; k++) {
-      double v = std::ldexp(coef_of(c, k, const_rem), k == KH + D ? 0 : -sk[(size_t)k]);
+      double v = std::ldexp(coef_of(c, k, const_rem), k == KR ? 0 : -skg[(size_t)k]);
       // null / zero-weight rows carry kNullConst: any constant whose 2^x is zero in f32 does
-      if (k == D && c[2 * D] <= -1.0e29) v = -60000.0;
+      if (k == KC && c[2 * D] <= -1.0e29) v = -60000.0;
       if (!(std::fabs(v) <= 60000.0)) {
         *bad_state = rs.g >= 0 ? row_state[(size_t)r] : -1;
         return false;
       }
       const _Float16 h1 = (_Float16)v;
       const _Float16 h2 = (_Float16)(v - (double)h1);
-      // what the two terms left of the constant goes to slot KH + D in that slot's own scale
-      if (k == D) const_rem = std::ldexp((v - (double)h1) - (double)h2, sk[(size_t)D] - sk[(size_t)(KH + D)]);
+      // what the two terms left of the constant goes to the remainder's slot in that slot's own scale
+      if (k == KC) const_rem = std::ldexp((v - (double)h1) - (double)h2, skg[(size_t)KC] - skg[(size_t)KR]);
       const uint16_t hs[2] = {bits(h1), bits(h2)};
       const int slab = k / 16, hk = (k % 16) / 8, i = k % 8;
       const int lane = hk * 32 + m32;
@@ -997,8 +1471,9 @@ static bool pack_f16x2(const aasr_gmm *g, const std::vector<RowSpec> &rows, cons
       }
     }
   }
+  if (m.n_pg() > 0) L.pg_tab.upload(tab.data(), tab.size());
   L.a16h.upload(a.data(), a.size());
-  L.f16tab.upload(tab.data(), tab.size());
+  L.f16tab.upload(tab.data(), (size_t)3 * KH);   // (the first group's: what single-pivot launches read)
   return true;
 }
 
@@ -1051,6 +1526,10 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
   L.mapped = false;
   L.n_sections = 0;
   L.states_f16 = 0;
+  L.n_pg = 0;
+  L.split_cap = TRACK_MAX_SPLITS;
+  const int P = m.n_pg();   // pivot groups (engine-internal multi-pivot models): grouped layouts only
+  if (P > 0 && (!grouped || f16_ok)) return;
   double ref = 0;
   if (!choose_reference(m, g->outlier, &ref)) return;
   L.ref_ln = (float)(ref * 0.69314718055994530942);
@@ -1059,7 +1538,16 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
 
   // ---- the sections' states, ascending
   std::vector<int64_t> order[2];
-  for (int64_t s = 0; s < m.S; s++) order[mixed && !(*f16_ok)[(size_t)s] ? 1 : 0].push_back(s);
+  std::vector<int> st_pg;   // pivot group of every state
+  if (P > 0) st_pg.resize((size_t)m.S);
+  for (int64_t s = 0; s < m.S; s++) {
+    if (P > 0) {
+      const int pgi = m.pg_of_state(s);
+      st_pg[(size_t)s] = pgi;
+      if (s >= m.pg_real_end[(size_t)pgi]) continue;   // a padding column: no rows, never closed
+    }
+    order[mixed && !(*f16_ok)[(size_t)s] ? 1 : 0].push_back(s);
+  }
   const int n_sec = mixed ? 2 : 1;
   if (mixed && (order[0].empty() || order[1].empty())) return;   // nothing to route
 
@@ -1068,7 +1556,7 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
   std::vector<int64_t> st_pos((size_t)m.S);
   int64_t len[2] = {0, 0};
   int64_t closed[2] = {0, 0};
-  struct Cand { std::vector<int64_t> tile, k0, k1; };
+  struct Cand { std::vector<int64_t> tile, k0, k1; std::vector<int> pg; };   // pg: the pivot group that starts there, -1: none
   Cand cand[2];
   struct PairEv { int64_t s0, s1, last; bool f16, f32; };   // grouped: the pair's states, its last quad, its flush flags
   std::vector<PairEv> pairs;
@@ -1086,6 +1574,8 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
     cand[sc].tile.push_back(std::max(len[0], len[1]) / 8);
     cand[sc].k0.push_back(closed[0]);
     cand[sc].k1.push_back(closed[1]);
+    cand[sc].pg.push_back(P > 0 ? 0 : -1);
+    int cur_pg = 0;
     if (sec_grouped(sc)) {
       // Pairs are formed inside groups of 16 output columns: (16 g, 16 g + 1), ... for the whole model, neighbours among
       // the section's states of a group for a subset (a lone state takes a pair with an empty partner track).  A group
@@ -1093,6 +1583,24 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
       size_t i = 0;
       while (i < st.size()) {
         const int64_t a = st[i];
+        if (P > 0 && st_pg[(size_t)a] != cur_pg) {
+          // a pivot group starts: on a whole tile (the groups are runs of whole tiles), on a whole line of output
+          // columns (the close counters jump to the group's first column), at a cut point of its own
+          cur_pg = st_pg[(size_t)a];
+          const int64_t top = (len[0] + 7) / 8 * 8;
+          len[0] = len[1] = top;
+          closed[0] = closed[1] = m.pg_begin[(size_t)cur_pg] / 2;
+          if (cand[sc].tile.back() == top / 8 && cand[sc].tile.size() > 1) {
+            cand[sc].k0.back() = closed[0];
+            cand[sc].k1.back() = closed[1];
+            cand[sc].pg.back() = cur_pg;
+          } else {
+            cand[sc].tile.push_back(top / 8);
+            cand[sc].k0.push_back(closed[0]);
+            cand[sc].k1.push_back(closed[1]);
+            cand[sc].pg.push_back(cur_pg);
+          }
+        }
         int64_t b = -1;
         if (i + 1 < st.size() && (st[i + 1] >> 4) == (a >> 4)) b = st[i + 1];
         const size_t nxt = i + (b >= 0 ? 2 : 1);
@@ -1116,6 +1624,7 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
           cand[sc].tile.push_back(len[0] / 8);
           cand[sc].k0.push_back(closed[0]);
           cand[sc].k1.push_back(closed[1]);
+          cand[sc].pg.push_back(-1);
         }
         i = nxt;
       }
@@ -1139,6 +1648,7 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
           cand[sc].tile.push_back(top / 8);
           cand[sc].k0.push_back(closed[0]);
           cand[sc].k1.push_back(closed[1]);
+          cand[sc].pg.push_back(-1);
           next_sync = top + sync_every;
         }
       }
@@ -1149,18 +1659,20 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
     len[0] = len[1] = top;
     int64_t end_tile = top / 8;
     if (sc == n_sec - 1) end_tile = std::max<int64_t>(1, end_tile);
-    if (cand[sc].tile.back() == end_tile && cand[sc].tile.size() > 1) {  // the end is always the last boundary
+    if (cand[sc].tile.back() == end_tile && cand[sc].tile.size() > 1 && cand[sc].pg.back() < 0) {  // the end is always the last boundary
       cand[sc].tile.pop_back();
       cand[sc].k0.pop_back();
       cand[sc].k1.pop_back();
+      cand[sc].pg.pop_back();
     }
     cand[sc].tile.push_back(end_tile);
     cand[sc].k0.push_back(closed[0]);
     cand[sc].k1.push_back(closed[1]);
+    cand[sc].pg.push_back(-1);
     sec_tile[sc + 1] = end_tile;
   }
   const int64_t tiles = std::max<int64_t>(1, sec_tile[n_sec]);
-  if (grouped && (double)(quads_used * 8) > 1.25 * (double)rows_real + 64 * n_sec) return;  // too much padding
+  if (grouped && (double)(quads_used * 8) > 1.25 * (double)rows_real + 64 * (n_sec + P)) return;  // too much padding
 
   // ---- rows, close bits, per-track state lists / pair table
   std::vector<RowSpec> rows((size_t)tiles * TILE_ROWS, RowSpec{-1, 0.0, 0.0});
@@ -1175,7 +1687,7 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
       for (int32_t k = a; k < b; k++) {
         if (!g->outlier.empty() && g->outlier[(size_t)m.mix_idx[k]]) continue;  // stays a null row
         const int64_t r = track_row(p0 + (k - a) / 4, h, (k - a) % 4);
-        rows[(size_t)r] = RowSpec{m.mix_idx[k], m.logw((size_t)k), ref};
+        rows[(size_t)r] = RowSpec{m.mix_idx[k], m.logw((size_t)k), ref, P > 0 ? st_pg[(size_t)s] : 0};
         row_state[(size_t)r] = (int32_t)s;
       }
       if (!sec_grouped(sc)) {
@@ -1215,7 +1727,13 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
     L.mapped = true;
   }
   // row-cut tables: the whole layout (or, mixed, one per section)
-  if (!mixed) {
+  if (P > 0) {
+    build_split_table_pg(L, cand[0].tile, cand[0].k0, cand[0].k1, cand[0].pg, P);
+    if (L.max_splits < P) return;
+    L.n_pg = P;
+    L.pg_pivot.upload(m.pg_pivot.data(), m.pg_pivot.size());
+    L.pg_colend.upload(m.pg_real_end.data(), m.pg_real_end.size());
+  } else if (!mixed) {
     build_split_table(L.splits, &L.max_splits, tiles, cand[0].tile, cand[0].k0, cand[0].k1);
   } else {
     L.n_sections = 2;
@@ -1241,8 +1759,11 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
       g->f16_bad_state = bad_state;   // the caller may move that state to the other section and try again
       return;
     }
-  } else if (f16_env && g->kappa_matrix <= KAPPA_LIMIT_F16 &&
-             g->kappa2_matrix <= (m.dim < 8 ? KAPPA2_LIMIT_F16_LOWDIM : KAPPA2_LIMIT_F16)) {
+  } else if (P > 0 && m.pg_arith != 2) {
+    // a three-term multi-pivot model: no fp16 rows
+  } else if (f16_env && (P > 0 ||   // (a multi-pivot model: the planner put only states that qualify here)
+                         (g->kappa_matrix <= KAPPA_LIMIT_F16 &&
+                          g->kappa2_matrix <= (m.dim < 8 ? KAPPA2_LIMIT_F16_LOWDIM : KAPPA2_LIMIT_F16)))) {
     if (pack_f16x2(g, rows, row_state, coef64, tiles, L, &bad_state)) L.states_f16 = m.S;
     else g->f16_bad_state = bad_state;
   }

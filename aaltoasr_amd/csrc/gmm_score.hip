@@ -640,8 +640,15 @@ static bool launch_tracks(const aasr_gmm *g, const TrackLayout &L, const float *
 // f32-class accuracy (dropped terms are 2^-24 relative; every MFMA rounds once
 // per 16 products instead of once per product), and the bf16 pipe co-executes
 // with the VALU epilogue of the other wave on the SIMD.
-// K order: k < KH: linear term of dimension k (k == dim: the constant, B = 1);
-// k >= KH: quadratic term of dimension k - KH; KH = 8*NK16.
+// K order (constant first, then interleaved): k = 0: the constant (B = 1), k = 1: the constant's remainder (f16x2; B = 1),
+// k = 2 + 2 d: linear term of dimension d, k = 3 + 2 d: its quadratic term, zero beyond; K = 16 NK16 >= 2 dim + 2.  A
+// dimension's two terms -- p mu' x' and -p/2 x'^2, each as large as the conditioning estimates say and of opposite sign
+// -- meet inside ONE matrix instruction, whose 16 products are summed before the f32 accumulator rounds, and the chain
+// starts from the constant (which holds -kappa/2): the running sum then moves from C towards the result by
+// (kappa_d - z_d^2)/2 per dimension and never leaves their range.  (Until round 5 the order was all linear terms, the
+// constant, then all quadratic terms: the accumulator climbed to the linear terms' sum, ~kappa + sqrt(kappa) |z| log2
+// units, and every later instruction rounded at that magnitude -- the dominant error of both split forms on models
+// fitted to data, 1.6e-4 on visible values where this order gives 6e-5.)
 // ---------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -673,7 +680,7 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &p1, un
 // state-level error is 3.4e-5 against 1.9e-5 (tools/exp_fp16_split.py), and the error grows with the
 // model's conditioning estimate as the other forms' does, so it is only chosen below tighter limits
 // (KAPPA_LIMIT_F16, gmm.h); models above them keep the bf16x3 form.  The constant rides in TWO K slots
-// (k = dim and k = KH + dim, the frame operand is 1 in both): 44 bits, so the largest term of the sum
+// (k = 2 dim and k = 2 dim + 1, the frame operand is 1 in both): 44 bits, so the largest term of the sum
 // loses nothing.  fp16 range: the frame operand is clamped to |x - pivot| <= kF16Clamp (its square stays
 // finite); load-time eligibility guarantees that a frame that far out is at the 1e-50 floor either way.
 // ---------------------------------------------------------------------------
@@ -728,7 +735,6 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   constexpr int kTileBytes = Bf16Smem<NK16, GROUPED, WIDE, NS>::kTileBytes;
   constexpr int kTileFloats = kTileBytes / 4;
   constexpr int kOS = Bf16Smem<NK16, GROUPED, WIDE, NS>::kOutStride;
-  constexpr int KH = 8 * NK16;
   constexpr int NW = WIDE ? 8 : 4;    // waves per workgroup
   constexpr int NBUF = WIDE ? 3 : 2;  // tile buffers
   // WIDE: slabs before the mid-stream barrier.  Between two barriers one wave of a SIMD runs the slabs behind its
@@ -765,13 +771,14 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         const int k = 16 * j + 8 * h + i;
-        const int d = k < KH ? k : k - KH;
-        const int dc = d < dim ? d : 0;
+        const int d = (k >> 1) - 1;   // k = 0 / 1: the constant's slots
+        const int dc = d >= 0 && d < dim ? d : 0;
         const float xc = xr[dc] - pivot[dc];
         float xq = xc;
         if (NS == 2) xq = fminf(fmaxf(xc, -kF16Clamp), kF16Clamp);  // fp16 range (see the f16x2 note above)
-        float val = k < KH ? xq : xq * xq;
-        if (d >= dim) val = (k == dim || (NS == 2 && k == KH + dim)) ? 1.0f : 0.0f;
+        float val = (k & 1) ? xq * xq : xq;
+        if (d < 0) val = (k == 0 || NS == 2) ? 1.0f : 0.0f;
+        else if (d >= dim) val = 0.0f;
         v[i] = val;
       }
       if constexpr (NS == 3) {
@@ -1062,6 +1069,12 @@ struct CutPlan {
   const int32_t *split_rem = nullptr;   // cut table row of the fine part
 };
 
+// Pivot groups of a launch (nullptr colend: one pivot, the model's)
+struct PivotGroups {
+  const int32_t *colend = nullptr;   // [groups] one past the group's last output column
+  int64_t fop_stride = 0;            // u32x4 elements between the groups' frame-operand images
+};
+
 template <int NK16, bool GROUPED, bool WIDE, int NS>
 struct PlSmem {
   static constexpr int kTileBytes = NK16 * NS * 2 * 64 * 16;
@@ -1098,7 +1111,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
     const uint16_t *__restrict__ close_mask, const int32_t *__restrict__ sid, int sid_stride,
     float *__restrict__ out, int64_t S, int64_t pitch, float ref_ln, int dbg, ClusterArgs cl,
-    const u32x4 *__restrict__ fop, CutPlan plan) {
+    const u32x4 *__restrict__ fop, CutPlan plan, PivotGroups pg) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   typedef PlSmem<NK16, GROUPED, WIDE, NS> SM;
   // work item -> (frame block, row cut): the first n_main workgroups take the coarse cuts of the frame blocks that fill
@@ -1166,6 +1179,14 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   const int64_t t_end = split_row[4 * cut + 4];
   if (t_begin < t_end) issue_tile(t_begin, 0);
   if (t_begin + 1 < t_end) issue_tile(t_begin + 1, 1);
+  // pivot groups (multi-pivot layouts, gmm.h TrackLayout::n_pg): a row cut lies inside ONE group -- its rows are expanded
+  // around that group's pivot, so the workgroup takes that group's image of the frame operand, and the group's columns end
+  // at its own limit (its last line goes out partly filled, the next group starts on a whole line)
+  if (pg.colend) {
+    const int gi = split_row[4 * cut + 3];
+    fop += (size_t)gi * pg.fop_stride;
+    S = pg.colend[gi];
+  }
 
   // ---- frame operand: lane (n, h) holds k = 16*j + 8*h + i, i < 8, of slab j -- split into its terms ONCE per launch by
   // k_frame_operand (below the kernel) and fetched here with 16-byte loads, 64 lanes x 16 B contiguous per instruction.
@@ -1489,13 +1510,14 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
 // the register layout of k_gmm_diag_score_pl -- [block][slab j][term][frame half nb][lane (n, h)] x 8 halves, K slot
 // k = 16 j + 8 h + i -- so that a wave's prologue is NK16 * NS * 2 coalesced 16-byte loads.  Per value the arithmetic of
 // the former in-kernel prologue: (x - pivot), the dimension's clamp and the column's power-of-two scale (f16x2), the
-// square for k >= KH, 1 in the constant's slot(s), then the two fp16 / three bf16 terms.  Frames past the end repeat the
+// square for odd k, 1 in the constant's slot(s), then the two fp16 / three bf16 terms.  Frames past the end repeat the
 // last one (their results are never stored).  One thread per (frame, slab, K half).
 // ---------------------------------------------------------------------------
 template <int NS>
 __global__ __launch_bounds__(256) void k_frame_operand(const float *__restrict__ frames, int64_t F, int dim,
                                                        const float *__restrict__ pivot, const float *__restrict__ f16tab,
-                                                       int nk16, u32x4 *__restrict__ out, int64_t n_units) {
+                                                       int nk16, u32x4 *__restrict__ out, int64_t n_units, int n_pg,
+                                                       int64_t pg_stride) {
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int lane = (int)(tid & 63);
   const int64_t unit = tid >> 6;   // (block of 64 frames, frame half, slab)
@@ -1508,88 +1530,103 @@ __global__ __launch_bounds__(256) void k_frame_operand(const float *__restrict__
   int64_t f = blk * 64 + nb * 32 + n;
   if (f > F - 1) f = F - 1;
   const float *xr = frames + f * dim;
-  float v[8];
-  // the thread's 8 K slots are 8 consecutive dimensions d0 .. d0 + 7 (linear terms for k < KH, quadratic from KH on: a
-  // slab half never straddles KH).  Where they all exist the frame components, pivots, clamps and scales come as two
-  // 16-byte loads each (rows are 4-byte aligned; the tables' loads are the same for every lane of a K half)
+  // the thread's 8 K slots are four (linear, quadratic) pairs: pair u = k / 2 is the constant's two slots for u = 0 and
+  // dimension u - 1 otherwise (the K order at the top of the split-term kernels), so a thread handles 4 consecutive
+  // dimensions d0 .. d0 + 3 (three and the constant in the first slab's first half).  Where they all exist the frame
+  // components, pivots and clamps come as one 16-byte load each, the column scales as two (rows are 4-byte aligned; the
+  // tables' loads are the same for every lane of a K half)
   const int k0 = 16 * j + 8 * h;
-  const int d0 = k0 < KH ? k0 : k0 - KH;
+  const int d0 = (k0 >> 1) - 1;
   typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-  if (d0 + 8 <= dim) {   // uniform per K half
-    float x[8], pv[8], lim[8], sc[8];
+  const bool whole = d0 >= 0 && d0 + 4 <= dim;   // uniform per K half
+  float x[4];
+  if (whole) {
+    const f32x4u a = *(const f32x4u *)(xr + d0);
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-      const f32x4u a = *(const f32x4u *)(xr + d0 + 4 * q), b = *(const f32x4u *)(pivot + d0 + 4 * q);
-      f32x4u c = {0, 0, 0, 0}, e = {1, 1, 1, 1};
+    for (int i = 0; i < 4; i++) x[i] = a[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = xr[d0 + i >= 0 && d0 + i < dim ? d0 + i : 0];
+  }
+  u32x4 *o = out + ((size_t)(blk * nk16 + j) * NS * 2 + nb) * 64 + lane;   // + term * 2 * 64
+  // one image per pivot group (multi-pivot layouts; n_pg = 1 otherwise): the frame is read once
+  for (int g = 0; g < n_pg; g++, pivot += dim, f16tab += (NS == 2 ? 3 * KH : 0), o += pg_stride) {
+    float v[8];
+    if (whole) {
+      const f32x4u b = *(const f32x4u *)(pivot + d0);
+      f32x4u c = {0, 0, 0, 0}, e0 = {1, 1, 1, 1}, e1 = {1, 1, 1, 1};
       if (NS == 2) {
-        c = *(const f32x4u *)(f16tab + 2 * KH + d0 + 4 * q);
-        e = *(const f32x4u *)(f16tab + k0 + 4 * q);
+        c = *(const f32x4u *)(f16tab + 2 * KH + d0);
+        e0 = *(const f32x4u *)(f16tab + k0);
+        e1 = *(const f32x4u *)(f16tab + k0 + 4);
       }
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        x[4 * q + i] = a[i];
-        pv[4 * q + i] = b[i];
-        lim[4 * q + i] = c[i];
-        sc[4 * q + i] = e[i];
+        const float xc = x[i] - b[i];
+        float xq = xc;
+        if (NS == 2) xq = fminf(fmaxf(xc, -c[i]), c[i]);   // fp16 range: the dimension's clamp (pack_f16x2)
+        float lin = xq, quad = xq * xq;
+        if (NS == 2) {   // the columns' power-of-two scales (the rows carry their inverses): exact
+          lin *= i < 2 ? e0[2 * i] : e1[2 * i - 4];
+          quad *= i < 2 ? e0[2 * i + 1] : e1[2 * i - 3];
+        }
+        v[2 * i] = lin;
+        v[2 * i + 1] = quad;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int k = k0 + i;
+        const int d = (k >> 1) - 1;
+        const int dc = d >= 0 && d < dim ? d : 0;
+        const float xc = x[i >> 1] - pivot[dc];
+        float xq = xc;
+        if (NS == 2) {  // fp16 range: the dimension's clamp (see the f16x2 note above and pack_f16x2)
+          const float lim = f16tab[2 * KH + dc];
+          xq = fminf(fmaxf(xc, -lim), lim);
+        }
+        float val = (k & 1) ? xq * xq : xq;
+        if (d < 0) val = (k == 0 || NS == 2) ? 1.0f : 0.0f;   // the constant and (f16x2) its remainder
+        else if (d >= dim) val = 0.0f;
+        if (NS == 2) val *= f16tab[k];   // the column's power-of-two scale (the rows carry its inverse): exact
+        v[i] = val;
       }
     }
+    if constexpr (NS == 3) {
+      unsigned w1[4], w2[4], w3[4];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const float xc = x[i] - pv[i];
-      float xq = xc;
-      if (NS == 2) xq = fminf(fmaxf(xc, -lim[i]), lim[i]);   // fp16 range: the dimension's clamp (pack_f16x2)
-      float val = k0 < KH ? xq : xq * xq;
-      if (NS == 2) val *= sc[i];   // the column's power-of-two scale (the rows carry its inverse): exact
-      v[i] = val;
+      for (int i = 0; i < 4; i++) split3_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i], w3[i]);
+      o[0] = u32x4{w1[0], w1[1], w1[2], w1[3]};
+      o[2 * 64] = u32x4{w2[0], w2[1], w2[2], w2[3]};
+      o[4 * 64] = u32x4{w3[0], w3[1], w3[2], w3[3]};
+    } else {
+      unsigned w1[4], w2[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) split2_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i]);
+      o[0] = u32x4{w1[0], w1[1], w1[2], w1[3]};
+      o[2 * 64] = u32x4{w2[0], w2[1], w2[2], w2[3]};
     }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int k = k0 + i;
-      const int d = k < KH ? k : k - KH;
-      const int dc = d < dim ? d : 0;
-      const float xc = xr[dc] - pivot[dc];
-      float xq = xc;
-      if (NS == 2) {  // fp16 range: the dimension's clamp (see the f16x2 note above and pack_f16x2)
-        const float lim = f16tab[2 * KH + dc];
-        xq = fminf(fmaxf(xc, -lim), lim);
-      }
-      float val = k < KH ? xq : xq * xq;
-      if (d >= dim) val = (k == dim || (NS == 2 && k == KH + dim)) ? 1.0f : 0.0f;
-      if (NS == 2) val *= f16tab[k];   // the column's power-of-two scale (the rows carry its inverse): exact
-      v[i] = val;
-    }
-  }
-  u32x4 *o = out + ((size_t)(blk * nk16 + j) * NS * 2 + nb) * 64 + lane;   // + term * 2 * 64
-  if constexpr (NS == 3) {
-    unsigned w1[4], w2[4], w3[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) split3_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i], w3[i]);
-    o[0] = u32x4{w1[0], w1[1], w1[2], w1[3]};
-    o[2 * 64] = u32x4{w2[0], w2[1], w2[2], w2[3]};
-    o[4 * 64] = u32x4{w3[0], w3[1], w3[2], w3[3]};
-  } else {
-    unsigned w1[4], w2[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) split2_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i]);
-    o[0] = u32x4{w1[0], w1[1], w1[2], w1[3]};
-    o[2 * 64] = u32x4{w2[0], w2[1], w2[2], w2[3]};
   }
 }
 
 // frame operand of `blocks64` blocks of 64 frames into the handle's scratch (grown as needed)
 template <int NS>
 static const u32x4 *frame_operand(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
-                                  int64_t blocks64, hipStream_t stream) {
+                                  int64_t blocks64, hipStream_t stream, int64_t *pg_stride) {
   const size_t per_block = (size_t)L.nk16 * NS * 2 * 64;   // u32x4 per 64 frames
-  if (blocks64 * per_block * 4 > g->fop_scratch.n) {
+  const int n_pg = L.n_pg > 1 ? L.n_pg : 1;
+  const size_t image = (size_t)blocks64 * per_block;       // u32x4 per pivot group
+  if (image * n_pg * 4 > g->fop_scratch.n) {
     AASR_HIP(hipDeviceSynchronize());   // growing frees the old buffer
-    g->fop_scratch.ensure(blocks64 * per_block * 4);
+    g->fop_scratch.ensure(image * n_pg * 4);
   }
   const int64_t n_units = blocks64 * 2 * L.nk16;
   hipLaunchKernelGGL(k_frame_operand<NS>, dim3((unsigned)((n_units * 64 + 255) / 256)), dim3(256), 0, stream, d_frames, F,
-                     g->dim, g->d_pivot.p, NS == 2 ? L.f16tab.p : nullptr, L.nk16, (u32x4 *)g->fop_scratch.p, n_units);
+                     g->dim, L.n_pg > 1 ? L.pg_pivot.p : g->d_pivot.p,
+                     NS == 2 ? (L.n_pg > 1 ? L.pg_tab.p : L.f16tab.p) : nullptr, L.nk16, (u32x4 *)g->fop_scratch.p, n_units,
+                     n_pg, (int64_t)image);
   AASR_HIP(hipGetLastError());
+  *pg_stride = (int64_t)image;
   return (const u32x4 *)g->fop_scratch.p;
 }
 
@@ -1622,7 +1659,7 @@ static int pick_row_cuts(int64_t blocks, double slots, int64_t tiles, int max_sp
 // 768 blocks x 2 cuts (6 rounds) + 110 blocks x 16 cuts (6.9 short rounds) instead of 7 long ones.  Same cost model as
 // pick_row_cuts; falls back to the uniform plan when that is no better.
 static CutPlan pick_cut_plan(int64_t blocks, double slots_d, int64_t tiles, int max_splits, double overhead,
-                             const int32_t *splits_base) {
+                             const int32_t *splits_base, int min_splits = 1, int split_cap = TRACK_MAX_SPLITS) {
   static const int force_r = getenv("AASR_SPLITS") ? atoi(getenv("AASR_SPLITS")) : 0;
   static const double force_c = getenv("AASR_CUT_OVERHEAD") ? atof(getenv("AASR_CUT_OVERHEAD")) : -1.0;
   static const int two_level = getenv("AASR_TWO_LEVEL") ? atoi(getenv("AASR_TWO_LEVEL")) : 1;
@@ -1630,9 +1667,9 @@ static CutPlan pick_cut_plan(int64_t blocks, double slots_d, int64_t tiles, int 
   const int64_t slots = (int64_t)slots_d;
   CutPlan best;
   double best_cost = 1e300;
-  auto row = [&](int r) { return splits_base + (size_t)(r - 1) * (TRACK_MAX_SPLITS + 1) * 4; };
-  for (int r1 = 1; r1 <= max_splits; r1++) {
-    if (force_r >= 1 && force_r <= max_splits && r1 != force_r) continue;
+  auto row = [&](int r) { return splits_base + (size_t)(r - 1) * (split_cap + 1) * 4; };
+  for (int r1 = min_splits; r1 <= max_splits; r1++) {   // (multi-pivot layouts: every pivot group is at least one cut)
+    if (force_r >= min_splits && force_r <= max_splits && r1 != force_r) continue;
     // uniform
     const double uni = std::ceil((double)blocks * r1 / slots_d) * ((double)tiles / r1 + overhead);
     if (uni < best_cost * 0.999) {
@@ -1707,16 +1744,20 @@ static void launch_pl_t(const aasr_gmm *g, const TrackLayout &L, const TrackSect
     attr_set[g->device & 63] = true;
   }
   const int32_t *splits_base = sec ? sec->splits.p : L.splits.p;
+  const bool multi = !sec && L.n_pg > 1;   // pivot groups: every group at least one cut, its own image of the frame operand
+  const int cap = multi ? L.split_cap : TRACK_MAX_SPLITS;
   const CutPlan plan = pick_cut_plan(blocks, (WIDE ? 1.0 : 2.0) * (g->num_cus > 0 ? g->num_cus : 256),
                                      sec ? sec->tile_end - sec->tile_begin : L.rows_padded / TILE_ROWS,
-                                     sec ? sec->max_splits : L.max_splits, 3.0, splits_base);
-  const int32_t *split_row = splits_base + (size_t)(plan.r_main - 1) * (TRACK_MAX_SPLITS + 1) * 4;
-  const u32x4 *fop = frame_operand<NS>(g, L, d_frames, F, blocks * NW, stream);
+                                     sec ? sec->max_splits : L.max_splits, 3.0, splits_base, multi ? L.n_pg : 1, cap);
+  const int32_t *split_row = splits_base + (size_t)(plan.r_main - 1) * (cap + 1) * 4;
+  PivotGroups pg;
+  const u32x4 *fop = frame_operand<NS>(g, L, d_frames, F, blocks * NW, stream, &pg.fop_stride);
+  if (multi) pg.colend = L.pg_colend.p;
   const unsigned n_items = (unsigned)(plan.n_main + (plan.r_rem ? plan.blocks_rem * plan.r_rem : 0));
   hipLaunchKernelGGL(kern, dim3(n_items), dim3(NW * 64), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, NS == 3 ? L.a16.p : L.a16h.p, split_row, L.close.p,
                      MAPPED ? L.pmap.p : L.sid.p, MAPPED ? 0 : L.sid_stride,
-                     d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, dbg, cl, fop, plan);
+                     d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, dbg, cl, fop, plan, pg);
   AASR_HIP(hipGetLastError());
 }
 
@@ -1724,7 +1765,9 @@ static void launch_pl_t(const aasr_gmm *g, const TrackLayout &L, const TrackSect
 template <int N, int NS>
 static constexpr bool wide_ok() {
   if (NS == 2) return PlSmem<N, true, true, NS>::kBytes <= 160 * 1024;
-  return 3 * Bf16Smem<N, true, true, NS>::kTileBytes + 8 * Bf16Smem<N, true, true, NS>::kOutFloatsPerWave * 4 <= 160 * 1024;
+  // (three terms: the wave-group kernel, or -- multi-pivot layouts -- the pipelined one: room for either)
+  return 3 * Bf16Smem<N, true, true, NS>::kTileBytes + 8 * Bf16Smem<N, true, true, NS>::kOutFloatsPerWave * 4 <= 160 * 1024 &&
+         PlSmem<N, true, true, NS>::kBytes <= 160 * 1024;
 }
 
 // NS = 3: three bf16 terms (AASR_PREC_BF16X3) on the wave-group kernel; NS = 2: two fp16 terms (AASR_PREC_F16X2) on
@@ -1754,7 +1797,10 @@ static bool launch_split(const aasr_gmm *g, const TrackLayout &L, const float *d
       if constexpr (GR && NS == 2) launch_pl_t<N, true, CLF, WD, NS, true>(g, L, sec, d_frames, F, d_out, stream, CLA, pitch); \
     } else if constexpr (NS == 2 || AASR_PL_BF16X3)                                        \
       launch_pl_t<N, GR, CLF, WD, NS>(g, L, sec, d_frames, F, d_out, stream, CLA, pitch);   \
-    else                                                                                   \
+    else if (L.n_pg > 1) {                                                                  \
+      /* three bf16 terms on a multi-pivot layout: the pipelined kernel takes the groups' operand images */ \
+      if constexpr (GR && !CLF) launch_pl_t<N, true, false, WD, NS>(g, L, sec, d_frames, F, d_out, stream, CLA, pitch); \
+    } else                                                                                 \
       launch_bf16_t<N, GR, CLF, WD, NS>(g, L, sec, d_frames, F, d_out, stream, CLA, pitch); \
   } while (0)
 #define AASR_CASE(N)                                                                       \
@@ -1915,6 +1961,7 @@ void gmm_probe_f16x2(aasr_gmm *g) {
     g->f16_probe_moved += n_bad;
     for (int64_t s2 = 0; s2 < S; s2++)
       if (bad[(size_t)s2]) g->f16_state_ok[(size_t)s2] = 0;
+    if (m.n_pg() > 0) return;   // a multi-pivot engine part: the planner takes the marked states out and builds it again
     // the whole-model fp16 rows are gone; what still qualifies goes to the mixed layout
     g->paired.a16h = DevBuf<uint16_t>();
     g->paired.states_f16 = 0;
@@ -2965,6 +3012,43 @@ extern "C" int aasr_debug_active_layout(const aasr_gmm *g) {
 }
 extern "C" double aasr_debug_kappa(const aasr_gmm *g) { return g ? g->kappa : -1.0; }
 
+// Diagnostic (tests, bench.py): the engine parts of a model (gmm_plan_engine_parts) -- out[0] parts, out[1] columns of an
+// engine score row, then per part (up to three) {arithmetic (2 / 3 / 0: ordinary model), states, pivot groups, rows
+// with the padding}; returns 0 when the model has none.
+// Diagnostic: the column of every state in an engine score row ([S]) and, for engine part `part`, its pivot groups --
+// first column / one past the last real column of every group (relative to the part's first column, which is returned in
+// *col0) and the groups' pivots [groups][dim].  Returns the number of groups (0: an ordinary model), -1: no such part.
+extern "C" int aasr_debug_engine_layout(const aasr_gmm *g, int part, int32_t *colmap, int32_t *begin, int32_t *real_end,
+                                       float *pivots, int64_t *col0) {
+  if (!g || part < 0 || (size_t)part >= g->engine_parts.size()) return -1;
+  if (colmap) std::copy(g->engine_colmap_h.begin(), g->engine_colmap_h.end(), colmap);
+  const auto &ep = g->engine_parts[(size_t)part];
+  if (col0) *col0 = ep.col0;
+  const aasr::HostModel &m = ep.model->host;
+  const int P = m.n_pg();
+  for (int p = 0; p < P; p++) {
+    if (begin) begin[p] = m.pg_begin[(size_t)p];
+    if (real_end) real_end[p] = m.pg_real_end[(size_t)p];
+  }
+  if (pivots) std::copy(m.pg_pivot.begin(), m.pg_pivot.end(), pivots);
+  return P;
+}
+extern "C" const char *aasr_debug_engine_plan_note(const aasr_gmm *g) { return g ? g->engine_plan_note.c_str() : ""; }
+extern "C" int aasr_debug_engine_parts(const aasr_gmm *g, int64_t *out, int n) {
+  if (!g || !out || n < 14) return -1;
+  for (int i = 0; i < n; i++) out[i] = 0;
+  out[0] = (int64_t)g->engine_parts.size();
+  out[1] = g->engine_cols;
+  for (size_t i = 0; i < g->engine_parts.size() && i < 3; i++) {
+    const auto &part = g->engine_parts[i];
+    out[2 + 4 * i] = part.arith;
+    out[3 + 4 * i] = part.states;
+    out[4 + 4 * i] = part.arith ? part.model->paired.n_pg : 0;
+    out[5 + 4 * i] = part.arith ? part.model->paired.rows_padded : (int64_t)part.model->host.mix_idx.size();
+  }
+  return (int)g->engine_parts.size();
+}
+
 // Diagnostic (bench.py): milliseconds of ONE k_frame_operand launch over F frames for the layout and arithmetic a scoring
 // call would use now -- the launch that precedes k_gmm_diag_score_pl in every scoring call, so that the bench can price
 // the scoring kernel on its own duration (HIP events around the call see both).  < 0: the current path forms its frame
@@ -2978,9 +3062,10 @@ extern "C" double aasr_debug_frame_operand_ms(aasr_gmm *g, const float *d_frames
   const int64_t blocks64 = (F + NW * FRAMES_PER_WAVE - 1) / (NW * FRAMES_PER_WAVE) * NW;
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.0;
-  frame_operand<2>(g, L, d_frames, F, blocks64, stream);
+  int64_t stride = 0;
+  frame_operand<2>(g, L, d_frames, F, blocks64, stream, &stride);
   (void)hipEventRecord(e0, stream);
-  for (int i = 0; i < reps; i++) frame_operand<2>(g, L, d_frames, F, blocks64, stream);
+  for (int i = 0; i < reps; i++) frame_operand<2>(g, L, d_frames, F, blocks64, stream, &stride);
   (void)hipEventRecord(e1, stream);
   (void)hipEventSynchronize(e1);
   float ms = 0;
@@ -3183,8 +3268,10 @@ static void add_output_bias(const aasr_gmm *g, float *d_out, int64_t F, hipStrea
 
 // Whether scores can be written with a row pitch other than S: the bf16x3 track kernels can
 // (rows padded to a multiple of 16 floats make every 64-byte output group a whole cache line).
+static bool engine_parts_public(const aasr_gmm *g);
 bool gmm_score_pitch_ok(const aasr_gmm *g) {
   if (!g->dim_parts.empty()) return false;
+  if (engine_parts_public(g)) return true;
   if (g->host.factor_path() || g->hyb_enabled || g->ill_conditioned || g->class_routing ||
       g->precision == AASR_PREC_F64)
     return false;
@@ -3208,17 +3295,115 @@ static bool engine_alias(const aasr_gmm *g) {
          !g->xf_a.p && g->out_bias_ln == 0 && g->dim_parts.empty() && gmm_score_pitch_ok(g);
 }
 
-int64_t gmm_engine_pitch(const aasr_gmm *g) {
-  if (!gmm_score_pitch_ok(g)) return g->S;
-  const int64_t base = (g->S + 31) / 32 * 32;
-  return engine_alias(g) ? base + (g->routed_sub->S + 31) / 32 * 32 : base;
+// Engine parts (gmm_plan_engine_parts): the model as internal multi-pivot models over disjoint sets of its states.  They
+// carry the default arithmetic only -- the other precisions are verification modes on the model's own layouts -- and
+// nothing that merges by state column (clustering, class routing).
+bool gmm_engine_parts_active(const aasr_gmm *g) {
+  return !g->engine_parts.empty() && g->precision == AASR_PREC_F16X2 && g->use_bf16x3 && !g->cl.enabled &&
+         !g->class_routing && g->dim_parts.empty() && (g->layout_mask & 3) == 3;
 }
 
-const int32_t *gmm_engine_colmap(const aasr_gmm *g) { return engine_alias(g) ? g->routed_colmap.p : nullptr; }
+// ... and whether public-layout calls (column = state) go through them too, with the columns gathered back: where the
+// model's own layouts have no two-term form at all
+static bool engine_parts_public(const aasr_gmm *g) {
+  if (!gmm_engine_parts_active(g)) return false;
+  const TrackLayout &L = g->paired.ok ? g->paired : g->tracks;
+  return !(L.ok && L.a16h.p) && !g->mixed.ok;
+}
+
+int64_t gmm_engine_pitch(const aasr_gmm *g) {
+  // (independent of the precision setting: a caller sizes its scratch once)
+  if (!g->engine_parts.empty()) return std::max(g->engine_cols, (g->S + 31) / 32 * 32);
+  if (!gmm_score_pitch_ok(g)) return g->S;
+  const int64_t base = (g->S + 31) / 32 * 32;
+  return g->routed_sub ? base + (g->routed_sub->S + 31) / 32 * 32 : base;
+}
+
+const int32_t *gmm_engine_colmap(const aasr_gmm *g) {
+  if (gmm_engine_parts_active(g)) return g->engine_colmap.p;
+  return engine_alias(g) ? g->routed_colmap.p : nullptr;
+}
+
+__global__ void k_scatter_columns(const float *__restrict__ in, int64_t F, int64_t n, float *__restrict__ out, int64_t pitch) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F * n) return;
+  const int64_t f = i / n;
+  out[f * pitch + (i - f * n)] = in[i];
+}
+
+// out[f][s] = rows[f][colmap[s]]: the engine's score rows back in the public layout
+__global__ __launch_bounds__(256) void k_gather_columns(const float *__restrict__ rows, int64_t F, int64_t in_pitch,
+                                                        const int32_t *__restrict__ colmap, int64_t S,
+                                                        float *__restrict__ out, int64_t out_pitch) {
+  const int64_t f = blockIdx.y;
+  const float *r = rows + f * in_pitch;
+  float *o = out + f * out_pitch;
+  for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) o[s] = r[colmap[s]];
+}
+
+static void launch_engine_parts(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, int64_t pitch,
+                                hipStream_t stream) {
+  if (g->xf_a.p) {   // one constrained-MLLR transform for the pool: the frames transformed once, log|det| at the output
+    if ((size_t)F * g->dim > g->d_xframes.n) AASR_HIP(hipDeviceSynchronize());
+    g->d_xframes.ensure((size_t)F * g->dim);
+    const int64_t n = F * g->dim;
+    hipLaunchKernelGGL(k_affine_frames, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_frames, F, g->dim,
+                       g->xf_a.p, g->xf_b.p, g->d_xframes.p);
+    AASR_HIP(hipGetLastError());
+    d_frames = g->d_xframes.p;
+  }
+  for (auto &part : g->engine_parts) {
+    aasr_gmm *sub = part.model.get();
+    sub->out_bias_ln = g->out_bias_ln;
+    float *o = d_out + part.col0;
+    bool done = false;
+    if (part.arith == 2) done = launch_split<2>(sub, sub->paired, d_frames, F, o, stream, nullptr, pitch);
+    else if (part.arith == 3) done = launch_split<3>(sub, sub->paired, d_frames, F, o, stream, nullptr, pitch);
+    else {
+      sub->precision = g->precision;
+      sub->use_bf16x3 = g->use_bf16x3;
+      if (gmm_score_pitch_ok(sub)) {
+        gmm_score_launch_pitched(sub, d_frames, F, o, pitch, stream);
+      } else {   // (an ill-conditioned remainder: its kernels write dense rows)
+        if ((size_t)F * sub->S > g->engine_part_scratch.n) AASR_HIP(hipDeviceSynchronize());
+        g->engine_part_scratch.ensure((size_t)F * sub->S);
+        gmm_score_launch(sub, d_frames, F, g->engine_part_scratch.p, stream);
+        const int64_t n = F * sub->S;
+        hipLaunchKernelGGL(k_scatter_columns, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                           g->engine_part_scratch.p, F, sub->S, o, pitch);
+        AASR_HIP(hipGetLastError());
+      }
+      done = true;
+    }
+    if (!done) raise(AASR_ERR_UNSUPPORTED, "no kernel instance for an engine part of the model");
+  }
+}
+
+// public layout through the engine parts: chunks of frames into the handle's scratch, columns gathered back
+static void launch_engine_parts_public(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, int64_t pitch,
+                                       hipStream_t stream) {
+  const int64_t ep = gmm_engine_pitch(g);
+  const int64_t chunk = std::max<int64_t>(512, std::min<int64_t>(F, (int64_t)(1.0e9 / (4.0 * (double)ep))) / 512 * 512);
+  if ((size_t)std::min(chunk, F) * ep > g->engine_scratch.n) {
+    AASR_HIP(hipDeviceSynchronize());
+    g->engine_scratch.ensure((size_t)std::min(chunk, F) * ep);
+  }
+  for (int64_t f0 = 0; f0 < F; f0 += chunk) {
+    const int64_t fc = std::min(chunk, F - f0);
+    launch_engine_parts(g, d_frames + f0 * g->dim, fc, g->engine_scratch.p, ep, stream);
+    hipLaunchKernelGGL(k_gather_columns, dim3((unsigned)std::min<int64_t>(8, (g->S + 255) / 256), (unsigned)fc), dim3(256), 0,
+                       stream, g->engine_scratch.p, fc, ep, g->engine_colmap.p, g->S, d_out + f0 * pitch, pitch);
+    AASR_HIP(hipGetLastError());
+  }
+}
 
 void gmm_score_launch_engine(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, int64_t pitch,
                              hipStream_t stream) {
   if (F <= 0) return;
+  if (gmm_engine_parts_active(g) && pitch >= g->engine_cols) {
+    launch_engine_parts(g, d_frames, F, d_out, pitch, stream);
+    return;
+  }
   if (!engine_alias(g) || pitch < gmm_engine_pitch(g)) {
     gmm_score_launch_pitched(g, d_frames, F, d_out, pitch, stream);
     return;
@@ -3236,6 +3421,10 @@ void gmm_score_launch_pitched(aasr_gmm *g, const float *d_frames, int64_t F, flo
   if (F <= 0) return;
   if (pitch == g->S) {
     gmm_score_launch(g, d_frames, F, d_out, stream);
+    return;
+  }
+  if (pitch > g->S && engine_parts_public(g)) {
+    launch_engine_parts_public(g, d_frames, F, d_out, pitch, stream);
     return;
   }
   if (pitch < g->S || !gmm_score_pitch_ok(g))
@@ -3389,6 +3578,10 @@ void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
   }
   if (g->host.factor_path()) {
     gmm_full_launch(g, d_frames, F, d_out, stream);
+    return;
+  }
+  if (engine_parts_public(g)) {
+    launch_engine_parts_public(g, d_frames, F, d_out, g->S, stream);
     return;
   }
   if (g->xf_a.p) {
