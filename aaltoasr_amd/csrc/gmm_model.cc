@@ -994,6 +994,11 @@ HostModel pg_sub_model(const HostModel &m, const std::vector<std::vector<int64_t
   }
   sm.pg_begin.push_back((int32_t)sm.S);
   sm.weights_normalized = true;
+  if (sm.G == 0) {   // states without components only: the pool still needs an entry (no row points at it)
+    sm.G = 1;
+    sm.mean.assign((size_t)m.dim, 0.0);
+    sm.var.assign((size_t)m.dim, 1.0);
+  }
   return sm;
 }
 }  // namespace
@@ -1107,6 +1112,8 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
     std::sort(out.begin(), out.end());
     cand = out;
   }
+  // (states the model's own probe moved are normally rejected here again: the union is what is reported)
+  g->f16_probe_moved = std::max(g->f16_probe_moved, probe_moved);
   if (parts.empty()) return;   // nothing qualifies for two terms around any pivot: the model's own paths
   // part 1: three bf16 terms
   if (!cand.empty()) {
@@ -1145,7 +1152,6 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
   g->engine_cols = col0;
   g->engine_colmap_h = colmap;
   g->engine_colmap.upload(colmap.data(), colmap.size());
-  g->f16_probe_moved += probe_moved;
   // the mixed layout's own spare-column arrangement is superseded
   g->routed_sub.reset();
   g->routed_colmap = DevBuf<int32_t>();

@@ -597,7 +597,7 @@ static void launch_tracks_t(const aasr_gmm *g, const TrackLayout &L, const float
     }
   }
   if (force_r >= 1 && force_r <= L.max_splits) R = force_r;
-  const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
+  const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (L.split_cap + 1) * 4;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(256), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, L.rows.a.p, split_row, L.close.p, L.sid.p, L.sid_stride,
                      d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, dbg, cl);
@@ -1720,7 +1720,7 @@ static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const TrackSe
   const int R = pick_row_cuts(blocks, (WIDE ? 1.0 : 2.0) * (g->num_cus > 0 ? g->num_cus : 256),
                               sec ? sec->tile_end - sec->tile_begin : L.rows_padded / TILE_ROWS,
                               sec ? sec->max_splits : L.max_splits, 6.0);
-  const int32_t *split_row = (sec ? sec->splits.p : L.splits.p) + (size_t)(R - 1) * (TRACK_MAX_SPLITS + 1) * 4;
+  const int32_t *split_row = (sec ? sec->splits.p : L.splits.p) + (size_t)(R - 1) * ((sec ? TRACK_MAX_SPLITS : L.split_cap) + 1) * 4;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(NW * 64), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, NS == 3 ? L.a16.p : L.a16h.p, split_row, L.close.p, L.sid.p, L.sid_stride,
                      d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, dbg, cl);
@@ -1745,7 +1745,7 @@ static void launch_pl_t(const aasr_gmm *g, const TrackLayout &L, const TrackSect
   }
   const int32_t *splits_base = sec ? sec->splits.p : L.splits.p;
   const bool multi = !sec && L.n_pg > 1;   // pivot groups: every group at least one cut, its own image of the frame operand
-  const int cap = multi ? L.split_cap : TRACK_MAX_SPLITS;
+  const int cap = sec ? TRACK_MAX_SPLITS : L.split_cap;   // rows of the cut table
   const CutPlan plan = pick_cut_plan(blocks, (WIDE ? 1.0 : 2.0) * (g->num_cus > 0 ? g->num_cus : 256),
                                      sec ? sec->tile_end - sec->tile_begin : L.rows_padded / TILE_ROWS,
                                      sec ? sec->max_splits : L.max_splits, 3.0, splits_base, multi ? L.n_pg : 1, cap);

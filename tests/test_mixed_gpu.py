@@ -81,16 +81,24 @@ def test_routed_states_on_independent_tracks_and_other_dimensions(capi, oracle):
         _routed(capi, oracle, model, bad, synth.make_frames(400, D=D, seed=433), grouped=True)
 
 
-def test_a_model_with_most_states_over_the_limits_keeps_one_arithmetic(capi, oracle):
-    """Beyond 45 % of the states the two launches of a routed model cost what the whole model costs on three bf16 terms
-    (the second section's scattered stores), so such a model is not routed: AASR_PREC_F16X2 runs it as AASR_PREC_BF16X3."""
+def test_a_model_with_most_states_over_the_limits_is_split_into_engine_parts(capi, oracle):
+    """Beyond 45 % of the states the two launches of the MIXED layout cost what the whole model costs on three bf16 terms
+    (the second section's scattered stores), so no mixed layout is built.  Since round 5 such a model is scored through
+    its engine parts instead (gmm_plan_engine_parts): the states that qualify keep two fp16 terms, the others take three
+    bf16 terms as a model of their own, public-layout calls get the columns gathered back."""
     S = 64
     bad = list(range(0, S, 2)) + [1]
     model = synth.push_states_over_the_f16_limits(synth.make_model(D=39, G=S * 8, S=S, comps=8, seed=470), bad)
     g = capi.Gmm.from_arrays(*model)
-    assert g.effective_precision() == 3 and g.precision_states() == (0, 0)
+    parts = g.engine_parts()
+    assert parts is not None and parts["parts"][0]["arith"] == 2, g.engine_plan_note()
+    assert g.effective_precision() == 4 and g.precision_states()[0] >= S - len(bad)
     fr = synth.make_frames(300, seed=471)
-    assert_ll(g.score(fr), oracle.DiagModel(*model).score(fr.astype(np.float64)), "unrouted model")
+    ref = oracle.DiagModel(*model).score(fr.astype(np.float64))
+    assert_ll(g.score(fr), ref, "engine parts, public layout")
+    g.set_precision(3)   # the other arithmetics stay on the model's own layouts
+    assert g.effective_precision() == 3 and g.precision_states() == (0, 0)
+    assert_ll(g.score(fr), ref, "unrouted model, three terms")
     g.close()
 
 
@@ -182,7 +190,9 @@ def test_routed_model_on_the_engines_own_score_layout(capi, oracle):
     F = 9000
     fr = synth.make_frames(F, seed=481)
     n_scratch = g.score_scratch_floats(F)
-    assert n_scratch >= F * (224 + 32)        # 200 states -> 224 columns, + one line of spare columns for the 20 states
+    parts = g.engine_parts()
+    assert parts is not None and parts["cols"] == 192 + 32 and parts["parts"][0]["states"] == S - len(bad)
+    assert n_scratch >= F * 224        # 180 states on two terms -> 192 columns, + one line of columns for the 20 others
     d_fr = torch.from_numpy(fr).cuda()
     d_scr = torch.empty(n_scratch, dtype=torch.float32, device="cuda")
     public = g.score(fr)
@@ -200,14 +210,15 @@ def test_routed_model_on_the_engines_own_score_layout(capi, oracle):
             b = want.reshape(F, S, 2).astype(np.int32)
             ca, cb = a[..., 0] * 256 + a[..., 1], b[..., 0] * 256 + b[..., 1]
             assert np.abs(ca - cb).max() <= 1 and (ca == cb).mean() > 0.99
-            # (the normaliser sums over all states, so a rounding-level move of the routed states' values can flip a code
-            # of any state; without normalisation the first section's states -- same kernel, same rows -- give the same bits)
+            # (the engine parts expand around pivots of their own, the public layout -- the mixed layout here -- around the
+            # pool's: rounding-level differences, a code step at most)
             d_raw = torch.empty((F, S * 2), dtype=torch.uint8, device="cuda")
             g.score_lna_dev(d_fr, d_scr, d_raw, False, 2)
             torch.cuda.synchronize()
-            good = [s for s in range(S) if s not in bad]
-            raw = d_raw.cpu().numpy().reshape(F, S, 2)
-            assert np.array_equal(raw[:, good], capi.lna_encode(public, False, 2)[1].reshape(F, S, 2)[:, good])
+            r = d_raw.cpu().numpy().reshape(F, S, 2).astype(np.int32)
+            w = capi.lna_encode(public, False, 2)[1].reshape(F, S, 2).astype(np.int32)
+            cr, cw = r[..., 0] * 256 + r[..., 1], w[..., 0] * 256 + w[..., 1]
+            assert np.abs(cr - cw).max() <= 1 and (cr == cw).mean() > 0.99
             o = by_ref.reshape(F, S, 2).astype(np.int32)
             co = o[..., 0] * 256 + o[..., 1]
             assert np.abs(ca - co).max() <= 1
