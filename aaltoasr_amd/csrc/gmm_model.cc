@@ -892,32 +892,49 @@ PgPlan pg_plan(const HostModel &m, const std::vector<int64_t> &cand, const PgLim
   std::vector<uint8_t> tried(n, 0);
   int P = 1;
   while (P < max_groups) {
-    // the worst failing state that has not been tried as a pivot
-    size_t pick = n;
-    double worst = 1.0;
+    // candidates for one more pivot: the centres of the worst failing state and of a few others spread over the failing
+    // ones; the one that rescues the most rows is taken
+    std::vector<size_t> failing;
     int64_t fail_rows = 0;
-    for (size_t i = 0; i < n; i++) {
-      if (best[i] <= 1.0) continue;
-      fail_rows += comps[i];
-      if (!tried[i] && best[i] > worst) { worst = best[i]; pick = i; }
-    }
-    if (pick == n) break;
-    tried[pick] = 1;
-    std::vector<float> c;
-    pg_centre(m, std::vector<int64_t>{cand[pick]}, c);
-    if (pg_state_ratio(m, cand[pick], c.data(), lim) > 1.0) continue;   // fails around its own centre: not for this part
-    std::vector<double> r(n);
-    int64_t rescued = 0;
-    for (size_t i = 0; i < n; i++) {
-      r[i] = pg_state_ratio(m, cand[i], c.data(), lim);
-      if (best[i] > 1.0 && r[i] <= 1.0) rescued += comps[i];
-    }
-    // the last failing rows are worth more than their share: they also cost a launch of their own
-    const double bonus = rescued == fail_rows ? 4.0 : 1.0;
-    if ((double)rescued * bonus < rows_per_pivot) continue;
-    plan.pivots.insert(plan.pivots.end(), c.begin(), c.end());
     for (size_t i = 0; i < n; i++)
-      if (r[i] < best[i] && (best[i] > 1.0 || r[i] <= 0.5 * best[i])) { best[i] = r[i]; grp[i] = P; }
+      if (best[i] > 1.0) {
+        fail_rows += comps[i];
+        if (!tried[i]) failing.push_back(i);
+      }
+    if (failing.empty()) break;
+    std::sort(failing.begin(), failing.end(), [&](size_t a, size_t b) { return best[a] != best[b] ? best[a] > best[b] : a < b; });
+    const size_t n_try = std::min<size_t>(8, failing.size());
+    std::vector<float> c_best;
+    std::vector<double> r_best;
+    int64_t rescued_best = -1;
+    for (size_t t = 0; t < n_try; t++) {
+      const size_t pick = failing[t * failing.size() / n_try];
+      std::vector<float> c;
+      pg_centre(m, std::vector<int64_t>{cand[pick]}, c);
+      if (pg_state_ratio(m, cand[pick], c.data(), lim) > 1.0) {   // fails around its own centre: not for this part
+        tried[pick] = 1;
+        continue;
+      }
+      std::vector<double> r(n);
+      int64_t rescued = 0;
+      for (size_t i = 0; i < n; i++) {
+        r[i] = best[i] > 1.0 ? pg_state_ratio(m, cand[i], c.data(), lim) : 2.0;
+        if (best[i] > 1.0 && r[i] <= 1.0) rescued += comps[i];
+      }
+      if (rescued > rescued_best) {
+        rescued_best = rescued;
+        c_best = c;
+        r_best = r;
+      }
+    }
+    tried[failing[0]] = 1;   // (the loop ends: the worst one is never tried twice)
+    if (rescued_best < 0) continue;
+    // the last failing rows are worth more than their share: they also cost a launch of their own
+    const double bonus = rescued_best == fail_rows ? 2.0 : 1.0;
+    if ((double)rescued_best * bonus < rows_per_pivot) continue;
+    plan.pivots.insert(plan.pivots.end(), c_best.begin(), c_best.end());
+    for (size_t i = 0; i < n; i++)
+      if (best[i] > 1.0 && r_best[i] < best[i]) { best[i] = r_best[i]; grp[i] = P; }
     P++;
   }
   // re-fit every group's pivot to its members' centre where no member is lost
@@ -1030,13 +1047,13 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
   }
   const int D = m.dim;
   const double rows_total = (double)m.mix_idx.size();
-  // one more image of the frame operand costs what ~240 rows cost per frame (k_frame_operand: 0.03 ms per 449 280 frames
-  // and image against 8.5 ms for 50 000 rows, + a tile of padding); a row on two terms instead of three saves 0.65 of
-  // a row, on three terms instead of the centred form several rows
+  // one more pivot costs what ~400 rows cost per frame (k_frame_operand: 0.05 ms per 449 280 frames and image against
+  // 8.5 ms for 50 000 rows, + a row cut more per frame block, + a tile of padding); a row on two terms instead of three
+  // saves 0.65 of a row, on three terms instead of the centred form several rows
   // AASR_PG_PIVOT_COST (test hook): the rows one more pivot has to rescue, instead of the cost model's figure
   static const double pivot_cost_env = getenv("AASR_PG_PIVOT_COST") ? atof(getenv("AASR_PG_PIVOT_COST")) : -1.0;
-  const double cost2 = pivot_cost_env >= 0 ? pivot_cost_env : 240.0 / 0.65;
-  const double cost3 = pivot_cost_env >= 0 ? pivot_cost_env : 240.0 / 4.0;
+  const double cost2 = pivot_cost_env >= 0 ? pivot_cost_env : 400.0 / 0.65;
+  const double cost3 = pivot_cost_env >= 0 ? pivot_cost_env : 400.0 / 4.0;
   static const double lim_scale = getenv("AASR_PG_LIMIT_SCALE") ? atof(getenv("AASR_PG_LIMIT_SCALE")) : 1.0;   // EXPERIMENT
   const PgLimits lim2{lim_scale * KAPPA_LIMIT_F16, lim_scale * (D < 8 ? KAPPA2_LIMIT_F16_LOWDIM : KAPPA2_LIMIT_F16)};
   const PgLimits lim3{lim_scale * KAPPA_LIMIT, lim_scale * KAPPA2_LIMIT};

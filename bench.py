@@ -631,6 +631,11 @@ def main():
                                                  with_models=(rank == 0)))
         except Exception as e:
             extra_cfg["precision_ladder"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0:
+            try:
+                extra_cfg["fitted_model"] = _measure_fitted_models(torch, capi, synth, pipeline, gmm, runner, dev, PREC)
+            except Exception as e:
+                extra_cfg["fitted_model"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:
             runner.release()
             torch.cuda.empty_cache()
@@ -812,6 +817,73 @@ def _measure_precisions(torch, capi, synth, gmm, runner, model, restore_precisio
                                         "what phone_probs / aasr_run_recipe run -- its ratio prices the scoring stage as all-f16x2 ms "
                                         "+ the extra ms of the whole path.  all-f16x2 engine path: %.4f ms" % base_engine,
                                 "models": routing}
+    return out
+
+
+def _measure_fitted_models(torch, capi, synth, pipeline, gmm, runner, dev, precision):
+    """The headline's robustness to the model's conditioning: 50 000 diagonal Gaussians FITTED (synth.fit_model: seeded
+    tree clustering + mixture splitting, variances floored at 0.1 of the global variance like aku's estimate --minvar) to
+    the engine's own 39-d features of one synthetic hour -- the stationary audio of the timed workload and a source-filter
+    imitation of speech (silence / voiced / fricative segments: the modes trained models see) --, features brought to zero
+    mean and unit variance per dimension as aku's normalization module does.  Such a model's Gaussians sit around their
+    STATE's centre with variances down to the floor: around the pool's one pivot most of them break the two-term limits, so
+    the engine sorts the states into pivot groups (engine parts).  Reported: the split of the states over the
+    arithmetics, the pivot groups, ms of frames -> 2-byte LNA codes on the engine's own layout against the BASELINE
+    model's on the same path, max |d ll| against the oracle on 64 frames (visible values)."""
+    import time as _t
+    from oracle import oracle as O
+    base_ms = _time_engine_path(torch, runner, gmm)
+    out = {"what": "synth.fit_model on %d frames of the engine's own features (360 distinct seeded 10-s utterances), "
+                   "standardised per dimension; engine path = aasr_gmm_score_lna_dev, frames -> 2-byte LNA codes" % runner.total_frames,
+           "baseline_model_engine_path_ms": round(base_ms, 4), "models": []}
+    n_utts = len(runner.utts)
+    sr = runner.feat.sample_rate
+    n = len(runner.utts[0])
+    for kind, mk in (("stationary", synth.make_audio), ("speechlike", synth.make_speechlike_audio)):
+        t0 = _t.perf_counter()
+        utts = [mk(n, seed=synth.SEED + 7000 + i, sample_rate=sr) for i in range(n_utts)]
+        r2 = pipeline.FullChainBench(gmm, n_utts, n / sr, 0, dev, cfg_text=runner.cfg_text, utts=utts)
+        r2.features_only()
+        torch.cuda.synchronize()
+        X = r2.d_fea.cpu().numpy()
+        X = ((X - X.mean(0)) / X.std(0)).astype(np.float32)
+        t_feat = _t.perf_counter() - t0
+        t0 = _t.perf_counter()
+        model = synth.fit_model(X, S=S, comps=COMPS)
+        t_fit = _t.perf_counter() - t0
+        t0 = _t.perf_counter()
+        g2 = capi.Gmm.from_arrays(*model)
+        g2.set_precision(precision)
+        t_build = _t.perf_counter() - t0
+        parts = g2.engine_parts()
+        n16, moved = g2.precision_states()
+        k1, k2 = synth.conditioning(model[0], model[1])
+        r2.d_fea.copy_(torch.from_numpy(X))
+        ms = _time_engine_path(torch, r2, g2)
+        rng = np.random.default_rng(synth.SEED + 71)
+        fi = np.sort(rng.choice(X.shape[0], 64, replace=False))
+        sub = np.ascontiguousarray(X[fi])
+        ref = O.DiagModel(*model).score(sub.astype(np.float64))
+        got = g2.score(sub)
+        vis = ref > -103.0
+        err = np.abs(got - ref)
+        best = ref.max(1, keepdims=True)
+        win = vis & (ref > best - 36.0)
+        entry = {"audio": kind, "states": S, "gaussians": G,
+                 "one_pivot_conditioning": {"kappa_max": round(float(k1.max()), 1), "kappa2_max": round(float(k2.max()), 1),
+                                            "states_within_the_f16x2_limits": int(((k1.reshape(S, COMPS).max(1) <= 330.0) &
+                                                                                   (k2.reshape(S, COMPS).max(1) <= 80.0)).sum())},
+                 "states_f16x2": n16, "share_f16x2": round(n16 / S, 4), "states_moved_by_the_probe": moved,
+                 "engine_parts": parts, "engine_path_ms": round(ms, 4), "ratio_to_baseline_model": round(ms / base_ms, 4),
+                 "max_abs_dll_vs_oracle_64_frames": float("%.3g" % err[vis].max()), "visible_values": int(vis.sum()),
+                 "max_abs_dll_inside_the_2_byte_lna_window": float("%.3g" % err[win].max()),
+                 "share_within_1e-4": round(float((err[vis] <= 1e-4).mean()), 6),
+                 "seconds": {"audio_and_features": round(t_feat, 1), "fit": round(t_fit, 1), "build": round(t_build, 2)}}
+        out["models"].append(entry)
+        g2.close()
+        r2.release()
+        del r2
+        torch.cuda.empty_cache()
     return out
 
 

@@ -111,6 +111,35 @@ if __name__ == "__main__":
         for S, comps in ((96, 8), (200, 16), (64, 3)):
             m = synth.fit_model(X, S=S, comps=comps)
             check(m, X[:4096], "blobs S=%d x %d" % (S, comps))
+    if "routing" in what:
+        import bench
+        model = synth.make_model(D=39, G=50000, S=3125, comps=16)
+        F = 449280
+        dev = torch.device("cuda:0")
+        d_all = torch.randn((F, 39), device=dev, dtype=torch.float32)
+        d_by = torch.empty((F, 3125 * 2), dtype=torch.uint8, device=dev)
+        rng = np.random.default_rng(synth.SEED + 99)
+        base = None
+        for share in (0.0, 0.01, 0.10, 0.40):
+            bad = sorted(rng.choice(3125, int(round(share * 3125)), replace=False).tolist()) if share else []
+            g = capi.Gmm.from_arrays(*(synth.push_states_over_the_f16_limits(model, bad) if bad else model))
+            d_scr = torch.empty(g.score_scratch_floats(F), dtype=torch.float32, device=dev)
+            for _ in range(2):
+                g.score_lna_dev(d_all, d_scr, d_by, True, 2)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                g.score_lna_dev(d_all, d_scr, d_by, True, 2)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            if base is None:
+                base = ms
+            print("share %.2f: engine path %.3f ms (+%.3f; scoring x%.3f at 8.5 ms)  f16 states %s parts %s" % (
+                share, ms, ms - base, (8.5 + ms - base) / 8.5, g.precision_states(), g.engine_parts()), flush=True)
+            print("    plan:", g.engine_plan_note(), flush=True)
+            g.close()
     n_utts = int(os.environ.get("EXP_UTTS", "360"))
     n_states = int(os.environ.get("EXP_STATES", "3125"))
     for kind in ("full", "speech"):
