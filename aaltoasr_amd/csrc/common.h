@@ -4,9 +4,25 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/aasr.h"
+
+// Environment variables.  The product library reads the few that INTEGRATION.md lists (AASR_PREC, AASR_PCGMM_AS_WRITTEN,
+// AASR_WRITER_THREADS, AASR_RECIPE_TIMING and the test hooks AASR_F16_PROBE_TOL / AASR_PG_PIVOT_COST) with plain getenv.
+// Every other switch is an EXPERIMENT switch -- it selects a kernel variant, a layout or an arithmetic for an A/B
+// measurement -- and exists only in a build made with AASR_BUILD_ABLATION=1 (-DAASR_ABLATION=1, into lib_ablation/): in
+// the product library the expression below is a null pointer and the name is not even in the object's strings
+// (tests/test_env_switches.py checks exactly that).
+#ifndef AASR_ABLATION
+#define AASR_ABLATION 0
+#endif
+#if AASR_ABLATION
+#define AASR_EXPERIMENT_ENV(name) getenv(name)
+#else
+#define AASR_EXPERIMENT_ENV(name) ((const char *)nullptr)
+#endif
 
 namespace aasr {
 

@@ -1264,7 +1264,7 @@ static inline unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256);
 
 // AASR_FEAT_FUSE=0 (or aasr_debug_feat_fusion(0)) evaluates every module with its own kernel;
 // the fused kernels must reproduce that path bit for bit.
-static int g_feat_fusion = getenv("AASR_FEAT_FUSE") ? atoi(getenv("AASR_FEAT_FUSE")) : 1;
+static int g_feat_fusion = AASR_EXPERIMENT_ENV("AASR_FEAT_FUSE") ? atoi(AASR_EXPERIMENT_ENV("AASR_FEAT_FUSE")) : 1;
 
 void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int target,
                     float *out_f32, double *out_f64, hipStream_t stream) {
@@ -1438,7 +1438,7 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
       h->bufs[i].ensure((size_t)rows * m.dim);
       hipLaunchKernelGGL(k_spectral_fused, dim3((unsigned)((nblk + passes - 1) / passes)), dim3(256), lds.total,
                          stream, db, d_pcm, ap, L[i], R[i], rows, sp, passes,
-                         getenv("AASR_SPEC_DBG") ? atoi(getenv("AASR_SPEC_DBG")) : 0, h->bufs[i].p);
+                         AASR_EXPERIMENT_ENV("AASR_SPEC_DBG") ? atoi(AASR_EXPERIMENT_ENV("AASR_SPEC_DBG")) : 0, h->bufs[i].p);
       AASR_HIP(hipGetLastError());
       continue;
     }
@@ -1464,7 +1464,7 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
         AASR_HIP(hipFuncSetAttribute((const void *)k_temporal_fused<TR, TNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
       hipLaunchKernelGGL((k_temporal_fused<TR, TNT>), dim3((unsigned)((rows + TR - 1) / TR)), dim3(TNT), smem, stream, db,
                          (const double *)h->bufs[tgX].p, map_of(i, tgX), span, rows, tp,
-                         getenv("AASR_TEMP_DBG") ? atoi(getenv("AASR_TEMP_DBG")) : 0, h->bufs[i].p);
+                         AASR_EXPERIMENT_ENV("AASR_TEMP_DBG") ? atoi(AASR_EXPERIMENT_ENV("AASR_TEMP_DBG")) : 0, h->bufs[i].p);
       AASR_HIP(hipGetLastError());
       continue;
     }
@@ -1652,7 +1652,7 @@ void feat_run_batch(aasr_feat *h, const int16_t *d_pcm, const UttBatch &ub, int 
         break;
       }
       case MOD_MEAN_SUBTRACTOR: {
-        const int ms_dbg = getenv("AASR_CMS_DBG") ? atoi(getenv("AASR_CMS_DBG")) : 0;
+        const int ms_dbg = AASR_EXPERIMENT_ENV("AASR_CMS_DBG") ? atoi(AASR_EXPERIMENT_ENV("AASR_CMS_DBG")) : 0;
         // tile: 128 rows x 512 threads where two such workgroups fit a CU's LDS (the look-around is re-read once per
         // tile: 2.3x the rows at 64, 1.6x at 128 -- 134 -> 90 us on the production graph), 64 x 256 where three of
         // those fit, 128 x 512 alone on a CU for wide windows (the reference's default 75 + 75 at 39 columns: 100 KB);

@@ -107,7 +107,7 @@ __device__ __forceinline__ float lin_key32(double ll) {
 }
 
 // diagnostic switch (aasr_debug_cluster_heap): every frame takes the queue replay
-static int g_force_heap = getenv("AASR_CLUSTER_HEAP") ? atoi(getenv("AASR_CLUSTER_HEAP")) : 0;
+static int g_force_heap = AASR_EXPERIMENT_ENV("AASR_CLUSTER_HEAP") ? atoi(AASR_EXPERIMENT_ENV("AASR_CLUSTER_HEAP")) : 0;
 
 // ---------------------------------------------------------------- centres --
 // thread = frame (float values parked in LDS, [dimension][thread]); the records
@@ -1300,7 +1300,7 @@ static void launch_centres(aasr_gmm *g, const XT *d_frames, int64_t F, hipStream
     attr_set[g->device & 63] = true;
   }
   // float frames: the expanded FMA form (AASR_CLUSTER_CENTRES_REF=1 keeps the reference operation order)
-  static const int ref_order = getenv("AASR_CLUSTER_CENTRES_REF") ? atoi(getenv("AASR_CLUSTER_CENTRES_REF")) : 0;
+  static const int ref_order = AASR_EXPERIMENT_ENV("AASR_CLUSTER_CENTRES_REF") ? atoi(AASR_EXPERIMENT_ENV("AASR_CLUSTER_CENTRES_REF")) : 0;
   if constexpr (std::is_same<XT, float>::value) {
     if (cl.dimp > 64) {
       // feature dimension > 63 (no matrix instance: K = 2 dim + 1 > 128): the expanded FMA form with one wave per
@@ -1328,7 +1328,7 @@ static void launch_centres(aasr_gmm *g, const XT *d_frames, int64_t F, hipStream
         attr_fma[g->device & 63] = true;
       }
       // the matrix-pipe form where an instance exists for the dimension
-      static const int use_mfma = getenv("AASR_CLUSTER_CENTRES_MFMA") ? atoi(getenv("AASR_CLUSTER_CENTRES_MFMA")) : 1;
+      static const int use_mfma = AASR_EXPERIMENT_ENV("AASR_CLUSTER_CENTRES_MFMA") ? atoi(AASR_EXPERIMENT_ENV("AASR_CLUSTER_CENTRES_MFMA")) : 1;
       if (use_mfma && cl.bpack.p && launch_centres_mfma(g, d_frames, F, stream)) return;
       hipLaunchKernelGGL(k_cluster_centres_fma, dim3((unsigned)bx, (unsigned)ny), dim3(kCentreThreads), smem, stream,
                          d_frames, F, g->dim, cl.dimp, cl.rec_fma.p, cl.cconst_fma.p, groups, gpy, cl.ll64.p,
@@ -1423,9 +1423,9 @@ static void launch_select(aasr_gmm *g, int64_t s0, int64_t F, hipStream_t stream
 // The float-key fast path of a sub-pass: float frames, a matrix centre kernel for the dimension, at most 64 x 64
 // clusters (AASR_CLUSTER_KEYS64=1 keeps the doubles throughout).
 static bool cluster_fast_keys(const aasr_gmm *g) {
-  static const int keys64 = getenv("AASR_CLUSTER_KEYS64") ? atoi(getenv("AASR_CLUSTER_KEYS64")) : 0;
-  static const int ref_order = getenv("AASR_CLUSTER_CENTRES_REF") ? atoi(getenv("AASR_CLUSTER_CENTRES_REF")) : 0;
-  static const int use_mfma = getenv("AASR_CLUSTER_CENTRES_MFMA") ? atoi(getenv("AASR_CLUSTER_CENTRES_MFMA")) : 1;
+  static const int keys64 = AASR_EXPERIMENT_ENV("AASR_CLUSTER_KEYS64") ? atoi(AASR_EXPERIMENT_ENV("AASR_CLUSTER_KEYS64")) : 0;
+  static const int ref_order = AASR_EXPERIMENT_ENV("AASR_CLUSTER_CENTRES_REF") ? atoi(AASR_EXPERIMENT_ENV("AASR_CLUSTER_CENTRES_REF")) : 0;
+  static const int use_mfma = AASR_EXPERIMENT_ENV("AASR_CLUSTER_CENTRES_MFMA") ? atoi(AASR_EXPERIMENT_ENV("AASR_CLUSTER_CENTRES_MFMA")) : 1;
   const ClusterState &cl = g->cl;
   return !keys64 && !ref_order && use_mfma && cl.dimp <= 64 && cl.bpack.p && cl.rec_fma.p && cl.mfma_ks >= 1 && cl.mfma_ks <= 32 &&
          (cl.C + 63) / 64 <= 64;
@@ -1495,7 +1495,7 @@ static void launch_merge(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hi
     AASR_HIP(hipGetLastError());
     return;
   }
-  static const int threads = getenv("AASR_MERGE_THREADS") ? atoi(getenv("AASR_MERGE_THREADS")) : 1024;
+  static const int threads = AASR_EXPERIMENT_ENV("AASR_MERGE_THREADS") ? atoi(AASR_EXPERIMENT_ENV("AASR_MERGE_THREADS")) : 1024;
   if (cl.nnz <= 8) launch_merge_t<8, 1024>(g, d_out, F, pitch, stream);
   else if (threads == 512) launch_merge_t<16, 512>(g, d_out, F, pitch, stream);
   else if (threads == 256) launch_merge_t<16, 256>(g, d_out, F, pitch, stream);
@@ -1677,7 +1677,7 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
   if (fb >= round_frames) fb = fb / round_frames * round_frames;
   else fb = std::max<int64_t>(FRAMES_PER_BLOCK, fb / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK);
   fb = std::min<int64_t>(fb, f_rounded);
-  static const double sub_bytes = getenv("AASR_CLUSTER_SUB_BYTES") ? atof(getenv("AASR_CLUSTER_SUB_BYTES")) : 8.6e9;
+  static const double sub_bytes = AASR_EXPERIMENT_ENV("AASR_CLUSTER_SUB_BYTES") ? atof(AASR_EXPERIMENT_ENV("AASR_CLUSTER_SUB_BYTES")) : 8.6e9;
   int64_t fs = (int64_t)(sub_bytes / (8.0 * (double)cl.Cs));
   fs = std::min<int64_t>(fb, std::max<int64_t>(FRAMES_PER_BLOCK, fs / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK));
   if (fb > cl.Fc || (size_t)fs * cl.Cs > cl.ll64.n) {
@@ -1732,7 +1732,7 @@ void gmm_cluster_score_f64_launch(aasr_gmm *g, const double *d_frames, const dou
   if (cl.crow_centred.n != std::max<size_t>(g->host.mix_idx.size(), 1))
     build_crow_comps(g, std::vector<int32_t>(), cl, cl.crow_centred);
   const int64_t f_rounded = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK;
-  static const double sub_bytes = getenv("AASR_CLUSTER_SUB_BYTES") ? atof(getenv("AASR_CLUSTER_SUB_BYTES")) : 8.6e9;
+  static const double sub_bytes = AASR_EXPERIMENT_ENV("AASR_CLUSTER_SUB_BYTES") ? atof(AASR_EXPERIMENT_ENV("AASR_CLUSTER_SUB_BYTES")) : 8.6e9;
   int64_t fs = (int64_t)(sub_bytes / (8.0 * (double)cl.Cs));
   fs = std::min<int64_t>(f_rounded, std::max<int64_t>(FRAMES_PER_BLOCK, fs / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK));
   if (fs > cl.Fc || (size_t)fs * cl.Cs > cl.ll64.n) {  // pass == sub-pass here

@@ -694,7 +694,7 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
     g->precision = g->use_bf16x3 ? atoi(e) : AASR_PREC_F32;
     if (atoi(e) == AASR_PREC_F64 && !m.any_full()) g->precision = AASR_PREC_F64;  // the tools' switch to the reference's arithmetic
   }
-  if (const char *e = getenv("AASR_LAYOUTS")) {
+  if (const char *e = AASR_EXPERIMENT_ENV("AASR_LAYOUTS")) {
     g->layout_mask = atoi(e);
     if ((g->layout_mask & 2) && !g->tracks.ok) gmm_build_tracks(g, false);
   }
@@ -709,7 +709,7 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
 void gmm_build_routed_sub(aasr_gmm *g) {
   g->routed_sub.reset();
   g->routed_colmap = DevBuf<int32_t>();
-  static const int alias_env = getenv("AASR_ROUTED_ALIAS") ? atoi(getenv("AASR_ROUTED_ALIAS")) : 1;
+  static const int alias_env = AASR_EXPERIMENT_ENV("AASR_ROUTED_ALIAS") ? atoi(AASR_EXPERIMENT_ENV("AASR_ROUTED_ALIAS")) : 1;
   const HostModel &m = g->host;
   if (!alias_env || g->is_routed_sub || !g->mixed.ok || !g->mixed.sec[0].mapped || m.n_transforms > 0 || m.S > 4096 ||
       !g->outlier.empty())
@@ -1054,7 +1054,7 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
   static const double pivot_cost_env = getenv("AASR_PG_PIVOT_COST") ? atof(getenv("AASR_PG_PIVOT_COST")) : -1.0;
   const double cost2 = pivot_cost_env >= 0 ? pivot_cost_env : 400.0 / 0.65;
   const double cost3 = pivot_cost_env >= 0 ? pivot_cost_env : 400.0 / 4.0;
-  static const double lim_scale = getenv("AASR_PG_LIMIT_SCALE") ? atof(getenv("AASR_PG_LIMIT_SCALE")) : 1.0;   // EXPERIMENT
+  static const double lim_scale = AASR_EXPERIMENT_ENV("AASR_PG_LIMIT_SCALE") ? atof(AASR_EXPERIMENT_ENV("AASR_PG_LIMIT_SCALE")) : 1.0;   // EXPERIMENT
   const PgLimits lim2{lim_scale * KAPPA_LIMIT_F16, lim_scale * (D < 8 ? KAPPA2_LIMIT_F16_LOWDIM : KAPPA2_LIMIT_F16)};
   const PgLimits lim3{lim_scale * KAPPA_LIMIT, lim_scale * KAPPA2_LIMIT};
   std::vector<int64_t> cand;
@@ -1774,7 +1774,7 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
   std::vector<double> coef64;
   pack_rows(g, rows, L.rows, &coef64, /*upload_f32=*/!mixed);
   pack_bf16x3(m.dim, coef64, tiles, L);
-  static const int f16_env = getenv("AASR_F16X2") ? atoi(getenv("AASR_F16X2")) : 1;   // 0: never pack the f16x2 form
+  static const int f16_env = AASR_EXPERIMENT_ENV("AASR_F16X2") ? atoi(AASR_EXPERIMENT_ENV("AASR_F16X2")) : 1;   // 0: never pack the f16x2 form
   L.a16h = DevBuf<uint16_t>();
   int64_t bad_state = -1;
   if (mixed) {
@@ -1807,8 +1807,8 @@ void gmm_build_tracks(aasr_gmm *g, bool grouped) { build_track_layout(g, grouped
 // the range / clamp conditions at packing time is moved to the three-term section and the layout is built again.
 void gmm_build_mixed(aasr_gmm *g, std::vector<uint8_t> &f16_ok) {
   g->mixed.ok = false;
-  static const int f16_env = getenv("AASR_F16X2") ? atoi(getenv("AASR_F16X2")) : 1;
-  static const int mixed_env = getenv("AASR_MIXED") ? atoi(getenv("AASR_MIXED")) : 1;   // 0: whole-model precision as before
+  static const int f16_env = AASR_EXPERIMENT_ENV("AASR_F16X2") ? atoi(AASR_EXPERIMENT_ENV("AASR_F16X2")) : 1;
+  static const int mixed_env = AASR_EXPERIMENT_ENV("AASR_MIXED") ? atoi(AASR_EXPERIMENT_ENV("AASR_MIXED")) : 1;   // 0: whole-model precision as before
   if (!f16_env || !mixed_env) return;
   for (int attempt = 0; attempt < 64; attempt++) {
     int64_t n_ok = 0;
@@ -1922,7 +1922,7 @@ static void find_outliers(aasr_gmm *g) {
   g->kappa2_matrix = kappa2_in;
   g->ill_conditioned = any_bad;
   const int dimp = centred_dimp_for(D);
-  static const int routing = getenv("AASR_OUTLIER_ROUTING") ? atoi(getenv("AASR_OUTLIER_ROUTING")) : 1;
+  static const int routing = AASR_EXPERIMENT_ENV("AASR_OUTLIER_ROUTING") ? atoi(AASR_EXPERIMENT_ENV("AASR_OUTLIER_ROUTING")) : 1;
   g->hyb_comps.clear();
   if (!g->ill_conditioned || !dimp || !routing) return;
   std::vector<int32_t> comps, off{0}, map;
@@ -2252,7 +2252,7 @@ void gmm_build_fullcov(aasr_gmm *g) {
       // diagonal form's choice, pushes the FRAME operand into the subnormals instead: measured fivefold worse.)
       L.a16h = DevBuf<uint16_t>();
       L.f16scale = DevBuf<float>();
-      static const bool f16_env = !(getenv("AASR_F16X2") && atoi(getenv("AASR_F16X2")) == 0);
+      static const bool f16_env = !(AASR_EXPERIMENT_ENV("AASR_F16X2") && atoi(AASR_EXPERIMENT_ENV("AASR_F16X2")) == 0);
       std::vector<double> kap((size_t)m.G, 0.0), colmax((size_t)m.G * D, 0.0), poolmax((size_t)D, 0.0);
       for (int64_t r = 0; r < tiles * TILE_ROWS; r++) {
         const int32_t gi = r < (int64_t)L.row_gauss.size() ? L.row_gauss[(size_t)r] : -1;

@@ -575,7 +575,7 @@ static void launch_tracks_t(const aasr_gmm *g, const TrackLayout &L, const float
                             int64_t pitch) {
   const int64_t blocks = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
   const int smem = TrackSmem<NKK, GROUPED>::kBytes;
-  static const int dbg = getenv("AASR_DBG") ? atoi(getenv("AASR_DBG")) : 0;
+  static const int dbg = AASR_EXPERIMENT_ENV("AASR_DBG") ? atoi(AASR_EXPERIMENT_ENV("AASR_DBG")) : 0;
   static bool attr_set[64] = {false};
   auto kern = k_gmm_diag_score_tracks<NKK, GROUPED, CL>;
   if (!attr_set[g->device & 63]) {
@@ -584,7 +584,7 @@ static void launch_tracks_t(const aasr_gmm *g, const TrackLayout &L, const float
   }
   // Row-range cuts: pick the number of cuts R that leaves the smallest tail
   // round on the chip (2 workgroups per CU resident), preferring fewer cuts.
-  static const int force_r = getenv("AASR_SPLITS") ? atoi(getenv("AASR_SPLITS")) : 0;
+  static const int force_r = AASR_EXPERIMENT_ENV("AASR_SPLITS") ? atoi(AASR_EXPERIMENT_ENV("AASR_SPLITS")) : 0;
   const double slots = 2.0 * (g->num_cus > 0 ? g->num_cus : 256);
   int R = 1;
   double best_eff = 0;
@@ -1636,8 +1636,8 @@ static const u32x4 *frame_operand(const aasr_gmm *g, const TrackLayout &L, const
 // R = 2 / 4 / 8 / 16: 8.51 / 8.68 / 8.94 / 9.20): the fixed part was 6.6 tiles with the operand built in the kernel.
 // The former rule -- the R whose last round is fullest -- took R = 9 there (8.86 ms).
 static int pick_row_cuts(int64_t blocks, double slots, int64_t tiles, int max_splits, double overhead) {
-  static const int force_r = getenv("AASR_SPLITS") ? atoi(getenv("AASR_SPLITS")) : 0;
-  static const double force_c = getenv("AASR_CUT_OVERHEAD") ? atof(getenv("AASR_CUT_OVERHEAD")) : -1.0;
+  static const int force_r = AASR_EXPERIMENT_ENV("AASR_SPLITS") ? atoi(AASR_EXPERIMENT_ENV("AASR_SPLITS")) : 0;
+  static const double force_c = AASR_EXPERIMENT_ENV("AASR_CUT_OVERHEAD") ? atof(AASR_EXPERIMENT_ENV("AASR_CUT_OVERHEAD")) : -1.0;
   if (force_r >= 1 && force_r <= max_splits) return force_r;
   if (force_c >= 0) overhead = force_c;
   int R = 1;
@@ -1660,9 +1660,9 @@ static int pick_row_cuts(int64_t blocks, double slots, int64_t tiles, int max_sp
 // pick_row_cuts; falls back to the uniform plan when that is no better.
 static CutPlan pick_cut_plan(int64_t blocks, double slots_d, int64_t tiles, int max_splits, double overhead,
                              const int32_t *splits_base, int min_splits = 1, int split_cap = TRACK_MAX_SPLITS) {
-  static const int force_r = getenv("AASR_SPLITS") ? atoi(getenv("AASR_SPLITS")) : 0;
-  static const double force_c = getenv("AASR_CUT_OVERHEAD") ? atof(getenv("AASR_CUT_OVERHEAD")) : -1.0;
-  static const int two_level = getenv("AASR_TWO_LEVEL") ? atoi(getenv("AASR_TWO_LEVEL")) : 1;
+  static const int force_r = AASR_EXPERIMENT_ENV("AASR_SPLITS") ? atoi(AASR_EXPERIMENT_ENV("AASR_SPLITS")) : 0;
+  static const double force_c = AASR_EXPERIMENT_ENV("AASR_CUT_OVERHEAD") ? atof(AASR_EXPERIMENT_ENV("AASR_CUT_OVERHEAD")) : -1.0;
+  static const int two_level = AASR_EXPERIMENT_ENV("AASR_TWO_LEVEL") ? atoi(AASR_EXPERIMENT_ENV("AASR_TWO_LEVEL")) : 1;
   if (force_c >= 0) overhead = force_c;
   const int64_t slots = (int64_t)slots_d;
   CutPlan best;
@@ -1710,7 +1710,7 @@ static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const TrackSe
   const int64_t blocks = (F + NW * FRAMES_PER_WAVE - 1) / (NW * FRAMES_PER_WAVE);
   const int smem = (WIDE ? 3 : 2) * Bf16Smem<NK16, GROUPED, WIDE, NS>::kTileBytes +
                    NW * Bf16Smem<NK16, GROUPED, WIDE, NS>::kOutFloatsPerWave * 4;
-  static const int dbg = getenv("AASR_DBG") ? atoi(getenv("AASR_DBG")) : 0;
+  static const int dbg = AASR_EXPERIMENT_ENV("AASR_DBG") ? atoi(AASR_EXPERIMENT_ENV("AASR_DBG")) : 0;
   static bool attr_set[64] = {false};
   auto kern = k_gmm_diag_score_bf16x3<NK16, GROUPED, CL, WIDE, NS>;
   if (!attr_set[g->device & 63]) {
@@ -1736,7 +1736,7 @@ static void launch_pl_t(const aasr_gmm *g, const TrackLayout &L, const TrackSect
   constexpr int NW = WIDE ? 8 : 4;
   const int64_t blocks = (F + NW * FRAMES_PER_WAVE - 1) / (NW * FRAMES_PER_WAVE);
   const int smem = PlSmem<NK16, GROUPED, WIDE, NS>::kBytes;
-  static const int dbg = getenv("AASR_DBG") ? atoi(getenv("AASR_DBG")) : 0;
+  static const int dbg = AASR_EXPERIMENT_ENV("AASR_DBG") ? atoi(AASR_EXPERIMENT_ENV("AASR_DBG")) : 0;
   static bool attr_set[64] = {false};
   auto kern = k_gmm_diag_score_pl<NK16, GROUPED, CL, WIDE, NS, MAPPED>;
   if (!attr_set[g->device & 63]) {
@@ -1785,7 +1785,7 @@ static bool launch_split(const aasr_gmm *g, const TrackLayout &L, const float *d
   const bool mapped = sec ? sec->mapped : false;
   const ClusterArgs none;
   // AASR_BF16_WIDE=0 selects the 4-wave workgroups
-  static const int wide_env = getenv("AASR_BF16_WIDE") ? atoi(getenv("AASR_BF16_WIDE")) : -1;
+  static const int wide_env = AASR_EXPERIMENT_ENV("AASR_BF16_WIDE") ? atoi(AASR_EXPERIMENT_ENV("AASR_BF16_WIDE")) : -1;
   // small batches (a decoder's per-utterance blocks) fill the chip better with 256-frame workgroups
   // ... and so does a short section of a mixed layout (a few states on three terms): more, smaller workgroups
   const int wide = wide_env >= 0 ? wide_env : ((F >= 8192 && (!sec || sec->tile_end - sec->tile_begin >= 64)) ? 1 : 0);
@@ -1864,7 +1864,7 @@ static const TrackLayout *split_layout(const aasr_gmm *g) {
 // AASR_F16_PROBE=0 switches the guard off.
 // ---------------------------------------------------------------------------
 void gmm_probe_f16x2(aasr_gmm *g) {
-  static const int probe_env = getenv("AASR_F16_PROBE") ? atoi(getenv("AASR_F16_PROBE")) : 1;
+  static const int probe_env = AASR_EXPERIMENT_ENV("AASR_F16_PROBE") ? atoi(AASR_EXPERIMENT_ENV("AASR_F16_PROBE")) : 1;
   static const float probe_tol = getenv("AASR_F16_PROBE_TOL") ? (float)atof(getenv("AASR_F16_PROBE_TOL")) : 5.0e-5f;  // test hook
   g->f16_probe_moved = 0;
   if (!probe_env || !g->dim_parts.empty() || g->class_routing || g->host.factor_path() || g->ill_conditioned) return;
@@ -2944,7 +2944,7 @@ static void launch_t(const aasr_gmm *g, const PackedRows &pr, const float *d_fra
   if (F <= 0) return;
   const int64_t blocks = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
   int smem = ScoreSmem<NKK>::kBytes;
-  static const int dbg = getenv("AASR_DBG") ? atoi(getenv("AASR_DBG")) : 0;
+  static const int dbg = AASR_EXPERIMENT_ENV("AASR_DBG") ? atoi(AASR_EXPERIMENT_ENV("AASR_DBG")) : 0;
   if (dbg & 2) smem = 100 * 1024;  // ablation: one workgroup per CU
   static bool attr_set[64] = {false};
   auto kern = k_gmm_diag_score<NKK, MODE>;

@@ -334,7 +334,7 @@ struct Job {
 // library has no such switch.
 static bool stub_device() {
 #if defined(AASR_ABLATION) && AASR_ABLATION
-  static const bool on = getenv("AASR_RECIPE_STUB") && atoi(getenv("AASR_RECIPE_STUB")) == 1;
+  static const bool on = AASR_EXPERIMENT_ENV("AASR_RECIPE_STUB") && atoi(AASR_EXPERIMENT_ENV("AASR_RECIPE_STUB")) == 1;
   return on;
 #else
   return false;
