@@ -428,7 +428,7 @@ aasr_status aasr_gmm_gauss_loglik(aasr_gmm *h, const float *frames, int64_t F,
 
 int64_t aasr_gmm_score_scratch_floats(const aasr_gmm *h, int64_t F) {
   if (!h || F < 0) return -1;
-  return F * gmm_engine_pitch(h);
+  return F * gmm_engine_pitch_max(h);   // independent of the precision / clustering / transform state (ADVICE, round 4)
 }
 
 aasr_status aasr_gmm_score_lna_dev(aasr_gmm *h, const float *d_frames, int64_t F, int normalize, int lnabytes,

@@ -454,6 +454,7 @@ void gmm_plan_engine_parts(aasr_gmm *g);
 bool gmm_engine_parts_active(const aasr_gmm *g);
 // the engine's own score layout: rows of gmm_engine_pitch() floats; state s in column gmm_engine_colmap()[s] (nullptr: s)
 int64_t gmm_engine_pitch(const aasr_gmm *g);
+int64_t gmm_engine_pitch_max(const aasr_gmm *g);
 const int32_t *gmm_engine_colmap(const aasr_gmm *g);
 void gmm_score_launch_engine(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, int64_t pitch, hipStream_t stream);
 void lna_encode_launch(const float *d_loglik, int64_t F, int S, int normalize, int lnabytes, float *d_lp,

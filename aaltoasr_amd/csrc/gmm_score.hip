@@ -3319,6 +3319,14 @@ int64_t gmm_engine_pitch(const aasr_gmm *g) {
   return g->routed_sub ? base + (g->routed_sub->S + 31) / 32 * 32 : base;
 }
 
+// the largest row pitch gmm_engine_pitch() can return for this model whatever the precision, clustering or transform
+// state: what a caller sizes its scratch with (aasr_gmm_score_scratch_floats)
+int64_t gmm_engine_pitch_max(const aasr_gmm *g) {
+  int64_t p = (g->S + 31) / 32 * 32;
+  if (g->routed_sub) p += (g->routed_sub->S + 31) / 32 * 32;
+  return std::max(p, g->engine_cols);
+}
+
 const int32_t *gmm_engine_colmap(const aasr_gmm *g) {
   if (gmm_engine_parts_active(g)) return g->engine_colmap.p;
   return engine_alias(g) ? g->routed_colmap.p : nullptr;

@@ -359,10 +359,12 @@ aasr_status aasr_lna_encode_dev(const float *d_state_loglik, int64_t F,
                                 void *stream);
 /* Frames straight to LNA codes on the device: aasr_gmm_score_dev followed by
  * aasr_lna_encode_dev, except that the engine may keep the state scores in its
- * own layout in between (rows padded to whole cache lines; the states a routed model scores with three terms --
- * aasr_gmm_precision_states -- in spare columns behind the others, read back through a column map).  d_scratch takes
- * aasr_gmm_score_scratch_floats(h, F) floats (ask again after a change of clustering / transforms: it only shrinks),
- * d_bytes_out F * num_states * lnabytes bytes.  What the recipe driver runs per block. */
+ * own layout in between (rows padded to whole cache lines; a model whose conditioning needs several pivots -- or three
+ * terms for part of its states, aasr_gmm_precision_states -- as internal models over disjoint sets of its states, each in
+ * its own column range, read back through a column map).  d_scratch takes aasr_gmm_score_scratch_floats(h, F) floats: a
+ * property of the MODEL -- it does not change with aasr_gmm_set_precision, clustering or transforms, so a buffer sized
+ * once stays valid for the handle's life --, d_bytes_out F * num_states * lnabytes bytes.  What the recipe driver runs
+ * per block. */
 int64_t aasr_gmm_score_scratch_floats(const aasr_gmm *h, int64_t F);
 aasr_status aasr_gmm_score_lna_dev(aasr_gmm *h, const float *d_frames, int64_t F, int normalize, int lnabytes,
                                    float *d_scratch, uint8_t *d_bytes_out, void *stream);
