@@ -821,7 +821,7 @@ static void build_pg_model(aasr_gmm *g) {
   g->precision = m.pg_arith == 2 ? AASR_PREC_F16X2 : AASR_PREC_BF16X3;
   g->use_bf16x3 = true;
   g->rows_unbiased = true;
-  if (m.pg_arith == 2) gmm_probe_f16x2(g);   // marks the states it rejects in f16_state_ok (the planner moves them)
+  gmm_probe_f16x2(g);   // marks the states it rejects in f16_state_ok (the planner moves them)
 }
 
 namespace {
@@ -1056,7 +1056,10 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
   const double cost3 = pivot_cost_env >= 0 ? pivot_cost_env : 400.0 / 4.0;
   static const double lim_scale = AASR_EXPERIMENT_ENV("AASR_PG_LIMIT_SCALE") ? atof(AASR_EXPERIMENT_ENV("AASR_PG_LIMIT_SCALE")) : 1.0;   // EXPERIMENT
   const PgLimits lim2{lim_scale * KAPPA_LIMIT_F16, lim_scale * (D < 8 ? KAPPA2_LIMIT_F16_LOWDIM : KAPPA2_LIMIT_F16)};
-  const PgLimits lim3{lim_scale * KAPPA_LIMIT, lim_scale * KAPPA2_LIMIT};
+  // three terms carry 4 bits more per operand than two: with the interleaved K order (gmm_score.hip) the error no longer
+  // follows kappa at the one-pivot forms' limits, so a part of its own admits states up to 1.5 times those -- every one of
+  // them probed on the device like the two-term rows (gmm_probe_f16x2)
+  const PgLimits lim3{lim_scale * 1.5 * KAPPA_LIMIT, lim_scale * 1.5 * KAPPA2_LIMIT};
   std::vector<int64_t> cand;
   for (int64_t s = 0; s < m.S; s++) cand.push_back(s);
   std::vector<aasr_gmm::EnginePart> parts;
@@ -1103,7 +1106,7 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
   // part 0: two fp16 terms
   {
     std::vector<int64_t> pool = cand, out;
-    for (int attempt = 0; attempt < 4 && !pool.empty(); attempt++) {
+    for (int attempt = 0; attempt < 8 && !pool.empty(); attempt++) {
       PgPlan plan = pg_plan(m, pool, lim2, cost2, PG_MAX);
       say("[two terms, attempt %d: %zu candidates -> %zu groups, %zu rejected] ", attempt, pool.size(), plan.groups.size(),
           plan.rejected.size());
@@ -1134,12 +1137,29 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
   if (parts.empty()) return;   // nothing qualifies for two terms around any pivot: the model's own paths
   // part 1: three bf16 terms
   if (!cand.empty()) {
-    PgPlan plan = pg_plan(m, cand, lim3, cost3, PG_MAX);
-    say("[three terms: %zu candidates -> %zu groups, %zu rejected] ", cand.size(), plan.groups.size(), plan.rejected.size());
-    if (!plan.groups.empty() && build_part(plan.groups, plan.pivots, 3, nullptr)) {
-      cand = plan.rejected;
-      std::sort(cand.begin(), cand.end());
+    std::vector<int64_t> pool = cand, out;
+    for (int attempt = 0; attempt < 8 && !pool.empty(); attempt++) {
+      PgPlan plan = pg_plan(m, pool, lim3, cost3, PG_MAX);
+      say("[three terms, attempt %d: %zu candidates -> %zu groups, %zu rejected] ", attempt, pool.size(), plan.groups.size(),
+          plan.rejected.size());
+      out.insert(out.end(), plan.rejected.begin(), plan.rejected.end());
+      if (plan.groups.empty()) { pool.clear(); break; }
+      std::vector<int64_t> rejects;
+      if (build_part(plan.groups, plan.pivots, 3, &rejects)) { pool.clear(); break; }
+      std::vector<uint8_t> rej((size_t)m.S, 0);
+      for (int64_t s : rejects) rej[(size_t)s] = 1;
+      if (rejects.empty())   // no layout at all
+        for (const auto &gr : plan.groups)
+          for (int64_t s : gr) rej[(size_t)s] = 1;
+      probe_moved += (int64_t)rejects.size();
+      pool.clear();
+      for (const auto &gr : plan.groups)
+        for (int64_t s : gr) (rej[(size_t)s] ? out : pool).push_back(s);
+      std::sort(pool.begin(), pool.end());
     }
+    out.insert(out.end(), pool.begin(), pool.end());   // (what eight attempts did not settle)
+    std::sort(out.begin(), out.end());
+    cand = out;
   }
   // part 2: whatever is left, as an ordinary model
   if (!cand.empty()) {

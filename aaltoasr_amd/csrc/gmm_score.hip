@@ -1891,7 +1891,10 @@ void gmm_probe_f16x2(aasr_gmm *g) {
   for (int round = 0; round < 2; round++) {
     TrackLayout &L0 = g->paired.ok ? g->paired : g->tracks;
     if (!L0.ok) return;
-    const TrackLayout *LF = g->mixed.ok ? &g->mixed : (L0.a16h.p ? &L0 : nullptr);
+    // (a three-term engine part -- gmm_plan_engine_parts admits states to it beyond the one-pivot forms' limits -- is
+    // probed the same way on its own rows)
+    const bool pg3 = m.n_pg() > 0 && m.pg_arith == 3;
+    const TrackLayout *LF = pg3 ? (L0.a16.p ? &L0 : nullptr) : g->mixed.ok ? &g->mixed : (L0.a16h.p ? &L0 : nullptr);
     if (!LF) return;
     // probe frames (deterministic): frame i sits on mixture component (i * step) % K
     std::vector<float> fr((size_t)P * D);
@@ -1925,7 +1928,7 @@ void gmm_probe_f16x2(aasr_gmm *g) {
     const bool use = g->use_bf16x3;
     g->precision = AASR_PREC_F16X2;
     g->use_bf16x3 = true;
-    const bool ok_a = launch_bf16(g, *LF, d_fr.p, P, d_a.p, nullptr);
+    const bool ok_a = pg3 ? launch_split<3>(g, *LF, d_fr.p, P, d_a.p, nullptr) : launch_bf16(g, *LF, d_fr.p, P, d_a.p, nullptr);
     g->precision = prec;
     g->use_bf16x3 = use;
     if (!ok_a) return;
@@ -1951,7 +1954,9 @@ void gmm_probe_f16x2(aasr_gmm *g) {
           sum += std::exp(cst[(size_t)k] - 0.5 * q);
         }
         const double ref = std::log(std::max(sum, 1e-50)) + g->out_bias_ln;
-        if (ref > -103.0 && !(std::fabs((double)a[(size_t)i * S + s2] - ref) <= (double)probe_tol)) {
+        // (three-term part: 3/4 of the contract -- its operands carry 24 bits, what the probe sees there is the f32
+        // accumulators' granularity at |log2 value| ~ 100, 5-7e-5 on the probe's 6-sigma frames, not conditioning)
+        if (ref > -103.0 && !(std::fabs((double)a[(size_t)i * S + s2] - ref) <= (double)probe_tol * (pg3 ? 1.5 : 1.0))) {
           bad[(size_t)s2] = 1;
           n_bad++;
         }

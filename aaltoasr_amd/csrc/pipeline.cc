@@ -681,7 +681,9 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
   // 12 -> 5.9, 16 -> 6.5, 24 -> 6.9 M frames/s, fresh files on tmpfs: a writer is a core's worth of page allocation +
   // copy, 2.7 GB/s).  N ranks on one host (aasr_set_host_share / LOCAL_WORLD_SIZE) divide the cores between them;
   // a constant 16 per rank put 128 writers on a 16-CPU quota at eight ranks.
-  int n_writers = std::max(2, std::min(32, host_usable_cores() / host_share()));
+  // (half as many writers again as cores: a writer that waits for a page does not hold its core -- 16 -> 24 threads on the
+  // 16-CPU quota measured 6.5 -> 6.9 M frames/s)
+  int n_writers = std::max(2, std::min(48, host_usable_cores() * 3 / 2 / host_share()));
   if (const char *e = getenv("AASR_WRITER_THREADS")) n_writers = std::max(1, std::min(64, atoi(e)));
   auto writer_main = [&] {
     for (;;) {
