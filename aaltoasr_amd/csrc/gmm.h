@@ -452,6 +452,10 @@ void gmm_probe_f16x2(aasr_gmm *g);
 void gmm_build_routed_sub(aasr_gmm *g);
 void gmm_plan_engine_parts(aasr_gmm *g);
 bool gmm_engine_parts_active(const aasr_gmm *g);
+bool gmm_engine_parts_clustered(const aasr_gmm *g);   // ... under Gaussian clustering (gmm_cluster_score_launch)
+void gmm_scatter_columns(const float *dense, int64_t F, int64_t n, float *out, int64_t pitch, hipStream_t stream);
+void gmm_gather_engine_columns(const aasr_gmm *g, const float *rows, int64_t F, int64_t in_pitch, float *out, int64_t out_pitch,
+                               hipStream_t stream);
 // the engine's own score layout: rows of gmm_engine_pitch() floats; state s in column gmm_engine_colmap()[s] (nullptr: s)
 int64_t gmm_engine_pitch(const aasr_gmm *g);
 int64_t gmm_engine_pitch_max(const aasr_gmm *g);

@@ -875,13 +875,13 @@ template <int NNZ, int kMergeThreads>
 __global__ __launch_bounds__(kMergeThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cluster_merge(
     float *__restrict__ out, int64_t F, int64_t S, const float *__restrict__ cval, int C,
     const int32_t *__restrict__ w_cluster, const float *__restrict__ w_weight, int nnz,
-    float ref, int frames_per_block, int cstride, int64_t pitch) {
+    float ref, int frames_per_block, int cstride, int64_t pitch, const int32_t *__restrict__ colmap) {
   // [C][cstride]: cstride = 12 floats spreads the 16-byte reads of different
   // clusters over all banks (8 would put every read on 4 bank groups)
   extern __shared__ __attribute__((aligned(16))) float cv[];
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x;
-  int64_t st[kMergeSPT];
+  int64_t st[kMergeSPT], col[kMergeSPT];   // col: the state's column in a score row (engine parts: gmm_engine_colmap)
   bool live[kMergeSPT];
   unsigned wcp[kMergeSPT][(NNZ + 1) / 2];  // LDS offsets of the clusters, two 16-bit values per register
   float ww[kMergeSPT][NNZ];
@@ -890,6 +890,7 @@ __global__ __launch_bounds__(kMergeThreads) __attribute__((amdgpu_waves_per_eu(4
     st[u] = ((int64_t)blockIdx.x * kMergeSPT + u) * kMergeThreads + tid;
     live[u] = st[u] < S;
     const int64_t sc = live[u] ? st[u] : S - 1;
+    col[u] = colmap ? colmap[sc] : sc;
 #pragma unroll
     for (int j = 0; j < NNZ; j += 2) {
       const unsigned c0 = j < nnz ? (unsigned)w_cluster[(int64_t)j * S + sc] : 0u;
@@ -914,7 +915,7 @@ __global__ __launch_bounds__(kMergeThreads) __attribute__((amdgpu_waves_per_eu(4
     for (int u = 0; u < kMergeSPT; u++)
 #pragma unroll
       for (int k = 0; k < kMergeFrames; k++)
-        onext[u][k] = (live[u] && k < nf) ? out[(fg + k) * pitch + st[u]] : 0.0f;
+        onext[u][k] = (live[u] && k < nf) ? out[(fg + k) * pitch + col[u]] : 0.0f;
   };
   if (f_begin < f_end) request(f_begin);
   for (int64_t fg = f_begin; fg < f_end; fg += kMergeFrames) {
@@ -973,7 +974,7 @@ __global__ __launch_bounds__(kMergeThreads) __attribute__((amdgpu_waves_per_eu(4
         if (k < nf) {
           const float l2 = xk[k] <= 60.0f ? __log2f(lin[k]) : xk[k] + __log2f(1.0f + lin[k] * exp2f(-xk[k]));
           const float l = fmaf(l2, 0.69314718055994530942f, -ref_ln);
-          out[(fg + k) * pitch + st[u]] = fmaxf(l, AASR_LOG_TINY_F);
+          out[(fg + k) * pitch + col[u]] = fmaxf(l, AASR_LOG_TINY_F);
         }
     }
   }
@@ -1085,10 +1086,14 @@ void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
   // fit under that exponent (clusters of variance-floored Gaussians: +121 nats at sigma 0.045), takes
   // the log-domain merge instead: centre values as log2, per-state (max, sum) -- no range limit.
   n.log_merge = !g->paired.ok && !g->tracks.ok;
+  // (a model scored through engine parts: its first part's layout stands in for the model's own)
+  const TrackLayout *part_layout = (!g->engine_parts.empty() && g->engine_parts[0].model->paired.ok)
+                                       ? &g->engine_parts[0].model->paired : nullptr;
+  if (n.log_merge && part_layout) n.log_merge = false;
   // the linear merge stages a frame group's centre values in LDS, [cluster][8 frames]: beyond 4 608 clusters they do
   // not fit, and the log-domain merge reads them through the caches
   if ((size_t)n_clusters * kMergeFrames * sizeof(float) > 144 * 1024) n.log_merge = true;
-  n.ref_log2 = g->paired.ok ? g->paired.ref_log2 : g->tracks.ok ? g->tracks.ref_log2 : 0.0;
+  n.ref_log2 = g->paired.ok ? g->paired.ref_log2 : g->tracks.ok ? g->tracks.ref_log2 : part_layout ? part_layout->ref_log2 : 0.0;
   n.csize_h.resize((size_t)n.Cs, 0);
   n.c_mean.assign((size_t)n.C * m.dim, 0.0);
   n.c_prec.assign((size_t)n.C * m.dim, 0.0);
@@ -1438,12 +1443,14 @@ static bool cluster_fast_keys(const aasr_gmm *g) {
 __global__ __launch_bounds__(256) void k_cluster_merge_log(float *__restrict__ out, int64_t F, int64_t S,
                                                            const float *__restrict__ cvl, int C,
                                                            const int32_t *__restrict__ w_cluster,
-                                                           const float *__restrict__ w_weight, int nnz, int64_t pitch) {
+                                                           const float *__restrict__ w_weight, int nnz, int64_t pitch,
+                                                           const int32_t *__restrict__ colmap) {
   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (s >= S) return;
+  const int64_t sc = colmap ? colmap[s] : s;
   for (int64_t f = blockIdx.y; f < F; f += gridDim.y) {
     const float *cv = cvl + f * C;
-    const float x = out[f * pitch + s] * 1.4426950408889634f;
+    const float x = out[f * pitch + sc] * 1.4426950408889634f;
     float m = x;
     for (int j = 0; j < nnz; j++) {
       const float w = w_weight[(int64_t)j * S + s];
@@ -1458,14 +1465,14 @@ __global__ __launch_bounds__(256) void k_cluster_merge_log(float *__restrict__ o
       }
       l = (m + __log2f(sum)) * 0.69314718055994530942f;
     }
-    out[f * pitch + s] = fmaxf(l, AASR_LOG_TINY_F);
+    out[f * pitch + sc] = fmaxf(l, AASR_LOG_TINY_F);
   }
 }
 
-static void launch_merge(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hipStream_t stream);
+static void launch_merge(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hipStream_t stream, const int32_t *colmap = nullptr);
 
 template <int NNZ, int kMergeThreads>
-static void launch_merge_t(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hipStream_t stream) {
+static void launch_merge_t(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hipStream_t stream, const int32_t *colmap) {
   ClusterState &cl = g->cl;
   const int64_t bx = (g->S + kMergeThreads * kMergeSPT - 1) / (kMergeThreads * kMergeSPT);
   // enough workgroups to fill the chip, each walking a contiguous run of frames
@@ -1483,23 +1490,23 @@ static void launch_merge_t(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, 
   }
   hipLaunchKernelGGL((k_cluster_merge<NNZ, kMergeThreads>), dim3((unsigned)bx, (unsigned)by), dim3(kMergeThreads), smem,
                      stream, d_out, F, g->S, cl.cval.p, cl.C, cl.w_cluster.p, cl.w_weight.p, cl.nnz,
-                     (float)cl.ref_log2, fpb, cstride, pitch);
+                     (float)cl.ref_log2, fpb, cstride, pitch, colmap);
   AASR_HIP(hipGetLastError());
 }
 
-static void launch_merge(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hipStream_t stream) {
+static void launch_merge(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hipStream_t stream, const int32_t *colmap) {
   ClusterState &cl = g->cl;
   if (cl.log_merge) {
     hipLaunchKernelGGL(k_cluster_merge_log, dim3((unsigned)((g->S + 255) / 256), (unsigned)std::min<int64_t>(F, 8192)),
-                       dim3(256), 0, stream, d_out, F, g->S, cl.cval.p, cl.C, cl.w_cluster.p, cl.w_weight.p, cl.nnz, pitch);
+                       dim3(256), 0, stream, d_out, F, g->S, cl.cval.p, cl.C, cl.w_cluster.p, cl.w_weight.p, cl.nnz, pitch, colmap);
     AASR_HIP(hipGetLastError());
     return;
   }
   static const int threads = AASR_EXPERIMENT_ENV("AASR_MERGE_THREADS") ? atoi(AASR_EXPERIMENT_ENV("AASR_MERGE_THREADS")) : 1024;
-  if (cl.nnz <= 8) launch_merge_t<8, 1024>(g, d_out, F, pitch, stream);
-  else if (threads == 512) launch_merge_t<16, 512>(g, d_out, F, pitch, stream);
-  else if (threads == 256) launch_merge_t<16, 256>(g, d_out, F, pitch, stream);
-  else launch_merge_t<16, 1024>(g, d_out, F, pitch, stream);   // weights beyond 16 per state come from L2
+  if (cl.nnz <= 8) launch_merge_t<8, 1024>(g, d_out, F, pitch, stream, colmap);
+  else if (threads == 512) launch_merge_t<16, 512>(g, d_out, F, pitch, stream, colmap);
+  else if (threads == 256) launch_merge_t<16, 256>(g, d_out, F, pitch, stream, colmap);
+  else launch_merge_t<16, 1024>(g, d_out, F, pitch, stream, colmap);   // weights beyond 16 per state come from L2
 }
 
 // What a model's exact part needs besides the selection bits: the cluster of each of ITS rows /
@@ -1613,7 +1620,13 @@ static void exact_part_launch(aasr_gmm *g, ClusterState &cl, const ExactPlan &p,
 // A row pitch (state rows padded to whole cache lines, gmm_score_pitch_ok) is carried by the plain plan only: one
 // masked track kernel and the merge.  Class sub-models, outlier routing, the centred and full-covariance kernels write
 // dense rows.
+// ... whatever the clustering state of the handle itself (an engine part's own exact part)
+static bool gmm_cluster_plan_pitch_ok(const aasr_gmm *g) {
+  return !g->class_routing && !g->host.any_full() && !g->host.factor_path() && !g->hyb_enabled && !g->ill_conditioned &&
+         g->dim_parts.empty() && (g->paired.ok || g->tracks.ok);
+}
 bool gmm_cluster_pitch_ok(const aasr_gmm *g) {
+  if (g->cl.enabled && gmm_engine_parts_clustered(g)) return true;   // gathered into any pitch
   return g->cl.enabled && !g->class_routing && !g->host.any_full() && !g->host.factor_path() && !g->hyb_enabled &&
          !g->ill_conditioned && (g->paired.ok || g->tracks.ok);
 }
@@ -1640,7 +1653,33 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
   ExactPlan plan{};
   std::vector<ExactPlan> sub_plans;
   int64_t mask_rows = 0;
-  if (classes) {
+  // Engine parts (gmm_plan_engine_parts: a model whose conditioning needs several pivots): every part gives the exact
+  // part of ITS states under the same selection bits -- its own rows, masks, arithmetic -- into its column range of an
+  // engine score row; the merge adds the centres' share through the column map, the columns are gathered back.  What a
+  // clustered recogniser run (pyrectool: always) costs on a model fitted to data then stays next to the BASELINE model's
+  // instead of falling to the centred form for every Gaussian.
+  const bool parts = gmm_engine_parts_clustered(g);
+  if (parts) {
+    sub_plans.resize(g->engine_parts.size());
+    for (size_t c = 0; c < g->engine_parts.size(); c++) {
+      aasr_gmm *sub = g->engine_parts[c].model.get();
+      if (!sub->cl.loaded || sub->cl.C != cl.C || sub->cl.g2c.size() != (size_t)sub->G) {
+        sub->cl = ClusterState();
+        sub->cl.C = cl.C;
+        sub->cl.g2c.assign((size_t)sub->G, -1);
+        for (int64_t i = 0; i < sub->G && i < (int64_t)sub->parent_gauss.size(); i++)
+          sub->cl.g2c[(size_t)i] = cl.g2c[(size_t)sub->parent_gauss[(size_t)i]];
+        sub->cl.loaded = true;
+      }
+      if (g->engine_parts[c].arith == 0) {
+        sub->precision = g->precision;
+        sub->use_bf16x3 = g->use_bf16x3;
+      }
+      sub->out_bias_ln = g->out_bias_ln;
+      sub_plans[c] = exact_part_plan(sub, sub->cl);
+      mask_rows = std::max(mask_rows, sub_plans[c].mask_rows);
+    }
+  } else if (classes) {
     sub_plans.resize(g->class_models.size());
     for (size_t c = 0; c < g->class_models.size(); c++) {
       aasr_gmm *sub = g->class_models[c].get();
@@ -1670,7 +1709,9 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
   // masks, 4 B per frame x cluster for the centre values) and a whole number of rounds
   // of the track kernel (2 workgroups of 256 frames per CU); the f64 centre
   // log-likelihoods (8 B per frame x cluster) only live for a sub-pass of <= 8.6 GB (10^6 frames x 1000 clusters in one go: 42.7 ms per pass instead of 45.0 with five sub-passes of 2 GB, whose launches each end in a partly filled round of the one-wave selection workgroups; smaller sub-passes are worse still: 512 MB 52 ms, 256 MB 61 ms).
-  const double per_frame = (double)mask_rows / 8.0 + 4.125 * (double)(cl.C + 1) + 4.0 + (classes ? 4.0 * (double)g->S : 0.0);
+  const int64_t ep = parts ? gmm_engine_pitch_max(g) : 0;
+  const double per_frame = (double)mask_rows / 8.0 + 4.125 * (double)(cl.C + 1) + 4.0 + (classes ? 4.0 * (double)g->S : 0.0) +
+                           (parts ? 8.0 * (double)ep : 0.0);
   const int64_t round_frames = 2 * (int64_t)(g->num_cus > 0 ? g->num_cus : 256) * FRAMES_PER_BLOCK;
   const int64_t f_rounded = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK;
   int64_t fb = (int64_t)(16.0e9 / per_frame);
@@ -1710,6 +1751,30 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
         launch_centres(g, fr + s0 * g->dim, ns, stream);
         launch_select(g, s0, ns, stream);
       }
+    }
+    if (parts) {
+      if ((size_t)n * ep > g->engine_scratch.n) {
+        AASR_HIP(hipDeviceSynchronize());
+        g->engine_scratch.ensure((size_t)cl.Fc * ep);
+      }
+      for (size_t c = 0; c < g->engine_parts.size(); c++) {
+        auto &part = g->engine_parts[c];
+        aasr_gmm *sub = part.model.get();
+        float *o = g->engine_scratch.p + part.col0;
+        if (gmm_cluster_plan_pitch_ok(sub)) {
+          exact_part_launch(sub, sub->cl, sub_plans[c], cl.maskw.p, cl.C + 1, n, fr_members, o, stream, ep);
+        } else {   // (the remainder's centred / outlier kernels write dense rows)
+          if ((size_t)n * sub->S > g->engine_part_scratch.n) {
+            AASR_HIP(hipDeviceSynchronize());
+            g->engine_part_scratch.ensure((size_t)cl.Fc * sub->S);
+          }
+          exact_part_launch(sub, sub->cl, sub_plans[c], cl.maskw.p, cl.C + 1, n, fr_members, g->engine_part_scratch.p, stream);
+          gmm_scatter_columns(g->engine_part_scratch.p, n, sub->S, o, ep, stream);
+        }
+      }
+      launch_merge(g, g->engine_scratch.p, n, ep, stream, g->engine_colmap.p);
+      gmm_gather_engine_columns(g, g->engine_scratch.p, n, ep, out, pitch, stream);
+      continue;
     }
     if (classes)
       gmm_classes_exact_launch(g, fr, n, out, [&](aasr_gmm *sub, size_t c, const float *xf, float *part) {

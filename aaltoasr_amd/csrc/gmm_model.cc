@@ -980,7 +980,8 @@ PgPlan pg_plan(const HostModel &m, const std::vector<int64_t> &cand, const PgLim
 }
 
 // the states `groups` list (in that order; groups padded to whole lines of 32 columns) as a model of their own
-HostModel pg_sub_model(const HostModel &m, const std::vector<std::vector<int64_t>> &groups, std::vector<int32_t> *col_of_state) {
+HostModel pg_sub_model(const HostModel &m, const std::vector<std::vector<int64_t>> &groups, std::vector<int32_t> *col_of_state,
+                       std::vector<int32_t> *parent_gauss = nullptr) {
   HostModel sm;
   sm.dim = m.dim;
   std::vector<int32_t> gmap((size_t)m.G, -1);
@@ -1011,6 +1012,11 @@ HostModel pg_sub_model(const HostModel &m, const std::vector<std::vector<int64_t
   }
   sm.pg_begin.push_back((int32_t)sm.S);
   sm.weights_normalized = true;
+  if (parent_gauss) {
+    parent_gauss->assign((size_t)sm.G, 0);
+    for (int64_t gi = 0; gi < m.G; gi++)
+      if (gmap[(size_t)gi] >= 0) (*parent_gauss)[(size_t)gmap[(size_t)gi]] = (int32_t)gi;
+  }
   if (sm.G == 0) {   // states without components only: the pool still needs an entry (no row points at it)
     sm.G = 1;
     sm.mean.assign((size_t)m.dim, 0.0);
@@ -1068,13 +1074,14 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
   int64_t probe_moved = 0;
   auto build_part = [&](const std::vector<std::vector<int64_t>> &groups, const std::vector<float> &pivots, int arith,
                         std::vector<int64_t> *probe_rejects) -> bool {
-    std::vector<int32_t> cols((size_t)m.S, -1);
-    HostModel sm = pg_sub_model(m, groups, &cols);
+    std::vector<int32_t> cols((size_t)m.S, -1), pgauss;
+    HostModel sm = pg_sub_model(m, groups, &cols, &pgauss);
     sm.pg_pivot = pivots;
     sm.pg_arith = arith;
     auto sub = std::make_unique<aasr_gmm>();
     sub->device = g->device;
     sub->is_engine_part = true;
+    sub->parent_gauss = pgauss;
     try {
       gmm_build(sub.get(), sm);
     } catch (const Error &e) {
@@ -1163,14 +1170,15 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
   }
   // part 2: whatever is left, as an ordinary model
   if (!cand.empty()) {
-    std::vector<int32_t> cols((size_t)m.S, -1);
-    HostModel sm = pg_sub_model(m, std::vector<std::vector<int64_t>>{cand}, &cols);
+    std::vector<int32_t> cols((size_t)m.S, -1), pgauss;
+    HostModel sm = pg_sub_model(m, std::vector<std::vector<int64_t>>{cand}, &cols, &pgauss);
     sm.pg_begin.clear();
     sm.pg_real_end.clear();
     auto sub = std::make_unique<aasr_gmm>();
     sub->device = g->device;
     sub->is_routed_sub = true;
     sub->is_engine_part = true;
+    sub->parent_gauss = pgauss;
     gmm_build(sub.get(), sm);
     aasr_gmm::EnginePart part;
     part.col0 = col0;

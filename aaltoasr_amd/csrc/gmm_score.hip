@@ -1799,7 +1799,7 @@ static bool launch_split(const aasr_gmm *g, const TrackLayout &L, const float *d
       launch_pl_t<N, GR, CLF, WD, NS>(g, L, sec, d_frames, F, d_out, stream, CLA, pitch);   \
     else if (L.n_pg > 1) {                                                                  \
       /* three bf16 terms on a multi-pivot layout: the pipelined kernel takes the groups' operand images */ \
-      if constexpr (GR && !CLF) launch_pl_t<N, true, false, WD, NS>(g, L, sec, d_frames, F, d_out, stream, CLA, pitch); \
+      if constexpr (GR) launch_pl_t<N, true, CLF, WD, NS>(g, L, sec, d_frames, F, d_out, stream, CLA, pitch); \
     } else                                                                                 \
       launch_bf16_t<N, GR, CLF, WD, NS>(g, L, sec, d_frames, F, d_out, stream, CLA, pitch); \
   } while (0)
@@ -3277,6 +3277,7 @@ static bool engine_parts_public(const aasr_gmm *g);
 bool gmm_score_pitch_ok(const aasr_gmm *g) {
   if (!g->dim_parts.empty()) return false;
   if (engine_parts_public(g)) return true;
+  if (g->cl.enabled && gmm_engine_parts_clustered(g)) return true;
   if (g->host.factor_path() || g->hyb_enabled || g->ill_conditioned || g->class_routing ||
       g->precision == AASR_PREC_F64)
     return false;
@@ -3306,6 +3307,11 @@ static bool engine_alias(const aasr_gmm *g) {
 bool gmm_engine_parts_active(const aasr_gmm *g) {
   return !g->engine_parts.empty() && g->precision == AASR_PREC_F16X2 && g->use_bf16x3 && !g->cl.enabled &&
          !g->class_routing && g->dim_parts.empty() && (g->layout_mask & 3) == 3;
+}
+
+bool gmm_engine_parts_clustered(const aasr_gmm *g) {
+  return !g->engine_parts.empty() && g->cl.enabled && g->precision == AASR_PREC_F16X2 && g->use_bf16x3 && !g->class_routing &&
+         g->dim_parts.empty() && (g->layout_mask & 3) == 3;
 }
 
 // ... and whether public-layout calls (column = state) go through them too, with the columns gathered back: where the
@@ -3344,14 +3350,59 @@ __global__ void k_scatter_columns(const float *__restrict__ in, int64_t F, int64
   out[f * pitch + (i - f * n)] = in[i];
 }
 
-// out[f][s] = rows[f][colmap[s]]: the engine's score rows back in the public layout
+// out[f][s] = rows[f][colmap[s]]: the engine's score rows back in the public layout.  A workgroup walks frames; a thread
+// keeps the columns of its states (s = tid, tid + 256, ...) in registers, so a frame costs one gather of its row (L2: the
+// row was written a moment ago) and coalesced stores.
+template <int VPT>
 __global__ __launch_bounds__(256) void k_gather_columns(const float *__restrict__ rows, int64_t F, int64_t in_pitch,
                                                         const int32_t *__restrict__ colmap, int64_t S,
                                                         float *__restrict__ out, int64_t out_pitch) {
-  const int64_t f = blockIdx.y;
-  const float *r = rows + f * in_pitch;
-  float *o = out + f * out_pitch;
-  for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) o[s] = r[colmap[s]];
+  int col[VPT];
+#pragma unroll
+  for (int j = 0; j < VPT; j++) {
+    const int64_t s = threadIdx.x + 256 * j;
+    col[j] = s < S ? colmap[s] : -1;
+  }
+  for (int64_t f = blockIdx.x; f < F; f += gridDim.x) {
+    const float *r = rows + f * in_pitch;
+    float *o = out + f * out_pitch;
+    float v[VPT];
+#pragma unroll
+    for (int j = 0; j < VPT; j++) v[j] = col[j] >= 0 ? r[col[j]] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < VPT; j++)
+      if (col[j] >= 0) o[threadIdx.x + 256 * j] = v[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gather_columns_any(const float *__restrict__ rows, int64_t F, int64_t in_pitch,
+                                                            const int32_t *__restrict__ colmap, int64_t S,
+                                                            float *__restrict__ out, int64_t out_pitch) {
+  for (int64_t f = blockIdx.x; f < F; f += gridDim.x)
+    for (int64_t s = threadIdx.x; s < S; s += 256) out[f * out_pitch + s] = rows[f * in_pitch + colmap[s]];
+}
+
+static void launch_gather_columns(const aasr_gmm *g, const float *rows, int64_t F, int64_t in_pitch, float *out,
+                                  int64_t out_pitch, hipStream_t stream) {
+  const unsigned blocks = (unsigned)std::min<int64_t>(F, (int64_t)(g->num_cus > 0 ? g->num_cus : 256) * 16);
+  if (g->S <= 256 * 4)
+    hipLaunchKernelGGL(k_gather_columns<4>, dim3(blocks), dim3(256), 0, stream, rows, F, in_pitch, g->engine_colmap.p, g->S, out, out_pitch);
+  else if (g->S <= 256 * 16)
+    hipLaunchKernelGGL(k_gather_columns<16>, dim3(blocks), dim3(256), 0, stream, rows, F, in_pitch, g->engine_colmap.p, g->S, out, out_pitch);
+  else
+    hipLaunchKernelGGL(k_gather_columns_any, dim3(blocks), dim3(256), 0, stream, rows, F, in_pitch, g->engine_colmap.p, g->S, out, out_pitch);
+  AASR_HIP(hipGetLastError());
+}
+
+void gmm_scatter_columns(const float *dense, int64_t F, int64_t n, float *out, int64_t pitch, hipStream_t stream) {
+  const int64_t tot = F * n;
+  if (tot <= 0) return;
+  hipLaunchKernelGGL(k_scatter_columns, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, dense, F, n, out, pitch);
+  AASR_HIP(hipGetLastError());
+}
+void gmm_gather_engine_columns(const aasr_gmm *g, const float *rows, int64_t F, int64_t in_pitch, float *out, int64_t out_pitch,
+                               hipStream_t stream) {
+  launch_gather_columns(g, rows, F, in_pitch, out, out_pitch, stream);
 }
 
 static void launch_engine_parts(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, int64_t pitch,
@@ -3404,9 +3455,7 @@ static void launch_engine_parts_public(aasr_gmm *g, const float *d_frames, int64
   for (int64_t f0 = 0; f0 < F; f0 += chunk) {
     const int64_t fc = std::min(chunk, F - f0);
     launch_engine_parts(g, d_frames + f0 * g->dim, fc, g->engine_scratch.p, ep, stream);
-    hipLaunchKernelGGL(k_gather_columns, dim3((unsigned)std::min<int64_t>(8, (g->S + 255) / 256), (unsigned)fc), dim3(256), 0,
-                       stream, g->engine_scratch.p, fc, ep, g->engine_colmap.p, g->S, d_out + f0 * pitch, pitch);
-    AASR_HIP(hipGetLastError());
+    launch_gather_columns(g, g->engine_scratch.p, fc, ep, d_out + f0 * pitch, pitch, stream);
   }
 }
 

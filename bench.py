@@ -879,6 +879,30 @@ def _measure_fitted_models(torch, capi, synth, pipeline, gmm, runner, dev, preci
                  "max_abs_dll_inside_the_2_byte_lna_window": float("%.3g" % err[win].max()),
                  "share_within_1e-4": round(float((err[vis] <= 1e-4).mean()), 6),
                  "seconds": {"audio_and_features": round(t_feat, 1), "fit": round(t_fit, 1), "build": round(t_build, 2)}}
+        # ... and the clustered pass on it (what pyrectool always runs: -C, --eval-ming 0.25): the parts' exact parts under
+        # the same selection bits, merged through the column map
+        try:
+            C_ = 1000
+            g2c = synth.make_clustering(model[0], C_, iters=2)
+            g2.set_clustering(C_, [(i, int(c)) for i, c in enumerate(g2c)])
+            g2.set_clustering_min_evals(0.0, 0.25)
+            pitch = r2.d_ll.shape[1]
+
+            def cstep():
+                g2.score_dev_pitched(r2.d_fea, r2.d_ll, pitch, r2.stream)
+            cstep()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(r2.stream)
+            for _ in range(3):
+                cstep()
+            e1.record(r2.stream)
+            torch.cuda.synchronize()
+            cms = e0.elapsed_time(e1) / 3
+            entry["clustered"] = {"clusters": C_, "eval_ming": 0.25, "ms_per_pass": round(cms, 3),
+                                  "ms_per_million_frames": round(cms * 1e6 / X.shape[0], 3)}
+        except Exception as e:
+            entry["clustered"] = {"error": "%s: %s" % (type(e).__name__, e)}
         out["models"].append(entry)
         g2.close()
         r2.release()

@@ -182,3 +182,47 @@ def test_global_transform_and_other_precisions_on_a_model_with_parts(capi, oracl
     err, n = visible_err(g.score(fr), ref)
     assert err <= TOL
     g.close()
+
+
+def test_gaussian_clustering_over_engine_parts(capi, oracle, fitted, monkeypatch):
+    """The clustered pass (aku/Distributions.cc:2684-2722; what pyrectool always runs) on a model with engine parts:
+    every part gives the exact part of its states under the same selection bits, the merge adds the centres' share through
+    the column map.  Scores within 1e-4 of the oracle's cluster branch, exact-evaluation counts bit-equal; also through
+    the LNA pass and with padded rows."""
+    import torch
+    X, model = fitted
+    monkeypatch.setenv("AASR_PG_PIVOT_COST", "64")
+    mean, var, off, idx, w = model
+    C = 48
+    g2c = synth.make_clustering(mean, C)
+    pairs = [(int(a), int(c)) for a, c in enumerate(g2c)]
+    fr = np.ascontiguousarray(X[2000:2000 + 900])
+    for minc, ming in ((0.0, 0.25), (0.2, 0.0), (1.0, 1.0)):
+        om = oracle.DiagModel(*model)
+        om.set_clustering(C, pairs, minc, ming)
+        want, want_n = om.score_clustered(fr.astype(np.float64), want_counts=True)
+        g = capi.Gmm.from_arrays(*model)
+        assert g.engine_parts() is not None
+        g.set_clustering(C, pairs)
+        g.set_clustering_min_evals(minc, ming)
+        got = g.score(fr)
+        assert np.array_equal(g.cluster_exact_counts(len(fr)), want_n)
+        vis = want > VISIBLE
+        assert np.abs(got - want)[vis].max() <= TOL, (minc, ming, np.abs(got - want)[vis].max())
+        if minc == 0.0:
+            assert g.score_pitch_ok()
+            d_fr = torch.from_numpy(fr).cuda()
+            padded = torch.full((len(fr), 224), -7.0, dtype=torch.float32, device="cuda")
+            g.score_dev_pitched(d_fr, padded, 224)
+            torch.cuda.synchronize()
+            p = padded.cpu().numpy()
+            assert np.array_equal(p[:, :200], got) and (p[:, 200:] == -7.0).all()
+            d_scr = torch.empty(g.score_scratch_floats(len(fr)), dtype=torch.float32, device="cuda")
+            d_by = torch.empty((len(fr), 200 * 2), dtype=torch.uint8, device="cuda")
+            g.score_lna_dev(d_fr, d_scr, d_by, True, 2)
+            torch.cuda.synchronize()
+            _, by_ref = oracle.lna_encode(np.exp(want), True, 2)
+            a = d_by.cpu().numpy().reshape(len(fr), 200, 2).astype(np.int32)
+            b = by_ref.reshape(len(fr), 200, 2).astype(np.int32)
+            assert np.abs((a[..., 0] * 256 + a[..., 1]) - (b[..., 0] * 256 + b[..., 1])).max() <= 1
+        g.close()
