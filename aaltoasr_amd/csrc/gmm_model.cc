@@ -1057,7 +1057,8 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
   // 8.5 ms for 50 000 rows, + a row cut more per frame block, + a tile of padding); a row on two terms instead of three
   // saves 0.65 of a row, on three terms instead of the centred form several rows
   // AASR_PG_PIVOT_COST (test hook): the rows one more pivot has to rescue, instead of the cost model's figure
-  static const double pivot_cost_env = getenv("AASR_PG_PIVOT_COST") ? atof(getenv("AASR_PG_PIVOT_COST")) : -1.0;
+  // (read at every build, not latched: a test sets it for one model)
+  const double pivot_cost_env = getenv("AASR_PG_PIVOT_COST") ? atof(getenv("AASR_PG_PIVOT_COST")) : -1.0;
   const double cost2 = pivot_cost_env >= 0 ? pivot_cost_env : 400.0 / 0.65;
   const double cost3 = pivot_cost_env >= 0 ? pivot_cost_env : 400.0 / 4.0;
   static const double lim_scale = AASR_EXPERIMENT_ENV("AASR_PG_LIMIT_SCALE") ? atof(AASR_EXPERIMENT_ENV("AASR_PG_LIMIT_SCALE")) : 1.0;   // EXPERIMENT
