@@ -875,7 +875,10 @@ template <int NNZ, int kMergeThreads>
 __global__ __launch_bounds__(kMergeThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cluster_merge(
     float *__restrict__ out, int64_t F, int64_t S, const float *__restrict__ cval, int C,
     const int32_t *__restrict__ w_cluster, const float *__restrict__ w_weight, int nnz,
-    float ref, int frames_per_block, int cstride, int64_t pitch, const int32_t *__restrict__ colmap) {
+    float ref, int frames_per_block, int cstride, int64_t pitch, const int32_t *__restrict__ colmap,
+    float *__restrict__ dst, int64_t dst_pitch) {
+  // dst (engine parts): the merged value goes to column = state of `dst` (the public layout) instead of back in place --
+  // the exact parts are read through the column map, so the pass needs no gather of the columns afterwards
   // [C][cstride]: cstride = 12 floats spreads the 16-byte reads of different
   // clusters over all banks (8 would put every read on 4 bank groups)
   extern __shared__ __attribute__((aligned(16))) float cv[];
@@ -974,7 +977,8 @@ __global__ __launch_bounds__(kMergeThreads) __attribute__((amdgpu_waves_per_eu(4
         if (k < nf) {
           const float l2 = xk[k] <= 60.0f ? __log2f(lin[k]) : xk[k] + __log2f(1.0f + lin[k] * exp2f(-xk[k]));
           const float l = fmaf(l2, 0.69314718055994530942f, -ref_ln);
-          out[(fg + k) * pitch + col[u]] = fmaxf(l, AASR_LOG_TINY_F);
+          if (dst) dst[(fg + k) * dst_pitch + st[u]] = fmaxf(l, AASR_LOG_TINY_F);
+          else out[(fg + k) * pitch + col[u]] = fmaxf(l, AASR_LOG_TINY_F);
         }
     }
   }
@@ -1469,10 +1473,12 @@ __global__ __launch_bounds__(256) void k_cluster_merge_log(float *__restrict__ o
   }
 }
 
-static void launch_merge(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hipStream_t stream, const int32_t *colmap = nullptr);
+static void launch_merge(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hipStream_t stream, const int32_t *colmap = nullptr,
+                         float *dst = nullptr, int64_t dst_pitch = 0);
 
 template <int NNZ, int kMergeThreads>
-static void launch_merge_t(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hipStream_t stream, const int32_t *colmap) {
+static void launch_merge_t(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hipStream_t stream, const int32_t *colmap,
+                           float *dst, int64_t dst_pitch) {
   ClusterState &cl = g->cl;
   const int64_t bx = (g->S + kMergeThreads * kMergeSPT - 1) / (kMergeThreads * kMergeSPT);
   // enough workgroups to fill the chip, each walking a contiguous run of frames
@@ -1490,11 +1496,12 @@ static void launch_merge_t(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, 
   }
   hipLaunchKernelGGL((k_cluster_merge<NNZ, kMergeThreads>), dim3((unsigned)bx, (unsigned)by), dim3(kMergeThreads), smem,
                      stream, d_out, F, g->S, cl.cval.p, cl.C, cl.w_cluster.p, cl.w_weight.p, cl.nnz,
-                     (float)cl.ref_log2, fpb, cstride, pitch, colmap);
+                     (float)cl.ref_log2, fpb, cstride, pitch, colmap, dst, dst_pitch);
   AASR_HIP(hipGetLastError());
 }
 
-static void launch_merge(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hipStream_t stream, const int32_t *colmap) {
+static void launch_merge(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hipStream_t stream, const int32_t *colmap,
+                         float *dst, int64_t dst_pitch) {
   ClusterState &cl = g->cl;
   if (cl.log_merge) {
     hipLaunchKernelGGL(k_cluster_merge_log, dim3((unsigned)((g->S + 255) / 256), (unsigned)std::min<int64_t>(F, 8192)),
@@ -1503,10 +1510,10 @@ static void launch_merge(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hi
     return;
   }
   static const int threads = AASR_EXPERIMENT_ENV("AASR_MERGE_THREADS") ? atoi(AASR_EXPERIMENT_ENV("AASR_MERGE_THREADS")) : 1024;
-  if (cl.nnz <= 8) launch_merge_t<8, 1024>(g, d_out, F, pitch, stream, colmap);
-  else if (threads == 512) launch_merge_t<16, 512>(g, d_out, F, pitch, stream, colmap);
-  else if (threads == 256) launch_merge_t<16, 256>(g, d_out, F, pitch, stream, colmap);
-  else launch_merge_t<16, 1024>(g, d_out, F, pitch, stream, colmap);   // weights beyond 16 per state come from L2
+  if (cl.nnz <= 8) launch_merge_t<8, 1024>(g, d_out, F, pitch, stream, colmap, dst, dst_pitch);
+  else if (threads == 512) launch_merge_t<16, 512>(g, d_out, F, pitch, stream, colmap, dst, dst_pitch);
+  else if (threads == 256) launch_merge_t<16, 256>(g, d_out, F, pitch, stream, colmap, dst, dst_pitch);
+  else launch_merge_t<16, 1024>(g, d_out, F, pitch, stream, colmap, dst, dst_pitch);   // weights beyond 16 per state come from L2
 }
 
 // What a model's exact part needs besides the selection bits: the cluster of each of ITS rows /
@@ -1705,7 +1712,7 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
     mask_rows = plan.mask_rows;
   }
   // Frames per pass.  The track kernel and the merge run once per pass, so a pass is
-  // as large as ~16 GB of scratch allow (1 bit per frame x packed row for the lane
+  // as large as ~24 GB of scratch allow (1 bit per frame x packed row for the lane
   // masks, 4 B per frame x cluster for the centre values) and a whole number of rounds
   // of the track kernel (2 workgroups of 256 frames per CU); the f64 centre
   // log-likelihoods (8 B per frame x cluster) only live for a sub-pass of <= 8.6 GB (10^6 frames x 1000 clusters in one go: 42.7 ms per pass instead of 45.0 with five sub-passes of 2 GB, whose launches each end in a partly filled round of the one-wave selection workgroups; smaller sub-passes are worse still: 512 MB 52 ms, 256 MB 61 ms).
@@ -1714,10 +1721,17 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
                            (parts ? 8.0 * (double)ep : 0.0);
   const int64_t round_frames = 2 * (int64_t)(g->num_cus > 0 ? g->num_cus : 256) * FRAMES_PER_BLOCK;
   const int64_t f_rounded = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK;
-  int64_t fb = (int64_t)(16.0e9 / per_frame);
+  int64_t fb = (int64_t)(24.0e9 / per_frame);
   if (fb >= round_frames) fb = fb / round_frames * round_frames;
   else fb = std::max<int64_t>(FRAMES_PER_BLOCK, fb / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK);
   fb = std::min<int64_t>(fb, f_rounded);
+  if (fb < f_rounded) {
+    // several passes: of equal size (a short last pass pays the fixed costs of every kernel -- the one-wave selection
+    // workgroups of 56 000 left-over frames took as long as those of 393 000)
+    const int64_t n_pass = (f_rounded + fb - 1) / fb;
+    fb = ((f_rounded + n_pass - 1) / n_pass + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK;
+  }
+  const int64_t fb_pass = fb;
   static const double sub_bytes = AASR_EXPERIMENT_ENV("AASR_CLUSTER_SUB_BYTES") ? atof(AASR_EXPERIMENT_ENV("AASR_CLUSTER_SUB_BYTES")) : 8.6e9;
   int64_t fs = (int64_t)(sub_bytes / (8.0 * (double)cl.Cs));
   fs = std::min<int64_t>(fb, std::max<int64_t>(FRAMES_PER_BLOCK, fs / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK));
@@ -1737,8 +1751,9 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
     cl.Fc = fb;
     cl.Fs = fs;
   }
-  for (int64_t f0 = 0; f0 < F; f0 += cl.Fc) {
-    const int64_t n = std::min<int64_t>(cl.Fc, F - f0);
+  const int64_t pass_frames = std::min<int64_t>(fb_pass, cl.Fc);   // (this call's balanced passes inside the allocation)
+  for (int64_t f0 = 0; f0 < F; f0 += pass_frames) {
+    const int64_t n = std::min<int64_t>(pass_frames, F - f0);
     const float *fr = d_frames + f0 * g->dim;
     const float *fr_members = d_members + f0 * g->dim;
     float *out = d_out + f0 * pitch;
@@ -1772,8 +1787,12 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
           gmm_scatter_columns(g->engine_part_scratch.p, n, sub->S, o, ep, stream);
         }
       }
-      launch_merge(g, g->engine_scratch.p, n, ep, stream, g->engine_colmap.p);
-      gmm_gather_engine_columns(g, g->engine_scratch.p, n, ep, out, pitch, stream);
+      if (cl.log_merge) {   // (the fallback merges in place)
+        launch_merge(g, g->engine_scratch.p, n, ep, stream, g->engine_colmap.p);
+        gmm_gather_engine_columns(g, g->engine_scratch.p, n, ep, out, pitch, stream);
+      } else {
+        launch_merge(g, g->engine_scratch.p, n, ep, stream, g->engine_colmap.p, out, pitch);
+      }
       continue;
     }
     if (classes)
