@@ -589,6 +589,11 @@ def main():
             "frac": round(achieved / peak, 4), "traffic": None,
             "kernel_ms": round(k_ms, 4), "scoring_call_ms": round(call_ms, 4),
             "frame_operand_kernel_ms": round(fop_ms, 4) if fop_ms > 0 else None,
+            # the same fraction priced on the whole scoring call (k_frame_operand is a launch of every split-term
+            # call): `frac` is the dominant kernel's own, this one what a caller of aasr_gmm_score_dev sees
+            "frac_of_scoring_call": round(algo_flop / (call_ms * 1e-3) / 1e12 / peak, 4),
+            "kernel_ms_is": ("scoring call minus the separately timed k_frame_operand launch" if k_ms != call_ms
+                             else "the scoring call (no separate operand launch timed)"),
             "algorithmic_flop_per_launch": algo_flop, "peak_note": peak_note,
             "frac_of_fp32_matrix_peak": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
         }
