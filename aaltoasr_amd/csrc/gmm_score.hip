@@ -1102,8 +1102,45 @@ constexpr int kMapEmpty = 1 << 28;     // this track holds no state in this pair
 constexpr int kMapFlush16 = 1 << 29;   // last pair of its group of 16 columns
 constexpr int kMapFlush32 = 1 << 30;   // ... of its group of 32
 
+// AASR_PL_TRACE (experiment builds only, tools/pl_trace.py): where one workgroup's waves spend their cycles.  Every wave of
+// workgroup AASR_PL_TRACE_BLOCK reads the shader clock (s_memtime) at the phase boundaries of its tile loop and sums the
+// intervals: [0] H0 matrix phase, [1] close logic behind H0, [2] H1 matrix phase, [3] the tile barrier (wait + the next
+// tile's copy issue; the lagging group passes it inside H0: its time is taken out of [0]), [4] fragment prefetch + close
+// logic behind H1, [5] the part of [3] spent in s_barrier, [6] the part of [3] spent in s_waitcnt vmcnt(0), [7] whole kernel, [8] tiles.  Reading the clock waits for every outstanding scalar and LDS
+// operation, so the traced launch runs slower than the product kernel (the tool reports by how much).
+#ifdef AASR_PL_TRACE
+__device__ unsigned long long g_pl_trace[8][10];
+#ifndef AASR_PL_TRACE_BLOCK
+#define AASR_PL_TRACE_BLOCK 300
+#endif
+#define PL_TRACE_DECL unsigned long long tr_tiles = 0, tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_prev = __builtin_readcyclecounter(), tr_t0 = tr_prev, tr_bar = 0, tr_vm = 0
+#define PL_TRACE(k) do { const unsigned long long tr_now = __builtin_readcyclecounter(); tr_acc[k] += tr_now - tr_prev; tr_prev = tr_now; } while (0)
+#else
+#define PL_TRACE_DECL
+#define PL_TRACE(k)
+#endif
 #ifndef AASR_PL_PRIO
 #define AASR_PL_PRIO 1   // issue priority of a wave of k_gmm_diag_score_pl inside its matrix phases (0: left alone)
+#endif
+// Priorities of the 8-wave form's two wave groups (AASR_PL_PRIO_SCHEME, round 5; found with the phase trace below).  The
+// two waves of a SIMD share the matrix pipe whenever their matrix phases overlap, and at equal priority the arbiter gives
+// the older wave -- the leading group's -- two thirds of it: the leading wave ran ahead through its H1 and then waited
+// ~1 200 cycles per tile at the barrier for the lagging wave, whose H1 had crawled along beside it, and in that wait (the
+// partner in its close logic, nobody in a matrix phase) the pipe idled 20 % of the time.  Scheme 1: the leading group
+// takes the higher priority in H0 and the lower in H1, the lagging group the reverse -- in the long H1 / H1 overlap the
+// lagging wave now wins, both groups reach the barrier together (waits 560 / 490 cycles in the traced build instead of
+// 1 230 / 450), a tile takes 5 000 cycles instead of 5 450: configs[1] 18.77 -> 18.14 ms (-3.3 %), three alternating
+// runs on one box.  Measured against it: the reverse assignment (scheme 2) 18.60, the lagging group higher throughout
+// (the roles swap: 19.3), priorities 3 / 1 the same as 2 / 1, 1 / 0 18.44, the lagging group's barrier one or two slabs
+// into H0 18.36 / 18.60.  0: every wave AASR_PL_PRIO in its matrix phases (round 4).
+#ifndef AASR_PL_PRIO_SCHEME
+#define AASR_PL_PRIO_SCHEME 1
+#endif
+#ifndef AASR_PL_PRIO_HI
+#define AASR_PL_PRIO_HI 2
+#endif
+#ifndef AASR_PL_PRIO_LO
+#define AASR_PL_PRIO_LO 1
 #endif
 template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS, bool MAPPED = false>
 __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_score_pl(
@@ -1129,6 +1166,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   }
   blk = __builtin_amdgcn_readfirstlane(blk);
   cut = __builtin_amdgcn_readfirstlane(cut);
+  PL_TRACE_DECL;
   constexpr int OG = SM::OG;
   constexpr int kTileFloats = SM::kTileBytes / 4;
   constexpr int kOS = SM::kOutStride;
@@ -1161,6 +1199,15 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
 #else
   const int group = WIDE ? __builtin_amdgcn_readfirstlane(wave >> 2) : 0;
 #endif
+  auto matrix_prio = [&](int phase) {
+    if (AASR_PL_PRIO_SCHEME >= 1 && WIDE) {
+      const bool hi = AASR_PL_PRIO_SCHEME == 1 ? ((group == 1) == (phase == 1)) : ((group == 1) != (phase == 1));
+      if (hi) __builtin_amdgcn_s_setprio(AASR_PL_PRIO_HI);
+      else __builtin_amdgcn_s_setprio(AASR_PL_PRIO_LO);
+    } else if (AASR_PL_PRIO > 0) {
+      __builtin_amdgcn_s_setprio(AASR_PL_PRIO);
+    }
+  };
   // slab of H0 in front of which the lagging group's barrier sits: early in the phase, so that the lagging waves run
   // nearly a whole tile behind (configs[2], NK16 = 5, ms of the scoring stage on one box: slab 0 8.45, slab 1 8.43,
   // slab 2 -- the middle, rounds 3's choice -- 8.51, slab 3 8.61; with the issue priority of the matrix phases, below:
@@ -1206,6 +1253,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  PL_TRACE(6);
   float s0 = 0.0f, s1 = 0.0f;
   int closes = split_row[4 * cut + 1 + (GROUPED ? 0 : h)];
   const int32_t *my_sid = sid + h * sid_stride;
@@ -1364,9 +1412,23 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     bi = bn;
     // barrier t of this wave: its share of tile t + 1 has landed, and every wave is past tile t - 1
     auto tile_barrier = [&]() {
+#ifdef AASR_PL_TRACE
+      const unsigned long long tb0 = __builtin_readcyclecounter();
+#endif
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(mask_v) : : "memory");
+#ifdef AASR_PL_TRACE
+      const unsigned long long tb1 = __builtin_readcyclecounter();
+      tr_vm += tb1 - tb0;
+#endif
       if (!AASR_DBG(16)) __builtin_amdgcn_s_barrier();
+#ifdef AASR_PL_TRACE
+      const unsigned long long tb2 = __builtin_readcyclecounter();
+      tr_acc[5] += tb2 - tb1;   // (the s_barrier itself; the tile count moves to the host side)
+#endif
       if (t + 2 < t_end) issue_tile(t + 2, bnn);
+#ifdef AASR_PL_TRACE
+      tr_bar += __builtin_readcyclecounter() - tb0;
+#endif
     };
     // close bits and selection bits of tile t+1: vector loads waited for by the vmcnt(0) in front of the barrier (an
     // aligned 32-bit word: the array has a spare element).  It has to stay a VECTOR load -- as a scalar load it would turn
@@ -1396,7 +1458,8 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     // s_setprio: while a wave is in a matrix phase the SIMD's issue arbiter prefers it to the other wave's close logic
     // (vector, LDS and store instructions), so its matrix instructions do not queue behind them: -0.9 % on configs[2]
     // (8.49 -> 8.41 ms same box, priority 1 and 3 alike)
-    if (AASR_PL_PRIO > 0) __builtin_amdgcn_s_setprio(AASR_PL_PRIO);
+    PL_TRACE(4);   // (what ran since the end of the previous tile's H1: its barrier excluded below)
+    matrix_prio(0);
     // ---------------- H0: block 0 of tile t  ||  exponentials of block 1 of tile t-1
     {
       int mi = 0;
@@ -1436,8 +1499,10 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
       }
     }
     if (AASR_PL_PRIO > 0) __builtin_amdgcn_s_setprio(0);
+    PL_TRACE(0);
     if (t > t_begin) commit(P, (GROUPED ? mask_prev : (h ? mask_prev >> 8 : mask_prev)) >> 4 & 0xfu, ep0, ep1);
-    if (AASR_PL_PRIO > 0) __builtin_amdgcn_s_setprio(AASR_PL_PRIO);
+    PL_TRACE(1);
+    matrix_prio(1);
     // ---------------- H1: block 1 of tile t  ||  exponentials of block 0 of tile t
     {
       int mi = 0;
@@ -1475,6 +1540,10 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
       }
     }
     if (AASR_PL_PRIO > 0) __builtin_amdgcn_s_setprio(0);
+    PL_TRACE(2);
+#ifdef AASR_PL_TRACE
+    tr_tiles++;
+#endif
     // end of tile: the leading group's barrier
     if (!WIDE || group == 0) tile_barrier();
     else asm volatile("" : "+v"(mask_v));
@@ -1503,6 +1572,19 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     for (int k = 0; k < 32; k++) epi_step(k, 1, cB0, cB1, bits_prev, P);
     commit(P, (GROUPED ? mask_prev : (h ? mask_prev >> 8 : mask_prev)) >> 4 & 0xfu, ep0, ep1);
   }
+#ifdef AASR_PL_TRACE
+  if ((int)blockIdx.x == AASR_PL_TRACE_BLOCK && lane == 0) {
+    PL_TRACE(4);
+    // the lagging group's barrier sits inside H0, the leading group's behind H1 (inside interval 4)
+    if (WIDE && group == 1) tr_acc[0] -= tr_bar;
+    else tr_acc[4] -= tr_bar;
+    tr_acc[3] = tr_bar;
+    tr_acc[6] = tr_vm;   // (of interval 3: the wait for the wave's own vector-memory operations, tile copy share and stores)
+    tr_acc[7] = tr_prev - tr_t0;
+    for (int k = 0; k < 8; k++) g_pl_trace[wave & 7][k] = tr_acc[k];
+    g_pl_trace[wave & 7][8] = tr_tiles;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -3727,3 +3809,11 @@ void gmm_gauss_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
 }
 
 }  // namespace aasr
+
+#ifdef AASR_PL_TRACE
+// Diagnostic of experiment builds (tools/pl_trace.py): the phase sums of the last traced launch, [wave][interval]
+extern "C" int aasr_debug_pl_trace(unsigned long long *out) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(aasr::g_pl_trace), sizeof(unsigned long long) * 80) == hipSuccess ? 0 : -1;
+}
+#endif

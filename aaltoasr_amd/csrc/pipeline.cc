@@ -274,6 +274,7 @@ std::vector<int16_t> decode_input_data(const aasr_feat *feat, const std::vector<
 // helper threads are sized from usable_cores / share: eight ranks that each start the thread count
 // tuned for a rank that owns the host oversubscribe the CPU quota eight times over.
 static std::atomic<int> g_host_share{0};
+static std::atomic<int64_t> g_upload_ring_limit{0};
 
 int host_usable_cores() {
   // affinity mask capped by the cgroup CPU quota (the GPU boxes expose 256 logical CPUs and
@@ -666,7 +667,8 @@ void run_recipe(aasr_feat *feat, aasr_gmm *gmm, const std::string &recipe_path,
     uint64_t head = 0, tail = 0;   // virtual sample offsets: allocated up to head, free again up to tail
   } ring;
   int16_t *const ring_base = scratch->pcm_ring;
-  const size_t ring_cap = scratch->ring_cap;
+  const int64_t ring_limit = g_upload_ring_limit.load();   // (aasr_debug_set_upload_ring_samples: tests of the fallback)
+  const size_t ring_cap = ring_limit > 0 ? std::min<size_t>((size_t)ring_limit, scratch->ring_cap) : scratch->ring_cap;
 
   // The reader only looks at the base module (mods[0]: sample rate, byte order, window, frame
   // rate); set_parameters is a no-op for audiofile / pre (FeatureModule::set_parameters,
@@ -1149,6 +1151,10 @@ aasr_status aasr_set_host_share(int32_t processes) {
 }
 
 int32_t aasr_host_usable_cores(void) { return (int32_t)host_usable_cores(); }
+
+// Diagnostic (not part of the public ABI): the recipe driver's pinned upload ring uses its first `samples` samples only
+// (0: all of it), so that a test can make files miss the ring and keep their pageable buffers.
+void aasr_debug_set_upload_ring_samples(int64_t samples) { g_upload_ring_limit.store(samples); }
 
 aasr_status aasr_recipe_last_timing(const aasr_gmm *gmm, aasr_recipe_timing *out) {
   return guarded([&] {

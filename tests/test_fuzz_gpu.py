@@ -124,3 +124,13 @@ def test_wide_model_sweep(capi, oracle):
     worst, fails = _load("fuzz_wide").run(3, 25)
     assert not fails, fails[:5]
 
+
+
+@pytest.mark.parametrize("seed,n", [(1, 10), (2, 10)])
+def test_fitted_model_sweep(capi, oracle, seed, n):
+    """tools/fuzz_fitted.py: models fitted to random mixtures of separated, differently scaled blobs -- the conditioning
+    that needs the engine's pivot groups (gmm_plan_engine_parts) -- on the public layout, through the LNA pass on the
+    engine's own layout, and under Gaussian clustering over the parts, against the oracle."""
+    worst, fails = _load("fuzz_fitted").run(seed, n)
+    assert not fails, "\n".join(fails)
+    assert worst.get("n parts", 0) >= 3 and worst.get("lna code steps", 0) <= 1

@@ -145,6 +145,40 @@ def test_recipe_run_and_batches(capi, oracle, setup, tmp_path):
     assert s3.utterances == 0
 
 
+def test_recipe_upload_ring_and_its_fallback_write_the_same_files(capi, setup, tmp_path):
+    """The recipe driver's reader copies every file's samples into a pinned upload ring (asynchronous uploads, one copy
+    per run of utterances); a file that finds no room keeps its pageable buffer.  With the ring cut down to two seconds of
+    audio (a diagnostic entry point) a recipe of 40 files of 0.3-2.4 s -- one block, so nothing is returned to the ring
+    before the end -- goes partly through the ring (incl. its wrap-free placement) and partly around it, and a ring smaller
+    than every file takes none: the LNA files are the same bytes as with the whole ring (aku/phone_probs.cc:145-267 has
+    one way to read a file)."""
+    import ctypes
+    L = capi.lib()
+    L.aasr_debug_set_upload_ring_samples.argtypes = [ctypes.c_int64]
+    L.aasr_debug_set_upload_ring_samples.restype = None
+    rng = np.random.default_rng(5)
+    lines = []
+    for i in range(40):
+        pcm = synth.make_audio(int(rng.integers(4800, 38400)), seed=300 + i)
+        _write_wav(str(tmp_path / ("v%d.wav" % i)), pcm)
+        lines.append("audio=%s lna=%s" % (tmp_path / ("v%d.wav" % i), "v%d.lna" % i))
+    recipe = str(tmp_path / "v.recipe")
+    open(recipe, "w").write("\n".join(lines) + "\n")
+    outs = {}
+    try:
+        for name, limit in (("whole", 0), ("two_seconds", 32000 * 4), ("none", 1000)):   # a file takes at most a quarter
+            L.aasr_debug_set_upload_ring_samples(limit)
+            out = str(tmp_path / name)
+            os.makedirs(out)
+            st = capi.run_recipe(setup["ft"], setup["gm"], recipe, lnabytes=2, out_dir=out)
+            assert st.utterances == 40
+            outs[name] = [open(os.path.join(out, "v%d.lna" % i), "rb").read() for i in range(40)]
+    finally:
+        L.aasr_debug_set_upload_ring_samples(0)
+    assert outs["two_seconds"] == outs["whole"] and outs["none"] == outs["whole"]
+    assert len(outs["whole"][0]) > 1000
+
+
 def test_dimension_mismatch_is_reported(capi, setup):
     g13 = capi.Gmm.from_arrays(*synth.make_model(D=13, G=16, S=2, comps=8))
     with pytest.raises(capi.AasrError, match="Gaussian dimension is 13 but feature dimension is 39"):
