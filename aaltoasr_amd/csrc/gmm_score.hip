@@ -1181,8 +1181,38 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   float *ost = abuf0 + NBUF * kTileFloats + wave * SM::kOutFloatsPerWave;
   int *emap = (int *)(abuf0 + NBUF * kTileFloats + NW * SM::kOutFloatsPerWave);   // MAPPED: [NBUF][2 tracks][8 positions]
   // a tile's rows and (MAPPED) its 16 pair entries into tile buffer `b`
+  // The tile copy in the scalar-base form of the LDS-DMA instruction: the tile's address is wave-uniform, so the base goes
+  // in a scalar register pair (two scalar additions per instruction) and the lanes carry ONE constant 32-bit offset,
+  // 16 * lane, for the whole launch -- no 64-bit per-lane address to form and to send to the address unit per instruction
+  // (AASR_PL_SADDR_COPY, default 1; 0: the generic per-lane pointers of issue_tile_copy_raw).  configs[1] 17.94 -> 17.84 ms,
+  // configs[2] 10.42 -> 10.38 ms per step, alternating runs on one box; two registers fewer.  (Round 5 also spread the copy
+  // instructions over the slabs of the H0 that follows the barrier instead of issuing them behind it -- the barrier interval
+  // of the phase trace fell from ~550 to ~260 cycles and H0 grew by as much: an LDS-DMA instruction costs the issuing wave
+  // 100-150 cycles wherever it stands; 1 % slower with twelve more registers, removed.)
+#ifndef AASR_PL_SADDR_COPY
+#define AASR_PL_SADDR_COPY 1
+#endif
+  const unsigned lane_off16 = (unsigned)lane * 16u;
   auto issue_tile = [&](int64_t tile, int b) {
-    issue_tile_copy_raw((const float *)apack + (size_t)tile * kTileFloats, abuf0 + b * kTileFloats, kTileFloats, wave, lane, NW);
+    if (AASR_PL_SADDR_COPY) {
+      constexpr int kChunks = kTileFloats / 4 / 64;   // 1 KB instructions per tile
+      const char *gbase = (const char *)((const float *)apack + (size_t)tile * kTileFloats);
+      const unsigned lbase = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(abuf0 + b * kTileFloats));
+#pragma unroll
+      for (int k = 0; k < (kChunks + NW - 1) / NW; k++) {
+        const int c = __builtin_amdgcn_readfirstlane(wave) + k * NW;   // wave-uniform
+        if (c < kChunks) {
+          const unsigned long long sb = (unsigned long long)(uintptr_t)gbase + (unsigned long long)c * 1024ull;
+          const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sb);
+          const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sb >> 32));
+          const unsigned long long sbase = (unsigned long long)lo | ((unsigned long long)hi << 32);
+          const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lbase + (unsigned)c * 1024u));
+          asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(dst), "v"(lane_off16), "s"(sbase) : "memory", "m0");
+        }
+      }
+    } else {
+      issue_tile_copy_raw((const float *)apack + (size_t)tile * kTileFloats, abuf0 + b * kTileFloats, kTileFloats, wave, lane, NW);
+    }
     if (MAPPED && wave == NW - 1 && lane < 16) {
       const int32_t *src = sid + tile * 16 + lane;
       const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(emap + b * 16));
