@@ -871,14 +871,15 @@ constexpr int kMergeFrames = 8;
 constexpr int kMaxClusters = 16384;
 constexpr int kMergeSPT = 2;  // states per thread
 
-template <int NNZ, int kMergeThreads>
+template <int NNZ, int kMergeThreads, bool DST>
 __global__ __launch_bounds__(kMergeThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cluster_merge(
     float *__restrict__ out, int64_t F, int64_t S, const float *__restrict__ cval, int C,
     const int32_t *__restrict__ w_cluster, const float *__restrict__ w_weight, int nnz,
     float ref, int frames_per_block, int cstride, int64_t pitch, const int32_t *__restrict__ colmap,
     float *__restrict__ dst, int64_t dst_pitch) {
-  // dst (engine parts): the merged value goes to column = state of `dst` (the public layout) instead of back in place --
-  // the exact parts are read through the column map, so the pass needs no gather of the columns afterwards
+  // DST (engine parts): the merged value goes to column = state of `dst` (the public layout) instead of back in place --
+  // the exact parts are read through the column map, so the pass needs no gather of the columns afterwards (an instance
+  // of its own: as a run-time branch the in-place form spilled four registers more)
   // [C][cstride]: cstride = 12 floats spreads the 16-byte reads of different
   // clusters over all banks (8 would put every read on 4 bank groups)
   extern __shared__ __attribute__((aligned(16))) float cv[];
@@ -977,7 +978,7 @@ __global__ __launch_bounds__(kMergeThreads) __attribute__((amdgpu_waves_per_eu(4
         if (k < nf) {
           const float l2 = xk[k] <= 60.0f ? __log2f(lin[k]) : xk[k] + __log2f(1.0f + lin[k] * exp2f(-xk[k]));
           const float l = fmaf(l2, 0.69314718055994530942f, -ref_ln);
-          if (dst) dst[(fg + k) * dst_pitch + st[u]] = fmaxf(l, AASR_LOG_TINY_F);
+          if (DST) dst[(fg + k) * dst_pitch + st[u]] = fmaxf(l, AASR_LOG_TINY_F);
           else out[(fg + k) * pitch + col[u]] = fmaxf(l, AASR_LOG_TINY_F);
         }
     }
@@ -1476,8 +1477,8 @@ __global__ __launch_bounds__(256) void k_cluster_merge_log(float *__restrict__ o
 static void launch_merge(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hipStream_t stream, const int32_t *colmap = nullptr,
                          float *dst = nullptr, int64_t dst_pitch = 0);
 
-template <int NNZ, int kMergeThreads>
-static void launch_merge_t(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hipStream_t stream, const int32_t *colmap,
+template <int NNZ, int kMergeThreads, bool DST>
+static void launch_merge_tt(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hipStream_t stream, const int32_t *colmap,
                            float *dst, int64_t dst_pitch) {
   ClusterState &cl = g->cl;
   const int64_t bx = (g->S + kMergeThreads * kMergeSPT - 1) / (kMergeThreads * kMergeSPT);
@@ -1490,14 +1491,21 @@ static void launch_merge_t(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, 
   const int smem = cstride * cl.C * (int)sizeof(float);
   static bool attr_set[64] = {false};
   if (!attr_set[g->device & 63]) {
-    AASR_HIP(hipFuncSetAttribute((const void *)k_cluster_merge<NNZ, kMergeThreads>,
+    AASR_HIP(hipFuncSetAttribute((const void *)k_cluster_merge<NNZ, kMergeThreads, DST>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
     attr_set[g->device & 63] = true;
   }
-  hipLaunchKernelGGL((k_cluster_merge<NNZ, kMergeThreads>), dim3((unsigned)bx, (unsigned)by), dim3(kMergeThreads), smem,
+  hipLaunchKernelGGL((k_cluster_merge<NNZ, kMergeThreads, DST>), dim3((unsigned)bx, (unsigned)by), dim3(kMergeThreads), smem,
                      stream, d_out, F, g->S, cl.cval.p, cl.C, cl.w_cluster.p, cl.w_weight.p, cl.nnz,
                      (float)cl.ref_log2, fpb, cstride, pitch, colmap, dst, dst_pitch);
   AASR_HIP(hipGetLastError());
+}
+
+template <int NNZ, int kMergeThreads>
+static void launch_merge_t(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hipStream_t stream, const int32_t *colmap,
+                           float *dst, int64_t dst_pitch) {
+  if (dst) launch_merge_tt<NNZ, kMergeThreads, true>(g, d_out, F, pitch, stream, colmap, dst, dst_pitch);
+  else launch_merge_tt<NNZ, kMergeThreads, false>(g, d_out, F, pitch, stream, colmap, dst, dst_pitch);
 }
 
 static void launch_merge(aasr_gmm *g, float *d_out, int64_t F, int64_t pitch, hipStream_t stream, const int32_t *colmap,

@@ -1188,7 +1188,8 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   // configs[2] 10.42 -> 10.38 ms per step, alternating runs on one box; two registers fewer.  (Round 5 also spread the copy
   // instructions over the slabs of the H0 that follows the barrier instead of issuing them behind it -- the barrier interval
   // of the phase trace fell from ~550 to ~260 cycles and H0 grew by as much: an LDS-DMA instruction costs the issuing wave
-  // 100-150 cycles wherever it stands; 1 % slower with twelve more registers, removed.)
+  // 100-150 cycles wherever it stands; 1 % slower with twelve more registers, removed.  The whole copy issued by the
+  // leading group alone, whose close logic follows the barrier: +0.7 %, removed.)
 #ifndef AASR_PL_SADDR_COPY
 #define AASR_PL_SADDR_COPY 1
 #endif
