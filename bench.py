@@ -633,10 +633,10 @@ def main():
             extra_cfg["stage_ms"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:
             extra_cfg.update(_measure_precisions(torch, capi, synth, gmm, runner, (mean, var, off, idx, w), PREC,
-                                                 with_models=(rank == 0)))
+                                                 with_models=(rank == 0 and world == 1)))
         except Exception as e:
             extra_cfg["precision_ladder"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if rank == 0:
+        if rank == 0 and world == 1:   # (one-GPU figures: the other ranks of a multi-GPU run would idle ~40 s at the next barrier)
             try:
                 extra_cfg["fitted_model"] = _measure_fitted_models(torch, capi, synth, pipeline, gmm, runner, dev, PREC)
             except Exception as e:
