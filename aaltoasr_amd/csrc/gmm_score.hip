@@ -1840,8 +1840,12 @@ static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const TrackSe
   AASR_HIP(hipGetLastError());
 }
 
+// The three-term bf16 arithmetic on the pipelined kernel as well, up to 39 dimensions (five slabs: with six the 8-wave
+// instance spills).  Round 3 measured it SLOWER there than on the wave-group kernel (33.2 against 32.4 ms per 10^6 frames);
+// with the wave groups' priorities crossed per phase (AASR_PL_PRIO_SCHEME) it is the faster one: 31.08 against 31.65 ms,
+// two alternating runs on one box.  0: k_gmm_diag_score_bf16x3 for every one-pivot three-term layout.
 #ifndef AASR_PL_BF16X3
-#define AASR_PL_BF16X3 0   // experiment: the three-term bf16 arithmetic on the pipelined kernel as well
+#define AASR_PL_BF16X3 1
 #endif
 template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS, bool MAPPED = false>
 static void launch_pl_t(const aasr_gmm *g, const TrackLayout &L, const TrackSection *sec, const float *d_frames, int64_t F,
@@ -1908,7 +1912,7 @@ static bool launch_split(const aasr_gmm *g, const TrackLayout &L, const float *d
   do {                                                                                     \
     if (mapped) {                                                                          \
       if constexpr (GR && NS == 2) launch_pl_t<N, true, CLF, WD, NS, true>(g, L, sec, d_frames, F, d_out, stream, CLA, pitch); \
-    } else if constexpr (NS == 2 || AASR_PL_BF16X3)                                        \
+    } else if constexpr (NS == 2 || (AASR_PL_BF16X3 && N <= 5))                            \
       launch_pl_t<N, GR, CLF, WD, NS>(g, L, sec, d_frames, F, d_out, stream, CLA, pitch);   \
     else if (L.n_pg > 1) {                                                                  \
       /* three bf16 terms on a multi-pivot layout: the pipelined kernel takes the groups' operand images */ \
