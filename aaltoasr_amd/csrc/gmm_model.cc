@@ -1832,8 +1832,10 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
 void gmm_build_tracks(aasr_gmm *g, bool grouped) { build_track_layout(g, grouped ? g->paired : g->tracks, grouped, nullptr); }
 
 // The mixed layout (per-state precision routing), built when the model as a whole does not qualify for the two-term fp16
-// form but some of its states do: grouped where the padding allows, independent tracks otherwise.  A state whose rows fail
-// the range / clamp conditions at packing time is moved to the three-term section and the layout is built again.
+// form but some of its states do: grouped exactly when the model's own grouped layout exists (a grouped mixed layout that
+// fails the padding test is NOT retried on independent tracks: the model then keeps one arithmetic -- or, where the
+// planner of gmm_plan_engine_parts applies, becomes engine parts).  A state whose rows fail the range / clamp conditions at
+// packing time is moved to the three-term section and the layout is built again.
 void gmm_build_mixed(aasr_gmm *g, std::vector<uint8_t> &f16_ok) {
   g->mixed.ok = false;
   static const int f16_env = AASR_EXPERIMENT_ENV("AASR_F16X2") ? atoi(AASR_EXPERIMENT_ENV("AASR_F16X2")) : 1;
