@@ -106,6 +106,9 @@ __device__ __forceinline__ float lin_key32(double ll) {
   return -1900.0f + __log2f((float)q);
 }
 
+// diagnostic (aasr_debug_cluster_pass_bytes): the scratch budget of a pass, so that a test can force several passes
+static double g_pass_bytes = 0;
+static int g_last_passes = 0;   // passes of the most recent clustered run (aasr_debug_cluster_last_passes)
 // diagnostic switch (aasr_debug_cluster_heap): every frame takes the queue replay
 static int g_force_heap = AASR_EXPERIMENT_ENV("AASR_CLUSTER_HEAP") ? atoi(AASR_EXPERIMENT_ENV("AASR_CLUSTER_HEAP")) : 0;
 
@@ -1729,7 +1732,7 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
                            (parts ? 8.0 * (double)ep : 0.0);
   const int64_t round_frames = 2 * (int64_t)(g->num_cus > 0 ? g->num_cus : 256) * FRAMES_PER_BLOCK;
   const int64_t f_rounded = (F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK;
-  int64_t fb = (int64_t)(24.0e9 / per_frame);
+  int64_t fb = (int64_t)((g_pass_bytes > 0 ? g_pass_bytes : 24.0e9) / per_frame);
   if (fb >= round_frames) fb = fb / round_frames * round_frames;
   else fb = std::max<int64_t>(FRAMES_PER_BLOCK, fb / FRAMES_PER_BLOCK * FRAMES_PER_BLOCK);
   fb = std::min<int64_t>(fb, f_rounded);
@@ -1760,6 +1763,7 @@ void gmm_cluster_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, flo
     cl.Fs = fs;
   }
   const int64_t pass_frames = std::min<int64_t>(fb_pass, cl.Fc);   // (this call's balanced passes inside the allocation)
+  g_last_passes = (int)((F + pass_frames - 1) / pass_frames);
   for (int64_t f0 = 0; f0 < F; f0 += pass_frames) {
     const int64_t n = std::min<int64_t>(pass_frames, F - f0);
     const float *fr = d_frames + f0 * g->dim;
@@ -1859,6 +1863,9 @@ void gmm_cluster_score_f64_launch(aasr_gmm *g, const double *d_frames, const dou
 // Diagnostic: 1 = every frame's cluster selection goes through the priority-queue replay
 // (k_cluster_select_heap) instead of the histogram selection; the two must agree.
 extern "C" void aasr_debug_cluster_heap(int on) { aasr::g_force_heap = on; }
+// Diagnostic: bytes of scratch a clustered pass may use (0: the default, 24 GB) -- small values force several passes.
+extern "C" void aasr_debug_cluster_pass_bytes(double bytes) { aasr::g_pass_bytes = bytes; }
+extern "C" int aasr_debug_cluster_last_passes(void) { return aasr::g_last_passes; }
 // Diagnostic: frames of the last sub-pass that were handed to the replay.
 extern "C" int aasr_debug_cluster_tie_frames(aasr_gmm *g) {
   if (!g || !g->cl.tie_list.p) return -1;

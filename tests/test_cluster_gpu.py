@@ -200,6 +200,43 @@ def test_many_clusters_multi_pass(capi, oracle):
     _check(capi, oracle, model, g2c, 1500, 0.05, 0.2, synth.make_frames(130, D=13))
 
 
+def test_several_passes_of_equal_size_give_the_single_pass_result(capi, oracle, monkeypatch):
+    """A clustered run takes as many frames per pass as its scratch budget allows (24 GB) and cuts what is left into passes
+    of equal size (gmm_cluster_score_launch).  With the budget cut down (a diagnostic entry point) 3 000 frames take five
+    and then two passes: the scores are those of the single pass, bit for bit -- on a plain model
+    and on a model with engine parts (the merge writes the public layout from the parts' columns pass by pass)."""
+    import ctypes
+    from test_pivot_groups_gpu import blobs
+    L = capi.lib()
+    L.aasr_debug_cluster_pass_bytes.argtypes = [ctypes.c_double]
+    L.aasr_debug_cluster_pass_bytes.restype = None
+    plain = synth.make_model(D=39, G=2048, S=128, comps=16)
+    Xb = blobs(30000)
+    fitted = synth.fit_model(Xb, S=200, comps=16)
+    for name, model, frames in (("plain", plain, synth.make_frames(3000, D=39)), ("parts", fitted, np.ascontiguousarray(Xb[:3000]))):
+        C = 40
+        g2c = synth.make_clustering(model[0], C, iters=2)
+        if name == "parts":
+            monkeypatch.setenv("AASR_PG_PIVOT_COST", "64")
+        gm = capi.Gmm.from_arrays(*model)
+        assert (gm.engine_parts() is not None) == (name == "parts")
+        gm.set_clustering(C, _pairs(g2c))
+        gm.set_clustering_min_evals(0.0, 0.25)
+        outs, passes = [], []
+        try:
+            # (bytes per frame of a pass: ~430 for the plain model, ~2 400 with the parts' engine rows)
+            for budget in ((0.0, 3.2e5, 8.0e5) if name == "plain" else (0.0, 1.7e6, 4.5e6)):
+                L.aasr_debug_cluster_pass_bytes(budget)
+                outs.append(gm.score(frames))
+                passes.append(L.aasr_debug_cluster_last_passes())
+        finally:
+            L.aasr_debug_cluster_pass_bytes(0.0)
+        assert passes[0] == 1 and passes[1] >= 4 and passes[2] == 2, (name, passes)
+        for sc in outs[1:]:
+            assert np.array_equal(sc, outs[0]), name
+        gm.close()
+
+
 def test_more_clusters_than_a_selection_wave_holds(capi, oracle):
     """> 4096 clusters: every frame takes the replay of the reference's priority queue (k_cluster_select_heap) and the
     log-domain merge; scores and counts as the oracle's."""
