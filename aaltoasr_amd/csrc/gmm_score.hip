@@ -1199,6 +1199,37 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
       constexpr int kChunks = kTileFloats / 4 / 64;   // 1 KB instructions per tile
       const char *gbase = (const char *)((const float *)apack + (size_t)tile * kTileFloats);
       const unsigned lbase = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(abuf0 + b * kTileFloats));
+      // a wave takes CONSECUTIVE 1 KB pieces: one scalar base, one M0, the pieces told apart by the instruction's immediate
+      // offset (it moves the global and the LDS address alike) -- AASR_PL_COPY_IMM, default 1; 0: piece c = wave + k * NW,
+      // a base and an M0 per instruction.  configs[1] 17.91 -> 17.82 ms, three alternating runs on one box.
+#ifndef AASR_PL_COPY_IMM
+#define AASR_PL_COPY_IMM 1
+#endif
+      constexpr int kRounds = (kChunks + NW - 1) / NW;
+      if (AASR_PL_COPY_IMM && kRounds <= 4) {
+        const int w = __builtin_amdgcn_readfirstlane(wave);
+        const int c0 = w * kRounds;   // pieces c0 .. c0 + kRounds - 1 (the last waves may run past the tile: guarded)
+        const unsigned long long sb = (unsigned long long)(uintptr_t)gbase + (unsigned long long)c0 * 1024ull;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sb);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sb >> 32));
+        const unsigned long long sbase = (unsigned long long)lo | ((unsigned long long)hi << 32);
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lbase + (unsigned)c0 * 1024u));
+        const int cnt = kChunks - c0 < kRounds ? kChunks - c0 : kRounds;   // wave-uniform
+        // (one statement per count: M0 must hold between the instructions)
+        if (cnt >= 4)
+          asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                       "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072"
+                       : : "s"(dst), "v"(lane_off16), "s"(sbase) : "memory", "m0");
+        else if (cnt == 3)
+          asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                       "global_load_lds_dwordx4 %1, %2 offset:2048"
+                       : : "s"(dst), "v"(lane_off16), "s"(sbase) : "memory", "m0");
+        else if (cnt == 2)
+          asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024"
+                       : : "s"(dst), "v"(lane_off16), "s"(sbase) : "memory", "m0");
+        else if (cnt == 1)
+          asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(dst), "v"(lane_off16), "s"(sbase) : "memory", "m0");
+      } else {
 #pragma unroll
       for (int k = 0; k < (kChunks + NW - 1) / NW; k++) {
         const int c = __builtin_amdgcn_readfirstlane(wave) + k * NW;   // wave-uniform
@@ -1210,6 +1241,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
           const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lbase + (unsigned)c * 1024u));
           asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(dst), "v"(lane_off16), "s"(sbase) : "memory", "m0");
         }
+      }
       }
     } else {
       issue_tile_copy_raw((const float *)apack + (size_t)tile * kTileFloats, abuf0 + b * kTileFloats, kTileFloats, wave, lane, NW);
