@@ -1106,14 +1106,14 @@ constexpr int kMapFlush32 = 1 << 30;   // ... of its group of 32
 // workgroup AASR_PL_TRACE_BLOCK reads the shader clock (s_memtime) at the phase boundaries of its tile loop and sums the
 // intervals: [0] H0 matrix phase, [1] close logic behind H0, [2] H1 matrix phase, [3] the tile barrier (wait + the next
 // tile's copy issue; the lagging group passes it inside H0: its time is taken out of [0]), [4] fragment prefetch + close
-// logic behind H1, [5] the part of [3] spent in s_barrier, [6] the part of [3] spent in s_waitcnt vmcnt(0), [7] whole kernel, [8] tiles.  Reading the clock waits for every outstanding scalar and LDS
+// logic behind H1, [5] the part of [3] spent in s_barrier, [6] the part of [3] spent in s_waitcnt vmcnt(0), [7] whole kernel, [8] tiles, [9] / [10] of interval 4: the fragment prefetch, the close logic of block 0.  Reading the clock waits for every outstanding scalar and LDS
 // operation, so the traced launch runs slower than the product kernel (the tool reports by how much).
 #ifdef AASR_PL_TRACE
-__device__ unsigned long long g_pl_trace[8][10];
+__device__ unsigned long long g_pl_trace[8][12];
 #ifndef AASR_PL_TRACE_BLOCK
 #define AASR_PL_TRACE_BLOCK 300
 #endif
-#define PL_TRACE_DECL unsigned long long tr_tiles = 0, tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_prev = __builtin_readcyclecounter(), tr_t0 = tr_prev, tr_bar = 0, tr_vm = 0
+#define PL_TRACE_DECL unsigned long long tr_tiles = 0, tr_sub[3] = {0, 0, 0}, tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_prev = __builtin_readcyclecounter(), tr_t0 = tr_prev, tr_bar = 0, tr_vm = 0
 #define PL_TRACE(k) do { const unsigned long long tr_now = __builtin_readcyclecounter(); tr_acc[k] += tr_now - tr_prev; tr_prev = tr_now; } while (0)
 #else
 #define PL_TRACE_DECL
@@ -1610,11 +1610,21 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     // end of tile: the leading group's barrier
     if (!WIDE || group == 0) tile_barrier();
     else asm volatile("" : "+v"(mask_v));
+#ifdef AASR_PL_TRACE
+    const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
     if (t + 1 < t_end) {
       load_frags(anext, 0, 0, 0);   // slab 0 of the next tile's block 0: in flight during the close logic
       __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef AASR_PL_TRACE
+    const unsigned long long ts1 = __builtin_readcyclecounter();
+    tr_sub[0] += ts1 - ts0;   // fragment prefetch (issue)
+#endif
     commit(P, (GROUPED ? mask_cur : (h ? mask_cur >> 8 : mask_cur)) & 0xfu, en00, en01);
+#ifdef AASR_PL_TRACE
+    tr_sub[1] += __builtin_readcyclecounter() - ts1;   // close logic of block 0
+#endif
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       ep0[q] = en10[q];
@@ -1646,6 +1656,8 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
     tr_acc[7] = tr_prev - tr_t0;
     for (int k = 0; k < 8; k++) g_pl_trace[wave & 7][k] = tr_acc[k];
     g_pl_trace[wave & 7][8] = tr_tiles;
+    g_pl_trace[wave & 7][9] = tr_sub[0];
+    g_pl_trace[wave & 7][10] = tr_sub[1];
   }
 #endif
 }
@@ -3881,6 +3893,6 @@ void gmm_gauss_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
 // Diagnostic of experiment builds (tools/pl_trace.py): the phase sums of the last traced launch, [wave][interval]
 extern "C" int aasr_debug_pl_trace(unsigned long long *out) {
   if (hipDeviceSynchronize() != hipSuccess) return -1;
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(aasr::g_pl_trace), sizeof(unsigned long long) * 80) == hipSuccess ? 0 : -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(aasr::g_pl_trace), sizeof(unsigned long long) * 96) == hipSuccess ? 0 : -1;
 }
 #endif

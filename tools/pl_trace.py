@@ -32,10 +32,10 @@ print("scoring call: %.3f ms per %d frames (traced build)" % (e0.elapsed_time(e1
 L = capi.lib()
 if not hasattr(L, "aasr_debug_pl_trace"):
     sys.exit("this library has no trace (build with AASR_BUILD_DEFINES=AASR_PL_TRACE=1)")
-buf = (C.c_uint64 * 80)()
+buf = (C.c_uint64 * 96)()
 L.aasr_debug_pl_trace.argtypes = [C.c_void_p]
 assert L.aasr_debug_pl_trace(buf) == 0
-t = np.array(list(buf), dtype=np.float64).reshape(8, 10)
+t = np.array(list(buf), dtype=np.float64).reshape(8, 12)
 NT = t[:, 8].copy()
 bar_own = t[:, 5].copy()
 t[:, 5] = NT
@@ -50,5 +50,7 @@ print("%-36s" % "sum" + "".join("%9.0f" % v for v in tot) + "  %8.0f" % tot.mean
 print("%-36s" % "tiles" + "".join("%9.0f" % v for v in t[:, 5]))
 print("%-36s" % "  of the barrier: vmcnt(0) wait" + "".join("%9.0f" % v for v in t[:, 6] / NT))
 print("%-36s" % "  of the barrier: s_barrier" + "".join("%9.0f" % v for v in bar_own / NT))
+print("%-36s" % "  behind H1: fragment prefetch" + "".join("%9.0f" % v for v in t[:, 9] / NT))
+print("%-36s" % "  behind H1: close logic" + "".join("%9.0f" % v for v in t[:, 10] / NT))
 print("%-36s" % "whole workgroup cycles" + "".join("%9.0f" % v for v in t[:, 7]))
 print("matrix-pipe share of a SIMD's time (2 waves x 1920 / the pair's mean tile time): %.3f" % (2 * 1920.0 / tot.mean()))
