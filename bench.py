@@ -874,6 +874,24 @@ def _measure_fitted_models(torch, capi, synth, pipeline, gmm, runner, dev, preci
         err = np.abs(got - ref)
         best = ref.max(1, keepdims=True)
         win = vis & (ref > best - 36.0)
+        # the same frames on the ENGINE's own layout (what the timed path runs: the parts' kernels): 4-byte LNA values
+        # without normalisation are the state log-likelihoods as floats; compared where the reference's float likelihood
+        # is a normal number (ll > ln 2^-126)
+        eng = None
+        try:
+            d_sub = torch.from_numpy(sub).to(dev)
+            d_scr = torch.empty(g2.score_scratch_floats(len(sub)), dtype=torch.float32, device=dev)
+            d_b4 = torch.empty((len(sub), S * 4), dtype=torch.uint8, device=dev)
+            g2.score_lna_dev(d_sub, d_scr, d_b4, False, 4, r2.stream)
+            torch.cuda.synchronize()
+            ll_eng = d_b4.cpu().numpy().view("<f4").reshape(len(sub), S).astype(np.float64)
+            nrm = ref > -87.0
+            e_eng = np.abs(ll_eng - ref)
+            eng = {"max_abs_dll": float("%.3g" % e_eng[nrm].max()), "values": int(nrm.sum()),
+                   "max_abs_dll_inside_the_2_byte_lna_window": float("%.3g" % e_eng[nrm & win].max()),
+                   "share_within_1e-4": round(float((e_eng[nrm] <= 1e-4).mean()), 6)}
+        except Exception as e:
+            eng = {"error": "%s: %s" % (type(e).__name__, e)}
         entry = {"audio": kind, "states": S, "gaussians": G,
                  "one_pivot_conditioning": {"kappa_max": round(float(k1.max()), 1), "kappa2_max": round(float(k2.max()), 1),
                                             "states_within_the_f16x2_limits": int(((k1.reshape(S, COMPS).max(1) <= 330.0) &
@@ -883,6 +901,9 @@ def _measure_fitted_models(torch, capi, synth, pipeline, gmm, runner, dev, preci
                  "max_abs_dll_vs_oracle_64_frames": float("%.3g" % err[vis].max()), "visible_values": int(vis.sum()),
                  "max_abs_dll_inside_the_2_byte_lna_window": float("%.3g" % err[win].max()),
                  "share_within_1e-4": round(float((err[vis] <= 1e-4).mean()), 6),
+                 "public_layout_note": "aasr_gmm_score on these frames: the model's own one-pivot layouts where they cover it, "
+                                       "the engine parts gathered back otherwise",
+                 "engine_layout_vs_oracle_64_frames": eng,
                  "seconds": {"audio_and_features": round(t_feat, 1), "fit": round(t_fit, 1), "build": round(t_build, 2)}}
         # ... and the clustered pass on it (what pyrectool always runs: -C, --eval-ming 0.25): the parts' exact parts under
         # the same selection bits, merged through the column map

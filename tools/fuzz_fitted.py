@@ -83,7 +83,15 @@ def run(seed=1, N=10, verbose=False):
         if win.any():
             note("public window", err[win].max())
             if err[win].max() > TOL:
-                fails.append("%s: public layout %.3g inside the LNA window, parts %s" % (tag, err[win].max(), parts))
+                # the worst value: its state's conditioning around the pool's pivot and how far out the frame is
+                fi_, si_ = np.unravel_index(np.argmax(np.where(win, err, 0.0)), err.shape)
+                mean_, var_, off_, idx_, _w = model
+                gi = idx_[off_[si_]:off_[si_ + 1]]
+                k1, k2 = synth.conditioning(mean_, var_)
+                z2 = (((fr[fi_].astype(np.float64) - mean_[gi]) ** 2) / var_[gi]).sum(1)
+                fails.append("%s: public layout %.3g inside the LNA window, parts %s; worst value ll %.1f (frame's best %.1f), state's kappa %.0f "
+                             "kappa2 %.0f, frame %.1f sigma from its nearest Gaussian" % (
+                                 tag, err[win].max(), parts, ref[fi_, si_], ref[fi_].max(), k1[gi].max(), k2[gi].max(), np.sqrt(z2.min())))
         # engine layout through the LNA pass
         d_f = torch.from_numpy(fr).cuda()
         d_scr = torch.empty(g.score_scratch_floats(nf), dtype=torch.float32, device="cuda")
