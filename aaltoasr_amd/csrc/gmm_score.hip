@@ -3476,11 +3476,15 @@ bool gmm_engine_parts_clustered(const aasr_gmm *g) {
 }
 
 // ... and whether public-layout calls (column = state) go through them too, with the columns gathered back: where the
-// model's own layouts have no two-term form at all
+// model's own layouts have no two-term form at all -- or hold Gaussians on the matrix path whose conditioning around the
+// pool's ONE pivot lies in the upper part of the three-term form's range (kappa > 400 or kappa2 > 130: where
+// tools/fuzz_fitted.py found 1.0-1.45e-4 on frames far from the model, gmm.h).  The parts expand every state around a
+// pivot of its group and stay below 1e-4 there; the gather of the columns is what the public layout pays for it.
 static bool engine_parts_public(const aasr_gmm *g) {
   if (!gmm_engine_parts_active(g)) return false;
   const TrackLayout &L = g->paired.ok ? g->paired : g->tracks;
-  return !(L.ok && L.a16h.p) && !g->mixed.ok;
+  if (!(L.ok && L.a16h.p) && !g->mixed.ok) return true;
+  return g->kappa_matrix > 400.0 || g->kappa2_matrix > 130.0;
 }
 
 int64_t gmm_engine_pitch(const aasr_gmm *g) {
