@@ -1591,6 +1591,18 @@ static ExactPlan exact_part_plan(aasr_gmm *g, ClusterState &cl) {
   return p;
 }
 
+// tiles a workgroup of k_cluster_expand takes: its staged copy of the word's cluster masks (8 bytes per cluster) serves
+// all of them, so as many as leave the grid a few thousand workgroups (AASR_EXPAND_TPB_MIN: 64 until round 5 for any size)
+static int expand_tiles_per_block(int64_t n_tiles, int64_t words) {
+#ifndef AASR_EXPAND_ALL_TILES
+#define AASR_EXPAND_ALL_TILES 1
+#endif
+  if (!AASR_EXPAND_ALL_TILES) return (int)std::min<int64_t>(n_tiles, 64);
+  const int64_t want_x = std::max<int64_t>(1, (4096 + words - 1) / words);   // workgroups along the tiles
+  const int64_t tpb = (n_tiles + want_x - 1) / want_x;
+  return (int)std::max<int64_t>(std::min<int64_t>(n_tiles, 16), tpb);
+}
+
 static void launch_expand(aasr_gmm *g, const unsigned long long *maskw, int c1, const int32_t *crow, int64_t rows_padded,
                           int64_t n_tiles, int tpb, int64_t words, unsigned long long *maskrow, hipStream_t stream) {
   static bool attr_set[64] = {false};
@@ -1616,7 +1628,7 @@ static void exact_part_launch(aasr_gmm *g, ClusterState &cl, const ExactPlan &p,
     const int64_t rows_padded = g->full.rows_padded;
     cl.maskrow.ensure((size_t)((n + 511) / 512 * 8) * (size_t)rows_padded);
     const int64_t n_tiles = rows_padded / TILE_ROWS;
-    const int tpb = (int)std::min<int64_t>(n_tiles, 64);
+    const int tpb = expand_tiles_per_block(n_tiles, words);
     launch_expand(g, maskw, c1, cl.crow_full.p, rows_padded, n_tiles, tpb, words, cl.maskrow.p, stream);
     gmm_full_masked_launch(g, fr_members, n, out, cl.maskrow.p, stream);
     return;
@@ -1629,7 +1641,7 @@ static void exact_part_launch(aasr_gmm *g, ClusterState &cl, const ExactPlan &p,
   // the track kernels read the lane masks of whole workgroups (up to 512 frames = 8 words)
   cl.maskrow.ensure((size_t)((n + 511) / 512 * 8) * (size_t)L.rows_padded);
   const int64_t n_tiles = L.rows_padded / TILE_ROWS;
-  const int tpb = (int)std::min<int64_t>(n_tiles, 64);  // the staged cluster masks serve 64 tiles
+  const int tpb = expand_tiles_per_block(n_tiles, words);
   launch_expand(g, maskw, c1, cl.crow[p.which].p, L.rows_padded, n_tiles, tpb, words, cl.maskrow.p, stream);
   gmm_tracks_masked_launch(g, p.which, fr_members, n, out, cl.maskrow.p, stream, pitch);
   if (p.with_outliers) gmm_outliers_masked_launch(g, fr_members, n, out, cl.crow_hyb.p, maskw, c1, words, stream);
