@@ -266,11 +266,9 @@ aasr_status aasr_gmm_precision_states(const aasr_gmm *h, int64_t *states_f16x2, 
     int64_t n = 0;
     if (aasr::gmm_engine_parts_active(h)) {
       for (const auto &part : h->engine_parts) {
-        if (part.arith == 2) n += part.states;
+        if (part.arith == 2) n += part.states;   // (the plain two-term layout: slab-constant rows count as routed)
         else if (part.arith == 0) {   // the remainder is a model of its own: it may hold two-term states around its pivot
-          int64_t k = 0;
-          part.model->precision = h->precision;
-          part.model->use_bf16x3 = h->use_bf16x3;
+          int64_t k = 0;   // (the remainder's precision follows the handle's: aasr_gmm_set_precision, gmm_plan_engine_parts)
           aasr_gmm_precision_states(part.model.get(), &k, nullptr);
           n += k;
         }
@@ -295,6 +293,13 @@ aasr_status aasr_gmm_set_precision(aasr_gmm *h, int prec) {
         raise(AASR_ERR_UNSUPPORTED, "the split-operand (bf16x3 / f16x2) kernels are not available for this model");
       h->precision = prec;
       h->use_bf16x3 = (prec == AASR_PREC_BF16X3 || prec == AASR_PREC_F16X2);
+      // the remainder part of a model with engine parts is an ordinary model scored under the handle's precision
+      // (queries such as aasr_gmm_precision_states read it and must not write: ADVICE round 5)
+      for (auto &part : h->engine_parts)
+        if (part.arith == 0 && part.model) {
+          part.model->precision = h->precision;
+          part.model->use_bf16x3 = h->use_bf16x3;
+        }
       return;
     }
     if (prec == AASR_PREC_F64) {

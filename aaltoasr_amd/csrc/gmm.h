@@ -71,7 +71,9 @@ struct HostModel {
   // whole line of the score matrix -- are padding columns without components, never scored, never read.
   std::vector<int32_t> pg_begin, pg_real_end;   // [P + 1], [P]
   std::vector<float> pg_pivot;                  // [P][dim]
-  int pg_arith = 0;                             // 2: two fp16 terms, 3: three bf16 terms (0: no pivot groups)
+  int pg_arith = 0;                             // 2: two fp16 terms, 3: three bf16 terms, 4: two fp16 terms with the
+                                                // constant dealt to the K slabs (pg_sc()) (0: no pivot groups)
+  bool pg_sc() const { return pg_arith == 4; }
   int n_pg() const { return pg_arith ? (int)pg_real_end.size() : 0; }
   int pg_of_state(int64_t s) const {
     int p = 0;
@@ -99,18 +101,24 @@ constexpr int TRACK_MAX_SPLITS = 16;  // row-range cuts available to the launche
 constexpr int PG_MAX = 32;            // pivot groups of a multi-pivot layout
 constexpr int PG_MAX_SPLITS = 48;     // ... and the cuts of its table (every group is at least one cut)
 constexpr int CENTRED_MAX_SPLITS = 32;
-// expanded-form error estimate eps * kappa beyond which the centred kernel is used.
-// (Round 5, tools/fuzz_fitted.py: the sweeps that set these values scored frames drawn near the model.  On frames 7-13
-// sigma from their nearest Gaussian -- what most (frame, state) pairs of real audio are -- the three-term form at kappa
-// 500-760, kappa2 120-195 reaches 1.0-1.45e-4 on 3 % of the swept models: the error grows with sqrt(kappa) |z|.  A build
-// with 400 / 130 (-DAASR_KAPPA_LIMIT_VALUE=400.0 -DAASR_KAPPA2_LIMIT_VALUE=130.0) leaves two marginal cases of 550
-// (1.04e-4; 1.07e-4 on a value at -97 nats) -- and moves every Gaussian between the old and the new limits to the centred
-// form, which the tests and the routing figures of the bench are not calibrated for: not adopted this round)
+// Conditioning limits of the expanded (matrix-core) forms.  kappa_g = sum_d p (mu - pivot)^2 -- how far a Gaussian's mean
+// lies from the expansion point in units of its own standard deviations -- and kappa2, the 2-norm of the same terms.
+//
+// Round 6 (tools/exp_calib.py, tools/mfma_sum): what limits the expanded form is NOT the operands' precision
+// (three bf16 terms are no better than two fp16 terms at the same kappa) but the matrix instruction's summation: every
+// 8-product step aligns its terms and the accumulator to the largest exponent and cuts them 24 bits below it, and in
+// the plain K layout the accumulator starts at -1/2 log2e kappa, so every instruction cuts at that magnitude: the
+// error grows linearly with kappa (2e-7 kappa + 3e-5, per-state maxima over 3 072 frames on and up to 1.5 sigma off
+// the data, 240 fitted models).  Sample maxima by (kappa, kappa2): plain two-term layout 4.8e-5 below (250, 80)
+// [7.6e-5 in 13 dimensions], 8.5e-5 at (330, 160), 1.0e-4 at (500, 200), 1.2e-4 at 600+ -- the round-5 limits
+// (330 / 80 two terms, 600 / 200 three terms) had been set on frames near the model and let 1.0-1.45e-4 through on
+// frames 7-14 sigma out; slab-constant layout (TrackLayout::sc) 7.4e-5 below (450, 120), 8.2e-5 at (600, 200), 1.0e-4 at
+// (1 100, 260).  Limits are set where the sample maxima stay at or below 7.5e-5; beyond them: the centred form.
 #ifndef AASR_KAPPA_LIMIT_VALUE
-#define AASR_KAPPA_LIMIT_VALUE 600.0
+#define AASR_KAPPA_LIMIT_VALUE 300.0
 #endif
 #ifndef AASR_KAPPA2_LIMIT_VALUE
-#define AASR_KAPPA2_LIMIT_VALUE 200.0
+#define AASR_KAPPA2_LIMIT_VALUE 130.0
 #endif
 constexpr double KAPPA_LIMIT = AASR_KAPPA_LIMIT_VALUE;
 // the same estimate taken as a 2-norm over the dimensions: rounding errors of different dimensions add
@@ -127,8 +135,23 @@ constexpr double KAPPA2_LIMIT = AASR_KAPPA2_LIMIT_VALUE;
 // averaging: a sweep's one-dimensional model (tools/fuzz_parity.py 3002, iteration 290) came out 8.85e-5 off with every
 // Gaussian below kappa2 = 80 -- 1.1e-6 per unit against 0.5e-6 for the 39-dimensional model -- so models of fewer than
 // 8 dimensions get the limit that keeps that case at the 5e-5 the other forms show.
-constexpr double KAPPA_LIMIT_F16 = 330.0;
-constexpr double KAPPA2_LIMIT_F16 = 80.0;
+#ifndef AASR_KAPPA_LIMIT_F16_VALUE
+#define AASR_KAPPA_LIMIT_F16_VALUE 250.0
+#endif
+#ifndef AASR_KAPPA2_LIMIT_F16_VALUE
+#define AASR_KAPPA2_LIMIT_F16_VALUE 80.0
+#endif
+constexpr double KAPPA_LIMIT_F16 = AASR_KAPPA_LIMIT_F16_VALUE;
+constexpr double KAPPA2_LIMIT_F16 = AASR_KAPPA2_LIMIT_F16_VALUE;
+// The slab-constant layout (TrackLayout::sc) of the engine parts: limits from tools/exp_calib.py (round 6)
+#ifndef AASR_KAPPA_LIMIT_SC_VALUE
+#define AASR_KAPPA_LIMIT_SC_VALUE 500.0
+#endif
+#ifndef AASR_KAPPA2_LIMIT_SC_VALUE
+#define AASR_KAPPA2_LIMIT_SC_VALUE 160.0
+#endif
+constexpr double KAPPA_LIMIT_SC = AASR_KAPPA_LIMIT_SC_VALUE;
+constexpr double KAPPA2_LIMIT_SC = AASR_KAPPA2_LIMIT_SC_VALUE;
 #ifdef AASR_F16_LOWDIM80   // experiment build
 constexpr double KAPPA2_LIMIT_F16_LOWDIM = 80.0;
 #else
@@ -195,6 +218,13 @@ struct TrackLayout {
   DevBuf<uint16_t> a16h;
   DevBuf<float> f16tab;      // f16x2: [2 KH] per-column scales of the frame operand (2^s_k), [KH] clamp of |x - pivot|
   int nk16 = 0;              // K/16 (K = 2*KH, KH = 8*nk16 >= dim+1)
+  // Slab-constant K layout (two fp16 terms, engine parts only): every slab of 16 K slots carries ITS seven dimensions'
+  // share of the constant in its first two slots (value + remainder) -- -1/2 log2e sum p mu'^2 over the slab's dimensions;
+  // the last slab in use also the rest, peak + log w + reference -- then (linear, quadratic) of dimensions 7 j .. 7 j + 6.
+  // The accumulators then never hold more than the value itself: in the plain layout they start at -1/2 log2e kappa and
+  // every matrix instruction cuts its smaller terms at the accumulator's exponent (tools/mfma_sum), an error that grows
+  // with kappa whatever the operands' precision (tools/exp_calib.py).  Six slabs instead of five for 39 dimensions.
+  bool sc = false;
   DevBuf<uint16_t> close;    // per tile: bit p (+8 for track 1) = a state closes after quad p
   DevBuf<int32_t> sid;       // [2][sid_stride] state index of the k-th close on each track
   int32_t sid_stride = 0;
@@ -339,7 +369,7 @@ struct aasr_gmm {
     std::unique_ptr<aasr_gmm> model;
     int64_t col0 = 0;        // first column of the part in an engine score row
     int64_t cols = 0;        // columns it occupies (a multiple of 32)
-    int arith = 0;           // 2 / 3: pivot-group model in that arithmetic, 0: ordinary model
+    int arith = 0;           // 2 / 3 / 4: pivot-group model in that arithmetic (HostModel::pg_arith), 0: ordinary model
     int64_t states = 0;      // real states
   };
   std::vector<EnginePart> engine_parts;
@@ -351,6 +381,7 @@ struct aasr_gmm {
   mutable aasr::DevBuf<float> engine_scratch, engine_part_scratch;   // public-layout callers: engine rows of a chunk of frames
   std::vector<uint8_t> f16_state_ok;   // per state: eligible for the two-term fp16 form (conditioning limits, probe)
   int64_t f16_probe_moved = 0;         // states the load-time probe (gmm_probe_f16x2) took out of the fp16 form
+  bool f16_whole_rejected = false;     // the probe took the whole-model two-term rows away: no layout packs them again
   // full-covariance path (k_gmm_full_score): rows are the rows of R^-1 of
   // every component, see gmm_build_fullcov()
   aasr::FullLayout full;
@@ -466,6 +497,7 @@ void gmm_plan_engine_parts(aasr_gmm *g);
 bool gmm_engine_parts_active(const aasr_gmm *g);
 bool gmm_engine_parts_clustered(const aasr_gmm *g);   // ... under Gaussian clustering (gmm_cluster_score_launch)
 void gmm_scatter_columns(const float *dense, int64_t F, int64_t n, float *out, int64_t pitch, hipStream_t stream);
+void gmm_add_bias_nofloor(float *d_out, int64_t n, float bias, hipStream_t stream);
 void gmm_gather_engine_columns(const aasr_gmm *g, const float *rows, int64_t F, int64_t in_pitch, float *out, int64_t out_pitch,
                                hipStream_t stream);
 // the engine's own score layout: rows of gmm_engine_pitch() floats; state s in column gmm_engine_colmap()[s] (nullptr: s)

@@ -1182,6 +1182,8 @@ void gmm_set_clustering(aasr_gmm *g, int32_t n_clusters, int64_t n_pairs,
   n.loaded = true;
   for (auto &sub : g->class_models)
     if (sub) sub->cl = ClusterState();  // the classes' views of the previous clustering
+  for (auto &part : g->engine_parts)    // ... and the engine parts' (rebuilt by the next clustered pass: another
+    if (part.model) part.model->cl = ClusterState();   // assignment with the same cluster count must not keep the old rows)
   // thresholds and the on/off state survive a re-read like the reference's members do
   n.enabled = cl.enabled;
   n.min_clusters = cl.min_clusters;
@@ -1635,6 +1637,9 @@ static void exact_part_launch(aasr_gmm *g, ClusterState &cl, const ExactPlan &p,
   }
   if (p.all_centred) {
     gmm_centred_masked_launch(g, fr_members, n, out, cl.crow_centred.p, maskw, c1, words, stream);
+    // log|det| of an in-place global transform: the centred records do not carry it (the track kernels take it at
+    // their output, the outlier merge adds it to the centred share)
+    if (g->out_bias_ln != 0) gmm_add_bias_nofloor(out, n * g->S, (float)g->out_bias_ln, stream);
     return;
   }
   const TrackLayout &L = p.which == 2 ? g->mixed : p.which == 0 ? g->paired : g->tracks;

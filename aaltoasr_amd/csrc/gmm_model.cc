@@ -505,6 +505,7 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
   g->routed_sub.reset();
   g->routed_colmap = DevBuf<int32_t>();
   g->f16_probe_moved = 0;
+  g->f16_whole_rejected = false;
   g->rows_unbiased = false;
   g->out_bias_ln = 0;
   g->dim = m.dim;
@@ -770,7 +771,7 @@ static void build_pg_model(aasr_gmm *g) {
   HostModel &m = g->host;
   const int P = m.n_pg(), D = m.dim;
   if (P < 1 || P > PG_MAX || (int)m.pg_begin.size() != P + 1 || (int64_t)m.pg_pivot.size() != (int64_t)P * D ||
-      m.pg_begin[0] != 0 || m.pg_begin[(size_t)P] != m.S || (m.pg_arith != 2 && m.pg_arith != 3))
+      m.pg_begin[0] != 0 || m.pg_begin[(size_t)P] != m.S || (m.pg_arith != 2 && m.pg_arith != 3 && m.pg_arith != 4))
     raise(AASR_ERR_INVALID, "malformed pivot groups");
   for (int p = 0; p < P; p++)
     if (m.pg_begin[(size_t)p] % 32 != 0 || m.pg_real_end[(size_t)p] <= m.pg_begin[(size_t)p] ||
@@ -816,9 +817,9 @@ static void build_pg_model(aasr_gmm *g) {
   g->f16_bad_state = -1;
   g->f16_state_ok.assign((size_t)m.S, 1);
   gmm_build_tracks(g, true);
-  if (!g->paired.ok || (m.pg_arith == 2 ? !g->paired.a16h.p : !g->paired.a16.p))
+  if (!g->paired.ok || (m.pg_arith != 3 ? !g->paired.a16h.p : !g->paired.a16.p))
     raise(AASR_ERR_UNSUPPORTED, "no grouped layout for the pivot groups (state %ld)", (long)g->f16_bad_state);
-  g->precision = m.pg_arith == 2 ? AASR_PREC_F16X2 : AASR_PREC_BF16X3;
+  g->precision = m.pg_arith != 3 ? AASR_PREC_F16X2 : AASR_PREC_BF16X3;
   g->use_bf16x3 = true;
   g->rows_unbiased = true;
   gmm_probe_f16x2(g);   // marks the states it rejects in f16_state_ok (the planner moves them)
@@ -1047,9 +1048,14 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
   if (g->is_routed_sub || g->is_engine_part || m.n_pg() > 0 || m.n_transforms > 0 || m.any_full() || !g->dim_parts.empty() ||
       g->class_routing || m.S < 2 || m.mix_idx.empty())
     return;
+  // EXPERIMENT (tools/exp_calib.py): every state into ONE slab-constant part around the pool's pivot, whatever its conditioning
+  static const int force_sc = AASR_EXPERIMENT_ENV("AASR_EXP_FORCE_SC") ? atoi(AASR_EXPERIMENT_ENV("AASR_EXP_FORCE_SC")) : 0;
   {
     const TrackLayout &L0 = g->paired.ok ? g->paired : g->tracks;
-    if (L0.ok && L0.a16h.p) return;   // the whole model on two fp16 terms around one pivot: nothing to gain
+    // the whole model on two fp16 terms around one pivot: nothing to gain -- unless Gaussians were taken off the matrix
+    // path to get there (outlier routing: the centred form costs several rows' time per row; a group's own pivot or the
+    // slab-constant layout keeps most of them on the matrix cores)
+    if (!force_sc && L0.ok && L0.a16h.p && !g->hyb_enabled && !g->ill_conditioned) return;
   }
   const int D = m.dim;
   const double rows_total = (double)m.mix_idx.size();
@@ -1072,7 +1078,7 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
 #ifndef AASR_PG3_LIMIT_SCALE
 #define AASR_PG3_LIMIT_SCALE 1.0
 #endif
-  const PgLimits lim3{lim_scale * AASR_PG3_LIMIT_SCALE * KAPPA_LIMIT, lim_scale * AASR_PG3_LIMIT_SCALE * KAPPA2_LIMIT};
+  const PgLimits lim3{lim_scale * AASR_PG3_LIMIT_SCALE * KAPPA_LIMIT_SC, lim_scale * AASR_PG3_LIMIT_SCALE * KAPPA2_LIMIT_SC};
   std::vector<int64_t> cand;
   for (int64_t s = 0; s < m.S; s++) cand.push_back(s);
   std::vector<aasr_gmm::EnginePart> parts;
@@ -1118,7 +1124,7 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
     return true;
   };
   // part 0: two fp16 terms
-  {
+  if (!force_sc) {
     std::vector<int64_t> pool = cand, out;
     for (int attempt = 0; attempt < 8 && !pool.empty(); attempt++) {
       PgPlan plan = pg_plan(m, pool, lim2, cost2, PG_MAX);
@@ -1148,18 +1154,26 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
   }
   // (states the model's own probe moved are normally rejected here again: the union is what is reported)
   g->f16_probe_moved = std::max(g->f16_probe_moved, probe_moved);
-  if (parts.empty()) return;   // nothing qualifies for two terms around any pivot: the model's own paths
-  // part 1: three bf16 terms
-  if (!cand.empty()) {
+  if (parts.empty() && !force_sc) return;   // nothing qualifies for two terms around any pivot: the model's own paths
+  // part 1: two fp16 terms in the slab-constant K layout (TrackLayout::sc): 6 slabs instead of 5 at 39 dimensions, and an
+  // error that no longer grows with kappa.  (Round 5 had three bf16 terms here: twice a two-term row's cost, and --
+  // tools/exp_calib.py -- no more accurate at the same kappa: the error is the accumulators', not the operands'.)
+  if (!cand.empty() && 7 * 8 >= D) {
     std::vector<int64_t> pool = cand, out;
     for (int attempt = 0; attempt < 8 && !pool.empty(); attempt++) {
-      PgPlan plan = pg_plan(m, pool, lim3, cost3, PG_MAX);
-      say("[three terms, attempt %d: %zu candidates -> %zu groups, %zu rejected] ", attempt, pool.size(), plan.groups.size(),
+      PgPlan plan;
+      if (force_sc) {
+        plan.groups.push_back(pool);
+        pg_centre(m, pool, plan.pivots);
+      } else {
+        plan = pg_plan(m, pool, lim3, cost3, PG_MAX);
+      }
+      say("[slab constants, attempt %d: %zu candidates -> %zu groups, %zu rejected] ", attempt, pool.size(), plan.groups.size(),
           plan.rejected.size());
       out.insert(out.end(), plan.rejected.begin(), plan.rejected.end());
       if (plan.groups.empty()) { pool.clear(); break; }
       std::vector<int64_t> rejects;
-      if (build_part(plan.groups, plan.pivots, 3, &rejects)) { pool.clear(); break; }
+      if (build_part(plan.groups, plan.pivots, 4, &rejects)) { pool.clear(); break; }
       std::vector<uint8_t> rej((size_t)m.S, 0);
       for (int64_t s : rejects) rej[(size_t)s] = 1;
       if (rejects.empty())   // no layout at all
@@ -1187,6 +1201,8 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
     sub->is_engine_part = true;
     sub->parent_gauss = pgauss;
     gmm_build(sub.get(), sm);
+    sub->precision = g->precision;
+    sub->use_bf16x3 = g->use_bf16x3;
     // a remainder of two or three states is scored in the centred form as a whole: one launch (5 us per row and 449 280
     // frames: 0.68 ms measured for 128 rows, 0.17 for 32) instead of the matrix kernel + the centred kernel for its outliers
     // + their merge, each with the fixed costs of a launch over every frame block (0.4-0.5 ms whatever the part's size)
@@ -1427,12 +1443,13 @@ static bool pack_f16x2(const aasr_gmm *g, const std::vector<RowSpec> &rows, cons
   const HostModel &m = g->host;
   const int D = m.dim;
   const int nk16 = L.nk16;
+  const bool sc = L.sc;
   L.a16h = DevBuf<uint16_t>();
   L.f16tab = DevBuf<float>();
   *bad_state = -1;
   if (nk16 <= 0) return false;
   const int KH = 8 * nk16;
-  if (2 * D + 1 >= 2 * KH) return false;  // no spare slot for the constant's remainder
+  if (sc ? 7 * nk16 < D : 2 * D + 1 >= 2 * KH) return false;  // no room (plain: no spare slot for the constant's remainder)
   const size_t tile_elems = (size_t)nk16 * 2 * 2 * 64 * 8;
   std::vector<uint16_t> a((size_t)tiles * tile_elems, 0);
   const size_t stride = 2 * (size_t)D + 1;
@@ -1441,11 +1458,47 @@ static bool pack_f16x2(const aasr_gmm *g, const std::vector<RowSpec> &rows, cons
     memcpy(&u, &h, 2);
     return u;
   };
-  const int KC = 0, KR = 1;   // K slots of the constant and of its remainder; dimension d: 2 + 2 d (linear), 3 + 2 d (quadratic)
-  auto coef_of = [&](const double *c, int k, double const_rem) {
-    if (k == KC) return c[2 * D];
-    if (k == KR) return const_rem;
-    return k - 2 < 2 * D ? c[k - 2] : 0.0;
+  // K slots.  Plain: 0 the constant, 1 its remainder, dimension d: 2 + 2 d (linear), 3 + 2 d (quadratic).  Slab-constant
+  // (TrackLayout::sc): slab j = slots 16 j ..: its constant share, the remainder, then dimensions 7 j .. 7 j + 6.
+  const int n_cslab = sc ? (D + 6) / 7 : 1;          // slabs that carry a constant
+  const int base_slab = sc ? n_cslab - 1 : 0;        // ... and the one with peak + log w + reference (and the null marker)
+  auto lin_slot = [&](int d) { return sc ? 16 * (d / 7) + 2 + 2 * (d % 7) : 2 + 2 * d; };
+  auto const_slot = [&](int j) { return sc ? 16 * j : 0; };
+  // kind of slot k: 0 constant of slab *j, 1 its remainder, 2 linear / 3 quadratic term of dimension *d, 4 unused
+  auto slot_kind = [&](int k, int *j, int *d) {
+    if (!sc) {
+      *j = 0;
+      if (k == 0) return 0;
+      if (k == 1) return 1;
+      *d = (k - 2) / 2;
+      return *d < D ? 2 + ((k - 2) & 1) : 4;
+    }
+    *j = k / 16;
+    const int q = k % 16;
+    if (*j >= n_cslab) return 4;
+    if (q == 0) return 0;
+    if (q == 1) return 1;
+    *d = 7 * *j + (q - 2) / 2;
+    return *d < D ? 2 + (q & 1) : 4;
+  };
+  // the constants of a row's slabs (log2 units); null / zero-weight rows: the marker only
+  std::vector<double> cs((size_t)n_cslab);
+  auto slab_constants = [&](const double *c, bool *null_row) {
+    std::fill(cs.begin(), cs.end(), 0.0);
+    *null_row = !(c[2 * D] > -1.0e29);
+    if (*null_row) return;
+    if (!sc) {
+      cs[0] = c[2 * D];
+      return;
+    }
+    double base = c[2 * D];
+    for (int d = 0; d < D; d++) {
+      const double lin = c[2 * d], quad = c[2 * d + 1];
+      const double h = quad < 0 ? lin * lin / (-4.0 * quad) : 0.0;   // 1/2 p mu'^2 log2e
+      cs[(size_t)(d / 7)] -= h;
+      base += h;
+    }
+    cs[(size_t)base_slab] += base;
   };
   // Per-column power-of-two scales: column k of the rows is divided by 2^s_k and the frame operand multiplied by it
   // (exact).  An fp16 `lo` term is a subnormal when its value is below 0.25, and a subnormal carries an ABSOLUTE error
@@ -1458,14 +1511,22 @@ static bool pack_f16x2(const aasr_gmm *g, const std::vector<RowSpec> &rows, cons
   for (int64_t r = 0; r < tiles * TILE_ROWS; r++) {
     if (rows[(size_t)r].g < 0) continue;
     const double *c = &coef64[(size_t)r * stride];
-    if (!(c[2 * D] > -1.0e29)) continue;   // zero-weight row: its constant is the null marker
+    bool null_row = false;
+    slab_constants(c, &null_row);
+    if (null_row) continue;   // zero-weight row: its constant is the null marker
     double *ma = &max_a[(size_t)rows[(size_t)r].pg * 2 * KH];
     for (int k = 0; k < 2 * KH; k++) {
-      double v = std::fabs(coef_of(c, k, 0.0));
-      if (k == KR) v = std::fabs(c[2 * D]) * 0x1p-22;   // the constant's remainder after two fp16 terms
+      int j = 0, d = 0;
+      const int kind = slot_kind(k, &j, &d);
+      double v = 0;
+      if (kind == 0) v = std::fabs(cs[(size_t)j]);
+      else if (kind == 1) v = std::fabs(cs[(size_t)j]) * 0x1p-22;   // the constant's remainder after two fp16 terms
+      else if (kind == 2) v = std::fabs(c[2 * d]);
+      else if (kind == 3) v = std::fabs(c[2 * d + 1]);
       ma[(size_t)k] = std::max(ma[(size_t)k], v);
     }
   }
+  const int KB = const_slot(base_slab);   // the column that also carries the null rows' marker
   std::vector<int> sk((size_t)NG * 2 * KH, 0);
   std::vector<float> tab((size_t)NG * 3 * KH, 0.0f);   // per group: [2 KH] frame-operand scales 2^s_k, [KH] clamp of |x - pivot|
   for (int gi = 0; gi < NG; gi++) {
@@ -1474,19 +1535,20 @@ static bool pack_f16x2(const aasr_gmm *g, const std::vector<RowSpec> &rows, cons
     for (int k = 0; k < 2 * KH; k++) {
       int e = 0;
       if (max_a[(size_t)gi * 2 * KH + k] > 0) e = (int)std::ceil(std::log2(max_a[(size_t)gi * 2 * KH + k] / 128.0));
-      // the constant's column carries the null rows' -60000 as well: its scale must leave 2^(-60000 * 2^s) = 0 in f32
+      // the marker's column carries the null rows' -60000 as well: its scale must leave 2^(-60000 * 2^s) = 0 in f32
       // (a model whose live constants are all tiny would otherwise get s = -14 and a null row worth 2^-3.7)
-      e = std::max(k == KC ? -8 : -14, std::min(14, e));
+      e = std::max(k == KB ? -8 : -14, std::min(14, e));
       skg[(size_t)k] = e;
       tabg[(size_t)k] = (float)std::ldexp(1.0, e);
     }
     for (int d = 0; d < D; d++) {
       // one clamp per dimension keeps x' 2^s and x'^2 2^s inside the fp16 range
-      const double x_lin = 60000.0 * std::ldexp(1.0, -skg[(size_t)(2 + 2 * d)]);
-      const double x_quad = std::sqrt(60000.0 * std::ldexp(1.0, -skg[(size_t)(3 + 2 * d)]));
+      const double x_lin = 60000.0 * std::ldexp(1.0, -skg[(size_t)lin_slot(d)]);
+      const double x_quad = std::sqrt(60000.0 * std::ldexp(1.0, -skg[(size_t)(lin_slot(d) + 1)]));
       tabg[(size_t)2 * KH + d] = (float)(0.99 * std::min((double)kF16Clamp, std::min(x_lin, x_quad)));
     }
   }
+  std::vector<double> rem((size_t)n_cslab);
   for (int64_t r = 0; r < tiles * TILE_ROWS; r++) {
     const double *c = &coef64[(size_t)r * stride];
     const RowSpec &rs = rows[(size_t)r];
@@ -1514,19 +1576,28 @@ static bool pack_f16x2(const aasr_gmm *g, const std::vector<RowSpec> &rows, cons
     const int64_t t = r / TILE_ROWS;
     const int jrow = (int)(r % TILE_ROWS);
     const int mb = jrow / 32, m32 = jrow % 32;
-    double const_rem = 0;
+    bool null_row = false;
+    slab_constants(c, &null_row);
+    std::fill(rem.begin(), rem.end(), 0.0);
     for (int k = 0; k < 2 * KH; k++) {
-      double v = std::ldexp(coef_of(c, k, const_rem), k == KR ? 0 : -skg[(size_t)k]);
+      int j = 0, d = 0;
+      const int kind = slot_kind(k, &j, &d);
+      double coef = 0;
+      if (kind == 0) coef = cs[(size_t)j];
+      else if (kind == 1) coef = rem[(size_t)j];
+      else if (kind == 2) coef = null_row ? 0.0 : c[2 * d];
+      else if (kind == 3) coef = null_row ? 0.0 : c[2 * d + 1];
+      double v = std::ldexp(coef, kind == 1 ? 0 : -skg[(size_t)k]);
       // null / zero-weight rows carry kNullConst: any constant whose 2^x is zero in f32 does
-      if (k == KC && c[2 * D] <= -1.0e29) v = -60000.0;
+      if (k == KB && null_row) v = -60000.0;
       if (!(std::fabs(v) <= 60000.0)) {
         *bad_state = rs.g >= 0 ? row_state[(size_t)r] : -1;
         return false;
       }
       const _Float16 h1 = (_Float16)v;
       const _Float16 h2 = (_Float16)(v - (double)h1);
-      // what the two terms left of the constant goes to the remainder's slot in that slot's own scale
-      if (k == KC) const_rem = std::ldexp((v - (double)h1) - (double)h2, skg[(size_t)KC] - skg[(size_t)KR]);
+      // what the two terms left of a constant goes to the remainder's slot (the next one) in that slot's own scale
+      if (kind == 0) rem[(size_t)j] = null_row ? 0.0 : std::ldexp((v - (double)h1) - (double)h2, skg[(size_t)k] - skg[(size_t)k + 1]);
       const uint16_t hs[2] = {bits(h1), bits(h2)};
       const int slab = k / 16, hk = (k % 16) / 8, i = k % 8;
       const int lane = hk * 32 + m32;
@@ -1815,7 +1886,16 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
   }
   std::vector<double> coef64;
   pack_rows(g, rows, L.rows, &coef64, /*upload_f32=*/!mixed);
-  pack_bf16x3(m.dim, coef64, tiles, L);
+  L.sc = P > 0 && m.pg_sc();
+  if (L.sc) {
+    // slab-constant layout: seven dimensions per slab, two fp16 terms only
+    L.a16 = DevBuf<uint16_t>();
+    L.nk16 = 0;
+    for (int c : {1, 2, 3, 4, 5, 6, 8})
+      if (7 * c >= m.dim) { L.nk16 = c; break; }
+  } else {
+    pack_bf16x3(m.dim, coef64, tiles, L);
+  }
   static const int f16_env = AASR_EXPERIMENT_ENV("AASR_F16X2") ? atoi(AASR_EXPERIMENT_ENV("AASR_F16X2")) : 1;   // 0: never pack the f16x2 form
   L.a16h = DevBuf<uint16_t>();
   int64_t bad_state = -1;
@@ -1824,8 +1904,10 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
       g->f16_bad_state = bad_state;   // the caller may move that state to the other section and try again
       return;
     }
-  } else if (P > 0 && m.pg_arith != 2) {
+  } else if (P > 0 && m.pg_arith == 3) {
     // a three-term multi-pivot model: no fp16 rows
+  } else if (P == 0 && g->f16_whole_rejected) {
+    // the load-time probe rejected states of this model: the whole-model two-term rows stay away
   } else if (f16_env && (P > 0 ||   // (a multi-pivot model: the planner put only states that qualify here)
                          (g->kappa_matrix <= KAPPA_LIMIT_F16 &&
                           g->kappa2_matrix <= (m.dim < 8 ? KAPPA2_LIMIT_F16_LOWDIM : KAPPA2_LIMIT_F16)))) {
@@ -2475,11 +2557,12 @@ void gmm_set_transforms(aasr_gmm *g, int32_t n_transforms, const int32_t *gauss_
     return;
   }
   // In place: none / one transform for the whole pool, over rows packed without a bias, on the
-  // kernels that take the bias at their output (the track layouts; no outlier routing).  A
+  // kernels that take the bias at their output (the track layouts; the centred form through an extra pass; outlier
+  // routing adds it to the centred share when it merges).  A
   // speaker change then costs two small uploads instead of re-packing every row (70 ms at 50 k
   // Gaussians).
   if ((n_transforms == 0 || global) && g->rows_unbiased && !cur.any_full() && !g->class_routing &&
-      (g->paired.ok || g->tracks.ok) && !g->ill_conditioned && !g->hyb_enabled) {
+      (g->paired.ok || g->tracks.ok || (g->ill_conditioned && g->centred_ok))) {
     cur.n_transforms = n_transforms;
     cur.g2t.clear();
     cur.xform.clear();
@@ -2517,7 +2600,7 @@ void gmm_set_transforms(aasr_gmm *g, int32_t n_transforms, const int32_t *gauss_
     // coming from per-class transforms or from rows with a folded bias: build the unadapted rows
     // once, then take the in-place path if this model can (the usual case)
     gmm_build(g, m);
-    if (g->rows_unbiased && (g->paired.ok || g->tracks.ok) && !g->ill_conditioned && !g->hyb_enabled) {
+    if (g->rows_unbiased && (g->paired.ok || g->tracks.ok || (g->ill_conditioned && g->centred_ok))) {
       gmm_set_transforms(g, n_transforms, gauss_to_transform, W);
       return;
     }

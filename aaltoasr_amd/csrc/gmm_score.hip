@@ -30,6 +30,8 @@
 //
 // Roofline: FP32 matrix rate, 2*K flop per frame x row pair; see DESIGN.md.
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <unordered_map>
 
 #include <cmath>
 #include <cstdlib>
@@ -1674,7 +1676,7 @@ template <int NS>
 __global__ __launch_bounds__(256) void k_frame_operand(const float *__restrict__ frames, int64_t F, int dim,
                                                        const float *__restrict__ pivot, const float *__restrict__ f16tab,
                                                        int nk16, u32x4 *__restrict__ out, int64_t n_units, int n_pg,
-                                                       int64_t pg_stride) {
+                                                       int64_t pg_stride, int sc) {
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int lane = (int)(tid & 63);
   const int64_t unit = tid >> 6;   // (block of 64 frames, frame half, slab)
@@ -1692,10 +1694,12 @@ __global__ __launch_bounds__(256) void k_frame_operand(const float *__restrict__
   // dimensions d0 .. d0 + 3 (three and the constant in the first slab's first half).  Where they all exist the frame
   // components, pivots and clamps come as one 16-byte load each, the column scales as two (rows are 4-byte aligned; the
   // tables' loads are the same for every lane of a K half)
+  // Slab-constant layout (sc, TrackLayout::sc): slab j = its constant's two slots, then dimensions 7 j .. 7 j + 6 -- the
+  // first K half holds the constant and three dimensions, the second four.
   const int k0 = 16 * j + 8 * h;
-  const int d0 = (k0 >> 1) - 1;
+  const int d0 = sc ? 7 * j + (h ? 3 : -1) : (k0 >> 1) - 1;
   typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-  const bool whole = d0 >= 0 && d0 + 4 <= dim;   // uniform per K half
+  const bool whole = !sc && d0 >= 0 && d0 + 4 <= dim;   // uniform per K half
   float x[4];
   if (whole) {
     const f32x4u a = *(const f32x4u *)(xr + d0);
@@ -1734,7 +1738,8 @@ __global__ __launch_bounds__(256) void k_frame_operand(const float *__restrict__
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         const int k = k0 + i;
-        const int d = (k >> 1) - 1;
+        // (the constant's slots: the first two of the plain layout, the first two of every slab of the slab-constant one)
+        const int d = (sc ? (h == 0 && i < 2) : k < 2) ? -1 : d0 + (i >> 1);
         const int dc = d >= 0 && d < dim ? d : 0;
         const float xc = x[i >> 1] - pivot[dc];
         float xq = xc;
@@ -1781,7 +1786,7 @@ static const u32x4 *frame_operand(const aasr_gmm *g, const TrackLayout &L, const
   hipLaunchKernelGGL(k_frame_operand<NS>, dim3((unsigned)((n_units * 64 + 255) / 256)), dim3(256), 0, stream, d_frames, F,
                      g->dim, L.n_pg > 1 ? L.pg_pivot.p : g->d_pivot.p,
                      NS == 2 ? (L.n_pg > 1 ? L.pg_tab.p : L.f16tab.p) : nullptr, L.nk16, (u32x4 *)g->fop_scratch.p, n_units,
-                     n_pg, (int64_t)image);
+                     n_pg, (int64_t)image, (NS == 2 && L.sc) ? 1 : 0);
   AASR_HIP(hipGetLastError());
   *pg_stride = (int64_t)image;
   return (const u32x4 *)g->fop_scratch.p;
@@ -2013,6 +2018,43 @@ static const TrackLayout *split_layout(const aasr_gmm *g) {
   return nullptr;
 }
 
+// Verdicts of the probe, keyed by what it depends on (the model's arrays, pivots, the rows' eligibility, the round and the
+// tolerance): a rebuild of the same content -- a second handle on the same files, a transform that is taken off again, a
+// sub-model rebuilt for a speaker whose classes did not change -- takes the verdict instead of scoring the probe frames
+// again.  Process-wide, bounded (256 entries), under a mutex.
+namespace {
+struct ProbeCache {
+  std::mutex mu;
+  std::unordered_map<uint64_t, std::vector<int32_t>> verdicts;   // key -> states rejected in that round
+  int64_t runs = 0, hits = 0;
+};
+ProbeCache &probe_cache() {
+  static ProbeCache c;
+  return c;
+}
+inline uint64_t fnv1a(const void *p, size_t n, uint64_t h) {
+  const unsigned char *b = (const unsigned char *)p;
+  for (size_t i = 0; i < n; i++) {
+    h ^= b[i];
+    h *= 0x100000001b3ull;
+  }
+  return h;
+}
+template <typename T>
+inline uint64_t fnv_vec(const std::vector<T> &v, uint64_t h) {
+  const uint64_t n = v.size();
+  h = fnv1a(&n, sizeof n, h);
+  return v.empty() ? h : fnv1a(v.data(), v.size() * sizeof(T), h);
+}
+}  // namespace
+// Diagnostic (tests): device runs of the probe and verdicts taken from the cache since the library was loaded
+extern "C" void aasr_debug_probe_counts(int64_t *runs, int64_t *hits) {
+  ProbeCache &c = probe_cache();
+  std::lock_guard<std::mutex> lk(c.mu);
+  if (runs) *runs = c.runs;
+  if (hits) *hits = c.hits;
+}
+
 // ---------------------------------------------------------------------------
 // Load-time guard of the two-term fp16 form.  Which states get it is decided by conditioning limits that were set
 // from sweeps (gmm.h, KAPPA_LIMIT_F16): a bound in the statistical sense, not a proof.  So every model that got fp16
@@ -2082,6 +2124,42 @@ void gmm_probe_f16x2(aasr_gmm *g) {
         fr[(size_t)i * D + d] = (float)x;
       }
     }
+    // the verdict of this round, if the same content has been probed before
+    uint64_t key = 0xcbf29ce484222325ull;
+    {
+      const int64_t hdr[8] = {D, S, K, P, round, pg3 ? 1 : 0, LF == &g->mixed ? 1 : 0, m.pg_arith};
+      key = fnv1a(hdr, sizeof hdr, key);
+      const double tol_d = (double)probe_tol, bias_d = g->out_bias_ln, lwb = m.logw_bias;
+      key = fnv1a(&tol_d, sizeof tol_d, key);
+      key = fnv1a(&bias_d, sizeof bias_d, key);
+      key = fnv1a(&lwb, sizeof lwb, key);
+      key = fnv_vec(m.mean, key);
+      key = fnv_vec(m.var, key);
+      key = fnv_vec(m.mix_off, key);
+      key = fnv_vec(m.mix_idx, key);
+      key = fnv_vec(m.mix_w, key);
+      key = fnv_vec(m.pg_pivot, key);
+      key = fnv_vec(m.pg_begin, key);
+      key = fnv_vec(m.pg_real_end, key);
+      key = fnv_vec(g->pivot, key);
+      key = fnv_vec(g->f16_state_ok, key);
+      key = fnv_vec(g->outlier, key);
+    }
+    std::vector<uint8_t> bad((size_t)S, 0);
+    int64_t n_bad = 0;
+    bool cached = false;
+    {
+      ProbeCache &pc = probe_cache();
+      std::lock_guard<std::mutex> lk(pc.mu);
+      auto it = pc.verdicts.find(key);
+      if (it != pc.verdicts.end()) {
+        cached = true;
+        pc.hits++;
+        for (int32_t s2 : it->second)
+          if (s2 >= 0 && s2 < S && !bad[(size_t)s2]) { bad[(size_t)s2] = 1; n_bad++; }
+      }
+    }
+    if (!cached) {
     DevBuf<float> d_fr, d_a;
     d_fr.upload(fr.data(), fr.size());
     d_a.alloc((size_t)P * S);
@@ -2095,8 +2173,6 @@ void gmm_probe_f16x2(aasr_gmm *g) {
     if (!ok_a) return;
     std::vector<float> a((size_t)P * S);
     AASR_HIP(hipMemcpy(a.data(), d_a.p, a.size() * 4, hipMemcpyDeviceToHost));
-    std::vector<uint8_t> bad((size_t)S, 0);
-    int64_t n_bad = 0;
     std::vector<double> ph((size_t)D);
     for (int i = 0; i < P; i++) {
       const float *x = &fr[(size_t)i * D];
@@ -2123,12 +2199,24 @@ void gmm_probe_f16x2(aasr_gmm *g) {
         }
       }
     }
+    {
+      ProbeCache &pc = probe_cache();
+      std::lock_guard<std::mutex> lk(pc.mu);
+      pc.runs++;
+      if (pc.verdicts.size() >= 256) pc.verdicts.clear();
+      std::vector<int32_t> &v = pc.verdicts[key];
+      v.clear();
+      for (int64_t s2 = 0; s2 < S; s2++)
+        if (bad[(size_t)s2]) v.push_back((int32_t)s2);
+    }
+    }   // !cached
     if (n_bad == 0) return;
     g->f16_probe_moved += n_bad;
     for (int64_t s2 = 0; s2 < S; s2++)
       if (bad[(size_t)s2]) g->f16_state_ok[(size_t)s2] = 0;
     if (m.n_pg() > 0) return;   // a multi-pivot engine part: the planner takes the marked states out and builds it again
     // the whole-model fp16 rows are gone; what still qualifies goes to the mixed layout
+    g->f16_whole_rejected = true;   // (a layout built later -- aasr_debug_set_layouts -- must not pack them again)
     g->paired.a16h = DevBuf<uint16_t>();
     g->paired.states_f16 = 0;
     g->tracks.a16h = DevBuf<uint16_t>();
@@ -2619,24 +2707,50 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
     const int32_t *__restrict__ state_off, const int32_t *__restrict__ split_state,
     float *__restrict__ out, int64_t frame_stride, int64_t state_stride,
     const int32_t *__restrict__ crow, const unsigned long long *__restrict__ maskw, int c1, int64_t n_words,
-    float floor_val) {
+    float floor_val, int tile_out) {
   // [mu x DIMP][p' x DIMP][C, pad, pad, pad][mu_lo x DIMP]: the mean as a float pair, mu = mu_hi + mu_lo
   // to 2^-48 -- a mean rounded to one float costs p t ulp(mu)/2, 1e-4 at 14 sigma from a sigma = 0.01 Gaussian
   constexpr int REC = 3 * DIMP + 4;
+  // LDS: first the staging area of the prologue (256 frames x (dim | 1) floats), then -- tile_out -- the results of 32
+  // consecutive states for the workgroup's 512 frames ([512][33]), written out as whole 128-byte lines per frame row
+  extern __shared__ float cen_smem[];
   // each lane owns TWO frames (f, f + 256): one scalar fetch of a Gaussian's
   // parameters feeds 128 frame x Gaussian pairs per wave
-  const int64_t fa = (int64_t)blockIdx.x * 512 + threadIdx.x;
+  const int tid = threadIdx.x;
+  const int64_t f_base = (int64_t)blockIdx.x * 512;
+  const int64_t fa = f_base + tid;
   const int64_t fb = fa + 256;
-  const int64_t fac = fa < F ? fa : F - 1, fbc = fb < F ? fb : F - 1;
   // The two frames of a lane travel as one <2 x float>: t = x - mu, t*t, fma with p' are
   // v_pk_add / v_pk_mul / v_pk_fma_f32 (two frames per instruction, the scalar operand
   // broadcast) -- 1.5 VALU instructions per frame and dimension instead of 3, same roundings.
-
   f32x2 x2[DIMP];
+  // Prologue: the workgroup's frames are one contiguous run of the frame matrix; it is copied through LDS in two halves
+  // (coalesced loads; a lane then reads its own row, rows an odd number of floats apart: no bank conflicts).  Lanes
+  // beyond F take the last frame's values (never stored).
+  {
+    const int dimo = dim | 1;
 #pragma unroll
-  for (int d = 0; d < DIMP; d++) {
-    x2[d].x = d < dim ? frames[fac * dim + d] : 0.0f;
-    x2[d].y = d < dim ? frames[fbc * dim + d] : 0.0f;
+    for (int half = 0; half < 2; half++) {
+      const int64_t f0 = f_base + half * 256;
+      const int nfr = (int)max((int64_t)0, min((int64_t)256, F - f0));
+      const int n = nfr * dim;
+      const float *src = frames + f0 * dim;
+      __syncthreads();
+      for (int i = tid; i < n; i += 256) {
+        const int fr = i / dim;
+        cen_smem[fr * dimo + (i - fr * dim)] = src[i];
+      }
+      __syncthreads();
+      const int row = min(tid, max(nfr - 1, 0));
+      if (half == 0) {
+#pragma unroll
+        for (int d = 0; d < DIMP; d++) x2[d].x = (d < dim && nfr > 0) ? cen_smem[row * dimo + d] : 0.0f;
+      } else {
+#pragma unroll
+        for (int d = 0; d < DIMP; d++) x2[d].y = (d < dim && nfr > 0) ? cen_smem[row * dimo + d] : 0.0f;
+      }
+    }
+    __syncthreads();
   }
   const int s_begin = split_state[blockIdx.y], s_end = split_state[blockIdx.y + 1];
   // the 64-frame words of this wave's two frame groups (wave-uniform)
@@ -2683,8 +2797,29 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
     lla = fmaxf(lla, floor_val);
     llb = fmaxf(llb, floor_val);
     if (r1 <= r0) lla = llb = floor_val;
-    if (fa < F) out[fa * frame_stride + s * state_stride] = lla;
-    if (fb < F) out[fb * frame_stride + s * state_stride] = llb;
+    if (!tile_out) {
+      if (fa < F) out[fa * frame_stride + s * state_stride] = lla;
+      if (fb < F) out[fb * frame_stride + s * state_stride] = llb;
+      continue;
+    }
+    // frame-major output (state_stride == 1): a lane's values of 32 consecutive states are collected in LDS and leave as
+    // runs of 32 floats per frame row -- whole 128-byte lines where the caller's pitch is a multiple of 32 floats
+    const int col = (s - s_begin) & 31;
+    cen_smem[tid * 33 + col] = lla;
+    cen_smem[(tid + 256) * 33 + col] = llb;
+    if (col == 31 || s == s_end - 1) {
+      __syncthreads();
+      const int c = tid & 31;
+      const int64_t s0 = s - col;
+      if (c <= col) {
+#pragma unroll 4
+        for (int r = tid >> 5; r < 512; r += 8) {
+          const int64_t f = f_base + r;
+          if (f < F) out[f * frame_stride + s0 + c] = cen_smem[r * 33 + c];
+        }
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -2984,35 +3119,51 @@ struct CentredOps {
   int c1 = 0;
   int64_t n_words = 1;
   float floor_val = LOG_TINY_F;  // NEG_BIG_F: no floor (clustered passes, per-Gaussian view)
+  int64_t n_recs = 0;            // records of the operand set (the launcher's cost model; 0: unknown)
 };
 
 template <int DIMP>
 static void launch_centred_t(const aasr_gmm *g, const CentredOps &ops, const float *d_frames, int64_t F,
                              float *d_out, hipStream_t stream) {
   const int64_t blocks = (F + 511) / 512;
-  // state-range cuts so that the grid fills the chip evenly (4 workgroups per CU)
-  const double slots = 4.0 * (g->num_cus > 0 ? g->num_cus : 256);
+  // frame-major callers (state_stride == 1) get their values as runs of 32 states per frame row through LDS
+  const int tile_out = ops.state_stride == 1 ? 1 : 0;
+  const int smem = 4 * std::max(256 * (g->dim | 1), tile_out ? 512 * 33 : 0);
+  // State-range cuts: a workgroup keeps its 512 frames in registers and walks the records of its state range, so a cut
+  // costs every frame block its prologue again (frames through LDS, ~c records' time) -- R minimises
+  // rounds x (records / R + c) over the workgroups the chip holds at once (LDS: two per CU with the output tile).
+  const double slots = (smem > 40 * 1024 ? 2.0 : 4.0) * (g->num_cus > 0 ? g->num_cus : 256);
+  const double c_fixed = 6.0;
   int R = 1;
-  double best = 0;
+  double best = 1e300;
   for (int r = 1; r <= ops.max_splits; r++) {
-    double xw = (double)blocks * r / slots;
-    double eff = xw / std::ceil(xw);
-    if (xw < 1.0) eff = xw;  // under-filled chip: more cuts = more parallelism
-    if (eff > best + 0.005) {
-      best = eff;
+    const double rounds = std::ceil((double)blocks * r / slots);
+    const double cost = rounds * ((double)std::max<int64_t>(1, ops.n_recs) / r + c_fixed);
+    if (cost < best * 0.995) {
+      best = cost;
       R = r;
     }
   }
   const int32_t *split = ops.splits + (size_t)(R - 1) * (CENTRED_MAX_SPLITS + 1);
+  static bool attr_set[64][2] = {{false}};
+  if (!attr_set[g->device & 63][ops.maskw ? 1 : 0]) {
+    if (ops.maskw)
+      AASR_HIP(hipFuncSetAttribute((const void *)k_gmm_diag_score_centred<DIMP, true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 512 * 33));
+    else
+      AASR_HIP(hipFuncSetAttribute((const void *)k_gmm_diag_score_centred<DIMP, false>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 512 * 33));
+    attr_set[g->device & 63][ops.maskw ? 1 : 0] = true;
+  }
   if (ops.maskw)
-    hipLaunchKernelGGL((k_gmm_diag_score_centred<DIMP, true>), dim3((unsigned)blocks, (unsigned)R), dim3(256), 0,
+    hipLaunchKernelGGL((k_gmm_diag_score_centred<DIMP, true>), dim3((unsigned)blocks, (unsigned)R), dim3(256), smem,
                        stream, d_frames, F, g->dim, ops.recs, ops.state_off, split, d_out, ops.frame_stride,
-                       ops.state_stride, ops.crow, ops.maskw, ops.c1, ops.n_words, NEG_BIG_F);
+                       ops.state_stride, ops.crow, ops.maskw, ops.c1, ops.n_words, NEG_BIG_F, tile_out);
   else
-    hipLaunchKernelGGL((k_gmm_diag_score_centred<DIMP, false>), dim3((unsigned)blocks, (unsigned)R), dim3(256), 0,
+    hipLaunchKernelGGL((k_gmm_diag_score_centred<DIMP, false>), dim3((unsigned)blocks, (unsigned)R), dim3(256), smem,
                        stream, d_frames, F, g->dim, ops.recs, ops.state_off, split, d_out, ops.frame_stride,
                        ops.state_stride, (const int32_t *)nullptr, (const unsigned long long *)nullptr, 0, (int64_t)1,
-                       ops.floor_val);
+                       ops.floor_val, tile_out);
   AASR_HIP(hipGetLastError());
 }
 
@@ -3031,9 +3182,10 @@ static bool launch_centred_ops(const aasr_gmm *g, const CentredOps &ops, int dim
 }
 
 static bool launch_centred(const aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
-                           hipStream_t stream) {
-  const CentredOps ops{g->centred_recs.p, g->centred_state_off.p, g->centred_splits.p, g->centred_max_splits,
-                       g->S, 1};
+                           hipStream_t stream, int64_t pitch = 0) {
+  CentredOps ops{g->centred_recs.p, g->centred_state_off.p, g->centred_splits.p, g->centred_max_splits,
+                 pitch > 0 ? pitch : g->S, 1};
+  ops.n_recs = (int64_t)g->host.mix_idx.size();
   return launch_centred_ops(g, ops, g->centred_dimp, d_frames, F, d_out, stream);
 }
 
@@ -3046,7 +3198,7 @@ static bool launch_centred(const aasr_gmm *g, const float *d_frames, int64_t F, 
 __global__ __launch_bounds__(256) void k_outlier_merge(float *__restrict__ out, int64_t S,
                                                        const float *__restrict__ part, int64_t pitch,
                                                        int64_t Sb, const int32_t *__restrict__ map,
-                                                       int64_t F, int floors) {
+                                                       int64_t F, int floors, float part_bias) {
   __shared__ float tile[64][65];
   const int64_t f0 = (int64_t)blockIdx.x * 64;
   const int64_t j0 = (int64_t)blockIdx.y * 64;
@@ -3063,7 +3215,11 @@ __global__ __launch_bounds__(256) void k_outlier_merge(float *__restrict__ out, 
     const int64_t f = f0 + ff;
     if (f >= F) break;
     float *o = out + f * S + col;
-    const float a = *o, b = tile[lane][ff];
+    // part_bias: log|det| of an in-place global transform -- the matrix path carries it at its output, the centred
+    // records do not (a part AT the floor holds nothing and stays there)
+    float b = tile[lane][ff];
+    if (!floors || b > LOG_TINY_F) b += part_bias;
+    const float a = *o;
     const float hi = fmaxf(a, b), lo = fminf(a, b);
     float r = hi;
     if (floors) {
@@ -3080,7 +3236,8 @@ __global__ __launch_bounds__(256) void k_outlier_merge(float *__restrict__ out, 
 // form, merged into the scores the matrix path has already written.
 static void score_outliers(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, hipStream_t stream,
                            const int32_t *crow = nullptr, const unsigned long long *maskw = nullptr, int c1 = 0,
-                           int64_t n_words = 1) {
+                           int64_t n_words = 1, int64_t pitch = 0) {
+  if (pitch <= 0) pitch = g->S;
   const int64_t Sb = g->hyb_states;
   if (Sb <= 0) return;
   // passes of at most ~1 GB of partial scores
@@ -3088,6 +3245,7 @@ static void score_outliers(aasr_gmm *g, const float *d_frames, int64_t F, float 
   if (pass > F) pass = (F + 63) / 64 * 64;
   g->hyb_scratch.ensure((size_t)pass * (size_t)Sb);
   CentredOps ops{g->hyb_recs.p, g->hyb_state_off.p, g->hyb_splits.p, g->hyb_max_splits, 1, pass};
+  ops.n_recs = g->hyb_rows;
   ops.crow = crow;
   ops.c1 = c1;
   for (int64_t f0 = 0; f0 < F; f0 += pass) {  // pass is a multiple of 512 frames: whole mask words
@@ -3099,7 +3257,8 @@ static void score_outliers(aasr_gmm *g, const float *d_frames, int64_t F, float 
     if (!launch_centred_ops(g, ops, g->centred_dimp, d_frames + f0 * g->dim, n, g->hyb_scratch.p, stream))
       raise(AASR_ERR_UNSUPPORTED, "no centred kernel instance for dimension %d", g->dim);
     hipLaunchKernelGGL(k_outlier_merge, dim3((unsigned)((n + 63) / 64), (unsigned)((Sb + 63) / 64)), dim3(256), 0,
-                       stream, d_out + f0 * g->S, g->S, g->hyb_scratch.p, pass, Sb, g->hyb_map.p, n, maskw ? 0 : 1);
+                       stream, d_out + f0 * pitch, pitch, g->hyb_scratch.p, pass, Sb, g->hyb_map.p, n, maskw ? 0 : 1,
+                       (float)g->out_bias_ln);
     AASR_HIP(hipGetLastError());
   }
 }
@@ -3295,6 +3454,7 @@ void gmm_centred_masked_launch(aasr_gmm *g, const float *d_frames, int64_t F, fl
                                const unsigned long long *maskw, int c1, int64_t n_words, hipStream_t stream) {
   if (!g->centred_ok) raise(AASR_ERR_UNSUPPORTED, "no centred kernel instance for dimension %d", g->dim);
   CentredOps ops{g->centred_recs.p, g->centred_state_off.p, g->centred_splits.p, g->centred_max_splits, g->S, 1};
+  ops.n_recs = (int64_t)g->host.mix_idx.size();
   ops.crow = crow;
   ops.maskw = maskw;
   ops.c1 = c1;
@@ -3421,14 +3581,27 @@ void gmm_classes_exact_launch(aasr_gmm *g, const float *d_frames, int64_t n, flo
 
 // log|det| of an in-place global transform for the kernels that do not take it at their output
 // (diagnostic layouts only: the track kernels fold it into their reference exponent)
-__global__ void k_add_bias(float *__restrict__ out, float bias, int64_t n) {
+__global__ void k_add_bias(float *__restrict__ out, float bias, int64_t n, int64_t S, int64_t pitch) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = fmaxf(out[i] + bias, LOG_TINY_F);
+  if (i >= n) return;
+  const int64_t f = i / S;
+  float *o = out + f * pitch + (i - f * S);
+  *o = fmaxf(*o + bias, LOG_TINY_F);
 }
-static void add_output_bias(const aasr_gmm *g, float *d_out, int64_t F, hipStream_t stream) {
+__global__ void k_add_bias_nofloor(float *__restrict__ out, float bias, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] += bias;
+}
+// (clustered passes: exact parts carry no floor before the merge)
+void gmm_add_bias_nofloor(float *d_out, int64_t n, float bias, hipStream_t stream) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_add_bias_nofloor, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_out, bias, n);
+  AASR_HIP(hipGetLastError());
+}
+static void add_output_bias(const aasr_gmm *g, float *d_out, int64_t F, hipStream_t stream, int64_t pitch = 0) {
   const int64_t n = F * g->S;
   hipLaunchKernelGGL(k_add_bias, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_out,
-                     (float)g->out_bias_ln, n);
+                     (float)g->out_bias_ln, n, g->S, pitch > 0 ? pitch : g->S);
   AASR_HIP(hipGetLastError());
 }
 
@@ -3439,9 +3612,10 @@ bool gmm_score_pitch_ok(const aasr_gmm *g) {
   if (!g->dim_parts.empty()) return false;
   if (engine_parts_public(g)) return true;
   if (g->cl.enabled && gmm_engine_parts_clustered(g)) return true;
-  if (g->host.factor_path() || g->hyb_enabled || g->ill_conditioned || g->class_routing ||
-      g->precision == AASR_PREC_F64)
-    return false;
+  if (g->host.factor_path() || g->class_routing || g->precision == AASR_PREC_F64) return false;
+  if (g->hyb_enabled && g->cl.enabled) return false;   // (the clustered pass over outlier routing writes dense rows)
+  // a model scored in the centred form as a whole: the kernel writes runs of 32 states per frame row at any pitch
+  if (g->ill_conditioned) return g->centred_ok && !g->cl.enabled && (g->layout_mask & 4);
   if (g->cl.enabled && !gmm_cluster_pitch_ok(g)) return false;
   if ((g->layout_mask & 3) != 3) return false;
   const TrackLayout &L = g->paired.ok ? g->paired : g->tracks;
@@ -3475,21 +3649,16 @@ bool gmm_engine_parts_clustered(const aasr_gmm *g) {
          g->dim_parts.empty() && (g->layout_mask & 3) == 3;
 }
 
-// ... and whether public-layout calls (column = state) go through them too, with the columns gathered back: where the
-// model's own layouts have no two-term form at all -- or hold Gaussians on the matrix path whose conditioning around the
-// pool's ONE pivot lies in the upper part of the three-term form's range (kappa > 400 or kappa2 > 130: where
-// tools/fuzz_fitted.py found 1.0-1.45e-4 on frames far from the model, gmm.h).  The parts expand every state around a
-// pivot of its group and stay below 1e-4 there; the gather of the columns is what the public layout pays for it.
-static bool engine_parts_public(const aasr_gmm *g) {
-  if (!gmm_engine_parts_active(g)) return false;
-  const TrackLayout &L = g->paired.ok ? g->paired : g->tracks;
-  if (!(L.ok && L.a16h.p) && !g->mixed.ok) return true;
-  return g->kappa_matrix > 400.0 || g->kappa2_matrix > 130.0;
-}
+// ... and public-layout calls (column = state) go through them too, with the columns gathered back: the parts are planned
+// only for models whose own one-pivot layouts cannot put every state on two fp16 terms, and what those layouts do with the
+// rest -- three bf16 terms up to their limits, the centred form beyond -- is slower than the parts + a gather of the columns.
+static bool engine_parts_public(const aasr_gmm *g) { return gmm_engine_parts_active(g); }
 
 int64_t gmm_engine_pitch(const aasr_gmm *g) {
-  // (independent of the precision setting: a caller sizes its scratch once)
-  if (!g->engine_parts.empty()) return std::max(g->engine_cols, (g->S + 31) / 32 * 32);
+  // the parts' pitch only while the parts are what a scoring call runs: under another precision (verification modes on
+  // the model's own layouts) the model's own rule holds (the parts' pitch there sent outlier-routed and
+  // centred models into a pitched launch they do not have).  Scratch is sized with gmm_engine_pitch_max.
+  if (gmm_engine_parts_active(g) || gmm_engine_parts_clustered(g)) return std::max(g->engine_cols, (g->S + 31) / 32 * 32);
   if (!gmm_score_pitch_ok(g)) return g->S;
   const int64_t base = (g->S + 31) / 32 * 32;
   return g->routed_sub ? base + (g->routed_sub->S + 31) / 32 * 32 : base;
@@ -3586,7 +3755,7 @@ static void launch_engine_parts(aasr_gmm *g, const float *d_frames, int64_t F, f
     sub->out_bias_ln = g->out_bias_ln;
     float *o = d_out + part.col0;
     bool done = false;
-    if (part.arith == 2) done = launch_split<2>(sub, sub->paired, d_frames, F, o, stream, nullptr, pitch);
+    if (part.arith == 2 || part.arith == 4) done = launch_split<2>(sub, sub->paired, d_frames, F, o, stream, nullptr, pitch);
     else if (part.arith == 3) done = launch_split<3>(sub, sub->paired, d_frames, F, o, stream, nullptr, pitch);
     else {
       sub->precision = g->precision;
@@ -3668,12 +3837,20 @@ void gmm_score_launch_pitched(aasr_gmm *g, const float *d_frames, int64_t F, flo
     AASR_HIP(hipGetLastError());
     d_frames = g->d_xframes.p;
   }
+  if (g->ill_conditioned) {
+    if (!launch_centred(g, d_frames, F, d_out, stream, pitch))
+      raise(AASR_ERR_UNSUPPORTED, "no centred kernel instance for dimension %d", g->dim);
+    if (g->out_bias_ln != 0) add_output_bias(g, d_out, F, stream, pitch);
+    return;
+  }
   const TrackLayout &L = g->paired.ok ? g->paired : g->tracks;
   const TrackLayout *LM = split_layout(g);
   const bool done = (LM && launch_bf16(g, *LM, d_frames, F, d_out, stream, nullptr, pitch)) ||
                     (g->use_bf16x3 && launch_bf16(g, L, d_frames, F, d_out, stream, nullptr, pitch)) ||
                     launch_tracks(g, L, d_frames, F, d_out, stream, nullptr, pitch);
   if (!done) raise(AASR_ERR_UNSUPPORTED, "no track kernel instance for this model");
+  // the Gaussians the matrix layouts left out (null rows): centred form, merged per state into the padded rows
+  if (g->hyb_enabled) score_outliers(g, d_frames, F, d_out, stream, nullptr, nullptr, 0, 1, pitch);
 }
 
 // ---------------------------------------------------------------------------
@@ -3882,6 +4059,7 @@ void gmm_gauss_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
     // evaluated in the centred form (one-record states, no floor)
     gmm_build_pool_centred(g);
     CentredOps ops{g->poolc_recs.p, g->poolc_state_off.p, g->poolc_splits.p, g->poolc_max_splits, g->G, 1};
+    ops.n_recs = g->G;
     ops.floor_val = NEG_BIG_F;
     if (!launch_centred_ops(g, ops, g->centred_dimp, d_frames, F, d_out, stream))
       raise(AASR_ERR_UNSUPPORTED, "no centred kernel instance for dimension %d", g->dim);

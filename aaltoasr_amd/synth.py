@@ -42,11 +42,11 @@ def make_model(D=39, G=256, S=32, comps=8, seed=SEED, tied=False, var_lo=0.25, v
     return mean, var, off, idx, w
 
 
-def push_states_over_the_f16_limits(model, states, kappa2=120.0):
+def push_states_over_the_f16_limits(model, states, kappa2=100.0):
     """Per-state precision routing test models: in every state of `states` the first component's Gaussian is moved away
     from the pool's pivot (the mean of the means) until its conditioning estimate sqrt(sum_d (p (mu - pivot)^2)^2) is
-    `kappa2` -- above the two-term fp16 form's limit (80), below the matrix path's (200), with the sum itself below its
-    limits as well for the synthetic models' variances.  Returns a new model tuple (disjoint pools: only those states
+    `kappa2` -- above the plain two-term fp16 layout's limit (80), below the slab-constant layout's (160), with the sum
+    itself (~380-420 for the synthetic models' variances) between their limits too (250 / 500).  Returns a new model tuple (disjoint pools: only those states
     are affected)."""
     mean, var, off, idx, w = model
     mean = np.array(mean, np.float64)

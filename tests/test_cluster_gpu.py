@@ -231,7 +231,7 @@ def test_several_passes_of_equal_size_give_the_single_pass_result(capi, oracle, 
                 passes.append(L.aasr_debug_cluster_last_passes())
         finally:
             L.aasr_debug_cluster_pass_bytes(0.0)
-        assert passes[0] == 1 and passes[1] >= 4 and passes[2] == 2, (name, passes)
+        assert passes[0] == 1 and passes[1] >= 4 and 2 <= passes[2] < passes[1], (name, passes)
         for sc in outs[1:]:
             assert np.array_equal(sc, outs[0]), name
         gm.close()

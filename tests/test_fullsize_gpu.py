@@ -301,10 +301,8 @@ def test_fitted_model_one_hour(capi, oracle):
     standardised per dimension; the shape HmmSet::read_all loads in production, aku/HmmSet.cc:351-357): around the pool's
     one pivot most of its states break the two-term limits, the engine's pivot groups must keep >= 90 % of them on two
     fp16 terms, and the whole hour scored on the engine's own layout must match the oracle (aku/Distributions.cc:1040-1062,
-    2078-2086; aku/phone_probs.cc:224-262) on sampled frames.  Tolerances: 1e-4 on every value a 2-byte LNA file can hold
-    (within 36 of the frame's best state), 1.5e-4 on every other visible value -- tight Gaussians far below their peak
-    accumulate at |log2 value| > 100 in the matrix cores' f32 accumulators, DESIGN section 4.2 -- and LNA codes never
-    more than one step apart."""
+    2078-2086; aku/phone_probs.cc:224-262) on sampled frames.  Tolerance: 1e-4 on every visible value (every value whose
+    likelihood the reference's float storage holds), LNA codes never more than one step apart."""
     import torch
     from aaltoasr_amd import pipeline
     base = capi.Gmm.from_arrays(*synth.make_model(D=D, G=256, S=32, comps=8))
@@ -341,7 +339,7 @@ def test_fitted_model_one_hour(capi, oracle):
     window = vis & (ref > ref.max(1, keepdims=True) - 36.0)
     print("fitted model: max |dll| %.3g over %d visible values, %.3g inside the 2-byte LNA window (%d values)" % (
         err[vis].max(), vis.sum(), err[window].max(), window.sum()))
-    assert err[window].max() <= TOL_LL and err[vis].max() <= 1.5e-4
+    assert err[window].max() <= TOL_LL and err[vis].max() <= TOL_LL
     assert (err[vis] <= TOL_LL).mean() >= 0.9999
     lp_ref, by_ref = oracle.lna_encode(lik, True, 2)
     codes = _codes(d_by[pick.tolist()].cpu().numpy(), S)

@@ -5,10 +5,9 @@ the engine parts (scores and exact-evaluation counts), all against the oracle (a
 2684-2722; aku/phone_probs.cc:224-262).  `run(seed, n)` returns (worst error per category, failures);
 `python tools/fuzz_fitted.py SEED N` exits non-zero on a failure.
 
-Tolerances: 1e-4 on every value within 36 nats of the frame's best state (what a 2-byte LNA file can hold) and on every
-4-byte LNA value above -60 whose likelihood is a normal float; 1.5e-4 on the other visible values (ll > -103), of which at least 99.99 % must be within 1e-4
-(far tails of tight Gaussians: f32 accumulation of the expanded form); LNA codes never more than one step
-apart (states and frames whose likelihood is a normal float); clustered counts bit-equal."""
+Tolerances: 1e-4 on every visible value (ll > -103: every value the reference's float storage holds) of the public layout
+and of the clustered pass, and on every 4-byte LNA value whose likelihood is a normal float; LNA codes never more than one
+step apart (states and frames whose likelihood is a normal float); clustered counts bit-equal."""
 import os
 import sys
 
@@ -17,7 +16,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 VISIBLE = -103.0
-TOL, TOL_TAIL = 1e-4, 1.5e-4
+TOL = 1e-4
+TOL_TAIL = TOL   # (round 5 allowed 1.5e-4 off the LNA window: gone)
 
 
 def blobs(rng, F, D):
@@ -105,7 +105,7 @@ def run(seed=1, N=10, verbose=False):
                 lp = by.view("<f4").reshape(nf, S).astype(np.float64)
                 # (ll below ln 2^-126: the reference stores a DENORMAL float likelihood -- quantised, the band
                 # conftest.assert_lp_denormal_band pins to one quantum; not this sweep's subject)
-                m = (lp_ref > -60.0) & (ref > -87.0)
+                m = ref > -87.0
                 if m.any():
                     e4 = np.abs(lp - lp_ref)[m].max()
                     note("lna 4-byte", e4)
