@@ -1123,11 +1123,29 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
     parts.push_back(std::move(part));
     return true;
   };
+  // a plan's groups and pivots restricted to the states still in `pool` (the attempts after the first: a new plan means new
+  // rows, new probe frames and new marginal rejects, and the attempts would run out on a part that is fine)
+  auto restrict_plan = [&](const PgPlan &kept, const std::vector<int64_t> &pool) {
+    PgPlan plan;
+    std::vector<uint8_t> in_pool((size_t)m.S, 0);
+    for (int64_t s : pool) in_pool[(size_t)s] = 1;
+    for (size_t p = 0; p < kept.groups.size(); p++) {
+      std::vector<int64_t> gr;
+      for (int64_t s : kept.groups[p])
+        if (in_pool[(size_t)s]) gr.push_back(s);
+      if (gr.empty()) continue;
+      plan.groups.push_back(gr);
+      plan.pivots.insert(plan.pivots.end(), kept.pivots.begin() + (size_t)p * D, kept.pivots.begin() + (size_t)(p + 1) * D);
+    }
+    return plan;
+  };
   // part 0: two fp16 terms
   if (!force_sc) {
     std::vector<int64_t> pool = cand, out;
-    for (int attempt = 0; attempt < 8 && !pool.empty(); attempt++) {
-      PgPlan plan = pg_plan(m, pool, lim2, cost2, PG_MAX);
+    PgPlan kept0;
+    for (int attempt = 0; attempt < 12 && !pool.empty(); attempt++) {
+      PgPlan plan = attempt == 0 ? pg_plan(m, pool, lim2, cost2, PG_MAX) : restrict_plan(kept0, pool);
+      kept0 = plan;
       say("[two terms, attempt %d: %zu candidates -> %zu groups, %zu rejected] ", attempt, pool.size(), plan.groups.size(),
           plan.rejected.size());
       out.insert(out.end(), plan.rejected.begin(), plan.rejected.end());
@@ -1149,6 +1167,7 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
           if (!rej[(size_t)s]) pool.push_back(s);
       std::sort(pool.begin(), pool.end());
     }
+    out.insert(out.end(), pool.begin(), pool.end());   // (what twelve attempts did not settle takes the next part)
     std::sort(out.begin(), out.end());
     cand = out;
   }
@@ -1160,14 +1179,18 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
   // tools/exp_calib.py -- no more accurate at the same kappa: the error is the accumulators', not the operands'.)
   if (!cand.empty() && 7 * 8 >= D) {
     std::vector<int64_t> pool = cand, out;
-    for (int attempt = 0; attempt < 8 && !pool.empty(); attempt++) {
+    PgPlan kept;
+    for (int attempt = 0; attempt < 12 && !pool.empty(); attempt++) {
       PgPlan plan;
       if (force_sc) {
         plan.groups.push_back(pool);
         pg_centre(m, pool, plan.pivots);
-      } else {
+      } else if (attempt == 0) {
         plan = pg_plan(m, pool, lim3, cost3, PG_MAX);
+      } else {
+        plan = restrict_plan(kept, pool);
       }
+      kept = plan;
       say("[slab constants, attempt %d: %zu candidates -> %zu groups, %zu rejected] ", attempt, pool.size(), plan.groups.size(),
           plan.rejected.size());
       out.insert(out.end(), plan.rejected.begin(), plan.rejected.end());
@@ -1185,7 +1208,7 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
         for (int64_t s : gr) (rej[(size_t)s] ? out : pool).push_back(s);
       std::sort(pool.begin(), pool.end());
     }
-    out.insert(out.end(), pool.begin(), pool.end());   // (what eight attempts did not settle)
+    out.insert(out.end(), pool.begin(), pool.end());   // (what twelve attempts did not settle)
     std::sort(out.begin(), out.end());
     cand = out;
   }
@@ -1963,10 +1986,13 @@ static void build_centred_tables(const HostModel &m, int dimp, const std::vector
                                  DevBuf<int32_t> &d_off, DevBuf<int32_t> &d_splits, int *max_splits,
                                  bool pool = false) {
   const int D = m.dim;
-  const int rec = 3 * dimp + 4;  // [mu_hi][p'][C, pad x 3][mu_lo], k_gmm_diag_score_centred
+  // k_gmm_diag_score_centred streams a record as groups of 16 floats, one scalar load each: group q =
+  // [mu_hi x 4][mu_lo x 4][p' x 4][C (group 0), pad x 3] of dimensions 4 q .. 4 q + 3; one spare record behind the last
+  // (the kernel fetches one group ahead)
+  const int rec = 4 * dimp;
   const size_t rows = comps.size();
   const int64_t n_states = (int64_t)off.size() - 1;
-  std::vector<float> recs(std::max<size_t>(1, rows) * rec, 0.0f);
+  std::vector<float> recs((rows + 1) * rec, 0.0f);
   for (size_t r = 0; r < rows; r++) {
     const size_t k = (size_t)comps[r];
     const int64_t gi = pool ? (int64_t)k : (int64_t)m.mix_idx[k];
@@ -1976,15 +2002,16 @@ static void build_centred_tables(const HostModel &m, int dimp, const std::vector
       double p = v > 0 ? 1 / v : 0;
       prod *= p;
       const double mu = m.mean[(size_t)gi * D + d];
-      recs[r * rec + d] = (float)mu;
-      recs[r * rec + 2 * dimp + 4 + d] = (float)(mu - (double)(float)mu);
-      recs[r * rec + dimp + d] = (float)(-0.5 * p * kLog2e);
+      float *gq = &recs[r * rec + (size_t)(d / 4) * 16];
+      gq[d % 4] = (float)mu;
+      gq[4 + d % 4] = (float)(mu - (double)(float)mu);
+      gq[8 + d % 4] = (float)(-0.5 * p * kLog2e);
     }
     double cst = (prod > 0) ? std::log(std::sqrt(prod)) : prod;
     double c = cst + (pool ? 0.0 : m.logw(k));
     if (std::isnan(c) || c == INFINITY)
       raise(AASR_ERR_INVALID, "Gaussian %ld has a non-finite constant (precision product overflow)", (long)gi);
-    recs[r * rec + 2 * dimp] = std::isfinite(c) ? (float)(c * kLog2e) : kNullConst;
+    recs[r * rec + 12] = std::isfinite(c) ? (float)(c * kLog2e) : kNullConst;
   }
   d_recs.upload(recs.data(), recs.size());
   d_off.upload(off.data(), off.size());

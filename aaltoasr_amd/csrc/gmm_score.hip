@@ -705,6 +705,53 @@ __device__ __forceinline__ void split2_pair(float x0, float x1, unsigned &p1, un
   p2 = __builtin_bit_cast(unsigned, (f16x2){l0, l1});
 }
 
+// ---------------------------------------------------------------------------
+// Frame operand of the two-term kernels, one unit: the 8 K-slot values of (frame row xr, slab j, K half h) around `pivot`
+// -- (x - pivot), the dimension's clamp and the column's power-of-two scale, the square for the quadratic slots, 1 in the
+// constant's slots -- the arithmetic of k_frame_operand (below), shared with the multi-pivot instances of
+// k_gmm_diag_score_pl, which form their group's operand in their prologue (round 6: one image per pivot group through
+// HBM was 320 B per frame and group, 0.46 ms of a fitted model's 11.1).  f16tab: [2 KH] column scales, [KH] clamps.
+// ---------------------------------------------------------------------------
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void fop_unit_f16(const float *__restrict__ xr, int dim, const float *__restrict__ pivot,
+                                             const float *__restrict__ f16tab, int KH, int j, int h, int sc,
+                                             unsigned w1[4], unsigned w2[4]) {
+  const int k0 = 16 * j + 8 * h;
+  const int d0 = sc ? 7 * j + (h ? 3 : -1) : (k0 >> 1) - 1;
+  const bool whole = !sc && d0 >= 0 && d0 + 4 <= dim;   // uniform per K half
+  float v[8];
+  if (whole) {
+    const f32x4u a = *(const f32x4u *)(xr + d0);
+    const f32x4u b = *(const f32x4u *)(pivot + d0);
+    const f32x4u c = *(const f32x4u *)(f16tab + 2 * KH + d0);
+    const f32x4u e0 = *(const f32x4u *)(f16tab + k0);
+    const f32x4u e1 = *(const f32x4u *)(f16tab + k0 + 4);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float xc = a[i] - b[i];
+      const float xq = fminf(fmaxf(xc, -c[i]), c[i]);   // fp16 range: the dimension's clamp (pack_f16x2)
+      v[2 * i] = xq * (i < 2 ? e0[2 * i] : e1[2 * i - 4]);
+      v[2 * i + 1] = (xq * xq) * (i < 2 ? e0[2 * i + 1] : e1[2 * i - 3]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int k = k0 + i;
+      const int d = (sc ? (h == 0 && i < 2) : k < 2) ? -1 : d0 + (i >> 1);
+      const int dc = d >= 0 && d < dim ? d : 0;
+      const float xc = xr[dc] - pivot[dc];
+      const float lim = f16tab[2 * KH + dc];
+      const float xq = fminf(fmaxf(xc, -lim), lim);
+      float val = (k & 1) ? xq * xq : xq;
+      if (d < 0) val = 1.0f;   // the constant and its remainder
+      else if (d >= dim) val = 0.0f;
+      v[i] = val * f16tab[k];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) split2_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i]);
+}
+
 template <int NK16, bool GROUPED, bool WIDE = false, int NS = 3>
 struct Bf16Smem {
   static constexpr int kTileBytes = NK16 * NS * 2 * 64 * 16;
@@ -1075,6 +1122,11 @@ struct CutPlan {
 struct PivotGroups {
   const int32_t *colend = nullptr;   // [groups] one past the group's last output column
   int64_t fop_stride = 0;            // u32x4 elements between the groups' frame-operand images
+  // PGF instances (the workgroup forms its group's operand in its prologue): the groups' pivots [groups][dim], their
+  // column scales and clamps [groups][3 KH], the slab-constant flag of the layout
+  const float *pivots = nullptr;
+  const float *tabs = nullptr;
+  int sc = 0;
 };
 
 template <int NK16, bool GROUPED, bool WIDE, int NS>
@@ -1144,7 +1196,7 @@ __device__ unsigned long long g_pl_trace[8][12];
 #ifndef AASR_PL_PRIO_LO
 #define AASR_PL_PRIO_LO 1
 #endif
-template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS, bool MAPPED = false>
+template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS, bool MAPPED = false, bool PGF = false>
 __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_score_pl(
     const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
     const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
@@ -1294,10 +1346,11 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   // pivot groups (multi-pivot layouts, gmm.h TrackLayout::n_pg): a row cut lies inside ONE group -- its rows are expanded
   // around that group's pivot, so the workgroup takes that group's image of the frame operand, and the group's columns end
   // at its own limit (its last line goes out partly filled, the next group starts on a whole line)
+  int pgi = 0;
   if (pg.colend) {
-    const int gi = split_row[4 * cut + 3];
-    fop += (size_t)gi * pg.fop_stride;
-    S = pg.colend[gi];
+    pgi = split_row[4 * cut + 3];
+    if (!PGF) fop += (size_t)pgi * pg.fop_stride;
+    S = pg.colend[pgi];
   }
 
   // ---- frame operand: lane (n, h) holds k = 16*j + 8*h + i, i < 8, of slab j -- split into its terms ONCE per launch by
@@ -1305,7 +1358,26 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   // Built in place (one 4-byte load per K slot at a lane-dependent address, ~2 000 instructions) it cost every workgroup
   // ~20 us -- six tiles' time in front of every row cut, paid R times per frame.
   u32x4 bq[NK16][NS][2];
-  {
+  if constexpr (PGF && NS == 2) {
+    // multi-pivot layouts: the group's image is formed here, around the group's pivot (fop_unit_f16 = k_frame_operand's
+    // arithmetic: the same bits), instead of being fetched -- one image per group and launch through HBM cost more than
+    // the ~800 instructions a row cut pays for it
+    const float *pv = pg.pivots + (size_t)pgi * dim;
+    const float *tab = pg.tabs + (size_t)pgi * (3 * 8 * NK16);
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++) {
+      int64_t f = f0 + nb * 32 + n;
+      if (f > F - 1) f = F - 1;
+      const float *xr = frames + f * dim;
+#pragma unroll
+      for (int j = 0; j < NK16; j++) {
+        unsigned w1[4], w2[4];
+        fop_unit_f16(xr, dim, pv, tab, 8 * NK16, j, h, pg.sc, w1, w2);
+        bq[j][0][nb] = u32x4{w1[0], w1[1], w1[2], w1[3]};
+        bq[j][1][nb] = u32x4{w2[0], w2[1], w2[2], w2[3]};
+      }
+    }
+  } else {
     const u32x4 *bw = fop + ((size_t)blk * NW + wave) * (NK16 * NS * 2 * 64) + lane;
 #pragma unroll
     for (int j = 0; j < NK16; j++)
@@ -1762,9 +1834,10 @@ __global__ __launch_bounds__(256) void k_frame_operand(const float *__restrict__
       o[2 * 64] = u32x4{w2[0], w2[1], w2[2], w2[3]};
       o[4 * 64] = u32x4{w3[0], w3[1], w3[2], w3[3]};
     } else {
+      // (the unit's arithmetic lives in fop_unit_f16, shared with the kernels that form their operand themselves; `v`
+      // above is the three-term form's)
       unsigned w1[4], w2[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) split2_pair(v[2 * i], v[2 * i + 1], w1[i], w2[i]);
+      fop_unit_f16(xr, dim, pivot, f16tab, KH, j, h, sc, w1, w2);
       o[0] = u32x4{w1[0], w1[1], w1[2], w1[3]};
       o[2 * 64] = u32x4{w2[0], w2[1], w2[2], w2[3]};
     }
@@ -1917,9 +1990,30 @@ static void launch_pl_t(const aasr_gmm *g, const TrackLayout &L, const TrackSect
                                      sec ? sec->max_splits : L.max_splits, 3.0, splits_base, multi ? L.n_pg : 1, cap);
   const int32_t *split_row = splits_base + (size_t)(plan.r_main - 1) * (cap + 1) * 4;
   PivotGroups pg;
+  const unsigned n_items = (unsigned)(plan.n_main + (plan.r_rem ? plan.blocks_rem * plan.r_rem : 0));
+  if constexpr (GROUPED && NS == 2 && !MAPPED) {
+    // multi-pivot layouts: the workgroups form their group's frame operand themselves (no k_frame_operand launch)
+    static const int pgf_env = AASR_EXPERIMENT_ENV("AASR_PGF") ? atoi(AASR_EXPERIMENT_ENV("AASR_PGF")) : 1;   // EXPERIMENT: 0 = images through HBM
+    if (multi && pgf_env && L.pg_tab.p) {
+      auto kern_pgf = k_gmm_diag_score_pl<NK16, GROUPED, CL, WIDE, NS, false, true>;
+      static bool attr_set_pgf[64] = {false};
+      if (!attr_set_pgf[g->device & 63]) {
+        AASR_HIP(hipFuncSetAttribute((const void *)kern_pgf, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set_pgf[g->device & 63] = true;
+      }
+      pg.colend = L.pg_colend.p;
+      pg.pivots = L.pg_pivot.p;
+      pg.tabs = L.pg_tab.p;
+      pg.sc = L.sc ? 1 : 0;
+      hipLaunchKernelGGL(kern_pgf, dim3(n_items), dim3(NW * 64), smem, stream, d_frames, F,
+                         g->dim, g->d_pivot.p, L.a16h.p, split_row, L.close.p, L.sid.p, L.sid_stride,
+                         d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, dbg, cl, (const u32x4 *)nullptr, plan, pg);
+      AASR_HIP(hipGetLastError());
+      return;
+    }
+  }
   const u32x4 *fop = frame_operand<NS>(g, L, d_frames, F, blocks * NW, stream, &pg.fop_stride);
   if (multi) pg.colend = L.pg_colend.p;
-  const unsigned n_items = (unsigned)(plan.n_main + (plan.r_rem ? plan.blocks_rem * plan.r_rem : 0));
   hipLaunchKernelGGL(kern, dim3(n_items), dim3(NW * 64), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, NS == 3 ? L.a16.p : L.a16h.p, split_row, L.close.p,
                      MAPPED ? L.pmap.p : L.sid.p, MAPPED ? 0 : L.sid_stride,
@@ -2113,6 +2207,9 @@ void gmm_probe_f16x2(aasr_gmm *g) {
       static const double amps[4] = {0.5, 1.0, 1.5, 2.5};
       const double amp = i < P * 2 / 3 ? amps[i & 3] : 1.0;
       const int far_d = i < P * 2 / 3 ? -1 : (int)(uni() * D) % D;
+      // every other far frame is far along SEVERAL dimensions at once (round 6: where tools/fuzz_fitted.py found the
+      // round-5 limits wanting): ~ a sixth of the dimensions at +-3.5 .. 5 sigma, 8-12 sigma in all at 39 dimensions
+      const bool multi = far_d >= 0 && ((i >> 1) & 1);
       for (int d = 0; d < D; d++) {
         const double v = m.var[(size_t)gi * D + d];
         const double sd = v > 0 ? std::sqrt(v) : 0.0;
@@ -2121,6 +2218,7 @@ void gmm_probe_f16x2(aasr_gmm *g) {
         for (int u = 0; u < 12; u++) z += uni();
         double x = m.mean[(size_t)gi * D + d] + amp * sd * z;
         if (d == far_d) x = m.mean[(size_t)gi * D + d] + ((i & 1) ? 6.0 : -6.0) * sd;
+        else if (multi && uni() < 1.0 / 6.0) x = m.mean[(size_t)gi * D + d] + (uni() < 0.5 ? -1.0 : 1.0) * (3.5 + 1.5 * uni()) * sd;
         fr[(size_t)i * D + d] = (float)x;
       }
     }
@@ -2193,7 +2291,8 @@ void gmm_probe_f16x2(aasr_gmm *g) {
         const double ref = std::log(std::max(sum, 1e-50)) + g->out_bias_ln;
         // (three-term part: 3/4 of the contract -- its operands carry 24 bits, what the probe sees there is the f32
         // accumulators' granularity at |log2 value| ~ 100, 5-7e-5 on the probe's 6-sigma frames, not conditioning)
-        if (ref > -103.0 && !(std::fabs((double)a[(size_t)i * S + s2] - ref) <= (double)probe_tol * (pg3 ? 1.5 : 1.0))) {
+        // (slab-constant part: admitted by limits calibrated off the data up to 7.5e-5, tools/exp_calib.py)
+        if (ref > -103.0 && !(std::fabs((double)a[(size_t)i * S + s2] - ref) <= (double)probe_tol * ((pg3 || m.pg_sc()) ? 1.5 : 1.0))) {
           bad[(size_t)s2] = 1;
           n_bad++;
         }
@@ -2708,11 +2807,17 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
     float *__restrict__ out, int64_t frame_stride, int64_t state_stride,
     const int32_t *__restrict__ crow, const unsigned long long *__restrict__ maskw, int c1, int64_t n_words,
     float floor_val, int tile_out) {
-  // [mu x DIMP][p' x DIMP][C, pad, pad, pad][mu_lo x DIMP]: the mean as a float pair, mu = mu_hi + mu_lo
-  // to 2^-48 -- a mean rounded to one float costs p t ulp(mu)/2, 1e-4 at 14 sigma from a sigma = 0.01 Gaussian
-  constexpr int REC = 3 * DIMP + 4;
-  // LDS: first the staging area of the prologue (256 frames x (dim | 1) floats), then -- tile_out -- the results of 32
-  // consecutive states for the workgroup's 512 frames ([512][33]), written out as whole 128-byte lines per frame row
+  // A record = DIMP / 4 groups of 16 floats, group q = [mu x 4][mu_lo x 4][p' x 4][C, pad x 3] of dimensions 4 q .. 4 q + 3
+  // (the constant in group 0): the mean as a float pair, mu = mu_hi + mu_lo to 2^-48 -- a mean rounded to one float
+  // costs p t ulp(mu)/2, 1e-4 at 14 sigma from a sigma = 0.01 Gaussian.  A group is ONE scalar load of 64 bytes and the
+  // groups of consecutive records follow each other in memory, so the kernel walks one stream and fetches a group ahead
+  // of the one it computes on (round 6: with [mu][p'][C][mu_lo] a dimension needed three loads from three places, none
+  // could be issued early within the scalar registers, and the waves stood at s_waitcnt: 36 % of the vector rate).
+  constexpr int NG = DIMP / 4;
+  constexpr int REC = 16 * NG;
+  typedef float f32x16u __attribute__((ext_vector_type(16), aligned(64)));
+  // LDS: first the staging area of the prologue (128 frames x (dim | 1) floats), then -- tile_out -- the results of 16
+  // consecutive states for the workgroup's 512 frames ([512][17]), written out as runs of 16 floats per frame row
   extern __shared__ float cen_smem[];
   // each lane owns TWO frames (f, f + 256): one scalar fetch of a Gaussian's
   // parameters feeds 128 frame x Gaussian pairs per wave
@@ -2724,15 +2829,15 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
   // v_pk_add / v_pk_mul / v_pk_fma_f32 (two frames per instruction, the scalar operand
   // broadcast) -- 1.5 VALU instructions per frame and dimension instead of 3, same roundings.
   f32x2 x2[DIMP];
-  // Prologue: the workgroup's frames are one contiguous run of the frame matrix; it is copied through LDS in two halves
+  // Prologue: the workgroup's frames are one contiguous run of the frame matrix; it is copied through LDS in four quarters
   // (coalesced loads; a lane then reads its own row, rows an odd number of floats apart: no bank conflicts).  Lanes
-  // beyond F take the last frame's values (never stored).
+  // beyond F take zeros (never stored).
   {
     const int dimo = dim | 1;
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-      const int64_t f0 = f_base + half * 256;
-      const int nfr = (int)max((int64_t)0, min((int64_t)256, F - f0));
+    for (int qt = 0; qt < 4; qt++) {
+      const int64_t f0 = f_base + qt * 128;
+      const int nfr = (int)max((int64_t)0, min((int64_t)128, F - f0));
       const int n = nfr * dim;
       const float *src = frames + f0 * dim;
       __syncthreads();
@@ -2741,13 +2846,16 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
         cen_smem[fr * dimo + (i - fr * dim)] = src[i];
       }
       __syncthreads();
-      const int row = min(tid, max(nfr - 1, 0));
-      if (half == 0) {
+      const int row = (tid & 127) < nfr ? (tid & 127) : 0;
+      const bool mine = (tid >> 7) == (qt & 1);   // frames f_base + tid (quarters 0, 1) and f_base + 256 + tid (2, 3)
+      if (mine) {
+        if (qt < 2) {
 #pragma unroll
-        for (int d = 0; d < DIMP; d++) x2[d].x = (d < dim && nfr > 0) ? cen_smem[row * dimo + d] : 0.0f;
-      } else {
+          for (int d = 0; d < DIMP; d++) x2[d].x = (d < dim && nfr > 0) ? cen_smem[row * dimo + d] : 0.0f;
+        } else {
 #pragma unroll
-        for (int d = 0; d < DIMP; d++) x2[d].y = (d < dim && nfr > 0) ? cen_smem[row * dimo + d] : 0.0f;
+          for (int d = 0; d < DIMP; d++) x2[d].y = (d < dim && nfr > 0) ? cen_smem[row * dimo + d] : 0.0f;
+        }
       }
     }
     __syncthreads();
@@ -2757,11 +2865,13 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
   const int64_t word_a = min((int64_t)blockIdx.x * 8 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), n_words - 1);
   const int64_t word_b = min(word_a + 4, n_words - 1);
   const int lane_bit = threadIdx.x & 63;
+  // the stream of groups: from the first record of the state range on, one group ahead
+  const f32x16u *gp = (const f32x16u *)(recs + (size_t)state_off[s_begin] * REC);
+  f32x16u cur = *gp;
   for (int s = s_begin; s < s_end; s++) {
     const int r0 = state_off[s], r1 = state_off[s + 1];
     float ma = NEG_BIG_F, sa = 0.0f, mb = NEG_BIG_F, sb = 0.0f;
     for (int r = r0; r < r1; r++) {
-      const float *rec = recs + (size_t)r * REC;
       bool on_a = true, on_b = true;
       if (CL) {
         const int c = crow[r];
@@ -2769,18 +2879,25 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
         on_b = (maskw[word_b * c1 + c] >> lane_bit) & 1ull;
       }
       f32x2 acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};  // two chains per frame
+      float c = 0.0f;
 #pragma unroll
-      for (int d = 0; d < DIMP; d += 2) {
-        const float mu0 = rec[d], mu1 = rec[d + 1];
-        const float ml0 = rec[2 * DIMP + 4 + d], ml1 = rec[2 * DIMP + 4 + d + 1];
-        const float p0 = rec[DIMP + d], p1 = rec[DIMP + d + 1];
-        const f32x2 t0 = (x2[d] - (f32x2){mu0, mu0}) - (f32x2){ml0, ml0};
-        const f32x2 t1 = (x2[d + 1] - (f32x2){mu1, mu1}) - (f32x2){ml1, ml1};
-        acc0 = __builtin_elementwise_fma(t0 * t0, (f32x2){p0, p0}, acc0);
-        acc1 = __builtin_elementwise_fma(t1 * t1, (f32x2){p1, p1}, acc1);
+      for (int q = 0; q < NG; q++) {
+        gp++;
+        const f32x16u nxt = *gp;   // (the spare record behind the last one keeps this inside the buffer)
+        if (q == 0) c = cur[12];
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+          const float mu0 = cur[j], mu1 = cur[j + 1];
+          const float ml0 = cur[4 + j], ml1 = cur[4 + j + 1];
+          const float p0 = cur[8 + j], p1 = cur[8 + j + 1];
+          const f32x2 t0 = (x2[4 * q + j] - (f32x2){mu0, mu0}) - (f32x2){ml0, ml0};
+          const f32x2 t1 = (x2[4 * q + j + 1] - (f32x2){mu1, mu1}) - (f32x2){ml1, ml1};
+          acc0 = __builtin_elementwise_fma(t0 * t0, (f32x2){p0, p0}, acc0);
+          acc1 = __builtin_elementwise_fma(t1 * t1, (f32x2){p1, p1}, acc1);
+        }
+        cur = nxt;
       }
       const float a0 = acc0.x, b0 = acc0.y, a1 = acc1.x, b1 = acc1.y;
-      const float c = rec[2 * DIMP];
       float la = c + (a0 + a1), lb = c + (b0 + b1);  // log2 units
       if (CL) {
         la = on_a ? la : NEG_BIG_F;
@@ -2802,20 +2919,20 @@ __global__ __launch_bounds__(256) void k_gmm_diag_score_centred(
       if (fb < F) out[fb * frame_stride + s * state_stride] = llb;
       continue;
     }
-    // frame-major output (state_stride == 1): a lane's values of 32 consecutive states are collected in LDS and leave as
-    // runs of 32 floats per frame row -- whole 128-byte lines where the caller's pitch is a multiple of 32 floats
-    const int col = (s - s_begin) & 31;
-    cen_smem[tid * 33 + col] = lla;
-    cen_smem[(tid + 256) * 33 + col] = llb;
-    if (col == 31 || s == s_end - 1) {
+    // frame-major output (state_stride == 1): a lane's values of 16 consecutive states are collected in LDS and leave as
+    // runs of 16 floats per frame row -- whole 64-byte half lines where the caller's pitch is a multiple of 16 floats
+    const int col = (s - s_begin) & 15;
+    cen_smem[tid * 17 + col] = lla;
+    cen_smem[(tid + 256) * 17 + col] = llb;
+    if (col == 15 || s == s_end - 1) {
       __syncthreads();
-      const int c = tid & 31;
+      const int c = tid & 15;
       const int64_t s0 = s - col;
       if (c <= col) {
 #pragma unroll 4
-        for (int r = tid >> 5; r < 512; r += 8) {
+        for (int r = tid >> 4; r < 512; r += 16) {
           const int64_t f = f_base + r;
-          if (f < F) out[f * frame_stride + s0 + c] = cen_smem[r * 33 + c];
+          if (f < F) out[f * frame_stride + s0 + c] = cen_smem[r * 17 + c];
         }
       }
       __syncthreads();
@@ -3128,11 +3245,11 @@ static void launch_centred_t(const aasr_gmm *g, const CentredOps &ops, const flo
   const int64_t blocks = (F + 511) / 512;
   // frame-major callers (state_stride == 1) get their values as runs of 32 states per frame row through LDS
   const int tile_out = ops.state_stride == 1 ? 1 : 0;
-  const int smem = 4 * std::max(256 * (g->dim | 1), tile_out ? 512 * 33 : 0);
+  const int smem = 4 * std::max(128 * (g->dim | 1), tile_out ? 512 * 17 : 0);
   // State-range cuts: a workgroup keeps its 512 frames in registers and walks the records of its state range, so a cut
   // costs every frame block its prologue again (frames through LDS, ~c records' time) -- R minimises
   // rounds x (records / R + c) over the workgroups the chip holds at once (LDS: two per CU with the output tile).
-  const double slots = (smem > 40 * 1024 ? 2.0 : 4.0) * (g->num_cus > 0 ? g->num_cus : 256);
+  const double slots = 4.0 * (g->num_cus > 0 ? g->num_cus : 256);
   const double c_fixed = 6.0;
   int R = 1;
   double best = 1e300;
@@ -3149,10 +3266,10 @@ static void launch_centred_t(const aasr_gmm *g, const CentredOps &ops, const flo
   if (!attr_set[g->device & 63][ops.maskw ? 1 : 0]) {
     if (ops.maskw)
       AASR_HIP(hipFuncSetAttribute((const void *)k_gmm_diag_score_centred<DIMP, true>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 512 * 33));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 512 * 17));
     else
       AASR_HIP(hipFuncSetAttribute((const void *)k_gmm_diag_score_centred<DIMP, false>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 512 * 33));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 512 * 17));
     attr_set[g->device & 63][ops.maskw ? 1 : 0] = true;
   }
   if (ops.maskw)

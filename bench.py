@@ -778,8 +778,8 @@ def _time_engine_path(torch, runner, gmm, reps=5):
 def _measure_precisions(torch, capi, synth, gmm, runner, model, restore_precision, with_models=True):
     """The scoring stage of configs[2] in every arithmetic form the engine has (the any-model numbers next to the
     headline's), and per-state precision routing: the same model with 1 / 10 / 40 % of its states holding one Gaussian
-    over the two-term form's conditioning limits -- those states run three bf16 terms, the rest keeps two fp16 terms
-    (a model with more than 45 % of such states keeps one arithmetic: routing would cost as much)."""
+    over the plain two-term layout's conditioning limits (kappa 250 / kappa2 80) -- those states become an engine part of
+    their own in the slab-constant K layout (two fp16 terms, 6 slabs instead of 5), the rest keeps the plain layout."""
     import numpy as np
     out = {}
     ladder = {}
@@ -814,11 +814,12 @@ def _measure_precisions(torch, capi, synth, gmm, runner, model, restore_precisio
                         "engine_path_scoring_ratio": round((ladder["f16x2"] + ms_engine - base_engine) / ladder["f16x2"], 4),
                         "scoring_ms_whole_model_bf16x3": round(ms3, 4)})
     out["precision_routing"] = {"what": "per-state precision routing (aasr_gmm_precision_states): the configs[2] model with one Gaussian "
-                                        "of a share of its states moved over the two-term form's conditioning limits; before round 4 "
-                                        "ONE such Gaussian sent the whole model to the three-term kernel.  scoring_ms: the public score "
-                                        "layout (columns = states: the routed states' values are stored one by one over the others' "
-                                        "lines); engine_path_*: frames -> LNA codes on the engine's own layout (the routed states "
-                                        "scored as a model of their own into spare columns, the LNA pass reads through a column map), "
+                                        "of a share of its states moved over the plain two-term layout's conditioning limits (to kappa2 = 100, "
+                                        "kappa ~ 400); before round 4 ONE such Gaussian sent the whole model to the three-term kernel, "
+                                        "rounds 4-5 scored those states with three bf16 terms, round 6 with two fp16 terms in the "
+                                        "slab-constant K layout (an engine part of their own).  scoring_ms: the public score "
+                                        "layout (columns = states: the parts' columns gathered back); engine_path_*: frames -> LNA codes on "
+                                        "the engine's own layout (every part scores into its own column range, the LNA pass reads through a column map), "
                                         "what phone_probs / aasr_run_recipe run -- its ratio prices the scoring stage as all-f16x2 ms "
                                         "+ the extra ms of the whole path.  all-f16x2 engine path: %.4f ms" % base_engine,
                                 "models": routing}
@@ -949,10 +950,51 @@ def _stage_rooflines(runner, split):
         if not ms:
             continue
         gbs = F * bpf / (ms * 1e-3) / 1e9
-        out.append({"stage": name, "kernels": kernels, "bound": "hbm", "algorithmic_bytes_per_frame": bpf,
-                    "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(gbs / HBM_PEAK_GBS, 4), "stage_ms": ms})
+        e = {"stage": name, "kernels": kernels, "bound": "hbm", "algorithmic_bytes_per_frame": bpf,
+             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(gbs / HBM_PEAK_GBS, 4), "stage_ms": ms}
+        if name == "features":
+            v = _spectral_valu_roofline(F, ms)
+            if v:
+                e["valu_issue"] = v
+        out.append(e)
     return out
+
+
+def _spectral_valu_roofline(frames, stage_ms):
+    """The ruler that fits k_spectral_fused (two thirds of the feature stage): it is bound by vector-instruction ISSUE, not by
+    HBM -- the reference's arithmetic prescribes ~430 vector instructions per frame (float butterflies in KissFFT's order,
+    serial float mel / power chains, double module buffers), a SIMD issues one vector instruction per 4 cycles, f32 or f64.
+    Instruction count: the committed counter pass (profiles/*spectral_pmc*.txt, SQ_INSTS_VALU per launch of 449 280
+    frames), scaled to this run's frames; the kernel's share of the stage: the committed kernel trace of the same tree
+    (profiles/*full_chain*kernel_stats.csv); clock: nominal (the feature kernels do not reach the power cap)."""
+    import csv
+    import glob
+    import re
+    pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*spectral_pmc*.txt")))
+    ks = sorted(glob.glob(os.path.join(ROOT, "profiles", "*full_chain*kernel_stats.csv")))
+    if not pm or not ks:
+        return None
+    m = re.search(r"SQ_INSTS_VALU\s+([0-9.e+]+)", open(pm[-1]).read())
+    if not m:
+        return None
+    insts = float(m.group(1)) * frames / 449280.0
+    t = {}
+    for r in csv.DictReader(open(ks[-1])):
+        for k in ("k_spectral_fused", "k_temporal_fused", "k_mean_subtract"):
+            if k in r["Name"]:
+                t[k] = float(r["AverageNs"]) * 1e-6
+    if "k_spectral_fused" not in t or len(t) < 2:
+        return None
+    share = t["k_spectral_fused"] / sum(t.values())
+    kernel_ms = stage_ms * share
+    simds = 256 * 4
+    slots_per_s = simds * NOMINAL_SCLK_MHZ * 1e6 / 4.0
+    bound_ms = insts / slots_per_s * 1e3
+    return {"kernel": "k_spectral_fused", "bound": "valu_issue", "vector_instructions_per_frame": round(insts / frames, 1),
+            "issue_slots_per_s": slots_per_s, "bound_ms": round(bound_ms, 4), "kernel_ms": round(kernel_ms, 4),
+            "kernel_share_of_stage": round(share, 3), "frac": round(bound_ms / kernel_ms, 4),
+            "source": {"instructions": os.path.basename(pm[-1]), "kernel_share": os.path.basename(ks[-1])}}
 
 
 def _measure_configs1(torch, synth, gmm, rank, dev, stream, sync_all, max_over_ranks, world, args, steps=5):
