@@ -895,7 +895,7 @@ def _measure_fitted_models(torch, capi, synth, pipeline, gmm, runner, dev, preci
             eng = {"error": "%s: %s" % (type(e).__name__, e)}
         entry = {"audio": kind, "states": S, "gaussians": G,
                  "one_pivot_conditioning": {"kappa_max": round(float(k1.max()), 1), "kappa2_max": round(float(k2.max()), 1),
-                                            "states_within_the_f16x2_limits": int(((k1.reshape(S, COMPS).max(1) <= 330.0) &
+                                            "states_within_the_f16x2_limits": int(((k1.reshape(S, COMPS).max(1) <= 250.0) &
                                                                                    (k2.reshape(S, COMPS).max(1) <= 80.0)).sum())},
                  "states_f16x2": n16, "share_f16x2": round(n16 / S, 4), "states_moved_by_the_probe": moved,
                  "engine_parts": parts, "engine_path_ms": round(ms, 4), "ratio_to_baseline_model": round(ms / base_ms, 4),

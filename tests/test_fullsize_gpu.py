@@ -315,7 +315,7 @@ def test_fitted_model_one_hour(capi, oracle):
     runner.release()
     model = synth.fit_model(X, S=S, comps=COMPS)
     k1, k2 = synth.conditioning(model[0], model[1])
-    one_pivot = ((k1.reshape(S, COMPS).max(1) <= 330.0) & (k2.reshape(S, COMPS).max(1) <= 80.0)).mean()
+    one_pivot = ((k1.reshape(S, COMPS).max(1) <= 250.0) & (k2.reshape(S, COMPS).max(1) <= 80.0)).mean()
     g = capi.Gmm.from_arrays(*model)
     parts = g.engine_parts()
     n16, moved = g.precision_states()

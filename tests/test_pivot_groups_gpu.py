@@ -73,7 +73,7 @@ def test_column_map_is_a_permutation_into_whole_lines(capi, fitted, monkeypatch)
         assert grp.size == 1
         gi = idx[off[s]:off[s + 1]]
         kk, kk2 = synth.conditioning(mean[gi], var[gi], piv[grp[0]].astype(np.float64))
-        assert kk.max() <= 330.0 * 1.0001 and kk2.max() <= 80.0 * 1.0001
+        assert kk.max() <= 250.0 * 1.0001 and kk2.max() <= 80.0 * 1.0001
     assert g.score_scratch_floats(100) >= 100 * parts["cols"]
     g.close()
 
