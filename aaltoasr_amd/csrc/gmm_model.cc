@@ -1988,7 +1988,7 @@ static void build_centred_tables(const HostModel &m, int dimp, const std::vector
   const int D = m.dim;
   // k_gmm_diag_score_centred streams a record as groups of 16 floats, one scalar load each: group q =
   // [mu_hi x 4][mu_lo x 4][p' x 4][C (group 0), pad x 3] of dimensions 4 q .. 4 q + 3; one spare record behind the last
-  // (the kernel fetches one group ahead)
+  // (the kernel fetches up to four groups ahead)
   const int rec = 4 * dimp;
   const size_t rows = comps.size();
   const int64_t n_states = (int64_t)off.size() - 1;
