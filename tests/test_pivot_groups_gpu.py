@@ -280,3 +280,48 @@ def test_a_second_clustering_with_the_same_cluster_count_reaches_the_parts(capi,
         vis = want > VISIBLE
         assert np.abs(got - want)[vis].max() <= TOL, (seed, np.abs(got - want)[vis].max())
     g.close()
+
+
+def test_probe_verdicts_are_cached_and_a_rejected_state_stays_rejected():
+    """Round-5 review item 8.  (a) The load-time probe's verdict is cached per model content: building the same model a second
+    time takes the verdicts instead of scoring the probe frames again (aasr_debug_probe_counts).  (b) With the test hook's
+    tolerance the probe takes the whole-model two-term rows away; a layout built LATER (aasr_debug_set_layouts builds the
+    independent tracks on demand) must not pack them again: under that layout the default precision then runs the
+    three-term rows, bit for bit what AASR_PREC_BF16X3 gives.  (A process of its own: the library reads the hook once.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, ctypes, numpy as np
+sys.path.insert(0, %r)
+from aaltoasr_amd import capi, synth
+capi.check(capi.lib().aasr_set_device(0))
+L = capi.lib()
+L.aasr_debug_probe_counts.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+L.aasr_debug_probe_counts.restype = None
+def counts():
+    r, h = ctypes.c_int64(0), ctypes.c_int64(0)
+    L.aasr_debug_probe_counts(ctypes.byref(r), ctypes.byref(h))
+    return r.value, h.value
+model = synth.make_model(D=39, G=64 * 8, S=64, comps=8, seed=77)
+r0, h0 = counts()
+g = capi.Gmm.from_arrays(*model)
+r1, h1 = counts()
+g2 = capi.Gmm.from_arrays(*model)
+r2, h2 = counts()
+n16, moved = g.precision_states()
+fr = synth.make_frames(200, seed=78)
+g.set_layouts(2)
+g.set_precision(4)
+s4 = g.score(fr)
+g.set_precision(3)
+s3 = g.score(fr)
+print("RESULT", r1 - r0, h1 - h0, r2 - r1, h2 - h1, moved, int(np.array_equal(s4, s3)), g.active_layout())
+""" % root
+    env = dict(os.environ, AASR_F16_PROBE_TOL="1.0e-6")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    runs1, hits1, runs2, hits2, moved, same, layout = [int(x) for x in r.stdout.split("RESULT")[1].split()]
+    assert runs1 > 0 and runs2 == 0 and hits2 > 0, r.stdout      # the second build ran no probe on the device
+    assert moved > 0 and layout == 2 and same == 1, r.stdout       # the late layout did not re-admit the rejected rows
