@@ -1065,8 +1065,13 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
   // AASR_PG_PIVOT_COST (test hook): the rows one more pivot has to rescue, instead of the cost model's figure
   // (read at every build, not latched: a test sets it for one model)
   const double pivot_cost_env = getenv("AASR_PG_PIVOT_COST") ? atof(getenv("AASR_PG_PIVOT_COST")) : -1.0;
-  const double cost2 = pivot_cost_env >= 0 ? pivot_cost_env : 400.0 / 0.65;
-  const double cost3 = pivot_cost_env >= 0 ? pivot_cost_env : 400.0 / 4.0;
+  // (round 6: the second part is the slab-constant layout at 1.2 rows' cost, not three terms at 2: a pivot of the first part
+  // has to rescue more rows to pay -- measured on the two fitted models of bench.py, engine path ms at 200 / 400 / 615 / 900 /
+  // 1 300 / 2 000 rows per pivot: 10.92 / 10.83 / 10.76 / 10.74 / 10.62-10.71 / 10.76-10.80 and 11.25 / 11.02 / 10.90 / 10.87 /
+  // 10.79-10.84 / 10.95: a flat minimum around 1 000)
+  const double cost2 = pivot_cost_env >= 0 ? pivot_cost_env : 1000.0;
+  const double pivot_cost3_env = getenv("AASR_PG_PIVOT_COST3") ? atof(getenv("AASR_PG_PIVOT_COST3")) : pivot_cost_env;   // (the second part's alone)
+  const double cost3 = pivot_cost3_env >= 0 ? pivot_cost3_env : 400.0 / 4.0;
   static const double lim_scale = AASR_EXPERIMENT_ENV("AASR_PG_LIMIT_SCALE") ? atof(AASR_EXPERIMENT_ENV("AASR_PG_LIMIT_SCALE")) : 1.0;   // EXPERIMENT
   const PgLimits lim2{lim_scale * KAPPA_LIMIT_F16, lim_scale * (D < 8 ? KAPPA2_LIMIT_F16_LOWDIM : KAPPA2_LIMIT_F16)};
   // three terms around a group's pivot: the one-pivot form's limits (AASR_PG3_LIMIT_SCALE 1.0).  The round first admitted
