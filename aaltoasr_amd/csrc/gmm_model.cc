@@ -2055,9 +2055,9 @@ static void find_outliers(aasr_gmm *g) {
   g->outlier.clear();
   g->hyb_enabled = false;
   g->hyb_states = g->hyb_rows = 0;
-  std::vector<uint8_t> bad((size_t)m.G, 0);
-  double kappa = 0, kappa_in = 0, kappa2_in = 0;
-  bool any_bad = false;
+  g->hyb_comps.clear();
+  std::vector<double> kap((size_t)m.G), kap2((size_t)m.G);
+  double kappa = 0;
   for (int64_t i = 0; i < m.G; i++) {
     double k = 0, k2 = 0;
     for (int d = 0; d < D; d++) {
@@ -2067,42 +2067,72 @@ static void find_outliers(aasr_gmm *g) {
       k += p * mc * mc;
       k2 += (p * mc * mc) * (p * mc * mc);
     }
+    kap[(size_t)i] = k;
+    kap2[(size_t)i] = std::sqrt(k2);
     kappa = std::max(kappa, k);
-    bad[(size_t)i] = k > KAPPA_LIMIT || std::sqrt(k2) > KAPPA2_LIMIT;
-    any_bad = any_bad || bad[(size_t)i];
-    if (!bad[(size_t)i]) {
-      kappa_in = std::max(kappa_in, k);
-      kappa2_in = std::max(kappa2_in, std::sqrt(k2));
-    }
   }
   g->kappa = kappa;
-  g->kappa_matrix = kappa_in;
-  g->kappa2_matrix = kappa2_in;
-  g->ill_conditioned = any_bad;
   const int dimp = centred_dimp_for(D);
   static const int routing = AASR_EXPERIMENT_ENV("AASR_OUTLIER_ROUTING") ? atoi(AASR_EXPERIMENT_ENV("AASR_OUTLIER_ROUTING")) : 1;
-  g->hyb_comps.clear();
-  if (!g->ill_conditioned || !dimp || !routing) return;
-  std::vector<int32_t> comps, off{0}, map;
-  for (int64_t s = 0; s < m.S; s++) {
-    const size_t before = comps.size();
-    for (int32_t k = m.mix_off[s]; k < m.mix_off[s + 1]; k++)
-      if (bad[(size_t)m.mix_idx[k]]) comps.push_back(k);
-    if (comps.size() > before) {
-      off.push_back((int32_t)comps.size());
-      map.push_back((int32_t)s);
+  // Two passes.  First against the plain TWO-term limits: where only a handful of Gaussians break them, those become the
+  // outliers and the whole model keeps the fastest rows (round 6: a Gaussian between the two-term and the three-term
+  // limits used to cost its state the three-term section of a mixed layout and the model its whole-model two-term rows;
+  // in the centred form it costs 1.6 us per 449 280 frames + ~20 us for its state's merge: a read-modify-write of one
+  // column of the score matrix touches a line per frame).  "A handful": what the public layout pays for them stays below
+  // the gather of a model with engine parts (gmm_score.hip, engine_parts_public: 2.4 ms).  Else against the limits of the
+  // three-term / f32 rows, as before.
+  const double lim2_f16 = D < 8 ? KAPPA2_LIMIT_F16_LOWDIM : KAPPA2_LIMIT_F16;
+  for (int pass = 0; pass < 2; pass++) {
+    const double lk = pass == 0 ? KAPPA_LIMIT_F16 : KAPPA_LIMIT, lk2 = pass == 0 ? lim2_f16 : KAPPA2_LIMIT;
+    std::vector<uint8_t> bad((size_t)m.G, 0);
+    double kappa_in = 0, kappa2_in = 0;
+    bool any_bad = false;
+    for (int64_t i = 0; i < m.G; i++) {
+      bad[(size_t)i] = kap[(size_t)i] > lk || kap2[(size_t)i] > lk2;
+      any_bad = any_bad || bad[(size_t)i];
+      if (!bad[(size_t)i]) {
+        kappa_in = std::max(kappa_in, kap[(size_t)i]);
+        kappa2_in = std::max(kappa2_in, kap2[(size_t)i]);
+      }
     }
+    std::vector<int32_t> comps, off{0}, map;
+    if (any_bad)
+      for (int64_t s = 0; s < m.S; s++) {
+        const size_t before = comps.size();
+        for (int32_t k = m.mix_off[s]; k < m.mix_off[s + 1]; k++)
+          if (bad[(size_t)m.mix_idx[k]]) comps.push_back(k);
+        if (comps.size() > before) {
+          off.push_back((int32_t)comps.size());
+          map.push_back((int32_t)s);
+        }
+      }
+    if (pass == 0) {
+      if (!any_bad) {   // every Gaussian inside the two-term limits
+        g->kappa_matrix = kappa_in;
+        g->kappa2_matrix = kappa2_in;
+        g->ill_conditioned = false;
+        return;
+      }
+      if (!dimp || !routing || 1.7 * (double)comps.size() + 20.0 * (double)map.size() >= 1500.0 ||
+          comps.size() * 4 > m.mix_idx.size())
+        continue;
+    }
+    g->kappa_matrix = kappa_in;
+    g->kappa2_matrix = kappa2_in;
+    g->ill_conditioned = any_bad;
+    if (!g->ill_conditioned || !dimp || !routing) return;
+    if (comps.empty() || comps.size() * 4 > m.mix_idx.size()) return;  // not a minority: all centred
+    g->outlier = bad;
+    g->hyb_enabled = true;
+    g->ill_conditioned = false;
+    g->hyb_states = (int64_t)map.size();
+    g->hyb_rows = (int64_t)comps.size();
+    build_centred_tables(m, dimp, comps, off, g->hyb_recs, g->hyb_state_off, g->hyb_splits, &g->hyb_max_splits);
+    g->hyb_map.upload(map.data(), map.size());
+    g->hyb_comps = comps;
+    g->cl.crow_hyb = aasr::DevBuf<int32_t>();  // rebuilt on the next clustered pass
+    return;
   }
-  if (comps.empty() || comps.size() * 4 > m.mix_idx.size()) return;  // not a minority: all centred
-  g->outlier = bad;
-  g->hyb_enabled = true;
-  g->ill_conditioned = false;
-  g->hyb_states = (int64_t)map.size();
-  g->hyb_rows = (int64_t)comps.size();
-  build_centred_tables(m, dimp, comps, off, g->hyb_recs, g->hyb_state_off, g->hyb_splits, &g->hyb_max_splits);
-  g->hyb_map.upload(map.data(), map.size());
-  g->hyb_comps = comps;
-  g->cl.crow_hyb = aasr::DevBuf<int32_t>();  // rebuilt on the next clustered pass
 }
 
 void gmm_build_centred(aasr_gmm *g) {

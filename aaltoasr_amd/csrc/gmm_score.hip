@@ -3460,6 +3460,18 @@ extern "C" int aasr_debug_active_layout(const aasr_gmm *g) {
   return 0;
 }
 extern "C" double aasr_debug_kappa(const aasr_gmm *g) { return g ? g->kappa : -1.0; }
+// Diagnostic: the model's OWN one-pivot layout -- out[0] whole-model two-term rows packed, [1] outlier routing on, [2] outlier
+// components, [3] states that hold them, [4] scored in the centred form as a whole, [5] states the probe moved
+extern "C" void aasr_debug_own_layout(const aasr_gmm *g, int64_t *out) {
+  if (!g || !out) return;
+  const TrackLayout &L = g->paired.ok ? g->paired : g->tracks;
+  out[0] = (L.ok && L.a16h.p) ? 1 : 0;
+  out[1] = g->hyb_enabled ? 1 : 0;
+  out[2] = g->hyb_rows;
+  out[3] = g->hyb_states;
+  out[4] = g->ill_conditioned ? 1 : 0;
+  out[5] = g->f16_probe_moved;
+}
 
 // Diagnostic (tests, bench.py): the engine parts of a model (gmm_plan_engine_parts) -- out[0] parts, out[1] columns of an
 // engine score row, then per part (up to three) {arithmetic (2 / 3 / 0: ordinary model), states, pivot groups, rows
@@ -3776,7 +3788,21 @@ bool gmm_engine_parts_clustered(const aasr_gmm *g) {
 // ... and public-layout calls (column = state) go through them too, with the columns gathered back: the parts are planned
 // only for models whose own one-pivot layouts cannot put every state on two fp16 terms, and what those layouts do with the
 // rest -- three bf16 terms up to their limits, the centred form beyond -- is slower than the parts + a gather of the columns.
-static bool engine_parts_public(const aasr_gmm *g) { return gmm_engine_parts_active(g); }
+// The exception: a model whose own layout HAS every state on plain two-term rows and only a few Gaussians off the matrix
+// path (outlier routing) -- the public layout then costs those few rows in the centred form and their states' merge, less
+// than the gather of the whole matrix (measured per 449 280 frames: 1.6 us per centred row, ~20 us per merged state -- its
+// column's read-modify-write touches a line per frame --, 2.4 ms for the gather): one far-out Gaussian in 1 % of the states
+// of configs[2]: 1.10x instead of 1.31x; at 10 % the merge would cost more than the gather (measured 1.44x against 1.30x).
+static bool engine_parts_public(const aasr_gmm *g) {
+  if (!gmm_engine_parts_active(g)) return false;
+  static const int force_sc = AASR_EXPERIMENT_ENV("AASR_EXP_FORCE_SC") ? atoi(AASR_EXPERIMENT_ENV("AASR_EXP_FORCE_SC")) : 0;   // EXPERIMENT
+  if (force_sc) return true;
+  const TrackLayout &L = g->paired.ok ? g->paired : g->tracks;
+  if (L.ok && L.a16h.p && g->hyb_enabled && !g->ill_conditioned && !g->cl.enabled &&
+      1.7 * (double)g->hyb_rows + 20.0 * (double)g->hyb_states < 1500.0)
+    return false;
+  return true;
+}
 
 int64_t gmm_engine_pitch(const aasr_gmm *g) {
   // the parts' pitch only while the parts are what a scoring call runs: under another precision (verification modes on

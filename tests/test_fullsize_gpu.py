@@ -299,8 +299,8 @@ def test_config1_one_million_frames(capi, oracle):
 def test_fitted_model_one_hour(capi, oracle):
     """A model FITTED to the engine's own features (synth.fit_model on one hour of the source-filter imitation of speech,
     standardised per dimension; the shape HmmSet::read_all loads in production, aku/HmmSet.cc:351-357): around the pool's
-    one pivot most of its states break the two-term limits, the engine's pivot groups must keep >= 90 % of them on two
-    fp16 terms, and the whole hour scored on the engine's own layout must match the oracle (aku/Distributions.cc:1040-1062,
+    one pivot most of its states break the two-term limits, the engine's pivot groups must keep >= 85 % of them on plain
+    two-term rows and >= 99 % on the matrix cores, and the whole hour scored on the engine's own layout must match the oracle (aku/Distributions.cc:1040-1062,
     2078-2086; aku/phone_probs.cc:224-262) on sampled frames.  Tolerance: 1e-4 on every visible value (every value whose
     likelihood the reference's float storage holds), LNA codes never more than one step apart."""
     import torch
@@ -321,7 +321,9 @@ def test_fitted_model_one_hour(capi, oracle):
     n16, moved = g.precision_states()
     print("fitted model: %.1f %% of the states within the two-term limits around one pivot; engine parts %s, %d states on "
           "two fp16 terms (%d moved by the probe)" % (100 * one_pivot, parts, n16, moved))
-    assert one_pivot < 0.7 and parts is not None and n16 >= 0.9 * S and g.effective_precision() == 4
+    # (n16: the plain two-term rows; the slab-constant part -- two fp16 terms as well, 1.2 rows' cost -- takes most of the rest)
+    matrix = sum(p["states"] for p in parts["parts"] if p["arith"] in (2, 4)) if parts else 0
+    assert one_pivot < 0.7 and parts is not None and n16 >= 0.85 * S and matrix >= 0.99 * S and g.effective_precision() == 4
     F = X.shape[0]
     d_f = torch.from_numpy(X).cuda()
     d_scr = torch.empty(g.score_scratch_floats(F), dtype=torch.float32, device="cuda")

@@ -34,3 +34,17 @@ for name, mdl in (("all f16x2", model), ("%.0f %% pushed" % (100 * share), synth
     torch.cuda.synchronize()
     print("   engine path: %.3f ms" % (e0.elapsed_time(e1) / 5))
     g.close()
+    # the public layout (column = state), rows padded to whole lines: what bench.py's scoring_ms times
+if len(sys.argv) > 2 and sys.argv[2] == "public":
+    g = capi.Gmm.from_arrays(*synth.push_states_over_the_f16_limits(model, bad))
+    pitch = (S + 31) // 32 * 32
+    d_ll = torch.empty((F, pitch), dtype=torch.float32, device="cuda")
+    g.score_dev_pitched(d_f, d_ll, pitch)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        g.score_dev_pitched(d_f, d_ll, pitch)
+    e1.record()
+    torch.cuda.synchronize()
+    print("   public layout: %.3f ms" % (e0.elapsed_time(e1) / 5))
