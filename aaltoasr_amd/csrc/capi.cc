@@ -255,8 +255,6 @@ int aasr_gmm_effective_precision(const aasr_gmm *h) {
   if (h->ill_conditioned) return AASR_PREC_F32_CENTRED;
   const aasr::TrackLayout &L = h->paired.ok ? h->paired : h->tracks;
   if (!L.ok || !L.a16.p) return AASR_PREC_F32;
-  // a mixed layout scores part of the states with two fp16 terms: aasr_gmm_precision_states says how many
-  if (h->precision == AASR_PREC_F16X2 && h->mixed.ok && (h->layout_mask & 3) == 3) return AASR_PREC_F16X2;
   return (h->precision == AASR_PREC_F16X2 && L.a16h.p) ? AASR_PREC_F16X2 : AASR_PREC_BF16X3;
 }
 
@@ -275,7 +273,7 @@ aasr_status aasr_gmm_precision_states(const aasr_gmm *h, int64_t *states_f16x2, 
       }
     } else if (aasr_gmm_effective_precision(h) == AASR_PREC_F16X2 && !h->host.factor_path()) {
       const aasr::TrackLayout &L = h->paired.ok ? h->paired : h->tracks;
-      n = (h->mixed.ok && (h->layout_mask & 3) == 3) ? h->mixed.states_f16 : L.states_f16;
+      n = L.states_f16;
     }
     if (states_f16x2) *states_f16x2 = n;
     if (states_probe_moved) *states_probe_moved = h->f16_probe_moved;

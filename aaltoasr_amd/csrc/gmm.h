@@ -184,29 +184,10 @@ struct PackedRows {
   DevBuf<double> a64;
 };
 
-// A run of whole tiles of a mixed layout with its own row-cut table (per-state precision routing, gmm_build_mixed()).
-struct TrackSection {
-  int64_t tile_begin = 0, tile_end = 0;
-  int64_t states = 0;
-  bool grouped = false;      // state pairs side by side on the two tracks (else: every state on one track, direct stores)
-  bool mapped = false;       // grouped over a subset of the states: output columns come from TrackLayout::pmap
-  DevBuf<int32_t> splits;    // [MAX_SPLITS][MAX_SPLITS+1][4], absolute tile indices
-  int max_splits = 1;
-};
-
 // Two-track row layout for the in-register epilogue (see gmm_build_tracks()).
 struct TrackLayout {
   bool ok = false;
   bool grouped = false;
-  // mixed layouts: section 0 = the states scored with two fp16 terms (a16h covers its tiles; grouped where the model's
-  // grouped layout exists: its pairs' output columns and flush points come from `pmap`, [tile][2 tracks][8 quad
-  // positions], k_gmm_diag_score_pl<..., MAPPED>), section 1 = the others on independent tracks (three bf16 terms, a16
-  // covers all tiles; `sid` lists its states)
-  int n_sections = 0;
-  TrackSection sec[2];
-  bool mapped = false;
-  DevBuf<int32_t> pmap;
-  int32_t pmap_stride = 0;
   int64_t states_f16 = 0;    // states the two-term fp16 rows cover (0: no a16h)
   PackedRows rows;
   // the same rows split into three bf16 terms for k_gmm_diag_score_bf16x3:
@@ -303,8 +284,8 @@ struct ClusterState {
   DevBuf<double> bpack;            // ... packed as f64 MFMA operands: [tile of 16][k step][64 lanes]
   int mfma_ks = 0;                 // k steps of 4 covering 2 dim + 1
   DevBuf<int32_t> csize;           // [Cs] members per cluster (0 beyond C)
-  DevBuf<int32_t> crow[3];         // cluster of each packed row of the grouped / independent / mixed
-                                   // track layout (C = no cluster or null row)
+  DevBuf<int32_t> crow[2];         // cluster of each packed row of the grouped / independent track layout
+                                   // (C = no cluster or null row)
   DevBuf<int32_t> crow_full;       // ... of the factor rows of a full-covariance pool
   DevBuf<int32_t> crow_hyb, crow_centred;  // the same for the records of the centred kernel: the
                                    // outlier components (outlier routing) / every component
@@ -351,16 +332,9 @@ struct aasr_gmm {
   // track layouts for the in-register epilogue (built when eligible)
   aasr::TrackLayout paired;   // grouped: states 2j/2j+1 side by side
   aasr::TrackLayout tracks;   // independent tracks (built when `paired` is not)
-  aasr::TrackLayout mixed;    // per-state precision routing: built when only part of the states qualify for f16x2
   int64_t f16_bad_state = -1; // builder scratch: the state whose rows failed the fp16 range / clamp conditions
-  // Engine-internal score layout of a routed model (gmm_score_launch_engine): the states of the mixed layout's second
-  // section as a model of their own (own pivot, own layouts: whole-line stores), scored into spare columns behind the
-  // S state columns; engine consumers (the LNA pass) read a score row through routed_colmap
-  std::unique_ptr<aasr_gmm> routed_sub;
-  aasr::DevBuf<int32_t> routed_colmap;   // [S] column of every state in the engine layout
-  int64_t routed_alias_base = 0;         // first spare column (S rounded up to 32)
-  bool is_routed_sub = false;
-  // Engine parts (gmm_plan_engine_parts; supersede the mixed layout + routed_sub where they exist): the model as up to
+  // Engine parts (gmm_plan_engine_parts; round 6: the one routing mechanism -- round 4's mixed layout and its spare-column
+  // sub-model are gone): the model as up to
   // three internal models over disjoint sets of its states -- [0] the states that qualify for two fp16 terms around the
   // pivot of their GROUP (a multi-pivot model: pivot groups, HostModel::pg_*), [1] the same for three bf16 terms, [2]
   // whatever is left, as an ordinary model (one pivot; outlier routing, centred form ...) -- each scored into its own
@@ -490,9 +464,7 @@ void gmm_f64_classes_masked_launch(aasr_gmm *g, const double *d_frames, int64_t 
 void gmm_score_f64_launch(aasr_gmm *g, const double *d_frames, int64_t F, double *d_out, int linear,
                           hipStream_t stream);
 void gmm_build_tracks(aasr_gmm *g, bool grouped);
-void gmm_build_mixed(aasr_gmm *g, std::vector<uint8_t> &f16_ok);
 void gmm_probe_f16x2(aasr_gmm *g);
-void gmm_build_routed_sub(aasr_gmm *g);
 void gmm_plan_engine_parts(aasr_gmm *g);
 bool gmm_engine_parts_active(const aasr_gmm *g);
 bool gmm_engine_parts_clustered(const aasr_gmm *g);   // ... under Gaussian clustering (gmm_cluster_score_launch)

@@ -1580,9 +1580,7 @@ static ExactPlan exact_part_plan(aasr_gmm *g, ClusterState &cl) {
     raise(AASR_ERR_UNSUPPORTED, "no centred kernel instance for dimension %d", g->dim);
   // the layout the exact part runs on: grouped unless it is missing or masked out
   p.which = (g->paired.ok && ((g->layout_mask & 1) || !g->tracks.ok)) ? 0 : 1;
-  // per-state precision routing (gmm_build_mixed): AASR_PREC_F16X2 runs the mixed layout's two sections
-  if (g->precision == AASR_PREC_F16X2 && g->use_bf16x3 && g->mixed.ok && (g->layout_mask & 3) == 3) p.which = 2;
-  const TrackLayout &L = p.which == 2 ? g->mixed : p.which == 0 ? g->paired : g->tracks;
+  const TrackLayout &L = p.which == 0 ? g->paired : g->tracks;
   if (!p.all_centred && !L.ok) raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering needs a track layout for this model");
   if (!p.all_centred && cl.crow[p.which].n != L.row_gauss.size()) build_crow(g, L, cl, cl.crow[p.which]);
   p.mask_rows = p.all_centred ? 0 : L.rows_padded;  // the centred kernel reads the cluster bits themselves
@@ -1642,7 +1640,7 @@ static void exact_part_launch(aasr_gmm *g, ClusterState &cl, const ExactPlan &p,
     if (g->out_bias_ln != 0) gmm_add_bias_nofloor(out, n * g->S, (float)g->out_bias_ln, stream);
     return;
   }
-  const TrackLayout &L = p.which == 2 ? g->mixed : p.which == 0 ? g->paired : g->tracks;
+  const TrackLayout &L = p.which == 0 ? g->paired : g->tracks;
   // the track kernels read the lane masks of whole workgroups (up to 512 frames = 8 words)
   cl.maskrow.ensure((size_t)((n + 511) / 512 * 8) * (size_t)L.rows_padded);
   const int64_t n_tiles = L.rows_padded / TILE_ROWS;

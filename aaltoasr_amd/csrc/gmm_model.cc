@@ -499,11 +499,6 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
   g->outlier.clear();
   g->hyb_enabled = false;
   g->hyb_states = g->hyb_rows = 0;
-  // per-state precision routing belongs to the plain diagonal build below: nothing of an earlier build may survive a
-  // rebuild that takes another path (class routing, dimension parts, factor rows)
-  g->mixed = TrackLayout();
-  g->routed_sub.reset();
-  g->routed_colmap = DevBuf<int32_t>();
   g->f16_probe_moved = 0;
   g->f16_whole_rejected = false;
   g->rows_unbiased = false;
@@ -674,18 +669,10 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
   g->f16_bad_state = -1;
   gmm_build_tracks(g, true);
   if (!g->paired.ok) gmm_build_tracks(g, false);
-  // per-state precision routing: where the model as a whole does not get the two-term fp16 rows, the states that
-  // qualify on their own still do (the mixed layout); AASR_PREC_F16X2 then runs both sections
-  g->mixed = TrackLayout();
-  g->cl.crow[2] = DevBuf<int32_t>();
+  // which states could take the plain two-term rows around the pool's one pivot (the probe and the planner of the engine
+  // parts start from it)
   f16x2_state_eligibility(g, g->f16_state_ok);
-  {
-    const TrackLayout &L0 = g->paired.ok ? g->paired : g->tracks;
-    if (L0.ok && L0.a16.p && !L0.a16h.p) {
-      if (g->f16_bad_state >= 0) g->f16_state_ok[(size_t)g->f16_bad_state] = 0;   // range / clamp failure of one state's rows
-      gmm_build_mixed(g, g->f16_state_ok);
-    }
-  }
+  if (g->f16_bad_state >= 0) g->f16_state_ok[(size_t)g->f16_bad_state] = 0;   // range / clamp failure of one state's rows
   gmm_build_centred(g);
   g->rows_unbiased = m.logw_bias == 0;
   // profiling hook: AASR_LAYOUTS=<mask> restricts the kernels like
@@ -700,55 +687,7 @@ void gmm_build(aasr_gmm *g, const HostModel &model) {
     if ((g->layout_mask & 2) && !g->tracks.ok) gmm_build_tracks(g, false);
   }
   gmm_probe_f16x2(g);   // load-time guard of the two-term fp16 rows
-  gmm_build_routed_sub(g);
   gmm_plan_engine_parts(g);
-}
-
-// The second section of a routed model as a model of its own (aasr_gmm::routed_sub): its states, the Gaussians they use,
-// its own pivot -- so that the engine's own paths can score it into spare columns with whole-line stores instead of
-// storing its values one by one over the first section's lines (gmm_score_launch_engine).
-void gmm_build_routed_sub(aasr_gmm *g) {
-  g->routed_sub.reset();
-  g->routed_colmap = DevBuf<int32_t>();
-  static const int alias_env = AASR_EXPERIMENT_ENV("AASR_ROUTED_ALIAS") ? atoi(AASR_EXPERIMENT_ENV("AASR_ROUTED_ALIAS")) : 1;
-  const HostModel &m = g->host;
-  if (!alias_env || g->is_routed_sub || !g->mixed.ok || !g->mixed.sec[0].mapped || m.n_transforms > 0 || m.S > 4096 ||
-      !g->outlier.empty())
-    return;
-  HostModel sm;
-  sm.dim = m.dim;
-  std::vector<int32_t> gmap((size_t)m.G, -1), colmap((size_t)m.S);
-  const int64_t base = (m.S + 31) / 32 * 32;
-  sm.mix_off.push_back(0);
-  for (int64_t s = 0; s < m.S; s++) {
-    if (g->f16_state_ok[(size_t)s]) {
-      colmap[(size_t)s] = (int32_t)s;
-      continue;
-    }
-    colmap[(size_t)s] = (int32_t)(base + sm.S);
-    for (int32_t k = m.mix_off[s]; k < m.mix_off[s + 1]; k++) {
-      const int32_t gi = m.mix_idx[k];
-      if (gmap[(size_t)gi] < 0) {
-        gmap[(size_t)gi] = (int32_t)sm.G++;
-        sm.mean.insert(sm.mean.end(), m.mean.begin() + (size_t)gi * m.dim, m.mean.begin() + (size_t)(gi + 1) * m.dim);
-        sm.var.insert(sm.var.end(), m.var.begin() + (size_t)gi * m.dim, m.var.begin() + (size_t)(gi + 1) * m.dim);
-      }
-      sm.mix_idx.push_back(gmap[(size_t)gi]);
-      sm.mix_w.push_back(m.mix_w[(size_t)k]);
-    }
-    sm.mix_off.push_back((int32_t)sm.mix_idx.size());
-    sm.S++;
-  }
-  if (sm.S == 0 || sm.G == 0) return;
-  sm.weights_normalized = true;
-  auto sub = std::make_unique<aasr_gmm>();
-  sub->device = g->device;
-  sub->is_routed_sub = true;
-  gmm_build(sub.get(), sm);
-  if (!gmm_score_pitch_ok(sub.get())) return;   // (needs a track layout: whole-line stores are the point)
-  g->routed_sub = std::move(sub);
-  g->routed_alias_base = base;
-  g->routed_colmap.upload(colmap.data(), colmap.size());
 }
 
 // ---------------------------------------------------------------------------
@@ -1045,7 +984,7 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
     note += buf;
   };
   const HostModel &m = g->host;
-  if (g->is_routed_sub || g->is_engine_part || m.n_pg() > 0 || m.n_transforms > 0 || m.any_full() || !g->dim_parts.empty() ||
+  if (g->is_engine_part || m.n_pg() > 0 || m.n_transforms > 0 || m.any_full() || !g->dim_parts.empty() ||
       g->class_routing || m.S < 2 || m.mix_idx.empty())
     return;
   // EXPERIMENT (tools/exp_calib.py): every state into ONE slab-constant part around the pool's pivot, whatever its conditioning
@@ -1225,7 +1164,6 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
     sm.pg_real_end.clear();
     auto sub = std::make_unique<aasr_gmm>();
     sub->device = g->device;
-    sub->is_routed_sub = true;
     sub->is_engine_part = true;
     sub->parent_gauss = pgauss;
     gmm_build(sub.get(), sm);
@@ -1255,9 +1193,6 @@ void gmm_plan_engine_parts(aasr_gmm *g) {
   g->engine_cols = col0;
   g->engine_colmap_h = colmap;
   g->engine_colmap.upload(colmap.data(), colmap.size());
-  // the mixed layout's own spare-column arrangement is superseded
-  g->routed_sub.reset();
-  g->routed_colmap = DevBuf<int32_t>();
 }
 
 // Track layouts for the in-register epilogue (k_gmm_diag_score_tracks).
@@ -1461,7 +1396,7 @@ static void pack_bf16x3(int D, const std::vector<double> &coef64, int64_t tiles,
 
 // Two-term fp16 split of the same rows for the f16x2 form (AASR_PREC_F16X2): same K order and tile layout with two
 // splits; the constant's remainder after its two terms goes to K slot 1 (the frame operand is 1 in both).
-// Covers the tiles [0, tiles) of the layout -- the whole layout, or the first section of a mixed one; rows with
+// Covers the tiles [0, tiles) of the layout; rows with
 // rs.g < 0 (and every row of a state that is not in `st_ok`, when given) are null rows.  Returns false -- and packs
 // nothing -- when a value leaves the fp16 range, or when a frame component clamped at kF16Clamp from the pivot could
 // still be visible above the 1e-50 floor for some row (the clamp must never change a result the reference's float
@@ -1673,35 +1608,23 @@ static void f16x2_state_eligibility(const aasr_gmm *g, std::vector<uint8_t> &ok)
       if (!g_ok[(size_t)m.mix_idx[k]]) ok[(size_t)s] = 0;
 }
 
-// Builds the grouped (paired), the independent or -- `f16_ok` given -- the MIXED layout:
-//
-//   mixed: per-state precision routing.  The states whose Gaussians all qualify for the two-term fp16 form
-//   (f16_ok[s]) make up section 0, the others section 1; a section is a run of whole tiles of the same layout, with its
-//   own row-cut table, and is scored by its own launch (f16x2 rows for section 0, bf16x3 rows for section 1).  In the
-//   grouped form the states of a section are a subset of the model's, so pairs are formed from neighbours IN THE
-//   SECTION that share a group of 16 output columns (a lone state takes a pair with an empty partner track), and the
-//   kernel takes a pair's output columns, its flush points and the mask of the columns its section owns from the
-//   pair table `pmap` (k_gmm_diag_score_pl<..., MAPPED>).  A model in which one Gaussian breaks the fp16 limits then
-//   costs that Gaussian's STATE the three-term arithmetic, not the whole model.
-static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const std::vector<uint8_t> *f16_ok) {
+// Builds the grouped (paired) or the independent track layout (the header of this section).
+static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped) {
   const HostModel &m = g->host;
   L.ok = false;
   L.grouped = grouped;
-  L.mapped = false;
-  L.n_sections = 0;
   L.states_f16 = 0;
   L.n_pg = 0;
   L.split_cap = TRACK_MAX_SPLITS;
   const int P = m.n_pg();   // pivot groups (engine-internal multi-pivot models): grouped layouts only
-  if (P > 0 && (!grouped || f16_ok)) return;
+  if (P > 0 && !grouped) return;
   double ref = 0;
   if (!choose_reference(m, g->outlier, &ref)) return;
   L.ref_ln = (float)(ref * 0.69314718055994530942);
   const int64_t rows_real = std::max<int64_t>(1, (int64_t)m.mix_idx.size());
-  const bool mixed = f16_ok != nullptr;
 
-  // ---- the sections' states, ascending
-  std::vector<int64_t> order[2];
+  // ---- the states, ascending (one "section": the index is kept for the cut candidates)
+  std::vector<int64_t> order[1];
   std::vector<int> st_pg;   // pivot group of every state
   if (P > 0) st_pg.resize((size_t)m.S);
   for (int64_t s = 0; s < m.S; s++) {
@@ -1710,10 +1633,9 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
       st_pg[(size_t)s] = pgi;
       if (s >= m.pg_real_end[(size_t)pgi]) continue;   // a padding column: no rows, never closed
     }
-    order[mixed && !(*f16_ok)[(size_t)s] ? 1 : 0].push_back(s);
+    order[0].push_back(s);
   }
-  const int n_sec = mixed ? 2 : 1;
-  if (mixed && (order[0].empty() || order[1].empty())) return;   // nothing to route
+  const int n_sec = 1;
 
   // ---- placement: (track, first quad) per state; close events; cut candidates per section
   std::vector<int8_t> st_track((size_t)m.S);
@@ -1721,7 +1643,7 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
   int64_t len[2] = {0, 0};
   int64_t closed[2] = {0, 0};
   struct Cand { std::vector<int64_t> tile, k0, k1; std::vector<int> pg; };   // pg: the pivot group that starts there, -1: none
-  Cand cand[2];
+  Cand cand[1];
   struct PairEv { int64_t s0, s1, last; bool f16, f32; };   // grouped: the pair's states, its last quad, its flush flags
   std::vector<PairEv> pairs;
   int64_t sec_tile[3] = {0, 0, 0};
@@ -1729,21 +1651,17 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
   auto quads_of = [&](int64_t s) {
     return std::max<int64_t>(1, ((int64_t)(m.mix_off[s + 1] - m.mix_off[s]) + 3) / 4);
   };
-  // mixed: section 0 keeps the layout's form (grouped: pairs over the section's states), section 1 -- the few states
-  // on three terms -- is always laid out as independent tracks; its close counters and state lists start at zero
-  auto sec_grouped = [&](int sc) { return grouped && !(mixed && sc == 1); };
+  auto sec_grouped = [&](int) { return grouped; };
   for (int sc = 0; sc < n_sec; sc++) {
     const std::vector<int64_t> &st = order[sc];
-    if (mixed && sc == 1 && grouped) closed[0] = closed[1] = 0;   // (a grouped section 0 left nothing in the lists)
     cand[sc].tile.push_back(std::max(len[0], len[1]) / 8);
     cand[sc].k0.push_back(closed[0]);
     cand[sc].k1.push_back(closed[1]);
     cand[sc].pg.push_back(P > 0 ? 0 : -1);
     int cur_pg = 0;
     if (sec_grouped(sc)) {
-      // Pairs are formed inside groups of 16 output columns: (16 g, 16 g + 1), ... for the whole model, neighbours among
-      // the section's states of a group for a subset (a lone state takes a pair with an empty partner track).  A group
-      // is staged and flushed as whole lines (k_gmm_diag_score_pl<..., MAPPED>).
+      // Pairs are formed inside groups of 16 output columns: (16 g, 16 g + 1), ... (a lone last state takes a pair with an
+      // empty partner track).  A group is staged and flushed as whole lines.
       size_t i = 0;
       while (i < st.size()) {
         const int64_t a = st[i];
@@ -1864,10 +1782,8 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
     // a pair closes where its longer member ends; both tracks carry the bit (the kernels read track 0's)
     for (const PairEv &pe : pairs) {
       close_mask[(size_t)(pe.last / 8)] |= (uint16_t)((1u << (pe.last % 8)) | (1u << (pe.last % 8 + 8)));
-      if (!mixed) {   // (a mixed layout's lists hold section 1's states; its section 0 reads the pair table)
-        sid[0].push_back((int32_t)pe.s0);
-        if (pe.s1 >= 0) sid[1].push_back((int32_t)pe.s1);
-      }
+      sid[0].push_back((int32_t)pe.s0);
+      if (pe.s1 >= 0) sid[1].push_back((int32_t)pe.s1);
     }
   }
   const size_t ns = std::max(sid[0].size(), sid[1].size()) + 1;
@@ -1876,44 +1792,18 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
     for (size_t k = 0; k < sid[h].size(); k++) sid_flat[h * ns + k] = sid[h][k];
   L.sid_stride = (int32_t)ns;
   L.sid.upload(sid_flat.data(), sid_flat.size());
-  if (mixed && grouped) {
-    // pair entries by tile, track and quad position: column | flags of the pair that closes there
-    // (k_gmm_diag_score_pl<..., MAPPED> fetches a tile's 16 words into LDS together with its rows)
-    std::vector<int32_t> pm((size_t)(tiles + 2) * 16, 0);
-    for (const PairEv &pe : pairs) {
-      const int32_t fl = (pe.f16 ? (1 << 29) : 0) | (pe.f32 ? (1 << 30) : 0);
-      const size_t t = (size_t)(pe.last / 8), pos = (size_t)(pe.last % 8);
-      pm[t * 16 + pos] = (int32_t)pe.s0 | fl;
-      pm[t * 16 + 8 + pos] = (pe.s1 >= 0 ? (int32_t)pe.s1 : ((int32_t)pe.s0 | (1 << 28))) | fl;
-    }
-    L.pmap.upload(pm.data(), pm.size());
-    L.pmap_stride = 16;
-    L.mapped = true;
-  }
-  // row-cut tables: the whole layout (or, mixed, one per section)
+  // row-cut table
   if (P > 0) {
     build_split_table_pg(L, cand[0].tile, cand[0].k0, cand[0].k1, cand[0].pg, P);
     if (L.max_splits < P) return;
     L.n_pg = P;
     L.pg_pivot.upload(m.pg_pivot.data(), m.pg_pivot.size());
     L.pg_colend.upload(m.pg_real_end.data(), m.pg_real_end.size());
-  } else if (!mixed) {
-    build_split_table(L.splits, &L.max_splits, tiles, cand[0].tile, cand[0].k0, cand[0].k1);
   } else {
-    L.n_sections = 2;
-    for (int sc = 0; sc < 2; sc++) {
-      L.sec[sc].tile_begin = sec_tile[sc];
-      L.sec[sc].tile_end = sec_tile[sc + 1];
-      L.sec[sc].states = (int64_t)order[sc].size();
-      L.sec[sc].grouped = sec_grouped(sc);
-      L.sec[sc].mapped = L.sec[sc].grouped;
-      build_split_table(L.sec[sc].splits, &L.sec[sc].max_splits, sec_tile[sc + 1] - sec_tile[sc], cand[sc].tile,
-                        cand[sc].k0, cand[sc].k1);
-    }
-    L.states_f16 = (int64_t)order[0].size();
+    build_split_table(L.splits, &L.max_splits, tiles, cand[0].tile, cand[0].k0, cand[0].k1);
   }
   std::vector<double> coef64;
-  pack_rows(g, rows, L.rows, &coef64, /*upload_f32=*/!mixed);
+  pack_rows(g, rows, L.rows, &coef64);
   L.sc = P > 0 && m.pg_sc();
   if (L.sc) {
     // slab-constant layout: seven dimensions per slab, two fp16 terms only
@@ -1927,12 +1817,7 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
   static const int f16_env = AASR_EXPERIMENT_ENV("AASR_F16X2") ? atoi(AASR_EXPERIMENT_ENV("AASR_F16X2")) : 1;   // 0: never pack the f16x2 form
   L.a16h = DevBuf<uint16_t>();
   int64_t bad_state = -1;
-  if (mixed) {
-    if (!L.a16.p || !pack_f16x2(g, rows, row_state, coef64, sec_tile[1], L, &bad_state)) {
-      g->f16_bad_state = bad_state;   // the caller may move that state to the other section and try again
-      return;
-    }
-  } else if (P > 0 && m.pg_arith == 3) {
+  if (P > 0 && m.pg_arith == 3) {
     // a three-term multi-pivot model: no fp16 rows
   } else if (P == 0 && g->f16_whole_rejected) {
     // the load-time probe rejected states of this model: the whole-model two-term rows stay away
@@ -1952,34 +1837,7 @@ static void build_track_layout(aasr_gmm *g, TrackLayout &L, bool grouped, const 
   L.ok = true;
 }
 
-void gmm_build_tracks(aasr_gmm *g, bool grouped) { build_track_layout(g, grouped ? g->paired : g->tracks, grouped, nullptr); }
-
-// The mixed layout (per-state precision routing), built when the model as a whole does not qualify for the two-term fp16
-// form but some of its states do: grouped exactly when the model's own grouped layout exists (a grouped mixed layout that
-// fails the padding test is NOT retried on independent tracks: the model then keeps one arithmetic -- or, where the
-// planner of gmm_plan_engine_parts applies, becomes engine parts).  A state whose rows fail the range / clamp conditions at
-// packing time is moved to the three-term section and the layout is built again.
-void gmm_build_mixed(aasr_gmm *g, std::vector<uint8_t> &f16_ok) {
-  g->mixed.ok = false;
-  static const int f16_env = AASR_EXPERIMENT_ENV("AASR_F16X2") ? atoi(AASR_EXPERIMENT_ENV("AASR_F16X2")) : 1;
-  static const int mixed_env = AASR_EXPERIMENT_ENV("AASR_MIXED") ? atoi(AASR_EXPERIMENT_ENV("AASR_MIXED")) : 1;   // 0: whole-model precision as before
-  if (!f16_env || !mixed_env) return;
-  for (int attempt = 0; attempt < 64; attempt++) {
-    int64_t n_ok = 0;
-    for (uint8_t v : f16_ok) n_ok += v;
-    if (n_ok == 0 || n_ok == (int64_t)f16_ok.size()) return;
-    // the second section stores its values one by one over the first one's whole lines, which costs about as much again
-    // as its arithmetic: with half of the states on three terms the two launches take what the whole model takes on three
-    // terms (measured on configs[2]: 1 % of the states routed 1.11x the all-fp16 pass, 10 % 1.31x, 50 % 1.62x = the
-    // whole model on three terms), so beyond 45 % the model keeps one arithmetic
-    if ((double)n_ok < 0.55 * (double)f16_ok.size()) return;
-    g->f16_bad_state = -1;
-    build_track_layout(g, g->mixed, g->paired.ok, &f16_ok);
-    if (g->mixed.ok) return;
-    if (g->f16_bad_state < 0 || !f16_ok[(size_t)g->f16_bad_state]) return;
-    f16_ok[(size_t)g->f16_bad_state] = 0;
-  }
-}
+void gmm_build_tracks(aasr_gmm *g, bool grouped) { build_track_layout(g, grouped ? g->paired : g->tracks, grouped); }
 
 // Operands of the centred-form kernel + the conditioning estimate that decides
 // whether the matrix-core (expanded form) kernels may be used.
@@ -2076,7 +1934,7 @@ static void find_outliers(aasr_gmm *g) {
   static const int routing = AASR_EXPERIMENT_ENV("AASR_OUTLIER_ROUTING") ? atoi(AASR_EXPERIMENT_ENV("AASR_OUTLIER_ROUTING")) : 1;
   // Two passes.  First against the plain TWO-term limits: where only a handful of Gaussians break them, those become the
   // outliers and the whole model keeps the fastest rows (round 6: a Gaussian between the two-term and the three-term
-  // limits used to cost its state the three-term section of a mixed layout and the model its whole-model two-term rows;
+  // limits used to cost its state a three-term section of its own and the model its whole-model two-term rows;
   // in the centred form it costs 1.6 us per 449 280 frames + ~20 us for its state's merge: a read-modify-write of one
   // column of the score matrix touches a line per frame).  "A handful": what the public layout pays for them stays below
   // the gather of a model with engine parts (gmm_score.hip, engine_parts_public: 2.4 ms).  Else against the limits of the

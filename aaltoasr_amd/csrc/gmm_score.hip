@@ -1141,7 +1141,9 @@ struct PlSmem {
   static constexpr int kBytes = NBUF * kTileBytes + (WIDE ? 8 : 4) * kOutFloatsPerWave * 4 + kMapBytes;
 };
 
-// MAPPED (GROUPED only; section 0 of a mixed layout, gmm.h TrackLayout::mapped): the section's states are a SUBSET of
+// MAPPED (GROUPED only; NOT INSTANTIATED since round 6: it served section 0 of round 4's mixed layout, which the engine
+// parts replaced; the branches stay in the kernel's source because the headline instance's code is better left untouched):
+// the section's states are a SUBSET of
 // the model's, so a pair's output columns come from a table instead of its ordinal: per tile, track and quad position
 // `sid` holds column | flags of the pair that closes there (16 words per tile; they ride into LDS with the tile's rows,
 // so the close logic never waits for global memory -- a per-close vector load is waited for in issue order, i.e. behind
@@ -1887,7 +1889,6 @@ static int pick_row_cuts(int64_t blocks, double slots, int64_t tiles, int max_sp
   return R;
 }
 
-// `sec`: the section of a mixed layout to score (its tiles and row-cut table), nullptr: the whole layout
 // Two-level plan: the workgroups of a launch run in rounds of `slots`, and a uniform R leaves the last round partly
 // empty (configs[2]: 878 blocks x 2 cuts = 6.86 rounds of 256).  So the frame blocks that fill whole rounds at a coarse
 // cut count go first, and the remaining blocks are cut finer so that THEIR last round is nearly full too: configs[2]
@@ -1939,7 +1940,7 @@ static CutPlan pick_cut_plan(int64_t blocks, double slots_d, int64_t tiles, int 
 }
 
 template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS>
-static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const TrackSection *sec, const float *d_frames, int64_t F,
+static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
                           float *d_out, hipStream_t stream, const ClusterArgs &cl, int64_t pitch) {
   constexpr int NW = WIDE ? 8 : 4;
   const int64_t blocks = (F + NW * FRAMES_PER_WAVE - 1) / (NW * FRAMES_PER_WAVE);
@@ -1953,9 +1954,8 @@ static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const TrackSe
     attr_set[g->device & 63] = true;
   }
   const int R = pick_row_cuts(blocks, (WIDE ? 1.0 : 2.0) * (g->num_cus > 0 ? g->num_cus : 256),
-                              sec ? sec->tile_end - sec->tile_begin : L.rows_padded / TILE_ROWS,
-                              sec ? sec->max_splits : L.max_splits, 6.0);
-  const int32_t *split_row = (sec ? sec->splits.p : L.splits.p) + (size_t)(R - 1) * ((sec ? TRACK_MAX_SPLITS : L.split_cap) + 1) * 4;
+                              L.rows_padded / TILE_ROWS, L.max_splits, 6.0);
+  const int32_t *split_row = L.splits.p + (size_t)(R - 1) * (L.split_cap + 1) * 4;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)R), dim3(NW * 64), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, NS == 3 ? L.a16.p : L.a16h.p, split_row, L.close.p, L.sid.p, L.sid_stride,
                      d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, dbg, cl);
@@ -1969,29 +1969,28 @@ static void launch_bf16_t(const aasr_gmm *g, const TrackLayout &L, const TrackSe
 #ifndef AASR_PL_BF16X3
 #define AASR_PL_BF16X3 1
 #endif
-template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS, bool MAPPED = false>
-static void launch_pl_t(const aasr_gmm *g, const TrackLayout &L, const TrackSection *sec, const float *d_frames, int64_t F,
+template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS>
+static void launch_pl_t(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
                         float *d_out, hipStream_t stream, const ClusterArgs &cl, int64_t pitch) {
   constexpr int NW = WIDE ? 8 : 4;
   const int64_t blocks = (F + NW * FRAMES_PER_WAVE - 1) / (NW * FRAMES_PER_WAVE);
   const int smem = PlSmem<NK16, GROUPED, WIDE, NS>::kBytes;
   static const int dbg = AASR_EXPERIMENT_ENV("AASR_DBG") ? atoi(AASR_EXPERIMENT_ENV("AASR_DBG")) : 0;
   static bool attr_set[64] = {false};
-  auto kern = k_gmm_diag_score_pl<NK16, GROUPED, CL, WIDE, NS, MAPPED>;
+  auto kern = k_gmm_diag_score_pl<NK16, GROUPED, CL, WIDE, NS>;
   if (!attr_set[g->device & 63]) {
     AASR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set[g->device & 63] = true;
   }
-  const int32_t *splits_base = sec ? sec->splits.p : L.splits.p;
-  const bool multi = !sec && L.n_pg > 1;   // pivot groups: every group at least one cut, its own image of the frame operand
-  const int cap = sec ? TRACK_MAX_SPLITS : L.split_cap;   // rows of the cut table
+  const int32_t *splits_base = L.splits.p;
+  const bool multi = L.n_pg > 1;   // pivot groups: every group at least one cut, its own frame operand
+  const int cap = L.split_cap;   // rows of the cut table
   const CutPlan plan = pick_cut_plan(blocks, (WIDE ? 1.0 : 2.0) * (g->num_cus > 0 ? g->num_cus : 256),
-                                     sec ? sec->tile_end - sec->tile_begin : L.rows_padded / TILE_ROWS,
-                                     sec ? sec->max_splits : L.max_splits, 3.0, splits_base, multi ? L.n_pg : 1, cap);
+                                     L.rows_padded / TILE_ROWS, L.max_splits, 3.0, splits_base, multi ? L.n_pg : 1, cap);
   const int32_t *split_row = splits_base + (size_t)(plan.r_main - 1) * (cap + 1) * 4;
   PivotGroups pg;
   const unsigned n_items = (unsigned)(plan.n_main + (plan.r_rem ? plan.blocks_rem * plan.r_rem : 0));
-  if constexpr (GROUPED && NS == 2 && !MAPPED) {
+  if constexpr (GROUPED && NS == 2) {
     // multi-pivot layouts: the workgroups form their group's frame operand themselves (no k_frame_operand launch)
     static const int pgf_env = AASR_EXPERIMENT_ENV("AASR_PGF") ? atoi(AASR_EXPERIMENT_ENV("AASR_PGF")) : 1;   // EXPERIMENT: 0 = images through HBM
     if (multi && pgf_env && L.pg_tab.p) {
@@ -2016,7 +2015,7 @@ static void launch_pl_t(const aasr_gmm *g, const TrackLayout &L, const TrackSect
   if (multi) pg.colend = L.pg_colend.p;
   hipLaunchKernelGGL(kern, dim3(n_items), dim3(NW * 64), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, NS == 3 ? L.a16.p : L.a16h.p, split_row, L.close.p,
-                     MAPPED ? L.pmap.p : L.sid.p, MAPPED ? 0 : L.sid_stride,
+                     L.sid.p, L.sid_stride,
                      d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, dbg, cl, fop, plan, pg);
   AASR_HIP(hipGetLastError());
 }
@@ -2034,34 +2033,25 @@ static constexpr bool wide_ok() {
 // the software-pipelined kernel
 template <int NS>
 static bool launch_split(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
-                         float *d_out, hipStream_t stream, const ClusterArgs *cl = nullptr, int64_t pitch = 0,
-                         int section = -1) {
+                         float *d_out, hipStream_t stream, const ClusterArgs *cl = nullptr, int64_t pitch = 0) {
   if (pitch <= 0) pitch = g->S;
   if (NS == 3 ? !L.a16.p : !L.a16h.p) return false;
-  const TrackSection *sec = section >= 0 ? &L.sec[section] : nullptr;
-  if (sec && sec->tile_end <= sec->tile_begin) return true;   // an empty section
-  // section 1 of a mixed layout is laid out as independent tracks (direct stores, no pair table) whatever section 0 is
-  const bool grouped = sec ? sec->grouped : L.grouped;
-  const bool mapped = sec ? sec->mapped : false;
+  const bool grouped = L.grouped;
   const ClusterArgs none;
   // AASR_BF16_WIDE=0 selects the 4-wave workgroups
   static const int wide_env = AASR_EXPERIMENT_ENV("AASR_BF16_WIDE") ? atoi(AASR_EXPERIMENT_ENV("AASR_BF16_WIDE")) : -1;
   // small batches (a decoder's per-utterance blocks) fill the chip better with 256-frame workgroups
-  // ... and so does a short section of a mixed layout (a few states on three terms): more, smaller workgroups
-  const int wide = wide_env >= 0 ? wide_env : ((F >= 8192 && (!sec || sec->tile_end - sec->tile_begin >= 64)) ? 1 : 0);
+  const int wide = wide_env >= 0 ? wide_env : (F >= 8192 ? 1 : 0);
   switch (L.nk16) {
-  // mapped (mixed, grouped) layouts run both arithmetic forms on the pipelined kernel, whose epilogue reads the pair table
 #define AASR_LAUNCH(N, GR, CLF, WD, CLA)                                                   \
   do {                                                                                     \
-    if (mapped) {                                                                          \
-      if constexpr (GR && NS == 2) launch_pl_t<N, true, CLF, WD, NS, true>(g, L, sec, d_frames, F, d_out, stream, CLA, pitch); \
-    } else if constexpr (NS == 2 || (AASR_PL_BF16X3 && N <= 5))                            \
-      launch_pl_t<N, GR, CLF, WD, NS>(g, L, sec, d_frames, F, d_out, stream, CLA, pitch);   \
+    if constexpr (NS == 2 || (AASR_PL_BF16X3 && N <= 5))                                   \
+      launch_pl_t<N, GR, CLF, WD, NS>(g, L, d_frames, F, d_out, stream, CLA, pitch);        \
     else if (L.n_pg > 1) {                                                                  \
       /* three bf16 terms on a multi-pivot layout: the pipelined kernel takes the groups' operand images */ \
-      if constexpr (GR) launch_pl_t<N, true, CLF, WD, NS>(g, L, sec, d_frames, F, d_out, stream, CLA, pitch); \
+      if constexpr (GR) launch_pl_t<N, true, CLF, WD, NS>(g, L, d_frames, F, d_out, stream, CLA, pitch); \
     } else                                                                                 \
-      launch_bf16_t<N, GR, CLF, WD, NS>(g, L, sec, d_frames, F, d_out, stream, CLA, pitch); \
+      launch_bf16_t<N, GR, CLF, WD, NS>(g, L, d_frames, F, d_out, stream, CLA, pitch);      \
   } while (0)
 #define AASR_CASE(N)                                                                       \
   case N:                                                                                  \
@@ -2094,22 +2084,9 @@ static bool launch_split(const aasr_gmm *g, const TrackLayout &L, const float *d
 // the split-operand kernel the handle's precision asks for (f16x2 only where the layout is eligible)
 static bool launch_bf16(const aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F,
                         float *d_out, hipStream_t stream, const ClusterArgs *cl = nullptr, int64_t pitch = 0) {
-  if (L.n_sections == 2) {
-    // a mixed layout (AASR_PREC_F16X2 only): the states that qualify in two fp16 terms, then -- the order matters, the
-    // first launch writes whole lines -- the others in three bf16 terms, which store their columns over them
-    return launch_split<2>(g, L, d_frames, F, d_out, stream, cl, pitch, 0) &&
-           launch_split<3>(g, L, d_frames, F, d_out, stream, cl, pitch, 1);
-  }
   if (g->precision == AASR_PREC_F16X2 && L.a16h.p && launch_split<2>(g, L, d_frames, F, d_out, stream, cl, pitch))
     return true;
   return launch_split<3>(g, L, d_frames, F, d_out, stream, cl, pitch);
-}
-
-// the layout the split-operand kernels run under the handle's precision: the mixed one where AASR_PREC_F16X2 can only
-// have part of the states (gmm_build_mixed), else the grouped / independent layout
-static const TrackLayout *split_layout(const aasr_gmm *g) {
-  if (g->precision == AASR_PREC_F16X2 && g->use_bf16x3 && g->mixed.ok && (g->layout_mask & 3) == 3) return &g->mixed;
-  return nullptr;
 }
 
 // Verdicts of the probe, keyed by what it depends on (the model's arrays, pivots, the rows' eligibility, the round and the
@@ -2191,7 +2168,7 @@ void gmm_probe_f16x2(aasr_gmm *g) {
     // (a three-term engine part -- gmm_plan_engine_parts admits states to it beyond the one-pivot forms' limits -- is
     // probed the same way on its own rows)
     const bool pg3 = m.n_pg() > 0 && m.pg_arith == 3;
-    const TrackLayout *LF = pg3 ? (L0.a16.p ? &L0 : nullptr) : g->mixed.ok ? &g->mixed : (L0.a16h.p ? &L0 : nullptr);
+    const TrackLayout *LF = pg3 ? (L0.a16.p ? &L0 : nullptr) : (L0.a16h.p ? &L0 : nullptr);
     if (!LF) return;
     // probe frames (deterministic): frame i sits on mixture component (i * step) % K
     std::vector<float> fr((size_t)P * D);
@@ -2225,7 +2202,7 @@ void gmm_probe_f16x2(aasr_gmm *g) {
     // the verdict of this round, if the same content has been probed before
     uint64_t key = 0xcbf29ce484222325ull;
     {
-      const int64_t hdr[8] = {D, S, K, P, round, pg3 ? 1 : 0, LF == &g->mixed ? 1 : 0, m.pg_arith};
+      const int64_t hdr[8] = {D, S, K, P, round, pg3 ? 1 : 0, 0, m.pg_arith};
       key = fnv1a(hdr, sizeof hdr, key);
       const double tol_d = (double)probe_tol, bias_d = g->out_bias_ln, lwb = m.logw_bias;
       key = fnv1a(&tol_d, sizeof tol_d, key);
@@ -2314,15 +2291,14 @@ void gmm_probe_f16x2(aasr_gmm *g) {
     for (int64_t s2 = 0; s2 < S; s2++)
       if (bad[(size_t)s2]) g->f16_state_ok[(size_t)s2] = 0;
     if (m.n_pg() > 0) return;   // a multi-pivot engine part: the planner takes the marked states out and builds it again
-    // the whole-model fp16 rows are gone; what still qualifies goes to the mixed layout
+    // the whole-model fp16 rows are gone: the model keeps its three-term rows, and the planner of the engine parts (which
+    // runs next and starts from f16_state_ok) gives the states that still qualify their two-term rows back
     g->f16_whole_rejected = true;   // (a layout built later -- aasr_debug_set_layouts -- must not pack them again)
     g->paired.a16h = DevBuf<uint16_t>();
     g->paired.states_f16 = 0;
     g->tracks.a16h = DevBuf<uint16_t>();
     g->tracks.states_f16 = 0;
-    g->mixed = TrackLayout();
-    g->cl.crow[2] = DevBuf<int32_t>();
-    gmm_build_mixed(g, g->f16_state_ok);
+    return;
   }
 }
 
@@ -3454,7 +3430,6 @@ extern "C" int aasr_debug_active_layout(const aasr_gmm *g) {
   if ((g->layout_mask & 4) && (g->ill_conditioned || g->precision == AASR_PREC_F32_CENTRED ||
                                !(g->layout_mask & 3)) && g->centred_ok)
     return 4;
-  if (const TrackLayout *LM = split_layout(g)) return LM->grouped ? 1 : 2;   // the mixed layout, in either form
   if ((g->layout_mask & 1) && g->paired.ok) return 1;
   if ((g->layout_mask & 2) && g->tracks.ok) return 2;
   return 0;
@@ -3567,7 +3542,7 @@ const float *gmm_adapted_frames(aasr_gmm *g, const float *d_frames, int64_t F, h
 void gmm_tracks_masked_launch(aasr_gmm *g, int which, const float *d_frames, int64_t F,
                               float *d_out, const unsigned long long *maskrow,
                               hipStream_t stream, int64_t pitch) {
-  const TrackLayout &L = which == 2 ? g->mixed : which == 0 ? g->paired : g->tracks;
+  const TrackLayout &L = which == 0 ? g->paired : g->tracks;
   if (!L.ok) raise(AASR_ERR_UNSUPPORTED, "Gaussian clustering needs a track layout for this model");
   ClusterArgs cl;
   cl.maskrow = maskrow;
@@ -3760,18 +3735,10 @@ bool gmm_score_pitch_ok(const aasr_gmm *g) {
 }
 
 // ---------------------------------------------------------------------------
-// The engine's own score layout (recipe driver, aasr_run_utterance, aasr_gmm_score_lna_dev: scores that only the LNA
-// pass reads).  A routed model's second section stores 4 bytes per (frame, state) over lines the first section wrote,
-// which costs about as much again as its arithmetic (a partial write of a line costs a fill).  Here its states are
-// scored as a model of their own (routed_sub) into spare columns behind the S state columns -- whole lines -- and the
-// LNA pass reads a score row through a column map.  Anything that merges by state column (clustering, outlier routing,
-// class routing, in-place transforms) keeps the public layout.
+// The engine's own score layout (recipe driver, aasr_run_utterance, aasr_gmm_score_lna_dev: scores that only the LNA pass
+// reads): rows padded to whole lines; a model with engine parts: every part in its own column range, read through a
+// column map.
 // ---------------------------------------------------------------------------
-static bool engine_alias(const aasr_gmm *g) {
-  return g->routed_sub && split_layout(g) == &g->mixed && !g->cl.enabled && !g->hyb_enabled && !g->class_routing &&
-         !g->xf_a.p && g->out_bias_ln == 0 && g->dim_parts.empty() && gmm_score_pitch_ok(g);
-}
-
 // Engine parts (gmm_plan_engine_parts): the model as internal multi-pivot models over disjoint sets of its states.  They
 // carry the default arithmetic only -- the other precisions are verification modes on the model's own layouts -- and
 // nothing that merges by state column (clustering, class routing).
@@ -3810,21 +3777,17 @@ int64_t gmm_engine_pitch(const aasr_gmm *g) {
   // centred models into a pitched launch they do not have).  Scratch is sized with gmm_engine_pitch_max.
   if (gmm_engine_parts_active(g) || gmm_engine_parts_clustered(g)) return std::max(g->engine_cols, (g->S + 31) / 32 * 32);
   if (!gmm_score_pitch_ok(g)) return g->S;
-  const int64_t base = (g->S + 31) / 32 * 32;
-  return g->routed_sub ? base + (g->routed_sub->S + 31) / 32 * 32 : base;
+  return (g->S + 31) / 32 * 32;
 }
 
 // the largest row pitch gmm_engine_pitch() can return for this model whatever the precision, clustering or transform
 // state: what a caller sizes its scratch with (aasr_gmm_score_scratch_floats)
 int64_t gmm_engine_pitch_max(const aasr_gmm *g) {
-  int64_t p = (g->S + 31) / 32 * 32;
-  if (g->routed_sub) p += (g->routed_sub->S + 31) / 32 * 32;
-  return std::max(p, g->engine_cols);
+  return std::max((g->S + 31) / 32 * 32, g->engine_cols);
 }
 
 const int32_t *gmm_engine_colmap(const aasr_gmm *g) {
-  if (gmm_engine_parts_active(g)) return g->engine_colmap.p;
-  return engine_alias(g) ? g->routed_colmap.p : nullptr;
+  return gmm_engine_parts_active(g) ? g->engine_colmap.p : nullptr;
 }
 
 __global__ void k_scatter_columns(const float *__restrict__ in, int64_t F, int64_t n, float *__restrict__ out, int64_t pitch) {
@@ -3950,16 +3913,7 @@ void gmm_score_launch_engine(aasr_gmm *g, const float *d_frames, int64_t F, floa
     launch_engine_parts(g, d_frames, F, d_out, pitch, stream);
     return;
   }
-  if (!engine_alias(g) || pitch < gmm_engine_pitch(g)) {
-    gmm_score_launch_pitched(g, d_frames, F, d_out, pitch, stream);
-    return;
-  }
-  if (!launch_split<2>(g, g->mixed, d_frames, F, d_out, stream, nullptr, pitch, 0))
-    raise(AASR_ERR_UNSUPPORTED, "no kernel instance for the first section of the routed model");
-  aasr_gmm *sub = g->routed_sub.get();
-  sub->precision = g->precision;
-  sub->use_bf16x3 = g->use_bf16x3;
-  gmm_score_launch_pitched(sub, d_frames, F, d_out + g->routed_alias_base, pitch, stream);
+  gmm_score_launch_pitched(g, d_frames, F, d_out, pitch, stream);
 }
 
 void gmm_score_launch_pitched(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out, int64_t pitch,
@@ -3994,9 +3948,7 @@ void gmm_score_launch_pitched(aasr_gmm *g, const float *d_frames, int64_t F, flo
     return;
   }
   const TrackLayout &L = g->paired.ok ? g->paired : g->tracks;
-  const TrackLayout *LM = split_layout(g);
-  const bool done = (LM && launch_bf16(g, *LM, d_frames, F, d_out, stream, nullptr, pitch)) ||
-                    (g->use_bf16x3 && launch_bf16(g, L, d_frames, F, d_out, stream, nullptr, pitch)) ||
+  const bool done = (g->use_bf16x3 && launch_bf16(g, L, d_frames, F, d_out, stream, nullptr, pitch)) ||
                     launch_tracks(g, L, d_frames, F, d_out, stream, nullptr, pitch);
   if (!done) raise(AASR_ERR_UNSUPPORTED, "no track kernel instance for this model");
   // the Gaussians the matrix layouts left out (null rows): centred form, merged per state into the padded rows
@@ -4155,9 +4107,8 @@ void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
       if (g->out_bias_ln != 0) add_output_bias(g, d_out, F, stream);
       return;
     }
-  // layout choice: (mixed, where f16x2 covers part of the states) > grouped tracks > independent tracks > general (LDS-staged)
+  // layout choice: grouped tracks > independent tracks > general (LDS-staged)
   bool done = false;
-  if (const TrackLayout *LM = split_layout(g)) done = launch_bf16(g, *LM, d_frames, F, d_out, stream);
   if (!done && (g->layout_mask & 1) && g->paired.ok)
     done = (g->use_bf16x3 && launch_bf16(g, g->paired, d_frames, F, d_out, stream)) ||
            launch_tracks(g, g->paired, d_frames, F, d_out, stream);

@@ -7,7 +7,7 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DOCUMENTED = {"AASR_PREC", "AASR_PCGMM_AS_WRITTEN", "AASR_WRITER_THREADS", "AASR_RECIPE_TIMING", "AASR_LOCAL_RANKS",
-              "AASR_F16_PROBE_TOL", "AASR_PG_PIVOT_COST"}
+              "AASR_F16_PROBE_TOL", "AASR_PG_PIVOT_COST", "AASR_PG_PIVOT_COST3"}
 # names of the public header that show up in messages, not environment variables
 NOT_ENV = re.compile(r"^AASR_(PREC_[A-Z0-9_]+|ERR_[A-Z_]+|OK)$")
 

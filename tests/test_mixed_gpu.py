@@ -1,8 +1,10 @@
-"""Per-state precision routing (gmm_build_mixed, k_gmm_diag_score_pl<..., MAPPED>): under AASR_PREC_F16X2 a model whose
-Gaussians do not ALL satisfy the two-term fp16 form's conditioning limits is scored in two sections -- the states whose
-Gaussians all qualify with two fp16 terms, the rest with three bf16 terms -- instead of dropping the whole model to the
-slower arithmetic.  States are independent output columns (Mixture::compute_likelihood, aku/Distributions.cc:2078-2086),
-so the parity bar is the usual one: every state log-likelihood within 1e-4 of the oracle's (aku/HmmSet.cc:484-501)."""
+"""Per-state precision routing: a model whose Gaussians do not ALL satisfy the plain two-term layout's conditioning limits
+keeps the fastest rows for the states that qualify and gives the others what their conditioning needs -- since round 6
+through ONE mechanism, the engine parts (gmm_plan_engine_parts: plain rows around a group's pivot, the slab-constant layout,
+the centred form), or, for a handful of far-out Gaussians, outlier routing on the model's own layout; rounds 4-5 had a
+"mixed" layout of two sections for it, whose tests these were.  States are independent output columns
+(Mixture::compute_likelihood, aku/Distributions.cc:2078-2086), so the parity bar is the usual one: every state
+log-likelihood within 1e-4 of the oracle's (aku/HmmSet.cc:484-501)."""
 import os
 import subprocess
 import sys
@@ -19,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _routed(capi, oracle, model, bad, frames, grouped=None, clustered=False):
-    """Scores `frames` in every precision; returns the f16x2 scores.  `bad`: the states expected in the three-term section."""
+    """Scores `frames` in every precision; returns the default precision's scores.  `bad`: the states over the plain limits."""
     S = len(model[2]) - 1
     ref = oracle.DiagModel(*model).score(frames.astype(np.float64))
     g = capi.Gmm.from_arrays(*model)
@@ -31,13 +33,13 @@ def _routed(capi, oracle, model, bad, frames, grouped=None, clustered=False):
     if grouped is not None:
         assert g.active_layout() == (1 if grouped else 2)
     got4 = g.score(frames)
-    assert_ll(got4, ref, "mixed layout, f16x2 + bf16x3 sections")
+    assert_ll(got4, ref, "routed model, default precision")
     for prec in (3, 0):
         g.set_precision(prec)
         assert g.effective_precision() == prec and g.precision_states()[0] == 0
         assert_ll(g.score(frames), ref, "precision %d on the routed model" % prec)
     g.set_precision(4)
-    assert np.array_equal(g.score(frames), got4)       # back on the mixed layout: the same bits
+    assert np.array_equal(g.score(frames), got4)       # back on the default precision: the same bits
     g.close()
     return got4, ref
 
