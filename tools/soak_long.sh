@@ -11,3 +11,6 @@ timeout 1500 python tools/fuzz_speakers.py $((B + 400)) 200 2>&1 | grep -i "fail
 timeout 1500 python tools/fuzz_subspace.py $((B + 500)) 300 2>&1 | grep -i "failures\|FAIL\|pcgmm" | tail -5 >> gpurun_out/soak_long/subspace.log
 grep -c "failures: 0" gpurun_out/soak_long/*.log
 grep -h "FAIL\|failures: [1-9]" gpurun_out/soak_long/*.log | head -20
+# models fitted to data (round 6): 120 seeds x 12 models, a third of them scored off the data
+bash tools/fuzz_fitted_many.sh $((B + 600)) 120 12 soak_long_$B | tail -3 >> gpurun_out/soak_long/fitted.log
+tail -3 gpurun_out/soak_long/fitted.log
