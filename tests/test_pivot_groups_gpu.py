@@ -325,3 +325,37 @@ print("RESULT", r1 - r0, h1 - h0, r2 - r1, h2 - h1, moved, int(np.array_equal(s4
     runs1, hits1, runs2, hits2, moved, same, layout = [int(x) for x in r.stdout.split("RESULT")[1].split()]
     assert runs1 > 0 and runs2 == 0 and hits2 > 0, r.stdout      # the second build ran no probe on the device
     assert moved > 0 and layout == 2 and same == 1, r.stdout       # the late layout did not re-admit the rejected rows
+
+
+@pytest.mark.parametrize("D", [13, 24, 39, 47, 55])
+def test_slab_constant_part_in_other_dimensions(capi, oracle, D):
+    """The slab-constant K layout (TrackLayout::sc: seven dimensions + their share of the constant per slab of 16 K slots)
+    picks another kernel instance per dimension (2 slabs at 13 dimensions ... 8 at 55).  Half of the states hold one Gaussian
+    over the plain two-term limits -- too many for outlier routing -- so they form the second engine part; frames on and
+    off the model; the clustered pass over the parts as well."""
+    S = 128
+    base = synth.make_model(D=D, G=S * 8, S=S, comps=8, seed=600 + D)
+    bad = list(range(0, S, 2))
+    model = synth.push_states_over_the_f16_limits(base, bad, kappa2=100.0)
+    g = capi.Gmm.from_arrays(*model)
+    parts = g.engine_parts()
+    assert parts is not None and any(p["arith"] == 4 for p in parts["parts"]), (parts, g.engine_plan_note())
+    rng = np.random.default_rng(D)
+    fr = synth.make_frames(600, D=D, seed=601 + D)
+    fr[300:] = (fr[300:] * 2.5).astype(np.float32)          # far from every Gaussian
+    om = oracle.DiagModel(*model)
+    ref = om.score(fr.astype(np.float64))
+    err, n = visible_err(g.score(fr), ref)
+    assert n > 1000 and err <= TOL, (D, err, parts)
+    C = 16
+    g2c = synth.make_clustering(model[0], C, seed=3)
+    pairs = [(int(a), int(c)) for a, c in enumerate(g2c)]
+    om.set_clustering(C, pairs, 0.0, 0.25)
+    want, want_n = om.score_clustered(fr.astype(np.float64), want_counts=True)
+    g.set_clustering(C, pairs)
+    g.set_clustering_min_evals(0.0, 0.25)
+    got = g.score(fr)
+    assert np.array_equal(g.cluster_exact_counts(len(fr)), want_n), D
+    vis = want > VISIBLE
+    assert np.abs(got - want)[vis].max() <= TOL, (D, np.abs(got - want)[vis].max())
+    g.close()
