@@ -401,6 +401,11 @@ struct aasr_gmm {
   std::vector<int32_t> hyb_comps;          // mixture-component index of every outlier record (host)
   std::vector<int32_t> parent_gauss;       // a class sub-model: parent pool index of each of its Gaussians
   aasr::DevBuf<float> hyb_scratch;         // [frames of a pass][hyb_states]
+  // the merge fused into the scoring kernel's close logic (k_gmm_diag_score_pl<..., HYB>): per state the next state of its
+  // track parity with outlier components | that state's record << 16 ([S]; models of up to 65 534 states and records);
+  // hyb_fuse: set by the scoring launcher around the launch that is to take the partial sums
+  aasr::DevBuf<uint32_t> hyb_tab;
+  mutable struct HybFuse { const float *part = nullptr; int64_t pitch = 0; } hyb_fuse;
   // Global constrained MLLR without re-packing: the rows stay those of the unadapted model
   // (rows_unbiased) and log|det| is added to every score at the kernels' output (out_bias_ln)
   bool rows_unbiased = false;

@@ -1914,6 +1914,7 @@ static void find_outliers(aasr_gmm *g) {
   g->hyb_enabled = false;
   g->hyb_states = g->hyb_rows = 0;
   g->hyb_comps.clear();
+  g->hyb_tab = aasr::DevBuf<uint32_t>();
   std::vector<double> kap((size_t)m.G), kap2((size_t)m.G);
   double kappa = 0;
   for (int64_t i = 0; i < m.G; i++) {
@@ -1971,7 +1972,10 @@ static void find_outliers(aasr_gmm *g) {
         g->ill_conditioned = false;
         return;
       }
-      if (!dimp || !routing || 1.7 * (double)comps.size() + 20.0 * (double)map.size() >= 1500.0 ||
+      // (the merge costs ~20 us per state as a pass of its own, nothing where the scoring kernel does it in its close logic:
+      // models of up to 65 534 states on the grouped layout, hyb_tab below)
+      const double merge_us = (m.S <= 65534 && 8 * (int64_t)map.size() <= m.S) ? 0.0 : 20.0;   // (fused only where such states are sparse)
+      if (!dimp || !routing || 1.7 * (double)comps.size() + merge_us * (double)map.size() >= (merge_us > 0 ? 1500.0 : 2400.0) ||
           comps.size() * 4 > m.mix_idx.size())
         continue;
     }
@@ -1988,6 +1992,18 @@ static void find_outliers(aasr_gmm *g) {
     build_centred_tables(m, dimp, comps, off, g->hyb_recs, g->hyb_state_off, g->hyb_splits, &g->hyb_max_splits);
     g->hyb_map.upload(map.data(), map.size());
     g->hyb_comps = comps;
+    g->hyb_tab = aasr::DevBuf<uint32_t>();
+    if (m.S <= 65534 && (int64_t)map.size() <= 65535) {   // (k_gmm_diag_score_pl<..., HYB>: the merge in the close logic)
+      std::vector<int32_t> slot((size_t)m.S, -1);
+      for (size_t j = 0; j < map.size(); j++) slot[(size_t)map[j]] = (int32_t)j;
+      std::vector<uint32_t> tab((size_t)m.S, 0xffffu);
+      uint32_t nxt[2] = {0xffffu, 0xffffu};
+      for (int64_t s = m.S - 1; s >= 0; s--) {
+        if (slot[(size_t)s] >= 0) nxt[s & 1] = (uint32_t)s | ((uint32_t)slot[(size_t)s] << 16);
+        tab[(size_t)s] = nxt[s & 1];
+      }
+      g->hyb_tab.upload(tab.data(), tab.size());
+    }
     g->cl.crow_hyb = aasr::DevBuf<int32_t>();  // rebuilt on the next clustered pass
     return;
   }

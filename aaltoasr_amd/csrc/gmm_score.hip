@@ -45,6 +45,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define LN2_F 0.69314718055994530942f
+#define LOG2E_F 1.4426950408889634074f
 // log(1e-50): HmmSet clamps state likelihoods at util::tiny_for_log
 // (aku/HmmSet.cc:497-498, aku/util.hh:131)
 #define LOG_TINY_F (-115.12925464970228f)
@@ -1119,6 +1120,17 @@ struct CutPlan {
 };
 
 // Pivot groups of a launch (nullptr colend: one pivot, the model's)
+// log(exp(a) + exp(b)) for a state's two shares (matrix rows / outlier components, both with the 1e-50 floor, which the
+// result keeps; a share AT the floor holds nothing).  The hardware's 2^x and log2 (1 ulp): 2e-7 on the result -- the
+// library's expf / log1pf cost ~120 instructions per value, a seventh of the scoring kernel's time where 10 % of the
+// states take this path in its close logic (k_gmm_diag_score_pl<..., HYB>); k_outlier_merge uses the same expression.
+__device__ __forceinline__ float merge_floored_shares(float a, float b) {
+  const float hi = fmaxf(a, b), lo = fminf(a, b);
+  float r = hi;
+  if (lo > LOG_TINY_F) r = fmaf(__builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f((lo - hi) * LOG2E_F)), LN2_F, hi);
+  return fmaxf(r, LOG_TINY_F);
+}
+
 struct PivotGroups {
   const int32_t *colend = nullptr;   // [groups] one past the group's last output column
   int64_t fop_stride = 0;            // u32x4 elements between the groups' frame-operand images
@@ -1127,6 +1139,14 @@ struct PivotGroups {
   const float *pivots = nullptr;
   const float *tabs = nullptr;
   int sc = 0;
+  // HYB instances (outlier routing fused into the close logic, below): hyb_tab[s] = the next state >= s of s's track
+  // parity that has outlier components (low 16 bits; 0xffff: none) and its record in the partial sums (high 16 bits);
+  // the partial sums [records][pitch] (natural log, state-major, one row of frames per record:
+  // k_gmm_diag_score_centred), log|det| of an in-place transform
+  const uint32_t *hyb_tab = nullptr;
+  const float *hyb_part = nullptr;
+  int64_t hyb_pitch = 0;
+  float hyb_bias = 0.0f;
 };
 
 template <int NK16, bool GROUPED, bool WIDE, int NS>
@@ -1198,7 +1218,16 @@ __device__ unsigned long long g_pl_trace[8][12];
 #ifndef AASR_PL_PRIO_LO
 #define AASR_PL_PRIO_LO 1
 #endif
-template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS, bool MAPPED = false, bool PGF = false>
+// HYB (GROUPED, two terms, one pivot, unmasked; round 6): outlier routing without a merge pass.  The Gaussians the matrix
+// layout left out (null rows) are summed per state by k_gmm_diag_score_centred BEFORE this launch, into a state-major
+// buffer; a lane that closes such a state adds the buffer's value for its frame -- the arithmetic of k_outlier_merge,
+// the same bits -- in front of the store.  The values are fetched a state ahead: per track parity a table says which state
+// comes next and where its sums are; a state's two values (frames n, 32 + n) and the table entry of the state after it are
+// requested when the previous one is consumed, so the close logic waits for global memory only where such states follow
+// each other within a tile's time (the launcher leaves models where they are dense to the engine parts).  (k_outlier_merge's read-modify-write of one column of the score matrix
+// touches a line per frame: 20 us per state and 449 280 frames, more than the gather of a model with engine parts from
+// ~100 states on.)
+template <int NK16, bool GROUPED, bool CL, bool WIDE, int NS, bool MAPPED = false, bool PGF = false, bool HYB = false>
 __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_score_pl(
     const float *__restrict__ frames, int64_t F, int dim, const float *__restrict__ pivot,
     const uint16_t *__restrict__ apack, const int32_t *__restrict__ split_row,
@@ -1395,6 +1424,30 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
   PL_TRACE(6);
   float s0 = 0.0f, s1 = 0.0f;
   int closes = split_row[4 * cut + 1 + (GROUPED ? 0 : h)];
+  // HYB: the next state of this lane's track that has outlier components, and its two values
+  int hyb_st = 0x7fffffff;
+  float hyb_v0 = LOG_TINY_F, hyb_v1 = LOG_TINY_F;
+  uint32_t hyb_e_next = 0xffffu;   // the table entry of the state AFTER hyb_st (requested together with hyb_st's values)
+  // ... whose values are requested BEHIND the next tile barrier, not where hyb_st is consumed: the barrier waits for every
+  // outstanding vector-memory operation of the wave (the tile copy's), and a request issued in the close logic in front
+  // of it made all eight waves wait for its latency (+13 % with such a state in every tenth column)
+  uint32_t hyb_pend = 0xffffu;
+  auto hyb_issue = [&](uint32_t e) {   // e: table entry of the state to take next (0xffff in the low half: none)
+    hyb_st = 0x7fffffff;
+    hyb_e_next = 0xffffu;
+    if ((e & 0xffffu) != 0xffffu) {
+      hyb_st = (int)(e & 0xffffu);
+      const float *pr = pg.hyb_part + (int64_t)(e >> 16) * pg.hyb_pitch;
+      const int64_t fa = f0 + n < F ? f0 + n : F - 1, fb = f0 + 32 + n < F ? f0 + 32 + n : F - 1;   // (never stored past F)
+      hyb_v0 = pr[fa];
+      hyb_v1 = pr[fb];
+      if (hyb_st + 2 < (int)S) hyb_e_next = pg.hyb_tab[hyb_st + 2];
+    }
+  };
+  if constexpr (HYB) {
+    const int from = 2 * closes + h;   // the first state of this lane's track (parity h) in this row cut
+    hyb_issue(from < (int)S ? pg.hyb_tab[from] : 0xffffu);
+  }
   const int32_t *my_sid = sid + h * sid_stride;
   int next_sid = GROUPED ? 0 : my_sid[closes];
   float *orow0 = out + (f0 + n) * pitch;  // pitch: row stride of `out` in floats (>= S)
@@ -1481,6 +1534,20 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
           }
         } else {
           const int pairs_closed = closes;
+          if constexpr (HYB) {
+            const int stc = 2 * (pairs_closed - 1) + h;
+            if ((hyb_pend & 0xffffu) != 0xffffu && stc == (int)(hyb_pend & 0xffffu)) {   // (closes before the barrier came)
+              hyb_issue(hyb_pend);
+              hyb_pend = 0xffffu;
+            }
+            if (stc == hyb_st) {
+              // k_outlier_merge's arithmetic: out = log(exp(out) + exp(part)); a part AT the floor holds nothing
+              l0 = merge_floored_shares(l0, hyb_v0 > LOG_TINY_F ? hyb_v0 + pg.hyb_bias : hyb_v0);
+              l1 = merge_floored_shares(l1, hyb_v1 > LOG_TINY_F ? hyb_v1 + pg.hyb_bias : hyb_v1);
+              hyb_pend = hyb_e_next;
+              hyb_st = 0x7fffffff;
+            }
+          }
           const int slot = ((2 * (pairs_closed - 1)) & (OG - 1)) + h;
           ost[n * kOS + slot] = l0;
           ost[(32 + n) * kOS + slot] = l1;
@@ -1565,6 +1632,12 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void k_gmm_diag_sco
       tr_acc[5] += tb2 - tb1;   // (the s_barrier itself; the tile count moves to the host side)
 #endif
       if (t + 2 < t_end) issue_tile(t + 2, bnn);
+      if constexpr (HYB) {
+        if ((hyb_pend & 0xffffu) != 0xffffu) {
+          hyb_issue(hyb_pend);
+          hyb_pend = 0xffffu;
+        }
+      }
 #ifdef AASR_PL_TRACE
       tr_bar += __builtin_readcyclecounter() - tb0;
 #endif
@@ -2013,6 +2086,26 @@ static void launch_pl_t(const aasr_gmm *g, const TrackLayout &L, const float *d_
   }
   const u32x4 *fop = frame_operand<NS>(g, L, d_frames, F, blocks * NW, stream, &pg.fop_stride);
   if (multi) pg.colend = L.pg_colend.p;
+  if constexpr (GROUPED && NS == 2 && !CL) {
+    // outlier routing with the merge in the close logic: the launcher has put the outliers' partial sums on the handle
+    if (!multi && g->hyb_fuse.part && g->hyb_tab.p) {
+      auto kern_hyb = k_gmm_diag_score_pl<NK16, GROUPED, CL, WIDE, NS, false, false, true>;
+      static bool attr_set_hyb[64] = {false};
+      if (!attr_set_hyb[g->device & 63]) {
+        AASR_HIP(hipFuncSetAttribute((const void *)kern_hyb, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set_hyb[g->device & 63] = true;
+      }
+      pg.hyb_tab = g->hyb_tab.p;
+      pg.hyb_part = g->hyb_fuse.part;
+      pg.hyb_pitch = g->hyb_fuse.pitch;
+      pg.hyb_bias = (float)g->out_bias_ln;
+      hipLaunchKernelGGL(kern_hyb, dim3(n_items), dim3(NW * 64), smem, stream, d_frames, F,
+                         g->dim, g->d_pivot.p, L.a16h.p, split_row, L.close.p, L.sid.p, L.sid_stride,
+                         d_out, g->S, pitch, L.ref_ln - (float)g->out_bias_ln, dbg, cl, fop, plan, pg);
+      AASR_HIP(hipGetLastError());
+      return;
+    }
+  }
   hipLaunchKernelGGL(kern, dim3(n_items), dim3(NW * 64), smem, stream, d_frames, F,
                      g->dim, g->d_pivot.p, NS == 3 ? L.a16.p : L.a16h.p, split_row, L.close.p,
                      L.sid.p, L.sid_stride,
@@ -3323,8 +3416,7 @@ __global__ __launch_bounds__(256) void k_outlier_merge(float *__restrict__ out, 
     const float hi = fmaxf(a, b), lo = fminf(a, b);
     float r = hi;
     if (floors) {
-      if (lo > LOG_TINY_F) r = hi + log1pf(expf(lo - hi));  // a part AT the floor holds nothing
-      r = fmaxf(r, LOG_TINY_F);
+      r = merge_floored_shares(a, b);  // a part AT the floor holds nothing
     } else {
       r = hi + log1pf(expf(lo - hi));  // clustered pass: no floors before k_cluster_merge
     }
@@ -3361,6 +3453,31 @@ static void score_outliers(aasr_gmm *g, const float *d_frames, int64_t F, float 
                        (float)g->out_bias_ln);
     AASR_HIP(hipGetLastError());
   }
+}
+
+// Outlier routing with the merge inside the scoring kernel (k_gmm_diag_score_pl<..., HYB>): where the launch that follows
+// is the grouped layout's two-term kernel, the outliers' partial sums of all F frames are formed first (state-major, the
+// centred kernel's coalesced form) and put on the handle for the launcher; returns false where the merge pass has to do
+// it (other layouts / precisions, clustering, more partial sums than a pass holds).
+static bool hyb_fuse_begin(aasr_gmm *g, const TrackLayout &L, const float *d_frames, int64_t F, hipStream_t stream) {
+  g->hyb_fuse = aasr_gmm::HybFuse();
+  static const int fuse_env = AASR_EXPERIMENT_ENV("AASR_HYB_FUSE") ? atoi(AASR_EXPERIMENT_ENV("AASR_HYB_FUSE")) : 1;   // EXPERIMENT: 0 = merge pass
+  const int64_t Sb = g->hyb_states;
+  if (!fuse_env || !g->hyb_enabled || Sb <= 0 || !g->hyb_tab.p || g->cl.enabled || g->precision != AASR_PREC_F16X2 ||
+      !g->use_bf16x3 || !L.ok || !L.grouped || !L.a16h.p || L.n_pg > 1 || !(g->layout_mask & 1) || L.nk16 <= 0)
+    return false;
+  const int64_t pass = (F + 63) / 64 * 64;
+  if ((double)pass * (double)Sb * 4.0 > g_pass_bytes) return false;
+  if ((size_t)pass * (size_t)Sb > g->hyb_scratch.n) {
+    AASR_HIP(hipDeviceSynchronize());   // growing frees the old buffer
+    g->hyb_scratch.ensure((size_t)pass * (size_t)Sb);
+  }
+  CentredOps ops{g->hyb_recs.p, g->hyb_state_off.p, g->hyb_splits.p, g->hyb_max_splits, 1, pass};
+  ops.n_recs = g->hyb_rows;
+  if (!launch_centred_ops(g, ops, g->centred_dimp, d_frames, F, g->hyb_scratch.p, stream)) return false;
+  g->hyb_fuse.part = g->hyb_scratch.p;
+  g->hyb_fuse.pitch = pass;
+  return true;
 }
 
 template <int NKK, int MODE>
@@ -3758,16 +3875,23 @@ bool gmm_engine_parts_clustered(const aasr_gmm *g) {
 // The exception: a model whose own layout HAS every state on plain two-term rows and only a few Gaussians off the matrix
 // path (outlier routing) -- the public layout then costs those few rows in the centred form and their states' merge, less
 // than the gather of the whole matrix (measured per 449 280 frames: 1.6 us per centred row, ~20 us per merged state -- its
-// column's read-modify-write touches a line per frame --, 2.4 ms for the gather): one far-out Gaussian in 1 % of the states
-// of configs[2]: 1.10x instead of 1.31x; at 10 % the merge would cost more than the gather (measured 1.44x against 1.30x).
+// column's read-modify-write touches a line per frame -- as a pass of its own, nothing where the scoring kernel merges in
+// its close logic (k_gmm_diag_score_pl<..., HYB>), 2.4 ms for the gather): one far-out Gaussian in 1 % / 10 % / 40 % of the
+// states of configs[2]: see DESIGN 4.2.
 static bool engine_parts_public(const aasr_gmm *g) {
   if (!gmm_engine_parts_active(g)) return false;
   static const int force_sc = AASR_EXPERIMENT_ENV("AASR_EXP_FORCE_SC") ? atoi(AASR_EXPERIMENT_ENV("AASR_EXP_FORCE_SC")) : 0;   // EXPERIMENT
   if (force_sc) return true;
   const TrackLayout &L = g->paired.ok ? g->paired : g->tracks;
-  if (L.ok && L.a16h.p && g->hyb_enabled && !g->ill_conditioned && !g->cl.enabled &&
-      1.7 * (double)g->hyb_rows + 20.0 * (double)g->hyb_states < 1500.0)
-    return false;
+  if (L.ok && L.a16h.p && g->hyb_enabled && !g->ill_conditioned && !g->cl.enabled) {
+    // (the scoring kernel merges the outliers' sums in its close logic where it can: hyb_fuse_begin)
+    // (... while such states are sparse: where they follow each other within a tile's time the close logic waits for its
+    // values -- 40 % of the states of configs[2]: 15 ms against 11 through the parts)
+    const bool fusable = g->hyb_tab.p && L.grouped && (g->layout_mask & 1) && 8 * g->hyb_states <= g->S;
+    if (fusable ? 1.7 * (double)g->hyb_rows < 2400.0
+                : 1.7 * (double)g->hyb_rows + 20.0 * (double)g->hyb_states < 1500.0)
+      return false;
+  }
   return true;
 }
 
@@ -3948,11 +4072,14 @@ void gmm_score_launch_pitched(aasr_gmm *g, const float *d_frames, int64_t F, flo
     return;
   }
   const TrackLayout &L = g->paired.ok ? g->paired : g->tracks;
+  const bool fused = hyb_fuse_begin(g, L, d_frames, F, stream);
   const bool done = (g->use_bf16x3 && launch_bf16(g, L, d_frames, F, d_out, stream, nullptr, pitch)) ||
                     launch_tracks(g, L, d_frames, F, d_out, stream, nullptr, pitch);
+  g->hyb_fuse = aasr_gmm::HybFuse();
   if (!done) raise(AASR_ERR_UNSUPPORTED, "no track kernel instance for this model");
-  // the Gaussians the matrix layouts left out (null rows): centred form, merged per state into the padded rows
-  if (g->hyb_enabled) score_outliers(g, d_frames, F, d_out, stream, nullptr, nullptr, 0, 1, pitch);
+  // the Gaussians the matrix layouts left out (null rows): centred form, merged per state into the padded rows (where
+  // the scoring kernel has not merged them itself)
+  if (g->hyb_enabled && !fused) score_outliers(g, d_frames, F, d_out, stream, nullptr, nullptr, 0, 1, pitch);
 }
 
 // ---------------------------------------------------------------------------
@@ -4109,9 +4236,13 @@ void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
     }
   // layout choice: grouped tracks > independent tracks > general (LDS-staged)
   bool done = false;
-  if (!done && (g->layout_mask & 1) && g->paired.ok)
+  bool fused = false;
+  if (!done && (g->layout_mask & 1) && g->paired.ok) {
+    fused = hyb_fuse_begin(g, g->paired, d_frames, F, stream);
     done = (g->use_bf16x3 && launch_bf16(g, g->paired, d_frames, F, d_out, stream)) ||
            launch_tracks(g, g->paired, d_frames, F, d_out, stream);
+    g->hyb_fuse = aasr_gmm::HybFuse();
+  }
   if (!done && (g->layout_mask & 2) && g->tracks.ok)
     done = (g->use_bf16x3 && launch_bf16(g, g->tracks, d_frames, F, d_out, stream)) ||
            launch_tracks(g, g->tracks, d_frames, F, d_out, stream);
@@ -4120,7 +4251,7 @@ void gmm_score_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_ou
     if (g->out_bias_ln != 0) add_output_bias(g, d_out, F, stream);  // this kernel has no output bias
   }
   // the Gaussians the matrix layouts left out (null rows): centred form, merged per state
-  if (g->hyb_enabled) score_outliers(g, d_frames, F, d_out, stream);
+  if (g->hyb_enabled && !fused) score_outliers(g, d_frames, F, d_out, stream);
 }
 
 void gmm_gauss_launch(aasr_gmm *g, const float *d_frames, int64_t F, float *d_out,
